@@ -1,0 +1,215 @@
+/* qa_sim.h -- C ABI of the MI355X-native Go2 vectorised environment ("quadrupedal-agility_amd").
+ *
+ * This is the drop-in boundary for the ONE hot path this build replaces: the
+ * legged_gym `LeggedRobot.step()` loop of NJU-RLC/quadrupedal-agility, i.e. everything the
+ * reference does between receiving `actions (N,12)` and returning obs/reward/reset
+ * (bbc/legged_gym/envs/base/legged_robot.py:78-115), including the calls it makes into the
+ * closed-source Isaac Gym tensor API (seam 1), plus the GAE scan of
+ * the learner (bbc/rsl_rl/storage/rollout_storage.py:97-111).
+ *
+ * Conventions (same as the reference's gym tensor API, legged_robot.py:747-770):
+ *   - all state lives in ONE caller-allocated device slab ("arena"); the engine lays the
+ *     tensors out inside it and the caller aliases them zero-copy (torch views).  The env
+ *     both reads and writes those aliases in place, exactly like gymtorch.wrap_tensor views.
+ *   - row-major, fp32 unless stated; quaternions xyzw; root velocities in the world frame;
+ *     DoF order FL,FR,RL,RR x (hip, thigh, calf); env ids are int32.
+ *   - every entry point returns 0 on success or a negative QA_E_* code; nothing aborts.
+ *   - single host thread per handle; device work is enqueued on the stream passed in
+ *     (hipStream_t as void*; NULL = default stream); no host-visible sync is performed.
+ *
+ * The CPU oracle (oracle/qa_oracle.c) implements the same functions with the prefix `qo_`
+ * over a host arena with the identical layout, so tests can memcpy an arena across.
+ */
+#ifndef QA_SIM_H
+#define QA_SIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QA_ABI_VERSION 1
+#define QA_NUM_DOF 12
+#define QA_NUM_BODIES_ABI 19
+#define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
+#define QA_NUM_PROP 57
+#define QA_HISTORY_LEN 10
+#define QA_NUM_OBS 671          /* 57 + 4 + 29 + 570 + 11 (legged_robot.py:261-331) */
+#define QA_NUM_OBS_DISC 49
+#define QA_ACTION_BUF_LEN 8
+#define QA_NUM_REWARDS 14
+
+/* error codes */
+#define QA_OK 0
+#define QA_E_ARG (-1)           /* null / out-of-range argument */
+#define QA_E_ARENA (-2)         /* arena too small or misaligned */
+#define QA_E_DEVICE (-3)        /* HIP runtime error (qa_last_error() has the text) */
+#define QA_E_VERSION (-4)
+
+/* reward terms, alphabetical = the order the reference sums them in
+ * (helpers.py:12-27 class_to_dict is dir()-sorted; legged_robot.py:922-946) */
+enum qa_reward {
+    QA_R_ACTION_RATE = 0, QA_R_COLLISION, QA_R_DELTA_TORQUES, QA_R_DOF_ACC, QA_R_DOF_ERROR,
+    QA_R_DOF_POS_LIMITS, QA_R_DOF_VEL_LIMITS, QA_R_HIP_POS, QA_R_JUMP_UP_HEIGHT,
+    QA_R_LOCOMOTION_HEIGHT, QA_R_TORQUE_LIMITS, QA_R_TORQUES, QA_R_TRACKING_ANG_VEL,
+    QA_R_TRACKING_LIN_VEL
+};
+
+/* tensors inside the arena.  Layout rule (part of the ABI): tensors are placed in enum
+ * order, each start rounded up to 256 bytes. */
+enum qa_tensor {
+    QA_T_ROOT_STATES = 0,     /* (N,13)  pos3 quat4(xyzw) linvel3 angvel3, world frame          */
+    QA_T_DOF_STATE,           /* (N,12,2) [pos, vel] interleaved like gym's dof_state            */
+    QA_T_CONTACT_FORCES,      /* (N,19,3) net contact force per body, world frame, last substep  */
+    QA_T_RIGID_BODY_POS,      /* (N,19,3) body-origin positions, world frame (refreshed by step) */
+    QA_T_TORQUES,             /* (N,12)  clipped torques of the last substep                     */
+    QA_T_TORQUES_ORG,         /* (N,12)  un-clipped torques of the last substep                  */
+    QA_T_ACTIONS,             /* (N,12)  clipped (and possibly delayed) actions                  */
+    QA_T_LAST_ACTIONS,        /* (N,12)                                                          */
+    QA_T_LAST_DOF_VEL,        /* (N,12)                                                          */
+    QA_T_LAST_TORQUES_ORG,    /* (N,12)                                                          */
+    QA_T_LAST_ROOT_VEL,       /* (N,6)                                                           */
+    QA_T_ACTION_HISTORY,      /* (N,8,12) oldest first                                           */
+    QA_T_OBS_HISTORY,         /* (N,10,57) oldest first, noise-free                              */
+    QA_T_OBS,                 /* (N,671) obs_buf == privileged_obs_buf                           */
+    QA_T_OBS_DISC,            /* (N,49)  discriminator observation                               */
+    QA_T_OBS_DISC_TERM,       /* (N,49)  OBS_DISC with rows of resetting envs replaced by their
+                                         terminal (pre-reset) disc obs                           */
+    QA_T_COMMANDS,            /* (N,5)   vx vy wz jump_height locomotion_height                  */
+    QA_T_LATENT_EPS,          /* (N,1)                                                           */
+    QA_T_LATENT_C,            /* (N,5)   one-hot gait                                            */
+    QA_T_REW,                 /* (N)                                                             */
+    QA_T_RESET,               /* (N) int64                                                       */
+    QA_T_TIME_OUT,            /* (N) uint8                                                       */
+    QA_T_EPISODE_LENGTH,      /* (N) int64                                                       */
+    QA_T_EPISODE_SUMS,        /* (14,N)                                                          */
+    QA_T_EPISODE_STATS,       /* (2,16)  [parity][0:14]=sum over resetting envs of episode sums,
+                                         [14]=number of resetting envs; parity = step & 1        */
+    QA_T_LAST_CONTACTS,       /* (N,4) uint8                                                     */
+    QA_T_CONTACT_FILT,        /* (N,4) uint8                                                     */
+    QA_T_FEET_FORCE,          /* (N,4)  norm of foot contact forces                              */
+    QA_T_BASE_LIN_VEL,        /* (N,3)  body frame                                               */
+    QA_T_BASE_ANG_VEL,        /* (N,3)  body frame                                               */
+    QA_T_PROJECTED_GRAVITY,   /* (N,3)                                                           */
+    QA_T_RPY,                 /* (N,3)  roll pitch yaw                                           */
+    QA_T_MOTOR_STRENGTH,      /* (2,N,12) p and d multipliers                                    */
+    QA_T_MASS_PARAMS,         /* (N,4)  added base mass, added CoM xyz                           */
+    QA_T_FRICTION,            /* (N)    robot-shape friction coefficient                         */
+    QA_T_ENV_ORIGINS,         /* (N,3)                                                           */
+    QA_T_BASE_INERTIA,        /* (N,10) base link incl. added mass: m, m*c (3), I about base
+                                         origin xx yy zz xy xz yz, base frame                    */
+    QA_T_PRIOR_PARAMETERS,    /* (5)    written by the learner (gail.py:463-464)                 */
+    QA_T_MOCAP_FRAMES,        /* (F,QA_MOCAP_FRAME) reset-state frames, see qa_set_mocap         */
+    QA_T_COUNT
+};
+
+enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3 };
+
+#define QA_MOCAP_FRAME 37       /* root pos3, root quat4, joint pos12, lin vel3, ang vel3 (root frame), joint vel12 */
+
+/* Plain-old-data configuration.  Field meanings follow the reference config classes
+ * (bbc/legged_gym/envs/go2/go2_locomotion_config.py, envs/base/legged_robot_config.py). */
+typedef struct qa_config {
+    int32_t abi_version;            /* QA_ABI_VERSION */
+    int32_t num_envs;
+    uint64_t seed;                  /* Philox key */
+    /* sim (legged_robot_config.py:173-190) */
+    float sim_dt;                   /* 0.005 */
+    int32_t decimation;             /* 4 */
+    float gravity_z;                /* -9.81 */
+    int32_t solver_iterations;      /* PGS sweeps per substep */
+    float contact_offset;           /* 0.01 */
+    float max_depenetration_velocity; /* 1.0 */
+    float ground_friction;          /* 1.0 (terrain.static_friction) */
+    int32_t terrain_type;           /* 0 = plane */
+    /* control (go2_locomotion_config.py:53-60) */
+    float kp, kd, action_scale, hip_scale_reduction, clip_actions;
+    float default_dof_pos[QA_NUM_DOF];
+    /* env */
+    float env_spacing;              /* 3.0 */
+    int32_t max_episode_length;     /* ceil(20 / 0.02) = 1000 */
+    int32_t resampling_steps;       /* int(6 / 0.02) = 300 */
+    int32_t push_interval;          /* ceil(8 / 0.02) = 400 */
+    int32_t push_robots;
+    float max_push_vel_xy;
+    int32_t reset_mode;             /* 0 = default pose (legged_robot.py:581-596,614-634), 1 = mocap frames */
+    float init_pos[3];              /* 0 0 0.42 */
+    int32_t add_noise;
+    /* noise_scale_vec entries (legged_robot.py:721-740): already multiplied by level and obs scale */
+    float noise_roll_pitch, noise_ang_vel, noise_dof_pos, noise_dof_vel, noise_lin_vel;
+    float clip_obs;                 /* 100 */
+    /* obs scales (go2_locomotion_config.py:115-125) */
+    float s_lin_vel, s_ang_vel, s_dof_pos, s_dof_vel, s_key_pos, s_foot_contact, s_lin_vel_dist, s_ang_vel_dist;
+    /* rewards: scale*dt for each term, enum qa_reward order; 0 disables (legged_robot.py:927-932) */
+    float reward_scale_dt[QA_NUM_REWARDS];
+    int32_t only_positive_rewards;
+    float tracking_sigma, soft_dof_pos_limit, soft_dof_vel_limit, soft_torque_limit, jump_goal;
+    /* commands (go2_locomotion_config.py:165-181) */
+    float lin_vel_x[QA_NUM_GAITS][2], lin_vel_y[QA_NUM_GAITS][2], ang_vel_yaw[QA_NUM_GAITS][2];
+    float jump_height[2], locomotion_height[2];
+    float lin_vel_x_clip, lin_vel_y_clip, ang_vel_yaw_clip;
+    float latent_temperature;       /* 0.25 (legged_robot.py:536) */
+    /* domain randomisation (go2_locomotion_config.py:74-100) */
+    int32_t randomize_friction, randomize_base_mass, randomize_base_com, randomize_motor, use_easi;
+    float friction_range[2], added_mass_range[2], added_com_range[2], motor_strength_range[2];
+    float easi_mean[6], easi_var[6];
+    /* mocap reset table (reset_mode 1) */
+    int32_t num_mocap_frames;       /* rows of QA_T_MOCAP_FRAMES */
+    int32_t mocap_clip_count[QA_NUM_GAITS];   /* unused when reset_mode == 0 */
+} qa_config;
+
+typedef struct qa_sim qa_sim;
+
+/* bytes the caller must allocate for the arena (256-byte aligned base). */
+int64_t qa_arena_bytes(const qa_config *cfg);
+
+/* Create a handle over a caller-owned DEVICE arena.  Replaces gym.create_sim / create_env /
+ * create_actor / prepare_sim / acquire_*_tensor (legged_robot.py:351-364,995-1107,747-754).
+ * Fills per-env parameters (friction buckets, added mass/CoM, motor strength, env origins)
+ * from the Philox key and puts every env in the reset state (reset_buf = 1). */
+int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stream, qa_sim **out);
+int qa_destroy(qa_sim *sim);
+
+/* Where tensor `which` lives inside the arena.  Replaces gymtorch.wrap_tensor. */
+int qa_tensor_info(const qa_config *cfg, int which, int64_t *byte_offset, int64_t shape[3],
+                   int32_t *ndim, int32_t *dtype);
+
+/* The fused LeggedRobot.step(): action-history roll, optional delay (delay_steps in {0,1},
+ * legged_robot.py:87-93), clip, `decimation` x (PD torque -> forward dynamics -> contact ->
+ * integrate), post_physics_step (termination, 14 rewards, reset of done envs, observations).
+ * `actions` is a device pointer to (N,12) fp32.  `global_step` is the env's step counter
+ * before this call (common_step_counter); it keys the RNG and triggers pushes. */
+int qa_env_step(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t global_step, void *stream);
+
+/* reset_idx(all) followed by nothing else (legged_robot.py:67-69).  The reference's reset()
+ * then takes one zero-action step; the host mirror does that through qa_env_step. */
+int qa_reset_all(qa_sim *sim, int64_t global_step, void *stream);
+
+/* Seam-1 granular entry: one physics substep with caller-provided joint torques (N,12),
+ * i.e. set_dof_actuation_force_tensor + simulate + fetch_results + refresh_*_tensor
+ * (legged_robot.py:103-106,129-131).  Updates ROOT_STATES, DOF_STATE, CONTACT_FORCES,
+ * RIGID_BODY_POS only. */
+int qa_simulate(qa_sim *sim, const float *torques, void *stream);
+
+/* Upload reset-state frames for reset_mode 1: `frames` is a HOST pointer to
+ * (num_frames, QA_MOCAP_FRAME) fp32 laid out as root_pos3, root_quat4, joint_pos12,
+ * lin_vel3, ang_vel3 (both in the root frame), joint_vel12; the frames of gait g are rows
+ * first_frame[g] .. first_frame[g+1]-1.  A reset draws one row uniformly within its gait. */
+int qa_set_mocap(qa_sim *sim, const float *frames, int32_t num_frames, const int32_t first_frame[QA_NUM_GAITS + 1], void *stream);
+
+/* Fused GAE (rollout_storage.py:97-111): reverse scan over T, then advantage
+ * normalisation over all T*N samples (unbiased std, +1e-8).  All pointers are device
+ * pointers; rewards/values/returns/advantages are (T,N) fp32, dones (T,N) uint8,
+ * last_values (N).  `scratch` must hold at least 4096 bytes. */
+int qa_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+           float *returns, float *advantages, int32_t T, int32_t N, float gamma, float lam,
+           int32_t normalize, void *scratch, void *stream);
+
+const char *qa_last_error(void);
+int qa_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QA_SIM_H */

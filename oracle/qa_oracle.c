@@ -1,0 +1,948 @@
+/* qa_oracle.c -- CPU oracle for the quadrupedal-agility hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (quadrupedal_agility_amd/) never links, imports or calls it.
+ *
+ * What it restates, and what pins it:
+ *  (1) env-side math of bbc/legged_gym/envs/base/legged_robot.py -- PD torques (:547-579),
+ *      post_physics_step (:124-166), check_termination (:168-176), the 14 active reward
+ *      terms (:242-259, :1231-1374), command/latent resampling (:474-545), default-pose
+ *      reset (:581-596, :614-634), compute_observations (:261-331) and compute_flat_key_pos
+ *      (:1377-1396) -- in fp32, following the torch op order.  PINNED by golden vectors
+ *      generated from the reference Python itself (tests/golden/, tools/gen_golden.py).
+ *  (2) GAE of bbc/rsl_rl/storage/rollout_storage.py:97-111.  PINNED by golden vectors.
+ *  (3) the physics the reference delegates to Isaac Gym / PhysX (legged_robot.py:103-106,
+ *      129-131).  That binary is closed and absent, so this part follows the build's OWN
+ *      stated model: floating base + 12 revolute DoF rigid-body dynamics
+ *      (composite-rigid-body mass matrix + recursive Newton-Euler bias), semi-implicit Euler
+ *      at dt = 5 ms, velocity-level contact with projected Gauss-Seidel.  PARITY UNPINNED
+ *      against the reference; pinned instead by analytic known-answer tests
+ *      (tests/test_oracle_physics.py) and by cross-checking the HIP kernels against it.
+ *
+ * The physics here is written in double precision with a DENSE 18x18 mass matrix and a
+ * generic Cholesky -- on purpose a different algebraic route from the HIP kernel (which
+ * eliminates the legs into a 6x6 base Schur complement, one leg per lane), so agreement
+ * between the two checks the optimised algebra, not a shared implementation.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/qa_sim.h"
+#include "qa_go2_model.h"
+
+/* ------------------------------------------------------------------ layout */
+typedef struct {
+    int64_t off[QA_T_COUNT];
+    int64_t shape[QA_T_COUNT][3];
+    int32_t ndim[QA_T_COUNT];
+    int32_t dtype[QA_T_COUNT];
+    int64_t total;
+} Layout;
+
+static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : 1; }
+
+static void set_t(Layout *L, int t, int dt, int nd, int64_t a, int64_t b, int64_t c) {
+    L->dtype[t] = dt; L->ndim[t] = nd; L->shape[t][0] = a; L->shape[t][1] = b; L->shape[t][2] = c;
+}
+
+static void make_layout(const qa_config *cfg, Layout *L) {
+    int64_t N = cfg->num_envs;
+    int64_t F = cfg->num_mocap_frames > 0 ? cfg->num_mocap_frames : 1;
+    memset(L, 0, sizeof(*L));
+    set_t(L, QA_T_ROOT_STATES, QA_F32, 2, N, 13, 1);
+    set_t(L, QA_T_DOF_STATE, QA_F32, 3, N, 12, 2);
+    set_t(L, QA_T_CONTACT_FORCES, QA_F32, 3, N, 19, 3);
+    set_t(L, QA_T_RIGID_BODY_POS, QA_F32, 3, N, 19, 3);
+    set_t(L, QA_T_TORQUES, QA_F32, 2, N, 12, 1);
+    set_t(L, QA_T_TORQUES_ORG, QA_F32, 2, N, 12, 1);
+    set_t(L, QA_T_ACTIONS, QA_F32, 2, N, 12, 1);
+    set_t(L, QA_T_LAST_ACTIONS, QA_F32, 2, N, 12, 1);
+    set_t(L, QA_T_LAST_DOF_VEL, QA_F32, 2, N, 12, 1);
+    set_t(L, QA_T_LAST_TORQUES_ORG, QA_F32, 2, N, 12, 1);
+    set_t(L, QA_T_LAST_ROOT_VEL, QA_F32, 2, N, 6, 1);
+    set_t(L, QA_T_ACTION_HISTORY, QA_F32, 3, N, QA_ACTION_BUF_LEN, 12);
+    set_t(L, QA_T_OBS_HISTORY, QA_F32, 3, N, QA_HISTORY_LEN, QA_NUM_PROP);
+    set_t(L, QA_T_OBS, QA_F32, 2, N, QA_NUM_OBS, 1);
+    set_t(L, QA_T_OBS_DISC, QA_F32, 2, N, QA_NUM_OBS_DISC, 1);
+    set_t(L, QA_T_OBS_DISC_TERM, QA_F32, 2, N, QA_NUM_OBS_DISC, 1);
+    set_t(L, QA_T_COMMANDS, QA_F32, 2, N, 5, 1);
+    set_t(L, QA_T_LATENT_EPS, QA_F32, 2, N, 1, 1);
+    set_t(L, QA_T_LATENT_C, QA_F32, 2, N, QA_NUM_GAITS, 1);
+    set_t(L, QA_T_REW, QA_F32, 1, N, 1, 1);
+    set_t(L, QA_T_RESET, QA_I64, 1, N, 1, 1);
+    set_t(L, QA_T_TIME_OUT, QA_U8, 1, N, 1, 1);
+    set_t(L, QA_T_EPISODE_LENGTH, QA_I64, 1, N, 1, 1);
+    set_t(L, QA_T_EPISODE_SUMS, QA_F32, 2, QA_NUM_REWARDS, N, 1);
+    set_t(L, QA_T_EPISODE_STATS, QA_F32, 2, 2, 16, 1);
+    set_t(L, QA_T_LAST_CONTACTS, QA_U8, 2, N, 4, 1);
+    set_t(L, QA_T_CONTACT_FILT, QA_U8, 2, N, 4, 1);
+    set_t(L, QA_T_FEET_FORCE, QA_F32, 2, N, 4, 1);
+    set_t(L, QA_T_BASE_LIN_VEL, QA_F32, 2, N, 3, 1);
+    set_t(L, QA_T_BASE_ANG_VEL, QA_F32, 2, N, 3, 1);
+    set_t(L, QA_T_PROJECTED_GRAVITY, QA_F32, 2, N, 3, 1);
+    set_t(L, QA_T_RPY, QA_F32, 2, N, 3, 1);
+    set_t(L, QA_T_MOTOR_STRENGTH, QA_F32, 3, 2, N, 12);
+    set_t(L, QA_T_MASS_PARAMS, QA_F32, 2, N, 4, 1);
+    set_t(L, QA_T_FRICTION, QA_F32, 1, N, 1, 1);
+    set_t(L, QA_T_ENV_ORIGINS, QA_F32, 2, N, 3, 1);
+    set_t(L, QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1);
+    set_t(L, QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1);
+    set_t(L, QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1);
+    int64_t off = 0;
+    for (int t = 0; t < QA_T_COUNT; ++t) {
+        off = (off + 255) & ~(int64_t)255;
+        L->off[t] = off;
+        off += L->shape[t][0] * L->shape[t][1] * L->shape[t][2] * dtype_size(L->dtype[t]);
+    }
+    L->total = (off + 255) & ~(int64_t)255;
+}
+
+struct qo_sim {
+    qa_config cfg;
+    Layout L;
+    char *arena;
+    int32_t mocap_first[QA_NUM_GAITS + 1];
+};
+typedef struct qo_sim qo_sim;
+
+#define TP(sim, t, type) ((type *)((sim)->arena + (sim)->L.off[t]))
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+static void philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* stream ids (shared spec with the HIP kernels) */
+enum { RS_INIT_BUCKET = 1, RS_INIT_FRICTION = 2, RS_INIT_MASS = 3, RS_INIT_MOTOR = 4,
+       RS_NOISE = 8, RS_CMD = 9, RS_CMD_RESET = 10, RS_PUSH = 11, RS_RESET = 12 };
+
+static void rng4(const qo_sim *s, uint32_t env, int64_t step, int stream, int block, float u[4]) {
+    uint32_t o[4];
+    philox(s->cfg.seed, env, (uint32_t)step, (uint32_t)(stream * 256 + block), (uint32_t)((uint64_t)step >> 32), o);
+    for (int i = 0; i < 4; ++i) u[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
+}
+
+/* ------------------------------------------------------------------ fp32 helpers (torch op order) */
+/* isaacgym.torch_utils quat_rotate / quat_rotate_inverse (xyzw), as used at legged_robot.py:138-140 */
+static void quat_rotate_f(const float q[4], const float v[3], float sign, float out[3]) {
+    float qw = q[3];
+    float s = 2.0f * qw * qw - 1.0f;
+    float a[3] = {v[0] * s, v[1] * s, v[2] * s};
+    float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+    float b[3] = {cx * qw * 2.0f, cy * qw * 2.0f, cz * qw * 2.0f};
+    float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+    float c[3] = {q[0] * d * 2.0f, q[1] * d * 2.0f, q[2] * d * 2.0f};
+    for (int i = 0; i < 3; ++i) out[i] = sign > 0 ? a[i] + b[i] + c[i] : a[i] - b[i] + c[i];
+}
+static float clipf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* ------------------------------------------------------------------ double helpers for physics */
+typedef double v3[3];
+typedef double m3[3][3];
+static void cross(const v3 a, const v3 b, v3 o) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static double dot3(const v3 a, const v3 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void mv(const m3 A, const v3 x, v3 o) {
+    v3 t; for (int i = 0; i < 3; ++i) t[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+static void mtv(const m3 A, const v3 x, v3 o) {
+    v3 t; for (int i = 0; i < 3; ++i) t[i] = A[0][i] * x[0] + A[1][i] * x[1] + A[2][i] * x[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+static void mm(const m3 A, const m3 B, m3 C) {
+    m3 T; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+    memcpy(C, T, sizeof(m3));
+}
+static void quat_to_mat(const double q[4], m3 R) { /* xyzw, body->world */
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0][0] = 1 - 2 * (y * y + z * z); R[0][1] = 2 * (x * y - z * w); R[0][2] = 2 * (x * z + y * w);
+    R[1][0] = 2 * (x * y + z * w); R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (y * z - x * w);
+    R[2][0] = 2 * (x * z - y * w); R[2][1] = 2 * (y * z + x * w); R[2][2] = 1 - 2 * (x * x + y * y);
+}
+
+/* rigid-body inertia about the base origin, base axes: mass, first moment h = m c, I_O (sym 3x3) */
+typedef struct { double m; v3 h; m3 I; } RB;
+static void rb_make(double m, const v3 c, const m3 Ic, RB *o) {
+    o->m = m; for (int i = 0; i < 3; ++i) o->h[i] = m * c[i];
+    double cc = dot3(c, c);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o->I[i][j] = Ic[i][j] + m * ((i == j ? cc : 0.0) - c[i] * c[j]);
+}
+static void rb_add(RB *a, const RB *b) {
+    a->m += b->m; for (int i = 0; i < 3; ++i) { a->h[i] += b->h[i]; for (int j = 0; j < 3; ++j) a->I[i][j] += b->I[i][j]; }
+}
+/* F = I V with V = (w; v), F = (n; f):  n = I_O w + h x v,  f = m v - h x w */
+static void rb_apply(const RB *I, const double V[6], double F[6]) {
+    v3 t, u;
+    mv(I->I, V, t); cross(I->h, V + 3, u);
+    for (int i = 0; i < 3; ++i) F[i] = t[i] + u[i];
+    cross(I->h, V, u);
+    for (int i = 0; i < 3; ++i) F[3 + i] = I->m * V[3 + i] - u[i];
+}
+/* spatial cross products: motion x motion and motion x* force */
+static void crm(const double V[6], const double M[6], double o[6]) {
+    v3 a, b, c; cross(V, M, a); cross(V, M + 3, b); cross(V + 3, M, c);
+    for (int i = 0; i < 3; ++i) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+static void crf(const double V[6], const double F[6], double o[6]) {
+    v3 a, b, c; cross(V, F, a); cross(V + 3, F + 3, b); cross(V, F + 3, c);
+    for (int i = 0; i < 3; ++i) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+static double dot6(const double a[6], const double b[6]) { double s = 0; for (int i = 0; i < 6; ++i) s += a[i] * b[i]; return s; }
+
+/* ------------------------------------------------------------------ kinematics of one env (base frame) */
+typedef struct {
+    m3 Rl[4][3];        /* link rotations, base <- link */
+    v3 o[4][3];         /* joint origins (= link frame origins) */
+    v3 a[4][3];         /* joint axes */
+    v3 foot[4];         /* foot body origin */
+    double S[4][3][6];  /* joint motion vectors (a; o x a) */
+    RB link[4][3];      /* single-link inertias */
+} Kin;
+
+static void leg_kin(int l, const double q[3], Kin *K) {
+    double c1 = cos(q[0]), s1 = sin(q[0]);
+    double c2 = cos(q[1]), s2 = sin(q[1]);
+    double c23 = cos(q[1] + q[2]), s23 = sin(q[1] + q[2]);
+    m3 R1 = {{1, 0, 0}, {0, c1, -s1}, {0, s1, c1}};
+    m3 Ry2 = {{c2, 0, s2}, {0, 1, 0}, {-s2, 0, c2}};
+    m3 Ry23 = {{c23, 0, s23}, {0, 1, 0}, {-s23, 0, c23}};
+    memcpy(K->Rl[l][0], R1, sizeof(m3));
+    mm(R1, Ry2, K->Rl[l][1]);
+    mm(R1, Ry23, K->Rl[l][2]);
+    v3 t, off;
+    for (int i = 0; i < 3; ++i) K->o[l][0][i] = QA_HIP_ORG[l][i];
+    for (int i = 0; i < 3; ++i) off[i] = QA_THIGH_ORG[l][i];
+    mv(K->Rl[l][0], off, t); for (int i = 0; i < 3; ++i) K->o[l][1][i] = K->o[l][0][i] + t[i];
+    for (int i = 0; i < 3; ++i) off[i] = QA_CALF_ORG[l][i];
+    mv(K->Rl[l][1], off, t); for (int i = 0; i < 3; ++i) K->o[l][2][i] = K->o[l][1][i] + t[i];
+    for (int i = 0; i < 3; ++i) off[i] = QA_FOOT_ORG[l][i];
+    mv(K->Rl[l][2], off, t); for (int i = 0; i < 3; ++i) K->foot[l][i] = K->o[l][2][i] + t[i];
+    K->a[l][0][0] = 1; K->a[l][0][1] = 0; K->a[l][0][2] = 0;
+    for (int k = 1; k < 3; ++k) { K->a[l][k][0] = 0; K->a[l][k][1] = c1; K->a[l][k][2] = s1; }
+    for (int k = 0; k < 3; ++k) {
+        v3 b; cross(K->o[l][k], K->a[l][k], b);
+        for (int i = 0; i < 3; ++i) { K->S[l][k][i] = K->a[l][k][i]; K->S[l][k][3 + i] = b[i]; }
+        /* link inertia into base frame */
+        const float *I6 = QA_LINK_I[l][k];
+        m3 Il = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}}, Rt, Ib;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i][j] = K->Rl[l][k][j][i];
+        mm(K->Rl[l][k], Il, Ib); mm(Ib, Rt, Ib);
+        v3 cl = {QA_LINK_COM[l][k][0], QA_LINK_COM[l][k][1], QA_LINK_COM[l][k][2]}, cb;
+        mv(K->Rl[l][k], cl, cb); for (int i = 0; i < 3; ++i) cb[i] += K->o[l][k][i];
+        rb_make(QA_LINK_MASS[l][k], cb, Ib, &K->link[l][k]);
+    }
+}
+
+static void base_rb(const float bi[10], RB *o) {
+    o->m = bi[0]; for (int i = 0; i < 3; ++i) o->h[i] = bi[1 + i];
+    o->I[0][0] = bi[4]; o->I[1][1] = bi[5]; o->I[2][2] = bi[6];
+    o->I[0][1] = o->I[1][0] = bi[7]; o->I[0][2] = o->I[2][0] = bi[8]; o->I[1][2] = o->I[2][1] = bi[9];
+}
+
+/* dense mass matrix (18x18; index 0..2 base angular, 3..5 base linear, 6+3l+k joints) and bias */
+static void dynamics_terms(const Kin *K, const RB *base, const double ub[6], const double qd[12],
+                           const v3 gB, double M[18][18], double h[18]) {
+    memset(M, 0, sizeof(double) * 18 * 18);
+    RB tot = *base;
+    for (int l = 0; l < 4; ++l) {
+        RB Ic[3];
+        Ic[2] = K->link[l][2];
+        Ic[1] = K->link[l][1]; rb_add(&Ic[1], &Ic[2]);
+        Ic[0] = K->link[l][0]; rb_add(&Ic[0], &Ic[1]);
+        rb_add(&tot, &Ic[0]);
+        for (int j = 0; j < 3; ++j) {
+            double F[6]; rb_apply(&Ic[j], K->S[l][j], F);
+            int cj = 6 + 3 * l + j;
+            for (int i = 0; i < 6; ++i) { M[i][cj] = F[i]; M[cj][i] = F[i]; }
+            for (int i = 0; i <= j; ++i) { double v = dot6(K->S[l][i], F); int ci = 6 + 3 * l + i; M[ci][cj] = v; M[cj][ci] = v; }
+        }
+    }
+    /* base block = spatial inertia of the whole robot */
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i][j] = tot.I[i][j];
+    double hx[3][3] = {{0, -tot.h[2], tot.h[1]}, {tot.h[2], 0, -tot.h[0]}, {-tot.h[1], tot.h[0], 0}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { M[i][3 + j] = hx[i][j]; M[3 + j][i] = hx[i][j]; }
+    for (int i = 0; i < 3; ++i) M[3 + i][3 + i] = tot.m;
+
+    /* bias: recursive Newton-Euler with zero joint acceleration, base acceleration = -gravity */
+    double A0[6] = {0, 0, 0, -gB[0], -gB[1], -gB[2]}, t6[6], f0[6];
+    rb_apply(base, A0, f0);
+    rb_apply(base, ub, t6); { double c[6]; crf(ub, t6, c); for (int i = 0; i < 6; ++i) f0[i] += c[i]; }
+    for (int l = 0; l < 4; ++l) {
+        double V[6], A[6], f[3][6];
+        memcpy(V, ub, sizeof(V)); memcpy(A, A0, sizeof(A));
+        for (int k = 0; k < 3; ++k) {
+            double Sq[6], c[6];
+            for (int i = 0; i < 6; ++i) Sq[i] = K->S[l][k][i] * qd[3 * l + k];
+            for (int i = 0; i < 6; ++i) V[i] += Sq[i];
+            crm(V, Sq, c); for (int i = 0; i < 6; ++i) A[i] += c[i];
+            double IA[6], IV[6], cf[6];
+            rb_apply(&K->link[l][k], A, IA); rb_apply(&K->link[l][k], V, IV); crf(V, IV, cf);
+            for (int i = 0; i < 6; ++i) f[k][i] = IA[i] + cf[i];
+        }
+        for (int i = 0; i < 6; ++i) { f[1][i] += f[2][i]; f[0][i] += f[1][i]; f0[i] += f[0][i]; }
+        for (int k = 0; k < 3; ++k) h[6 + 3 * l + k] = dot6(K->S[l][k], f[k]);
+    }
+    for (int i = 0; i < 6; ++i) h[i] = f0[i];
+}
+
+/* in-place Cholesky (lower) and solve for n <= 18 */
+static int chol(double A[18][18], int n) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[j][j];
+        for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+        if (!(d > 0)) return -1;
+        d = sqrt(d); A[j][j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[i][j];
+            for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+            A[i][j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(double Lc[18][18], int n, const double b[18], double x[18]) {
+    double y[18];
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= Lc[i][k] * y[k]; y[i] = s / Lc[i][i]; }
+    for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s -= Lc[k][i] * x[k]; x[i] = s / Lc[i][i]; }
+}
+
+/* ------------------------------------------------------------------ one physics substep */
+typedef struct { double J[18], W[18], dinv, bias, lam, lo_mul, hi_mul; int kind; /*0 normal,1 tangent,2 limit*/ int parent; } Row;
+
+#define LIMIT_MARGIN 0.5   /* rad: limit rows further than this from the stop cannot bind (|qd| <= ~100 rad/s) */
+#define LIMIT_DEPEN 1.0    /* rad/s cap on limit-violation recovery speed */
+#define CFM 1e-6
+
+static double ground_height(const qa_config *cfg, double x, double y) { (void)cfg; (void)x; (void)y; return 0.0; }
+
+static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
+    const qa_config *cfg = &s->cfg;
+    float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e;
+    float *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
+    float *cf = TP(s, QA_T_CONTACT_FORCES, float) + 57 * e;
+    float *rbp = TP(s, QA_T_RIGID_BODY_POS, float) + 57 * e;
+    const float *binert = TP(s, QA_T_BASE_INERTIA, float) + 10 * e;
+    double dt = cfg->sim_dt;
+    double pos[3] = {root[0], root[1], root[2]}, quat[4] = {root[3], root[4], root[5], root[6]};
+    m3 R; quat_to_mat(quat, R);
+    v3 vw = {root[7], root[8], root[9]}, ww = {root[10], root[11], root[12]}, gw = {0, 0, cfg->gravity_z}, gB;
+    double ub[6]; mtv(R, ww, ub); mtv(R, vw, ub + 3); mtv(R, gw, gB);
+    double q[12], qd[12];
+    for (int j = 0; j < 12; ++j) { q[j] = dof[2 * j]; qd[j] = dof[2 * j + 1]; }
+
+    Kin K;
+    for (int l = 0; l < 4; ++l) leg_kin(l, q + 3 * l, &K);
+    RB base; base_rb(binert, &base);
+    double M[18][18], h[18], Lc[18][18];
+    dynamics_terms(&K, &base, ub, qd, gB, M, h);
+    memcpy(Lc, M, sizeof(M));
+    if (chol(Lc, 18) != 0) return; /* singular: leave state untouched (never happens for a physical robot) */
+
+    /* unconstrained velocity: u* = u + dt (M^-1 (tau - h) + [0; w x v; 0]) */
+    double rhs[18], acc[18], u[18];
+    for (int i = 0; i < 6; ++i) rhs[i] = -h[i];
+    for (int j = 0; j < 12; ++j) rhs[6 + j] = (double)tau_in[j] - h[6 + j];
+    chol_solve(Lc, 18, rhs, acc);
+    v3 wxv; cross(ub, ub + 3, wxv);
+    for (int i = 0; i < 6; ++i) u[i] = ub[i] + dt * acc[i];
+    for (int i = 0; i < 3; ++i) u[3 + i] += dt * wxv[i];
+    for (int j = 0; j < 12; ++j) u[6 + j] = qd[j] + dt * acc[6 + j];
+
+    /* ---- constraint rows, in the fixed Gauss-Seidel order: for leg l: foot(n,t1,t2), extra(n,t1,t2), limits */
+    Row rows[4 * 9];
+    int nrows = 0;
+    int foot_row[4], extra_row[4], extra_body[4];
+    double mu = 0.5 * ((double)TP(s, QA_T_FRICTION, float)[e] + cfg->ground_friction);
+    v3 nB = {R[2][0], R[2][1], R[2][2]}, t1B = {R[0][0], R[0][1], R[0][2]}, t2B = {R[1][0], R[1][1], R[1][2]};
+    for (int l = 0; l < 4; ++l) {
+        foot_row[l] = extra_row[l] = -1; extra_body[l] = -1;
+        /* candidate points of this leg: slot 0 = foot; the other slot takes the min-gap non-foot point */
+        double best_gap = 1e30; v3 best_p = {0, 0, 0}; int best_depth = -1, best_body = -1;
+        double foot_gap = 0; v3 foot_p = {0, 0, 0};
+        for (int c = 0; c < QA_NUM_LEG_PTS; ++c) {
+            int k = QA_LEG_PT_LINK[l][c];
+            v3 pl = {QA_LEG_PT_POS[l][c][0], QA_LEG_PT_POS[l][c][1], QA_LEG_PT_POS[l][c][2]}, p, pwld;
+            mv(K.Rl[l][k], pl, p); for (int i = 0; i < 3; ++i) p[i] += K.o[l][k][i];
+            mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
+            double gap = pwld[2] - QA_LEG_PT_RAD[l][c] - ground_height(cfg, pwld[0], pwld[1]);
+            if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); }
+            else if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); best_depth = k; best_body = QA_LEG_PT_BODY[l][c]; }
+        }
+        for (int c = l; c < QA_NUM_BASE_PTS; c += 4) { /* base points are dealt round-robin to the four legs */
+            v3 p = {QA_BASE_PT_POS[c][0], QA_BASE_PT_POS[c][1], QA_BASE_PT_POS[c][2]}, pwld;
+            mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
+            double gap = pwld[2] - QA_BASE_PT_RAD[c] - ground_height(cfg, pwld[0], pwld[1]);
+            if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); best_depth = -1; best_body = QA_BASE_PT_BODY[c]; }
+        }
+        for (int slot = 0; slot < 2; ++slot) {
+            double gap = slot == 0 ? foot_gap : best_gap;
+            const double *p = slot == 0 ? foot_p : best_p;
+            int depth = slot == 0 ? 2 : best_depth;
+            if (!(gap < cfg->contact_offset)) continue;
+            if (slot == 0) foot_row[l] = nrows; else { extra_row[l] = nrows; extra_body[l] = best_body; }
+            const double *dirs[3] = {nB, t1B, t2B};
+            for (int d = 0; d < 3; ++d) {
+                Row *r = &rows[nrows];
+                memset(r, 0, sizeof(*r));
+                v3 pxd; cross(p, dirs[d], pxd);
+                for (int i = 0; i < 3; ++i) { r->J[i] = pxd[i]; r->J[3 + i] = dirs[d][i]; }
+                for (int k = 0; k <= depth; ++k) {
+                    v3 rel = {p[0] - K.o[l][k][0], p[1] - K.o[l][k][1], p[2] - K.o[l][k][2]}, axr;
+                    cross(K.a[l][k], rel, axr);
+                    r->J[6 + 3 * l + k] = dot3(dirs[d], axr);
+                }
+                r->kind = d == 0 ? 0 : 1; r->parent = nrows - d;
+                if (d == 0) {
+                    double mdv = cfg->max_depenetration_velocity;
+                    r->bias = gap >= 0 ? gap / dt : (gap / dt > -mdv ? gap / dt : -mdv);
+                }
+                nrows++;
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            int j = 3 * l + k;
+            double glo = q[j] - QA_DOF_LOWER[l][k], ghi = QA_DOF_UPPER[l][k] - q[j];
+            double sgn = 0, gap = 0;
+            if (glo < LIMIT_MARGIN) { sgn = 1; gap = glo; } else if (ghi < LIMIT_MARGIN) { sgn = -1; gap = ghi; }
+            if (sgn == 0) continue;
+            Row *r = &rows[nrows++];
+            memset(r, 0, sizeof(*r));
+            r->J[6 + j] = sgn; r->kind = 2;
+            r->bias = gap >= 0 ? gap / dt : (gap / dt > -LIMIT_DEPEN ? gap / dt : -LIMIT_DEPEN);
+        }
+    }
+    for (int i = 0; i < nrows; ++i) {
+        chol_solve(Lc, 18, rows[i].J, rows[i].W);
+        double d = 0; for (int k = 0; k < 18; ++k) d += rows[i].J[k] * rows[i].W[k];
+        rows[i].dinv = 1.0 / (d + CFM);
+    }
+    for (int it = 0; it < cfg->solver_iterations; ++it) {
+        for (int i = 0; i < nrows; ++i) {
+            Row *r = &rows[i];
+            double res = r->bias; for (int k = 0; k < 18; ++k) res += r->J[k] * u[k];
+            double lam = r->lam - res * r->dinv;
+            if (r->kind == 1) { double lim = mu * rows[r->parent].lam; lam = lam < -lim ? -lim : (lam > lim ? lim : lam); }
+            else if (lam < 0) lam = 0;
+            double dl = lam - r->lam; r->lam = lam;
+            for (int k = 0; k < 18; ++k) u[k] += r->W[k] * dl;
+        }
+    }
+    /* joint velocity clamp (PhysX maxJointVelocity = URDF velocity limit) */
+    for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) {
+        double vl = QA_DOF_VELLIM[l][k]; int j = 6 + 3 * l + k;
+        u[j] = u[j] < -vl ? -vl : (u[j] > vl ? vl : u[j]);
+    }
+
+    /* ---- integrate: new world velocities expressed through the old frame, then the pose */
+    v3 wn, vn; mv(R, u, wn); mv(R, u + 3, vn);
+    for (int i = 0; i < 3; ++i) pos[i] += dt * vn[i];
+    double wb[3] = {u[0], u[1], u[2]};
+    double ang = sqrt(dot3(wb, wb)) * dt, dq[4];
+    if (ang > 1e-12) { double sc = sin(0.5 * ang) / (ang / dt); dq[0] = wb[0] * sc; dq[1] = wb[1] * sc; dq[2] = wb[2] * sc; dq[3] = cos(0.5 * ang); }
+    else { dq[0] = 0.5 * dt * wb[0]; dq[1] = 0.5 * dt * wb[1]; dq[2] = 0.5 * dt * wb[2]; dq[3] = 1; }
+    double qn[4] = { /* quat (x) dq  (body-frame increment => right multiplication) */
+        quat[3] * dq[0] + quat[0] * dq[3] + quat[1] * dq[2] - quat[2] * dq[1],
+        quat[3] * dq[1] - quat[0] * dq[2] + quat[1] * dq[3] + quat[2] * dq[0],
+        quat[3] * dq[2] + quat[0] * dq[1] - quat[1] * dq[0] + quat[2] * dq[3],
+        quat[3] * dq[3] - quat[0] * dq[0] - quat[1] * dq[1] - quat[2] * dq[2]};
+    double nn = 1.0 / sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int i = 0; i < 3; ++i) { root[i] = (float)pos[i]; root[7 + i] = (float)vn[i]; root[10 + i] = (float)wn[i]; }
+    for (int i = 0; i < 4; ++i) root[3 + i] = (float)(qn[i] * nn);
+    for (int j = 0; j < 12; ++j) { dof[2 * j] = (float)(q[j] + dt * u[6 + j]); dof[2 * j + 1] = (float)u[6 + j]; }
+
+    /* ---- contact forces per body (world frame; plane => (t1,t2,n) are world x,y,z) */
+    memset(cf, 0, sizeof(float) * 57);
+    for (int l = 0; l < 4; ++l) {
+        if (foot_row[l] >= 0) { int b = QA_LEG_PT_BODY[l][0], r0 = foot_row[l];
+            cf[3 * b + 0] += (float)(rows[r0 + 1].lam / dt); cf[3 * b + 1] += (float)(rows[r0 + 2].lam / dt); cf[3 * b + 2] += (float)(rows[r0].lam / dt); }
+        if (extra_row[l] >= 0) { int b = extra_body[l], r0 = extra_row[l];
+            cf[3 * b + 0] += (float)(rows[r0 + 1].lam / dt); cf[3 * b + 1] += (float)(rows[r0 + 2].lam / dt); cf[3 * b + 2] += (float)(rows[r0].lam / dt); }
+    }
+    /* ---- body-origin positions with the NEW state (what refresh_rigid_body_state_tensor returns) */
+    {
+        double q2[12]; for (int j = 0; j < 12; ++j) q2[j] = dof[2 * j];
+        double qq[4] = {root[3], root[4], root[5], root[6]}; m3 R2; quat_to_mat(qq, R2);
+        Kin K2; for (int l = 0; l < 4; ++l) leg_kin(l, q2 + 3 * l, &K2);
+        v3 pts[19]; memset(pts, 0, sizeof(pts));
+        pts[1][0] = 0.285; pts[1][2] = 0.01; pts[2][0] = 0.293; pts[2][2] = -0.06;
+        for (int l = 0; l < 4; ++l) { for (int k = 0; k < 3; ++k) memcpy(pts[3 + 4 * l + k], K2.o[l][k], sizeof(v3)); memcpy(pts[3 + 4 * l + 3], K2.foot[l], sizeof(v3)); }
+        for (int b = 0; b < 19; ++b) { v3 w; mv(R2, pts[b], w); for (int i = 0; i < 3; ++i) rbp[3 * b + i] = (float)(w[i] + (double)root[i]); }
+    }
+}
+
+/* ------------------------------------------------------------------ env-side math (fp32) */
+static void compute_torques(const qo_sim *s, int e, const float *act, float tau[12], float tau_org[12]) {
+    /* legged_robot.py:547-579, control_type 'P', randomize_motor */
+    const qa_config *c = &s->cfg;
+    const float *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
+    const float *ms = TP(s, QA_T_MOTOR_STRENGTH, float);
+    int N = c->num_envs;
+    for (int j = 0; j < 12; ++j) {
+        float a = act[j] * c->action_scale;
+        if (j % 3 == 0) a *= c->hip_scale_reduction;
+        float sp = c->randomize_motor ? ms[(0 * N + e) * 12 + j] : 1.0f, sd = c->randomize_motor ? ms[(1 * N + e) * 12 + j] : 1.0f;
+        float t;
+        if (c->randomize_motor) t = sp * c->kp * (a + c->default_dof_pos[j] - dof[2 * j]) - sd * c->kd * dof[2 * j + 1];
+        else t = c->kp * (a + c->default_dof_pos[j] - dof[2 * j]) - c->kd * dof[2 * j + 1];
+        tau_org[j] = t;
+        float lim = QA_DOF_EFFORT[j / 3][j % 3];
+        tau[j] = clipf(t, -lim, lim);
+    }
+}
+
+static void resample_commands(qo_sim *s, int e, int64_t step, int stream) {
+    /* legged_robot.py:532-540 (latents) and :474-530 (commands) */
+    const qa_config *c = &s->cfg;
+    float u0[4], u1[4];
+    rng4(s, e, step, stream, 0, u0); rng4(s, e, step, stream, 1, u1);
+    float *eps = TP(s, QA_T_LATENT_EPS, float) + e, *lc = TP(s, QA_T_LATENT_C, float) + 5 * e, *cmd = TP(s, QA_T_COMMANDS, float) + 5 * e;
+    const float *prior = TP(s, QA_T_PRIOR_PARAMETERS, float);
+    eps[0] = u0[1] * 2.0f - 1.0f;
+    float z[5], zmax = -1e30f, sum = 0;
+    for (int g = 0; g < 5; ++g) { z[g] = prior[g] / c->latent_temperature; if (z[g] > zmax) zmax = z[g]; }
+    for (int g = 0; g < 5; ++g) { z[g] = expf(z[g] - zmax); sum += z[g]; }
+    int gait = 4; float acc = 0;
+    for (int g = 0; g < 5; ++g) { acc += z[g] / sum; if (u0[0] < acc) { gait = g; break; } }
+    for (int g = 0; g < 5; ++g) lc[g] = g == gait ? 1.0f : 0.0f;
+    float vx = (c->lin_vel_x[gait][1] - c->lin_vel_x[gait][0]) * u0[2] + c->lin_vel_x[gait][0];
+    float vy = (c->lin_vel_y[gait][1] - c->lin_vel_y[gait][0]) * u0[3] + c->lin_vel_y[gait][0];
+    float wz = (c->ang_vel_yaw[gait][1] - c->ang_vel_yaw[gait][0]) * u1[0] + c->ang_vel_yaw[gait][0];
+    int jump = gait == QA_NUM_GAITS - 1;
+    float hj = ((c->jump_height[1] - c->jump_height[0]) * u1[1] + c->jump_height[0]) * (jump ? 1.0f : 0.0f);
+    float hl = ((c->locomotion_height[1] - c->locomotion_height[0]) * u1[2] + c->locomotion_height[0]) * (jump ? 0.0f : 1.0f);
+    cmd[0] = vx * (fabsf(vx) > c->lin_vel_x_clip ? 1.0f : 0.0f);
+    cmd[1] = vy * (fabsf(vy) > c->lin_vel_y_clip ? 1.0f : 0.0f);
+    cmd[2] = wz * (fabsf(wz) > c->ang_vel_yaw_clip ? 1.0f : 0.0f);
+    cmd[3] = hj; cmd[4] = hl;
+}
+
+static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity) {
+    /* legged_robot.py:178-240 */
+    const qa_config *c = &s->cfg;
+    int N = c->num_envs;
+    resample_commands(s, e, step, RS_CMD_RESET);
+    float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e, *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
+    const float *org = TP(s, QA_T_ENV_ORIGINS, float) + 3 * e;
+    if (c->reset_mode == 1 && s->mocap_first[QA_NUM_GAITS] > 0) {
+        /* mocap frame reset (:598-612, :660-680): one pre-sampled frame row of the env's gait */
+        const float *lc = TP(s, QA_T_LATENT_C, float) + 5 * e;
+        int gait = 0; for (int g = 1; g < 5; ++g) if (lc[g] > lc[gait]) gait = g;
+        float u[4]; rng4(s, e, step, RS_RESET, 0, u);
+        int n = s->mocap_first[gait + 1] - s->mocap_first[gait];
+        int row = s->mocap_first[gait] + (int)(u[0] * (float)n); if (row >= s->mocap_first[gait + 1]) row = s->mocap_first[gait + 1] - 1;
+        const float *f = TP(s, QA_T_MOCAP_FRAMES, float) + (int64_t)row * QA_MOCAP_FRAME;
+        for (int i = 0; i < 3; ++i) root[i] = f[i] + org[i];
+        for (int i = 0; i < 4; ++i) root[3 + i] = f[3 + i];
+        quat_rotate_f(f + 3, f + 19, +1.0f, root + 7);
+        quat_rotate_f(f + 3, f + 22, +1.0f, root + 10);
+        for (int j = 0; j < 12; ++j) { dof[2 * j] = f[7 + j]; dof[2 * j + 1] = f[25 + j]; }
+    } else {
+        /* default pose (:581-596, :614-634; plane => custom_origins False) */
+        float u[20];
+        for (int b = 0; b < 5; ++b) rng4(s, e, step, RS_RESET, b, u + 4 * b);
+        for (int j = 0; j < 12; ++j) { dof[2 * j] = c->default_dof_pos[j] * ((1.5f - 0.5f) * u[j] + 0.5f); dof[2 * j + 1] = 0.0f; }
+        for (int i = 0; i < 3; ++i) root[i] = c->init_pos[i] + org[i];
+        root[3] = 0; root[4] = 0; root[5] = 0; root[6] = 1;
+        for (int i = 0; i < 6; ++i) root[7 + i] = (0.5f - -0.5f) * u[12 + i] + -0.5f;
+    }
+    memset(TP(s, QA_T_LAST_ACTIONS, float) + 12 * e, 0, 48);
+    memset(TP(s, QA_T_LAST_DOF_VEL, float) + 12 * e, 0, 48);
+    memset(TP(s, QA_T_LAST_ROOT_VEL, float) + 6 * e, 0, 24);
+    memset(TP(s, QA_T_LAST_TORQUES_ORG, float) + 12 * e, 0, 48);
+    TP(s, QA_T_EPISODE_LENGTH, int64_t)[e] = 0;
+    TP(s, QA_T_RESET, int64_t)[e] = 1;
+    memset(TP(s, QA_T_ACTION_HISTORY, float) + 96 * e, 0, 96 * 4);
+    memset(TP(s, QA_T_OBS_HISTORY, float) + 570 * e, 0, 570 * 4);
+    float *st = TP(s, QA_T_EPISODE_STATS, float) + 16 * stats_parity, *es = TP(s, QA_T_EPISODE_SUMS, float);
+#pragma omp critical(qo_stats)
+    {
+        for (int r = 0; r < QA_NUM_REWARDS; ++r) st[r] += es[(int64_t)r * N + e];
+        st[14] += 1.0f;
+    }
+    for (int r = 0; r < QA_NUM_REWARDS; ++r) es[(int64_t)r * N + e] = 0;
+}
+
+static void compute_observations(qo_sim *s, int e, int64_t step) {
+    /* legged_robot.py:261-331 + compute_flat_key_pos :1377-1396 (plane: measured heights are 0) */
+    const qa_config *c = &s->cfg;
+    const float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e, *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
+    const float *rpy = TP(s, QA_T_RPY, float) + 3 * e, *blv = TP(s, QA_T_BASE_LIN_VEL, float) + 3 * e, *bav = TP(s, QA_T_BASE_ANG_VEL, float) + 3 * e;
+    const float *rbp = TP(s, QA_T_RIGID_BODY_POS, float) + 57 * e;
+    const uint8_t *cfilt = TP(s, QA_T_CONTACT_FILT, uint8_t) + 4 * e;
+    int N = c->num_envs;
+    float root_h = root[2];
+    /* heading-inverse rotation of the feet (torch_jit_utils.py:23-76) */
+    float xdir[3] = {1, 0, 0}, rot_dir[3];
+    quat_rotate_f(root + 3, xdir, +1.0f, rot_dir);
+    float heading = atan2f(rot_dir[1], rot_dir[0]);
+    float th = -heading; /* quat_from_angle_axis(-heading, z): xyz = axis*sin(th/2), w = cos(th/2), then normalize */
+    float hq[4] = {0.0f * sinf(th / 2), 0.0f * sinf(th / 2), 1.0f * sinf(th / 2), cosf(th / 2)};
+    float hn = sqrtf(hq[0] * hq[0] + hq[1] * hq[1] + hq[2] * hq[2] + hq[3] * hq[3]); if (hn < 1e-9f) hn = 1e-9f;
+    for (int i = 0; i < 4; ++i) hq[i] /= hn;
+    float key[12];
+    for (int l = 0; l < 4; ++l) {
+        const float *fp = rbp + 3 * (3 + 4 * l + 3);
+        float rel[3] = {fp[0] - root[0], fp[1] - root[1], fp[2] - root[2]};
+        quat_rotate_f(hq, rel, +1.0f, key + 3 * l);
+    }
+    float *od = TP(s, QA_T_OBS_DISC, float) + QA_NUM_OBS_DISC * e;
+    od[0] = rpy[0]; od[1] = rpy[1]; od[2] = root_h;
+    for (int i = 0; i < 3; ++i) { od[3 + i] = blv[i] * c->s_lin_vel_dist; od[6 + i] = bav[i] * c->s_ang_vel_dist; }
+    for (int j = 0; j < 12; ++j) { od[9 + j] = (dof[2 * j] - c->default_dof_pos[j]) * c->s_dof_pos; od[21 + j] = dof[2 * j + 1] * c->s_dof_vel; od[33 + j] = key[j] * c->s_key_pos; }
+    for (int l = 0; l < 4; ++l) od[45 + l] = (cfilt[l] ? 1.0f : 0.0f) * c->s_foot_contact;
+
+    float prop[QA_NUM_PROP];
+    const float *ah = TP(s, QA_T_ACTION_HISTORY, float) + 96 * e + 12 * (QA_ACTION_BUF_LEN - 1);
+    prop[0] = rpy[0]; prop[1] = rpy[1];
+    for (int i = 0; i < 3; ++i) prop[2 + i] = bav[i] * c->s_ang_vel;
+    for (int j = 0; j < 12; ++j) { prop[5 + j] = (dof[2 * j] - c->default_dof_pos[j]) * c->s_dof_pos; prop[17 + j] = dof[2 * j + 1] * c->s_dof_vel; prop[29 + j] = ah[j]; }
+    for (int l = 0; l < 4; ++l) prop[41 + l] = (cfilt[l] ? 1.0f : 0.0f) - 0.5f;
+    for (int j = 0; j < 12; ++j) prop[45 + j] = key[j] * 0.0f;
+
+    float *hist = TP(s, QA_T_OBS_HISTORY, float) + 570 * e;
+    int64_t epl = TP(s, QA_T_EPISODE_LENGTH, int64_t)[e];
+    if (epl <= 1) { for (int t = 0; t < QA_HISTORY_LEN; ++t) memcpy(hist + 57 * t, prop, 57 * 4); }
+    else { memmove(hist, hist + 57, 57 * 9 * 4); memcpy(hist + 57 * 9, prop, 57 * 4); }
+
+    float *o = TP(s, QA_T_OBS, float) + (int64_t)QA_NUM_OBS * e;
+    memcpy(o, prop, 57 * 4);
+    o[57] = root_h; for (int i = 0; i < 3; ++i) o[58 + i] = blv[i] * c->s_lin_vel;
+    const float *mp = TP(s, QA_T_MASS_PARAMS, float) + 4 * e, *ms = TP(s, QA_T_MOTOR_STRENGTH, float);
+    for (int i = 0; i < 4; ++i) o[61 + i] = mp[i];
+    o[65] = TP(s, QA_T_FRICTION, float)[e];
+    for (int j = 0; j < 12; ++j) { o[66 + j] = ms[(0 * N + e) * 12 + j] - 1.0f; o[78 + j] = ms[(1 * N + e) * 12 + j] - 1.0f; }
+    memcpy(o + 90, hist, 570 * 4);
+    memcpy(o + 660, TP(s, QA_T_COMMANDS, float) + 5 * e, 20);
+    o[665] = TP(s, QA_T_LATENT_EPS, float)[e];
+    memcpy(o + 666, TP(s, QA_T_LATENT_C, float) + 5 * e, 20);
+    if (c->add_noise) {
+        /* only these 32 entries of noise_scale_vec are non-zero (:721-740); draw index i -> obs index */
+        float u[32];
+        for (int b = 0; b < 8; ++b) rng4(s, e, step, RS_NOISE, b, u + 4 * b);
+        for (int i = 0; i < 32; ++i) {
+            int idx = i < 29 ? i : 58 + (i - 29);
+            float sc = idx < 2 ? c->noise_roll_pitch : idx < 5 ? c->noise_ang_vel : idx < 17 ? c->noise_dof_pos : idx < 29 ? c->noise_dof_vel : c->noise_lin_vel;
+            o[idx] += (2.0f * u[i] - 1.0f) * sc;
+        }
+    }
+    for (int i = 0; i < QA_NUM_OBS; ++i) o[i] = clipf(o[i], -c->clip_obs, c->clip_obs);
+    for (int i = 0; i < 570; ++i) hist[i] = clipf(hist[i], -c->clip_obs, c->clip_obs);
+}
+
+static void post_physics(qo_sim *s, int e, int64_t step, float *term_disc_tmp) {
+    const qa_config *c = &s->cfg;
+    int N = c->num_envs;
+    float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e;
+    const float *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e, *cfo = TP(s, QA_T_CONTACT_FORCES, float) + 57 * e;
+    int64_t *epl = TP(s, QA_T_EPISODE_LENGTH, int64_t) + e;
+    *epl += 1;
+    int64_t common = step + 1; /* common_step_counter after the increment (:134) */
+    float *blv = TP(s, QA_T_BASE_LIN_VEL, float) + 3 * e, *bav = TP(s, QA_T_BASE_ANG_VEL, float) + 3 * e, *pg = TP(s, QA_T_PROJECTED_GRAVITY, float) + 3 * e, *rpy = TP(s, QA_T_RPY, float) + 3 * e;
+    float gvec[3] = {0, 0, -1};
+    quat_rotate_f(root + 3, root + 7, -1.0f, blv); quat_rotate_f(root + 3, root + 10, -1.0f, bav); quat_rotate_f(root + 3, gvec, -1.0f, pg);
+    { /* euler_from_quaternion, torch_jit_utils.py:169-192 */
+        float x = root[3], y = root[4], z = root[5], w = root[6];
+        rpy[0] = atan2f(2.0f * (w * x + y * z), 1.0f - 2.0f * (x * x + y * y));
+        rpy[1] = asinf(clipf(2.0f * (w * y - z * x), -1.0f, 1.0f));
+        rpy[2] = atan2f(2.0f * (w * z + x * y), 1.0f - 2.0f * (y * y + z * z));
+    }
+    float *ff = TP(s, QA_T_FEET_FORCE, float) + 4 * e; uint8_t *lastc = TP(s, QA_T_LAST_CONTACTS, uint8_t) + 4 * e, *cfilt = TP(s, QA_T_CONTACT_FILT, uint8_t) + 4 * e;
+    for (int l = 0; l < 4; ++l) {
+        const float *f = cfo + 3 * (3 + 4 * l + 3);
+        ff[l] = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+        uint8_t ct = ff[l] > 2.0f; cfilt[l] = ct | lastc[l]; lastc[l] = ct;
+    }
+    /* _post_physics_step_callback :449-472 */
+    if (*epl % c->resampling_steps == 0) resample_commands(s, e, step, RS_CMD);
+    if (c->push_robots && common % c->push_interval == 0) {
+        float u[4]; rng4(s, e, step, RS_PUSH, 0, u);
+        root[7] = (c->max_push_vel_xy - -c->max_push_vel_xy) * u[0] + -c->max_push_vel_xy;
+        root[8] = (c->max_push_vel_xy - -c->max_push_vel_xy) * u[1] + -c->max_push_vel_xy;
+    }
+    /* check_termination :168-176 : bodies whose name contains "base" or "hip" */
+    int reset = 0;
+    { const int tb[5] = {0, 3, 7, 11, 15};
+      for (int i = 0; i < 5; ++i) { const float *f = cfo + 3 * tb[i]; if (sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 1.0f) reset = 1; } }
+    int timeout = (*epl > c->max_episode_length) || (root[2] < -6.0f);
+    for (int i = 0; i < 13; ++i) if (!isfinite(root[i])) timeout = 1;   /* build-added failure detection */
+    reset |= timeout;
+    TP(s, QA_T_TIME_OUT, uint8_t)[e] = (uint8_t)timeout;
+    TP(s, QA_T_RESET, int64_t)[e] = reset;
+
+    /* compute_reward :242-259 -- terms in alphabetical order */
+    const float *act = TP(s, QA_T_ACTIONS, float) + 12 * e, *lact = TP(s, QA_T_LAST_ACTIONS, float) + 12 * e;
+    const float *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e, *ltorg = TP(s, QA_T_LAST_TORQUES_ORG, float) + 12 * e, *ldv = TP(s, QA_T_LAST_DOF_VEL, float) + 12 * e;
+    const float *cmd = TP(s, QA_T_COMMANDS, float) + 5 * e;
+    float dtp = c->sim_dt * (float)c->decimation; /* self.dt */
+    float term[QA_NUM_REWARDS]; for (int i = 0; i < QA_NUM_REWARDS; ++i) term[i] = 0;
+    for (int j = 0; j < 12; ++j) {
+        int l = j / 3, k = j % 3;
+        float qj = dof[2 * j], qdj = dof[2 * j + 1], d;
+        d = lact[j] - act[j]; term[QA_R_ACTION_RATE] += d * d;
+        d = torg[j] - ltorg[j]; term[QA_R_DELTA_TORQUES] += d * d;
+        d = (ldv[j] - qdj) / dtp; term[QA_R_DOF_ACC] += d * d;
+        d = qj - c->default_dof_pos[j]; term[QA_R_DOF_ERROR] += d * d; if (k == 0) term[QA_R_HIP_POS] += d * d;
+        { float lo = QA_DOF_LOWER[l][k], hi = QA_DOF_UPPER[l][k], m = (lo + hi) / 2, r = hi - lo;
+          float slo = m - 0.5f * r * c->soft_dof_pos_limit, shi = m + 0.5f * r * c->soft_dof_pos_limit;
+          float a = qj - slo; a = a > 0 ? 0 : a; float b = qj - shi; b = b < 0 ? 0 : b; term[QA_R_DOF_POS_LIMITS] += -a + b; }
+        term[QA_R_DOF_VEL_LIMITS] += clipf(fabsf(qdj) - QA_DOF_VELLIM[l][k] * c->soft_dof_vel_limit, 0.0f, 1.0f);
+        { float a = fabsf(torg[j]) - QA_DOF_EFFORT[l][k] * c->soft_torque_limit; term[QA_R_TORQUE_LIMITS] += a < 0 ? 0 : a; }
+        term[QA_R_TORQUES] += torg[j] * torg[j];
+    }
+    for (int l = 0; l < 4; ++l) for (int k = 1; k < 3; ++k) { /* thigh, calf bodies */
+        const float *f = cfo + 3 * (3 + 4 * l + k);
+        if (sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 0.1f) term[QA_R_COLLISION] += 1.0f;
+    }
+    { float root_h = root[2];
+      float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
+      term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c->jump_height[0]) ? c->jump_goal : 0.0f;
+      float el = sqrtf((cmd[4] - root_h) * (cmd[4] - root_h));
+      float rl = expf(-10.0f * (el * el) / c->tracking_sigma);
+      term[QA_R_LOCOMOTION_HEIGHT] = (cmd[3] > c->jump_height[0]) ? 0.0f : rl;
+      float ea = (cmd[2] - bav[2]) * (cmd[2] - bav[2]);
+      term[QA_R_TRACKING_ANG_VEL] = expf(-ea / c->tracking_sigma);
+      float elv = (cmd[0] - blv[0]) * (cmd[0] - blv[0]) + (cmd[1] - blv[1]) * (cmd[1] - blv[1]);
+      term[QA_R_TRACKING_LIN_VEL] = expf(-elv / c->tracking_sigma); }
+    float rew = 0; float *es = TP(s, QA_T_EPISODE_SUMS, float);
+    for (int r = 0; r < QA_NUM_REWARDS; ++r) {
+        if (c->reward_scale_dt[r] == 0.0f) continue;
+        float v = term[r] * c->reward_scale_dt[r]; rew += v; es[(int64_t)r * N + e] += v;
+    }
+    if (c->only_positive_rewards && rew < 0) rew = 0;
+    TP(s, QA_T_REW, float)[e] = rew;
+
+    /* terminal disc obs = obs_disc_buf of the previous compute_observations (:153-154) */
+    memcpy(term_disc_tmp, TP(s, QA_T_OBS_DISC, float) + QA_NUM_OBS_DISC * e, QA_NUM_OBS_DISC * 4);
+    if (reset) reset_env(s, e, step, (int)(step & 1));
+    compute_observations(s, e, step);
+    float *odt = TP(s, QA_T_OBS_DISC_TERM, float) + QA_NUM_OBS_DISC * e;
+    memcpy(odt, reset ? term_disc_tmp : TP(s, QA_T_OBS_DISC, float) + QA_NUM_OBS_DISC * e, QA_NUM_OBS_DISC * 4);
+    /* :158-161 */
+    memcpy(TP(s, QA_T_LAST_ACTIONS, float) + 12 * e, act, 48);
+    for (int j = 0; j < 12; ++j) TP(s, QA_T_LAST_DOF_VEL, float)[12 * e + j] = dof[2 * j + 1];
+    memcpy(TP(s, QA_T_LAST_ROOT_VEL, float) + 6 * e, root + 7, 24);
+    memcpy(TP(s, QA_T_LAST_TORQUES_ORG, float) + 12 * e, torg, 48);
+}
+
+/* ------------------------------------------------------------------ C ABI (qo_ = oracle twin of qa_) */
+int64_t qo_arena_bytes(const qa_config *cfg) { Layout L; if (!cfg || cfg->num_envs <= 0) return QA_E_ARG; make_layout(cfg, &L); return L.total; }
+
+int qo_tensor_info(const qa_config *cfg, int which, int64_t *off, int64_t shape[3], int32_t *ndim, int32_t *dtype) {
+    if (!cfg || which < 0 || which >= QA_T_COUNT) return QA_E_ARG;
+    Layout L; make_layout(cfg, &L);
+    if (off) *off = L.off[which];
+    if (shape) for (int i = 0; i < 3; ++i) shape[i] = L.shape[which][i];
+    if (ndim) *ndim = L.ndim[which];
+    if (dtype) *dtype = L.dtype[which];
+    return QA_OK;
+}
+
+static float normal_from(float u1, float u2) { /* Box-Muller */
+    if (u1 < 1e-7f) u1 = 1e-7f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+int qo_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stream, qo_sim **out) {
+    (void)stream;
+    if (!cfg || !arena || !out || cfg->num_envs <= 0) return QA_E_ARG;
+    if (cfg->abi_version != QA_ABI_VERSION) return QA_E_VERSION;
+    qo_sim *s = (qo_sim *)calloc(1, sizeof(qo_sim));
+    s->cfg = *cfg; make_layout(cfg, &s->L); s->arena = (char *)arena;
+    if (arena_bytes < s->L.total || ((uintptr_t)arena & 255)) { free(s); return QA_E_ARENA; }
+    memset(arena, 0, (size_t)s->L.total);
+    int N = cfg->num_envs;
+    /* env origins: grid (legged_robot.py:1126-1136) */
+    int ncols = (int)floor(sqrt((double)N));
+    for (int e = 0; e < N; ++e) {
+        float *o = TP(s, QA_T_ENV_ORIGINS, float) + 3 * e;
+        o[0] = cfg->env_spacing * (float)(e / ncols); o[1] = cfg->env_spacing * (float)(e % ncols); o[2] = 0;
+        float u[4];
+        /* friction: 64 buckets, legged_robot.py:386-401 */
+        float fr = 1.0f;
+        if (cfg->randomize_friction) {
+            rng4(s, e, 0, RS_INIT_FRICTION, 0, u); int b = (int)(u[0] * 64.0f); if (b > 63) b = 63;
+            rng4(s, (uint32_t)b, 0, RS_INIT_BUCKET, 0, u);
+            fr = (cfg->friction_range[1] - cfg->friction_range[0]) * u[0] + cfg->friction_range[0];
+        }
+        TP(s, QA_T_FRICTION, float)[e] = fr;
+        /* base mass / CoM: legged_robot.py:432-447 */
+        rng4(s, e, 0, RS_INIT_MASS, 0, u);
+        float *mp = TP(s, QA_T_MASS_PARAMS, float) + 4 * e;
+        mp[0] = cfg->randomize_base_mass ? (cfg->added_mass_range[1] - cfg->added_mass_range[0]) * u[0] + cfg->added_mass_range[0] : 0.0f;
+        for (int i = 0; i < 3; ++i) mp[1 + i] = cfg->randomize_base_com ? (cfg->added_com_range[1] - cfg->added_com_range[0]) * u[1 + i] + cfg->added_com_range[0] : 0.0f;
+        { /* base link inertia about the base origin: mass m0+dm at c0+dc, CoM inertia scaled with mass */
+            double m = (double)QA_BASE_MASS + mp[0], sc = m / (double)QA_BASE_MASS;
+            v3 cc = {(double)QA_BASE_COM[0] + mp[1], (double)QA_BASE_COM[1] + mp[2], (double)QA_BASE_COM[2] + mp[3]};
+            m3 Ic = {{QA_BASE_I[0] * sc, QA_BASE_I[3] * sc, QA_BASE_I[4] * sc}, {QA_BASE_I[3] * sc, QA_BASE_I[1] * sc, QA_BASE_I[5] * sc}, {QA_BASE_I[4] * sc, QA_BASE_I[5] * sc, QA_BASE_I[2] * sc}};
+            RB rb; rb_make(m, cc, Ic, &rb);
+            float *bi = TP(s, QA_T_BASE_INERTIA, float) + 10 * e;
+            bi[0] = (float)rb.m; for (int i = 0; i < 3; ++i) bi[1 + i] = (float)rb.h[i];
+            bi[4] = (float)rb.I[0][0]; bi[5] = (float)rb.I[1][1]; bi[6] = (float)rb.I[2][2]; bi[7] = (float)rb.I[0][1]; bi[8] = (float)rb.I[0][2]; bi[9] = (float)rb.I[1][2];
+        }
+        /* motor strength: legged_robot.py:799-807, 861-888 */
+        float uu[48];
+        for (int b = 0; b < 12; ++b) rng4(s, e, 0, RS_INIT_MOTOR, b, uu + 4 * b);
+        float *ms = TP(s, QA_T_MOTOR_STRENGTH, float);
+        for (int j = 0; j < 12; ++j) {
+            int pi = 2 * (j % 3);
+            float sp, sd;
+            if (!cfg->randomize_motor) { sp = sd = 1.0f; }
+            else if (cfg->use_easi) { sp = cfg->easi_mean[pi] + cfg->easi_var[pi] * normal_from(uu[j], uu[12 + j]);
+                                      sd = cfg->easi_mean[pi + 1] + cfg->easi_var[pi + 1] * normal_from(uu[24 + j], uu[36 + j]); }
+            else { sp = (cfg->motor_strength_range[1] - cfg->motor_strength_range[0]) * uu[j] + cfg->motor_strength_range[0];
+                   sd = (cfg->motor_strength_range[1] - cfg->motor_strength_range[0]) * uu[12 + j] + cfg->motor_strength_range[0]; }
+            ms[(0 * N + e) * 12 + j] = sp; ms[(1 * N + e) * 12 + j] = sd;
+        }
+        TP(s, QA_T_RESET, int64_t)[e] = 1;
+        TP(s, QA_T_ROOT_STATES, float)[13 * e + 6] = 1.0f;
+    }
+    for (int g = 0; g < QA_NUM_GAITS; ++g) TP(s, QA_T_PRIOR_PARAMETERS, float)[g] = 1.0f / QA_NUM_GAITS; /* :822-823 */
+    *out = s;
+    return QA_OK;
+}
+
+int qo_destroy(qo_sim *s) { free(s); return QA_OK; }
+
+int qo_set_mocap(qo_sim *s, const float *frames, int32_t nf, const int32_t first[QA_NUM_GAITS + 1], void *stream) {
+    (void)stream;
+    if (!s || !frames || nf <= 0 || nf > s->cfg.num_mocap_frames) return QA_E_ARG;
+    memcpy(TP(s, QA_T_MOCAP_FRAMES, float), frames, (size_t)nf * QA_MOCAP_FRAME * 4);
+    memcpy(s->mocap_first, first, sizeof(s->mocap_first));
+    return QA_OK;
+}
+
+int qo_simulate(qo_sim *s, const float *torques, void *stream) {
+    (void)stream;
+    if (!s || !torques) return QA_E_ARG;
+    for (int e = 0; e < s->cfg.num_envs; ++e) {
+        float tau[12];
+        for (int j = 0; j < 12; ++j) tau[j] = clipf(torques[12 * e + j], -QA_DOF_EFFORT[j / 3][j % 3], QA_DOF_EFFORT[j / 3][j % 3]);
+        phys_substep(s, e, tau);
+    }
+    return QA_OK;
+}
+
+int qo_reset_all(qo_sim *s, int64_t step, void *stream) {
+    (void)stream;
+    if (!s) return QA_E_ARG;
+    memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * (step & 1), 0, 64);
+    for (int e = 0; e < s->cfg.num_envs; ++e) reset_env(s, e, step, (int)(step & 1));
+    return QA_OK;
+}
+
+int qo_env_step(qo_sim *s, const float *actions, int32_t delay_steps, int64_t step, void *stream) {
+    (void)stream;
+    if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    const qa_config *c = &s->cfg;
+    memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * (step & 1), 0, 64);
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < c->num_envs; ++e) {
+        /* legged_robot.py:84-98 */
+        float *ah = TP(s, QA_T_ACTION_HISTORY, float) + 96 * e;
+        memmove(ah, ah + 12, 7 * 12 * 4);
+        memcpy(ah + 7 * 12, actions + 12 * e, 48);
+        const float *src = ah + 12 * (QA_ACTION_BUF_LEN - 1 - delay_steps);
+        float *act = TP(s, QA_T_ACTIONS, float) + 12 * e;
+        float clipa = c->clip_actions / c->action_scale;
+        for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
+        float *tau = TP(s, QA_T_TORQUES, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e;
+        for (int d = 0; d < c->decimation; ++d) {     /* :101-106 */
+            compute_torques(s, e, act, tau, torg);
+            phys_substep(s, e, tau);
+        }
+        float tmp[QA_NUM_OBS_DISC];
+        post_physics(s, e, step, tmp);
+    }
+    return QA_OK;
+}
+
+/* GAE: rollout_storage.py:97-111 (fp32 like the reference; mean/std accumulated in double) */
+int qo_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+           float *returns, float *advantages, int32_t T, int32_t N, float gamma, float lam, int32_t normalize,
+           void *scratch, void *stream) {
+    (void)scratch; (void)stream;
+    if (!rewards || !values || !dones || !last_values || !returns || !advantages || T <= 0 || N <= 0) return QA_E_ARG;
+    for (int e = 0; e < N; ++e) {
+        float adv = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            float nv = t == T - 1 ? last_values[e] : values[(int64_t)(t + 1) * N + e];
+            float nt = 1.0f - (float)dones[(int64_t)t * N + e];
+            float delta = rewards[(int64_t)t * N + e] + nt * gamma * nv - values[(int64_t)t * N + e];
+            adv = delta + nt * gamma * lam * adv;
+            returns[(int64_t)t * N + e] = adv + values[(int64_t)t * N + e];
+        }
+    }
+    int64_t n = (int64_t)T * N; double sum = 0, sq = 0;
+    for (int64_t i = 0; i < n; ++i) { advantages[i] = returns[i] - values[i]; sum += advantages[i]; }
+    if (normalize) {
+        double mean = sum / (double)n;
+        for (int64_t i = 0; i < n; ++i) { double d = advantages[i] - mean; sq += d * d; }
+        double sd = sqrt(sq / (double)(n - 1));
+        for (int64_t i = 0; i < n; ++i) advantages[i] = (float)(((double)advantages[i] - mean) / (sd + 1e-8));
+    }
+    return QA_OK;
+}
+
+/* ---- debug entry points used only by the physics known-answer tests ---- */
+/* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
+int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {
+    Kin K; double qq[12], qdd[12], u[6];
+    for (int j = 0; j < 12; ++j) { qq[j] = q[j]; qdd[j] = qd[j]; }
+    for (int i = 0; i < 6; ++i) u[i] = ub[i];
+    for (int l = 0; l < 4; ++l) leg_kin(l, qq + 3 * l, &K);
+    v3 c0 = {QA_BASE_COM[0], QA_BASE_COM[1], QA_BASE_COM[2]};
+    m3 Ic = {{QA_BASE_I[0], QA_BASE_I[3], QA_BASE_I[4]}, {QA_BASE_I[3], QA_BASE_I[1], QA_BASE_I[5]}, {QA_BASE_I[4], QA_BASE_I[5], QA_BASE_I[2]}};
+    RB base; rb_make(QA_BASE_MASS, c0, Ic, &base);
+    double qd4[4] = {quat[0], quat[1], quat[2], quat[3]}; m3 R; quat_to_mat(qd4, R);
+    v3 gw = {0, 0, -9.81}, gB; mtv(R, gw, gB);
+    double M[18][18], h[18];
+    dynamics_terms(&K, &base, u, qdd, gB, M, h);
+    memcpy(Mout, M, sizeof(M)); memcpy(hout, h, sizeof(h));
+    return QA_OK;
+}
+/* per-body kinematics (CoM position and velocity in the base frame, mass, inertia) for an independent energy check */
+int qo_debug_bodies(const float q[12], const float qd[12], const float ub[6], double com[13 * 3], double vel[13 * 3], double omg[13 * 3], double mass[13], double Icom[13 * 9]) {
+    Kin K; double qq[12];
+    for (int j = 0; j < 12; ++j) qq[j] = q[j];
+    for (int l = 0; l < 4; ++l) leg_kin(l, qq + 3 * l, &K);
+    for (int i = 0; i < 3; ++i) { com[i] = QA_BASE_COM[i]; omg[i] = ub[i]; }
+    { v3 w = {ub[0], ub[1], ub[2]}, c = {com[0], com[1], com[2]}, t; cross(w, c, t); for (int i = 0; i < 3; ++i) vel[i] = ub[3 + i] + t[i]; }
+    mass[0] = QA_BASE_MASS;
+    { double I9[9] = {QA_BASE_I[0], QA_BASE_I[3], QA_BASE_I[4], QA_BASE_I[3], QA_BASE_I[1], QA_BASE_I[5], QA_BASE_I[4], QA_BASE_I[5], QA_BASE_I[2]}; memcpy(Icom, I9, sizeof(I9)); }
+    for (int l = 0; l < 4; ++l) {
+        v3 w = {ub[0], ub[1], ub[2]};
+        /* velocity of a point p on link k: v_B + w_B x p + sum_j qd_j a_j x (p - o_j) */
+        for (int k = 0; k < 3; ++k) {
+            int b = 1 + 3 * l + k;
+            v3 cl = {QA_LINK_COM[l][k][0], QA_LINK_COM[l][k][1], QA_LINK_COM[l][k][2]}, c;
+            mv(K.Rl[l][k], cl, c); for (int i = 0; i < 3; ++i) c[i] += K.o[l][k][i];
+            v3 v, t, wk = {w[0], w[1], w[2]};
+            cross(w, c, t); for (int i = 0; i < 3; ++i) v[i] = ub[3 + i] + t[i];
+            for (int j = 0; j <= k; ++j) {
+                v3 rel = {c[0] - K.o[l][j][0], c[1] - K.o[l][j][1], c[2] - K.o[l][j][2]};
+                cross(K.a[l][j], rel, t);
+                for (int i = 0; i < 3; ++i) { v[i] += qd[3 * l + j] * t[i]; wk[i] += qd[3 * l + j] * K.a[l][j][i]; }
+            }
+            const float *I6 = QA_LINK_I[l][k];
+            m3 Il = {{I6[0], I6[3], I6[4]}, {I6[3], I6[1], I6[5]}, {I6[4], I6[5], I6[2]}}, Rt, Ib;
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i][j] = K.Rl[l][k][j][i];
+            mm(K.Rl[l][k], Il, Ib); mm(Ib, Rt, Ib);
+            for (int i = 0; i < 3; ++i) { com[3 * b + i] = c[i]; vel[3 * b + i] = v[i]; omg[3 * b + i] = wk[i]; }
+            mass[b] = QA_LINK_MASS[l][k];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Icom[9 * b + 3 * i + j] = Ib[i][j];
+        }
+    }
+    return QA_OK;
+}

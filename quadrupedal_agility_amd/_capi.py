@@ -1,0 +1,124 @@
+"""ctypes mirror of include/qa_sim.h (struct qa_config, enums) and the loader of the HIP library.
+
+The product path loads ONLY quadrupedal_agility_amd/csrc/libqa_sim.so (built by
+__graft_entry__.build()).  It never falls back to a CPU path: a missing library raises.
+"""
+import ctypes as C
+import os
+
+QA_ABI_VERSION = 1
+NUM_DOF = 12
+NUM_GAITS = 5
+NUM_PROP = 57
+HISTORY_LEN = 10
+NUM_OBS = 671
+NUM_OBS_DISC = 49
+ACTION_BUF_LEN = 8
+NUM_REWARDS = 14
+MOCAP_FRAME = 37
+
+REWARD_NAMES = [
+    "action_rate", "collision", "delta_torques", "dof_acc", "dof_error", "dof_pos_limits",
+    "dof_vel_limits", "hip_pos", "jump_up_height", "locomotion_height", "torque_limits",
+    "torques", "tracking_ang_vel", "tracking_lin_vel",
+]
+
+TENSORS = [
+    "ROOT_STATES", "DOF_STATE", "CONTACT_FORCES", "RIGID_BODY_POS", "TORQUES", "TORQUES_ORG",
+    "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_TORQUES_ORG", "LAST_ROOT_VEL",
+    "ACTION_HISTORY", "OBS_HISTORY", "OBS", "OBS_DISC", "OBS_DISC_TERM", "COMMANDS",
+    "LATENT_EPS", "LATENT_C", "REW", "RESET", "TIME_OUT", "EPISODE_LENGTH", "EPISODE_SUMS",
+    "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
+    "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",
+    "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES",
+]
+T = {name: i for i, name in enumerate(TENSORS)}
+DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32 = 0, 1, 2, 3
+
+BODY_NAMES = ["base", "Head_upper", "Head_lower"] + [
+    f"{l}_{p}" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf", "foot")]
+DOF_NAMES = [f"{l}_{p}_joint" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf")]
+
+
+class QaConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("num_envs", C.c_int32), ("seed", C.c_uint64),
+        ("sim_dt", C.c_float), ("decimation", C.c_int32), ("gravity_z", C.c_float),
+        ("solver_iterations", C.c_int32), ("contact_offset", C.c_float),
+        ("max_depenetration_velocity", C.c_float), ("ground_friction", C.c_float),
+        ("terrain_type", C.c_int32),
+        ("kp", C.c_float), ("kd", C.c_float), ("action_scale", C.c_float),
+        ("hip_scale_reduction", C.c_float), ("clip_actions", C.c_float),
+        ("default_dof_pos", C.c_float * NUM_DOF),
+        ("env_spacing", C.c_float), ("max_episode_length", C.c_int32),
+        ("resampling_steps", C.c_int32), ("push_interval", C.c_int32), ("push_robots", C.c_int32),
+        ("max_push_vel_xy", C.c_float), ("reset_mode", C.c_int32), ("init_pos", C.c_float * 3),
+        ("add_noise", C.c_int32),
+        ("noise_roll_pitch", C.c_float), ("noise_ang_vel", C.c_float), ("noise_dof_pos", C.c_float),
+        ("noise_dof_vel", C.c_float), ("noise_lin_vel", C.c_float), ("clip_obs", C.c_float),
+        ("s_lin_vel", C.c_float), ("s_ang_vel", C.c_float), ("s_dof_pos", C.c_float),
+        ("s_dof_vel", C.c_float), ("s_key_pos", C.c_float), ("s_foot_contact", C.c_float),
+        ("s_lin_vel_dist", C.c_float), ("s_ang_vel_dist", C.c_float),
+        ("reward_scale_dt", C.c_float * NUM_REWARDS), ("only_positive_rewards", C.c_int32),
+        ("tracking_sigma", C.c_float), ("soft_dof_pos_limit", C.c_float),
+        ("soft_dof_vel_limit", C.c_float), ("soft_torque_limit", C.c_float), ("jump_goal", C.c_float),
+        ("lin_vel_x", (C.c_float * 2) * NUM_GAITS), ("lin_vel_y", (C.c_float * 2) * NUM_GAITS),
+        ("ang_vel_yaw", (C.c_float * 2) * NUM_GAITS),
+        ("jump_height", C.c_float * 2), ("locomotion_height", C.c_float * 2),
+        ("lin_vel_x_clip", C.c_float), ("lin_vel_y_clip", C.c_float), ("ang_vel_yaw_clip", C.c_float),
+        ("latent_temperature", C.c_float),
+        ("randomize_friction", C.c_int32), ("randomize_base_mass", C.c_int32),
+        ("randomize_base_com", C.c_int32), ("randomize_motor", C.c_int32), ("use_easi", C.c_int32),
+        ("friction_range", C.c_float * 2), ("added_mass_range", C.c_float * 2),
+        ("added_com_range", C.c_float * 2), ("motor_strength_range", C.c_float * 2),
+        ("easi_mean", C.c_float * 6), ("easi_var", C.c_float * 6),
+        ("num_mocap_frames", C.c_int32), ("mocap_clip_count", C.c_int32 * NUM_GAITS),
+    ]
+
+
+def bind(lib, prefix):
+    """Declare argtypes/restypes of the C ABI on a loaded library (prefix 'qa_' or 'qo_')."""
+    P = C.POINTER
+    f = getattr(lib, prefix + "arena_bytes"); f.argtypes = [P(QaConfig)]; f.restype = C.c_int64
+    f = getattr(lib, prefix + "create"); f.argtypes = [P(QaConfig), C.c_void_p, C.c_int64, C.c_void_p, P(C.c_void_p)]; f.restype = C.c_int
+    f = getattr(lib, prefix + "destroy"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "tensor_info"); f.argtypes = [P(QaConfig), C.c_int, P(C.c_int64), C.c_int64 * 3, P(C.c_int32), P(C.c_int32)]; f.restype = C.c_int
+    f = getattr(lib, prefix + "env_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "reset_all"); f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "simulate"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "set_mocap"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "gae"); f.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+    return lib
+
+
+ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "reset_all", "simulate",
+               "set_mocap", "gae", "last_error", "abi_version"]
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")
+
+
+def load_library():
+    """Load the HIP library; raise loudly if it has not been built (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). quadrupedal_agility_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        bind(lib, "qa_")
+        lib.qa_last_error.restype = C.c_char_p
+        lib.qa_abi_version.restype = C.c_int
+        if lib.qa_abi_version() != QA_ABI_VERSION:
+            raise RuntimeError("libqa_sim.so ABI version mismatch")
+        _LIB = lib
+    return _LIB
+
+
+def tensor_info(lib, prefix, cfg, which):
+    off = C.c_int64(); shape = (C.c_int64 * 3)(); nd = C.c_int32(); dt = C.c_int32()
+    rc = getattr(lib, prefix + "tensor_info")(C.byref(cfg), which, C.byref(off), shape, C.byref(nd), C.byref(dt))
+    if rc != 0:
+        raise RuntimeError(f"{prefix}tensor_info({which}) -> {rc}")
+    return off.value, tuple(shape[i] for i in range(nd.value)), dt.value
