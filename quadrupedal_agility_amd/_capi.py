@@ -77,7 +77,8 @@ class QaConfig(C.Structure):
 
 
 def bind(lib, prefix):
-    """Declare argtypes/restypes of the C ABI on a loaded library (prefix 'qa_' or 'qo_')."""
+    """Declare argtypes/restypes of the C ABI of include/qa_sim.h on a loaded library whose
+    symbols carry `prefix` (the product library uses "qa_")."""
     P = C.POINTER
     f = getattr(lib, prefix + "arena_bytes"); f.argtypes = [P(QaConfig)]; f.restype = C.c_int64
     f = getattr(lib, prefix + "create"); f.argtypes = [P(QaConfig), C.c_void_p, C.c_int64, C.c_void_p, P(C.c_void_p)]; f.restype = C.c_int

@@ -1,0 +1,461 @@
+// qa_physics.h -- one physics substep of one Go2, executed by the 4 lanes of a quad (lane = leg).
+//
+// Model: floating base + 4 x 3 revolute joints, all spatial quantities
+// expressed in the base frame at the base origin.  Each lane builds its own leg (kinematics,
+// link inertias, composite inertias, the 3x3 leg block L of the mass matrix and the 6x3
+// base-coupling block F, Newton-Euler bias).  The legs only couple through the base, so
+//     M = [ Mbb  F ] ,   a_leg = Linv (r_leg - F^T a_b) ,   (Mbb - sum_l F Linv F^T) a_b = r_b - sum_l F Linv r_leg
+//         [ F^T  L ]
+// i.e. the 18x18 solve collapses to four lane-local 3x3 inverses, a quad-sum of a 6x6 Schur
+// complement (DPP), and one 6x6 SPD inverse that every lane evaluates redundantly.  Contact and
+// joint-limit rows are solved by projected Gauss-Seidel in the reduced coordinates
+// (u_b, w_l = u_l - G_l u_b), in which an impulse on leg l touches only u_b and w_l.
+#pragma once
+#include "qa_device.h"
+
+#define QA_LEG_TBL 124           // floats per leg in the constant table
+#define QA_BASE_TBL 44
+#define QA_TBL_FLOATS (4 * QA_LEG_TBL + QA_BASE_TBL)
+// offsets inside a leg table
+#define T_HIP_ORG 0
+#define T_THIGH_ORG 3
+#define T_CALF_ORG 6
+#define T_FOOT_ORG 9
+#define T_MASS 12
+#define T_COM 15
+#define T_INERTIA 24
+#define T_LOWER 42
+#define T_UPPER 45
+#define T_EFFORT 48
+#define T_VELLIM 51
+#define T_POINTS 54              // 17 x (x y z r); point 0 is the foot sphere
+#define QA_LEG_PTS 17
+#define QA_BASE_PTS 11
+
+#define QA_LIMIT_MARGIN 0.5f     // rad
+#define QA_LIMIT_DEPEN 1.0f      // rad/s
+#define QA_CFM 1e-6f
+
+struct PhysParams {
+    float dt, gz, contact_offset, max_depen, ground_friction;
+    int iters;
+};
+
+// packed lower-triangular index of a symmetric 6x6
+#define SIDX(i, j) ((i) >= (j) ? ((i) * ((i) + 1) / 2 + (j)) : ((j) * ((j) + 1) / 2 + (i)))
+
+// inverse of a symmetric positive definite 6x6 given packed (21); Cholesky + triangular inverse
+QA_DEV void spd6_inverse(const float *A, float *Ainv) {
+    float Lc[21];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float d = A[SIDX(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= Lc[SIDX(j, k)] * Lc[SIDX(j, k)];
+        float inv = rsqrtf(d);
+        Lc[SIDX(j, j)] = inv;                 // store 1/L_jj on the diagonal
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            float s = A[SIDX(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= Lc[SIDX(i, k)] * Lc[SIDX(j, k)];
+            Lc[SIDX(i, j)] = s * inv;
+        }
+    }
+    // T = L^-1 (lower triangular), column by column
+    float T[21];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        T[SIDX(j, j)] = Lc[SIDX(j, j)];
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = j; k < i; ++k) s -= Lc[SIDX(i, k)] * T[SIDX(k, j)];
+            T[SIDX(i, j)] = s * Lc[SIDX(i, i)];
+        }
+    }
+    // A^-1 = T^T T
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = i; k < 6; ++k) s += T[SIDX(k, i)] * T[SIDX(k, j)];
+            Ainv[SIDX(i, j)] = s;
+        }
+}
+
+QA_DEV void sym6_mul(const float *A, const float *x, float *y) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s = fmaf(A[SIDX(i, j)], x[j], s);
+        y[i] = s;
+    }
+}
+
+// state of one env as seen by one lane (registers)
+struct EnvState {
+    V3 pos; float qx, qy, qz, qw; V3 vw, ww;    // root, replicated across the quad
+    float q[3], qd[3];                          // this lane's leg
+};
+
+struct ContactOut {
+    V3 foot_f;         // world-frame force on this leg's foot
+    V3 extra_f;        // world-frame force on the extra contact owned by this lane
+    int extra_body;    // body id of the extra contact (-1 none)
+};
+
+// one scalar constraint row in reduced coordinates
+struct Row {
+    float jh[6];   // J_b + G^T j_l
+    float jl[3];
+    float bj[6];   // Binv jh
+    float lj[3];   // Linv jl
+    float dinv, bias, lam;
+};
+
+QA_DEV void row_finish(Row &r, const float *G, const float *Linv, const float *Binv, const float *jb) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.jh[i] = jb[i] + G[0 * 6 + i] * r.jl[0] + G[1 * 6 + i] * r.jl[1] + G[2 * 6 + i] * r.jl[2];
+    sym6_mul(Binv, r.jh, r.bj);
+    // Linv packed: 00 01 02 11 12 22
+    r.lj[0] = Linv[0] * r.jl[0] + Linv[1] * r.jl[1] + Linv[2] * r.jl[2];
+    r.lj[1] = Linv[1] * r.jl[0] + Linv[3] * r.jl[1] + Linv[4] * r.jl[2];
+    r.lj[2] = Linv[2] * r.jl[0] + Linv[4] * r.jl[1] + Linv[5] * r.jl[2];
+    float d = r.jl[0] * r.lj[0] + r.jl[1] * r.lj[1] + r.jl[2] * r.lj[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d = fmaf(r.jh[i], r.bj[i], d);
+    r.dinv = 1.0f / (d + QA_CFM);
+    r.lam = 0.f;
+}
+
+// Gauss-Seidel update of one row on the lane-local copy (ub, w); lo/hi bound the multiplier
+QA_DEV void row_update(Row &r, float *ub, float *w, float lo, float hi) {
+    float res = r.bias + r.jl[0] * w[0] + r.jl[1] * w[1] + r.jl[2] * w[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) res = fmaf(r.jh[i], ub[i], res);
+    float lam = clampf(r.lam - res * r.dinv, lo, hi);
+    float dl = lam - r.lam;
+    r.lam = lam;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ub[i] = fmaf(r.bj[i], dl, ub[i]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] = fmaf(r.lj[k], dl, w[k]);
+}
+
+// build the three rows (normal, tangent1, tangent2) of a contact at base-frame point p of chain depth `depth`
+QA_DEV void contact_rows(Row *rows, V3 p, int depth, float gap, const V3 *o, const V3 *ax, V3 nB, V3 t1B, V3 t2B,
+                         const float *G, const float *Linv, const float *Binv, const PhysParams &P) {
+    V3 dirs[3] = {nB, t1B, t2B};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        V3 pxd = cross(p, dirs[d]);
+        float jb[6] = {pxd.x, pxd.y, pxd.z, dirs[d].x, dirs[d].y, dirs[d].z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rows[d].jl[k] = (k < depth) ? dot(dirs[d], cross(ax[k], p - o[k])) : 0.f;
+        row_finish(rows[d], G, Linv, Binv, jb);
+        rows[d].bias = 0.f;
+    }
+    float g = gap / P.dt;
+    rows[0].bias = gap >= 0.f ? g : fmaxf(g, -P.max_depen);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One substep.  tbl = this lane's leg table (LDS), btbl = base point table (LDS), binert = base
+// link inertia (10 floats), tau = joint torques of this leg (already clipped), mu = friction.
+// Returns contact forces; updates st in place.  If fk_out != nullptr, writes the joint origins
+// and the foot origin of the NEW state in the base frame (4 points) for RIGID_BODY_POS.
+template <bool PLANE>
+QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
+                         float mu, int leg, const PhysParams &P, ContactOut &co) {
+    const float dt = P.dt;
+    M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
+    S6 V0 = s6(mulT(R, st.ww), mulT(R, st.vw));
+    V3 gB = v3(R.m[6] * P.gz, R.m[7] * P.gz, R.m[8] * P.gz);
+
+    // ---- leg kinematics in the base frame
+    float s1, c1, s2, c2, s23, c23;
+    sincosf(st.q[0], &s1, &c1); sincosf(st.q[1], &s2, &c2); sincosf(st.q[1] + st.q[2], &s23, &c23);
+    M3 Rl[3];
+    Rl[0].m[0] = 1; Rl[0].m[1] = 0; Rl[0].m[2] = 0; Rl[0].m[3] = 0; Rl[0].m[4] = c1; Rl[0].m[5] = -s1; Rl[0].m[6] = 0; Rl[0].m[7] = s1; Rl[0].m[8] = c1;
+    // R1 * Ry(t) = [[c,0,s],[s1 s, c1, -s1 c],[-c1 s, s1, c1 c]]
+    Rl[1].m[0] = c2; Rl[1].m[1] = 0; Rl[1].m[2] = s2; Rl[1].m[3] = s1 * s2; Rl[1].m[4] = c1; Rl[1].m[5] = -s1 * c2; Rl[1].m[6] = -c1 * s2; Rl[1].m[7] = s1; Rl[1].m[8] = c1 * c2;
+    Rl[2].m[0] = c23; Rl[2].m[1] = 0; Rl[2].m[2] = s23; Rl[2].m[3] = s1 * s23; Rl[2].m[4] = c1; Rl[2].m[5] = -s1 * c23; Rl[2].m[6] = -c1 * s23; Rl[2].m[7] = s1; Rl[2].m[8] = c1 * c23;
+    V3 o[3], ax[3];
+    o[0] = v3(tbl[T_HIP_ORG], tbl[T_HIP_ORG + 1], tbl[T_HIP_ORG + 2]);
+    o[1] = o[0] + mul(Rl[0], v3(tbl[T_THIGH_ORG], tbl[T_THIGH_ORG + 1], tbl[T_THIGH_ORG + 2]));
+    o[2] = o[1] + mul(Rl[1], v3(tbl[T_CALF_ORG], tbl[T_CALF_ORG + 1], tbl[T_CALF_ORG + 2]));
+    ax[0] = v3(1, 0, 0); ax[1] = v3(0, c1, s1); ax[2] = ax[1];
+    S6 S[3];
+    RB link[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        S[k] = s6(ax[k], cross(o[k], ax[k]));
+        link[k] = link_rb(tbl[T_MASS + k], v3(tbl[T_COM + 3 * k], tbl[T_COM + 3 * k + 1], tbl[T_COM + 3 * k + 2]),
+                          tbl + T_INERTIA + 6 * k, Rl[k], o[k]);
+    }
+    // ---- composite inertias, mass-matrix blocks
+    RB Ic2 = link[2], Ic1 = link[1] + Ic2, Ic0 = link[0] + Ic1;
+    S6 F[3] = {apply(Ic0, S[0]), apply(Ic1, S[1]), apply(Ic2, S[2])};
+    float L00 = dot(S[0], F[0]), L01 = dot(S[0], F[1]), L02 = dot(S[0], F[2]);
+    float L11 = dot(S[1], F[1]), L12 = dot(S[1], F[2]), L22 = dot(S[2], F[2]);
+    RB base; base.m = binert[0]; base.h = v3(binert[1], binert[2], binert[3]);
+    base.xx = binert[4]; base.yy = binert[5]; base.zz = binert[6]; base.xy = binert[7]; base.xz = binert[8]; base.yz = binert[9];
+    RB tot = base + quad_sum(Ic0);
+
+    // ---- bias forces: Newton-Euler with zero joint acceleration, base acceleration = -gravity
+    S6 A0 = s6(v3(0, 0, 0), v3(-gB.x, -gB.y, -gB.z));
+    S6 fl[3];
+    {
+        S6 V = V0, A = A0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            S6 Sq = st.qd[k] * S[k];
+            V = V + Sq;
+            A = A + crm(V, Sq);
+            fl[k] = apply(link[k], A) + crf(V, apply(link[k], V));
+        }
+    }
+    fl[1] = fl[1] + fl[2]; fl[0] = fl[0] + fl[1];
+    float hl[3] = {dot(S[0], fl[0]), dot(S[1], fl[1]), dot(S[2], fl[2])};
+    S6 f0 = apply(base, A0) + crf(V0, apply(base, V0)) + quad_sum(fl[0]);
+
+    // ---- leg elimination: Linv (packed 00 01 02 11 12 22), G = -Linv F^T (3x6 row-major)
+    float Linv[6];
+    {
+        float cA = L11 * L22 - L12 * L12, cB = L02 * L12 - L01 * L22, cC = L01 * L12 - L02 * L11;
+        float cD = L00 * L22 - L02 * L02, cE = L01 * L02 - L00 * L12, cF = L00 * L11 - L01 * L01;
+        float idet = 1.0f / (L00 * cA + L01 * cB + L02 * cC);
+        Linv[0] = cA * idet; Linv[1] = cB * idet; Linv[2] = cC * idet; Linv[3] = cD * idet; Linv[4] = cE * idet; Linv[5] = cF * idet;
+    }
+    float Fm[3][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Fm[k][0] = F[k].a.x; Fm[k][1] = F[k].a.y; Fm[k][2] = F[k].a.z; Fm[k][3] = F[k].l.x; Fm[k][4] = F[k].l.y; Fm[k][5] = F[k].l.z; }
+    float G[18];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        G[0 * 6 + i] = -(Linv[0] * Fm[0][i] + Linv[1] * Fm[1][i] + Linv[2] * Fm[2][i]);
+        G[1 * 6 + i] = -(Linv[1] * Fm[0][i] + Linv[3] * Fm[1][i] + Linv[4] * Fm[2][i]);
+        G[2 * 6 + i] = -(Linv[2] * Fm[0][i] + Linv[4] * Fm[1][i] + Linv[5] * Fm[2][i]);
+    }
+    // Schur complement of the base: Mbb + sum_legs F G   (packed symmetric 6x6)
+    float Bm[21];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            Bm[SIDX(i, j)] = quad_sum(Fm[0][i] * G[0 * 6 + j] + Fm[1][i] * G[1 * 6 + j] + Fm[2][i] * G[2 * 6 + j]);
+    Bm[SIDX(0, 0)] += tot.xx; Bm[SIDX(1, 1)] += tot.yy; Bm[SIDX(2, 2)] += tot.zz;
+    Bm[SIDX(1, 0)] += tot.xy; Bm[SIDX(2, 0)] += tot.xz; Bm[SIDX(2, 1)] += tot.yz;
+    Bm[SIDX(3, 3)] += tot.m; Bm[SIDX(4, 4)] += tot.m; Bm[SIDX(5, 5)] += tot.m;
+    // lower-left block M[3+j][i] = hx[i][j], hx = [h]x
+    Bm[SIDX(3, 1)] += tot.h.z; Bm[SIDX(3, 2)] += -tot.h.y;
+    Bm[SIDX(4, 0)] += -tot.h.z; Bm[SIDX(4, 2)] += tot.h.x;
+    Bm[SIDX(5, 0)] += tot.h.y; Bm[SIDX(5, 1)] += -tot.h.x;
+    float Binv[21];
+    spd6_inverse(Bm, Binv);
+
+    // ---- unconstrained velocity
+    float rl[3] = {tau[0] - hl[0], tau[1] - hl[1], tau[2] - hl[2]};
+    float rb[6] = {-f0.a.x, -f0.a.y, -f0.a.z, -f0.l.x, -f0.l.y, -f0.l.z};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rb[i] += quad_sum(G[0 * 6 + i] * rl[0] + G[1 * 6 + i] * rl[1] + G[2 * 6 + i] * rl[2]);
+    float ab[6];
+    sym6_mul(Binv, rb, ab);
+    V3 wxv = cross(V0.a, V0.l);
+    float ub[6] = {V0.a.x + dt * ab[0], V0.a.y + dt * ab[1], V0.a.z + dt * ab[2],
+                   V0.l.x + dt * (ab[3] + wxv.x), V0.l.y + dt * (ab[4] + wxv.y), V0.l.z + dt * (ab[5] + wxv.z)};
+    float w[3];   // w = u_leg* - G ub*  with u_leg* = qd + dt (Linv r + G ab)  =>  w = qd + dt Linv r + G (dt ab - ub*)... keep it explicit:
+    {
+        float lr0 = Linv[0] * rl[0] + Linv[1] * rl[1] + Linv[2] * rl[2];
+        float lr1 = Linv[1] * rl[0] + Linv[3] * rl[1] + Linv[4] * rl[2];
+        float lr2 = Linv[2] * rl[0] + Linv[4] * rl[1] + Linv[5] * rl[2];
+        float lr[3] = {lr0, lr1, lr2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float gab = 0.f, gub = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { gab = fmaf(G[k * 6 + i], ab[i], gab); gub = fmaf(G[k * 6 + i], ub[i], gub); }
+            float ul = st.qd[k] + dt * (lr[k] + gab);
+            w[k] = ul - gub;
+        }
+    }
+
+    // ---- contact candidates: slot 0 = foot sphere, slot 1 = closest other point owned by this lane
+    V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);
+    float foot_gap; V3 foot_p;
+    float best_gap = 1e30f; V3 best_p = v3(0, 0, 0); int best_depth = 0, best_body = -1;
+#pragma unroll
+    for (int c = 0; c < QA_LEG_PTS; ++c) {
+        const int k = (c == 0) ? 2 : (c < 3 ? 0 : (c < 11 ? 1 : 2));
+        const float *pt = tbl + T_POINTS + 4 * c;
+        V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
+        float zw = dot(nB, p) + st.pos.z;            // plane: only the world height matters
+        float gap = zw - pt[3];
+        if (c == 0) { foot_gap = gap; foot_p = p; }
+        else if (gap < best_gap) { best_gap = gap; best_p = p; best_depth = k + 1; best_body = 3 + 4 * leg + k; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int c = leg + 4 * j;
+        if (c < QA_BASE_PTS) {
+            const float *pt = btbl + 4 * c;
+            V3 p = v3(pt[0], pt[1], pt[2]);
+            float gap = dot(nB, p) + st.pos.z - pt[3];
+            if (gap < best_gap) { best_gap = gap; best_p = p; best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2); }
+        }
+    }
+    const bool foot_on = foot_gap < P.contact_offset;
+    const bool extra_on = best_gap < P.contact_offset;
+
+    // ---- rows (all in registers; inactive ones are skipped wave-uniformly below)
+    Row rf[3], re[3];
+    contact_rows(rf, foot_p, 3, foot_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
+    const bool any_extra = __any(extra_on);
+    if (any_extra) contact_rows(re, best_p, best_depth, best_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
+    // joint limits: at most one stop per joint can be within the margin
+    float lim_sgn[3], lim_bias[3], lim_bj[3][6], lim_dinv[3], lim_lam[3];
+    bool lim_on[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float glo = st.q[k] - tbl[T_LOWER + k], ghi = tbl[T_UPPER + k] - st.q[k];
+        bool lo = glo < QA_LIMIT_MARGIN, hi = !lo && (ghi < QA_LIMIT_MARGIN);
+        lim_on[k] = lo || hi;
+        lim_sgn[k] = lo ? 1.f : -1.f;
+        float gap = lo ? glo : ghi, g = gap / dt;
+        lim_bias[k] = gap >= 0.f ? g : fmaxf(g, -QA_LIMIT_DEPEN);
+        lim_lam[k] = 0.f;
+    }
+    const bool any_lim = __any(lim_on[0] || lim_on[1] || lim_on[2]);
+    if (any_lim) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // jl = sgn e_k  =>  jh = sgn G[k,:],  lj = sgn Linv[:,k]
+            float jh[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) jh[i] = lim_sgn[k] * G[k * 6 + i];
+            sym6_mul(Binv, jh, lim_bj[k]);
+            float lkk = (k == 0) ? Linv[0] : (k == 1 ? Linv[3] : Linv[5]);
+            float d = lkk;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d = fmaf(jh[i], lim_bj[k][i], d);
+            lim_dinv[k] = 1.0f / (d + QA_CFM);
+        }
+    }
+
+    // ---- projected Gauss-Seidel, true sequential order over the legs: the lane whose turn it is
+    // updates its local (ub, w); its accumulated base-velocity change is then quad-broadcast.
+    const bool any_foot = __any(foot_on);
+    for (int it = 0; it < P.iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float ub2[6], w2[3];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ub2[i] = ub[i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w2[k] = w[k];
+            const bool mine = (leg == s);
+            if (any_foot) {
+                Row t0 = rf[0], t1 = rf[1], t2 = rf[2];
+                if (foot_on) {
+                    row_update(t0, ub2, w2, 0.f, 3.0e38f);
+                    float lim = mu * t0.lam;
+                    row_update(t1, ub2, w2, -lim, lim);
+                    row_update(t2, ub2, w2, -lim, lim);
+                }
+                if (mine) { rf[0].lam = t0.lam; rf[1].lam = t1.lam; rf[2].lam = t2.lam; }
+            }
+            if (any_extra) {
+                Row t0 = re[0], t1 = re[1], t2 = re[2];
+                if (extra_on) {
+                    row_update(t0, ub2, w2, 0.f, 3.0e38f);
+                    float lim = mu * t0.lam;
+                    row_update(t1, ub2, w2, -lim, lim);
+                    row_update(t2, ub2, w2, -lim, lim);
+                }
+                if (mine) { re[0].lam = t0.lam; re[1].lam = t1.lam; re[2].lam = t2.lam; }
+            }
+            if (any_lim) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (lim_on[k]) {
+                        // residual = bias + sgn * u_k,   u_k = w_k + G[k,:] ub
+                        float uk = w2[k];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) uk = fmaf(G[k * 6 + i], ub2[i], uk);
+                        float res = lim_bias[k] + lim_sgn[k] * uk;
+                        float lam = fmaxf(lim_lam[k] - res * lim_dinv[k], 0.f);
+                        float dl = lam - lim_lam[k];
+                        if (mine) lim_lam[k] = lam;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) ub2[i] = fmaf(lim_bj[k][i], dl, ub2[i]);
+                        float sd = lim_sgn[k] * dl;
+                        w2[0] = fmaf(k == 0 ? Linv[0] : (k == 1 ? Linv[1] : Linv[2]), sd, w2[0]);
+                        w2[1] = fmaf(k == 0 ? Linv[1] : (k == 1 ? Linv[3] : Linv[4]), sd, w2[1]);
+                        w2[2] = fmaf(k == 0 ? Linv[2] : (k == 1 ? Linv[4] : Linv[5]), sd, w2[2]);
+                    }
+                }
+            }
+            // commit: lane s keeps its w; everyone takes lane s's base velocity
+            if (mine) { w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float v = ub2[i];
+                ub[i] = s == 0 ? quad_bcast<0>(v) : (s == 1 ? quad_bcast<1>(v) : (s == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+            }
+        }
+    }
+
+    // ---- leg velocity, clamp, integrate
+    float ul[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float g = w[k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g = fmaf(G[k * 6 + i], ub[i], g);
+        float vl = tbl[T_VELLIM + k];
+        ul[k] = clampf(g, -vl, vl);
+    }
+    V3 wb = v3(ub[0], ub[1], ub[2]);
+    V3 wn = mul(R, wb), vn = mul(R, v3(ub[3], ub[4], ub[5]));
+    st.pos = st.pos + dt * vn;
+    {
+        float wn2 = dot(wb, wb), wnorm = sqrtf(wn2), ang = wnorm * dt;
+        float dx, dy, dz, dw;
+        if (ang > 1e-12f) { float sh, ch; sincosf(0.5f * ang, &sh, &ch); float sc = sh / wnorm; dx = wb.x * sc; dy = wb.y * sc; dz = wb.z * sc; dw = ch; }
+        else { dx = 0.5f * dt * wb.x; dy = 0.5f * dt * wb.y; dz = 0.5f * dt * wb.z; dw = 1.f; }
+        float nx = st.qw * dx + st.qx * dw + st.qy * dz - st.qz * dy;
+        float ny = st.qw * dy - st.qx * dz + st.qy * dw + st.qz * dx;
+        float nz = st.qw * dz + st.qx * dy - st.qy * dx + st.qz * dw;
+        float nw = st.qw * dw - st.qx * dx - st.qy * dy - st.qz * dz;
+        float inv = rsqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+        st.qx = nx * inv; st.qy = ny * inv; st.qz = nz * inv; st.qw = nw * inv;
+    }
+    st.vw = vn; st.ww = wn;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { st.q[k] = fmaf(dt, ul[k], st.q[k]); st.qd[k] = ul[k]; }
+
+    // ---- contact forces, world frame (plane: t1, t2, n are world x, y, z)
+    float idt = 1.0f / dt;
+    co.foot_f = (any_foot && foot_on) ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
+    co.extra_f = (any_extra && extra_on) ? v3(re[1].lam * idt, re[2].lam * idt, re[0].lam * idt) : v3(0, 0, 0);
+    co.extra_body = (any_extra && extra_on) ? best_body : -1;
+}
+
+// joint origins + foot origin of a leg in the base frame (for RIGID_BODY_POS after the last substep)
+QA_DEV void leg_origins(const float q[3], const float *tbl, V3 out[4]) {
+    float s1, c1, s2, c2, s23, c23;
+    sincosf(q[0], &s1, &c1); sincosf(q[1], &s2, &c2); sincosf(q[1] + q[2], &s23, &c23);
+    M3 R0, R1, R2;
+    R0.m[0] = 1; R0.m[1] = 0; R0.m[2] = 0; R0.m[3] = 0; R0.m[4] = c1; R0.m[5] = -s1; R0.m[6] = 0; R0.m[7] = s1; R0.m[8] = c1;
+    R1.m[0] = c2; R1.m[1] = 0; R1.m[2] = s2; R1.m[3] = s1 * s2; R1.m[4] = c1; R1.m[5] = -s1 * c2; R1.m[6] = -c1 * s2; R1.m[7] = s1; R1.m[8] = c1 * c2;
+    R2.m[0] = c23; R2.m[1] = 0; R2.m[2] = s23; R2.m[3] = s1 * s23; R2.m[4] = c1; R2.m[5] = -s1 * c23; R2.m[6] = -c1 * s23; R2.m[7] = s1; R2.m[8] = c1 * c23;
+    out[0] = v3(tbl[T_HIP_ORG], tbl[T_HIP_ORG + 1], tbl[T_HIP_ORG + 2]);
+    out[1] = out[0] + mul(R0, v3(tbl[T_THIGH_ORG], tbl[T_THIGH_ORG + 1], tbl[T_THIGH_ORG + 2]));
+    out[2] = out[1] + mul(R1, v3(tbl[T_CALF_ORG], tbl[T_CALF_ORG + 1], tbl[T_CALF_ORG + 2]));
+    out[3] = out[2] + mul(R2, v3(tbl[T_FOOT_ORG], tbl[T_FOOT_ORG + 1], tbl[T_FOOT_ORG + 2]));
+}

@@ -1,0 +1,865 @@
+// qa_sim.hip -- gfx950 kernels and the C ABI of include/qa_sim.h.
+//
+// Launch geometry: one quad (4 lanes) per env, 64-thread workgroups = 16 envs per wavefront, so
+// 4096 envs give 256 workgroups -- one per CU of the MI355X, each wave alone on its SIMD with the
+// full 512-VGPR budget (the substep keeps ~300 live values in registers).  The whole
+// LeggedRobot.step() is ONE launch: action-history roll, 4 x (PD torque -> dynamics -> contact
+// PGS -> integrate), termination, rewards, resets, observation assembly.  Per-env rows are
+// (N,k) row-major exactly as the reference's gym tensors; a quad reads its 12 joint values as 4 x
+// 12 B contiguous (a wave covers 768 contiguous bytes), so the AoS layout is already coalesced
+// for this lane mapping.  The 671-float observation rows are staged in LDS and written by the
+// whole wave, 256 B per instruction.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/qa_sim.h"
+#include "qa_go2_model.h"
+#include "qa_physics.h"
+
+#define QA_BLOCK 64
+#define ENVS_PER_BLOCK (QA_BLOCK / 4)
+
+static_assert(QA_NUM_LEG_PTS == QA_LEG_PTS && QA_NUM_BASE_PTS == QA_BASE_PTS, "model/table mismatch");
+
+__constant__ float c_tbl[QA_TBL_FLOATS];
+
+// ------------------------------------------------------------------ arena layout (ABI: enum order, 256 B aligned)
+struct Layout {
+    int64_t off[QA_T_COUNT];
+    int64_t shape[QA_T_COUNT][3];
+    int32_t ndim[QA_T_COUNT];
+    int32_t dtype[QA_T_COUNT];
+    int64_t total;
+};
+static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : 1; }
+static void make_layout(const qa_config *cfg, Layout *L) {
+    const int64_t N = cfg->num_envs, F = cfg->num_mocap_frames > 0 ? cfg->num_mocap_frames : 1;
+    struct Spec { int t, dt, nd; int64_t a, b, c; };
+    const Spec specs[] = {
+        {QA_T_ROOT_STATES, QA_F32, 2, N, 13, 1}, {QA_T_DOF_STATE, QA_F32, 3, N, 12, 2},
+        {QA_T_CONTACT_FORCES, QA_F32, 3, N, 19, 3}, {QA_T_RIGID_BODY_POS, QA_F32, 3, N, 19, 3},
+        {QA_T_TORQUES, QA_F32, 2, N, 12, 1}, {QA_T_TORQUES_ORG, QA_F32, 2, N, 12, 1},
+        {QA_T_ACTIONS, QA_F32, 2, N, 12, 1}, {QA_T_LAST_ACTIONS, QA_F32, 2, N, 12, 1},
+        {QA_T_LAST_DOF_VEL, QA_F32, 2, N, 12, 1}, {QA_T_LAST_TORQUES_ORG, QA_F32, 2, N, 12, 1},
+        {QA_T_LAST_ROOT_VEL, QA_F32, 2, N, 6, 1}, {QA_T_ACTION_HISTORY, QA_F32, 3, N, QA_ACTION_BUF_LEN, 12},
+        {QA_T_OBS_HISTORY, QA_F32, 3, N, QA_HISTORY_LEN, QA_NUM_PROP}, {QA_T_OBS, QA_F32, 2, N, QA_NUM_OBS, 1},
+        {QA_T_OBS_DISC, QA_F32, 2, N, QA_NUM_OBS_DISC, 1}, {QA_T_OBS_DISC_TERM, QA_F32, 2, N, QA_NUM_OBS_DISC, 1},
+        {QA_T_COMMANDS, QA_F32, 2, N, 5, 1}, {QA_T_LATENT_EPS, QA_F32, 2, N, 1, 1},
+        {QA_T_LATENT_C, QA_F32, 2, N, QA_NUM_GAITS, 1}, {QA_T_REW, QA_F32, 1, N, 1, 1},
+        {QA_T_RESET, QA_I64, 1, N, 1, 1}, {QA_T_TIME_OUT, QA_U8, 1, N, 1, 1},
+        {QA_T_EPISODE_LENGTH, QA_I64, 1, N, 1, 1}, {QA_T_EPISODE_SUMS, QA_F32, 2, QA_NUM_REWARDS, N, 1},
+        {QA_T_EPISODE_STATS, QA_F32, 2, 2, 16, 1}, {QA_T_LAST_CONTACTS, QA_U8, 2, N, 4, 1},
+        {QA_T_CONTACT_FILT, QA_U8, 2, N, 4, 1}, {QA_T_FEET_FORCE, QA_F32, 2, N, 4, 1},
+        {QA_T_BASE_LIN_VEL, QA_F32, 2, N, 3, 1}, {QA_T_BASE_ANG_VEL, QA_F32, 2, N, 3, 1},
+        {QA_T_PROJECTED_GRAVITY, QA_F32, 2, N, 3, 1}, {QA_T_RPY, QA_F32, 2, N, 3, 1},
+        {QA_T_MOTOR_STRENGTH, QA_F32, 3, 2, N, 12}, {QA_T_MASS_PARAMS, QA_F32, 2, N, 4, 1},
+        {QA_T_FRICTION, QA_F32, 1, N, 1, 1}, {QA_T_ENV_ORIGINS, QA_F32, 2, N, 3, 1},
+        {QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1}, {QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1},
+        {QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1},
+    };
+    static_assert(sizeof(specs) / sizeof(specs[0]) == QA_T_COUNT, "every tensor needs a spec");
+    memset(L, 0, sizeof(*L));
+    for (const Spec &s : specs) { L->dtype[s.t] = s.dt; L->ndim[s.t] = s.nd; L->shape[s.t][0] = s.a; L->shape[s.t][1] = s.b; L->shape[s.t][2] = s.c; }
+    int64_t off = 0;
+    for (int t = 0; t < QA_T_COUNT; ++t) {
+        off = (off + 255) & ~(int64_t)255;
+        L->off[t] = off;
+        off += L->shape[t][0] * L->shape[t][1] * L->shape[t][2] * dtype_size(L->dtype[t]);
+    }
+    L->total = (off + 255) & ~(int64_t)255;
+}
+
+// device pointers into the arena
+struct Ptrs {
+    float *root, *dof, *cforce, *rbpos, *torques, *torques_org, *actions, *last_actions, *last_dof_vel,
+        *last_torques_org, *last_root_vel, *action_hist, *obs_hist, *obs, *obs_disc, *obs_disc_term, *commands,
+        *latent_eps, *latent_c, *rew, *episode_sums, *episode_stats, *feet_force, *base_lin_vel, *base_ang_vel,
+        *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap;
+    int64_t *reset, *episode_length;
+    uint8_t *time_out, *last_contacts, *contact_filt;
+};
+
+struct qa_sim {
+    qa_config cfg;
+    Layout L;
+    char *arena;
+    Ptrs p;
+    int32_t mocap_first[QA_NUM_GAITS + 1];
+};
+
+struct MocapIdx { int32_t first[QA_NUM_GAITS + 1]; };
+
+static thread_local char g_err[512] = "";
+static int fail_hip(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return QA_E_DEVICE;
+}
+#define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail_hip(_e, #x); } while (0)
+
+// ------------------------------------------------------------------ shared device pieces
+__device__ __forceinline__ void stage_table(float *s_tbl) {
+    for (int i = threadIdx.x; i < QA_TBL_FLOATS; i += blockDim.x) s_tbl[i] = c_tbl[i];
+    __syncthreads();
+}
+
+// legged_robot.py:532-540 + :474-530, executed redundantly by the 4 lanes of the quad
+__device__ __forceinline__ void resample_commands(const qa_config &c, const float *prior, int env, int64_t step, int stream,
+                                                  float cmd[5], float &eps, int &gait) {
+    F4 u0 = rng4(c.seed, env, step, stream, 0), u1 = rng4(c.seed, env, step, stream, 1);
+    eps = u0.v[1] * 2.0f - 1.0f;
+    float z[5], zmax = -1e30f, sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { z[g] = prior[g] / c.latent_temperature; zmax = fmaxf(zmax, z[g]); }
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { z[g] = expf(z[g] - zmax); sum += z[g]; }
+    gait = 4; float acc = 0.f; bool found = false;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { acc += z[g] / sum; if (!found && u0.v[0] < acc) { gait = g; found = true; } }
+    float vxl = c.lin_vel_x[0][0], vxh = c.lin_vel_x[0][1], vyl = c.lin_vel_y[0][0], vyh = c.lin_vel_y[0][1], wl = c.ang_vel_yaw[0][0], wh = c.ang_vel_yaw[0][1];
+#pragma unroll
+    for (int g = 1; g < 5; ++g) if (gait == g) { vxl = c.lin_vel_x[g][0]; vxh = c.lin_vel_x[g][1]; vyl = c.lin_vel_y[g][0]; vyh = c.lin_vel_y[g][1]; wl = c.ang_vel_yaw[g][0]; wh = c.ang_vel_yaw[g][1]; }
+    float vx = (vxh - vxl) * u0.v[2] + vxl, vy = (vyh - vyl) * u0.v[3] + vyl, wz = (wh - wl) * u1.v[0] + wl;
+    bool jump = gait == QA_NUM_GAITS - 1;
+    float hj = ((c.jump_height[1] - c.jump_height[0]) * u1.v[1] + c.jump_height[0]) * (jump ? 1.0f : 0.0f);
+    float hl = ((c.locomotion_height[1] - c.locomotion_height[0]) * u1.v[2] + c.locomotion_height[0]) * (jump ? 0.0f : 1.0f);
+    cmd[0] = vx * (fabsf(vx) > c.lin_vel_x_clip ? 1.0f : 0.0f);
+    cmd[1] = vy * (fabsf(vy) > c.lin_vel_y_clip ? 1.0f : 0.0f);
+    cmd[2] = wz * (fabsf(wz) > c.ang_vel_yaw_clip ? 1.0f : 0.0f);
+    cmd[3] = hj; cmd[4] = hl;
+}
+
+// isaacgym torch_utils.quat_rotate / quat_rotate_inverse (sign = +1 / -1), xyzw
+__device__ __forceinline__ V3 quat_rot(float qx, float qy, float qz, float qw, V3 v, float sign) {
+    float s = 2.0f * qw * qw - 1.0f;
+    V3 qv = v3(qx, qy, qz);
+    V3 a = s * v, b = (2.0f * qw) * cross(qv, v), cc = (2.0f * dot(qv, v)) * qv;
+    return v3(a.x + sign * b.x + cc.x, a.y + sign * b.y + cc.y, a.z + sign * b.z + cc.z);
+}
+
+// reset of one env by its quad (legged_robot.py:178-240).  Updates st and the command/latent registers.
+__device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, const MocapIdx &mi, int env, int leg, int64_t step,
+                                          EnvState &st, float cmd[5], float &eps, int &gait) {
+    resample_commands(c, p.prior, env, step, RS_CMD_RESET, cmd, eps, gait);
+    const float ox = p.env_origins[3 * env], oy = p.env_origins[3 * env + 1], oz = p.env_origins[3 * env + 2];
+    if (c.reset_mode == 1 && mi.first[QA_NUM_GAITS] > 0) {
+        F4 u = rng4(c.seed, env, step, RS_RESET, 0);
+        int n = mi.first[gait + 1] - mi.first[gait];
+        int row = mi.first[gait] + (int)(u.v[0] * (float)n);
+        row = min(row, mi.first[gait + 1] - 1);
+        const float *f = p.mocap + (int64_t)row * QA_MOCAP_FRAME;
+        st.pos = v3(f[0] + ox, f[1] + oy, f[2] + oz);
+        st.qx = f[3]; st.qy = f[4]; st.qz = f[5]; st.qw = f[6];
+        st.vw = quat_rot(f[3], f[4], f[5], f[6], v3(f[19], f[20], f[21]), 1.0f);
+        st.ww = quat_rot(f[3], f[4], f[5], f[6], v3(f[22], f[23], f[24]), 1.0f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { st.q[k] = f[7 + 3 * leg + k]; st.qd[k] = f[25 + 3 * leg + k]; }
+    } else {
+        float u[20];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) { F4 t = rng4(c.seed, env, step, RS_RESET, b); u[4 * b] = t.v[0]; u[4 * b + 1] = t.v[1]; u[4 * b + 2] = t.v[2]; u[4 * b + 3] = t.v[3]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float uj = leg == 0 ? u[k] : (leg == 1 ? u[3 + k] : (leg == 2 ? u[6 + k] : u[9 + k]));
+            st.q[k] = c.default_dof_pos[k] * ((1.5f - 0.5f) * uj + 0.5f);    // default pose is the same for every leg
+            st.qd[k] = 0.f;
+        }
+        st.pos = v3(c.init_pos[0] + ox, c.init_pos[1] + oy, c.init_pos[2] + oz);
+        st.qx = 0; st.qy = 0; st.qz = 0; st.qw = 1;
+        st.vw = v3(u[12] - 0.5f, u[13] - 0.5f, u[14] - 0.5f);
+        st.ww = v3(u[15] - 0.5f, u[16] - 0.5f, u[17] - 0.5f);
+    }
+}
+
+// ------------------------------------------------------------------ the fused env step
+struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; };
+
+#define S_PROP 0        // 57  proprioception (noise-free)
+#define S_HEAD 57       // 90  obs[0:90] with noise
+#define S_TAIL 147      // 11  obs[660:671]
+#define S_DISC 158      // 49
+#define S_DISCT 207     // 49
+#define S_FLAGS 256     // [0] = refill history (episode length <= 1)
+#define S_ENV 260       // floats of LDS staging per env
+
+__global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
+    __shared__ float s_tbl[QA_TBL_FLOATS];
+    __shared__ float s_stage[ENVS_PER_BLOCK * S_ENV];
+    stage_table(s_tbl);
+    const qa_config &c = a.c;
+    const Ptrs &p = a.p;
+    const int N = c.num_envs;
+    const int tid = blockIdx.x * QA_BLOCK + threadIdx.x;
+    const int leg = threadIdx.x & 3;
+    const int env_raw = tid >> 2;
+    const bool valid = env_raw < N;
+    const int env = valid ? env_raw : N - 1;
+    const int le = threadIdx.x >> 2;                 // env slot inside the block
+    const float *tbl = s_tbl + leg * QA_LEG_TBL;
+    const float *btbl = s_tbl + 4 * QA_LEG_TBL;
+    const int64_t step = a.step;
+
+    if (blockIdx.x == 0 && threadIdx.x < 16) p.episode_stats[16 * ((step + 1) & 1) + threadIdx.x] = 0.f;   // next step's bin
+
+    // ---- action history roll, delay, clip (legged_robot.py:84-98); lane handles its 3 joints
+    float act[3], raw_act[3];
+    {
+        float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
+        float h[QA_ACTION_BUF_LEN][3];
+#pragma unroll
+        for (int r = 1; r < QA_ACTION_BUF_LEN; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) h[r - 1][k] = ah[12 * r + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { raw_act[k] = a.actions[(int64_t)env * 12 + 3 * leg + k]; h[QA_ACTION_BUF_LEN - 1][k] = raw_act[k]; }
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < QA_ACTION_BUF_LEN; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ah[12 * r + k] = h[r][k];
+        }
+        const float clipa = c.clip_actions / c.action_scale;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float src = a.delay == 0 ? h[QA_ACTION_BUF_LEN - 1][k] : h[QA_ACTION_BUF_LEN - 2][k];
+            if (a.delay > 1) {
+#pragma unroll
+                for (int r = 0; r < QA_ACTION_BUF_LEN - 2; ++r) if (QA_ACTION_BUF_LEN - 1 - r == a.delay) src = h[r][k];
+            }
+            act[k] = clampf(src, -clipa, clipa);
+        }
+    }
+
+    // ---- load state
+    EnvState st;
+    {
+        const float *r = p.root + (int64_t)env * 13;
+        st.pos = v3(r[0], r[1], r[2]); st.qx = r[3]; st.qy = r[4]; st.qz = r[5]; st.qw = r[6];
+        st.vw = v3(r[7], r[8], r[9]); st.ww = v3(r[10], r[11], r[12]);
+        const float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { st.q[k] = d[2 * k]; st.qd[k] = d[2 * k + 1]; }
+    }
+    float binert[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) binert[i] = p.base_inertia[(int64_t)env * 10 + i];
+    float sp[3], sd[3], q0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sp[k] = c.randomize_motor ? p.motor_strength[((int64_t)0 * N + env) * 12 + 3 * leg + k] : 1.0f;
+        sd[k] = c.randomize_motor ? p.motor_strength[((int64_t)1 * N + env) * 12 + 3 * leg + k] : 1.0f;
+        q0[k] = c.default_dof_pos[k];
+    }
+    const float fric = p.friction[env];
+    const float mu = 0.5f * (fric + c.ground_friction);
+    PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity;
+    P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
+
+    // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
+    float tau[3], tau_org[3];
+    ContactOut co;
+    for (int d = 0; d < c.decimation; ++d) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float as = act[k] * c.action_scale;
+            if (k == 0) as *= c.hip_scale_reduction;
+            float t = c.randomize_motor ? sp[k] * c.kp * (as + q0[k] - st.q[k]) - sd[k] * c.kd * st.qd[k]
+                                        : c.kp * (as + q0[k] - st.q[k]) - c.kd * st.qd[k];
+            tau_org[k] = t;
+            float lim = tbl[T_EFFORT + k];
+            tau[k] = clampf(t, -lim, lim);
+        }
+        phys_substep<true>(st, tbl, btbl, binert, tau, mu, leg, P, co);
+    }
+
+    // ---- refresh_*: body positions of the new state, contact forces per body
+    V3 org[4];
+    leg_origins(st.q, tbl, org);
+    M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
+    V3 foot_w = mul(R, org[3]) + st.pos;
+    V3 base_f, hu_f, hl_f;   // extra contacts that landed on base / Head_upper / Head_lower, summed over the quad
+    {
+        V3 z = v3(0, 0, 0);
+        V3 eb = co.extra_body == 0 ? co.extra_f : z, e1 = co.extra_body == 1 ? co.extra_f : z, e2 = co.extra_body == 2 ? co.extra_f : z;
+        base_f = v3(quad_sum(eb.x), quad_sum(eb.y), quad_sum(eb.z));
+        hu_f = v3(quad_sum(e1.x), quad_sum(e1.y), quad_sum(e1.z));
+        hl_f = v3(quad_sum(e2.x), quad_sum(e2.y), quad_sum(e2.z));
+    }
+    const int myb = 3 + 4 * leg;
+    V3 hip_f = co.extra_body == myb ? co.extra_f : v3(0, 0, 0);
+    V3 thigh_f = co.extra_body == myb + 1 ? co.extra_f : v3(0, 0, 0);
+    V3 calf_f = co.extra_body == myb + 2 ? co.extra_f : v3(0, 0, 0);
+    if (valid) {
+        float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
+        float *m = cf + 3 * myb;
+        m[0] = hip_f.x; m[1] = hip_f.y; m[2] = hip_f.z; m[3] = thigh_f.x; m[4] = thigh_f.y; m[5] = thigh_f.z;
+        m[6] = calf_f.x; m[7] = calf_f.y; m[8] = calf_f.z; m[9] = co.foot_f.x; m[10] = co.foot_f.y; m[11] = co.foot_f.z;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { V3 w = mul(R, org[k]) + st.pos; rb[3 * (myb + k)] = w.x; rb[3 * (myb + k) + 1] = w.y; rb[3 * (myb + k) + 2] = w.z; }
+        rb[3 * (myb + 3)] = foot_w.x; rb[3 * (myb + 3) + 1] = foot_w.y; rb[3 * (myb + 3) + 2] = foot_w.z;
+        if (leg == 0) {
+            cf[0] = base_f.x; cf[1] = base_f.y; cf[2] = base_f.z; cf[3] = hu_f.x; cf[4] = hu_f.y; cf[5] = hu_f.z; cf[6] = hl_f.x; cf[7] = hl_f.y; cf[8] = hl_f.z;
+            V3 h1 = mul(R, v3(0.285f, 0.f, 0.01f)) + st.pos, h2 = mul(R, v3(0.293f, 0.f, -0.06f)) + st.pos;
+            rb[0] = st.pos.x; rb[1] = st.pos.y; rb[2] = st.pos.z; rb[3] = h1.x; rb[4] = h1.y; rb[5] = h1.z; rb[6] = h2.x; rb[7] = h2.y; rb[8] = h2.z;
+        }
+    }
+
+    // =========================== post_physics_step (legged_robot.py:124-166) ===========================
+    int64_t epl = p.episode_length[env] + 1;
+    const int64_t common = step + 1;
+    V3 blv = quat_rot(st.qx, st.qy, st.qz, st.qw, st.vw, -1.f), bav = quat_rot(st.qx, st.qy, st.qz, st.qw, st.ww, -1.f);
+    V3 pg = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(0, 0, -1), -1.f);
+    float roll = atan2f(2.0f * (st.qw * st.qx + st.qy * st.qz), 1.0f - 2.0f * (st.qx * st.qx + st.qy * st.qy));
+    float pitch = asinf(clampf(2.0f * (st.qw * st.qy - st.qz * st.qx), -1.0f, 1.0f));
+    float yaw = atan2f(2.0f * (st.qw * st.qz + st.qx * st.qy), 1.0f - 2.0f * (st.qy * st.qy + st.qz * st.qz));
+    const float ffn = sqrtf(dot(co.foot_f, co.foot_f));
+    const uint8_t contact = ffn > 2.0f;
+    const uint8_t cfilt = contact | p.last_contacts[(int64_t)env * 4 + leg];
+
+    // commands / latents in registers (replicated)
+    float cmd[5], eps; int gait = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cmd[i] = p.commands[(int64_t)env * 5 + i];
+    eps = p.latent_eps[env];
+    {
+        float best = p.latent_c[(int64_t)env * 5];
+#pragma unroll
+        for (int g = 1; g < 5; ++g) { float v = p.latent_c[(int64_t)env * 5 + g]; if (v > best) { best = v; gait = g; } }
+    }
+    bool cmd_dirty = false;
+    if (__any(epl % c.resampling_steps == 0)) {
+        float c2[5], e2; int g2;
+        resample_commands(c, p.prior, env, step, RS_CMD, c2, e2, g2);
+        if (epl % c.resampling_steps == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cmd[i] = c2[i];
+            eps = e2; gait = g2; cmd_dirty = true;
+        }
+    }
+    if (c.push_robots && (common % c.push_interval == 0)) {   // uniform over the grid
+        F4 u = rng4(c.seed, env, step, RS_PUSH, 0);
+        st.vw.x = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[0] + -c.max_push_vel_xy;
+        st.vw.y = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[1] + -c.max_push_vel_xy;
+    }
+    // ---- check_termination :168-176
+    int term_c = (sqrtf(dot(hip_f, hip_f)) > 1.0f) ? 1 : 0;
+    term_c = quad_or(term_c) | (sqrtf(dot(base_f, base_f)) > 1.0f ? 1 : 0);
+    int timeout = (epl > c.max_episode_length) || (st.pos.z < -6.0f);
+    {
+        float chk = st.pos.x + st.pos.y + st.pos.z + st.qx + st.qy + st.qz + st.qw + st.vw.x + st.vw.y + st.vw.z + st.ww.x + st.ww.y + st.ww.z;
+        if (!isfinite(chk)) timeout = 1;          // build-added failure detection
+    }
+    const int reset = term_c | timeout;
+
+    // ---- rewards :242-259, alphabetical order
+    float term[QA_NUM_REWARDS];
+    {
+        const float dtp = c.sim_dt * (float)c.decimation;
+        float s_ar = 0, s_dt = 0, s_acc = 0, s_err = 0, s_hip = 0, s_pl = 0, s_vl = 0, s_tl = 0, s_tq = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+            float d;
+            d = p.last_actions[j] - act[k]; s_ar += d * d;
+            d = tau_org[k] - p.last_torques_org[j]; s_dt += d * d;
+            d = (p.last_dof_vel[j] - st.qd[k]) / dtp; s_acc += d * d;
+            d = st.q[k] - q0[k]; s_err += d * d; if (k == 0) s_hip += d * d;
+            float lo = tbl[T_LOWER + k], hi = tbl[T_UPPER + k], mid = (lo + hi) / 2, rng = hi - lo;
+            float slo = mid - 0.5f * rng * c.soft_dof_pos_limit, shi = mid + 0.5f * rng * c.soft_dof_pos_limit;
+            s_pl += -fminf(st.q[k] - slo, 0.f) + fmaxf(st.q[k] - shi, 0.f);
+            s_vl += clampf(fabsf(st.qd[k]) - tbl[T_VELLIM + k] * c.soft_dof_vel_limit, 0.f, 1.f);
+            s_tl += fmaxf(fabsf(tau_org[k]) - tbl[T_EFFORT + k] * c.soft_torque_limit, 0.f);
+            s_tq += tau_org[k] * tau_org[k];
+        }
+        float ncol = (sqrtf(dot(thigh_f, thigh_f)) > 0.1f ? 1.f : 0.f) + (sqrtf(dot(calf_f, calf_f)) > 0.1f ? 1.f : 0.f);
+        term[QA_R_ACTION_RATE] = quad_sum(s_ar); term[QA_R_COLLISION] = quad_sum(ncol); term[QA_R_DELTA_TORQUES] = quad_sum(s_dt);
+        term[QA_R_DOF_ACC] = quad_sum(s_acc); term[QA_R_DOF_ERROR] = quad_sum(s_err); term[QA_R_DOF_POS_LIMITS] = quad_sum(s_pl);
+        term[QA_R_DOF_VEL_LIMITS] = quad_sum(s_vl); term[QA_R_HIP_POS] = quad_sum(s_hip); term[QA_R_TORQUE_LIMITS] = quad_sum(s_tl);
+        term[QA_R_TORQUES] = quad_sum(s_tq);
+        const float root_h = st.pos.z;
+        float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
+        term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c.jump_height[0]) ? c.jump_goal : 0.f;
+        float el = sqrtf((cmd[4] - root_h) * (cmd[4] - root_h));
+        term[QA_R_LOCOMOTION_HEIGHT] = (cmd[3] > c.jump_height[0]) ? 0.f : expf(-10.0f * (el * el) / c.tracking_sigma);
+        float ea = (cmd[2] - bav.z) * (cmd[2] - bav.z);
+        term[QA_R_TRACKING_ANG_VEL] = expf(-ea / c.tracking_sigma);
+        float elv = (cmd[0] - blv.x) * (cmd[0] - blv.x) + (cmd[1] - blv.y) * (cmd[1] - blv.y);
+        term[QA_R_TRACKING_LIN_VEL] = expf(-elv / c.tracking_sigma);
+    }
+    float rew = 0.f;
+    float esum[QA_NUM_REWARDS];
+#pragma unroll
+    for (int r = 0; r < QA_NUM_REWARDS; ++r) {
+        esum[r] = p.episode_sums[(int64_t)r * N + env];
+        if (c.reward_scale_dt[r] != 0.0f) { float v = term[r] * c.reward_scale_dt[r]; rew += v; esum[r] += v; }
+    }
+    if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
+
+    // ---- terminal disc obs = previous OBS_DISC row; stage it
+    float *sst = s_stage + le * S_ENV;
+    for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
+
+    // ---- reset_idx :178-240
+    V3 lav = st.vw, law = st.ww;      // last_root_vel is taken after the reset (:160)
+    if (__any(reset)) {
+        if (reset) {
+#pragma unroll
+            for (int r = 0; r < QA_NUM_REWARDS; ++r) {
+                if ((r & 3) == leg && valid) atomicAdd(&p.episode_stats[16 * (step & 1) + r], esum[r]);
+                esum[r] = 0.f;
+            }
+            if (leg == 0 && valid) atomicAdd(&p.episode_stats[16 * (step & 1) + 14], 1.0f);
+            reset_env(c, p, a.mi, env, leg, step, st, cmd, eps, gait);
+            cmd_dirty = true;
+            epl = 0;
+            lav = st.vw; law = st.ww;
+        }
+    }
+    const bool refill = epl <= 1;
+
+    // ---- observations :261-331
+    // heading-inverse rotation of the (stale for reset envs) foot position, torch_jit_utils.py:23-76
+    V3 key;
+    {
+        V3 rd = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(1, 0, 0), 1.f);
+        float heading = atan2f(rd.y, rd.x);
+        float sh, ch; sincosf(-0.5f * heading, &sh, &ch);
+        float hn = rsqrtf(sh * sh + ch * ch);
+        V3 rel = foot_w - st.pos;
+        key = quat_rot(0.f, 0.f, sh * hn, ch * hn, rel, 1.f);
+    }
+    const float root_h = st.pos.z;
+    // proprioception (57): lanes write their own joints, lane 0 the shared entries
+    {
+        float *pr = sst + S_PROP;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = 3 * leg + k;
+            pr[5 + j] = (st.q[k] - q0[k]) * c.s_dof_pos;
+            pr[17 + j] = st.qd[k] * c.s_dof_vel;
+            pr[29 + j] = reset ? 0.0f : raw_act[k];      // reset_idx zeroes the action history first (:227)
+            pr[45 + j] = 0.0f * (k == 0 ? key.x : (k == 1 ? key.y : key.z));
+            sst[S_DISC + 9 + j] = (st.q[k] - q0[k]) * c.s_dof_pos;
+            sst[S_DISC + 21 + j] = st.qd[k] * c.s_dof_vel;
+            sst[S_DISC + 33 + j] = (k == 0 ? key.x : (k == 1 ? key.y : key.z)) * c.s_key_pos;
+        }
+        pr[41 + leg] = (cfilt ? 1.0f : 0.0f) - 0.5f;
+        sst[S_DISC + 45 + leg] = (cfilt ? 1.0f : 0.0f) * c.s_foot_contact;
+        if (leg == 0) {
+            pr[0] = roll; pr[1] = pitch; pr[2] = bav.x * c.s_ang_vel; pr[3] = bav.y * c.s_ang_vel; pr[4] = bav.z * c.s_ang_vel;
+            sst[S_DISC + 0] = roll; sst[S_DISC + 1] = pitch; sst[S_DISC + 2] = root_h;
+            sst[S_DISC + 3] = blv.x * c.s_lin_vel_dist; sst[S_DISC + 4] = blv.y * c.s_lin_vel_dist; sst[S_DISC + 5] = blv.z * c.s_lin_vel_dist;
+            sst[S_DISC + 6] = bav.x * c.s_ang_vel_dist; sst[S_DISC + 7] = bav.y * c.s_ang_vel_dist; sst[S_DISC + 8] = bav.z * c.s_ang_vel_dist;
+            sst[S_FLAGS] = refill ? 1.0f : 0.0f;
+            sst[S_FLAGS + 1] = reset ? 1.0f : 0.0f;
+            // tail: commands, eps, one-hot gait
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { sst[S_TAIL + i] = cmd[i]; sst[S_TAIL + 6 + i] = (gait == i) ? 1.0f : 0.0f; }
+            sst[S_TAIL + 5] = eps;
+        }
+    }
+    __syncthreads();
+    // head of the obs row: prop + explicit + latent, with noise on the 32 noisy entries
+    {
+        float *hd = sst + S_HEAD;
+        for (int i = leg; i < QA_NUM_PROP; i += 4) hd[i] = sst[S_PROP + i];
+        if (leg == 1) { hd[57] = root_h; hd[58] = blv.x * c.s_lin_vel; hd[59] = blv.y * c.s_lin_vel; hd[60] = blv.z * c.s_lin_vel; }
+        if (leg == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hd[61 + i] = p.mass_params[(int64_t)env * 4 + i];
+            hd[65] = fric;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { hd[66 + 3 * leg + k] = sp[k] - 1.0f; hd[78 + 3 * leg + k] = sd[k] - 1.0f; }
+    }
+    __syncthreads();
+    if (c.add_noise) {
+        // draw i (0..31) -> obs index i (<29) or 58 + (i - 29); lane handles blocks 2*leg, 2*leg+1
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            F4 u = rng4(c.seed, env, step, RS_NOISE, 2 * leg + b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int i = 4 * (2 * leg + b) + e;
+                int idx = i < 29 ? i : 58 + (i - 29);
+                float sc = idx < 2 ? c.noise_roll_pitch : (idx < 5 ? c.noise_ang_vel : (idx < 17 ? c.noise_dof_pos : (idx < 29 ? c.noise_dof_vel : c.noise_lin_vel)));
+                sst[S_HEAD + idx] += (2.0f * u.v[e] - 1.0f) * sc;
+            }
+        }
+    }
+    // ---- per-env scalars and small rows, written by the quad
+    if (valid) {
+        float *rt = p.root + (int64_t)env * 13;
+        if (leg == 0) {
+            rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
+            rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
+            p.rew[env] = rew; p.reset[env] = reset; p.time_out[env] = (uint8_t)timeout; p.episode_length[env] = epl;
+            float *o3;
+            o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
+            o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = bav.x; o3[1] = bav.y; o3[2] = bav.z;
+            o3 = p.proj_grav + (int64_t)env * 3; o3[0] = pg.x; o3[1] = pg.y; o3[2] = pg.z;
+            o3 = p.rpy + (int64_t)env * 3; o3[0] = roll; o3[1] = pitch; o3[2] = yaw;
+            float *lr = p.last_root_vel + (int64_t)env * 6; lr[0] = lav.x; lr[1] = lav.y; lr[2] = lav.z; lr[3] = law.x; lr[4] = law.y; lr[5] = law.z;
+            if (cmd_dirty) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { p.commands[(int64_t)env * 5 + i] = cmd[i]; p.latent_c[(int64_t)env * 5 + i] = (gait == i) ? 1.0f : 0.0f; }
+                p.latent_eps[env] = eps;
+            }
+        }
+        float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+            d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
+            p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k];
+            p.last_actions[j] = act[k]; p.last_dof_vel[j] = st.qd[k]; p.last_torques_org[j] = tau_org[k];   // :158-161
+        }
+        p.feet_force[(int64_t)env * 4 + leg] = ffn;
+        p.last_contacts[(int64_t)env * 4 + leg] = contact;
+        p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
+#pragma unroll
+        for (int r = 0; r < QA_NUM_REWARDS; ++r) if ((r & 3) == leg) p.episode_sums[(int64_t)r * N + env] = esum[r];
+        if (reset) {   // action history is zeroed by reset_idx (:227)
+            float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
+#pragma unroll
+            for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
+        }
+    }
+    __syncthreads();
+
+    // ---- wave-cooperative row writes: history shift, obs row, disc rows (256 B per instruction)
+    const float clipo = c.clip_obs;
+    for (int e = 0; e < ENVS_PER_BLOCK; ++e) {
+        const int ge = blockIdx.x * ENVS_PER_BLOCK + e;
+        if (ge >= N) break;
+        const float *ss = s_stage + e * S_ENV;
+        const bool rf = ss[S_FLAGS] != 0.f, rs = ss[S_FLAGS + 1] != 0.f;
+        float *hist = p.obs_hist + (int64_t)ge * 570, *ob = p.obs + (int64_t)ge * QA_NUM_OBS;
+        float hv[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            int i = threadIdx.x + QA_BLOCK * r;          // new history index
+            float v = 0.f;
+            if (i < 570) {
+                int slot = i / 57, k = i - slot * 57;
+                v = (rf || slot == 9) ? ss[S_PROP + k] : hist[i + 57];
+            }
+            hv[r] = clampf(v, -clipo, clipo);
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            int i = threadIdx.x + QA_BLOCK * r;
+            if (i < 570) { hist[i] = hv[r]; ob[90 + i] = hv[r]; }
+        }
+        for (int i = threadIdx.x; i < 90; i += QA_BLOCK) ob[i] = clampf(ss[S_HEAD + i], -clipo, clipo);
+        if (threadIdx.x < 11) ob[660 + threadIdx.x] = clampf(ss[S_TAIL + threadIdx.x], -clipo, clipo);
+        if (threadIdx.x < QA_NUM_OBS_DISC) {
+            float dv = ss[S_DISC + threadIdx.x];
+            p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = dv;
+            p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = rs ? ss[S_DISCT + threadIdx.x] : dv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ init / reset / simulate kernels
+__device__ __forceinline__ float normal_from(float u1, float u2) {
+    u1 = fmaxf(u1, 1e-7f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+struct BaseConst { float m, com[3], I[6]; };
+
+__global__ void qa_init_kernel(qa_config c, Ptrs p, BaseConst bc) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = c.num_envs;
+    if (e >= N) return;
+    const int ncols = (int)floor(sqrt((double)N));
+    p.env_origins[3 * e] = c.env_spacing * (float)(e / ncols); p.env_origins[3 * e + 1] = c.env_spacing * (float)(e % ncols); p.env_origins[3 * e + 2] = 0.f;
+    float fr = 1.0f;
+    if (c.randomize_friction) {
+        F4 u = rng4(c.seed, e, 0, RS_INIT_FRICTION, 0); int b = min((int)(u.v[0] * 64.0f), 63);
+        F4 ub = rng4(c.seed, b, 0, RS_INIT_BUCKET, 0);
+        fr = (c.friction_range[1] - c.friction_range[0]) * ub.v[0] + c.friction_range[0];
+    }
+    p.friction[e] = fr;
+    F4 um = rng4(c.seed, e, 0, RS_INIT_MASS, 0);
+    float mp[4];
+    mp[0] = c.randomize_base_mass ? (c.added_mass_range[1] - c.added_mass_range[0]) * um.v[0] + c.added_mass_range[0] : 0.f;
+    for (int i = 0; i < 3; ++i) mp[1 + i] = c.randomize_base_com ? (c.added_com_range[1] - c.added_com_range[0]) * um.v[1 + i] + c.added_com_range[0] : 0.f;
+    for (int i = 0; i < 4; ++i) p.mass_params[4 * e + i] = mp[i];
+    {
+        double m = (double)bc.m + mp[0], sc = m / (double)bc.m;
+        double cx = (double)bc.com[0] + mp[1], cy = (double)bc.com[1] + mp[2], cz = (double)bc.com[2] + mp[3];
+        double cc = cx * cx + cy * cy + cz * cz;
+        float *bi = p.base_inertia + 10 * e;
+        bi[0] = (float)m; bi[1] = (float)(m * cx); bi[2] = (float)(m * cy); bi[3] = (float)(m * cz);
+        bi[4] = (float)(bc.I[0] * sc + m * (cc - cx * cx)); bi[5] = (float)(bc.I[1] * sc + m * (cc - cy * cy)); bi[6] = (float)(bc.I[2] * sc + m * (cc - cz * cz));
+        bi[7] = (float)(bc.I[3] * sc - m * cx * cy); bi[8] = (float)(bc.I[4] * sc - m * cx * cz); bi[9] = (float)(bc.I[5] * sc - m * cy * cz);
+    }
+    float uu[48];
+    for (int b = 0; b < 12; ++b) { F4 t = rng4(c.seed, e, 0, RS_INIT_MOTOR, b); for (int i = 0; i < 4; ++i) uu[4 * b + i] = t.v[i]; }
+    for (int j = 0; j < 12; ++j) {
+        int pi = 2 * (j % 3); float s_p, s_d;
+        if (!c.randomize_motor) { s_p = s_d = 1.0f; }
+        else if (c.use_easi) { s_p = c.easi_mean[pi] + c.easi_var[pi] * normal_from(uu[j], uu[12 + j]); s_d = c.easi_mean[pi + 1] + c.easi_var[pi + 1] * normal_from(uu[24 + j], uu[36 + j]); }
+        else { s_p = (c.motor_strength_range[1] - c.motor_strength_range[0]) * uu[j] + c.motor_strength_range[0]; s_d = (c.motor_strength_range[1] - c.motor_strength_range[0]) * uu[12 + j] + c.motor_strength_range[0]; }
+        p.motor_strength[((int64_t)0 * N + e) * 12 + j] = s_p; p.motor_strength[((int64_t)1 * N + e) * 12 + j] = s_d;
+    }
+    p.reset[e] = 1;
+    p.root[13 * e + 6] = 1.0f;
+    if (e < QA_NUM_GAITS) p.prior[e] = 1.0f / QA_NUM_GAITS;
+}
+
+__global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptrs p, MocapIdx mi, int64_t step) {
+    const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, leg = threadIdx.x & 3, env = tid >> 2, N = c.num_envs;
+    if (blockIdx.x == 0 && threadIdx.x < 16) { p.episode_stats[16 * (step & 1) + threadIdx.x] = 0.f; }
+    if (env >= N) return;
+    EnvState st; float cmd[5], eps; int gait;
+    reset_env(c, p, mi, env, leg, step, st, cmd, eps, gait);
+    if (leg == 0) {
+        float *rt = p.root + (int64_t)env * 13;
+        rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
+        rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
+        for (int i = 0; i < 5; ++i) { p.commands[(int64_t)env * 5 + i] = cmd[i]; p.latent_c[(int64_t)env * 5 + i] = (gait == i) ? 1.0f : 0.0f; }
+        p.latent_eps[env] = eps;
+        p.episode_length[env] = 0; p.reset[env] = 1;
+        for (int i = 0; i < 6; ++i) p.last_root_vel[(int64_t)env * 6 + i] = 0.f;
+        for (int r = 0; r < QA_NUM_REWARDS; ++r) p.episode_sums[(int64_t)r * N + env] = 0.f;   // stats of a full reset are not reported
+    }
+    float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+    for (int k = 0; k < 3; ++k) {
+        const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+        d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
+        p.last_actions[j] = 0.f; p.last_dof_vel[j] = 0.f; p.last_torques_org[j] = 0.f;
+        for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) p.action_hist[(int64_t)env * 96 + 12 * r + 3 * leg + k] = 0.f;
+    }
+    for (int i = leg; i < 570; i += 4) p.obs_hist[(int64_t)env * 570 + i] = 0.f;
+}
+
+__global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques) {
+    __shared__ float s_tbl[QA_TBL_FLOATS];
+    stage_table(s_tbl);
+    const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, leg = threadIdx.x & 3, N = c.num_envs;
+    const bool valid = (tid >> 2) < N;
+    const int env = valid ? (tid >> 2) : N - 1;
+    const float *tbl = s_tbl + leg * QA_LEG_TBL, *btbl = s_tbl + 4 * QA_LEG_TBL;
+    EnvState st;
+    const float *r = p.root + (int64_t)env * 13;
+    st.pos = v3(r[0], r[1], r[2]); st.qx = r[3]; st.qy = r[4]; st.qz = r[5]; st.qw = r[6]; st.vw = v3(r[7], r[8], r[9]); st.ww = v3(r[10], r[11], r[12]);
+    const float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+    float tau[3], binert[10];
+    for (int k = 0; k < 3; ++k) { st.q[k] = d[2 * k]; st.qd[k] = d[2 * k + 1]; float lim = tbl[T_EFFORT + k]; tau[k] = clampf(torques[(int64_t)env * 12 + 3 * leg + k], -lim, lim); }
+    for (int i = 0; i < 10; ++i) binert[i] = p.base_inertia[(int64_t)env * 10 + i];
+    PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity; P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
+    ContactOut co;
+    phys_substep<true>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co);
+    V3 org[4]; leg_origins(st.q, tbl, org);
+    M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
+    V3 z = v3(0, 0, 0);
+    V3 eb = co.extra_body == 0 ? co.extra_f : z, e1 = co.extra_body == 1 ? co.extra_f : z, e2 = co.extra_body == 2 ? co.extra_f : z;
+    V3 base_f = v3(quad_sum(eb.x), quad_sum(eb.y), quad_sum(eb.z)), hu_f = v3(quad_sum(e1.x), quad_sum(e1.y), quad_sum(e1.z)), hl_f = v3(quad_sum(e2.x), quad_sum(e2.y), quad_sum(e2.z));
+    if (!valid) return;
+    const int myb = 3 + 4 * leg;
+    float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
+    for (int k = 0; k < 3; ++k) {
+        V3 f = co.extra_body == myb + k ? co.extra_f : z;
+        cf[3 * (myb + k)] = f.x; cf[3 * (myb + k) + 1] = f.y; cf[3 * (myb + k) + 2] = f.z;
+        V3 w = mul(R, org[k]) + st.pos; rb[3 * (myb + k)] = w.x; rb[3 * (myb + k) + 1] = w.y; rb[3 * (myb + k) + 2] = w.z;
+    }
+    cf[3 * (myb + 3)] = co.foot_f.x; cf[3 * (myb + 3) + 1] = co.foot_f.y; cf[3 * (myb + 3) + 2] = co.foot_f.z;
+    { V3 w = mul(R, org[3]) + st.pos; rb[3 * (myb + 3)] = w.x; rb[3 * (myb + 3) + 1] = w.y; rb[3 * (myb + 3) + 2] = w.z; }
+    float *dd = p.dof + (int64_t)env * 24 + 6 * leg;
+    for (int k = 0; k < 3; ++k) { dd[2 * k] = st.q[k]; dd[2 * k + 1] = st.qd[k]; }
+    if (leg == 0) {
+        float *rt = p.root + (int64_t)env * 13;
+        rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
+        rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
+        cf[0] = base_f.x; cf[1] = base_f.y; cf[2] = base_f.z; cf[3] = hu_f.x; cf[4] = hu_f.y; cf[5] = hu_f.z; cf[6] = hl_f.x; cf[7] = hl_f.y; cf[8] = hl_f.z;
+        V3 h1 = mul(R, v3(0.285f, 0.f, 0.01f)) + st.pos, h2 = mul(R, v3(0.293f, 0.f, -0.06f)) + st.pos;
+        rb[0] = st.pos.x; rb[1] = st.pos.y; rb[2] = st.pos.z; rb[3] = h1.x; rb[4] = h1.y; rb[5] = h1.z; rb[6] = h2.x; rb[7] = h2.y; rb[8] = h2.z;
+    }
+}
+
+// ------------------------------------------------------------------ fused GAE (rollout_storage.py:97-111)
+// pass 1: one lane per env, reverse scan over T (coalesced across envs); per-block partial sums in double.
+#define GAE_BLOCK 256
+#define GAE_MAX_BLOCKS 128          // scratch = 128 x 2 doubles = 2 KB + 2 doubles of result
+__global__ void __launch_bounds__(GAE_BLOCK) qa_gae_scan_kernel(const float *rewards, const float *values, const uint8_t *dones,
+                                                                  const float *last_values, float *returns, float *advantages,
+                                                                  int T, int N, float gamma, float lam, double *partial) {
+    double sum = 0.0, sq = 0.0;
+    for (int e = blockIdx.x * GAE_BLOCK + threadIdx.x; e < N; e += gridDim.x * GAE_BLOCK) {
+        float adv = 0.f, nv = last_values[e];
+        for (int t = T - 1; t >= 0; --t) {
+            const int64_t i = (int64_t)t * N + e;
+            const float v = values[i];
+            const float nt = 1.0f - (float)dones[i];
+            const float delta = rewards[i] + nt * gamma * nv - v;
+            adv = delta + nt * gamma * lam * adv;
+            const float ret = adv + v;
+            returns[i] = ret;
+            const float a = ret - v;
+            advantages[i] = a;
+            sum += (double)a; sq += (double)a * (double)a;
+            nv = v;
+        }
+    }
+    __shared__ double s_sum[GAE_BLOCK], s_sq[GAE_BLOCK];
+    s_sum[threadIdx.x] = sum; s_sq[threadIdx.x] = sq;
+    __syncthreads();
+    for (int s = GAE_BLOCK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { s_sum[threadIdx.x] += s_sum[threadIdx.x + s]; s_sq[threadIdx.x] += s_sq[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_sum[0]; partial[2 * blockIdx.x + 1] = s_sq[0]; }
+}
+// pass 2: every block re-reduces the <=128 partials in the same fixed order, then normalises its slice.
+__global__ void __launch_bounds__(GAE_BLOCK) qa_gae_norm_kernel(float *advantages, int64_t n, const double *partial, int nblocks) {
+    double sum = 0.0, sq = 0.0;
+    for (int b = 0; b < nblocks; ++b) { sum += partial[2 * b]; sq += partial[2 * b + 1]; }
+    const double mean = sum / (double)n;
+    double var = (sq - (double)n * mean * mean) / (double)(n - 1);
+    var = var > 0.0 ? var : 0.0;
+    const float fm = (float)mean, inv = (float)(1.0 / (sqrt(var) + 1e-8));
+    for (int64_t i = (int64_t)blockIdx.x * GAE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GAE_BLOCK)
+        advantages[i] = (advantages[i] - fm) * inv;
+}
+
+// ------------------------------------------------------------------ host side
+static void fill_ptrs(qa_sim *s) {
+    char *a = s->arena; const Layout &L = s->L; Ptrs &p = s->p;
+#define FP(name, T_) p.name = (float *)(a + L.off[T_])
+    FP(root, QA_T_ROOT_STATES); FP(dof, QA_T_DOF_STATE); FP(cforce, QA_T_CONTACT_FORCES); FP(rbpos, QA_T_RIGID_BODY_POS);
+    FP(torques, QA_T_TORQUES); FP(torques_org, QA_T_TORQUES_ORG); FP(actions, QA_T_ACTIONS); FP(last_actions, QA_T_LAST_ACTIONS);
+    FP(last_dof_vel, QA_T_LAST_DOF_VEL); FP(last_torques_org, QA_T_LAST_TORQUES_ORG); FP(last_root_vel, QA_T_LAST_ROOT_VEL);
+    FP(action_hist, QA_T_ACTION_HISTORY); FP(obs_hist, QA_T_OBS_HISTORY); FP(obs, QA_T_OBS); FP(obs_disc, QA_T_OBS_DISC);
+    FP(obs_disc_term, QA_T_OBS_DISC_TERM); FP(commands, QA_T_COMMANDS); FP(latent_eps, QA_T_LATENT_EPS); FP(latent_c, QA_T_LATENT_C);
+    FP(rew, QA_T_REW); FP(episode_sums, QA_T_EPISODE_SUMS); FP(episode_stats, QA_T_EPISODE_STATS); FP(feet_force, QA_T_FEET_FORCE);
+    FP(base_lin_vel, QA_T_BASE_LIN_VEL); FP(base_ang_vel, QA_T_BASE_ANG_VEL); FP(proj_grav, QA_T_PROJECTED_GRAVITY); FP(rpy, QA_T_RPY);
+    FP(motor_strength, QA_T_MOTOR_STRENGTH); FP(mass_params, QA_T_MASS_PARAMS); FP(friction, QA_T_FRICTION); FP(env_origins, QA_T_ENV_ORIGINS);
+    FP(base_inertia, QA_T_BASE_INERTIA); FP(prior, QA_T_PRIOR_PARAMETERS); FP(mocap, QA_T_MOCAP_FRAMES);
+#undef FP
+    p.reset = (int64_t *)(a + L.off[QA_T_RESET]); p.episode_length = (int64_t *)(a + L.off[QA_T_EPISODE_LENGTH]);
+    p.time_out = (uint8_t *)(a + L.off[QA_T_TIME_OUT]); p.last_contacts = (uint8_t *)(a + L.off[QA_T_LAST_CONTACTS]);
+    p.contact_filt = (uint8_t *)(a + L.off[QA_T_CONTACT_FILT]);
+}
+
+static void build_table(float *t) {
+    memset(t, 0, sizeof(float) * QA_TBL_FLOATS);
+    for (int l = 0; l < 4; ++l) {
+        float *g = t + l * QA_LEG_TBL;
+        for (int i = 0; i < 3; ++i) {
+            g[T_HIP_ORG + i] = QA_HIP_ORG[l][i]; g[T_THIGH_ORG + i] = QA_THIGH_ORG[l][i]; g[T_CALF_ORG + i] = QA_CALF_ORG[l][i]; g[T_FOOT_ORG + i] = QA_FOOT_ORG[l][i];
+            g[T_MASS + i] = QA_LINK_MASS[l][i]; g[T_LOWER + i] = QA_DOF_LOWER[l][i]; g[T_UPPER + i] = QA_DOF_UPPER[l][i];
+            g[T_EFFORT + i] = QA_DOF_EFFORT[l][i]; g[T_VELLIM + i] = QA_DOF_VELLIM[l][i];
+            for (int j = 0; j < 3; ++j) g[T_COM + 3 * i + j] = QA_LINK_COM[l][i][j];
+            for (int j = 0; j < 6; ++j) g[T_INERTIA + 6 * i + j] = QA_LINK_I[l][i][j];
+        }
+        for (int c = 0; c < QA_LEG_PTS; ++c) {
+            for (int j = 0; j < 3; ++j) g[T_POINTS + 4 * c + j] = QA_LEG_PT_POS[l][c][j];
+            g[T_POINTS + 4 * c + 3] = QA_LEG_PT_RAD[l][c];
+        }
+    }
+    float *b = t + 4 * QA_LEG_TBL;
+    for (int c = 0; c < QA_BASE_PTS; ++c) { for (int j = 0; j < 3; ++j) b[4 * c + j] = QA_BASE_PT_POS[c][j]; b[4 * c + 3] = QA_BASE_PT_RAD[c]; }
+}
+
+extern "C" {
+
+int qa_abi_version(void) { return QA_ABI_VERSION; }
+const char *qa_last_error(void) { return g_err; }
+
+int64_t qa_arena_bytes(const qa_config *cfg) {
+    if (!cfg || cfg->num_envs <= 0) return QA_E_ARG;
+    Layout L; make_layout(cfg, &L); return L.total;
+}
+
+int qa_tensor_info(const qa_config *cfg, int which, int64_t *off, int64_t shape[3], int32_t *ndim, int32_t *dtype) {
+    if (!cfg || which < 0 || which >= QA_T_COUNT || cfg->num_envs <= 0) return QA_E_ARG;
+    Layout L; make_layout(cfg, &L);
+    if (off) *off = L.off[which];
+    if (shape) for (int i = 0; i < 3; ++i) shape[i] = L.shape[which][i];
+    if (ndim) *ndim = L.ndim[which];
+    if (dtype) *dtype = L.dtype[which];
+    return QA_OK;
+}
+
+int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stream, qa_sim **out) {
+    if (!cfg || !arena || !out || cfg->num_envs <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: bad argument"); return QA_E_ARG; }
+    if (cfg->abi_version != QA_ABI_VERSION) return QA_E_VERSION;
+    if (cfg->terrain_type != 0 || cfg->decimation <= 0 || cfg->solver_iterations <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: unsupported config"); return QA_E_ARG; }
+    qa_sim *s = new qa_sim();
+    s->cfg = *cfg; make_layout(cfg, &s->L); s->arena = (char *)arena;
+    memset(s->mocap_first, 0, sizeof(s->mocap_first));
+    if (arena_bytes < s->L.total || ((uintptr_t)arena & 255)) { delete s; snprintf(g_err, sizeof(g_err), "qa_create: arena too small or misaligned"); return QA_E_ARENA; }
+    fill_ptrs(s);
+    hipStream_t st = (hipStream_t)stream;
+    float tbl[QA_TBL_FLOATS]; build_table(tbl);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_tbl), tbl, sizeof(tbl));
+    if (e != hipSuccess) { delete s; return fail_hip(e, "hipMemcpyToSymbol(c_tbl)"); }
+    e = hipMemsetAsync(arena, 0, (size_t)s->L.total, st);
+    if (e != hipSuccess) { delete s; return fail_hip(e, "hipMemsetAsync(arena)"); }
+    const int N = cfg->num_envs;
+    BaseConst bc; bc.m = QA_BASE_MASS; for (int i = 0; i < 3; ++i) bc.com[i] = QA_BASE_COM[i]; for (int i = 0; i < 6; ++i) bc.I[i] = QA_BASE_I[i];
+    hipLaunchKernelGGL(qa_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, s->cfg, s->p, bc);
+    e = hipGetLastError();
+    if (e != hipSuccess) { delete s; return fail_hip(e, "qa_init_kernel"); }
+    *out = s;
+    return QA_OK;
+}
+
+int qa_destroy(qa_sim *s) { delete s; return QA_OK; }
+
+int qa_set_mocap(qa_sim *s, const float *frames, int32_t nf, const int32_t first[QA_NUM_GAITS + 1], void *stream) {
+    if (!s || !frames || !first || nf <= 0 || nf > s->cfg.num_mocap_frames) return QA_E_ARG;
+    HIP_TRY(hipMemcpyAsync(s->p.mocap, frames, (size_t)nf * QA_MOCAP_FRAME * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    memcpy(s->mocap_first, first, sizeof(s->mocap_first));
+    return QA_OK;
+}
+
+static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; memcpy(m.first, s->mocap_first, sizeof(m.first)); return m; }
+
+int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t global_step, void *stream) {
+    if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step;
+    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    hipLaunchKernelGGL(qa_env_step_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+int qa_reset_all(qa_sim *s, int64_t global_step, void *stream) {
+    if (!s) return QA_E_ARG;
+    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    hipLaunchKernelGGL(qa_reset_all_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, mocap_idx(s), global_step);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+int qa_simulate(qa_sim *s, const float *torques, void *stream) {
+    if (!s || !torques) return QA_E_ARG;
+    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    hipLaunchKernelGGL(qa_simulate_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+int qa_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float *returns,
+           float *advantages, int32_t T, int32_t N, float gamma, float lam, int32_t normalize, void *scratch, void *stream) {
+    if (!rewards || !values || !dones || !last_values || !returns || !advantages || !scratch || T <= 0 || N <= 0) return QA_E_ARG;
+    int blocks = (N + GAE_BLOCK - 1) / GAE_BLOCK; if (blocks > GAE_MAX_BLOCKS) blocks = GAE_MAX_BLOCKS;
+    hipLaunchKernelGGL(qa_gae_scan_kernel, dim3(blocks), dim3(GAE_BLOCK), 0, (hipStream_t)stream, rewards, values, dones, last_values,
+                       returns, advantages, T, N, gamma, lam, (double *)scratch);
+    HIP_TRY(hipGetLastError());
+    if (normalize) {
+        const int64_t n = (int64_t)T * N;
+        int nb = (int)((n + GAE_BLOCK - 1) / GAE_BLOCK); if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(qa_gae_norm_kernel, dim3(nb), dim3(GAE_BLOCK), 0, (hipStream_t)stream, advantages, n, (const double *)scratch, blocks);
+        HIP_TRY(hipGetLastError());
+    }
+    return QA_OK;
+}
+
+}  // extern "C"

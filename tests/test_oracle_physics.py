@@ -169,3 +169,26 @@ def test_drop_does_not_tunnel_or_explode():
         assert np.isfinite(s.t["ROOT_STATES"]).all() and np.isfinite(s.t["OBS"]).all()
         zmin = min(zmin, s.t["RIGID_BODY_POS"][:, :, 2].min())
     assert zmin > -0.02
+
+
+def test_zero_gravity_kinetic_energy():
+    """No gravity, no contact, no torque: kinetic energy is conserved (checks the velocity-product
+    (Coriolis/centrifugal) terms of the bias); stop before any joint reaches a limit stop."""
+    qc = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, gravity_z=0.0)
+    s = OracleSim(qc)
+    rng = np.random.default_rng(5)
+    q, qd, ub = rand_state(rng)
+    quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+    s.t["ROOT_STATES"][0] = np.concatenate([[0, 0, 50.0], quat, rng.uniform(-1, 1, 3), rng.uniform(-2, 2, 3)])
+    s.t["DOF_STATE"][0, :, 0] = q
+    s.t["DOF_STATE"][0, :, 1] = qd * 0.3
+    E = []
+    for _ in range(41):
+        root = s.t["ROOT_STATES"][0].astype(np.float64)
+        R = quat_to_mat(root[3:7])
+        ubody = np.concatenate([R.T @ root[10:13], R.T @ root[7:10]])
+        com, vel, omg, mass, I = bodies(s.lib, s.t["DOF_STATE"][0, :, 0].copy(), s.t["DOF_STATE"][0, :, 1].copy(), ubody)
+        E.append(sum(0.5 * mass[b] * vel[b] @ vel[b] + 0.5 * omg[b] @ I[b] @ omg[b] for b in range(13)))
+        s.simulate(np.zeros((1, 12), np.float32))
+    E = np.array(E)
+    assert np.abs(E / E[0] - 1).max() < 2e-3
