@@ -85,7 +85,9 @@ enum qa_tensor {
     QA_T_EPISODE_LENGTH,      /* (N) int64                                                       */
     QA_T_EPISODE_SUMS,        /* (14,N)                                                          */
     QA_T_EPISODE_STATS,       /* (2,16)  [parity][0:14]=sum over resetting envs of episode sums,
-                                         [14]=number of resetting envs; parity = step & 1        */
+                                         [14]=number of resetting envs; parity = global_step & 1.
+                                         A step accumulates into its own bin and clears the bin
+                                         of the next step, so global_step must advance by 1.     */
     QA_T_LAST_CONTACTS,       /* (N,4) uint8                                                     */
     QA_T_CONTACT_FILT,        /* (N,4) uint8                                                     */
     QA_T_FEET_FORCE,          /* (N,4)  norm of foot contact forces                              */

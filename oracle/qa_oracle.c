@@ -528,7 +528,7 @@ static void resample_commands(qo_sim *s, int e, int64_t step, int stream) {
     cmd[3] = hj; cmd[4] = hl;
 }
 
-static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity) {
+static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity, int report) {
     /* legged_robot.py:178-240 */
     const qa_config *c = &s->cfg;
     int N = c->num_envs;
@@ -566,6 +566,7 @@ static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity) {
     memset(TP(s, QA_T_ACTION_HISTORY, float) + 96 * e, 0, 96 * 4);
     memset(TP(s, QA_T_OBS_HISTORY, float) + 570 * e, 0, 570 * 4);
     float *st = TP(s, QA_T_EPISODE_STATS, float) + 16 * stats_parity, *es = TP(s, QA_T_EPISODE_SUMS, float);
+    if (report)
 #pragma omp critical(qo_stats)
     {
         for (int r = 0; r < QA_NUM_REWARDS; ++r) st[r] += es[(int64_t)r * N + e];
@@ -725,7 +726,7 @@ static void post_physics(qo_sim *s, int e, int64_t step, float *term_disc_tmp) {
 
     /* terminal disc obs = obs_disc_buf of the previous compute_observations (:153-154) */
     memcpy(term_disc_tmp, TP(s, QA_T_OBS_DISC, float) + QA_NUM_OBS_DISC * e, QA_NUM_OBS_DISC * 4);
-    if (reset) reset_env(s, e, step, (int)(step & 1));
+    if (reset) reset_env(s, e, step, (int)(step & 1), 1);
     compute_observations(s, e, step);
     float *odt = TP(s, QA_T_OBS_DISC_TERM, float) + QA_NUM_OBS_DISC * e;
     memcpy(odt, reset ? term_disc_tmp : TP(s, QA_T_OBS_DISC, float) + QA_NUM_OBS_DISC * e, QA_NUM_OBS_DISC * 4);
@@ -838,7 +839,7 @@ int qo_reset_all(qo_sim *s, int64_t step, void *stream) {
     (void)stream;
     if (!s) return QA_E_ARG;
     memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * (step & 1), 0, 64);
-    for (int e = 0; e < s->cfg.num_envs; ++e) reset_env(s, e, step, (int)(step & 1));
+    for (int e = 0; e < s->cfg.num_envs; ++e) reset_env(s, e, step, (int)(step & 1), 0);   /* a full reset reports no episode stats */
     return QA_OK;
 }
 
@@ -846,7 +847,9 @@ int qo_env_step(qo_sim *s, const float *actions, int32_t delay_steps, int64_t st
     (void)stream;
     if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
     const qa_config *c = &s->cfg;
-    memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * (step & 1), 0, 64);
+    /* EPISODE_STATS[step & 1] accumulates this step; the bin of the NEXT step is cleared here (the HIP kernel
+     * cannot clear its own bin without a grid-wide barrier, so this is the ABI's rule for both sides) */
+    memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * ((step + 1) & 1), 0, 64);
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < c->num_envs; ++e) {
         /* legged_robot.py:84-98 */
