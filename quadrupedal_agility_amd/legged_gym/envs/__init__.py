@@ -1,0 +1,6 @@
+from quadrupedal_agility_amd.legged_gym.utils.task_registry import task_registry
+
+from .base.legged_robot import LeggedRobot
+from .go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+
+task_registry.register("go2_locomotion", LeggedRobot, Go2LocomotionCfg(), Go2LocomotionCfgAlgo())

@@ -1,0 +1,329 @@
+"""SSInfoGAIL: PPO (clipped surrogate + clipped value + privileged-latent regulariser + estimator)
+and the semi-supervised InfoGAIL discriminator update.
+
+Follows bbc/rsl_rl/algorithms/gail.py (act :176-197, process_env_step :199-212, update :231-326,
+update_actor_critic :328-413, update_ss_info_gail :415-541, update_dagger :543-575) term by term;
+constructor signature and attribute names are the reference's.  What is different is mechanical:
+  * no host sync inside the minibatch loops: loss scalars are accumulated on the device and read
+    once per iteration; the adaptive-KL learning rate lives in a device tensor (Adam capturable);
+    the discriminator normaliser's running moments stay on the device;
+  * `grad_sync` (set by the runner when world_size > 1) all-reduces one flat gradient bucket per
+    optimiser step and the scalars that must agree across ranks (KL mean) over RCCL;
+  * `amp_enabled=False` skips the discriminator update (BASELINE config 2; the reference has no
+    such switch).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
+
+
+class SSInfoGAIL:
+    def __init__(self, env, actor_critic, discriminator, estimator, estimator_paras, motion_loader, disc_normalizer,
+                 disc_history_len, disc_obs_len, num_disc_obs, obs_disc_weight_step, disc_loss_function=None,
+                 num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 surrogate_loss_coef=1.0, value_loss_coef=5.0, entropy_coef=0.0, bounds_loss_coef=10.0, disc_coef=5.0,
+                 disc_logit_reg=0.05, disc_grad_penalty=0.2, disc_weight_decay=0.0001, lr_ac=1e-3, lr_disc=1e-3,
+                 lr_q=1e-3, max_grad_norm=1.0, use_clipped_value_loss=False, schedule="fixed", desired_kl=0.01,
+                 device="cpu", disc_replay_buffer_size=100000, min_std=None, us_coef=1.0, ss_coef=4.0,
+                 prior_soft_coef=1e-3, info_max_coef=2.0, begin_rim=100, priv_reg_coef_schedual=[0, 0.1, 0, 1],
+                 priv_reg_coef_schedual_resume=[0, 0.1, 0, 1], amp_enabled=True):
+        self.device, self.env = device, env
+        self.desired_kl, self.schedule = desired_kl, schedule
+        self.lr_disc, self.lr_q, self.min_std = lr_disc, lr_q, min_std
+        self.dim_c = env.dim_c
+        self.disc_loss_function = disc_loss_function
+        self.disc_history_len, self.disc_obs_len = disc_history_len, disc_obs_len
+        self.num_disc_obs, self.obs_disc_weight_step = num_disc_obs, obs_disc_weight_step
+        self.amp_enabled = amp_enabled
+        self._on_gpu = torch.device(device).type == "cuda"
+
+        self.disc = discriminator.to(device)
+        self.disc_storage = ReplayBuffer(env.num_obs_disc, self.dim_c, disc_obs_len, disc_replay_buffer_size, device) if amp_enabled else None
+        self.motion_loader = motion_loader
+        self.disc_normalizer = disc_normalizer
+        c = env.cfg.env
+        self.num_prop, self.num_explicit, self.num_latent = c.num_prop, c.num_explicit, c.num_latent
+        self.num_hist, self.num_command = c.history_len, c.num_command
+
+        self.actor_critic = actor_critic.to(device)
+        self.transition = None
+        self.storage = None
+        self.estimator = estimator
+        # adaptive learning rate: a device tensor on GPU (no host round trip per minibatch), a float on CPU
+        self._lr_ac = torch.tensor(float(lr_ac), device=device) if self._on_gpu else float(lr_ac)
+        adam = dict(capturable=True) if self._on_gpu else {}
+        self.optim_ac = optim.Adam([{"params": self.actor_critic.parameters(), "name": "actor_critic"}], lr=self._lr_ac, **adam)
+        self.optim_hist_encoder = optim.Adam(self.actor_critic.history_encoder.parameters(), lr=estimator_paras["learning_rate"])
+        self.optim_estimator = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"])
+        self.priv_reg_coef_schedual = priv_reg_coef_schedual
+        self.priv_reg_counter = 0
+        self.train_with_estimated_explicit = estimator_paras["train_with_estimated_explicit"]
+
+        def groups(head, name):   # the reference's extra keys (weight_decay / momentum) are inert for Adam without weight_decay arg... keep them
+            return [{"params": self.disc.trunk.parameters(), "weight_decay": 1e-3, "momentum": 0.9, "name": "trunk"},
+                    {"params": head.parameters(), "weight_decay": 1e-3, "momentum": 0.9, "name": name}]
+        if disc_loss_function == "WassersteinLoss":
+            self.optim_d = optim.RMSprop(groups(self.disc.linear, "head"), lr=lr_disc)
+        else:
+            self.optim_d = optim.Adam(groups(self.disc.linear, "head"), lr=lr_disc)
+        self.optim_q_eps = optim.Adam(groups(self.disc.encoder_eps, "encoder_eps"), lr=lr_q)
+        self.optim_q_c = optim.Adam(groups(self.disc.classifier, "classifier"), lr=lr_q)
+
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.surrogate_loss_coef, self.value_loss_coef, self.entropy_coef = surrogate_loss_coef, value_loss_coef, entropy_coef
+        self.bounds_loss_coef, self.disc_coef, self.disc_logit_reg = bounds_loss_coef, disc_coef, disc_logit_reg
+        self.disc_grad_penalty, self.disc_weight_decay = disc_grad_penalty, disc_weight_decay
+        self.gamma, self.lam, self.max_grad_norm = gamma, lam, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.us_coef, self.ss_coef, self.prior_soft_coef = us_coef, ss_coef, prior_soft_coef
+        self.info_max_coef_on, self.info_max_coef = 0, info_max_coef
+        self.learning_steps, self.begin_rim = 0, begin_rim
+        self.grad_sync = None          # callable(list_of_params, extra_scalars) -> None, installed for world_size > 1
+
+    # ---- lr_ac is read by the logger and by checkpoints as a float
+    @property
+    def lr_ac(self):
+        return float(self._lr_ac)
+
+    @lr_ac.setter
+    def lr_ac(self, v):
+        if self._on_gpu:
+            self._lr_ac.fill_(float(v))
+        else:
+            self._lr_ac = float(v)
+            for g in self.optim_ac.param_groups:
+                g["lr"] = self._lr_ac
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, gae_fn=None):
+        self.transition = RolloutStorage.Transition()
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape,
+                                      self.device, gae_fn=gae_fn)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    # ------------------------------------------------------------------ rollout side
+    def act(self, obs, critic_obs, hist_encoding=False):
+        tr = self.transition
+        if self.train_with_estimated_explicit:
+            a, b = self.num_prop, self.num_prop + self.num_explicit
+            est = self.estimator(obs[:, :a])
+            obs_in = torch.cat([obs[:, :a], est, obs[:, b:]], dim=-1)     # estimated root height / base lin vel
+        else:
+            obs_in = obs
+        tr.actions = self.actor_critic.act(obs_in, hist_encoding).detach()
+        tr.values = self.actor_critic.evaluate(critic_obs).detach()
+        tr.actions_log_prob = self.actor_critic.get_actions_log_prob(tr.actions).detach()
+        tr.action_mean = self.actor_critic.action_mean.detach()
+        tr.action_sigma = self.actor_critic.action_std.detach()
+        tr.observations = obs
+        tr.critic_observations = critic_obs
+        return tr.actions
+
+    def process_env_step(self, rewards, dones, infos, obs_disc_history_buf):
+        tr = self.transition
+        tr.rewards = rewards.clone()
+        tr.dones = dones
+        if "time_outs" in infos:        # bootstrap on time-outs (gail.py:203-205)
+            tr.rewards += self.gamma * torch.squeeze(tr.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        if self.amp_enabled:
+            self.disc_storage.insert(obs_disc_history_buf.view(obs_disc_history_buf.shape[0], -1), self.env.latent_eps, self.env.latent_c)
+        self.storage.add_transitions(tr)
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs.detach()).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    # ------------------------------------------------------------------ update
+    def update(self):
+        self.learning_steps += 1
+        if self.learning_steps >= self.begin_rim:
+            self.info_max_coef_on = min(self.info_max_coef * (self.learning_steps - self.begin_rim) / 10000, self.info_max_coef)
+        dev = self.device
+        acc_ac = torch.zeros(6, device=dev)
+        for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            acc_ac += torch.stack(self.update_actor_critic(sample))
+        n_ac = self.num_learning_epochs * self.num_mini_batches
+        n_d = n_ac * 4
+        acc_d = torch.zeros(11, device=dev)
+        if self.amp_enabled:
+            mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
+            gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
+                       self.motion_loader.feed_forward_generator_lb(n_d, mb),
+                       self.motion_loader.feed_forward_generator_ulb(n_d, mb))
+            for s_pi, s_lb, s_ulb in gens:
+                acc_d += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
+        self.storage.clear()
+        self.priv_reg_counter += 1
+        out = torch.cat([acc_ac / n_ac, acc_d / n_d]).tolist()      # the one host read of the update
+        return tuple(out)
+
+    def _sync_grads(self, params):
+        if self.grad_sync is not None:
+            self.grad_sync(params)
+
+    def update_actor_critic(self, sample):
+        (obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _masks) = sample
+        ac = self.actor_critic
+        ac.act(obs.detach())
+        logp = ac.get_actions_log_prob(actions)
+        value = ac.evaluate(critic_obs.detach())
+        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+
+        a = self.num_prop; b = a + self.num_explicit; c = b + self.num_latent; d = c + self.num_hist * self.num_prop
+        obs_prop, obs_explicit, obs_latent, obs_hist = obs[:, :a], obs[:, a:b], obs[:, b:c], obs[:, c:d]
+        priv_latent = ac.infer_priv_latent(obs_latent)
+        with torch.no_grad():
+            hist_latent = ac.infer_hist_latent(obs_hist)
+        priv_reg_loss = (priv_latent - hist_latent).norm(p=2, dim=1).mean()
+        s0, s1, t0, t1 = self.priv_reg_coef_schedual
+        stage = min(max(self.priv_reg_counter - t0, 0) / t1, 1)
+        priv_reg_coef = stage * (s1 - s0) + s0
+
+        # estimator regression on the true privileged explicit state (gail.py:356-362)
+        estimator_loss = (self.estimator(obs_prop) - obs_explicit).pow(2).mean()
+        self.optim_estimator.zero_grad()
+        estimator_loss.backward()
+        self._sync_grads(list(self.estimator.parameters()))
+        nn.utils.clip_grad_norm_(self.estimator.parameters(), self.max_grad_norm)
+        self.optim_estimator.step()
+
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            with torch.no_grad():
+                kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) +
+                               (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
+                kl_mean = kl.mean()
+                if self.grad_sync is not None:
+                    kl_mean = self.grad_sync.mean_scalar(kl_mean)
+                self._apply_kl_schedule(kl_mean)
+
+        adv = torch.squeeze(advantages)
+        ratio = torch.exp(logp - torch.squeeze(old_logp))
+        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        if self.use_clipped_value_loss:
+            v_clip = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - returns).pow(2), (v_clip - returns).pow(2)).mean()
+        else:
+            value_loss = (returns - value).pow(2).mean()
+        b_loss = (torch.clamp(mu + 1.0, max=0.0) ** 2 + torch.clamp(mu - 1.0, min=0.0) ** 2).sum(dim=-1)
+        loss = (self.surrogate_loss_coef * surrogate_loss + self.value_loss_coef * value_loss +
+                self.bounds_loss_coef * b_loss.mean() - self.entropy_coef * entropy.mean() + priv_reg_coef * priv_reg_loss)
+        self.optim_ac.zero_grad()
+        loss.backward()
+        params = list(ac.parameters())
+        self._sync_grads(params)
+        nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+        self.optim_ac.step()
+        return (surrogate_loss.detach(), value_loss.detach(), b_loss.mean().detach(), entropy.mean().detach(),
+                priv_reg_loss.detach(), estimator_loss.detach())
+
+    def _apply_kl_schedule(self, kl_mean):
+        """lr /= 1.5 if KL > 2 target; lr *= 1.5 if 0 < KL < target/2; clamp [1e-5, 1e-2] (gail.py:367-379)."""
+        tgt = self.desired_kl
+        if self._on_gpu:
+            lr = self._lr_ac
+            down = torch.clamp(lr / 1.5, min=1e-5)
+            up = torch.clamp(lr * 1.5, max=1e-2)
+            new = torch.where(kl_mean > tgt * 2.0, down, torch.where((kl_mean < tgt / 2.0) & (kl_mean > 0.0), up, lr))
+            lr.copy_(new)
+        else:
+            k = float(kl_mean)
+            if k > tgt * 2.0:
+                self._lr_ac = max(1e-5, self._lr_ac / 1.5)
+            elif tgt / 2.0 > k > 0.0:
+                self._lr_ac = min(1e-2, self._lr_ac * 1.5)
+            for g in self.optim_ac.param_groups:
+                g["lr"] = self._lr_ac
+
+    def update_ss_info_gail(self, sample_disc_policy, sample_disc_expert_lb, sample_disc_expert_ulb):
+        policy_state, policy_eps, policy_c = sample_disc_policy
+        expert_lb, label_lb = sample_disc_expert_lb
+        expert_ulb = sample_disc_expert_ulb
+        w = self.env.task_obs_weight
+        prep = lambda x: self.disc.prepare_input(x.view(len(x), self.disc_obs_len, -1), w)
+        policy_state, expert_lb, expert_ulb = prep(policy_state), prep(expert_lb), prep(expert_ulb)
+        if self.disc_normalizer is not None:
+            with torch.no_grad():
+                policy_state = self.disc_normalizer.normalize_torch(policy_state, self.device)
+                expert_lb = self.disc_normalizer.normalize_torch(expert_lb, self.device)
+                expert_ulb = self.disc_normalizer.normalize_torch(expert_ulb, self.device)
+
+        _, _, pred_c_lb = self.disc(expert_lb)
+        ss_loss = F.cross_entropy(pred_c_lb, label_lb)          # CE on softmaxed probabilities, as the reference
+        policy_c_idx = torch.argmax(policy_c, dim=-1)
+        logits_pi, eps, pred_c = self.disc(policy_state)
+        logits_exp, _, pred_c_ulb = self.disc(expert_ulb)
+
+        pred_mean = torch.mean(pred_c_ulb, dim=0).detach()
+        if self.grad_sync is not None:
+            pred_mean = self.grad_sync.mean_vector(pred_mean)
+        self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
+        info_max_loss = torch.mean(-torch.sum(pred_c_ulb * torch.log(pred_c_ulb + 1e-20), dim=-1))
+
+        if self.disc_loss_function == "BCEWithLogitsLoss":
+            l_exp = F.binary_cross_entropy_with_logits(logits_exp, torch.ones_like(logits_exp))
+            l_pi = F.binary_cross_entropy_with_logits(logits_pi, torch.zeros_like(logits_pi))
+        elif self.disc_loss_function == "MSELoss":
+            l_exp = F.mse_loss(logits_exp, torch.ones_like(logits_exp))
+            l_pi = F.mse_loss(logits_pi, -torch.ones_like(logits_pi))
+        elif self.disc_loss_function == "WassersteinLoss":
+            l_exp, l_pi = -logits_exp.mean(), logits_pi.mean()
+        else:
+            raise ValueError("Unexpected loss function specified")
+        disc_loss = 0.5 * (l_pi + l_exp)
+        us_loss = F.l1_loss(eps, policy_eps)
+        disc_logit_loss = torch.sum(torch.square(self.disc.get_disc_logit_weights()))
+        # gradient penalty on expert samples (double backward)
+        x = expert_ulb.clone().requires_grad_(True)
+        out = self.disc.linear(self.disc.trunk(x))
+        g = torch.autograd.grad(out, x, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True, only_inputs=True)[0]
+        grad_pen_loss = torch.mean(torch.sum(torch.square(g), dim=-1))
+        disc_weight_decay = torch.sum(torch.square(torch.cat(self.disc.get_disc_weights(), dim=-1)))
+        loss = (self.ss_coef * ss_loss + self.info_max_coef_on * info_max_loss + self.disc_coef * disc_loss +
+                self.us_coef * us_loss + self.disc_grad_penalty * grad_pen_loss + self.disc_logit_reg * disc_logit_loss +
+                self.disc_weight_decay * disc_weight_decay)
+        for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
+            o.zero_grad()
+        loss.backward()
+        self._sync_grads(list(self.disc.parameters()))
+        for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
+            o.step()
+        if not self.actor_critic.fixed_std and self.min_std is not None:
+            self.actor_critic.std.data = self.actor_critic.std.data.clamp(min=self.min_std)
+        if self.disc_normalizer is not None:
+            self.disc_normalizer.update_torch([policy_state, expert_lb, expert_ulb])
+        with torch.no_grad():
+            acc_lb = (torch.argmax(pred_c_lb, dim=-1) == label_lb).float().mean()
+            acc_pi = (logits_pi < 0).float().mean()
+            acc_exp = (logits_exp > 0).float().mean()
+            acc_ulb = (torch.argmax(pred_c, dim=-1) == policy_c_idx).float().mean()
+        return (ss_loss.detach(), info_max_loss.detach(), disc_loss.detach(), us_loss.detach(), grad_pen_loss.detach(),
+                disc_logit_loss.detach(), disc_weight_decay.detach(), acc_lb, acc_pi, acc_exp, acc_ulb)
+
+    def update_dagger(self):
+        """History-encoder regression onto the privileged latent, every dagger_update_freq iterations (gail.py:543-575)."""
+        ac = self.actor_critic
+        a = self.num_prop + self.num_explicit; b = a + self.num_latent; c = b + self.num_hist * self.num_prop
+        total = torch.zeros((), device=self.device)
+        for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            obs = sample[0]
+            with torch.no_grad():
+                target = ac.infer_priv_latent(obs[:, a:b])
+            loss = (target - ac.infer_hist_latent(obs[:, b:c])).norm(p=2, dim=1).mean()
+            self.optim_hist_encoder.zero_grad()
+            loss.backward()
+            params = list(ac.history_encoder.parameters())
+            self._sync_grads(params)
+            nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+            self.optim_hist_encoder.step()
+            total += loss.detach()
+        self.storage.clear()
+        self.priv_reg_counter += 1
+        return float(total) / (self.num_learning_epochs * self.num_mini_batches)

@@ -1,0 +1,144 @@
+"""Actor-critic with privileged-latent encoder and 1-D-conv history encoder.
+
+Same parameter names/shapes as bbc/rsl_rl/modules/actor_critic.py:9-225 (that is the model.pt
+contract): std, priv_encoder.{0,2}, history_encoder.{encoder.0, conv_layers.{0,2},
+linear_output.0}, actor_trunk.{0,2,4}, actor_head, critic_trunk.{0,2,4}, critic_head.
+Sub-modules are created in the reference's order so a given torch seed yields the same init.
+"""
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+_ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU,
+                "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+
+
+def get_activation(act_name):
+    if act_name not in _ACTIVATIONS:
+        print("invalid activation function!")
+        return None
+    return _ACTIVATIONS[act_name]()
+
+
+def _mlp(sizes, act, last_act):
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i < len(sizes) - 2 or last_act:
+            layers.append(act)
+    return nn.Sequential(*layers)
+
+
+class StateHistoryEncoder(nn.Module):
+    """(B, T, n_prop) -> latent: per-frame linear to 30 channels, two temporal convs, linear out."""
+    _CONV = {10: [(4, 2), (2, 1)], 20: [(6, 2), (4, 2)], 50: [(8, 4), (5, 1), (5, 1)]}
+
+    def __init__(self, activation_fn, input_size, tsteps, output_size, tanh_encoder_output=False):
+        super().__init__()
+        if tsteps not in self._CONV:
+            raise ValueError("tsteps must be 10, 20 or 50")
+        self.activation_fn = activation_fn
+        self.tsteps = tsteps
+        ch = 10
+        self.encoder = nn.Sequential(nn.Linear(input_size, 3 * ch), activation_fn)
+        chans = [3 * ch, 2 * ch, ch, ch]
+        convs = []
+        for i, (k, s) in enumerate(self._CONV[tsteps]):
+            convs += [nn.Conv1d(chans[i], chans[i + 1], kernel_size=k, stride=s), activation_fn]
+        convs.append(nn.Flatten())
+        self.conv_layers = nn.Sequential(*convs)
+        self.linear_output = nn.Sequential(nn.Linear(ch * 3, output_size), activation_fn)
+
+    def forward(self, obs):
+        b = obs.shape[0]
+        x = self.encoder(obs.reshape(b * self.tsteps, -1))
+        x = self.conv_layers(x.reshape(b, self.tsteps, -1).permute(0, 2, 1))
+        return self.linear_output(x)
+
+
+class ActorCritic(nn.Module):
+    is_recurrent = False
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, num_prop, num_hist, num_explicit, num_latent,
+                 num_command, actor_hidden_dims=[256, 256, 256], critic_hidden_dims=[256, 256, 256],
+                 priv_encoder_dims=[256, 256], activation="elu", init_noise_std=1.0, fixed_std=False,
+                 train_with_estimated_latent=False, **kwargs):
+        if kwargs:
+            print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs.keys())))
+        super().__init__()
+        act = get_activation(activation)
+        self.num_actor_obs, self.num_critic_obs = num_actor_obs, num_critic_obs
+        self.train_with_estimated_latent = train_with_estimated_latent
+        self.num_prop, self.num_explicit, self.num_latent = num_prop, num_explicit, num_latent
+        self.num_hist, self.num_command = num_hist, num_command
+        # slices of the observation row (legged_robot.py:261-331)
+        a, b, c = num_prop, num_prop + num_explicit, num_prop + num_explicit + num_latent
+        d = c + num_hist * num_prop
+        self._sl = (slice(0, a), slice(a, b), slice(b, c), slice(c, d), slice(d, None))
+
+        if len(priv_encoder_dims) > 0:
+            self.priv_encoder = _mlp([num_latent] + list(priv_encoder_dims) + [num_latent], act, last_act=True)
+        else:
+            self.priv_encoder = nn.Identity()
+        self.history_encoder = StateHistoryEncoder(act, num_prop, num_hist, num_latent)
+        self.actor_trunk = _mlp([num_actor_obs] + list(actor_hidden_dims), act, last_act=True)
+        self.actor_head = nn.Linear(actor_hidden_dims[-1], num_actions)
+        self.critic_trunk = _mlp([num_critic_obs] + list(critic_hidden_dims), act, last_act=True)
+        self.critic_head = nn.Linear(critic_hidden_dims[-1], 1)
+        for m in self.actor_trunk.modules():
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+        self.fixed_std = fixed_std
+        std = init_noise_std * torch.ones(num_actions)
+        self.std = std.clone() if fixed_std else nn.Parameter(std)
+        self.distribution = None
+        Normal.set_default_validate_args = False
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def infer_priv_latent(self, obs):
+        return self.priv_encoder(obs)
+
+    def infer_hist_latent(self, obs):
+        return self.history_encoder(obs.view(-1, self.num_hist, self.num_prop))
+
+    def _actor_mean(self, observations, hist_encoding):
+        prop, explicit, latent, hist, command = (observations[:, s] for s in self._sl)
+        if self.train_with_estimated_latent:
+            latent = self.infer_hist_latent(hist) if hist_encoding else self.infer_priv_latent(latent)
+        x = torch.cat([prop, explicit, latent, command], dim=-1)
+        return self.actor_head(self.actor_trunk(x))
+
+    def update_distribution(self, observations, hist_encoding: bool):
+        mean = self._actor_mean(observations, hist_encoding)
+        self.distribution = Normal(mean, mean * 0.0 + self.std.to(mean.device))
+
+    def act(self, observations, hist_encoding=False, **kwargs):
+        self.update_distribution(observations, hist_encoding)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_inference(self, observations, hist_encoding=True):
+        return self._actor_mean(observations, hist_encoding)
+
+    def evaluate(self, critic_observations, **kwargs):
+        return self.critic_head(self.critic_trunk(critic_observations))

@@ -1,0 +1,314 @@
+"""OnPolicyRunner: rollout (24 env steps) -> GAE -> PPO / discriminator update -> log / checkpoint.
+
+Public surface and model.pt layout of bbc/rsl_rl/runners/on_policy_runner.py (ctor :20-118,
+learn :120-236, log :238-304, save/load :306-339).  The rollout loop is free of host syncs: resets
+are handled with masks on the device (the reference calls nonzero()/tolist() every step, :183-206)
+and finished-episode statistics are gathered with one device->host copy per iteration.  With
+torch.distributed initialised (one process per GPU, RCCL) every rank owns num_envs envs and the
+gradient buckets / normalisation statistics are all-reduced.
+"""
+import json
+import os
+import statistics
+import time
+from collections import deque
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from quadrupedal_agility_amd.legged_gym.utils.torch_jit_utils import compute_flat_key_pos
+from quadrupedal_agility_amd.rsl_rl.algorithms import SSInfoGAIL  # noqa: F401  (resolved by name from the cfg)
+from quadrupedal_agility_amd.rsl_rl.algorithms.discriminator import Discriminator
+from quadrupedal_agility_amd.rsl_rl.datasets.motion_loader import MotionLoader
+from quadrupedal_agility_amd.rsl_rl.modules import ActorCritic, Estimator  # noqa: F401
+from quadrupedal_agility_amd.rsl_rl.utils.utils import Normalizer, TorchNormalizer
+
+
+class _ScalarLog:
+    """SummaryWriter stand-in when tensorboard is not installed: JSON lines with the same tags."""
+
+    def __init__(self, log_dir, flush_secs=10):
+        os.makedirs(log_dir, exist_ok=True)
+        self._fh = open(os.path.join(log_dir, "scalars.jsonl"), "a")
+
+    def add_scalar(self, tag, value, step):
+        self._fh.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    def flush(self):
+        self._fh.flush()
+
+
+def _make_writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir, flush_secs=10)
+    except Exception:
+        return _ScalarLog(log_dir)
+
+
+class GradSync:
+    """One flat all-reduce per optimiser step over RCCL/xGMI (gloo in the CPU tests).  The buckets are small
+    (actor-critic 2.9 MB, discriminator 0.7 MB, estimator 64 KB), i.e. latency-bound: a single flat buffer keeps it
+    to one collective launch per step."""
+
+    def __init__(self):
+        self.world = dist.get_world_size()
+
+    def __call__(self, params):
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat)
+        flat.div_(self.world)
+        for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(s)
+
+    def mean_scalar(self, x):
+        x = x.clone()
+        dist.all_reduce(x)
+        return x / self.world
+
+    mean_vector = mean_scalar
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cpu"):
+        self.device, self.env = device, env
+        self.cfg, self.alg_cfg = train_cfg["runner"], dict(train_cfg["algorithm"])
+        self.policy_cfg, self.estimator_cfg = train_cfg["policy"], train_cfg["estimator"]
+        self.disc_loss_function = self.alg_cfg["disc_loss_function"]
+        r = self.cfg
+        self.reward_i_coef, self.reward_us_coef = r["reward_i_coef"], r["reward_us_coef"]
+        self.reward_ss_coef, self.reward_t_coef = r["reward_ss_coef"], r["reward_t_coef"]
+        ecfg = env.cfg.env
+        self.disc_history_len, self.disc_obs_len = ecfg.disc_history_len, ecfg.disc_obs_len
+        self.obs_disc_weight_step = ecfg.obs_disc_weight_step
+        self.amp_enabled = bool(r.get("amp_enabled", True))
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.distributed else 0
+
+        num_prop, num_hist = ecfg.num_prop, ecfg.history_len
+        num_actor_obs = env.num_obs
+        num_critic_obs = env.num_obs + num_hist * num_prop
+        num_disc_obs = env.num_obs_disc
+        actor_critic = eval(r["policy_class_name"])(num_actor_obs, num_critic_obs, env.num_actions, num_prop, num_hist,
+                                                    ecfg.num_explicit, ecfg.num_latent, ecfg.num_command,
+                                                    **self.policy_cfg).to(device)
+        estimator = Estimator(input_dim=num_prop, output_dim=ecfg.num_explicit, hidden_dims=self.estimator_cfg["hidden_dims"]).to(device)
+        motion_loader = None
+        if self.amp_enabled:
+            motion_loader = MotionLoader(device, time_between_frames=env.dt, motion_files_lb=r["motion_files_lb"],
+                                         motion_files_ulb=r["motion_files_ulb"], mocap_category=env.mocap_category,
+                                         num_preload_transitions=r["num_preload_transitions"],
+                                         compute_flat_key_pos=compute_flat_key_pos, default_dof_pos=env.default_dof_pos,
+                                         obs_scales=env.obs_scales, num_disc_obs=num_disc_obs, disc_obs_len=self.disc_obs_len,
+                                         obs_disc_weight_step=self.obs_disc_weight_step,
+                                         frame_duration_scale=ecfg.frame_duration_scale)
+        disc_normalizer = TorchNormalizer(num_disc_obs * self.disc_obs_len, device)
+        reward_i_normalizer = Normalizer(1) if self.disc_loss_function == "WassersteinLoss" else None
+        discriminator = Discriminator(env, num_disc_obs * self.disc_obs_len, num_disc_obs, len(env.mocap_category), env.dt,
+                                      self.disc_loss_function, reward_i_normalizer, self.reward_i_coef, self.reward_us_coef,
+                                      self.reward_ss_coef, self.reward_t_coef, self.disc_history_len, self.disc_obs_len,
+                                      self.obs_disc_weight_step, r["disc_hidden_units"], device).to(device)
+        min_std = (torch.tensor(r["min_normalized_std"], device=device) *
+                   torch.abs(env.dof_pos_limits[:, 1] - env.dof_pos_limits[:, 0]).to(device))
+        alg_class = eval(r["algorithm_class_name"])
+        self.alg = alg_class(env, actor_critic, discriminator, estimator, self.estimator_cfg, motion_loader, disc_normalizer,
+                             self.disc_history_len, self.disc_obs_len, num_disc_obs, self.obs_disc_weight_step,
+                             device=device, min_std=min_std, amp_enabled=self.amp_enabled, **self.alg_cfg)
+        self.num_steps_per_env, self.save_interval = r["num_steps_per_env"], r["save_interval"]
+        self.dagger_update_freq = r["dagger_update_freq"]
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [num_actor_obs + num_hist * num_prop],
+                              [env.num_privileged_obs + num_hist * num_prop], [env.num_actions], gae_fn=self._make_gae())
+        if self.distributed:
+            self.alg.grad_sync = GradSync()
+            for m in (actor_critic, estimator, discriminator):      # every rank starts from rank 0's weights
+                for p in m.parameters():
+                    dist.broadcast(p.data, src=0)
+        self.log_dir, self.writer = log_dir, None
+        self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0, 0
+        self.last_perf = {}
+        env.sync_reset_ids = False
+        env.reset()
+
+    # ------------------------------------------------------------------ GAE
+    def _make_gae(self):
+        sim = getattr(self.env, "sim", None)
+        if sim is None or not hasattr(sim, "gae"):
+            return None
+
+        def gae(rewards, values, dones, last_values, returns, advantages, gamma, lam):
+            T, N = rewards.shape[0], rewards.shape[1]
+            v = lambda x: x.view(T, N)
+            if not self.distributed:
+                sim.gae(v(rewards), v(values), v(dones), last_values, v(returns), v(advantages), gamma, lam, normalize=True)
+                return
+            # data parallel: the reference normalises over ALL T*N samples, so the moments are all-reduced
+            sim.gae(v(rewards), v(values), v(dones), last_values, v(returns), v(advantages), gamma, lam, normalize=False)
+            a64 = advantages.to(torch.float64)
+            s = torch.stack([a64.sum(), (a64 * a64).sum(), torch.tensor(float(a64.numel()), dtype=torch.float64, device=a64.device)])
+            dist.all_reduce(s)
+            mean = s[0] / s[2]
+            std = torch.sqrt(torch.clamp((s[1] - s[2] * mean * mean) / (s[2] - 1), min=0.0))
+            advantages.sub_(mean.float()).div_(std.float() + 1e-8)
+        return gae
+
+    # ------------------------------------------------------------------ learn
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        env, alg, dev = self.env, self.alg, self.device
+        if self.log_dir is not None and self.writer is None and self.rank == 0:
+            self.writer = _make_writer(self.log_dir)
+        if init_at_random_ep_len:
+            env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        obs = env.get_observations().to(dev).clone()
+        disc_obs = env.get_disc_observations().to(dev)
+        obs_disc_history_buf = torch.stack([disc_obs] * self.disc_obs_len, dim=1)
+        alg.actor_critic.train()
+        alg.disc.train()
+        N, T = env.num_envs, self.num_steps_per_env
+        logging = self.log_dir is not None
+        ep_infos = []
+        buffers = {k: deque(maxlen=100) for k in ("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")}
+        cur = torch.zeros(6, N, device=dev)                 # running sums: total, i, us, ss, t, length
+        fin_vals = torch.zeros(T, 6, N, device=dev)
+        fin_mask = torch.zeros(T, N, dtype=torch.bool, device=dev)
+        zeros_n = torch.zeros(N, device=dev)
+        mean_hist_latent_loss = 0.0
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            self._sync()
+            start = time.time()
+            hist_encoding = it % self.dagger_update_freq == 0
+            with torch.inference_mode():
+                for i in range(T):
+                    actions = alg.act(obs, obs, hist_encoding)
+                    next_obs, _, rewards, dones, infos, _, _ = env.step(actions)
+                    done_mask = dones > 0
+                    if self.amp_enabled:
+                        # the frame pair seen by the discriminator ends with the TERMINAL frame for envs that reset (:168-172)
+                        obs_disc_history_buf = torch.cat([obs_disc_history_buf[:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
+                        rewards, r_i, r_us, r_ss, r_t = alg.disc.predict_disc_reward(
+                            rewards.unsqueeze(1), obs, obs_disc_history_buf, normalizer=alg.disc_normalizer)
+                    else:
+                        r_t = rewards
+                        rewards = self.reward_t_coef * rewards
+                        r_i = r_us = r_ss = zeros_n
+                    alg.process_env_step(rewards, dones.to(torch.uint8), infos, obs_disc_history_buf)
+                    obs = next_obs.clone()
+                    if self.amp_enabled:
+                        fresh = torch.stack([env.get_disc_observations()] * self.disc_obs_len, dim=1)
+                        obs_disc_history_buf = torch.where(done_mask[:, None, None], fresh, obs_disc_history_buf)
+                    if logging:
+                        if "episode" in infos:
+                            ep_infos.append(dict(infos["episode"]))
+                        cur += torch.stack([rewards, r_i, r_us, r_ss, r_t, torch.ones_like(rewards)])
+                        fin_vals[i] = cur
+                        fin_mask[i] = done_mask
+                        cur = cur * (~done_mask)
+                self._sync()
+                stop = time.time()
+                collection_time = stop - start
+                start = stop
+                alg.compute_returns(obs)
+            losses = alg.update()
+            if hist_encoding:
+                mean_hist_latent_loss = alg.update_dagger()
+            if env.task_obs_weight_decay_steps:
+                env.task_obs_weight = max(0, env.task_obs_weight - 1.0 / env.task_obs_weight_decay_steps)
+            self._sync()
+            stop = time.time()
+            learn_time = stop - start
+            self.last_perf = {"collection_time": collection_time, "learn_time": learn_time,
+                              "fps": T * N / (collection_time + learn_time)}
+            if logging:
+                vals = fin_vals.permute(0, 2, 1)[fin_mask].cpu().numpy()       # (n_finished, 6) in (step, env) order
+                for col, k in enumerate(("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")):
+                    buffers[k].extend(vals[:, col].tolist())
+                if self.rank == 0:
+                    self.log(dict(it=it, collection_time=collection_time, learn_time=learn_time, ep_infos=ep_infos,
+                                  losses=losses, mean_hist_latent_loss=mean_hist_latent_loss, buffers=buffers))
+                if (it + 1) % self.save_interval == 0 and self.rank == 0:
+                    self.save(os.path.join(self.log_dir, "model.pt"))
+            ep_infos.clear()
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None and self.rank == 0:
+            self.save(os.path.join(self.log_dir, "model.pt"))
+
+    def _sync(self):
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize()
+
+    _LOSS_TAGS = ["surrogate_loss", "value_loss", "b_loss", "entropy_batch", "priv_reg_loss", "estimator_loss", "ss_loss",
+                  "info_max_loss", "disc_loss", "us_loss", "grad_pen_loss", "disc_logit_loss", "disc_weight_decay"]
+    _ACC_TAGS = ["acc_lb", "acc_pi", "acc_exp", "acc_ulb"]
+
+    def log(self, locs, pbar=None):
+        it = locs["it"]
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
+        self.tot_time += locs["collection_time"] + locs["learn_time"]
+        w = self.writer
+        if locs["ep_infos"]:
+            for key in locs["ep_infos"][0]:
+                vals = torch.stack([torch.as_tensor(e[key], device=self.device).reshape(()) for e in locs["ep_infos"]])
+                w.add_scalar("Episode/" + key, (vals.mean() / self.env.reward_scales[key[4:]]).item(), it)
+        for tag, v in zip(self._LOSS_TAGS, locs["losses"][:13]):
+            w.add_scalar("Loss/" + tag, v, it)
+        w.add_scalar("Loss/hist_latent_loss", locs["mean_hist_latent_loss"], it)
+        w.add_scalar("Loss/mean_noise_std", self.alg.actor_critic.std.mean().item(), it)
+        for tag, v in zip(self._ACC_TAGS, locs["losses"][13:]):
+            w.add_scalar("Acc/" + tag, v, it)
+        w.add_scalar("LR/lr_ac", self.alg.lr_ac, it)
+        w.add_scalar("LR/lr_disc", self.alg.lr_disc, it)
+        w.add_scalar("LR/lr_q", self.alg.lr_q, it)
+        fps = int(self.num_steps_per_env * self.env.num_envs / (locs["collection_time"] + locs["learn_time"]))
+        w.add_scalar("Perf/total_fps", fps, it)
+        w.add_scalar("Perf/collection time", locs["collection_time"], it)
+        w.add_scalar("Perf/learning_time", locs["learn_time"], it)
+        b = locs["buffers"]
+        if len(b["rew"]) > 0:
+            for tag, k in (("mean_reward", "rew"), ("mean_reward_i", "rew_i"), ("mean_reward_us", "rew_us"),
+                           ("mean_reward_ss", "rew_ss"), ("mean_reward_t", "rew_t"), ("mean_episode_length", "len")):
+                w.add_scalar("Train/" + tag, statistics.mean(b[k]), it)
+        if hasattr(w, "flush"):
+            w.flush()
+
+    # ------------------------------------------------------------------ checkpoints (same keys as the reference)
+    def save(self, path, infos=None):
+        a = self.alg
+        norm = a.disc_normalizer.to_reference() if isinstance(a.disc_normalizer, TorchNormalizer) else a.disc_normalizer
+        torch.save({
+            "actor_critic": a.actor_critic.state_dict(), "estimator": a.estimator.state_dict(), "disc": a.disc.state_dict(),
+            "optim_ac": a.optim_ac.state_dict(), "optim_hist_encoder": a.optim_hist_encoder.state_dict(),
+            "optim_estimator": a.optim_estimator.state_dict(), "optim_d": a.optim_d.state_dict(),
+            "optim_q_eps": a.optim_q_eps.state_dict(), "optim_q_c": a.optim_q_c.state_dict(),
+            "disc_normalizer": norm, "reward_i_normalizer": a.disc.reward_i_normalizer,
+            "iter": self.current_learning_iteration, "infos": infos,
+        }, path)
+
+    def load(self, path, load_optimizer=True):
+        import quadrupedal_agility_amd
+        quadrupedal_agility_amd.install_reference_aliases()     # so a pickled rsl_rl.utils.utils.Normalizer resolves
+        d = torch.load(path, map_location=self.device, weights_only=False)
+        a = self.alg
+        a.actor_critic.load_state_dict(d["actor_critic"])
+        a.estimator.load_state_dict(d["estimator"])
+        a.disc.load_state_dict(d["disc"])
+        a.disc_normalizer = TorchNormalizer.from_reference(d["disc_normalizer"], self.device)
+        if d["reward_i_normalizer"]:
+            a.disc.reward_i_normalizer = d["reward_i_normalizer"]
+        if load_optimizer:
+            for key in ("optim_ac", "optim_hist_encoder", "optim_estimator", "optim_d", "optim_q_eps", "optim_q_c"):
+                try:
+                    getattr(a, key).load_state_dict(d[key])
+                except Exception as e:      # e.g. a reference checkpoint whose Adam step counters live on the host
+                    print(f"[load] optimizer state {key} not restored: {e}")
+        self.current_learning_iteration = d["iter"]
+        return d["infos"]
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

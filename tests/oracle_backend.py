@@ -1,0 +1,39 @@
+"""Test-only engine with QaSim's interface, backed by the CPU oracle, so that the host-side mirror
+(LeggedRobot / OnPolicyRunner / SSInfoGAIL) can be exercised end to end without a GPU -- BASELINE
+config 1 ("64 envs, CPU physics + CPU torch, plumbing").  Never imported by the product."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from tests.oracle_lib import OracleSim
+
+
+class OracleBackend:
+    def __init__(self, qcfg):
+        self.o = OracleSim(qcfg)
+        self.cfg = qcfg
+        self.device = torch.device("cpu")
+        self.t = {k: torch.from_numpy(v) for k, v in self.o.t.items()}     # zero-copy views of the host arena
+        self.global_step = 0
+
+    def reset_all(self):
+        self.o.global_step = self.global_step
+        self.o.reset_all()
+
+    def step(self, actions, delay=0):
+        self.o.global_step = self.global_step
+        self.o.step(actions.detach().cpu().numpy(), delay)
+        self.global_step += 1
+
+    def set_mocap(self, frames, first_frame):
+        f = np.ascontiguousarray(frames, dtype=np.float32)
+        first = (C.c_int32 * 6)(*[int(x) for x in first_frame])
+        assert self.o.lib.qo_set_mocap(self.o.h, f.ctypes.data, f.shape[0], first, None) == 0
+
+    def gae(self, rewards, values, dones, last_values, returns, advantages, gamma, lam, normalize=True):
+        T, N = rewards.shape
+        p = lambda x: x.numpy().ctypes.data
+        rc = self.o.lib.qo_gae(p(rewards), p(values), p(dones), p(last_values), p(returns), p(advantages), T, N,
+                               float(gamma), float(lam), int(bool(normalize)), None, None)
+        assert rc == 0

@@ -1,0 +1,86 @@
+"""BASELINE config 1: go2_locomotion BBC, 64 envs, plane, PPO on CPU physics (the oracle) + CPU torch.
+Exercises the whole host-side mirror -- task registry, LeggedRobot views, runner, SSInfoGAIL update,
+checkpoint round trip -- without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from quadrupedal_agility_amd.legged_gym.envs import *  # noqa: F401,F403
+from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+from quadrupedal_agility_amd.legged_gym.utils import get_args, task_registry
+from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
+from tests.oracle_backend import OracleBackend
+
+
+def make_env(n=64, mocap=False, amp=False):
+    cfg = Go2LocomotionCfg()
+    cfg.env.num_envs = n
+    cfg.terrain.mesh_type = "plane"
+    cfg.env.mocap_state_init = mocap
+    cfg.seed = 1
+    qc = make_qa_config(cfg, seed=1)
+    if mocap:
+        qc.num_mocap_frames = 5 * 4096
+    args = get_args(["--device", "cpu", "--num_envs", str(n)])
+    env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=OracleBackend(qc))
+    return env, args
+
+
+def test_env_api_surface():
+    env, _ = make_env(16)
+    assert (env.num_envs, env.num_obs, env.num_privileged_obs, env.num_obs_disc, env.num_actions) == (16, 101, 101, 49, 12)
+    assert env.dt == pytest.approx(0.02) and env.max_episode_length == 1000 and env.dim_c == 5
+    assert env.default_dof_pos.shape == (1, 12) and env.dof_pos_limits.shape == (12, 2)
+    assert list(env.reward_scales.keys()) == sorted(env.reward_scales.keys()) and len(env.reward_names) == 14
+    obs, priv = env.reset()
+    assert obs.shape == (16, 671) and priv.shape == (16, 671) and env.get_disc_observations().shape == (16, 49)
+    out = env.step(torch.zeros(16, 12))
+    assert len(out) == 7 and out[2].shape == (16,) and out[3].dtype == torch.int64
+    assert out[5].dtype == torch.int64 and out[6].shape[1] == 49
+    # learner-written attributes go through to the engine
+    env.prior_parameters = torch.tensor([0.5, 0.1, 0.1, 0.2, 0.1])
+    assert np.allclose(env.sim.o.t["PRIOR_PARAMETERS"], [0.5, 0.1, 0.1, 0.2, 0.1])
+    env.episode_length_buf = torch.full((16,), 7, dtype=torch.int64)
+    assert (env.sim.o.t["EPISODE_LENGTH"] == 7).all()
+    # views alias the arena: dof_pos is dof_state[..., 0]
+    env.dof_pos[0, 0] = 0.123
+    assert env.dof_state.view(16, 12, 2)[0, 0, 0] == pytest.approx(0.123)
+
+
+def _train_cfg(amp):
+    t = Go2LocomotionCfgAlgo()
+    t.runner.amp_enabled = amp
+    t.runner.num_preload_transitions = 2000
+    t.algorithm.disc_replay_buffer_size = 20000
+    t.runner.save_interval = 2
+    return t
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_learn_two_iterations_and_checkpoint(tmp_path, amp):
+    torch.manual_seed(0)
+    env, args = make_env(64, mocap=amp, amp=amp)
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=_train_cfg(amp), log_root=str(tmp_path))
+    before = {k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()}
+    runner.learn(2, init_at_random_ep_len=True)
+    after = runner.alg.actor_critic.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)
+    assert all(torch.isfinite(v).all() for v in after.values())
+    path = os.path.join(runner.log_dir, "model.pt")
+    assert os.path.exists(path)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck.keys()) == {"actor_critic", "estimator", "disc", "optim_ac", "optim_hist_encoder", "optim_estimator",
+                              "optim_d", "optim_q_eps", "optim_q_c", "disc_normalizer", "reward_i_normalizer", "iter", "infos"}
+    assert type(ck["disc_normalizer"]).__name__ == "Normalizer" and ck["disc_normalizer"].mean.shape == (98,)
+    shapes = {k: tuple(v.shape) for k, v in ck["actor_critic"].items()}
+    assert shapes["actor_trunk.0.weight"] == (512, 101) and shapes["critic_trunk.0.weight"] == (512, 671)
+    assert shapes["history_encoder.conv_layers.0.weight"] == (20, 30, 4) and shapes["std"] == (12,)
+    assert sum(v.numel() for v in ck["actor_critic"].values()) == 735699
+    # round trip
+    runner2, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=_train_cfg(amp), log_root=None)
+    runner2.load(path)
+    for k, v in runner2.alg.actor_critic.state_dict().items():
+        assert torch.equal(v, after[k])
+    assert os.path.exists(os.path.join(runner.log_dir, "scalars.jsonl")) or any(f.startswith("events") for f in os.listdir(runner.log_dir))
