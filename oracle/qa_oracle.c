@@ -949,3 +949,33 @@ int qo_debug_bodies(const float q[12], const float qd[12], const float ub[6], do
     }
     return QA_OK;
 }
+
+/* ---- debug entry points used by the golden-vector tests (tests/test_golden_env.py) ---- */
+/* legged_robot.py:84-106 only: action-history roll, delay, clip, decimation x (PD torque + physics).  Leaves the arena
+ * in the state the reference has when it enters post_physics_step (after the refresh_* calls, :129-131). */
+int qo_debug_pre_physics(qo_sim *s, const float *actions, int32_t delay_steps) {
+    const qa_config *c = &s->cfg;
+    for (int e = 0; e < c->num_envs; ++e) {
+        float *ah = TP(s, QA_T_ACTION_HISTORY, float) + 96 * e;
+        memmove(ah, ah + 12, 7 * 12 * 4);
+        memcpy(ah + 7 * 12, actions + 12 * e, 48);
+        const float *src = ah + 12 * (QA_ACTION_BUF_LEN - 1 - delay_steps);
+        float *act = TP(s, QA_T_ACTIONS, float) + 12 * e;
+        float clipa = c->clip_actions / c->action_scale;
+        for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
+        float *tau = TP(s, QA_T_TORQUES, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e;
+        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep(s, e, tau); }
+    }
+    return QA_OK;
+}
+/* legged_robot.py:124-166 only, on whatever state is in the arena */
+int qo_debug_post_physics(qo_sim *s, int64_t step) {
+    memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * ((step + 1) & 1), 0, 64);
+    for (int e = 0; e < s->cfg.num_envs; ++e) { float tmp[QA_NUM_OBS_DISC]; post_physics(s, e, step, tmp); }
+    return QA_OK;
+}
+/* legged_robot.py:547-579 on the current dof state */
+int qo_debug_torques(qo_sim *s, const float *actions, float *tau, float *tau_org) {
+    for (int e = 0; e < s->cfg.num_envs; ++e) compute_torques(s, e, actions + 12 * e, tau + 12 * e, tau_org + 12 * e);
+    return QA_OK;
+}

@@ -54,23 +54,23 @@ class SSInfoGAIL:
         self.estimator = estimator
         # adaptive learning rate: a device tensor on GPU (no host round trip per minibatch), a float on CPU
         self._lr_ac = torch.tensor(float(lr_ac), device=device) if self._on_gpu else float(lr_ac)
-        adam = dict(capturable=True) if self._on_gpu else {}
+        adam = dict(fused=True) if self._on_gpu else {}       # one multi-tensor kernel per step; accepts a tensor lr
         self.optim_ac = optim.Adam([{"params": self.actor_critic.parameters(), "name": "actor_critic"}], lr=self._lr_ac, **adam)
-        self.optim_hist_encoder = optim.Adam(self.actor_critic.history_encoder.parameters(), lr=estimator_paras["learning_rate"])
-        self.optim_estimator = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"])
+        self.optim_hist_encoder = optim.Adam(self.actor_critic.history_encoder.parameters(), lr=estimator_paras["learning_rate"], **adam)
+        self.optim_estimator = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"], **adam)
         self.priv_reg_coef_schedual = priv_reg_coef_schedual
         self.priv_reg_counter = 0
         self.train_with_estimated_explicit = estimator_paras["train_with_estimated_explicit"]
 
-        def groups(head, name):   # the reference's extra keys (weight_decay / momentum) are inert for Adam without weight_decay arg... keep them
+        def groups(head, name):   # per-group weight_decay 1e-3 is live for Adam (gail.py:107-124); 'momentum' is an inert key
             return [{"params": self.disc.trunk.parameters(), "weight_decay": 1e-3, "momentum": 0.9, "name": "trunk"},
                     {"params": head.parameters(), "weight_decay": 1e-3, "momentum": 0.9, "name": name}]
         if disc_loss_function == "WassersteinLoss":
             self.optim_d = optim.RMSprop(groups(self.disc.linear, "head"), lr=lr_disc)
         else:
-            self.optim_d = optim.Adam(groups(self.disc.linear, "head"), lr=lr_disc)
-        self.optim_q_eps = optim.Adam(groups(self.disc.encoder_eps, "encoder_eps"), lr=lr_q)
-        self.optim_q_c = optim.Adam(groups(self.disc.classifier, "classifier"), lr=lr_q)
+            self.optim_d = optim.Adam(groups(self.disc.linear, "head"), lr=lr_disc, **adam)
+        self.optim_q_eps = optim.Adam(groups(self.disc.encoder_eps, "encoder_eps"), lr=lr_q, **adam)
+        self.optim_q_c = optim.Adam(groups(self.disc.classifier, "classifier"), lr=lr_q, **adam)
 
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.surrogate_loss_coef, self.value_loss_coef, self.entropy_coef = surrogate_loss_coef, value_loss_coef, entropy_coef

@@ -50,10 +50,31 @@ class StateHistoryEncoder(nn.Module):
         self.linear_output = nn.Sequential(nn.Linear(ch * 3, output_size), activation_fn)
 
     def forward(self, obs):
+        """Same arithmetic as encoder -> Conv1d stack -> Flatten -> linear_output, but the temporal convolutions are
+        evaluated as window-gather + GEMM: a (B=24576, C=30, T=10) Conv1d goes through MIOpen's im2col/igemm paths
+        on ROCm (0.5 ms per call, 0.2 s of solver search on first use -- profiles/r1_bench_kernel_stats_v0*), while the
+        equivalent (B*T_out, k*C) x (k*C, C_out) matmul is one small hipBLASLt GEMM.  Parameters stay in the Conv1d
+        modules, so state_dict names/shapes are unchanged."""
         b = obs.shape[0]
-        x = self.encoder(obs.reshape(b * self.tsteps, -1))
-        x = self.conv_layers(x.reshape(b, self.tsteps, -1).permute(0, 2, 1))
+        x = self.encoder(obs.reshape(b * self.tsteps, -1)).reshape(b, self.tsteps, -1)      # (B, T, C) channels last
+        for m in self.conv_layers:
+            if isinstance(m, nn.Conv1d):
+                x = _conv1d_channels_last(x, m)
+            elif not isinstance(m, nn.Flatten):
+                x = m(x)
+        x = x.permute(0, 2, 1).reshape(b, -1)           # Flatten of (B, C, T): channel-major
         return self.linear_output(x)
+
+
+def _conv1d_channels_last(x, conv):
+    """x (B, T, C_in) -> (B, T_out, C_out) for a Conv1d(C_in, C_out, k, stride) without padding/dilation."""
+    k, s = conv.kernel_size[0], conv.stride[0]
+    b, t, c = x.shape
+    t_out = (t - k) // s + 1
+    win = x.unfold(1, k, s)                              # (B, T_out, C_in, k) view
+    w = conv.weight.reshape(conv.out_channels, c * k)    # (C_out, C_in * k), same (c, k) order as the window
+    y = torch.addmm(conv.bias, win.reshape(b * t_out, c * k), w.t())
+    return y.reshape(b, t_out, conv.out_channels)
 
 
 class ActorCritic(nn.Module):

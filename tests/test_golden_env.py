@@ -1,0 +1,105 @@
+"""The CPU oracle against golden vectors produced by the REFERENCE'S OWN PYTHON (tools/gen_golden.py):
+post_physics_step / check_termination / compute_reward / reset bookkeeping / compute_observations /
+compute_flat_key_pos (bbc/legged_gym/envs/base/legged_robot.py:124-331, 1231-1396) and _compute_torques (:547-579).
+This is what pins the env-side part of the oracle; the HIP kernel is then pinned to the oracle by the -m gpu tests."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from quadrupedal_agility_amd import _capi
+from tests.oracle_lib import OracleSim, go2_cfg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "env_post_physics.npz"), allow_pickle=False)
+
+
+def _load_case(o, gold, i):
+    for name in _capi.TENSORS:
+        key = f"c{i}_in_{name}"
+        if key in gold.files:
+            o.t[name][...] = gold[key]
+    return int(gold[f"c{i}_in__step"])
+
+
+def _run(gold, i):
+    n = int(gold["num_envs"])
+    o = OracleSim(go2_cfg(n, seed=int(gold["seed"]), add_noise=0))
+    o.lib.qo_debug_post_physics.argtypes = [C.c_void_p, C.c_int64]
+    step = _load_case(o, gold, i)
+    assert o.lib.qo_debug_post_physics(o.h, step) == 0
+    return o, step, (lambda k: gold[f"c{i}_ref_{k}"])
+
+
+def test_reward_names_order(gold):
+    assert list(gold["c0_ref_reward_names"]) == _capi.REWARD_NAMES     # alphabetical = the reference's summation order
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_post_physics_matches_reference(gold, case):
+    assert case < int(gold["num_cases"])
+    o, step, ref = _run(gold, case)
+    t = o.t
+    # integer / boolean outputs: exact
+    assert (t["RESET"] == ref("reset")).all()
+    assert (t["TIME_OUT"].astype(bool) == ref("time_out")).all()
+    assert (t["EPISODE_LENGTH"] == ref("episode_length")).all()
+    assert (t["CONTACT_FILT"].astype(bool) == ref("contact_filt")).all()
+    assert (t["LAST_CONTACTS"].astype(bool) == ref("last_contacts")).all()
+    assert (np.nonzero(t["RESET"])[0] == ref("reset_env_ids")).all()
+    # derived state
+    f32 = dict(atol=2e-6, rtol=1e-5)
+    for mine, theirs in (("BASE_LIN_VEL", "base_lin_vel"), ("BASE_ANG_VEL", "base_ang_vel"), ("PROJECTED_GRAVITY", "projected_gravity"),
+                         ("RPY", "rpy"), ("FEET_FORCE", "feet_force")):
+        assert np.allclose(t[mine], ref(theirs), **f32), mine
+    # rewards: total after the >=0 clip, and every one of the 14 running episode sums
+    assert np.allclose(t["REW"], ref("rew"), atol=1e-6, rtol=1e-5)
+    assert np.allclose(t["EPISODE_SUMS"], ref("episode_sums"), atol=1e-6, rtol=1e-5)
+    # observations (noise off): 671-row, 49-row, history
+    assert np.allclose(t["OBS"], ref("obs"), **f32)
+    assert np.allclose(t["OBS"], ref("priv_obs"), **f32)
+    assert np.allclose(t["OBS_DISC"], ref("obs_disc"), **f32)
+    assert np.allclose(t["OBS_HISTORY"].reshape(-1, 570), ref("obs_history").reshape(-1, 570), **f32)
+    # last_* copies and histories
+    for mine, theirs in (("LAST_ACTIONS", "last_actions"), ("LAST_DOF_VEL", "last_dof_vel"), ("LAST_ROOT_VEL", "last_root_vel"),
+                         ("LAST_TORQUES_ORG", "last_torques_org"), ("ACTION_HISTORY", "action_history"), ("COMMANDS", "commands"),
+                         ("ROOT_STATES", "root_states")):
+        assert np.allclose(t[mine], ref(theirs), **f32), mine
+    # terminal discriminator observation of the envs that reset = their previous OBS_DISC row
+    ids = ref("reset_env_ids")
+    assert np.allclose(t["OBS_DISC_TERM"][ids], ref("terminal_disc"), **f32)
+    keep = np.setdiff1d(np.arange(t["RESET"].shape[0]), ids)
+    assert np.allclose(t["OBS_DISC_TERM"][keep], t["OBS_DISC"][keep])
+    # extras["episode"]: mean episode sum of the resetting envs / episode_length_s
+    if len(ids):
+        st = t["EPISODE_STATS"][step & 1]
+        assert st[14] == len(ids)
+        assert np.allclose(st[:14] / st[14] / 20.0, ref("extras_episode"), atol=1e-6, rtol=1e-4)
+
+
+def test_fixture_covers_the_branches(gold):
+    n_cases = int(gold["num_cases"])
+    resets = sum(len(gold[f"c{i}_ref_reset_env_ids"]) for i in range(n_cases))
+    timeouts = sum(int(gold[f"c{i}_ref_time_out"].sum()) for i in range(n_cases))
+    pushes = sum(int((int(gold[f"c{i}_in__step"]) + 1) % 400 == 0) for i in range(n_cases))
+    collisions = sum(float(np.abs(gold[f"c{i}_in_CONTACT_FORCES"][:, [4, 5, 8, 9, 12, 13, 16, 17]]).sum() > 0) for i in range(n_cases))
+    assert resets >= 3 and timeouts >= 2 and pushes == 1 and collisions >= 1
+
+
+def test_compute_torques_matches_reference():
+    g = np.load(os.path.join(GOLD, "env_torques.npz"))
+    n = g["actions"].shape[0]
+    o = OracleSim(go2_cfg(n, seed=int(g["seed"])))
+    o.t["DOF_STATE"][...] = g["dof_state"]; o.t["MOTOR_STRENGTH"][...] = g["motor_strength"]
+    tau = np.zeros((n, 12), np.float32); tau_org = np.zeros((n, 12), np.float32)
+    o.lib.qo_debug_torques.argtypes = [C.c_void_p] * 4
+    act = np.ascontiguousarray(g["actions"])
+    assert o.lib.qo_debug_torques(o.h, act.ctypes.data, tau.ctypes.data, tau_org.ctypes.data) == 0
+    assert np.allclose(tau_org, g["torques_org"], atol=1e-5, rtol=1e-6)
+    assert np.allclose(tau, g["torques"], atol=1e-5, rtol=1e-6)
+    assert (np.abs(g["torques"]) == np.array([20, 20, 40] * 4)).any()          # the clip is exercised
