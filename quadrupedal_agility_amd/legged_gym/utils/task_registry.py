@@ -4,8 +4,6 @@ import os
 from typing import Tuple
 
 from quadrupedal_agility_amd.legged_gym import LEGGED_GYM_ROOT_DIR
-from quadrupedal_agility_amd.legged_gym.envs.base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgAlgo
-from quadrupedal_agility_amd.rsl_rl.runners import OnPolicyRunner  # noqa: F401  (resolved by name)
 
 from .helpers import class_to_dict, get_args, get_load_path, parse_sim_params, set_seed, update_cfg_from_args
 
@@ -14,13 +12,13 @@ class TaskRegistry:
     def __init__(self):
         self.task_classes, self.env_cfgs, self.train_cfgs = {}, {}, {}
 
-    def register(self, name: str, task_class, env_cfg: LeggedRobotCfg, train_cfg: LeggedRobotCfgAlgo):
+    def register(self, name: str, task_class, env_cfg, train_cfg):
         self.task_classes[name], self.env_cfgs[name], self.train_cfgs[name] = task_class, env_cfg, train_cfg
 
     def get_task_class(self, name: str):
         return self.task_classes[name]
 
-    def get_cfgs(self, name) -> Tuple[LeggedRobotCfg, LeggedRobotCfgAlgo]:
+    def get_cfgs(self, name) -> Tuple[object, object]:
         env_cfg, train_cfg = self.env_cfgs[name], self.train_cfgs[name]
         env_cfg.seed = train_cfg.seed
         return env_cfg, train_cfg
@@ -53,6 +51,7 @@ class TaskRegistry:
         if log_root == "default":
             log_root = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name)
         log_dir = None if log_root is None else os.path.join(log_root, "{}".format(int(train_cfg.runner.experiment_idx)))
+        from quadrupedal_agility_amd.rsl_rl.runners import OnPolicyRunner  # noqa: F401  (resolved by name below)
         runner_class = eval(train_cfg.runner_class_name)
         runner = runner_class(env, class_to_dict(train_cfg), log_dir, device=args.rl_device)
         if train_cfg.runner.resume:

@@ -1,0 +1,89 @@
+"""world_size-2 gloo tests of the data-parallel learner path (one process per GPU in production, RCCL).  The env path
+has no collective (envs are independent); the learner all-reduces one flat gradient bucket per optimiser step, the KL
+mean, the advantage moments and the prior vector, and starts from rank 0's weights."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _grad_sync_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import GradSync
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ELU(), torch.nn.Linear(7, 2))
+    x = torch.full((3, 5), float(rank + 1))
+    m(x).sum().backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    gs = GradSync()
+    gs(list(m.parameters()))
+    q.put((rank, [g.numpy() for g in local], [p.grad.numpy().copy() for p in m.parameters()],
+           float(gs.mean_scalar(torch.tensor(float(rank))))))
+    dist.destroy_process_group()
+
+
+def test_grad_sync_averages_flat_bucket():
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_grad_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    for i in range(len(out[0][1])):
+        mean = 0.5 * (out[0][1][i] + out[1][1][i])
+        assert np.allclose(out[0][2][i], mean) and np.allclose(out[1][2][i], mean)
+    assert out[0][3] == pytest.approx(0.5) and out[1][3] == pytest.approx(0.5)
+
+
+def _runner_worker(rank, world, port, q, tmp):
+    _init(rank, world, port)
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+    from quadrupedal_agility_amd.legged_gym.utils import get_args
+    from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
+    from tests.oracle_backend import OracleBackend
+    cfg = Go2LocomotionCfg(); cfg.env.num_envs = 16; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = False
+    cfg.seed = 1 + 7919 * rank
+    t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = True; t.runner.num_preload_transitions = 500; t.algorithm.disc_replay_buffer_size = 5000
+    args = get_args(["--device", "cpu"])
+    torch.manual_seed(100 + rank)                      # different initial weights per rank: the broadcast must fix that
+    env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=OracleBackend(make_qa_config(cfg, seed=cfg.seed)))
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
+    assert runner.distributed
+    runner.learn(1, init_at_random_ep_len=True)
+    a = runner.alg
+    flat = torch.cat([p.detach().flatten() for m in (a.actor_critic, a.estimator, a.disc) for p in m.parameters()])
+    adv = a.storage.advantages
+    q.put((rank, flat.numpy(), a.lr_ac, float(adv.sum()), float((adv * adv).sum()), adv.numel(), env.prior_parameters.numpy().copy(),
+           env.root_states[:, :3].numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_keeps_replicas_identical(tmp_path):
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_runner_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    (_, w0, lr0, s0, ss0, n0, pr0, pos0), (_, w1, lr1, s1, ss1, n1, pr1, pos1) = out
+    assert np.array_equal(w0, w1)                      # same broadcast start + same averaged gradients -> bit-identical replicas
+    assert lr0 == lr1                                  # KL mean is all-reduced, both ranks took the same LR branch
+    assert np.allclose(pr0, pr1)
+    n = n0 + n1                                        # advantages are normalised over BOTH ranks' samples
+    mean = (s0 + s1) / n
+    var = ((ss0 + ss1) - n * mean * mean) / (n - 1)
+    assert abs(mean) < 1e-4 and abs(var - 1.0) < 1e-3
+    assert not np.allclose(pos0, pos1)                 # the ranks simulate different envs (disjoint Philox streams)
