@@ -6,5 +6,6 @@ def __getattr__(name):
     # `import quadrupedal_agility_amd.rsl_rl...` circular (the reference has the same knot)
     if name == "task_registry":
         from .task_registry import task_registry
+        globals()["task_registry"] = task_registry      # the import above bound the SUBMODULE to this name; rebind the object
         return task_registry
     raise AttributeError(name)

@@ -1,0 +1,17 @@
+"""Workload for the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): 60 fused env steps at N envs, plus a
+calibration stream of known size (a 256 MiB float32 copy: 256 MiB read + 256 MiB written)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from tests.oracle_lib import go2_cfg
+from quadrupedal_agility_amd.sim import QaSim
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+h = QaSim(go2_cfg(n)); h.reset_all()
+act = torch.randn(n, 12, device="cuda") * 0.3
+for _ in range(60):
+    h.step(act)
+x = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+for _ in range(5):
+    y = x.clone()
+torch.cuda.synchronize()
+print("done")
