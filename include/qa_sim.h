@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 1
+#define QA_ABI_VERSION 2
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -103,6 +103,8 @@ enum qa_tensor {
                                          origin xx yy zz xy xz yz, base frame                    */
     QA_T_PRIOR_PARAMETERS,    /* (5)    written by the learner (gail.py:463-464)                 */
     QA_T_MOCAP_FRAMES,        /* (F,QA_MOCAP_FRAME) reset-state frames, see qa_set_mocap         */
+    QA_T_FOOT_IMPULSE,        /* (N,4,3) foot contact impulses (normal, tangent x, tangent y) of the last
+                                         substep: warm start of the contact solver; zeroed on reset   */
     QA_T_COUNT
 };
 

@@ -90,6 +90,7 @@ static void make_layout(const qa_config *cfg, Layout *L) {
     set_t(L, QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1);
     set_t(L, QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1);
     set_t(L, QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1);
+    set_t(L, QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3);
     int64_t off = 0;
     for (int t = 0; t < QA_T_COUNT; ++t) {
         off = (off + 255) & ~(int64_t)255;
@@ -428,6 +429,17 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
         double d = 0; for (int k = 0; k < 18; ++k) d += rows[i].J[k] * rows[i].W[k];
         rows[i].dinv = 1.0 / (d + CFM);
     }
+    /* warm start: the foot rows start from the impulses of the previous substep (applied to u first);
+     * a foot that is not in contact this substep forgets its impulse */
+    float *fimp = TP(s, QA_T_FOOT_IMPULSE, float) + 12 * e;
+    for (int l = 0; l < 4; ++l) {
+        if (foot_row[l] < 0) { fimp[3 * l] = fimp[3 * l + 1] = fimp[3 * l + 2] = 0.0f; continue; }
+        for (int d = 0; d < 3; ++d) {
+            Row *r = &rows[foot_row[l] + d];
+            r->lam = fimp[3 * l + d];
+            for (int k = 0; k < 18; ++k) u[k] += r->W[k] * r->lam;
+        }
+    }
     for (int it = 0; it < cfg->solver_iterations; ++it) {
         for (int i = 0; i < nrows; ++i) {
             Row *r = &rows[i];
@@ -462,6 +474,7 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     for (int i = 0; i < 4; ++i) root[3 + i] = (float)(qn[i] * nn);
     for (int j = 0; j < 12; ++j) { dof[2 * j] = (float)(q[j] + dt * u[6 + j]); dof[2 * j + 1] = (float)u[6 + j]; }
 
+    for (int l = 0; l < 4; ++l) if (foot_row[l] >= 0) for (int d = 0; d < 3; ++d) fimp[3 * l + d] = (float)rows[foot_row[l] + d].lam;
     /* ---- contact forces per body (world frame; plane => (t1,t2,n) are world x,y,z) */
     memset(cf, 0, sizeof(float) * 57);
     for (int l = 0; l < 4; ++l) {
@@ -557,6 +570,7 @@ static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity, int repo
         root[3] = 0; root[4] = 0; root[5] = 0; root[6] = 1;
         for (int i = 0; i < 6; ++i) root[7 + i] = (0.5f - -0.5f) * u[12 + i] + -0.5f;
     }
+    memset(TP(s, QA_T_FOOT_IMPULSE, float) + 12 * e, 0, 48);
     memset(TP(s, QA_T_LAST_ACTIONS, float) + 12 * e, 0, 48);
     memset(TP(s, QA_T_LAST_DOF_VEL, float) + 12 * e, 0, 48);
     memset(TP(s, QA_T_LAST_ROOT_VEL, float) + 6 * e, 0, 24);

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 1
+QA_ABI_VERSION = 2
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -30,7 +30,7 @@ TENSORS = [
     "LATENT_EPS", "LATENT_C", "REW", "RESET", "TIME_OUT", "EPISODE_LENGTH", "EPISODE_SUMS",
     "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
     "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",
-    "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES",
+    "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES", "FOOT_IMPULSE",
 ]
 T = {name: i for i, name in enumerate(TENSORS)}
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32 = 0, 1, 2, 3

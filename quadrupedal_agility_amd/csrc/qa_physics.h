@@ -169,9 +169,33 @@ QA_DEV void contact_rows(Row *rows, V3 p, int depth, float gap, const V3 *o, con
 // link inertia (10 floats), tau = joint torques of this leg (already clipped), mu = friction.
 // Returns contact forces; updates st in place.  If fk_out != nullptr, writes the joint origins
 // and the foot origin of the NEW state in the base frame (4 points) for RIGID_BODY_POS.
+// rarely-active rows live in per-lane LDS slots: slot k of this lane is priv[k * QA_PRIV_STRIDE]
+#define QA_PRIV_STRIDE 64
+#define QA_PRIV_EXTRA 0                  // 3 rows x 20 floats: jh6 jl3 bj6 lj3 dinv bias
+#define QA_PRIV_LIMIT 60                 // 3 rows x 8 floats:  bj6 dinv (sgn/bias/on stay in registers)
+#define QA_PRIV_STEP 84                  // env-step persistents parked between substeps: act3 sp3 sd3 binert10
+#define QA_PRIV_FLOATS 104
+struct LRow { float *p; };               // row view in LDS
+QA_DEV float &lr(float *priv, int k) { return priv[k * QA_PRIV_STRIDE]; }
+
+QA_DEV void row_store(float *priv, int base, const Row &r) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { lr(priv, base + i) = r.jh[i]; lr(priv, base + 9 + i) = r.bj[i]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lr(priv, base + 6 + k) = r.jl[k]; lr(priv, base + 15 + k) = r.lj[k]; }
+    lr(priv, base + 18) = r.dinv; lr(priv, base + 19) = r.bias;
+}
+QA_DEV void row_load(float *priv, int base, Row &r) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { r.jh[i] = lr(priv, base + i); r.bj[i] = lr(priv, base + 9 + i); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.jl[k] = lr(priv, base + 6 + k); r.lj[k] = lr(priv, base + 15 + k); }
+    r.dinv = lr(priv, base + 18); r.bias = lr(priv, base + 19);
+}
+
 template <bool PLANE>
 QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
-                         float mu, int leg, const PhysParams &P, ContactOut &co) {
+                         float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3]) {
     const float dt = P.dt;
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     S6 V0 = s6(mulT(R, st.ww), mulT(R, st.vw));
@@ -179,7 +203,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 
     // ---- leg kinematics in the base frame
     float s1, c1, s2, c2, s23, c23;
-    sincosf(st.q[0], &s1, &c1); sincosf(st.q[1], &s2, &c2); sincosf(st.q[1] + st.q[2], &s23, &c23);
+    __sincosf(st.q[0], &s1, &c1); __sincosf(st.q[1], &s2, &c2); __sincosf(st.q[1] + st.q[2], &s23, &c23);
     M3 Rl[3];
     Rl[0].m[0] = 1; Rl[0].m[1] = 0; Rl[0].m[2] = 0; Rl[0].m[3] = 0; Rl[0].m[4] = c1; Rl[0].m[5] = -s1; Rl[0].m[6] = 0; Rl[0].m[7] = s1; Rl[0].m[8] = c1;
     // R1 * Ry(t) = [[c,0,s],[s1 s, c1, -s1 c],[-c1 s, s1, c1 c]]
@@ -313,12 +337,18 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     const bool extra_on = best_gap < P.contact_offset;
 
     // ---- rows (all in registers; inactive ones are skipped wave-uniformly below)
-    Row rf[3], re[3];
+    Row rf[3];
     contact_rows(rf, foot_p, 3, foot_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
     const bool any_extra = __any(extra_on);
-    if (any_extra) contact_rows(re, best_p, best_depth, best_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
+    float re_lam[3] = {0.f, 0.f, 0.f};
+    if (any_extra) {
+        Row re[3];
+        contact_rows(re, best_p, best_depth, best_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 20 * d, re[d]);
+    }
     // joint limits: at most one stop per joint can be within the margin
-    float lim_sgn[3], lim_bias[3], lim_bj[3][6], lim_dinv[3], lim_lam[3];
+    float lim_sgn[3], lim_bias[3], lim_lam[3];
     bool lim_on[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -335,18 +365,33 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             // jl = sgn e_k  =>  jh = sgn G[k,:],  lj = sgn Linv[:,k]
-            float jh[6];
+            float jh[6], bj[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) jh[i] = lim_sgn[k] * G[k * 6 + i];
-            sym6_mul(Binv, jh, lim_bj[k]);
+            sym6_mul(Binv, jh, bj);
             float lkk = (k == 0) ? Linv[0] : (k == 1 ? Linv[3] : Linv[5]);
             float d = lkk;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) d = fmaf(jh[i], lim_bj[k][i], d);
-            lim_dinv[k] = 1.0f / (d + QA_CFM);
+            for (int i = 0; i < 6; ++i) { d = fmaf(jh[i], bj[i], d); lr(priv, QA_PRIV_LIMIT + 8 * k + i) = bj[i]; }
+            lr(priv, QA_PRIV_LIMIT + 8 * k + 6) = 1.0f / (d + QA_CFM);
         }
     }
 
+    // ---- warm start: the foot rows start from the previous substep's impulses, applied to (ub, w) first
+    {
+        float dub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float l0 = foot_on ? fimp[d] : 0.f;
+            rf[d].lam = l0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dub[i] = fmaf(rf[d].bj[i], l0, dub[i]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[k] = fmaf(rf[d].lj[k], l0, w[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ub[i] += quad_sum(dub[i]);
+    }
     // ---- projected Gauss-Seidel, true sequential order over the legs: the lane whose turn it is
     // updates its local (ub, w); its accumulated base-velocity change is then quad-broadcast.
     const bool any_foot = __any(foot_on);
@@ -360,24 +405,26 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             for (int k = 0; k < 3; ++k) w2[k] = w[k];
             const bool mine = (leg == s);
             if (any_foot) {
-                Row t0 = rf[0], t1 = rf[1], t2 = rf[2];
                 if (foot_on) {
-                    row_update(t0, ub2, w2, 0.f, 3.0e38f);
-                    float lim = mu * t0.lam;
-                    row_update(t1, ub2, w2, -lim, lim);
-                    row_update(t2, ub2, w2, -lim, lim);
+                    const float l0 = rf[0].lam, l1 = rf[1].lam, l2 = rf[2].lam;
+                    row_update(rf[0], ub2, w2, 0.f, 3.0e38f);
+                    float lim = mu * rf[0].lam;
+                    row_update(rf[1], ub2, w2, -lim, lim);
+                    row_update(rf[2], ub2, w2, -lim, lim);
+                    if (!mine) { rf[0].lam = l0; rf[1].lam = l1; rf[2].lam = l2; }
                 }
-                if (mine) { rf[0].lam = t0.lam; rf[1].lam = t1.lam; rf[2].lam = t2.lam; }
             }
             if (any_extra) {
-                Row t0 = re[0], t1 = re[1], t2 = re[2];
                 if (extra_on) {
+                    Row t0, t1, t2;
+                    row_load(priv, QA_PRIV_EXTRA, t0); row_load(priv, QA_PRIV_EXTRA + 20, t1); row_load(priv, QA_PRIV_EXTRA + 40, t2);
+                    t0.lam = re_lam[0]; t1.lam = re_lam[1]; t2.lam = re_lam[2];
                     row_update(t0, ub2, w2, 0.f, 3.0e38f);
                     float lim = mu * t0.lam;
                     row_update(t1, ub2, w2, -lim, lim);
                     row_update(t2, ub2, w2, -lim, lim);
+                    if (mine) { re_lam[0] = t0.lam; re_lam[1] = t1.lam; re_lam[2] = t2.lam; }
                 }
-                if (mine) { re[0].lam = t0.lam; re[1].lam = t1.lam; re[2].lam = t2.lam; }
             }
             if (any_lim) {
 #pragma unroll
@@ -388,11 +435,11 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
                         for (int i = 0; i < 6; ++i) uk = fmaf(G[k * 6 + i], ub2[i], uk);
                         float res = lim_bias[k] + lim_sgn[k] * uk;
-                        float lam = fmaxf(lim_lam[k] - res * lim_dinv[k], 0.f);
+                        float lam = fmaxf(lim_lam[k] - res * lr(priv, QA_PRIV_LIMIT + 8 * k + 6), 0.f);
                         float dl = lam - lim_lam[k];
                         if (mine) lim_lam[k] = lam;
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) ub2[i] = fmaf(lim_bj[k][i], dl, ub2[i]);
+                        for (int i = 0; i < 6; ++i) ub2[i] = fmaf(lr(priv, QA_PRIV_LIMIT + 8 * k + i), dl, ub2[i]);
                         float sd = lim_sgn[k] * dl;
                         w2[0] = fmaf(k == 0 ? Linv[0] : (k == 1 ? Linv[1] : Linv[2]), sd, w2[0]);
                         w2[1] = fmaf(k == 0 ? Linv[1] : (k == 1 ? Linv[3] : Linv[4]), sd, w2[1]);
@@ -439,17 +486,19 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
     for (int k = 0; k < 3; ++k) { st.q[k] = fmaf(dt, ul[k], st.q[k]); st.qd[k] = ul[k]; }
 
+#pragma unroll
+    for (int d = 0; d < 3; ++d) fimp[d] = foot_on ? rf[d].lam : 0.f;
     // ---- contact forces, world frame (plane: t1, t2, n are world x, y, z)
     float idt = 1.0f / dt;
-    co.foot_f = (any_foot && foot_on) ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
-    co.extra_f = (any_extra && extra_on) ? v3(re[1].lam * idt, re[2].lam * idt, re[0].lam * idt) : v3(0, 0, 0);
+    co.foot_f = foot_on ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
+    co.extra_f = (any_extra && extra_on) ? v3(re_lam[1] * idt, re_lam[2] * idt, re_lam[0] * idt) : v3(0, 0, 0);
     co.extra_body = (any_extra && extra_on) ? best_body : -1;
 }
 
 // joint origins + foot origin of a leg in the base frame (for RIGID_BODY_POS after the last substep)
 QA_DEV void leg_origins(const float q[3], const float *tbl, V3 out[4]) {
     float s1, c1, s2, c2, s23, c23;
-    sincosf(q[0], &s1, &c1); sincosf(q[1], &s2, &c2); sincosf(q[1] + q[2], &s23, &c23);
+    __sincosf(q[0], &s1, &c1); __sincosf(q[1], &s2, &c2); __sincosf(q[1] + q[2], &s23, &c23);
     M3 R0, R1, R2;
     R0.m[0] = 1; R0.m[1] = 0; R0.m[2] = 0; R0.m[3] = 0; R0.m[4] = c1; R0.m[5] = -s1; R0.m[6] = 0; R0.m[7] = s1; R0.m[8] = c1;
     R1.m[0] = c2; R1.m[1] = 0; R1.m[2] = s2; R1.m[3] = s1 * s2; R1.m[4] = c1; R1.m[5] = -s1 * c2; R1.m[6] = -c1 * s2; R1.m[7] = s1; R1.m[8] = c1 * c2;

@@ -58,7 +58,7 @@ static void make_layout(const qa_config *cfg, Layout *L) {
         {QA_T_MOTOR_STRENGTH, QA_F32, 3, 2, N, 12}, {QA_T_MASS_PARAMS, QA_F32, 2, N, 4, 1},
         {QA_T_FRICTION, QA_F32, 1, N, 1, 1}, {QA_T_ENV_ORIGINS, QA_F32, 2, N, 3, 1},
         {QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1}, {QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1},
-        {QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1},
+        {QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1}, {QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3},
     };
     static_assert(sizeof(specs) / sizeof(specs[0]) == QA_T_COUNT, "every tensor needs a spec");
     memset(L, 0, sizeof(*L));
@@ -77,7 +77,7 @@ struct Ptrs {
     float *root, *dof, *cforce, *rbpos, *torques, *torques_org, *actions, *last_actions, *last_dof_vel,
         *last_torques_org, *last_root_vel, *action_hist, *obs_hist, *obs, *obs_disc, *obs_disc_term, *commands,
         *latent_eps, *latent_c, *rew, *episode_sums, *episode_stats, *feet_force, *base_lin_vel, *base_ang_vel,
-        *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap;
+        *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap, *foot_impulse;
     int64_t *reset, *episode_length;
     uint8_t *time_out, *last_contacts, *contact_filt;
 };
@@ -187,6 +187,7 @@ struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int de
 __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_stage[ENVS_PER_BLOCK * S_ENV];
+    __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     stage_table(s_tbl);
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
@@ -258,21 +259,39 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
 
     // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
+    // per-step constants are parked in per-lane LDS slots between substeps so that they do not hold VGPRs
+    // through the substep (the substep alone needs ~340 registers)
+    float *priv = s_priv + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lr(priv, QA_PRIV_STEP + k) = act[k]; lr(priv, QA_PRIV_STEP + 3 + k) = sp[k]; lr(priv, QA_PRIV_STEP + 6 + k) = sd[k]; }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) lr(priv, QA_PRIV_STEP + 9 + i) = binert[i];
     float tau[3], tau_org[3];
     ContactOut co;
+    float fimp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
     for (int d = 0; d < c.decimation; ++d) {
+        // compiler fence: without it LICM hoists the ~120 loop-invariant LDS table reads of the substep out of this
+        // loop and keeps them in registers across it, which is what pushed the kernel into scratch
+        asm volatile("" ::: "memory");
+        float bi[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) bi[i] = lr(priv, QA_PRIV_STEP + 9 + i);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float as = act[k] * c.action_scale;
+            float as = lr(priv, QA_PRIV_STEP + k) * c.action_scale;
             if (k == 0) as *= c.hip_scale_reduction;
-            float t = c.randomize_motor ? sp[k] * c.kp * (as + q0[k] - st.q[k]) - sd[k] * c.kd * st.qd[k]
+            float t = c.randomize_motor ? lr(priv, QA_PRIV_STEP + 3 + k) * c.kp * (as + q0[k] - st.q[k]) - lr(priv, QA_PRIV_STEP + 6 + k) * c.kd * st.qd[k]
                                         : c.kp * (as + q0[k] - st.q[k]) - c.kd * st.qd[k];
             tau_org[k] = t;
             float lim = tbl[T_EFFORT + k];
             tau[k] = clampf(t, -lim, lim);
         }
-        phys_substep<true>(st, tbl, btbl, binert, tau, mu, leg, P, co);
+        phys_substep<true>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp);
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
 
     // ---- refresh_*: body positions of the new state, contact forces per body
     V3 org[4];
@@ -517,6 +536,8 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             p.last_actions[j] = act[k]; p.last_dof_vel[j] = st.qd[k]; p.last_torques_org[j] = tau_org[k];   // :158-161
         }
         p.feet_force[(int64_t)env * 4 + leg] = ffn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = reset ? 0.f : fimp[k];
         p.last_contacts[(int64_t)env * 4 + leg] = contact;
         p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
 #pragma unroll
@@ -529,36 +550,50 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     }
     __syncthreads();
 
-    // ---- wave-cooperative row writes: history shift, obs row, disc rows (256 B per instruction)
+    // ---- wave-cooperative row writes: history shift, obs row, disc rows (256 B per instruction).
+    // Four envs are in flight at a time: all 36 history loads of a group are issued before its stores, so the
+    // wave pays the HBM latency 4 times per block instead of 16.
     const float clipo = c.clip_obs;
-    for (int e = 0; e < ENVS_PER_BLOCK; ++e) {
-        const int ge = blockIdx.x * ENVS_PER_BLOCK + e;
-        if (ge >= N) break;
-        const float *ss = s_stage + e * S_ENV;
-        const bool rf = ss[S_FLAGS] != 0.f, rs = ss[S_FLAGS + 1] != 0.f;
-        float *hist = p.obs_hist + (int64_t)ge * 570, *ob = p.obs + (int64_t)ge * QA_NUM_OBS;
-        float hv[9];
+#define OBS_GROUP 4
+    for (int e0 = 0; e0 < ENVS_PER_BLOCK; e0 += OBS_GROUP) {
+        float hv[OBS_GROUP][9];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            int i = threadIdx.x + QA_BLOCK * r;          // new history index
-            float v = 0.f;
-            if (i < 570) {
-                int slot = i / 57, k = i - slot * 57;
-                v = (rf || slot == 9) ? ss[S_PROP + k] : hist[i + 57];
+        for (int g = 0; g < OBS_GROUP; ++g) {
+            const int e = e0 + g, ge = blockIdx.x * ENVS_PER_BLOCK + e;
+            const float *ss = s_stage + e * S_ENV;
+            const bool rf = ss[S_FLAGS] != 0.f;
+            const float *hist = p.obs_hist + (int64_t)min(ge, N - 1) * 570;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                int i = threadIdx.x + QA_BLOCK * r;          // new history index
+                float v = 0.f;
+                if (i < 570) {
+                    int slot = i / 57, k = i - slot * 57;
+                    v = (rf || slot == 9) ? ss[S_PROP + k] : hist[i + 57];
+                }
+                hv[g][r] = clampf(v, -clipo, clipo);
             }
-            hv[r] = clampf(v, -clipo, clipo);
         }
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            int i = threadIdx.x + QA_BLOCK * r;
-            if (i < 570) { hist[i] = hv[r]; ob[90 + i] = hv[r]; }
-        }
-        for (int i = threadIdx.x; i < 90; i += QA_BLOCK) ob[i] = clampf(ss[S_HEAD + i], -clipo, clipo);
-        if (threadIdx.x < 11) ob[660 + threadIdx.x] = clampf(ss[S_TAIL + threadIdx.x], -clipo, clipo);
-        if (threadIdx.x < QA_NUM_OBS_DISC) {
-            float dv = ss[S_DISC + threadIdx.x];
-            p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = dv;
-            p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = rs ? ss[S_DISCT + threadIdx.x] : dv;
+        for (int g = 0; g < OBS_GROUP; ++g) {
+            const int e = e0 + g, ge = blockIdx.x * ENVS_PER_BLOCK + e;
+            if (ge < N) {
+                const float *ss = s_stage + e * S_ENV;
+                const bool rs = ss[S_FLAGS + 1] != 0.f;
+                float *hist = p.obs_hist + (int64_t)ge * 570, *ob = p.obs + (int64_t)ge * QA_NUM_OBS;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    int i = threadIdx.x + QA_BLOCK * r;
+                    if (i < 570) { hist[i] = hv[g][r]; ob[90 + i] = hv[g][r]; }
+                }
+                for (int i = threadIdx.x; i < 90; i += QA_BLOCK) ob[i] = clampf(ss[S_HEAD + i], -clipo, clipo);
+                if (threadIdx.x < 11) ob[660 + threadIdx.x] = clampf(ss[S_TAIL + threadIdx.x], -clipo, clipo);
+                if (threadIdx.x < QA_NUM_OBS_DISC) {
+                    float dv = ss[S_DISC + threadIdx.x];
+                    p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = dv;
+                    p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = rs ? ss[S_DISCT + threadIdx.x] : dv;
+                }
+            }
         }
     }
 }
@@ -632,7 +667,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptr
     for (int k = 0; k < 3; ++k) {
         const int64_t j = (int64_t)env * 12 + 3 * leg + k;
         d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
-        p.last_actions[j] = 0.f; p.last_dof_vel[j] = 0.f; p.last_torques_org[j] = 0.f;
+        p.last_actions[j] = 0.f; p.last_dof_vel[j] = 0.f; p.last_torques_org[j] = 0.f; p.foot_impulse[j] = 0.f;
         for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) p.action_hist[(int64_t)env * 96 + 12 * r + 3 * leg + k] = 0.f;
     }
     for (int i = leg; i < 570; i += 4) p.obs_hist[(int64_t)env * 570 + i] = 0.f;
@@ -640,6 +675,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptr
 
 __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
+    __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     stage_table(s_tbl);
     const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, leg = threadIdx.x & 3, N = c.num_envs;
     const bool valid = (tid >> 2) < N;
@@ -654,7 +690,9 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     for (int i = 0; i < 10; ++i) binert[i] = p.base_inertia[(int64_t)env * 10 + i];
     PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity; P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
     ContactOut co;
-    phys_substep<true>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co);
+    float fimp[3];
+    for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
+    phys_substep<true>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp);
     V3 org[4]; leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 z = v3(0, 0, 0);
@@ -671,7 +709,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     cf[3 * (myb + 3)] = co.foot_f.x; cf[3 * (myb + 3) + 1] = co.foot_f.y; cf[3 * (myb + 3) + 2] = co.foot_f.z;
     { V3 w = mul(R, org[3]) + st.pos; rb[3 * (myb + 3)] = w.x; rb[3 * (myb + 3) + 1] = w.y; rb[3 * (myb + 3) + 2] = w.z; }
     float *dd = p.dof + (int64_t)env * 24 + 6 * leg;
-    for (int k = 0; k < 3; ++k) { dd[2 * k] = st.q[k]; dd[2 * k + 1] = st.qd[k]; }
+    for (int k = 0; k < 3; ++k) { dd[2 * k] = st.q[k]; dd[2 * k + 1] = st.qd[k]; p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = fimp[k]; }
     if (leg == 0) {
         float *rt = p.root + (int64_t)env * 13;
         rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
@@ -739,7 +777,7 @@ static void fill_ptrs(qa_sim *s) {
     FP(rew, QA_T_REW); FP(episode_sums, QA_T_EPISODE_SUMS); FP(episode_stats, QA_T_EPISODE_STATS); FP(feet_force, QA_T_FEET_FORCE);
     FP(base_lin_vel, QA_T_BASE_LIN_VEL); FP(base_ang_vel, QA_T_BASE_ANG_VEL); FP(proj_grav, QA_T_PROJECTED_GRAVITY); FP(rpy, QA_T_RPY);
     FP(motor_strength, QA_T_MOTOR_STRENGTH); FP(mass_params, QA_T_MASS_PARAMS); FP(friction, QA_T_FRICTION); FP(env_origins, QA_T_ENV_ORIGINS);
-    FP(base_inertia, QA_T_BASE_INERTIA); FP(prior, QA_T_PRIOR_PARAMETERS); FP(mocap, QA_T_MOCAP_FRAMES);
+    FP(base_inertia, QA_T_BASE_INERTIA); FP(prior, QA_T_PRIOR_PARAMETERS); FP(mocap, QA_T_MOCAP_FRAMES); FP(foot_impulse, QA_T_FOOT_IMPULSE);
 #undef FP
     p.reset = (int64_t *)(a + L.off[QA_T_RESET]); p.episode_length = (int64_t *)(a + L.off[QA_T_EPISODE_LENGTH]);
     p.time_out = (uint8_t *)(a + L.off[QA_T_TIME_OUT]); p.last_contacts = (uint8_t *)(a + L.off[QA_T_LAST_CONTACTS]);

@@ -185,7 +185,7 @@ class LeggedRobotCfg(BaseConfig):
 
         class qa:
             """Solver knobs of THIS build's physics (no reference counterpart)."""
-            solver_iterations = 8
+            solver_iterations = 4
 
 
 class LeggedRobotCfgAlgo(BaseConfig):

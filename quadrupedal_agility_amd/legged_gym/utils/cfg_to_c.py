@@ -29,7 +29,7 @@ def make_qa_config(cfg, seed=1, sim_dt=None):
     c.decimation = int(cfg.control.decimation)
     c.gravity_z = float(cfg.sim.gravity[2])
     qa = getattr(cfg.sim, "qa", None)
-    c.solver_iterations = int(getattr(qa, "solver_iterations", 8))
+    c.solver_iterations = int(getattr(qa, "solver_iterations", 4))
     c.contact_offset = float(cfg.sim.physx.contact_offset)
     c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
     c.ground_friction = float(cfg.terrain.static_friction)

@@ -23,7 +23,7 @@ TOL = {
     "OBS": (3e-3, 1e-3), "OBS_DISC": (3e-3, 1e-3), "OBS_DISC_TERM": (3e-3, 1e-3), "COMMANDS": (1e-6, 1e-6), "LATENT_EPS": (1e-7, 0),
     "LATENT_C": (0, 0), "REW": (2e-4, 1e-3), "RESET": (0, 0), "TIME_OUT": (0, 0), "EPISODE_LENGTH": (0, 0),
     "EPISODE_SUMS": (5e-4, 1e-3), "LAST_CONTACTS": (0, 0), "CONTACT_FILT": (0, 0), "FEET_FORCE": (0.5, 2e-2),
-    "BASE_LIN_VEL": (3e-4, 1e-4), "BASE_ANG_VEL": (3e-4, 1e-4), "PROJECTED_GRAVITY": (1e-5, 1e-5), "RPY": (1e-5, 1e-5),
+    "FOOT_IMPULSE": (3e-3, 2e-2), "BASE_LIN_VEL": (3e-4, 1e-4), "BASE_ANG_VEL": (3e-4, 1e-4), "PROJECTED_GRAVITY": (1e-5, 1e-5), "RPY": (1e-5, 1e-5),
 }
 STATIC = ["MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION", "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS"]
 
