@@ -443,10 +443,23 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     for (int it = 0; it < cfg->solver_iterations; ++it) {
         for (int i = 0; i < nrows; ++i) {
             Row *r = &rows[i];
+            if (r->kind == 1) {
+                /* the two tangent rows of a contact are updated TOGETHER from the velocity left by its normal row
+                 * (block-Jacobi inside the friction pair, Gauss-Seidel everywhere else) */
+                if (i - r->parent != 1) continue;
+                Row *r2 = &rows[i + 1];
+                double res1 = 0, res2 = 0;
+                for (int k = 0; k < 18; ++k) { res1 += r->J[k] * u[k]; res2 += r2->J[k] * u[k]; }
+                double lim = mu * rows[r->parent].lam;
+                double l1 = r->lam - res1 * r->dinv, l2 = r2->lam - res2 * r2->dinv;
+                l1 = l1 < -lim ? -lim : (l1 > lim ? lim : l1); l2 = l2 < -lim ? -lim : (l2 > lim ? lim : l2);
+                double d1 = l1 - r->lam, d2 = l2 - r2->lam; r->lam = l1; r2->lam = l2;
+                for (int k = 0; k < 18; ++k) u[k] += r->W[k] * d1 + r2->W[k] * d2;
+                continue;
+            }
             double res = r->bias; for (int k = 0; k < 18; ++k) res += r->J[k] * u[k];
             double lam = r->lam - res * r->dinv;
-            if (r->kind == 1) { double lim = mu * rows[r->parent].lam; lam = lam < -lim ? -lim : (lam > lim ? lim : lam); }
-            else if (lam < 0) lam = 0;
+            if (lam < 0) lam = 0;
             double dl = lam - r->lam; r->lam = lam;
             for (int k = 0; k < 18; ++k) u[k] += r->W[k] * dl;
         }

@@ -133,18 +133,35 @@ QA_DEV void row_finish(Row &r, const float *G, const float *Linv, const float *B
     r.lam = 0.f;
 }
 
-// Gauss-Seidel update of one row on the lane-local copy (ub, w); lo/hi bound the multiplier
-QA_DEV void row_update(Row &r, float *ub, float *w, float lo, float hi) {
-    float res = r.bias + r.jl[0] * w[0] + r.jl[1] * w[1] + r.jl[2] * w[2];
+// residual of a row with three independent partial sums (short dependency chains: one wave per SIMD has no
+// other wave to hide VALU latency behind)
+QA_DEV float row_residual(const Row &r, const float *ub, const float *w) {
+    float a = fmaf(r.jh[2], ub[2], fmaf(r.jh[1], ub[1], r.jh[0] * ub[0]));
+    float b = fmaf(r.jh[5], ub[5], fmaf(r.jh[4], ub[4], r.jh[3] * ub[3]));
+    float c = fmaf(r.jl[2], w[2], fmaf(r.jl[1], w[1], r.jl[0] * w[0]));
+    return (a + b) + (c + r.bias);
+}
+// Gauss-Seidel update of one contact on the lane-local copy (ub, w): normal row, then the two tangent rows
+// TOGETHER from the velocity the normal row left (pyramid friction |lam_t| <= mu lam_n)
+QA_DEV void contact_update(Row *r, float *ub, float *w, float mu) {
+    {
+        float lam = fmaxf(r[0].lam - row_residual(r[0], ub, w) * r[0].dinv, 0.f);
+        float dl = lam - r[0].lam;
+        r[0].lam = lam;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) res = fmaf(r.jh[i], ub[i], res);
-    float lam = clampf(r.lam - res * r.dinv, lo, hi);
-    float dl = lam - r.lam;
-    r.lam = lam;
+        for (int i = 0; i < 6; ++i) ub[i] = fmaf(r[0].bj[i], dl, ub[i]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) ub[i] = fmaf(r.bj[i], dl, ub[i]);
+        for (int k = 0; k < 3; ++k) w[k] = fmaf(r[0].lj[k], dl, w[k]);
+    }
+    const float lim = mu * r[0].lam;
+    float l1 = clampf(r[1].lam - row_residual(r[1], ub, w) * r[1].dinv, -lim, lim);
+    float l2 = clampf(r[2].lam - row_residual(r[2], ub, w) * r[2].dinv, -lim, lim);
+    float d1 = l1 - r[1].lam, d2 = l2 - r[2].lam;
+    r[1].lam = l1; r[2].lam = l2;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) w[k] = fmaf(r.lj[k], dl, w[k]);
+    for (int i = 0; i < 6; ++i) ub[i] = fmaf(r[2].bj[i], d2, fmaf(r[1].bj[i], d1, ub[i]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] = fmaf(r[2].lj[k], d2, fmaf(r[1].lj[k], d1, w[k]));
 }
 
 // build the three rows (normal, tangent1, tangent2) of a contact at base-frame point p of chain depth `depth`
@@ -407,23 +424,17 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             if (any_foot) {
                 if (foot_on) {
                     const float l0 = rf[0].lam, l1 = rf[1].lam, l2 = rf[2].lam;
-                    row_update(rf[0], ub2, w2, 0.f, 3.0e38f);
-                    float lim = mu * rf[0].lam;
-                    row_update(rf[1], ub2, w2, -lim, lim);
-                    row_update(rf[2], ub2, w2, -lim, lim);
+                    contact_update(rf, ub2, w2, mu);
                     if (!mine) { rf[0].lam = l0; rf[1].lam = l1; rf[2].lam = l2; }
                 }
             }
             if (any_extra) {
                 if (extra_on) {
-                    Row t0, t1, t2;
-                    row_load(priv, QA_PRIV_EXTRA, t0); row_load(priv, QA_PRIV_EXTRA + 20, t1); row_load(priv, QA_PRIV_EXTRA + 40, t2);
-                    t0.lam = re_lam[0]; t1.lam = re_lam[1]; t2.lam = re_lam[2];
-                    row_update(t0, ub2, w2, 0.f, 3.0e38f);
-                    float lim = mu * t0.lam;
-                    row_update(t1, ub2, w2, -lim, lim);
-                    row_update(t2, ub2, w2, -lim, lim);
-                    if (mine) { re_lam[0] = t0.lam; re_lam[1] = t1.lam; re_lam[2] = t2.lam; }
+                    Row t[3];
+                    row_load(priv, QA_PRIV_EXTRA, t[0]); row_load(priv, QA_PRIV_EXTRA + 20, t[1]); row_load(priv, QA_PRIV_EXTRA + 40, t[2]);
+                    t[0].lam = re_lam[0]; t[1].lam = re_lam[1]; t[2].lam = re_lam[2];
+                    contact_update(t, ub2, w2, mu);
+                    if (mine) { re_lam[0] = t[0].lam; re_lam[1] = t[1].lam; re_lam[2] = t[2].lam; }
                 }
             }
             if (any_lim) {

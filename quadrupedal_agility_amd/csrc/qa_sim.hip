@@ -83,6 +83,7 @@ struct Ptrs {
 };
 
 struct qa_sim {
+    long long *prof = nullptr;
     qa_config cfg;
     Layout L;
     char *arena;
@@ -101,7 +102,12 @@ static int fail_hip(hipError_t e, const char *what) {
 
 // ------------------------------------------------------------------ shared device pieces
 __device__ __forceinline__ void stage_table(float *s_tbl) {
-    for (int i = threadIdx.x; i < QA_TBL_FLOATS; i += blockDim.x) s_tbl[i] = c_tbl[i];
+    constexpr int PER = (QA_TBL_FLOATS + QA_BLOCK - 1) / QA_BLOCK;
+    float v[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { int i = threadIdx.x + QA_BLOCK * r; v[r] = (i < QA_TBL_FLOATS) ? c_tbl[i] : 0.f; }   // loads in flight together
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { int i = threadIdx.x + QA_BLOCK * r; if (i < QA_TBL_FLOATS) s_tbl[i] = v[r]; }
     __syncthreads();
 }
 
@@ -174,7 +180,8 @@ __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, con
 }
 
 // ------------------------------------------------------------------ the fused env step
-struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; };
+struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; long long *prof; };
+#define QA_STAMP(k) do { if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 #define S_PROP 0        // 57  proprioception (noise-free)
 #define S_HEAD 57       // 90  obs[0:90] with noise
@@ -183,11 +190,28 @@ struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int de
 #define S_DISCT 207     // 49
 #define S_FLAGS 256     // [0] = refill history (episode length <= 1)
 #define S_ENV 260       // floats of LDS staging per env
+#define S_ROW 672       // assembled observation row per env
+
+// wave-cooperative copy of n floats LDS -> global with 16-byte stores where the destination allows
+__device__ __forceinline__ void copy_row(float *dst, const float *src, int n) {
+    const int head = (int)(((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2);      // floats until dst is 16-B aligned (0..3)
+    const int nvec = (n - head) >> 2;
+    if ((int)threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    float4 *d4 = reinterpret_cast<float4 *>(dst + head);
+    for (int v = threadIdx.x; v < nvec; v += QA_BLOCK) {
+        const float *sp4 = src + head + 4 * v;
+        d4[v] = make_float4(sp4[0], sp4[1], sp4[2], sp4[3]);
+    }
+    const int done = head + 4 * nvec;
+    if ((int)threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}
 
 __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_stage[ENVS_PER_BLOCK * S_ENV];
     __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
+    __shared__ float s_rows[ENVS_PER_BLOCK * S_ROW];
+    QA_STAMP(0);
     stage_table(s_tbl);
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
@@ -233,6 +257,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         }
     }
 
+    QA_STAMP(1);
     // ---- load state
     EnvState st;
     {
@@ -258,6 +283,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity;
     P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
 
+    QA_STAMP(2);
     // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
     // per-step constants are parked in per-lane LDS slots between substeps so that they do not hold VGPRs
     // through the substep (the substep alone needs ~340 registers)
@@ -293,6 +319,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
 
+    QA_STAMP(3);
     // ---- refresh_*: body positions of the new state, contact forces per body
     V3 org[4];
     leg_origins(st.q, tbl, org);
@@ -325,6 +352,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         }
     }
 
+    QA_STAMP(4);
     // =========================== post_physics_step (legged_robot.py:124-166) ===========================
     int64_t epl = p.episode_length[env] + 1;
     const int64_t common = step + 1;
@@ -372,6 +400,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     }
     const int reset = term_c | timeout;
 
+    QA_STAMP(5);
     // ---- rewards :242-259, alphabetical order
     float term[QA_NUM_REWARDS];
     {
@@ -416,6 +445,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     }
     if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
 
+    QA_STAMP(6);
     // ---- terminal disc obs = previous OBS_DISC row; stage it
     float *sst = s_stage + le * S_ENV;
     for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
@@ -438,6 +468,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     }
     const bool refill = epl <= 1;
 
+    QA_STAMP(7);
     // ---- observations :261-331
     // heading-inverse rotation of the (stale for reset envs) foot position, torch_jit_utils.py:23-76
     V3 key;
@@ -508,6 +539,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             }
         }
     }
+    QA_STAMP(8);
     // ---- per-env scalars and small rows, written by the quad
     if (valid) {
         float *rt = p.root + (int64_t)env * 13;
@@ -550,52 +582,54 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     }
     __syncthreads();
 
-    // ---- wave-cooperative row writes: history shift, obs row, disc rows (256 B per instruction).
-    // Four envs are in flight at a time: all 36 history loads of a group are issued before its stores, so the
-    // wave pays the HBM latency 4 times per block instead of 16.
+    QA_STAMP(9);
+    // ---- wave-cooperative row writes.  The complete 671-float observation row of every env of the block is
+    // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
+    // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
 #define OBS_GROUP 4
     for (int e0 = 0; e0 < ENVS_PER_BLOCK; e0 += OBS_GROUP) {
         float hv[OBS_GROUP][9];
 #pragma unroll
+        for (int g = 0; g < OBS_GROUP; ++g) {          // all history loads of the group in flight first
+            const int e = e0 + g; const int ge = min((int)(blockIdx.x * ENVS_PER_BLOCK) + e, N - 1);
+            const float *hist = p.obs_hist + (int64_t)ge * 570 + 57;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) { int i = threadIdx.x + QA_BLOCK * r; hv[g][r] = (i < 513) ? hist[i] : 0.f; }
+        }
+#pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
-            const int e = e0 + g, ge = blockIdx.x * ENVS_PER_BLOCK + e;
+            const int e = e0 + g;
             const float *ss = s_stage + e * S_ENV;
+            float *row = s_rows + e * S_ROW;
             const bool rf = ss[S_FLAGS] != 0.f;
-            const float *hist = p.obs_hist + (int64_t)min(ge, N - 1) * 570;
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
-                int i = threadIdx.x + QA_BLOCK * r;          // new history index
-                float v = 0.f;
-                if (i < 570) {
-                    int slot = i / 57, k = i - slot * 57;
-                    v = (rf || slot == 9) ? ss[S_PROP + k] : hist[i + 57];
-                }
-                hv[g][r] = clampf(v, -clipo, clipo);
+                int i = threadIdx.x + QA_BLOCK * r;       // history index 0..512 = slots 0..8
+                if (i < 513) row[90 + i] = clampf(rf ? ss[S_PROP + (i % 57)] : hv[g][r], -clipo, clipo);
             }
-        }
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {
-            const int e = e0 + g, ge = blockIdx.x * ENVS_PER_BLOCK + e;
-            if (ge < N) {
-                const float *ss = s_stage + e * S_ENV;
-                const bool rs = ss[S_FLAGS + 1] != 0.f;
-                float *hist = p.obs_hist + (int64_t)ge * 570, *ob = p.obs + (int64_t)ge * QA_NUM_OBS;
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {
-                    int i = threadIdx.x + QA_BLOCK * r;
-                    if (i < 570) { hist[i] = hv[g][r]; ob[90 + i] = hv[g][r]; }
-                }
-                for (int i = threadIdx.x; i < 90; i += QA_BLOCK) ob[i] = clampf(ss[S_HEAD + i], -clipo, clipo);
-                if (threadIdx.x < 11) ob[660 + threadIdx.x] = clampf(ss[S_TAIL + threadIdx.x], -clipo, clipo);
-                if (threadIdx.x < QA_NUM_OBS_DISC) {
-                    float dv = ss[S_DISC + threadIdx.x];
-                    p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = dv;
-                    p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = rs ? ss[S_DISCT + threadIdx.x] : dv;
-                }
-            }
+            if (threadIdx.x < 57) row[90 + 513 + threadIdx.x] = clampf(ss[S_PROP + threadIdx.x], -clipo, clipo);
+            for (int i = threadIdx.x; i < 90; i += QA_BLOCK) row[i] = clampf(ss[S_HEAD + i], -clipo, clipo);
+            if (threadIdx.x < 11) row[660 + threadIdx.x] = clampf(ss[S_TAIL + threadIdx.x], -clipo, clipo);
         }
     }
+    QA_STAMP(11);
+    __syncthreads();
+    QA_STAMP(12);
+    for (int e = 0; e < ENVS_PER_BLOCK; ++e) {
+        const int ge = blockIdx.x * ENVS_PER_BLOCK + e;
+        if (ge >= N) break;
+        const float *row = s_rows + e * S_ROW;
+        copy_row(p.obs + (int64_t)ge * QA_NUM_OBS, row, QA_NUM_OBS);
+        copy_row(p.obs_hist + (int64_t)ge * 570, row + 90, 570);
+        if (threadIdx.x < QA_NUM_OBS_DISC) {
+            const float *ss = s_stage + e * S_ENV;
+            float dv = ss[S_DISC + threadIdx.x];
+            p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = dv;
+            p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + threadIdx.x] : dv;
+        }
+    }
+    QA_STAMP(10);
 }
 
 // ------------------------------------------------------------------ init / reset / simulate kernels
@@ -861,7 +895,7 @@ static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; memcpy(m.first, s->moca
 
 int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t global_step, void *stream) {
     if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
-    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step;
+    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step; a.prof = s->prof;
     const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     hipLaunchKernelGGL(qa_env_step_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -883,6 +917,9 @@ int qa_simulate(qa_sim *s, const float *torques, void *stream) {
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }
+
+/* development aid (not part of include/qa_sim.h): per-block s_memtime stamps of the env-step phases, 16 slots per block */
+int qa_debug_set_profile_buffer(qa_sim *s, long long *dev_buf) { if (!s) return QA_E_ARG; s->prof = dev_buf; return QA_OK; }
 
 int qa_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float *returns,
            float *advantages, int32_t T, int32_t N, float gamma, float lam, int32_t normalize, void *scratch, void *stream) {
