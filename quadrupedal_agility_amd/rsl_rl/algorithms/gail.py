@@ -172,7 +172,7 @@ class SSInfoGAIL:
     def update_actor_critic(self, sample):
         (obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _masks) = sample
         ac = self.actor_critic
-        ac.act(obs.detach())
+        ac.update_distribution(obs.detach(), False)      # the reference calls act() here and discards the sample (gail.py:333)
         logp = ac.get_actions_log_prob(actions)
         value = ac.evaluate(critic_obs.detach())
         mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy

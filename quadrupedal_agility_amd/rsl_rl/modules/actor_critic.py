@@ -114,7 +114,6 @@ class ActorCritic(nn.Module):
         std = init_noise_std * torch.ones(num_actions)
         self.std = std.clone() if fixed_std else nn.Parameter(std)
         self.distribution = None
-        Normal.set_default_validate_args = False
 
     def reset(self, dones=None):
         pass
@@ -149,11 +148,15 @@ class ActorCritic(nn.Module):
 
     def update_distribution(self, observations, hist_encoding: bool):
         mean = self._actor_mean(observations, hist_encoding)
-        self.distribution = Normal(mean, mean * 0.0 + self.std.to(mean.device))
+        # validate_args=False: the reference means to switch validation off (`Normal.set_default_validate_args = False`,
+        # actor_critic.py:148, which as written is a no-op); each validation is a device->host sync per call
+        self.distribution = Normal(mean, mean * 0.0 + self.std.to(mean.device), validate_args=False)
 
     def act(self, observations, hist_encoding=False, **kwargs):
         self.update_distribution(observations, hist_encoding)
-        return self.distribution.sample()
+        d = self.distribution
+        with torch.no_grad():      # == Normal.sample(); torch.normal(tensor, tensor) checks std >= 0 on the host (2 syncs per call)
+            return d.loc + d.scale * torch.randn_like(d.loc)
 
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)
