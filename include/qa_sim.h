@@ -186,6 +186,11 @@ int qa_tensor_info(const qa_config *cfg, int which, int64_t *byte_offset, int64_
  * before this call (common_step_counter); it keys the RNG and triggers pushes. */
 int qa_env_step(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t global_step, void *stream);
 
+/* qa_env_step for recorded launches: the step counter is read from DEVICE memory (one int64) and incremented on the
+ * stream right after the step, so a hipGraph holding N consecutive steps replays without host-side arguments
+ * (the reference keeps `common_step_counter` on the host, legged_robot.py:134). */
+int qa_env_step_dev(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t *step_counter_dev, void *stream);
+
 /* reset_idx(all) followed by nothing else (legged_robot.py:67-69).  The reference's reset()
  * then takes one zero-action step; the host mirror does that through qa_env_step. */
 int qa_reset_all(qa_sim *sim, int64_t global_step, void *stream);

@@ -898,6 +898,13 @@ int qo_env_step(qo_sim *s, const float *actions, int32_t delay_steps, int64_t st
     return QA_OK;
 }
 
+int qo_env_step_dev(qo_sim *s, const float *actions, int32_t delay_steps, int64_t *step_counter, void *stream) {
+    if (!step_counter) return QA_E_ARG;
+    int rc = qo_env_step(s, actions, delay_steps, *step_counter, stream);
+    if (rc == QA_OK) *step_counter += 1;
+    return rc;
+}
+
 /* GAE: rollout_storage.py:97-111 (fp32 like the reference; mean/std accumulated in double) */
 int qo_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
            float *returns, float *advantages, int32_t T, int32_t N, float gamma, float lam, int32_t normalize,

@@ -85,6 +85,7 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "destroy"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "tensor_info"); f.argtypes = [P(QaConfig), C.c_int, P(C.c_int64), C.c_int64 * 3, P(C.c_int32), P(C.c_int32)]; f.restype = C.c_int
     f = getattr(lib, prefix + "env_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "env_step_dev"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "reset_all"); f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "simulate"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "set_mocap"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]; f.restype = C.c_int
@@ -92,7 +93,7 @@ def bind(lib, prefix):
     return lib
 
 
-ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "reset_all", "simulate",
+ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "last_error", "abi_version"]
 
 _LIB = None

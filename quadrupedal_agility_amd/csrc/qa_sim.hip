@@ -180,7 +180,7 @@ __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, con
 }
 
 // ------------------------------------------------------------------ the fused env step
-struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; long long *prof; };
+struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; const int64_t *step_ptr; long long *prof; };
 #define QA_STAMP(k) do { if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 #define S_PROP 0        // 57  proprioception (noise-free)
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     const int le = threadIdx.x >> 2;                 // env slot inside the block
     const float *tbl = s_tbl + leg * QA_LEG_TBL;
     const float *btbl = s_tbl + 4 * QA_LEG_TBL;
-    const int64_t step = a.step;
+    const int64_t step = a.step_ptr ? *a.step_ptr : a.step;
 
     if (blockIdx.x == 0 && threadIdx.x < 16) p.episode_stats[16 * ((step + 1) & 1) + threadIdx.x] = 0.f;   // next step's bin
 
@@ -895,9 +895,22 @@ static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; memcpy(m.first, s->moca
 
 int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t global_step, void *stream) {
     if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
-    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step; a.prof = s->prof;
+    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step; a.step_ptr = nullptr; a.prof = s->prof;
     const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     hipLaunchKernelGGL(qa_env_step_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+__global__ void qa_tick_kernel(int64_t *ctr) { *ctr += 1; }
+
+int qa_env_step_dev(qa_sim *s, const float *actions, int32_t delay_steps, int64_t *step_counter_dev, void *stream) {
+    if (!s || !actions || !step_counter_dev || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = 0;
+    a.step_ptr = step_counter_dev; a.prof = s->prof;
+    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    hipLaunchKernelGGL(qa_env_step_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(qa_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter_dev);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }

@@ -82,6 +82,7 @@ class LeggedRobot:
         self.delay = 0
         self._delay_schedule = list(getattr(cfg.domain_rand, "action_curr_step", []))
         self.sync_reset_ids = True      # False: step() returns (None, None) for the last two outputs, no host sync
+        self._step_ctr = None           # device-side step counter (graph-replayable stepping), see use_device_step_counter()
 
     # ------------------------------------------------------------------ config
     def _parse_cfg(self):
@@ -231,8 +232,11 @@ class LeggedRobot:
             delay = 0
         self.global_counter += 1
         a = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        self.sim.global_step = self.common_step_counter
-        self.sim.step(a, delay)
+        if self._step_ctr is not None:
+            self.sim.step_dev(a, delay, self._step_ctr)       # counter read + incremented on the device
+        else:
+            self.sim.global_step = self.common_step_counter
+            self.sim.step(a, delay)
         self.common_step_counter += 1
         self._fill_extras()
         if self.sync_reset_ids:
@@ -241,6 +245,24 @@ class LeggedRobot:
         else:
             env_ids, terminal = None, None
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras, env_ids, terminal
+
+    def use_device_step_counter(self):
+        """Keep `common_step_counter` ALSO in device memory so that recorded (hipGraph) rollouts can replay without
+        host arguments; the host integer stays the authority for logging and is advanced by the caller on replay."""
+        if self._step_ctr is None:
+            self._step_ctr = torch.tensor([self.common_step_counter], dtype=torch.int64, device=self.device)
+        return self._step_ctr
+
+    def advance_host_counters(self, n):
+        self.common_step_counter += n
+        self.global_counter += n
+
+    def steps_until_delay_change(self):
+        """Number of steps that can be taken before the action-delay schedule fires again (legged_robot.py:87-93)."""
+        if not self.cfg.domain_rand.action_delay or not self._delay_schedule:
+            return 1 << 62
+        period = self.cfg.domain_rand.delay_update_global_steps
+        return (-self.global_counter) % period if self.global_counter % period else 0
 
     def _fill_extras(self):
         """extras['episode'] / extras['time_outs'] of reset_idx (legged_robot.py:229-240) without a host sync:

@@ -53,7 +53,7 @@ class Discriminator(nn.Module):
     def predict_disc_reward(self, reward_t, obs, obs_disc, normalizer=None):
         label_eps = obs[:, -self.dim_c - 1].unsqueeze(-1)
         label_c = F.one_hot(torch.argmax(obs[:, -self.dim_c:], dim=-1), num_classes=self.dim_c)
-        x = self.prepare_input(obs_disc, self.env.task_obs_weight)
+        x = self.prepare_input(obs_disc, getattr(self.env, "task_obs_weight_dev", None) if getattr(self.env, "task_obs_weight_dev", None) is not None else self.env.task_obs_weight)
         with torch.no_grad():
             self.eval()
             if normalizer is not None:

@@ -126,14 +126,19 @@ class SSInfoGAIL:
         tr.critic_observations = critic_obs
         return tr.actions
 
-    def process_env_step(self, rewards, dones, infos, obs_disc_history_buf):
+    def process_env_step(self, rewards, dones, infos, obs_disc_history_buf, disc_stage=None):
         tr = self.transition
         tr.rewards = rewards.clone()
         tr.dones = dones
         if "time_outs" in infos:        # bootstrap on time-outs (gail.py:203-205)
             tr.rewards += self.gamma * torch.squeeze(tr.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
         if self.amp_enabled:
-            self.disc_storage.insert(obs_disc_history_buf.view(obs_disc_history_buf.shape[0], -1), self.env.latent_eps, self.env.latent_c)
+            flat = obs_disc_history_buf.view(obs_disc_history_buf.shape[0], -1)
+            if disc_stage is not None:          # recorded rollout: the ring position is a host variable, so stage and insert after replay
+                t = self.storage.step
+                disc_stage[0][t].copy_(flat); disc_stage[1][t].copy_(self.env.latent_eps); disc_stage[2][t].copy_(self.env.latent_c)
+            else:
+                self.disc_storage.insert(flat, self.env.latent_eps, self.env.latent_c)
         self.storage.add_transitions(tr)
         self.actor_critic.reset(dones)
 
@@ -296,7 +301,7 @@ class SSInfoGAIL:
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.step()
         if not self.actor_critic.fixed_std and self.min_std is not None:
-            self.actor_critic.std.data = self.actor_critic.std.data.clamp(min=self.min_std)
+            self.actor_critic.std.data.clamp_(min=self.min_std)       # in place: recorded rollouts keep reading this buffer
         if self.disc_normalizer is not None:
             self.disc_normalizer.update_torch([policy_state, expert_lb, expert_ulb])
         with torch.no_grad():

@@ -177,6 +177,97 @@ class OnPolicyRunner:
             advantages.sub_(mean.float()).div_(std.float() + 1e-8)
         return gae
 
+    # ------------------------------------------------------------------ rollout
+    def _alloc_rollout_state(self):
+        env, dev, N, T = self.env, self.device, self.env.num_envs, self.num_steps_per_env
+        self._obs_cur = env.get_observations().to(dev).clone()
+        d = env.get_disc_observations().to(dev)
+        self._disc_hist = torch.stack([d] * self.disc_obs_len, dim=1).clone()
+        self._cur = torch.zeros(6, N, device=dev)                # running sums: total, i, us, ss, t, length
+        self._fin_vals = torch.zeros(T, 6, N, device=dev)
+        self._fin_mask = torch.zeros(T, N, dtype=torch.bool, device=dev)
+        self._zeros_n = torch.zeros(N, device=dev)
+        self._disc_stage = None
+        if self.amp_enabled:
+            self._disc_stage = (torch.zeros(T, N, env.num_obs_disc * self.disc_obs_len, device=dev), torch.zeros(T, N, 1, device=dev),
+                                torch.zeros(T, N, env.dim_c, device=dev))
+        self._graph, self._graph_delay, self._graph_ep_infos = None, None, None
+        self._graph_failed = False
+
+    def _rollout_steps(self, hist_encoding, logging, recorded):
+        """The 24 env steps of one iteration (on_policy_runner.py:155-206).  Reads/writes only persistent tensors, so the
+        same code runs eagerly or is recorded once into a hipGraph and replayed."""
+        env, alg, T = self.env, self.alg, self.num_steps_per_env
+        obs, hist, cur = self._obs_cur, self._disc_hist, self._cur
+        ep_infos = []
+        for i in range(T):
+            actions = alg.act(obs, obs, hist_encoding)
+            next_obs, _, rewards, dones, infos, _, _ = env.step(actions)
+            done_mask = dones > 0
+            if self.amp_enabled:
+                # the frame pair seen by the discriminator ends with the TERMINAL frame for envs that reset (:168-172)
+                hist = torch.cat([hist[:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
+                rewards, r_i, r_us, r_ss, r_t = alg.disc.predict_disc_reward(rewards.unsqueeze(1), obs, hist, normalizer=alg.disc_normalizer)
+            else:
+                r_t = rewards
+                rewards = self.reward_t_coef * rewards
+                r_i = r_us = r_ss = self._zeros_n
+            alg.process_env_step(rewards, dones.to(torch.uint8), infos, hist, disc_stage=self._disc_stage if recorded else None)
+            obs = next_obs.clone()
+            if self.amp_enabled:
+                fresh = torch.stack([env.get_disc_observations()] * self.disc_obs_len, dim=1)
+                hist = torch.where(done_mask[:, None, None], fresh, hist)
+            if logging:
+                if "episode" in infos:
+                    ep_infos.append(dict(infos["episode"]))
+                cur = cur + torch.stack([rewards, r_i, r_us, r_ss, r_t, torch.ones_like(rewards)])
+                self._fin_vals[i].copy_(cur)
+                self._fin_mask[i].copy_(done_mask)
+                cur = cur * (~done_mask)
+        self._obs_cur.copy_(obs)
+        self._disc_hist.copy_(hist)
+        self._cur.copy_(cur)
+        return ep_infos
+
+    def _collect(self, hist_encoding, logging):
+        """One rollout.  On the GPU the non-DAgger variant is recorded into a hipGraph the second time it runs and replayed
+        from then on: ~2,400 launches per rollout become one graph launch (the rollout is launch-bound: the fused env step
+        is 0.1 ms, the ~100 small inference/bookkeeping kernels around it 0.6 ms of host time per step)."""
+        env, alg, T = self.env, self.alg, self.num_steps_per_env
+        can_graph = (self.use_rollout_graph and not self._graph_failed and not hist_encoding and self._eager_rollouts >= 1
+                     and env.steps_until_delay_change() >= T)
+        if can_graph and self._graph is not None and self._graph_delay == env.delay:
+            self._graph.replay()
+            env.advance_host_counters(T)
+            alg.storage.step = T
+            ep_infos = self._graph_ep_infos
+        elif can_graph:
+            try:
+                with torch.inference_mode():
+                    alg.act(self._obs_cur, self._obs_cur, False)          # touch every GEMM shape once outside the capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                alg.storage.step = 0
+                with torch.cuda.graph(g):
+                    with torch.inference_mode():
+                        ep_infos = self._rollout_steps(False, logging, recorded=True)    # host side effects run now, GPU work on replay
+                self._graph, self._graph_delay, self._graph_ep_infos = g, env.delay, ep_infos
+                g.replay()
+            except Exception as e:      # never fatal: fall back to eager launches
+                print(f"[rollout graph] capture failed, staying eager: {e}")
+                self._graph, self._graph_failed = None, True
+                torch.cuda.synchronize()
+                return self._collect(hist_encoding, logging)
+        else:
+            with torch.inference_mode():
+                ep_infos = self._rollout_steps(hist_encoding, logging, recorded=False)
+            self._eager_rollouts += 1
+            return ep_infos
+        if self.amp_enabled:            # ring insert of the staged (T*N) discriminator samples, in step order
+            st = self._disc_stage
+            alg.disc_storage.insert(st[0].flatten(0, 1), st[1].flatten(0, 1), st[2].flatten(0, 1))
+        return ep_infos
+
     # ------------------------------------------------------------------ learn
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         env, alg, dev = self.env, self.alg, self.device
@@ -184,68 +275,49 @@ class OnPolicyRunner:
             self.writer = _make_writer(self.log_dir)
         if init_at_random_ep_len:
             env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
-        obs = env.get_observations().to(dev).clone()
-        disc_obs = env.get_disc_observations().to(dev)
-        obs_disc_history_buf = torch.stack([disc_obs] * self.disc_obs_len, dim=1)
+        if not hasattr(self, "_obs_cur"):
+            self._alloc_rollout_state()
+            self._eager_rollouts = 0
+            on_gpu = torch.device(dev).type == "cuda"
+            self.use_rollout_graph = on_gpu and bool(self.cfg.get("rollout_graph", True)) and os.environ.get("QA_ROLLOUT_GRAPH", "1") != "0"
+            if self.use_rollout_graph:
+                env.use_device_step_counter()
+                if self.amp_enabled:
+                    env.task_obs_weight_dev = torch.tensor(float(env.task_obs_weight), device=dev)
         alg.actor_critic.train()
         alg.disc.train()
         N, T = env.num_envs, self.num_steps_per_env
         logging = self.log_dir is not None
-        ep_infos = []
-        buffers = {k: deque(maxlen=100) for k in ("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")}
-        cur = torch.zeros(6, N, device=dev)                 # running sums: total, i, us, ss, t, length
-        fin_vals = torch.zeros(T, 6, N, device=dev)
-        fin_mask = torch.zeros(T, N, dtype=torch.bool, device=dev)
-        zeros_n = torch.zeros(N, device=dev)
+        if not hasattr(self, "_buffers"):
+            self._buffers = {k: deque(maxlen=100) for k in ("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")}
+        buffers = self._buffers
         mean_hist_latent_loss = 0.0
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             self._sync()
             start = time.time()
             hist_encoding = it % self.dagger_update_freq == 0
+            ep_infos = self._collect(hist_encoding, logging)
+            self._sync()
+            stop = time.time()
+            collection_time = stop - start
+            start = stop
             with torch.inference_mode():
-                for i in range(T):
-                    actions = alg.act(obs, obs, hist_encoding)
-                    next_obs, _, rewards, dones, infos, _, _ = env.step(actions)
-                    done_mask = dones > 0
-                    if self.amp_enabled:
-                        # the frame pair seen by the discriminator ends with the TERMINAL frame for envs that reset (:168-172)
-                        obs_disc_history_buf = torch.cat([obs_disc_history_buf[:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
-                        rewards, r_i, r_us, r_ss, r_t = alg.disc.predict_disc_reward(
-                            rewards.unsqueeze(1), obs, obs_disc_history_buf, normalizer=alg.disc_normalizer)
-                    else:
-                        r_t = rewards
-                        rewards = self.reward_t_coef * rewards
-                        r_i = r_us = r_ss = zeros_n
-                    alg.process_env_step(rewards, dones.to(torch.uint8), infos, obs_disc_history_buf)
-                    obs = next_obs.clone()
-                    if self.amp_enabled:
-                        fresh = torch.stack([env.get_disc_observations()] * self.disc_obs_len, dim=1)
-                        obs_disc_history_buf = torch.where(done_mask[:, None, None], fresh, obs_disc_history_buf)
-                    if logging:
-                        if "episode" in infos:
-                            ep_infos.append(dict(infos["episode"]))
-                        cur += torch.stack([rewards, r_i, r_us, r_ss, r_t, torch.ones_like(rewards)])
-                        fin_vals[i] = cur
-                        fin_mask[i] = done_mask
-                        cur = cur * (~done_mask)
-                self._sync()
-                stop = time.time()
-                collection_time = stop - start
-                start = stop
-                alg.compute_returns(obs)
+                alg.compute_returns(self._obs_cur)
             losses = alg.update()
             if hist_encoding:
                 mean_hist_latent_loss = alg.update_dagger()
             if env.task_obs_weight_decay_steps:
                 env.task_obs_weight = max(0, env.task_obs_weight - 1.0 / env.task_obs_weight_decay_steps)
+                if getattr(env, "task_obs_weight_dev", None) is not None:
+                    env.task_obs_weight_dev.fill_(float(env.task_obs_weight))
             self._sync()
             stop = time.time()
             learn_time = stop - start
             self.last_perf = {"collection_time": collection_time, "learn_time": learn_time,
                               "fps": T * N / (collection_time + learn_time)}
             if logging:
-                vals = fin_vals.permute(0, 2, 1)[fin_mask].cpu().numpy()       # (n_finished, 6) in (step, env) order
+                vals = self._fin_vals.permute(0, 2, 1)[self._fin_mask].cpu().numpy()       # (n_finished, 6) in (step, env) order
                 for col, k in enumerate(("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")):
                     buffers[k].extend(vals[:, col].tolist())
                 if self.rank == 0:
@@ -253,7 +325,6 @@ class OnPolicyRunner:
                                   losses=losses, mean_hist_latent_loss=mean_hist_latent_loss, buffers=buffers))
                 if (it + 1) % self.save_interval == 0 and self.rank == 0:
                     self.save(os.path.join(self.log_dir, "model.pt"))
-            ep_infos.clear()
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None and self.rank == 0:
             self.save(os.path.join(self.log_dir, "model.pt"))

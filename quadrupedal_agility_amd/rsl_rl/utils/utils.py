@@ -106,9 +106,9 @@ class TorchNormalizer:
             delta = bm - self.mean
             total = self.count + n
             m2 = self.var * self.count + bv * n + torch.square(delta) * self.count * n / total
-            self.mean = self.mean + delta * n / total
-            self.var = m2 / total
-            self.count = total
+            self.mean.add_(delta * n / total)          # in place: recorded launches keep reading the same buffers
+            self.var.copy_(m2 / total)
+            self.count.copy_(total)
 
     def update(self, arr):
         self.update_torch([torch.as_tensor(arr, device=self.device)])

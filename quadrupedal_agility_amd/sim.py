@@ -64,6 +64,13 @@ class QaSim:
                self.lib, "qa_env_step")
         self.global_step += 1
 
+    def step_dev(self, actions, delay, step_counter):
+        """qa_env_step_dev: the step counter lives in device memory (graph-replayable)."""
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        assert step_counter.is_cuda and step_counter.dtype == torch.int64
+        _check(self.lib.qa_env_step_dev(self.h, actions.data_ptr(), int(delay), step_counter.data_ptr(), self._stream()),
+               self.lib, "qa_env_step_dev")
+
     def simulate(self, torques):
         assert torques.is_cuda and torques.dtype == torch.float32 and torques.is_contiguous()
         _check(self.lib.qa_simulate(self.h, torques.data_ptr(), self._stream()), self.lib, "qa_simulate")

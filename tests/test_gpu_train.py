@@ -68,6 +68,10 @@ def test_short_training_run_on_gpu(tmp_path, amp):
     assert all(torch.isfinite(v).all() for v in after.values())
     assert any(not torch.equal(before[k], after[k]) for k in before)
     assert runner.last_perf["fps"] > 1e4
+    # the non-DAgger rollouts were replayed from a hipGraph; the device-side step counter tracks the host's
+    assert runner._graph is not None and not runner._graph_failed
+    assert int(env._step_ctr.item()) == env.common_step_counter == 1 + 3 * 24
+    assert runner.alg.storage.step == 0 and torch.isfinite(runner.alg.storage.advantages).all()
     path = os.path.join(runner.log_dir, "model.pt")
     ck = torch.load(path, weights_only=False)
     assert type(ck["disc_normalizer"]).__name__ == "Normalizer"
