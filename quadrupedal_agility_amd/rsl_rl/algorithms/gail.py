@@ -54,7 +54,7 @@ class SSInfoGAIL:
         self.estimator = estimator
         # adaptive learning rate: a device tensor on GPU (no host round trip per minibatch), a float on CPU
         self._lr_ac = torch.tensor(float(lr_ac), device=device) if self._on_gpu else float(lr_ac)
-        adam = dict(fused=True) if self._on_gpu else {}       # one multi-tensor kernel per step; accepts a tensor lr
+        adam = dict(fused=True, capturable=True) if self._on_gpu else {}   # one multi-tensor kernel per step, tensor lr, recordable
         self.optim_ac = optim.Adam([{"params": self.actor_critic.parameters(), "name": "actor_critic"}], lr=self._lr_ac, **adam)
         self.optim_hist_encoder = optim.Adam(self.actor_critic.history_encoder.parameters(), lr=estimator_paras["learning_rate"], **adam)
         self.optim_estimator = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"], **adam)
@@ -82,6 +82,9 @@ class SSInfoGAIL:
         self.info_max_coef_on, self.info_max_coef = 0, info_max_coef
         self.learning_steps, self.begin_rim = 0, begin_rim
         self.grad_sync = None          # callable(list_of_params, extra_scalars) -> None, installed for world_size > 1
+        self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
+        self._disc_graph = None
+        self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
 
     # ---- lr_ac is read by the logger and by checkpoints as a float
     @property
@@ -160,15 +163,63 @@ class SSInfoGAIL:
         acc_d = torch.zeros(11, device=dev)
         if self.amp_enabled:
             mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
-            gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
-                       self.motion_loader.feed_forward_generator_lb(n_d, mb),
-                       self.motion_loader.feed_forward_generator_ulb(n_d, mb))
-            for s_pi, s_lb, s_ulb in gens:
-                acc_d += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
+            if self._on_gpu and self.use_update_graph and self.grad_sync is None and self.learning_steps >= 2 and self._disc_graph is not False:
+                acc_d = self._disc_updates_recorded(n_d, mb)
+            else:
+                gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
+                           self.motion_loader.feed_forward_generator_lb(n_d, mb),
+                           self.motion_loader.feed_forward_generator_ulb(n_d, mb))
+                for s_pi, s_lb, s_ulb in gens:
+                    acc_d += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
         self.storage.clear()
         self.priv_reg_counter += 1
         out = torch.cat([acc_ac / n_ac, acc_d / n_d]).tolist()      # the one host read of the update
         return tuple(out)
+
+    def _disc_updates_recorded(self, n_steps, mb):
+        """The discriminator steps are tiny (3 x 1228 x 98 inputs, ~300 launches each, double backward) and therefore
+        launch-bound: one step is recorded into a hipGraph -- sampling included, with the replay-buffer fill level and the
+        info-max coefficient read from device scalars -- and replayed n_steps times."""
+        dev = self.device
+        if self._disc_graph is None:
+            try:
+                self._n_samples_dev = torch.zeros((), device=dev)
+                self._acc_d = torch.zeros(11, device=dev)
+                ml, rb = self.motion_loader, self.disc_storage
+                n_lb, n_ulb = ml.preloaded_s_lb.shape[0], ml.preloaded_s_ulb.shape[0]
+
+                def one_step():
+                    i_pi = (torch.rand(mb, device=dev) * self._n_samples_dev).long()
+                    i_lb = torch.randint(0, n_lb, (mb,), device=dev)
+                    i_ulb = torch.randint(0, n_ulb, (mb,), device=dev)
+                    out = self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
+                                                   (ml.preloaded_s_lb[i_lb], ml.preloaded_label[i_lb]), ml.preloaded_s_ulb[i_ulb])
+                    self._acc_d.add_(torch.stack(out))
+                self._n_samples_dev.fill_(float(rb.num_samples))
+                self._info_max_dev.fill_(float(self.info_max_coef_on))
+                torch.cuda.synchronize()
+                for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
+                    o.zero_grad(set_to_none=True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one_step()
+                self._disc_graph = g
+            except Exception as e:      # never fatal
+                print(f"[disc update graph] capture failed, staying eager: {e}")
+                self._disc_graph = False
+                torch.cuda.synchronize()
+                acc = torch.zeros(11, device=dev)
+                gens = zip(self.disc_storage.feed_forward_generator(n_steps, mb), self.motion_loader.feed_forward_generator_lb(n_steps, mb),
+                           self.motion_loader.feed_forward_generator_ulb(n_steps, mb))
+                for s_pi, s_lb, s_ulb in gens:
+                    acc += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
+                return acc
+        self._n_samples_dev.fill_(float(self.disc_storage.num_samples))
+        self._info_max_dev.fill_(float(self.info_max_coef_on))
+        self._acc_d.zero_()
+        for _ in range(n_steps):
+            self._disc_graph.replay()
+        return self._acc_d.clone()
 
     def _sync_grads(self, params):
         if self.grad_sync is not None:
@@ -251,7 +302,8 @@ class SSInfoGAIL:
         policy_state, policy_eps, policy_c = sample_disc_policy
         expert_lb, label_lb = sample_disc_expert_lb
         expert_ulb = sample_disc_expert_ulb
-        w = self.env.task_obs_weight
+        w = getattr(self.env, "task_obs_weight_dev", None)
+        w = self.env.task_obs_weight if w is None else w
         prep = lambda x: self.disc.prepare_input(x.view(len(x), self.disc_obs_len, -1), w)
         policy_state, expert_lb, expert_ulb = prep(policy_state), prep(expert_lb), prep(expert_ulb)
         if self.disc_normalizer is not None:
@@ -260,11 +312,17 @@ class SSInfoGAIL:
                 expert_lb = self.disc_normalizer.normalize_torch(expert_lb, self.device)
                 expert_ulb = self.disc_normalizer.normalize_torch(expert_ulb, self.device)
 
-        _, _, pred_c_lb = self.disc(expert_lb)
+        # ONE trunk pass over [labelled expert | policy | unlabelled expert] instead of the reference's four
+        # (three forwards + a separate forward for the gradient penalty, gail.py:452-492): same functions of the
+        # same parameters, so losses and gradients are identical up to GEMM rounding; half the launches.
+        b_lb, b_pi = expert_lb.shape[0], policy_state.shape[0]
+        x_ulb = expert_ulb.clone().requires_grad_(True)
+        d_all, eps_all, c_all = self.disc(torch.cat([expert_lb, policy_state, x_ulb], dim=0))
+        pred_c_lb = c_all[:b_lb]
+        logits_pi, eps, pred_c = d_all[b_lb:b_lb + b_pi], eps_all[b_lb:b_lb + b_pi], c_all[b_lb:b_lb + b_pi]
+        logits_exp, pred_c_ulb = d_all[b_lb + b_pi:], c_all[b_lb + b_pi:]
         ss_loss = F.cross_entropy(pred_c_lb, label_lb)          # CE on softmaxed probabilities, as the reference
         policy_c_idx = torch.argmax(policy_c, dim=-1)
-        logits_pi, eps, pred_c = self.disc(policy_state)
-        logits_exp, _, pred_c_ulb = self.disc(expert_ulb)
 
         pred_mean = torch.mean(pred_c_ulb, dim=0).detach()
         if self.grad_sync is not None:
@@ -285,13 +343,12 @@ class SSInfoGAIL:
         disc_loss = 0.5 * (l_pi + l_exp)
         us_loss = F.l1_loss(eps, policy_eps)
         disc_logit_loss = torch.sum(torch.square(self.disc.get_disc_logit_weights()))
-        # gradient penalty on expert samples (double backward)
-        x = expert_ulb.clone().requires_grad_(True)
-        out = self.disc.linear(self.disc.trunk(x))
-        g = torch.autograd.grad(out, x, grad_outputs=torch.ones_like(out), create_graph=True, retain_graph=True, only_inputs=True)[0]
+        # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
+        g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
         grad_pen_loss = torch.mean(torch.sum(torch.square(g), dim=-1))
         disc_weight_decay = torch.sum(torch.square(torch.cat(self.disc.get_disc_weights(), dim=-1)))
-        loss = (self.ss_coef * ss_loss + self.info_max_coef_on * info_max_loss + self.disc_coef * disc_loss +
+        info_coef = self._info_max_dev if (self._info_max_dev is not None and torch.cuda.is_current_stream_capturing()) else self.info_max_coef_on
+        loss = (self.ss_coef * ss_loss + info_coef * info_max_loss + self.disc_coef * disc_loss +
                 self.us_coef * us_loss + self.disc_grad_penalty * grad_pen_loss + self.disc_logit_reg * disc_logit_loss +
                 self.disc_weight_decay * disc_weight_decay)
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
