@@ -322,7 +322,7 @@ static void chol_solve(double Lc[18][18], int n, const double b[18], double x[18
 /* ------------------------------------------------------------------ one physics substep */
 typedef struct { double J[18], W[18], dinv, bias, lam, lo_mul, hi_mul; int kind; /*0 normal,1 tangent,2 limit*/ int parent; } Row;
 
-#define LIMIT_MARGIN 0.5   /* rad: limit rows further than this from the stop cannot bind (|qd| <= ~100 rad/s) */
+#define LIMIT_MARGIN 0.2   /* rad: beyond 30.1 rad/s x 5 ms = 0.15 rad a stop cannot bind within one substep */
 #define LIMIT_DEPEN 1.0    /* rad/s cap on limit-violation recovery speed */
 #define CFM 1e-6
 

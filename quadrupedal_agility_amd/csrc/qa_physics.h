@@ -32,7 +32,7 @@
 #define QA_LEG_PTS 17
 #define QA_BASE_PTS 11
 
-#define QA_LIMIT_MARGIN 0.5f     // rad
+#define QA_LIMIT_MARGIN 0.2f     // rad: beyond 30.1 rad/s x 5 ms = 0.15 rad a stop cannot bind within one substep
 #define QA_LIMIT_DEPEN 1.0f      // rad/s
 #define QA_CFM 1e-6f
 
@@ -365,7 +365,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 20 * d, re[d]);
     }
     // joint limits: at most one stop per joint can be within the margin
-    float lim_sgn[3], lim_bias[3], lim_lam[3];
+    float lim_sgn[3], lim_bias[3], lim_lam[3], lim_bj[3][6], lim_dinv[3];   // registers: these rows run in most waves
     bool lim_on[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -389,8 +389,8 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             float lkk = (k == 0) ? Linv[0] : (k == 1 ? Linv[3] : Linv[5]);
             float d = lkk;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { d = fmaf(jh[i], bj[i], d); lr(priv, QA_PRIV_LIMIT + 8 * k + i) = bj[i]; }
-            lr(priv, QA_PRIV_LIMIT + 8 * k + 6) = 1.0f / (d + QA_CFM);
+            for (int i = 0; i < 6; ++i) { d = fmaf(jh[i], bj[i], d); lim_bj[k][i] = bj[i]; }
+            lim_dinv[k] = 1.0f / (d + QA_CFM);
         }
     }
 
@@ -446,11 +446,11 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
                         for (int i = 0; i < 6; ++i) uk = fmaf(G[k * 6 + i], ub2[i], uk);
                         float res = lim_bias[k] + lim_sgn[k] * uk;
-                        float lam = fmaxf(lim_lam[k] - res * lr(priv, QA_PRIV_LIMIT + 8 * k + 6), 0.f);
+                        float lam = fmaxf(lim_lam[k] - res * lim_dinv[k], 0.f);
                         float dl = lam - lim_lam[k];
                         if (mine) lim_lam[k] = lam;
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) ub2[i] = fmaf(lr(priv, QA_PRIV_LIMIT + 8 * k + i), dl, ub2[i]);
+                        for (int i = 0; i < 6; ++i) ub2[i] = fmaf(lim_bj[k][i], dl, ub2[i]);
                         float sd = lim_sgn[k] * dl;
                         w2[0] = fmaf(k == 0 ? Linv[0] : (k == 1 ? Linv[1] : Linv[2]), sd, w2[0]);
                         w2[1] = fmaf(k == 0 ? Linv[1] : (k == 1 ? Linv[3] : Linv[4]), sd, w2[1]);

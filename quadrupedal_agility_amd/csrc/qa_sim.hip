@@ -190,20 +190,23 @@ struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int de
 #define S_DISCT 207     // 49
 #define S_FLAGS 256     // [0] = refill history (episode length <= 1)
 #define S_ENV 260       // floats of LDS staging per env
-#define S_ROW 672       // assembled observation row per env
+#define S_ROW 676       // assembled observation row per env (+ up to 3 floats of phase padding in front)
 
-// wave-cooperative copy of n floats LDS -> global with 16-byte stores where the destination allows
-__device__ __forceinline__ void copy_row(float *dst, const float *src, int n) {
-    const int head = (int)(((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2);      // floats until dst is 16-B aligned (0..3)
-    const int nvec = (n - head) >> 2;
-    if ((int)threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+// The 671-float observation row of env `ge` starts at a 4-byte-aligned address whose 16-byte phase is
+// head = floats until the next 16-B boundary (0..3).  The LDS copy of the row is stored with the SAME phase
+// (row base shifted by pad = (4 - head) & 3), so the body moves as ds_read_b128 -> global_store_dwordx4:
+// 167 vectors = 2 full wave iterations + 39 lanes, plus `head` leading and 3 - head trailing scalars.
+__device__ __forceinline__ int obs_row_head(const float *dst) { return (int)(((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2); }
+
+__device__ __forceinline__ void store_obs_row(float *dst, const float *row, int head) {
+    const int lane = threadIdx.x;
+    const float4 *s4 = reinterpret_cast<const float4 *>(row + head);      // 16-B aligned by construction
     float4 *d4 = reinterpret_cast<float4 *>(dst + head);
-    for (int v = threadIdx.x; v < nvec; v += QA_BLOCK) {
-        const float *sp4 = src + head + 4 * v;
-        d4[v] = make_float4(sp4[0], sp4[1], sp4[2], sp4[3]);
-    }
-    const int done = head + 4 * nvec;
-    if ((int)threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+    float4 a = s4[lane], b = s4[lane + 64];
+    d4[lane] = a; d4[lane + 64] = b;
+    if (lane < 167 - 128) d4[lane + 128] = s4[lane + 128];
+    if (lane < head) dst[lane] = row[lane];
+    if (lane < 3 - head) dst[head + 668 + lane] = row[head + 668 + lane];
 }
 
 __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
@@ -588,29 +591,44 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
 #define OBS_GROUP 4
+    const int lane = threadIdx.x;
     for (int e0 = 0; e0 < ENVS_PER_BLOCK; e0 += OBS_GROUP) {
         float hv[OBS_GROUP][9];
 #pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {          // all history loads of the group in flight first
-            const int e = e0 + g; const int ge = min((int)(blockIdx.x * ENVS_PER_BLOCK) + e, N - 1);
-            const float *hist = p.obs_hist + (int64_t)ge * 570 + 57;
+        for (int g = 0; g < OBS_GROUP; ++g) {          // all history loads of the group in flight first: 8 full + 1 single-lane
+            const int ge = min((int)(blockIdx.x * ENVS_PER_BLOCK) + e0 + g, N - 1);
+            const float *hist = p.obs_hist + (int64_t)ge * 570 + 57 + lane;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) { int i = threadIdx.x + QA_BLOCK * r; hv[g][r] = (i < 513) ? hist[i] : 0.f; }
+            for (int r = 0; r < 8; ++r) hv[g][r] = hist[QA_BLOCK * r];
+            hv[g][8] = (lane == 0) ? hist[512] : 0.f;
         }
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
-            const int e = e0 + g;
-            const float *ss = s_stage + e * S_ENV;
-            float *row = s_rows + e * S_ROW;
-            const bool rf = ss[S_FLAGS] != 0.f;
+            const int e = e0 + g, ge = (int)(blockIdx.x * ENVS_PER_BLOCK) + e;
+            if (ge < N) {
+                const float *ss = s_stage + e * S_ENV;
+                const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
+                float *row = s_rows + e * S_ROW + ((4 - head) & 3);
+                float *hout = p.obs_hist + (int64_t)ge * 570;
+                const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
+                const float pr = (lane < 57) ? clampf(ss[S_PROP + lane], -clipo, clipo) : 0.f;
+                if (!rf) {
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                int i = threadIdx.x + QA_BLOCK * r;       // history index 0..512 = slots 0..8
-                if (i < 513) row[90 + i] = clampf(rf ? ss[S_PROP + (i % 57)] : hv[g][r], -clipo, clipo);
+                    for (int r = 0; r < 8; ++r) { float v = clampf(hv[g][r], -clipo, clipo); row[90 + lane + QA_BLOCK * r] = v; hout[lane + QA_BLOCK * r] = v; }
+                    if (lane == 0) { float v = clampf(hv[g][8], -clipo, clipo); row[90 + 512] = v; hout[512] = v; }
+                } else {                                 // first observation of an episode: all ten slots = current frame
+                    for (int i = lane; i < 513; i += QA_BLOCK) { float v = clampf(ss[S_PROP + (i % 57)], -clipo, clipo); row[90 + i] = v; hout[i] = v; }
+                }
+                if (lane < 57) { row[603 + lane] = pr; hout[513 + lane] = pr; }
+                row[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
+                if (lane < 26) row[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
+                if (lane < 11) row[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
+                if (lane < QA_NUM_OBS_DISC) {
+                    float dv = ss[S_DISC + lane];
+                    p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + lane] = dv;
+                    p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
+                }
             }
-            if (threadIdx.x < 57) row[90 + 513 + threadIdx.x] = clampf(ss[S_PROP + threadIdx.x], -clipo, clipo);
-            for (int i = threadIdx.x; i < 90; i += QA_BLOCK) row[i] = clampf(ss[S_HEAD + i], -clipo, clipo);
-            if (threadIdx.x < 11) row[660 + threadIdx.x] = clampf(ss[S_TAIL + threadIdx.x], -clipo, clipo);
         }
     }
     QA_STAMP(11);
@@ -619,15 +637,9 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     for (int e = 0; e < ENVS_PER_BLOCK; ++e) {
         const int ge = blockIdx.x * ENVS_PER_BLOCK + e;
         if (ge >= N) break;
-        const float *row = s_rows + e * S_ROW;
-        copy_row(p.obs + (int64_t)ge * QA_NUM_OBS, row, QA_NUM_OBS);
-        copy_row(p.obs_hist + (int64_t)ge * 570, row + 90, 570);
-        if (threadIdx.x < QA_NUM_OBS_DISC) {
-            const float *ss = s_stage + e * S_ENV;
-            float dv = ss[S_DISC + threadIdx.x];
-            p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = dv;
-            p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + threadIdx.x] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + threadIdx.x] : dv;
-        }
+        float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
+        const int head = obs_row_head(dst);
+        store_obs_row(dst, s_rows + e * S_ROW + ((4 - head) & 3), head);
     }
     QA_STAMP(10);
 }
