@@ -367,7 +367,9 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     int foot_row[4], extra_row[4], extra_body[4];
     double mu = 0.5 * ((double)TP(s, QA_T_FRICTION, float)[e] + cfg->ground_friction);
     v3 nB = {R[2][0], R[2][1], R[2][2]}, t1B = {R[0][0], R[0][1], R[0][2]}, t2B = {R[1][0], R[1][1], R[1][2]};
+    int row_leg_first[5] = {0, 0, 0, 0, 0};
     for (int l = 0; l < 4; ++l) {
+        row_leg_first[l] = nrows;
         foot_row[l] = extra_row[l] = -1; extra_body[l] = -1;
         /* candidate points of this leg: slot 0 = foot; the other slot takes the min-gap non-foot point */
         double best_gap = 1e30; v3 best_p = {0, 0, 0}; int best_depth = -1, best_body = -1;
@@ -424,6 +426,7 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             r->bias = gap >= 0 ? gap / dt : (gap / dt > -LIMIT_DEPEN ? gap / dt : -LIMIT_DEPEN);
         }
     }
+    row_leg_first[4] = nrows;
     for (int i = 0; i < nrows; ++i) {
         chol_solve(Lc, 18, rows[i].J, rows[i].W);
         double d = 0; for (int k = 0; k < 18; ++k) d += rows[i].J[k] * rows[i].W[k];
@@ -440,28 +443,40 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             for (int k = 0; k < 18; ++k) u[k] += r->W[k] * r->lam;
         }
     }
+    /* Projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs {FL, RR} and {FR, RL} couple
+     * only weakly through the base (their lever arms cancel in the rotational term), so the two legs of a colour are
+     * updated from the SAME base velocity and their velocity changes are summed (block Jacobi inside a colour),
+     * while the colours, and the rows inside a leg, follow each other Gauss-Seidel fashion.  On the GPU this is
+     * 2 instead of 4 serial passes per sweep (one lane per leg).  Inside a leg: foot (normal, then both tangents
+     * together), extra contact (same), joint-limit rows. */
     for (int it = 0; it < cfg->solver_iterations; ++it) {
-        for (int i = 0; i < nrows; ++i) {
-            Row *r = &rows[i];
-            if (r->kind == 1) {
-                /* the two tangent rows of a contact are updated TOGETHER from the velocity left by its normal row
-                 * (block-Jacobi inside the friction pair, Gauss-Seidel everywhere else) */
-                if (i - r->parent != 1) continue;
-                Row *r2 = &rows[i + 1];
-                double res1 = 0, res2 = 0;
-                for (int k = 0; k < 18; ++k) { res1 += r->J[k] * u[k]; res2 += r2->J[k] * u[k]; }
-                double lim = mu * rows[r->parent].lam;
-                double l1 = r->lam - res1 * r->dinv, l2 = r2->lam - res2 * r2->dinv;
-                l1 = l1 < -lim ? -lim : (l1 > lim ? lim : l1); l2 = l2 < -lim ? -lim : (l2 > lim ? lim : l2);
-                double d1 = l1 - r->lam, d2 = l2 - r2->lam; r->lam = l1; r2->lam = l2;
-                for (int k = 0; k < 18; ++k) u[k] += r->W[k] * d1 + r2->W[k] * d2;
-                continue;
+        for (int color = 0; color < 2; ++color) {
+            double u0[18], du[18]; memcpy(u0, u, sizeof(u0)); memset(du, 0, sizeof(du));
+            for (int l = 0; l < 4; ++l) {
+                if (((l == 0 || l == 3) ? 0 : 1) != color) continue;
+                double ul[18]; memcpy(ul, u0, sizeof(ul));
+                for (int i = row_leg_first[l]; i < row_leg_first[l + 1]; ++i) {
+                    Row *r = &rows[i];
+                    if (r->kind == 1) {
+                        if (i - r->parent != 1) continue;
+                        Row *r2 = &rows[i + 1];
+                        double res1 = 0, res2 = 0;
+                        for (int k = 0; k < 18; ++k) { res1 += r->J[k] * ul[k]; res2 += r2->J[k] * ul[k]; }
+                        double lim = mu * rows[r->parent].lam;
+                        double l1 = r->lam - res1 * r->dinv, l2 = r2->lam - res2 * r2->dinv;
+                        l1 = l1 < -lim ? -lim : (l1 > lim ? lim : l1); l2 = l2 < -lim ? -lim : (l2 > lim ? lim : l2);
+                        double d1 = l1 - r->lam, d2 = l2 - r2->lam; r->lam = l1; r2->lam = l2;
+                        for (int k = 0; k < 18; ++k) ul[k] += r->W[k] * d1 + r2->W[k] * d2;
+                        continue;
+                    }
+                    double res = r->bias; for (int k = 0; k < 18; ++k) res += r->J[k] * ul[k];
+                    double lam = r->lam - res * r->dinv; if (lam < 0) lam = 0;
+                    double dl = lam - r->lam; r->lam = lam;
+                    for (int k = 0; k < 18; ++k) ul[k] += r->W[k] * dl;
+                }
+                for (int k = 0; k < 18; ++k) du[k] += ul[k] - u0[k];
             }
-            double res = r->bias; for (int k = 0; k < 18; ++k) res += r->J[k] * u[k];
-            double lam = r->lam - res * r->dinv;
-            if (lam < 0) lam = 0;
-            double dl = lam - r->lam; r->lam = lam;
-            for (int k = 0; k < 18; ++k) u[k] += r->W[k] * dl;
+            for (int k = 0; k < 18; ++k) u[k] = u0[k] + du[k];
         }
     }
     /* joint velocity clamp (PhysX maxJointVelocity = URDF velocity limit) */

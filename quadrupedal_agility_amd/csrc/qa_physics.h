@@ -409,18 +409,22 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
         for (int i = 0; i < 6; ++i) ub[i] += quad_sum(dub[i]);
     }
-    // ---- projected Gauss-Seidel, true sequential order over the legs: the lane whose turn it is
-    // updates its local (ub, w); its accumulated base-velocity change is then quad-broadcast.
+    // ---- projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs
+    // {FL, RR} and {FR, RL} are updated from the same base velocity (their coupling through the base is weak: the
+    // lever arms cancel in the rotational term) and their base-velocity changes are quad-summed; colours follow each
+    // other Gauss-Seidel fashion.  2 serial passes per sweep instead of 4; every lane runs its own rows in both
+    // passes and only the lanes of the active colour commit.
     const bool any_foot = __any(foot_on);
+    const bool colour_a = (leg == 0) || (leg == 3);
     for (int it = 0; it < P.iters; ++it) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int colour = 0; colour < 2; ++colour) {
+            const bool mine = (colour == 0) == colour_a;
             float ub2[6], w2[3];
 #pragma unroll
             for (int i = 0; i < 6; ++i) ub2[i] = ub[i];
 #pragma unroll
             for (int k = 0; k < 3; ++k) w2[k] = w[k];
-            const bool mine = (leg == s);
             if (any_foot) {
                 if (foot_on) {
                     const float l0 = rf[0].lam, l1 = rf[1].lam, l2 = rf[2].lam;
@@ -458,13 +462,10 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                     }
                 }
             }
-            // commit: lane s keeps its w; everyone takes lane s's base velocity
+            // commit: lanes of the active colour keep their w; the base takes the SUM of their velocity changes
             if (mine) { w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float v = ub2[i];
-                ub[i] = s == 0 ? quad_bcast<0>(v) : (s == 1 ? quad_bcast<1>(v) : (s == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
-            }
+            for (int i = 0; i < 6; ++i) ub[i] += quad_sum(mine ? (ub2[i] - ub[i]) : 0.f);
         }
     }
 
