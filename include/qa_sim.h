@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 2
+#define QA_ABI_VERSION 3
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -71,8 +71,9 @@ enum qa_tensor {
     QA_T_LAST_TORQUES_ORG,    /* (N,12)                                                          */
     QA_T_LAST_ROOT_VEL,       /* (N,6)                                                           */
     QA_T_ACTION_HISTORY,      /* (N,8,12) oldest first                                           */
-    QA_T_OBS_HISTORY,         /* (N,10,57) oldest first, noise-free                              */
-    QA_T_OBS,                 /* (N,671) obs_buf == privileged_obs_buf                           */
+    QA_T_OBS,                 /* (N,671) obs_buf == privileged_obs_buf.  Columns [90:660] ARE the proprioceptive
+                                         history (10 x 57, oldest first, noise-free): the reference's separate
+                                         obs_history_buf is this slice, kept in place from step to step     */
     QA_T_OBS_DISC,            /* (N,49)  discriminator observation                               */
     QA_T_OBS_DISC_TERM,       /* (N,49)  OBS_DISC with rows of resetting envs replaced by their
                                          terminal (pre-reset) disc obs                           */

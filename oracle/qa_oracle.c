@@ -63,7 +63,6 @@ static void make_layout(const qa_config *cfg, Layout *L) {
     set_t(L, QA_T_LAST_TORQUES_ORG, QA_F32, 2, N, 12, 1);
     set_t(L, QA_T_LAST_ROOT_VEL, QA_F32, 2, N, 6, 1);
     set_t(L, QA_T_ACTION_HISTORY, QA_F32, 3, N, QA_ACTION_BUF_LEN, 12);
-    set_t(L, QA_T_OBS_HISTORY, QA_F32, 3, N, QA_HISTORY_LEN, QA_NUM_PROP);
     set_t(L, QA_T_OBS, QA_F32, 2, N, QA_NUM_OBS, 1);
     set_t(L, QA_T_OBS_DISC, QA_F32, 2, N, QA_NUM_OBS_DISC, 1);
     set_t(L, QA_T_OBS_DISC_TERM, QA_F32, 2, N, QA_NUM_OBS_DISC, 1);
@@ -606,7 +605,7 @@ static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity, int repo
     TP(s, QA_T_EPISODE_LENGTH, int64_t)[e] = 0;
     TP(s, QA_T_RESET, int64_t)[e] = 1;
     memset(TP(s, QA_T_ACTION_HISTORY, float) + 96 * e, 0, 96 * 4);
-    memset(TP(s, QA_T_OBS_HISTORY, float) + 570 * e, 0, 570 * 4);
+    memset(TP(s, QA_T_OBS, float) + (int64_t)QA_NUM_OBS * e + 90, 0, 570 * 4);      /* obs_history_buf lives in the obs row */
     float *st = TP(s, QA_T_EPISODE_STATS, float) + 16 * stats_parity, *es = TP(s, QA_T_EPISODE_SUMS, float);
     if (report)
 #pragma omp critical(qo_stats)
@@ -654,7 +653,7 @@ static void compute_observations(qo_sim *s, int e, int64_t step) {
     for (int l = 0; l < 4; ++l) prop[41 + l] = (cfilt[l] ? 1.0f : 0.0f) - 0.5f;
     for (int j = 0; j < 12; ++j) prop[45 + j] = key[j] * 0.0f;
 
-    float *hist = TP(s, QA_T_OBS_HISTORY, float) + 570 * e;
+    float *hist = TP(s, QA_T_OBS, float) + (int64_t)QA_NUM_OBS * e + 90;      /* previous step's history, shifted in place */
     int64_t epl = TP(s, QA_T_EPISODE_LENGTH, int64_t)[e];
     if (epl <= 1) { for (int t = 0; t < QA_HISTORY_LEN; ++t) memcpy(hist + 57 * t, prop, 57 * 4); }
     else { memmove(hist, hist + 57, 57 * 9 * 4); memcpy(hist + 57 * 9, prop, 57 * 4); }
@@ -666,7 +665,6 @@ static void compute_observations(qo_sim *s, int e, int64_t step) {
     for (int i = 0; i < 4; ++i) o[61 + i] = mp[i];
     o[65] = TP(s, QA_T_FRICTION, float)[e];
     for (int j = 0; j < 12; ++j) { o[66 + j] = ms[(0 * N + e) * 12 + j] - 1.0f; o[78 + j] = ms[(1 * N + e) * 12 + j] - 1.0f; }
-    memcpy(o + 90, hist, 570 * 4);
     memcpy(o + 660, TP(s, QA_T_COMMANDS, float) + 5 * e, 20);
     o[665] = TP(s, QA_T_LATENT_EPS, float)[e];
     memcpy(o + 666, TP(s, QA_T_LATENT_C, float) + 5 * e, 20);

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 2
+QA_ABI_VERSION = 3
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -26,7 +26,7 @@ REWARD_NAMES = [
 TENSORS = [
     "ROOT_STATES", "DOF_STATE", "CONTACT_FORCES", "RIGID_BODY_POS", "TORQUES", "TORQUES_ORG",
     "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_TORQUES_ORG", "LAST_ROOT_VEL",
-    "ACTION_HISTORY", "OBS_HISTORY", "OBS", "OBS_DISC", "OBS_DISC_TERM", "COMMANDS",
+    "ACTION_HISTORY", "OBS", "OBS_DISC", "OBS_DISC_TERM", "COMMANDS",
     "LATENT_EPS", "LATENT_C", "REW", "RESET", "TIME_OUT", "EPISODE_LENGTH", "EPISODE_SUMS",
     "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
     "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",

@@ -45,7 +45,7 @@ static void make_layout(const qa_config *cfg, Layout *L) {
         {QA_T_ACTIONS, QA_F32, 2, N, 12, 1}, {QA_T_LAST_ACTIONS, QA_F32, 2, N, 12, 1},
         {QA_T_LAST_DOF_VEL, QA_F32, 2, N, 12, 1}, {QA_T_LAST_TORQUES_ORG, QA_F32, 2, N, 12, 1},
         {QA_T_LAST_ROOT_VEL, QA_F32, 2, N, 6, 1}, {QA_T_ACTION_HISTORY, QA_F32, 3, N, QA_ACTION_BUF_LEN, 12},
-        {QA_T_OBS_HISTORY, QA_F32, 3, N, QA_HISTORY_LEN, QA_NUM_PROP}, {QA_T_OBS, QA_F32, 2, N, QA_NUM_OBS, 1},
+        {QA_T_OBS, QA_F32, 2, N, QA_NUM_OBS, 1},
         {QA_T_OBS_DISC, QA_F32, 2, N, QA_NUM_OBS_DISC, 1}, {QA_T_OBS_DISC_TERM, QA_F32, 2, N, QA_NUM_OBS_DISC, 1},
         {QA_T_COMMANDS, QA_F32, 2, N, 5, 1}, {QA_T_LATENT_EPS, QA_F32, 2, N, 1, 1},
         {QA_T_LATENT_C, QA_F32, 2, N, QA_NUM_GAITS, 1}, {QA_T_REW, QA_F32, 1, N, 1, 1},
@@ -75,7 +75,7 @@ static void make_layout(const qa_config *cfg, Layout *L) {
 // device pointers into the arena
 struct Ptrs {
     float *root, *dof, *cforce, *rbpos, *torques, *torques_org, *actions, *last_actions, *last_dof_vel,
-        *last_torques_org, *last_root_vel, *action_hist, *obs_hist, *obs, *obs_disc, *obs_disc_term, *commands,
+        *last_torques_org, *last_root_vel, *action_hist, *obs, *obs_disc, *obs_disc_term, *commands,
         *latent_eps, *latent_c, *rew, *episode_sums, *episode_stats, *feet_force, *base_lin_vel, *base_ang_vel,
         *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap, *foot_impulse;
     int64_t *reset, *episode_length;
@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {          // all history loads of the group in flight first: 8 full + 1 single-lane
             const int ge = min((int)(blockIdx.x * ENVS_PER_BLOCK) + e0 + g, N - 1);
-            const float *hist = p.obs_hist + (int64_t)ge * 570 + 57 + lane;
+            const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
 #pragma unroll
             for (int r = 0; r < 8; ++r) hv[g][r] = hist[QA_BLOCK * r];
             hv[g][8] = (lane == 0) ? hist[512] : 0.f;
@@ -609,17 +609,16 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
                 const float *ss = s_stage + e * S_ENV;
                 const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
                 float *row = s_rows + e * S_ROW + ((4 - head) & 3);
-                float *hout = p.obs_hist + (int64_t)ge * 570;
                 const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
                 const float pr = (lane < 57) ? clampf(ss[S_PROP + lane], -clipo, clipo) : 0.f;
                 if (!rf) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { float v = clampf(hv[g][r], -clipo, clipo); row[90 + lane + QA_BLOCK * r] = v; hout[lane + QA_BLOCK * r] = v; }
-                    if (lane == 0) { float v = clampf(hv[g][8], -clipo, clipo); row[90 + 512] = v; hout[512] = v; }
+                    for (int r = 0; r < 8; ++r) { float v = clampf(hv[g][r], -clipo, clipo); row[90 + lane + QA_BLOCK * r] = v; }
+                    if (lane == 0) { float v = clampf(hv[g][8], -clipo, clipo); row[90 + 512] = v; }
                 } else {                                 // first observation of an episode: all ten slots = current frame
-                    for (int i = lane; i < 513; i += QA_BLOCK) { float v = clampf(ss[S_PROP + (i % 57)], -clipo, clipo); row[90 + i] = v; hout[i] = v; }
+                    for (int i = lane; i < 513; i += QA_BLOCK) { float v = clampf(ss[S_PROP + (i % 57)], -clipo, clipo); row[90 + i] = v; }
                 }
-                if (lane < 57) { row[603 + lane] = pr; hout[513 + lane] = pr; }
+                if (lane < 57) row[603 + lane] = pr;
                 row[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
                 if (lane < 26) row[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
                 if (lane < 11) row[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
@@ -716,7 +715,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptr
         p.last_actions[j] = 0.f; p.last_dof_vel[j] = 0.f; p.last_torques_org[j] = 0.f; p.foot_impulse[j] = 0.f;
         for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) p.action_hist[(int64_t)env * 96 + 12 * r + 3 * leg + k] = 0.f;
     }
-    for (int i = leg; i < 570; i += 4) p.obs_hist[(int64_t)env * 570 + i] = 0.f;
+    for (int i = leg; i < 570; i += 4) p.obs[(int64_t)env * QA_NUM_OBS + 90 + i] = 0.f;
 }
 
 __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques) {
@@ -818,7 +817,7 @@ static void fill_ptrs(qa_sim *s) {
     FP(root, QA_T_ROOT_STATES); FP(dof, QA_T_DOF_STATE); FP(cforce, QA_T_CONTACT_FORCES); FP(rbpos, QA_T_RIGID_BODY_POS);
     FP(torques, QA_T_TORQUES); FP(torques_org, QA_T_TORQUES_ORG); FP(actions, QA_T_ACTIONS); FP(last_actions, QA_T_LAST_ACTIONS);
     FP(last_dof_vel, QA_T_LAST_DOF_VEL); FP(last_torques_org, QA_T_LAST_TORQUES_ORG); FP(last_root_vel, QA_T_LAST_ROOT_VEL);
-    FP(action_hist, QA_T_ACTION_HISTORY); FP(obs_hist, QA_T_OBS_HISTORY); FP(obs, QA_T_OBS); FP(obs_disc, QA_T_OBS_DISC);
+    FP(action_hist, QA_T_ACTION_HISTORY); FP(obs, QA_T_OBS); FP(obs_disc, QA_T_OBS_DISC);
     FP(obs_disc_term, QA_T_OBS_DISC_TERM); FP(commands, QA_T_COMMANDS); FP(latent_eps, QA_T_LATENT_EPS); FP(latent_c, QA_T_LATENT_C);
     FP(rew, QA_T_REW); FP(episode_sums, QA_T_EPISODE_SUMS); FP(episode_stats, QA_T_EPISODE_STATS); FP(feet_force, QA_T_FEET_FORCE);
     FP(base_lin_vel, QA_T_BASE_LIN_VEL); FP(base_ang_vel, QA_T_BASE_ANG_VEL); FP(proj_grav, QA_T_PROJECTED_GRAVITY); FP(rpy, QA_T_RPY);

@@ -140,7 +140,7 @@ class LeggedRobot:
         self.last_root_vel = t["LAST_ROOT_VEL"]
         self.last_torques_org = t["LAST_TORQUES_ORG"]
         self.action_history_buf = t["ACTION_HISTORY"]
-        self.obs_history_buf = t["OBS_HISTORY"]
+        self.obs_history_buf = t["OBS"][:, 90:660].unflatten(1, (_capi.HISTORY_LEN, _capi.NUM_PROP))   # (N,10,57) view into the obs rows
         self.commands = t["COMMANDS"]
         self.latent_eps = t["LATENT_EPS"]
         self.latent_c = t["LATENT_C"]

@@ -64,7 +64,7 @@ def test_post_physics_matches_reference(gold, case):
     assert np.allclose(t["OBS"], ref("obs"), **f32)
     assert np.allclose(t["OBS"], ref("priv_obs"), **f32)
     assert np.allclose(t["OBS_DISC"], ref("obs_disc"), **f32)
-    assert np.allclose(t["OBS_HISTORY"].reshape(-1, 570), ref("obs_history").reshape(-1, 570), **f32)
+    assert np.allclose(t["OBS"][:, 90:660], ref("obs_history").reshape(-1, 570), **f32)      # obs_history_buf == obs[:, 90:660]
     # last_* copies and histories
     for mine, theirs in (("LAST_ACTIONS", "last_actions"), ("LAST_DOF_VEL", "last_dof_vel"), ("LAST_ROOT_VEL", "last_root_vel"),
                          ("LAST_TORQUES_ORG", "last_torques_org"), ("ACTION_HISTORY", "action_history"), ("COMMANDS", "commands"),

@@ -99,7 +99,7 @@ def make_ref_env(ref_lr, RefCfg, n, arena):
     env.p_gains = torch.full((12,), 40.0); env.d_gains = torch.full((12,), 1.0)
     env.actions = T(a["ACTIONS"]); env.last_actions = T(a["LAST_ACTIONS"])
     env.last_dof_vel = T(a["LAST_DOF_VEL"]); env.last_root_vel = T(a["LAST_ROOT_VEL"]); env.last_torques_org = T(a["LAST_TORQUES_ORG"])
-    env.action_history_buf = T(a["ACTION_HISTORY"]); env.obs_history_buf = T(a["OBS_HISTORY"])
+    env.action_history_buf = T(a["ACTION_HISTORY"]); env.obs_history_buf = T(a["OBS"])[:, 90:660].reshape(n, 10, 57).clone()
     env.motor_strength = T(a["MOTOR_STRENGTH"])
     env.contact_buf = torch.zeros(n, 100, 4); env.contact_force_buf = torch.zeros(n, 100, 4)
     env.commands = T(a["COMMANDS"]); env.latent_eps = T(a["LATENT_EPS"]); env.latent_c = T(a["LATENT_C"])
