@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 3
+#define QA_ABI_VERSION 4
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -104,12 +104,18 @@ enum qa_tensor {
                                          origin xx yy zz xy xz yz, base frame                    */
     QA_T_PRIOR_PARAMETERS,    /* (5)    written by the learner (gail.py:463-464)                 */
     QA_T_MOCAP_FRAMES,        /* (F,QA_MOCAP_FRAME) reset-state frames, see qa_set_mocap         */
+    QA_T_HEIGHT_SAMPLES,      /* (hf_rows, hf_cols) int16 terrain height samples (terrain_type 1), written by the caller
+                                         after qa_create exactly like gym.add_heightfield's samples
+                                         (legged_robot.py:958-975): height = sample * hf_vscale at
+                                         x = row * hf_hscale - hf_border, y = col * hf_hscale - hf_border        */
+    QA_T_SCAN_HEIGHT,         /* (N) terrain height under scan point 94 of the reference's 17x11 height scan, the only
+                                         sample the BBC env uses (root_h = z - measured_heights[:, 94], :264-268); 0 on a plane */
     QA_T_FOOT_IMPULSE,        /* (N,4,3) foot contact impulses (normal, tangent x, tangent y) of the last
                                          substep: warm start of the contact solver; zeroed on reset   */
     QA_T_COUNT
 };
 
-enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3 };
+enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3, QA_I16 = 4 };
 
 #define QA_MOCAP_FRAME 37       /* root pos3, root quat4, joint pos12, lin vel3, ang vel3 (root frame), joint vel12 */
 
@@ -127,7 +133,7 @@ typedef struct qa_config {
     float contact_offset;           /* 0.01 */
     float max_depenetration_velocity; /* 1.0 */
     float ground_friction;          /* 1.0 (terrain.static_friction) */
-    int32_t terrain_type;           /* 0 = plane */
+    int32_t terrain_type;           /* 0 = plane, 1 = height field (the reference's 'heightfield' and 'trimesh' terrains) */
     /* control (go2_locomotion_config.py:53-60) */
     float kp, kd, action_scale, hip_scale_reduction, clip_actions;
     float default_dof_pos[QA_NUM_DOF];
@@ -159,6 +165,11 @@ typedef struct qa_config {
     int32_t randomize_friction, randomize_base_mass, randomize_base_com, randomize_motor, use_easi;
     float friction_range[2], added_mass_range[2], added_com_range[2], motor_strength_range[2];
     float easi_mean[6], easi_var[6];
+    /* height-field terrain (terrain_type 1; legged_robot_config.py:19-44, terrain.py:10-45) */
+    int32_t hf_rows, hf_cols;       /* samples along x and y (tot_rows, tot_cols) */
+    float hf_hscale, hf_vscale;     /* 0.1 m, 0.005 m */
+    float hf_border;                /* border_size [m]: world x = row * hscale - border */
+    float reset_xy_jitter;          /* custom_origins: default-pose resets add U(-j, j) to x and y (legged_robot.py:622-625) */
     /* mocap reset table (reset_mode 1) */
     int32_t num_mocap_frames;       /* rows of QA_T_MOCAP_FRAMES */
     int32_t mocap_clip_count[QA_NUM_GAITS];   /* unused when reset_mode == 0 */

@@ -41,7 +41,7 @@ typedef struct {
     int64_t total;
 } Layout;
 
-static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : 1; }
+static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : d == QA_I16 ? 2 : 1; }
 
 static void set_t(Layout *L, int t, int dt, int nd, int64_t a, int64_t b, int64_t c) {
     L->dtype[t] = dt; L->ndim[t] = nd; L->shape[t][0] = a; L->shape[t][1] = b; L->shape[t][2] = c;
@@ -89,6 +89,9 @@ static void make_layout(const qa_config *cfg, Layout *L) {
     set_t(L, QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1);
     set_t(L, QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1);
     set_t(L, QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1);
+    { int64_t hr = cfg->terrain_type == 1 ? cfg->hf_rows : 1, hc = cfg->terrain_type == 1 ? cfg->hf_cols : 1;
+      set_t(L, QA_T_HEIGHT_SAMPLES, QA_I16, 2, hr, hc, 1); }
+    set_t(L, QA_T_SCAN_HEIGHT, QA_F32, 1, N, 1, 1);
     set_t(L, QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3);
     int64_t off = 0;
     for (int t = 0; t < QA_T_COUNT; ++t) {
@@ -325,7 +328,57 @@ typedef struct { double J[18], W[18], dinv, bias, lam, lo_mul, hi_mul; int kind;
 #define LIMIT_DEPEN 1.0    /* rad/s cap on limit-violation recovery speed */
 #define CFM 1e-6
 
-static double ground_height(const qa_config *cfg, double x, double y) { (void)cfg; (void)x; (void)y; return 0.0; }
+/* Terrain under world point (x, y): height and unit normal.  Height field = two triangles per cell split along the
+ * (i,j)-(i+1,j+1) diagonal, as isaacgym's heightfield->trimesh conversion the reference uses (terrain.py:41-45). */
+static void ground_query(const qo_sim *s, double x, double y, double *h, double n[3]) {
+    const qa_config *c = &s->cfg;
+    if (c->terrain_type != 1) { *h = 0.0; n[0] = 0; n[1] = 0; n[2] = 1; return; }
+    const int16_t *hs = TP(s, QA_T_HEIGHT_SAMPLES, int16_t);
+    double fx = (x + c->hf_border) / c->hf_hscale, fy = (y + c->hf_border) / c->hf_hscale;
+    int ix = (int)floor(fx), iy = (int)floor(fy);
+    if (ix < 0) ix = 0; if (ix > c->hf_rows - 2) ix = c->hf_rows - 2;
+    if (iy < 0) iy = 0; if (iy > c->hf_cols - 2) iy = c->hf_cols - 2;
+    double u = fx - ix, v = fy - iy;
+    if (u < 0) u = 0; if (u > 1) u = 1; if (v < 0) v = 0; if (v > 1) v = 1;
+    double vs = c->hf_vscale;
+    double h00 = vs * hs[(int64_t)ix * c->hf_cols + iy], h10 = vs * hs[(int64_t)(ix + 1) * c->hf_cols + iy];
+    double h01 = vs * hs[(int64_t)ix * c->hf_cols + iy + 1], h11 = vs * hs[(int64_t)(ix + 1) * c->hf_cols + iy + 1];
+    double gx, gy;
+    if (u >= v) { gx = h10 - h00; gy = h11 - h10; *h = h00 + u * gx + v * gy; }
+    else { gy = h01 - h00; gx = h11 - h01; *h = h00 + v * gy + u * gx; }
+    gx /= c->hf_hscale; gy /= c->hf_hscale;
+    double inv = 1.0 / sqrt(gx * gx + gy * gy + 1.0);
+    n[0] = -gx * inv; n[1] = -gy * inv; n[2] = inv;
+}
+/* tangent basis of a contact: t1 = x-axis projected onto the tangent plane, t2 = n x t1 */
+static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
+    double d = n[0];
+    t1[0] = 1.0 - d * n[0]; t1[1] = -d * n[1]; t1[2] = -d * n[2];
+    double inv = 1.0 / sqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+    t1[0] *= inv; t1[1] *= inv; t1[2] *= inv;
+    cross(n, t1, t2);
+}
+/* the height-scan sample the BBC env actually uses: point 94 of the 17 x 11 scan = (0.0, 0.1) in the yaw frame,
+ * looked up the way _get_heights does (legged_robot.py:1209-1228): truncate to a cell, min of three samples */
+static float scan_center_height(const qo_sim *s, const float *root) {
+    const qa_config *c = &s->cfg;
+    if (c->terrain_type != 1) return 0.0f;
+    const int16_t *hs = TP(s, QA_T_HEIGHT_SAMPLES, int16_t);
+    float qz = root[5], qw = root[6];
+    float nrm = sqrtf(qz * qz + qw * qw); if (nrm < 1e-9f) nrm = 1e-9f;
+    qz /= nrm; qw /= nrm;
+    /* quat_apply of (0,0,qz,qw) to (0, 0.1, 0):  v + 2 w (q x v) + 2 q x (q x v) */
+    float vx = 0.0f, vy = 0.1f;
+    float tx = -qz * vy * 2.0f, ty = qz * vx * 2.0f;
+    float px = vx + qw * tx - qz * ty + root[0], py = vy + qw * ty + qz * tx + root[1];
+    px += c->hf_border; py += c->hf_border;
+    long ix = (long)(px / c->hf_hscale), iy = (long)(py / c->hf_hscale);
+    if (ix < 0) ix = 0; if (ix > c->hf_rows - 2) ix = c->hf_rows - 2;
+    if (iy < 0) iy = 0; if (iy > c->hf_cols - 2) iy = c->hf_cols - 2;
+    int16_t a = hs[ix * c->hf_cols + iy], b = hs[(ix + 1) * c->hf_cols + iy], d = hs[ix * c->hf_cols + iy + 1];
+    int16_t m = a < b ? a : b; m = m < d ? m : d;
+    return (float)m * c->hf_vscale;
+}
 
 static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     const qa_config *cfg = &s->cfg;
@@ -365,28 +418,30 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     int nrows = 0;
     int foot_row[4], extra_row[4], extra_body[4];
     double mu = 0.5 * ((double)TP(s, QA_T_FRICTION, float)[e] + cfg->ground_friction);
-    v3 nB = {R[2][0], R[2][1], R[2][2]}, t1B = {R[0][0], R[0][1], R[0][2]}, t2B = {R[1][0], R[1][1], R[1][2]};
+    double cdirs[8][3][3];      /* world-frame (n, t1, t2) of each contact slot, for the force report */
     int row_leg_first[5] = {0, 0, 0, 0, 0};
     for (int l = 0; l < 4; ++l) {
         row_leg_first[l] = nrows;
         foot_row[l] = extra_row[l] = -1; extra_body[l] = -1;
         /* candidate points of this leg: slot 0 = foot; the other slot takes the min-gap non-foot point */
-        double best_gap = 1e30; v3 best_p = {0, 0, 0}; int best_depth = -1, best_body = -1;
-        double foot_gap = 0; v3 foot_p = {0, 0, 0};
+        double best_gap = 1e30; v3 best_p = {0, 0, 0}, best_n = {0, 0, 1}; int best_depth = -1, best_body = -1;
+        double foot_gap = 0; v3 foot_p = {0, 0, 0}, foot_n = {0, 0, 1};
         for (int c = 0; c < QA_NUM_LEG_PTS; ++c) {
             int k = QA_LEG_PT_LINK[l][c];
             v3 pl = {QA_LEG_PT_POS[l][c][0], QA_LEG_PT_POS[l][c][1], QA_LEG_PT_POS[l][c][2]}, p, pwld;
             mv(K.Rl[l][k], pl, p); for (int i = 0; i < 3; ++i) p[i] += K.o[l][k][i];
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
-            double gap = pwld[2] - QA_LEG_PT_RAD[l][c] - ground_height(cfg, pwld[0], pwld[1]);
-            if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); }
-            else if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); best_depth = k; best_body = QA_LEG_PT_BODY[l][c]; }
+            double gh; v3 gn; ground_query(s, pwld[0], pwld[1], &gh, gn);
+            double gap = (pwld[2] - gh) * gn[2] - QA_LEG_PT_RAD[l][c];      /* distance to the terrain triangle's plane */
+            if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); memcpy(foot_n, gn, sizeof(v3)); }
+            else if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); memcpy(best_n, gn, sizeof(v3)); best_depth = k; best_body = QA_LEG_PT_BODY[l][c]; }
         }
         for (int c = l; c < QA_NUM_BASE_PTS; c += 4) { /* base points are dealt round-robin to the four legs */
             v3 p = {QA_BASE_PT_POS[c][0], QA_BASE_PT_POS[c][1], QA_BASE_PT_POS[c][2]}, pwld;
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
-            double gap = pwld[2] - QA_BASE_PT_RAD[c] - ground_height(cfg, pwld[0], pwld[1]);
-            if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); best_depth = -1; best_body = QA_BASE_PT_BODY[c]; }
+            double gh; v3 gn; ground_query(s, pwld[0], pwld[1], &gh, gn);
+            double gap = (pwld[2] - gh) * gn[2] - QA_BASE_PT_RAD[c];
+            if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); memcpy(best_n, gn, sizeof(v3)); best_depth = -1; best_body = QA_BASE_PT_BODY[c]; }
         }
         for (int slot = 0; slot < 2; ++slot) {
             double gap = slot == 0 ? foot_gap : best_gap;
@@ -394,7 +449,11 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             int depth = slot == 0 ? 2 : best_depth;
             if (!(gap < cfg->contact_offset)) continue;
             if (slot == 0) foot_row[l] = nrows; else { extra_row[l] = nrows; extra_body[l] = best_body; }
-            const double *dirs[3] = {nB, t1B, t2B};
+            double (*cw)[3] = cdirs[2 * l + slot];
+            memcpy(cw[0], slot == 0 ? foot_n : best_n, sizeof(v3));
+            tangent_basis(cw[0], cw[1], cw[2]);
+            v3 dB[3]; for (int d = 0; d < 3; ++d) mtv(R, cw[d], dB[d]);       /* contact frame in base coordinates */
+            const double *dirs[3] = {dB[0], dB[1], dB[2]};
             for (int d = 0; d < 3; ++d) {
                 Row *r = &rows[nrows];
                 memset(r, 0, sizeof(*r));
@@ -502,13 +561,15 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     for (int j = 0; j < 12; ++j) { dof[2 * j] = (float)(q[j] + dt * u[6 + j]); dof[2 * j + 1] = (float)u[6 + j]; }
 
     for (int l = 0; l < 4; ++l) if (foot_row[l] >= 0) for (int d = 0; d < 3; ++d) fimp[3 * l + d] = (float)rows[foot_row[l] + d].lam;
-    /* ---- contact forces per body (world frame; plane => (t1,t2,n) are world x,y,z) */
+    /* ---- contact forces per body, world frame: lam_n n + lam_t1 t1 + lam_t2 t2 (plane: t1, t2, n are world x, y, z) */
     memset(cf, 0, sizeof(float) * 57);
-    for (int l = 0; l < 4; ++l) {
-        if (foot_row[l] >= 0) { int b = QA_LEG_PT_BODY[l][0], r0 = foot_row[l];
-            cf[3 * b + 0] += (float)(rows[r0 + 1].lam / dt); cf[3 * b + 1] += (float)(rows[r0 + 2].lam / dt); cf[3 * b + 2] += (float)(rows[r0].lam / dt); }
-        if (extra_row[l] >= 0) { int b = extra_body[l], r0 = extra_row[l];
-            cf[3 * b + 0] += (float)(rows[r0 + 1].lam / dt); cf[3 * b + 1] += (float)(rows[r0 + 2].lam / dt); cf[3 * b + 2] += (float)(rows[r0].lam / dt); }
+    for (int l = 0; l < 4; ++l) for (int slot = 0; slot < 2; ++slot) {
+        int r0 = slot == 0 ? foot_row[l] : extra_row[l];
+        if (r0 < 0) continue;
+        int b = slot == 0 ? QA_LEG_PT_BODY[l][0] : extra_body[l];
+        double (*cw)[3] = cdirs[2 * l + slot];
+        for (int i = 0; i < 3; ++i)
+            cf[3 * b + i] += (float)((rows[r0].lam * cw[0][i] + rows[r0 + 1].lam * cw[1][i] + rows[r0 + 2].lam * cw[2][i]) / dt);
     }
     /* ---- body-origin positions with the NEW state (what refresh_rigid_body_state_tensor returns) */
     {
@@ -594,6 +655,7 @@ static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity, int repo
         for (int b = 0; b < 5; ++b) rng4(s, e, step, RS_RESET, b, u + 4 * b);
         for (int j = 0; j < 12; ++j) { dof[2 * j] = c->default_dof_pos[j] * ((1.5f - 0.5f) * u[j] + 0.5f); dof[2 * j + 1] = 0.0f; }
         for (int i = 0; i < 3; ++i) root[i] = c->init_pos[i] + org[i];
+        if (c->reset_xy_jitter > 0.0f) { root[0] += (2.0f * u[18] - 1.0f) * c->reset_xy_jitter; root[1] += (2.0f * u[19] - 1.0f) * c->reset_xy_jitter; }   /* :622-625 */
         root[3] = 0; root[4] = 0; root[5] = 0; root[6] = 1;
         for (int i = 0; i < 6; ++i) root[7 + i] = (0.5f - -0.5f) * u[12 + i] + -0.5f;
     }
@@ -624,7 +686,7 @@ static void compute_observations(qo_sim *s, int e, int64_t step) {
     const float *rbp = TP(s, QA_T_RIGID_BODY_POS, float) + 57 * e;
     const uint8_t *cfilt = TP(s, QA_T_CONTACT_FILT, uint8_t) + 4 * e;
     int N = c->num_envs;
-    float root_h = root[2];
+    float root_h = root[2] - TP(s, QA_T_SCAN_HEIGHT, float)[e];      /* measured height is the pre-reset one, like the reference's */
     /* heading-inverse rotation of the feet (torch_jit_utils.py:23-76) */
     float xdir[3] = {1, 0, 0}, rot_dir[3];
     quat_rotate_f(root + 3, xdir, +1.0f, rot_dir);
@@ -707,6 +769,7 @@ static void post_physics(qo_sim *s, int e, int64_t step, float *term_disc_tmp) {
     }
     /* _post_physics_step_callback :449-472 */
     if (*epl % c->resampling_steps == 0) resample_commands(s, e, step, RS_CMD);
+    TP(s, QA_T_SCAN_HEIGHT, float)[e] = scan_center_height(s, root);      /* self.measured_heights = self._get_heights() (:469-470) */
     if (c->push_robots && common % c->push_interval == 0) {
         float u[4]; rng4(s, e, step, RS_PUSH, 0, u);
         root[7] = (c->max_push_vel_xy - -c->max_push_vel_xy) * u[0] + -c->max_push_vel_xy;
@@ -746,7 +809,7 @@ static void post_physics(qo_sim *s, int e, int64_t step, float *term_disc_tmp) {
         const float *f = cfo + 3 * (3 + 4 * l + k);
         if (sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) > 0.1f) term[QA_R_COLLISION] += 1.0f;
     }
-    { float root_h = root[2];
+    { float root_h = root[2] - TP(s, QA_T_SCAN_HEIGHT, float)[e];
       float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
       term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c->jump_height[0]) ? c->jump_goal : 0.0f;
       float el = sqrtf((cmd[4] - root_h) * (cmd[4] - root_h));

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 3
+QA_ABI_VERSION = 4
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -30,10 +30,10 @@ TENSORS = [
     "LATENT_EPS", "LATENT_C", "REW", "RESET", "TIME_OUT", "EPISODE_LENGTH", "EPISODE_SUMS",
     "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
     "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",
-    "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES", "FOOT_IMPULSE",
+    "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES", "HEIGHT_SAMPLES", "SCAN_HEIGHT", "FOOT_IMPULSE",
 ]
 T = {name: i for i, name in enumerate(TENSORS)}
-DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32 = 0, 1, 2, 3
+DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32, DTYPE_I16 = 0, 1, 2, 3, 4
 
 BODY_NAMES = ["base", "Head_upper", "Head_lower"] + [
     f"{l}_{p}" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf", "foot")]
@@ -72,6 +72,8 @@ class QaConfig(C.Structure):
         ("friction_range", C.c_float * 2), ("added_mass_range", C.c_float * 2),
         ("added_com_range", C.c_float * 2), ("motor_strength_range", C.c_float * 2),
         ("easi_mean", C.c_float * 6), ("easi_var", C.c_float * 6),
+        ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("hf_hscale", C.c_float), ("hf_vscale", C.c_float),
+        ("hf_border", C.c_float), ("reset_xy_jitter", C.c_float),
         ("num_mocap_frames", C.c_int32), ("mocap_clip_count", C.c_int32 * NUM_GAITS),
     ]
 

@@ -97,6 +97,80 @@ QA_DEV void sym6_mul(const float *A, const float *x, float *y) {
     }
 }
 
+// Terrain under an env: a 16 x 16 window of height samples (metres) staged in LDS once per env step, centred on the
+// base.  Leg points reach < 0.6 m from the base origin and the base moves < 0.1 m per env step, so every contact
+// query of the 4 substeps falls inside the window (+-0.8 m); indices are clamped regardless.
+#define QA_PATCH 16
+struct TerrainView {
+    const float *patch;      // LDS, QA_PATCH x QA_PATCH, row-major (x major), metres
+    const int16_t *samples;  // the whole field in HBM (fallback for queries outside the window)
+    int ix0, iy0;            // global cell of patch[0][0]
+    int rows, cols;
+    float border, hscale, inv_hscale, vscale;
+};
+// window origin for a base at world (x, y)
+QA_DEV void patch_origin(TerrainView &T, float x, float y) {
+    int cx = (int)floorf((x + T.border) * T.inv_hscale), cy = (int)floorf((y + T.border) * T.inv_hscale);
+    T.ix0 = max(min(cx - (QA_PATCH / 2 - 1), T.rows - QA_PATCH), 0);
+    T.iy0 = max(min(cy - (QA_PATCH / 2 - 1), T.cols - QA_PATCH), 0);
+}
+// the quad of an env fills its window: lane `leg` loads rows 4 leg .. 4 leg + 3
+QA_DEV void stage_patch(const TerrainView &T, float *patch, int leg) {
+#pragma unroll
+    for (int r = 0; r < QA_PATCH / 4; ++r) {
+        const int lx = 4 * leg + r, gx = min(T.ix0 + lx, T.rows - 1);
+        const int16_t *src = T.samples + (int64_t)gx * T.cols;
+        int16_t v[QA_PATCH];
+#pragma unroll
+        for (int j = 0; j < QA_PATCH; ++j) v[j] = src[min(T.iy0 + j, T.cols - 1)];
+#pragma unroll
+        for (int j = 0; j < QA_PATCH; ++j) patch[lx * QA_PATCH + j] = (float)v[j] * T.vscale;
+    }
+}
+// height and unit normal of the terrain under world (x, y): two triangles per cell, split along (i,j)-(i+1,j+1)
+QA_DEV void ground_query(const TerrainView &T, float x, float y, float &h, V3 &n) {
+    float fx = (x + T.border) * T.inv_hscale, fy = (y + T.border) * T.inv_hscale;
+    int ix = min(max((int)floorf(fx), 0), T.rows - 2), iy = min(max((int)floorf(fy), 0), T.cols - 2);
+    float u = clampf(fx - (float)ix, 0.f, 1.f), v = clampf(fy - (float)iy, 0.f, 1.f);
+    int lx = ix - T.ix0, ly = iy - T.iy0;
+    float h00, h01, h10, h11;
+    if ((unsigned)lx <= QA_PATCH - 2 && (unsigned)ly <= QA_PATCH - 2) {
+        const float *c = T.patch + lx * QA_PATCH + ly;
+        h00 = c[0]; h01 = c[1]; h10 = c[QA_PATCH]; h11 = c[QA_PATCH + 1];
+    } else {        // outside the window (a fully stretched leg at the window edge): read the field itself
+        const int16_t *g = T.samples + (int64_t)ix * T.cols + iy;
+        h00 = (float)g[0] * T.vscale; h01 = (float)g[1] * T.vscale; h10 = (float)g[T.cols] * T.vscale; h11 = (float)g[T.cols + 1] * T.vscale;
+    }
+    float gx, gy;
+    if (u >= v) { gx = h10 - h00; gy = h11 - h10; h = h00 + u * gx + v * gy; }
+    else { gy = h01 - h00; gx = h11 - h01; h = h00 + v * gy + u * gx; }
+    gx *= T.inv_hscale; gy *= T.inv_hscale;
+    float inv = rsqrtf(gx * gx + gy * gy + 1.0f);
+    n = v3(-gx * inv, -gy * inv, inv);
+}
+// legged_robot.py:1209-1228 for the one scan point the BBC env consumes: (0, 0.1) in the yaw frame, truncated to a
+// cell, min of three samples.  Integer samples are read from HBM (one env-step-level lookup per quad).
+QA_DEV float scan_center_height(const TerrainView &T, V3 pos, float qz, float qw) {
+    float nrm = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+    qz /= nrm; qw /= nrm;
+    const float vx = 0.0f, vy = 0.1f;
+    float tx = -qz * vy * 2.0f, ty = qz * vx * 2.0f;
+    float px = vx + qw * tx - qz * ty + pos.x, py = vy + qw * ty + qz * tx + pos.y;
+    px += T.border; py += T.border;
+    int ix = (int)(px / T.hscale), iy = (int)(py / T.hscale);
+    ix = min(max(ix, 0), T.rows - 2); iy = min(max(iy, 0), T.cols - 2);
+    const int16_t *g = T.samples + (int64_t)ix * T.cols + iy;
+    int a = g[0], b = g[T.cols], d = g[1];
+    int m = min(min(a, b), d);
+    return (float)m * T.vscale;
+}
+// tangent basis of a contact: t1 = world x projected onto the tangent plane, t2 = n x t1
+QA_DEV void tangent_basis(V3 n, V3 &t1, V3 &t2) {
+    V3 a = v3(1.0f - n.x * n.x, -n.x * n.y, -n.x * n.z);
+    t1 = rsqrtf(dot(a, a)) * a;
+    t2 = cross(n, t1);
+}
+
 // state of one env as seen by one lane (registers)
 struct EnvState {
     V3 pos; float qx, qy, qz, qw; V3 vw, ww;    // root, replicated across the quad
@@ -212,7 +286,7 @@ QA_DEV void row_load(float *priv, int base, Row &r) {
 
 template <bool PLANE>
 QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
-                         float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3]) {
+                         float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3], const TerrainView &T) {
     const float dt = P.dt;
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     S6 V0 = s6(mulT(R, st.ww), mulT(R, st.vw));
@@ -327,7 +401,8 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     }
 
     // ---- contact candidates: slot 0 = foot sphere, slot 1 = closest other point owned by this lane
-    V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);
+    V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);   // plane: world z, x, y
+    V3 foot_n = v3(0, 0, 1), best_n = v3(0, 0, 1);          // world-frame contact normals (height field)
     float foot_gap; V3 foot_p;
     float best_gap = 1e30f; V3 best_p = v3(0, 0, 0); int best_depth = 0, best_body = -1;
 #pragma unroll
@@ -335,10 +410,15 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         const int k = (c == 0) ? 2 : (c < 3 ? 0 : (c < 11 ? 1 : 2));
         const float *pt = tbl + T_POINTS + 4 * c;
         V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
-        float zw = dot(nB, p) + st.pos.z;            // plane: only the world height matters
-        float gap = zw - pt[3];
-        if (c == 0) { foot_gap = gap; foot_p = p; }
-        else if (gap < best_gap) { best_gap = gap; best_p = p; best_depth = k + 1; best_body = 3 + 4 * leg + k; }
+        float zw = dot(nB, p) + st.pos.z;
+        float gap; V3 gn = v3(0, 0, 1);
+        if (PLANE) gap = zw - pt[3];                 // plane: only the world height matters
+        else {
+            float gh; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
+            gap = (zw - gh) * gn.z - pt[3];          // distance to the terrain triangle's plane
+        }
+        if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; }
+        else if (gap < best_gap) { best_gap = gap; best_p = p; best_n = gn; best_depth = k + 1; best_body = 3 + 4 * leg + k; }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -346,8 +426,14 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         if (c < QA_BASE_PTS) {
             const float *pt = btbl + 4 * c;
             V3 p = v3(pt[0], pt[1], pt[2]);
-            float gap = dot(nB, p) + st.pos.z - pt[3];
-            if (gap < best_gap) { best_gap = gap; best_p = p; best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2); }
+            float zw = dot(nB, p) + st.pos.z;
+            float gap; V3 gn = v3(0, 0, 1);
+            if (PLANE) gap = zw - pt[3];
+            else {
+                float gh; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
+                gap = (zw - gh) * gn.z - pt[3];
+            }
+            if (gap < best_gap) { best_gap = gap; best_p = p; best_n = gn; best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2); }
         }
     }
     const bool foot_on = foot_gap < P.contact_offset;
@@ -355,12 +441,16 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 
     // ---- rows (all in registers; inactive ones are skipped wave-uniformly below)
     Row rf[3];
-    contact_rows(rf, foot_p, 3, foot_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
+    V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
+    if (!PLANE) { tangent_basis(foot_n, ft1_w, ft2_w); fn_b = mulT(R, foot_n); ft1_b = mulT(R, ft1_w); ft2_b = mulT(R, ft2_w); }
+    contact_rows(rf, foot_p, 3, foot_gap, o, ax, fn_b, ft1_b, ft2_b, G, Linv, Binv, P);
     const bool any_extra = __any(extra_on);
     float re_lam[3] = {0.f, 0.f, 0.f};
     if (any_extra) {
         Row re[3];
-        contact_rows(re, best_p, best_depth, best_gap, o, ax, nB, t1B, t2B, G, Linv, Binv, P);
+        V3 en_b = nB, et1_b = t1B, et2_b = t2B;
+        if (!PLANE) { V3 a, b; tangent_basis(best_n, a, b); en_b = mulT(R, best_n); et1_b = mulT(R, a); et2_b = mulT(R, b); }
+        contact_rows(re, best_p, best_depth, best_gap, o, ax, en_b, et1_b, et2_b, G, Linv, Binv, P);
 #pragma unroll
         for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 20 * d, re[d]);
     }
@@ -502,8 +592,14 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     for (int d = 0; d < 3; ++d) fimp[d] = foot_on ? rf[d].lam : 0.f;
     // ---- contact forces, world frame (plane: t1, t2, n are world x, y, z)
     float idt = 1.0f / dt;
-    co.foot_f = foot_on ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
-    co.extra_f = (any_extra && extra_on) ? v3(re_lam[1] * idt, re_lam[2] * idt, re_lam[0] * idt) : v3(0, 0, 0);
+    if (PLANE) {
+        co.foot_f = foot_on ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
+        co.extra_f = (any_extra && extra_on) ? v3(re_lam[1] * idt, re_lam[2] * idt, re_lam[0] * idt) : v3(0, 0, 0);
+    } else {   // lam_n n + lam_t1 t1 + lam_t2 t2 in the world frame
+        co.foot_f = foot_on ? idt * ((rf[0].lam * foot_n) + (rf[1].lam * ft1_w) + (rf[2].lam * ft2_w)) : v3(0, 0, 0);
+        V3 a, b; tangent_basis(best_n, a, b);
+        co.extra_f = (any_extra && extra_on) ? idt * ((re_lam[0] * best_n) + (re_lam[1] * a) + (re_lam[2] * b)) : v3(0, 0, 0);
+    }
     co.extra_body = (any_extra && extra_on) ? best_body : -1;
 }
 

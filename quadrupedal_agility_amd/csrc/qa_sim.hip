@@ -34,9 +34,10 @@ struct Layout {
     int32_t dtype[QA_T_COUNT];
     int64_t total;
 };
-static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : 1; }
+static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : d == QA_I16 ? 2 : 1; }
 static void make_layout(const qa_config *cfg, Layout *L) {
     const int64_t N = cfg->num_envs, F = cfg->num_mocap_frames > 0 ? cfg->num_mocap_frames : 1;
+    const int64_t HR = cfg->terrain_type == 1 ? cfg->hf_rows : 1, HC = cfg->terrain_type == 1 ? cfg->hf_cols : 1;
     struct Spec { int t, dt, nd; int64_t a, b, c; };
     const Spec specs[] = {
         {QA_T_ROOT_STATES, QA_F32, 2, N, 13, 1}, {QA_T_DOF_STATE, QA_F32, 3, N, 12, 2},
@@ -58,7 +59,8 @@ static void make_layout(const qa_config *cfg, Layout *L) {
         {QA_T_MOTOR_STRENGTH, QA_F32, 3, 2, N, 12}, {QA_T_MASS_PARAMS, QA_F32, 2, N, 4, 1},
         {QA_T_FRICTION, QA_F32, 1, N, 1, 1}, {QA_T_ENV_ORIGINS, QA_F32, 2, N, 3, 1},
         {QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1}, {QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1},
-        {QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1}, {QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3},
+        {QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1}, {QA_T_HEIGHT_SAMPLES, QA_I16, 2, HR, HC, 1},
+        {QA_T_SCAN_HEIGHT, QA_F32, 1, N, 1, 1}, {QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3},
     };
     static_assert(sizeof(specs) / sizeof(specs[0]) == QA_T_COUNT, "every tensor needs a spec");
     memset(L, 0, sizeof(*L));
@@ -77,7 +79,8 @@ struct Ptrs {
     float *root, *dof, *cforce, *rbpos, *torques, *torques_org, *actions, *last_actions, *last_dof_vel,
         *last_torques_org, *last_root_vel, *action_hist, *obs, *obs_disc, *obs_disc_term, *commands,
         *latent_eps, *latent_c, *rew, *episode_sums, *episode_stats, *feet_force, *base_lin_vel, *base_ang_vel,
-        *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap, *foot_impulse;
+        *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap, *foot_impulse, *scan_height;
+    int16_t *height_samples;
     int64_t *reset, *episode_length;
     uint8_t *time_out, *last_contacts, *contact_filt;
 };
@@ -173,10 +176,18 @@ __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, con
             st.qd[k] = 0.f;
         }
         st.pos = v3(c.init_pos[0] + ox, c.init_pos[1] + oy, c.init_pos[2] + oz);
+        if (c.reset_xy_jitter > 0.0f) { st.pos.x += (2.0f * u[18] - 1.0f) * c.reset_xy_jitter; st.pos.y += (2.0f * u[19] - 1.0f) * c.reset_xy_jitter; }   // :622-625
         st.qx = 0; st.qy = 0; st.qz = 0; st.qw = 1;
         st.vw = v3(u[12] - 0.5f, u[13] - 0.5f, u[14] - 0.5f);
         st.ww = v3(u[15] - 0.5f, u[16] - 0.5f, u[17] - 0.5f);
     }
+}
+
+__device__ __forceinline__ TerrainView terrain_view(const qa_config &c, const Ptrs &p, const float *patch) {
+    TerrainView T;
+    T.patch = patch; T.samples = p.height_samples; T.ix0 = 0; T.iy0 = 0; T.rows = c.hf_rows; T.cols = c.hf_cols;
+    T.border = c.hf_border; T.hscale = c.hf_hscale; T.inv_hscale = 1.0f / c.hf_hscale; T.vscale = c.hf_vscale;
+    return T;
 }
 
 // ------------------------------------------------------------------ the fused env step
@@ -209,6 +220,7 @@ __device__ __forceinline__ void store_obs_row(float *dst, const float *row, int 
     if (lane < 3 - head) dst[head + 668 + lane] = row[head + 668 + lane];
 }
 
+template <bool PLANE>
 __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_stage[ENVS_PER_BLOCK * S_ENV];
@@ -286,6 +298,14 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity;
     P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
 
+    // ---- terrain window: staged in the rows buffer, which is idle until the observation phase
+    TerrainView T = terrain_view(c, p, s_rows + le * (QA_PATCH * QA_PATCH));
+    if (!PLANE) {
+        patch_origin(T, st.pos.x, st.pos.y);
+        stage_patch(T, s_rows + le * (QA_PATCH * QA_PATCH), leg);
+        __syncthreads();
+    }
+
     QA_STAMP(2);
     // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
     // per-step constants are parked in per-lane LDS slots between substeps so that they do not hold VGPRs
@@ -317,7 +337,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             float lim = tbl[T_EFFORT + k];
             tau[k] = clampf(t, -lim, lim);
         }
-        phys_substep<true>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp);
+        phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
@@ -393,6 +413,8 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         st.vw.x = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[0] + -c.max_push_vel_xy;
         st.vw.y = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[1] + -c.max_push_vel_xy;
     }
+    // measured_heights (:469-470): before any reset, like the reference's callback
+    const float scan_h = PLANE ? 0.0f : scan_center_height(T, st.pos, st.qz, st.qw);
     // ---- check_termination :168-176
     int term_c = (sqrtf(dot(hip_f, hip_f)) > 1.0f) ? 1 : 0;
     term_c = quad_or(term_c) | (sqrtf(dot(base_f, base_f)) > 1.0f ? 1 : 0);
@@ -429,7 +451,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         term[QA_R_DOF_ACC] = quad_sum(s_acc); term[QA_R_DOF_ERROR] = quad_sum(s_err); term[QA_R_DOF_POS_LIMITS] = quad_sum(s_pl);
         term[QA_R_DOF_VEL_LIMITS] = quad_sum(s_vl); term[QA_R_HIP_POS] = quad_sum(s_hip); term[QA_R_TORQUE_LIMITS] = quad_sum(s_tl);
         term[QA_R_TORQUES] = quad_sum(s_tq);
-        const float root_h = st.pos.z;
+        const float root_h = st.pos.z - scan_h;
         float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
         term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c.jump_height[0]) ? c.jump_goal : 0.f;
         float el = sqrtf((cmd[4] - root_h) * (cmd[4] - root_h));
@@ -483,7 +505,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         V3 rel = foot_w - st.pos;
         key = quat_rot(0.f, 0.f, sh * hn, ch * hn, rel, 1.f);
     }
-    const float root_h = st.pos.z;
+    const float root_h = st.pos.z - scan_h;      // post-reset z, pre-reset measured height (:261-273 after :178)
     // proprioception (57): lanes write their own joints, lane 0 the shared entries
     {
         float *pr = sst + S_PROP;
@@ -549,6 +571,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         if (leg == 0) {
             rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
             rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
+            if (!PLANE) p.scan_height[env] = scan_h;
             p.rew[env] = rew; p.reset[env] = reset; p.time_out[env] = (uint8_t)timeout; p.episode_length[env] = epl;
             float *o3;
             o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
@@ -718,9 +741,11 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptr
     for (int i = leg; i < 570; i += 4) p.obs[(int64_t)env * QA_NUM_OBS + 90 + i] = 0.f;
 }
 
+template <bool PLANE>
 __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
+    __shared__ float s_patch[PLANE ? 1 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH];
     stage_table(s_tbl);
     const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, leg = threadIdx.x & 3, N = c.num_envs;
     const bool valid = (tid >> 2) < N;
@@ -737,7 +762,15 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     ContactOut co;
     float fimp[3];
     for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
-    phys_substep<true>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp);
+    TerrainView T = terrain_view(c, p, s_patch);
+    if (!PLANE) {
+        float *mine = s_patch + (threadIdx.x >> 2) * (QA_PATCH * QA_PATCH);
+        T.patch = mine;
+        patch_origin(T, st.pos.x, st.pos.y);
+        stage_patch(T, mine, leg);
+        __syncthreads();
+    }
+    phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
     V3 org[4]; leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 z = v3(0, 0, 0);
@@ -822,11 +855,12 @@ static void fill_ptrs(qa_sim *s) {
     FP(rew, QA_T_REW); FP(episode_sums, QA_T_EPISODE_SUMS); FP(episode_stats, QA_T_EPISODE_STATS); FP(feet_force, QA_T_FEET_FORCE);
     FP(base_lin_vel, QA_T_BASE_LIN_VEL); FP(base_ang_vel, QA_T_BASE_ANG_VEL); FP(proj_grav, QA_T_PROJECTED_GRAVITY); FP(rpy, QA_T_RPY);
     FP(motor_strength, QA_T_MOTOR_STRENGTH); FP(mass_params, QA_T_MASS_PARAMS); FP(friction, QA_T_FRICTION); FP(env_origins, QA_T_ENV_ORIGINS);
-    FP(base_inertia, QA_T_BASE_INERTIA); FP(prior, QA_T_PRIOR_PARAMETERS); FP(mocap, QA_T_MOCAP_FRAMES); FP(foot_impulse, QA_T_FOOT_IMPULSE);
+    FP(base_inertia, QA_T_BASE_INERTIA); FP(prior, QA_T_PRIOR_PARAMETERS); FP(mocap, QA_T_MOCAP_FRAMES); FP(foot_impulse, QA_T_FOOT_IMPULSE); FP(scan_height, QA_T_SCAN_HEIGHT);
 #undef FP
     p.reset = (int64_t *)(a + L.off[QA_T_RESET]); p.episode_length = (int64_t *)(a + L.off[QA_T_EPISODE_LENGTH]);
     p.time_out = (uint8_t *)(a + L.off[QA_T_TIME_OUT]); p.last_contacts = (uint8_t *)(a + L.off[QA_T_LAST_CONTACTS]);
     p.contact_filt = (uint8_t *)(a + L.off[QA_T_CONTACT_FILT]);
+    p.height_samples = (int16_t *)(a + L.off[QA_T_HEIGHT_SAMPLES]);
 }
 
 static void build_table(float *t) {
@@ -872,7 +906,7 @@ int qa_tensor_info(const qa_config *cfg, int which, int64_t *off, int64_t shape[
 int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stream, qa_sim **out) {
     if (!cfg || !arena || !out || cfg->num_envs <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: bad argument"); return QA_E_ARG; }
     if (cfg->abi_version != QA_ABI_VERSION) return QA_E_VERSION;
-    if (cfg->terrain_type != 0 || cfg->decimation <= 0 || cfg->solver_iterations <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: unsupported config"); return QA_E_ARG; }
+    if ((cfg->terrain_type != 0 && cfg->terrain_type != 1) || (cfg->terrain_type == 1 && (cfg->hf_rows < 2 || cfg->hf_cols < 2 || !(cfg->hf_hscale > 0.0f))) || cfg->decimation <= 0 || cfg->solver_iterations <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: unsupported config"); return QA_E_ARG; }
     qa_sim *s = new qa_sim();
     s->cfg = *cfg; make_layout(cfg, &s->L); s->arena = (char *)arena;
     memset(s->mocap_first, 0, sizeof(s->mocap_first));
@@ -908,7 +942,8 @@ int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t gl
     if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step; a.step_ptr = nullptr; a.prof = s->prof;
     const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-    hipLaunchKernelGGL(qa_env_step_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL(qa_env_step_kernel<false>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(qa_env_step_kernel<true>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }
@@ -920,7 +955,8 @@ int qa_env_step_dev(qa_sim *s, const float *actions, int32_t delay_steps, int64_
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = 0;
     a.step_ptr = step_counter_dev; a.prof = s->prof;
     const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-    hipLaunchKernelGGL(qa_env_step_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL(qa_env_step_kernel<false>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(qa_env_step_kernel<true>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(qa_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter_dev);
     HIP_TRY(hipGetLastError());
     return QA_OK;
@@ -937,7 +973,8 @@ int qa_reset_all(qa_sim *s, int64_t global_step, void *stream) {
 int qa_simulate(qa_sim *s, const float *torques, void *stream) {
     if (!s || !torques) return QA_E_ARG;
     const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-    hipLaunchKernelGGL(qa_simulate_kernel, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL(qa_simulate_kernel<false>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    else hipLaunchKernelGGL(qa_simulate_kernel<true>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }

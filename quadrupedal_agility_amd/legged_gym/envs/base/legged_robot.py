@@ -57,7 +57,11 @@ class LeggedRobot:
             raise NotImplementedError("observation layout is fixed by the kernels: 57 prop, 10 history frames, 49 disc")
 
         # ---- engine
-        self.qcfg = make_qa_config(cfg, seed=getattr(cfg, "seed", 1), sim_dt=self.sim_params.dt)
+        self.terrain = None
+        if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            from quadrupedal_agility_amd.legged_gym.utils.terrain import Terrain
+            self.terrain = Terrain(cfg.terrain, cfg.env.num_envs)          # legged_robot.py:353-355
+        self.qcfg = make_qa_config(cfg, seed=getattr(cfg, "seed", 1), sim_dt=self.sim_params.dt, terrain=self.terrain)
         self._mocap_table = None
         if cfg.env.mocap_state_init:
             self._mocap_table = self._build_mocap_reset_table()
@@ -70,6 +74,7 @@ class LeggedRobot:
         if self._mocap_table is not None:
             self.sim.set_mocap(*self._mocap_table)
         self._init_buffers()
+        self._install_terrain()
         self._prepare_reward_function()
         self.init_done = True
 
@@ -178,7 +183,6 @@ class LeggedRobot:
         self.thigh_indices = torch.tensor([1, 4, 7, 10], device=dev)
         self.calf_indices = torch.tensor([2, 5, 8, 11], device=dev)
         self.prior_prob = torch.ones(self.dim_c, device=dev) / self.dim_c
-        self.measured_heights = 0
         self.add_noise = self.cfg.noise.add_noise
         self.noise_scale_vec = self._get_noise_scale_vec(self.cfg)
         self._episode_means = torch.zeros(_capi.NUM_REWARDS, device=dev)
@@ -189,6 +193,47 @@ class LeggedRobot:
         v[:2] = q.noise_roll_pitch; v[2:5] = q.noise_ang_vel; v[5:17] = q.noise_dof_pos; v[17:29] = q.noise_dof_vel
         v[58:61] = q.noise_lin_vel
         return v
+
+    # ------------------------------------------------------------------ terrain (legged_robot.py:958-993, 1109-1125, 1174-1228)
+    def _install_terrain(self):
+        self.custom_origins = self.terrain is not None
+        dev = self.device
+        y = torch.tensor(self.cfg.terrain.measured_points_y, device=dev)
+        x = torch.tensor(self.cfg.terrain.measured_points_x, device=dev)
+        gx, gy = torch.meshgrid(x, y, indexing="ij")
+        self.num_height_points = gx.numel()
+        self.height_points = torch.zeros(self.num_envs, self.num_height_points, 3, device=dev)
+        self.height_points[:, :, 0] = gx.flatten()
+        self.height_points[:, :, 1] = gy.flatten()
+        if self.terrain is None:
+            return
+        t = self.terrain
+        self.height_samples = torch.tensor(t.heightsamples).view(t.tot_rows, t.tot_cols).to(dev)
+        self.sim.t["HEIGHT_SAMPLES"].copy_(self.height_samples)                 # gym.add_heightfield / add_triangle_mesh
+        max_init_level = self.cfg.terrain.max_init_terrain_level if self.cfg.terrain.curriculum else self.cfg.terrain.num_rows - 1
+        self.terrain_levels = torch.randint(0, max_init_level + 1, (self.num_envs,), device=dev)
+        self.terrain_types = torch.div(torch.arange(self.num_envs, device=dev), (self.num_envs / self.cfg.terrain.num_cols),
+                                       rounding_mode="floor").to(torch.long)
+        self.max_terrain_level = self.cfg.terrain.num_rows
+        self.terrain_origins = torch.from_numpy(t.env_origins).to(dev).to(torch.float)
+        self.env_origins.copy_(self.terrain_origins[self.terrain_levels, self.terrain_types])
+
+    def _get_heights(self, env_ids=None):
+        """The reference's 187-point height scan (legged_robot.py:1190-1228) for callers that want all of it; the
+        kernel itself only evaluates the one sample the BBC observation/reward use (SCAN_HEIGHT)."""
+        from quadrupedal_agility_amd.legged_gym.utils.torch_jit_utils import quat_apply_yaw
+        if self.terrain is None:
+            return torch.zeros(self.num_envs, self.num_height_points, device=self.device)
+        pts = quat_apply_yaw(self.base_quat.repeat(1, self.num_height_points), self.height_points) + self.root_states[:, :3].unsqueeze(1)
+        pts = ((pts + self.cfg.terrain.border_size) / self.cfg.terrain.horizontal_scale).long()
+        px = torch.clip(pts[:, :, 0].reshape(-1), 0, self.height_samples.shape[0] - 2)
+        py = torch.clip(pts[:, :, 1].reshape(-1), 0, self.height_samples.shape[1] - 2)
+        h = torch.min(torch.min(self.height_samples[px, py], self.height_samples[px + 1, py]), self.height_samples[px, py + 1])
+        return h.view(self.num_envs, -1) * self.cfg.terrain.vertical_scale
+
+    @property
+    def measured_heights(self):
+        return self._get_heights() if self.cfg.terrain.measure_heights else 0
 
     # attributes the learner REBINDS (on_policy_runner.py:123-125, gail.py:463-464): write through to the arena
     @property

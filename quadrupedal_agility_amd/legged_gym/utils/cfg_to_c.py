@@ -20,7 +20,7 @@ def class_to_dict(obj):
     return out
 
 
-def make_qa_config(cfg, seed=1, sim_dt=None):
+def make_qa_config(cfg, seed=1, sim_dt=None, terrain=None):
     c = _capi.QaConfig()
     c.abi_version = _capi.QA_ABI_VERSION
     c.num_envs = int(cfg.env.num_envs)
@@ -33,10 +33,18 @@ def make_qa_config(cfg, seed=1, sim_dt=None):
     c.contact_offset = float(cfg.sim.physx.contact_offset)
     c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
     c.ground_friction = float(cfg.terrain.static_friction)
-    if cfg.terrain.mesh_type not in ("plane", None, "none"):
-        raise NotImplementedError(
-            f"terrain.mesh_type={cfg.terrain.mesh_type!r}: only 'plane' is implemented (SURVEY.md 8f row 2)")
-    c.terrain_type = 0
+    if cfg.terrain.mesh_type in ("plane", None, "none"):
+        c.terrain_type = 0
+    elif cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+        if terrain is None:
+            raise ValueError("a generated Terrain is needed for mesh_type 'heightfield' / 'trimesh'")
+        c.terrain_type = 1
+        c.hf_rows, c.hf_cols = int(terrain.tot_rows), int(terrain.tot_cols)
+        c.hf_hscale, c.hf_vscale = float(cfg.terrain.horizontal_scale), float(cfg.terrain.vertical_scale)
+        c.hf_border = float(cfg.terrain.border_size)
+        c.reset_xy_jitter = 1.0          # custom_origins branch of _reset_root_states (legged_robot.py:622-625)
+    else:
+        raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
     if cfg.control.control_type != "P":
         raise NotImplementedError("only control_type 'P' (legged_robot.py:563-570) is on the hot path")
     kp = _gain(cfg.control.stiffness)

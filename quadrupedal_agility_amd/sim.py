@@ -11,8 +11,8 @@ import torch
 from . import _capi
 
 _TORCH_DT = {_capi.DTYPE_F32: torch.float32, _capi.DTYPE_I64: torch.int64, _capi.DTYPE_U8: torch.uint8,
-             _capi.DTYPE_I32: torch.int32}
-_ITEM = {_capi.DTYPE_F32: 4, _capi.DTYPE_I64: 8, _capi.DTYPE_U8: 1, _capi.DTYPE_I32: 4}
+             _capi.DTYPE_I32: torch.int32, _capi.DTYPE_I16: torch.int16}
+_ITEM = {_capi.DTYPE_F32: 4, _capi.DTYPE_I64: 8, _capi.DTYPE_U8: 1, _capi.DTYPE_I32: 4, _capi.DTYPE_I16: 2}
 
 
 def _check(rc, lib, what):

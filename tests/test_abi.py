@@ -48,6 +48,11 @@ def test_layout_agrees_between_library_and_oracle(hip_lib):
         assert hip_lib.qa_arena_bytes(C.byref(q)) == lib_o.qo_arena_bytes(C.byref(q))
         for name, idx in _capi.T.items():
             assert _capi.tensor_info(hip_lib, "qa_", q, idx) == _capi.tensor_info(lib_o, "qo_", q, idx), name
+    q = go2_cfg(33); q.terrain_type = 1; q.hf_rows, q.hf_cols, q.hf_hscale, q.hf_vscale, q.hf_border = 321, 123, 0.1, 0.005, 2.0
+    assert hip_lib.qa_arena_bytes(C.byref(q)) == lib_o.qo_arena_bytes(C.byref(q))
+    for name, idx in _capi.T.items():
+        assert _capi.tensor_info(hip_lib, "qa_", q, idx) == _capi.tensor_info(lib_o, "qo_", q, idx), name
+    assert _capi.tensor_info(hip_lib, "qa_", q, _capi.T["HEIGHT_SAMPLES"])[1:] == ((321, 123), _capi.DTYPE_I16)
     q = go2_cfg(4096)
     off, shape, dt = _capi.tensor_info(hip_lib, "qa_", q, _capi.T["OBS"])
     assert shape == (4096, 671) and dt == _capi.DTYPE_F32 and off % 256 == 0
@@ -56,7 +61,7 @@ def test_layout_agrees_between_library_and_oracle(hip_lib):
 def test_config_struct_size_matches_c():
     # the oracle is plain C: ask it how big it thinks qa_config is by probing an out-of-range read guard
     q = go2_cfg(8)
-    assert C.sizeof(q) == 576
+    assert C.sizeof(q) == 600          # ABI v4: + hf_rows/cols/hscale/vscale/border, reset_xy_jitter
     lib = load_oracle()
     assert lib.qo_arena_bytes(C.byref(q)) > 0
     assert q.max_episode_length == 1000 and q.resampling_steps == 300 and q.push_interval == 400

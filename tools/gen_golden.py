@@ -367,10 +367,10 @@ def gen_mocap():
                         frames=frames.numpy(), frame_duration=np.array(js["FrameDuration"]))
 
 
-if __name__ == "__main__":
+def _main():
     os.makedirs(GOLD, exist_ok=True)
     ref_lr, RefCfg, RefAlgoCfg = import_reference()
-    which = sys.argv[1:] or ["env", "gae", "learner", "mocap"]
+    which = sys.argv[1:] or ["env", "gae", "learner", "mocap", "heights"]
     if "env" in which:
         gen_env(ref_lr, RefCfg)
     if "gae" in which:
@@ -379,5 +379,32 @@ if __name__ == "__main__":
         gen_learner(RefCfg, RefAlgoCfg)
     if "mocap" in which:
         gen_mocap()
+    if "heights" in which:
+        gen_heights(ref_lr, RefCfg)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+def gen_heights(ref_lr, RefCfg):
+    """The reference's _get_heights (legged_robot.py:1190-1228) on a synthetic rough height field."""
+    rng = np.random.default_rng(21)
+    n, rows, cols = 64, 200, 180
+    hs = (rng.integers(-40, 40, (rows, cols))).astype(np.int16)
+    cfg = RefCfg(); cfg.env.num_envs = n; cfg.terrain.mesh_type = "trimesh"; cfg.terrain.border_size = 3.0
+    env = object.__new__(ref_lr.LeggedRobot)
+    env.cfg = cfg; env.device = "cpu"; env.num_envs = n
+    env.terrain = types.SimpleNamespace(cfg=cfg.terrain)
+    env.height_samples = torch.tensor(hs)
+    env.height_points = env._init_height_points()
+    root = np.zeros((n, 13), np.float32)
+    root[:, 0] = rng.uniform(0.5, rows * 0.1 - 6.5, n); root[:, 1] = rng.uniform(0.5, cols * 0.1 - 6.5, n); root[:, 2] = 0.3
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); root[:, 3:7] = q
+    env.root_states = torch.tensor(root); env.base_quat = env.root_states[:, 3:7]
+    heights = env._get_heights()
+    np.savez_compressed(os.path.join(GOLD, "heights.npz"), height_samples=hs, root_states=root, heights=heights.numpy(),
+                        border=np.array(3.0), hscale=np.array(0.1), vscale=np.array(0.005))
+    print("  heights golden:", heights.shape, float(heights.min()), float(heights.max()))
+
+
+if __name__ == "__main__":
+    _main()
