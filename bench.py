@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU (weak scaling)")
     ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator + mocap reset (synthetic clips unless QA_MOCAP_DIR)")
+    ap.add_argument("--terrain", default="plane", choices=["plane", "trimesh"],
+                    help="plane = BASELINE configs 1-2 (flat terrain); trimesh = the reference's 10x40 tile course as a height field")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch the rollout eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
@@ -62,7 +64,7 @@ def main():
 
     cfg = Go2LocomotionCfg()
     cfg.env.num_envs = args.num_envs
-    cfg.terrain.mesh_type = "plane"
+    cfg.terrain.mesh_type = args.terrain
     cfg.env.mocap_state_init = bool(args.amp)
     cfg.seed = 1 + 7919 * rank                       # disjoint Philox streams per rank
     tcfg = Go2LocomotionCfgAlgo()
@@ -125,7 +127,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("go2_locomotion BBC + AMP (synthetic mocap clips), " if args.amp else
                                     "go2_locomotion BBC, discriminator off, default-pose reset, ") +
-                                   f"{args.num_envs} envs/GPU, plane terrain, 24 steps/iter, 5 epochs x 4 minibatches",
+                                   f"{args.num_envs} envs/GPU, {'plane' if args.terrain == 'plane' else 'height-field (trimesh course)'} terrain, 24 steps/iter, 5 epochs x 4 minibatches",
                        "num_envs_per_gpu": args.num_envs, "steps_per_iter": T, "parallelism": f"dp{world}"},
             "wallclock_1k_iters_s": dt / args.steps * 1000.0,
             "rollout_env_steps_per_s": args.num_envs * T * world / (sum(coll) / len(coll)),
@@ -157,7 +159,7 @@ def cpu_baseline(num_envs, budget_s):
         o.step(act); n += 1
     dt = time.perf_counter() - t0
     return {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fused env steps of {num_envs} envs (rollout physics+obs/reward only, no learner), OpenMP over envs, {dt:.1f} s"}
+            "sample": f"{n} fused env steps of {num_envs} envs on plane terrain (rollout physics+obs/reward only, no learner), OpenMP over envs, {dt:.1f} s"}
 
 
 if __name__ == "__main__":

@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _make(n, amp):
+def _make(n, amp, mesh="plane"):
     from quadrupedal_agility_amd.legged_gym.envs import task_registry
     from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
     from quadrupedal_agility_amd.legged_gym.utils import get_args
-    cfg = Go2LocomotionCfg(); cfg.env.num_envs = n; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = amp; cfg.seed = 1
+    cfg = Go2LocomotionCfg(); cfg.env.num_envs = n; cfg.terrain.mesh_type = mesh; cfg.env.mocap_state_init = amp; cfg.seed = 1
     t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = amp; t.runner.num_preload_transitions = 5000; t.algorithm.disc_replay_buffer_size = 50000
     args = get_args(["--device", "gpu"])
     env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
@@ -76,3 +76,31 @@ def test_short_training_run_on_gpu(tmp_path, amp):
     ck = torch.load(path, weights_only=False)
     assert type(ck["disc_normalizer"]).__name__ == "Normalizer"
     runner.load(path)
+
+
+def test_trimesh_course_env_and_training(tmp_path):
+    """the reference's default terrain (go2_locomotion_config.py:62-64: trimesh + measure_heights) as a height field"""
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    np.random.seed(0); torch.manual_seed(0)
+    env, args, tcfg = _make(512, False, mesh="trimesh")
+    assert env.sim.cfg.terrain_type == 1 and env.height_samples.shape == (1600, 1600)
+    assert torch.equal(env.sim.t["HEIGHT_SAMPLES"], env.height_samples)
+    env.reset()
+    for _ in range(60):
+        env.step(torch.zeros(512, 12, device="cuda"))
+    # the kernel's scan sample is point 94 of the reference's 17 x 11 scan (legged_robot.py:1209-1228), evaluated before resets
+    fresh = env.episode_length_buf > 0
+    full = env._get_heights()
+    assert torch.equal(env.sim.t["SCAN_HEIGHT"][fresh], full[fresh, 94])
+    assert (full[:, 94] != 0).float().mean() > 0.5
+    alive = env.episode_length_buf > 40
+    assert alive.float().mean() > 0.8
+    clearance = env.root_states[alive, 2] - env.sim.t["SCAN_HEIGHT"][alive]
+    assert clearance.min() > 0.15 and clearance.max() < 0.5
+    fz = env.contact_forces[alive][:, :, 2].sum(1)
+    m = (15.019 + env.mass_params_tensor[alive, 0]) * 9.81
+    assert (torch.abs(fz - m) < 0.25 * m).float().mean() > 0.9          # slopes up to 0.4: normal force ~ weight
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=str(tmp_path))
+    runner.learn(2, init_at_random_ep_len=True)
+    assert all(torch.isfinite(v).all() for v in runner.alg.actor_critic.state_dict().values())
+    assert runner._graph is not None and not runner._graph_failed
