@@ -136,7 +136,7 @@ def get_args(argv=None):
     p.add_argument("--rl_device", type=str, default=None)
     p.add_argument("--num_threads", type=int, default=0)
     p.add_argument("--physics_engine", default="qa")
-    p.add_argument("--terrain", type=str, default=None, help="override terrain.mesh_type (this build implements 'plane')")
+    p.add_argument("--terrain", type=str, default=None, help="override terrain.mesh_type: plane | heightfield | trimesh")
     p.add_argument("--no_amp", action="store_true", help="disable the discriminator (BASELINE config 2)")
     p.add_argument("--no_mocap_init", action="store_true", help="reset from the default pose instead of mocap frames")
     p.add_argument("--log_root", type=str, default="default")
