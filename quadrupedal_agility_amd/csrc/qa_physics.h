@@ -263,9 +263,8 @@ QA_DEV void contact_rows(Row *rows, V3 p, int depth, float gap, const V3 *o, con
 // rarely-active rows live in per-lane LDS slots: slot k of this lane is priv[k * QA_PRIV_STRIDE]
 #define QA_PRIV_STRIDE 64
 #define QA_PRIV_EXTRA 0                  // 3 rows x 20 floats: jh6 jl3 bj6 lj3 dinv bias
-#define QA_PRIV_LIMIT 60                 // 3 rows x 8 floats:  bj6 dinv (sgn/bias/on stay in registers)
-#define QA_PRIV_STEP 84                  // env-step persistents parked between substeps: act3 sp3 sd3 binert10
-#define QA_PRIV_FLOATS 104
+#define QA_PRIV_STEP 60                  // env-step persistents parked between substeps: act3 sp3 sd3 binert10
+#define QA_PRIV_FLOATS 80
 struct LRow { float *p; };               // row view in LDS
 QA_DEV float &lr(float *priv, int k) { return priv[k * QA_PRIV_STRIDE]; }
 

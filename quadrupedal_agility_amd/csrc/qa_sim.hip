@@ -202,6 +202,7 @@ struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int de
 #define S_FLAGS 256     // [0] = refill history (episode length <= 1)
 #define S_ENV 260       // floats of LDS staging per env
 #define S_ROW 676       // assembled observation row per env (+ up to 3 floats of phase padding in front)
+#define OBS_GROUP 4     // rows assembled and streamed out per pass
 
 // The 671-float observation row of env `ge` starts at a 4-byte-aligned address whose 16-byte phase is
 // head = floats until the next 16-B boundary (0..3).  The LDS copy of the row is stored with the SAME phase
@@ -223,9 +224,16 @@ __device__ __forceinline__ void store_obs_row(float *dst, const float *row, int 
 template <bool PLANE>
 __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
-    __shared__ float s_stage[ENVS_PER_BLOCK * S_ENV];
-    __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
-    __shared__ float s_rows[ENVS_PER_BLOCK * S_ROW];
+    // One LDS scratch region used by two disjoint phases (a workgroup's LDS footprint decides how many of them a CU
+    // holds -- 160 KB per CU -- and with it the throughput once there are more workgroups than CUs):
+    //   physics phase:      per-lane private slots | terrain windows (height field only)
+    //   observation phase:  per-env staging | OBS_GROUP assembled observation rows
+    constexpr int U_PHYS = QA_PRIV_FLOATS * QA_PRIV_STRIDE + (PLANE ? 0 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH);
+    constexpr int U_OBS = ENVS_PER_BLOCK * S_ENV + OBS_GROUP * S_ROW;
+    __shared__ __attribute__((aligned(16))) float s_u[U_PHYS > U_OBS ? U_PHYS : U_OBS];
+    float *s_priv = s_u, *s_patch = s_u + QA_PRIV_FLOATS * QA_PRIV_STRIDE;
+    float *s_stage = s_u, *s_rows = s_u + ENVS_PER_BLOCK * S_ENV;
+    static_assert((ENVS_PER_BLOCK * S_ENV) % 4 == 0, "row buffer must stay 16-byte aligned");
     QA_STAMP(0);
     stage_table(s_tbl);
     const qa_config &c = a.c;
@@ -299,10 +307,10 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
 
     // ---- terrain window: staged in the rows buffer, which is idle until the observation phase
-    TerrainView T = terrain_view(c, p, s_rows + le * (QA_PATCH * QA_PATCH));
+    TerrainView T = terrain_view(c, p, s_patch + le * (QA_PATCH * QA_PATCH));
     if (!PLANE) {
         patch_origin(T, st.pos.x, st.pos.y);
-        stage_patch(T, s_rows + le * (QA_PATCH * QA_PATCH), leg);
+        stage_patch(T, s_patch + le * (QA_PATCH * QA_PATCH), leg);
         __syncthreads();
     }
 
@@ -471,6 +479,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
 
     QA_STAMP(6);
+    __syncthreads();          // physics scratch is dead from here on; the staging area takes its place
     // ---- terminal disc obs = previous OBS_DISC row; stage it
     float *sst = s_stage + le * S_ENV;
     for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
@@ -613,7 +622,6 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
     // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
-#define OBS_GROUP 4
     const int lane = threadIdx.x;
     for (int e0 = 0; e0 < ENVS_PER_BLOCK; e0 += OBS_GROUP) {
         float hv[OBS_GROUP][9];
@@ -625,13 +633,14 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             for (int r = 0; r < 8; ++r) hv[g][r] = hist[QA_BLOCK * r];
             hv[g][8] = (lane == 0) ? hist[512] : 0.f;
         }
+        if (e0) __syncthreads();                       // the previous group's row stores have read their LDS rows
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
             const int e = e0 + g, ge = (int)(blockIdx.x * ENVS_PER_BLOCK) + e;
             if (ge < N) {
                 const float *ss = s_stage + e * S_ENV;
                 const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
-                float *row = s_rows + e * S_ROW + ((4 - head) & 3);
+                float *row = s_rows + g * S_ROW + ((4 - head) & 3);
                 const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
                 const float pr = (lane < 57) ? clampf(ss[S_PROP + lane], -clipo, clipo) : 0.f;
                 if (!rf) {
@@ -652,16 +661,16 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
                 }
             }
         }
-    }
-    QA_STAMP(11);
-    __syncthreads();
-    QA_STAMP(12);
-    for (int e = 0; e < ENVS_PER_BLOCK; ++e) {
-        const int ge = blockIdx.x * ENVS_PER_BLOCK + e;
-        if (ge >= N) break;
-        float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
-        const int head = obs_row_head(dst);
-        store_obs_row(dst, s_rows + e * S_ROW + ((4 - head) & 3), head);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < OBS_GROUP; ++g) {
+            const int ge = blockIdx.x * ENVS_PER_BLOCK + e0 + g;
+            if (ge < N) {
+                float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
+                const int head = obs_row_head(dst);
+                store_obs_row(dst, s_rows + g * S_ROW + ((4 - head) & 3), head);
+            }
+        }
     }
     QA_STAMP(10);
 }
