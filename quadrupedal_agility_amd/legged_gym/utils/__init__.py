@@ -1,4 +1,5 @@
-from .helpers import class_to_dict, get_args, get_load_path, set_seed, update_cfg_from_args  # noqa: F401
+from .helpers import class_to_dict, export_policy_as_jit, get_args, get_load_path, set_seed, update_cfg_from_args  # noqa: F401
+from .logger import Logger  # noqa: F401
 
 
 def __getattr__(name):

@@ -58,7 +58,7 @@ def make_qa_config(cfg, seed=1, sim_dt=None, terrain=None):
     dt = cfg.control.decimation * (cfg.sim.dt if sim_dt is None else sim_dt)   # python double, legged_robot.py:1139
     c.env_spacing = float(cfg.env.env_spacing)
     c.max_episode_length = int(np.ceil(cfg.env.episode_length_s / dt))
-    c.resampling_steps = int(cfg.commands.resampling_time / dt)
+    c.resampling_steps = int(min(cfg.commands.resampling_time / dt, 2 ** 31 - 1))      # play.py sets 1e10 s = never
     c.push_interval = int(np.ceil(cfg.domain_rand.push_interval_s / dt))
     c.push_robots = int(bool(cfg.domain_rand.push_robots))
     c.max_push_vel_xy = float(cfg.domain_rand.max_push_vel_xy)

@@ -147,3 +147,47 @@ def get_args(argv=None):
     args.compute_device_id = args.sim_device_id = args.device_id
     args.use_gpu_pipeline = args.device == "gpu"
     return args
+
+
+# ------------------------------------------------------------------ deployment export
+class PolicyExporter(torch.nn.Module):
+    """The deployed policy as one scriptable module: obs (B, 671) -> actions (B, 12), the arithmetic of
+    ActorCritic.act_inference(obs, hist_encoding=True) (bbc/rsl_rl/modules/actor_critic.py:203-214): latent from the
+    history encoder over obs[:, 90:660], actor trunk on [prop | explicit | latent | command].
+
+    The reference's `export_policy_as_jit` (bbc/legged_gym/utils/helpers.py:233-242) copies `actor_critic.actor`, an
+    attribute the BBC ActorCritic does not have (it has actor_trunk/actor_head), so it cannot export this model; same
+    entry point and output file (`policy_1.pt`) here, over the modules that exist."""
+
+    def __init__(self, actor_critic):
+        super().__init__()
+        import copy
+        ac = actor_critic
+        he = ac.history_encoder
+        self.frame = copy.deepcopy(he.encoder)                       # Linear(57, 30) + act
+        self.convs = copy.deepcopy(he.conv_layers)                   # Conv1d stack + act + Flatten, channels-first
+        self.out = copy.deepcopy(he.linear_output)
+        self.trunk = copy.deepcopy(ac.actor_trunk)
+        self.head = copy.deepcopy(ac.actor_head)
+        self.num_prop, self.num_explicit, self.num_latent = int(ac.num_prop), int(ac.num_explicit), int(ac.num_latent)
+        self.num_hist = int(ac.num_hist)
+
+    def forward(self, obs: torch.Tensor) -> torch.Tensor:
+        a = self.num_prop
+        b = a + self.num_explicit
+        c = b + self.num_latent
+        d = c + self.num_hist * self.num_prop
+        hist = obs[:, c:d].reshape(-1, self.num_prop)
+        x = self.frame(hist).reshape(obs.shape[0], self.num_hist, -1).permute(0, 2, 1)       # (B, C, T)
+        latent = self.out(self.convs(x))
+        x = torch.cat([obs[:, :a], obs[:, a:b], latent, obs[:, d:]], dim=-1)
+        return self.head(self.trunk(x))
+
+
+def export_policy_as_jit(actor_critic, path):
+    os.makedirs(path, exist_ok=True)
+    path = os.path.join(path, "policy_1.pt")
+    model = PolicyExporter(actor_critic).to("cpu").eval()
+    scripted = torch.jit.script(model)
+    scripted.save(path)
+    return path

@@ -32,6 +32,8 @@ class TaskRegistry:
         if env_cfg is None:
             env_cfg, _ = self.get_cfgs(name)
         env_cfg, _ = update_cfg_from_args(env_cfg, None, args)
+        if not hasattr(env_cfg, "seed"):            # a hand-built config: take the task's training seed, as get_cfgs does
+            env_cfg.seed = self.train_cfgs[name].seed
         set_seed(env_cfg.seed)
         sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
         env = task_class(cfg=env_cfg, sim_params=sim_params, physics_engine=args.physics_engine, sim_device=args.sim_device,
