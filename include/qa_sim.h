@@ -227,6 +227,24 @@ int qa_gae(const float *rewards, const float *values, const uint8_t *dones, cons
            float *returns, float *advantages, int32_t T, int32_t N, float gamma, float lam,
            int32_t normalize, void *scratch, void *stream);
 
+/* ---- learner kernels ------------------------------------------------------------------------
+ * Fused PPO minibatch objective and its gradient (SSInfoGAIL.update_actor_critic,
+ * bbc/rsl_rl/algorithms/gail.py:333-345, 363-403; Normal log_prob/entropy as torch.distributions):
+ *   logp   = sum_j -(a-mu)^2/(2 std^2) - log std - log sqrt(2 pi)          entropy = sum_j 1/2 + log sqrt(2 pi) + log std
+ *   ratio  = exp(logp - old_logp);   surrogate = mean max(-A ratio, -A clamp(ratio, 1-clip, 1+clip))
+ *   value  = mean max((v-R)^2, (tv + clamp(v-tv, -clip, clip) - R)^2)       (clipped_value != 0; else mean (R-v)^2)
+ *   bound  = mean sum_j clamp(mu+1, max=0)^2 + clamp(mu-1, min=0)^2
+ *   kl     = mean sum_j log(std/old_sigma + 1e-5) + (old_sigma^2 + (old_mu-mu)^2)/(2 std^2) - 1/2   (no gradient)
+ *   loss   = c_surr surrogate + c_value value + c_bound bound - c_entropy entropy
+ * Inputs (device, fp32): mu, actions, old_mu, old_sigma (B,12) row-major and 16-byte aligned; std (12);
+ * value, old_logp, advantages, returns, target_values (B).  Outputs: dmu (B,12) = dloss/dmu, dstd (12),
+ * dvalue (B), out[8] = {loss, surrogate, value, bound, entropy, kl, 0, 0}.  `scratch` >= 256 bytes. */
+int qa_ppo_loss(const float *mu, const float *std, const float *value, const float *actions, const float *old_logp,
+                const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
+                const float *target_values, int64_t B, int32_t num_actions, float clip, float c_surr, float c_value,
+                float c_bound, float c_entropy, int32_t clipped_value, float *dmu, float *dstd, float *dvalue, float *out,
+                void *scratch, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

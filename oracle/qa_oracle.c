@@ -1008,6 +1008,57 @@ int qo_gae(const float *rewards, const float *values, const uint8_t *dones, cons
     return QA_OK;
 }
 
+/* PPO minibatch objective + gradient (gail.py:333-345, 363-403; torch.distributions.Normal log_prob / entropy;
+ * torch.max / clamp sub-gradients: ties split evenly, clamp passes the gradient on the closed interval).
+ * Double arithmetic; same signature as qa_ppo_loss, host pointers. */
+int qo_ppo_loss(const float *mu, const float *std, const float *value, const float *actions, const float *old_logp,
+                const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
+                const float *target_values, int64_t B, int32_t D, float clip_f, float c_surr, float c_value,
+                float c_bound, float c_entropy, int32_t clipped_value, float *dmu, float *dstd, float *dvalue, float *out,
+                void *scratch, void *stream) {
+    (void)scratch; (void)stream;
+    if (!mu || !std || !value || !actions || !old_logp || !old_mu || !old_sigma || !advantages || !returns || !target_values ||
+        !dmu || !dstd || !dvalue || !out || B <= 0 || D != 12) return QA_E_ARG;
+    const double HALF_LOG_2PI = 0.91893853320467274178, clip = clip_f, invB = 1.0 / (double)B;
+    double sums[5] = {0, 0, 0, 0, 0}, gs[12] = {0};
+    for (int64_t i = 0; i < B; ++i) {
+        double logp = 0, ent = 0, kl = 0, bl = 0, dl_dmu[12], dl_dsd[12], dbl[12];
+        for (int j = 0; j < 12; ++j) {
+            double s = std[j], m = mu[i * 12 + j], d = (double)actions[i * 12 + j] - m, os = old_sigma[i * 12 + j], dm = (double)old_mu[i * 12 + j] - m;
+            logp += -(d * d) / (2 * s * s) - log(s) - HALF_LOG_2PI;
+            ent += 0.5 + HALF_LOG_2PI + log(s);
+            kl += log(s / os + 1.0e-5) + (os * os + dm * dm) / (2 * s * s) - 0.5;
+            dl_dmu[j] = d / (s * s); dl_dsd[j] = d * d / (s * s * s) - 1.0 / s;
+            double lo = m + 1.0 < 0 ? m + 1.0 : 0.0, hi = m - 1.0 > 0 ? m - 1.0 : 0.0;
+            bl += lo * lo + hi * hi; dbl[j] = 2 * lo + 2 * hi;
+        }
+        double A = advantages[i], ratio = exp(logp - (double)old_logp[i]);
+        double rc = ratio < 1 - clip ? 1 - clip : (ratio > 1 + clip ? 1 + clip : ratio);
+        double s1 = -A * ratio, s2 = -A * rc, pass = (ratio >= 1 - clip && ratio <= 1 + clip) ? 1.0 : 0.0;
+        double surr = s1 > s2 ? s1 : s2;
+        double dsr = s1 > s2 ? -A : (s1 == s2 ? 0.5 * (-A) + 0.5 * (-A) * pass : (-A) * pass);
+        double dsl = dsr * ratio;
+        double v = value[i], R = returns[i], tv = target_values[i], vl, dvl;
+        if (clipped_value) {
+            double dv = v - tv, dvc = dv < -clip ? -clip : (dv > clip ? clip : dv), vc = tv + dvc, pv = (dv >= -clip && dv <= clip) ? 1.0 : 0.0;
+            double l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            vl = l1 > l2 ? l1 : l2;
+            dvl = l1 > l2 ? 2 * (v - R) : (l1 == l2 ? (v - R) + (vc - R) * pv : 2 * (vc - R) * pv);
+        } else { vl = (R - v) * (R - v); dvl = 2 * (v - R); }
+        for (int j = 0; j < 12; ++j) {
+            dmu[i * 12 + j] = (float)(invB * (c_surr * dsl * dl_dmu[j] + c_bound * dbl[j]));
+            gs[j] += c_surr * dsl * dl_dsd[j] - (double)c_entropy / (double)std[j];
+        }
+        dvalue[i] = (float)(invB * c_value * dvl);
+        sums[0] += surr; sums[1] += vl; sums[2] += bl; sums[3] += ent; sums[4] += kl;
+    }
+    for (int k = 0; k < 5; ++k) out[1 + k] = (float)(sums[k] * invB);
+    out[0] = (float)((c_surr * sums[0] + c_value * sums[1] + c_bound * sums[2] - c_entropy * sums[3]) * invB);
+    out[6] = 0; out[7] = 0;
+    for (int j = 0; j < 12; ++j) dstd[j] = (float)(gs[j] * invB);
+    return QA_OK;
+}
+
 /* ---- debug entry points used only by the physics known-answer tests ---- */
 /* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
 int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {

@@ -96,7 +96,8 @@ struct qa_sim {
 
 struct MocapIdx { int32_t first[QA_NUM_GAITS + 1]; };
 
-static thread_local char g_err[512] = "";
+thread_local char qa_err_buf[512] = "";      // shared with qa_learner.hip
+#define g_err qa_err_buf
 static int fail_hip(hipError_t e, const char *what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return QA_E_DEVICE;

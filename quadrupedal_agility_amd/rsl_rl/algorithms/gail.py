@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
+from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ppo_loss
 from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
 
 
@@ -82,6 +83,7 @@ class SSInfoGAIL:
         self.info_max_coef_on, self.info_max_coef = 0, info_max_coef
         self.learning_steps, self.begin_rim = 0, begin_rim
         self.grad_sync = None          # callable(list_of_params, extra_scalars) -> None, installed for world_size > 1
+        self.use_fused_loss = True     # GPU: PPO objective + gradient as one HIP kernel (qa_ppo_loss); False = eager PyTorch ops
         self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
@@ -228,10 +230,19 @@ class SSInfoGAIL:
     def update_actor_critic(self, sample):
         (obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _masks) = sample
         ac = self.actor_critic
-        ac.update_distribution(obs.detach(), False)      # the reference calls act() here and discards the sample (gail.py:333)
-        logp = ac.get_actions_log_prob(actions)
-        value = ac.evaluate(critic_obs.detach())
-        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+        fused = self._on_gpu and self.use_fused_loss
+        if fused:
+            # mean / value only; log-prob, entropy, KL, the four loss terms and their gradient are ONE kernel (fused.py)
+            mu = ac._actor_mean(obs.detach(), False)
+            value = ac.evaluate(critic_obs.detach())
+            ppo, stats = ppo_loss(mu, ac.std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
+                                  clip=self.clip_param, c_surr=self.surrogate_loss_coef, c_value=self.value_loss_coef,
+                                  c_bound=self.bounds_loss_coef, c_entropy=self.entropy_coef, clipped_value=self.use_clipped_value_loss)
+        else:
+            ac.update_distribution(obs.detach(), False)      # the reference calls act() here and discards the sample (gail.py:333)
+            logp = ac.get_actions_log_prob(actions)
+            value = ac.evaluate(critic_obs.detach())
+            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
 
         a = self.num_prop; b = a + self.num_explicit; c = b + self.num_latent; d = c + self.num_hist * self.num_prop
         obs_prop, obs_explicit, obs_latent, obs_hist = obs[:, :a], obs[:, a:b], obs[:, b:c], obs[:, c:d]
@@ -253,31 +264,39 @@ class SSInfoGAIL:
 
         if self.desired_kl is not None and self.schedule == "adaptive":
             with torch.no_grad():
-                kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) +
-                               (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
-                kl_mean = kl.mean()
+                if fused:
+                    kl_mean = stats[5]
+                else:
+                    kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) +
+                                   (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
+                    kl_mean = kl.mean()
                 if self.grad_sync is not None:
                     kl_mean = self.grad_sync.mean_scalar(kl_mean)
                 self._apply_kl_schedule(kl_mean)
 
-        adv = torch.squeeze(advantages)
-        ratio = torch.exp(logp - torch.squeeze(old_logp))
-        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-        if self.use_clipped_value_loss:
-            v_clip = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
-            value_loss = torch.max((value - returns).pow(2), (v_clip - returns).pow(2)).mean()
+        if fused:
+            surrogate_loss, value_loss, b_mean, ent_mean = stats[1], stats[2], stats[3], stats[4]
+            loss = ppo + priv_reg_coef * priv_reg_loss
         else:
-            value_loss = (returns - value).pow(2).mean()
-        b_loss = (torch.clamp(mu + 1.0, max=0.0) ** 2 + torch.clamp(mu - 1.0, min=0.0) ** 2).sum(dim=-1)
-        loss = (self.surrogate_loss_coef * surrogate_loss + self.value_loss_coef * value_loss +
-                self.bounds_loss_coef * b_loss.mean() - self.entropy_coef * entropy.mean() + priv_reg_coef * priv_reg_loss)
+            adv = torch.squeeze(advantages)
+            ratio = torch.exp(logp - torch.squeeze(old_logp))
+            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+            if self.use_clipped_value_loss:
+                v_clip = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value - returns).pow(2), (v_clip - returns).pow(2)).mean()
+            else:
+                value_loss = (returns - value).pow(2).mean()
+            b_loss = (torch.clamp(mu + 1.0, max=0.0) ** 2 + torch.clamp(mu - 1.0, min=0.0) ** 2).sum(dim=-1)
+            b_mean, ent_mean = b_loss.mean(), entropy.mean()
+            loss = (self.surrogate_loss_coef * surrogate_loss + self.value_loss_coef * value_loss +
+                    self.bounds_loss_coef * b_mean - self.entropy_coef * ent_mean + priv_reg_coef * priv_reg_loss)
         self.optim_ac.zero_grad()
         loss.backward()
         params = list(ac.parameters())
         self._sync_grads(params)
         nn.utils.clip_grad_norm_(params, self.max_grad_norm)
         self.optim_ac.step()
-        return (surrogate_loss.detach(), value_loss.detach(), b_loss.mean().detach(), entropy.mean().detach(),
+        return (surrogate_loss.detach(), value_loss.detach(), b_mean.detach(), ent_mean.detach(),
                 priv_reg_loss.detach(), estimator_loss.detach())
 
     def _apply_kl_schedule(self, kl_mean):

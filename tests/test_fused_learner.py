@@ -1,0 +1,123 @@
+"""Fused PPO objective (qa_ppo_loss): the C restatement against the eager PyTorch expression (CPU), the HIP kernel
+against both (GPU), and the update step with the kernel against the update step without it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ppo_loss_reference
+from tests.oracle_lib import load_oracle
+
+KW = dict(clip=0.2, c_surr=2.0, c_value=5.0, c_bound=0.3, c_entropy=0.01)
+
+
+def batch(B, seed, spread=1.0, dev="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    old_mu = r(B, 12) * 0.8
+    old_sigma = (0.3 + torch.rand(B, 12, generator=g)) * torch.ones(B, 12)
+    actions = old_mu + old_sigma * r(B, 12)
+    mu = old_mu + 0.15 * spread * r(B, 12)
+    mu[::7] *= 3.0                                   # some means beyond +-1: the bound loss is live
+    std = 0.4 + torch.rand(12, generator=g)
+    old_logp = (-(actions - old_mu) ** 2 / (2 * old_sigma ** 2) - old_sigma.log() - 0.9189385332).sum(-1, keepdim=True)
+    target_values = r(B, 1)
+    value = target_values + 0.3 * spread * r(B, 1)     # both inside and outside the +-0.2 clip
+    returns = target_values + 0.5 * r(B, 1)
+    adv = r(B, 1)
+    adv[::11] = 0.0
+    t = dict(mu=mu, std=std, value=value, actions=actions, old_logp=old_logp, old_mu=old_mu, old_sigma=old_sigma,
+             advantages=adv, returns=returns, target_values=target_values)
+    return {k: v.to(dev) for k, v in t.items()}
+
+
+def reference(t, clipped=True):
+    mu = t["mu"].clone().requires_grad_(True); std = t["std"].clone().requires_grad_(True); value = t["value"].clone().requires_grad_(True)
+    loss, stats = ppo_loss_reference(mu, std, value, t["actions"], t["old_logp"], t["old_mu"], t["old_sigma"], t["advantages"],
+                                     t["returns"], t["target_values"], clipped_value=clipped, **KW)
+    loss.backward()
+    return stats, mu.grad, std.grad, value.grad
+
+
+def oracle(t, clipped=True):
+    lib = load_oracle()
+    lib.qo_ppo_loss.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 6
+    a = {k: np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32) for k, v in t.items()}
+    B = a["mu"].shape[0]
+    dmu = np.zeros((B, 12), np.float32); dstd = np.zeros(12, np.float32); dval = np.zeros(B, np.float32); out = np.zeros(8, np.float32)
+    p = lambda x: x.ctypes.data
+    rc = lib.qo_ppo_loss(p(a["mu"]), p(a["std"]), p(a["value"]), p(a["actions"]), p(a["old_logp"]), p(a["old_mu"]), p(a["old_sigma"]),
+                         p(a["advantages"]), p(a["returns"]), p(a["target_values"]), B, 12, KW["clip"], KW["c_surr"], KW["c_value"],
+                         KW["c_bound"], KW["c_entropy"], int(clipped), p(dmu), p(dstd), p(dval), p(out), None, None)
+    assert rc == 0
+    return out, dmu, dstd, dval
+
+
+@pytest.mark.parametrize("B,clipped", [(1, True), (37, True), (4096, True), (4096, False)])
+def test_oracle_matches_eager_pytorch(B, clipped):
+    t = batch(B, seed=B)
+    stats, gmu, gstd, gval = reference(t, clipped)
+    out, dmu, dstd, dval = oracle(t, clipped)
+    assert np.allclose(out[:6], stats.numpy(), rtol=2e-5, atol=2e-6)
+    assert np.allclose(dmu, gmu.numpy(), rtol=2e-4, atol=1e-7 + 2e-6 / B)
+    assert np.allclose(dstd, gstd.numpy(), rtol=2e-4, atol=2e-6)
+    assert np.allclose(dval, gval.numpy().ravel(), rtol=2e-5, atol=1e-9)
+
+
+def test_oracle_rejects_bad_arguments():
+    lib = load_oracle()
+    lib.qo_ppo_loss.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 6
+    assert lib.qo_ppo_loss(*([None] * 10), 4, 12, 0.2, 1, 1, 1, 1, 1, *([None] * 6)) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,clipped", [(1, True), (37, True), (24576, True), (24576, False), (100001, True)])
+def test_hip_kernel_matches_oracle_and_pytorch(B, clipped):
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ppo_loss
+    t = batch(B, seed=B + 1)
+    g = {k: v.cuda() for k, v in t.items()}
+    mu = g["mu"].clone().requires_grad_(True); std = g["std"].clone().requires_grad_(True); value = g["value"].clone().requires_grad_(True)
+    loss, stats = ppo_loss(mu, std, value, g["actions"], g["old_logp"], g["old_mu"], g["old_sigma"], g["advantages"], g["returns"],
+                           g["target_values"], clipped_value=clipped, **KW)
+    (3.0 * loss).backward()                                     # upstream gradient is applied
+    out, dmu, dstd, dval = oracle(t, clipped)
+    assert np.allclose(stats.cpu().numpy()[:6], out[:6], rtol=2e-5, atol=2e-6)
+    assert float(loss.detach()) == pytest.approx(float(out[0]), rel=2e-5, abs=2e-6)
+    # a sample whose ratio sits within fp32 rounding of 1 +- clip may take the other branch of the max (its gradient is
+    # then 0 instead of -A ratio, or vice versa): count such rows, do not hide them
+    bad = ~np.isclose(mu.grad.cpu().numpy(), 3.0 * dmu, rtol=3e-4, atol=1e-7 + 6e-6 / B)
+    flipped = np.unique(np.nonzero(bad)[0])
+    assert len(flipped) <= B // 30000, flipped
+    if len(flipped):
+        a = {k: v.double() for k, v in t.items()}
+        logp = (-(a["actions"] - a["mu"]) ** 2 / (2 * a["std"] ** 2) - a["std"].log() - 0.9189385332046727).sum(-1)
+        ratio = torch.exp(logp - a["old_logp"][:, 0])[flipped]
+        assert (torch.minimum((ratio - 0.8).abs(), (ratio - 1.2).abs()) < 5e-6).all()
+    assert np.allclose(std.grad.cpu().numpy(), 3.0 * dstd, rtol=3e-4, atol=6e-6 + 3.0 * len(flipped) / B)
+    assert np.allclose(value.grad.cpu().numpy().ravel(), 3.0 * dval, rtol=2e-5, atol=1e-9)
+    rs, gmu, gstd, gval = reference(g, clipped)                 # eager PyTorch on the GPU
+    assert np.allclose(stats.cpu().numpy()[:6], rs.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    bad = ~np.isclose(mu.grad.cpu().numpy(), 3.0 * gmu.cpu().numpy(), rtol=3e-4, atol=1e-7 + 6e-6 / B)
+    assert len(np.unique(np.nonzero(bad)[0])) <= B // 30000
+
+
+@pytest.mark.gpu
+def test_update_step_with_and_without_the_fused_kernel(tmp_path):
+    """same seed, same rollout: one PPO update through qa_ppo_loss and one through eager ops end in the same weights"""
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        env, args, tcfg = _make(256, False)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+        runner.alg.use_fused_loss = fused
+        runner.learn(1, init_at_random_ep_len=True)
+        res.append({k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()})
+        lr = float(runner.alg.lr_ac)
+        res.append(lr)
+    (wa, lra, wb, lrb) = res
+    assert lra == lrb
+    for k in wa:
+        assert torch.allclose(wa[k], wb[k], atol=2e-4, rtol=1e-3), k
