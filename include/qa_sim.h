@@ -238,12 +238,23 @@ int qa_gae(const float *rewards, const float *values, const uint8_t *dones, cons
  *   loss   = c_surr surrogate + c_value value + c_bound bound - c_entropy entropy
  * Inputs (device, fp32): mu, actions, old_mu, old_sigma (B,12) row-major and 16-byte aligned; std (12);
  * value, old_logp, advantages, returns, target_values (B).  Outputs: dmu (B,12) = dloss/dmu, dstd (12),
- * dvalue (B), out[8] = {loss, surrogate, value, bound, entropy, kl, 0, 0}.  `scratch` >= 256 bytes. */
+ * dvalue (B), out[8] = {loss, surrogate, value, bound, entropy, kl, 0, 0}.  `scratch`: device memory of at least
+ * qa_ppo_loss_scratch_bytes(B) bytes (per-wavefront partial sums; reduced in a fixed order, no atomics). */
+int64_t qa_ppo_loss_scratch_bytes(int64_t B);
 int qa_ppo_loss(const float *mu, const float *std, const float *value, const float *actions, const float *old_logp,
                 const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
                 const float *target_values, int64_t B, int32_t num_actions, float clip, float c_surr, float c_value,
                 float c_bound, float c_entropy, int32_t clipped_value, float *dmu, float *dstd, float *dvalue, float *out,
-                void *scratch, void *stream);
+                void *scratch, int64_t scratch_bytes, void *stream);
+
+/* ELU backward fused with the bias-gradient column sum: the part of the backward of a Linear+ELU layer
+ * (the `_mlp` blocks of bbc/rsl_rl/modules/actor_critic.py:92-139, estimator.py:12-33) that is not a GEMM:
+ *   grad_in[r][c] = grad_out[r][c] * (out[r][c] > 0 ? 1 : out[r][c] + alpha),   grad_bias[c] = sum_r grad_in[r][c]
+ * `out` is the layer's ELU OUTPUT (rows, cols) row-major; grad_in may not alias grad_out.  `scratch` holds at least
+ * qa_elu_backward_bias_scratch_bytes(rows, cols) bytes. */
+int64_t qa_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols);
+int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
+                         float alpha, void *scratch, int64_t scratch_bytes, void *stream);
 
 const char *qa_last_error(void);
 int qa_abi_version(void);

@@ -1015,8 +1015,8 @@ int qo_ppo_loss(const float *mu, const float *std, const float *value, const flo
                 const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
                 const float *target_values, int64_t B, int32_t D, float clip_f, float c_surr, float c_value,
                 float c_bound, float c_entropy, int32_t clipped_value, float *dmu, float *dstd, float *dvalue, float *out,
-                void *scratch, void *stream) {
-    (void)scratch; (void)stream;
+                void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
     if (!mu || !std || !value || !actions || !old_logp || !old_mu || !old_sigma || !advantages || !returns || !target_values ||
         !dmu || !dstd || !dvalue || !out || B <= 0 || D != 12) return QA_E_ARG;
     const double HALF_LOG_2PI = 0.91893853320467274178, clip = clip_f, invB = 1.0 / (double)B;
@@ -1056,6 +1056,25 @@ int qo_ppo_loss(const float *mu, const float *std, const float *value, const flo
     out[0] = (float)((c_surr * sums[0] + c_value * sums[1] + c_bound * sums[2] - c_entropy * sums[3]) * invB);
     out[6] = 0; out[7] = 0;
     for (int j = 0; j < 12; ++j) dstd[j] = (float)(gs[j] * invB);
+    return QA_OK;
+}
+
+int64_t qo_ppo_loss_scratch_bytes(int64_t B) { return B <= 0 ? -1 : 0; }
+
+/* torch's elu_backward with is_result=True (alpha e^x = y + alpha for y <= 0) + the column sum of the bias gradient */
+int64_t qo_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols) { return (rows <= 0 || cols <= 0) ? -1 : 0; }
+int qo_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
+                         float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!grad_out || !out || !grad_in || !grad_bias || rows <= 0 || cols <= 0) return QA_E_ARG;
+    for (int c = 0; c < cols; ++c) {
+        double acc = 0;
+        for (int64_t r = 0; r < rows; ++r) {
+            float y = out[r * cols + c], g = grad_out[r * cols + c] * (y > 0.0f ? 1.0f : y + alpha);
+            grad_in[r * cols + c] = g; acc += g;
+        }
+        grad_bias[c] = (float)acc;
+    }
     return QA_OK;
 }
 

@@ -18,14 +18,14 @@
 
 namespace {
 
-constexpr int PPO_BLOCK = 256;
+constexpr int PPO_BLOCK = 64;            // one wavefront per workgroup: its 17 partial sums go to scratch without atomics
 constexpr int PPO_D = 12;           // actions per sample (num_actions of the Go2 task)
 constexpr int PPO_SUMS = 5 + PPO_D; // surrogate, value, bound, entropy, kl, dstd[12]
 
 struct PpoArgs {
     const float *mu, *std, *value, *actions, *old_logp, *old_mu, *old_sigma, *adv, *returns, *target_values;
     float *dmu, *dvalue;
-    double *sums;
+    float *partial;          // (gridDim.x, PPO_SUMS)
     int64_t B;
     float clip, c_surr, c_value, c_bound, c_entropy;
     int clipped_value;
@@ -114,19 +114,105 @@ __global__ void __launch_bounds__(PPO_BLOCK) qa_ppo_loss_kernel(PpoArgs a) {
 #pragma unroll
     for (int k = 0; k < PPO_SUMS; ++k) {
         float s = wave_sum(part[k]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&a.sums[k], (double)s);
+        if (threadIdx.x == k) a.partial[(int64_t)blockIdx.x * PPO_SUMS + k] = s;      // lane k keeps sum k
     }
 }
 
-// sums -> out[8] = {loss, surrogate, value, bound, entropy, kl, 0, 0} (means) and dstd[12]
-__global__ void qa_ppo_finish_kernel(const double *sums, int64_t B, float c_surr, float c_value, float c_bound, float c_entropy,
-                                     float *out, float *dstd) {
+// per-wave partial sums -> out[8] = {loss, surrogate, value, bound, entropy, kl, 0, 0} (means) and dstd[12];
+// fixed summation order (double), so results do not depend on scheduling
+__global__ void __launch_bounds__(256) qa_ppo_finish_kernel(const float *partial, int nblocks, int64_t B, float c_surr, float c_value,
+                                                            float c_bound, float c_entropy, float *out, float *dstd) {
+    __shared__ double s_acc[256];
+    __shared__ double s_tot[PPO_SUMS];
     const int t = threadIdx.x;
+    for (int k = 0; k < PPO_SUMS; ++k) {
+        double acc = 0.0;
+        for (int b = t; b < nblocks; b += 256) acc += (double)partial[(int64_t)b * PPO_SUMS + k];
+        s_acc[t] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (t < o) s_acc[t] += s_acc[t + o]; __syncthreads(); }
+        if (t == 0) s_tot[k] = s_acc[0];
+        __syncthreads();
+    }
     const double invB = 1.0 / (double)B;
-    if (t < 5) out[1 + t] = (float)(sums[t] * invB);
-    if (t == 5) out[0] = (float)((c_surr * sums[0] + c_value * sums[1] + c_bound * sums[2] - c_entropy * sums[3]) * invB);
+    if (t < 5) out[1 + t] = (float)(s_tot[t] * invB);
+    if (t == 5) out[0] = (float)((c_surr * s_tot[0] + c_value * s_tot[1] + c_bound * s_tot[2] - c_entropy * s_tot[3]) * invB);
     if (t == 6 || t == 7) out[t] = 0.f;
-    if (t >= 8 && t < 8 + PPO_D) dstd[t - 8] = (float)(sums[5 + t - 8] * invB);
+    if (t >= 8 && t < 8 + PPO_D) dstd[t - 8] = (float)(s_tot[5 + t - 8] * invB);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ELU backward fused with the bias-gradient column sum (the backward of  y = elu(x W^T + b)  up to the two GEMMs):
+//   grad_in[r][c] = grad_out[r][c] * (out[r][c] > 0 ? 1 : out[r][c] + alpha);   grad_bias[c] = sum_r grad_in[r][c]
+// (`out` is the ELU OUTPUT: for y <= 0, d elu/dx = alpha e^x = y + alpha.)  In eager PyTorch these are two kernels that
+// each stream the (rows, cols) tensor: elu_backward, then a column reduction.
+// Block = 256 threads = CW columns x (256/CW) row lanes over a tile of ELU_ROWS rows; per-block column partials go to
+// scratch and a second, tiny kernel adds them in a fixed order.
+constexpr int ELU_ROWS = 64;
+
+template <int CW>
+__global__ void __launch_bounds__(256) qa_elu_bwd_bias_kernel(const float *__restrict__ gout, const float *__restrict__ out, float *__restrict__ gin,
+                                                              float *__restrict__ partial, int64_t rows, int cols, float alpha) {
+    constexpr int RL = 256 / CW;
+    __shared__ float s_red[256];
+    const int c0 = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int64_t r0 = (int64_t)blockIdx.x * ELU_ROWS;
+    const int64_t r1 = r0 + ELU_ROWS < rows ? r0 + ELU_ROWS : rows;
+    for (int cb = 0; cb < cols; cb += CW) {
+        const int c = cb + c0;
+        float acc = 0.f;
+        if (c < cols) {
+            int64_t r = r0 + rl;
+            for (; r + 3 * RL < r1; r += 4 * RL) {          // 4 rows in flight per lane
+                const int64_t i0 = r * cols + c, st = (int64_t)RL * cols;
+                const float y0 = out[i0], y1 = out[i0 + st], y2 = out[i0 + 2 * st], y3 = out[i0 + 3 * st];
+                const float g0 = gout[i0] * (y0 > 0.f ? 1.0f : y0 + alpha), g1 = gout[i0 + st] * (y1 > 0.f ? 1.0f : y1 + alpha);
+                const float g2 = gout[i0 + 2 * st] * (y2 > 0.f ? 1.0f : y2 + alpha), g3 = gout[i0 + 3 * st] * (y3 > 0.f ? 1.0f : y3 + alpha);
+                gin[i0] = g0; gin[i0 + st] = g1; gin[i0 + 2 * st] = g2; gin[i0 + 3 * st] = g3;
+                acc += (g0 + g1) + (g2 + g3);
+            }
+            for (; r < r1; r += RL) {
+                const int64_t i = r * cols + c;
+                const float y = out[i], g = gout[i] * (y > 0.f ? 1.0f : y + alpha);
+                gin[i] = g;
+                acc += g;
+            }
+        }
+        if (RL > 1) {
+            s_red[threadIdx.x] = acc;
+            __syncthreads();
+            if (rl == 0) {
+#pragma unroll
+                for (int k = 1; k < RL; ++k) acc += s_red[k * CW + c0];
+            }
+            __syncthreads();
+        }
+        if (rl == 0 && c < cols) partial[(int64_t)blockIdx.x * cols + c] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) qa_colsum_finish_kernel(const float *__restrict__ partial, int nblocks, int cols, float *__restrict__ gbias) {
+    // block = 32 columns x 8 lanes; lane q adds partials q, q+8, ... with 4 independent accumulators, then the 8 lanes
+    // are combined through LDS in a fixed order
+    __shared__ float s_q[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        int b = q;
+        for (; b + 24 < nblocks; b += 32) {
+            a0 += partial[(int64_t)b * cols + c]; a1 += partial[(int64_t)(b + 8) * cols + c];
+            a2 += partial[(int64_t)(b + 16) * cols + c]; a3 += partial[(int64_t)(b + 24) * cols + c];
+        }
+        for (; b < nblocks; b += 8) a0 += partial[(int64_t)b * cols + c];
+    }
+    s_q[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_q[threadIdx.x + 32 * k];
+        gbias[c] = t;
+    }
 }
 
 }  // namespace
@@ -136,26 +222,48 @@ extern thread_local char qa_err_buf[512];
 
 extern "C" {
 
+int64_t qa_ppo_loss_scratch_bytes(int64_t B) { return B <= 0 ? -1 : (int64_t)sizeof(float) * PPO_SUMS * ((B + PPO_BLOCK - 1) / PPO_BLOCK); }
+
 int qa_ppo_loss(const float *mu, const float *std, const float *value, const float *actions, const float *old_logp,
                 const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
                 const float *target_values, int64_t B, int32_t num_actions, float clip, float c_surr, float c_value,
                 float c_bound, float c_entropy, int32_t clipped_value, float *dmu, float *dstd, float *dvalue, float *out,
-                void *scratch, void *stream) {
+                void *scratch, int64_t scratch_bytes, void *stream) {
     if (!mu || !std || !value || !actions || !old_logp || !old_mu || !old_sigma || !advantages || !returns || !target_values ||
         !dmu || !dstd || !dvalue || !out || !scratch || B <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: null pointer or empty batch"); return QA_E_ARG; }
     if (num_actions != PPO_D) { snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: num_actions must be %d", PPO_D); return QA_E_ARG; }
     if ((((uintptr_t)mu | (uintptr_t)actions | (uintptr_t)old_mu | (uintptr_t)old_sigma | (uintptr_t)dmu) & 15) != 0) {
         snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: (B,12) tensors must be 16-byte aligned"); return QA_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * PPO_SUMS, st);
-    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
-    PpoArgs a{mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values, dmu, dvalue, (double *)scratch,
-              B, clip, c_surr, c_value, c_bound, c_entropy, clipped_value};
     const int blocks = (int)((B + PPO_BLOCK - 1) / PPO_BLOCK);
+    if (scratch_bytes < qa_ppo_loss_scratch_bytes(B)) { snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: scratch too small"); return QA_E_ARG; }
+    PpoArgs a{mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values, dmu, dvalue, (float *)scratch,
+              B, clip, c_surr, c_value, c_bound, c_entropy, clipped_value};
     hipLaunchKernelGGL(qa_ppo_loss_kernel, dim3(blocks), dim3(PPO_BLOCK), 0, st, a);
-    hipLaunchKernelGGL(qa_ppo_finish_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch, B, c_surr, c_value, c_bound, c_entropy, out, dstd);
-    e = hipGetLastError();
+    hipLaunchKernelGGL(qa_ppo_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)scratch, blocks, B, c_surr, c_value, c_bound, c_entropy, out, dstd);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int64_t qa_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols) {
+    return (rows <= 0 || cols <= 0) ? -1 : (int64_t)sizeof(float) * cols * ((rows + ELU_ROWS - 1) / ELU_ROWS);
+}
+
+int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
+                         float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!grad_out || !out || !grad_in || !grad_bias || !scratch || rows <= 0 || cols <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: bad argument"); return QA_E_ARG; }
+    if (scratch_bytes < qa_elu_backward_bias_scratch_bytes(rows, cols)) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: scratch too small"); return QA_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)((rows + ELU_ROWS - 1) / ELU_ROWS);
+    float *partial = (float *)scratch;
+    if (cols > 128) hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<256>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
+    else if (cols > 64) hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<128>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
+    else if (cols > 32) hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<64>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
+    else hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<32>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
+    hipLaunchKernelGGL(qa_colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float *)partial, nb, (int)cols, grad_bias);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

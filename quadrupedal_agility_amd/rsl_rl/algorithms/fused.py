@@ -9,6 +9,9 @@ import torch
 from quadrupedal_agility_amd import _capi
 
 
+ENABLED = True      # tests flip this to compare against the unfused modules
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
@@ -33,11 +36,12 @@ class _PpoLoss(torch.autograd.Function):
         dstd = torch.empty(12, dtype=torch.float32, device=mu_c.device)
         dvalue = torch.empty(B, dtype=torch.float32, device=mu_c.device)
         out = torch.empty(8, dtype=torch.float32, device=mu_c.device)
-        scratch = torch.empty(32, dtype=torch.float64, device=mu_c.device)
+        nscratch = int(lib.qa_ppo_loss_scratch_bytes(B))
+        scratch = torch.empty(nscratch, dtype=torch.uint8, device=mu_c.device)
         stream = C.c_void_p(torch.cuda.current_stream(mu_c.device).cuda_stream)
         rc = lib.qa_ppo_loss(_ptr(mu_c), _ptr(std_c), _ptr(val_c), *[_ptr(x) for x in fixed], B, 12, float(clip), float(c_surr),
                              float(c_value), float(c_bound), float(c_entropy), int(bool(clipped_value)),
-                             _ptr(dmu), _ptr(dstd), _ptr(dvalue), _ptr(out), _ptr(scratch), stream)
+                             _ptr(dmu), _ptr(dstd), _ptr(dvalue), _ptr(out), _ptr(scratch), nscratch, stream)
         if rc != 0:
             raise RuntimeError(f"qa_ppo_loss failed with code {rc}: {lib.qa_last_error().decode()}")
         ctx.save_for_backward(dmu, dstd, dvalue)
@@ -51,6 +55,60 @@ class _PpoLoss(torch.autograd.Function):
         dmu, dstd, dvalue = ctx.saved_tensors
         return (dmu * g_loss, (dstd * g_loss).view(ctx.std_shape), (dvalue * g_loss).view(ctx.value_shape),
                 None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+class _LinearElu(torch.autograd.Function):
+    """y = elu(x W^T + b).  Forward: addmm (hipBLASLt) + in-place ELU.  Backward: ONE kernel for the ELU derivative and
+    the bias gradient (qa_elu_backward_bias), then the two GEMMs.  Saves the ELU output only (elu' = y + alpha for y <= 0)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha):
+        y = torch.addmm(bias, x, weight.t())
+        torch.nn.functional.elu(y, alpha=alpha, inplace=True)
+        ctx.save_for_backward(x, weight, y)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        lib = _capi.load_library()
+        gy = _f32c(gy)
+        rows, cols = y.shape
+        g = torch.empty_like(y)
+        gb = torch.empty(cols, dtype=torch.float32, device=y.device)
+        nscratch = int(lib.qa_elu_backward_bias_scratch_bytes(rows, cols))
+        scratch = torch.empty(nscratch, dtype=torch.uint8, device=y.device)
+        stream = C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
+        rc = lib.qa_elu_backward_bias(_ptr(gy), _ptr(y), _ptr(g), _ptr(gb), rows, cols, float(ctx.alpha), _ptr(scratch), nscratch, stream)
+        if rc != 0:
+            raise RuntimeError(f"qa_elu_backward_bias failed with code {rc}: {lib.qa_last_error().decode()}")
+        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None        # operand order of F.linear's own backward: tuned GEMM picks apply
+        return gx, gw, (gb if ctx.needs_input_grad[2] else None), None
+
+
+def linear_elu(x, weight, bias, alpha=1.0):
+    return _LinearElu.apply(x, weight, bias, alpha)
+
+
+def mlp_forward(seq, x):
+    """Run an nn.Sequential of Linear / ELU modules; on ROCm tensors with gradients enabled every Linear+ELU pair goes
+    through `linear_elu`.  Anything else (CPU tensors, other activations, no_grad) takes the modules as they are."""
+    mods = list(seq)
+    if not (x.is_cuda and torch.is_grad_enabled()):
+        return seq(x)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if isinstance(m, torch.nn.Linear) and isinstance(nxt, torch.nn.ELU) and m.bias is not None and x.dim() == 2:
+            x = linear_elu(x, m.weight, m.bias, float(nxt.alpha))
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 def ppo_loss(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values, *, clip,

@@ -203,7 +203,8 @@ class SSInfoGAIL:
                 for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
                     o.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
+                with _no_gc(), torch.cuda.graph(g):
                     one_step()
                 self._disc_graph = g
             except Exception as e:      # never fatal

@@ -3,7 +3,7 @@ Parameter names `estimator.{0,2,4}` as in bbc/rsl_rl/modules/estimator.py:12-36.
 import torch
 import torch.nn as nn
 
-from .actor_critic import get_activation
+from .actor_critic import _run, get_activation
 
 
 class Estimator(nn.Module):
@@ -20,7 +20,7 @@ class Estimator(nn.Module):
         self.estimator = nn.Sequential(*layers)
 
     def forward(self, input):
-        return self.estimator(input)
+        return _run(self.estimator, input)
 
     def inference(self, input):
         with torch.no_grad():

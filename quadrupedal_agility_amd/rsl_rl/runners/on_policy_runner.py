@@ -8,6 +8,8 @@ torch.distributed initialised (one process per GPU, RCCL) every rank owns num_en
 gradient buckets / normalisation statistics are all-reduced.
 """
 import json
+import contextlib
+import gc
 import os
 import statistics
 import time
@@ -45,6 +47,21 @@ def _make_writer(log_dir):
         return SummaryWriter(log_dir=log_dir, flush_secs=10)
     except Exception:
         return _ScalarLog(log_dir)
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is capturing: a collection that happens to run inside the capture can
+    destroy old device objects (graphs, tensors with recorded events), whose destructors call HIP APIs that are illegal
+    during capture and abort the process.  (torch.cuda.graph collects once on entry; this keeps it from running again.)"""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class GradSync:
@@ -248,7 +265,7 @@ class OnPolicyRunner:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 alg.storage.step = 0
-                with torch.cuda.graph(g):
+                with _no_gc(), torch.cuda.graph(g):
                     with torch.inference_mode():
                         ep_infos = self._rollout_steps(False, logging, recorded=True)    # host side effects run now, GPU work on replay
                 self._graph, self._graph_delay, self._graph_ep_infos = g, env.delay, ep_infos

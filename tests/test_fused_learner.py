@@ -42,14 +42,14 @@ def reference(t, clipped=True):
 
 def oracle(t, clipped=True):
     lib = load_oracle()
-    lib.qo_ppo_loss.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 6
+    lib.qo_ppo_loss.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
     a = {k: np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32) for k, v in t.items()}
     B = a["mu"].shape[0]
     dmu = np.zeros((B, 12), np.float32); dstd = np.zeros(12, np.float32); dval = np.zeros(B, np.float32); out = np.zeros(8, np.float32)
     p = lambda x: x.ctypes.data
     rc = lib.qo_ppo_loss(p(a["mu"]), p(a["std"]), p(a["value"]), p(a["actions"]), p(a["old_logp"]), p(a["old_mu"]), p(a["old_sigma"]),
                          p(a["advantages"]), p(a["returns"]), p(a["target_values"]), B, 12, KW["clip"], KW["c_surr"], KW["c_value"],
-                         KW["c_bound"], KW["c_entropy"], int(clipped), p(dmu), p(dstd), p(dval), p(out), None, None)
+                         KW["c_bound"], KW["c_entropy"], int(clipped), p(dmu), p(dstd), p(dval), p(out), None, 0, None)
     assert rc == 0
     return out, dmu, dstd, dval
 
@@ -67,8 +67,8 @@ def test_oracle_matches_eager_pytorch(B, clipped):
 
 def test_oracle_rejects_bad_arguments():
     lib = load_oracle()
-    lib.qo_ppo_loss.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 6
-    assert lib.qo_ppo_loss(*([None] * 10), 4, 12, 0.2, 1, 1, 1, 1, 1, *([None] * 6)) == -1
+    lib.qo_ppo_loss.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
+    assert lib.qo_ppo_loss(*([None] * 10), 4, 12, 0.2, 1, 1, 1, 1, 1, *([None] * 5), 0, None) == -1
 
 
 @pytest.mark.gpu
@@ -121,3 +121,67 @@ def test_update_step_with_and_without_the_fused_kernel(tmp_path):
     assert lra == lrb
     for k in wa:
         assert torch.allclose(wa[k], wb[k], atol=2e-4, rtol=1e-3), k
+
+
+# ------------------------------------------------------------------ Linear+ELU backward
+def elu_case(rows, cols, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, cols, generator=g) * 1.5
+    y = torch.nn.functional.elu(x)
+    gy = torch.randn(rows, cols, generator=g)
+    return y, gy
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (33, 29), (1000, 64), (4096, 512)])
+def test_elu_backward_bias_oracle_matches_pytorch(rows, cols):
+    y, gy = elu_case(rows, cols, rows + cols)
+    lib = load_oracle()
+    lib.qo_elu_backward_bias.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+    yn, gn = y.numpy().copy(), gy.numpy().copy()
+    gin = np.zeros_like(yn); gb = np.zeros(cols, np.float32)
+    assert lib.qo_elu_backward_bias(gn.ctypes.data, yn.ctypes.data, gin.ctypes.data, gb.ctypes.data, rows, cols, 1.0, None, 0, None) == 0
+    want = torch.ops.aten.elu_backward(gy, 1.0, 1.0, 1.0, True, y)
+    assert np.array_equal(gin, want.numpy())
+    assert np.allclose(gb, want.sum(0).numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(rows))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(1, 1), (33, 29), (1000, 64), (24576, 128), (24576, 512), (5000, 700)])
+def test_elu_backward_bias_hip(rows, cols):
+    from quadrupedal_agility_amd import _capi
+    lib = _capi.load_library()
+    y, gy = elu_case(rows, cols, rows + cols)
+    yd, gd = y.cuda(), gy.cuda()
+    gin = torch.empty_like(yd); gb = torch.empty(cols, device="cuda")
+    n = int(lib.qa_elu_backward_bias_scratch_bytes(rows, cols))
+    scratch = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.qa_elu_backward_bias(P(gd), P(yd), P(gin), P(gb), rows, cols, 1.0, P(scratch), n, st) == 0
+    assert lib.qa_elu_backward_bias(P(gd), P(yd), P(gin), P(gb), rows, cols, 1.0, P(scratch), n - 1, st) == -1      # scratch too small
+    torch.cuda.synchronize()
+    want = torch.ops.aten.elu_backward(gy, 1.0, 1.0, 1.0, True, y)
+    assert torch.equal(gin.cpu(), want)                                       # elementwise part is exact
+    assert np.allclose(gb.cpu().numpy(), want.double().sum(0).numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(rows))
+    gb2 = torch.empty_like(gb)
+    assert lib.qa_elu_backward_bias(P(gd), P(yd), P(gin), P(gb2), rows, cols, 1.0, P(scratch), n, st) == 0
+    assert torch.equal(gb, gb2)                                               # fixed summation order: bit-reproducible
+
+
+@pytest.mark.gpu
+def test_fused_mlp_matches_modules():
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(torch.nn.Linear(101, 512), torch.nn.ELU(), torch.nn.Linear(512, 256), torch.nn.ELU(),
+                              torch.nn.Linear(256, 128), torch.nn.ELU(), torch.nn.Linear(128, 12)).cuda()
+    x = torch.randn(3000, 101, device="cuda", requires_grad=True)
+    w = torch.randn(3000, 12, device="cuda")
+    (fused.mlp_forward(seq, x) * w).sum().backward()
+    got = [p.grad.clone() for p in seq.parameters()] + [x.grad.clone()]
+    for p in seq.parameters():
+        p.grad = None
+    x.grad = None
+    (seq(x) * w).sum().backward()
+    want = [p.grad for p in seq.parameters()] + [x.grad]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
