@@ -105,6 +105,13 @@ static int fail_hip(hipError_t e, const char *what) {
 #define HIP_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail_hip(_e, #x); } while (0)
 
 // ------------------------------------------------------------------ shared device pieces
+// Workgroups of the env kernels are ONE wavefront (QA_BLOCK == 64), and a wavefront's LDS operations execute in issue
+// order, so lanes exchange data through LDS without s_barrier.  What is needed is (a) that the LDS queue has drained and
+// (b) that the compiler does not move LDS accesses across the point.  __syncthreads() would additionally wait for
+// vmcnt(0), i.e. drain every outstanding global load and store at each exchange -- 8 full memory drains in the
+// observation phase alone.
+static_assert(QA_BLOCK == 64, "wave_lds_sync() assumes single-wavefront workgroups");
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void stage_table(float *s_tbl) {
     constexpr int PER = (QA_TBL_FLOATS + QA_BLOCK - 1) / QA_BLOCK;
     float v[PER];
@@ -112,7 +119,7 @@ __device__ __forceinline__ void stage_table(float *s_tbl) {
     for (int r = 0; r < PER; ++r) { int i = threadIdx.x + QA_BLOCK * r; v[r] = (i < QA_TBL_FLOATS) ? c_tbl[i] : 0.f; }   // loads in flight together
 #pragma unroll
     for (int r = 0; r < PER; ++r) { int i = threadIdx.x + QA_BLOCK * r; if (i < QA_TBL_FLOATS) s_tbl[i] = v[r]; }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // legged_robot.py:532-540 + :474-530, executed redundantly by the 4 lanes of the quad
@@ -312,7 +319,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     if (!PLANE) {
         patch_origin(T, st.pos.x, st.pos.y);
         stage_patch(T, s_patch + le * (QA_PATCH * QA_PATCH), leg);
-        __syncthreads();
+        wave_lds_sync();
     }
 
     QA_STAMP(2);
@@ -480,7 +487,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
 
     QA_STAMP(6);
-    __syncthreads();          // physics scratch is dead from here on; the staging area takes its place
+    wave_lds_sync();          // physics scratch is dead from here on; the staging area takes its place
     // ---- terminal disc obs = previous OBS_DISC row; stage it
     float *sst = s_stage + le * S_ENV;
     for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
@@ -545,7 +552,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             sst[S_TAIL + 5] = eps;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     // head of the obs row: prop + explicit + latent, with noise on the 32 noisy entries
     {
         float *hd = sst + S_HEAD;
@@ -559,7 +566,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { hd[66 + 3 * leg + k] = sp[k] - 1.0f; hd[78 + 3 * leg + k] = sd[k] - 1.0f; }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (c.add_noise) {
         // draw i (0..31) -> obs index i (<29) or 58 + (i - 29); lane handles blocks 2*leg, 2*leg+1
 #pragma unroll
@@ -616,7 +623,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     QA_STAMP(9);
     // ---- wave-cooperative row writes.  The complete 671-float observation row of every env of the block is
@@ -624,17 +631,26 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
     const int lane = threadIdx.x;
-    for (int e0 = 0; e0 < ENVS_PER_BLOCK; e0 += OBS_GROUP) {
-        float hv[OBS_GROUP][9];
+    // history loads run one group ahead of the assembly (double-buffered in registers): the HBM latency of group
+    // k+1's 36 loads is hidden behind the LDS assembly and the row stores of group k
+    float hvb[2][OBS_GROUP][9];
+    auto load_hist = [&](int buf, int e0) {
 #pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {          // all history loads of the group in flight first: 8 full + 1 single-lane
+        for (int g = 0; g < OBS_GROUP; ++g) {          // 8 full wave loads + 1 single-lane load per env
             const int ge = min((int)(blockIdx.x * ENVS_PER_BLOCK) + e0 + g, N - 1);
             const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
 #pragma unroll
-            for (int r = 0; r < 8; ++r) hv[g][r] = hist[QA_BLOCK * r];
-            hv[g][8] = (lane == 0) ? hist[512] : 0.f;
+            for (int r = 0; r < 8; ++r) hvb[buf][g][r] = hist[QA_BLOCK * r];
+            hvb[buf][g][8] = (lane == 0) ? hist[512] : 0.f;
         }
-        if (e0) __syncthreads();                       // the previous group's row stores have read their LDS rows
+    };
+    load_hist(0, 0);
+#pragma unroll
+    for (int gi = 0; gi < ENVS_PER_BLOCK / OBS_GROUP; ++gi) {
+        const int e0 = gi * OBS_GROUP;
+        if (gi + 1 < ENVS_PER_BLOCK / OBS_GROUP) load_hist((gi + 1) & 1, e0 + OBS_GROUP);
+        float (&hv)[OBS_GROUP][9] = hvb[gi & 1];
+        if (e0) wave_lds_sync();                       // the previous group's row stores have read their LDS rows
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
             const int e = e0 + g, ge = (int)(blockIdx.x * ENVS_PER_BLOCK) + e;
@@ -662,7 +678,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
             const int ge = blockIdx.x * ENVS_PER_BLOCK + e0 + g;
@@ -778,7 +794,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
         T.patch = mine;
         patch_origin(T, st.pos.x, st.pos.y);
         stage_patch(T, mine, leg);
-        __syncthreads();
+        wave_lds_sync();
     }
     phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
     V3 org[4]; leg_origins(st.q, tbl, org);

@@ -16,10 +16,8 @@ for _ in range(K):
     h.step(act); torch.cuda.synchronize()
     b = buf.view(-1, 16).cpu().double()
     acc += (b[:, 1:11] - b[:, 0:10]).mean(0)
-    extra = [(b[:, 11] - b[:, 9]).mean().item(), (b[:, 12] - b[:, 11]).mean().item(), (b[:, 10] - b[:, 12]).mean().item()]
 names = ["stage table", "action history", "load state", "4 substeps", "refresh/body pos", "post: derived+cmd", "rewards", "reset+stage", "obs head/noise", "scalar writes", "obs row writes"]
 tot = acc.sum().item() / K
 for i in range(10):
     print(f"{names[i]:22s} {acc[i].item()/K:10.0f} ticks  {100*acc[i].item()/K/tot:5.1f}%")
-print("last phase split: assemble", extra[0], "barrier", extra[1], "copies", extra[2])
 print("total ticks", tot, "(s_memtime; 100 MHz constant clock => 10 ns per tick)")
