@@ -255,15 +255,20 @@ class SSInfoGAIL:
         stage = min(max(self.priv_reg_counter - t0, 0) / t1, 1)
         priv_reg_coef = stage * (s1 - s0) + s0
 
-        # estimator regression on the true privileged explicit state (gail.py:356-362)
+        # estimator regression on the true privileged explicit state (gail.py:356-362).  Its parameters do not enter the
+        # actor-critic objective, so its optimiser step can wait until both backward passes are done: data-parallel runs
+        # then need ONE collective per minibatch (estimator grads + actor-critic grads + the KL scalar in one bucket)
         estimator_loss = (self.estimator(obs_prop) - obs_explicit).pow(2).mean()
         self.optim_estimator.zero_grad()
         estimator_loss.backward()
-        self._sync_grads(list(self.estimator.parameters()))
-        nn.utils.clip_grad_norm_(self.estimator.parameters(), self.max_grad_norm)
-        self.optim_estimator.step()
+        est_params = list(self.estimator.parameters())
+        if self.grad_sync is None:
+            nn.utils.clip_grad_norm_(est_params, self.max_grad_norm)
+            self.optim_estimator.step()
 
-        if self.desired_kl is not None and self.schedule == "adaptive":
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        kl_mean = None
+        if adaptive:
             with torch.no_grad():
                 if fused:
                     kl_mean = stats[5]
@@ -271,9 +276,8 @@ class SSInfoGAIL:
                     kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) +
                                    (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
                     kl_mean = kl.mean()
-                if self.grad_sync is not None:
-                    kl_mean = self.grad_sync.mean_scalar(kl_mean)
-                self._apply_kl_schedule(kl_mean)
+                if self.grad_sync is None:
+                    self._apply_kl_schedule(kl_mean)
 
         if fused:
             surrogate_loss, value_loss, b_mean, ent_mean = stats[1], stats[2], stats[3], stats[4]
@@ -294,7 +298,12 @@ class SSInfoGAIL:
         self.optim_ac.zero_grad()
         loss.backward()
         params = list(ac.parameters())
-        self._sync_grads(params)
+        if self.grad_sync is not None:
+            synced = self.grad_sync(est_params + params, extra=[kl_mean] if adaptive else None)
+            nn.utils.clip_grad_norm_(est_params, self.max_grad_norm)
+            self.optim_estimator.step()
+            if adaptive:
+                self._apply_kl_schedule(synced[0].reshape(()))      # every rank takes the same LR branch
         nn.utils.clip_grad_norm_(params, self.max_grad_norm)
         self.optim_ac.step()
         return (surrogate_loss.detach(), value_loss.detach(), b_mean.detach(), ent_mean.detach(),
@@ -345,9 +354,8 @@ class SSInfoGAIL:
         policy_c_idx = torch.argmax(policy_c, dim=-1)
 
         pred_mean = torch.mean(pred_c_ulb, dim=0).detach()
-        if self.grad_sync is not None:
-            pred_mean = self.grad_sync.mean_vector(pred_mean)
-        self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
+        if self.grad_sync is None:      # data-parallel: the vector rides in the gradient bucket below (one collective per step)
+            self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
         info_max_loss = torch.mean(-torch.sum(pred_c_ulb * torch.log(pred_c_ulb + 1e-20), dim=-1))
 
         if self.disc_loss_function == "BCEWithLogitsLoss":
@@ -374,7 +382,9 @@ class SSInfoGAIL:
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.zero_grad()
         loss.backward()
-        self._sync_grads(list(self.disc.parameters()))
+        if self.grad_sync is not None:
+            pred_mean = self.grad_sync(list(self.disc.parameters()), extra=[pred_mean])[0]
+            self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.step()
         if not self.actor_critic.fixed_std and self.min_std is not None:

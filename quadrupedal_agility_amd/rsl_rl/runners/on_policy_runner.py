@@ -72,15 +72,21 @@ class GradSync:
     def __init__(self):
         self.world = dist.get_world_size()
 
-    def __call__(self, params):
+    def __call__(self, params, extra=None):
+        """Average the gradients of `params` over the ranks in place; `extra` (a list of small tensors, e.g. the
+        minibatch KL) rides in the same bucket and is returned averaged.  One cat, one all-reduce, one scale, one
+        multi-tensor copy back."""
         grads = [p.grad for p in params if p.grad is not None]
-        if not grads:
-            return
-        flat = torch._utils._flatten_dense_tensors(grads)
+        extra = [] if extra is None else [e.detach().reshape(-1).to(torch.float32) for e in extra]
+        if not grads and not extra:
+            return []
+        flat = torch._utils._flatten_dense_tensors(grads + extra)
         dist.all_reduce(flat)
         flat.div_(self.world)
-        for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-            g.copy_(s)
+        parts = torch._utils._unflatten_dense_tensors(flat, grads + extra)
+        if grads:
+            torch._foreach_copy_(grads, list(parts[:len(grads)]))
+        return [x.clone() for x in parts[len(grads):]]
 
     def mean_scalar(self, x):
         x = x.clone()
