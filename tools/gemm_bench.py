@@ -26,7 +26,10 @@ def timeit(fn, n=30):
 
 tot = 0.0
 for name, i, o, need_dx in layers:
-    x = torch.randn(B, i, device="cuda"); w = torch.randn(o, i, device="cuda"); b = torch.randn(o, device="cuda"); g = torch.randn(B, o, device="cuda")
+    x = torch.randn(B, i, device="cuda")
+    if name in ("priv0", "est0"):          # in the update these inputs are column slices of the (B, 671) observation rows
+        x = torch.randn(B, 671, device="cuda")[:, 61:61 + i] if name == "priv0" else torch.randn(B, 671, device="cuda")[:, :i]
+    w = torch.randn(o, i, device="cuda"); b = torch.randn(o, device="cuda"); g = torch.randn(B, o, device="cuda")
     fl = 2.0 * B * i * o
     t_f = timeit(lambda: torch.addmm(b, x, w.t()))
     t_w = timeit(lambda: g.t().mm(x))
