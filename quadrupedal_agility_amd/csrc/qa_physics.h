@@ -260,6 +260,15 @@ QA_DEV void contact_rows(Row *rows, V3 p, int depth, float gap, const V3 *o, con
 // link inertia (10 floats), tau = joint torques of this leg (already clipped), mu = friction.
 // Returns contact forces; updates st in place.  If fk_out != nullptr, writes the joint origins
 // and the foot origin of the NEW state in the base frame (4 points) for RIGID_BODY_POS.
+// development aid: -DQA_SUBPROF adds s_memtime stamps of the substep's sections (tools/substep_profile.py builds its own
+// copy of the library with it; the product build has none of this)
+#ifdef QA_SUBPROF
+__device__ long long *g_subprof = nullptr;
+#define QA_SUBSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (g_subprof && threadIdx.x == 0) g_subprof[blockIdx.x * 32 + 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define QA_SUBSTAMP(k) do { } while (0)
+#endif
+
 // rarely-active rows live in per-lane LDS slots: slot k of this lane is priv[k * QA_PRIV_STRIDE]
 #define QA_PRIV_STRIDE 64
 #define QA_PRIV_EXTRA 0                  // 3 rows x 20 floats: jh6 jl3 bj6 lj3 dinv bias
@@ -291,6 +300,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     S6 V0 = s6(mulT(R, st.ww), mulT(R, st.vw));
     V3 gB = v3(R.m[6] * P.gz, R.m[7] * P.gz, R.m[8] * P.gz);
 
+    QA_SUBSTAMP(0);
     // ---- leg kinematics in the base frame
     float s1, c1, s2, c2, s23, c23;
     __sincosf(st.q[0], &s1, &c1); __sincosf(st.q[1], &s2, &c2); __sincosf(st.q[1] + st.q[2], &s23, &c23);
@@ -312,6 +322,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         link[k] = link_rb(tbl[T_MASS + k], v3(tbl[T_COM + 3 * k], tbl[T_COM + 3 * k + 1], tbl[T_COM + 3 * k + 2]),
                           tbl + T_INERTIA + 6 * k, Rl[k], o[k]);
     }
+    QA_SUBSTAMP(1);
     // ---- composite inertias, mass-matrix blocks
     RB Ic2 = link[2], Ic1 = link[1] + Ic2, Ic0 = link[0] + Ic1;
     S6 F[3] = {apply(Ic0, S[0]), apply(Ic1, S[1]), apply(Ic2, S[2])};
@@ -321,6 +332,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     base.xx = binert[4]; base.yy = binert[5]; base.zz = binert[6]; base.xy = binert[7]; base.xz = binert[8]; base.yz = binert[9];
     RB tot = base + quad_sum(Ic0);
 
+    QA_SUBSTAMP(2);
     // ---- bias forces: Newton-Euler with zero joint acceleration, base acceleration = -gravity
     S6 A0 = s6(v3(0, 0, 0), v3(-gB.x, -gB.y, -gB.z));
     S6 fl[3];
@@ -338,6 +350,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     float hl[3] = {dot(S[0], fl[0]), dot(S[1], fl[1]), dot(S[2], fl[2])};
     S6 f0 = apply(base, A0) + crf(V0, apply(base, V0)) + quad_sum(fl[0]);
 
+    QA_SUBSTAMP(3);
     // ---- leg elimination: Linv (packed 00 01 02 11 12 22), G = -Linv F^T (3x6 row-major)
     float Linv[6];
     {
@@ -373,6 +386,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     float Binv[21];
     spd6_inverse(Bm, Binv);
 
+    QA_SUBSTAMP(5);
     // ---- unconstrained velocity
     float rl[3] = {tau[0] - hl[0], tau[1] - hl[1], tau[2] - hl[2]};
     float rb[6] = {-f0.a.x, -f0.a.y, -f0.a.z, -f0.l.x, -f0.l.y, -f0.l.z};
@@ -399,23 +413,60 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         }
     }
 
+    QA_SUBSTAMP(6);
     // ---- contact candidates: slot 0 = foot sphere, slot 1 = closest other point owned by this lane
     V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);   // plane: world z, x, y
     V3 foot_n = v3(0, 0, 1), best_n = v3(0, 0, 1);          // world-frame contact normals (height field)
     float foot_gap; V3 foot_p;
     float best_gap = 1e30f; V3 best_p = v3(0, 0, 0); int best_depth = 0, best_body = -1;
+    if (PLANE) {
+        // On the plane only a candidate's world height matters: z_w = nB . (Rl_k pt + o_k) + z = (Rl_k^T nB) . pt + (nB . o_k + z),
+        // i.e. 3 FMAs per point after 3 per-link vectors; the full base-frame position is built for the winner only.
+        V3 nk[3]; float hk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nk[k] = mulT(Rl[k], nB); hk[k] = dot(nB, o[k]) + st.pos.z; }
+        {
+            const float *pt = tbl + T_POINTS;
+            foot_p = mul(Rl[2], v3(pt[0], pt[1], pt[2])) + o[2];
+            foot_gap = dot(nB, foot_p) + st.pos.z - pt[3];
+        }
+        int best_c = 0;                           // 1..QA_LEG_PTS-1: leg point, 64 + c: base point
+#pragma unroll
+        for (int c = 1; c < QA_LEG_PTS; ++c) {
+            const int k = (c < 3 ? 0 : (c < 11 ? 1 : 2));
+            const float *pt = tbl + T_POINTS + 4 * c;
+            const float gap = dot(nk[k], v3(pt[0], pt[1], pt[2])) + hk[k] - pt[3];
+            if (gap < best_gap) { best_gap = gap; best_c = c; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = leg + 4 * j;
+            if (c < QA_BASE_PTS) {
+                const float *pt = btbl + 4 * c;
+                const float gap = dot(nB, v3(pt[0], pt[1], pt[2])) + st.pos.z - pt[3];
+                if (gap < best_gap) { best_gap = gap; best_c = 64 + c; }
+            }
+        }
+        if (best_c >= 64) {
+            const int c = best_c - 64;
+            const float *pt = btbl + 4 * c;
+            best_p = v3(pt[0], pt[1], pt[2]); best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2);
+        } else if (best_c > 0) {
+            const int k = (best_c < 3 ? 0 : (best_c < 11 ? 1 : 2));
+            const float *pt = tbl + T_POINTS + 4 * best_c;
+            const M3 Rs = k == 0 ? Rl[0] : (k == 1 ? Rl[1] : Rl[2]);
+            const V3 os = k == 0 ? o[0] : (k == 1 ? o[1] : o[2]);
+            best_p = mul(Rs, v3(pt[0], pt[1], pt[2])) + os; best_depth = k + 1; best_body = 3 + 4 * leg + k;
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < QA_LEG_PTS; ++c) {
         const int k = (c == 0) ? 2 : (c < 3 ? 0 : (c < 11 ? 1 : 2));
         const float *pt = tbl + T_POINTS + 4 * c;
         V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
         float zw = dot(nB, p) + st.pos.z;
-        float gap; V3 gn = v3(0, 0, 1);
-        if (PLANE) gap = zw - pt[3];                 // plane: only the world height matters
-        else {
-            float gh; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
-            gap = (zw - gh) * gn.z - pt[3];          // distance to the terrain triangle's plane
-        }
+        float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
+        float gap = (zw - gh) * gn.z - pt[3];          // distance to the terrain triangle's plane
         if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; }
         else if (gap < best_gap) { best_gap = gap; best_p = p; best_n = gn; best_depth = k + 1; best_body = 3 + 4 * leg + k; }
     }
@@ -426,18 +477,16 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             const float *pt = btbl + 4 * c;
             V3 p = v3(pt[0], pt[1], pt[2]);
             float zw = dot(nB, p) + st.pos.z;
-            float gap; V3 gn = v3(0, 0, 1);
-            if (PLANE) gap = zw - pt[3];
-            else {
-                float gh; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
-                gap = (zw - gh) * gn.z - pt[3];
-            }
+            float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
+            float gap = (zw - gh) * gn.z - pt[3];
             if (gap < best_gap) { best_gap = gap; best_p = p; best_n = gn; best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2); }
         }
+    }
     }
     const bool foot_on = foot_gap < P.contact_offset;
     const bool extra_on = best_gap < P.contact_offset;
 
+    QA_SUBSTAMP(7);
     // ---- rows (all in registers; inactive ones are skipped wave-uniformly below)
     Row rf[3];
     V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
@@ -483,6 +532,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         }
     }
 
+    QA_SUBSTAMP(8);
     // ---- warm start: the foot rows start from the previous substep's impulses, applied to (ub, w) first
     {
         float dub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -498,6 +548,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
         for (int i = 0; i < 6; ++i) ub[i] += quad_sum(dub[i]);
     }
+    QA_SUBSTAMP(4);
     // ---- projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs
     // {FL, RR} and {FR, RL} are updated from the same base velocity (their coupling through the base is weak: the
     // lever arms cancel in the rotational term) and their base-velocity changes are quad-summed; colours follow each
@@ -558,6 +609,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         }
     }
 
+    QA_SUBSTAMP(9);
     // ---- leg velocity, clamp, integrate
     float ul[3];
 #pragma unroll
@@ -589,6 +641,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 
 #pragma unroll
     for (int d = 0; d < 3; ++d) fimp[d] = foot_on ? rf[d].lam : 0.f;
+    QA_SUBSTAMP(10);
     // ---- contact forces, world frame (plane: t1, t2, n are world x, y, z)
     float idt = 1.0f / dt;
     if (PLANE) {

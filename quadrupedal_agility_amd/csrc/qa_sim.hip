@@ -200,7 +200,11 @@ __device__ __forceinline__ TerrainView terrain_view(const qa_config &c, const Pt
 
 // ------------------------------------------------------------------ the fused env step
 struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; const int64_t *step_ptr; long long *prof; };
+#ifdef QA_SUBPROF
+#define QA_STAMP(k) do { } while (0)      // the substep stamps own the buffer in this build
+#else
 #define QA_STAMP(k) do { if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#endif
 
 #define S_PROP 0        // 57  proprioception (noise-free)
 #define S_HEAD 57       // 90  obs[0:90] with noise
@@ -1006,7 +1010,14 @@ int qa_simulate(qa_sim *s, const float *torques, void *stream) {
 }
 
 /* development aid (not part of include/qa_sim.h): per-block s_memtime stamps of the env-step phases, 16 slots per block */
-int qa_debug_set_profile_buffer(qa_sim *s, long long *dev_buf) { if (!s) return QA_E_ARG; s->prof = dev_buf; return QA_OK; }
+int qa_debug_set_profile_buffer(qa_sim *s, long long *dev_buf) {
+    if (!s) return QA_E_ARG;
+    s->prof = dev_buf;
+#ifdef QA_SUBPROF
+    hipMemcpyToSymbol(HIP_SYMBOL(g_subprof), &dev_buf, sizeof(dev_buf));
+#endif
+    return QA_OK;
+}
 
 int qa_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, float *returns,
            float *advantages, int32_t T, int32_t N, float gamma, float lam, int32_t normalize, void *scratch, void *stream) {
