@@ -256,6 +256,16 @@ int64_t qa_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols);
 int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
                          float alpha, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* Running-moment normaliser of the discriminator inputs (bbc/rsl_rl/utils/utils.py:62-103).
+ * qa_normalizer_update folds num_batches (1..4) row-major (rows[i], dim) fp32 device batches, in order, into the
+ * device-resident double moments (mean[dim], var[dim], *count): each batch contributes its mean and biased variance
+ * (RunningMeanStd.update_from_moments).  `batches` / `rows` are HOST arrays of device pointers / row counts; dim <= 128.
+ * qa_normalizer_apply writes y = clamp((x - (float)mean) / sqrt((float)(var + epsilon)), -clip, clip). */
+int qa_normalizer_update(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim,
+                         double *mean, double *var, double *count, void *stream);
+int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, const double *mean, const double *var,
+                        float epsilon, float clip, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

@@ -1078,6 +1078,42 @@ int qo_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
     return QA_OK;
 }
 
+/* RunningMeanStd.update / update_from_moments (utils.py:62-84) on host memory, plain double loops */
+int qo_normalizer_update(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim,
+                         double *mean, double *var, double *count, void *stream) {
+    (void)stream;
+    if (!batches || !rows || !mean || !var || !count || num_batches <= 0 || num_batches > 4 || dim <= 0 || dim > 128) return QA_E_ARG;
+    for (int b = 0; b < num_batches; ++b) {
+        const float *x = batches[b]; int64_t n = rows[b];
+        if (!x || n <= 0) return QA_E_ARG;
+        double total = *count + (double)n;
+        for (int c = 0; c < dim; ++c) {
+            double bm = 0, bv = 0;
+            for (int64_t r = 0; r < n; ++r) bm += x[r * dim + c];
+            bm /= (double)n;
+            for (int64_t r = 0; r < n; ++r) { double d = x[r * dim + c] - bm; bv += d * d; }
+            bv /= (double)n;
+            double delta = bm - mean[c];
+            double m2 = var[c] * *count + bv * (double)n + delta * delta * *count * (double)n / total;
+            mean[c] += delta * (double)n / total;
+            var[c] = m2 / total;
+        }
+        *count = total;
+    }
+    return QA_OK;
+}
+int qo_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, const double *mean, const double *var,
+                        float epsilon, float clip, void *stream) {
+    (void)stream;
+    if (!x || !y || !mean || !var || rows <= 0 || dim <= 0) return QA_E_ARG;
+    for (int64_t i = 0; i < rows * dim; ++i) {
+        int c = (int)(i % dim);
+        float m = (float)mean[c], sd = sqrtf((float)(var[c] + (double)epsilon)), v = (x[i] - m) / sd;
+        y[i] = v < -clip ? -clip : (v > clip ? clip : v);
+    }
+    return QA_OK;
+}
+
 /* ---- debug entry points used only by the physics known-answer tests ---- */
 /* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
 int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {

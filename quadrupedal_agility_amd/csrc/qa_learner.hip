@@ -215,6 +215,70 @@ __global__ void __launch_bounds__(256) qa_colsum_finish_kernel(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Running-moment normaliser of the discriminator inputs (bbc/rsl_rl/utils/utils.py:62-103, RunningMeanStd): fold up to
+// four (n_i, d) fp32 batches, in order, into (mean, var, count) kept in double on the device; each batch contributes
+// its mean and biased variance (two passes over the batch in double, as numpy's mean/var), merged with the parallel-
+// variance formula.  In eager PyTorch one such update is ~35 launches of double-precision reductions and elementwise
+// ops per batch (3 batches x 80 discriminator steps per iteration).  One workgroup: d columns x (1024/CW) row lanes.
+constexpr int NORM_MAX_BATCHES = 4;
+struct NormArgs { const float *batch[NORM_MAX_BATCHES]; int64_t n[NORM_MAX_BATCHES]; int k, d; double *mean, *var, *count; };
+
+__global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) {
+    __shared__ double s_red[1024];
+    __shared__ double s_col[128];
+    const int CW = 128, RL = 1024 / CW;
+    const int c = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const bool col = c < a.d;
+    double run_mean = (col && rl == 0) ? a.mean[c] : 0.0, run_var = (col && rl == 0) ? a.var[c] : 0.0;
+    double count = *a.count;
+    for (int b = 0; b < a.k; ++b) {
+        const float *x = a.batch[b];
+        const int64_t n = a.n[b];
+        double acc = 0.0;
+        if (col) for (int64_t r = rl; r < n; r += RL) acc += (double)x[r * a.d + c];
+        s_red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < RL; ++q) t += s_red[q * CW + c];
+            s_col[c] = t / (double)n;
+        }
+        __syncthreads();
+        const double bm = s_col[c];
+        acc = 0.0;
+        if (col) for (int64_t r = rl; r < n; r += RL) { const double dlt = (double)x[r * a.d + c] - bm; acc += dlt * dlt; }
+        __syncthreads();
+        s_red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0 && col) {
+            double m2b = 0.0;
+#pragma unroll
+            for (int q = 0; q < RL; ++q) m2b += s_red[q * CW + c];
+            const double bv = m2b / (double)n, nb = (double)n;
+            const double delta = bm - run_mean, total = count + nb;
+            const double m2 = run_var * count + bv * nb + delta * delta * count * nb / total;
+            run_mean += delta * nb / total;
+            run_var = m2 / total;
+        }
+        count += (double)n;
+        __syncthreads();
+    }
+    if (rl == 0 && col) { a.mean[c] = run_mean; a.var[c] = run_var; }
+    if (threadIdx.x == 0) *a.count = count;
+}
+
+// y = clamp((x - mean) / sqrt(var + eps), -clip, clip) with mean / std rounded to fp32 first (utils.py:97-103)
+__global__ void __launch_bounds__(256) qa_normalizer_apply_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t total, int d,
+                                                                  const double *__restrict__ mean, const double *__restrict__ var, float eps, float clip) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % d);
+    const float m = (float)mean[c], sd = sqrtf((float)(var[c] + (double)eps));
+    y[i] = fminf(fmaxf((x[i] - m) / sd, -clip), clip);
+}
+
 }  // namespace
 
 extern thread_local char qa_err_buf[512];
@@ -264,6 +328,32 @@ int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
     hipLaunchKernelGGL(qa_colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float *)partial, nb, (int)cols, grad_bias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_normalizer_update(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim,
+                         double *mean, double *var, double *count, void *stream) {
+    if (!batches || !rows || !mean || !var || !count || num_batches <= 0 || num_batches > NORM_MAX_BATCHES || dim <= 0 || dim > 128) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_update: bad argument (1..4 batches, dim <= 128)"); return QA_E_ARG; }
+    NormArgs a{};
+    for (int b = 0; b < num_batches; ++b) {
+        if (!batches[b] || rows[b] <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_update: empty batch"); return QA_E_ARG; }
+        a.batch[b] = batches[b]; a.n[b] = rows[b];
+    }
+    a.k = num_batches; a.d = dim; a.mean = mean; a.var = var; a.count = count;
+    hipLaunchKernelGGL(qa_normalizer_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_update: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, const double *mean, const double *var,
+                        float epsilon, float clip, void *stream) {
+    if (!x || !y || !mean || !var || rows <= 0 || dim <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_apply: bad argument"); return QA_E_ARG; }
+    const int64_t total = rows * dim;
+    hipLaunchKernelGGL(qa_normalizer_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, total, (int)dim, mean, var, epsilon, clip);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_apply: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

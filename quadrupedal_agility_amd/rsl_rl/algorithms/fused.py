@@ -141,3 +141,30 @@ def ppo_loss_reference(mu, std, value, actions, old_logp, old_mu, old_sigma, adv
     ent = entropy.mean()
     loss = c_surr * surrogate + c_value * value_loss + c_bound * b_loss - c_entropy * ent
     return loss, torch.stack([loss.detach(), surrogate.detach(), value_loss.detach(), b_loss.detach(), ent.detach(), kl])
+
+
+def normalizer_update(mean, var, count, batches):
+    """RunningMeanStd update of the device-resident double moments with 1..4 fp32 batches, one launch (qa_normalizer_update)."""
+    lib = _capi.load_library()
+    bs = [_f32c(b.detach()) for b in batches]
+    k, d = len(bs), mean.shape[0]
+    assert 1 <= k <= 4 and all(b.dim() == 2 and b.shape[1] == d for b in bs) and mean.dtype == torch.float64
+    ptrs = (C.c_void_p * k)(*[b.data_ptr() for b in bs])
+    rows = (C.c_int64 * k)(*[b.shape[0] for b in bs])
+    stream = C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream)
+    rc = lib.qa_normalizer_update(ptrs, rows, k, d, _ptr(mean), _ptr(var), _ptr(count), stream)
+    if rc != 0:
+        raise RuntimeError(f"qa_normalizer_update failed with code {rc}: {lib.qa_last_error().decode()}")
+
+
+def normalizer_apply(x, mean, var, epsilon, clip):
+    lib = _capi.load_library()
+    xc = _f32c(x)
+    y = torch.empty_like(xc)
+    d = mean.shape[0]
+    assert xc.shape[-1] == d
+    stream = C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)
+    rc = lib.qa_normalizer_apply(_ptr(xc), _ptr(y), xc.numel() // d, d, _ptr(mean), _ptr(var), float(epsilon), float(clip), stream)
+    if rc != 0:
+        raise RuntimeError(f"qa_normalizer_apply failed with code {rc}: {lib.qa_last_error().decode()}")
+    return y
