@@ -23,6 +23,12 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_ENV_STEP = 6166          # 2,648 B read + 3,518 B written per env-step (BBC)
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak (6.3 TB/s achievable)
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, exact f32
+# Algorithmic learner FLOPs per sample (2 x MAC), DESIGN.md section 6: forward MACs actor 217,088, privileged encoder
+# 3,712 (evaluated twice in the update), critic 507,520, estimator 15,744, history encoder 28,770 (forward only, no_grad)
+_FWD = 217088 + 2 * 3712 + 507520 + 15744
+UPDATE_FLOPS_PER_SAMPLE = 2 * (3 * _FWD - 343552 - 7296) + 2 * 28770      # fwd + dW + dx; no dx for the two first layers fed by raw observations
+ROLLOUT_FLOPS_PER_SAMPLE = 2 * (217088 + 3712 + 507520 + 15744)
 
 
 def main():
@@ -137,6 +143,14 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
                          "note": "latency/occupancy-bound: 4096 envs = 256 wavefronts on 1024 SIMDs, ~0.1 MFLOP of serial rigid-body algebra per env-step"},
         }
+        epochs, nmb = runner.alg.num_learning_epochs, runner.alg.num_mini_batches
+        samples = args.num_envs * T
+        if not args.amp:      # the discriminator's GEMMs are not counted, so the figure would overstate the AMP config
+            lf = samples * (epochs * UPDATE_FLOPS_PER_SAMPLE + ROLLOUT_FLOPS_PER_SAMPLE)
+            out["learner_roofline"] = {"bound": "mfma", "dtype": "f32", "achieved": lf / (dt / args.steps) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": lf / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                       "algorithmic_flops_per_iteration": lf,
+                                       "note": f"whole iteration time; {epochs} epochs x {nmb} minibatches of {samples // nmb} samples, GEMMs through hipBLASLt (fp32 MFMA 16x16x4)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.num_envs, args.cpu_seconds)
         print(json.dumps(out))
