@@ -104,3 +104,32 @@ def test_tile_generator_statistics():
     random_uniform_terrain(r, -0.05, 0.05, 0.005, downsampled_scale=0.2)
     hr = r.height_field_raw * 0.005
     assert -0.0501 <= hr.min() and hr.max() <= 0.0501 and hr.std() > 0.015
+
+
+def test_slide_down_a_slope_follows_coulomb():
+    """tan(theta) = 0.4 > mu = 0.2: the standing robot slides as a rigid block, a = g (sin theta - mu cos theta)."""
+    n, slope, mu = 2, 0.4, 0.2
+    q = hf_cfg(n, 600, 120, border=3.0, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0,
+               push_robots=0, add_noise=0)
+    q.reset_xy_jitter = 0.0; q.env_spacing = 3.0; q.ground_friction = mu
+    o = OracleSim(q)
+    o.t["FRICTION"][:] = mu                                   # contact friction = mean of robot and ground friction
+    z = 30.0 - slope * (np.arange(600)[:, None] * 0.1)        # downhill towards +x
+    o.t["HEIGHT_SAMPLES"][...] = np.rint(z / 0.005).astype(np.int16) * np.ones((1, 120), np.int16)
+    o.t["ENV_ORIGINS"][:, 0] = 5.0; o.t["ENV_ORIGINS"][:, 1] = 3.0 + np.arange(n)
+    o.t["ENV_ORIGINS"][:, 2] = 30.0 - slope * (5.0 + 3.0)
+    o.reset_all()
+    o.t["ROOT_STATES"][:, 7:13] = 0
+    speed = []
+    for k in range(60):
+        o.step(np.zeros((n, 12), np.float32))
+        assert not o.t["RESET"].any()
+        speed.append(np.linalg.norm(o.t["ROOT_STATES"][:, 7:10], axis=1))
+    speed = np.array(speed)
+    th = np.arctan(slope)
+    a = G * (np.sin(th) - mu * np.cos(th))                    # 1.82 m/s^2
+    t = np.arange(60) * 0.02
+    fit = np.polyfit(t[25:], speed[25:], 1)                   # after the landing transient
+    assert fit[0][0] == pytest.approx(a, rel=0.04) and fit[0][1] == pytest.approx(a, rel=0.04)
+    v = o.t["ROOT_STATES"][:, 7:10]
+    assert np.all(np.abs(v[:, 1]) < 0.1) and np.allclose(v[:, 2] / v[:, 0], -slope, atol=0.05)       # along the fall line
