@@ -236,7 +236,18 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
         const float *x = a.batch[b];
         const int64_t n = a.n[b];
         double acc = 0.0;
-        if (col) for (int64_t r = rl; r < n; r += RL) acc += (double)x[r * a.d + c];
+        if (col) {       // 8 loads in flight per lane, 4 independent accumulators (a lone dependent chain is latency-bound)
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int64_t r = rl;
+            const int64_t st = (int64_t)RL * a.d;
+            for (; r + 7 * RL < n; r += 8 * RL) {
+                const float *q = x + r * a.d + c;
+                const float v0 = q[0], v1 = q[st], v2 = q[2 * st], v3 = q[3 * st], v4 = q[4 * st], v5 = q[5 * st], v6 = q[6 * st], v7 = q[7 * st];
+                a0 += (double)v0 + (double)v4; a1 += (double)v1 + (double)v5; a2 += (double)v2 + (double)v6; a3 += (double)v3 + (double)v7;
+            }
+            for (; r < n; r += RL) a0 += (double)x[r * a.d + c];
+            acc = (a0 + a1) + (a2 + a3);
+        }
         s_red[threadIdx.x] = acc;
         __syncthreads();
         if (rl == 0) {
@@ -248,7 +259,19 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
         __syncthreads();
         const double bm = s_col[c];
         acc = 0.0;
-        if (col) for (int64_t r = rl; r < n; r += RL) { const double dlt = (double)x[r * a.d + c] - bm; acc += dlt * dlt; }
+        if (col) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int64_t r = rl;
+            const int64_t st = (int64_t)RL * a.d;
+            for (; r + 7 * RL < n; r += 8 * RL) {
+                const float *q = x + r * a.d + c;
+                const double d0 = (double)q[0] - bm, d1 = (double)q[st] - bm, d2 = (double)q[2 * st] - bm, d3 = (double)q[3 * st] - bm;
+                const double d4 = (double)q[4 * st] - bm, d5 = (double)q[5 * st] - bm, d6 = (double)q[6 * st] - bm, d7 = (double)q[7 * st] - bm;
+                a0 += d0 * d0 + d4 * d4; a1 += d1 * d1 + d5 * d5; a2 += d2 * d2 + d6 * d6; a3 += d3 * d3 + d7 * d7;
+            }
+            for (; r < n; r += RL) { const double dlt = (double)x[r * a.d + c] - bm; a0 += dlt * dlt; }
+            acc = (a0 + a1) + (a2 + a3);
+        }
         __syncthreads();
         s_red[threadIdx.x] = acc;
         __syncthreads();
