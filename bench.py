@@ -96,6 +96,8 @@ def main():
     for _ in range(args.steps):
         runner.learn(1, init_at_random_ep_len=False)
         coll.append(runner.last_perf["collection_time"]); lrn.append(runner.last_perf["learn_time"])
+    if os.environ.get("QA_BENCH_TRACE") and rank == 0:
+        print("per-iteration ms:", " ".join(f"{(c + l) * 1e3:.1f}" for c, l in zip(coll, lrn)), file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -84,6 +84,7 @@ class SSInfoGAIL:
         self.learning_steps, self.begin_rim = 0, begin_rim
         self.grad_sync = None          # callable(list_of_params, extra_scalars) -> None, installed for world_size > 1
         self.use_fused_loss = True     # GPU: PPO objective + gradient as one HIP kernel (qa_ppo_loss); False = eager PyTorch ops
+        self._ac_graph, self._recording_ac, self._priv_coef_dev = None, False, None
         self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
@@ -157,9 +158,13 @@ class SSInfoGAIL:
         if self.learning_steps >= self.begin_rim:
             self.info_max_coef_on = min(self.info_max_coef * (self.learning_steps - self.begin_rim) / 10000, self.info_max_coef)
         dev = self.device
-        acc_ac = torch.zeros(6, device=dev)
-        for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            acc_ac += torch.stack(self.update_actor_critic(sample))
+        if (self._on_gpu and self.use_update_graph and self.grad_sync is None and self.learning_steps >= 2 and self._ac_graph is not False
+                and self.desired_kl is not None and self.schedule == "adaptive"):
+            acc_ac = self._ac_updates_recorded()
+        else:
+            acc_ac = torch.zeros(6, device=dev)
+            for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+                acc_ac += torch.stack(self.update_actor_critic(sample))
         n_ac = self.num_learning_epochs * self.num_mini_batches
         n_d = n_ac * 4
         acc_d = torch.zeros(11, device=dev)
@@ -177,6 +182,61 @@ class SSInfoGAIL:
         self.priv_reg_counter += 1
         out = torch.cat([acc_ac / n_ac, acc_d / n_d]).tolist()      # the one host read of the update
         return tuple(out)
+
+    def _priv_reg_coef_now(self):
+        s0, s1, t0, t1 = self.priv_reg_coef_schedual
+        stage = min(max(self.priv_reg_counter - t0, 0) / t1, 1)
+        return stage * (s1 - s0) + s0
+
+    def _ac_updates_recorded(self):
+        """The 20 PPO minibatch steps of an iteration are ~270 launches each and the host cannot issue them faster than
+        the GPU retires them (the iteration time followed the host's launch rate, 59-78 ms, not the GPU's 57 ms of kernel
+        time).  One step -- minibatch gather from a device index buffer, both forwards, the fused objective, both
+        backward passes, clipping, the KL-adaptive learning rate and the three Adam updates -- is recorded into a
+        hipGraph once and replayed; per step the host only copies the next 24,576 indices into the index buffer."""
+        dev, st = self.device, self.storage
+        batch = st.num_envs * st.num_transitions_per_env
+        mb = batch // self.num_mini_batches
+        if self._ac_graph is None:
+            try:
+                self._mb_idx = torch.zeros(mb, dtype=torch.int64, device=dev)
+                self._acc_ac = torch.zeros(6, device=dev)
+                self._priv_coef_dev = torch.zeros((), device=dev)
+                flat = [x.flatten(0, 1) for x in (st.observations, st.actions, st.values, st.advantages, st.returns,
+                                                  st.actions_log_prob, st.mu, st.sigma)]
+
+                def one_step():
+                    obs, act, val, adv, ret, logp, mu, sig = (x[self._mb_idx] for x in flat)
+                    out = self.update_actor_critic((obs, obs, act, val, adv, ret, logp, mu, sig, (None, None), None))
+                    self._acc_ac.add_(torch.stack(out))
+                torch.cuda.synchronize()
+                for o in (self.optim_ac, self.optim_estimator):
+                    o.zero_grad(set_to_none=True)
+                from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
+                g = torch.cuda.CUDAGraph()
+                self._recording_ac = True
+                try:
+                    with _no_gc(), torch.cuda.graph(g):
+                        one_step()
+                finally:
+                    self._recording_ac = False
+                self._ac_graph = g
+            except Exception as e:      # never fatal
+                print(f"[ppo update graph] capture failed, staying eager: {e}")
+                self._ac_graph = False
+                torch.cuda.synchronize()
+                acc = torch.zeros(6, device=dev)
+                for sample in st.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+                    acc += torch.stack(self.update_actor_critic(sample))
+                return acc
+        self._priv_coef_dev.fill_(float(self._priv_reg_coef_now()))
+        self._acc_ac.zero_()
+        perm = torch.randperm(self.num_mini_batches * mb, device=dev)       # one permutation for all epochs (rollout_storage.py:122-157)
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                self._mb_idx.copy_(perm[i * mb:(i + 1) * mb])
+                self._ac_graph.replay()
+        return self._acc_ac.clone()
 
     def _disc_updates_recorded(self, n_steps, mb):
         """The discriminator steps are tiny (3 x 1228 x 98 inputs, ~300 launches each, double backward) and therefore
@@ -251,9 +311,8 @@ class SSInfoGAIL:
         with torch.no_grad():
             hist_latent = ac.infer_hist_latent(obs_hist)
         priv_reg_loss = (priv_latent - hist_latent).norm(p=2, dim=1).mean()
-        s0, s1, t0, t1 = self.priv_reg_coef_schedual
-        stage = min(max(self.priv_reg_counter - t0, 0) / t1, 1)
-        priv_reg_coef = stage * (s1 - s0) + s0
+        # a device scalar while the step is being recorded (the ramp changes between iterations, replays must see it)
+        priv_reg_coef = self._priv_coef_dev if self._recording_ac else self._priv_reg_coef_now()
 
         # estimator regression on the true privileged explicit state (gail.py:356-362).  Its parameters do not enter the
         # actor-critic objective, so its optimiser step can wait until both backward passes are done: data-parallel runs

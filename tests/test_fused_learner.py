@@ -239,3 +239,27 @@ def test_normalizer_hip_matches_eager_and_oracle():
     assert torch.allclose(y, y2, rtol=1e-6, atol=1e-6) and float(y.abs().max()) <= 10.0
     ref = a.to_reference()
     assert type(ref).__name__ == "Normalizer" and np.allclose(ref.mean, a.mean.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_recorded_ppo_update_matches_eager_launches():
+    """3 iterations with the PPO minibatch step replayed from a hipGraph (iterations 2-3) vs launched eagerly: same
+    weights, same learning rate, same loss means"""
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    res = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        env, args, tcfg = _make(256, False)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+        runner.alg.use_update_graph = graph
+        runner.learn(3, init_at_random_ep_len=True)
+        assert (runner.alg._ac_graph is not None and runner.alg._ac_graph is not False) == graph
+        res.append(({k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()},
+                    {k: v.clone() for k, v in runner.alg.estimator.state_dict().items()}, float(runner.alg.lr_ac)))
+    (wa, ea, lra), (wb, eb, lrb) = res
+    assert lra == lrb
+    for k in wa:
+        assert torch.allclose(wa[k], wb[k], atol=3e-4, rtol=3e-3), k
+    for k in ea:
+        assert torch.allclose(ea[k], eb[k], atol=3e-4, rtol=3e-3), k
