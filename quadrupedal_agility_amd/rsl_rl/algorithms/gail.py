@@ -85,6 +85,7 @@ class SSInfoGAIL:
         self.grad_sync = None          # callable(list_of_params, extra_scalars) -> None, installed for world_size > 1
         self.use_fused_loss = True     # GPU: PPO objective + gradient as one HIP kernel (qa_ppo_loss); False = eager PyTorch ops
         self._ac_graph, self._recording_ac, self._priv_coef_dev = None, False, None
+        self._dagger_graph, self._dagger_calls = None, 0
         self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
@@ -458,23 +459,61 @@ class SSInfoGAIL:
         return (ss_loss.detach(), info_max_loss.detach(), disc_loss.detach(), us_loss.detach(), grad_pen_loss.detach(),
                 disc_logit_loss.detach(), disc_weight_decay.detach(), acc_lb, acc_pi, acc_exp, acc_ulb)
 
-    def update_dagger(self):
-        """History-encoder regression onto the privileged latent, every dagger_update_freq iterations (gail.py:543-575)."""
+    def _dagger_step(self, obs):
         ac = self.actor_critic
         a = self.num_prop + self.num_explicit; b = a + self.num_latent; c = b + self.num_hist * self.num_prop
+        with torch.no_grad():
+            target = ac.infer_priv_latent(obs[:, a:b])
+        loss = (target - ac.infer_hist_latent(obs[:, b:c])).norm(p=2, dim=1).mean()
+        self.optim_hist_encoder.zero_grad()
+        loss.backward()
+        params = list(ac.history_encoder.parameters())
+        self._sync_grads(params)
+        nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+        self.optim_hist_encoder.step()
+        return loss.detach()
+
+    def update_dagger(self):
+        """History-encoder regression onto the privileged latent, every dagger_update_freq iterations (gail.py:543-575)."""
+        n = self.num_learning_epochs * self.num_mini_batches
+        st = self.storage
+        if (self._on_gpu and self.use_update_graph and self.grad_sync is None and self._dagger_calls >= 1 and self._dagger_graph is not False):
+            # same recording scheme as the PPO step: gather from the device index buffer + one optimiser step per replay
+            mb = st.num_envs * st.num_transitions_per_env // self.num_mini_batches
+            if self._dagger_graph is None:
+                try:
+                    self._dg_idx = torch.zeros(mb, dtype=torch.int64, device=self.device)
+                    self._dg_acc = torch.zeros((), device=self.device)
+                    flat_obs = st.observations.flatten(0, 1)
+
+                    def one_step():
+                        self._dg_acc.add_(self._dagger_step(flat_obs[self._dg_idx]))
+                    torch.cuda.synchronize()
+                    self.optim_hist_encoder.zero_grad(set_to_none=True)
+                    from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
+                    g = torch.cuda.CUDAGraph()
+                    with _no_gc(), torch.cuda.graph(g):
+                        one_step()
+                    self._dagger_graph = g
+                except Exception as e:
+                    print(f"[dagger update graph] capture failed, staying eager: {e}")
+                    self._dagger_graph = False
+                    torch.cuda.synchronize()
+            if self._dagger_graph:
+                self._dg_acc.zero_()
+                perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
+                for _ in range(self.num_learning_epochs):
+                    for i in range(self.num_mini_batches):
+                        self._dg_idx.copy_(perm[i * mb:(i + 1) * mb])
+                        self._dagger_graph.replay()
+                self._dagger_calls += 1
+                st.clear()
+                self.priv_reg_counter += 1
+                return float(self._dg_acc) / n
         total = torch.zeros((), device=self.device)
-        for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            obs = sample[0]
-            with torch.no_grad():
-                target = ac.infer_priv_latent(obs[:, a:b])
-            loss = (target - ac.infer_hist_latent(obs[:, b:c])).norm(p=2, dim=1).mean()
-            self.optim_hist_encoder.zero_grad()
-            loss.backward()
-            params = list(ac.history_encoder.parameters())
-            self._sync_grads(params)
-            nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-            self.optim_hist_encoder.step()
-            total += loss.detach()
-        self.storage.clear()
+        for sample in st.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            total += self._dagger_step(sample[0])
+        self._dagger_calls += 1
+        st.clear()
         self.priv_reg_counter += 1
-        return float(total) / (self.num_learning_epochs * self.num_mini_batches)
+        return float(total) / n

@@ -214,7 +214,7 @@ class OnPolicyRunner:
         if self.amp_enabled:
             self._disc_stage = (torch.zeros(T, N, env.num_obs_disc * self.disc_obs_len, device=dev), torch.zeros(T, N, 1, device=dev),
                                 torch.zeros(T, N, env.dim_c, device=dev))
-        self._graph, self._graph_delay, self._graph_ep_infos = None, None, None
+        self._graph, self._graphs = None, {}          # hist_encoding -> (graph, action delay it was recorded with, ep_infos)
         self._graph_failed = False
 
     def _rollout_steps(self, hist_encoding, logging, recorded):
@@ -257,28 +257,35 @@ class OnPolicyRunner:
         from then on: ~2,400 launches per rollout become one graph launch (the rollout is launch-bound: the fused env step
         is 0.1 ms, the ~100 small inference/bookkeeping kernels around it 0.6 ms of host time per step)."""
         env, alg, T = self.env, self.alg, self.num_steps_per_env
-        can_graph = (self.use_rollout_graph and not self._graph_failed and not hist_encoding and self._eager_rollouts >= 1
+        can_graph = (self.use_rollout_graph and not self._graph_failed and self._eager_rollouts >= 1
                      and env.steps_until_delay_change() >= T)
-        if can_graph and self._graph is not None and self._graph_delay == env.delay:
-            self._graph.replay()
+        # one recording per variant: the DAgger rollouts (every dagger_update_freq-th iteration) act through the history
+        # encoder instead of the privileged encoder
+        key = bool(hist_encoding)
+        have = self._graphs.get(key)
+        if can_graph and have is not None and have[1] == env.delay:
+            have[0].replay()
             env.advance_host_counters(T)
             alg.storage.step = T
-            ep_infos = self._graph_ep_infos
+            ep_infos = have[2]
         elif can_graph:
             try:
                 with torch.inference_mode():
-                    alg.act(self._obs_cur, self._obs_cur, False)          # touch every GEMM shape once outside the capture
+                    alg.act(self._obs_cur, self._obs_cur, hist_encoding)          # touch every GEMM shape once outside the capture
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 alg.storage.step = 0
                 with _no_gc(), torch.cuda.graph(g):
                     with torch.inference_mode():
-                        ep_infos = self._rollout_steps(False, logging, recorded=True)    # host side effects run now, GPU work on replay
-                self._graph, self._graph_delay, self._graph_ep_infos = g, env.delay, ep_infos
+                        ep_infos = self._rollout_steps(hist_encoding, logging, recorded=True)    # host side effects run now, GPU work on replay
+                self._graphs[key] = (g, env.delay, ep_infos)
+                if not key:
+                    self._graph = g
                 g.replay()
             except Exception as e:      # never fatal: fall back to eager launches
                 print(f"[rollout graph] capture failed, staying eager: {e}")
                 self._graph, self._graph_failed = None, True
+                self._graphs = {}
                 torch.cuda.synchronize()
                 return self._collect(hist_encoding, logging)
         else:

@@ -104,3 +104,19 @@ def test_trimesh_course_env_and_training(tmp_path):
     runner.learn(2, init_at_random_ep_len=True)
     assert all(torch.isfinite(v).all() for v in runner.alg.actor_critic.state_dict().values())
     assert runner._graph is not None and not runner._graph_failed
+
+
+def test_dagger_iterations_are_recorded_too(tmp_path):
+    """iterations 0, 20, 40 act through the history encoder and run the DAgger regression: eager, recorded, replayed"""
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    torch.manual_seed(0)
+    env, args, tcfg = _make(256, False)
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+    assert runner.dagger_update_freq == 20
+    he0 = {k: v.clone() for k, v in runner.alg.actor_critic.history_encoder.state_dict().items()}
+    runner.learn(41, init_at_random_ep_len=True)
+    assert set(runner._graphs) == {False, True} and not runner._graph_failed
+    assert runner.alg._dagger_graph not in (None, False) and runner.alg._dagger_calls == 3
+    he1 = runner.alg.actor_critic.history_encoder.state_dict()
+    assert all(torch.isfinite(v).all() for v in he1.values()) and any(not torch.equal(he0[k], he1[k]) for k in he0)
+    assert int(env._step_ctr.item()) == env.common_step_counter == 1 + 41 * 24
