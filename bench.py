@@ -108,13 +108,18 @@ def main():
     # same env state, right after the timed region (inside it the 24 steps of a rollout replay as ONE hipGraph launch,
     # which leaves no place for per-kernel events; profiles/ holds the rocprofv3 per-kernel average of the same command)
     act = torch.zeros(args.num_envs, 12, device=dev)
-    ev_pairs = []
-    for _ in range(48):
+    env.sync_reset_ids = False                         # no host sync between launches: the queue stays full
+    reps, per = 5, 40
+    spans = []
+    for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); env.step(act); e1.record()
-        ev_pairs.append((e0, e1))
+        e0.record()
+        for _ in range(per):                           # back-to-back launches; HIP events bracket the batch on the launch stream
+            env.step(act)
+        e1.record()
+        spans.append((e0, e1))
     torch.cuda.synchronize()
-    kern_ms = sorted(a.elapsed_time(b) for a, b in ev_pairs)[len(ev_pairs) // 2]
+    kern_ms = sorted(a.elapsed_time(b) for a, b in spans)[reps // 2] / per
     T = runner.num_steps_per_env
     env_steps = args.num_envs * T * args.steps * world
     value = env_steps / dt
@@ -143,7 +148,7 @@ def main():
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
-                         "note": "latency/occupancy-bound: 4096 envs = 256 wavefronts on 1024 SIMDs, ~0.1 MFLOP of serial rigid-body algebra per env-step"},
+                         "note": "VALU-issue-bound, not byte-bound: 4096 envs = 256 wavefronts = one per CU, ~41k instructions per wavefront at 4.4 cycles each (DESIGN.md 4.1); 16384 envs/GPU reach 4 wavefronts per CU and 3.4x this rate"},
         }
         epochs, nmb = runner.alg.num_learning_epochs, runner.alg.num_mini_batches
         samples = args.num_envs * T
