@@ -159,7 +159,7 @@ class SSInfoGAIL:
         if self.learning_steps >= self.begin_rim:
             self.info_max_coef_on = min(self.info_max_coef * (self.learning_steps - self.begin_rim) / 10000, self.info_max_coef)
         dev = self.device
-        if (self._on_gpu and self.use_update_graph and self.grad_sync is None and self.learning_steps >= 2 and self._ac_graph is not False
+        if (self._on_gpu and self.use_update_graph and self.learning_steps >= 2 and self._ac_graph is not False
                 and self.desired_kl is not None and self.schedule == "adaptive"):
             acc_ac = self._ac_updates_recorded()
         else:
@@ -193,8 +193,11 @@ class SSInfoGAIL:
         """The 20 PPO minibatch steps of an iteration are ~270 launches each and the host cannot issue them faster than
         the GPU retires them (the iteration time followed the host's launch rate, 59-78 ms, not the GPU's 57 ms of kernel
         time).  One step -- minibatch gather from a device index buffer, both forwards, the fused objective, both
-        backward passes, clipping, the KL-adaptive learning rate and the three Adam updates -- is recorded into a
-        hipGraph once and replayed; per step the host only copies the next 24,576 indices into the index buffer."""
+        backward passes, clipping, the KL-adaptive learning rate and the Adam updates -- is recorded into a hipGraph once
+        and replayed; per step the host only copies the next 24,576 indices into the index buffer.
+        Data-parallel runs record the step as TWO graphs around the gradient collective, which stays an ordinary
+        launch: [gather .. backward, gradients + KL packed into a persistent bucket] -> all-reduce(bucket) ->
+        [scale + unpack, clip, LR rule, Adam]."""
         dev, st = self.device, self.storage
         batch = st.num_envs * st.num_transitions_per_env
         mb = batch // self.num_mini_batches
@@ -205,23 +208,44 @@ class SSInfoGAIL:
                 self._priv_coef_dev = torch.zeros((), device=dev)
                 flat = [x.flatten(0, 1) for x in (st.observations, st.actions, st.values, st.advantages, st.returns,
                                                   st.actions_log_prob, st.mu, st.sigma)]
+                sync = self.grad_sync
+                all_params = list(self.estimator.parameters()) + list(self.actor_critic.parameters())
 
-                def one_step():
+                def front():
                     obs, act, val, adv, ret, logp, mu, sig = (x[self._mb_idx] for x in flat)
-                    out = self.update_actor_critic((obs, obs, act, val, adv, ret, logp, mu, sig, (None, None), None))
-                    self._acc_ac.add_(torch.stack(out))
+                    return self._ac_forward_backward((obs, obs, act, val, adv, ret, logp, mu, sig, (None, None), None))
+
                 torch.cuda.synchronize()
                 for o in (self.optim_ac, self.optim_estimator):
                     o.zero_grad(set_to_none=True)
                 from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
-                g = torch.cuda.CUDAGraph()
                 self._recording_ac = True
                 try:
-                    with _no_gc(), torch.cuda.graph(g):
-                        one_step()
+                    if sync is None:
+                        g = torch.cuda.CUDAGraph()
+                        with _no_gc(), torch.cuda.graph(g):
+                            stats, kl = front()
+                            self._ac_apply(kl)
+                            self._acc_ac.add_(torch.stack(stats))
+                        self._ac_graph = (g, None)
+                    else:
+                        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                        pool = torch.cuda.graph_pool_handle()
+                        with _no_gc(), torch.cuda.graph(ga, pool=pool):
+                            stats, kl = front()
+                            grads = [p.grad for p in all_params if p.grad is not None]
+                            packed = grads + [kl.detach().reshape(1)]
+                            self._bucket = torch._utils._flatten_dense_tensors(packed)       # lives in the graphs' pool
+                            self._stats_tmp = torch.stack(stats)
+                        with _no_gc(), torch.cuda.graph(gb, pool=pool):
+                            self._bucket.div_(sync.world)
+                            parts = torch._utils._unflatten_dense_tensors(self._bucket, packed)
+                            torch._foreach_copy_(grads, list(parts[:len(grads)]))
+                            self._ac_apply(parts[-1].reshape(()))
+                            self._acc_ac.add_(self._stats_tmp)
+                        self._ac_graph = (ga, gb)
                 finally:
                     self._recording_ac = False
-                self._ac_graph = g
             except Exception as e:      # never fatal
                 print(f"[ppo update graph] capture failed, staying eager: {e}")
                 self._ac_graph = False
@@ -232,11 +256,15 @@ class SSInfoGAIL:
                 return acc
         self._priv_coef_dev.fill_(float(self._priv_reg_coef_now()))
         self._acc_ac.zero_()
+        ga, gb = self._ac_graph
         perm = torch.randperm(self.num_mini_batches * mb, device=dev)       # one permutation for all epochs (rollout_storage.py:122-157)
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 self._mb_idx.copy_(perm[i * mb:(i + 1) * mb])
-                self._ac_graph.replay()
+                ga.replay()
+                if gb is not None:
+                    self.grad_sync.all_reduce_(self._bucket)
+                    gb.replay()
         return self._acc_ac.clone()
 
     def _disc_updates_recorded(self, n_steps, mb):
@@ -289,7 +317,8 @@ class SSInfoGAIL:
         if self.grad_sync is not None:
             self.grad_sync(params)
 
-    def update_actor_critic(self, sample):
+    def _ac_forward_backward(self, sample):
+        """Everything of one PPO minibatch step up to the gradients: returns (6 loss scalars, minibatch KL or None)."""
         (obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _masks) = sample
         ac = self.actor_critic
         fused = self._on_gpu and self.use_fused_loss
@@ -321,10 +350,6 @@ class SSInfoGAIL:
         estimator_loss = (self.estimator(obs_prop) - obs_explicit).pow(2).mean()
         self.optim_estimator.zero_grad()
         estimator_loss.backward()
-        est_params = list(self.estimator.parameters())
-        if self.grad_sync is None:
-            nn.utils.clip_grad_norm_(est_params, self.max_grad_norm)
-            self.optim_estimator.step()
 
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         kl_mean = None
@@ -336,8 +361,6 @@ class SSInfoGAIL:
                     kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) +
                                    (torch.square(old_sigma) + torch.square(old_mu - mu)) / (2.0 * torch.square(sigma)) - 0.5, dim=-1)
                     kl_mean = kl.mean()
-                if self.grad_sync is None:
-                    self._apply_kl_schedule(kl_mean)
 
         if fused:
             surrogate_loss, value_loss, b_mean, ent_mean = stats[1], stats[2], stats[3], stats[4]
@@ -357,17 +380,28 @@ class SSInfoGAIL:
                     self.bounds_loss_coef * b_mean - self.entropy_coef * ent_mean + priv_reg_coef * priv_reg_loss)
         self.optim_ac.zero_grad()
         loss.backward()
-        params = list(ac.parameters())
-        if self.grad_sync is not None:
-            synced = self.grad_sync(est_params + params, extra=[kl_mean] if adaptive else None)
-            nn.utils.clip_grad_norm_(est_params, self.max_grad_norm)
-            self.optim_estimator.step()
-            if adaptive:
-                self._apply_kl_schedule(synced[0].reshape(()))      # every rank takes the same LR branch
-        nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-        self.optim_ac.step()
         return (surrogate_loss.detach(), value_loss.detach(), b_mean.detach(), ent_mean.detach(),
-                priv_reg_loss.detach(), estimator_loss.detach())
+                priv_reg_loss.detach(), estimator_loss.detach()), kl_mean
+
+    def _ac_apply(self, kl_mean):
+        """Second half of the step: clip + step the estimator, the KL-adaptive learning rate, clip + step the actor-critic."""
+        est_params = list(self.estimator.parameters())
+        nn.utils.clip_grad_norm_(est_params, self.max_grad_norm)
+        self.optim_estimator.step()
+        if kl_mean is not None:
+            self._apply_kl_schedule(kl_mean)
+        nn.utils.clip_grad_norm_(list(self.actor_critic.parameters()), self.max_grad_norm)
+        self.optim_ac.step()
+
+    def update_actor_critic(self, sample):
+        stats, kl_mean = self._ac_forward_backward(sample)
+        if self.grad_sync is not None:      # one bucket: estimator grads | actor-critic grads | KL (every rank takes the same LR branch)
+            params = list(self.estimator.parameters()) + list(self.actor_critic.parameters())
+            synced = self.grad_sync(params, extra=[kl_mean] if kl_mean is not None else None)
+            if kl_mean is not None:
+                kl_mean = synced[0].reshape(())
+        self._ac_apply(kl_mean)
+        return stats
 
     def _apply_kl_schedule(self, kl_mean):
         """lr /= 1.5 if KL > 2 target; lr *= 1.5 if 0 < KL < target/2; clamp [1e-5, 1e-2] (gail.py:367-379)."""

@@ -88,6 +88,10 @@ class GradSync:
             torch._foreach_copy_(grads, list(parts[:len(grads)]))
         return [x.clone() for x in parts[len(grads):]]
 
+    def all_reduce_(self, flat):
+        """sum-all-reduce of a persistent bucket in place (the recorded update scales and unpacks it inside its second graph)"""
+        dist.all_reduce(flat)
+
     def mean_scalar(self, x):
         x = x.clone()
         dist.all_reduce(x)
@@ -131,7 +135,9 @@ class OnPolicyRunner:
         self.disc_history_len, self.disc_obs_len = ecfg.disc_history_len, ecfg.disc_obs_len
         self.obs_disc_weight_step = ecfg.obs_disc_weight_step
         self.amp_enabled = bool(r.get("amp_enabled", True))
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # QA_FORCE_DATA_PARALLEL=1 takes the data-parallel code path with a process group of any size (a 1-rank group on one
+        # GPU exercises the collectives and the two-graph update without a second device)
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("QA_FORCE_DATA_PARALLEL") == "1")
         self.rank = dist.get_rank() if self.distributed else 0
 
         num_prop, num_hist = ecfg.num_prop, ecfg.history_len

@@ -263,3 +263,36 @@ def test_recorded_ppo_update_matches_eager_launches():
         assert torch.allclose(wa[k], wb[k], atol=3e-4, rtol=3e-3), k
     for k in ea:
         assert torch.allclose(ea[k], eb[k], atol=3e-4, rtol=3e-3), k
+
+
+@pytest.mark.gpu
+def test_data_parallel_update_as_two_graphs_around_the_collective(monkeypatch):
+    """a 1-rank RCCL group on one GPU takes the data-parallel path: the PPO step is recorded as two graphs with the
+    bucket all-reduce between them; with one rank the result must equal the single-graph run"""
+    import torch.distributed as dist
+    from tests.test_gpu_train import _make
+    from tests.test_distributed_cpu import _free_port
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    res = []
+    for dp in (False, True):
+        if dp:
+            monkeypatch.setenv("QA_FORCE_DATA_PARALLEL", "1")
+            monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            torch.manual_seed(0)
+            env, args, tcfg = _make(256, False)
+            runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+            assert (runner.alg.grad_sync is not None) == dp
+            runner.learn(3, init_at_random_ep_len=True)
+            ga, gb = runner.alg._ac_graph
+            assert (gb is not None) == dp
+            res.append({k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()})
+            res.append(float(runner.alg.lr_ac))
+        finally:
+            if dp:
+                dist.destroy_process_group()
+    wa, lra, wb, lrb = res
+    assert lra == lrb
+    for k in wa:
+        assert torch.allclose(wa[k], wb[k], atol=3e-4, rtol=3e-3), k
