@@ -55,9 +55,10 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    forced_dp = os.environ.get("QA_FORCE_DATA_PARALLEL") == "1" and "MASTER_ADDR" in os.environ     # dev: DP code path on one GPU
+    if world > 1 or forced_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        dist.init_process_group("nccl", device_id=torch.device(dev), rank=rank, world_size=world)
 
     import __graft_entry__ as g
     if rank == 0:
@@ -161,7 +162,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.num_envs, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or forced_dp:
         dist.destroy_process_group()
 
 
