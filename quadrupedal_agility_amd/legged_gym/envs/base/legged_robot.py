@@ -316,8 +316,12 @@ class LeggedRobot:
         st = self.sim.t["EPISODE_STATS"][(self.common_step_counter - 1) & 1]
         cnt = st[14]
         mean = st[:_capi.NUM_REWARDS] / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
-        self._episode_means = torch.where(cnt > 0, mean, self._episode_means)
-        self.extras["episode"] = {"rew_" + n: self._episode_means[_capi.REWARD_NAMES.index(n)] for n in self.reward_names}
+        # in place: `_episode_means` is a persistent buffer.  A recorded rollout bakes the ADDRESS of whatever tensor it
+        # read first; rebinding the attribute to a fresh tensor every step let the pre-capture one be freed and reused,
+        # and replays then read foreign data whenever no env reset in their first steps.
+        self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
+        snap = self._episode_means.clone()          # per-step values for the runner's per-iteration mean over the 24 steps
+        self.extras["episode"] = {"rew_" + n: snap[_capi.REWARD_NAMES.index(n)] for n in self.reward_names}
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
 

@@ -106,6 +106,25 @@ def test_trimesh_course_env_and_training(tmp_path):
     assert runner._graph is not None and not runner._graph_failed
 
 
+def test_logged_episode_statistics_survive_graph_replays(tmp_path):
+    """state that recorded rollouts read across replays must live in persistent buffers (a rebinding of
+    `_episode_means` once let replays read freed memory: negative 'collision counts' in 2-5 % of the logged iterations)"""
+    import json
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    torch.manual_seed(0)
+    env, args, tcfg = _make(256, False)
+    p0 = env._episode_means.data_ptr()
+    env.reset(); env.step(torch.zeros(256, 12, device="cuda"))
+    assert env._episode_means.data_ptr() == p0
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=str(tmp_path))
+    runner.learn(60, init_at_random_ep_len=True)
+    assert env._episode_means.data_ptr() == p0
+    rows = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
+    for tag in ("Episode/rew_collision", "Episode/rew_torques", "Episode/rew_dof_acc", "Episode/rew_tracking_lin_vel"):
+        v = np.array([r["value"] for r in rows if r["tag"] == tag])
+        assert len(v) == 60 and np.isfinite(v).all() and (v >= 0).all(), tag          # un-scaled sums of non-negative terms
+
+
 def test_dagger_iterations_are_recorded_too(tmp_path):
     """iterations 0, 20, 40 act through the history encoder and run the DAgger regression: eager, recorded, replayed"""
     from quadrupedal_agility_amd.legged_gym.envs import task_registry
