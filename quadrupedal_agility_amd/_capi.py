@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 4
+QA_ABI_VERSION = 5
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
