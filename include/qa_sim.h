@@ -266,6 +266,18 @@ int qa_normalizer_update(const float *const *batches, const int64_t *rows, int32
 int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, const double *mean, const double *var,
                         float epsilon, float clip, void *stream);
 
+/* Gradient clipping + Adam over a set of fp32 tensors in three launches (torch.nn.utils.clip_grad_norm_ followed by
+ * torch.optim.Adam.step with amsgrad=False, maximize=False, L2 weight decay; gail.py:363-365, 403-405):
+ *   coef = max_norm > 0 ? min(1, max_norm / (||g||_2 + 1e-6)) : 1;   g = coef grad + wd p;   t = steps[0][0] + 1
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+ * params / grads / exp_avg / exp_avg_sq / steps are DEVICE arrays of num_tensors device pointers (steps: one float
+ * counter per tensor, all set to t); the work list is num_chunks (tensor, start, length <= 2048) triples in device
+ * memory; weight_decay is per tensor, lr one device float.  scratch >= 4 + num_chunks floats; scratch[3] = ||g||_2. */
+int qa_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                      float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                      const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                      float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

@@ -1114,6 +1114,34 @@ int qo_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, con
     return QA_OK;
 }
 
+/* clip_grad_norm_ + Adam.step on host pointer tables (same signature as qa_clip_adam_step; fp32 state, double norm) */
+int qo_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                      float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                      const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                      float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
+    (void)stream;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !chunk_tensor || !chunk_start || !chunk_len || !weight_decay || !lr ||
+        !scratch || num_tensors <= 0 || num_chunks <= 0 || scratch_floats < 4 + (int64_t)num_chunks) return QA_E_ARG;
+    double ss = 0;
+    for (int c = 0; c < num_chunks; ++c) { const float *g = grads[chunk_tensor[c]] + chunk_start[c]; for (int i = 0; i < chunk_len[c]; ++i) ss += (double)g[i] * g[i]; }
+    float norm = (float)sqrt(ss), coef = max_norm > 0.0f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    float step = steps[0][0] + 1.0f;
+    for (int t = 0; t < num_tensors; ++t) steps[t][0] = step;
+    float bc1 = 1.0f - powf(beta1, step), bc2s = sqrtf(1.0f - powf(beta2, step)), step_size = lr[0] / bc1;
+    for (int c = 0; c < num_chunks; ++c) {
+        int t = chunk_tensor[c], s0 = chunk_start[c];
+        float *p = params[t] + s0, *m = exp_avg[t] + s0, *v = exp_avg_sq[t] + s0; const float *g = grads[t] + s0;
+        for (int i = 0; i < chunk_len[c]; ++i) {
+            float gi = weight_decay[t] * p[i] + g[i] * coef;
+            m[i] = beta1 * m[i] + (1.0f - beta1) * gi;
+            v[i] = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+            p[i] -= step_size * m[i] / (sqrtf(v[i]) / bc2s + eps);
+        }
+    }
+    scratch[0] = coef; scratch[1] = bc1; scratch[2] = bc2s; scratch[3] = norm;
+    return QA_OK;
+}
+
 /* ---- debug entry points used only by the physics known-answer tests ---- */
 /* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
 int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {

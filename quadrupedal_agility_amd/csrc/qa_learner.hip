@@ -302,6 +302,71 @@ __global__ void __launch_bounds__(256) qa_normalizer_apply_kernel(const float *_
     y[i] = fminf(fmaxf((x[i] - m) / sd, -clip), clip);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient clipping + Adam for a set of tensors in three launches (torch: clip_grad_norm_ = ~8 launches, then the
+// multi-tensor Adam kernel, whose 64k-element chunks give a 0.7 M-parameter model 12 workgroups): (1) per-chunk sums of
+// squares, (2) one workgroup: total norm -> clip coefficient, step counter + bias corrections, (3) the update
+//   g = coef * grad + wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// which is torch.optim.Adam (amsgrad=False, maximize=False, L2 weight decay) on gradients clipped to max_norm.
+// Work is a static table of (tensor, start, length) chunks of <= 2048 elements; tensors are addressed through device
+// pointer tables (the gradient table is refreshed by the host whenever autograd allocated new gradient tensors).
+constexpr int ADAM_CHUNK = 2048;
+struct AdamArgs {
+    float *const *params; const float *const *grads; float *const *exp_avg; float *const *exp_avg_sq; float *const *steps;
+    const int32_t *chunk_tensor; const int32_t *chunk_start; const int32_t *chunk_len; const float *weight_decay;
+    const float *lr; float *scratch;      // scratch: [0] coef [1] bc1 [2] sqrt(bc2) [3] total norm, then one partial per chunk
+    int num_chunks, num_tensors;
+    float beta1, beta2, eps, max_norm;
+};
+
+__global__ void __launch_bounds__(256) qa_adam_sumsq_kernel(AdamArgs a) {
+    __shared__ float s_w[4];
+    const int c = blockIdx.x;
+    const float *g = a.grads[a.chunk_tensor[c]] + a.chunk_start[c];
+    const int n = a.chunk_len[c];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const float v = g[i]; acc = fmaf(v, v, acc); }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.scratch[4 + c] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ void __launch_bounds__(256) qa_adam_finalize_kernel(AdamArgs a) {
+    __shared__ double s_acc[256];
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < a.num_chunks; c += 256) acc += (double)a.scratch[4 + c];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; __syncthreads(); }
+    const float step = a.steps[0][0] + 1.0f;
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.num_tensors; t += 256) a.steps[t][0] = step;
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(s_acc[0]);
+        a.scratch[0] = a.max_norm > 0.f ? fminf(1.0f, a.max_norm / (norm + 1e-6f)) : 1.0f;
+        a.scratch[1] = 1.0f - powf(a.beta1, step);
+        a.scratch[2] = sqrtf(1.0f - powf(a.beta2, step));
+        a.scratch[3] = norm;
+    }
+}
+
+__global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
+    const int c = blockIdx.x, t = a.chunk_tensor[c], s0 = a.chunk_start[c], n = a.chunk_len[c];
+    float *p = a.params[t] + s0, *m = a.exp_avg[t] + s0, *v = a.exp_avg_sq[t] + s0;
+    const float *g = a.grads[t] + s0;
+    const float coef = a.scratch[0], bc1 = a.scratch[1], bc2s = a.scratch[2], wd = a.weight_decay[t];
+    const float step_size = a.lr[0] / bc1;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, g[i] * coef);
+        const float mi = a.beta1 * m[i] + (1.0f - a.beta1) * gi;
+        const float vi = a.beta2 * v[i] + (1.0f - a.beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + a.eps);
+    }
+}
+
 }  // namespace
 
 extern thread_local char qa_err_buf[512];
@@ -377,6 +442,24 @@ int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, con
     hipLaunchKernelGGL(qa_normalizer_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, total, (int)dim, mean, var, epsilon, clip);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_apply: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                      float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                      const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                      float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !chunk_tensor || !chunk_start || !chunk_len || !weight_decay || !lr ||
+        !scratch || num_tensors <= 0 || num_chunks <= 0 || scratch_floats < 4 + (int64_t)num_chunks) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: bad argument"); return QA_E_ARG; }
+    AdamArgs a{params, grads, exp_avg, exp_avg_sq, steps, chunk_tensor, chunk_start, chunk_len, weight_decay, lr, scratch, num_chunks, num_tensors,
+               beta1, beta2, eps, max_norm};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(qa_adam_sumsq_kernel, dim3(num_chunks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(qa_adam_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -168,3 +168,89 @@ def normalizer_apply(x, mean, var, epsilon, clip):
     if rc != 0:
         raise RuntimeError(f"qa_normalizer_apply failed with code {rc}: {lib.qa_last_error().decode()}")
     return y
+
+
+class ClipAdam:
+    """clip_grad_norm_(max_norm) + optimizer.step() of ONE torch.optim.Adam as three launches (qa_clip_adam_step).
+
+    The torch optimizer stays the owner of the state (`exp_avg`, `exp_avg_sq`, `step` tensors), so `state_dict()` /
+    `load_state_dict()` and with them model.pt are unchanged; this object only replaces the arithmetic of a step.  It
+    falls back to the PyTorch calls whenever something is not as the kernel needs it (CPU tensors, state not created
+    yet, groups with different learning rates, non-contiguous gradients)."""
+
+    CHUNK = 2048
+
+    def __init__(self, optimizer, max_norm=None):
+        self.opt = optimizer
+        self.max_norm = float(max_norm) if max_norm else 0.0
+        self._tab = None
+
+    def _torch_step(self, params):
+        if self.max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(params, self.max_norm)
+        self.opt.step()
+
+    def _build(self, items):
+        opt = self.opt
+        dev = items[0][0].device
+        g0 = opt.param_groups[0]
+        i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
+        st = [opt.state[p] for p, _ in items]
+        ct, cs, cl = [], [], []
+        for t, (p, _) in enumerate(items):
+            n = p.numel()
+            for s0 in range(0, n, self.CHUNK):
+                ct.append(t); cs.append(s0); cl.append(min(self.CHUNK, n - s0))
+        i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device=dev)
+        tab = dict(items=[p for p, _ in items], n=len(items), params=i64([p.data_ptr() for p, _ in items]),
+                   exp_avg=i64([s["exp_avg"].data_ptr() for s in st]), exp_avg_sq=i64([s["exp_avg_sq"].data_ptr() for s in st]),
+                   steps=i64([s["step"].data_ptr() for s in st]), state_refs=st,
+                   grads=torch.zeros(len(items), dtype=torch.int64, device=dev),
+                   grads_host=torch.zeros(len(items), dtype=torch.int64).pin_memory(), grad_ptrs=None,
+                   chunk_tensor=i32(ct), chunk_start=i32(cs), chunk_len=i32(cl), num_chunks=len(ct),
+                   wd=torch.tensor([g["weight_decay"] for _, g in items], dtype=torch.float32, device=dev),
+                   scratch=torch.zeros(4 + len(ct), dtype=torch.float32, device=dev),
+                   betas=g0["betas"], eps=g0["eps"], lr_dev=None, lr_val=None)
+        self._tab = tab
+
+    def step(self):
+        opt = self.opt
+        items = [(p, g) for g in opt.param_groups for p in g["params"] if p.grad is not None]
+        params = [p for p, _ in items]
+        if not items:
+            return
+        g0 = opt.param_groups[0]
+        ok = (ENABLED and params[0].is_cuda and not g0.get("amsgrad", False) and not g0.get("maximize", False)
+              and all(("exp_avg" in opt.state.get(p, {})) and torch.is_tensor(opt.state[p]["step"]) and opt.state[p]["step"].is_cuda for p in params)
+              and all(g["lr"] is g0["lr"] or (not torch.is_tensor(g["lr"]) and not torch.is_tensor(g0["lr"]) and g["lr"] == g0["lr"]) for _, g in items)
+              and all(g["betas"] == g0["betas"] and g["eps"] == g0["eps"] for _, g in items)
+              and all(p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32 for p in params))
+        if not ok:
+            return self._torch_step(params)
+        if self._tab is None or len(self._tab["items"]) != len(params) or any(a is not b for a, b in zip(self._tab["items"], params)):
+            self._build(items)
+        t = self._tab
+        ptrs = [p.grad.data_ptr() for p in params]
+        if ptrs != t["grad_ptrs"]:                      # autograd allocated new gradient tensors: refresh the pointer table
+            t["grads_host"].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            t["grads"].copy_(t["grads_host"], non_blocking=True)
+            t["grad_ptrs"] = ptrs
+        lr = g0["lr"]
+        if torch.is_tensor(lr):
+            lr_dev = lr if lr.dtype == torch.float32 else None
+            if lr_dev is None:
+                return self._torch_step(params)
+        else:
+            if t["lr_dev"] is None:
+                t["lr_dev"] = torch.zeros((), dtype=torch.float32, device=params[0].device)
+            if t["lr_val"] != float(lr):
+                t["lr_dev"].fill_(float(lr)); t["lr_val"] = float(lr)
+            lr_dev = t["lr_dev"]
+        lib = _capi.load_library()
+        stream = C.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
+        rc = lib.qa_clip_adam_step(_ptr(t["params"]), _ptr(t["grads"]), _ptr(t["exp_avg"]), _ptr(t["exp_avg_sq"]), _ptr(t["steps"]), t["n"],
+                                   _ptr(t["chunk_tensor"]), _ptr(t["chunk_start"]), _ptr(t["chunk_len"]), t["num_chunks"], _ptr(t["wd"]),
+                                   _ptr(lr_dev), float(t["betas"][0]), float(t["betas"][1]), float(t["eps"]), self.max_norm,
+                                   _ptr(t["scratch"]), t["scratch"].numel(), stream)
+        if rc != 0:
+            raise RuntimeError(f"qa_clip_adam_step failed with code {rc}: {lib.qa_last_error().decode()}")

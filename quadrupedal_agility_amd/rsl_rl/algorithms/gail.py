@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
-from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ppo_loss
+from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, ppo_loss
 from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
 
 
@@ -73,6 +73,10 @@ class SSInfoGAIL:
         self.optim_q_eps = optim.Adam(groups(self.disc.encoder_eps, "encoder_eps"), lr=lr_q, **adam)
         self.optim_q_c = optim.Adam(groups(self.disc.classifier, "classifier"), lr=lr_q, **adam)
 
+        self._step_ac = ClipAdam(self.optim_ac, max_grad_norm)
+        self._step_estimator = ClipAdam(self.optim_estimator, max_grad_norm)
+        self._step_hist_encoder = ClipAdam(self.optim_hist_encoder, max_grad_norm)
+        self._step_disc = [ClipAdam(o, None) if isinstance(o, optim.Adam) else o for o in (self.optim_d, self.optim_q_eps, self.optim_q_c)]
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.surrogate_loss_coef, self.value_loss_coef, self.entropy_coef = surrogate_loss_coef, value_loss_coef, entropy_coef
         self.bounds_loss_coef, self.disc_coef, self.disc_logit_reg = bounds_loss_coef, disc_coef, disc_logit_reg
@@ -385,13 +389,10 @@ class SSInfoGAIL:
 
     def _ac_apply(self, kl_mean):
         """Second half of the step: clip + step the estimator, the KL-adaptive learning rate, clip + step the actor-critic."""
-        est_params = list(self.estimator.parameters())
-        nn.utils.clip_grad_norm_(est_params, self.max_grad_norm)
-        self.optim_estimator.step()
+        self._step_estimator.step()                  # clip_grad_norm_(max_grad_norm) + Adam, three launches on the GPU
         if kl_mean is not None:
             self._apply_kl_schedule(kl_mean)
-        nn.utils.clip_grad_norm_(list(self.actor_critic.parameters()), self.max_grad_norm)
-        self.optim_ac.step()
+        self._step_ac.step()
 
     def update_actor_critic(self, sample):
         stats, kl_mean = self._ac_forward_backward(sample)
@@ -479,7 +480,7 @@ class SSInfoGAIL:
         if self.grad_sync is not None:
             pred_mean = self.grad_sync(list(self.disc.parameters()), extra=[pred_mean])[0]
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
-        for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
+        for o in self._step_disc:
             o.step()
         if not self.actor_critic.fixed_std and self.min_std is not None:
             self.actor_critic.std.data.clamp_(min=self.min_std)       # in place: recorded rollouts keep reading this buffer
@@ -503,8 +504,7 @@ class SSInfoGAIL:
         loss.backward()
         params = list(ac.history_encoder.parameters())
         self._sync_grads(params)
-        nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-        self.optim_hist_encoder.step()
+        self._step_hist_encoder.step()
         return loss.detach()
 
     def update_dagger(self):
