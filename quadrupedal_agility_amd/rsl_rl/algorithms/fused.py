@@ -204,7 +204,7 @@ class ClipAdam:
         i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device=dev)
         tab = dict(items=[p for p, _ in items], n=len(items), params=i64([p.data_ptr() for p, _ in items]),
                    exp_avg=i64([s["exp_avg"].data_ptr() for s in st]), exp_avg_sq=i64([s["exp_avg_sq"].data_ptr() for s in st]),
-                   steps=i64([s["step"].data_ptr() for s in st]), state_refs=st,
+                   steps=i64([s["step"].data_ptr() for s in st]), state_refs=st, exp_avg_ptrs=[s["exp_avg"].data_ptr() for s in st],
                    grads=torch.zeros(len(items), dtype=torch.int64, device=dev),
                    grads_host=torch.zeros(len(items), dtype=torch.int64).pin_memory(), grad_ptrs=None,
                    chunk_tensor=i32(ct), chunk_start=i32(cs), chunk_len=i32(cl), num_chunks=len(ct),
@@ -227,8 +227,10 @@ class ClipAdam:
               and all(p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32 for p in params))
         if not ok:
             return self._torch_step(params)
-        if self._tab is None or len(self._tab["items"]) != len(params) or any(a is not b for a, b in zip(self._tab["items"], params)):
-            self._build(items)
+        tab = self._tab
+        if (tab is None or len(tab["items"]) != len(params) or any(a is not b for a, b in zip(tab["items"], params))
+                or any(opt.state[p] is not s or s["exp_avg"].data_ptr() != e for p, s, e in zip(params, tab["state_refs"], tab["exp_avg_ptrs"]))):
+            self._build(items)          # first use, or load_state_dict() replaced the state tensors
         t = self._tab
         ptrs = [p.grad.data_ptr() for p in params]
         if ptrs != t["grad_ptrs"]:                      # autograd allocated new gradient tensors: refresh the pointer table

@@ -90,6 +90,9 @@ class SSInfoGAIL:
         self.use_fused_loss = True     # GPU: PPO objective + gradient as one HIP kernel (qa_ppo_loss); False = eager PyTorch ops
         self._ac_graph, self._recording_ac, self._priv_coef_dev = None, False, None
         self._dagger_graph, self._dagger_calls = None, 0
+        # recordings wait for one eager update since construction / checkpoint load: optimizer state and the pointer
+        # tables of the fused optimizer steps must exist before a capture (building them copies from pageable host memory)
+        self._warm_updates, self._dagger_warm = 0, 0
         self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
@@ -163,7 +166,7 @@ class SSInfoGAIL:
         if self.learning_steps >= self.begin_rim:
             self.info_max_coef_on = min(self.info_max_coef * (self.learning_steps - self.begin_rim) / 10000, self.info_max_coef)
         dev = self.device
-        if (self._on_gpu and self.use_update_graph and self.learning_steps >= 2 and self._ac_graph is not False
+        if (self._on_gpu and self.use_update_graph and self._warm_updates >= 1 and self._ac_graph is not False
                 and self.desired_kl is not None and self.schedule == "adaptive"):
             acc_ac = self._ac_updates_recorded()
         else:
@@ -175,7 +178,7 @@ class SSInfoGAIL:
         acc_d = torch.zeros(11, device=dev)
         if self.amp_enabled:
             mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
-            if self._on_gpu and self.use_update_graph and self.grad_sync is None and self.learning_steps >= 2 and self._disc_graph is not False:
+            if self._on_gpu and self.use_update_graph and self.grad_sync is None and self._warm_updates >= 1 and self._disc_graph is not False:
                 acc_d = self._disc_updates_recorded(n_d, mb)
             else:
                 gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
@@ -185,6 +188,7 @@ class SSInfoGAIL:
                     acc_d += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
         self.storage.clear()
         self.priv_reg_counter += 1
+        self._warm_updates += 1
         out = torch.cat([acc_ac / n_ac, acc_d / n_d]).tolist()      # the one host read of the update
         return tuple(out)
 
@@ -511,7 +515,7 @@ class SSInfoGAIL:
         """History-encoder regression onto the privileged latent, every dagger_update_freq iterations (gail.py:543-575)."""
         n = self.num_learning_epochs * self.num_mini_batches
         st = self.storage
-        if (self._on_gpu and self.use_update_graph and self.grad_sync is None and self._dagger_calls >= 1 and self._dagger_graph is not False):
+        if (self._on_gpu and self.use_update_graph and self.grad_sync is None and self._dagger_warm >= 1 and self._dagger_graph is not False):
             # same recording scheme as the PPO step: gather from the device index buffer + one optimiser step per replay
             mb = st.num_envs * st.num_transitions_per_env // self.num_mini_batches
             if self._dagger_graph is None:
@@ -541,6 +545,7 @@ class SSInfoGAIL:
                         self._dg_idx.copy_(perm[i * mb:(i + 1) * mb])
                         self._dagger_graph.replay()
                 self._dagger_calls += 1
+                self._dagger_warm += 1
                 st.clear()
                 self.priv_reg_counter += 1
                 return float(self._dg_acc) / n
@@ -548,6 +553,7 @@ class SSInfoGAIL:
         for sample in st.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             total += self._dagger_step(sample[0])
         self._dagger_calls += 1
+        self._dagger_warm += 1
         st.clear()
         self.priv_reg_counter += 1
         return float(total) / n

@@ -434,6 +434,10 @@ class OnPolicyRunner:
                 except Exception as e:      # e.g. a reference checkpoint whose Adam step counters live on the host
                     print(f"[load] optimizer state {key} not restored: {e}")
         self.current_learning_iteration = d["iter"]
+        # recorded launches hold the addresses of the optimizer state they were captured with: start over
+        a._ac_graph = a._dagger_graph = a._disc_graph = None
+        a._warm_updates = a._dagger_warm = 0
+        self._graphs, self._graph = {}, None
         return d["infos"]
 
     def get_inference_policy(self, device=None):

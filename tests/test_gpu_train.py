@@ -76,6 +76,13 @@ def test_short_training_run_on_gpu(tmp_path, amp):
     ck = torch.load(path, weights_only=False)
     assert type(ck["disc_normalizer"]).__name__ == "Normalizer"
     runner.load(path)
+    # training goes on after a load: recorded launches and the optimizer pointer tables are rebuilt around the new state
+    assert runner.alg._ac_graph is None and runner._graphs == {}
+    runner.learn(3, init_at_random_ep_len=False)          # one eager update, then recorded again
+    assert runner.alg._ac_graph not in (None, False)
+    assert all(torch.isfinite(v).all() for v in runner.alg.actor_critic.state_dict().values())
+    st = runner.alg.optim_ac.state_dict()["state"]
+    assert float(st[0]["step"]) == 20 * 6        # 3 iterations before the checkpoint + 3 after, 20 Adam steps each
 
 
 def test_trimesh_course_env_and_training(tmp_path):
