@@ -278,6 +278,21 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
                       const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
                       float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream);
 
+/* Rollout bookkeeping around qa_env_step (SSInfoGAIL.act / process_env_step, bbc/rsl_rl/algorithms/gail.py:176-212;
+ * RolloutStorage.add_transitions, rollout_storage.py:60-74; the runner's episode sums, on_policy_runner.py:187-206).
+ * qa_rollout_act: a = mean + std * eps, log-prob of a under N(mean, std); writes `actions` (N,12) for the env and the
+ *   step's storage rows st_actions / st_mu / st_sigma (N,12), st_logp / st_values (N).  `noise` (N,12) supplies eps;
+ *   NULL draws it from the engine's Philox generator, stream 20, keyed by (seed; env, step) with step = *step_dev when
+ *   step_dev != NULL (recorded launches) else `step`.
+ * qa_rollout_post: st_rewards = reward_coef * rew + gamma * values * time_out; st_dones = reset > 0; if `cur` != NULL,
+ *   the six running sums cur (6,N) [total, i, us, ss, t, length] advance by [reward_coef*rew, 0, 0, 0, rew, 1], are
+ *   copied to fin_vals (6,N), and are cleared where done; fin_mask (N) = done. */
+int qa_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
+                   int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                   float *st_values, void *stream);
+int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
+                    int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

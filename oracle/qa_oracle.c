@@ -1142,6 +1142,53 @@ int qo_clip_adam_step(float *const *params, const float *const *grads, float *co
     return QA_OK;
 }
 
+/* rollout bookkeeping twins (host pointers) */
+int qo_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
+                   int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                   float *st_values, void *stream) {
+    (void)stream;
+    if (!mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp || !st_values || num_envs <= 0) return QA_E_ARG;
+    if (step_dev) step = *step_dev;
+    for (int e = 0; e < num_envs; ++e) {
+        float eps[12];
+        if (noise) for (int j = 0; j < 12; ++j) eps[j] = noise[(int64_t)e * 12 + j];
+        else for (int b = 0; b < 3; ++b) {
+            uint32_t o[4]; float u[4];
+            philox(seed, (uint32_t)e, (uint32_t)step, (uint32_t)(20 * 256 + b), (uint32_t)((uint64_t)step >> 32), o);
+            for (int i = 0; i < 4; ++i) u[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
+            float r0 = sqrtf(-2.0f * logf(fmaxf(u[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(u[2], 1e-7f)));
+            eps[4 * b] = r0 * cosf(6.28318530717958647692f * u[1]); eps[4 * b + 1] = r0 * sinf(6.28318530717958647692f * u[1]);
+            eps[4 * b + 2] = r1 * cosf(6.28318530717958647692f * u[3]); eps[4 * b + 3] = r1 * sinf(6.28318530717958647692f * u[3]);
+        }
+        float logp = 0.0f;
+        for (int j = 0; j < 12; ++j) {
+            int64_t i = (int64_t)e * 12 + j;
+            float m = mean[i], s = std[j], a = m + s * eps[j], d = a - m;
+            logp += -(d * d) / (2.0f * s * s) - logf(s) - 0.91893853320467274178f;
+            actions[i] = a; st_actions[i] = a; st_mu[i] = m; st_sigma[i] = s;
+        }
+        st_logp[e] = logp; st_values[e] = value[e];
+    }
+    return QA_OK;
+}
+int qo_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
+                    int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream) {
+    (void)stream;
+    if (!rew || !reset || !time_out || !values || !st_rewards || !st_dones || num_envs <= 0 || (cur && (!fin_vals || !fin_mask))) return QA_E_ARG;
+    int N = num_envs;
+    for (int e = 0; e < N; ++e) {
+        float r_t = rew[e], r = reward_coef * r_t; int done = reset[e] > 0;
+        st_rewards[e] = r + gamma * values[e] * (time_out[e] ? 1.0f : 0.0f);
+        st_dones[e] = (uint8_t)done;
+        if (cur) {
+            const float add[6] = {r, 0, 0, 0, r_t, 1.0f};
+            for (int k = 0; k < 6; ++k) { float c = cur[(int64_t)k * N + e] + add[k]; fin_vals[(int64_t)k * N + e] = c; cur[(int64_t)k * N + e] = done ? 0.0f : c; }
+            fin_mask[e] = (uint8_t)done;
+        }
+    }
+    return QA_OK;
+}
+
 /* ---- debug entry points used only by the physics known-answer tests ---- */
 /* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
 int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {

@@ -15,6 +15,7 @@
 #include <stdio.h>
 
 #include "../../include/qa_sim.h"
+#include "qa_device.h"
 
 namespace {
 
@@ -367,6 +368,72 @@ __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Rollout bookkeeping around the env step (rows a10, a12: gail.py:176-212, rollout_storage.py:60-74).
+// qa_rollout_act: after the actor / critic GEMMs -- sample a = mu + std * eps, log-prob, and write the step's rows of
+// the rollout storage (actions, mu, sigma, log-prob, value) plus the action buffer the env reads: one launch for what
+// is ~18 in eager PyTorch (expand std, randn, mul, add, the log_prob chain, five copies).  eps is either supplied
+// (tests) or drawn from the engine's Philox stream RS_ACT_NOISE keyed by (seed; env, step).
+// qa_rollout_post: after the env step -- reward scaling + time-out bootstrap (r += gamma V time_out), done flags, and
+// the runner's per-episode logging sums, another ~12 launches.
+constexpr int RS_ACT_NOISE = 20;
+
+__global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ value,
+                                                             const float *__restrict__ noise, uint64_t seed, const int64_t *step_ptr, int64_t step_host, int N,
+                                                             float *__restrict__ actions, float *__restrict__ st_actions, float *__restrict__ st_mu,
+                                                             float *__restrict__ st_sigma, float *__restrict__ st_logp, float *__restrict__ st_values) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    const int64_t step = step_ptr ? *step_ptr : step_host;
+    const float HALF_LOG_2PI = 0.91893853320467274178f;
+    float eps[12];
+    if (noise) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) eps[j] = noise[(int64_t)e * 12 + j];
+    } else {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {          // Box-Muller on the 4 uniforms of a Philox block: 4 normals
+            F4 u = rng4(seed, (uint32_t)e, step, RS_ACT_NOISE, b);
+            const float r0 = sqrtf(-2.0f * logf(fmaxf(u.v[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(u.v[2], 1e-7f)));
+            float s0, c0, s1, c1;
+            sincosf(6.28318530717958647692f * u.v[1], &s0, &c0);
+            sincosf(6.28318530717958647692f * u.v[3], &s1, &c1);
+            eps[4 * b] = r0 * c0; eps[4 * b + 1] = r0 * s0; eps[4 * b + 2] = r1 * c1; eps[4 * b + 3] = r1 * s1;
+        }
+    }
+    float logp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const float m = mean[(int64_t)e * 12 + j], s = std[j], a = m + s * eps[j], d = a - m;
+        logp += -(d * d) / (2.0f * s * s) - logf(s) - HALF_LOG_2PI;
+        const int64_t i = (int64_t)e * 12 + j;
+        actions[i] = a; st_actions[i] = a; st_mu[i] = m; st_sigma[i] = s;
+    }
+    st_logp[e] = logp;
+    st_values[e] = value[e];
+}
+
+__global__ void __launch_bounds__(256) qa_rollout_post_kernel(const float *__restrict__ rew, const int64_t *__restrict__ reset, const uint8_t *__restrict__ time_out,
+                                                              const float *__restrict__ values, float reward_coef, float gamma, int N, float *__restrict__ st_rewards,
+                                                              uint8_t *__restrict__ st_dones, float *__restrict__ cur, float *__restrict__ fin_vals, uint8_t *__restrict__ fin_mask) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    const float r_t = rew[e], r = reward_coef * r_t;
+    const bool done = reset[e] > 0;
+    st_rewards[e] = r + gamma * values[e] * (time_out[e] ? 1.0f : 0.0f);        // bootstrap on time-outs (gail.py:203-205)
+    st_dones[e] = done ? 1 : 0;
+    if (cur) {      // running episode sums [total, i, us, ss, t, length] (on_policy_runner.py:187-206), logged before the reset clears them
+        const float add[6] = {r, 0.f, 0.f, 0.f, r_t, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float c = cur[(int64_t)k * N + e] + add[k];
+            fin_vals[(int64_t)k * N + e] = c;
+            cur[(int64_t)k * N + e] = done ? 0.f : c;
+        }
+        fin_mask[e] = done ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern thread_local char qa_err_buf[512];
@@ -460,6 +527,29 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
     hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
+                   int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                   float *st_values, void *stream) {
+    if (!mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp || !st_values || num_envs <= 0) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_rollout_act_kernel, dim3((num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, std, value, noise, seed, step_dev, step,
+                       (int)num_envs, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
+                    int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream) {
+    if (!rew || !reset || !time_out || !values || !st_rewards || !st_dones || num_envs <= 0 || (cur && (!fin_vals || !fin_mask))) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_post: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_rollout_post_kernel, dim3((num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, reset, time_out, values, reward_coef,
+                       gamma, (int)num_envs, st_rewards, st_dones, cur, fin_vals, fin_mask);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_post: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -140,6 +140,15 @@ class SSInfoGAIL:
         tr.critic_observations = critic_obs
         return tr.actions
 
+    def act_mean_value(self, obs, critic_obs, hist_encoding=False):
+        """The GEMM half of act(): action mean and value; sampling, log-prob and the storage writes are qa_rollout_act."""
+        if self.train_with_estimated_explicit:
+            a, b = self.num_prop, self.num_prop + self.num_explicit
+            obs_in = torch.cat([obs[:, :a], self.estimator(obs[:, :a]), obs[:, b:]], dim=-1)
+        else:
+            obs_in = obs
+        return self.actor_critic._actor_mean(obs_in, hist_encoding), self.actor_critic.evaluate(critic_obs)
+
     def process_env_step(self, rewards, dones, infos, obs_disc_history_buf, disc_stage=None):
         tr = self.transition
         tr.rewards = rewards.clone()

@@ -221,12 +221,17 @@ class OnPolicyRunner:
             self._disc_stage = (torch.zeros(T, N, env.num_obs_disc * self.disc_obs_len, device=dev), torch.zeros(T, N, 1, device=dev),
                                 torch.zeros(T, N, env.dim_c, device=dev))
         self._graph, self._graphs = None, {}          # hist_encoding -> (graph, action delay it was recorded with, ep_infos)
+        self._act_buf = None
         self._graph_failed = False
+
+    use_fused_rollout = True     # GPU, discriminator off: per-step bookkeeping as qa_rollout_act / qa_rollout_post
 
     def _rollout_steps(self, hist_encoding, logging, recorded):
         """The 24 env steps of one iteration (on_policy_runner.py:155-206).  Reads/writes only persistent tensors, so the
         same code runs eagerly or is recorded once into a hipGraph and replayed."""
         env, alg, T = self.env, self.alg, self.num_steps_per_env
+        if self.use_fused_rollout and not self.amp_enabled and self._obs_cur.is_cuda:
+            return self._rollout_steps_fused(hist_encoding, logging)
         obs, hist, cur = self._obs_cur, self._disc_hist, self._cur
         ep_infos = []
         for i in range(T):
@@ -256,6 +261,47 @@ class OnPolicyRunner:
         self._obs_cur.copy_(obs)
         self._disc_hist.copy_(hist)
         self._cur.copy_(cur)
+        return ep_infos
+
+    def _rollout_steps_fused(self, hist_encoding, logging):
+        """GPU, discriminator off: the same 24 steps with the per-step bookkeeping in two kernels.  Per step:
+        GEMMs (estimator, encoder, actor, critic) -> qa_rollout_act (sample, log-prob, storage rows) -> observation row
+        copy -> qa_env_step -> qa_rollout_post (reward scaling, time-out bootstrap, dones, episode sums)."""
+        import ctypes as C
+        from quadrupedal_agility_amd import _capi
+        env, alg, T, st = self.env, self.alg, self.num_steps_per_env, self.alg.storage
+        lib = _capi.load_library()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        N = env.num_envs
+        if self._act_buf is None:
+            self._act_buf = torch.zeros(N, env.num_actions, device=self._obs_cur.device)
+        obs = self._obs_cur
+        std = alg.actor_critic.std
+        seed = int(env.sim.cfg.seed)
+        ep_infos = []
+        for i in range(T):
+            t = st.step
+            if t >= T:
+                raise AssertionError("Rollout buffer overflow")
+            mean, value = alg.act_mean_value(obs, obs, hist_encoding)
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            ctr = env._step_ctr
+            rc = lib.qa_rollout_act(P(mean), P(std), P(value), None, seed, P(ctr) if ctr is not None else None, int(env.common_step_counter), N,
+                                    P(self._act_buf), P(st.actions[t]), P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob[t]), P(st.values[t]), stream)
+            if rc != 0:
+                raise RuntimeError(f"qa_rollout_act failed with code {rc}: {lib.qa_last_error().decode()}")
+            st.observations[t].copy_(obs)
+            next_obs, _, _rew, _dones, infos, _, _ = env.step(self._act_buf)
+            rc = lib.qa_rollout_post(P(env.rew_buf), P(env.reset_buf), P(env.time_out_buf), P(st.values[t]), float(self.reward_t_coef), float(alg.gamma), N,
+                                     P(st.rewards[t]), P(st.dones[t]), P(self._cur) if logging else None,
+                                     P(self._fin_vals[i]) if logging else None, P(self._fin_mask[i]) if logging else None, stream)
+            if rc != 0:
+                raise RuntimeError(f"qa_rollout_post failed with code {rc}: {lib.qa_last_error().decode()}")
+            st.step += 1
+            obs = next_obs.clone()
+            if logging and "episode" in infos:
+                ep_infos.append(dict(infos["episode"]))
+        self._obs_cur.copy_(obs)
         return ep_infos
 
     def _collect(self, hist_encoding, logging):

@@ -380,3 +380,105 @@ def test_clip_adam_hip_matches_pytorch(wd, lr_tensor, max_norm):
         # with weight decay the moments inherit the (ill-conditioned, see _close_params) parameter differences x wd
         assert torch.allclose(sa[i]["exp_avg"], sb[i]["exp_avg"], rtol=2e-5, atol=1e-6 if wd else 1e-8)
         assert torch.allclose(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
+
+
+# ------------------------------------------------------------------ rollout bookkeeping kernels
+def _rollout_case(N, seed):
+    g = torch.Generator().manual_seed(seed)
+    return dict(mean=torch.randn(N, 12, generator=g), std=0.3 + torch.rand(12, generator=g), value=torch.randn(N, 1, generator=g),
+                noise=torch.randn(N, 12, generator=g), rew=torch.rand(N, generator=g), reset=(torch.rand(N, generator=g) < 0.2).long(),
+                time_out=(torch.rand(N, generator=g) < 0.1).to(torch.uint8), cur=torch.rand(6, N, generator=g))
+
+
+def _bind_rollout(lib, prefix):
+    getattr(lib, prefix + "rollout_act").argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7
+    getattr(lib, prefix + "rollout_post").argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int32] + [C.c_void_p] * 6
+
+
+def test_rollout_kernels_oracle_matches_pytorch_expressions():
+    from torch.distributions import Normal
+    N = 777
+    c = _rollout_case(N, 1)
+    lib = load_oracle(); _bind_rollout(lib, "qo_")
+    n = {k: np.ascontiguousarray(v.numpy()) for k, v in c.items()}
+    out = {k: np.zeros((N, 12), np.float32) for k in ("actions", "sa", "smu", "ssig")}
+    logp = np.zeros(N, np.float32); sval = np.zeros(N, np.float32)
+    p = lambda x: x.ctypes.data
+    assert lib.qo_rollout_act(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]), 1, None, 5, N, p(out["actions"]), p(out["sa"]), p(out["smu"]),
+                              p(out["ssig"]), p(logp), p(sval), None) == 0
+    act = c["mean"] + c["std"] * c["noise"]
+    want = Normal(c["mean"], c["mean"] * 0 + c["std"]).log_prob(act).sum(-1)
+    assert np.allclose(out["actions"], act.numpy(), atol=1e-6) and np.array_equal(out["actions"], out["sa"])
+    assert np.allclose(logp, want.numpy(), rtol=1e-5, atol=1e-5) and np.array_equal(out["smu"], n["mean"]) and np.allclose(out["ssig"], n["std"][None])
+    assert np.array_equal(sval, n["value"][:, 0])
+    # Philox path: N(0,1) noise, reproducible, different per step
+    a1 = np.zeros((N, 12), np.float32); a2 = np.zeros((N, 12), np.float32); a3 = np.zeros((N, 12), np.float32)
+    zero = np.zeros((N, 12), np.float32); one = np.ones(12, np.float32)
+    for buf, step in ((a1, 7), (a2, 7), (a3, 8)):
+        lib.qo_rollout_act(p(zero), p(one), p(n["value"]), None, 42, None, step, N, p(buf), p(out["sa"]), p(out["smu"]), p(out["ssig"]), p(logp), p(sval), None)
+    assert np.array_equal(a1, a2) and not np.array_equal(a1, a3)
+    assert abs(a1.mean()) < 0.03 and abs(a1.std() - 1.0) < 0.03
+    # post
+    st_r = np.zeros(N, np.float32); st_d = np.zeros(N, np.uint8); cur = n["cur"].copy(); fin = np.zeros((6, N), np.float32); mask = np.zeros(N, np.uint8)
+    assert lib.qo_rollout_post(p(n["rew"]), p(n["reset"]), p(n["time_out"]), p(n["value"]), 0.2, 0.99, N, p(st_r), p(st_d), p(cur), p(fin), p(mask), None) == 0
+    r = 0.2 * c["rew"]
+    assert np.allclose(st_r, (r + 0.99 * c["value"][:, 0] * c["time_out"].float()).numpy(), atol=1e-6)
+    assert np.array_equal(st_d, (c["reset"] > 0).numpy().astype(np.uint8)) and np.array_equal(mask, st_d)
+    want_cur = c["cur"] + torch.stack([r, torch.zeros(N), torch.zeros(N), torch.zeros(N), c["rew"], torch.ones(N)])
+    assert np.allclose(fin, want_cur.numpy(), atol=1e-6) and np.allclose(cur, (want_cur * (c["reset"] == 0)).numpy(), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_rollout_kernels_hip_match_oracle():
+    from quadrupedal_agility_amd import _capi
+    N = 4099
+    c = _rollout_case(N, 2)
+    lo = load_oracle(); _bind_rollout(lo, "qo_")
+    lib = _capi.load_library()
+    n = {k: np.ascontiguousarray(v.numpy()) for k, v in c.items()}
+    d = {k: v.cuda() for k, v in c.items()}
+    p = lambda x: x.ctypes.data
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    step_dev = torch.tensor([123], dtype=torch.int64, device="cuda")
+    for noise in (True, False):
+        o = {k: np.zeros((N, 12), np.float32) for k in ("a", "sa", "smu", "ssig")}; ol = np.zeros(N, np.float32); ov = np.zeros(N, np.float32)
+        g = {k: torch.zeros(N, 12, device="cuda") for k in ("a", "sa", "smu", "ssig")}; gl = torch.zeros(N, device="cuda"); gv = torch.zeros(N, device="cuda")
+        assert lo.qo_rollout_act(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]) if noise else None, 9, None, 123, N,
+                                 p(o["a"]), p(o["sa"]), p(o["smu"]), p(o["ssig"]), p(ol), p(ov), None) == 0
+        assert lib.qa_rollout_act(P(d["mean"]), P(d["std"]), P(d["value"]), P(d["noise"]) if noise else None, 9, P(step_dev), 0, N,
+                                  P(g["a"]), P(g["sa"]), P(g["smu"]), P(g["ssig"]), P(gl), P(gv), st) == 0
+        torch.cuda.synchronize()
+        tol = dict(atol=1e-6) if noise else dict(atol=2e-5, rtol=1e-5)          # Philox path: libm vs device log/sincos
+        assert np.allclose(g["a"].cpu().numpy(), o["a"], **tol) and np.allclose(gl.cpu().numpy(), ol, rtol=1e-4, atol=1e-4)
+        assert torch.equal(g["a"], g["sa"]) and np.array_equal(g["smu"].cpu().numpy(), n["mean"]) and np.array_equal(gv.cpu().numpy(), n["value"][:, 0])
+    o_r = np.zeros(N, np.float32); o_d = np.zeros(N, np.uint8); o_cur = n["cur"].copy(); o_fin = np.zeros((6, N), np.float32); o_m = np.zeros(N, np.uint8)
+    lo.qo_rollout_post(p(n["rew"]), p(n["reset"]), p(n["time_out"]), p(n["value"]), 0.2, 0.99, N, p(o_r), p(o_d), p(o_cur), p(o_fin), p(o_m), None)
+    g_r = torch.zeros(N, device="cuda"); g_d = torch.zeros(N, dtype=torch.uint8, device="cuda"); g_cur = d["cur"].clone()
+    g_fin = torch.zeros(6, N, device="cuda"); g_m = torch.zeros(N, dtype=torch.bool, device="cuda")
+    assert lib.qa_rollout_post(P(d["rew"]), P(d["reset"]), P(d["time_out"]), P(d["value"]), 0.2, 0.99, N, P(g_r), P(g_d), P(g_cur), P(g_fin), P(g_m), st) == 0
+    torch.cuda.synchronize()
+    assert np.allclose(g_r.cpu().numpy(), o_r, atol=1e-6) and np.array_equal(g_d.cpu().numpy(), o_d) and np.array_equal(g_m.cpu().numpy().astype(np.uint8), o_m)
+    assert np.allclose(g_cur.cpu().numpy(), o_cur, atol=1e-6) and np.allclose(g_fin.cpu().numpy(), o_fin, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fused_rollout_fills_the_storage_consistently():
+    from torch.distributions import Normal
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    torch.manual_seed(0)
+    env, args, tcfg = _make(512, False)
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+    runner.learn(1, init_at_random_ep_len=True)
+    runner._collect(False, True)                           # one more (recorded) rollout; storage is left full
+    st = runner.alg.storage
+    assert st.step == 24
+    logp = Normal(st.mu, st.sigma).log_prob(st.actions).sum(-1, keepdim=True)
+    assert torch.allclose(logp, st.actions_log_prob, rtol=1e-4, atol=1e-4)
+    z = (st.actions - st.mu) / st.sigma
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02 and torch.equal(st.sigma[0, 0], runner.alg.actor_critic.std.detach())
+    assert torch.isfinite(st.values).all() and torch.isfinite(st.rewards).all() and (st.rewards >= 0).all()
+    assert 0 < int(st.dones.sum()) < 24 * 512 // 4
+    z0 = z.clone(); runner.alg.storage.clear(); runner._collect(False, True)
+    assert not torch.equal(z0, (st.actions - st.mu) / st.sigma)                  # the device step counter moved the Philox key
