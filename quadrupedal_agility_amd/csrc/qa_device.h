@@ -38,6 +38,24 @@ QA_DEV float quad_bcast(float x) { return dpp_f<S * 0x55>(x); }
 template <int S>
 QA_DEV int quad_bcast_i(int x) { return dpp_i<S * 0x55>(x); }
 
+// ---------------------------------------------------------------- cross-leg reductions for both lane mappings
+// LPE = lanes per env.  4: lane&3 = leg, the legs of an env are one quad.  16: lane = 16 env + 4 leg + sub, the legs of
+// an env are the 4 quads of one 16-lane DPP row; row_ror:4 / row_ror:8 add the lanes that share `sub`.
+template <int LPE>
+QA_DEV float xsum(float x) {
+    if (LPE == 4) return quad_sum(x);
+    x += dpp_f<0x124>(x);      // row_ror:4
+    x += dpp_f<0x128>(x);      // row_ror:8
+    return x;
+}
+template <int LPE>
+QA_DEV int xor_(int x) {
+    if (LPE == 4) return quad_or(x);
+    x |= dpp_i<0x124>(x);
+    x |= dpp_i<0x128>(x);
+    return x;
+}
+
 // ---------------------------------------------------------------- 3-vectors
 struct V3 { float x, y, z; };
 QA_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -78,6 +96,10 @@ QA_DEV S6 crf(S6 V, S6 F) { return s6(cross(V.a, F.a) + cross(V.l, F.l), cross(V
 QA_DEV S6 quad_sum(S6 p) {
     return s6(v3(quad_sum(p.a.x), quad_sum(p.a.y), quad_sum(p.a.z)), v3(quad_sum(p.l.x), quad_sum(p.l.y), quad_sum(p.l.z)));
 }
+template <int LPE>
+QA_DEV S6 xsum(S6 p) {
+    return s6(v3(xsum<LPE>(p.a.x), xsum<LPE>(p.a.y), xsum<LPE>(p.a.z)), v3(xsum<LPE>(p.l.x), xsum<LPE>(p.l.y), xsum<LPE>(p.l.z)));
+}
 
 // rigid-body inertia about the base origin in base axes: mass, first moment h = m c, I_O (xx yy zz xy xz yz)
 struct RB { float m; V3 h; float xx, yy, zz, xy, xz, yz; };
@@ -95,6 +117,12 @@ QA_DEV RB operator+(const RB &a, const RB &b) {
 QA_DEV RB quad_sum(const RB &a) {
     RB r; r.m = quad_sum(a.m); r.h = v3(quad_sum(a.h.x), quad_sum(a.h.y), quad_sum(a.h.z));
     r.xx = quad_sum(a.xx); r.yy = quad_sum(a.yy); r.zz = quad_sum(a.zz); r.xy = quad_sum(a.xy); r.xz = quad_sum(a.xz); r.yz = quad_sum(a.yz);
+    return r;
+}
+template <int LPE>
+QA_DEV RB xsum(const RB &a) {
+    RB r; r.m = xsum<LPE>(a.m); r.h = v3(xsum<LPE>(a.h.x), xsum<LPE>(a.h.y), xsum<LPE>(a.h.z));
+    r.xx = xsum<LPE>(a.xx); r.yy = xsum<LPE>(a.yy); r.zz = xsum<LPE>(a.zz); r.xy = xsum<LPE>(a.xy); r.xz = xsum<LPE>(a.xz); r.yz = xsum<LPE>(a.yz);
     return r;
 }
 // link inertia (mass m, CoM c_l and CoM inertia I6 in the link frame) moved to the base frame:

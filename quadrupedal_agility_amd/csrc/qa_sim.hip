@@ -12,12 +12,14 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
 #include "../../include/qa_sim.h"
 #include "qa_go2_model.h"
 #include "qa_physics.h"
+#include "qa_physics16.h"
 
 #define QA_BLOCK 64
 #define ENVS_PER_BLOCK (QA_BLOCK / 4)
@@ -87,6 +89,7 @@ struct Ptrs {
 
 struct qa_sim {
     long long *prof = nullptr;
+    int lanes = 4;                 // lanes per env of the step / simulate kernels (16 = experimental, QA_LANES)
     qa_config cfg;
     Layout L;
     char *arena;
@@ -203,7 +206,7 @@ struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int de
 #ifdef QA_SUBPROF
 #define QA_STAMP(k) do { } while (0)      // the substep stamps own the buffer in this build
 #else
-#define QA_STAMP(k) do { if (a.prof && threadIdx.x == 0) a.prof[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define QA_STAMP(k) do { if (a.prof && tix == 0) a.prof[bix * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #endif
 
 #define S_PROP 0        // 57  proprioception (noise-free)
@@ -223,7 +226,7 @@ struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int de
 __device__ __forceinline__ int obs_row_head(const float *dst) { return (int)(((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2); }
 
 __device__ __forceinline__ void store_obs_row(float *dst, const float *row, int head) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (QA_BLOCK - 1);
     const float4 *s4 = reinterpret_cast<const float4 *>(row + head);      // 16-B aligned by construction
     float4 *d4 = reinterpret_cast<float4 *>(dst + head);
     float4 a = s4[lane], b = s4[lane + 64];
@@ -233,35 +236,51 @@ __device__ __forceinline__ void store_obs_row(float *dst, const float *row, int 
     if (lane < 3 - head) dst[head + 668 + lane] = row[head + 668 + lane];
 }
 
-template <bool PLANE>
-__global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
+// LPE = lanes per env: 4 (lane&3 = leg) or 16 (lane = 16 env + 4 leg + sub; plane terrain only, qa_physics16.h)
+// With 16 lanes per env a workgroup is FOUR wavefronts (16 envs, as with 4 lanes): the hardware spreads the wavefronts
+// of one workgroup over the four SIMDs of a CU, whereas four single-wavefront workgroups of a kernel that needs <= 256
+// registers are packed two per SIMD and then share its issue slots (measured: 143 us instead of the expected ~50).
+// Each wavefront works on its own 4 envs with its own LDS region; only the constant table is shared.
+template <bool PLANE, int LPE>
+__global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_kernel(StepArgs a) {
+    constexpr int WPB = LPE == 16 ? 4 : 1;             // wavefronts per workgroup
+    constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
+    const int tix = threadIdx.x & (QA_BLOCK - 1);      // lane
+    const int bix = blockIdx.x * WPB + (threadIdx.x >> 6);   // index of this wavefront's env group
+    static_assert(LPE == 4 || (LPE == 16 && PLANE), "the 16-lane substep exists for the plane only");
     __shared__ float s_tbl[QA_TBL_FLOATS];
     // One LDS scratch region used by two disjoint phases (a workgroup's LDS footprint decides how many of them a CU
     // holds -- 160 KB per CU -- and with it the throughput once there are more workgroups than CUs):
     //   physics phase:      per-lane private slots | terrain windows (height field only)
     //   observation phase:  per-env staging | OBS_GROUP assembled observation rows
-    constexpr int U_PHYS = QA_PRIV_FLOATS * QA_PRIV_STRIDE + (PLANE ? 0 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH);
-    constexpr int U_OBS = ENVS_PER_BLOCK * S_ENV + OBS_GROUP * S_ROW;
-    __shared__ __attribute__((aligned(16))) float s_u[U_PHYS > U_OBS ? U_PHYS : U_OBS];
+    constexpr int U_PHYS = QA_PRIV_FLOATS * QA_PRIV_STRIDE + (PLANE ? 0 : EPB * QA_PATCH * QA_PATCH);
+    constexpr int U_OBS = EPB * S_ENV + OBS_GROUP * S_ROW;
+    constexpr int U_ALL = ((U_PHYS > U_OBS ? U_PHYS : U_OBS) + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float s_u_all[WPB * U_ALL];
+    float *s_u = s_u_all + (threadIdx.x >> 6) * U_ALL;
     float *s_priv = s_u, *s_patch = s_u + QA_PRIV_FLOATS * QA_PRIV_STRIDE;
-    float *s_stage = s_u, *s_rows = s_u + ENVS_PER_BLOCK * S_ENV;
-    static_assert((ENVS_PER_BLOCK * S_ENV) % 4 == 0, "row buffer must stay 16-byte aligned");
+    float *s_stage = s_u, *s_rows = s_u + EPB * S_ENV;
+    static_assert((EPB * S_ENV) % 4 == 0, "row buffer must stay 16-byte aligned");
     QA_STAMP(0);
     stage_table(s_tbl);
+    if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
     const int N = c.num_envs;
-    const int tid = blockIdx.x * QA_BLOCK + threadIdx.x;
-    const int leg = threadIdx.x & 3;
-    const int env_raw = tid >> 2;
-    const bool valid = env_raw < N;
-    const int env = valid ? env_raw : N - 1;
-    const int le = threadIdx.x >> 2;                 // env slot inside the block
+    const int tid = bix * QA_BLOCK + tix;
+    const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
+    const int sub = LPE == 4 ? 0 : (tix & 3);
+    const bool owner = sub == 0;                     // with 16 lanes per env the four sub-lanes of a leg hold identical values; one writes
+    const int env_raw = tid / LPE;
+    const bool in_range = env_raw < N;
+    const bool valid = in_range && owner;            // guards every global write
+    const int env = in_range ? env_raw : N - 1;
+    const int le = tix / LPE;                // env slot inside the block
     const float *tbl = s_tbl + leg * QA_LEG_TBL;
     const float *btbl = s_tbl + 4 * QA_LEG_TBL;
     const int64_t step = a.step_ptr ? *a.step_ptr : a.step;
 
-    if (blockIdx.x == 0 && threadIdx.x < 16) p.episode_stats[16 * ((step + 1) & 1) + threadIdx.x] = 0.f;   // next step's bin
+    if (bix == 0 && tix < 16) p.episode_stats[16 * ((step + 1) & 1) + tix] = 0.f;   // next step's bin
 
     // ---- action history roll, delay, clip (legged_robot.py:84-98); lane handles its 3 joints
     float act[3], raw_act[3];
@@ -330,7 +349,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
     // per-step constants are parked in per-lane LDS slots between substeps so that they do not hold VGPRs
     // through the substep (the substep alone needs ~340 registers)
-    float *priv = s_priv + threadIdx.x;
+    float *priv = s_priv + tix;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { lr(priv, QA_PRIV_STEP + k) = act[k]; lr(priv, QA_PRIV_STEP + 3 + k) = sp[k]; lr(priv, QA_PRIV_STEP + 6 + k) = sd[k]; }
 #pragma unroll
@@ -357,7 +376,8 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             float lim = tbl[T_EFFORT + k];
             tau[k] = clampf(t, -lim, lim);
         }
-        phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
+        if (LPE == 16) phys_substep16(st, tbl, btbl, bi, tau, mu, leg, sub, P, co, fimp);
+        else phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
@@ -372,9 +392,9 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     {
         V3 z = v3(0, 0, 0);
         V3 eb = co.extra_body == 0 ? co.extra_f : z, e1 = co.extra_body == 1 ? co.extra_f : z, e2 = co.extra_body == 2 ? co.extra_f : z;
-        base_f = v3(quad_sum(eb.x), quad_sum(eb.y), quad_sum(eb.z));
-        hu_f = v3(quad_sum(e1.x), quad_sum(e1.y), quad_sum(e1.z));
-        hl_f = v3(quad_sum(e2.x), quad_sum(e2.y), quad_sum(e2.z));
+        base_f = v3(xsum<LPE>(eb.x), xsum<LPE>(eb.y), xsum<LPE>(eb.z));
+        hu_f = v3(xsum<LPE>(e1.x), xsum<LPE>(e1.y), xsum<LPE>(e1.z));
+        hl_f = v3(xsum<LPE>(e2.x), xsum<LPE>(e2.y), xsum<LPE>(e2.z));
     }
     const int myb = 3 + 4 * leg;
     V3 hip_f = co.extra_body == myb ? co.extra_f : v3(0, 0, 0);
@@ -437,7 +457,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     const float scan_h = PLANE ? 0.0f : scan_center_height(T, st.pos, st.qz, st.qw);
     // ---- check_termination :168-176
     int term_c = (sqrtf(dot(hip_f, hip_f)) > 1.0f) ? 1 : 0;
-    term_c = quad_or(term_c) | (sqrtf(dot(base_f, base_f)) > 1.0f ? 1 : 0);
+    term_c = xor_<LPE>(term_c) | (sqrtf(dot(base_f, base_f)) > 1.0f ? 1 : 0);
     int timeout = (epl > c.max_episode_length) || (st.pos.z < -6.0f);
     {
         float chk = st.pos.x + st.pos.y + st.pos.z + st.qx + st.qy + st.qz + st.qw + st.vw.x + st.vw.y + st.vw.z + st.ww.x + st.ww.y + st.ww.z;
@@ -467,10 +487,10 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
             s_tq += tau_org[k] * tau_org[k];
         }
         float ncol = (sqrtf(dot(thigh_f, thigh_f)) > 0.1f ? 1.f : 0.f) + (sqrtf(dot(calf_f, calf_f)) > 0.1f ? 1.f : 0.f);
-        term[QA_R_ACTION_RATE] = quad_sum(s_ar); term[QA_R_COLLISION] = quad_sum(ncol); term[QA_R_DELTA_TORQUES] = quad_sum(s_dt);
-        term[QA_R_DOF_ACC] = quad_sum(s_acc); term[QA_R_DOF_ERROR] = quad_sum(s_err); term[QA_R_DOF_POS_LIMITS] = quad_sum(s_pl);
-        term[QA_R_DOF_VEL_LIMITS] = quad_sum(s_vl); term[QA_R_HIP_POS] = quad_sum(s_hip); term[QA_R_TORQUE_LIMITS] = quad_sum(s_tl);
-        term[QA_R_TORQUES] = quad_sum(s_tq);
+        term[QA_R_ACTION_RATE] = xsum<LPE>(s_ar); term[QA_R_COLLISION] = xsum<LPE>(ncol); term[QA_R_DELTA_TORQUES] = xsum<LPE>(s_dt);
+        term[QA_R_DOF_ACC] = xsum<LPE>(s_acc); term[QA_R_DOF_ERROR] = xsum<LPE>(s_err); term[QA_R_DOF_POS_LIMITS] = xsum<LPE>(s_pl);
+        term[QA_R_DOF_VEL_LIMITS] = xsum<LPE>(s_vl); term[QA_R_HIP_POS] = xsum<LPE>(s_hip); term[QA_R_TORQUE_LIMITS] = xsum<LPE>(s_tl);
+        term[QA_R_TORQUES] = xsum<LPE>(s_tq);
         const float root_h = st.pos.z - scan_h;
         float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
         term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c.jump_height[0]) ? c.jump_goal : 0.f;
@@ -581,7 +601,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
                 int i = 4 * (2 * leg + b) + e;
                 int idx = i < 29 ? i : 58 + (i - 29);
                 float sc = idx < 2 ? c.noise_roll_pitch : (idx < 5 ? c.noise_ang_vel : (idx < 17 ? c.noise_dof_pos : (idx < 29 ? c.noise_dof_vel : c.noise_lin_vel)));
-                sst[S_HEAD + idx] += (2.0f * u.v[e] - 1.0f) * sc;
+                if (owner) sst[S_HEAD + idx] += (2.0f * u.v[e] - 1.0f) * sc;
             }
         }
     }
@@ -634,14 +654,14 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
     // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
-    const int lane = threadIdx.x;
+    const int lane = tix;
     // history loads run one group ahead of the assembly (double-buffered in registers): the HBM latency of group
     // k+1's 36 loads is hidden behind the LDS assembly and the row stores of group k
     float hvb[2][OBS_GROUP][9];
     auto load_hist = [&](int buf, int e0) {
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {          // 8 full wave loads + 1 single-lane load per env
-            const int ge = min((int)(blockIdx.x * ENVS_PER_BLOCK) + e0 + g, N - 1);
+            const int ge = min((int)(bix * EPB) + e0 + g, N - 1);
             const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
 #pragma unroll
             for (int r = 0; r < 8; ++r) hvb[buf][g][r] = hist[QA_BLOCK * r];
@@ -650,14 +670,14 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
     };
     load_hist(0, 0);
 #pragma unroll
-    for (int gi = 0; gi < ENVS_PER_BLOCK / OBS_GROUP; ++gi) {
+    for (int gi = 0; gi < EPB / OBS_GROUP; ++gi) {
         const int e0 = gi * OBS_GROUP;
-        if (gi + 1 < ENVS_PER_BLOCK / OBS_GROUP) load_hist((gi + 1) & 1, e0 + OBS_GROUP);
+        if (gi + 1 < EPB / OBS_GROUP) load_hist((gi + 1) & 1, e0 + OBS_GROUP);
         float (&hv)[OBS_GROUP][9] = hvb[gi & 1];
         if (e0) wave_lds_sync();                       // the previous group's row stores have read their LDS rows
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
-            const int e = e0 + g, ge = (int)(blockIdx.x * ENVS_PER_BLOCK) + e;
+            const int e = e0 + g, ge = (int)(bix * EPB) + e;
             if (ge < N) {
                 const float *ss = s_stage + e * S_ENV;
                 const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
@@ -685,7 +705,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_env_step_kernel(StepArgs a) {
         wave_lds_sync();
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {
-            const int ge = blockIdx.x * ENVS_PER_BLOCK + e0 + g;
+            const int ge = bix * EPB + e0 + g;
             if (ge < N) {
                 float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
                 const int head = obs_row_head(dst);
@@ -771,15 +791,17 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptr
     for (int i = leg; i < 570; i += 4) p.obs[(int64_t)env * QA_NUM_OBS + 90 + i] = 0.f;
 }
 
-template <bool PLANE>
+template <bool PLANE, int LPE>
 __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     __shared__ float s_patch[PLANE ? 1 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH];
+    static_assert(LPE == 4 || (LPE == 16 && PLANE), "the 16-lane substep exists for the plane only");
     stage_table(s_tbl);
-    const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, leg = threadIdx.x & 3, N = c.num_envs;
-    const bool valid = (tid >> 2) < N;
-    const int env = valid ? (tid >> 2) : N - 1;
+    const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, N = c.num_envs;
+    const int leg = LPE == 4 ? (threadIdx.x & 3) : ((threadIdx.x >> 2) & 3), sub = LPE == 4 ? 0 : (threadIdx.x & 3);
+    const bool in_range = (tid / LPE) < N, valid = in_range && sub == 0;
+    const int env = in_range ? (tid / LPE) : N - 1;
     const float *tbl = s_tbl + leg * QA_LEG_TBL, *btbl = s_tbl + 4 * QA_LEG_TBL;
     EnvState st;
     const float *r = p.root + (int64_t)env * 13;
@@ -800,12 +822,13 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
         stage_patch(T, mine, leg);
         wave_lds_sync();
     }
-    phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
+    if (LPE == 16) phys_substep16(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, sub, P, co, fimp);
+    else phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
     V3 org[4]; leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 z = v3(0, 0, 0);
     V3 eb = co.extra_body == 0 ? co.extra_f : z, e1 = co.extra_body == 1 ? co.extra_f : z, e2 = co.extra_body == 2 ? co.extra_f : z;
-    V3 base_f = v3(quad_sum(eb.x), quad_sum(eb.y), quad_sum(eb.z)), hu_f = v3(quad_sum(e1.x), quad_sum(e1.y), quad_sum(e1.z)), hl_f = v3(quad_sum(e2.x), quad_sum(e2.y), quad_sum(e2.z));
+    V3 base_f = v3(xsum<LPE>(eb.x), xsum<LPE>(eb.y), xsum<LPE>(eb.z)), hu_f = v3(xsum<LPE>(e1.x), xsum<LPE>(e1.y), xsum<LPE>(e1.z)), hl_f = v3(xsum<LPE>(e2.x), xsum<LPE>(e2.y), xsum<LPE>(e2.z));
     if (!valid) return;
     const int myb = 3 + 4 * leg;
     float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
@@ -939,6 +962,11 @@ int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
     if ((cfg->terrain_type != 0 && cfg->terrain_type != 1) || (cfg->terrain_type == 1 && (cfg->hf_rows < 2 || cfg->hf_cols < 2 || !(cfg->hf_hscale > 0.0f))) || cfg->decimation <= 0 || cfg->solver_iterations <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: unsupported config"); return QA_E_ARG; }
     qa_sim *s = new qa_sim();
     s->cfg = *cfg; make_layout(cfg, &s->L); s->arena = (char *)arena;
+    // lane mapping of the step kernels: 4 lanes per env (lane&3 = leg).  QA_LANES=16 selects the experimental mapping of
+    // qa_physics16.h (an env per 16-lane DPP row, plane only): parity-green, 24 % fewer cycles per wavefront, but slower in
+    // wall time at 4096 envs (79.7 vs 72.8 us: four times as many busy SIMDs) -- DESIGN.md section 9.
+    s->lanes = 4;
+    if (const char *e = getenv("QA_LANES")) { if (atoi(e) == 4) s->lanes = 4; else if (atoi(e) == 16 && cfg->terrain_type == 0) s->lanes = 16; }
     memset(s->mocap_first, 0, sizeof(s->mocap_first));
     if (arena_bytes < s->L.total || ((uintptr_t)arena & 255)) { delete s; snprintf(g_err, sizeof(g_err), "qa_create: arena too small or misaligned"); return QA_E_ARENA; }
     fill_ptrs(s);
@@ -968,12 +996,17 @@ int qa_set_mocap(qa_sim *s, const float *frames, int32_t nf, const int32_t first
 
 static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; memcpy(m.first, s->mocap_first, sizeof(m.first)); return m; }
 
+static void launch_env_step(qa_sim *s, const StepArgs &a, hipStream_t st) {
+    const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_env_step_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+    else if (s->lanes == 16) hipLaunchKernelGGL((qa_env_step_kernel<true, 16>), dim3((blocks + 3) / 4), dim3(4 * QA_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((qa_env_step_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+}
+
 int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t global_step, void *stream) {
     if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step; a.step_ptr = nullptr; a.prof = s->prof;
-    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL(qa_env_step_kernel<false>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(qa_env_step_kernel<true>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    launch_env_step(s, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }
@@ -984,9 +1017,7 @@ int qa_env_step_dev(qa_sim *s, const float *actions, int32_t delay_steps, int64_
     if (!s || !actions || !step_counter_dev || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = 0;
     a.step_ptr = step_counter_dev; a.prof = s->prof;
-    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL(qa_env_step_kernel<false>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(qa_env_step_kernel<true>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    launch_env_step(s, a, (hipStream_t)stream);
     hipLaunchKernelGGL(qa_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter_dev);
     HIP_TRY(hipGetLastError());
     return QA_OK;
@@ -1002,9 +1033,10 @@ int qa_reset_all(qa_sim *s, int64_t global_step, void *stream) {
 
 int qa_simulate(qa_sim *s, const float *torques, void *stream) {
     if (!s || !torques) return QA_E_ARG;
-    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
-    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL(qa_simulate_kernel<false>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
-    else hipLaunchKernelGGL(qa_simulate_kernel<true>, dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_simulate_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    else if (s->lanes == 16) hipLaunchKernelGGL((qa_simulate_kernel<true, 16>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    else hipLaunchKernelGGL((qa_simulate_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }
