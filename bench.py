@@ -115,14 +115,14 @@ def main():
     # same env state, right after the timed region (inside it the 24 steps of a rollout replay as ONE hipGraph launch,
     # which leaves no place for per-kernel events; profiles/ holds the rocprofv3 per-kernel average of the same command)
     act = torch.zeros(args.num_envs, 12, device=dev)
-    env.sync_reset_ids = False                         # no host sync between launches: the queue stays full
+    sim.global_step = env.common_step_counter
     reps, per = 5, 40
     spans = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(per):                           # back-to-back launches; HIP events bracket the batch on the launch stream
-            env.step(act)
+        for _ in range(per):                           # back-to-back launches of the kernel alone (no wrapper bookkeeping);
+            sim.step(act, env.delay)                   # HIP events bracket the batch on the launch stream
         e1.record()
         spans.append((e0, e1))
     torch.cuda.synchronize()
