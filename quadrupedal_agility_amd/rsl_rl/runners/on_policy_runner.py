@@ -298,7 +298,8 @@ class OnPolicyRunner:
             if rc != 0:
                 raise RuntimeError(f"qa_rollout_post failed with code {rc}: {lib.qa_last_error().decode()}")
             st.step += 1
-            obs = next_obs.clone()
+            obs = next_obs          # the arena's observation rows themselves: everything that reads them (GEMMs, the storage copy)
+                                    # is enqueued before the next env step overwrites them, so no private copy is needed
             if logging and "episode" in infos:
                 ep_infos.append(dict(infos["episode"]))
         self._obs_cur.copy_(obs)
