@@ -293,6 +293,21 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
 int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
                     int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream);
 
+/* Head losses of the SS-InfoGAIL discriminator step and their gradient w.r.t. the head outputs
+ * (bbc/rsl_rl/algorithms/gail.py:452-520, MSELoss variant).  Rows are [labelled expert b_lb | policy b_pi | unlabelled
+ * expert b_ulb]; d, eps (rows), c (rows,5: the clamped softmax the discriminator returns) are the three heads' outputs;
+ * label_lb (b_lb) int64 gait labels; policy_eps (b_pi), policy_c (b_pi,5) the latents the policy samples were generated with.
+ *   ss = mean_lb CE(log_softmax(c), label);  info = mean_ulb -sum c log(c + 1e-20);
+ *   disc = 1/2 (mean_pi (d+1)^2 + mean_ulb (d-1)^2);  us = mean_pi |eps - policy_eps|
+ *   loss = c_ss ss + (*info_coef_dev) info + c_disc disc + c_us us
+ * Outputs: grad_d, grad_eps (rows), grad_c (rows,5) = d loss / d heads; out[16] = {loss, ss, info, disc, us, acc_lb
+ * (argmax c == label), acc_pi (d < 0), acc_exp (d > 0 on ulb), acc_ulb (argmax c == argmax policy_c), mean_ulb c [5], 0, 0}.
+ * The gradient penalty and the weight regularisers of the step are not part of this entry point. */
+int64_t qa_disc_loss_scratch_bytes(int64_t rows);
+int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                 int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                 float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

@@ -1189,6 +1189,55 @@ int qo_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_
     return QA_OK;
 }
 
+/* discriminator head losses + gradient (gail.py:452-520, MSELoss variant); double arithmetic, host pointers */
+int64_t qo_disc_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : 0; }
+int qo_disc_loss(const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                 int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                 float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!d || !eps || !c || !label_lb || !policy_eps || !policy_c || !info_coef_dev || !grad_d || !grad_eps || !grad_c || !out ||
+        b_lb <= 0 || b_pi <= 0 || b_ulb <= 0) return QA_E_ARG;
+    int B = b_lb + b_pi + b_ulb;
+    double ss = 0, info = 0, dpi = 0, dex = 0, us = 0, acc[4] = {0, 0, 0, 0}, pm[5] = {0, 0, 0, 0, 0}, c_info = info_coef_dev[0];
+    for (int i = 0; i < B; ++i) {
+        const float *ci = c + (int64_t)i * 5; float *gc = grad_c + (int64_t)i * 5;
+        int arg = 0; for (int j = 1; j < 5; ++j) if (ci[j] > ci[arg]) arg = j;
+        for (int j = 0; j < 5; ++j) gc[j] = 0; grad_d[i] = 0; grad_eps[i] = 0;
+        if (i < b_lb) {
+            double m = ci[0]; for (int j = 1; j < 5; ++j) if (ci[j] > m) m = ci[j];
+            double e[5], se = 0; for (int j = 0; j < 5; ++j) { e[j] = exp((double)ci[j] - m); se += e[j]; }
+            int lab = (int)label_lb[i];
+            ss += m + log(se) - ci[lab];
+            for (int j = 0; j < 5; ++j) gc[j] = (float)((double)c_ss / b_lb * (e[j] / se - (lab == j ? 1.0 : 0.0)));
+            acc[0] += arg == lab;
+        } else if (i < b_lb + b_pi) {
+            int r = i - b_lb; double dd = d[i];
+            dpi += (dd + 1) * (dd + 1); grad_d[i] = (float)((double)c_disc * (dd + 1) / b_pi);
+            double de = (double)eps[i] - policy_eps[r];
+            us += fabs(de); grad_eps[i] = (float)((double)c_us * (de > 0 ? 1.0 : (de < 0 ? -1.0 : 0.0)) / b_pi);
+            acc[1] += dd < 0;
+            int pa = 0; for (int j = 1; j < 5; ++j) if (policy_c[(int64_t)r * 5 + j] > policy_c[(int64_t)r * 5 + pa]) pa = j;
+            acc[3] += arg == pa;
+        } else {
+            double dd = d[i];
+            dex += (dd - 1) * (dd - 1); grad_d[i] = (float)((double)c_disc * (dd - 1) / b_ulb);
+            for (int j = 0; j < 5; ++j) {
+                double p = ci[j], l = log(p + 1e-20);
+                info -= p * l; gc[j] = (float)(-c_info / b_ulb * (l + p / (p + 1e-20))); pm[j] += p;
+            }
+            acc[2] += dd > 0;
+        }
+    }
+    ss /= b_lb; info /= b_ulb; us /= b_pi;
+    double disc = 0.5 * (dpi / b_pi + dex / b_ulb);
+    out[0] = (float)(c_ss * ss + c_info * info + c_disc * disc + c_us * us);
+    out[1] = (float)ss; out[2] = (float)info; out[3] = (float)disc; out[4] = (float)us;
+    out[5] = (float)(acc[0] / b_lb); out[6] = (float)(acc[1] / b_pi); out[7] = (float)(acc[2] / b_ulb); out[8] = (float)(acc[3] / b_pi);
+    for (int j = 0; j < 5; ++j) out[9 + j] = (float)(pm[j] / b_ulb);
+    out[14] = 0; out[15] = 0;
+    return QA_OK;
+}
+
 /* ---- debug entry points used only by the physics known-answer tests ---- */
 /* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
 int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {

@@ -434,6 +434,123 @@ __global__ void __launch_bounds__(256) qa_rollout_post_kernel(const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The head losses of the SS-InfoGAIL discriminator step (bbc/rsl_rl/algorithms/gail.py:452-520) and their gradient with
+// respect to the three heads' outputs, one pass over the batch [labelled expert | policy | unlabelled expert]:
+//   ss   = mean_lb  CE(log_softmax(c), label)                 (cross-entropy applied to the already-softmaxed c, as the reference)
+//   info = mean_ulb -sum_j c_j log(c_j + 1e-20)
+//   disc = 1/2 (mean_pi (d + 1)^2 + mean_ulb (d - 1)^2)        (MSELoss variant)
+//   us   = mean_pi |eps - eps_label|
+//   loss = c_ss ss + c_info info + c_disc disc + c_us us       (gradient penalty, logit and weight regularisers stay in autograd)
+// plus the four accuracies the runner logs and mean_ulb c (the prior EMA input).  Eager PyTorch: ~90 launches on
+// (3,684 x <=5) tensors per step, 80 steps per iteration.
+constexpr int DISC_BLOCK = 256;
+constexpr int DISC_SUMS = 13;         // ss, info, disc_pi, disc_exp, us, acc_lb, acc_pi, acc_exp, acc_ulb (counts), pred_mean[4] + the 5th below
+struct DiscArgs {
+    const float *d, *eps, *c; const int64_t *label; const float *pol_eps, *pol_c; const float *info_coef;
+    float *gd, *geps, *gc; float *partial;
+    int b_lb, b_pi, b_ulb;
+    float c_ss, c_disc, c_us;
+};
+
+__global__ void __launch_bounds__(DISC_BLOCK) qa_disc_loss_kernel(DiscArgs a) {
+    __shared__ float s_w[DISC_BLOCK / 64][DISC_SUMS + 1];
+    const int i = blockIdx.x * DISC_BLOCK + threadIdx.x, B = a.b_lb + a.b_pi + a.b_ulb;
+    float part[DISC_SUMS + 1];
+#pragma unroll
+    for (int k = 0; k <= DISC_SUMS; ++k) part[k] = 0.f;
+    if (i < B) {
+        const float c_info = a.info_coef[0];
+        float c[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) c[j] = a.c[(int64_t)i * 5 + j];
+        int arg = 0;
+#pragma unroll
+        for (int j = 1; j < 5; ++j) if (c[j] > c[arg]) arg = j;
+        float gc[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, gd = 0.f, ge = 0.f;
+        const float d = a.d[i];
+        if (i < a.b_lb) {                                   // labelled expert: cross-entropy on log_softmax(c)
+            float m = c[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) m = fmaxf(m, c[j]);
+            float e[5], se = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { e[j] = expf(c[j] - m); se += e[j]; }
+            const int lab = (int)a.label[i];
+            const float lse = m + logf(se), inv = 1.0f / se, w = a.c_ss / (float)a.b_lb;
+            float cl = c[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) cl = lab == j ? c[j] : cl;
+            part[0] = lse - cl;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) gc[j] = w * (e[j] * inv - (lab == j ? 1.0f : 0.0f));
+            part[5] = arg == lab ? 1.0f : 0.0f;
+        } else if (i < a.b_lb + a.b_pi) {                   // policy samples: discriminator target -1, eps regression
+            const int r = i - a.b_lb;
+            part[2] = (d + 1.0f) * (d + 1.0f);
+            gd = a.c_disc * (d + 1.0f) / (float)a.b_pi;
+            const float de = a.eps[i] - a.pol_eps[r];
+            part[4] = fabsf(de);
+            ge = a.c_us * (de > 0.f ? 1.0f : (de < 0.f ? -1.0f : 0.0f)) / (float)a.b_pi;
+            part[6] = d < 0.f ? 1.0f : 0.0f;
+            int pa = 0;
+#pragma unroll
+            for (int j = 1; j < 5; ++j) if (a.pol_c[(int64_t)r * 5 + j] > a.pol_c[(int64_t)r * 5 + pa]) pa = j;
+            part[8] = arg == pa ? 1.0f : 0.0f;
+        } else {                                            // unlabelled expert: target +1, information maximisation, prior mean
+            part[3] = (d - 1.0f) * (d - 1.0f);
+            gd = a.c_disc * (d - 1.0f) / (float)a.b_ulb;
+            const float w = c_info / (float)a.b_ulb;
+            float h = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float l = logf(c[j] + 1e-20f);
+                h -= c[j] * l;
+                gc[j] = -w * (l + c[j] / (c[j] + 1e-20f));
+                part[9 + j] = c[j];
+            }
+            part[1] = h;
+            part[7] = d > 0.f ? 1.0f : 0.0f;
+        }
+        a.gd[i] = gd; a.geps[i] = ge;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a.gc[(int64_t)i * 5 + j] = gc[j];
+    }
+#pragma unroll
+    for (int k = 0; k <= DISC_SUMS; ++k) {
+        const float s = wave_sum(part[k]);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x <= DISC_SUMS) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < DISC_BLOCK / 64; ++w) t += s_w[w][threadIdx.x];
+        a.partial[(int64_t)blockIdx.x * (DISC_SUMS + 1) + threadIdx.x] = t;
+    }
+}
+
+// out[16] = {loss, ss, info, disc, us, acc_lb, acc_pi, acc_exp, acc_ulb, pred_mean[5], 0, 0}
+__global__ void qa_disc_finish_kernel(const float *partial, int nblocks, int b_lb, int b_pi, int b_ulb, float c_ss, const float *info_coef,
+                                      float c_disc, float c_us, float *out) {
+    __shared__ double s_tot[DISC_SUMS + 1];
+    const int t = threadIdx.x;
+    if (t <= DISC_SUMS) {
+        double acc = 0.0;
+        for (int b = 0; b < nblocks; ++b) acc += (double)partial[(int64_t)b * (DISC_SUMS + 1) + t];
+        s_tot[t] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const double ss = s_tot[0] / b_lb, info = s_tot[1] / b_ulb, disc = 0.5 * (s_tot[2] / b_pi + s_tot[3] / b_ulb), us = s_tot[4] / b_pi;
+        out[0] = (float)(c_ss * ss + (double)info_coef[0] * info + c_disc * disc + c_us * us);
+        out[1] = (float)ss; out[2] = (float)info; out[3] = (float)disc; out[4] = (float)us;
+        out[5] = (float)(s_tot[5] / b_lb); out[6] = (float)(s_tot[6] / b_pi); out[7] = (float)(s_tot[7] / b_ulb); out[8] = (float)(s_tot[8] / b_pi);
+        for (int j = 0; j < 5; ++j) out[9 + j] = (float)(s_tot[9 + j] / b_ulb);
+        out[14] = 0.f; out[15] = 0.f;
+    }
+}
+
 }  // namespace
 
 extern thread_local char qa_err_buf[512];
@@ -550,6 +667,25 @@ int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_
                        gamma, (int)num_envs, st_rewards, st_dones, cur, fin_vals, fin_mask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_post: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int64_t qa_disc_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * (DISC_SUMS + 1) * ((rows + DISC_BLOCK - 1) / DISC_BLOCK); }
+
+int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                 int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                 float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    const int64_t B = (int64_t)b_lb + b_pi + b_ulb;
+    if (!d || !eps || !c || !label_lb || !policy_eps || !policy_c || !info_coef_dev || !grad_d || !grad_eps || !grad_c || !out || !scratch ||
+        b_lb <= 0 || b_pi <= 0 || b_ulb <= 0 || scratch_bytes < qa_disc_loss_scratch_bytes(B)) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_disc_loss: bad argument"); return QA_E_ARG; }
+    DiscArgs a{d, eps, c, label_lb, policy_eps, policy_c, info_coef_dev, grad_d, grad_eps, grad_c, (float *)scratch, b_lb, b_pi, b_ulb, c_ss, c_disc, c_us};
+    const int blocks = (int)((B + DISC_BLOCK - 1) / DISC_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(qa_disc_loss_kernel, dim3(blocks), dim3(DISC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(qa_disc_finish_kernel, dim3(1), dim3(64), 0, st, (const float *)scratch, blocks, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -256,3 +256,61 @@ class ClipAdam:
                                    _ptr(t["scratch"]), t["scratch"].numel(), stream)
         if rc != 0:
             raise RuntimeError(f"qa_clip_adam_step failed with code {rc}: {lib.qa_last_error().decode()}")
+
+
+class _DiscLoss(torch.autograd.Function):
+    """loss, stats = f(d (B,1), eps (B,1), c (B,5) | labels, policy latents): the head losses of the discriminator step
+    (MSELoss variant) and their gradient in one pass (qa_disc_loss); backward only scales the stored gradients.
+    stats = [loss, ss, info, disc, us, acc_lb, acc_pi, acc_exp, acc_ulb, pred_mean(5), 0, 0]."""
+
+    @staticmethod
+    def forward(ctx, d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us):
+        lib = _capi.load_library()
+        dc, ec, cc = _f32c(d), _f32c(eps), _f32c(c)
+        pe, pc = _f32c(policy_eps), _f32c(policy_c)
+        lab = label_lb if (label_lb.dtype == torch.int64 and label_lb.is_contiguous()) else label_lb.contiguous().long()
+        B = b_lb + b_pi + b_ulb
+        assert dc.numel() == B and ec.numel() == B and cc.shape == (B, 5) and lab.numel() == b_lb and pe.numel() == b_pi and pc.shape == (b_pi, 5)
+        assert info_coef_dev.is_cuda and info_coef_dev.dtype == torch.float32
+        gd = torch.empty(B, dtype=torch.float32, device=dc.device); ge = torch.empty_like(gd); gc = torch.empty_like(cc)
+        out = torch.empty(16, dtype=torch.float32, device=dc.device)
+        n = int(lib.qa_disc_loss_scratch_bytes(B))
+        scratch = torch.empty(n, dtype=torch.uint8, device=dc.device)
+        stream = C.c_void_p(torch.cuda.current_stream(dc.device).cuda_stream)
+        rc = lib.qa_disc_loss(_ptr(dc), _ptr(ec), _ptr(cc), _ptr(lab), _ptr(pe), _ptr(pc), b_lb, b_pi, b_ulb, float(c_ss), _ptr(info_coef_dev),
+                              float(c_disc), float(c_us), _ptr(gd), _ptr(ge), _ptr(gc), _ptr(out), _ptr(scratch), n, stream)
+        if rc != 0:
+            raise RuntimeError(f"qa_disc_loss failed with code {rc}: {lib.qa_last_error().decode()}")
+        ctx.save_for_backward(gd, ge, gc)
+        ctx.shapes = (d.shape, eps.shape, c.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        gd, ge, gc = ctx.saved_tensors
+        sd, se, sc = ctx.shapes
+        return ((gd * g_loss).view(sd), (ge * g_loss).view(se), (gc * g_loss).view(sc)) + (None,) * 10
+
+
+def disc_loss(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, *, c_ss, info_coef_dev, c_disc, c_us):
+    return _DiscLoss.apply(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us)
+
+
+def disc_loss_reference(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, *, c_ss, info_coef, c_disc, c_us):
+    """The same head losses as eager PyTorch ops, as gail.py:452-520 writes them (any device)."""
+    import torch.nn.functional as F
+    pred_c_lb = c[:b_lb]
+    logits_pi, e_pi, pred_c = d[b_lb:b_lb + b_pi], eps[b_lb:b_lb + b_pi], c[b_lb:b_lb + b_pi]
+    logits_exp, pred_c_ulb = d[b_lb + b_pi:], c[b_lb + b_pi:]
+    ss = F.cross_entropy(pred_c_lb, label_lb)
+    info = torch.mean(-torch.sum(pred_c_ulb * torch.log(pred_c_ulb + 1e-20), dim=-1))
+    disc = 0.5 * (F.mse_loss(logits_pi, -torch.ones_like(logits_pi)) + F.mse_loss(logits_exp, torch.ones_like(logits_exp)))
+    us = F.l1_loss(e_pi, policy_eps.view_as(e_pi))
+    loss = c_ss * ss + info_coef * info + c_disc * disc + c_us * us
+    with torch.no_grad():
+        acc = [(torch.argmax(pred_c_lb, -1) == label_lb).float().mean(), (logits_pi < 0).float().mean(), (logits_exp > 0).float().mean(),
+               (torch.argmax(pred_c, -1) == torch.argmax(policy_c, -1)).float().mean()]
+        stats = torch.stack([loss.detach(), ss.detach(), info.detach(), disc.detach(), us.detach()] + acc)
+        stats = torch.cat([stats, pred_c_ulb.mean(0), torch.zeros(2, device=d.device)])
+    return loss, stats

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
-from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, ppo_loss
+from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, disc_loss, ppo_loss
 from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
 
 
@@ -458,35 +458,44 @@ class SSInfoGAIL:
         pred_c_lb = c_all[:b_lb]
         logits_pi, eps, pred_c = d_all[b_lb:b_lb + b_pi], eps_all[b_lb:b_lb + b_pi], c_all[b_lb:b_lb + b_pi]
         logits_exp, pred_c_ulb = d_all[b_lb + b_pi:], c_all[b_lb + b_pi:]
-        ss_loss = F.cross_entropy(pred_c_lb, label_lb)          # CE on softmaxed probabilities, as the reference
-        policy_c_idx = torch.argmax(policy_c, dim=-1)
-
-        pred_mean = torch.mean(pred_c_ulb, dim=0).detach()
+        fused_heads = self._on_gpu and self.use_fused_loss and self.disc_loss_function == "MSELoss"
+        if fused_heads:
+            # the four head losses, their gradient, the four logged accuracies and the prior mean: ONE kernel (fused.py)
+            self._info_max_dev.fill_(float(self.info_max_coef_on)) if not torch.cuda.is_current_stream_capturing() else None
+            heads, hs = disc_loss(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0],
+                                  c_ss=self.ss_coef, info_coef_dev=self._info_max_dev, c_disc=self.disc_coef, c_us=self.us_coef)
+            ss_loss, info_max_loss, disc_loss_v, us_loss = hs[1], hs[2], hs[3], hs[4]
+            pred_mean = hs[9:14]
+        else:
+            ss_loss = F.cross_entropy(pred_c_lb, label_lb)          # CE on softmaxed probabilities, as the reference
+            policy_c_idx = torch.argmax(policy_c, dim=-1)
+            pred_mean = torch.mean(pred_c_ulb, dim=0).detach()
+            info_max_loss = torch.mean(-torch.sum(pred_c_ulb * torch.log(pred_c_ulb + 1e-20), dim=-1))
+            if self.disc_loss_function == "BCEWithLogitsLoss":
+                l_exp = F.binary_cross_entropy_with_logits(logits_exp, torch.ones_like(logits_exp))
+                l_pi = F.binary_cross_entropy_with_logits(logits_pi, torch.zeros_like(logits_pi))
+            elif self.disc_loss_function == "MSELoss":
+                l_exp = F.mse_loss(logits_exp, torch.ones_like(logits_exp))
+                l_pi = F.mse_loss(logits_pi, -torch.ones_like(logits_pi))
+            elif self.disc_loss_function == "WassersteinLoss":
+                l_exp, l_pi = -logits_exp.mean(), logits_pi.mean()
+            else:
+                raise ValueError("Unexpected loss function specified")
+            disc_loss_v = 0.5 * (l_pi + l_exp)
+            us_loss = F.l1_loss(eps, policy_eps)
         if self.grad_sync is None:      # data-parallel: the vector rides in the gradient bucket below (one collective per step)
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
-        info_max_loss = torch.mean(-torch.sum(pred_c_ulb * torch.log(pred_c_ulb + 1e-20), dim=-1))
-
-        if self.disc_loss_function == "BCEWithLogitsLoss":
-            l_exp = F.binary_cross_entropy_with_logits(logits_exp, torch.ones_like(logits_exp))
-            l_pi = F.binary_cross_entropy_with_logits(logits_pi, torch.zeros_like(logits_pi))
-        elif self.disc_loss_function == "MSELoss":
-            l_exp = F.mse_loss(logits_exp, torch.ones_like(logits_exp))
-            l_pi = F.mse_loss(logits_pi, -torch.ones_like(logits_pi))
-        elif self.disc_loss_function == "WassersteinLoss":
-            l_exp, l_pi = -logits_exp.mean(), logits_pi.mean()
-        else:
-            raise ValueError("Unexpected loss function specified")
-        disc_loss = 0.5 * (l_pi + l_exp)
-        us_loss = F.l1_loss(eps, policy_eps)
         disc_logit_loss = torch.sum(torch.square(self.disc.get_disc_logit_weights()))
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
         g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
         grad_pen_loss = torch.mean(torch.sum(torch.square(g), dim=-1))
         disc_weight_decay = torch.sum(torch.square(torch.cat(self.disc.get_disc_weights(), dim=-1)))
-        info_coef = self._info_max_dev if (self._info_max_dev is not None and torch.cuda.is_current_stream_capturing()) else self.info_max_coef_on
-        loss = (self.ss_coef * ss_loss + info_coef * info_max_loss + self.disc_coef * disc_loss +
-                self.us_coef * us_loss + self.disc_grad_penalty * grad_pen_loss + self.disc_logit_reg * disc_logit_loss +
-                self.disc_weight_decay * disc_weight_decay)
+        rest = self.disc_grad_penalty * grad_pen_loss + self.disc_logit_reg * disc_logit_loss + self.disc_weight_decay * disc_weight_decay
+        if fused_heads:
+            loss = heads + rest
+        else:
+            info_coef = self._info_max_dev if (self._info_max_dev is not None and torch.cuda.is_current_stream_capturing()) else self.info_max_coef_on
+            loss = self.ss_coef * ss_loss + info_coef * info_max_loss + self.disc_coef * disc_loss_v + self.us_coef * us_loss + rest
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.zero_grad()
         loss.backward()
@@ -499,12 +508,15 @@ class SSInfoGAIL:
             self.actor_critic.std.data.clamp_(min=self.min_std)       # in place: recorded rollouts keep reading this buffer
         if self.disc_normalizer is not None:
             self.disc_normalizer.update_torch([policy_state, expert_lb, expert_ulb])
-        with torch.no_grad():
-            acc_lb = (torch.argmax(pred_c_lb, dim=-1) == label_lb).float().mean()
-            acc_pi = (logits_pi < 0).float().mean()
-            acc_exp = (logits_exp > 0).float().mean()
-            acc_ulb = (torch.argmax(pred_c, dim=-1) == policy_c_idx).float().mean()
-        return (ss_loss.detach(), info_max_loss.detach(), disc_loss.detach(), us_loss.detach(), grad_pen_loss.detach(),
+        if fused_heads:
+            acc_lb, acc_pi, acc_exp, acc_ulb = hs[5], hs[6], hs[7], hs[8]
+        else:
+            with torch.no_grad():
+                acc_lb = (torch.argmax(pred_c_lb, dim=-1) == label_lb).float().mean()
+                acc_pi = (logits_pi < 0).float().mean()
+                acc_exp = (logits_exp > 0).float().mean()
+                acc_ulb = (torch.argmax(pred_c, dim=-1) == policy_c_idx).float().mean()
+        return (ss_loss.detach(), info_max_loss.detach(), disc_loss_v.detach(), us_loss.detach(), grad_pen_loss.detach(),
                 disc_logit_loss.detach(), disc_weight_decay.detach(), acc_lb, acc_pi, acc_exp, acc_ulb)
 
     def _dagger_step(self, obs):

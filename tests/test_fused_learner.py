@@ -482,3 +482,86 @@ def test_fused_rollout_fills_the_storage_consistently():
     assert 0 < int(st.dones.sum()) < 24 * 512 // 4
     z0 = z.clone(); runner.alg.storage.clear(); runner._collect(False, True)
     assert not torch.equal(z0, (st.actions - st.mu) / st.sigma)                  # the device step counter moved the Philox key
+
+
+# ------------------------------------------------------------------ discriminator head losses
+def _disc_case(b_lb, b_pi, b_ulb, seed):
+    g = torch.Generator().manual_seed(seed)
+    B = b_lb + b_pi + b_ulb
+    c = torch.clamp(torch.softmax(2.0 * torch.randn(B, 5, generator=g), -1), 1e-20)
+    return dict(d=torch.randn(B, 1, generator=g), eps=torch.randn(B, 1, generator=g), c=c, label=torch.randint(0, 5, (b_lb,), generator=g),
+                pol_eps=torch.rand(b_pi, 1, generator=g) * 2 - 1, pol_c=torch.nn.functional.one_hot(torch.randint(0, 5, (b_pi,), generator=g), 5).float())
+
+
+DKW = dict(c_ss=1.0, c_disc=1.0, c_us=1.0)
+
+
+def _disc_reference(t, sizes, info_coef, dev="cpu"):
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import disc_loss_reference
+    d = t["d"].to(dev).clone().requires_grad_(True); e = t["eps"].to(dev).clone().requires_grad_(True); c = t["c"].to(dev).clone().requires_grad_(True)
+    loss, stats = disc_loss_reference(d, e, c, t["label"].to(dev), t["pol_eps"].to(dev), t["pol_c"].to(dev), *sizes, info_coef=info_coef, **DKW)
+    loss.backward()
+    return stats, d.grad, e.grad, c.grad
+
+
+def _disc_oracle(t, sizes, info_coef):
+    lib = load_oracle()
+    lib.qo_disc_loss.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
+    n = {k: np.ascontiguousarray(v.numpy()) for k, v in t.items()}
+    B = sum(sizes)
+    gd = np.zeros(B, np.float32); ge = np.zeros(B, np.float32); gc = np.zeros((B, 5), np.float32); out = np.zeros(16, np.float32)
+    ic = np.array([info_coef], np.float32)
+    p = lambda x: x.ctypes.data
+    assert lib.qo_disc_loss(p(n["d"]), p(n["eps"]), p(n["c"]), p(n["label"]), p(n["pol_eps"]), p(n["pol_c"]), *sizes, DKW["c_ss"], p(ic), DKW["c_disc"],
+                            DKW["c_us"], p(gd), p(ge), p(gc), p(out), None, 0, None) == 0
+    return out, gd, ge, gc
+
+
+@pytest.mark.parametrize("sizes", [(1, 1, 1), (37, 41, 29), (1228, 1228, 1228)])
+def test_disc_loss_oracle_matches_pytorch(sizes):
+    t = _disc_case(*sizes, seed=sum(sizes))
+    stats, gd, ge, gc = _disc_reference(t, sizes, 0.37)
+    out, od, oe, oc = _disc_oracle(t, sizes, 0.37)
+    assert np.allclose(out[:14], stats.numpy()[:14], rtol=2e-5, atol=2e-6)
+    assert np.allclose(od, gd.numpy().ravel(), rtol=1e-5, atol=1e-9) and np.allclose(oe, ge.numpy().ravel(), rtol=1e-5, atol=1e-9)
+    assert np.allclose(oc, gc.numpy(), rtol=2e-4, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [(1, 1, 1), (37, 41, 29), (1228, 1228, 1228)])
+def test_disc_loss_hip_matches_oracle_and_pytorch(sizes):
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import disc_loss
+    t = _disc_case(*sizes, seed=sum(sizes) + 1)
+    g = {k: v.cuda() for k, v in t.items()}
+    d = g["d"].clone().requires_grad_(True); e = g["eps"].clone().requires_grad_(True); c = g["c"].clone().requires_grad_(True)
+    ic = torch.tensor(0.37, device="cuda")
+    loss, stats = disc_loss(d, e, c, g["label"], g["pol_eps"], g["pol_c"], *sizes, info_coef_dev=ic, **DKW)
+    (2.0 * loss).backward()
+    out, od, oe, oc = _disc_oracle(t, sizes, 0.37)
+    assert np.allclose(stats.cpu().numpy()[:14], out[:14], rtol=2e-5, atol=2e-6)
+    assert np.allclose(d.grad.cpu().numpy().ravel(), 2 * od, rtol=1e-5, atol=1e-9) and np.allclose(e.grad.cpu().numpy().ravel(), 2 * oe, rtol=1e-5, atol=1e-9)
+    assert np.allclose(c.grad.cpu().numpy(), 2 * oc, rtol=3e-4, atol=1e-8)
+    rs, rd, re_, rc = _disc_reference(t, sizes, 0.37, dev="cuda")
+    assert np.allclose(stats.cpu().numpy()[:14], rs.cpu().numpy()[:14], rtol=2e-5, atol=2e-6)
+    assert np.allclose(c.grad.cpu().numpy(), 2 * rc.cpu().numpy(), rtol=3e-4, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_amp_iteration_with_and_without_fused_heads():
+    """one AMP iteration (80 discriminator steps, eager) through qa_disc_loss and through the eager head losses"""
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        env, args, tcfg = _make(256, True)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+        runner.alg.use_fused_loss = fused
+        runner.learn(1, init_at_random_ep_len=True)
+        res.append({k: v.clone() for k, v in runner.alg.disc.state_dict().items()})
+        res.append(env.prior_parameters.clone())
+    wa, pa, wb, pb = res
+    assert torch.allclose(pa, pb, atol=1e-5)
+    for k in wa:
+        d = (wa[k] - wb[k]).abs()
+        assert float((d > 2e-4 + 2e-3 * wb[k].abs()).float().mean()) < 0.01 and float(d.max()) < 5e-3, k
