@@ -42,6 +42,31 @@ class Discriminator(nn.Module):
         c = torch.softmax(self.classifier(x), -1)
         return self.linear(x), self.encoder_eps(x), torch.clamp(c, 1e-20, torch.inf)
 
+    def _relu_trunk(self):
+        mods = list(self.trunk)
+        ok = len(mods) % 2 == 0 and all(isinstance(mods[i], nn.Linear) and isinstance(mods[i + 1], nn.ReLU) for i in range(0, len(mods), 2))
+        return [mods[i] for i in range(0, len(mods), 2)] if ok else None
+
+    def forward_with_input_gradient(self, x, rows):
+        """Heads on all rows of x plus d logit / d x on the row slice `rows` -- the quantity the gradient penalty squares
+        (gail.py:487-492 obtains it with autograd.grad(..., create_graph=True)).  For this piecewise-linear trunk it is
+            g = W_1^T diag(m_1) W_2^T diag(m_2) ... w_out,      m_l = [layer l is active]
+        evaluated as a chain of small GEMMs on the slice only; the masks are constants (ReLU has no curvature), so
+        differentiating g w.r.t. the weights with ordinary autograd gives exactly the double-backward result, without
+        making the input a leaf, without a second-order graph over the whole batch."""
+        lins = self._relu_trunk()
+        assert lins is not None
+        h, masks = x, []
+        for lin in lins:
+            h = torch.relu(lin(h))
+            masks.append((h[rows] > 0).to(h.dtype))
+        c = torch.softmax(self.classifier(h), -1)
+        heads = (self.linear(h), self.encoder_eps(h), torch.clamp(c, 1e-20, torch.inf))
+        v = masks[-1] * self.linear.weight                      # (rows, H_last): d logit / d (last pre-activation)
+        for l in range(len(lins) - 1, 0, -1):
+            v = (v @ lins[l].weight) * masks[l - 1]
+        return heads, v @ lins[0].weight                        # (rows, input_dim)
+
     def prepare_input(self, obs_disc, task_obs_weight):
         """(B, disc_obs_len, 49) -> (B, 98): task dims weighted (discriminator.py:77-87)."""
         if self.env.task_obs_weight_decay:

@@ -453,8 +453,13 @@ class SSInfoGAIL:
         # (three forwards + a separate forward for the gradient penalty, gail.py:452-492): same functions of the
         # same parameters, so losses and gradients are identical up to GEMM rounding; half the launches.
         b_lb, b_pi = expert_lb.shape[0], policy_state.shape[0]
-        x_ulb = expert_ulb.clone().requires_grad_(True)
-        d_all, eps_all, c_all = self.disc(torch.cat([expert_lb, policy_state, x_ulb], dim=0))
+        analytic_gp = self.disc._relu_trunk() is not None
+        if analytic_gp:      # d logit / d x on the unlabelled rows as a chain of small GEMMs (discriminator.py), no second-order graph
+            (d_all, eps_all, c_all), g = self.disc.forward_with_input_gradient(torch.cat([expert_lb, policy_state, expert_ulb], dim=0),
+                                                                                slice(b_lb + b_pi, None))
+        else:
+            x_ulb = expert_ulb.clone().requires_grad_(True)
+            d_all, eps_all, c_all = self.disc(torch.cat([expert_lb, policy_state, x_ulb], dim=0))
         pred_c_lb = c_all[:b_lb]
         logits_pi, eps, pred_c = d_all[b_lb:b_lb + b_pi], eps_all[b_lb:b_lb + b_pi], c_all[b_lb:b_lb + b_pi]
         logits_exp, pred_c_ulb = d_all[b_lb + b_pi:], c_all[b_lb + b_pi:]
@@ -487,7 +492,8 @@ class SSInfoGAIL:
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
         disc_logit_loss = torch.sum(torch.square(self.disc.get_disc_logit_weights()))
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
-        g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
+        if not analytic_gp:
+            g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
         grad_pen_loss = torch.mean(torch.sum(torch.square(g), dim=-1))
         disc_weight_decay = torch.sum(torch.square(torch.cat(self.disc.get_disc_weights(), dim=-1)))
         rest = self.disc_grad_penalty * grad_pen_loss + self.disc_logit_reg * disc_logit_loss + self.disc_weight_decay * disc_weight_decay

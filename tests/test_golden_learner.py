@@ -152,3 +152,31 @@ def test_mocap_reorder_and_frame_blending():
                       mocap_category=cfg.env.mocap_category, default_dof_pos=q0, obs_scales=cfg.normalization.obs_scales)
     fr = ml.get_full_frame_at_time_batch(np.zeros(len(g["times"]), dtype=np.int64), g["times"], labeled=True)
     assert np.allclose(fr.numpy(), g["frames"], atol=2e-6)
+
+
+def test_analytic_input_gradient_equals_autograd_double_backward():
+    """Discriminator.forward_with_input_gradient vs autograd.grad(create_graph=True): value of d logit / d x AND the
+    gradient of its squared norm w.r.t. every weight (what the gradient penalty contributes to the step)"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms.discriminator import Discriminator
+
+    class _Env:
+        task_obs_weight_decay = False
+    torch.manual_seed(4)
+    disc = Discriminator(_Env(), 98, 49, 5, 0.02, "MSELoss", None, 1.0, 0.01, 0.2, 0.2, 2, 2, 0.0, [512, 256], "cpu")
+    x = torch.randn(90, 98)
+    rows = slice(60, None)
+    (d, e, c), g = disc.forward_with_input_gradient(x, rows)
+    pen = g.square().sum(-1).mean()
+    grads = torch.autograd.grad(pen, [p for p in disc.parameters()], allow_unused=True)
+    xr = x[rows].clone().requires_grad_(True)
+    d2, e2, c2 = disc(torch.cat([x[:60], xr]))
+    g2 = torch.autograd.grad(d2[60:], xr, grad_outputs=torch.ones_like(d2[60:]), create_graph=True)[0]
+    pen2 = g2.square().sum(-1).mean()
+    grads2 = torch.autograd.grad(pen2, [p for p in disc.parameters()], allow_unused=True)
+    assert torch.allclose(d, d2, atol=1e-6) and torch.allclose(c, c2, atol=1e-6) and torch.allclose(e, e2, atol=1e-6)
+    assert torch.allclose(g, g2, atol=1e-6) and float(pen) == pytest.approx(float(pen2), rel=1e-6)
+    for a, b in zip(grads, grads2):
+        if a is None:            # the penalty does not depend on the biases: no gradient here, exact zeros from the double backward
+            assert b is None or float(b.abs().max()) == 0.0
+        else:
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
