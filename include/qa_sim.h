@@ -308,6 +308,14 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
                  int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
                  float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* Discriminator input preparation (bbc/rsl_rl/algorithms/discriminator.py:77-87, utils.py:97-103): 1..3 row-major
+ * (rows[i], dim) fp32 device batches are written one under the other into out (sum rows, dim):
+ *   y = ((x * (task_mask[c] ? *task_weight_dev : 1)) * frame_mult[c] - (float)mean[c]) / sqrt((float)(var[c] + epsilon)), clipped to +-clip
+ * task_weight_dev == NULL skips the task weighting, mean == var == NULL the normalisation.  `batches` / `rows` are HOST arrays. */
+int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim, const float *task_mask,
+                    const float *frame_mult, const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip,
+                    float *out, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

@@ -1238,6 +1238,26 @@ int qo_disc_loss(const float *d, const float *eps, const float *c, const int64_t
     return QA_OK;
 }
 
+int qo_disc_prepare(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim, const float *task_mask,
+                    const float *frame_mult, const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip,
+                    float *out, void *stream) {
+    (void)stream;
+    if (!batches || !rows || !task_mask || !frame_mult || !out || num_batches <= 0 || num_batches > 3 || dim <= 0 || ((mean == NULL) != (var == NULL))) return QA_E_ARG;
+    int64_t o = 0;
+    for (int b = 0; b < num_batches; ++b) {
+        if (!batches[b] || rows[b] <= 0) return QA_E_ARG;
+        for (int64_t r = 0; r < rows[b]; ++r)
+            for (int c = 0; c < dim; ++c) {
+                float x = batches[b][r * dim + c];
+                if (task_weight_dev && task_mask[c] != 0.0f) x *= task_weight_dev[0];
+                x *= frame_mult[c];
+                if (mean) { float m = (float)mean[c], sd = sqrtf((float)(var[c] + (double)epsilon)); x = (x - m) / sd; x = x < -clip ? -clip : (x > clip ? clip : x); }
+                out[o++] = x;
+            }
+    }
+    return QA_OK;
+}
+
 /* ---- debug entry points used only by the physics known-answer tests ---- */
 /* mass matrix and bias for a configuration: ub = base twist (w; v) in the base frame */
 int qo_debug_dynamics(const float q[12], const float qd[12], const float ub[6], const float quat[4], double Mout[18 * 18], double hout[18]) {

@@ -116,6 +116,9 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "disc_loss")
     f.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
     f.restype = C.c_int
+    f = getattr(lib, prefix + "disc_prepare")
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    f.restype = C.c_int
     f = getattr(lib, prefix + "elu_backward_bias")
     f.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
@@ -124,7 +127,7 @@ def bind(lib, prefix):
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

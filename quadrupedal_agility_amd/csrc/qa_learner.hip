@@ -551,6 +551,32 @@ __global__ void qa_disc_finish_kernel(const float *partial, int nblocks, int b_l
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Discriminator input preparation (bbc/rsl_rl/algorithms/discriminator.py:77-87 + utils.py:97-103) for up to three
+// (rows_i, dim) batches written one under the other into one (sum rows_i, dim) matrix:
+//   y = clamp(((x * (task_mask ? w : 1)) * frame_mult - (float)mean) / sqrt((float)(var + eps)), -clip, clip)
+// Eager PyTorch: clone, two slice multiplies, a reshape multiply, the normaliser's four ops, per batch, plus the cat.
+struct PrepArgs { const float *src[3]; int64_t rows[3]; int k, dim; const float *task_mask, *frame_mult, *task_w; const double *mean, *var; float eps, clip; float *out; };
+
+__global__ void __launch_bounds__(256) qa_disc_prepare_kernel(PrepArgs a) {
+    const int64_t total = (a.rows[0] + a.rows[1] + a.rows[2]) * a.dim;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = i / a.dim; const int c = (int)(i - r * a.dim);
+    const float *src; int64_t rr = r;
+    if (rr < a.rows[0]) src = a.src[0];
+    else if ((rr -= a.rows[0]) < a.rows[1]) src = a.src[1];
+    else { rr -= a.rows[1]; src = a.src[2]; }
+    float x = src[rr * a.dim + c];
+    if (a.task_w && a.task_mask[c] != 0.f) x *= a.task_w[0];
+    x *= a.frame_mult[c];
+    if (a.mean) {
+        const float m = (float)a.mean[c], sd = sqrtf((float)(a.var[c] + (double)a.eps));
+        x = fminf(fmaxf((x - m) / sd, -a.clip), a.clip);
+    }
+    a.out[i] = x;
+}
+
 }  // namespace
 
 extern thread_local char qa_err_buf[512];
@@ -686,6 +712,25 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
     hipLaunchKernelGGL(qa_disc_finish_kernel, dim3(1), dim3(64), 0, st, (const float *)scratch, blocks, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim, const float *task_mask,
+                    const float *frame_mult, const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip,
+                    float *out, void *stream) {
+    if (!batches || !rows || !task_mask || !frame_mult || !out || num_batches <= 0 || num_batches > 3 || dim <= 0 || ((mean == nullptr) != (var == nullptr))) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_disc_prepare: bad argument"); return QA_E_ARG; }
+    PrepArgs a{};
+    int64_t total = 0;
+    for (int b = 0; b < num_batches; ++b) {
+        if (!batches[b] || rows[b] <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_prepare: empty batch"); return QA_E_ARG; }
+        a.src[b] = batches[b]; a.rows[b] = rows[b]; total += rows[b] * dim;
+    }
+    a.k = num_batches; a.dim = dim; a.task_mask = task_mask; a.frame_mult = frame_mult; a.task_w = task_weight_dev; a.mean = mean; a.var = var;
+    a.eps = epsilon; a.clip = clip; a.out = out;
+    hipLaunchKernelGGL(qa_disc_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_prepare: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

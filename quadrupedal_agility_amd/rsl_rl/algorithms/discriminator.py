@@ -36,6 +36,9 @@ class Discriminator(nn.Module):
         self.train()
         mult = torch.arange(disc_obs_len, dtype=torch.float32) * obs_disc_weight_step + 1
         self.register_buffer("_frame_mult", mult.view(1, -1, 1).repeat(1, 1, num_disc_obs).view(1, -1), persistent=False)
+        task = torch.zeros(disc_obs_len, num_disc_obs)
+        task[:, 3:9] = 1.0; task[:, 33:] = 1.0                 # the dims prepare_input() scales by task_obs_weight
+        self.register_buffer("_task_mask", task.view(-1).contiguous(), persistent=False)
 
     def forward(self, x):
         x = self.trunk(x)

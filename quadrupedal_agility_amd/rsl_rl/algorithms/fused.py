@@ -314,3 +314,24 @@ def disc_loss_reference(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b
         stats = torch.stack([loss.detach(), ss.detach(), info.detach(), disc.detach(), us.detach()] + acc)
         stats = torch.cat([stats, pred_c_ulb.mean(0), torch.zeros(2, device=d.device)])
     return loss, stats
+
+
+def disc_prepare(batches, task_mask, frame_mult, task_weight_dev, normalizer=None):
+    """[x_0; x_1; x_2] -> one (sum rows, dim) matrix with the discriminator's task weighting, frame weighting and (optionally)
+    the running-moment normalisation + clip applied: one launch (qa_disc_prepare)."""
+    lib = _capi.load_library()
+    bs = [_f32c(b.detach()) for b in batches]
+    k, d = len(bs), bs[0].shape[1]
+    assert 1 <= k <= 3 and all(b.dim() == 2 and b.shape[1] == d for b in bs)
+    ptrs = (C.c_void_p * k)(*[b.data_ptr() for b in bs])
+    rows = (C.c_int64 * k)(*[b.shape[0] for b in bs])
+    out = torch.empty(sum(b.shape[0] for b in bs), d, dtype=torch.float32, device=bs[0].device)
+    stream = C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+    mean = _ptr(normalizer.mean) if normalizer is not None else None
+    var = _ptr(normalizer.var) if normalizer is not None else None
+    rc = lib.qa_disc_prepare(ptrs, rows, k, d, _ptr(task_mask), _ptr(frame_mult), _ptr(task_weight_dev) if task_weight_dev is not None else None,
+                             mean, var, float(normalizer.epsilon) if normalizer is not None else 0.0,
+                             float(normalizer.clip_obs) if normalizer is not None else 0.0, _ptr(out), stream)
+    if rc != 0:
+        raise RuntimeError(f"qa_disc_prepare failed with code {rc}: {lib.qa_last_error().decode()}")
+    return out

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.optim as optim
 
-from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, disc_loss, ppo_loss
+from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, disc_loss, disc_prepare, ppo_loss
 from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
 
 
@@ -90,6 +90,7 @@ class SSInfoGAIL:
         self.use_fused_loss = True     # GPU: PPO objective + gradient as one HIP kernel (qa_ppo_loss); False = eager PyTorch ops
         self._ac_graph, self._recording_ac, self._priv_coef_dev = None, False, None
         self._dagger_graph, self._dagger_calls = None, 0
+        self._task_w_dev = None
         # recordings wait for one eager update since construction / checkpoint load: optimizer state and the pointer
         # tables of the fused optimizer steps must exist before a capture (building them copies from pageable host memory)
         self._warm_updates, self._dagger_warm = 0, 0
@@ -440,14 +441,30 @@ class SSInfoGAIL:
         expert_lb, label_lb = sample_disc_expert_lb
         expert_ulb = sample_disc_expert_ulb
         w = getattr(self.env, "task_obs_weight_dev", None)
-        w = self.env.task_obs_weight if w is None else w
-        prep = lambda x: self.disc.prepare_input(x.view(len(x), self.disc_obs_len, -1), w)
-        policy_state, expert_lb, expert_ulb = prep(policy_state), prep(expert_lb), prep(expert_ulb)
-        if self.disc_normalizer is not None:
-            with torch.no_grad():
-                policy_state = self.disc_normalizer.normalize_torch(policy_state, self.device)
-                expert_lb = self.disc_normalizer.normalize_torch(expert_lb, self.device)
-                expert_ulb = self.disc_normalizer.normalize_torch(expert_ulb, self.device)
+        fused_prep = (self._on_gpu and self.use_fused_loss and self.disc_normalizer is not None and hasattr(self.disc_normalizer, "count")
+                      and torch.is_tensor(getattr(self.disc_normalizer, "mean", None)) and self.disc.disc_obs_len * self.disc.num_disc_obs == policy_state.shape[-1])
+        if fused_prep:
+            # task weighting, frame weighting, normalisation + clip of the three batches, written as ONE (3B, 98) matrix
+            if w is None:
+                if self._task_w_dev is None:
+                    self._task_w_dev = torch.ones((), device=self.device)
+                if not torch.cuda.is_current_stream_capturing():
+                    self._task_w_dev.fill_(float(self.env.task_obs_weight))
+                w = self._task_w_dev
+            x_all = disc_prepare([expert_lb.reshape(len(expert_lb), -1), policy_state.reshape(len(policy_state), -1), expert_ulb.reshape(len(expert_ulb), -1)],
+                                 self.disc._task_mask, self.disc._frame_mult.view(-1), w if self.env.task_obs_weight_decay else None, self.disc_normalizer)
+            nl, npi = len(expert_lb), len(policy_state)
+            expert_lb, policy_state, expert_ulb = x_all[:nl], x_all[nl:nl + npi], x_all[nl + npi:]
+        else:
+            w = self.env.task_obs_weight if w is None else w
+            prep = lambda x: self.disc.prepare_input(x.view(len(x), self.disc_obs_len, -1), w)
+            policy_state, expert_lb, expert_ulb = prep(policy_state), prep(expert_lb), prep(expert_ulb)
+            if self.disc_normalizer is not None:
+                with torch.no_grad():
+                    policy_state = self.disc_normalizer.normalize_torch(policy_state, self.device)
+                    expert_lb = self.disc_normalizer.normalize_torch(expert_lb, self.device)
+                    expert_ulb = self.disc_normalizer.normalize_torch(expert_ulb, self.device)
+            x_all = None
 
         # ONE trunk pass over [labelled expert | policy | unlabelled expert] instead of the reference's four
         # (three forwards + a separate forward for the gradient penalty, gail.py:452-492): same functions of the
@@ -455,7 +472,7 @@ class SSInfoGAIL:
         b_lb, b_pi = expert_lb.shape[0], policy_state.shape[0]
         analytic_gp = self.disc._relu_trunk() is not None
         if analytic_gp:      # d logit / d x on the unlabelled rows as a chain of small GEMMs (discriminator.py), no second-order graph
-            (d_all, eps_all, c_all), g = self.disc.forward_with_input_gradient(torch.cat([expert_lb, policy_state, expert_ulb], dim=0),
+            (d_all, eps_all, c_all), g = self.disc.forward_with_input_gradient(x_all if x_all is not None else torch.cat([expert_lb, policy_state, expert_ulb], dim=0),
                                                                                 slice(b_lb + b_pi, None))
         else:
             x_ulb = expert_ulb.clone().requires_grad_(True)

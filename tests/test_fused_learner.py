@@ -565,3 +565,47 @@ def test_amp_iteration_with_and_without_fused_heads():
     for k in wa:
         d = (wa[k] - wb[k]).abs()
         assert float((d > 2e-4 + 2e-3 * wb[k].abs()).float().mean()) < 0.01 and float(d.max()) < 5e-3, k
+
+
+# ------------------------------------------------------------------ discriminator input preparation
+def _prep_case(seed):
+    g = torch.Generator().manual_seed(seed)
+    bs = [torch.randn(n, 98, generator=g) * 3 for n in (50, 61, 7)]
+    task = torch.zeros(2, 49); task[:, 3:9] = 1; task[:, 33:] = 1
+    fm = (torch.arange(2, dtype=torch.float32) * 0.5 + 1).view(-1, 1).repeat(1, 49)
+    mean = torch.randn(98, generator=g, dtype=torch.float64); var = torch.rand(98, generator=g, dtype=torch.float64) + 0.1
+    return bs, task.view(-1).contiguous(), fm.view(-1).contiguous(), torch.tensor(0.37), mean, var
+
+
+def _prep_eager(bs, task, fm, w, mean, var):
+    outs = []
+    for b in bs:
+        x = b.clone().view(len(b), 2, 49)
+        x[:, :, 3:9] *= w; x[:, :, 33:] *= w
+        x = x.reshape(len(b), -1) * fm
+        outs.append(torch.clamp((x - mean.float()) / torch.sqrt((var + 1e-4).float()), -10.0, 10.0))
+    return torch.cat(outs)
+
+
+def test_disc_prepare_oracle_matches_eager():
+    bs, task, fm, w, mean, var = _prep_case(3)
+    lib = load_oracle()
+    lib.qo_disc_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    n = [np.ascontiguousarray(b.numpy()) for b in bs]
+    ptrs = (C.c_void_p * 3)(*[x.ctypes.data for x in n]); rows = (C.c_int64 * 3)(*[x.shape[0] for x in n])
+    out = np.zeros((sum(x.shape[0] for x in n), 98), np.float32)
+    tn, fn, wn, mn, vn = task.numpy(), fm.numpy(), np.array([0.37], np.float32), mean.numpy(), var.numpy()
+    assert lib.qo_disc_prepare(ptrs, rows, 3, 98, tn.ctypes.data, fn.ctypes.data, wn.ctypes.data, mn.ctypes.data, vn.ctypes.data, 1e-4, 10.0, out.ctypes.data, None) == 0
+    assert np.allclose(out, _prep_eager(bs, task, fm, w, mean, var).numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_disc_prepare_hip_matches_eager():
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    from quadrupedal_agility_amd.rsl_rl.utils.utils import TorchNormalizer
+    bs, task, fm, w, mean, var = _prep_case(4)
+    nz = TorchNormalizer(98, "cuda"); nz.mean.copy_(mean); nz.var.copy_(var)
+    got = fused.disc_prepare([b.cuda() for b in bs], task.cuda(), fm.cuda(), w.cuda(), nz)
+    assert torch.allclose(got.cpu(), _prep_eager(bs, task, fm, w, mean, var), rtol=1e-6, atol=1e-6)
+    raw = fused.disc_prepare([b.cuda() for b in bs[:2]], task.cuda(), fm.cuda(), None, None)           # no task weight, no normaliser
+    assert torch.allclose(raw.cpu(), torch.cat([b * fm for b in bs[:2]]), rtol=1e-6, atol=1e-6)
