@@ -11,6 +11,10 @@
  *      (:1377-1396) -- in fp32, following the torch op order.  PINNED by golden vectors
  *      generated from the reference Python itself (tests/golden/, tools/gen_golden.py).
  *  (2) GAE of bbc/rsl_rl/storage/rollout_storage.py:97-111.  PINNED by golden vectors.
+ *  (2b) plain-C twins of the fused learner kernels (qo_ppo_loss, qo_elu_backward_bias, qo_normalizer_*, qo_clip_adam_step,
+ *      qo_rollout_act / _post, qo_disc_loss, qo_disc_prepare): each restates the PyTorch expression the reference's
+ *      learner evaluates (gail.py, utils.py, discriminator.py; cited at the functions).  PINNED by tests/test_fused_learner.py
+ *      against those eager expressions, which tests/test_golden_learner.py in turn pins to the reference's own numbers.
  *  (3) the physics the reference delegates to Isaac Gym / PhysX (legged_robot.py:103-106,
  *      129-131).  That binary is closed and absent, so this part follows the build's OWN
  *      stated model: floating base + 12 revolute DoF rigid-body dynamics
