@@ -335,3 +335,22 @@ def disc_prepare(batches, task_mask, frame_mult, task_weight_dev, normalizer=Non
     if rc != 0:
         raise RuntimeError(f"qa_disc_prepare failed with code {rc}: {lib.qa_last_error().decode()}")
     return out
+
+
+_GAE_SCRATCH = {}
+
+
+def gae(rewards, values, dones, last_values, returns, advantages, gamma, lam, normalize=True):
+    """qa_gae on (T, N[, 1]) ROCm tensors without an engine handle (the task-level learner has no simulator of its own)."""
+    T, N = rewards.shape[0], rewards.shape[1]
+    for x in (rewards, values, dones, last_values, returns, advantages):
+        assert x.is_cuda and x.is_contiguous()
+    assert dones.dtype == torch.uint8
+    scratch = _GAE_SCRATCH.get(rewards.device)
+    if scratch is None:
+        scratch = _GAE_SCRATCH[rewards.device] = torch.zeros(1024, dtype=torch.float32, device=rewards.device)
+    lib = _capi.load_library()
+    rc = lib.qa_gae(_ptr(rewards), _ptr(values), _ptr(dones), _ptr(last_values), _ptr(returns), _ptr(advantages), T, N, float(gamma),
+                    float(lam), int(bool(normalize)), _ptr(scratch), C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"qa_gae failed with code {rc}: {lib.qa_last_error().decode()}")
