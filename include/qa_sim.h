@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 5
+#define QA_ABI_VERSION 6
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -315,6 +315,45 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
 int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim, const float *task_mask,
                     const float *frame_mult, const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip,
                     float *out, void *stream);
+
+/* Policy inference: a chain of fully connected layers evaluated per 16-row tile with the activations in LDS (one launch
+ * for Estimator.forward + ActorCritic.update_distribution + ActorCritic.evaluate of SSInfoGAIL.act,
+ * bbc/rsl_rl/algorithms/gail.py:176-197; estimator.py:35-36; actor_critic.py:171-196,222-225 -- and the same modules
+ * behind play.py / the exported policy).  The chain is a HOST array of ops run in order on every tile:
+ *   QA_MLP_COPY : dst_buf[:, dst_col : dst_col+n] = src_buf[:, src_col : src_col+n]
+ *   QA_MLP_LAYER: y = src_buf[:, src_col : src_col+k] @ W^T + b, W (n,k) row-major as nn.Linear stores it; act 1 applies
+ *                 ELU(alpha 1).  y goes to dst_buf[:, dst_col : dst_col+n], or with dst_buf = -1 to rows of the global
+ *                 output `out_index`.
+ * Buffer 0 holds the tile of the input rows x (x_cols <= QA_MLP_BUF0_COLS) and is read-only; buffers 1..3 are scratch
+ * with QA_MLP_BUFn_COLS columns, zero at the start of the chain.  A layer's src_col must be a multiple of 4 and its
+ * source and destination buffers must differ.  fp32 throughout (fp32 MFMA accumulation; the K order differs from a
+ * library GEMM, so results agree with torch to rounding, not bit for bit).
+ * qa_mlp_pack repacks the layers' weights into `packed` (w_off / b_off: float offsets chosen by the caller, w_off a
+ * multiple of 4; qa_mlp_packed_floats gives the size the chosen offsets need); it must be re-run after the weights change.
+ * weights[i] / biases[i] are DEVICE pointers for op i (ignored for copies; a NULL bias is zero). */
+#define QA_MLP_COPY 0
+#define QA_MLP_LAYER 1
+#define QA_MLP_MAX_OPS 24
+#define QA_MLP_MAX_OUTPUTS 4
+#define QA_MLP_BUF0_COLS 672
+#define QA_MLP_BUF1_COLS 512
+#define QA_MLP_BUF2_COLS 256
+#define QA_MLP_BUF3_COLS 128
+typedef struct qa_mlp_op {
+    int32_t kind;
+    int32_t src_buf, src_col;
+    int32_t dst_buf, dst_col;
+    int32_t k, n;
+    int32_t act;
+    int32_t out_index;
+    int32_t reserved;
+    int64_t w_off, b_off;
+} qa_mlp_op;
+int64_t qa_mlp_packed_floats(const qa_mlp_op *ops, int32_t num_ops);
+int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weights, const float *const *biases, float *packed,
+                int64_t packed_floats, void *stream);
+int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops,
+                   const float *packed, float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream);
 
 const char *qa_last_error(void);
 int qa_abi_version(void);

@@ -12,7 +12,7 @@
  *      generated from the reference Python itself (tests/golden/, tools/gen_golden.py).
  *  (2) GAE of bbc/rsl_rl/storage/rollout_storage.py:97-111.  PINNED by golden vectors.
  *  (2b) plain-C twins of the fused learner kernels (qo_ppo_loss, qo_elu_backward_bias, qo_normalizer_*, qo_clip_adam_step,
- *      qo_rollout_act / _post, qo_disc_loss, qo_disc_prepare): each restates the PyTorch expression the reference's
+ *      qo_rollout_act / _post, qo_disc_loss, qo_disc_prepare, qo_mlp_*): each restates the PyTorch expression the reference's
  *      learner evaluates (gail.py, utils.py, discriminator.py; cited at the functions).  PINNED by tests/test_fused_learner.py
  *      against those eager expressions, which tests/test_golden_learner.py in turn pins to the reference's own numbers.
  *  (3) the physics the reference delegates to Isaac Gym / PhysX (legged_robot.py:103-106,
@@ -1260,6 +1260,75 @@ int qo_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
             }
     }
     return QA_OK;
+}
+
+/* ---- policy inference chain (include/qa_sim.h "policy inference"): Estimator.forward (bbc/rsl_rl/modules/estimator.py:35-36),
+ * ActorCritic.update_distribution / evaluate (actor_critic.py:171-196,222-225) as nn.Linear + ELU layers and column copies.
+ * The twin keeps the weights row-major inside `packed` (the caller's offsets leave room: the device layout is padded) and
+ * accumulates every dot product in double. */
+int64_t qo_mlp_packed_floats(const qa_mlp_op *ops, int32_t num_ops) {
+    if (!ops || num_ops <= 0) return -1;
+    int64_t end = 0;
+    for (int i = 0; i < num_ops; ++i) {
+        if (ops[i].kind != QA_MLP_LAYER) continue;
+        const int64_t nt = (ops[i].n + 15) / 16, per = (nt + 7) / 8, pf = per > 2 ? 4 : 8;     /* the device layout's padding */
+        const int64_t kb = ((ops[i].k + 15) / 16 + pf - 1) / pf * pf;
+        const int64_t we = ops[i].w_off + nt * kb * 256, be = ops[i].b_off + nt * 16;
+        if (we > end) end = we;
+        if (be > end) end = be;
+    }
+    return end;
+}
+
+int qo_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weights, const float *const *biases, float *packed, int64_t packed_floats,
+                void *stream) {
+    (void)stream;
+    if (!ops || num_ops <= 0 || num_ops > QA_MLP_MAX_OPS || !weights || !biases || !packed || packed_floats < qo_mlp_packed_floats(ops, num_ops)) return QA_E_ARG;
+    for (int i = 0; i < num_ops; ++i) {
+        if (ops[i].kind != QA_MLP_LAYER) continue;
+        if (!weights[i]) return QA_E_ARG;
+        memcpy(packed + ops[i].w_off, weights[i], sizeof(float) * (size_t)ops[i].n * (size_t)ops[i].k);
+        for (int c = 0; c < ops[i].n; ++c) packed[ops[i].b_off + c] = biases[i] ? biases[i][c] : 0.0f;
+    }
+    return QA_OK;
+}
+
+int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops, const float *packed,
+                   float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream) {
+    (void)stream;
+    static const int cols[4] = {QA_MLP_BUF0_COLS, QA_MLP_BUF1_COLS, QA_MLP_BUF2_COLS, QA_MLP_BUF3_COLS};
+    if (!x || !ops || !packed || rows <= 0 || x_cols <= 0 || x_cols > cols[0] || num_ops <= 0 || num_ops > QA_MLP_MAX_OPS || num_outs < 0 ||
+        num_outs > QA_MLP_MAX_OUTPUTS) return QA_E_ARG;
+    float *buf[4];
+    for (int b = 0; b < 4; ++b) buf[b] = (float *)malloc(sizeof(float) * (size_t)cols[b]);
+    int rc = QA_OK;
+    for (int64_t r = 0; r < rows && rc == QA_OK; ++r) {
+        for (int b = 0; b < 4; ++b) memset(buf[b], 0, sizeof(float) * (size_t)cols[b]);
+        memcpy(buf[0], x + r * x_stride, sizeof(float) * (size_t)x_cols);
+        for (int i = 0; i < num_ops; ++i) {
+            const qa_mlp_op *o = &ops[i];
+            if (o->src_buf < 0 || o->src_buf > 3 || o->dst_buf > 3 || o->n <= 0) { rc = QA_E_ARG; break; }
+            if (o->kind == QA_MLP_COPY) {
+                if (o->dst_buf < 1 || o->src_col + o->n > cols[o->src_buf] || o->dst_col + o->n > cols[o->dst_buf]) { rc = QA_E_ARG; break; }
+                memmove(buf[o->dst_buf] + o->dst_col, buf[o->src_buf] + o->src_col, sizeof(float) * (size_t)o->n);
+                continue;
+            }
+            if (o->kind != QA_MLP_LAYER || o->src_col + o->k > cols[o->src_buf] || o->dst_buf == o->src_buf || o->dst_buf == 0 ||
+                (o->dst_buf > 0 && o->dst_col + o->n > cols[o->dst_buf]) ||
+                (o->dst_buf < 0 && (o->out_index < 0 || o->out_index >= num_outs || !outs || !outs[o->out_index]))) { rc = QA_E_ARG; break; }
+            const float *w = packed + o->w_off, *bias = packed + o->b_off, *in = buf[o->src_buf] + o->src_col;
+            for (int c = 0; c < o->n; ++c) {
+                double acc = bias[c];
+                for (int k = 0; k < o->k; ++k) acc += (double)w[(int64_t)c * o->k + k] * (double)in[k];
+                float v = (float)acc;
+                if (o->act) v = v > 0.0f ? v : (float)(exp((double)v) - 1.0);
+                if (o->dst_buf > 0) buf[o->dst_buf][o->dst_col + c] = v;
+                else outs[o->out_index][r * out_strides[o->out_index] + c] = v;
+            }
+        }
+    }
+    for (int b = 0; b < 4; ++b) free(buf[b]);
+    return rc;
 }
 
 /* ---- debug entry points used only by the physics known-answer tests ---- */

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 5
+QA_ABI_VERSION = 6
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -119,15 +119,30 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "disc_prepare")
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     f.restype = C.c_int
+    f = getattr(lib, prefix + "mlp_packed_floats"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
+    f = getattr(lib, prefix + "mlp_pack"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "mlp_forward")
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    f.restype = C.c_int
     f = getattr(lib, prefix + "elu_backward_bias")
     f.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
     return lib
 
 
+class QaMlpOp(C.Structure):
+    """qa_mlp_op of include/qa_sim.h"""
+    _fields_ = [("kind", C.c_int32), ("src_buf", C.c_int32), ("src_col", C.c_int32), ("dst_buf", C.c_int32), ("dst_col", C.c_int32),
+                ("k", C.c_int32), ("n", C.c_int32), ("act", C.c_int32), ("out_index", C.c_int32), ("reserved", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+MLP_COPY, MLP_LAYER, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 24, 4
+MLP_BUF_COLS = (672, 512, 256, 128)
+
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

@@ -1,0 +1,301 @@
+/* Policy inference of the rollout as ONE launch per env step (include/qa_sim.h, "policy inference").
+ *
+ * What it replaces: SSInfoGAIL.act (bbc/rsl_rl/algorithms/gail.py:176-197) = Estimator.forward (estimator.py:35-36) +
+ * ActorCritic.update_distribution / evaluate (actor_critic.py:171-196,222-225): ~9 small GEMMs at M = num_envs, 10 ELU
+ * launches, 3 concatenations per env step.  At M = 4096 every one of those is launch-latency sized (5-30 us each).
+ *
+ * Shape of the work: a chain of fully connected layers over row-independent data.  One workgroup owns a tile of 16 rows
+ * and carries it through the WHOLE chain with the activations in LDS; only the weights are streamed (from L2: they are
+ * ~3 MB, shared by all workgroups) and only the heads' outputs go back to HBM.
+ *
+ *   - fp32 MFMA v_mfma_f32_16x16x4f32: 16 rows x 16 output columns per tile, K consumed 4 at a time.
+ *   - 8 wavefronts per workgroup (two per SIMD), each owning a contiguous range of output-column tiles of the current
+ *     layer (up to 4 tiles = 16 accumulator registers), all sharing the A fragment read from LDS.
+ *   - weights are repacked once per rollout (qa_mlp_pack) so that the B fragment of (k-block j, column tile t) is one
+ *     contiguous 1 KB run: lane l reads float4 #l.  Within a 16-wide k-block lane (n, kq) holds W[n][16j + 4kq + 0..3];
+ *     MFMA step s of the block uses element s of that float4 as "k = kq" -- a permutation of K that A follows, so the
+ *     sum is the same.
+ *   - 256 workgroups at 4096 envs = one per CU.
+ *
+ * Roofline: MFMA-bound.  1.488 MFLOP per row (bench.py ROLLOUT_FLOPS_PER_SAMPLE); a 16-row tile on one CU at the fp32
+ * dense peak (256 FLOP/cycle/CU) needs 93 k cycles = 39 us.  L2 -> CU weight traffic is 3 MB per workgroup.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/qa_sim.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int MLP_ROWS = 16;
+constexpr int MLP_WAVES = 8;      /* two per SIMD: one issues MFMAs while the other waits for its weight fragments */
+/* LDS buffers (floats per row incl. padding; strides = 4 mod 32 so the 16 rows of an A read fall on distinct bank groups) */
+constexpr int MLP_NBUF = 4;
+constexpr int S0 = QA_MLP_BUF0_COLS + 4, S1 = QA_MLP_BUF1_COLS + 4, S2 = QA_MLP_BUF2_COLS + 4, S3 = QA_MLP_BUF3_COLS + 4;
+constexpr int B1 = MLP_ROWS * S0, B2 = B1 + MLP_ROWS * S1, B3 = B2 + MLP_ROWS * S2;
+constexpr int MLP_LDS_FLOATS = B3 + MLP_ROWS * S3;
+__device__ __forceinline__ int mlp_stride(int b) { return b == 0 ? S0 : b == 1 ? S1 : b == 2 ? S2 : S3; }
+__device__ __forceinline__ int mlp_base(int b) { return b == 0 ? 0 : b == 1 ? B1 : b == 2 ? B2 : B3; }
+
+/* column tiles per wavefront for a layer of nt tiles, and the prefetch depth that goes with it */
+__host__ __device__ constexpr int mlp_tpw(int nt) { return (nt + MLP_WAVES - 1) / MLP_WAVES <= 1 ? 1 : (nt + MLP_WAVES - 1) / MLP_WAVES <= 2 ? 2 : 4; }
+__host__ __device__ constexpr int mlp_pf(int tpw) { return tpw >= 4 ? 4 : 8; }
+/* k-blocks of 16 a layer is stored with: rounded up to the prefetch depth so the pipelined loop has no remainder */
+__host__ __device__ constexpr int mlp_kb(int k, int n) { return ((k + 15) / 16 + mlp_pf(mlp_tpw((n + 15) / 16)) - 1) / mlp_pf(mlp_tpw((n + 15) / 16)) * mlp_pf(mlp_tpw((n + 15) / 16)); }
+
+struct MlpDevOp {
+    int32_t kind, src_buf, src_col, dst_buf, dst_col, k, n, act, out_index, nt, kb, tpw;
+    int64_t w_off, b_off;
+};
+
+struct MlpArgs {
+    const float *x;
+    int64_t x_stride;
+    int32_t rows, x_cols, num_ops;
+    const float *packed;
+    float *out[QA_MLP_MAX_OUTPUTS];
+    int64_t out_stride[QA_MLP_MAX_OUTPUTS];
+    MlpDevOp ops[QA_MLP_MAX_OPS];
+};
+
+struct PackLayer { const float *w, *b; int32_t n, k; int64_t w_off, b_off; };
+struct PackArgs { PackLayer l[QA_MLP_MAX_OPS]; int32_t num; float *packed; };
+
+/* packed[w_off + ((j * nt + t) * 64 + lane) * 4 + s] = W[16 t + lane % 16][16 j + 4 (lane / 16) + s], zero outside (n, k) */
+__global__ void qa_mlp_pack_kernel(PackArgs a) {
+    const PackLayer L = a.l[blockIdx.y];
+    const int nt = (L.n + 15) / 16, kb = mlp_kb(L.k, L.n);
+    const int64_t total = (int64_t)nt * kb * 256;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const int64_t jt = i >> 8;
+        const int t = (int)(jt % nt), j = (int)(jt / nt);
+        const int row = 16 * t + (lane & 15), col = 16 * j + 4 * (lane >> 4) + s;
+        a.packed[L.w_off + i] = (row < L.n && col < L.k) ? L.w[(int64_t)row * L.k + col] : 0.f;
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) a.packed[L.b_off + i] = (i < L.n && L.b) ? L.b[i] : 0.f;
+}
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 1.f; }
+
+/* one layer for this wavefront: TPW column tiles starting at tile t0.
+ * The weight fragments are fetched PF-1 k-blocks ahead of their use into a ring of PF register stages (the L2 round trip is
+ * several hundred cycles; one k-block of MFMAs is 128 * TPW cycles).  The sched_barriers keep the compiler from sinking the
+ * prefetch back down to its use, which it otherwise does to shorten live ranges. */
+template <int TPW>
+__device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packed, float *lds, const MlpArgs &a, int row0, int wave, int lane) {
+    constexpr int PF = mlp_pf(TPW);
+    const int nt = op.nt, kb = op.kb;
+    const int t0 = wave * TPW;
+    if (t0 >= nt) return;
+    const int m = lane & 15, kq = lane >> 4;
+    const float *src = lds + mlp_base(op.src_buf) + m * mlp_stride(op.src_buf) + op.src_col + 4 * kq;
+    const f4 *wp = reinterpret_cast<const f4 *>(packed + op.w_off) + lane;
+    int toff[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) toff[i] = (t0 + i < nt ? t0 + i : nt - 1) * 64;
+    const int jstride = nt * 64;
+    f4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float bias[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) bias[i] = packed[op.b_off + (toff[i] >> 2) + m];       /* padded to whole tiles by qa_mlp_pack */
+    f4 bw[PF][TPW], av[PF];
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
+        const int j = u < kb ? u : kb - 1;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) bw[u][i] = wp[j * jstride + toff[i]];
+        av[u] = *reinterpret_cast<const f4 *>(src + 16 * j);
+        __builtin_amdgcn_sched_barrier(0);          /* same issue order as inside the loop, so the wait counts at the loop head stay exact */
+    }
+    for (int j0 = 0; j0 < kb; j0 += PF) {          /* kb is a multiple of PF (zero k-blocks appended by qa_mlp_pack) */
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int j = j0 + u;
+            {
+                constexpr int PFm1 = PF - 1;
+                const int jp = j + PFm1 < kb ? j + PFm1 : kb - 1;
+                const int st = (u + PFm1) % PF;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) bw[st][i] = wp[jp * jstride + toff[i]];
+                av[st] = *reinterpret_cast<const f4 *>(src + 16 * jp);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s4], bw[u][i][s4], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    /* D layout: register r of lane l = D[row 4 (l / 16) + r][column l % 16] */
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        if (t0 + i >= nt) break;
+        const int col = (t0 + i) * 16 + m;
+        if (col >= op.n) continue;
+        const float bv = bias[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[i][r] + bv;
+            if (op.act) v = elu1(v);
+            const int row = 4 * kq + r;
+            if (op.dst_buf >= 0) lds[mlp_base(op.dst_buf) + row * mlp_stride(op.dst_buf) + op.dst_col + col] = v;
+            else if (row0 + row < a.rows) a.out[op.out_index][(int64_t)(row0 + row) * a.out_stride[op.out_index] + col] = v;
+        }
+    }
+}
+
+/* -DQA_MLP_PROF (tools/mlp_profile.py): s_memtime after every op of workgroup 0 into output 3, read as int64[] */
+#ifdef QA_MLP_PROF
+#define MLP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long *>(a.out[3])[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MLP_STAMP(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[MLP_LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * MLP_ROWS;
+    MLP_STAMP(QA_MLP_MAX_OPS + 1);
+    /* scratch buffers start at zero (padding columns are read against zero weights and must be finite) */
+    for (int i = mlp_base(1) + tid; i < MLP_LDS_FLOATS; i += MLP_WAVES * 64) lds[i] = 0.f;
+    {   /* input tile: one wavefront per 4 rows, coalesced along the row; every load of a row is issued before the first store */
+        constexpr int PER = (S0 + 63) / 64;
+        for (int r = wave; r < MLP_ROWS; r += MLP_WAVES) {
+            const bool live = row0 + r < a.rows;
+            const float *xr = a.x + (int64_t)(row0 + r) * a.x_stride;
+            float v[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int c = lane + 64 * q; v[q] = (live && c < a.x_cols) ? xr[c] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int c = lane + 64 * q; if (c < S0) lds[r * S0 + c] = v[q]; }
+        }
+    }
+    __syncthreads();
+    MLP_STAMP(0);
+    MlpDevOp op = a.ops[0];
+    for (int o = 0; o < a.num_ops; ++o) {
+        const MlpDevOp nxt = a.ops[o + 1 < a.num_ops ? o + 1 : o];      /* scalar loads of the next descriptor fly during this op */
+        if (op.kind == QA_MLP_COPY) {
+            const int ss = mlp_stride(op.src_buf), ds = mlp_stride(op.dst_buf);
+            for (int i = tid; i < MLP_ROWS * op.n; i += MLP_WAVES * 64) {
+                const int r = i / op.n, c = i - r * op.n;
+                lds[mlp_base(op.dst_buf) + r * ds + op.dst_col + c] = lds[mlp_base(op.src_buf) + r * ss + op.src_col + c];
+            }
+        } else {
+            switch (op.tpw) {
+                case 1: mlp_layer<1>(op, a.packed, lds, a, row0, wave, lane); break;
+                case 2: mlp_layer<2>(op, a.packed, lds, a, row0, wave, lane); break;
+                default: mlp_layer<4>(op, a.packed, lds, a, row0, wave, lane); break;
+            }
+        }
+        __syncthreads();
+        MLP_STAMP(o + 1);
+        op = nxt;
+    }
+}
+
+int lds_base(int b) { return b == 0 ? 0 : b == 1 ? B1 : b == 2 ? B2 : B3; }
+int buf_cols(int b) { return b == 0 ? QA_MLP_BUF0_COLS : b == 1 ? QA_MLP_BUF1_COLS : b == 2 ? QA_MLP_BUF2_COLS : QA_MLP_BUF3_COLS; }
+
+}  // namespace
+
+#ifdef QA_MLP_PROF
+thread_local char qa_err_buf[512];
+#else
+extern thread_local char qa_err_buf[512];
+#endif
+#define g_perr qa_err_buf
+
+extern "C" {
+
+int64_t qa_mlp_packed_floats(const qa_mlp_op *ops, int32_t num_ops) {
+    if (!ops || num_ops <= 0) return -1;
+    int64_t end = 0;
+    for (int i = 0; i < num_ops; ++i) {
+        if (ops[i].kind != QA_MLP_LAYER) continue;
+        const int64_t nt = (ops[i].n + 15) / 16, kb = mlp_kb(ops[i].k, ops[i].n);
+        const int64_t we = ops[i].w_off + nt * kb * 256, be = ops[i].b_off + nt * 16;
+        end = we > end ? we : end;
+        end = be > end ? be : end;
+    }
+    return end;
+}
+
+static int mlp_check(const qa_mlp_op *ops, int32_t num_ops, const char *who) {
+    if (!ops || num_ops <= 0 || num_ops > QA_MLP_MAX_OPS) { snprintf(g_perr, sizeof(g_perr), "%s: 1..%d ops expected", who, QA_MLP_MAX_OPS); return QA_E_ARG; }
+    for (int i = 0; i < num_ops; ++i) {
+        const qa_mlp_op &o = ops[i];
+        const bool layer = o.kind == QA_MLP_LAYER;
+        bool ok = (layer || o.kind == QA_MLP_COPY) && o.src_buf >= 0 && o.src_buf < MLP_NBUF && o.src_col >= 0 && o.n > 0;
+        if (ok && layer) {
+            const int kpad = mlp_kb(o.k, o.n) * 16;         /* columns the layer reads (beyond k: against zero weights) */
+            /* reading past the row's padding lands in the next row / buffer (finite activations, zero weights): allowed while inside LDS */
+            ok = o.k > 0 && (o.src_col % 4) == 0 && o.src_col + o.k <= buf_cols(o.src_buf) + 4 &&
+                 lds_base(o.src_buf) + (MLP_ROWS - 1) * (buf_cols(o.src_buf) + 4) + o.src_col + kpad <= MLP_LDS_FLOATS && o.w_off >= 0 && o.b_off >= 0 && (o.w_off % 4) == 0 &&
+                 (o.n + 15) / 16 <= 4 * MLP_WAVES;
+            if (ok && o.dst_buf >= 0) ok = o.dst_buf > 0 && o.dst_buf < MLP_NBUF && o.dst_buf != o.src_buf && o.dst_col >= 0 && o.dst_col + o.n <= buf_cols(o.dst_buf);
+            if (ok && o.dst_buf < 0) ok = o.out_index >= 0 && o.out_index < QA_MLP_MAX_OUTPUTS;
+        } else if (ok) {
+            ok = o.src_col + o.n <= buf_cols(o.src_buf) && o.dst_buf > 0 && o.dst_buf < MLP_NBUF && o.dst_col >= 0 && o.dst_col + o.n <= buf_cols(o.dst_buf) &&
+                 (o.dst_buf != o.src_buf || o.dst_col >= o.src_col + o.n || o.src_col >= o.dst_col + o.n);
+        }
+        if (!ok) { snprintf(g_perr, sizeof(g_perr), "%s: op %d is malformed (kind %d, src %d@%d, dst %d@%d, k %d, n %d)", who, i, o.kind, o.src_buf, o.src_col,
+                            o.dst_buf, o.dst_col, o.k, o.n); return QA_E_ARG; }
+    }
+    return QA_OK;
+}
+
+int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weights, const float *const *biases, float *packed, int64_t packed_floats,
+                void *stream) {
+    int rc = mlp_check(ops, num_ops, "qa_mlp_pack");
+    if (rc != QA_OK) return rc;
+    if (!weights || !biases || !packed || packed_floats < qa_mlp_packed_floats(ops, num_ops)) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_pack: bad argument"); return QA_E_ARG; }
+    PackArgs a{};
+    a.packed = packed;
+    for (int i = 0; i < num_ops; ++i) {
+        if (ops[i].kind != QA_MLP_LAYER) continue;
+        if (!weights[i]) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_pack: op %d has no weight", i); return QA_E_ARG; }
+        a.l[a.num++] = PackLayer{weights[i], biases[i], ops[i].n, ops[i].k, ops[i].w_off, ops[i].b_off};
+    }
+    if (a.num == 0) return QA_OK;
+    hipLaunchKernelGGL(qa_mlp_pack_kernel, dim3(64, a.num), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_pack: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops, const float *packed,
+                   float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream) {
+    int rc = mlp_check(ops, num_ops, "qa_mlp_forward");
+    if (rc != QA_OK) return rc;
+    if (!x || !packed || rows <= 0 || x_cols <= 0 || x_cols > QA_MLP_BUF0_COLS || x_stride < x_cols || num_outs < 0 || num_outs > QA_MLP_MAX_OUTPUTS ||
+        (num_outs > 0 && (!outs || !out_strides))) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: bad argument"); return QA_E_ARG; }
+    MlpArgs a{};
+    a.x = x; a.x_stride = x_stride; a.rows = rows; a.x_cols = x_cols; a.num_ops = num_ops; a.packed = packed;
+    for (int i = 0; i < num_outs; ++i) { a.out[i] = outs[i]; a.out_stride[i] = out_strides[i]; }
+    for (int i = 0; i < num_ops; ++i) {
+        const qa_mlp_op &o = ops[i];
+        MlpDevOp &d = a.ops[i];
+        d.kind = o.kind; d.src_buf = o.src_buf; d.src_col = o.src_col; d.dst_buf = o.dst_buf; d.dst_col = o.dst_col; d.k = o.k; d.n = o.n; d.act = o.act;
+        d.out_index = o.out_index; d.w_off = o.w_off; d.b_off = o.b_off;
+        if (o.kind == QA_MLP_LAYER) {
+            d.nt = (o.n + 15) / 16; d.kb = mlp_kb(o.k, o.n); d.tpw = mlp_tpw(d.nt);
+            if (o.dst_buf < 0 && (o.out_index >= num_outs || !outs[o.out_index] || out_strides[o.out_index] < o.n)) {
+                snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: op %d writes output %d which is missing or too narrow", i, o.out_index); return QA_E_ARG; }
+        }
+    }
+    hipLaunchKernelGGL(qa_mlp_forward_kernel, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+}  // extern "C"

@@ -354,3 +354,153 @@ def gae(rewards, values, dones, last_values, returns, advantages, gamma, lam, no
                     float(lam), int(bool(normalize)), _ptr(scratch), C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"qa_gae failed with code {rc}: {lib.qa_last_error().decode()}")
+
+
+class PolicyChain:
+    """SSInfoGAIL.act's network half -- Estimator.forward, the privileged-latent encoder, the actor trunk + head and the
+    critic trunk + head (gail.py:176-197) -- as ONE launch: `qa_mlp_forward` carries each 16-row tile through every
+    layer with the activations in LDS.  `describe()` turns the modules into the op list of include/qa_sim.h; `pack()`
+    repacks the weights (once per rollout: they only change in update()); `forward(obs)` -> (mean (N,A), value (N,1)).
+
+    Only the privileged-encoder variant (hist_encoding=False) is described: the history-encoder rollouts (every
+    dagger_update_freq-th iteration) keep the GEMM path."""
+
+    BUF_COLS = _capi.MLP_BUF_COLS
+
+    def __init__(self, ops, params, num_actions):
+        self.n_ops = len(ops)
+        self.ops = (_capi.QaMlpOp * self.n_ops)(*ops)
+        self.params = params                      # per op: (weight, bias) tensors or None
+        self.num_actions = num_actions
+        self.packed = None
+        self._out = {}
+
+    # ---------------------------------------------------------------- description (host logic, no device access)
+    @staticmethod
+    def k_blocks(k, n):
+        """16-wide k-blocks a layer is stored with (qa_policy.hip mlp_kb): rounded up to the kernel's prefetch depth"""
+        per = ((n + 15) // 16 + 7) // 8
+        pf = 4 if per > 2 else 8
+        return ((k + 15) // 16 + pf - 1) // pf * pf
+
+    @staticmethod
+    def _linears(seq):
+        """[(Linear, elu?)] of an nn.Sequential of Linear / ELU(alpha=1) modules, None for anything else"""
+        import torch.nn as nn
+        mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
+        out = []
+        for m in mods:
+            if isinstance(m, nn.Linear):
+                out.append([m, 0])
+            elif isinstance(m, nn.ELU) and m.alpha == 1.0 and out and out[-1][1] == 0:
+                out[-1][1] = 1
+            else:
+                return None
+        return out
+
+    @classmethod
+    def describe(cls, actor_critic, estimator, use_estimator):
+        """-> PolicyChain, or None when the modules are not plain Linear/ELU stacks that fit the kernel's buffers"""
+        import torch.nn as nn
+        ac = actor_critic
+        sl = ac._sl
+        n_prop, n_exp, n_lat = ac.num_prop, ac.num_explicit, ac.num_latent
+        cmd0 = sl[4].start
+        n_obs = ac.num_critic_obs
+        n_cmd = n_obs - cmd0
+        n_in = n_prop + n_exp + n_lat + n_cmd
+        stacks = dict(actor=cls._linears(ac.actor_trunk), critic=cls._linears(ac.critic_trunk))
+        if ac.train_with_estimated_latent and not isinstance(ac.priv_encoder, nn.Identity):
+            stacks["priv"] = cls._linears(ac.priv_encoder)
+        if use_estimator:
+            stacks["est"] = cls._linears(estimator.estimator)
+        if any(v is None for v in stacks.values()) or n_obs > cls.BUF_COLS[0] or n_in > cls.BUF_COLS[3] or cmd0 + n_cmd != n_obs:
+            return None
+        stacks["actor"] = stacks["actor"] + [[ac.actor_head, 0]]
+        stacks["critic"] = stacks["critic"] + [[ac.critic_head, 0]]
+        ops, params, woff = [], [], [0]
+        Z = 3
+
+        def copy(src, scol, dst, dcol, n):
+            ops.append(_capi.QaMlpOp(kind=_capi.MLP_COPY, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=0, n=n))
+            params.append(None)
+
+        def chain(layers, src, scol, k, final, reserved):
+            """layers through scratch buffers; `final` = ("buf", b, col) or ("out", index)"""
+            for i, (lin, act) in enumerate(layers):
+                if lin.in_features != k:
+                    return False
+                n = lin.out_features
+                if i == len(layers) - 1:
+                    dst, dcol, oi = (final[1], final[2], 0) if final[0] == "buf" else (-1, 0, final[1])
+                else:
+                    fit = [b for b in (3, 2, 1) if b != src and b not in reserved and cls.BUF_COLS[b] >= n]
+                    if not fit:
+                        return False
+                    dst, dcol, oi = fit[0], 0, 0
+                if dst == src:
+                    return False
+                nt, kb = (n + 15) // 16, cls.k_blocks(k, n)
+                base = sum(16 * (c + 4) for c in cls.BUF_COLS[:src])
+                if base + 15 * (cls.BUF_COLS[src] + 4) + scol + 16 * kb > sum(16 * (c + 4) for c in cls.BUF_COLS):
+                    return False            # the padded k-blocks would be read from beyond the kernel's LDS
+                w_off = woff[0]; b_off = w_off + nt * kb * 256; woff[0] = b_off + nt * 16
+                ops.append(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=k, n=n, act=act,
+                                         out_index=oi, w_off=w_off, b_off=b_off))
+                params.append((lin.weight, lin.bias))
+                src, scol, k = dst, 0, n
+            return True
+
+        ok = True
+        copy(0, 0, Z, 0, n_prop)
+        if use_estimator:
+            ok &= chain(stacks["est"], 0, 0, n_prop, ("buf", Z, n_prop), {Z}) and stacks["est"][-1][0].out_features == n_exp
+        else:
+            copy(0, n_prop, Z, n_prop, n_exp)
+        if "priv" in stacks:
+            copy(0, n_prop + n_exp, 2, 0, n_lat)                     # to column 0: a layer's source must be 16-byte aligned
+            ok &= chain(stacks["priv"], 2, 0, n_lat, ("buf", Z, n_prop + n_exp), {Z}) and stacks["priv"][-1][0].out_features == n_lat
+        else:
+            copy(0, n_prop + n_exp, Z, n_prop + n_exp, n_lat)
+        copy(0, cmd0, Z, n_prop + n_exp + n_lat, n_cmd)
+        ok &= chain(stacks["actor"], Z, 0, n_in, ("out", 0), set())
+        ok &= chain(stacks["critic"], 0, 0, n_obs, ("out", 1), set())
+        if not ok or len(ops) > _capi.MLP_MAX_OPS or stacks["critic"][-1][0].out_features != 1:
+            return None
+        self = cls(ops, params, stacks["actor"][-1][0].out_features)
+        self.packed_floats = woff[0]
+        return self
+
+    # ---------------------------------------------------------------- device side
+    def _ptr_arrays(self):
+        w = (C.c_void_p * self.n_ops)(*[(p[0].data_ptr() if p else None) for p in self.params])
+        b = (C.c_void_p * self.n_ops)(*[(p[1].data_ptr() if p and p[1] is not None else None) for p in self.params])
+        return w, b
+
+    def pack(self):
+        dev = next(p[0] for p in self.params if p).device
+        if self.packed is None:
+            self.packed = torch.zeros(self.packed_floats, dtype=torch.float32, device=dev)
+        for p in self.params:
+            if p and not (p[0].is_cuda and p[0].is_contiguous() and p[0].dtype == torch.float32):
+                raise RuntimeError("PolicyChain: parameters must be contiguous fp32 ROCm tensors")
+        w, b = self._ptr_arrays()
+        lib = _capi.load_library()
+        rc = lib.qa_mlp_pack(self.ops, self.n_ops, w, b, _ptr(self.packed), self.packed_floats, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"qa_mlp_pack failed with code {rc}: {lib.qa_last_error().decode()}")
+
+    def forward(self, obs):
+        n = obs.shape[0]
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.stride(1) == 1 and self.packed is not None
+        out = self._out.get(n)
+        if out is None:
+            mean = torch.zeros(n, self.num_actions, device=obs.device)
+            value = torch.zeros(n, 1, device=obs.device)
+            out = self._out[n] = (mean, value, (C.c_void_p * 2)(mean.data_ptr(), value.data_ptr()), (C.c_int64 * 2)(self.num_actions, 1))
+        lib = _capi.load_library()
+        rc = lib.qa_mlp_forward(_ptr(obs), obs.stride(0), n, obs.shape[1], self.ops, self.n_ops, _ptr(self.packed), out[2], out[3], 2,
+                                C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"qa_mlp_forward failed with code {rc}: {lib.qa_last_error().decode()}")
+        return out[0], out[1]

@@ -124,8 +124,21 @@ class SSInfoGAIL:
         self.actor_critic.train()
 
     # ------------------------------------------------------------------ rollout side
-    def act(self, obs, critic_obs, hist_encoding=False):
+    def act(self, obs, critic_obs, hist_encoding=False, chain=None):
+        """gail.py:176-197.  `chain` (fused.PolicyChain, privileged-encoder variant only) evaluates the estimator, encoder,
+        actor and critic in one launch; the sampling and the transition record are the same either way."""
         tr = self.transition
+        if chain is not None and not hist_encoding:
+            ac = self.actor_critic
+            mean, value = chain.forward(obs)
+            ac.distribution = torch.distributions.Normal(mean, mean * 0.0 + ac.std, validate_args=False)
+            with torch.no_grad():
+                tr.actions = mean + ac.distribution.scale * torch.randn_like(mean)
+            tr.values = value
+            tr.actions_log_prob = ac.get_actions_log_prob(tr.actions).detach()
+            tr.action_mean, tr.action_sigma = mean, ac.distribution.scale.detach()
+            tr.observations, tr.critic_observations = obs, critic_obs
+            return tr.actions
         if self.train_with_estimated_explicit:
             a, b = self.num_prop, self.num_prop + self.num_explicit
             est = self.estimator(obs[:, :a])

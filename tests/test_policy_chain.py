@@ -1,0 +1,145 @@
+"""qa_mlp_pack / qa_mlp_forward (policy inference as one launch) against the modules they stand for.
+
+CPU: PolicyChain.describe() + the oracle's plain-C twin (qo_mlp_*) vs. Estimator / ActorCritic evaluated by torch --
+pins the op list (host logic) and the twin.  GPU: the HIP kernel vs. the twin and vs. torch on the device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from quadrupedal_agility_amd import _capi
+from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
+from quadrupedal_agility_amd.rsl_rl.modules import ActorCritic, Estimator
+
+DIMS = dict(num_prop=57, num_hist=10, num_explicit=4, num_latent=29, num_command=11)
+
+
+def modules(seed=0, priv_dims=(64,), hidden=(512, 256, 128), est_hidden=(128, 64)):
+    torch.manual_seed(seed)
+    n_obs = 57 + 4 + 29 + 570 + 11
+    ac = ActorCritic(57 + 4 + 29 + 11, n_obs, 12, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden),
+                     priv_encoder_dims=list(priv_dims), activation="elu", train_with_estimated_latent=True, **DIMS)
+    est = Estimator(57, 4, hidden_dims=list(est_hidden))
+    with torch.no_grad():
+        for p in list(ac.parameters()) + list(est.parameters()):
+            if p.dim() == 1:
+                p.uniform_(-0.2, 0.2)          # biases are zero-initialised in the actor trunk: make them count
+    return ac, est, n_obs
+
+
+def torch_reference(ac, est, obs, use_estimator):
+    with torch.no_grad():
+        x = torch.cat([obs[:, :57], est(obs[:, :57]), obs[:, 61:]], dim=-1) if use_estimator else obs
+        return ac._actor_mean(x, False), ac.evaluate(obs)
+
+
+def run_oracle(chain, obs):
+    from tests.oracle_lib import load_oracle
+    lib = load_oracle()
+    n = obs.shape[0]
+    w = (C.c_void_p * chain.n_ops)(*[(p[0].data_ptr() if p else None) for p in chain.params])
+    b = (C.c_void_p * chain.n_ops)(*[(p[1].data_ptr() if p and p[1] is not None else None) for p in chain.params])
+    packed = np.zeros(chain.packed_floats, np.float32)
+    assert lib.qo_mlp_packed_floats(chain.ops, chain.n_ops) == chain.packed_floats
+    assert lib.qo_mlp_pack(chain.ops, chain.n_ops, w, b, packed.ctypes.data, packed.size, None) == 0
+    mean, value = np.zeros((n, 12), np.float32), np.zeros((n, 1), np.float32)
+    x = np.ascontiguousarray(obs.numpy())
+    outs = (C.c_void_p * 2)(mean.ctypes.data, value.ctypes.data)
+    strides = (C.c_int64 * 2)(12, 1)
+    assert lib.qo_mlp_forward(x.ctypes.data, x.shape[1], n, x.shape[1], chain.ops, chain.n_ops, packed.ctypes.data, outs, strides, 2, None) == 0
+    return mean, value
+
+
+@pytest.mark.parametrize("use_estimator", [True, False])
+def test_description_and_twin_match_torch_modules(use_estimator):
+    ac, est, n_obs = modules()
+    chain = PolicyChain.describe(ac, est, use_estimator)
+    assert chain is not None and chain.n_ops == (16 if use_estimator else 14)
+    obs = torch.randn(37, n_obs)
+    mean, value = run_oracle(chain, obs)
+    rm, rv = torch_reference(ac, est, obs, use_estimator)
+    np.testing.assert_allclose(mean, rm.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(value, rv.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_description_refuses_what_the_kernel_cannot_hold():
+    ac, est, _ = modules(hidden=(1024, 256, 128))                    # 1024 > widest scratch buffer
+    assert PolicyChain.describe(ac, est, True) is None
+    ac, est, _ = modules()
+    ac.actor_trunk[1] = torch.nn.Tanh()
+    assert PolicyChain.describe(ac, est, True) is None
+    ac, est, _ = modules(priv_dims=())                                # Identity encoder: latent copied through
+    chain = PolicyChain.describe(ac, est, True)
+    assert chain is not None
+    obs = torch.randn(5, 671)
+    mean, value = run_oracle(chain, obs)
+    rm, rv = torch_reference(ac, est, obs, True)
+    np.testing.assert_allclose(mean, rm.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 16, 100, 4096])
+def test_hip_chain_matches_twin_and_torch(n):
+    ac, est, n_obs = modules(seed=3)
+    obs = torch.randn(n, n_obs) * 1.5
+    chain_cpu = PolicyChain.describe(ac, est, True)
+    om, ov = run_oracle(chain_cpu, obs[:256])
+    ac, est = ac.cuda(), est.cuda()
+    chain = PolicyChain.describe(ac, est, True)
+    chain.pack()
+    g = obs.cuda()
+    mean, value = chain.forward(g)
+    torch.cuda.synchronize()
+    rm, rv = torch_reference(ac, est, g, True)
+    np.testing.assert_allclose(mean.cpu().numpy(), rm.cpu().numpy(), rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), rv.cpu().numpy(), rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(mean.cpu().numpy()[:256], om, rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(value.cpu().numpy()[:256], ov, rtol=2e-4, atol=5e-5)
+    # weights change -> repack -> new outputs; strided input rows (a view into a wider arena)
+    with torch.no_grad():
+        ac.actor_head.weight.mul_(0.5); ac.actor_head.bias.mul_(0.5)
+    chain.pack()
+    wide = torch.zeros(n, n_obs + 9, device="cuda"); wide[:, :n_obs] = g
+    m2, _ = chain.forward(wide[:, :n_obs])
+    np.testing.assert_allclose(m2.cpu().numpy(), 0.5 * rm.cpu().numpy(), rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_hip_chain_rejects_malformed_ops():
+    lib = _capi.load_library()
+    x = torch.zeros(16, 671, device="cuda"); packed = torch.zeros(1 << 20, device="cuda")
+    op = _capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=0, src_col=61, dst_buf=1, dst_col=0, k=29, n=64, act=1, w_off=0, b_off=4096)
+    ops = (_capi.QaMlpOp * 1)(op)
+    rc = lib.qa_mlp_forward(x.data_ptr(), 671, 16, 671, ops, 1, packed.data_ptr(), None, None, 0, None)
+    assert rc == -1 and b"malformed" in lib.qa_last_error()            # source column not a multiple of 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [False, True])
+def test_rollout_through_the_chain_matches_the_gemm_path(amp):
+    """Two identically seeded runners, one acting through qa_mlp_forward and one through the GEMMs: the first step's action
+    mean / value (before the environments can diverge through contact flips) agree to rounding, later steps stay close."""
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    from tests.test_gpu_train import _make
+    got = {}
+    for fused in (True, False):
+        env, args, t = _make(256, amp)
+        torch.manual_seed(7)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
+        runner.use_fused_policy = fused
+        runner.use_rollout_graph = False
+        if not hasattr(runner, "_obs_cur"):
+            runner._alloc_rollout_state()
+        torch.manual_seed(11)
+        with torch.inference_mode():
+            runner._rollout_steps(False, False, recorded=False)
+        torch.cuda.synchronize()
+        st = runner.alg.storage
+        got[fused] = (st.mu.cpu().clone(), st.values.cpu().clone(), st.actions_log_prob.cpu().clone())
+        assert (runner._chain is not None and runner._chain is not False) == fused
+    (m1, v1, l1), (m0, v0, l0) = got[True], got[False]
+    np.testing.assert_allclose(m1[0], m0[0], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(v1[0], v0[0], rtol=1e-4, atol=2e-5)
+    close = np.isclose(m1.numpy(), m0.numpy(), rtol=1e-2, atol=1e-2).all(axis=-1)
+    assert close.mean() > 0.9
