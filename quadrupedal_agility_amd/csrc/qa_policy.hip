@@ -56,6 +56,7 @@ struct MlpArgs {
     int64_t x_stride;
     int32_t rows, x_cols, num_ops;
     const float *packed;
+    int64_t packed_f4;          /* size of `packed` in float4 units (what the chain's layers cover) */
     float *out[QA_MLP_MAX_OUTPUTS];
     int64_t out_stride[QA_MLP_MAX_OUTPUTS];
     MlpDevOp ops[QA_MLP_MAX_OPS];
@@ -80,7 +81,9 @@ __global__ void qa_mlp_pack_kernel(PackArgs a) {
         for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) a.packed[L.b_off + i] = (i < L.n && L.b) ? L.b[i] : 0.f;
 }
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expf(v) - 1.f; }
+/* ELU(alpha 1).  __expf = v_exp_f32(v * log2 e), 2 instructions, relative error ~2^-22 of exp(v) <= 1: the same size as
+ * the rounding noise of the fp32 dot product in front of it; expf() is ~35 instructions x 16 values per lane per wide layer */
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
 
 /* one layer for this wavefront: TPW column tiles starting at tile t0.
  * The weight fragments are fetched PF-1 k-blocks ahead of their use into a ring of PF register stages (the L2 round trip is
@@ -122,9 +125,15 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
                 constexpr int PFm1 = PF - 1;
                 const int jp = j + PFm1 < kb ? j + PFm1 : kb - 1;
                 const int st = (u + PFm1) % PF;
+#ifndef QA_MLP_ABLATE_W          /* profiling ablations (tools/mlp_profile.py): results are wrong with either defined */
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) bw[st][i] = wp[jp * jstride + toff[i]];
+#else
+                (void)jp;
+#endif
+#ifndef QA_MLP_ABLATE_A
                 av[st] = *reinterpret_cast<const f4 *>(src + 16 * jp);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -134,20 +143,36 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    /* D layout: register r of lane l = D[row 4 (l / 16) + r][column l % 16] */
+    /* D layout: register r of lane l = D[row 4 (l / 16) + r][column l % 16].  Destination resolved once per layer. */
+    const bool act = op.act != 0;
+    if (op.dst_buf >= 0) {
+        const int ds = mlp_stride(op.dst_buf);
+        float *d = lds + mlp_base(op.dst_buf) + (4 * kq) * ds + op.dst_col + m;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        if (t0 + i >= nt) break;
-        const int col = (t0 + i) * 16 + m;
-        if (col >= op.n) continue;
-        const float bv = bias[i];
+        for (int i = 0; i < TPW; ++i) {
+            const int col = (t0 + i) * 16;
+            if (t0 + i < nt && col + m < op.n) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[i][r] + bv;
-            if (op.act) v = elu1(v);
-            const int row = 4 * kq + r;
-            if (op.dst_buf >= 0) lds[mlp_base(op.dst_buf) + row * mlp_stride(op.dst_buf) + op.dst_col + col] = v;
-            else if (row0 + row < a.rows) a.out[op.out_index][(int64_t)(row0 + row) * a.out_stride[op.out_index] + col] = v;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][r] + bias[i];
+                    d[r * ds + col] = act ? elu1(v) : v;
+                }
+            }
+        }
+    } else {
+        const int64_t os = a.out_stride[op.out_index];
+        float *g = a.out[op.out_index] + (int64_t)(row0 + 4 * kq) * os + m;
+        const int live = a.rows - (row0 + 4 * kq);          /* rows of this lane's group of 4 that exist */
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int col = (t0 + i) * 16;
+            if (t0 + i < nt && col + m < op.n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][r] + bias[i];
+                    if (r < live) g[r * os + col] = act ? elu1(v) : v;
+                }
+            }
         }
     }
 }
@@ -164,6 +189,17 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * MLP_ROWS;
     MLP_STAMP(QA_MLP_MAX_OPS + 1);
+    {   /* pull the weights into this XCD's L2 ahead of their use: consecutive workgroup ids go round-robin over the 8 XCDs, so
+         * the 32 workgroups sharing an L2 each touch 1/32 of `packed` (one float4 per 128-byte line; values discarded).  Without
+         * this every layer starts on an L2 miss that all 32 CUs of the XCD wait on together. */
+        const int64_t lines = (a.packed_f4 + 7) / 8, share = (lines + 31) / 32;
+        const int64_t l0 = ((blockIdx.x >> 3) & 31) * share;
+        const f4 *pf = reinterpret_cast<const f4 *>(a.packed);
+        for (int64_t l = l0 + tid; l < l0 + share && l < lines; l += MLP_WAVES * 64) {
+            const f4 v = __builtin_nontemporal_load(pf + l * 8);
+            asm volatile("" ::"v"(v));
+        }
+    }
     /* scratch buffers start at zero (padding columns are read against zero weights and must be finite) */
     for (int i = mlp_base(1) + tid; i < MLP_LDS_FLOATS; i += MLP_WAVES * 64) lds[i] = 0.f;
     {   /* input tile: one wavefront per 4 rows, coalesced along the row; every load of a row is issued before the first store */
@@ -280,6 +316,7 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
         (num_outs > 0 && (!outs || !out_strides))) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: bad argument"); return QA_E_ARG; }
     MlpArgs a{};
     a.x = x; a.x_stride = x_stride; a.rows = rows; a.x_cols = x_cols; a.num_ops = num_ops; a.packed = packed;
+    a.packed_f4 = qa_mlp_packed_floats(ops, num_ops) / 4;
     for (int i = 0; i < num_outs; ++i) { a.out[i] = outs[i]; a.out_stride[i] = out_strides[i]; }
     for (int i = 0; i < num_ops; ++i) {
         const qa_mlp_op &o = ops[i];

@@ -3,11 +3,14 @@ qa_policy.hip into tools/_prof/ (run once here with `build`, then on the GPU box
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SO = os.path.join(ROOT, "tools", "_prof", "libqa_policy_prof.so")
+VARIANT = os.environ.get("QA_MLP_VARIANT", "")          # "", "W" (no weight loads in the k loop), "A" (no LDS reads), "WA"
+SO = os.path.join(ROOT, "tools", "_prof", f"libqa_policy_prof{VARIANT}.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQA_MLP_PROF",
-                           os.path.join(ROOT, "quadrupedal_agility_amd", "csrc", "qa_policy.hip"), "-o", SO])
+    for v in ("", "W", "A", "WA"):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DQA_MLP_PROF"] +
+                              [f"-DQA_MLP_ABLATE_{c}" for c in v] +
+                              [os.path.join(ROOT, "quadrupedal_agility_amd", "csrc", "qa_policy.hip"), "-o", SO.replace(f"prof{VARIANT}.so", f"prof{v}.so")])
     sys.exit(0)
 import torch
 from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
