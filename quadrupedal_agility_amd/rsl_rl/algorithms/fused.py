@@ -234,8 +234,12 @@ class ClipAdam:
         t = self._tab
         ptrs = [p.grad.data_ptr() for p in params]
         if ptrs != t["grad_ptrs"]:                      # autograd allocated new gradient tensors: refresh the pointer table
+            if t.get("copied") is not None:
+                t["copied"].synchronize()               # the pinned staging buffer may still be waiting for its last async copy
             t["grads_host"].copy_(torch.tensor(ptrs, dtype=torch.int64))
             t["grads"].copy_(t["grads_host"], non_blocking=True)
+            t["copied"] = torch.cuda.Event()
+            t["copied"].record()
             t["grad_ptrs"] = ptrs
         lr = g0["lr"]
         if torch.is_tensor(lr):

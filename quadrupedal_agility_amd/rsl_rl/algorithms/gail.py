@@ -21,6 +21,30 @@ from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, disc_loss,
 from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
 
 
+class LossReadout:
+    """The 17 loss / accuracy means of one update() (same order as the reference's return tuple, gail.py:318-326), still on
+    the device: the ONE host read of the update happens when somebody looks at a value (the logger), not at the end of
+    update() -- a run without a log directory never waits for the GPU and the host can enqueue the next rollout while the
+    last minibatch step is still running."""
+
+    def __init__(self, dev_values):
+        self._dev, self._host = dev_values, None
+
+    def _values(self):
+        if self._host is None:
+            self._host = tuple(self._dev.tolist())
+        return self._host
+
+    def __iter__(self):
+        return iter(self._values())
+
+    def __getitem__(self, i):
+        return self._values()[i]
+
+    def __len__(self):
+        return int(self._dev.shape[0])
+
+
 class SSInfoGAIL:
     def __init__(self, env, actor_critic, discriminator, estimator, estimator_paras, motion_loader, disc_normalizer,
                  disc_history_len, disc_obs_len, num_disc_obs, obs_disc_weight_step, disc_loss_function=None,
@@ -212,8 +236,7 @@ class SSInfoGAIL:
         self.storage.clear()
         self.priv_reg_counter += 1
         self._warm_updates += 1
-        out = torch.cat([acc_ac / n_ac, acc_d / n_d]).tolist()      # the one host read of the update
-        return tuple(out)
+        return LossReadout(torch.cat([acc_ac / n_ac, acc_d / n_d]))
 
     def _priv_reg_coef_now(self):
         s0, s1, t0, t1 = self.priv_reg_coef_schedual

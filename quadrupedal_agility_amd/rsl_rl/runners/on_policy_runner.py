@@ -225,6 +225,7 @@ class OnPolicyRunner:
         self._graph_failed = False
 
     use_fused_rollout = True     # GPU, discriminator off: per-step bookkeeping as qa_rollout_act / qa_rollout_post
+    phase_timing = os.environ.get("QA_PHASE_TIMING", "0") == "1" or bool(os.environ.get("QA_BENCH_TRACE"))
     use_fused_policy = True      # ... and the policy's networks as one qa_mlp_forward launch per step
     _chain = None
 
@@ -432,7 +433,10 @@ class OnPolicyRunner:
             self.save(os.path.join(self.log_dir, "model.pt"))
 
     def _sync(self):
-        if torch.device(self.device).type == "cuda":
+        """Phase timing needs the GPU drained at the phase boundaries.  Without a log directory nobody reads those times, so
+        the three waits per iteration are skipped (QA_PHASE_TIMING=1 forces them) and the host runs ahead of the GPU: the
+        next rollout's launch latency hides behind the update still executing."""
+        if torch.device(self.device).type == "cuda" and (self.log_dir is not None or self.phase_timing):
             torch.cuda.synchronize()
 
     _LOSS_TAGS = ["surrogate_loss", "value_loss", "b_loss", "entropy_batch", "priv_reg_loss", "estimator_loss", "ss_loss",
