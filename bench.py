@@ -127,6 +127,30 @@ def main():
         spans.append((e0, e1))
     torch.cuda.synchronize()
     kern_ms = sorted(a.elapsed_time(b) for a, b in spans)[reps // 2] / per
+    # the two phases of an iteration, measured apart AFTER the timed region (inside it the host never waits for the GPU, so
+    # per-phase host clocks mean nothing there): 5 rollouts alone, bracketed by synchronize; the update is the remainder
+    roll = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        runner._collect(False, False)
+        torch.cuda.synchronize(); roll.append(time.perf_counter() - t1)
+        runner.alg.storage.clear()
+    coll = [sorted(roll)[len(roll) // 2]]
+    lrn = [dt / args.steps - coll[0]]
+    # live timing of the policy-inference kernel (qa_mlp_forward), same recipe as the env-step kernel
+    chain, mlp_ms = runner._policy_chain(), None
+    if chain is not None and chain.packed is not None:
+        obs_now = env.get_observations()
+        spans = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                chain.forward(obs_now)
+            e1.record()
+            spans.append((e0, e1))
+        torch.cuda.synchronize()
+        mlp_ms = sorted(a.elapsed_time(b) for a, b in spans)[reps // 2] / per
     T = runner.num_steps_per_env
     env_steps = args.num_envs * T * args.steps * world
     value = env_steps / dt
@@ -157,6 +181,12 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
                          "note": "VALU-issue-bound, not byte-bound: 4096 envs = 256 wavefronts = one per CU, ~41k instructions per wavefront at 4.4 cycles each (DESIGN.md 4.1); 16384 envs/GPU reach 4 wavefronts per CU and 3.4x this rate"},
         }
+        if mlp_ms is not None:
+            pf = ROLLOUT_FLOPS_PER_SAMPLE * args.num_envs
+            out["policy_roofline"] = {"kernel": "qa_mlp_forward_kernel", "bound": "mfma", "dtype": "f32", "achieved": pf / (mlp_ms * 1e-3) / 1e12,
+                                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pf / (mlp_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                      "kernel_ms": mlp_ms, "algorithmic_flops_per_launch": pf,
+                                      "note": "estimator + privileged encoder + actor + critic of one env step in one launch, activations in LDS (DESIGN.md 4.11)"}
         epochs, nmb = runner.alg.num_learning_epochs, runner.alg.num_mini_batches
         samples = args.num_envs * T
         if not args.amp:      # the discriminator's GEMMs are not counted, so the figure would overstate the AMP config
@@ -167,9 +197,14 @@ def main():
                                        "note": f"whole iteration time; {epochs} epochs x {nmb} minibatches of {samples // nmb} samples, GEMMs through hipBLASLt (fp32 MFMA 16x16x4)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.num_envs, args.cpu_seconds)
-        print(json.dumps(out))
     if world > 1 or forced_dp:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL's start-up banner sits in the C library's stdout buffer until somebody flushes it: do that first so the
+        # JSON line is the LAST line of output
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(num_envs, budget_s):

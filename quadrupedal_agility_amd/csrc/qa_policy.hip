@@ -56,7 +56,6 @@ struct MlpArgs {
     int64_t x_stride;
     int32_t rows, x_cols, num_ops;
     const float *packed;
-    int64_t packed_f4;          /* size of `packed` in float4 units (what the chain's layers cover) */
     float *out[QA_MLP_MAX_OUTPUTS];
     int64_t out_stride[QA_MLP_MAX_OUTPUTS];
     MlpDevOp ops[QA_MLP_MAX_OPS];
@@ -189,17 +188,6 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * MLP_ROWS;
     MLP_STAMP(QA_MLP_MAX_OPS + 1);
-    {   /* pull the weights into this XCD's L2 ahead of their use: consecutive workgroup ids go round-robin over the 8 XCDs, so
-         * the 32 workgroups sharing an L2 each touch 1/32 of `packed` (one float4 per 128-byte line; values discarded).  Without
-         * this every layer starts on an L2 miss that all 32 CUs of the XCD wait on together. */
-        const int64_t lines = (a.packed_f4 + 7) / 8, share = (lines + 31) / 32;
-        const int64_t l0 = ((blockIdx.x >> 3) & 31) * share;
-        const f4 *pf = reinterpret_cast<const f4 *>(a.packed);
-        for (int64_t l = l0 + tid; l < l0 + share && l < lines; l += MLP_WAVES * 64) {
-            const f4 v = __builtin_nontemporal_load(pf + l * 8);
-            asm volatile("" ::"v"(v));
-        }
-    }
     /* scratch buffers start at zero (padding columns are read against zero weights and must be finite) */
     for (int i = mlp_base(1) + tid; i < MLP_LDS_FLOATS; i += MLP_WAVES * 64) lds[i] = 0.f;
     {   /* input tile: one wavefront per 4 rows, coalesced along the row; every load of a row is issued before the first store */
@@ -316,7 +304,6 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
         (num_outs > 0 && (!outs || !out_strides))) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: bad argument"); return QA_E_ARG; }
     MlpArgs a{};
     a.x = x; a.x_stride = x_stride; a.rows = rows; a.x_cols = x_cols; a.num_ops = num_ops; a.packed = packed;
-    a.packed_f4 = qa_mlp_packed_floats(ops, num_ops) / 4;
     for (int i = 0; i < num_outs; ++i) { a.out[i] = outs[i]; a.out_stride[i] = out_strides[i]; }
     for (int i = 0; i < num_ops; ++i) {
         const qa_mlp_op &o = ops[i];
