@@ -278,6 +278,11 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
                       const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
                       float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream);
 
+/* KL-adaptive learning rate of the PPO step (bbc/rsl_rl/algorithms/gail.py:367-379) on DEVICE scalars, so that a recorded
+ * step never reads the KL on the host:  *lr = max(lr_min, *lr / factor) if *kl > 2 desired_kl;  min(lr_max, *lr * factor) if
+ * 0 < *kl < desired_kl / 2;  unchanged otherwise.  The reference uses factor 1.5, lr_min 1e-5, lr_max 1e-2. */
+int qa_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr, void *stream);
+
 /* Rollout bookkeeping around qa_env_step (SSInfoGAIL.act / process_env_step, bbc/rsl_rl/algorithms/gail.py:176-212;
  * RolloutStorage.add_transitions, rollout_storage.py:60-74; the runner's episode sums, on_policy_runner.py:187-206).
  * qa_rollout_act: a = mean + std * eps, log-prob of a under N(mean, std); writes `actions` (N,12) for the env and the

@@ -1262,6 +1262,15 @@ int qo_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
     return QA_OK;
 }
 
+int qo_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr, void *stream) {
+    (void)stream;
+    if (!kl || !lr || !(desired_kl > 0.f) || !(factor > 1.f) || !(lr_min > 0.f) || !(lr_max >= lr_min)) return QA_E_ARG;
+    const float k = kl[0];                                  /* gail.py:367-379 */
+    if (k > desired_kl * 2.0f) { const float v = lr[0] / factor; lr[0] = v > lr_min ? v : lr_min; }
+    else if (k < desired_kl / 2.0f && k > 0.0f) { const float v = lr[0] * factor; lr[0] = v < lr_max ? v : lr_max; }
+    return QA_OK;
+}
+
 /* ---- policy inference chain (include/qa_sim.h "policy inference"): Estimator.forward (bbc/rsl_rl/modules/estimator.py:35-36),
  * ActorCritic.update_distribution / evaluate (actor_critic.py:171-196,222-225) as nn.Linear + ELU layers and column copies.
  * The twin keeps the weights row-major inside `packed` (the caller's offsets leave room: the device layout is padded) and

@@ -352,6 +352,15 @@ __global__ void __launch_bounds__(256) qa_adam_finalize_kernel(AdamArgs a) {
     }
 }
 
+/* KL-adaptive learning rate (gail.py:367-379) on device scalars: one thread */
+__global__ void qa_kl_lr_rule_kernel(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr) {
+    const float k = kl[0], cur = lr[0];
+    float out = cur;
+    if (k > desired_kl * 2.0f) out = fmaxf(lr_min, cur / factor);
+    else if (k < desired_kl / 2.0f && k > 0.0f) out = fminf(lr_max, cur * factor);
+    lr[0] = out;
+}
+
 __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
     const int c = blockIdx.x, t = a.chunk_tensor[c], s0 = a.chunk_start[c], n = a.chunk_len[c];
     float *p = a.params[t] + s0, *m = a.exp_avg[t] + s0, *v = a.exp_avg_sq[t] + s0;
@@ -670,6 +679,15 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
     hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr, void *stream) {
+    if (!kl || !lr || !(desired_kl > 0.f) || !(factor > 1.f) || !(lr_min > 0.f) || !(lr_max >= lr_min)) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_kl_lr_rule: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_kl_lr_rule_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, kl, desired_kl, factor, lr_min, lr_max, lr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_kl_lr_rule: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -609,3 +609,21 @@ def test_disc_prepare_hip_matches_eager():
     assert torch.allclose(got.cpu(), _prep_eager(bs, task, fm, w, mean, var), rtol=1e-6, atol=1e-6)
     raw = fused.disc_prepare([b.cuda() for b in bs[:2]], task.cuda(), fm.cuda(), None, None)           # no task weight, no normaliser
     assert torch.allclose(raw.cpu(), torch.cat([b * fm for b in bs[:2]]), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_kl_lr_rule_kernel_matches_the_reference_rule():
+    """gail.py:367-379 on device scalars vs. the Python rule and the oracle's C twin, over all three branches and both clamps"""
+    import ctypes as C
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import kl_lr_rule
+    from tests.oracle_lib import load_oracle
+    qo = load_oracle()
+    cases = [(0.05, 1e-3), (0.004, 1e-3), (0.01, 1e-3), (0.0, 1e-3), (-1.0, 1e-3), (0.05, 1.2e-5), (0.001, 9e-3), (0.021, 5e-4), (0.0049, 5e-4)]
+    for kl, lr0 in cases:
+        want = max(1e-5, lr0 / 1.5) if kl > 0.02 else (min(1e-2, lr0 * 1.5) if 0.0 < kl < 0.005 else lr0)
+        k, lr = torch.tensor(kl, device="cuda"), torch.tensor(lr0, device="cuda")
+        kl_lr_rule(k, 0.01, lr)
+        hk, hl = np.array([kl], np.float32), np.array([lr0], np.float32)
+        assert qo.qo_kl_lr_rule(hk.ctypes.data, 0.01, 1.5, 1e-5, 1e-2, hl.ctypes.data, None) == 0
+        assert abs(float(lr) - want) <= 1e-6 * want and abs(float(hl[0]) - want) <= 1e-6 * want, (kl, lr0)
+        assert float(lr) == float(hl[0])

@@ -35,5 +35,10 @@ for name, i, o, need_dx in layers:
     t_w = timeit(lambda: g.t().mm(x))
     t_x = timeit(lambda: g.mm(w)) if need_dx else 0.0
     tot += t_f + t_w + t_x
-    print(f"{name:12s} {i:4d}->{o:4d}  fwd {t_f:7.1f} us {fl / t_f / 1e6:6.1f} TF/s | dW {t_w:7.1f} us {fl / t_w / 1e6:6.1f} TF/s | dx {t_x:7.1f} us {(fl / t_x / 1e6) if t_x else 0:6.1f} TF/s")
+    alt = []
+    for S in (4, 8, 16, 32):        # dW with the row reduction split into S slabs through a batched GEMM, partials added
+        alt.append((S, timeit(lambda: torch.bmm(g.unflatten(0, (S, B // S)).transpose(1, 2), x.unflatten(0, (S, B // S))).sum(0))))
+    t_mv = timeit(lambda: torch.addmv(b.expand(B), x, w[0])) if o == 1 else 0.0
+    print(f"{name:12s} {i:4d}->{o:4d}  fwd {t_f:7.1f} us {fl / t_f / 1e6:6.1f} TF/s | dW {t_w:7.1f} us {fl / t_w / 1e6:6.1f} TF/s | dx {t_x:7.1f} us {(fl / t_x / 1e6) if t_x else 0:6.1f} TF/s"
+          f" | dW split " + " ".join(f"S{S}:{t:.1f}" for S, t in alt) + (f" | addmv fwd {t_mv:.1f}" if o == 1 else ""))
 print(f"sum per minibatch {tot / 1e3:.2f} ms -> x20 = {tot * 20 / 1e3:.1f} ms/iter")
