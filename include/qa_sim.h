@@ -278,6 +278,24 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
                       const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
                       float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream);
 
+/* Two small losses of the PPO step with their gradient in the same pass (a (rows, cols) contiguous, b (rows, cols) with row
+ * stride b_stride, fp32 device pointers; grad_a (rows, cols); out[1]):
+ *   QA_PAIR_ROW_L2: out = mean_r ||a_r - b_r||_2, grad_a = (a - b) / (||a_r - b_r|| rows), 0 where the norm is 0 -- the
+ *                   privileged-latent regulariser (a = priv_encoder(latent), b = history latent, gail.py:346-350)
+ *   QA_PAIR_MSE:    out = mean (a - b)^2, grad_a = 2 (a - b) / (rows cols) -- the estimator regression (gail.py:356-358) */
+#define QA_PAIR_ROW_L2 0
+#define QA_PAIR_MSE 1
+int64_t qa_pair_loss_scratch_bytes(int64_t rows);
+int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int64_t b_stride, int32_t mode, float *grad_a, float *out,
+                 void *scratch, int64_t scratch_bytes, void *stream);
+
+/* Minibatch gather (RolloutStorage.mini_batch_generator, bbc/rsl_rl/storage/rollout_storage.py:122-157): for t < num_tensors,
+ * dst[t][r, 0:widths[t]] = src[t][idx[r], 0:widths[t]]; src rows are src_strides[t] floats apart, dst rows are dense.  `src`,
+ * `src_strides`, `widths`, `dst` are HOST arrays of device pointers / sizes; idx (rows) int64 on the device. */
+#define QA_GATHER_MAX 12
+int qa_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides,
+                   const int32_t *widths, float *const *dst, void *stream);
+
 /* KL-adaptive learning rate of the PPO step (bbc/rsl_rl/algorithms/gail.py:367-379) on DEVICE scalars, so that a recorded
  * step never reads the KL on the host:  *lr = max(lr_min, *lr / factor) if *kl > 2 desired_kl;  min(lr_max, *lr * factor) if
  * 0 < *kl < desired_kl / 2;  unchanged otherwise.  The reference uses factor 1.5, lr_min 1e-5, lr_max 1e-2. */

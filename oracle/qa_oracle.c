@@ -1262,6 +1262,41 @@ int qo_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
     return QA_OK;
 }
 
+int64_t qo_pair_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * ((rows + 255) / 256); }
+
+int qo_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int64_t b_stride, int32_t mode, float *grad_a, float *out,
+                 void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!a || !b || !grad_a || !out || rows <= 0 || cols <= 0 || b_stride < cols || (mode != QA_PAIR_ROW_L2 && mode != QA_PAIR_MSE)) return QA_E_ARG;
+    double acc = 0.0;
+    for (int64_t r = 0; r < rows; ++r) {
+        double ss = 0.0;
+        for (int c = 0; c < cols; ++c) { const double d = (double)a[r * cols + c] - (double)b[r * b_stride + c]; ss += d * d; }
+        if (mode == QA_PAIR_ROW_L2) {               /* (p - h).norm(p=2, dim=1).mean(), gail.py:348 */
+            const double n = sqrt(ss), sc = n > 0.0 ? 1.0 / (n * (double)rows) : 0.0;
+            for (int c = 0; c < cols; ++c) grad_a[r * cols + c] = (float)(((double)a[r * cols + c] - (double)b[r * b_stride + c]) * sc);
+            acc += n;
+        } else {                                    /* (e - t).pow(2).mean(), gail.py:357 */
+            const double sc = 2.0 / ((double)rows * (double)cols);
+            for (int c = 0; c < cols; ++c) grad_a[r * cols + c] = (float)(((double)a[r * cols + c] - (double)b[r * b_stride + c]) * sc);
+            acc += ss;
+        }
+    }
+    out[0] = (float)(mode == QA_PAIR_ROW_L2 ? acc / (double)rows : acc / ((double)rows * (double)cols));
+    return QA_OK;
+}
+
+int qo_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides, const int32_t *widths,
+                   float *const *dst, void *stream) {
+    (void)stream;
+    if (!idx || !src || !src_strides || !widths || !dst || rows <= 0 || num_tensors <= 0 || num_tensors > QA_GATHER_MAX) return QA_E_ARG;
+    for (int t = 0; t < num_tensors; ++t) {
+        if (!src[t] || !dst[t] || widths[t] <= 0 || src_strides[t] < widths[t]) return QA_E_ARG;
+        for (int64_t r = 0; r < rows; ++r) memcpy(dst[t] + r * widths[t], src[t] + idx[r] * src_strides[t], sizeof(float) * (size_t)widths[t]);
+    }
+    return QA_OK;
+}
+
 int qo_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr, void *stream) {
     (void)stream;
     if (!kl || !lr || !(desired_kl > 0.f) || !(factor > 1.f) || !(lr_min > 0.f) || !(lr_max >= lr_min)) return QA_E_ARG;

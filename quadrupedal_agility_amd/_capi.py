@@ -119,6 +119,11 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "disc_prepare")
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     f.restype = C.c_int
+    f = getattr(lib, prefix + "pair_loss_scratch_bytes"); f.argtypes = [C.c_int64]; f.restype = C.c_int64
+    f = getattr(lib, prefix + "pair_loss")
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    f.restype = C.c_int
+    f = getattr(lib, prefix + "gather_rows"); f.argtypes = [C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5; f.restype = C.c_int
     f = getattr(lib, prefix + "kl_lr_rule"); f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_packed_floats"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "mlp_pack"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
@@ -143,7 +148,7 @@ MLP_BUF_COLS = (672, 512, 256, 128)
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

@@ -352,6 +352,70 @@ __global__ void __launch_bounds__(256) qa_adam_finalize_kernel(AdamArgs a) {
     }
 }
 
+/* ---- pair losses: mean row L2 norm of (a - b) (privileged-latent regulariser, gail.py:346-350) and mean squared difference
+ * (estimator regression, gail.py:356-358), each with its gradient w.r.t. a in the same pass.  One lane per row. */
+constexpr int PAIR_BLOCK = 256;
+
+__global__ void __launch_bounds__(PAIR_BLOCK) qa_pair_loss_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t rows, int cols,
+                                                                 int64_t b_stride, int mode, float *__restrict__ grad_a, float *__restrict__ partial) {
+    __shared__ float s_red[PAIR_BLOCK];
+    const int64_t r = (int64_t)blockIdx.x * PAIR_BLOCK + threadIdx.x;
+    float contrib = 0.f;
+    if (r < rows) {
+        const float *ar = a + r * cols, *br = b + r * b_stride;
+        float *gr = grad_a + r * cols;
+        float ss = 0.f;
+        for (int c = 0; c < cols; ++c) { const float d = ar[c] - br[c]; ss = fmaf(d, d, ss); }
+        if (mode == 0) {
+            const float nrm = sqrtf(ss);
+            const float sc = nrm > 0.f ? 1.0f / (nrm * (float)rows) : 0.f;          /* subgradient 0 at the origin, as torch.norm's backward */
+            for (int c = 0; c < cols; ++c) gr[c] = (ar[c] - br[c]) * sc;
+            contrib = nrm;
+        } else {
+            const float sc = 2.0f / ((float)rows * (float)cols);
+            for (int c = 0; c < cols; ++c) gr[c] = (ar[c] - br[c]) * sc;
+            contrib = ss;
+        }
+    }
+    s_red[threadIdx.x] = contrib;
+    __syncthreads();
+    for (int o = PAIR_BLOCK / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+
+__global__ void __launch_bounds__(256) qa_pair_finish_kernel(const float *__restrict__ partial, int nb, float scale, float *__restrict__ out) {
+    __shared__ double s_acc[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += (double)partial[i];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = (float)(s_acc[0] * (double)scale);
+}
+
+/* ---- minibatch gather: dst_t[r, :] = src_t[idx[r], :] for up to QA_GATHER_MAX row-major fp32 tensors in one launch
+ * (RolloutStorage.mini_batch_generator, rollout_storage.py:122-157: nine indexed reads per minibatch) */
+constexpr int GATHER_ROWS = 4;
+struct GatherArgs {
+    const float *src[QA_GATHER_MAX]; float *dst[QA_GATHER_MAX]; int32_t width[QA_GATHER_MAX]; int64_t src_stride[QA_GATHER_MAX];
+    const int64_t *idx; int64_t rows; int32_t n;
+};
+
+__global__ void __launch_bounds__(256) qa_gather_rows_kernel(GatherArgs a) {
+    const int64_t r0 = (int64_t)blockIdx.x * GATHER_ROWS;
+#pragma unroll
+    for (int q = 0; q < GATHER_ROWS; ++q) {
+        const int64_t r = r0 + q;
+        if (r >= a.rows) return;
+        const int64_t s = a.idx[r];
+        for (int t = 0; t < a.n; ++t) {
+            const float *sp = a.src[t] + s * a.src_stride[t];
+            float *dp = a.dst[t] + r * a.width[t];
+            for (int c = threadIdx.x; c < a.width[t]; c += 256) dp[c] = sp[c];
+        }
+    }
+}
+
 /* KL-adaptive learning rate (gail.py:367-379) on device scalars: one thread */
 __global__ void qa_kl_lr_rule_kernel(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr) {
     const float k = kl[0], cur = lr[0];
@@ -679,6 +743,38 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
     hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int64_t qa_pair_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * ((rows + PAIR_BLOCK - 1) / PAIR_BLOCK); }
+
+int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int64_t b_stride, int32_t mode, float *grad_a, float *out,
+                 void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!a || !b || !grad_a || !out || !scratch || rows <= 0 || cols <= 0 || b_stride < cols || (mode != QA_PAIR_ROW_L2 && mode != QA_PAIR_MSE) ||
+        scratch_bytes < qa_pair_loss_scratch_bytes(rows)) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_loss: bad argument"); return QA_E_ARG; }
+    const int nb = (int)((rows + PAIR_BLOCK - 1) / PAIR_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(qa_pair_loss_kernel, dim3(nb), dim3(PAIR_BLOCK), 0, st, a, b, rows, (int)cols, b_stride, (int)mode, grad_a, (float *)scratch);
+    const float scale = mode == QA_PAIR_ROW_L2 ? 1.0f / (float)rows : 1.0f / ((float)rows * (float)cols);
+    hipLaunchKernelGGL(qa_pair_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)scratch, nb, scale, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides, const int32_t *widths,
+                   float *const *dst, void *stream) {
+    if (!idx || !src || !src_strides || !widths || !dst || rows <= 0 || num_tensors <= 0 || num_tensors > QA_GATHER_MAX) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_gather_rows: bad argument (1..%d tensors)", QA_GATHER_MAX); return QA_E_ARG; }
+    GatherArgs a{};
+    for (int t = 0; t < num_tensors; ++t) {
+        if (!src[t] || !dst[t] || widths[t] <= 0 || src_strides[t] < widths[t]) { snprintf(g_lerr, sizeof(g_lerr), "qa_gather_rows: tensor %d is malformed", t); return QA_E_ARG; }
+        a.src[t] = src[t]; a.dst[t] = dst[t]; a.width[t] = widths[t]; a.src_stride[t] = src_strides[t];
+    }
+    a.idx = idx; a.rows = rows; a.n = num_tensors;
+    hipLaunchKernelGGL(qa_gather_rows_kernel, dim3((unsigned)((rows + GATHER_ROWS - 1) / GATHER_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_gather_rows: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

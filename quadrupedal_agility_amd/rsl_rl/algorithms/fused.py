@@ -187,6 +187,60 @@ def normalizer_apply(x, mean, var, epsilon, clip):
     return y
 
 
+PAIR_ROW_L2, PAIR_MSE = 0, 1
+
+
+class _PairLoss(torch.autograd.Function):
+    """loss = f(a, b) with b constant: mean row L2 norm of a - b (PAIR_ROW_L2) or mean squared difference (PAIR_MSE).  Loss and
+    d loss / d a come out of one pass (qa_pair_loss); backward only scales.  b may be a column slice of wider rows."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        a = _f32c(a)
+        assert b.dtype == torch.float32 and b.stride(1) == 1 and a.shape == b.shape
+        rows, cols = a.shape
+        lib = _capi.load_library()
+        grad = torch.empty_like(a)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        nscratch = int(lib.qa_pair_loss_scratch_bytes(rows))
+        scratch = torch.empty(nscratch, dtype=torch.uint8, device=a.device)
+        rc = lib.qa_pair_loss(_ptr(a), _ptr(b), rows, cols, b.stride(0), int(mode), _ptr(grad), _ptr(out), _ptr(scratch), nscratch,
+                              C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"qa_pair_loss failed with code {rc}: {lib.qa_last_error().decode()}")
+        ctx.save_for_backward(grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def pair_loss(a, b, mode):
+    return _PairLoss.apply(a, b, mode)
+
+
+def gather_rows(idx, srcs, dsts=None):
+    """[src[idx] for src in srcs] for row-major fp32 tensors (N, w) in ONE launch; idx (rows) int64 on the device.  `dsts`
+    (dense (rows, w) tensors) are allocated when not given."""
+    rows = idx.shape[0]
+    n = len(srcs)
+    flat = [x if x.dim() == 2 else x.reshape(x.shape[0], -1) for x in srcs]
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and all(x.dtype == torch.float32 and x.stride(1) == 1 for x in flat)
+    if dsts is None:
+        dsts = [torch.empty(rows, x.shape[1], dtype=torch.float32, device=idx.device) for x in flat]
+    lib = _capi.load_library()
+    src = (C.c_void_p * n)(*[x.data_ptr() for x in flat])
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    strides = (C.c_int64 * n)(*[x.stride(0) for x in flat])
+    widths = (C.c_int32 * n)(*[x.shape[1] for x in flat])
+    rc = lib.qa_gather_rows(_ptr(idx), rows, n, src, strides, widths, dst, C.c_void_p(torch.cuda.current_stream(idx.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"qa_gather_rows failed with code {rc}: {lib.qa_last_error().decode()}")
+    return dsts
+
+
 def kl_lr_rule(kl, desired_kl, lr, factor=1.5, lr_min=1e-5, lr_max=1e-2):
     """lr (0-d ROCm tensor) <- the KL-adaptive rule of gail.py:367-379 applied to kl (0-d ROCm tensor); one launch"""
     lib = _capi.load_library()

@@ -274,9 +274,12 @@ class SSInfoGAIL:
                                         self.num_prop + self.num_explicit + self.num_latent + self.num_hist * self.num_prop)
 
                 def front():
-                    obs, act, val, adv, ret, logp, mu, sig = (x[self._mb_idx] for x in flat)
-                    return self._ac_forward_backward((obs, obs, act, val, adv, ret, logp, mu, sig, (None, None), None,
-                                                      self._hist_latent_all[self._mb_idx]))
+                    if self.use_fused_loss:        # the nine indexed reads of a minibatch in one launch
+                        obs, act, val, adv, ret, logp, mu, sig, hl = fused_mod.gather_rows(self._mb_idx, flat + [self._hist_latent_all])
+                    else:
+                        obs, act, val, adv, ret, logp, mu, sig = (x[self._mb_idx] for x in flat)
+                        hl = self._hist_latent_all[self._mb_idx]
+                    return self._ac_forward_backward((obs, obs, act, val, adv, ret, logp, mu, sig, (None, None), None, hl))
 
                 torch.cuda.synchronize()
                 for o in (self.optim_ac, self.optim_estimator):
@@ -407,14 +410,20 @@ class SSInfoGAIL:
         if hist_latent is None:
             with torch.no_grad():
                 hist_latent = ac.infer_hist_latent(obs_hist)
-        priv_reg_loss = (priv_latent - hist_latent).norm(p=2, dim=1).mean()
+        if fused:
+            priv_reg_loss = fused_mod.pair_loss(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)        # value + gradient in one pass
+        else:
+            priv_reg_loss = (priv_latent - hist_latent).norm(p=2, dim=1).mean()
         # a device scalar while the step is being recorded (the ramp changes between iterations, replays must see it)
         priv_reg_coef = self._priv_coef_dev if self._recording_ac else self._priv_reg_coef_now()
 
         # estimator regression on the true privileged explicit state (gail.py:356-362).  Its parameters do not enter the
         # actor-critic objective, so its optimiser step can wait until both backward passes are done: data-parallel runs
         # then need ONE collective per minibatch (estimator grads + actor-critic grads + the KL scalar in one bucket)
-        estimator_loss = (self.estimator(obs_prop) - obs_explicit).pow(2).mean()
+        if fused:
+            estimator_loss = fused_mod.pair_loss(self.estimator(obs_prop), obs_explicit, fused_mod.PAIR_MSE)
+        else:
+            estimator_loss = (self.estimator(obs_prop) - obs_explicit).pow(2).mean()
         self.optim_estimator.zero_grad()
         estimator_loss.backward()
 
