@@ -221,15 +221,18 @@ __global__ void __launch_bounds__(256) qa_colsum_finish_kernel(const float *__re
 // four (n_i, d) fp32 batches, in order, into (mean, var, count) kept in double on the device; each batch contributes
 // its mean and biased variance (two passes over the batch in double, as numpy's mean/var), merged with the parallel-
 // variance formula.  In eager PyTorch one such update is ~35 launches of double-precision reductions and elementwise
-// ops per batch (3 batches x 80 discriminator steps per iteration).  One workgroup: d columns x (1024/CW) row lanes.
+// ops per batch (3 batches x 80 discriminator steps per iteration).  Columns are independent, so a workgroup owns 16 of them
+// (16 columns x 64 row lanes; 7 workgroups for the 98-wide discriminator input: 46 -> ~10 us); the shared sample count is
+// advanced by a second one-thread launch, because a workgroup that starts late must still read the old value.
 constexpr int NORM_MAX_BATCHES = 4;
 struct NormArgs { const float *batch[NORM_MAX_BATCHES]; int64_t n[NORM_MAX_BATCHES]; int k, d; double *mean, *var, *count; };
 
 __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) {
     __shared__ double s_red[1024];
-    __shared__ double s_col[128];
-    const int CW = 128, RL = 1024 / CW;
-    const int c = threadIdx.x % CW, rl = threadIdx.x / CW;
+    __shared__ double s_col[16];
+    const int CW = 16, RL = 1024 / CW;
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     const bool col = c < a.d;
     double run_mean = (col && rl == 0) ? a.mean[c] : 0.0, run_var = (col && rl == 0) ? a.var[c] : 0.0;
     double count = *a.count;
@@ -254,11 +257,11 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
         if (rl == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int q = 0; q < RL; ++q) t += s_red[q * CW + c];
-            s_col[c] = t / (double)n;
+            for (int q = 0; q < RL; ++q) t += s_red[q * CW + cl];
+            s_col[cl] = t / (double)n;
         }
         __syncthreads();
-        const double bm = s_col[c];
+        const double bm = s_col[cl];
         acc = 0.0;
         if (col) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
         if (rl == 0 && col) {
             double m2b = 0.0;
 #pragma unroll
-            for (int q = 0; q < RL; ++q) m2b += s_red[q * CW + c];
+            for (int q = 0; q < RL; ++q) m2b += s_red[q * CW + cl];
             const double bv = m2b / (double)n, nb = (double)n;
             const double delta = bm - run_mean, total = count + nb;
             const double m2 = run_var * count + bv * nb + delta * delta * count * nb / total;
@@ -290,7 +293,12 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
         __syncthreads();
     }
     if (rl == 0 && col) { a.mean[c] = run_mean; a.var[c] = run_var; }
-    if (threadIdx.x == 0) *a.count = count;
+}
+
+__global__ void qa_normalizer_count_kernel(NormArgs a) {
+    double count = *a.count;
+    for (int b = 0; b < a.k; ++b) count += (double)a.n[b];
+    *a.count = count;
 }
 
 // y = clamp((x - mean) / sqrt(var + eps), -clip, clip) with mean / std rounded to fp32 first (utils.py:97-103)
@@ -712,7 +720,8 @@ int qa_normalizer_update(const float *const *batches, const int64_t *rows, int32
         a.batch[b] = batches[b]; a.n[b] = rows[b];
     }
     a.k = num_batches; a.d = dim; a.mean = mean; a.var = var; a.count = count;
-    hipLaunchKernelGGL(qa_normalizer_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(qa_normalizer_update_kernel, dim3((dim + 15) / 16), dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(qa_normalizer_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_normalizer_update: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

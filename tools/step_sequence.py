@@ -1,9 +1,10 @@
 """Dev tool: the kernel sequence of ONE PPO minibatch step (between two qa_ppo_loss launches late in the run), with
-durations and the gap before each kernel.  usage: step_sequence.py <kernel_trace.csv>"""
+durations and the gap before each kernel.  usage: step_sequence.py <kernel_trace.csv> [marker kernel]"""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
-idx = [i for i, e in enumerate(ev) if "qa_ppo_loss_kernel" in e[2]]
+MARK = sys.argv[2] if len(sys.argv) > 2 else "qa_ppo_loss_kernel"        # "qa_disc_loss_kernel": one discriminator step
+idx = [i for i, e in enumerate(ev) if MARK in e[2]]
 a, b = idx[-6], idx[-5]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
