@@ -126,7 +126,23 @@ def main():
         e1.record()
         spans.append((e0, e1))
     torch.cuda.synchronize()
-    kern_ms = sorted(a.elapsed_time(b) for a, b in spans)[reps // 2] / per
+    kern_ms_alone = sorted(a.elapsed_time(b) for a, b in spans)[reps // 2] / per
+    # ... and as it runs inside a rollout: one event pair per launch, with the policy kernel (which sweeps 3 MB of weights and
+    # the observation rows through L2) between two env steps.  This is the figure the rocprofv3 average of the whole
+    # command corresponds to, and the one the roofline object uses.
+    chain0 = runner._policy_chain()
+    obs_now = env.get_observations()
+    pairs = []
+    for _ in range(reps * per):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sim.step(act, env.delay)
+        e1.record()
+        pairs.append((e0, e1))
+        if chain0 is not None and chain0.packed is not None:
+            chain0.forward(obs_now)
+    torch.cuda.synchronize()
+    kern_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     # the two phases of an iteration, measured apart AFTER the timed region (inside it the host never waits for the GPU, so
     # per-phase host clocks mean nothing there): 5 rollouts alone, bracketed by synchronize; the update is the remainder
     roll = []
@@ -177,7 +193,7 @@ def main():
             "rollout_env_steps_per_s": args.num_envs * T * world / (sum(coll) / len(coll)),
             "collection_s": sum(coll) / len(coll), "learn_s": sum(lrn) / len(lrn),
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_ms_alone, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
                          "note": "VALU-issue-bound, not byte-bound: 4096 envs = 256 wavefronts = one per CU, ~41k instructions per wavefront at 4.4 cycles each (DESIGN.md 4.1); 16384 envs/GPU reach 4 wavefronts per CU and 3.4x this rate"},
         }
