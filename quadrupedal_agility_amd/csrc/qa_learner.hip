@@ -410,17 +410,23 @@ struct GatherArgs {
 };
 
 __global__ void __launch_bounds__(256) qa_gather_rows_kernel(GatherArgs a) {
-    const int64_t r0 = (int64_t)blockIdx.x * GATHER_ROWS;
-#pragma unroll
-    for (int q = 0; q < GATHER_ROWS; ++q) {
-        const int64_t r = r0 + q;
-        if (r >= a.rows) return;
-        const int64_t s = a.idx[r];
-        for (int t = 0; t < a.n; ++t) {
-            const float *sp = a.src[t] + s * a.src_stride[t];
-            float *dp = a.dst[t] + r * a.width[t];
-            for (int c = threadIdx.x; c < a.width[t]; c += 256) dp[c] = sp[c];
+    /* one wavefront per row: the row index is wave-uniform, and a lane's loads along the row (11 for the 671-float
+     * observation) are all independent and in flight together */
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * GATHER_ROWS + (threadIdx.x >> 6);
+    if (r >= a.rows) return;
+    const int64_t s = a.idx[r];
+    for (int t = 0; t < a.n; ++t) {
+        const float *sp = a.src[t] + s * a.src_stride[t];
+        float *dp = a.dst[t] + r * a.width[t];
+        const int w = a.width[t];
+        if (w <= 64) { if (lane < w) dp[lane] = sp[lane]; continue; }
+        int c = lane;
+        for (; c + 192 < w; c += 256) {
+            const float v0 = sp[c], v1 = sp[c + 64], v2 = sp[c + 128], v3 = sp[c + 192];
+            dp[c] = v0; dp[c + 64] = v1; dp[c + 128] = v2; dp[c + 192] = v3;
         }
+        for (; c < w; c += 64) dp[c] = sp[c];
     }
 }
 
