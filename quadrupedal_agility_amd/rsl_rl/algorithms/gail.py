@@ -12,6 +12,8 @@ constructor signature and attribute names are the reference's.  What is differen
   * `amp_enabled=False` skips the discriminator update (BASELINE config 2; the reference has no
     such switch).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -114,6 +116,8 @@ class SSInfoGAIL:
         self.grad_sync = None          # callable(list_of_params, extra_scalars) -> None, installed for world_size > 1
         self.use_fused_loss = True     # GPU: PPO objective + gradient as one HIP kernel (qa_ppo_loss); False = eager PyTorch ops
         self._ac_graph, self._recording_ac, self._priv_coef_dev = None, False, None
+        self._disc_stream, self._recording_disc = None, False
+        self.overlap_updates = os.environ.get("QA_OVERLAP_UPDATES", "1") != "0"     # GPU: discriminator steps on a second stream beside the PPO steps
         self._dagger_graph, self._dagger_calls = None, 0
         self._task_w_dev = None
         # recordings wait for one eager update since construction / checkpoint load: optimizer state and the pointer
@@ -214,20 +218,41 @@ class SSInfoGAIL:
         if self.learning_steps >= self.begin_rim:
             self.info_max_coef_on = min(self.info_max_coef * (self.learning_steps - self.begin_rim) / 10000, self.info_max_coef)
         dev = self.device
-        if (self._on_gpu and self.use_update_graph and self._warm_updates >= 1 and self._ac_graph is not False
-                and self.desired_kl is not None and self.schedule == "adaptive"):
+        n_ac = self.num_learning_epochs * self.num_mini_batches
+        n_d = n_ac * 4
+        ac_recorded = (self._on_gpu and self.use_update_graph and self._warm_updates >= 1 and self._ac_graph is not False
+                       and self.desired_kl is not None and self.schedule == "adaptive")
+        # The discriminator steps read the replay ring, the mocap clips and their own networks; the PPO steps read the rollout
+        # storage and theirs: no data flows between the two loops inside update() (the reference runs them one after the other,
+        # gail.py:274-289).  Once both steps exist as recorded launches, the 80 tiny discriminator steps (launch-latency-bound,
+        # a few CUs each) are replayed on a second stream WHILE the 20 GEMM-bound PPO steps run.
+        if (ac_recorded and self.amp_enabled and self.overlap_updates and self.grad_sync is None and self._ac_graph and self._disc_graph):
+            main = torch.cuda.current_stream()
+            # drawn first so that the generator is consumed in the same order as when the loops run one after the other
+            perm = torch.randperm(self.storage.num_envs * self.storage.num_transitions_per_env // self.num_mini_batches * self.num_mini_batches, device=dev)
+            self._disc_stream.wait_stream(main)
+            with torch.cuda.stream(self._disc_stream):
+                mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
+                acc_d_dev = self._disc_updates_recorded(n_d, mb)
+            acc_ac = self._ac_updates_recorded(perm)
+            main.wait_stream(self._disc_stream)
+            self._clamp_std()
+            self.storage.clear()
+            self.priv_reg_counter += 1
+            self._warm_updates += 1
+            return LossReadout(torch.cat([acc_ac / n_ac, acc_d_dev / n_d]))
+        if ac_recorded:
             acc_ac = self._ac_updates_recorded()
         else:
             acc_ac = torch.zeros(6, device=dev)
             for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
                 acc_ac += torch.stack(self.update_actor_critic(sample))
-        n_ac = self.num_learning_epochs * self.num_mini_batches
-        n_d = n_ac * 4
         acc_d = torch.zeros(11, device=dev)
         if self.amp_enabled:
             mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
             if self._on_gpu and self.use_update_graph and self.grad_sync is None and self._warm_updates >= 1 and self._disc_graph is not False:
-                acc_d = self._disc_updates_recorded(n_d, mb)
+                acc_d = self._disc_updates_recorded(n_d, mb).clone()
+                self._clamp_std()
             else:
                 gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
                            self.motion_loader.feed_forward_generator_lb(n_d, mb),
@@ -239,12 +264,17 @@ class SSInfoGAIL:
         self._warm_updates += 1
         return LossReadout(torch.cat([acc_ac / n_ac, acc_d / n_d]))
 
+    def _clamp_std(self):
+        """gail.py:522-523 (inside every discriminator step there; idempotent, and nothing reads std in between)"""
+        if not self.actor_critic.fixed_std and self.min_std is not None:
+            self.actor_critic.std.data.clamp_(min=self.min_std)       # in place: recorded rollouts keep reading this buffer
+
     def _priv_reg_coef_now(self):
         s0, s1, t0, t1 = self.priv_reg_coef_schedual
         stage = min(max(self.priv_reg_counter - t0, 0) / t1, 1)
         return stage * (s1 - s0) + s0
 
-    def _ac_updates_recorded(self):
+    def _ac_updates_recorded(self, perm=None):
         """The 20 PPO minibatch steps of an iteration are ~270 launches each and the host cannot issue them faster than
         the GPU retires them (the iteration time followed the host's launch rate, 59-78 ms, not the GPU's 57 ms of kernel
         time).  One step -- minibatch gather from a device index buffer, both forwards, the fused objective, both
@@ -325,7 +355,8 @@ class SSInfoGAIL:
         with torch.no_grad():
             self._hist_latent_all.copy_(self.actor_critic.infer_hist_latent(st.observations.flatten(0, 1)[:, self._hist_cols]))
         ga, gb = self._ac_graph
-        perm = torch.randperm(self.num_mini_batches * mb, device=dev)       # one permutation for all epochs (rollout_storage.py:122-157)
+        if perm is None:
+            perm = torch.randperm(self.num_mini_batches * mb, device=dev)   # one permutation for all epochs (rollout_storage.py:122-157)
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 self._mb_idx.copy_(perm[i * mb:(i + 1) * mb])
@@ -361,8 +392,16 @@ class SSInfoGAIL:
                     o.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
                 from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
-                with _no_gc(), torch.cuda.graph(g):
-                    one_step()
+                # recorded on a stream of its own: the library GEMM workspace is keyed by the stream a launch is recorded on,
+                # and this step is replayed CONCURRENTLY with the PPO step's recording (update(), "overlap")
+                if self._disc_stream is None:
+                    self._disc_stream = torch.cuda.Stream(device=dev)
+                self._recording_disc = True
+                try:
+                    with _no_gc(), torch.cuda.graph(g, stream=self._disc_stream):
+                        one_step()
+                finally:
+                    self._recording_disc = False
                 self._disc_graph = g
             except Exception as e:      # never fatal
                 print(f"[disc update graph] capture failed, staying eager: {e}")
@@ -379,7 +418,7 @@ class SSInfoGAIL:
         self._acc_d.zero_()
         for _ in range(n_steps):
             self._disc_graph.replay()
-        return self._acc_d.clone()
+        return self._acc_d          # persistent: the caller copies it on ITS stream after joining
 
     def _sync_grads(self, params):
         if self.grad_sync is not None:
@@ -602,8 +641,8 @@ class SSInfoGAIL:
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
         for o in self._step_disc:
             o.step()
-        if not self.actor_critic.fixed_std and self.min_std is not None:
-            self.actor_critic.std.data.clamp_(min=self.min_std)       # in place: recorded rollouts keep reading this buffer
+        if not self._recording_disc:          # the recorded step leaves this to update(): once after the loop is the same thing
+            self._clamp_std()
         if self.disc_normalizer is not None:
             self.disc_normalizer.update_torch([policy_state, expert_lb, expert_ulb])
         if fused_heads:

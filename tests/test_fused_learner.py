@@ -669,3 +669,26 @@ def test_gather_rows_kernel_is_exact():
     out = gather_rows(idx, srcs)
     for o, s_ in zip(out, srcs):
         assert torch.equal(o, s_[idx])
+
+
+@pytest.mark.gpu
+def test_overlapped_discriminator_and_ppo_updates_match_sequential(monkeypatch):
+    """AMP config: discriminator steps replayed on a second stream beside the PPO steps vs. one loop after the other --
+    no data flows between the two loops, so weights of all three networks agree to GEMM rounding after 4 iterations"""
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    res = []
+    for overlap in (True, False):
+        torch.manual_seed(0)
+        env, args, tcfg = _make(256, True)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+        runner.alg.overlap_updates = overlap
+        runner.learn(4, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        a = runner.alg
+        assert a._disc_graph and a._ac_graph
+        res.append([{k: v.clone() for k, v in m.state_dict().items()} for m in (a.actor_critic, a.estimator, a.disc)] + [float(a.lr_ac)])
+    for wa, wb in zip(res[0][:3], res[1][:3]):
+        for k in wa:
+            assert torch.allclose(wa[k].float(), wb[k].float(), atol=5e-4, rtol=5e-3), k
+    assert res[0][3] == res[1][3]
