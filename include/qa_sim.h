@@ -272,7 +272,8 @@ int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, con
  *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
  * params / grads / exp_avg / exp_avg_sq / steps are DEVICE arrays of num_tensors device pointers (steps: one float
  * counter per tensor, all set to t); the work list is num_chunks (tensor, start, length <= 2048) triples in device
- * memory; weight_decay is per tensor, lr one device float.  scratch >= 4 + num_chunks floats; scratch[3] = ||g||_2. */
+ * memory; weight_decay is per tensor, lr one device float.  scratch >= 4 + num_chunks floats; scratch[3] = ||g||_2 (0 when
+ * max_norm <= 0: the norm is then not computed and the step is two launches). */
 int qa_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                       float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
                       const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,

@@ -344,7 +344,8 @@ __global__ void __launch_bounds__(256) qa_adam_sumsq_kernel(AdamArgs a) {
 __global__ void __launch_bounds__(256) qa_adam_finalize_kernel(AdamArgs a) {
     __shared__ double s_acc[256];
     double acc = 0.0;
-    for (int c = threadIdx.x; c < a.num_chunks; c += 256) acc += (double)a.scratch[4 + c];
+    if (a.max_norm > 0.f)          /* without clipping the per-chunk sums were not computed (and the norm is reported as 0) */
+        for (int c = threadIdx.x; c < a.num_chunks; c += 256) acc += (double)a.scratch[4 + c];
     s_acc[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; __syncthreads(); }
@@ -753,7 +754,7 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
     AdamArgs a{params, grads, exp_avg, exp_avg_sq, steps, chunk_tensor, chunk_start, chunk_len, weight_decay, lr, scratch, num_chunks, num_tensors,
                beta1, beta2, eps, max_norm};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(qa_adam_sumsq_kernel, dim3(num_chunks), dim3(256), 0, st, a);
+    if (max_norm > 0.f) hipLaunchKernelGGL(qa_adam_sumsq_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(qa_adam_finalize_kernel, dim3(1), dim3(256), 0, st, a);
     hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
