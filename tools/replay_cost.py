@@ -1,5 +1,6 @@
+"""Dev tool: host cost vs. total cost of replaying the recorded discriminator step, PPO step and rollout (AMP config)."""
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.test_gpu_train import _make
 from quadrupedal_agility_amd.legged_gym.envs import task_registry
 env, args, t = _make(4096, True); t.algorithm.disc_replay_buffer_size = 1000000
