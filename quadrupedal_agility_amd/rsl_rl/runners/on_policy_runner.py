@@ -226,7 +226,7 @@ class OnPolicyRunner:
 
     use_fused_rollout = True     # GPU, discriminator off: per-step bookkeeping as qa_rollout_act / qa_rollout_post
     phase_timing = os.environ.get("QA_PHASE_TIMING", "0") == "1" or bool(os.environ.get("QA_BENCH_TRACE"))
-    use_fused_policy = True      # ... and the policy's networks as one qa_mlp_forward launch per step
+    use_fused_policy = os.environ.get("QA_FUSED_POLICY", "1") != "0"      # ... and the policy networks as one qa_mlp_forward launch per step
     _chain = None
 
     def _rollout_steps(self, hist_encoding, logging, recorded):
