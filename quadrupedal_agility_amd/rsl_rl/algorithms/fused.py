@@ -57,6 +57,31 @@ class _PpoLoss(torch.autograd.Function):
                 None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
+def ppo_loss_raw(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values, *, clip, c_surr,
+                 c_value, c_bound, c_entropy, clipped_value=True):
+    """qa_ppo_loss without the autograd wrapper: (stats[8], d loss/d mu (B,12), d loss/d std (12), d loss/d value (B)).  The
+    caller feeds the gradients straight into autograd.backward() of the network outputs -- no scalar loss node, so none of
+    the ones-fill / scale / accumulate launches a `loss.backward()` spends on it."""
+    lib = _capi.load_library()
+    mu_c, std_c, val_c = _f32c(mu.detach()), _f32c(std.detach()), _f32c(value.detach())
+    fixed = [_f32c(x) for x in (actions, old_logp, old_mu, old_sigma, advantages, returns, target_values)]
+    B = mu_c.shape[0]
+    assert mu_c.is_cuda and mu_c.shape == (B, 12) and std_c.numel() == 12 and val_c.numel() == B
+    dmu = torch.empty_like(mu_c)
+    dstd = torch.empty(12, dtype=torch.float32, device=mu_c.device)
+    dvalue = torch.empty(B, dtype=torch.float32, device=mu_c.device)
+    out = torch.empty(8, dtype=torch.float32, device=mu_c.device)
+    nscratch = int(lib.qa_ppo_loss_scratch_bytes(B))
+    scratch = torch.empty(nscratch, dtype=torch.uint8, device=mu_c.device)
+    rc = lib.qa_ppo_loss(_ptr(mu_c), _ptr(std_c), _ptr(val_c), *[_ptr(x) for x in fixed], B, 12, float(clip), float(c_surr),
+                         float(c_value), float(c_bound), float(c_entropy), int(bool(clipped_value)),
+                         _ptr(dmu), _ptr(dstd), _ptr(dvalue), _ptr(out), _ptr(scratch), nscratch,
+                         C.c_void_p(torch.cuda.current_stream(mu_c.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"qa_ppo_loss failed with code {rc}: {lib.qa_last_error().decode()}")
+    return out, dmu, dstd, dvalue
+
+
 class _LinearElu(torch.autograd.Function):
     """y = elu(x W^T + b).  Forward: addmm (hipBLASLt) + in-place ELU.  Backward: ONE kernel for the ELU derivative and
     the bias gradient (qa_elu_backward_bias), then the two GEMMs.  Saves the ELU output only (elu' = y + alpha for y <= 0)."""
@@ -219,6 +244,23 @@ class _PairLoss(torch.autograd.Function):
 
 def pair_loss(a, b, mode):
     return _PairLoss.apply(a, b, mode)
+
+
+def pair_loss_raw(a, b, mode):
+    """qa_pair_loss without the autograd wrapper: (loss (0-d), d loss / d a)"""
+    a = _f32c(a.detach())
+    assert b.dtype == torch.float32 and b.stride(1) == 1 and a.shape == b.shape
+    rows, cols = a.shape
+    lib = _capi.load_library()
+    grad = torch.empty_like(a)
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    nscratch = int(lib.qa_pair_loss_scratch_bytes(rows))
+    scratch = torch.empty(nscratch, dtype=torch.uint8, device=a.device)
+    rc = lib.qa_pair_loss(_ptr(a), _ptr(b), rows, cols, b.stride(0), int(mode), _ptr(grad), _ptr(out), _ptr(scratch), nscratch,
+                          C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"qa_pair_loss failed with code {rc}: {lib.qa_last_error().decode()}")
+    return out, grad
 
 
 def gather_rows(idx, srcs, dsts=None):

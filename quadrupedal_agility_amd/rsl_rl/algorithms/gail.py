@@ -430,6 +430,8 @@ class SSInfoGAIL:
         hist_latent = sample[11] if len(sample) > 11 else None       # recorded updates: evaluated once per update() for all samples
         ac = self.actor_critic
         fused = self._on_gpu and self.use_fused_loss
+        if fused and not ac.fixed_std:
+            return self._ac_forward_backward_direct(obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hist_latent)
         if fused:
             # mean / value only; log-prob, entropy, KL, the four loss terms and their gradient are ONE kernel (fused.py)
             mu = ac._actor_mean(obs.detach(), False)
@@ -497,6 +499,34 @@ class SSInfoGAIL:
         loss.backward()
         return (surrogate_loss.detach(), value_loss.detach(), b_mean.detach(), ent_mean.detach(),
                 priv_reg_loss.detach(), estimator_loss.detach()), kl_mean
+
+    def _ac_forward_backward_direct(self, obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hist_latent):
+        """The same step on the GPU without scalar loss nodes: the kernels return every term's value AND its gradient w.r.t. the
+        network outputs, which go straight into autograd.backward() of those outputs (what `loss.backward()` computes, minus the
+        ones-fills, scalings and accumulations of the scalar graph: ~10 launches per step)."""
+        ac = self.actor_critic
+        mu = ac._actor_mean(obs.detach(), False)
+        value = ac.evaluate(critic_obs.detach())
+        out, dmu, dstd, dvalue = fused_mod.ppo_loss_raw(mu, ac.std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
+                                                        clip=self.clip_param, c_surr=self.surrogate_loss_coef, c_value=self.value_loss_coef,
+                                                        c_bound=self.bounds_loss_coef, c_entropy=self.entropy_coef,
+                                                        clipped_value=self.use_clipped_value_loss)
+        a = self.num_prop; b = a + self.num_explicit; c = b + self.num_latent; d = c + self.num_hist * self.num_prop
+        priv_latent = ac.infer_priv_latent(obs[:, b:c])
+        if hist_latent is None:
+            with torch.no_grad():
+                hist_latent = ac.infer_hist_latent(obs[:, c:d])
+        priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
+        priv_reg_coef = self._priv_coef_dev if self._recording_ac else self._priv_reg_coef_now()
+        est = self.estimator(obs[:, :a])
+        estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
+        self.optim_estimator.zero_grad()
+        est.backward(g_est)
+        self.optim_ac.zero_grad()
+        torch.autograd.backward([mu, value, priv_latent], [dmu, dvalue.view_as(value), g_priv * priv_reg_coef])
+        ac.std.grad = dstd.view_as(ac.std)          # std enters the objective through qa_ppo_loss only
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        return (out[1], out[2], out[3], out[4], priv_reg_loss, estimator_loss), (out[5] if adaptive else None)
 
     def _ac_apply(self, kl_mean):
         """Second half of the step: clip + step the estimator, the KL-adaptive learning rate, clip + step the actor-critic."""

@@ -114,7 +114,9 @@ def test_update_step_with_and_without_the_fused_kernel(tmp_path):
         runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
         runner.alg.use_fused_loss = fused
         runner.learn(1, init_at_random_ep_len=True)
-        res.append({k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()})
+        w = {k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()}
+        w.update({"estimator." + k: v.clone() for k, v in runner.alg.estimator.state_dict().items()})
+        res.append(w)
         lr = float(runner.alg.lr_ac)
         res.append(lr)
     (wa, lra, wb, lrb) = res
