@@ -123,18 +123,24 @@ __global__ void __launch_bounds__(PPO_BLOCK) qa_ppo_loss_kernel(PpoArgs a) {
 // fixed summation order (double), so results do not depend on scheduling
 __global__ void __launch_bounds__(256) qa_ppo_finish_kernel(const float *partial, int nblocks, int64_t B, float c_surr, float c_value,
                                                             float c_bound, float c_entropy, float *out, float *dstd) {
+    /* all PPO_SUMS sums in one pass: thread = (sum k, lane l of LANES); a lane adds every LANES-th block partial in double,
+     * then one thread per sum adds the lanes in a fixed order (was: one full tree reduction per sum, 17 in sequence) */
+    constexpr int LANES = 256 / PPO_SUMS;
     __shared__ double s_acc[256];
     __shared__ double s_tot[PPO_SUMS];
     const int t = threadIdx.x;
-    for (int k = 0; k < PPO_SUMS; ++k) {
-        double acc = 0.0;
-        for (int b = t; b < nblocks; b += 256) acc += (double)partial[(int64_t)b * PPO_SUMS + k];
-        s_acc[t] = acc;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (t < o) s_acc[t] += s_acc[t + o]; __syncthreads(); }
-        if (t == 0) s_tot[k] = s_acc[0];
-        __syncthreads();
+    const int k = t / LANES, l = t % LANES;
+    double acc = 0.0;
+    if (k < PPO_SUMS)
+        for (int b = l; b < nblocks; b += LANES) acc += (double)partial[(int64_t)b * PPO_SUMS + k];
+    s_acc[t] = acc;
+    __syncthreads();
+    if (k < PPO_SUMS && l == 0) {
+        double tot = 0.0;
+        for (int q = 0; q < LANES; ++q) tot += s_acc[k * LANES + q];
+        s_tot[k] = tot;
     }
+    __syncthreads();
     const double invB = 1.0 / (double)B;
     if (t < 5) out[1 + t] = (float)(s_tot[t] * invB);
     if (t == 5) out[0] = (float)((c_surr * s_tot[0] + c_value * s_tot[1] + c_bound * s_tot[2] - c_entropy * s_tot[3]) * invB);
