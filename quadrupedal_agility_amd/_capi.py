@@ -162,6 +162,10 @@ def load_library():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). quadrupedal_agility_amd has no CPU fallback.")
+        # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); the device pointers and streams this library is
+        # handed belong to THAT runtime.  Loading torch first makes our DT_NEEDED libamdhip64 resolve to the copy already in
+        # the process -- loaded the other way round, the process holds two runtimes and ours sees no device.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         bind(lib, "qa_")
         lib.qa_last_error.restype = C.c_char_p
