@@ -360,8 +360,8 @@ int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
 #define QA_MLP_MAX_OPS 24
 #define QA_MLP_MAX_OUTPUTS 4
 #define QA_MLP_BUF0_COLS 672
-#define QA_MLP_BUF1_COLS 512
-#define QA_MLP_BUF2_COLS 256
+#define QA_MLP_BUF1_COLS 576
+#define QA_MLP_BUF2_COLS 320
 #define QA_MLP_BUF3_COLS 128
 typedef struct qa_mlp_op {
     int32_t kind;

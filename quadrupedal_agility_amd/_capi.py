@@ -144,7 +144,7 @@ class QaMlpOp(C.Structure):
 
 
 MLP_COPY, MLP_LAYER, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 24, 4
-MLP_BUF_COLS = (672, 512, 256, 128)
+MLP_BUF_COLS = (672, 576, 320, 128)
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",

@@ -525,31 +525,54 @@ class PolicyChain:
         return out
 
     @classmethod
-    def describe(cls, actor_critic, estimator, use_estimator):
-        """-> PolicyChain, or None when the modules are not plain Linear/ELU stacks that fit the kernel's buffers"""
+    def describe(cls, actor_critic, estimator, use_estimator, hist_encoding=False, with_critic=True):
+        """-> PolicyChain, or None when the modules are not plain Linear/ELU stacks that fit the kernel's buffers.
+        hist_encoding=True describes the variant whose latent comes from the history encoder (rollouts of every
+        dagger_update_freq-th iteration, play.py, the exported policy): its per-frame Linear and its two Conv1d layers are
+        each ONE layer op over the t-major window buffer, with the structured matrix (block-diagonal / banded) built from the
+        module's parameters at pack() time; Flatten's channel-major order is folded into the output layer's columns."""
         import torch.nn as nn
         ac = actor_critic
         sl = ac._sl
         n_prop, n_exp, n_lat = ac.num_prop, ac.num_explicit, ac.num_latent
-        cmd0 = sl[4].start
+        hist0, cmd0 = sl[3].start, sl[4].start
         n_obs = ac.num_critic_obs
         n_cmd = n_obs - cmd0
         n_in = n_prop + n_exp + n_lat + n_cmd
-        stacks = dict(actor=cls._linears(ac.actor_trunk), critic=cls._linears(ac.critic_trunk))
-        if ac.train_with_estimated_latent and not isinstance(ac.priv_encoder, nn.Identity):
+        stacks = dict(actor=cls._linears(ac.actor_trunk))
+        if with_critic:
+            stacks["critic"] = cls._linears(ac.critic_trunk)
+        use_priv = ac.train_with_estimated_latent and not hist_encoding and not isinstance(ac.priv_encoder, nn.Identity)
+        use_hist = ac.train_with_estimated_latent and hist_encoding
+        if use_priv:
             stacks["priv"] = cls._linears(ac.priv_encoder)
         if use_estimator:
             stacks["est"] = cls._linears(estimator.estimator)
         if any(v is None for v in stacks.values()) or n_obs > cls.BUF_COLS[0] or n_in > cls.BUF_COLS[3] or cmd0 + n_cmd != n_obs:
             return None
         stacks["actor"] = stacks["actor"] + [[ac.actor_head, 0]]
-        stacks["critic"] = stacks["critic"] + [[ac.critic_head, 0]]
+        if with_critic:
+            stacks["critic"] = stacks["critic"] + [[ac.critic_head, 0]]
         ops, params, woff = [], [], [0]
         Z = 3
+        lds_end = sum(16 * (c + 4) for c in cls.BUF_COLS)
 
         def copy(src, scol, dst, dcol, n):
             ops.append(_capi.QaMlpOp(kind=_capi.MLP_COPY, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=0, n=n))
             params.append(None)
+
+        def layer(src, scol, k, dst, dcol, n, act, oi, w, bias):
+            if dst == src or (dst >= 0 and dcol + n > cls.BUF_COLS[dst]) or scol % 4 or scol + k > cls.BUF_COLS[src] + 4:
+                return False
+            nt, kb = (n + 15) // 16, cls.k_blocks(k, n)
+            base = sum(16 * (c + 4) for c in cls.BUF_COLS[:src])
+            if base + 15 * (cls.BUF_COLS[src] + 4) + scol + 16 * kb > lds_end:
+                return False            # the padded k-blocks would be read from beyond the kernel's LDS
+            w_off = woff[0]; b_off = w_off + nt * kb * 256; woff[0] = b_off + nt * 16
+            ops.append(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=k, n=n, act=act,
+                                     out_index=oi, w_off=w_off, b_off=b_off))
+            params.append((w, bias))
+            return True
 
         def chain(layers, src, scol, k, final, reserved):
             """layers through scratch buffers; `final` = ("buf", b, col) or ("out", index)"""
@@ -564,34 +587,63 @@ class PolicyChain:
                     if not fit:
                         return False
                     dst, dcol, oi = fit[0], 0, 0
-                if dst == src:
+                if not layer(src, scol, k, dst, dcol, n, act, oi, lin.weight, lin.bias):
                     return False
-                nt, kb = (n + 15) // 16, cls.k_blocks(k, n)
-                base = sum(16 * (c + 4) for c in cls.BUF_COLS[:src])
-                if base + 15 * (cls.BUF_COLS[src] + 4) + scol + 16 * kb > sum(16 * (c + 4) for c in cls.BUF_COLS):
-                    return False            # the padded k-blocks would be read from beyond the kernel's LDS
-                w_off = woff[0]; b_off = w_off + nt * kb * 256; woff[0] = b_off + nt * 16
-                ops.append(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=k, n=n, act=act,
-                                         out_index=oi, w_off=w_off, b_off=b_off))
-                params.append((lin.weight, lin.bias))
                 src, scol, k = dst, 0, n
             return True
 
         ok = True
+        lat_col = n_prop + n_exp
+        if use_hist:        # first: it borrows buffer 3 (the actor-input buffer Z) for the first convolution's output
+            he = ac.history_encoder
+            convs = [m for m in he.conv_layers if isinstance(m, nn.Conv1d)]
+            elu = isinstance(he.activation_fn, nn.ELU) and he.activation_fn.alpha == 1.0
+            if len(convs) != 2 or not elu or any(c.padding[0] or c.dilation[0] != 1 or c.bias is None for c in convs):
+                return None
+            enc, outl, T = he.encoder[0], he.linear_output[0], he.tsteps
+            (c1, c2) = convs
+            C0, C1, C2 = enc.out_features, c1.out_channels, c2.out_channels
+            T1 = (T - c1.kernel_size[0]) // c1.stride[0] + 1
+            T2 = (T1 - c2.kernel_size[0]) // c2.stride[0] + 1
+            if (enc.in_features != n_prop or hist0 + T * n_prop != cmd0 or outl.in_features != C2 * T2 or outl.out_features != n_lat
+                    or T * n_prop > cls.BUF_COLS[1] or T * C0 > cls.BUF_COLS[2] or T1 * C1 > cls.BUF_COLS[3] or T2 * C2 > cls.BUF_COLS[1]):
+                return None
+
+            def conv_matrix(conv, t_in, t_out):
+                """(t_out C_out, t_in C_in): row p C_out + o, column (s p + j) C_in + c  <-  conv.weight[o, c, j]"""
+                def build():
+                    w = conv.weight
+                    co, ci, k = w.shape
+                    s_ = conv.stride[0]
+                    full = torch.zeros(t_out * co, t_in * ci, dtype=w.dtype, device=w.device)
+                    blk = w.permute(0, 2, 1).reshape(co, k * ci)
+                    for p_ in range(t_out):
+                        full[p_ * co:(p_ + 1) * co, s_ * p_ * ci:(s_ * p_ + k) * ci] = blk
+                    return full
+                return build
+
+            rep = lambda b_, r: (lambda: b_.repeat(r))
+            copy(0, hist0, 1, 0, T * n_prop)
+            ok &= layer(1, 0, T * n_prop, 2, 0, T * C0, 1, 0, lambda: torch.block_diag(*([enc.weight] * T)).contiguous(), rep(enc.bias, T))
+            ok &= layer(2, 0, T * C0, 3, 0, T1 * C1, 1, 0, conv_matrix(c1, T, T1), rep(c1.bias, T1))
+            ok &= layer(3, 0, T1 * C1, 1, 0, T2 * C2, 1, 0, conv_matrix(c2, T1, T2), rep(c2.bias, T2))
+            ok &= layer(1, 0, T2 * C2, Z, lat_col, n_lat, 1, 0,
+                        lambda: outl.weight.view(n_lat, C2, T2).permute(0, 2, 1).reshape(n_lat, T2 * C2).contiguous(), outl.bias)
         copy(0, 0, Z, 0, n_prop)
         if use_estimator:
             ok &= chain(stacks["est"], 0, 0, n_prop, ("buf", Z, n_prop), {Z}) and stacks["est"][-1][0].out_features == n_exp
         else:
             copy(0, n_prop, Z, n_prop, n_exp)
-        if "priv" in stacks:
-            copy(0, n_prop + n_exp, 2, 0, n_lat)                     # to column 0: a layer's source must be 16-byte aligned
-            ok &= chain(stacks["priv"], 2, 0, n_lat, ("buf", Z, n_prop + n_exp), {Z}) and stacks["priv"][-1][0].out_features == n_lat
-        else:
-            copy(0, n_prop + n_exp, Z, n_prop + n_exp, n_lat)
-        copy(0, cmd0, Z, n_prop + n_exp + n_lat, n_cmd)
+        if use_priv:
+            copy(0, lat_col, 2, 0, n_lat)                            # to column 0: a layer's source must be 16-byte aligned
+            ok &= chain(stacks["priv"], 2, 0, n_lat, ("buf", Z, lat_col), {Z}) and stacks["priv"][-1][0].out_features == n_lat
+        elif not use_hist:
+            copy(0, lat_col, Z, lat_col, n_lat)
+        copy(0, cmd0, Z, lat_col + n_lat, n_cmd)
         ok &= chain(stacks["actor"], Z, 0, n_in, ("out", 0), set())
-        ok &= chain(stacks["critic"], 0, 0, n_obs, ("out", 1), set())
-        if not ok or len(ops) > _capi.MLP_MAX_OPS or stacks["critic"][-1][0].out_features != 1:
+        if with_critic:
+            ok &= chain(stacks["critic"], 0, 0, n_obs, ("out", 1), set()) and stacks["critic"][-1][0].out_features == 1
+        if not ok or len(ops) > _capi.MLP_MAX_OPS:
             return None
         self = cls(ops, params, stacks["actor"][-1][0].out_features)
         self.packed_floats = woff[0]
@@ -599,18 +651,21 @@ class PolicyChain:
 
     # ---------------------------------------------------------------- device side
     def _ptr_arrays(self):
-        w = (C.c_void_p * self.n_ops)(*[(p[0].data_ptr() if p else None) for p in self.params])
-        b = (C.c_void_p * self.n_ops)(*[(p[1].data_ptr() if p and p[1] is not None else None) for p in self.params])
+        """device pointers of every layer's (weight, bias); entries of `params` may be callables that build the tensor from the
+        module's parameters (the structured matrices of the history encoder) -- the results stay referenced in self._built"""
+        self._built = [tuple((t() if callable(t) else t) for t in p) if p else None for p in self.params]
+        w = (C.c_void_p * self.n_ops)(*[(p[0].data_ptr() if p else None) for p in self._built])
+        b = (C.c_void_p * self.n_ops)(*[(p[1].data_ptr() if p and p[1] is not None else None) for p in self._built])
         return w, b
 
     def pack(self):
-        dev = next(p[0] for p in self.params if p).device
+        w, b = self._ptr_arrays()
+        dev = next(p[0] for p in self._built if p).device
         if self.packed is None:
             self.packed = torch.zeros(self.packed_floats, dtype=torch.float32, device=dev)
-        for p in self.params:
+        for p in self._built:
             if p and not (p[0].is_cuda and p[0].is_contiguous() and p[0].dtype == torch.float32):
                 raise RuntimeError("PolicyChain: parameters must be contiguous fp32 ROCm tensors")
-        w, b = self._ptr_arrays()
         lib = _capi.load_library()
         rc = lib.qa_mlp_pack(self.ops, self.n_ops, w, b, _ptr(self.packed), self.packed_floats, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc != 0:

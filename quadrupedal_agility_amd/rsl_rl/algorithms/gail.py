@@ -154,10 +154,10 @@ class SSInfoGAIL:
 
     # ------------------------------------------------------------------ rollout side
     def act(self, obs, critic_obs, hist_encoding=False, chain=None):
-        """gail.py:176-197.  `chain` (fused.PolicyChain, privileged-encoder variant only) evaluates the estimator, encoder,
+        """gail.py:176-197.  `chain` (fused.PolicyChain of the same actor variant) evaluates the estimator, encoder,
         actor and critic in one launch; the sampling and the transition record are the same either way."""
         tr = self.transition
-        if chain is not None and not hist_encoding:
+        if chain is not None:           # described for this actor variant (privileged / history encoder) by the caller
             ac = self.actor_critic
             mean, value = chain.forward(obs)
             ac.distribution = torch.distributions.Normal(mean, mean * 0.0 + ac.std, validate_args=False)

@@ -237,7 +237,7 @@ class OnPolicyRunner:
             return self._rollout_steps_fused(hist_encoding, logging)
         obs, hist, cur = self._obs_cur, self._disc_hist, self._cur
         ep_infos = []
-        chain = self._policy_chain() if (obs.is_cuda and not hist_encoding) else None
+        chain = self._policy_chain(hist_encoding) if obs.is_cuda else None
         if chain is not None:
             chain.pack()
         for i in range(T):
@@ -285,7 +285,7 @@ class OnPolicyRunner:
         std = alg.actor_critic.std
         seed = int(env.sim.cfg.seed)
         ep_infos = []
-        chain = self._policy_chain() if not hist_encoding else None
+        chain = self._policy_chain(hist_encoding)
         if chain is not None:
             chain.pack()                # the weights changed in the last update(); one small launch per rollout
         for i in range(T):
@@ -314,16 +314,20 @@ class OnPolicyRunner:
         self._obs_cur.copy_(obs)
         return ep_infos
 
-    def _policy_chain(self):
-        """qa_mlp_forward description of the policy (estimator + privileged encoder + actor + critic), built once; None when
-        the modules do not fit the kernel (then the rollout keeps the GEMM path)."""
+    def _policy_chain(self, hist_encoding=False):
+        """qa_mlp_forward description of the policy (estimator + latent encoder + actor + critic), one per actor variant
+        (privileged encoder / history encoder), built once; None when the modules do not fit the kernel (then the rollout
+        keeps the GEMM path)."""
         if not self.use_fused_policy:
             return None
         if self._chain is None:
+            self._chain = {}
+        key = bool(hist_encoding)
+        if key not in self._chain:
             from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
             alg = self.alg
-            self._chain = PolicyChain.describe(alg.actor_critic, alg.estimator, alg.train_with_estimated_explicit) or False
-        return self._chain or None
+            self._chain[key] = PolicyChain.describe(alg.actor_critic, alg.estimator, alg.train_with_estimated_explicit, hist_encoding=key)
+        return self._chain[key]
 
     def _collect(self, hist_encoding, logging):
         """One rollout.  On the GPU the non-DAgger variant is recorded into a hipGraph the second time it runs and replayed
@@ -511,7 +515,28 @@ class OnPolicyRunner:
         return d["infos"]
 
     def get_inference_policy(self, device=None):
-        self.alg.actor_critic.eval()
+        """obs (B, 671) -> action means, `ActorCritic.act_inference` (history-encoder variant by default), as the reference's.
+        On the GPU the returned callable evaluates the history encoder and the actor in ONE launch (qa_mlp_forward) from a
+        snapshot of the weights taken now; `policy.refresh()` re-reads them."""
+        ac = self.alg.actor_critic
+        ac.eval()
         if device is not None:
-            self.alg.actor_critic.to(device)
-        return self.alg.actor_critic.act_inference
+            ac.to(device)
+        chain = None
+        if self.use_fused_policy and next(ac.parameters()).is_cuda:
+            from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
+            chain = PolicyChain.describe(ac, self.alg.estimator, False, hist_encoding=True, with_critic=False)
+        if chain is None:
+            return ac.act_inference
+
+        def refresh():
+            with torch.inference_mode():
+                chain.pack()
+
+        def policy(observations, hist_encoding=True):
+            if not hist_encoding or not observations.is_cuda or observations.dim() != 2 or observations.dtype != torch.float32:
+                return ac.act_inference(observations, hist_encoding)
+            return chain.forward(observations if observations.stride(1) == 1 else observations.contiguous())[0].clone()
+        refresh()
+        policy.refresh = refresh
+        return policy

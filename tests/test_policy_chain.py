@@ -28,18 +28,18 @@ def modules(seed=0, priv_dims=(64,), hidden=(512, 256, 128), est_hidden=(128, 64
     return ac, est, n_obs
 
 
-def torch_reference(ac, est, obs, use_estimator):
+def torch_reference(ac, est, obs, use_estimator, hist_encoding=False):
     with torch.no_grad():
         x = torch.cat([obs[:, :57], est(obs[:, :57]), obs[:, 61:]], dim=-1) if use_estimator else obs
-        return ac._actor_mean(x, False), ac.evaluate(obs)
+        return ac._actor_mean(x, hist_encoding), ac.evaluate(obs)
 
 
 def run_oracle(chain, obs):
     from tests.oracle_lib import load_oracle
     lib = load_oracle()
     n = obs.shape[0]
-    w = (C.c_void_p * chain.n_ops)(*[(p[0].data_ptr() if p else None) for p in chain.params])
-    b = (C.c_void_p * chain.n_ops)(*[(p[1].data_ptr() if p and p[1] is not None else None) for p in chain.params])
+    with torch.no_grad():
+        w, b = chain._ptr_arrays()          # evaluates the structured-matrix providers of the history-encoder variant
     packed = np.zeros(chain.packed_floats, np.float32)
     assert lib.qo_mlp_packed_floats(chain.ops, chain.n_ops) == chain.packed_floats
     assert lib.qo_mlp_pack(chain.ops, chain.n_ops, w, b, packed.ctypes.data, packed.size, None) == 0
@@ -61,6 +61,21 @@ def test_description_and_twin_match_torch_modules(use_estimator):
     rm, rv = torch_reference(ac, est, obs, use_estimator)
     np.testing.assert_allclose(mean, rm.numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(value, rv.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("use_estimator,with_critic", [(True, True), (False, False)])
+def test_history_encoder_variant_matches_torch_modules(use_estimator, with_critic):
+    """the variant of DAgger rollouts / play.py / the exported policy: per-frame Linear, two Conv1d and Flatten of the history
+    encoder as four layer ops with structured matrices"""
+    ac, est, n_obs = modules(seed=5)
+    chain = PolicyChain.describe(ac, est, use_estimator, hist_encoding=True, with_critic=with_critic)
+    assert chain is not None and chain.n_ops <= _capi.MLP_MAX_OPS
+    obs = torch.randn(21, n_obs)
+    mean, value = run_oracle(chain, obs)
+    rm, rv = torch_reference(ac, est, obs, use_estimator, hist_encoding=True)
+    np.testing.assert_allclose(mean, rm.numpy(), rtol=1e-4, atol=2e-5)
+    if with_critic:
+        np.testing.assert_allclose(value, rv.numpy(), rtol=1e-4, atol=2e-5)
 
 
 def test_description_refuses_what_the_kernel_cannot_hold():
@@ -106,6 +121,24 @@ def test_hip_chain_matches_twin_and_torch(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 100, 4096])
+def test_hip_chain_history_encoder_variant(n):
+    ac, est, n_obs = modules(seed=9)
+    ac, est = ac.cuda(), est.cuda()
+    obs = torch.randn(n, n_obs, device="cuda") * 1.5
+    for use_est, with_critic in ((True, True), (False, False)):
+        chain = PolicyChain.describe(ac, est, use_est, hist_encoding=True, with_critic=with_critic)
+        with torch.inference_mode():
+            chain.pack()
+            mean, value = chain.forward(obs)
+        torch.cuda.synchronize()
+        rm, rv = torch_reference(ac, est, obs, use_est, hist_encoding=True)
+        np.testing.assert_allclose(mean.cpu().numpy(), rm.cpu().numpy(), rtol=2e-4, atol=5e-5)
+        if with_critic:
+            np.testing.assert_allclose(value.cpu().numpy(), rv.cpu().numpy(), rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
 def test_hip_chain_rejects_malformed_ops():
     lib = _capi.load_library()
     x = torch.zeros(16, 671, device="cuda"); packed = torch.zeros(1 << 20, device="cuda")
@@ -137,7 +170,7 @@ def test_rollout_through_the_chain_matches_the_gemm_path(amp):
         torch.cuda.synchronize()
         st = runner.alg.storage
         got[fused] = (st.mu.cpu().clone(), st.values.cpu().clone(), st.actions_log_prob.cpu().clone())
-        assert (runner._chain is not None and runner._chain is not False) == fused
+        assert bool(runner._chain and runner._chain.get(False)) == fused
     (m1, v1, l1), (m0, v0, l0) = got[True], got[False]
     np.testing.assert_allclose(m1[0], m0[0], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(v1[0], v0[0], rtol=1e-4, atol=2e-5)

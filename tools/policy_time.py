@@ -32,6 +32,16 @@ with torch.inference_mode():
     with torch.cuda.graph(g):
         torch_reference(ac, est, obs, True)
     t_graph = timed(g.replay)
+hchain = PolicyChain.describe(ac, est, False, hist_encoding=True, with_critic=False)      # what play.py / the exported policy evaluates
+with torch.inference_mode():
+    hchain.pack()
+    t_hist = timed(lambda: hchain.forward(obs))
+    t_hist_torch = timed(lambda: ac.act_inference(obs, hist_encoding=True))
+    gh = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gh):
+        ac.act_inference(obs, hist_encoding=True)
+    t_hist_graph = timed(gh.replay)
+print(f"N={N}: act_inference(history encoder): qa_mlp_forward {t_hist:.1f} us, torch eager {t_hist_torch:.1f} us, torch in a hipGraph {t_hist_graph:.1f} us")
 flops = 1488128 * N
 print(f"N={N}: qa_mlp_forward {t_chain:.1f} us ({flops / t_chain / 1e6:.1f} TFLOP/s, {flops / t_chain / 1e6 / 157.3 * 100:.1f}% of fp32 MFMA peak), "
       f"qa_mlp_pack {t_pack:.1f} us, torch eager {t_torch:.1f} us, torch in a hipGraph {t_graph:.1f} us")
