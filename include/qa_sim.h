@@ -316,6 +316,18 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
                    float *st_values, void *stream);
 int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
                     int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream);
+/* The same with the discriminator's rewards (Discriminator.predict_disc_reward, bbc/rsl_rl/algorithms/discriminator.py:88-118,
+ * MSELoss mapping): d, eps (N) and class logits (N, dim_c <= 8) are the three heads' outputs for this step's frame pair; the
+ * labels are read from the step's observation rows obs (N rows, obs_stride floats apart): eps label = obs[num_obs - dim_c - 1],
+ * class label = argmax obs[num_obs - dim_c :].
+ *   p = max(softmax(logits), 1e-20);  r_i = max(0, 1 - (d - 1)^2 / 4) dt;  r_us = -|eps - label| dt;
+ *   r_ss = (p[label] - logsumexp(p)) dt   (cross-entropy applied to the already-softmaxed p, as the reference)
+ *   total = c_i r_i + c_us r_us + c_ss r_ss + c_t rew;   st_rewards = total + gamma values time_out
+ * and the running sums advance by [total, r_i, r_us, r_ss, rew, 1]. */
+int qa_rollout_post_amp(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, const float *d, const float *eps,
+                        const float *logits, int32_t dim_c, const float *obs, int64_t obs_stride, int32_t num_obs, float c_i, float c_us,
+                        float c_ss, float c_t, float dt, float gamma, int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur,
+                        float *fin_vals, uint8_t *fin_mask, void *stream);
 
 /* Head losses of the SS-InfoGAIL discriminator step and their gradient w.r.t. the head outputs
  * (bbc/rsl_rl/algorithms/gail.py:452-520, MSELoss variant).  Rows are [labelled expert b_lb | policy b_pi | unlabelled
@@ -346,7 +358,7 @@ int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
  * behind play.py / the exported policy).  The chain is a HOST array of ops run in order on every tile:
  *   QA_MLP_COPY : dst_buf[:, dst_col : dst_col+n] = src_buf[:, src_col : src_col+n]
  *   QA_MLP_LAYER: y = src_buf[:, src_col : src_col+k] @ W^T + b, W (n,k) row-major as nn.Linear stores it; act 1 applies
- *                 ELU(alpha 1).  y goes to dst_buf[:, dst_col : dst_col+n], or with dst_buf = -1 to rows of the global
+ *                 ELU(alpha 1), act 2 ReLU.  y goes to dst_buf[:, dst_col : dst_col+n], or with dst_buf = -1 to rows of the global
  *                 output `out_index`.
  * Buffer 0 holds the tile of the input rows x (x_cols <= QA_MLP_BUF0_COLS) and is read-only; buffers 1..3 are scratch
  * with QA_MLP_BUFn_COLS columns, zero at the start of the chain.  A layer's src_col must be a multiple of 4 and its

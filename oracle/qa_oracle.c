@@ -1262,6 +1262,44 @@ int qo_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
     return QA_OK;
 }
 
+int qo_rollout_post_amp(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, const float *d, const float *eps,
+                        const float *logits, int32_t dim_c, const float *obs, int64_t obs_stride, int32_t num_obs, float c_i, float c_us,
+                        float c_ss, float c_t, float dt, float gamma, int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur,
+                        float *fin_vals, uint8_t *fin_mask, void *stream) {
+    (void)stream;
+    if (!rew || !reset || !time_out || !values || !d || !eps || !logits || !obs || !st_rewards || !st_dones || num_envs <= 0 || dim_c <= 0 || dim_c > 8 ||
+        num_obs < dim_c + 1 || obs_stride < num_obs || (cur && (!fin_vals || !fin_mask))) return QA_E_ARG;
+    const int N = num_envs;
+    for (int e = 0; e < N; ++e) {               /* Discriminator.predict_disc_reward, discriminator.py:88-118 (MSELoss mapping) */
+        const float *o = obs + (int64_t)e * obs_stride;
+        const double label_eps = o[num_obs - dim_c - 1];
+        int label = 0;
+        for (int k = 1; k < dim_c; ++k) if (o[num_obs - dim_c + k] > o[num_obs - dim_c + label]) label = k;
+        double p[8], m = logits[(int64_t)e * dim_c], z = 0.0, lse = 0.0;
+        for (int k = 1; k < dim_c; ++k) if (logits[(int64_t)e * dim_c + k] > m) m = logits[(int64_t)e * dim_c + k];
+        for (int k = 0; k < dim_c; ++k) { p[k] = exp((double)logits[(int64_t)e * dim_c + k] - m); z += p[k]; }
+        for (int k = 0; k < dim_c; ++k) { p[k] /= z; if (p[k] < 1e-20) p[k] = 1e-20; }
+        for (int k = 0; k < dim_c; ++k) lse += exp(p[k]);
+        lse = log(lse);
+        const double dd = (double)d[e] - 1.0, r_i0 = 1.0 - 0.25 * dd * dd;
+        const double r_i = (r_i0 > 0.0 ? r_i0 : 0.0) * dt, r_us = -fabs((double)eps[e] - label_eps) * dt, r_ss = (p[label] - lse) * dt, r_t = rew[e];
+        const double total = c_i * r_i + c_us * r_us + c_ss * r_ss + c_t * r_t;
+        const int done = reset[e] > 0;
+        st_rewards[e] = (float)(total + (double)gamma * values[e] * (time_out[e] ? 1.0 : 0.0));
+        st_dones[e] = done ? 1 : 0;
+        if (cur) {
+            const double add[6] = {total, r_i, r_us, r_ss, r_t, 1.0};
+            for (int k = 0; k < 6; ++k) {
+                const float c = (float)((double)cur[(int64_t)k * N + e] + add[k]);
+                fin_vals[(int64_t)k * N + e] = c;
+                cur[(int64_t)k * N + e] = done ? 0.0f : c;
+            }
+            fin_mask[e] = done ? 1 : 0;
+        }
+    }
+    return QA_OK;
+}
+
 int64_t qo_pair_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * ((rows + 255) / 256); }
 
 int qo_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int64_t b_stride, int32_t mode, float *grad_a, float *out,
@@ -1365,7 +1403,8 @@ int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
                 double acc = bias[c];
                 for (int k = 0; k < o->k; ++k) acc += (double)w[(int64_t)c * o->k + k] * (double)in[k];
                 float v = (float)acc;
-                if (o->act) v = v > 0.0f ? v : (float)(exp((double)v) - 1.0);
+                if (o->act == 1) v = v > 0.0f ? v : (float)(exp((double)v) - 1.0);
+                else if (o->act == 2) v = v > 0.0f ? v : 0.0f;
                 if (o->dst_buf > 0) buf[o->dst_buf][o->dst_col + c] = v;
                 else outs[o->out_index][r * out_strides[o->out_index] + c] = v;
             }

@@ -112,6 +112,9 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "rollout_post")
     f.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int32] + [C.c_void_p] * 6
     f.restype = C.c_int
+    f = getattr(lib, prefix + "rollout_post_amp")
+    f.argtypes = ([C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int64, C.c_int32] + [C.c_float] * 6 + [C.c_int32] + [C.c_void_p] * 6)
+    f.restype = C.c_int
     f = getattr(lib, prefix + "disc_loss_scratch_bytes"); f.argtypes = [C.c_int64]; f.restype = C.c_int64
     f = getattr(lib, prefix + "disc_loss")
     f.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
@@ -148,7 +151,7 @@ MLP_BUF_COLS = (672, 576, 320, 128)
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

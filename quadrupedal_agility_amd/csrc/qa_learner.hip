@@ -528,6 +528,50 @@ __global__ void __launch_bounds__(256) qa_rollout_post_kernel(const float *__res
     }
 }
 
+struct PostAmpArgs {
+    const float *rew; const int64_t *reset; const uint8_t *time_out; const float *values, *d, *eps, *logits, *obs;
+    int64_t obs_stride; int num_obs, dim_c, N;
+    float c_i, c_us, c_ss, c_t, dt, gamma;
+    float *st_rewards; uint8_t *st_dones; float *cur, *fin_vals; uint8_t *fin_mask;
+};
+
+__global__ void __launch_bounds__(256) qa_rollout_post_amp_kernel(PostAmpArgs a) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.N) return;
+    const float *o = a.obs + (int64_t)e * a.obs_stride;
+    const float label_eps = o[a.num_obs - a.dim_c - 1];
+    int label = 0;                              /* argmax: first maximum, as torch.argmax */
+    for (int k = 1; k < a.dim_c; ++k) if (o[a.num_obs - a.dim_c + k] > o[a.num_obs - a.dim_c + label]) label = k;
+    float p[8], m = a.logits[(int64_t)e * a.dim_c];
+    for (int k = 1; k < a.dim_c; ++k) m = fmaxf(m, a.logits[(int64_t)e * a.dim_c + k]);
+    float z = 0.f;
+    for (int k = 0; k < a.dim_c; ++k) { p[k] = expf(a.logits[(int64_t)e * a.dim_c + k] - m); z += p[k]; }
+    float pm = 0.f;
+    for (int k = 0; k < a.dim_c; ++k) { p[k] = fmaxf(p[k] / z, 1e-20f); pm = fmaxf(pm, p[k]); }
+    float lse = 0.f;
+    for (int k = 0; k < a.dim_c; ++k) lse += expf(p[k] - pm);
+    lse = pm + logf(lse);
+    const float dd = a.d[e] - 1.0f;
+    const float r_i = fmaxf(1.0f - 0.25f * dd * dd, 0.f) * a.dt;
+    const float r_us = -fabsf(a.eps[e] - label_eps) * a.dt;
+    const float r_ss = (p[label] - lse) * a.dt;
+    const float r_t = a.rew[e];
+    const float total = a.c_i * r_i + a.c_us * r_us + a.c_ss * r_ss + a.c_t * r_t;
+    const bool done = a.reset[e] > 0;
+    a.st_rewards[e] = total + a.gamma * a.values[e] * (a.time_out[e] ? 1.0f : 0.0f);
+    a.st_dones[e] = done ? 1 : 0;
+    if (a.cur) {
+        const float add[6] = {total, r_i, r_us, r_ss, r_t, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float c = a.cur[(int64_t)k * a.N + e] + add[k];
+            a.fin_vals[(int64_t)k * a.N + e] = c;
+            a.cur[(int64_t)k * a.N + e] = done ? 0.f : c;
+        }
+        a.fin_mask[e] = done ? 1 : 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The head losses of the SS-InfoGAIL discriminator step (bbc/rsl_rl/algorithms/gail.py:452-520) and their gradient with
 // respect to the three heads' outputs, one pass over the batch [labelled expert | policy | unlabelled expert]:
@@ -829,6 +873,21 @@ int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_
                        gamma, (int)num_envs, st_rewards, st_dones, cur, fin_vals, fin_mask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_post: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_rollout_post_amp(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, const float *d, const float *eps,
+                        const float *logits, int32_t dim_c, const float *obs, int64_t obs_stride, int32_t num_obs, float c_i, float c_us,
+                        float c_ss, float c_t, float dt, float gamma, int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur,
+                        float *fin_vals, uint8_t *fin_mask, void *stream) {
+    if (!rew || !reset || !time_out || !values || !d || !eps || !logits || !obs || !st_rewards || !st_dones || num_envs <= 0 || dim_c <= 0 || dim_c > 8 ||
+        num_obs < dim_c + 1 || obs_stride < num_obs || (cur && (!fin_vals || !fin_mask))) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_post_amp: bad argument"); return QA_E_ARG; }
+    PostAmpArgs a{rew, reset, time_out, values, d, eps, logits, obs, obs_stride, (int)num_obs, (int)dim_c, (int)num_envs, c_i, c_us, c_ss, c_t, dt, gamma,
+                  st_rewards, st_dones, cur, fin_vals, fin_mask};
+    hipLaunchKernelGGL(qa_rollout_post_amp_kernel, dim3((num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_post_amp: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

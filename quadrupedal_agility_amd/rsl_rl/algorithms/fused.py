@@ -493,11 +493,12 @@ class PolicyChain:
 
     BUF_COLS = _capi.MLP_BUF_COLS
 
-    def __init__(self, ops, params, num_actions):
+    def __init__(self, ops, params, num_actions, out_widths=None):
         self.n_ops = len(ops)
         self.ops = (_capi.QaMlpOp * self.n_ops)(*ops)
-        self.params = params                      # per op: (weight, bias) tensors or None
+        self.params = params                      # per op: (weight, bias) tensors (or callables building them) or None
         self.num_actions = num_actions
+        self.out_widths = list(out_widths) if out_widths is not None else [num_actions, 1]
         self.packed = None
         self._out = {}
 
@@ -520,9 +521,42 @@ class PolicyChain:
                 out.append([m, 0])
             elif isinstance(m, nn.ELU) and m.alpha == 1.0 and out and out[-1][1] == 0:
                 out[-1][1] = 1
+            elif isinstance(m, nn.ReLU) and out and out[-1][1] == 0:
+                out[-1][1] = 2
             else:
                 return None
         return out
+
+    @classmethod
+    def describe_discriminator(cls, disc):
+        """Discriminator.forward (bbc/rsl_rl/algorithms/discriminator.py:48-69) on prepared inputs x (N, 98): ReLU trunk, then the
+        three heads as global outputs (logit (N,1), epsilon (N,1), class LOGITS (N,dim_c): the softmax is the consumer's)."""
+        trunk = cls._linears(disc.trunk)
+        if trunk is None or any(a != 2 for _, a in trunk) or disc.input_dim > cls.BUF_COLS[0] or disc.dim_c > 8:
+            return None
+        ops, params, woff, src, scol, k = [], [], 0, 0, 0, disc.input_dim
+        bufs = {0: 1, 1: 2, 2: 1}
+        for lin, act in trunk:
+            dst = bufs[src]
+            n = lin.out_features
+            if lin.in_features != k or n > cls.BUF_COLS[dst]:
+                return None
+            nt, kb = (n + 15) // 16, cls.k_blocks(k, n)
+            ops.append(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=0, dst_buf=dst, dst_col=0, k=k, n=n, act=act, out_index=0,
+                                     w_off=woff, b_off=woff + nt * kb * 256))
+            params.append((lin.weight, lin.bias))
+            woff += nt * kb * 256 + nt * 16
+            src, k = dst, n
+        for oi, head in enumerate((disc.linear, disc.encoder_eps, disc.classifier)):
+            n = head.out_features
+            nt, kb = (n + 15) // 16, cls.k_blocks(k, n)
+            ops.append(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=0, dst_buf=-1, dst_col=0, k=k, n=n, act=0, out_index=oi,
+                                     w_off=woff, b_off=woff + nt * kb * 256))
+            params.append((head.weight, head.bias))
+            woff += nt * kb * 256 + nt * 16
+        self = cls(ops, params, 0, out_widths=[1, 1, disc.dim_c])
+        self.packed_floats = woff
+        return self
 
     @classmethod
     def describe(cls, actor_critic, estimator, use_estimator, hist_encoding=False, with_critic=True):
@@ -672,16 +706,18 @@ class PolicyChain:
             raise RuntimeError(f"qa_mlp_pack failed with code {rc}: {lib.qa_last_error().decode()}")
 
     def forward(self, obs):
+        """-> one (N, width) tensor per global output of the chain (policy chains: action mean, value).  The tensors are
+        persistent per batch size: the next call overwrites them."""
         n = obs.shape[0]
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.stride(1) == 1 and self.packed is not None
         out = self._out.get(n)
         if out is None:
-            mean = torch.zeros(n, self.num_actions, device=obs.device)
-            value = torch.zeros(n, 1, device=obs.device)
-            out = self._out[n] = (mean, value, (C.c_void_p * 2)(mean.data_ptr(), value.data_ptr()), (C.c_int64 * 2)(self.num_actions, 1))
+            bufs = [torch.zeros(n, w, device=obs.device) for w in self.out_widths]
+            k = len(bufs)
+            out = self._out[n] = (bufs, (C.c_void_p * k)(*[b.data_ptr() for b in bufs]), (C.c_int64 * k)(*self.out_widths))
         lib = _capi.load_library()
-        rc = lib.qa_mlp_forward(_ptr(obs), obs.stride(0), n, obs.shape[1], self.ops, self.n_ops, _ptr(self.packed), out[2], out[3], 2,
+        rc = lib.qa_mlp_forward(_ptr(obs), obs.stride(0), n, obs.shape[1], self.ops, self.n_ops, _ptr(self.packed), out[1], out[2], len(out[0]),
                                 C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"qa_mlp_forward failed with code {rc}: {lib.qa_last_error().decode()}")
-        return out[0], out[1]
+        return tuple(out[0])

@@ -694,3 +694,76 @@ def test_overlapped_discriminator_and_ppo_updates_match_sequential(monkeypatch):
         for k in wa:
             assert torch.allclose(wa[k].float(), wb[k].float(), atol=5e-4, rtol=5e-3), k
     assert res[0][3] == res[1][3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 300, 4096])
+def test_rollout_post_amp_matches_predict_disc_reward(n):
+    """qa_rollout_post_amp vs. Discriminator.predict_disc_reward's expressions (discriminator.py:88-118) + the time-out
+    bootstrap and episode sums of the runner, and vs. the oracle's C twin"""
+    import ctypes as C
+    import torch.nn.functional as F
+    from quadrupedal_agility_amd import _capi
+    from tests.oracle_lib import load_oracle
+    torch.manual_seed(n)
+    dim_c, num_obs, stride = 5, 671, 680
+    obs = torch.randn(n, stride)
+    rew, values, d, eps, logits = torch.rand(n), torch.randn(n), torch.randn(n) * 1.5 + 0.5, torch.randn(n), torch.randn(n, dim_c) * 2
+    reset = (torch.rand(n) < 0.2).long(); tout = ((torch.rand(n) < 0.5) & (reset > 0)).to(torch.uint8)
+    cur = torch.randn(6, n)
+    ci, cus, css, ct, dt, gamma = 0.35, 0.1, 0.25, 0.3, 0.02, 0.99
+    # reference expressions
+    label_eps = obs[:, num_obs - dim_c - 1]
+    label_c = F.one_hot(torch.argmax(obs[:, num_obs - dim_c:num_obs], dim=-1), num_classes=dim_c).float()
+    c = torch.clamp(torch.softmax(logits, -1), 1e-20, torch.inf)
+    r_i = torch.clamp(1 - 0.25 * torch.square(d - 1), min=0) * dt
+    r_us = -torch.abs(eps - label_eps) * dt
+    r_ss = -F.cross_entropy(c, label_c, reduction="none") * dt
+    total = ci * r_i + cus * r_us + css * r_ss + ct * rew
+    want_rew = total + gamma * values * tout.float()
+    want_fin = cur + torch.stack([total, r_i, r_us, r_ss, rew, torch.ones(n)])
+    want_cur = want_fin * (reset == 0)
+    for side in ("hip", "oracle"):
+        if side == "hip":
+            lib, pre, dev = _capi.load_library(), "qa_", "cuda"
+        else:
+            lib, pre, dev = load_oracle(), "qo_", "cpu"
+        t = lambda x: x.to(dev).contiguous()
+        a = [t(x) for x in (rew, reset, tout, values, d, eps, logits, obs)]
+        st_r, st_d = torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+        cur_d, fin, mask = t(cur).clone(), torch.zeros(6, n, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+        P = lambda x: C.c_void_p(x.data_ptr())
+        rc = getattr(lib, pre + "rollout_post_amp")(P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(a[4]), P(a[5]), P(a[6]), dim_c, P(a[7]), stride, num_obs,
+                                                     ci, cus, css, ct, dt, gamma, n, P(st_r), P(st_d), P(cur_d), P(fin), P(mask), None)
+        assert rc == 0
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        np.testing.assert_allclose(st_r.cpu().numpy(), want_rew.numpy(), rtol=2e-5, atol=2e-6, err_msg=side)
+        assert torch.equal(st_d.cpu(), (reset > 0).to(torch.uint8)) and torch.equal(mask.cpu(), (reset > 0).to(torch.uint8))
+        np.testing.assert_allclose(fin.cpu().numpy(), want_fin.numpy(), rtol=2e-5, atol=2e-6, err_msg=side)
+        np.testing.assert_allclose(cur_d.cpu().numpy(), want_cur.numpy(), rtol=2e-5, atol=2e-6, err_msg=side)
+
+
+@pytest.mark.gpu
+def test_discriminator_chain_matches_module():
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    env, args, tcfg = _make(64, True)
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+    disc = runner.alg.disc
+    with torch.no_grad():
+        for p in disc.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    chain = PolicyChain.describe_discriminator(disc)
+    assert chain is not None
+    x = torch.randn(777, disc.input_dim, device="cuda")
+    with torch.inference_mode():
+        chain.pack()
+        d, eps, logits = chain.forward(x)
+        rd, reps, rc = disc(x)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d.cpu().numpy(), rd.cpu().numpy(), rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(eps.cpu().numpy(), reps.cpu().numpy(), rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(torch.softmax(logits, -1).cpu().numpy(), rc.cpu().numpy(), rtol=2e-4, atol=5e-6)
