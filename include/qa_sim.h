@@ -291,11 +291,13 @@ int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int
                  void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Minibatch gather (RolloutStorage.mini_batch_generator, bbc/rsl_rl/storage/rollout_storage.py:122-157): for t < num_tensors,
- * dst[t][r, 0:widths[t]] = src[t][idx[r], 0:widths[t]]; src rows are src_strides[t] floats apart, dst rows are dense.  `src`,
- * `src_strides`, `widths`, `dst` are HOST arrays of device pointers / sizes; idx (rows) int64 on the device. */
+ * dst[t][r, 0:widths[t]] = src[t][idx[b rows + r], 0:widths[t]] with b = *idx_block (a DEVICE scalar; NULL = 0: idx is then
+ * just `rows` long); src rows are src_strides[t] floats apart, dst rows are dense.  `src`, `src_strides`, `widths`, `dst` are HOST
+ * arrays of device pointers / sizes; idx int64 on the device.  The block form lets a recorded step walk through a table of
+ * pre-drawn sample indices (one block per step) with a device-side step counter. */
 #define QA_GATHER_MAX 12
-int qa_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides,
-                   const int32_t *widths, float *const *dst, void *stream);
+int qa_gather_rows(const int64_t *idx, const int64_t *idx_block, int64_t rows, int32_t num_tensors, const float *const *src,
+                   const int64_t *src_strides, const int32_t *widths, float *const *dst, void *stream);
 
 /* KL-adaptive learning rate of the PPO step (bbc/rsl_rl/algorithms/gail.py:367-379) on DEVICE scalars, so that a recorded
  * step never reads the KL on the host:  *lr = max(lr_min, *lr / factor) if *kl > 2 desired_kl;  min(lr_max, *lr * factor) if

@@ -1324,9 +1324,10 @@ int qo_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int
     return QA_OK;
 }
 
-int qo_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides, const int32_t *widths,
-                   float *const *dst, void *stream) {
+int qo_gather_rows(const int64_t *idx, const int64_t *idx_block, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides,
+                   const int32_t *widths, float *const *dst, void *stream) {
     (void)stream;
+    if (idx && idx_block) idx += idx_block[0] * rows;
     if (!idx || !src || !src_strides || !widths || !dst || rows <= 0 || num_tensors <= 0 || num_tensors > QA_GATHER_MAX) return QA_E_ARG;
     for (int t = 0; t < num_tensors; ++t) {
         if (!src[t] || !dst[t] || widths[t] <= 0 || src_strides[t] < widths[t]) return QA_E_ARG;

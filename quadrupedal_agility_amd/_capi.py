@@ -126,7 +126,7 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "pair_loss")
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
-    f = getattr(lib, prefix + "gather_rows"); f.argtypes = [C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5; f.restype = C.c_int
+    f = getattr(lib, prefix + "gather_rows"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5; f.restype = C.c_int
     f = getattr(lib, prefix + "kl_lr_rule"); f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_packed_floats"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "mlp_pack"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int

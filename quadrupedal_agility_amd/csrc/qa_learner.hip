@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) qa_pair_finish_kernel(const float *__rest
 constexpr int GATHER_ROWS = 4;
 struct GatherArgs {
     const float *src[QA_GATHER_MAX]; float *dst[QA_GATHER_MAX]; int32_t width[QA_GATHER_MAX]; int64_t src_stride[QA_GATHER_MAX];
-    const int64_t *idx; int64_t rows; int32_t n;
+    const int64_t *idx; const int64_t *idx_block; int64_t rows; int32_t n;
 };
 
 __global__ void __launch_bounds__(256) qa_gather_rows_kernel(GatherArgs a) {
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) qa_gather_rows_kernel(GatherArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * GATHER_ROWS + (threadIdx.x >> 6);
     if (r >= a.rows) return;
-    const int64_t s = a.idx[r];
+    const int64_t s = a.idx[(a.idx_block ? a.idx_block[0] * a.rows : 0) + r];
     for (int t = 0; t < a.n; ++t) {
         const float *sp = a.src[t] + s * a.src_stride[t];
         float *dp = a.dst[t] + r * a.width[t];
@@ -828,8 +828,8 @@ int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int
     return QA_OK;
 }
 
-int qa_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides, const int32_t *widths,
-                   float *const *dst, void *stream) {
+int qa_gather_rows(const int64_t *idx, const int64_t *idx_block, int64_t rows, int32_t num_tensors, const float *const *src, const int64_t *src_strides,
+                   const int32_t *widths, float *const *dst, void *stream) {
     if (!idx || !src || !src_strides || !widths || !dst || rows <= 0 || num_tensors <= 0 || num_tensors > QA_GATHER_MAX) {
         snprintf(g_lerr, sizeof(g_lerr), "qa_gather_rows: bad argument (1..%d tensors)", QA_GATHER_MAX); return QA_E_ARG; }
     GatherArgs a{};
@@ -837,7 +837,7 @@ int qa_gather_rows(const int64_t *idx, int64_t rows, int32_t num_tensors, const 
         if (!src[t] || !dst[t] || widths[t] <= 0 || src_strides[t] < widths[t]) { snprintf(g_lerr, sizeof(g_lerr), "qa_gather_rows: tensor %d is malformed", t); return QA_E_ARG; }
         a.src[t] = src[t]; a.dst[t] = dst[t]; a.width[t] = widths[t]; a.src_stride[t] = src_strides[t];
     }
-    a.idx = idx; a.rows = rows; a.n = num_tensors;
+    a.idx = idx; a.idx_block = idx_block; a.rows = rows; a.n = num_tensors;
     hipLaunchKernelGGL(qa_gather_rows_kernel, dim3((unsigned)((rows + GATHER_ROWS - 1) / GATHER_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_gather_rows: %s", hipGetErrorString(e)); return QA_E_DEVICE; }

@@ -263,10 +263,11 @@ def pair_loss_raw(a, b, mode):
     return out, grad
 
 
-def gather_rows(idx, srcs, dsts=None):
+def gather_rows(idx, srcs, dsts=None, block_dev=None):
     """[src[idx] for src in srcs] for row-major fp32 tensors (N, w) in ONE launch; idx (rows) int64 on the device.  `dsts`
-    (dense (rows, w) tensors) are allocated when not given."""
-    rows = idx.shape[0]
+    (dense (rows, w) tensors) are allocated when not given.  With block_dev (0-d int64 device tensor) idx is a (blocks, rows)
+    table and row block *block_dev is used."""
+    rows = idx.shape[-1]
     n = len(srcs)
     flat = [x if x.dim() == 2 else x.reshape(x.shape[0], -1) for x in srcs]
     assert idx.dtype == torch.int64 and idx.is_contiguous() and all(x.dtype == torch.float32 and x.stride(1) == 1 for x in flat)
@@ -277,7 +278,8 @@ def gather_rows(idx, srcs, dsts=None):
     dst = (C.c_void_p * n)(*[d.data_ptr() for d in dsts])
     strides = (C.c_int64 * n)(*[x.stride(0) for x in flat])
     widths = (C.c_int32 * n)(*[x.shape[1] for x in flat])
-    rc = lib.qa_gather_rows(_ptr(idx), rows, n, src, strides, widths, dst, C.c_void_p(torch.cuda.current_stream(idx.device).cuda_stream))
+    rc = lib.qa_gather_rows(_ptr(idx), _ptr(block_dev) if block_dev is not None else None, rows, n, src, strides, widths, dst,
+                            C.c_void_p(torch.cuda.current_stream(idx.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"qa_gather_rows failed with code {rc}: {lib.qa_last_error().decode()}")
     return dsts

@@ -378,13 +378,26 @@ class SSInfoGAIL:
                 ml, rb = self.motion_loader, self.disc_storage
                 n_lb, n_ulb = ml.preloaded_s_lb.shape[0], ml.preloaded_s_ulb.shape[0]
 
+                # the sample indices of all n_steps steps are drawn once per update into tables (3 launches per update instead of
+                # 5 per step); a recorded step reads its row block through a device-side step counter (qa_gather_rows)
+                self._d_tables = [torch.zeros(n_steps, mb, dtype=torch.int64, device=dev) for _ in range(4)]      # i_pi, i_lb, i_ulb, labels
+                self._d_step = torch.zeros((), dtype=torch.int64, device=dev)
+                flat2 = lambda x: x.reshape(x.shape[0], -1)
+
                 def one_step():
-                    i_pi = (torch.rand(mb, device=dev) * self._n_samples_dev).long()
-                    i_lb = torch.randint(0, n_lb, (mb,), device=dev)
-                    i_ulb = torch.randint(0, n_ulb, (mb,), device=dev)
-                    out = self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
-                                                   (ml.preloaded_s_lb[i_lb], ml.preloaded_label[i_lb]), ml.preloaded_s_ulb[i_ulb])
+                    t_pi, t_lb, t_ulb, t_lab = self._d_tables
+                    if self.use_fused_loss:
+                        s_pi, e_pi, c_pi = fused_mod.gather_rows(t_pi, [flat2(rb.states), flat2(rb.latent_eps), flat2(rb.latent_c)], block_dev=self._d_step)
+                        (s_lb,) = fused_mod.gather_rows(t_lb, [flat2(ml.preloaded_s_lb)], block_dev=self._d_step)
+                        (s_ulb,) = fused_mod.gather_rows(t_ulb, [flat2(ml.preloaded_s_ulb)], block_dev=self._d_step)
+                    else:
+                        sel = lambda tb: tb.index_select(0, self._d_step.view(1)).view(-1)
+                        i_pi, i_lb, i_ulb = sel(t_pi), sel(t_lb), sel(t_ulb)
+                        s_pi, e_pi, c_pi, s_lb, s_ulb = rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi], ml.preloaded_s_lb[i_lb], ml.preloaded_s_ulb[i_ulb]
+                    label = t_lab.index_select(0, self._d_step.view(1)).view(-1)
+                    out = self.update_ss_info_gail((s_pi, e_pi, c_pi), (s_lb, label), s_ulb)
                     self._acc_d.add_(torch.stack(out))
+                    self._d_step.add_(1)
                 self._n_samples_dev.fill_(float(rb.num_samples))
                 self._info_max_dev.fill_(float(self.info_max_coef_on))
                 torch.cuda.synchronize()
@@ -416,6 +429,13 @@ class SSInfoGAIL:
         self._n_samples_dev.fill_(float(self.disc_storage.num_samples))
         self._info_max_dev.fill_(float(self.info_max_coef_on))
         self._acc_d.zero_()
+        ml = self.motion_loader
+        t_pi, t_lb, t_ulb, t_lab = self._d_tables
+        t_pi.copy_((torch.rand(t_pi.shape, device=dev) * self._n_samples_dev).long())
+        torch.randint(0, ml.preloaded_s_lb.shape[0], t_lb.shape, device=dev, out=t_lb)
+        torch.randint(0, ml.preloaded_s_ulb.shape[0], t_ulb.shape, device=dev, out=t_ulb)
+        t_lab.copy_(ml.preloaded_label[t_lb.view(-1)].view(t_lb.shape))
+        self._d_step.zero_()
         for _ in range(n_steps):
             self._disc_graph.replay()
         return self._acc_d          # persistent: the caller copies it on ITS stream after joining
@@ -635,7 +655,11 @@ class SSInfoGAIL:
             disc_loss_v = 0.5 * (l_pi + l_exp)
             us_loss = F.l1_loss(eps, policy_eps)
         if self.grad_sync is None:      # data-parallel: the vector rides in the gradient bucket below (one collective per step)
-            self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
+            prior = self.env.prior_parameters
+            if torch.is_tensor(prior) and prior.is_cuda:    # the arena's own tensor: the EMA (gail.py:463-464) in place, 2 launches
+                prior.mul_(1 - self.prior_soft_coef).add_(pred_mean, alpha=self.prior_soft_coef)
+            else:
+                self.env.prior_parameters = pred_mean * self.prior_soft_coef + prior * (1 - self.prior_soft_coef)
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
         if not analytic_gp:
             g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
