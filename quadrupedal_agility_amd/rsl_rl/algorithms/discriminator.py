@@ -62,7 +62,7 @@ class Discriminator(nn.Module):
         h, masks = x, []
         for lin in lins:
             h = torch.relu(lin(h))
-            masks.append((h[rows] > 0).to(h.dtype))
+            masks.append(torch.sign(h[rows].detach()))   # h >= 0 after the ReLU: sign = [h > 0] as floats, one launch instead of two (a constant: detached)
         c = torch.softmax(self.classifier(h), -1)
         heads = (self.linear(h), self.encoder_eps(h), torch.clamp(c, 1e-20, torch.inf))
         v = masks[-1] * self.linear.weight                      # (rows, H_last): d logit / d (last pre-activation)
