@@ -333,7 +333,8 @@ int qa_rollout_post_amp(const float *rew, const int64_t *reset, const uint8_t *t
 
 /* Head losses of the SS-InfoGAIL discriminator step and their gradient w.r.t. the head outputs
  * (bbc/rsl_rl/algorithms/gail.py:452-520, MSELoss variant).  Rows are [labelled expert b_lb | policy b_pi | unlabelled
- * expert b_ulb]; d, eps (rows), c (rows,5: the clamped softmax the discriminator returns) are the three heads' outputs;
+ * expert b_ulb]; d, eps (rows), c (rows,5: the softmax the discriminator returns; entries below 1e-20 are clamped to 1e-20 here and
+ * pass no gradient, i.e. discriminator.py:52's torch.clamp may be left to this kernel) are the three heads' outputs;
  * label_lb (b_lb) int64 gait labels; policy_eps (b_pi), policy_c (b_pi,5) the latents the policy samples were generated with.
  *   ss = mean_lb CE(log_softmax(c), label);  info = mean_ulb -sum c log(c + 1e-20);
  *   disc = 1/2 (mean_pi (d+1)^2 + mean_ulb (d-1)^2);  us = mean_pi |eps - policy_eps|

@@ -1204,7 +1204,9 @@ int qo_disc_loss(const float *d, const float *eps, const float *c, const int64_t
     int B = b_lb + b_pi + b_ulb;
     double ss = 0, info = 0, dpi = 0, dex = 0, us = 0, acc[4] = {0, 0, 0, 0}, pm[5] = {0, 0, 0, 0, 0}, c_info = info_coef_dev[0];
     for (int i = 0; i < B; ++i) {
-        const float *ci = c + (int64_t)i * 5; float *gc = grad_c + (int64_t)i * 5;
+        const float *craw = c + (int64_t)i * 5; float *gc = grad_c + (int64_t)i * 5;
+        float ci[5]; int pass[5];                   /* torch.clamp(c, 1e-20) of Discriminator.forward (discriminator.py:52): clamped entries pass no gradient */
+        for (int j = 0; j < 5; ++j) { pass[j] = craw[j] >= 1e-20f; ci[j] = pass[j] ? craw[j] : 1e-20f; }
         int arg = 0; for (int j = 1; j < 5; ++j) if (ci[j] > ci[arg]) arg = j;
         for (int j = 0; j < 5; ++j) gc[j] = 0; grad_d[i] = 0; grad_eps[i] = 0;
         if (i < b_lb) {
@@ -1231,6 +1233,7 @@ int qo_disc_loss(const float *d, const float *eps, const float *c, const int64_t
             }
             acc[2] += dd > 0;
         }
+        for (int j = 0; j < 5; ++j) if (!pass[j]) gc[j] = 0;
     }
     ss /= b_lb; info /= b_ulb; us /= b_pi;
     double disc = 0.5 * (dpi / b_pi + dex / b_ulb);

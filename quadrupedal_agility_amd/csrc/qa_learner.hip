@@ -600,8 +600,9 @@ __global__ void __launch_bounds__(DISC_BLOCK) qa_disc_loss_kernel(DiscArgs a) {
     if (i < B) {
         const float c_info = a.info_coef[0];
         float c[5];
+        bool pass[5];               /* torch.clamp(c, 1e-20) of Discriminator.forward applied here: clamped entries pass no gradient */
 #pragma unroll
-        for (int j = 0; j < 5; ++j) c[j] = a.c[(int64_t)i * 5 + j];
+        for (int j = 0; j < 5; ++j) { const float cr = a.c[(int64_t)i * 5 + j]; pass[j] = cr >= 1e-20f; c[j] = fmaxf(cr, 1e-20f); }
         int arg = 0;
 #pragma unroll
         for (int j = 1; j < 5; ++j) if (c[j] > c[arg]) arg = j;
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__(DISC_BLOCK) qa_disc_loss_kernel(DiscArgs a) {
         }
         a.gd[i] = gd; a.geps[i] = ge;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) a.gc[(int64_t)i * 5 + j] = gc[j];
+        for (int j = 0; j < 5; ++j) a.gc[(int64_t)i * 5 + j] = pass[j] ? gc[j] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k <= DISC_SUMS; ++k) {

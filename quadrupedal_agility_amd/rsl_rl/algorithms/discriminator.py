@@ -50,7 +50,7 @@ class Discriminator(nn.Module):
         ok = len(mods) % 2 == 0 and all(isinstance(mods[i], nn.Linear) and isinstance(mods[i + 1], nn.ReLU) for i in range(0, len(mods), 2))
         return [mods[i] for i in range(0, len(mods), 2)] if ok else None
 
-    def forward_with_input_gradient(self, x, rows):
+    def forward_with_input_gradient(self, x, rows, clamp=True):
         """Heads on all rows of x plus d logit / d x on the row slice `rows` -- the quantity the gradient penalty squares
         (gail.py:487-492 obtains it with autograd.grad(..., create_graph=True)).  For this piecewise-linear trunk it is
             g = W_1^T diag(m_1) W_2^T diag(m_2) ... w_out,      m_l = [layer l is active]
@@ -64,7 +64,7 @@ class Discriminator(nn.Module):
             h = torch.relu(lin(h))
             masks.append(torch.sign(h[rows].detach()))   # h >= 0 after the ReLU: sign = [h > 0] as floats, one launch instead of two (a constant: detached)
         c = torch.softmax(self.classifier(h), -1)
-        heads = (self.linear(h), self.encoder_eps(h), torch.clamp(c, 1e-20, torch.inf))
+        heads = (self.linear(h), self.encoder_eps(h), torch.clamp(c, 1e-20, torch.inf) if clamp else c)     # clamp=False: qa_disc_loss clamps
         v = masks[-1] * self.linear.weight                      # (rows, H_last): d logit / d (last pre-activation)
         for l in range(len(lins) - 1, 0, -1):
             v = (v @ lins[l].weight) * masks[l - 1]

@@ -620,16 +620,16 @@ class SSInfoGAIL:
         # same parameters, so losses and gradients are identical up to GEMM rounding; half the launches.
         b_lb, b_pi = expert_lb.shape[0], policy_state.shape[0]
         analytic_gp = self.disc._relu_trunk() is not None
+        fused_heads = self._on_gpu and self.use_fused_loss and self.disc_loss_function == "MSELoss"
         if analytic_gp:      # d logit / d x on the unlabelled rows as a chain of small GEMMs (discriminator.py), no second-order graph
             (d_all, eps_all, c_all), g = self.disc.forward_with_input_gradient(x_all if x_all is not None else torch.cat([expert_lb, policy_state, expert_ulb], dim=0),
-                                                                                slice(b_lb + b_pi, None))
+                                                                                slice(b_lb + b_pi, None), clamp=not fused_heads)
         else:
             x_ulb = expert_ulb.clone().requires_grad_(True)
             d_all, eps_all, c_all = self.disc(torch.cat([expert_lb, policy_state, x_ulb], dim=0))
         pred_c_lb = c_all[:b_lb]
         logits_pi, eps, pred_c = d_all[b_lb:b_lb + b_pi], eps_all[b_lb:b_lb + b_pi], c_all[b_lb:b_lb + b_pi]
         logits_exp, pred_c_ulb = d_all[b_lb + b_pi:], c_all[b_lb + b_pi:]
-        fused_heads = self._on_gpu and self.use_fused_loss and self.disc_loss_function == "MSELoss"
         if fused_heads:
             # the four head losses, their gradient, the four logged accuracies and the prior mean: ONE kernel (fused.py)
             self._info_max_dev.fill_(float(self.info_max_coef_on)) if not torch.cuda.is_current_stream_capturing() else None
