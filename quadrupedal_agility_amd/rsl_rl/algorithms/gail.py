@@ -630,11 +630,15 @@ class SSInfoGAIL:
         pred_c_lb = c_all[:b_lb]
         logits_pi, eps, pred_c = d_all[b_lb:b_lb + b_pi], eps_all[b_lb:b_lb + b_pi], c_all[b_lb:b_lb + b_pi]
         logits_exp, pred_c_ulb = d_all[b_lb + b_pi:], c_all[b_lb + b_pi:]
+        direct = fused_heads and analytic_gp      # no scalar loss nodes: the kernels' gradients go straight into autograd.backward below
         if fused_heads:
             # the four head losses, their gradient, the four logged accuracies and the prior mean: ONE kernel (fused.py)
             self._info_max_dev.fill_(float(self.info_max_coef_on)) if not torch.cuda.is_current_stream_capturing() else None
-            heads, hs = disc_loss(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0],
-                                  c_ss=self.ss_coef, info_coef_dev=self._info_max_dev, c_disc=self.disc_coef, c_us=self.us_coef)
+            kw = dict(c_ss=self.ss_coef, info_coef_dev=self._info_max_dev, c_disc=self.disc_coef, c_us=self.us_coef)
+            if direct:
+                hs, g_d, g_eps, g_c = fused_mod.disc_loss_raw(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0], **kw)
+            else:
+                heads, hs = disc_loss(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0], **kw)
             ss_loss, info_max_loss, disc_loss_v, us_loss = hs[1], hs[2], hs[3], hs[4]
             pred_mean = hs[9:14]
         else:
@@ -663,7 +667,12 @@ class SSInfoGAIL:
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
         if not analytic_gp:
             g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
-        grad_pen_loss = torch.mean(torch.sum(torch.square(g), dim=-1))
+        if direct:      # value for the log; its gradient w.r.t. g, 2 c_gp g / rows, is fed to backward() directly
+            with torch.no_grad():
+                gdet = g.detach()
+                grad_pen_loss = gdet.square().sum() / gdet.shape[0]
+        else:
+            grad_pen_loss = torch.mean(torch.sum(torch.square(g), dim=-1))
         # The two weight regularisers (gail.py:497-504) are functions of the weights alone: c_logit |W_out|^2 + c_wd (|W_1|^2 +
         # |W_2|^2 + |W_out|^2).  On the GPU their values come from one multi-tensor norm and their gradient 2 c W is added to
         # .grad after backward() with one multi-tensor launch, instead of ~15 autograd launches; same numbers.
@@ -673,19 +682,24 @@ class SSInfoGAIL:
             with torch.no_grad():
                 sq = torch.stack(torch._foreach_norm(reg_w)).square()
                 disc_logit_loss, disc_weight_decay = sq[-1], sq.sum()
-            rest = self.disc_grad_penalty * grad_pen_loss
+            rest = None if direct else self.disc_grad_penalty * grad_pen_loss
         else:
             disc_logit_loss = torch.sum(torch.square(self.disc.get_disc_logit_weights()))
             disc_weight_decay = torch.sum(torch.square(torch.cat(self.disc.get_disc_weights(), dim=-1)))
             rest = self.disc_grad_penalty * grad_pen_loss + self.disc_logit_reg * disc_logit_loss + self.disc_weight_decay * disc_weight_decay
-        if fused_heads:
+        if direct:
+            loss = None
+        elif fused_heads:
             loss = heads + rest
         else:
             info_coef = self._info_max_dev if (self._info_max_dev is not None and torch.cuda.is_current_stream_capturing()) else self.info_max_coef_on
             loss = self.ss_coef * ss_loss + info_coef * info_max_loss + self.disc_coef * disc_loss_v + self.us_coef * us_loss + rest
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.zero_grad()
-        loss.backward()
+        if direct:
+            torch.autograd.backward([d_all, eps_all, c_all, g], [g_d, g_eps, g_c, gdet * (2.0 * self.disc_grad_penalty / gdet.shape[0])])
+        else:
+            loss.backward()
         if fold_reg:
             with torch.no_grad():
                 torch._foreach_add_([w.grad for w in reg_w[:-1]], reg_w[:-1], alpha=2.0 * self.disc_weight_decay)
