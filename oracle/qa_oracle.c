@@ -1146,6 +1146,15 @@ int qo_clip_adam_step(float *const *params, const float *const *grads, float *co
     return QA_OK;
 }
 
+int qo_clip_adam_step_hostgrads(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                                float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                                const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                                float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
+    if (num_tensors > QA_ADAM_MAX_INLINE) return QA_E_ARG;          /* on the host both forms read the same array */
+    return qo_clip_adam_step(params, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay, lr,
+                             beta1, beta2, eps, max_norm, scratch, scratch_floats, stream);
+}
+
 /* rollout bookkeeping twins (host pointers) */
 int qo_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
                    int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,

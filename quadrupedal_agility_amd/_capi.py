@@ -106,6 +106,9 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "clip_adam_step")
     f.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
+    f = getattr(lib, prefix + "clip_adam_step_hostgrads")
+    f.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]
+    f.restype = C.c_int
     f = getattr(lib, prefix + "rollout_act")
     f.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7
     f.restype = C.c_int
@@ -151,7 +154,7 @@ MLP_BUF_COLS = (672, 576, 320, 128)
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

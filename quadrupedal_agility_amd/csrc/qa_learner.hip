@@ -332,12 +332,15 @@ struct AdamArgs {
     const float *lr; float *scratch;      // scratch: [0] coef [1] bc1 [2] sqrt(bc2) [3] total norm, then one partial per chunk
     int num_chunks, num_tensors;
     float beta1, beta2, eps, max_norm;
+    int inline_grads;                     // 1: the gradient pointers travel in the kernel arguments (gin), not in a device table
+    const float *gin[QA_ADAM_MAX_INLINE];
 };
+__device__ __forceinline__ const float *adam_grad(const AdamArgs &a, int t) { return a.inline_grads ? a.gin[t] : a.grads[t]; }
 
 __global__ void __launch_bounds__(256) qa_adam_sumsq_kernel(AdamArgs a) {
     __shared__ float s_w[4];
     const int c = blockIdx.x;
-    const float *g = a.grads[a.chunk_tensor[c]] + a.chunk_start[c];
+    const float *g = adam_grad(a, a.chunk_tensor[c]) + a.chunk_start[c];
     const int n = a.chunk_len[c];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { const float v = g[i]; acc = fmaf(v, v, acc); }
@@ -449,7 +452,7 @@ __global__ void qa_kl_lr_rule_kernel(const float *kl, float desired_kl, float fa
 __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
     const int c = blockIdx.x, t = a.chunk_tensor[c], s0 = a.chunk_start[c], n = a.chunk_len[c];
     float *p = a.params[t] + s0, *m = a.exp_avg[t] + s0, *v = a.exp_avg_sq[t] + s0;
-    const float *g = a.grads[t] + s0;
+    const float *g = adam_grad(a, t) + s0;
     const float coef = a.scratch[0], bc1 = a.scratch[1], bc2s = a.scratch[2], wd = a.weight_decay[t];
     const float step_size = a.lr[0] / bc1;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -795,22 +798,39 @@ int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, con
     return QA_OK;
 }
 
-int qa_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
-                      float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
-                      const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
-                      float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !chunk_tensor || !chunk_start || !chunk_len || !weight_decay || !lr ||
-        !scratch || num_tensors <= 0 || num_chunks <= 0 || scratch_floats < 4 + (int64_t)num_chunks) {
-        snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: bad argument"); return QA_E_ARG; }
-    AdamArgs a{params, grads, exp_avg, exp_avg_sq, steps, chunk_tensor, chunk_start, chunk_len, weight_decay, lr, scratch, num_chunks, num_tensors,
-               beta1, beta2, eps, max_norm};
+static int clip_adam_launch(float *const *params, const float *const *grads_dev, const float *const *grads_host, float *const *exp_avg,
+                            float *const *exp_avg_sq, float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                            const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1, float beta2, float eps,
+                            float max_norm, float *scratch, int64_t scratch_floats, void *stream, const char *who) {
+    if (!params || (!grads_dev && !grads_host) || !exp_avg || !exp_avg_sq || !steps || !chunk_tensor || !chunk_start || !chunk_len || !weight_decay || !lr ||
+        !scratch || num_tensors <= 0 || num_chunks <= 0 || scratch_floats < 4 + (int64_t)num_chunks || (grads_host && num_tensors > QA_ADAM_MAX_INLINE)) {
+        snprintf(g_lerr, sizeof(g_lerr), "%s: bad argument", who); return QA_E_ARG; }
+    AdamArgs a{params, grads_dev, exp_avg, exp_avg_sq, steps, chunk_tensor, chunk_start, chunk_len, weight_decay, lr, scratch, num_chunks, num_tensors,
+               beta1, beta2, eps, max_norm, grads_host ? 1 : 0, {}};
+    if (grads_host) for (int t = 0; t < num_tensors; ++t) a.gin[t] = grads_host[t];
     hipStream_t st = (hipStream_t)stream;
     if (max_norm > 0.f) hipLaunchKernelGGL(qa_adam_sumsq_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(qa_adam_finalize_kernel, dim3(1), dim3(256), 0, st, a);
     hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "%s: %s", who, hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
+}
+
+int qa_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                      float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                      const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                      float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
+    return clip_adam_launch(params, grads, nullptr, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay, lr,
+                            beta1, beta2, eps, max_norm, scratch, scratch_floats, stream, "qa_clip_adam_step");
+}
+
+int qa_clip_adam_step_hostgrads(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                                float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                                const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                                float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
+    return clip_adam_launch(params, nullptr, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay,
+                            lr, beta1, beta2, eps, max_norm, scratch, scratch_floats, stream, "qa_clip_adam_step_hostgrads");
 }
 
 int64_t qa_pair_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * ((rows + PAIR_BLOCK - 1) / PAIR_BLOCK); }

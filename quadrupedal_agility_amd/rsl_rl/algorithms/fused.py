@@ -357,7 +357,8 @@ class ClipAdam:
             self._build(items)          # first use, or load_state_dict() replaced the state tensors
         t = self._tab
         ptrs = [p.grad.data_ptr() for p in params]
-        if ptrs != t["grad_ptrs"]:                      # autograd allocated new gradient tensors: refresh the pointer table
+        inline = len(ptrs) <= 32                        # QA_ADAM_MAX_INLINE: the pointers ride in the kernel arguments, no table copy
+        if not inline and ptrs != t["grad_ptrs"]:       # autograd allocated new gradient tensors: refresh the pointer table
             if t.get("copied") is not None:
                 t["copied"].synchronize()               # the pinned staging buffer may still be waiting for its last async copy
             t["grads_host"].copy_(torch.tensor(ptrs, dtype=torch.int64))
@@ -378,7 +379,8 @@ class ClipAdam:
             lr_dev = t["lr_dev"]
         lib = _capi.load_library()
         stream = C.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
-        rc = lib.qa_clip_adam_step(_ptr(t["params"]), _ptr(t["grads"]), _ptr(t["exp_avg"]), _ptr(t["exp_avg_sq"]), _ptr(t["steps"]), t["n"],
+        fn, garg = (lib.qa_clip_adam_step_hostgrads, (C.c_void_p * len(ptrs))(*ptrs)) if inline else (lib.qa_clip_adam_step, _ptr(t["grads"]))
+        rc = fn(_ptr(t["params"]), garg, _ptr(t["exp_avg"]), _ptr(t["exp_avg_sq"]), _ptr(t["steps"]), t["n"],
                                    _ptr(t["chunk_tensor"]), _ptr(t["chunk_start"]), _ptr(t["chunk_len"]), t["num_chunks"], _ptr(t["wd"]),
                                    _ptr(lr_dev), float(t["betas"][0]), float(t["betas"][1]), float(t["eps"]), self.max_norm,
                                    _ptr(t["scratch"]), t["scratch"].numel(), stream)
