@@ -177,3 +177,34 @@ def test_rollout_through_the_chain_matches_the_gemm_path(amp):
     if not amp:      # config 3: the fused rollout draws its action noise from the engine's Philox stream, the unfused one from
         close = np.isclose(m1.numpy(), m0.numpy(), rtol=1e-2, atol=1e-2).all(axis=-1)      # torch's generator: only step 0 is comparable
         assert close.mean() > 0.9
+
+
+def test_discriminator_description_and_twin_match_the_module():
+    """PolicyChain.describe_discriminator (ReLU trunk + three heads as global outputs) through the oracle's C twin vs. the module"""
+    import types
+    from quadrupedal_agility_amd.rsl_rl.algorithms.discriminator import Discriminator
+    from tests.oracle_lib import load_oracle
+    torch.manual_seed(2)
+    env = types.SimpleNamespace(task_obs_weight_decay=False)
+    disc = Discriminator(env, 98, 49, 5, 0.02, "MSELoss", None, 0.35, 0.1, 0.25, 0.3, 2, 2, 0.0, [512, 256], "cpu")
+    with torch.no_grad():
+        for p in disc.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    chain = PolicyChain.describe_discriminator(disc)
+    assert chain is not None and chain.out_widths == [1, 1, 5] and [int(o.act) for o in chain.ops] == [2, 2, 0, 0, 0]
+    lib = load_oracle()
+    x = torch.randn(33, 98)
+    with torch.no_grad():
+        w, b = chain._ptr_arrays()
+    packed = np.zeros(chain.packed_floats, np.float32)
+    assert lib.qo_mlp_pack(chain.ops, chain.n_ops, w, b, packed.ctypes.data, packed.size, None) == 0
+    outs = [np.zeros((33, k), np.float32) for k in (1, 1, 5)]
+    ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in outs]); strides = (C.c_int64 * 3)(1, 1, 5)
+    xn = np.ascontiguousarray(x.numpy())
+    assert lib.qo_mlp_forward(xn.ctypes.data, 98, 33, 98, chain.ops, chain.n_ops, packed.ctypes.data, ptrs, strides, 3, None) == 0
+    with torch.no_grad():
+        d, eps, c = disc(x)
+    np.testing.assert_allclose(outs[0], d.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(outs[1], eps.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(torch.softmax(torch.from_numpy(outs[2]), -1).numpy(), c.numpy(), rtol=1e-4, atol=2e-6)
