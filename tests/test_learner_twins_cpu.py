@@ -1,0 +1,91 @@
+"""CPU: the oracle's plain-C twins of the small learner kernels (qo_pair_loss, qo_gather_rows, qo_kl_lr_rule, qo_rollout_post_amp)
+against the PyTorch expressions of the reference they restate.  The HIP kernels are held to the same expressions AND to these
+twins in tests/test_fused_learner.py (-m gpu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.oracle_lib import load_oracle
+
+P = lambda a: C.c_void_p(a.ctypes.data)
+
+
+@pytest.mark.parametrize("mode,rows,cols", [(0, 1000, 29), (1, 257, 4), (0, 1, 3)])
+def test_pair_loss_twin(mode, rows, cols):
+    """gail.py:346-358: mean row L2 norm of (a - b) / mean squared difference, value and gradient"""
+    qo = load_oracle()
+    torch.manual_seed(mode + cols)
+    a0, wide = torch.randn(rows, cols), torch.randn(rows, cols + 7)
+    if rows > 2:
+        wide[2, 3:3 + cols] = a0[2]
+    b0 = wide[:, 3:3 + cols]
+    ra = a0.clone().requires_grad_(True)
+    ref = (ra - b0).norm(p=2, dim=1).mean() if mode == 0 else (ra - b0).pow(2).mean()
+    ref.backward()
+    g, out = np.zeros((rows, cols), np.float32), np.zeros(1, np.float32)
+    an, wn = np.ascontiguousarray(a0.numpy()), np.ascontiguousarray(wide.numpy())
+    assert qo.qo_pair_loss(P(an), C.c_void_p(wn.ctypes.data + 12), rows, cols, cols + 7, mode, P(g), P(out), None, 0, None) == 0
+    assert abs(out[0] - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    np.testing.assert_allclose(g, ra.grad.numpy(), rtol=2e-5, atol=1e-9)
+
+
+def test_gather_rows_twin_plain_and_block_form():
+    """rollout_storage.py:122-157: indexed reads of a minibatch; block form = row block of a (blocks, rows) index table"""
+    qo = load_oracle()
+    rng = np.random.default_rng(0)
+    n, rows, blocks = 500, 64, 5
+    srcs = [rng.normal(size=(n, w)).astype(np.float32) for w in (671, 12, 1, 29)]
+    table = rng.integers(0, n, size=(blocks, rows)).astype(np.int64)
+    k = len(srcs)
+    sp = (C.c_void_p * k)(*[s.ctypes.data for s in srcs]); st = (C.c_int64 * k)(*[s.shape[1] for s in srcs]); wd = (C.c_int32 * k)(*[s.shape[1] for s in srcs])
+    for blk in (None, 3):
+        dsts = [np.zeros((rows, s.shape[1]), np.float32) for s in srcs]
+        dp = (C.c_void_p * k)(*[d.ctypes.data for d in dsts])
+        b = np.array([blk if blk is not None else 0], np.int64)
+        assert qo.qo_gather_rows(P(table), P(b) if blk is not None else None, rows, k, sp, st, wd, dp, None) == 0
+        idx = table[blk if blk is not None else 0]
+        for d, s in zip(dsts, srcs):
+            assert np.array_equal(d, s[idx])
+
+
+def test_kl_lr_rule_twin():
+    """gail.py:367-379"""
+    qo = load_oracle()
+    for kl, lr0 in [(0.05, 1e-3), (0.004, 1e-3), (0.01, 1e-3), (0.0, 1e-3), (-1.0, 1e-3), (0.05, 1.2e-5), (0.001, 9e-3)]:
+        want = max(1e-5, lr0 / 1.5) if kl > 0.02 else (min(1e-2, lr0 * 1.5) if 0.0 < kl < 0.005 else lr0)
+        hk, hl = np.array([kl], np.float32), np.array([lr0], np.float32)
+        assert qo.qo_kl_lr_rule(P(hk), 0.01, 1.5, 1e-5, 1e-2, P(hl), None) == 0
+        assert abs(float(hl[0]) - want) <= 1e-6 * want
+
+
+def test_rollout_post_amp_twin():
+    """discriminator.py:88-118 (MSELoss mapping) + the time-out bootstrap and episode sums of the runner"""
+    qo = load_oracle()
+    torch.manual_seed(7)
+    n, dim_c, num_obs, stride = 300, 5, 671, 680
+    obs = torch.randn(n, stride)
+    rew, values, d, eps, logits = torch.rand(n), torch.randn(n), torch.randn(n) * 1.5 + 0.5, torch.randn(n), torch.randn(n, dim_c) * 2
+    reset = (torch.rand(n) < 0.2).long(); tout = ((torch.rand(n) < 0.5) & (reset > 0)).to(torch.uint8)
+    cur = torch.randn(6, n)
+    ci, cus, css, ct, dt, gamma = 0.35, 0.1, 0.25, 0.3, 0.02, 0.99
+    label_eps = obs[:, num_obs - dim_c - 1]
+    label_c = F.one_hot(torch.argmax(obs[:, num_obs - dim_c:num_obs], dim=-1), num_classes=dim_c).float()
+    c = torch.clamp(torch.softmax(logits, -1), 1e-20, torch.inf)
+    r_i = torch.clamp(1 - 0.25 * torch.square(d - 1), min=0) * dt
+    r_us = -torch.abs(eps - label_eps) * dt
+    r_ss = -F.cross_entropy(c, label_c, reduction="none") * dt
+    total = ci * r_i + cus * r_us + css * r_ss + ct * rew
+    a = [np.ascontiguousarray(x.numpy()) for x in (rew, reset, tout, values, d, eps, logits, obs)]
+    st_r, st_d = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+    cur_n, fin, mask = cur.numpy().copy(), np.zeros((6, n), np.float32), np.zeros(n, np.uint8)
+    qo.qo_rollout_post_amp.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_int64, C.c_int32] + [C.c_float] * 6 + [C.c_int32] + [C.c_void_p] * 6
+    assert qo.qo_rollout_post_amp(*[P(x) for x in a[:7]], dim_c, P(a[7]), stride, num_obs, ci, cus, css, ct, dt, gamma, n,
+                                  P(st_r), P(st_d), P(cur_n), P(fin), P(mask), None) == 0
+    np.testing.assert_allclose(st_r, (total + gamma * values * tout.float()).numpy(), rtol=2e-5, atol=2e-6)
+    want_fin = cur + torch.stack([total, r_i, r_us, r_ss, rew, torch.ones(n)])
+    np.testing.assert_allclose(fin, want_fin.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(cur_n, (want_fin * (reset == 0)).numpy(), rtol=2e-5, atol=2e-6)
+    assert np.array_equal(st_d, (reset > 0).numpy().astype(np.uint8)) and np.array_equal(mask, st_d)
