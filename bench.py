@@ -195,7 +195,7 @@ def main():
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_ms_alone, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
-                         "note": "VALU-issue-bound, not byte-bound: 4096 envs = 256 wavefronts = one per CU, ~41k instructions per wavefront at 4.4 cycles each (DESIGN.md 4.1); 16384 envs/GPU reach 4 wavefronts per CU and 3.4x this rate"},
+                         "note": "not byte-bound: 4096 envs = 256 wavefronts = one per CU; by the SQ counters that wavefront spends 65 % of its time issuing instructions (21.6 k VALU) and 33 % parked on s_waitcnt with nothing else to run (profiles/r1_env_step_pmc.md, DESIGN.md 4.1); 16384 envs/GPU reach 4 wavefronts per CU and 3.4x this rate"},
         }
         if mlp_ms is not None:
             pf = ROLLOUT_FLOPS_PER_SAMPLE * args.num_envs
