@@ -512,8 +512,8 @@ class PolicyChain:
     layer with the activations in LDS.  `describe()` turns the modules into the op list of include/qa_sim.h; `pack()`
     repacks the weights (once per rollout: they only change in update()); `forward(obs)` -> (mean (N,A), value (N,1)).
 
-    Only the privileged-encoder variant (hist_encoding=False) is described: the history-encoder rollouts (every
-    dagger_update_freq-th iteration) keep the GEMM path."""
+    Both actor variants are described (privileged encoder; history encoder with its Conv1d stack as structured layers), and
+    `describe_discriminator` covers Discriminator.forward for the rollout's reward."""
 
     BUF_COLS = _capi.MLP_BUF_COLS
 
