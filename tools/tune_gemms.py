@@ -1,7 +1,7 @@
 """Dev tool: extend the committed TunableOp picks with the GEMM shapes the learner launches today.  Runs a few EAGER
 iterations (no recorded launches: tuning cannot run inside a capture) with tuning enabled; shapes already in
 quadrupedal_agility_amd/rsl_rl/tunableop_gfx950.csv are kept, new ones are tuned, everything is written to
-gpurun_out/tunableop_gfx950_new.csv for review.  usage: tune_gemms.py [--amp]"""
+gpurun_out/tunableop_gfx950_new.csv for review.  usage: tune_gemms.py [--amp] [--num_envs N]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +14,8 @@ from quadrupedal_agility_amd.rsl_rl.runners import on_policy_runner as opr
 amp = "--amp" in sys.argv
 out = os.path.join(ROOT, "gpurun_out", "tunableop_gfx950_new.csv")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-cfg = Go2LocomotionCfg(); cfg.env.num_envs = 4096; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = amp; cfg.seed = 1
+NUM_ENVS = int(sys.argv[sys.argv.index("--num_envs") + 1]) if "--num_envs" in sys.argv else 4096
+cfg = Go2LocomotionCfg(); cfg.env.num_envs = NUM_ENVS; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = amp; cfg.seed = 1
 t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = amp
 args = get_args(["--device", "gpu"])
 env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
