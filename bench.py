@@ -237,8 +237,21 @@ def cpu_baseline(num_envs, budget_s):
     while time.perf_counter() - t0 < budget_s:
         o.step(act); n += 1
     dt = time.perf_counter() - t0
-    return {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fused env steps of {num_envs} envs on plane terrain (rollout physics+obs/reward only, no learner), OpenMP over envs, {dt:.1f} s"}
+    out = {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n} fused env steps of {num_envs} envs on plane terrain (rollout physics+obs/reward only, no learner), OpenMP over envs, {dt:.1f} s"}
+    # the single-core figure SURVEY 8d asks for: the same steps with the OpenMP team held to one thread (~3 s)
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        t0 = time.perf_counter(); n1 = 0
+        while time.perf_counter() - t0 < 3.0:
+            o.step(act); n1 += 1
+        out["single_core_value"] = num_envs * n1 / (time.perf_counter() - t0)
+        gomp.omp_set_num_threads(cores)
+    except OSError:
+        pass
+    return out
 
 
 if __name__ == "__main__":

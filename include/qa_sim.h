@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 6
+#define QA_ABI_VERSION 7
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -400,6 +400,88 @@ int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weigh
                 int64_t packed_floats, void *stream);
 int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops,
                    const float *packed, float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Task-level (TSC) env-side math of SURVEY 8a row a18: the two per-step pieces of tsc/legged_gym/envs/base/legged_robot.py
+ * that need no obstacle physics.  The obstacle-course simulation itself is not part of this library.
+ *
+ * qa_tsc_set_commands  =  LeggedRobot.set_commands (tsc/legged_gym/envs/base/legged_robot.py:699-760): turn the task policy's
+ * hybrid action (N, 1 + num_d * num_c) = [behaviour id, num_d x num_c parameters] into the behaviour policy's command block.
+ * For envs with episode_length % interval == 0:  g = mocap_index[id];  p = clip(params of behaviour `id`, -1, 1);
+ * latent_c = one_hot(g, dim_c);  latent_eps = p[num_c - 1];  u = (p + 1) / 2;  commands[0..2] = lo[g] + (hi[g] - lo[g]) u[0..2]
+ * (per-gait ranges, `vel_ranges` (3, dim_c, 2): lin_vel_x, lin_vel_y, ang_vel_yaw);  commands[3] = jump range(u[3]) if g is the
+ * last gait else 0;  commands[4] = locomotion-height range(u[4]) if g is not the last gait else 0.  Then, if `noise` is not
+ * NULL, commands (ALL envs) *= noise (N,5) (domain_rand.randomize_action; the reference draws U(0.8,1.2) with torch's
+ * generator, here the caller supplies the draw).  next_commands (N, 5 + 1 + dim_c) = [commands, latent_eps, latent_c].
+ * num_c must be 6 and dim_c <= 8.  `mocap_index` (num_d) and the ranges are HOST arrays. */
+int qa_tsc_set_commands(const float *actions, const int64_t *episode_length, int64_t num_envs, int32_t num_d, int32_t num_c, int32_t dim_c,
+                        int32_t interval, const int32_t *mocap_index, const float *vel_ranges, const float *jump_range,
+                        const float *height_range, const float *noise, float *commands, float *latent_eps, float *latent_c,
+                        float *next_commands, void *stream);
+
+/* qa_tsc_goal_step  =  the post-physics bookkeeping of the task-level env between `refresh_*` and `reset_idx`
+ * (tsc/legged_gym/envs/base/legged_robot.py:226-262): episode_length += 1; body-frame velocities, projected gravity and
+ * roll/pitch/yaw (:239-246, euler_from_quaternion :32-55); filtered foot contacts (:247-249); _update_goals (:204-224);
+ * current obstacle type (:255-258); check_termination (:322-346); compute_reward (:412-430) with the 8 active terms of
+ * legged_robot_config.py:307-332 in the reference's (alphabetical) summation order -- QA_TSC_REW_*, `reward_scales` already
+ * multiplied by dt as _prepare_reward_function does (:1107-1113) -- clipped at zero before the termination term is added;
+ * finally the goal gather of :272-273 for the (possibly advanced) goal index.  One thread per env.
+ * All pointers are device pointers; `cur_goals` / `next_goals` are read first (they hold the previous step's gather) and
+ * rewritten last.  Envs that the caller then resets must have their goal index zeroed and goals re-gathered by the reset. */
+#define QA_TSC_REW_ACTION_HL_RATE 0
+#define QA_TSC_REW_COLLISION 1
+#define QA_TSC_REW_FEET_EDGE 2
+#define QA_TSC_REW_LATENT_C_RATE 3
+#define QA_TSC_REW_REACH_GOAL 4
+#define QA_TSC_REW_TRACKING_GOAL_VEL 5
+#define QA_TSC_REW_TRACKING_YAW 6
+#define QA_TSC_REW_TERMINATION 7
+#define QA_TSC_NUM_REWARDS 8
+#define QA_TSC_MAX_BODY_IDS 24
+typedef struct qa_tsc_goal_cfg {
+    int64_t num_envs;
+    int32_t num_bodies;                 /* rows of contact_forces / rigid_body_states per env */
+    int32_t num_goal_slots;             /* env_goals.size(1), the repeated last goal included */
+    int32_t last_goal_repeat, goals_per_obstacle, num_obstacles;
+    int32_t history_len, history_width; /* action_hl_history (N, history_len, history_width); history_len >= 3 */
+    int32_t mask_rows, mask_cols;       /* x_edge_mask */
+    int32_t use_camera;                 /* cfg.depth.use_camera: also reset on reaching the last goal */
+    int32_t num_termination_bodies, num_penalised_bodies;
+    int32_t termination_bodies[QA_TSC_MAX_BODY_IDS], penalised_bodies[QA_TSC_MAX_BODY_IDS], feet_bodies[4];
+    float reach_goal_delay_steps;       /* cfg.env.reach_goal_delay / dt */
+    float next_goal_threshold, leave_goal_threshold;
+    float max_episode_length;
+    float target_lin_vel;               /* cfg.rewards.target_lin_vel; obstacle types 0 and 4 use 2.5 */
+    float border_size, horizontal_scale;
+    float reward_scales[QA_TSC_NUM_REWARDS];
+} qa_tsc_goal_cfg;
+typedef struct qa_tsc_goal_io {
+    /* in */
+    const float *root_states;           /* (N,13) pos, quat xyzw, linvel, angvel (world) */
+    const float *contact_forces;        /* (N,num_bodies,3) */
+    const float *rigid_body_states;     /* (N,num_bodies,13) */
+    const float *env_goals;             /* (N,num_goal_slots,3) */
+    const int64_t *obstacle_types;      /* (N,num_obstacles) */
+    const float *action_hl_history;     /* (N,history_len,history_width) or NULL (the two rate terms are then 0) */
+    const uint8_t *x_edge_mask;         /* (mask_rows,mask_cols) */
+    /* in/out */
+    int64_t *episode_length;            /* (N) */
+    int64_t *cur_goal_idx;              /* (N) */
+    float *reach_goal_timer;            /* (N) */
+    uint8_t *last_contacts;             /* (N,4) */
+    float *cur_goals, *next_goals;      /* (N,3) */
+    float *episode_sums;                /* (QA_TSC_NUM_REWARDS,N) */
+    /* out */
+    float *base_lin_vel, *base_ang_vel, *projected_gravity, *rpy;   /* (N,3) each */
+    uint8_t *contact_filt;              /* (N,4) */
+    float *target_pos_rel, *next_target_pos_rel;                    /* (N,2) */
+    float *target_yaw, *next_target_yaw;                            /* (N) */
+    uint8_t *reached_goal;              /* (N) */
+    int64_t *cur_obstacle_type;         /* (N) */
+    uint8_t *reset_buf, *time_out_buf, *reach_goal_cutoff;          /* (N) */
+    float *rew_buf;                     /* (N) */
+} qa_tsc_goal_io;
+int qa_tsc_goal_step(const qa_tsc_goal_cfg *cfg, const qa_tsc_goal_io *io, void *stream);
 
 const char *qa_last_error(void);
 int qa_abi_version(void);

@@ -1508,3 +1508,183 @@ int qo_debug_torques(qo_sim *s, const float *actions, float *tau, float *tau_org
     for (int e = 0; e < s->cfg.num_envs; ++e) compute_torques(s, e, actions + 12 * e, tau + 12 * e, tau_org + 12 * e);
     return QA_OK;
 }
+
+/* ================================================================================================================
+ * Task-level (TSC) env-side math: CPU twins of qa_tsc_set_commands / qa_tsc_goal_step (include/qa_sim.h), following
+ * tsc/legged_gym/envs/base/legged_robot.py:699-760 (set_commands) and :204-262, 322-346, 412-430, 1779-1925 (goal update,
+ * termination, the 8 active rewards).  Pinned by tests/golden/tsc_env.npz, which tools/gen_golden_tsc_env.py makes by running
+ * the reference's own set_commands / post_physics_step on CPU.
+ * ================================================================================================================ */
+int qo_tsc_set_commands(const float *actions, const int64_t *episode_length, int64_t num_envs, int32_t num_d, int32_t num_c, int32_t dim_c,
+                        int32_t interval, const int32_t *mocap_index, const float *vel_ranges, const float *jump_range,
+                        const float *height_range, const float *noise, float *commands, float *latent_eps, float *latent_c,
+                        float *next_commands, void *stream) {
+    (void)stream;
+    if (!actions || !episode_length || !mocap_index || !vel_ranges || !jump_range || !height_range || !commands || !latent_eps ||
+        !latent_c || !next_commands || num_envs <= 0) return QA_E_ARG;
+    if (num_c != 6 || dim_c < 1 || dim_c > 8 || num_d < 1 || num_d > 8 || interval < 1) return QA_E_ARG;
+    for (int i = 0; i < num_d; ++i) if (mocap_index[i] < 0 || mocap_index[i] >= dim_c) return QA_E_ARG;
+    const int width = 1 + num_d * num_c;
+    for (int64_t e = 0; e < num_envs; ++e) {
+        float *cmd = commands + e * 5, *lc = latent_c + e * dim_c;
+        if (episode_length[e] % interval == 0) {                                   /* :700-701 */
+            const float *row = actions + e * width;
+            int id = (int)row[0];                                                  /* :702 */
+            if (id < 0) id = 0;
+            if (id >= num_d) id = num_d - 1;
+            const int g = mocap_index[id];                                         /* :704 */
+            float u[6];
+            for (int k = 0; k < 6; ++k) {
+                const float p = clipf(row[1 + id * num_c + k], -1.0f, 1.0f);       /* :705-711 */
+                if (k == 5) latent_eps[e] = p;                                     /* :716 */
+                u[k] = (p + 1.0f) / 2.0f;                                          /* :718 */
+            }
+            for (int k = 0; k < dim_c; ++k) lc[k] = k == g ? 1.0f : 0.0f;          /* :713-714 */
+            for (int k = 0; k < 3; ++k) {                                          /* :740-742 */
+                const float lo = vel_ranges[(k * dim_c + g) * 2], hi = vel_ranges[(k * dim_c + g) * 2 + 1];
+                cmd[k] = lo + (hi - lo) * u[k];
+            }
+            const int jump = g == dim_c - 1;                                       /* :749 */
+            cmd[3] = (jump_range[0] + (jump_range[1] - jump_range[0]) * u[3]) * (jump ? 1.0f : 0.0f);
+            cmd[4] = (height_range[0] + (height_range[1] - height_range[0]) * u[4]) * (jump ? 0.0f : 1.0f);
+        }
+        if (noise) for (int k = 0; k < 5; ++k) cmd[k] *= noise[e * 5 + k];         /* :756-759, every env */
+        float *nx = next_commands + e * (6 + dim_c);                               /* :760 */
+        for (int k = 0; k < 5; ++k) nx[k] = cmd[k];
+        nx[5] = latent_eps[e];
+        for (int k = 0; k < dim_c; ++k) nx[6 + k] = lc[k];
+    }
+    return QA_OK;
+}
+
+static void tsc_rotate_inverse(const float q[4], const float v[3], float out[3]) {
+    const float w = q[3], s = 2.0f * w * w - 1.0f;
+    const float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+    const float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+    out[0] = v[0] * s - cx * w * 2.0f + q[0] * d * 2.0f;
+    out[1] = v[1] * s - cy * w * 2.0f + q[1] * d * 2.0f;
+    out[2] = v[2] * s - cz * w * 2.0f + q[2] * d * 2.0f;
+}
+static float tsc_norm3(const float *f) { return sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]); }
+static float tsc_floor_mod(float a, float b) {
+    float r = fmodf(a, b);
+    if (r != 0.0f && ((r < 0.0f) != (b < 0.0f))) r += b;
+    return r;
+}
+
+int qo_tsc_goal_step(const qa_tsc_goal_cfg *c, const qa_tsc_goal_io *io, void *stream) {
+    (void)stream;
+    if (!c || !io || c->num_envs <= 0) return QA_E_ARG;
+    const int64_t N = c->num_envs;
+    for (int64_t e = 0; e < N; ++e) {
+        const float *rs = io->root_states + e * 13;
+        const float *cf = io->contact_forces + e * c->num_bodies * 3;
+        const int64_t ep_len = ++io->episode_length[e];                            /* :236 */
+        const float q[4] = {rs[3], rs[4], rs[5], rs[6]}, grav[3] = {0.0f, 0.0f, -1.0f};
+        tsc_rotate_inverse(q, rs + 7, io->base_lin_vel + e * 3);                   /* :240-243 */
+        tsc_rotate_inverse(q, rs + 10, io->base_ang_vel + e * 3);
+        tsc_rotate_inverse(q, grav, io->projected_gravity + e * 3);
+        const float x = q[0], y = q[1], z = q[2], w = q[3];                        /* :32-55 */
+        const float roll = atan2f(2.0f * (w * x + y * z), 1.0f - 2.0f * (x * x + y * y));
+        const float pitch = asinf(clipf(2.0f * (w * y - z * x), -1.0f, 1.0f));
+        const float yaw = atan2f(2.0f * (w * z + x * y), 1.0f - 2.0f * (y * y + z * z));
+        io->rpy[e * 3] = roll; io->rpy[e * 3 + 1] = pitch; io->rpy[e * 3 + 2] = yaw;
+        int filt[4];
+        for (int f = 0; f < 4; ++f) {                                              /* :247-249 */
+            const int now = tsc_norm3(cf + c->feet_bodies[f] * 3) > 2.0f;
+            filt[f] = now || io->last_contacts[e * 4 + f];
+            io->last_contacts[e * 4 + f] = (uint8_t)now;
+            io->contact_filt[e * 4 + f] = (uint8_t)filt[f];
+        }
+        /* _update_goals :204-224 */
+        int64_t gi = io->cur_goal_idx[e];
+        float timer = io->reach_goal_timer[e];
+        if (timer > c->reach_goal_delay_steps) { gi += 1; timer = 0.0f; }
+        const float gx = io->cur_goals[e * 3], gy = io->cur_goals[e * 3 + 1];
+        const float nx = io->next_goals[e * 3], ny = io->next_goals[e * 3 + 1];
+        const float dxr = rs[0] - gx, dyr = rs[1] - gy;
+        const float dist = sqrtf(dxr * dxr + dyr * dyr);
+        const int reached = dist < c->next_goal_threshold, leave = dist > c->leave_goal_threshold;
+        if (reached) timer += 1.0f;
+        io->cur_goal_idx[e] = gi; io->reach_goal_timer[e] = timer; io->reached_goal[e] = (uint8_t)reached;
+        const float tx = gx - rs[0], ty = gy - rs[1];
+        const float tn = sqrtf(tx * tx + ty * ty);
+        const float tvx = tx / (tn + 1e-5f), tvy = ty / (tn + 1e-5f);
+        const float target_yaw = atan2f(tvy, tvx);
+        const float ux = nx - rs[0], uy = ny - rs[1];
+        const float un = sqrtf(ux * ux + uy * uy);
+        const float next_yaw = atan2f(uy / (un + 1e-5f), ux / (un + 1e-5f));
+        io->target_pos_rel[e * 2] = tx; io->target_pos_rel[e * 2 + 1] = ty;
+        io->next_target_pos_rel[e * 2] = ux; io->next_target_pos_rel[e * 2 + 1] = uy;
+        io->target_yaw[e] = target_yaw; io->next_target_yaw[e] = next_yaw;
+        /* :255-258 */
+        int64_t gclamp = gi < 0 ? 0 : gi;
+        const int64_t gmax = c->num_goal_slots - c->last_goal_repeat - 1;
+        if (gclamp > gmax) gclamp = gmax;
+        int ob = (int)(gclamp / c->goals_per_obstacle);
+        if (ob >= c->num_obstacles) ob = c->num_obstacles - 1;
+        const int64_t otype = io->obstacle_types[e * c->num_obstacles + ob];
+        io->cur_obstacle_type[e] = otype;
+        /* check_termination :322-346 */
+        int reset = 0;
+        for (int k = 0; k < c->num_termination_bodies; ++k) reset |= tsc_norm3(cf + c->termination_bodies[k] * 3) > 1.0f;
+        const int goal_cut = gi >= (int64_t)(c->num_goal_slots - c->last_goal_repeat);
+        const int time_out = ((float)ep_len > c->max_episode_length) || goal_cut;
+        reset |= time_out || fabsf(roll) > 1.5f || fabsf(pitch) > 1.5f || rs[2] < -0.25f || leave;
+        if (c->use_camera) {
+            const float *lg = io->env_goals + (e * c->num_goal_slots + (c->num_goal_slots - c->last_goal_repeat)) * 3;
+            const float lx = rs[0] - lg[0], ly = rs[1] - lg[1];
+            reset |= sqrtf(lx * lx + ly * ly) < c->next_goal_threshold;
+        }
+        io->reset_buf[e] = (uint8_t)reset; io->time_out_buf[e] = (uint8_t)time_out; io->reach_goal_cutoff[e] = (uint8_t)goal_cut;
+        /* rewards :1779-1925, order and clipping of compute_reward :412-430 */
+        float term[QA_TSC_NUM_REWARDS];
+        term[QA_TSC_REW_ACTION_HL_RATE] = 0.0f; term[QA_TSC_REW_LATENT_C_RATE] = 0.0f;
+        if (io->action_hl_history) {
+            const float *h = io->action_hl_history + e * c->history_len * c->history_width;
+            const float *h1 = h + (c->history_len - 1) * c->history_width, *h2 = h + (c->history_len - 2) * c->history_width,
+                        *h3 = h + (c->history_len - 3) * c->history_width;
+            float ss = 0.0f;
+            for (int k = 0; k < c->history_width; ++k) { const float d = h2[k] - h1[k]; ss += d * d; }
+            term[QA_TSC_REW_ACTION_HL_RATE] = sqrtf(ss);
+            term[QA_TSC_REW_LATENT_C_RATE] = 0.5f * (fabsf(h3[0] - h1[0]) + fabsf(h2[0] - h1[0]));
+        }
+        int hits = 0;
+        for (int k = 0; k < c->num_penalised_bodies; ++k) hits += tsc_norm3(cf + c->penalised_bodies[k] * 3) > 0.1f;
+        term[QA_TSC_REW_COLLISION] = (float)hits;
+        int edge = 0;
+        for (int f = 0; f < 4; ++f) {
+            const float *fp = io->rigid_body_states + (e * c->num_bodies + c->feet_bodies[f]) * 13;
+            int64_t ix = (int64_t)rintf((fp[0] + c->border_size) / c->horizontal_scale);
+            int64_t iy = (int64_t)rintf((fp[1] + c->border_size) / c->horizontal_scale);
+            if (ix < 0) ix = 0; if (ix > c->mask_rows - 1) ix = c->mask_rows - 1;
+            if (iy < 0) iy = 0; if (iy > c->mask_cols - 1) iy = c->mask_cols - 1;
+            edge += (filt[f] && io->x_edge_mask[ix * c->mask_cols + iy]) ? 1 : 0;
+        }
+        term[QA_TSC_REW_FEET_EDGE] = (float)edge;
+        term[QA_TSC_REW_REACH_GOAL] = reached ? 1.0f : 0.0f;
+        const float vt = (otype == 0 || otype == 4) ? 2.5f : c->target_lin_vel;
+        term[QA_TSC_REW_TRACKING_GOAL_VEL] = fminf(tvx * rs[7] + tvy * rs[8], vt) / (vt + 1e-5f);
+        const float PI_F = 3.14159265358979323846f;
+        const float dyaw = tsc_floor_mod((target_yaw - yaw) + PI_F, 2.0f * PI_F) - PI_F;
+        term[QA_TSC_REW_TRACKING_YAW] = expf(-fabsf(dyaw));
+        term[QA_TSC_REW_TERMINATION] = (reset && !time_out) ? 1.0f : 0.0f;
+        float total = 0.0f;
+        for (int k = 0; k < QA_TSC_NUM_REWARDS - 1; ++k) {
+            const float r = term[k] * c->reward_scales[k];
+            total += r;
+            io->episode_sums[k * N + e] += r;
+        }
+        total = fmaxf(total, 0.0f);
+        const float rt = term[QA_TSC_REW_TERMINATION] * c->reward_scales[QA_TSC_REW_TERMINATION];
+        total += rt;
+        io->episode_sums[(int64_t)QA_TSC_REW_TERMINATION * N + e] += rt;
+        io->rew_buf[e] = total;
+        /* :272-273 */
+        int64_t g0 = gi < 0 ? 0 : (gi > c->num_goal_slots - 1 ? c->num_goal_slots - 1 : gi);
+        int64_t g1 = gi + 1 < 0 ? 0 : (gi + 1 > c->num_goal_slots - 1 ? c->num_goal_slots - 1 : gi + 1);
+        const float *eg = io->env_goals + e * c->num_goal_slots * 3;
+        for (int k = 0; k < 3; ++k) { io->cur_goals[e * 3 + k] = eg[g0 * 3 + k]; io->next_goals[e * 3 + k] = eg[g1 * 3 + k]; }
+    }
+    return QA_OK;
+}

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 6
+QA_ABI_VERSION = 7
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -131,6 +131,10 @@ def bind(lib, prefix):
     f.restype = C.c_int
     f = getattr(lib, prefix + "gather_rows"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5; f.restype = C.c_int
     f = getattr(lib, prefix + "kl_lr_rule"); f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "tsc_set_commands")
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10
+    f.restype = C.c_int
+    f = getattr(lib, prefix + "tsc_goal_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_packed_floats"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "mlp_pack"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_forward")
@@ -152,9 +156,38 @@ class QaMlpOp(C.Structure):
 MLP_COPY, MLP_LAYER, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 24, 4
 MLP_BUF_COLS = (672, 576, 320, 128)
 
+TSC_REWARD_NAMES = ("action_hl_rate", "collision", "feet_edge", "latent_c_rate", "reach_goal", "tracking_goal_vel", "tracking_yaw",
+                    "termination")          # QA_TSC_REW_* order
+TSC_MAX_BODY_IDS = 24
+
+
+class QaTscGoalCfg(C.Structure):
+    """qa_tsc_goal_cfg of include/qa_sim.h"""
+    _fields_ = [("num_envs", C.c_int64), ("num_bodies", C.c_int32), ("num_goal_slots", C.c_int32), ("last_goal_repeat", C.c_int32),
+                ("goals_per_obstacle", C.c_int32), ("num_obstacles", C.c_int32), ("history_len", C.c_int32), ("history_width", C.c_int32),
+                ("mask_rows", C.c_int32), ("mask_cols", C.c_int32), ("use_camera", C.c_int32),
+                ("num_termination_bodies", C.c_int32), ("num_penalised_bodies", C.c_int32),
+                ("termination_bodies", C.c_int32 * TSC_MAX_BODY_IDS), ("penalised_bodies", C.c_int32 * TSC_MAX_BODY_IDS),
+                ("feet_bodies", C.c_int32 * 4), ("reach_goal_delay_steps", C.c_float), ("next_goal_threshold", C.c_float),
+                ("leave_goal_threshold", C.c_float), ("max_episode_length", C.c_float), ("target_lin_vel", C.c_float),
+                ("border_size", C.c_float), ("horizontal_scale", C.c_float), ("reward_scales", C.c_float * len(TSC_REWARD_NAMES))]
+
+
+TSC_GOAL_IO_FIELDS = ("root_states", "contact_forces", "rigid_body_states", "env_goals", "obstacle_types", "action_hl_history", "x_edge_mask",
+                      "episode_length", "cur_goal_idx", "reach_goal_timer", "last_contacts", "cur_goals", "next_goals", "episode_sums",
+                      "base_lin_vel", "base_ang_vel", "projected_gravity", "rpy", "contact_filt", "target_pos_rel", "next_target_pos_rel",
+                      "target_yaw", "next_target_yaw", "reached_goal", "cur_obstacle_type", "reset_buf", "time_out_buf", "reach_goal_cutoff",
+                      "rew_buf")
+
+
+class QaTscGoalIo(C.Structure):
+    """qa_tsc_goal_io of include/qa_sim.h (every member is a pointer)"""
+    _fields_ = [(name, C.c_void_p) for name in TSC_GOAL_IO_FIELDS]
+
+
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

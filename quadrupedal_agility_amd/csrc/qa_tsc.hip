@@ -1,0 +1,286 @@
+// Task-level (TSC) env-side math for gfx950: the command mapping and the goal / termination / reward bookkeeping of
+// tsc/legged_gym/envs/base/legged_robot.py that need no obstacle physics (include/qa_sim.h has the
+// contracts).  Both are one-thread-per-env streaming kernels: a few hundred bytes in and out per env, no reuse, so they are
+// launch/latency-bound at 8192 envs (128 wavefronts) and exist to replace ~150 eager launches per step, not to move bytes.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/qa_sim.h"
+
+extern thread_local char qa_err_buf[512];
+#define g_terr qa_err_buf
+
+namespace {
+
+constexpr int TSC_BLOCK = 64;          // one wavefront per workgroup: 8192 envs = 128 workgroups spread over 128 CUs (256-thread blocks would use 32)
+constexpr int TSC_MAX_DIM_C = 8;
+constexpr int TSC_NUM_C = 6;
+
+struct SetCmdArgs {
+    const float *actions; const int64_t *episode_length; const float *noise;
+    float *commands, *latent_eps, *latent_c, *next_commands;
+    int64_t n;
+    int num_d, dim_c, interval;
+    int mocap_index[TSC_MAX_DIM_C];
+    float vel[3][TSC_MAX_DIM_C][2];
+    float jump[2], height[2];
+};
+
+__global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_set_commands_kernel(SetCmdArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * TSC_BLOCK + threadIdx.x;
+    if (e >= a.n) return;
+    const int width = 1 + a.num_d * TSC_NUM_C;
+    float cmd[5], eps, c[TSC_MAX_DIM_C];
+    if (a.episode_length[e] % a.interval == 0) {
+        const float *row = a.actions + e * width;
+        int id = (int)row[0];                      // .to(torch.long): truncation
+        id = id < 0 ? 0 : (id >= a.num_d ? a.num_d - 1 : id);
+        const int g = a.mocap_index[id];
+        float u[TSC_NUM_C];
+#pragma unroll
+        for (int k = 0; k < TSC_NUM_C; ++k) {
+            const float p = fminf(fmaxf(row[1 + id * TSC_NUM_C + k], -1.0f), 1.0f);
+            if (k == TSC_NUM_C - 1) eps = p;
+            u[k] = (p + 1.0f) / 2.0f;
+        }
+        for (int k = 0; k < a.dim_c; ++k) c[k] = k == g ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float lo = a.vel[k][g][0], hi = a.vel[k][g][1];
+            cmd[k] = lo + (hi - lo) * u[k];
+        }
+        const bool jump = g == a.dim_c - 1;
+        cmd[3] = (a.jump[0] + (a.jump[1] - a.jump[0]) * u[3]) * (jump ? 1.0f : 0.0f);
+        cmd[4] = (a.height[0] + (a.height[1] - a.height[0]) * u[4]) * (jump ? 0.0f : 1.0f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cmd[k] = a.commands[e * 5 + k];
+        eps = a.latent_eps[e];
+        for (int k = 0; k < a.dim_c; ++k) c[k] = a.latent_c[e * a.dim_c + k];
+    }
+    if (a.noise) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cmd[k] *= a.noise[e * 5 + k];
+    }
+    float *nx = a.next_commands + e * (6 + a.dim_c);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { a.commands[e * 5 + k] = cmd[k]; nx[k] = cmd[k]; }
+    a.latent_eps[e] = eps; nx[5] = eps;
+    for (int k = 0; k < a.dim_c; ++k) { a.latent_c[e * a.dim_c + k] = c[k]; nx[6 + k] = c[k]; }
+}
+
+// v rotated into the frame of q (xyzw), the isaacgym.torch_utils.quat_rotate_inverse formula:  v (2w^2 - 1) - 2w (q x v) + 2 q (q . v)
+__device__ inline void rotate_inverse(const float q[4], const float v[3], float out[3]) {
+    const float w = q[3];
+    const float s = 2.0f * w * w - 1.0f;
+    const float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+    const float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+    out[0] = v[0] * s - cx * w * 2.0f + q[0] * d * 2.0f;
+    out[1] = v[1] * s - cy * w * 2.0f + q[1] * d * 2.0f;
+    out[2] = v[2] * s - cz * w * 2.0f + q[2] * d * 2.0f;
+}
+
+__device__ inline float norm3(const float *f) { return sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]); }
+
+// python's float modulo (result has the sign of b)
+__device__ inline float floor_mod(float a, float b) {
+    float r = fmodf(a, b);
+    if (r != 0.0f && ((r < 0.0f) != (b < 0.0f))) r += b;
+    return r;
+}
+
+__global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal_cfg c, qa_tsc_goal_io io) {
+    const int64_t e = (int64_t)blockIdx.x * TSC_BLOCK + threadIdx.x;
+    if (e >= c.num_envs) return;
+    const int64_t N = c.num_envs;
+    const float *rs = io.root_states + e * 13;
+    const float *cf = io.contact_forces + e * c.num_bodies * 3;
+    const int64_t ep_len = io.episode_length[e] + 1;
+    io.episode_length[e] = ep_len;
+
+    // body-frame quantities and euler angles
+    const float q[4] = {rs[3], rs[4], rs[5], rs[6]};
+    const float grav[3] = {0.0f, 0.0f, -1.0f};
+    float lin[3], ang[3], pg[3];
+    rotate_inverse(q, rs + 7, lin);
+    rotate_inverse(q, rs + 10, ang);
+    rotate_inverse(q, grav, pg);
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float roll = atan2f(2.0f * (w * x + y * z), 1.0f - 2.0f * (x * x + y * y));
+    const float pitch = asinf(fminf(fmaxf(2.0f * (w * y - z * x), -1.0f), 1.0f));
+    const float yaw = atan2f(2.0f * (w * z + x * y), 1.0f - 2.0f * (y * y + z * z));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        io.base_lin_vel[e * 3 + k] = lin[k]; io.base_ang_vel[e * 3 + k] = ang[k]; io.projected_gravity[e * 3 + k] = pg[k];
+    }
+    io.rpy[e * 3 + 0] = roll; io.rpy[e * 3 + 1] = pitch; io.rpy[e * 3 + 2] = yaw;
+
+    // filtered foot contacts
+    bool filt[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const bool now = norm3(cf + c.feet_bodies[f] * 3) > 2.0f;
+        filt[f] = now || io.last_contacts[e * 4 + f] != 0;
+        io.last_contacts[e * 4 + f] = now;
+        io.contact_filt[e * 4 + f] = filt[f];
+    }
+
+    // goals: advance after the dwell, distances to the goal gathered at the end of the previous step
+    int64_t gi = io.cur_goal_idx[e];
+    float timer = io.reach_goal_timer[e];
+    if (timer > c.reach_goal_delay_steps) { gi += 1; timer = 0.0f; }
+    const float gx = io.cur_goals[e * 3 + 0], gy = io.cur_goals[e * 3 + 1];
+    const float nx = io.next_goals[e * 3 + 0], ny = io.next_goals[e * 3 + 1];
+    const float dxr = rs[0] - gx, dyr = rs[1] - gy;
+    const float dist = sqrtf(dxr * dxr + dyr * dyr);
+    const bool reached = dist < c.next_goal_threshold, leave = dist > c.leave_goal_threshold;
+    if (reached) timer += 1.0f;
+    io.cur_goal_idx[e] = gi;
+    io.reach_goal_timer[e] = timer;
+    io.reached_goal[e] = reached;
+    const float tx = gx - rs[0], ty = gy - rs[1];
+    const float tn = sqrtf(tx * tx + ty * ty);
+    const float tvx = tx / (tn + 1e-5f), tvy = ty / (tn + 1e-5f);
+    const float target_yaw = atan2f(tvy, tvx);
+    const float ux = nx - rs[0], uy = ny - rs[1];
+    const float un = sqrtf(ux * ux + uy * uy);
+    const float next_yaw = atan2f(uy / (un + 1e-5f), ux / (un + 1e-5f));
+    io.target_pos_rel[e * 2 + 0] = tx; io.target_pos_rel[e * 2 + 1] = ty;
+    io.next_target_pos_rel[e * 2 + 0] = ux; io.next_target_pos_rel[e * 2 + 1] = uy;
+    io.target_yaw[e] = target_yaw; io.next_target_yaw[e] = next_yaw;
+
+    // the obstacle the current goal belongs to
+    int64_t gclamp = gi < 0 ? 0 : gi;
+    const int64_t gmax = c.num_goal_slots - c.last_goal_repeat - 1;
+    gclamp = gclamp > gmax ? gmax : gclamp;
+    int ob = (int)(gclamp / c.goals_per_obstacle);
+    ob = ob >= c.num_obstacles ? c.num_obstacles - 1 : ob;
+    const int64_t otype = io.obstacle_types[e * c.num_obstacles + ob];
+    io.cur_obstacle_type[e] = otype;
+
+    // termination
+    bool reset = false;
+    for (int k = 0; k < c.num_termination_bodies; ++k) reset = reset || norm3(cf + c.termination_bodies[k] * 3) > 1.0f;
+    const bool goal_cut = gi >= (int64_t)(c.num_goal_slots - c.last_goal_repeat);
+    const bool time_out = ((float)ep_len > c.max_episode_length) || goal_cut;
+    reset = reset || time_out || fabsf(roll) > 1.5f || fabsf(pitch) > 1.5f || rs[2] < -0.25f || leave;
+    if (c.use_camera) {
+        const float *lg = io.env_goals + (e * c.num_goal_slots + (c.num_goal_slots - c.last_goal_repeat)) * 3;
+        const float lx = rs[0] - lg[0], ly = rs[1] - lg[1];
+        reset = reset || sqrtf(lx * lx + ly * ly) < c.next_goal_threshold;
+    }
+    io.reset_buf[e] = reset; io.time_out_buf[e] = time_out; io.reach_goal_cutoff[e] = goal_cut;
+
+    // rewards, summed in the reference's order
+    float term[QA_TSC_NUM_REWARDS];
+    if (io.action_hl_history) {
+        const float *h = io.action_hl_history + e * c.history_len * c.history_width;
+        const float *h1 = h + (c.history_len - 1) * c.history_width, *h2 = h + (c.history_len - 2) * c.history_width,
+                    *h3 = h + (c.history_len - 3) * c.history_width;
+        float ss = 0.0f;
+        for (int k = 0; k < c.history_width; ++k) { const float d = h2[k] - h1[k]; ss += d * d; }
+        term[QA_TSC_REW_ACTION_HL_RATE] = sqrtf(ss);
+        term[QA_TSC_REW_LATENT_C_RATE] = 0.5f * (fabsf(h3[0] - h1[0]) + fabsf(h2[0] - h1[0]));
+    } else {
+        term[QA_TSC_REW_ACTION_HL_RATE] = 0.0f;
+        term[QA_TSC_REW_LATENT_C_RATE] = 0.0f;
+    }
+    int hits = 0;
+    for (int k = 0; k < c.num_penalised_bodies; ++k) hits += norm3(cf + c.penalised_bodies[k] * 3) > 0.1f;
+    term[QA_TSC_REW_COLLISION] = (float)hits;
+    int edge = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const float *fp = io.rigid_body_states + (e * c.num_bodies + c.feet_bodies[f]) * 13;
+        int64_t ix = (int64_t)rintf((fp[0] + c.border_size) / c.horizontal_scale);      // torch.round: half to even
+        int64_t iy = (int64_t)rintf((fp[1] + c.border_size) / c.horizontal_scale);
+        ix = ix < 0 ? 0 : (ix > c.mask_rows - 1 ? c.mask_rows - 1 : ix);
+        iy = iy < 0 ? 0 : (iy > c.mask_cols - 1 ? c.mask_cols - 1 : iy);
+        edge += (filt[f] && io.x_edge_mask[ix * c.mask_cols + iy] != 0) ? 1 : 0;
+    }
+    term[QA_TSC_REW_FEET_EDGE] = (float)edge;
+    term[QA_TSC_REW_REACH_GOAL] = reached ? 1.0f : 0.0f;
+    const float vt = (otype == 0 || otype == 4) ? 2.5f : c.target_lin_vel;
+    term[QA_TSC_REW_TRACKING_GOAL_VEL] = fminf(tvx * rs[7] + tvy * rs[8], vt) / (vt + 1e-5f);
+    const float PI_F = 3.14159265358979323846f;
+    const float dyaw = floor_mod((target_yaw - yaw) + PI_F, 2.0f * PI_F) - PI_F;
+    term[QA_TSC_REW_TRACKING_YAW] = expf(-fabsf(dyaw));
+    term[QA_TSC_REW_TERMINATION] = (reset && !time_out) ? 1.0f : 0.0f;
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < QA_TSC_NUM_REWARDS - 1; ++k) {
+        const float r = term[k] * c.reward_scales[k];
+        total += r;
+        io.episode_sums[k * N + e] += r;
+    }
+    total = fmaxf(total, 0.0f);
+    const float rt = term[QA_TSC_REW_TERMINATION] * c.reward_scales[QA_TSC_REW_TERMINATION];
+    total += rt;
+    io.episode_sums[(int64_t)QA_TSC_REW_TERMINATION * N + e] += rt;
+    io.rew_buf[e] = total;
+
+    // gather of the goals for the next step
+    int64_t g0 = gi < 0 ? 0 : (gi > c.num_goal_slots - 1 ? c.num_goal_slots - 1 : gi);
+    int64_t g1 = gi + 1 < 0 ? 0 : (gi + 1 > c.num_goal_slots - 1 ? c.num_goal_slots - 1 : gi + 1);
+    const float *eg = io.env_goals + e * c.num_goal_slots * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { io.cur_goals[e * 3 + k] = eg[g0 * 3 + k]; io.next_goals[e * 3 + k] = eg[g1 * 3 + k]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int qa_tsc_set_commands(const float *actions, const int64_t *episode_length, int64_t num_envs, int32_t num_d, int32_t num_c, int32_t dim_c,
+                        int32_t interval, const int32_t *mocap_index, const float *vel_ranges, const float *jump_range,
+                        const float *height_range, const float *noise, float *commands, float *latent_eps, float *latent_c,
+                        float *next_commands, void *stream) {
+    if (!actions || !episode_length || !mocap_index || !vel_ranges || !jump_range || !height_range || !commands || !latent_eps ||
+        !latent_c || !next_commands || num_envs <= 0) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_set_commands: null pointer or no envs"); return QA_E_ARG; }
+    if (num_c != TSC_NUM_C || dim_c < 1 || dim_c > TSC_MAX_DIM_C || num_d < 1 || num_d > TSC_MAX_DIM_C || interval < 1) {
+        snprintf(g_terr, sizeof(g_terr), "qa_tsc_set_commands: num_c must be %d, 1 <= num_d, dim_c <= %d, interval >= 1", TSC_NUM_C, TSC_MAX_DIM_C); return QA_E_ARG; }
+    SetCmdArgs a{};
+    a.actions = actions; a.episode_length = episode_length; a.noise = noise;
+    a.commands = commands; a.latent_eps = latent_eps; a.latent_c = latent_c; a.next_commands = next_commands;
+    a.n = num_envs; a.num_d = num_d; a.dim_c = dim_c; a.interval = interval;
+    for (int i = 0; i < num_d; ++i) {
+        if (mocap_index[i] < 0 || mocap_index[i] >= dim_c) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_set_commands: mocap_index[%d] out of range", i); return QA_E_ARG; }
+        a.mocap_index[i] = mocap_index[i];
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int g = 0; g < dim_c; ++g) { a.vel[k][g][0] = vel_ranges[(k * dim_c + g) * 2]; a.vel[k][g][1] = vel_ranges[(k * dim_c + g) * 2 + 1]; }
+    a.jump[0] = jump_range[0]; a.jump[1] = jump_range[1]; a.height[0] = height_range[0]; a.height[1] = height_range[1];
+    hipLaunchKernelGGL(qa_tsc_set_commands_kernel, dim3((unsigned)((num_envs + TSC_BLOCK - 1) / TSC_BLOCK)), dim3(TSC_BLOCK), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_set_commands: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_tsc_goal_step(const qa_tsc_goal_cfg *cfg, const qa_tsc_goal_io *io, void *stream) {
+    if (!cfg || !io) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: null argument"); return QA_E_ARG; }
+    const void *need[] = {io->root_states, io->contact_forces, io->rigid_body_states, io->env_goals, io->obstacle_types, io->x_edge_mask,
+                          io->episode_length, io->cur_goal_idx, io->reach_goal_timer, io->last_contacts, io->cur_goals, io->next_goals,
+                          io->episode_sums, io->base_lin_vel, io->base_ang_vel, io->projected_gravity, io->rpy, io->contact_filt,
+                          io->target_pos_rel, io->next_target_pos_rel, io->target_yaw, io->next_target_yaw, io->reached_goal,
+                          io->cur_obstacle_type, io->reset_buf, io->time_out_buf, io->reach_goal_cutoff, io->rew_buf};
+    for (size_t i = 0; i < sizeof(need) / sizeof(need[0]); ++i)
+        if (!need[i]) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: io pointer %zu is null", i); return QA_E_ARG; }
+    const qa_tsc_goal_cfg &c = *cfg;
+    bool ok = c.num_envs > 0 && c.num_bodies > 0 && c.num_goal_slots > c.last_goal_repeat && c.last_goal_repeat >= 0 && c.goals_per_obstacle > 0 &&
+              c.num_obstacles > 0 && c.mask_rows > 0 && c.mask_cols > 0 && c.horizontal_scale > 0.0f &&
+              c.num_termination_bodies >= 0 && c.num_termination_bodies <= QA_TSC_MAX_BODY_IDS &&
+              c.num_penalised_bodies >= 0 && c.num_penalised_bodies <= QA_TSC_MAX_BODY_IDS &&
+              (!io->action_hl_history || (c.history_len >= 3 && c.history_width >= 1));
+    for (int k = 0; ok && k < c.num_termination_bodies; ++k) ok = c.termination_bodies[k] >= 0 && c.termination_bodies[k] < c.num_bodies;
+    for (int k = 0; ok && k < c.num_penalised_bodies; ++k) ok = c.penalised_bodies[k] >= 0 && c.penalised_bodies[k] < c.num_bodies;
+    for (int k = 0; ok && k < 4; ++k) ok = c.feet_bodies[k] >= 0 && c.feet_bodies[k] < c.num_bodies;
+    if (!ok) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: inconsistent configuration"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_tsc_goal_step_kernel, dim3((unsigned)((c.num_envs + TSC_BLOCK - 1) / TSC_BLOCK)), dim3(TSC_BLOCK), 0, (hipStream_t)stream, c, *io);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+}  // extern "C"

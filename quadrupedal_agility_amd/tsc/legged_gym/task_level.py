@@ -1,0 +1,144 @@
+"""Host-side mirror of the task-level `LeggedRobot`'s command mapping and goal bookkeeping
+(tsc/legged_gym/envs/base/legged_robot.py: set_commands :699-760, post_physics_step :226-273, _update_goals :204-224,
+check_termination :322-346, compute_reward :412-430 with the rewards of :1779-1925).  Attribute names are the reference's
+(`commands`, `latent_eps`, `latent_c`, `cur_goal_idx`, `reach_goal_timer`, `target_yaw`, `reset_buf`, `rew_buf`, ...), so code
+written against the reference env reads the same tensors.  All arithmetic runs in the HIP library (no CPU path)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _capi
+
+
+class TaskLevelBookkeeping:
+    """State and per-step calls of one rank's task-level envs.
+
+    cfg: an object with the reference's config fields (`env.mocap_category(_all)`, `env.num_actions_c`, `env.reach_goal_delay`,
+    `env.next_goal_threshold`, `env.leave_goal_threshold`, `env.episode_length_s`, `commands.ranges`, `commands.resampling_time`,
+    `rewards.scales`, `rewards.target_lin_vel`, `obstacle.{num_goals,last_goal_repeat,border_size,horizontal_scale}`,
+    `depth.use_camera`, `control.decimation`, `sim.dt`).
+    env_goals (N, slots, 3), obstacle_types (N, K) long, x_edge_mask (rows, cols) bool; body index lists as in the reference's
+    `feet_indices`, `penalised_contact_indices`, `termination_contact_indices`."""
+
+    def __init__(self, cfg, env_goals, obstacle_types, x_edge_mask, feet_indices, penalised_contact_indices,
+                 termination_contact_indices, num_bodies, device="cuda:0"):
+        self.lib = _capi.load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("TaskLevelBookkeeping needs a GPU: quadrupedal_agility_amd has no CPU fallback")
+        self.cfg, self.device = cfg, torch.device(device)
+        dev = self.device
+        self.dt = cfg.control.decimation * cfg.sim.dt
+        self.env_goals = env_goals.to(dev, torch.float32).contiguous()
+        self.obstacle_types = obstacle_types.to(dev, torch.long).contiguous()
+        self.x_edge_mask = x_edge_mask.to(dev, torch.uint8).contiguous()
+        n = self.num_envs = self.env_goals.shape[0]
+        cats_all = list(cfg.env.mocap_category_all)
+        self.dim_c = len(cats_all)
+        self.num_actions_d, self.num_actions_c = len(cfg.env.mocap_category), cfg.env.num_actions_c
+        self._mocap_index = np.array([cats_all.index(c) for c in cfg.env.mocap_category], np.int32)
+        r = cfg.commands.ranges
+        self._vel_ranges = np.ascontiguousarray([r.lin_vel_x, r.lin_vel_y, r.ang_vel_yaw], np.float32)
+        self._jump_range = np.ascontiguousarray(r.jump_height, np.float32)
+        self._height_range = np.ascontiguousarray(r.locomotion_height, np.float32)
+        self.max_episode_length = float(np.ceil(cfg.env.episode_length_s / self.dt))
+
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)       # noqa: E731
+        self.commands, self.latent_eps, self.latent_c = z(n, 5), z(n, 1), z(n, self.dim_c)
+        self.next_commands = z(n, 6 + self.dim_c)
+        self.episode_length_buf, self.cur_goal_idx = z(n, dt=torch.long), z(n, dt=torch.long)
+        self.reach_goal_timer, self.last_contacts = z(n), z(n, 4, dt=torch.uint8)
+        self.episode_sums_buf = z(len(_capi.TSC_REWARD_NAMES), n)
+        self.episode_sums = {name: self.episode_sums_buf[i] for i, name in enumerate(_capi.TSC_REWARD_NAMES)}
+        self.base_lin_vel, self.base_ang_vel, self.projected_gravity, self.rpy = z(n, 3), z(n, 3), z(n, 3), z(n, 3)
+        self.contact_filt = z(n, 4, dt=torch.uint8)
+        self.target_pos_rel, self.next_target_pos_rel, self.target_yaw, self.next_target_yaw = z(n, 2), z(n, 2), z(n), z(n)
+        self.reached_goal_ids, self.cur_obstacle_types = z(n, dt=torch.uint8), z(n, dt=torch.long)
+        self.reset_buf, self.time_out_buf, self.reach_goal_cutoff = (z(n, dt=torch.uint8) for _ in range(3))
+        self.rew_buf = z(n)
+        self.cur_goals, self.next_goals = self._gather_cur_goals(), self._gather_cur_goals(future=1)
+
+        c = self._cfg = _capi.QaTscGoalCfg()
+        c.num_envs, c.num_bodies = n, int(num_bodies)
+        c.num_goal_slots, c.last_goal_repeat = self.env_goals.shape[1], cfg.obstacle.last_goal_repeat
+        c.goals_per_obstacle, c.num_obstacles = cfg.obstacle.num_goals, self.obstacle_types.shape[1]
+        c.mask_rows, c.mask_cols = self.x_edge_mask.shape
+        c.use_camera = int(bool(cfg.depth.use_camera))
+        for name, ids in (("termination", termination_contact_indices), ("penalised", penalised_contact_indices)):
+            ids = [int(i) for i in ids]
+            if len(ids) > _capi.TSC_MAX_BODY_IDS:
+                raise ValueError(f"at most {_capi.TSC_MAX_BODY_IDS} {name} bodies")
+            setattr(c, f"num_{name}_bodies", len(ids))
+            for i, b in enumerate(ids):
+                getattr(c, f"{name}_bodies")[i] = b
+        for i, b in enumerate(feet_indices):
+            c.feet_bodies[i] = int(b)
+        c.reach_goal_delay_steps = cfg.env.reach_goal_delay / self.dt
+        c.next_goal_threshold, c.leave_goal_threshold = cfg.env.next_goal_threshold, cfg.env.leave_goal_threshold
+        c.max_episode_length, c.target_lin_vel = self.max_episode_length, cfg.rewards.target_lin_vel
+        c.border_size, c.horizontal_scale = cfg.obstacle.border_size, cfg.obstacle.horizontal_scale
+        self.reward_scales = {}
+        for i, name in enumerate(_capi.TSC_REWARD_NAMES):                 # _prepare_reward_function :1107-1113: scale * dt
+            self.reward_scales[name] = float(getattr(cfg.rewards.scales, name)) * self.dt
+            c.reward_scales[i] = self.reward_scales[name]
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.qa_last_error().decode()}")
+
+    def _gather_cur_goals(self, future=0):
+        """legged_robot.py:646-648"""
+        idx = (self.cur_goal_idx[:, None, None] + future).clamp(0, self.env_goals.shape[1] - 1).expand(-1, -1, 3)
+        return self.env_goals.gather(1, idx).squeeze(1).contiguous()
+
+    def set_commands(self, actions, action_noise=None):
+        """legged_robot.py:699-760.  `action_noise` (N,5): the U(domain_rand.action_noise) draw, or None for no noise."""
+        actions = actions.to(self.device, torch.float32).contiguous()
+        interval = max(1, int(self.cfg.commands.resampling_time / self.dt))
+        if action_noise is not None:
+            action_noise = action_noise.to(self.device, torch.float32).contiguous()
+        rc = self.lib.qa_tsc_set_commands(
+            actions.data_ptr(), self.episode_length_buf.data_ptr(), self.num_envs, self.num_actions_d, self.num_actions_c, self.dim_c,
+            interval, self._mocap_index.ctypes.data, self._vel_ranges.ctypes.data, self._jump_range.ctypes.data,
+            self._height_range.ctypes.data, action_noise.data_ptr() if action_noise is not None else None, self.commands.data_ptr(),
+            self.latent_eps.data_ptr(), self.latent_c.data_ptr(), self.next_commands.data_ptr(), self._stream())
+        self._check(rc, "qa_tsc_set_commands")
+        return self.next_commands
+
+    def post_physics_step(self, root_states, contact_forces, rigid_body_states, action_hl_history_buf=None):
+        """The goal / termination / reward part of legged_robot.py:226-273 on the simulator's tensors; returns the ids to reset.
+        The caller's reset then calls `reset_idx(env_ids)`."""
+        keep = [t.to(self.device, torch.float32).contiguous() for t in (root_states, contact_forces, rigid_body_states)]
+        io = _capi.QaTscGoalIo()
+        io.root_states, io.contact_forces, io.rigid_body_states = (t.data_ptr() for t in keep)
+        if action_hl_history_buf is not None:
+            hist = action_hl_history_buf.to(self.device, torch.float32).contiguous()
+            self._cfg.history_len, self._cfg.history_width = hist.shape[1], hist.shape[2]
+            io.action_hl_history = hist.data_ptr()
+        members = dict(env_goals=self.env_goals, obstacle_types=self.obstacle_types, x_edge_mask=self.x_edge_mask,
+                       episode_length=self.episode_length_buf, cur_goal_idx=self.cur_goal_idx, reach_goal_timer=self.reach_goal_timer,
+                       last_contacts=self.last_contacts, cur_goals=self.cur_goals, next_goals=self.next_goals,
+                       episode_sums=self.episode_sums_buf, base_lin_vel=self.base_lin_vel, base_ang_vel=self.base_ang_vel,
+                       projected_gravity=self.projected_gravity, rpy=self.rpy, contact_filt=self.contact_filt,
+                       target_pos_rel=self.target_pos_rel, next_target_pos_rel=self.next_target_pos_rel, target_yaw=self.target_yaw,
+                       next_target_yaw=self.next_target_yaw, reached_goal=self.reached_goal_ids, cur_obstacle_type=self.cur_obstacle_types,
+                       reset_buf=self.reset_buf, time_out_buf=self.time_out_buf, reach_goal_cutoff=self.reach_goal_cutoff,
+                       rew_buf=self.rew_buf)
+        for name, t in members.items():
+            setattr(io, name, t.data_ptr())
+        self._check(self.lib.qa_tsc_goal_step(C.byref(self._cfg), C.byref(io), self._stream()), "qa_tsc_goal_step")
+        self.roll, self.pitch, self.yaw = self.rpy[:, 0], self.rpy[:, 1], self.rpy[:, 2]
+        return self.reset_buf.nonzero(as_tuple=False).flatten()
+
+    def reset_idx(self, env_ids):
+        """The goal / episode bookkeeping of the reference's reset_idx (:376, :396-404) and the re-gather of :272-273."""
+        if len(env_ids):
+            self.cur_goal_idx[env_ids] = 0
+            self.reach_goal_timer[env_ids] = 0
+            self.episode_sums_buf[:, env_ids] = 0
+            self.episode_length_buf[env_ids] = 0
+            self.cur_goals[env_ids] = self.env_goals[env_ids, 0]
+            self.next_goals[env_ids] = self.env_goals[env_ids, 1]
