@@ -483,6 +483,69 @@ typedef struct qa_tsc_goal_io {
 } qa_tsc_goal_io;
 int qa_tsc_goal_step(const qa_tsc_goal_cfg *cfg, const qa_tsc_goal_io *io, void *stream);
 
+/* qa_tsc_observations  =  the task-level env's 132-point height scan and observation assembly
+ * (tsc/legged_gym/envs/base/legged_robot.py: _get_heights :1708-1755 with quat_apply_yaw of legged_gym/utils/math.py:10-14,
+ * compute_observations :432-515, compute_flat_key_pos :1929-1947), run after qa_tsc_goal_step on its outputs.  Layouts:
+ *   proprio (57)   = [roll, pitch | base_ang_vel * ang_vel (3) | (dof_pos - default_dof_pos_all) * dof_pos (12) | dof_vel * dof_vel (12) |
+ *                     last action (12) | contact_filt - 0.5 (4) | zeros (12)]
+ *   obs_buf (800)  = [proprio 57 | delta_yaw, delta_next_yaw | one_hot(cur_obstacle_type, 6) | clip(z - 0.3 - heights, -1, 1) (132) |
+ *                     root_h_obs, base_lin_vel * lin_vel (4) | mass params 4, friction 1, motor_strength[0]-1 (12), [1]-1 (12) |
+ *                     obs_history BEFORE this step's push (10 x 57, oldest first)]
+ *   obs_bbc (671)  = [proprio 57 | the 4 + 29 privileged values | the same history 570 | commands 5, latent_eps 1, latent_c 5]
+ *   obs_disc (49)  = [roll, pitch, root_h, base_lin_vel * lin_vel_dist, base_ang_vel * ang_vel_dist, (dof_pos - default_dof_pos) *
+ *                     dof_pos, dof_vel * dof_vel, key-body positions in the heading frame * key_pos (12), contact_filt * foot_contact]
+ * root_h = z - heights[132 / 2 + 1].  Then the history push (:497-505): all 10 slots = proprio where episode_length <= 1, else shift
+ * by one and append; obs_buf, obs_bbc and the history are clipped to +-clip_observations.  delta yaws are recomputed from
+ * target_yaw - yaw (wrapped to [-pi, pi)) when `update_yaw` is set and carried over otherwise (:445-450).  The reference's
+ * contact_buf roll (:507, read by nothing active) is not kept.  One wavefront per env; all pointers are device pointers. */
+#define QA_TSC_NUM_SCAN 132
+#define QA_TSC_NUM_PROPRIO 57
+#define QA_TSC_HISTORY_LEN 10
+#define QA_TSC_NUM_OBS 800
+#define QA_TSC_NUM_OBS_BBC 671
+#define QA_TSC_NUM_OBS_DISC 49
+#define QA_TSC_NUM_OBSTACLE_CLASSES 6
+typedef struct qa_tsc_obs_cfg {
+    int64_t num_envs;
+    int32_t num_bodies;                 /* rows of rigid_body_states per env */
+    int32_t key_bodies[4];              /* the reference's key_body_ids (the feet) */
+    int32_t map_rows, map_cols;         /* height_samples */
+    int32_t update_yaw;                 /* global_counter % depth.update_interval == 0 */
+    int32_t root_height_obs;            /* cfg.env.root_height_obs */
+    int64_t action_stride;              /* floats between consecutive envs' rows of `last_action` (action_history_buf[:, -1]) */
+    int64_t points_env_stride;          /* floats between consecutive envs' scan grids in `height_points`; 0 = one grid for all */
+    int32_t point_stride, reserved;     /* floats between consecutive points (2 for xy, 3 for the reference's xyz tensor) */
+    float border_size, horizontal_scale, vertical_scale;
+    float lin_vel, ang_vel, dof_pos, dof_vel, lin_vel_dist, ang_vel_dist, key_pos, foot_contact;   /* obs_scales */
+    float clip_observations;
+    float default_dof_pos[12], default_dof_pos_all[12];
+} qa_tsc_obs_cfg;
+typedef struct qa_tsc_obs_io {
+    /* in */
+    const float *root_states;           /* (N,13) */
+    const float *rpy, *base_lin_vel, *base_ang_vel;     /* (N,3), from qa_tsc_goal_step */
+    const uint8_t *contact_filt;        /* (N,4) */
+    const float *dof_pos, *dof_vel;     /* (N,12) */
+    const float *last_action;           /* (N,12) with row stride action_stride */
+    const float *rigid_body_states;     /* (N,num_bodies,13) */
+    const float *mass_params;           /* (N,4) */
+    const float *friction;              /* (N,1) */
+    const float *motor_strength;        /* (2,N,12) */
+    const int64_t *cur_obstacle_type;   /* (N) */
+    const float *target_yaw, *next_target_yaw;          /* (N) */
+    const int16_t *height_samples;      /* (map_rows,map_cols) */
+    const float *height_points;         /* body-frame xy of the QA_TSC_NUM_SCAN scan points, strides in the cfg */
+    const float *commands, *latent_eps, *latent_c;      /* (N,5), (N,1), (N,5) */
+    const int64_t *episode_length;      /* (N) */
+    /* in/out */
+    float *delta_yaw, *delta_next_yaw;  /* (N) */
+    float *obs_history;                 /* (N,10,57) */
+    /* out */
+    float *measured_heights;            /* (N,132) */
+    float *obs_buf, *obs_bbc_buf, *obs_disc_buf;        /* (N,800), (N,671), (N,49) */
+} qa_tsc_obs_io;
+int qa_tsc_observations(const qa_tsc_obs_cfg *cfg, const qa_tsc_obs_io *io, void *stream);
+
 const char *qa_last_error(void);
 int qa_abi_version(void);
 

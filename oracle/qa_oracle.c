@@ -1688,3 +1688,103 @@ int qo_tsc_goal_step(const qa_tsc_goal_cfg *c, const qa_tsc_goal_io *io, void *s
     }
     return QA_OK;
 }
+
+/* CPU twin of qa_tsc_observations: _get_heights (tsc/legged_gym/envs/base/legged_robot.py:1708-1755), compute_observations
+ * (:432-515), compute_flat_key_pos (:1929-1947).  Pinned by tests/golden/tsc_env.npz (`obs_*` arrays). */
+int qo_tsc_observations(const qa_tsc_obs_cfg *c, const qa_tsc_obs_io *io, void *stream) {
+    (void)stream;
+    if (!c || !io || c->num_envs <= 0 || c->map_rows < 2 || c->map_cols < 2 || c->point_stride < 2) return QA_E_ARG;
+    const int64_t N = c->num_envs;
+    const float PI_F = 3.14159265358979323846f, cl = c->clip_observations;
+    for (int64_t e = 0; e < N; ++e) {
+        const float *rs = io->root_states + e * 13;
+        float row[QA_TSC_NUM_OBS], prop[QA_TSC_NUM_PROPRIO], priv[33], *meas = io->measured_heights + e * QA_TSC_NUM_SCAN;
+        /* proprio :463-469 */
+        prop[0] = io->rpy[e * 3]; prop[1] = io->rpy[e * 3 + 1];
+        for (int k = 0; k < 3; ++k) prop[2 + k] = io->base_ang_vel[e * 3 + k] * c->ang_vel;
+        for (int k = 0; k < 12; ++k) {
+            prop[5 + k] = (io->dof_pos[e * 12 + k] - c->default_dof_pos_all[k]) * c->dof_pos;
+            prop[17 + k] = io->dof_vel[e * 12 + k] * c->dof_vel;
+            prop[29 + k] = io->last_action[e * c->action_stride + k];
+            prop[45 + k] = 0.0f;
+        }
+        for (int k = 0; k < 4; ++k) prop[41 + k] = (io->contact_filt[e * 4 + k] ? 1.0f : 0.0f) - 0.5f;
+        /* delta yaws :445-452 */
+        if (c->update_yaw) {
+            io->delta_yaw[e] = tsc_floor_mod((io->target_yaw[e] - io->rpy[e * 3 + 2]) + PI_F, 2.0f * PI_F) - PI_F;
+            io->delta_next_yaw[e] = tsc_floor_mod((io->next_target_yaw[e] - io->rpy[e * 3 + 2]) + PI_F, 2.0f * PI_F) - PI_F;
+        }
+        /* scan :1708-1755 */
+        const float qn = fmaxf(sqrtf(rs[5] * rs[5] + rs[6] * rs[6]), 1e-9f);
+        const float qz = rs[5] / qn, qw = rs[6] / qn;
+        for (int p = 0; p < QA_TSC_NUM_SCAN; ++p) {
+            const float *hp = io->height_points + e * c->points_env_stride + p * c->point_stride;
+            const float bx = hp[0], by = hp[1];
+            const float t0 = (0.0f - qz * by) * 2.0f, t1 = (qz * bx - 0.0f) * 2.0f;
+            const float wx = (bx + qw * t0) + (0.0f - qz * t1) + rs[0];
+            const float wy = (by + qw * t1) + (qz * t0 - 0.0f) + rs[1];
+            int64_t px = (int64_t)((wx + c->border_size) / c->horizontal_scale), py = (int64_t)((wy + c->border_size) / c->horizontal_scale);
+            if (px < 0) px = 0; if (px > c->map_rows - 2) px = c->map_rows - 2;
+            if (py < 0) py = 0; if (py > c->map_cols - 2) py = c->map_cols - 2;
+            int16_t hm = io->height_samples[px * c->map_cols + py];
+            const int16_t h2 = io->height_samples[(px + 1) * c->map_cols + py], h3 = io->height_samples[px * c->map_cols + py + 1];
+            if (h2 < hm) hm = h2;
+            if (h3 < hm) hm = h3;
+            meas[p] = (float)hm * c->vertical_scale;
+        }
+        const float root_h = rs[2] - meas[QA_TSC_NUM_SCAN / 2 + 1];                 /* :436-438 */
+        /* privileged values :471-478 */
+        priv[0] = c->root_height_obs ? root_h : 0.0f;
+        for (int k = 0; k < 3; ++k) priv[1 + k] = io->base_lin_vel[e * 3 + k] * c->lin_vel;
+        for (int k = 0; k < 4; ++k) priv[4 + k] = io->mass_params[e * 4 + k];
+        priv[8] = io->friction[e];
+        for (int k = 0; k < 12; ++k) { priv[9 + k] = io->motor_strength[e * 12 + k] - 1.0f; priv[21 + k] = io->motor_strength[(N + e) * 12 + k] - 1.0f; }
+        /* discriminator view :456-461 with compute_flat_key_pos */
+        float *d = io->obs_disc_buf + e * QA_TSC_NUM_OBS_DISC;
+        d[0] = prop[0]; d[1] = prop[1]; d[2] = root_h;
+        for (int k = 0; k < 3; ++k) { d[3 + k] = io->base_lin_vel[e * 3 + k] * c->lin_vel_dist; d[6 + k] = io->base_ang_vel[e * 3 + k] * c->ang_vel_dist; }
+        for (int k = 0; k < 12; ++k) { d[9 + k] = (io->dof_pos[e * 12 + k] - c->default_dof_pos[k]) * c->dof_pos; d[21 + k] = io->dof_vel[e * 12 + k] * c->dof_vel; }
+        {
+            const float *q = rs + 3;
+            const float s = 2.0f * q[3] * q[3] - 1.0f;
+            const float hx = s + q[0] * q[0] * 2.0f, hy = q[2] * q[3] * 2.0f + q[1] * q[0] * 2.0f;
+            const float half = -atan2f(hy, hx) / 2.0f;
+            float hz = sinf(half), hw = cosf(half);
+            const float hn = fmaxf(sqrtf(hz * hz + hw * hw), 1e-9f);
+            hz /= hn; hw /= hn;
+            const float s2 = 2.0f * hw * hw - 1.0f;
+            for (int kb = 0; kb < 4; ++kb) {
+                const float *bp = io->rigid_body_states + (e * c->num_bodies + c->key_bodies[kb]) * 13;
+                const float lx = bp[0] - rs[0], ly = bp[1] - rs[1], lz = bp[2] - rs[2];
+                d[33 + kb * 3 + 0] = (lx * s2 + (0.0f - hz * ly) * hw * 2.0f) * c->key_pos;
+                d[33 + kb * 3 + 1] = (ly * s2 + (hz * lx - 0.0f) * hw * 2.0f) * c->key_pos;
+                d[33 + kb * 3 + 2] = (lz * s2 + hz * (hz * lz) * 2.0f) * c->key_pos;
+            }
+        }
+        for (int k = 0; k < 4; ++k) d[45 + k] = (io->contact_filt[e * 4 + k] ? 1.0f : 0.0f) * c->foot_contact;
+        /* rows :479-495, history BEFORE the push */
+        float *hist = io->obs_history + e * 570;
+        memcpy(row, prop, sizeof(prop));
+        row[57] = io->delta_yaw[e]; row[58] = io->delta_next_yaw[e];
+        for (int k = 0; k < QA_TSC_NUM_OBSTACLE_CLASSES; ++k) row[59 + k] = io->cur_obstacle_type[e] == k ? 1.0f : 0.0f;
+        for (int p = 0; p < QA_TSC_NUM_SCAN; ++p) row[65 + p] = clipf((rs[2] - 0.3f) - meas[p], -1.0f, 1.0f);
+        memcpy(row + 197, priv, sizeof(priv));
+        memcpy(row + 230, hist, 570 * sizeof(float));
+        float *ob = io->obs_buf + e * QA_TSC_NUM_OBS, *bb = io->obs_bbc_buf + e * QA_TSC_NUM_OBS_BBC;
+        for (int i = 0; i < QA_TSC_NUM_OBS; ++i) ob[i] = clipf(row[i], -cl, cl);
+        for (int i = 0; i < 57; ++i) bb[i] = clipf(prop[i], -cl, cl);
+        for (int i = 0; i < 33; ++i) bb[57 + i] = clipf(priv[i], -cl, cl);
+        for (int i = 0; i < 570; ++i) bb[90 + i] = clipf(hist[i], -cl, cl);
+        for (int k = 0; k < 5; ++k) { bb[660 + k] = clipf(io->commands[e * 5 + k], -cl, cl); bb[666 + k] = clipf(io->latent_c[e * 5 + k], -cl, cl); }
+        bb[665] = clipf(io->latent_eps[e], -cl, cl);
+        /* history push :497-505, clipped :511 */
+        if (io->episode_length[e] <= 1) {
+            for (int s = 0; s < QA_TSC_HISTORY_LEN; ++s) for (int j = 0; j < 57; ++j) hist[s * 57 + j] = clipf(prop[j], -cl, cl);
+        } else {
+            memmove(hist, hist + 57, 9 * 57 * sizeof(float));
+            for (int i = 0; i < 9 * 57; ++i) hist[i] = clipf(hist[i], -cl, cl);
+            for (int j = 0; j < 57; ++j) hist[9 * 57 + j] = clipf(prop[j], -cl, cl);
+        }
+    }
+    return QA_OK;
+}

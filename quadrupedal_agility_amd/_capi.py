@@ -135,6 +135,7 @@ def bind(lib, prefix):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10
     f.restype = C.c_int
     f = getattr(lib, prefix + "tsc_goal_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "tsc_observations"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_packed_floats"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "mlp_pack"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_forward")
@@ -185,9 +186,32 @@ class QaTscGoalIo(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in TSC_GOAL_IO_FIELDS]
 
 
+class QaTscObsCfg(C.Structure):
+    """qa_tsc_obs_cfg of include/qa_sim.h"""
+    _fields_ = [("num_envs", C.c_int64), ("num_bodies", C.c_int32), ("key_bodies", C.c_int32 * 4), ("map_rows", C.c_int32), ("map_cols", C.c_int32),
+                ("update_yaw", C.c_int32), ("root_height_obs", C.c_int32), ("action_stride", C.c_int64),
+                ("points_env_stride", C.c_int64), ("point_stride", C.c_int32), ("reserved", C.c_int32),
+                ("border_size", C.c_float), ("horizontal_scale", C.c_float), ("vertical_scale", C.c_float),
+                ("lin_vel", C.c_float), ("ang_vel", C.c_float), ("dof_pos", C.c_float), ("dof_vel", C.c_float), ("lin_vel_dist", C.c_float),
+                ("ang_vel_dist", C.c_float), ("key_pos", C.c_float), ("foot_contact", C.c_float), ("clip_observations", C.c_float),
+                ("default_dof_pos", C.c_float * 12), ("default_dof_pos_all", C.c_float * 12)]
+
+
+TSC_OBS_IO_FIELDS = ("root_states", "rpy", "base_lin_vel", "base_ang_vel", "contact_filt", "dof_pos", "dof_vel", "last_action",
+                     "rigid_body_states", "mass_params", "friction", "motor_strength", "cur_obstacle_type", "target_yaw", "next_target_yaw",
+                     "height_samples", "height_points", "commands", "latent_eps", "latent_c", "episode_length", "delta_yaw", "delta_next_yaw",
+                     "obs_history", "measured_heights", "obs_buf", "obs_bbc_buf", "obs_disc_buf")
+TSC_NUM_SCAN, TSC_NUM_OBS, TSC_NUM_OBS_BBC, TSC_NUM_OBS_DISC = 132, 800, 671, 49
+
+
+class QaTscObsIo(C.Structure):
+    """qa_tsc_obs_io of include/qa_sim.h (every member is a pointer)"""
+    _fields_ = [(name, C.c_void_p) for name in TSC_OBS_IO_FIELDS]
+
+
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

@@ -229,6 +229,137 @@ __global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal
     for (int k = 0; k < 3; ++k) { io.cur_goals[e * 3 + k] = eg[g0 * 3 + k]; io.next_goals[e * 3 + k] = eg[g1 * 3 + k]; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Height scan + observation assembly: one wavefront per env, 4 envs per workgroup.  The 800-wide row is built in LDS
+// (segments filled by the lanes that own them, the 570-float history streamed in), then the three observation rows and
+// the pushed history go out as contiguous, lane-strided stores: 8.4 KB written and 2.9 KB read per env, HBM-bound.
+constexpr int OBS_WAVES = 4;
+constexpr int OBS_ROW = QA_TSC_NUM_OBS + 11;            // the 800 row + [commands, latent_eps, latent_c]
+constexpr int OFF_YAW = 57, OFF_TYPE = 59, OFF_SCAN = 65, OFF_PRIV = 197, OFF_LATENT = 201, OFF_HIST = 230, OFF_CMD = 800;
+
+__device__ inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__global__ void __launch_bounds__(64 * OBS_WAVES) qa_tsc_observations_kernel(qa_tsc_obs_cfg c, qa_tsc_obs_io io) {
+    __shared__ float s_row[OBS_WAVES][OBS_ROW];
+    __shared__ float s_meas[OBS_WAVES][QA_TSC_NUM_SCAN];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * OBS_WAVES + wave;
+    const bool valid = e < c.num_envs;
+    const int64_t N = c.num_envs;
+    float *row = s_row[wave], *meas = s_meas[wave];
+    const float *rs = io.root_states + (valid ? e : 0) * 13;
+    const float rz = rs[2];
+    const float PI_F = 3.14159265358979323846f;
+    if (valid) {
+        // proprio: each lane owns one of the 57 entries
+        if (lane < QA_TSC_NUM_PROPRIO) {
+            float v;
+            if (lane < 2) v = io.rpy[e * 3 + lane];
+            else if (lane < 5) v = io.base_ang_vel[e * 3 + lane - 2] * c.ang_vel;
+            else if (lane < 17) v = (io.dof_pos[e * 12 + lane - 5] - c.default_dof_pos_all[lane - 5]) * c.dof_pos;
+            else if (lane < 29) v = io.dof_vel[e * 12 + lane - 17] * c.dof_vel;
+            else if (lane < 41) v = io.last_action[e * c.action_stride + lane - 29];
+            else if (lane < 45) v = (io.contact_filt[e * 4 + lane - 41] ? 1.0f : 0.0f) - 0.5f;
+            else v = 0.0f;
+            row[lane] = v;
+        }
+        if (lane < 2) {          // delta yaws, wrapped to [-pi, pi)
+            float *keep = lane == 0 ? io.delta_yaw : io.delta_next_yaw;
+            float d = keep[e];
+            if (c.update_yaw) {
+                const float t = (lane == 0 ? io.target_yaw : io.next_target_yaw)[e];
+                d = floor_mod((t - io.rpy[e * 3 + 2]) + PI_F, 2.0f * PI_F) - PI_F;
+                keep[e] = d;
+            }
+            row[OFF_YAW + lane] = d;
+        }
+        if (lane < QA_TSC_NUM_OBSTACLE_CLASSES) row[OFF_TYPE + lane] = io.cur_obstacle_type[e] == lane ? 1.0f : 0.0f;
+        // scan: yaw-only rotation of the body-frame grid (quat_apply of the normalised (0,0,z,w)), truncation to the cell, min of 3
+        {
+            const float qz0 = rs[5], qw0 = rs[6];
+            const float qn = fmaxf(sqrtf(qz0 * qz0 + qw0 * qw0), 1e-9f);
+            const float qz = qz0 / qn, qw = qw0 / qn;
+            for (int p = lane; p < QA_TSC_NUM_SCAN; p += 64) {
+                const float *hp = io.height_points + e * c.points_env_stride + p * c.point_stride;
+                const float bx = hp[0], by = hp[1];
+                const float t0 = (0.0f - qz * by) * 2.0f, t1 = (qz * bx - 0.0f) * 2.0f;
+                const float wx = (bx + qw * t0) + (0.0f - qz * t1) + rs[0];
+                const float wy = (by + qw * t1) + (qz * t0 - 0.0f) + rs[1];
+                int64_t px = (int64_t)((wx + c.border_size) / c.horizontal_scale);
+                int64_t py = (int64_t)((wy + c.border_size) / c.horizontal_scale);
+                px = px < 0 ? 0 : (px > c.map_rows - 2 ? c.map_rows - 2 : px);
+                py = py < 0 ? 0 : (py > c.map_cols - 2 ? c.map_cols - 2 : py);
+                const int16_t h1 = io.height_samples[px * c.map_cols + py], h2 = io.height_samples[(px + 1) * c.map_cols + py],
+                              h3 = io.height_samples[px * c.map_cols + py + 1];
+                const int16_t hm = h1 < h2 ? (h1 < h3 ? h1 : h3) : (h2 < h3 ? h2 : h3);
+                const float h = (float)hm * c.vertical_scale;
+                meas[p] = h;
+                io.measured_heights[e * QA_TSC_NUM_SCAN + p] = h;
+                row[OFF_SCAN + p] = clampf((rz - 0.3f) - h, -1.0f, 1.0f);
+            }
+        }
+        if (lane < 3) row[OFF_PRIV + 1 + lane] = io.base_lin_vel[e * 3 + lane] * c.lin_vel;
+        if (lane < 29) {
+            float v;
+            if (lane < 4) v = io.mass_params[e * 4 + lane];
+            else if (lane < 5) v = io.friction[e];
+            else if (lane < 17) v = io.motor_strength[e * 12 + lane - 5] - 1.0f;
+            else v = io.motor_strength[(N + e) * 12 + lane - 17] - 1.0f;
+            row[OFF_LATENT + lane] = v;
+        }
+        for (int i = lane; i < QA_TSC_HISTORY_LEN * QA_TSC_NUM_PROPRIO; i += 64) row[OFF_HIST + i] = io.obs_history[e * 570 + i];
+        if (lane < 5) row[OFF_CMD + lane] = io.commands[e * 5 + lane];
+        else if (lane == 5) row[OFF_CMD + 5] = io.latent_eps[e];
+        else if (lane < 11) row[OFF_CMD + lane] = io.latent_c[e * 5 + lane - 6];
+    }
+    __syncthreads();
+    if (valid) {
+        const float root_h = rz - meas[QA_TSC_NUM_SCAN / 2 + 1];
+        if (lane == 0) row[OFF_PRIV] = c.root_height_obs ? root_h : 0.0f;
+        if (lane < QA_TSC_NUM_OBS_DISC) {       // the imitation discriminator's view
+            float v;
+            if (lane < 2) v = io.rpy[e * 3 + lane];
+            else if (lane < 3) v = root_h;
+            else if (lane < 6) v = io.base_lin_vel[e * 3 + lane - 3] * c.lin_vel_dist;
+            else if (lane < 9) v = io.base_ang_vel[e * 3 + lane - 6] * c.ang_vel_dist;
+            else if (lane < 21) v = (io.dof_pos[e * 12 + lane - 9] - c.default_dof_pos[lane - 9]) * c.dof_pos;
+            else if (lane < 33) v = io.dof_vel[e * 12 + lane - 21] * c.dof_vel;
+            else if (lane < 45) {
+                // key body (lane-33)/3 relative to the root, rotated by the inverse heading (compute_flat_key_pos)
+                const int kb = (lane - 33) / 3, ax = (lane - 33) % 3;
+                const float q[4] = {rs[3], rs[4], rs[5], rs[6]};
+                const float s = 2.0f * q[3] * q[3] - 1.0f;                 // heading = atan2 of the rotated x axis (quat_rotate)
+                const float hx = s + q[0] * q[0] * 2.0f, hy = q[2] * q[3] * 2.0f + q[1] * q[0] * 2.0f;
+                const float half = -atan2f(hy, hx) / 2.0f;
+                float hz = sinf(half), hw = cosf(half);
+                const float hn = fmaxf(sqrtf(hz * hz + hw * hw), 1e-9f);
+                hz /= hn; hw /= hn;
+                const float *bp = io.rigid_body_states + (e * c.num_bodies + c.key_bodies[kb]) * 13;
+                const float lx = bp[0] - rs[0], ly = bp[1] - rs[1], lz = bp[2] - rs[2];
+                const float s2 = 2.0f * hw * hw - 1.0f;
+                const float r[3] = {lx * s2 + (0.0f - hz * ly) * hw * 2.0f, ly * s2 + (hz * lx - 0.0f) * hw * 2.0f, lz * s2 + hz * (hz * lz) * 2.0f};
+                v = r[ax] * c.key_pos;
+            } else v = (io.contact_filt[e * 4 + lane - 45] ? 1.0f : 0.0f) * c.foot_contact;
+            io.obs_disc_buf[e * QA_TSC_NUM_OBS_DISC + lane] = v;
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+    const float cl = c.clip_observations;
+    for (int i = lane; i < QA_TSC_NUM_OBS; i += 64) io.obs_buf[e * QA_TSC_NUM_OBS + i] = clampf(row[i], -cl, cl);
+    for (int i = lane; i < QA_TSC_NUM_OBS_BBC; i += 64) {
+        const int src = i < 57 ? i : (i < 90 ? OFF_PRIV + (i - 57) : (i < 660 ? OFF_HIST + (i - 90) : OFF_CMD + (i - 660)));
+        io.obs_bbc_buf[e * QA_TSC_NUM_OBS_BBC + i] = clampf(row[src], -cl, cl);
+    }
+    const bool first = io.episode_length[e] <= 1;
+    for (int i = lane; i < 570; i += 64) {
+        const int slot = i / 57, j = i - slot * 57;
+        const float v = (first || slot == QA_TSC_HISTORY_LEN - 1) ? row[j] : row[OFF_HIST + i + 57];
+        io.obs_history[e * 570 + i] = clampf(v, -cl, cl);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,6 +411,27 @@ int qa_tsc_goal_step(const qa_tsc_goal_cfg *cfg, const qa_tsc_goal_io *io, void 
     hipLaunchKernelGGL(qa_tsc_goal_step_kernel, dim3((unsigned)((c.num_envs + TSC_BLOCK - 1) / TSC_BLOCK)), dim3(TSC_BLOCK), 0, (hipStream_t)stream, c, *io);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_tsc_observations(const qa_tsc_obs_cfg *cfg, const qa_tsc_obs_io *io, void *stream) {
+    if (!cfg || !io) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_observations: null argument"); return QA_E_ARG; }
+    const void *need[] = {io->root_states, io->rpy, io->base_lin_vel, io->base_ang_vel, io->contact_filt, io->dof_pos, io->dof_vel, io->last_action,
+                          io->rigid_body_states, io->mass_params, io->friction, io->motor_strength, io->cur_obstacle_type, io->target_yaw,
+                          io->next_target_yaw, io->height_samples, io->height_points, io->commands, io->latent_eps, io->latent_c,
+                          io->episode_length, io->delta_yaw, io->delta_next_yaw, io->obs_history, io->measured_heights, io->obs_buf,
+                          io->obs_bbc_buf, io->obs_disc_buf};
+    for (size_t i = 0; i < sizeof(need) / sizeof(need[0]); ++i)
+        if (!need[i]) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_observations: io pointer %zu is null", i); return QA_E_ARG; }
+    const qa_tsc_obs_cfg &c = *cfg;
+    bool ok = c.num_envs > 0 && c.num_bodies > 0 && c.map_rows >= 2 && c.map_cols >= 2 && c.horizontal_scale > 0.0f && c.action_stride >= 12 && c.point_stride >= 2 && c.points_env_stride >= 0 &&
+              c.clip_observations > 0.0f;
+    for (int k = 0; ok && k < 4; ++k) ok = c.key_bodies[k] >= 0 && c.key_bodies[k] < c.num_bodies;
+    if (!ok) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_observations: inconsistent configuration"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_tsc_observations_kernel, dim3((unsigned)((c.num_envs + OBS_WAVES - 1) / OBS_WAVES)), dim3(64 * OBS_WAVES), 0,
+                       (hipStream_t)stream, c, *io);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_observations: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

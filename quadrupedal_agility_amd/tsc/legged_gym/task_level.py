@@ -1,6 +1,7 @@
 """Host-side mirror of the task-level `LeggedRobot`'s command mapping and goal bookkeeping
 (tsc/legged_gym/envs/base/legged_robot.py: set_commands :699-760, post_physics_step :226-273, _update_goals :204-224,
-check_termination :322-346, compute_reward :412-430 with the rewards of :1779-1925).  Attribute names are the reference's
+check_termination :322-346, compute_reward :412-430 with the rewards of :1779-1925, _get_heights :1708-1755, compute_observations
+:432-515).  Attribute names are the reference's
 (`commands`, `latent_eps`, `latent_c`, `cur_goal_idx`, `reach_goal_timer`, `target_yaw`, `reset_buf`, `rew_buf`, ...), so code
 written against the reference env reads the same tensors.  All arithmetic runs in the HIP library (no CPU path)."""
 import ctypes as C
@@ -132,6 +133,70 @@ class TaskLevelBookkeeping:
         self._check(self.lib.qa_tsc_goal_step(C.byref(self._cfg), C.byref(io), self._stream()), "qa_tsc_goal_step")
         self.roll, self.pitch, self.yaw = self.rpy[:, 0], self.rpy[:, 1], self.rpy[:, 2]
         return self.reset_buf.nonzero(as_tuple=False).flatten()
+
+    def init_observations(self, height_samples, height_points, default_dof_pos, default_dof_pos_all=None, key_body_ids=None):
+        """Buffers and constants of compute_observations: the obstacle course's int16 height map, the reference's
+        `height_points` tensor (N,132,3) or one shared (132,2|3) grid, the default joint angles."""
+        dev, n, cfg = self.device, self.num_envs, self.cfg
+        self.height_samples = height_samples.to(dev, torch.int16).contiguous()
+        self.height_points = height_points.to(dev, torch.float32).contiguous()
+        if self.height_points.shape[-2] != _capi.TSC_NUM_SCAN:
+            raise ValueError(f"{_capi.TSC_NUM_SCAN} scan points expected")
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)       # noqa: E731
+        self.obs_buf, self.obs_bbc_buf, self.obs_disc_buf = z(n, _capi.TSC_NUM_OBS), z(n, _capi.TSC_NUM_OBS_BBC), z(n, _capi.TSC_NUM_OBS_DISC)
+        self.obs_history_buf, self.measured_heights = z(n, 10, 57), z(n, _capi.TSC_NUM_SCAN)
+        self.delta_yaw, self.delta_next_yaw = z(n), z(n)
+        c = self._ocfg = _capi.QaTscObsCfg()
+        c.num_envs, c.num_bodies = n, self._cfg.num_bodies
+        for i, b in enumerate(key_body_ids if key_body_ids is not None else list(self._cfg.feet_bodies)):
+            c.key_bodies[i] = int(b)
+        c.map_rows, c.map_cols = self.height_samples.shape
+        c.root_height_obs = int(bool(cfg.env.root_height_obs))
+        c.point_stride = self.height_points.shape[-1]
+        c.points_env_stride = self.height_points.shape[-2] * self.height_points.shape[-1] if self.height_points.dim() == 3 else 0
+        c.border_size, c.horizontal_scale, c.vertical_scale = cfg.obstacle.border_size, cfg.obstacle.horizontal_scale, cfg.obstacle.vertical_scale
+        sc = cfg.normalization.obs_scales
+        c.lin_vel, c.ang_vel, c.dof_pos, c.dof_vel = sc.lin_vel, sc.ang_vel, sc.dof_pos, sc.dof_vel
+        c.lin_vel_dist, c.ang_vel_dist, c.key_pos, c.foot_contact = sc.lin_vel_dist, sc.ang_vel_dist, sc.key_pos, sc.foot_contact
+        c.clip_observations = cfg.normalization.clip_observations
+        d0 = [float(v) for v in torch.as_tensor(default_dof_pos).flatten()[:12]]
+        d1 = [float(v) for v in torch.as_tensor(default_dof_pos_all).flatten()[:12]] if default_dof_pos_all is not None else d0
+        for i in range(12):
+            c.default_dof_pos[i], c.default_dof_pos_all[i] = d0[i], d1[i]
+
+    def compute_observations(self, root_states, dof_pos, dof_vel, action_history_buf, rigid_body_states, mass_params_tensor,
+                             friction_coeffs_tensor, motor_strength, update_yaw=True):
+        """legged_robot.py:432-515 with the scan of :1708-1755, after `post_physics_step`; fills obs_buf (N,800), obs_bbc_buf (N,671),
+        obs_disc_buf (N,49), measured_heights, and pushes obs_history_buf.  `update_yaw` = (global_counter % depth.update_interval == 0)."""
+        f32 = lambda t: t.to(self.device, torch.float32)                       # noqa: E731
+        hist = f32(action_history_buf)
+        last = hist[:, -1]
+        keep = dict(root_states=f32(root_states).contiguous(), dof_pos=f32(dof_pos).contiguous(), dof_vel=f32(dof_vel).contiguous(),
+                    rigid_body_states=f32(rigid_body_states).contiguous(), mass_params=f32(mass_params_tensor).contiguous(),
+                    friction=f32(friction_coeffs_tensor).contiguous(), motor_strength=f32(motor_strength).contiguous())
+        if last.stride(-1) != 1:
+            last = last.contiguous()
+        self._ocfg.action_stride, self._ocfg.update_yaw = last.stride(0), int(bool(update_yaw))
+        members = dict(keep, last_action=last, rpy=self.rpy, base_lin_vel=self.base_lin_vel, base_ang_vel=self.base_ang_vel,
+                       contact_filt=self.contact_filt, cur_obstacle_type=self.cur_obstacle_types, target_yaw=self.target_yaw,
+                       next_target_yaw=self.next_target_yaw, height_samples=self.height_samples, height_points=self.height_points,
+                       commands=self.commands, latent_eps=self.latent_eps, latent_c=self.latent_c, episode_length=self.episode_length_buf,
+                       delta_yaw=self.delta_yaw, delta_next_yaw=self.delta_next_yaw, obs_history=self.obs_history_buf,
+                       measured_heights=self.measured_heights, obs_buf=self.obs_buf, obs_bbc_buf=self.obs_bbc_buf, obs_disc_buf=self.obs_disc_buf)
+        io = _capi.QaTscObsIo()
+        for name in _capi.TSC_OBS_IO_FIELDS:
+            setattr(io, name, members[name].data_ptr())
+        self._check(self.lib.qa_tsc_observations(C.byref(self._ocfg), C.byref(io), self._stream()), "qa_tsc_observations")
+        return self.obs_buf
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_observations_bbc(self):
+        return self.obs_bbc_buf
+
+    def get_observations_disc(self):
+        return self.obs_disc_buf
 
     def reset_idx(self, env_ids):
         """The goal / episode bookkeeping of the reference's reset_idx (:376, :396-404) and the re-gather of :272-273."""

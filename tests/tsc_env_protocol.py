@@ -151,3 +151,79 @@ def compare_goal_steps(results, fx, rtol=1e-5, atol=2e-6, exact_flags=True):
             np.testing.assert_allclose(res["episode_sums"][:, keep], fx[tag + "episode_sums"][:, keep], rtol=rtol, atol=atol, err_msg=tag + "sums")
             for k in ("cur_goals", "next_goals"):
                 np.testing.assert_array_equal(res[k][keep], fx[tag + k][keep], err_msg=tag + k)
+
+
+# ------------------------------------------------------------------------------------------------- observations
+OBS_STEPS = 3
+
+
+def obs_cfg(fx, n):
+    border, hs, vs, lin, ang, dp, dv, lin_d, ang_d, key, foot, clip = (float(v) for v in fx["obs_scalars"])
+    c = _capi.QaTscObsCfg()
+    c.num_envs, c.num_bodies = n, 19
+    for i, b in enumerate(fx["goal_feet"]):
+        c.key_bodies[i] = int(b)
+    c.map_rows, c.map_cols = fx["obs_height_samples"].shape
+    c.root_height_obs, c.action_stride = 1, 8 * 12
+    c.points_env_stride, c.point_stride = 132 * 3, 3                  # the reference's (N,132,3) tensor as it is
+    c.border_size, c.horizontal_scale, c.vertical_scale = border, hs, vs
+    c.lin_vel, c.ang_vel, c.dof_pos, c.dof_vel = lin, ang, dp, dv
+    c.lin_vel_dist, c.ang_vel_dist, c.key_pos, c.foot_contact, c.clip_observations = lin_d, ang_d, key, foot, clip
+    for i in range(12):
+        c.default_dof_pos[i] = float(fx["obs_default_dof_pos"][i])
+        c.default_dof_pos_all[i] = float(fx["obs_default_dof_pos_all"][i])
+    return c
+
+
+def run_observations(be, fx, reps=1, prepare_only=False):
+    """The fixture's 3 observation steps in sequence (history and yaw errors carried from step to step).  reps > 1 tiles the envs."""
+    tile = (lambda a: np.tile(a, (reps,) + (1,) * (a.ndim - 1))) if reps > 1 else (lambda a: a)
+    n = fx["obs_history0"].shape[0] * reps
+    cfg = obs_cfg(fx, n)
+    f = getattr(be.lib, be.prefix + "tsc_observations")
+    const = {k: be.put(v) for k, v in dict(
+        height_samples=fx["obs_height_samples"].astype(np.int16), height_points=tile(fx["obs_height_points"].astype(np.float32)),
+        mass_params=tile(fx["obs_mass_params"]), friction=tile(fx["obs_friction"]),
+        motor_strength=np.ascontiguousarray(np.tile(fx["obs_motor_strength"], (1, reps, 1))), commands=tile(fx["obs_commands"]),
+        latent_eps=tile(fx["obs_latent_eps"]), latent_c=tile(fx["obs_latent_c"])).items()}
+    state = {k: be.put(v) for k, v in dict(obs_history=tile(fx["obs_history0"]), delta_yaw=np.zeros(n, np.float32),
+                                           delta_next_yaw=np.zeros(n, np.float32)).items()}
+    outs = {k: be.put(np.zeros((n, w), np.float32)) for k, w in dict(measured_heights=132, obs_buf=800, obs_bbc_buf=671, obs_disc_buf=49).items()}
+    if prepare_only:
+        return cfg, const, state, outs, tile
+    results = []
+    for t in range(OBS_STEPS):
+        io, dev = obs_io(be, fx, cfg, const, state, outs, t, tile)
+        assert f(C.byref(cfg), C.byref(io), be.stream) == 0
+        results.append({k: be.get(dev[k]) for k in ("measured_heights", "obs_buf", "obs_bbc_buf", "obs_disc_buf", "obs_history", "delta_yaw",
+                                                     "delta_next_yaw")})
+    return results
+
+
+def obs_io(be, fx, cfg, const, state, outs, t, tile):
+    """qa_tsc_obs_io for fixture step t (sets cfg.update_yaw); returns it with the dict that keeps the buffers alive"""
+    tag = f"obs_t{t}_"
+    dev = dict(const); dev.update(state); dev.update(outs)
+    for k in ("root_states", "rpy", "base_lin_vel", "base_ang_vel", "contact_filt", "dof_pos", "dof_vel", "rigid_body_states", "target_yaw",
+              "next_target_yaw"):
+        dev[k] = be.put(tile(fx[tag + k]))
+    dev["cur_obstacle_type"] = be.put(tile(fx[tag + "cur_obstacle_type"].astype(np.int64)))
+    dev["episode_length"] = be.put(tile(fx[tag + "episode_length"].astype(np.int64)))
+    dev["_action_history"] = be.put(tile(fx[tag + "action_history"]))     # (N,8,12); the kernel reads the last slot through the stride
+    cfg.update_yaw = int(fx[tag + "update_yaw"])
+    io = _capi.QaTscObsIo()
+    for name in _capi.TSC_OBS_IO_FIELDS:
+        if name != "last_action":
+            setattr(io, name, be.ptr(dev[name]))
+    io.last_action = be.ptr(dev["_action_history"]) + 7 * 12 * 4
+    return io, dev
+
+
+def compare_observations(results, fx, rtol=1e-5, atol=2e-6):
+    for t, res in enumerate(results):
+        tag = f"obs_t{t}_"
+        np.testing.assert_array_equal(res["measured_heights"], fx[tag + "measured_heights"], err_msg=tag + "heights")   # integer cells x scale
+        for k in ("delta_yaw", "delta_next_yaw", "obs_buf", "obs_bbc_buf", "obs_disc_buf"):
+            np.testing.assert_allclose(res[k], fx[tag + k], rtol=rtol, atol=atol, err_msg=tag + k)
+        np.testing.assert_allclose(res["obs_history"], fx[tag + "obs_history"].reshape(res["obs_history"].shape), rtol=rtol, atol=atol,
+                                   err_msg=tag + "history")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tests/golden/tsc_env.npz: the reference's task-level env math run here on CPU -- LeggedRobot.set_commands
-(tsc/legged_gym/envs/base/legged_robot.py:699-760) and the goal / termination / reward part of post_physics_step (:226-273)
--- on a LeggedRobot built without Isaac Gym (object.__new__ + synthetic tensors), with the callbacks that need the simulator
+(tsc/legged_gym/envs/base/legged_robot.py:699-760) the goal / termination / reward part of post_physics_step (:226-273), and _get_heights (:1708-1755) +
+compute_observations (:432-515) -- on a LeggedRobot built without Isaac Gym (object.__new__ + synthetic tensors), with the callbacks that need the simulator
 (_post_physics_step_callback, everything of reset_idx but its goal/episode bookkeeping, get_observations_disc, update_depth_buffer, compute_observations, the gym refreshes) stubbed out.
 Build container only (needs /root/reference).  The uniform action noise set_commands draws with torch's generator is
 replaced by values stored in the fixture (torch_rand_float is patched), everything else is the reference's own arithmetic."""
@@ -36,7 +36,7 @@ from legged_gym.utils.helpers import class_to_dict                              
 os.chdir(cwd)
 
 BODY_NAMES = ["base", "Head_upper", "Head_lower"] + [f"{l}_{p}" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf", "foot")]
-N, STEPS = 128, 4
+N, STEPS = 64, 4
 rng = np.random.default_rng(20250404)
 T = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt)          # noqa: E731
 
@@ -199,6 +199,75 @@ def main():
                 rew_buf=env.rew_buf.numpy().copy(),
                 episode_sums=np.stack([env.episode_sums[n].numpy() for n in env.reward_names + ["termination"]]),
                 cur_goals=env.cur_goals.numpy().copy(), next_goals=env.next_goals.numpy().copy()).items()})
+
+    # ---------------------------------------------------------------- _get_heights + compute_observations
+    del env.compute_observations                      # back to the reference's own method
+    env.obs_scales = cfg.normalization.obs_scales
+    env.obstacle.proportions = list(range(6))
+    env.obstacle.cfg = cfg.obstacle
+    rows_h, cols_h = 320, 240
+    hs = (rng.integers(0, 3, (rows_h, cols_h)) * rng.integers(0, 120, (rows_h, cols_h))).astype(np.int16)     # sparse boxes up to 0.6 m
+    hs[100:140, :] = 60
+    env.height_samples = T(hs, torch.int16)
+    ref_lr.torch_rand_float = lambda lo, hi, shape, device=None: torch.zeros(shape)
+    env.height_points = env._init_height_points()
+    env.key_body_ids = env.feet_indices
+    default = np.array([0.1, 0.8, -1.5, -0.1, 0.8, -1.5, 0.1, 1.0, -1.5, -0.1, 1.0, -1.5], np.float32)
+    env.default_dof_pos = T(default[None])
+    env.default_dof_pos_all = T(default[None] + 0.01)
+    env.mass_params_tensor = T(rng.uniform(-1, 1, (N, 4)).astype(np.float32))
+    env.friction_coeffs_tensor = T(rng.uniform(0.6, 2.0, (N, 1)).astype(np.float32))
+    env.motor_strength = T(rng.uniform(0.8, 1.2, (2, N, 12)).astype(np.float32))
+    env.obs_history_buf = T(rng.normal(0, 1, (N, 10, 57)).astype(np.float32))
+    env.contact_buf = torch.zeros(N, cfg.env.contact_buf_len, 4)
+    env.commands = T(rng.uniform(-1, 1, (N, 5)).astype(np.float32))
+    env.latent_eps = T(rng.uniform(-1, 1, (N, 1)).astype(np.float32))
+    env.latent_c = T(np.eye(5, dtype=np.float32)[rng.integers(0, 5, N)])
+    env.delta_yaw, env.delta_next_yaw = torch.zeros(N), torch.zeros(N)
+    cfg.depth.update_interval = 2                     # so that one of the steps carries the yaw errors over
+    out.update(obs_height_samples=hs, obs_height_points=env.height_points.numpy().copy(), obs_default_dof_pos=default,
+               obs_default_dof_pos_all=default + np.float32(0.01), obs_mass_params=env.mass_params_tensor.numpy(),
+               obs_friction=env.friction_coeffs_tensor.numpy(), obs_motor_strength=env.motor_strength.numpy(),
+               obs_history0=env.obs_history_buf.numpy().copy(), obs_commands=env.commands.numpy(), obs_latent_eps=env.latent_eps.numpy(),
+               obs_latent_c=env.latent_c.numpy(),
+               obs_scalars=np.array([cfg.obstacle.border_size, cfg.obstacle.horizontal_scale, cfg.obstacle.vertical_scale,
+                                     env.obs_scales.lin_vel, env.obs_scales.ang_vel, env.obs_scales.dof_pos, env.obs_scales.dof_vel,
+                                     0.7, 0.3, 1.5, 2.0,          # the four discriminator scales are 0 in the config: exercised non-zero
+                                     cfg.normalization.clip_observations], np.float64))
+    env.obs_scales.lin_vel_dist, env.obs_scales.ang_vel_dist, env.obs_scales.key_pos, env.obs_scales.foot_contact = 0.7, 0.3, 1.5, 2.0
+    for t in range(3):
+        root = np.zeros((N, 13), np.float32)
+        root[:, 0] = rng.uniform(-4.0, 10.0, N); root[:, 1] = rng.uniform(-4.0, 6.0, N); root[:, 2] = rng.uniform(0.2, 1.4, N)
+        root[:, 3:7] = random_quats(N)
+        env.root_states = T(root)
+        env.base_quat = env.root_states[:, 3:7]
+        env.roll, env.pitch, env.yaw = ref_lr.euler_from_quaternion(env.base_quat)
+        env.base_lin_vel, env.base_ang_vel = T(rng.normal(0, 1, (N, 3)).astype(np.float32)), T(rng.normal(0, 1, (N, 3)).astype(np.float32))
+        if t == 2:
+            env.base_lin_vel[:4] *= 150.0             # past the +-100 clip
+        env.contact_filt = T(rng.random((N, 4)) < 0.5, torch.bool)
+        env.dof_pos, env.dof_vel = T(default[None] + rng.normal(0, 0.3, (N, 12)).astype(np.float32)), T(rng.normal(0, 3, (N, 12)).astype(np.float32))
+        env.action_history_buf = T(rng.normal(0, 1, (N, 8, 12)).astype(np.float32))
+        rb = np.zeros((N, 19, 13), np.float32); rb[:, :, :3] = root[:, None, :3] + rng.uniform(-0.4, 0.4, (N, 19, 3))
+        env.rigid_body_states = T(rb); env.rigid_body_pos = env.rigid_body_states[:, :, :3]
+        env.cur_obstacle_types = T(rng.integers(0, 6, N), torch.long)
+        env.target_yaw, env.next_target_yaw = T(rng.uniform(-np.pi, np.pi, N).astype(np.float32)), T(rng.uniform(-np.pi, np.pi, N).astype(np.float32))
+        env.episode_length_buf = T(rng.integers(0, 6, N), torch.long)
+        env.global_counter = t                        # with update_interval 2: steps 0 and 2 recompute the yaw errors, step 1 carries them over
+        env.measured_heights = env._get_heights()     # what _post_physics_step_callback does when measure_heights is set
+        env.compute_observations()
+        tag = f"obs_t{t}_"
+        out.update({tag + k: v for k, v in dict(
+            root_states=root, rpy=torch.stack([env.roll, env.pitch, env.yaw], 1).numpy(), base_lin_vel=env.base_lin_vel.numpy().copy(),
+            base_ang_vel=env.base_ang_vel.numpy().copy(), contact_filt=env.contact_filt.numpy().astype(np.uint8), dof_pos=env.dof_pos.numpy(),
+            dof_vel=env.dof_vel.numpy(), action_history=env.action_history_buf.numpy(), rigid_body_states=rb,
+            cur_obstacle_type=env.cur_obstacle_types.numpy(), target_yaw=env.target_yaw.numpy(), next_target_yaw=env.next_target_yaw.numpy(),
+            episode_length=env.episode_length_buf.numpy(), update_yaw=np.int32(env.global_counter % cfg.depth.update_interval == 0),
+            measured_heights=env.measured_heights.numpy().copy(), delta_yaw=env.delta_yaw.numpy().copy(),
+            delta_next_yaw=env.delta_next_yaw.numpy().copy(), obs_buf=env.obs_buf.numpy().copy(), obs_bbc_buf=env.obs_bbc_buf.numpy().copy(),
+            obs_disc_buf=env.obs_disc_buf.numpy().copy(), obs_history=env.obs_history_buf.numpy().copy()).items()})
+    print("obs", out["obs_t0_obs_buf"].shape, out["obs_t0_obs_bbc_buf"].shape, out["obs_t0_obs_disc_buf"].shape,
+          "scan hits", int((out["obs_t0_measured_heights"] > 0).sum()), "first-step envs", int((out["obs_t0_episode_length"] <= 1).sum()))
     path = os.path.join(ROOT, "tests", "golden", "tsc_env.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes,", len(out), "arrays; reward order", list(out["goal_reward_names"]))

@@ -58,6 +58,11 @@ mi = np.ascontiguousarray(fx["cmd_mocap_index"], np.int32)
 vr, jr, hr = (np.ascontiguousarray(fx[k], np.float32) for k in ("cmd_vel_ranges", "cmd_jump_range", "cmd_height_range"))
 t_cmd = timeit(lambda: lib.qa_tsc_set_commands(acts.data_ptr(), ep.data_ptr(), N, 3, 6, 5, 1, mi.ctypes.data, vr.ctypes.data, jr.ctypes.data,
                                                hr.ctypes.data, noise.data_ptr(), cmd.data_ptr(), eps.data_ptr(), lc.data_ptr(), nxt.data_ptr(), st))
-print(json.dumps({"num_envs": N, "qa_tsc_goal_step_us": round(t_goal, 2), "goal_step_bytes_per_launch": int(bytes_goal),
+ocfg, const, state, outs, otile = proto.run_observations(be, fx, reps=reps, prepare_only=True)
+oio, okeep = proto.obs_io(be, fx, ocfg, const, state, outs, 2, otile)
+t_obs = timeit(lambda: lib.qa_tsc_observations(C.byref(ocfg), C.byref(oio), st))
+obs_bytes = N * 4 * ((800 + 671 + 49 + 570 + 132) + (570 + 13 + 9 + 1 + 36 + 4 * 3 + 29 + 11 + 4 + 2))      # written + read per env (scan gathers apart)
+print(json.dumps({"num_envs": N, "qa_tsc_observations_us": round(t_obs, 2), "observations_algorithmic_bytes_per_launch": obs_bytes,
+                  "observations_GBps": round(obs_bytes / t_obs / 1e3, 1), "observations_frac_of_8TBps": round(obs_bytes / t_obs / 1e3 / 8000, 3), "qa_tsc_goal_step_us": round(t_goal, 2), "goal_step_bytes_per_launch": int(bytes_goal),
                   "goal_step_GBps": round(bytes_goal / t_goal / 1e3, 1), "qa_tsc_set_commands_us": round(t_cmd, 2),
                   "note": "launch-to-launch time of back-to-back launches from the host (includes launch overhead)"}))
