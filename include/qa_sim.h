@@ -440,7 +440,7 @@ int qa_tsc_set_commands(const float *actions, const int64_t *episode_length, int
 #define QA_TSC_MAX_BODY_IDS 24
 typedef struct qa_tsc_goal_cfg {
     int64_t num_envs;
-    int32_t num_bodies;                 /* rows of contact_forces / rigid_body_states per env */
+    int32_t num_bodies;                 /* rows of contact_forces / rigid_body_states per env, <= 32; body lists hold each body once */
     int32_t num_goal_slots;             /* env_goals.size(1), the repeated last goal included */
     int32_t last_goal_repeat, goals_per_obstacle, num_obstacles;
     int32_t history_len, history_width; /* action_hl_history (N, history_len, history_width); history_len >= 3 */

@@ -91,7 +91,13 @@ __device__ inline float floor_mod(float a, float b) {
     return r;
 }
 
-__global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal_cfg c, qa_tsc_goal_io io) {
+// (Staging the 64 envs' array-of-structure records -- root state, contact forces, task-action history -- through LDS with
+// coalesced loads was measured and is SLOWER here: 17.9 us against 12.5 us at 8192 envs.  With one wavefront per CU nothing
+// hides the extra load -> LDS -> barrier round trips, while the direct per-thread loads are all issued up front.)
+// term_mask / pen_mask: bit b set = body b is in the termination / penalised list.  Every body's contact-force norm is taken
+// once in a branch-free loop (independent loads, one exposed round trip) and the lists become bit tests; a loop over each
+// list with `||` short-circuits costs one dependent round trip per listed body (11 + 15 of them for the Go2).
+__global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal_cfg c, qa_tsc_goal_io io, uint32_t term_mask, uint32_t pen_mask) {
     const int64_t e = (int64_t)blockIdx.x * TSC_BLOCK + threadIdx.x;
     if (e >= c.num_envs) return;
     const int64_t N = c.num_envs;
@@ -117,11 +123,17 @@ __global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal
     }
     io.rpy[e * 3 + 0] = roll; io.rpy[e * 3 + 1] = pitch; io.rpy[e * 3 + 2] = yaw;
 
+    // contact-force norms of all bodies, as three threshold bit sets
+    uint32_t over01 = 0, over1 = 0, over2 = 0;
+    for (int b = 0; b < c.num_bodies; ++b) {
+        const float f = norm3(cf + b * 3);
+        over01 |= (uint32_t)(f > 0.1f) << b; over1 |= (uint32_t)(f > 1.0f) << b; over2 |= (uint32_t)(f > 2.0f) << b;
+    }
     // filtered foot contacts
     bool filt[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const bool now = norm3(cf + c.feet_bodies[f] * 3) > 2.0f;
+        const bool now = (over2 >> c.feet_bodies[f]) & 1u;
         filt[f] = now || io.last_contacts[e * 4 + f] != 0;
         io.last_contacts[e * 4 + f] = now;
         io.contact_filt[e * 4 + f] = filt[f];
@@ -161,8 +173,7 @@ __global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal
     io.cur_obstacle_type[e] = otype;
 
     // termination
-    bool reset = false;
-    for (int k = 0; k < c.num_termination_bodies; ++k) reset = reset || norm3(cf + c.termination_bodies[k] * 3) > 1.0f;
+    bool reset = (over1 & term_mask) != 0;
     const bool goal_cut = gi >= (int64_t)(c.num_goal_slots - c.last_goal_repeat);
     const bool time_out = ((float)ep_len > c.max_episode_length) || goal_cut;
     reset = reset || time_out || fabsf(roll) > 1.5f || fabsf(pitch) > 1.5f || rs[2] < -0.25f || leave;
@@ -187,9 +198,7 @@ __global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal
         term[QA_TSC_REW_ACTION_HL_RATE] = 0.0f;
         term[QA_TSC_REW_LATENT_C_RATE] = 0.0f;
     }
-    int hits = 0;
-    for (int k = 0; k < c.num_penalised_bodies; ++k) hits += norm3(cf + c.penalised_bodies[k] * 3) > 0.1f;
-    term[QA_TSC_REW_COLLISION] = (float)hits;
+    term[QA_TSC_REW_COLLISION] = (float)__popc(over01 & pen_mask);
     int edge = 0;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -198,7 +207,8 @@ __global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal
         int64_t iy = (int64_t)rintf((fp[1] + c.border_size) / c.horizontal_scale);
         ix = ix < 0 ? 0 : (ix > c.mask_rows - 1 ? c.mask_rows - 1 : ix);
         iy = iy < 0 ? 0 : (iy > c.mask_cols - 1 ? c.mask_cols - 1 : iy);
-        edge += (filt[f] && io.x_edge_mask[ix * c.mask_cols + iy] != 0) ? 1 : 0;
+        const uint8_t at_edge = io.x_edge_mask[ix * c.mask_cols + iy];           // unconditional: no load behind a branch
+        edge += (int)filt[f] & (int)(at_edge != 0);
     }
     term[QA_TSC_REW_FEET_EDGE] = (float)edge;
     term[QA_TSC_REW_REACH_GOAL] = reached ? 1.0f : 0.0f;
@@ -235,128 +245,188 @@ __global__ void __launch_bounds__(TSC_BLOCK) qa_tsc_goal_step_kernel(qa_tsc_goal
 // (segments filled by the lanes that own them, the 570-float history streamed in), then the three observation rows and
 // the pushed history go out as contiguous, lane-strided stores: 8.4 KB written and 2.9 KB read per env, HBM-bound.
 constexpr int OBS_WAVES = 4;
-constexpr int OBS_ROW = QA_TSC_NUM_OBS + 11;            // the 800 row + [commands, latent_eps, latent_c]
+constexpr int OBS_ROW = QA_TSC_NUM_OBS + 12;            // the 800 row + [commands, latent_eps, latent_c] + 1 pad (16-byte rows)
 constexpr int OFF_YAW = 57, OFF_TYPE = 59, OFF_SCAN = 65, OFF_PRIV = 197, OFF_LATENT = 201, OFF_HIST = 230, OFF_CMD = 800;
 
 __device__ inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
 __global__ void __launch_bounds__(64 * OBS_WAVES) qa_tsc_observations_kernel(qa_tsc_obs_cfg c, qa_tsc_obs_io io) {
-    __shared__ float s_row[OBS_WAVES][OBS_ROW];
+    // A wavefront's lifetime is a chain of memory latencies, so the code is written load-first: every lane picks its source
+    // ADDRESS with selects, all loads of a phase are issued back to back with no branch between them, and only then do the
+    // values go through the (select-based) arithmetic into LDS.  A load inside each arm of an if-chain costs one exposed
+    // round trip per arm (the first version: ~40 of them, 37.7 us per 8192-env launch).
+    __shared__ __align__(16) float s_row[OBS_WAVES][OBS_ROW];
     __shared__ float s_meas[OBS_WAVES][QA_TSC_NUM_SCAN];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t e = (int64_t)blockIdx.x * OBS_WAVES + wave;
-    const bool valid = e < c.num_envs;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t N = c.num_envs;
+    const int64_t e_raw = (int64_t)blockIdx.x * OBS_WAVES + wave;
+    const bool valid = e_raw < N;
+    const int64_t e = valid ? e_raw : N - 1;          // a ragged tail recomputes the last env and stores nothing
     float *row = s_row[wave], *meas = s_meas[wave];
-    const float *rs = io.root_states + (valid ? e : 0) * 13;
-    const float rz = rs[2];
+    const float *rs = io.root_states + e * 13;
     const float PI_F = 3.14159265358979323846f;
-    if (valid) {
-        // proprio: each lane owns one of the 57 entries
-        if (lane < QA_TSC_NUM_PROPRIO) {
-            float v;
-            if (lane < 2) v = io.rpy[e * 3 + lane];
-            else if (lane < 5) v = io.base_ang_vel[e * 3 + lane - 2] * c.ang_vel;
-            else if (lane < 17) v = (io.dof_pos[e * 12 + lane - 5] - c.default_dof_pos_all[lane - 5]) * c.dof_pos;
-            else if (lane < 29) v = io.dof_vel[e * 12 + lane - 17] * c.dof_vel;
-            else if (lane < 41) v = io.last_action[e * c.action_stride + lane - 29];
-            else if (lane < 45) v = (io.contact_filt[e * 4 + lane - 41] ? 1.0f : 0.0f) - 0.5f;
-            else v = 0.0f;
-            row[lane] = v;
-        }
-        if (lane < 2) {          // delta yaws, wrapped to [-pi, pi)
-            float *keep = lane == 0 ? io.delta_yaw : io.delta_next_yaw;
-            float d = keep[e];
-            if (c.update_yaw) {
-                const float t = (lane == 0 ? io.target_yaw : io.next_target_yaw)[e];
-                d = floor_mod((t - io.rpy[e * 3 + 2]) + PI_F, 2.0f * PI_F) - PI_F;
-                keep[e] = d;
-            }
-            row[OFF_YAW + lane] = d;
-        }
-        if (lane < QA_TSC_NUM_OBSTACLE_CLASSES) row[OFF_TYPE + lane] = io.cur_obstacle_type[e] == lane ? 1.0f : 0.0f;
-        // scan: yaw-only rotation of the body-frame grid (quat_apply of the normalised (0,0,z,w)), truncation to the cell, min of 3
-        {
-            const float qz0 = rs[5], qw0 = rs[6];
-            const float qn = fmaxf(sqrtf(qz0 * qz0 + qw0 * qw0), 1e-9f);
-            const float qz = qz0 / qn, qw = qw0 / qn;
-            for (int p = lane; p < QA_TSC_NUM_SCAN; p += 64) {
-                const float *hp = io.height_points + e * c.points_env_stride + p * c.point_stride;
-                const float bx = hp[0], by = hp[1];
-                const float t0 = (0.0f - qz * by) * 2.0f, t1 = (qz * bx - 0.0f) * 2.0f;
-                const float wx = (bx + qw * t0) + (0.0f - qz * t1) + rs[0];
-                const float wy = (by + qw * t1) + (qz * t0 - 0.0f) + rs[1];
-                int64_t px = (int64_t)((wx + c.border_size) / c.horizontal_scale);
-                int64_t py = (int64_t)((wy + c.border_size) / c.horizontal_scale);
-                px = px < 0 ? 0 : (px > c.map_rows - 2 ? c.map_rows - 2 : px);
-                py = py < 0 ? 0 : (py > c.map_cols - 2 ? c.map_cols - 2 : py);
-                const int16_t h1 = io.height_samples[px * c.map_cols + py], h2 = io.height_samples[(px + 1) * c.map_cols + py],
-                              h3 = io.height_samples[px * c.map_cols + py + 1];
-                const int16_t hm = h1 < h2 ? (h1 < h3 ? h1 : h3) : (h2 < h3 ? h2 : h3);
-                const float h = (float)hm * c.vertical_scale;
-                meas[p] = h;
-                io.measured_heights[e * QA_TSC_NUM_SCAN + p] = h;
-                row[OFF_SCAN + p] = clampf((rz - 0.3f) - h, -1.0f, 1.0f);
-            }
-        }
-        if (lane < 3) row[OFF_PRIV + 1 + lane] = io.base_lin_vel[e * 3 + lane] * c.lin_vel;
-        if (lane < 29) {
-            float v;
-            if (lane < 4) v = io.mass_params[e * 4 + lane];
-            else if (lane < 5) v = io.friction[e];
-            else if (lane < 17) v = io.motor_strength[e * 12 + lane - 5] - 1.0f;
-            else v = io.motor_strength[(N + e) * 12 + lane - 17] - 1.0f;
-            row[OFF_LATENT + lane] = v;
-        }
-        for (int i = lane; i < QA_TSC_HISTORY_LEN * QA_TSC_NUM_PROPRIO; i += 64) row[OFF_HIST + i] = io.obs_history[e * 570 + i];
-        if (lane < 5) row[OFF_CMD + lane] = io.commands[e * 5 + lane];
-        else if (lane == 5) row[OFF_CMD + 5] = io.latent_eps[e];
-        else if (lane < 11) row[OFF_CMD + lane] = io.latent_c[e * 5 + lane - 6];
+
+    // ---- phase A loads
+    const float r0 = rs[0], r1 = rs[1], rz = rs[2], q0 = rs[3], q1 = rs[4], q2 = rs[5], q3 = rs[6];
+    // proprio: one float source per lane (< 41), value = (x - sub) * mul
+    const float *psrc = io.rpy + e * 3 + (lane < 2 ? lane : 0);
+    float psub = 0.0f, pmul = 1.0f;
+    const float dall = c.default_dof_pos_all[lane >= 5 && lane < 17 ? lane - 5 : 0];
+    if (lane >= 2 && lane < 5) { psrc = io.base_ang_vel + e * 3 + (lane - 2); pmul = c.ang_vel; }
+    if (lane >= 5 && lane < 17) { psrc = io.dof_pos + e * 12 + (lane - 5); psub = dall; pmul = c.dof_pos; }
+    if (lane >= 17 && lane < 29) { psrc = io.dof_vel + e * 12 + (lane - 17); pmul = c.dof_vel; }
+    if (lane >= 29 && lane < 41) psrc = io.last_action + e * c.action_stride + (lane - 29);
+    const float px_ = *psrc;
+    const uint8_t pcf2 = io.contact_filt[e * 4 + ((lane + 3) & 3)];      // lanes 41..44 read foot (lane - 41) = (lane + 3) & 3
+    // yaw errors (lanes 0, 1)
+    float *ykeep = (lane & 1) ? io.delta_next_yaw : io.delta_yaw;
+    const float yold = ykeep[e];
+    const float ytarget = ((lane & 1) ? io.next_target_yaw : io.target_yaw)[e];
+    const float yaw = io.rpy[e * 3 + 2];
+    const int64_t otype = io.cur_obstacle_type[e];
+    // scan points: 3 per lane (132 = 64 + 64 + 4), addresses clamped, stores predicated
+    float hbx[3], hby[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = lane + 64 * k < QA_TSC_NUM_SCAN ? lane + 64 * k : QA_TSC_NUM_SCAN - 1;
+        const float *hp = io.height_points + e * c.points_env_stride + p * c.point_stride;
+        hbx[k] = hp[0]; hby[k] = hp[1];
     }
-    __syncthreads();
-    if (valid) {
-        const float root_h = rz - meas[QA_TSC_NUM_SCAN / 2 + 1];
-        if (lane == 0) row[OFF_PRIV] = c.root_height_obs ? root_h : 0.0f;
-        if (lane < QA_TSC_NUM_OBS_DISC) {       // the imitation discriminator's view
-            float v;
-            if (lane < 2) v = io.rpy[e * 3 + lane];
-            else if (lane < 3) v = root_h;
-            else if (lane < 6) v = io.base_lin_vel[e * 3 + lane - 3] * c.lin_vel_dist;
-            else if (lane < 9) v = io.base_ang_vel[e * 3 + lane - 6] * c.ang_vel_dist;
-            else if (lane < 21) v = (io.dof_pos[e * 12 + lane - 9] - c.default_dof_pos[lane - 9]) * c.dof_pos;
-            else if (lane < 33) v = io.dof_vel[e * 12 + lane - 21] * c.dof_vel;
-            else if (lane < 45) {
-                // key body (lane-33)/3 relative to the root, rotated by the inverse heading (compute_flat_key_pos)
-                const int kb = (lane - 33) / 3, ax = (lane - 33) % 3;
-                const float q[4] = {rs[3], rs[4], rs[5], rs[6]};
-                const float s = 2.0f * q[3] * q[3] - 1.0f;                 // heading = atan2 of the rotated x axis (quat_rotate)
-                const float hx = s + q[0] * q[0] * 2.0f, hy = q[2] * q[3] * 2.0f + q[1] * q[0] * 2.0f;
-                const float half = -atan2f(hy, hx) / 2.0f;
-                float hz = sinf(half), hw = cosf(half);
-                const float hn = fmaxf(sqrtf(hz * hz + hw * hw), 1e-9f);
-                hz /= hn; hw /= hn;
-                const float *bp = io.rigid_body_states + (e * c.num_bodies + c.key_bodies[kb]) * 13;
-                const float lx = bp[0] - rs[0], ly = bp[1] - rs[1], lz = bp[2] - rs[2];
-                const float s2 = 2.0f * hw * hw - 1.0f;
-                const float r[3] = {lx * s2 + (0.0f - hz * ly) * hw * 2.0f, ly * s2 + (hz * lx - 0.0f) * hw * 2.0f, lz * s2 + hz * (hz * lz) * 2.0f};
-                v = r[ax] * c.key_pos;
-            } else v = (io.contact_filt[e * 4 + lane - 45] ? 1.0f : 0.0f) * c.foot_contact;
-            io.obs_disc_buf[e * QA_TSC_NUM_OBS_DISC + lane] = v;
+    const float plin = io.base_lin_vel[e * 3 + (lane < 3 ? lane : 0)];
+    // privileged latent (lanes < 29): value = x - sub
+    const float *lsrc = io.mass_params + e * 4 + (lane < 4 ? lane : 0);
+    if (lane == 4) lsrc = io.friction + e;
+    if (lane >= 5 && lane < 17) lsrc = io.motor_strength + e * 12 + (lane - 5);
+    if (lane >= 17 && lane < 29) lsrc = io.motor_strength + (N + e) * 12 + (lane - 17);
+    const float lx_ = *lsrc;
+    // commands block (lanes < 11)
+    const float *csrc = io.commands + e * 5 + (lane < 5 ? lane : 0);
+    if (lane == 5) csrc = io.latent_eps + e;
+    if (lane >= 6 && lane < 11) csrc = io.latent_c + e * 5 + (lane - 6);
+    const float cx_ = *csrc;
+    // the history before this step's push: 285 8-byte words, 5 per lane
+    float2 hv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = lane + 64 * k < 285 ? lane + 64 * k : 284;
+        hv[k] = reinterpret_cast<const float2 *>(io.obs_history + e * 570)[i];
+    }
+    const int64_t ep_len = io.episode_length[e];
+    // discriminator row sources (lanes < 49), used in phase B but loaded here
+    const float *dsrc = io.rpy + e * 3 + (lane < 2 ? lane : 0);
+    float dsub = 0.0f, dmul = 1.0f;
+    const float dd = c.default_dof_pos[lane >= 9 && lane < 21 ? lane - 9 : 0];
+    if (lane >= 3 && lane < 6) { dsrc = io.base_lin_vel + e * 3 + (lane - 3); dmul = c.lin_vel_dist; }
+    if (lane >= 6 && lane < 9) { dsrc = io.base_ang_vel + e * 3 + (lane - 6); dmul = c.ang_vel_dist; }
+    if (lane >= 9 && lane < 21) { dsrc = io.dof_pos + e * 12 + (lane - 9); dsub = dd; dmul = c.dof_pos; }
+    if (lane >= 21 && lane < 33) { dsrc = io.dof_vel + e * 12 + (lane - 21); dmul = c.dof_vel; }
+    const float dx_ = *dsrc;
+    const int kl = lane >= 33 && lane < 45 ? lane - 33 : 0;
+    const int kb = kl / 3, kax = kl - kb * 3;
+    const float *bp = io.rigid_body_states + (e * c.num_bodies + c.key_bodies[kb]) * 13;
+    const float b0 = bp[0], b1 = bp[1], b2 = bp[2];
+    const uint8_t dcf = io.contact_filt[e * 4 + ((lane + 3) & 3)];      // lanes 45..48 read foot (lane - 45) = (lane + 3) & 3
+
+    // ---- scan gathers (depend on the points only)
+    const float qn = fmaxf(sqrtf(q2 * q2 + q3 * q3), 1e-9f);
+    const float qz = q2 / qn, qw = q3 / qn;
+    int16_t g1[3], g2[3], g3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float bx = hbx[k], by = hby[k];
+        const float t0 = (0.0f - qz * by) * 2.0f, t1 = (qz * bx - 0.0f) * 2.0f;
+        const float wx = (bx + qw * t0) + (0.0f - qz * t1) + r0;
+        const float wy = (by + qw * t1) + (qz * t0 - 0.0f) + r1;
+        int64_t px = (int64_t)((wx + c.border_size) / c.horizontal_scale);
+        int64_t py = (int64_t)((wy + c.border_size) / c.horizontal_scale);
+        px = px < 0 ? 0 : (px > c.map_rows - 2 ? c.map_rows - 2 : px);
+        py = py < 0 ? 0 : (py > c.map_cols - 2 ? c.map_cols - 2 : py);
+        g1[k] = io.height_samples[px * c.map_cols + py];
+        g2[k] = io.height_samples[(px + 1) * c.map_cols + py];
+        g3[k] = io.height_samples[px * c.map_cols + py + 1];
+    }
+
+    // ---- phase A arithmetic into LDS
+    if (lane < QA_TSC_NUM_PROPRIO) {
+        const float v = lane < 41 ? (px_ - psub) * pmul : (lane < 45 ? (pcf2 ? 1.0f : 0.0f) - 0.5f : 0.0f);
+        row[lane] = v;
+    }
+    if (lane < 2) {
+        float d = yold;
+        if (c.update_yaw) {
+            d = floor_mod((ytarget - yaw) + PI_F, 2.0f * PI_F) - PI_F;
+            if (valid) ykeep[e] = d;
         }
+        row[OFF_YAW + lane] = d;
+    }
+    if (lane < QA_TSC_NUM_OBSTACLE_CLASSES) row[OFF_TYPE + lane] = otype == lane ? 1.0f : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = lane + 64 * k;
+        const int16_t hm = g1[k] < g2[k] ? (g1[k] < g3[k] ? g1[k] : g3[k]) : (g2[k] < g3[k] ? g2[k] : g3[k]);
+        const float h = (float)hm * c.vertical_scale;
+        if (p < QA_TSC_NUM_SCAN) {
+            meas[p] = h;
+            if (valid) io.measured_heights[e * QA_TSC_NUM_SCAN + p] = h;
+            row[OFF_SCAN + p] = clampf((rz - 0.3f) - h, -1.0f, 1.0f);
+        }
+    }
+    if (lane < 3) row[OFF_PRIV + 1 + lane] = plin * c.lin_vel;
+    if (lane < 29) row[OFF_LATENT + lane] = lx_ - (lane < 5 ? 0.0f : 1.0f);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (lane + 64 * k < 285) *reinterpret_cast<float2 *>(row + OFF_HIST + 2 * (lane + 64 * k)) = hv[k];
+    if (lane < 11) row[OFF_CMD + lane] = cx_;
+    __syncthreads();
+
+    // ---- phase B: what needs the scan's centre height
+    const float root_h = rz - meas[QA_TSC_NUM_SCAN / 2 + 1];
+    if (lane == 0) row[OFF_PRIV] = c.root_height_obs ? root_h : 0.0f;
+    if (lane < QA_TSC_NUM_OBS_DISC) {          // the imitation discriminator's view
+        float v = (dx_ - dsub) * dmul;
+        if (lane == 2) v = root_h;
+        if (lane >= 33 && lane < 45) {
+            // key body relative to the root, rotated by the inverse heading (compute_flat_key_pos)
+            const float s = 2.0f * q3 * q3 - 1.0f;                      // heading = atan2 of the rotated x axis (quat_rotate)
+            const float hx = s + q0 * q0 * 2.0f, hy = q2 * q3 * 2.0f + q1 * q0 * 2.0f;
+            const float half = -atan2f(hy, hx) / 2.0f;
+            float hz = sinf(half), hw = cosf(half);
+            const float hn = fmaxf(sqrtf(hz * hz + hw * hw), 1e-9f);
+            hz /= hn; hw /= hn;
+            const float lx = b0 - r0, ly = b1 - r1, lz = b2 - rz;
+            const float s2 = 2.0f * hw * hw - 1.0f;
+            const float rx = lx * s2 + (0.0f - hz * ly) * hw * 2.0f, ry = ly * s2 + (hz * lx - 0.0f) * hw * 2.0f, rzz = lz * s2 + hz * (hz * lz) * 2.0f;
+            v = (kax == 0 ? rx : (kax == 1 ? ry : rzz)) * c.key_pos;
+        }
+        if (lane >= 45) v = (dcf ? 1.0f : 0.0f) * c.foot_contact;
+        if (valid) io.obs_disc_buf[e * QA_TSC_NUM_OBS_DISC + lane] = v;
     }
     __syncthreads();
     if (!valid) return;
+
+    // ---- phase C: rows out
     const float cl = c.clip_observations;
-    for (int i = lane; i < QA_TSC_NUM_OBS; i += 64) io.obs_buf[e * QA_TSC_NUM_OBS + i] = clampf(row[i], -cl, cl);
+    for (int i = lane; i < QA_TSC_NUM_OBS / 4; i += 64) {      // 16-byte stores: 800 floats per env, rows 16-byte aligned
+        float4 v = reinterpret_cast<const float4 *>(row)[i];
+        v.x = clampf(v.x, -cl, cl); v.y = clampf(v.y, -cl, cl); v.z = clampf(v.z, -cl, cl); v.w = clampf(v.w, -cl, cl);
+        reinterpret_cast<float4 *>(io.obs_buf + e * QA_TSC_NUM_OBS)[i] = v;
+    }
     for (int i = lane; i < QA_TSC_NUM_OBS_BBC; i += 64) {
         const int src = i < 57 ? i : (i < 90 ? OFF_PRIV + (i - 57) : (i < 660 ? OFF_HIST + (i - 90) : OFF_CMD + (i - 660)));
         io.obs_bbc_buf[e * QA_TSC_NUM_OBS_BBC + i] = clampf(row[src], -cl, cl);
     }
-    const bool first = io.episode_length[e] <= 1;
-    for (int i = lane; i < 570; i += 64) {
-        const int slot = i / 57, j = i - slot * 57;
-        const float v = (first || slot == QA_TSC_HISTORY_LEN - 1) ? row[j] : row[OFF_HIST + i + 57];
-        io.obs_history[e * 570 + i] = clampf(v, -cl, cl);
+    const bool first = ep_len <= 1;
+    for (int i2 = lane; i2 < 285; i2 += 64) {
+        float2 v;
+        {
+            const int i = 2 * i2, slot = i / 57, j = i - slot * 57;
+            v.x = clampf((first || slot == QA_TSC_HISTORY_LEN - 1) ? row[j] : row[OFF_HIST + i + 57], -cl, cl);
+        }
+        {
+            const int i = 2 * i2 + 1, slot = i / 57, j = i - slot * 57;
+            v.y = clampf((first || slot == QA_TSC_HISTORY_LEN - 1) ? row[j] : row[OFF_HIST + i + 57], -cl, cl);
+        }
+        reinterpret_cast<float2 *>(io.obs_history + e * 570)[i2] = v;
     }
 }
 
@@ -399,7 +469,7 @@ int qa_tsc_goal_step(const qa_tsc_goal_cfg *cfg, const qa_tsc_goal_io *io, void 
     for (size_t i = 0; i < sizeof(need) / sizeof(need[0]); ++i)
         if (!need[i]) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: io pointer %zu is null", i); return QA_E_ARG; }
     const qa_tsc_goal_cfg &c = *cfg;
-    bool ok = c.num_envs > 0 && c.num_bodies > 0 && c.num_goal_slots > c.last_goal_repeat && c.last_goal_repeat >= 0 && c.goals_per_obstacle > 0 &&
+    bool ok = c.num_envs > 0 && c.num_bodies > 0 && c.num_bodies <= 32 && c.num_goal_slots > c.last_goal_repeat && c.last_goal_repeat >= 0 && c.goals_per_obstacle > 0 &&
               c.num_obstacles > 0 && c.mask_rows > 0 && c.mask_cols > 0 && c.horizontal_scale > 0.0f &&
               c.num_termination_bodies >= 0 && c.num_termination_bodies <= QA_TSC_MAX_BODY_IDS &&
               c.num_penalised_bodies >= 0 && c.num_penalised_bodies <= QA_TSC_MAX_BODY_IDS &&
@@ -408,7 +478,14 @@ int qa_tsc_goal_step(const qa_tsc_goal_cfg *cfg, const qa_tsc_goal_io *io, void 
     for (int k = 0; ok && k < c.num_penalised_bodies; ++k) ok = c.penalised_bodies[k] >= 0 && c.penalised_bodies[k] < c.num_bodies;
     for (int k = 0; ok && k < 4; ++k) ok = c.feet_bodies[k] >= 0 && c.feet_bodies[k] < c.num_bodies;
     if (!ok) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: inconsistent configuration"); return QA_E_ARG; }
-    hipLaunchKernelGGL(qa_tsc_goal_step_kernel, dim3((unsigned)((c.num_envs + TSC_BLOCK - 1) / TSC_BLOCK)), dim3(TSC_BLOCK), 0, (hipStream_t)stream, c, *io);
+    uint32_t term_mask = 0, pen_mask = 0;
+    for (int k = 0; k < c.num_termination_bodies; ++k) term_mask |= 1u << c.termination_bodies[k];
+    for (int k = 0; k < c.num_penalised_bodies; ++k) {
+        if (pen_mask & (1u << c.penalised_bodies[k])) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: body %d listed twice as penalised", c.penalised_bodies[k]); return QA_E_ARG; }
+        pen_mask |= 1u << c.penalised_bodies[k];
+    }
+    hipLaunchKernelGGL(qa_tsc_goal_step_kernel, dim3((unsigned)((c.num_envs + TSC_BLOCK - 1) / TSC_BLOCK)), dim3(TSC_BLOCK), 0, (hipStream_t)stream, c, *io,
+                       term_mask, pen_mask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_goal_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
