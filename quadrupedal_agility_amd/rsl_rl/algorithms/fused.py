@@ -583,7 +583,7 @@ class PolicyChain:
         return self
 
     @classmethod
-    def describe(cls, actor_critic, estimator, use_estimator, hist_encoding=False, with_critic=True):
+    def describe(cls, actor_critic, estimator, use_estimator, hist_encoding=False, with_critic=True, estimate_col=None):
         """-> PolicyChain, or None when the modules are not plain Linear/ELU stacks that fit the kernel's buffers.
         hist_encoding=True describes the variant whose latent comes from the history encoder (rollouts of every
         dagger_update_freq-th iteration, play.py, the exported policy): its per-frame Linear and its two Conv1d layers are
@@ -652,6 +652,13 @@ class PolicyChain:
 
         ok = True
         lat_col = n_prop + n_exp
+        # estimate_col: where the estimator's output is written in the OBSERVATION row (default: the explicit privileged columns
+        # right after proprio).  The task-level tree's act_bbc writes it at num_prop + num_scan of the 671-wide behaviour row
+        # (tsc/rsl_rl/algorithms/ppo.py:127-137), i.e. into the history block, and leaves the explicit columns as they came: the
+        # estimate then goes into the history window buffer before the history encoder reads it (and is moot without that encoder).
+        est_in_obs = use_estimator and estimate_col is not None and estimate_col != n_prop
+        if est_in_obs and not (hist0 <= estimate_col and estimate_col + n_exp <= cmd0):
+            return None
         if use_hist:        # first: it borrows buffer 3 (the actor-input buffer Z) for the first convolution's output
             he = ac.history_encoder
             convs = [m for m in he.conv_layers if isinstance(m, nn.Conv1d)]
@@ -682,13 +689,15 @@ class PolicyChain:
 
             rep = lambda b_, r: (lambda: b_.repeat(r))
             copy(0, hist0, 1, 0, T * n_prop)
+            if est_in_obs:
+                ok &= chain(stacks["est"], 0, 0, n_prop, ("buf", 1, estimate_col - hist0), {1}) and stacks["est"][-1][0].out_features == n_exp
             ok &= layer(1, 0, T * n_prop, 2, 0, T * C0, 1, 0, lambda: torch.block_diag(*([enc.weight] * T)).contiguous(), rep(enc.bias, T))
             ok &= layer(2, 0, T * C0, 3, 0, T1 * C1, 1, 0, conv_matrix(c1, T, T1), rep(c1.bias, T1))
             ok &= layer(3, 0, T1 * C1, 1, 0, T2 * C2, 1, 0, conv_matrix(c2, T1, T2), rep(c2.bias, T2))
             ok &= layer(1, 0, T2 * C2, Z, lat_col, n_lat, 1, 0,
                         lambda: outl.weight.view(n_lat, C2, T2).permute(0, 2, 1).reshape(n_lat, T2 * C2).contiguous(), outl.bias)
         copy(0, 0, Z, 0, n_prop)
-        if use_estimator:
+        if use_estimator and not est_in_obs:
             ok &= chain(stacks["est"], 0, 0, n_prop, ("buf", Z, n_prop), {Z}) and stacks["est"][-1][0].out_features == n_exp
         else:
             copy(0, n_prop, Z, n_prop, n_exp)

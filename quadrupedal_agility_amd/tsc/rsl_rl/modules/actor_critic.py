@@ -152,6 +152,8 @@ class ActorCriticBBC(nn.Module):
         self.train_with_estimated_latent = train_with_estimated_latent
         self.num_prop, self.num_explicit, self.num_latent = num_prop - num_auxiliary, num_explicit, num_latent
         self.num_hist, self.num_command = num_hist, num_command
+        a = self.num_prop; b = a + num_explicit; c = b + num_latent; d = c + num_hist * self.num_prop
+        self._sl = (slice(0, a), slice(a, b), slice(b, c), slice(c, d), slice(d, None))     # as the BBC tree's ActorCritic: PolicyChain.describe reads it
         if len(priv_encoder_dims) > 0:
             self.priv_encoder = _mlp([num_latent] + list(priv_encoder_dims) + [num_latent], act, last_act=True)
         else:
