@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 7
+#define QA_ABI_VERSION 8
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -103,7 +103,7 @@ enum qa_tensor {
     QA_T_BASE_INERTIA,        /* (N,10) base link incl. added mass: m, m*c (3), I about base
                                          origin xx yy zz xy xz yz, base frame                    */
     QA_T_PRIOR_PARAMETERS,    /* (5)    written by the learner (gail.py:463-464)                 */
-    QA_T_MOCAP_FRAMES,        /* (F,QA_MOCAP_FRAME) reset-state frames, see qa_set_mocap         */
+    QA_T_MOCAP_FRAMES,        /* (F,QA_MOCAP_FRAME) frames of the labelled mocap clips, see qa_set_mocap */
     QA_T_HEIGHT_SAMPLES,      /* (hf_rows, hf_cols) int16 terrain height samples (terrain_type 1), written by the caller
                                          after qa_create exactly like gym.add_heightfield's samples
                                          (legged_robot.py:958-975): height = sample * hf_vscale at
@@ -112,12 +112,21 @@ enum qa_tensor {
                                          sample the BBC env uses (root_h = z - measured_heights[:, 94], :264-268); 0 on a plane */
     QA_T_FOOT_IMPULSE,        /* (N,4,3) foot contact impulses (normal, tangent x, tangent y) of the last
                                          substep: warm start of the contact solver; zeroed on reset   */
+    QA_T_MOCAP_CLIPS,         /* (QA_MAX_MOCAP_CLIPS,QA_MOCAP_CLIP) float64 clip table of qa_set_mocap            */
+    QA_T_RIGID_BODY_STATE,    /* (N,19,13) pos3 quat4(xyzw) linvel3 angvel3 per body, world frame -- the reference's
+                                         rigid_body_state viewed as (N, num_bodies, 13) (legged_robot.py:759-768).
+                                         Written by step / simulate only when cfg.export_body_state != 0 (else one row) */
+    QA_T_STEP_TICKET,         /* (4) int32: arrival counter of qa_env_step_dev's last-workgroup step-counter update */
     QA_T_COUNT
 };
 
-enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3, QA_I16 = 4 };
+enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3, QA_I16 = 4, QA_F64 = 5 };
 
 #define QA_MOCAP_FRAME 37       /* root pos3, root quat4, joint pos12, lin vel3, ang vel3 (root frame), joint vel12 */
+#define QA_MAX_MOCAP_CLIPS 64
+#define QA_MOCAP_CLIP 8         /* first frame row, number of frames n, clip length (n-1) frame_duration [s], sampling range
+                                   length - (time_between_frames disc_obs_len + frame_duration) [s], cumulative sampling
+                                   probability inside the clip's gait (the last clip of a gait has 1), 3 unused */
 
 /* Plain-old-data configuration.  Field meanings follow the reference config classes
  * (bbc/legged_gym/envs/go2/go2_locomotion_config.py, envs/base/legged_robot_config.py). */
@@ -170,9 +179,10 @@ typedef struct qa_config {
     float hf_hscale, hf_vscale;     /* 0.1 m, 0.005 m */
     float hf_border;                /* border_size [m]: world x = row * hscale - border */
     float reset_xy_jitter;          /* custom_origins: default-pose resets add U(-j, j) to x and y (legged_robot.py:622-625) */
-    /* mocap reset table (reset_mode 1) */
+    /* mocap clips (reset_mode 1) */
     int32_t num_mocap_frames;       /* rows of QA_T_MOCAP_FRAMES */
-    int32_t mocap_clip_count[QA_NUM_GAITS];   /* unused when reset_mode == 0 */
+    int32_t export_body_state;      /* != 0: step / simulate also refresh QA_T_RIGID_BODY_STATE (N,19,13) */
+    int32_t reserved_cfg[4];
 } qa_config;
 
 typedef struct qa_sim qa_sim;
@@ -198,9 +208,9 @@ int qa_tensor_info(const qa_config *cfg, int which, int64_t *byte_offset, int64_
  * before this call (common_step_counter); it keys the RNG and triggers pushes. */
 int qa_env_step(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t global_step, void *stream);
 
-/* qa_env_step for recorded launches: the step counter is read from DEVICE memory (one int64) and incremented on the
- * stream right after the step, so a hipGraph holding N consecutive steps replays without host-side arguments
- * (the reference keeps `common_step_counter` on the host, legged_robot.py:134). */
+/* qa_env_step for recorded launches: the step counter is read from DEVICE memory (one int64) and incremented by the
+ * last workgroup of the step kernel to finish (arrival counter QA_T_STEP_TICKET), so a hipGraph holding N consecutive
+ * steps replays without host-side arguments (the reference keeps `common_step_counter` on the host, legged_robot.py:134). */
 int qa_env_step_dev(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t *step_counter_dev, void *stream);
 
 /* reset_idx(all) followed by nothing else (legged_robot.py:67-69).  The reference's reset()
@@ -210,14 +220,29 @@ int qa_reset_all(qa_sim *sim, int64_t global_step, void *stream);
 /* Seam-1 granular entry: one physics substep with caller-provided joint torques (N,12),
  * i.e. set_dof_actuation_force_tensor + simulate + fetch_results + refresh_*_tensor
  * (legged_robot.py:103-106,129-131).  Updates ROOT_STATES, DOF_STATE, CONTACT_FORCES,
- * RIGID_BODY_POS only. */
+ * RIGID_BODY_POS (and RIGID_BODY_STATE with cfg.export_body_state) only. */
 int qa_simulate(qa_sim *sim, const float *torques, void *stream);
 
-/* Upload reset-state frames for reset_mode 1: `frames` is a HOST pointer to
- * (num_frames, QA_MOCAP_FRAME) fp32 laid out as root_pos3, root_quat4, joint_pos12,
- * lin_vel3, ang_vel3 (both in the root frame), joint_vel12; the frames of gait g are rows
- * first_frame[g] .. first_frame[g+1]-1.  A reset draws one row uniformly within its gait. */
-int qa_set_mocap(qa_sim *sim, const float *frames, int32_t num_frames, const int32_t first_frame[QA_NUM_GAITS + 1], void *stream);
+/* Upload the labelled mocap clips for reset_mode 1 (LeggedRobot.reset_idx with mocap_state_init,
+ * bbc/legged_gym/envs/base/legged_robot.py:205-214, 598-612, 660-680; MotionLoader.get_full_frame_batch,
+ * bbc/rsl_rl/datasets/motion_loader.py:461-474).  `frames` is a HOST pointer to (num_frames, QA_MOCAP_FRAME) fp32: the clips'
+ * frames one after the other, each row root_pos3, root_quat4 (xyzw, normalised, w >= 0), joint_pos12, lin_vel3, ang_vel3
+ * (both in the root frame), joint_vel12 -- i.e. columns [0:19] and [31:49] of the reference's 61-float frame after
+ * MotionLoader.reorder.  `clips` is a HOST pointer to (num_clips <= QA_MAX_MOCAP_CLIPS, QA_MOCAP_CLIP) float64 rows, sorted
+ * by gait; the clips of gait g are rows first_clip[g] .. first_clip[g+1]-1.  A reset of an env with gait g then does what the
+ * reference does: clip ~ MotionWeight inside the gait (first clip whose cumulative probability exceeds u0), t = max(1e-7,
+ * range u1) (traj_time_sample_batch, :333-342), p n = t / length n in float64, frames floor / ceil(p n), blend = p n -
+ * floor, linear interpolation of everything but the root quaternion, which goes through the reference's quaternion_slerp
+ * (bbc/rsl_rl/utils/utils.py:126-159, including its 1/angle weights); root velocities rotated into the world frame. */
+int qa_set_mocap(qa_sim *sim, const float *frames, int32_t num_frames, const double *clips, int32_t num_clips,
+                 const int32_t first_clip[QA_NUM_GAITS + 1], void *stream);
+
+/* Verification entry (twin of the oracle's qo_debug_post_physics): LeggedRobot.post_physics_step
+ * (bbc/legged_gym/envs/base/legged_robot.py:124-166) ALONE, on whatever state is in the arena -- the same device code the
+ * fused step runs after its last substep, fed from ROOT_STATES / DOF_STATE / CONTACT_FORCES / RIGID_BODY_POS / TORQUES(_ORG) /
+ * ACTIONS / ACTION_HISTORY instead of from registers.  tests/test_hip_parity.py replays the reference's own
+ * post_physics_step fixtures (tests/golden/env_post_physics.npz) through it on the GPU. */
+int qa_debug_post_physics(qa_sim *sim, int64_t global_step, void *stream);
 
 /* Fused GAE (rollout_storage.py:97-111): reverse scan over T, then advantage
  * normalisation over all T*N samples (unbiased std, +1e-8).  All pointers are device

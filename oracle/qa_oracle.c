@@ -45,7 +45,7 @@ typedef struct {
     int64_t total;
 } Layout;
 
-static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : d == QA_I16 ? 2 : 1; }
+static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : (d == QA_I64 || d == QA_F64) ? 8 : d == QA_I32 ? 4 : d == QA_I16 ? 2 : 1; }
 
 static void set_t(Layout *L, int t, int dt, int nd, int64_t a, int64_t b, int64_t c) {
     L->dtype[t] = dt; L->ndim[t] = nd; L->shape[t][0] = a; L->shape[t][1] = b; L->shape[t][2] = c;
@@ -97,6 +97,9 @@ static void make_layout(const qa_config *cfg, Layout *L) {
       set_t(L, QA_T_HEIGHT_SAMPLES, QA_I16, 2, hr, hc, 1); }
     set_t(L, QA_T_SCAN_HEIGHT, QA_F32, 1, N, 1, 1);
     set_t(L, QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3);
+    set_t(L, QA_T_MOCAP_CLIPS, QA_F64, 2, QA_MAX_MOCAP_CLIPS, QA_MOCAP_CLIP, 1);
+    set_t(L, QA_T_RIGID_BODY_STATE, QA_F32, 3, cfg->export_body_state ? N : 1, QA_NUM_BODIES_ABI, 13);
+    set_t(L, QA_T_STEP_TICKET, QA_I32, 1, 4, 1, 1);
     int64_t off = 0;
     for (int t = 0; t < QA_T_COUNT; ++t) {
         off = (off + 255) & ~(int64_t)255;
@@ -584,6 +587,41 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
         pts[1][0] = 0.285; pts[1][2] = 0.01; pts[2][0] = 0.293; pts[2][2] = -0.06;
         for (int l = 0; l < 4; ++l) { for (int k = 0; k < 3; ++k) memcpy(pts[3 + 4 * l + k], K2.o[l][k], sizeof(v3)); memcpy(pts[3 + 4 * l + 3], K2.foot[l], sizeof(v3)); }
         for (int b = 0; b < 19; ++b) { v3 w; mv(R2, pts[b], w); for (int i = 0; i < 3; ++i) rbp[3 * b + i] = (float)(w[i] + (double)root[i]); }
+        if (cfg->export_body_state) {
+            /* QA_T_RIGID_BODY_STATE: origin position, orientation (xyzw), origin velocity, angular velocity, world frame.
+             * Link k of a leg is moved by joints 0..k, its origin (joint k) by joints 0..k-1; the foot is fixed to the calf;
+             * Head_upper / Head_lower are fixed to the base. */
+            float *rbs = TP(s, QA_T_RIGID_BODY_STATE, float) + (int64_t)e * (QA_NUM_BODIES_ABI * 13);
+            v3 wB, vB; { v3 a = {root[10], root[11], root[12]}, b2 = {root[7], root[8], root[9]}; mtv(R2, a, wB); mtv(R2, b2, vB); }
+            for (int b = 0; b < 19; ++b) {
+                int l = b < 3 ? -1 : (b - 3) / 4, kb = b < 3 ? -1 : (b - 3) % 4, kq = kb > 2 ? 2 : kb;
+                v3 w = {wB[0], wB[1], wB[2]}, v, t; cross(wB, pts[b], t); for (int i = 0; i < 3; ++i) v[i] = vB[i] + t[i];
+                double qbody[4] = {qq[0], qq[1], qq[2], qq[3]};
+                if (l >= 0) {
+                    for (int j = 0; j < 3; ++j) {
+                        double qdj = dof[2 * (3 * l + j) + 1];
+                        if (j <= kq) for (int i = 0; i < 3; ++i) w[i] += qdj * K2.a[l][j][i];
+                        if (j < kb) { v3 rel = {pts[b][0] - K2.o[l][j][0], pts[b][1] - K2.o[l][j][1], pts[b][2] - K2.o[l][j][2]}, axr; cross(K2.a[l][j], rel, axr); for (int i = 0; i < 3; ++i) v[i] += qdj * axr[i]; }
+                    }
+                    double hq = 0.5 * q2[3 * l], ha = 0.5 * (kq == 0 ? 0.0 : (kq == 1 ? q2[3 * l + 1] : q2[3 * l + 1] + q2[3 * l + 2]));
+                    double qx_[4] = {sin(hq), 0, 0, cos(hq)}, qy_[4] = {0, sin(ha), 0, cos(ha)}, ql[4], qt[4];
+                    /* ql = qx (x) qy, qbody = qbase (x) ql   (xyzw Hamilton products) */
+                    ql[0] = qx_[3] * qy_[0] + qx_[0] * qy_[3] + qx_[1] * qy_[2] - qx_[2] * qy_[1];
+                    ql[1] = qx_[3] * qy_[1] - qx_[0] * qy_[2] + qx_[1] * qy_[3] + qx_[2] * qy_[0];
+                    ql[2] = qx_[3] * qy_[2] + qx_[0] * qy_[1] - qx_[1] * qy_[0] + qx_[2] * qy_[3];
+                    ql[3] = qx_[3] * qy_[3] - qx_[0] * qy_[0] - qx_[1] * qy_[1] - qx_[2] * qy_[2];
+                    qt[0] = qq[3] * ql[0] + qq[0] * ql[3] + qq[1] * ql[2] - qq[2] * ql[1];
+                    qt[1] = qq[3] * ql[1] - qq[0] * ql[2] + qq[1] * ql[3] + qq[2] * ql[0];
+                    qt[2] = qq[3] * ql[2] + qq[0] * ql[1] - qq[1] * ql[0] + qq[2] * ql[3];
+                    qt[3] = qq[3] * ql[3] - qq[0] * ql[0] - qq[1] * ql[1] - qq[2] * ql[2];
+                    memcpy(qbody, qt, sizeof(qt));
+                }
+                v3 vw, ww2; mv(R2, v, vw); mv(R2, w, ww2);
+                float *r = rbs + 13 * b;
+                for (int i = 0; i < 3; ++i) { r[i] = rbp[3 * b + i]; r[7 + i] = (float)vw[i]; r[10 + i] = (float)ww2[i]; }
+                for (int i = 0; i < 4; ++i) r[3 + i] = (float)qbody[i];
+            }
+        }
     }
 }
 
@@ -633,6 +671,34 @@ static void resample_commands(qo_sim *s, int e, int64_t step, int stream) {
     cmd[3] = hj; cmd[4] = hl;
 }
 
+/* quaternion_slerp of bbc/rsl_rl/utils/utils.py:126-159 for one pair, fp32, masks in the reference's order (see the HIP twin) */
+static void mocap_slerp(const float *q0, const float *q1, float f, float out[4]) {
+    float d = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+    int at_zero = fabsf(f) <= 1e-8f, at_one = fabsf(f - 1.0f) <= (1e-8f + 1e-5f);
+    int same = fabsf(fabsf(d) - 1.0f) < 8.8817842e-16f;
+    float sg = d < 0.f ? -1.0f : 1.0f;
+    d = clipf(d * sg, -1.0f, 1.0f);
+    float ang = acosf(d);
+    int tiny = fabsf(ang) < 8.8817842e-16f;
+    float isin = 1.0f / ang, w0 = sinf((1.0f - f) * ang) * isin, w1 = sinf(f * ang) * isin * sg;
+    for (int i = 0; i < 4; ++i) out[i] = (same || tiny) ? q0[i] : (at_one ? q1[i] : (at_zero ? q0[i] : q0[i] * w0 + q1[i] * w1));
+}
+
+/* one draw of MotionLoader.get_full_frame_batch for gait `gait` from the uniforms (u0, u1): the blended 37-float frame */
+static void mocap_sample(const qo_sim *s, int gait, float u0, float u1, float f[QA_MOCAP_FRAME]) {
+    const double *clips = TP(s, QA_T_MOCAP_CLIPS, double);
+    int c0 = s->mocap_first[gait], c1 = s->mocap_first[gait + 1], clip = c1 - 1;
+    for (int i = c0; i < c1; ++i) if ((double)u0 < clips[QA_MOCAP_CLIP * i + 4]) { clip = i; break; }
+    const double *ct = clips + QA_MOCAP_CLIP * clip;
+    double t = ct[3] * (double)u1; if (t < 1e-7) t = 1e-7;
+    double pn = t / ct[2] * ct[1], lo = floor(pn), hi = ceil(pn);
+    float b = (float)(pn - lo);
+    const float *f0 = TP(s, QA_T_MOCAP_FRAMES, float) + ((int64_t)ct[0] + (int64_t)lo) * QA_MOCAP_FRAME;
+    const float *f1 = TP(s, QA_T_MOCAP_FRAMES, float) + ((int64_t)ct[0] + (int64_t)hi) * QA_MOCAP_FRAME;
+    for (int i = 0; i < QA_MOCAP_FRAME; ++i) f[i] = (1.0f - b) * f0[i] + b * f1[i];
+    mocap_slerp(f0 + 3, f1 + 3, b, f + 3);
+}
+
 static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity, int report) {
     /* legged_robot.py:178-240 */
     const qa_config *c = &s->cfg;
@@ -641,13 +707,15 @@ static void reset_env(qo_sim *s, int e, int64_t step, int stats_parity, int repo
     float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e, *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
     const float *org = TP(s, QA_T_ENV_ORIGINS, float) + 3 * e;
     if (c->reset_mode == 1 && s->mocap_first[QA_NUM_GAITS] > 0) {
-        /* mocap frame reset (:598-612, :660-680): one pre-sampled frame row of the env's gait */
+        /* mocap frame reset (:205-214, :598-612, :660-680) = MotionLoader.get_full_frame_batch (motion_loader.py:461-474):
+         * clip ~ MotionWeight inside the env's gait (np.random.choice: first clip whose cumulative probability exceeds u),
+         * t = max(1e-7, range u) (:333-342), p n = t / length n in float64 (:411-416), frames floor / ceil, blend in fp32,
+         * quaternion_slerp (utils.py:126-159) for the root orientation, root velocities rotated into the world frame */
         const float *lc = TP(s, QA_T_LATENT_C, float) + 5 * e;
         int gait = 0; for (int g = 1; g < 5; ++g) if (lc[g] > lc[gait]) gait = g;
         float u[4]; rng4(s, e, step, RS_RESET, 0, u);
-        int n = s->mocap_first[gait + 1] - s->mocap_first[gait];
-        int row = s->mocap_first[gait] + (int)(u[0] * (float)n); if (row >= s->mocap_first[gait + 1]) row = s->mocap_first[gait + 1] - 1;
-        const float *f = TP(s, QA_T_MOCAP_FRAMES, float) + (int64_t)row * QA_MOCAP_FRAME;
+        float f[QA_MOCAP_FRAME];
+        mocap_sample(s, gait, u[0], u[1], f);
         for (int i = 0; i < 3; ++i) root[i] = f[i] + org[i];
         for (int i = 0; i < 4; ++i) root[3 + i] = f[3 + i];
         quat_rotate_f(f + 3, f + 19, +1.0f, root + 7);
@@ -923,10 +991,16 @@ int qo_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
 
 int qo_destroy(qo_sim *s) { free(s); return QA_OK; }
 
-int qo_set_mocap(qo_sim *s, const float *frames, int32_t nf, const int32_t first[QA_NUM_GAITS + 1], void *stream) {
+int qo_set_mocap(qo_sim *s, const float *frames, int32_t nf, const double *clips, int32_t nc, const int32_t first[QA_NUM_GAITS + 1], void *stream) {
     (void)stream;
-    if (!s || !frames || nf <= 0 || nf > s->cfg.num_mocap_frames) return QA_E_ARG;
+    if (!s || !frames || !clips || !first || nf <= 0 || nf > s->cfg.num_mocap_frames || nc <= 0 || nc > QA_MAX_MOCAP_CLIPS) return QA_E_ARG;
+    if (first[0] != 0 || first[QA_NUM_GAITS] != nc) return QA_E_ARG;
+    for (int g = 0; g < QA_NUM_GAITS; ++g) if (first[g + 1] <= first[g]) return QA_E_ARG;
     memcpy(TP(s, QA_T_MOCAP_FRAMES, float), frames, (size_t)nf * QA_MOCAP_FRAME * 4);
+    double *ct = TP(s, QA_T_MOCAP_CLIPS, double);
+    memset(ct, 0, sizeof(double) * QA_MAX_MOCAP_CLIPS * QA_MOCAP_CLIP);
+    for (int i = 0; i < nc; ++i) for (int k = 0; k < 5; ++k) ct[QA_MOCAP_CLIP * i + k] = clips[QA_MOCAP_CLIP * i + k];
+    for (int g = 0; g <= QA_NUM_GAITS; ++g) ct[QA_MOCAP_CLIP * g + 5] = (double)first[g];
     memcpy(s->mocap_first, first, sizeof(s->mocap_first));
     return QA_OK;
 }
@@ -1501,6 +1575,18 @@ int qo_debug_pre_physics(qo_sim *s, const float *actions, int32_t delay_steps) {
 int qo_debug_post_physics(qo_sim *s, int64_t step) {
     memset(TP(s, QA_T_EPISODE_STATS, float) + 16 * ((step + 1) & 1), 0, 64);
     for (int e = 0; e < s->cfg.num_envs; ++e) { float tmp[QA_NUM_OBS_DISC]; post_physics(s, e, step, tmp); }
+    return QA_OK;
+}
+/* the mocap reset's frame sampling alone, for given uniforms (tests/test_mocap_reset.py against the reference's own frames):
+ * out = root state 13 (origin not added) | joint positions 12 | joint velocities 12 */
+int qo_debug_mocap_reset(qo_sim *s, int gait, float u0, float u1, float out[37]) {
+    if (!s || gait < 0 || gait >= QA_NUM_GAITS || s->mocap_first[QA_NUM_GAITS] <= 0) return QA_E_ARG;
+    float f[QA_MOCAP_FRAME];
+    mocap_sample(s, gait, u0, u1, f);
+    for (int i = 0; i < 7; ++i) out[i] = f[i];
+    quat_rotate_f(f + 3, f + 19, +1.0f, out + 7);
+    quat_rotate_f(f + 3, f + 22, +1.0f, out + 10);
+    for (int j = 0; j < 12; ++j) { out[13 + j] = f[7 + j]; out[25 + j] = f[25 + j]; }
     return QA_OK;
 }
 /* legged_robot.py:547-579 on the current dof state */

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 7
+QA_ABI_VERSION = 8
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -16,6 +16,7 @@ NUM_OBS_DISC = 49
 ACTION_BUF_LEN = 8
 NUM_REWARDS = 14
 MOCAP_FRAME = 37
+MAX_MOCAP_CLIPS, MOCAP_CLIP = 64, 8
 
 REWARD_NAMES = [
     "action_rate", "collision", "delta_torques", "dof_acc", "dof_error", "dof_pos_limits",
@@ -31,9 +32,10 @@ TENSORS = [
     "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
     "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",
     "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES", "HEIGHT_SAMPLES", "SCAN_HEIGHT", "FOOT_IMPULSE",
+    "MOCAP_CLIPS", "RIGID_BODY_STATE", "STEP_TICKET",
 ]
 T = {name: i for i, name in enumerate(TENSORS)}
-DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32, DTYPE_I16 = 0, 1, 2, 3, 4
+DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32, DTYPE_I16, DTYPE_F64 = 0, 1, 2, 3, 4, 5
 
 BODY_NAMES = ["base", "Head_upper", "Head_lower"] + [
     f"{l}_{p}" for l in ("FL", "FR", "RL", "RR") for p in ("hip", "thigh", "calf", "foot")]
@@ -74,7 +76,7 @@ class QaConfig(C.Structure):
         ("easi_mean", C.c_float * 6), ("easi_var", C.c_float * 6),
         ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("hf_hscale", C.c_float), ("hf_vscale", C.c_float),
         ("hf_border", C.c_float), ("reset_xy_jitter", C.c_float),
-        ("num_mocap_frames", C.c_int32), ("mocap_clip_count", C.c_int32 * NUM_GAITS),
+        ("num_mocap_frames", C.c_int32), ("export_body_state", C.c_int32), ("reserved_cfg", C.c_int32 * 4),
     ]
 
 
@@ -90,7 +92,8 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "env_step_dev"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "reset_all"); f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "simulate"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
-    f = getattr(lib, prefix + "set_mocap"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "set_mocap"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "debug_post_physics"); f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "gae"); f.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "ppo_loss")
     f.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
@@ -210,7 +213,7 @@ class QaTscObsIo(C.Structure):
 
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
-               "set_mocap", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
+               "set_mocap", "debug_post_physics", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
                "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "last_error", "abi_version"]
 
 _LIB = None

@@ -36,7 +36,7 @@ struct Layout {
     int32_t dtype[QA_T_COUNT];
     int64_t total;
 };
-static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : d == QA_I64 ? 8 : d == QA_I32 ? 4 : d == QA_I16 ? 2 : 1; }
+static int64_t dtype_size(int d) { return d == QA_F32 ? 4 : (d == QA_I64 || d == QA_F64) ? 8 : d == QA_I32 ? 4 : d == QA_I16 ? 2 : 1; }
 static void make_layout(const qa_config *cfg, Layout *L) {
     const int64_t N = cfg->num_envs, F = cfg->num_mocap_frames > 0 ? cfg->num_mocap_frames : 1;
     const int64_t HR = cfg->terrain_type == 1 ? cfg->hf_rows : 1, HC = cfg->terrain_type == 1 ? cfg->hf_cols : 1;
@@ -63,6 +63,9 @@ static void make_layout(const qa_config *cfg, Layout *L) {
         {QA_T_BASE_INERTIA, QA_F32, 2, N, 10, 1}, {QA_T_PRIOR_PARAMETERS, QA_F32, 1, QA_NUM_GAITS, 1, 1},
         {QA_T_MOCAP_FRAMES, QA_F32, 2, F, QA_MOCAP_FRAME, 1}, {QA_T_HEIGHT_SAMPLES, QA_I16, 2, HR, HC, 1},
         {QA_T_SCAN_HEIGHT, QA_F32, 1, N, 1, 1}, {QA_T_FOOT_IMPULSE, QA_F32, 3, N, 4, 3},
+        {QA_T_MOCAP_CLIPS, QA_F64, 2, QA_MAX_MOCAP_CLIPS, QA_MOCAP_CLIP, 1},
+        {QA_T_RIGID_BODY_STATE, QA_F32, 3, cfg->export_body_state ? N : 1, QA_NUM_BODIES_ABI, 13},
+        {QA_T_STEP_TICKET, QA_I32, 1, 4, 1, 1},
     };
     static_assert(sizeof(specs) / sizeof(specs[0]) == QA_T_COUNT, "every tensor needs a spec");
     memset(L, 0, sizeof(*L));
@@ -82,6 +85,9 @@ struct Ptrs {
         *last_torques_org, *last_root_vel, *action_hist, *obs, *obs_disc, *obs_disc_term, *commands,
         *latent_eps, *latent_c, *rew, *episode_sums, *episode_stats, *feet_force, *base_lin_vel, *base_ang_vel,
         *proj_grav, *rpy, *motor_strength, *mass_params, *friction, *env_origins, *base_inertia, *prior, *mocap, *foot_impulse, *scan_height;
+    float *rbstate;
+    double *mocap_clips;
+    int32_t *ticket;
     int16_t *height_samples;
     int64_t *reset, *episode_length;
     uint8_t *time_out, *last_contacts, *contact_filt;
@@ -95,9 +101,10 @@ struct qa_sim {
     char *arena;
     Ptrs p;
     int32_t mocap_first[QA_NUM_GAITS + 1];
+    double clip_stage[QA_MAX_MOCAP_CLIPS * QA_MOCAP_CLIP];     // host staging of the clip table (must outlive the async copy)
 };
 
-struct MocapIdx { int32_t first[QA_NUM_GAITS + 1]; };
+struct MocapIdx { int32_t on; };      // clips uploaded; the per-gait clip ranges live in column 5 of QA_T_MOCAP_CLIPS
 
 thread_local char qa_err_buf[512] = "";      // shared with qa_learner.hip
 #define g_err qa_err_buf
@@ -138,9 +145,15 @@ __device__ __forceinline__ void resample_commands(const qa_config &c, const floa
     gait = 4; float acc = 0.f; bool found = false;
 #pragma unroll
     for (int g = 0; g < 5; ++g) { acc += z[g] / sum; if (!found && u0.v[0] < acc) { gait = g; found = true; } }
-    float vxl = c.lin_vel_x[0][0], vxh = c.lin_vel_x[0][1], vyl = c.lin_vel_y[0][0], vyh = c.lin_vel_y[0][1], wl = c.ang_vel_yaw[0][0], wh = c.ang_vel_yaw[0][1];
+    // per-gait ranges blended arithmetically: a compare/select chain over the config arrays is folded into a select of
+    // ADDRESSES, and a dynamically addressed kernel-argument record is kept as a 1 KB private (scratch) copy
+    float vxl = 0.f, vxh = 0.f, vyl = 0.f, vyh = 0.f, wl = 0.f, wh = 0.f;
 #pragma unroll
-    for (int g = 1; g < 5; ++g) if (gait == g) { vxl = c.lin_vel_x[g][0]; vxh = c.lin_vel_x[g][1]; vyl = c.lin_vel_y[g][0]; vyh = c.lin_vel_y[g][1]; wl = c.ang_vel_yaw[g][0]; wh = c.ang_vel_yaw[g][1]; }
+    for (int g = 0; g < 5; ++g) {
+        const float m = gait == g ? 1.0f : 0.0f;
+        vxl = fmaf(m, c.lin_vel_x[g][0], vxl); vxh = fmaf(m, c.lin_vel_x[g][1], vxh); vyl = fmaf(m, c.lin_vel_y[g][0], vyl);
+        vyh = fmaf(m, c.lin_vel_y[g][1], vyh); wl = fmaf(m, c.ang_vel_yaw[g][0], wl); wh = fmaf(m, c.ang_vel_yaw[g][1], wh);
+    }
     float vx = (vxh - vxl) * u0.v[2] + vxl, vy = (vyh - vyl) * u0.v[3] + vyl, wz = (wh - wl) * u1.v[0] + wl;
     bool jump = gait == QA_NUM_GAITS - 1;
     float hj = ((c.jump_height[1] - c.jump_height[0]) * u1.v[1] + c.jump_height[0]) * (jump ? 1.0f : 0.0f);
@@ -159,23 +172,53 @@ __device__ __forceinline__ V3 quat_rot(float qx, float qy, float qz, float qw, V
     return v3(a.x + sign * b.x + cc.x, a.y + sign * b.y + cc.y, a.z + sign * b.z + cc.z);
 }
 
+// quaternion_slerp of bbc/rsl_rl/utils/utils.py:126-159 for one pair (fp32 like the torch tensors it runs on), masks in the
+// order the reference applies them: identical / zero-angle pairs -> q0; fraction ~ 1 -> q1; fraction ~ 0 -> q0; otherwise
+// q0 sin((1-f) a) / a + (+-q1) sin(f a) / a with a = acos|q0.q1| -- the reference divides by the ANGLE, not by its sine, so
+// the result is not exactly unit length; it is written to the root state as is, like the reference does.
+__device__ __forceinline__ void mocap_slerp(const float *q0, const float *q1, float f, float out[4]) {
+    float d = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+    const bool at_zero = fabsf(f) <= 1e-8f, at_one = fabsf(f - 1.0f) <= (1e-8f + 1e-5f);
+    const bool same = fabsf(fabsf(d) - 1.0f) < 8.8817842e-16f;
+    const float sg = d < 0.f ? -1.0f : 1.0f;
+    d = clampf(d * sg, -1.0f, 1.0f);
+    const float ang = acosf(d);
+    const bool tiny = fabsf(ang) < 8.8817842e-16f;
+    const float isin = 1.0f / ang;
+    const float w0 = sinf((1.0f - f) * ang) * isin, w1 = sinf(f * ang) * isin * sg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (same || tiny) ? q0[i] : (at_one ? q1[i] : (at_zero ? q0[i] : q0[i] * w0 + q1[i] * w1));
+}
+
 // reset of one env by its quad (legged_robot.py:178-240).  Updates st and the command/latent registers.
 __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, const MocapIdx &mi, int env, int leg, int64_t step,
                                           EnvState &st, float cmd[5], float &eps, int &gait) {
     resample_commands(c, p.prior, env, step, RS_CMD_RESET, cmd, eps, gait);
     const float ox = p.env_origins[3 * env], oy = p.env_origins[3 * env + 1], oz = p.env_origins[3 * env + 2];
-    if (c.reset_mode == 1 && mi.first[QA_NUM_GAITS] > 0) {
+    if (c.reset_mode == 1 && mi.on) {
+        // MotionLoader.get_full_frame_batch (motion_loader.py:461-474): clip ~ MotionWeight inside the gait, time ~ U over the
+        // clip's sampling range, the two bracketing frames blended (get_full_frame_at_time_batch :410-447); index arithmetic in
+        // float64 as numpy does it, the blend itself in fp32 as torch does it
         F4 u = rng4(c.seed, env, step, RS_RESET, 0);
-        int n = mi.first[gait + 1] - mi.first[gait];
-        int row = mi.first[gait] + (int)(u.v[0] * (float)n);
-        row = min(row, mi.first[gait + 1] - 1);
-        const float *f = p.mocap + (int64_t)row * QA_MOCAP_FRAME;
-        st.pos = v3(f[0] + ox, f[1] + oy, f[2] + oz);
-        st.qx = f[3]; st.qy = f[4]; st.qz = f[5]; st.qw = f[6];
-        st.vw = quat_rot(f[3], f[4], f[5], f[6], v3(f[19], f[20], f[21]), 1.0f);
-        st.ww = quat_rot(f[3], f[4], f[5], f[6], v3(f[22], f[23], f[24]), 1.0f);
+        const int c0 = (int)p.mocap_clips[QA_MOCAP_CLIP * gait + 5], c1 = (int)p.mocap_clips[QA_MOCAP_CLIP * (gait + 1) + 5];   // first_clip[] rides in column 5
+        int clip = c1 - 1;
+        for (int i = c1 - 2; i >= c0; --i) if ((double)u.v[0] < p.mocap_clips[QA_MOCAP_CLIP * i + 4]) clip = i;     // first clip with u < cdf
+        const double *ct = p.mocap_clips + QA_MOCAP_CLIP * clip;
+        const double nf = ct[1];
+        const double t = fmax(1e-7, ct[3] * (double)u.v[1]);
+        const double pn = t / ct[2] * nf;
+        const double lo = floor(pn), hi = ceil(pn);
+        const float b = (float)(pn - lo);
+        const float *f0 = p.mocap + ((int64_t)ct[0] + (int64_t)lo) * QA_MOCAP_FRAME, *f1 = p.mocap + ((int64_t)ct[0] + (int64_t)hi) * QA_MOCAP_FRAME;
+        auto mix = [&](int i) { return (1.0f - b) * f0[i] + b * f1[i]; };
+        st.pos = v3(mix(0) + ox, mix(1) + oy, mix(2) + oz);
+        float q[4];
+        mocap_slerp(f0 + 3, f1 + 3, b, q);
+        st.qx = q[0]; st.qy = q[1]; st.qz = q[2]; st.qw = q[3];
+        st.vw = quat_rot(q[0], q[1], q[2], q[3], v3(mix(19), mix(20), mix(21)), 1.0f);
+        st.ww = quat_rot(q[0], q[1], q[2], q[3], v3(mix(22), mix(23), mix(24)), 1.0f);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { st.q[k] = f[7 + 3 * leg + k]; st.qd[k] = f[25 + 3 * leg + k]; }
+        for (int k = 0; k < 3; ++k) { st.q[k] = mix(7 + 3 * leg + k); st.qd[k] = mix(25 + 3 * leg + k); }
     } else {
         float u[20];
 #pragma unroll
@@ -202,11 +245,11 @@ __device__ __forceinline__ TerrainView terrain_view(const qa_config &c, const Pt
 }
 
 // ------------------------------------------------------------------ the fused env step
-struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; const int64_t *step_ptr; long long *prof; };
+struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; int64_t *step_ptr; long long *prof; };
 #ifdef QA_SUBPROF
 #define QA_STAMP(k) do { } while (0)      // the substep stamps own the buffer in this build
 #else
-#define QA_STAMP(k) do { if (a.prof && tix == 0) a.prof[bix * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define QA_STAMP(k) do { if (qa_prof && tix == 0) qa_prof[bix * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #endif
 
 #define S_PROP 0        // 57  proprioception (noise-free)
@@ -236,6 +279,377 @@ __device__ __forceinline__ void store_obs_row(float *dst, const float *row, int 
     if (lane < 3 - head) dst[head + 668 + lane] = row[head + 668 + lane];
 }
 
+// QA_T_RIGID_BODY_STATE rows of this lane's leg (hip, thigh, calf, foot) and -- lane 0 -- of base / Head_upper / Head_lower:
+// body-origin position, orientation (xyzw), linear velocity of the origin and angular velocity, world frame, from the NEW
+// state.  Link k is moved by joints 0..k, its origin (= joint k) by joints 0..k-1; the foot is fixed to the calf.
+__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float o[4]) {     // xyzw, a (x) b
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+__device__ __forceinline__ void write_body_state(float *rows, const EnvState &st, const M3 &R, const V3 org[4], int leg) {
+    const float qb[4] = {st.qx, st.qy, st.qz, st.qw};
+    float s1, c1, s2, c2, s3, c3;
+    sincosf(0.5f * st.q[0], &s1, &c1); sincosf(0.5f * st.q[1], &s2, &c2); sincosf(0.5f * (st.q[1] + st.q[2]), &s3, &c3);
+    const float qh[4] = {s1, 0.f, 0.f, c1}, qy2[4] = {0.f, s2, 0.f, c2}, qy3[4] = {0.f, s3, 0.f, c3};
+    float ql[3][4], t[4];
+    quat_mul(qb, qh, ql[0]); quat_mul(qh, qy2, t); quat_mul(qb, t, ql[1]); quat_mul(qh, qy3, t); quat_mul(qb, t, ql[2]);
+    float sq, cq; sincosf(st.q[0], &sq, &cq);
+    const V3 ax[3] = {v3(1, 0, 0), v3(0, cq, sq), v3(0, cq, sq)};
+    const V3 wB = mulT(R, st.ww), vB = mulT(R, st.vw);        // base twist in base axes
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int kq = b < 3 ? b : 2;                          // link whose frame the body shares
+        V3 w = wB, v = vB + cross(wB, org[b]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j <= kq) w = w + st.qd[j] * ax[j];
+            if (j < b) v = v + st.qd[j] * cross(ax[j], org[b] - org[j]);
+        }
+        const V3 pw = mul(R, org[b]) + st.pos, vw = mul(R, v), ww = mul(R, w);
+        float *r = rows + 13 * (3 + 4 * leg + b);
+        r[0] = pw.x; r[1] = pw.y; r[2] = pw.z; r[3] = ql[kq][0]; r[4] = ql[kq][1]; r[5] = ql[kq][2]; r[6] = ql[kq][3];
+        r[7] = vw.x; r[8] = vw.y; r[9] = vw.z; r[10] = ww.x; r[11] = ww.y; r[12] = ww.z;
+    }
+    if (leg == 0) {
+        const V3 offs[3] = {v3(0, 0, 0), v3(0.285f, 0.f, 0.01f), v3(0.293f, 0.f, -0.06f)};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const V3 pw = mul(R, offs[b]) + st.pos, vw = st.vw + cross(st.ww, mul(R, offs[b]));
+            float *r = rows + 13 * b;
+            r[0] = pw.x; r[1] = pw.y; r[2] = pw.z; r[3] = qb[0]; r[4] = qb[1]; r[5] = qb[2]; r[6] = qb[3];
+            r[7] = vw.x; r[8] = vw.y; r[9] = vw.z; r[10] = st.ww.x; r[11] = st.ww.y; r[12] = st.ww.z;
+        }
+    }
+}
+
+// What the physics phase of the fused step hands to post_physics_step, per lane (lane = leg): the new state, the torques of
+// the LAST substep, the contact forces of the leg's bodies and of the base.  qa_post_physics_kernel fills the same record from
+// the arena instead, which makes the post-physics device code testable on its own against the reference's fixtures.
+struct PostIn {
+    EnvState st;
+    float act[3], raw_act[3], tau[3], tau_org[3], sp[3], sd[3], fimp[3];
+    V3 foot_f, hip_f, thigh_f, calf_f, base_f;
+    V3 foot_w;
+    float fric;
+};
+
+template <bool PLANE, int LPE>
+__device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptrs &p, const MocapIdx &mi, long long *qa_prof, PostIn &in, const TerrainView &T,
+                                                   const float *tbl, float *s_stage, float *s_rows, const int tix, const int bix, const int env,
+                                                   const int leg, const bool valid, const bool owner, const int le, const int64_t step) {
+    // (the kernel argument record is NOT passed as a whole: a reference to it makes the compiler keep a 1 KB private copy)
+    constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
+    const int N = c.num_envs;
+    EnvState &st = in.st;
+    float (&act)[3] = in.act, (&raw_act)[3] = in.raw_act, (&tau)[3] = in.tau, (&tau_org)[3] = in.tau_org, (&sp)[3] = in.sp, (&sd)[3] = in.sd, (&fimp)[3] = in.fimp;
+    const V3 foot_f = in.foot_f, hip_f = in.hip_f, thigh_f = in.thigh_f, calf_f = in.calf_f, base_f = in.base_f, foot_w = in.foot_w;
+    const float fric = in.fric;
+    const float q0[3] = {c.default_dof_pos[0], c.default_dof_pos[1], c.default_dof_pos[2]};
+    QA_STAMP(4);
+    // =========================== post_physics_step (legged_robot.py:124-166) ===========================
+    int64_t epl = p.episode_length[env] + 1;
+    const int64_t common = step + 1;
+    V3 blv = quat_rot(st.qx, st.qy, st.qz, st.qw, st.vw, -1.f), bav = quat_rot(st.qx, st.qy, st.qz, st.qw, st.ww, -1.f);
+    V3 pg = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(0, 0, -1), -1.f);
+    float roll = atan2f(2.0f * (st.qw * st.qx + st.qy * st.qz), 1.0f - 2.0f * (st.qx * st.qx + st.qy * st.qy));
+    float pitch = asinf(clampf(2.0f * (st.qw * st.qy - st.qz * st.qx), -1.0f, 1.0f));
+    float yaw = atan2f(2.0f * (st.qw * st.qz + st.qx * st.qy), 1.0f - 2.0f * (st.qy * st.qy + st.qz * st.qz));
+    const float ffn = sqrtf(dot(foot_f, foot_f));
+    const uint8_t contact = ffn > 2.0f;
+    const uint8_t cfilt = contact | p.last_contacts[(int64_t)env * 4 + leg];
+
+    // commands / latents in registers (replicated)
+    float cmd[5], eps; int gait = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cmd[i] = p.commands[(int64_t)env * 5 + i];
+    eps = p.latent_eps[env];
+    {
+        float best = p.latent_c[(int64_t)env * 5];
+#pragma unroll
+        for (int g = 1; g < 5; ++g) { float v = p.latent_c[(int64_t)env * 5 + g]; if (v > best) { best = v; gait = g; } }
+    }
+    bool cmd_dirty = false;
+    if (__any(epl % c.resampling_steps == 0)) {
+        float c2[5], e2; int g2;
+        resample_commands(c, p.prior, env, step, RS_CMD, c2, e2, g2);
+        if (epl % c.resampling_steps == 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cmd[i] = c2[i];
+            eps = e2; gait = g2; cmd_dirty = true;
+        }
+    }
+    if (c.push_robots && (common % c.push_interval == 0)) {   // uniform over the grid
+        F4 u = rng4(c.seed, env, step, RS_PUSH, 0);
+        st.vw.x = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[0] + -c.max_push_vel_xy;
+        st.vw.y = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[1] + -c.max_push_vel_xy;
+    }
+    // measured_heights (:469-470): before any reset, like the reference's callback
+    const float scan_h = PLANE ? 0.0f : scan_center_height(T, st.pos, st.qz, st.qw);
+    // ---- check_termination :168-176
+    int term_c = (sqrtf(dot(hip_f, hip_f)) > 1.0f) ? 1 : 0;
+    term_c = xor_<LPE>(term_c) | (sqrtf(dot(base_f, base_f)) > 1.0f ? 1 : 0);
+    int timeout = (epl > c.max_episode_length) || (st.pos.z < -6.0f);
+    {
+        float chk = st.pos.x + st.pos.y + st.pos.z + st.qx + st.qy + st.qz + st.qw + st.vw.x + st.vw.y + st.vw.z + st.ww.x + st.ww.y + st.ww.z;
+        if (!isfinite(chk)) timeout = 1;          // build-added failure detection
+    }
+    const int reset = term_c | timeout;
+
+    QA_STAMP(5);
+    // ---- rewards :242-259, alphabetical order
+    float term[QA_NUM_REWARDS];
+    {
+        const float dtp = c.sim_dt * (float)c.decimation;
+        float s_ar = 0, s_dt = 0, s_acc = 0, s_err = 0, s_hip = 0, s_pl = 0, s_vl = 0, s_tl = 0, s_tq = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+            float d;
+            d = p.last_actions[j] - act[k]; s_ar += d * d;
+            d = tau_org[k] - p.last_torques_org[j]; s_dt += d * d;
+            d = (p.last_dof_vel[j] - st.qd[k]) / dtp; s_acc += d * d;
+            d = st.q[k] - q0[k]; s_err += d * d; if (k == 0) s_hip += d * d;
+            float lo = tbl[T_LOWER + k], hi = tbl[T_UPPER + k], mid = (lo + hi) / 2, rng = hi - lo;
+            float slo = mid - 0.5f * rng * c.soft_dof_pos_limit, shi = mid + 0.5f * rng * c.soft_dof_pos_limit;
+            s_pl += -fminf(st.q[k] - slo, 0.f) + fmaxf(st.q[k] - shi, 0.f);
+            s_vl += clampf(fabsf(st.qd[k]) - tbl[T_VELLIM + k] * c.soft_dof_vel_limit, 0.f, 1.f);
+            s_tl += fmaxf(fabsf(tau_org[k]) - tbl[T_EFFORT + k] * c.soft_torque_limit, 0.f);
+            s_tq += tau_org[k] * tau_org[k];
+        }
+        float ncol = (sqrtf(dot(thigh_f, thigh_f)) > 0.1f ? 1.f : 0.f) + (sqrtf(dot(calf_f, calf_f)) > 0.1f ? 1.f : 0.f);
+        term[QA_R_ACTION_RATE] = xsum<LPE>(s_ar); term[QA_R_COLLISION] = xsum<LPE>(ncol); term[QA_R_DELTA_TORQUES] = xsum<LPE>(s_dt);
+        term[QA_R_DOF_ACC] = xsum<LPE>(s_acc); term[QA_R_DOF_ERROR] = xsum<LPE>(s_err); term[QA_R_DOF_POS_LIMITS] = xsum<LPE>(s_pl);
+        term[QA_R_DOF_VEL_LIMITS] = xsum<LPE>(s_vl); term[QA_R_HIP_POS] = xsum<LPE>(s_hip); term[QA_R_TORQUE_LIMITS] = xsum<LPE>(s_tl);
+        term[QA_R_TORQUES] = xsum<LPE>(s_tq);
+        const float root_h = st.pos.z - scan_h;
+        float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
+        term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c.jump_height[0]) ? c.jump_goal : 0.f;
+        float el = sqrtf((cmd[4] - root_h) * (cmd[4] - root_h));
+        term[QA_R_LOCOMOTION_HEIGHT] = (cmd[3] > c.jump_height[0]) ? 0.f : expf(-10.0f * (el * el) / c.tracking_sigma);
+        float ea = (cmd[2] - bav.z) * (cmd[2] - bav.z);
+        term[QA_R_TRACKING_ANG_VEL] = expf(-ea / c.tracking_sigma);
+        float elv = (cmd[0] - blv.x) * (cmd[0] - blv.x) + (cmd[1] - blv.y) * (cmd[1] - blv.y);
+        term[QA_R_TRACKING_LIN_VEL] = expf(-elv / c.tracking_sigma);
+    }
+    float rew = 0.f;
+    float esum[QA_NUM_REWARDS];
+#pragma unroll
+    for (int r = 0; r < QA_NUM_REWARDS; ++r) {
+        esum[r] = p.episode_sums[(int64_t)r * N + env];
+        if (c.reward_scale_dt[r] != 0.0f) { float v = term[r] * c.reward_scale_dt[r]; rew += v; esum[r] += v; }
+    }
+    if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
+
+    QA_STAMP(6);
+    wave_lds_sync();          // physics scratch is dead from here on; the staging area takes its place
+    // ---- terminal disc obs = previous OBS_DISC row; stage it
+    float *sst = s_stage + le * S_ENV;
+    for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
+
+    // ---- reset_idx :178-240
+    V3 lav = st.vw, law = st.ww;      // last_root_vel is taken after the reset (:160)
+    if (__any(reset)) {
+        if (reset) {
+#pragma unroll
+            for (int r = 0; r < QA_NUM_REWARDS; ++r) {
+                if ((r & 3) == leg && valid) atomicAdd(&p.episode_stats[16 * (step & 1) + r], esum[r]);
+                esum[r] = 0.f;
+            }
+            if (leg == 0 && valid) atomicAdd(&p.episode_stats[16 * (step & 1) + 14], 1.0f);
+            reset_env(c, p, mi, env, leg, step, st, cmd, eps, gait);
+            cmd_dirty = true;
+            epl = 0;
+            lav = st.vw; law = st.ww;
+        }
+    }
+    const bool refill = epl <= 1;
+
+    QA_STAMP(7);
+    // ---- observations :261-331
+    // heading-inverse rotation of the (stale for reset envs) foot position, torch_jit_utils.py:23-76
+    V3 key;
+    {
+        V3 rd = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(1, 0, 0), 1.f);
+        float heading = atan2f(rd.y, rd.x);
+        float sh, ch; sincosf(-0.5f * heading, &sh, &ch);
+        float hn = rsqrtf(sh * sh + ch * ch);
+        V3 rel = foot_w - st.pos;
+        key = quat_rot(0.f, 0.f, sh * hn, ch * hn, rel, 1.f);
+    }
+    const float root_h = st.pos.z - scan_h;      // post-reset z, pre-reset measured height (:261-273 after :178)
+    // proprioception (57): lanes write their own joints, lane 0 the shared entries
+    {
+        float *pr = sst + S_PROP;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = 3 * leg + k;
+            pr[5 + j] = (st.q[k] - q0[k]) * c.s_dof_pos;
+            pr[17 + j] = st.qd[k] * c.s_dof_vel;
+            pr[29 + j] = reset ? 0.0f : raw_act[k];      // reset_idx zeroes the action history first (:227)
+            pr[45 + j] = 0.0f * (k == 0 ? key.x : (k == 1 ? key.y : key.z));
+            sst[S_DISC + 9 + j] = (st.q[k] - q0[k]) * c.s_dof_pos;
+            sst[S_DISC + 21 + j] = st.qd[k] * c.s_dof_vel;
+            sst[S_DISC + 33 + j] = (k == 0 ? key.x : (k == 1 ? key.y : key.z)) * c.s_key_pos;
+        }
+        pr[41 + leg] = (cfilt ? 1.0f : 0.0f) - 0.5f;
+        sst[S_DISC + 45 + leg] = (cfilt ? 1.0f : 0.0f) * c.s_foot_contact;
+        if (leg == 0) {
+            pr[0] = roll; pr[1] = pitch; pr[2] = bav.x * c.s_ang_vel; pr[3] = bav.y * c.s_ang_vel; pr[4] = bav.z * c.s_ang_vel;
+            sst[S_DISC + 0] = roll; sst[S_DISC + 1] = pitch; sst[S_DISC + 2] = root_h;
+            sst[S_DISC + 3] = blv.x * c.s_lin_vel_dist; sst[S_DISC + 4] = blv.y * c.s_lin_vel_dist; sst[S_DISC + 5] = blv.z * c.s_lin_vel_dist;
+            sst[S_DISC + 6] = bav.x * c.s_ang_vel_dist; sst[S_DISC + 7] = bav.y * c.s_ang_vel_dist; sst[S_DISC + 8] = bav.z * c.s_ang_vel_dist;
+            sst[S_FLAGS] = refill ? 1.0f : 0.0f;
+            sst[S_FLAGS + 1] = reset ? 1.0f : 0.0f;
+            // tail: commands, eps, one-hot gait
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { sst[S_TAIL + i] = cmd[i]; sst[S_TAIL + 6 + i] = (gait == i) ? 1.0f : 0.0f; }
+            sst[S_TAIL + 5] = eps;
+        }
+    }
+    wave_lds_sync();
+    // head of the obs row: prop + explicit + latent, with noise on the 32 noisy entries
+    {
+        float *hd = sst + S_HEAD;
+        for (int i = leg; i < QA_NUM_PROP; i += 4) hd[i] = sst[S_PROP + i];
+        if (leg == 1) { hd[57] = root_h; hd[58] = blv.x * c.s_lin_vel; hd[59] = blv.y * c.s_lin_vel; hd[60] = blv.z * c.s_lin_vel; }
+        if (leg == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hd[61 + i] = p.mass_params[(int64_t)env * 4 + i];
+            hd[65] = fric;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { hd[66 + 3 * leg + k] = sp[k] - 1.0f; hd[78 + 3 * leg + k] = sd[k] - 1.0f; }
+    }
+    wave_lds_sync();
+    if (c.add_noise) {
+        // draw i (0..31) -> obs index i (<29) or 58 + (i - 29); lane handles blocks 2*leg, 2*leg+1
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            F4 u = rng4(c.seed, env, step, RS_NOISE, 2 * leg + b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int i = 4 * (2 * leg + b) + e;
+                int idx = i < 29 ? i : 58 + (i - 29);
+                // arithmetic blend, not a select chain over config fields (see resample_commands)
+                const float sc = (idx < 2 ? 1.f : 0.f) * c.noise_roll_pitch + ((idx >= 2 && idx < 5) ? 1.f : 0.f) * c.noise_ang_vel + ((idx >= 5 && idx < 17) ? 1.f : 0.f) * c.noise_dof_pos +
+                                 ((idx >= 17 && idx < 29) ? 1.f : 0.f) * c.noise_dof_vel + (idx >= 29 ? 1.f : 0.f) * c.noise_lin_vel;
+                if (owner) sst[S_HEAD + idx] += (2.0f * u.v[e] - 1.0f) * sc;
+            }
+        }
+    }
+    QA_STAMP(8);
+    // ---- per-env scalars and small rows, written by the quad
+    if (valid) {
+        float *rt = p.root + (int64_t)env * 13;
+        if (leg == 0) {
+            rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
+            rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
+            if (!PLANE) p.scan_height[env] = scan_h;
+            p.rew[env] = rew; p.reset[env] = reset; p.time_out[env] = (uint8_t)timeout; p.episode_length[env] = epl;
+            float *o3;
+            o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
+            o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = bav.x; o3[1] = bav.y; o3[2] = bav.z;
+            o3 = p.proj_grav + (int64_t)env * 3; o3[0] = pg.x; o3[1] = pg.y; o3[2] = pg.z;
+            o3 = p.rpy + (int64_t)env * 3; o3[0] = roll; o3[1] = pitch; o3[2] = yaw;
+            float *lr = p.last_root_vel + (int64_t)env * 6; lr[0] = lav.x; lr[1] = lav.y; lr[2] = lav.z; lr[3] = law.x; lr[4] = law.y; lr[5] = law.z;
+            if (cmd_dirty) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { p.commands[(int64_t)env * 5 + i] = cmd[i]; p.latent_c[(int64_t)env * 5 + i] = (gait == i) ? 1.0f : 0.0f; }
+                p.latent_eps[env] = eps;
+            }
+        }
+        float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+            d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
+            p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k];
+            p.last_actions[j] = act[k]; p.last_dof_vel[j] = st.qd[k]; p.last_torques_org[j] = tau_org[k];   // :158-161
+        }
+        p.feet_force[(int64_t)env * 4 + leg] = ffn;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = reset ? 0.f : fimp[k];
+        p.last_contacts[(int64_t)env * 4 + leg] = contact;
+        p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
+#pragma unroll
+        for (int r = 0; r < QA_NUM_REWARDS; ++r) if ((r & 3) == leg) p.episode_sums[(int64_t)r * N + env] = esum[r];
+        if (reset) {   // action history is zeroed by reset_idx (:227)
+            float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
+#pragma unroll
+            for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
+        }
+    }
+    wave_lds_sync();
+
+    QA_STAMP(9);
+    // ---- wave-cooperative row writes.  The complete 671-float observation row of every env of the block is
+    // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
+    // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
+    const float clipo = c.clip_obs;
+    const int lane = tix;
+    // history loads run one group ahead of the assembly (double-buffered in registers): the HBM latency of group
+    // k+1's 36 loads is hidden behind the LDS assembly and the row stores of group k
+    float hvb[2][OBS_GROUP][9];
+    auto load_hist = [&](int buf, int e0) {
+#pragma unroll
+        for (int g = 0; g < OBS_GROUP; ++g) {          // 8 full wave loads + 1 single-lane load per env
+            const int ge = min((int)(bix * EPB) + e0 + g, N - 1);
+            const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
+#pragma unroll
+            for (int r = 0; r < 8; ++r) hvb[buf][g][r] = hist[QA_BLOCK * r];
+            hvb[buf][g][8] = (lane == 0) ? hist[512] : 0.f;
+        }
+    };
+    load_hist(0, 0);
+#pragma unroll
+    for (int gi = 0; gi < EPB / OBS_GROUP; ++gi) {
+        const int e0 = gi * OBS_GROUP;
+        if (gi + 1 < EPB / OBS_GROUP) load_hist((gi + 1) & 1, e0 + OBS_GROUP);
+        float (&hv)[OBS_GROUP][9] = hvb[gi & 1];
+        if (e0) wave_lds_sync();                       // the previous group's row stores have read their LDS rows
+#pragma unroll
+        for (int g = 0; g < OBS_GROUP; ++g) {
+            const int e = e0 + g, ge = (int)(bix * EPB) + e;
+            if (ge < N) {
+                const float *ss = s_stage + e * S_ENV;
+                const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
+                float *row = s_rows + g * S_ROW + ((4 - head) & 3);
+                const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
+                const float pr = (lane < 57) ? clampf(ss[S_PROP + lane], -clipo, clipo) : 0.f;
+                if (!rf) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { float v = clampf(hv[g][r], -clipo, clipo); row[90 + lane + QA_BLOCK * r] = v; }
+                    if (lane == 0) { float v = clampf(hv[g][8], -clipo, clipo); row[90 + 512] = v; }
+                } else {                                 // first observation of an episode: all ten slots = current frame
+                    for (int i = lane; i < 513; i += QA_BLOCK) { float v = clampf(ss[S_PROP + (i % 57)], -clipo, clipo); row[90 + i] = v; }
+                }
+                if (lane < 57) row[603 + lane] = pr;
+                row[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
+                if (lane < 26) row[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
+                if (lane < 11) row[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
+                if (lane < QA_NUM_OBS_DISC) {
+                    float dv = ss[S_DISC + lane];
+                    p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + lane] = dv;
+                    p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
+                }
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int g = 0; g < OBS_GROUP; ++g) {
+            const int ge = bix * EPB + e0 + g;
+            if (ge < N) {
+                float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
+                const int head = obs_row_head(dst);
+                store_obs_row(dst, s_rows + g * S_ROW + ((4 - head) & 3), head);
+            }
+        }
+    }
+    QA_STAMP(10);
+}
+
 // LPE = lanes per env: 4 (lane&3 = leg) or 16 (lane = 16 env + 4 leg + sub; plane terrain only, qa_physics16.h)
 // With 16 lanes per env a workgroup is FOUR wavefronts (16 envs, as with 4 lanes): the hardware spreads the wavefronts
 // of one workgroup over the four SIMDs of a CU, whereas four single-wavefront workgroups of a kernel that needs <= 256
@@ -261,6 +675,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     float *s_priv = s_u, *s_patch = s_u + QA_PRIV_FLOATS * QA_PRIV_STRIDE;
     float *s_stage = s_u, *s_rows = s_u + EPB * S_ENV;
     static_assert((EPB * S_ENV) % 4 == 0, "row buffer must stay 16-byte aligned");
+    long long *const qa_prof = a.prof;
     QA_STAMP(0);
     stage_table(s_tbl);
     if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
@@ -415,305 +830,61 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         }
     }
 
+    if (c.export_body_state && valid) write_body_state(p.rbstate + (int64_t)env * (QA_NUM_BODIES_ABI * 13), st, R, org, leg);
     QA_STAMP(4);
-    // =========================== post_physics_step (legged_robot.py:124-166) ===========================
-    int64_t epl = p.episode_length[env] + 1;
-    const int64_t common = step + 1;
-    V3 blv = quat_rot(st.qx, st.qy, st.qz, st.qw, st.vw, -1.f), bav = quat_rot(st.qx, st.qy, st.qz, st.qw, st.ww, -1.f);
-    V3 pg = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(0, 0, -1), -1.f);
-    float roll = atan2f(2.0f * (st.qw * st.qx + st.qy * st.qz), 1.0f - 2.0f * (st.qx * st.qx + st.qy * st.qy));
-    float pitch = asinf(clampf(2.0f * (st.qw * st.qy - st.qz * st.qx), -1.0f, 1.0f));
-    float yaw = atan2f(2.0f * (st.qw * st.qz + st.qx * st.qy), 1.0f - 2.0f * (st.qy * st.qy + st.qz * st.qz));
-    const float ffn = sqrtf(dot(co.foot_f, co.foot_f));
-    const uint8_t contact = ffn > 2.0f;
-    const uint8_t cfilt = contact | p.last_contacts[(int64_t)env * 4 + leg];
+    PostIn in;
+    in.st = st; in.foot_f = co.foot_f; in.hip_f = hip_f; in.thigh_f = thigh_f; in.calf_f = calf_f; in.base_f = base_f; in.foot_w = foot_w; in.fric = fric;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in.act[k] = act[k]; in.raw_act[k] = raw_act[k]; in.tau[k] = tau[k]; in.tau_org[k] = tau_org[k]; in.sp[k] = sp[k]; in.sd[k] = sd[k]; in.fimp[k] = fimp[k]; }
+    post_physics_phase<PLANE, LPE>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step);
+    // the device-side step counter advances once every wavefront of the launch is done with it (they all read it at their
+    // start): the last one to arrive resets the arrival counter and bumps the step -- no separate 1-thread launch per env step
+    if (a.step_ptr && tix == 0) {
+        __threadfence();
+        const int total = (int)gridDim.x * WPB;
+        if (atomicAdd(p.ticket, 1) == total - 1) { *p.ticket = 0; *a.step_ptr = step + 1; __threadfence(); }
+    }
+}
 
-    // commands / latents in registers (replicated)
-    float cmd[5], eps; int gait = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) cmd[i] = p.commands[(int64_t)env * 5 + i];
-    eps = p.latent_eps[env];
+// post_physics_step alone, from the arena (qa_debug_post_physics): the PostIn record is loaded instead of computed
+template <bool PLANE>
+__global__ void __launch_bounds__(QA_BLOCK) qa_post_physics_kernel(StepArgs a) {
+    constexpr int LPE = 4, EPB = QA_BLOCK / LPE;
+    const int tix = threadIdx.x & (QA_BLOCK - 1), bix = blockIdx.x;
+    __shared__ float s_tbl[QA_TBL_FLOATS];
+    constexpr int U_OBS = (EPB * S_ENV + OBS_GROUP * S_ROW + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float s_u[U_OBS];
+    stage_table(s_tbl);
+    const qa_config &c = a.c;
+    const Ptrs &p = a.p;
+    const int N = c.num_envs, tid = bix * QA_BLOCK + tix, leg = tix & 3, env_raw = tid / LPE;
+    const bool valid = env_raw < N;
+    const int env = valid ? env_raw : N - 1, le = tix / LPE;
+    const int64_t step = a.step;
+    if (bix == 0 && tix < 16) p.episode_stats[16 * ((step + 1) & 1) + tix] = 0.f;
+    PostIn in;
     {
-        float best = p.latent_c[(int64_t)env * 5];
-#pragma unroll
-        for (int g = 1; g < 5; ++g) { float v = p.latent_c[(int64_t)env * 5 + g]; if (v > best) { best = v; gait = g; } }
-    }
-    bool cmd_dirty = false;
-    if (__any(epl % c.resampling_steps == 0)) {
-        float c2[5], e2; int g2;
-        resample_commands(c, p.prior, env, step, RS_CMD, c2, e2, g2);
-        if (epl % c.resampling_steps == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) cmd[i] = c2[i];
-            eps = e2; gait = g2; cmd_dirty = true;
-        }
-    }
-    if (c.push_robots && (common % c.push_interval == 0)) {   // uniform over the grid
-        F4 u = rng4(c.seed, env, step, RS_PUSH, 0);
-        st.vw.x = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[0] + -c.max_push_vel_xy;
-        st.vw.y = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[1] + -c.max_push_vel_xy;
-    }
-    // measured_heights (:469-470): before any reset, like the reference's callback
-    const float scan_h = PLANE ? 0.0f : scan_center_height(T, st.pos, st.qz, st.qw);
-    // ---- check_termination :168-176
-    int term_c = (sqrtf(dot(hip_f, hip_f)) > 1.0f) ? 1 : 0;
-    term_c = xor_<LPE>(term_c) | (sqrtf(dot(base_f, base_f)) > 1.0f ? 1 : 0);
-    int timeout = (epl > c.max_episode_length) || (st.pos.z < -6.0f);
-    {
-        float chk = st.pos.x + st.pos.y + st.pos.z + st.qx + st.qy + st.qz + st.qw + st.vw.x + st.vw.y + st.vw.z + st.ww.x + st.ww.y + st.ww.z;
-        if (!isfinite(chk)) timeout = 1;          // build-added failure detection
-    }
-    const int reset = term_c | timeout;
-
-    QA_STAMP(5);
-    // ---- rewards :242-259, alphabetical order
-    float term[QA_NUM_REWARDS];
-    {
-        const float dtp = c.sim_dt * (float)c.decimation;
-        float s_ar = 0, s_dt = 0, s_acc = 0, s_err = 0, s_hip = 0, s_pl = 0, s_vl = 0, s_tl = 0, s_tq = 0;
+        const float *r = p.root + (int64_t)env * 13;
+        in.st.pos = v3(r[0], r[1], r[2]); in.st.qx = r[3]; in.st.qy = r[4]; in.st.qz = r[5]; in.st.qw = r[6];
+        in.st.vw = v3(r[7], r[8], r[9]); in.st.ww = v3(r[10], r[11], r[12]);
+        const float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+        const float *cf = p.cforce + (int64_t)env * 57, *m = cf + 3 * (3 + 4 * leg), *rb = p.rbpos + (int64_t)env * 57 + 3 * (3 + 4 * leg + 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int64_t j = (int64_t)env * 12 + 3 * leg + k;
-            float d;
-            d = p.last_actions[j] - act[k]; s_ar += d * d;
-            d = tau_org[k] - p.last_torques_org[j]; s_dt += d * d;
-            d = (p.last_dof_vel[j] - st.qd[k]) / dtp; s_acc += d * d;
-            d = st.q[k] - q0[k]; s_err += d * d; if (k == 0) s_hip += d * d;
-            float lo = tbl[T_LOWER + k], hi = tbl[T_UPPER + k], mid = (lo + hi) / 2, rng = hi - lo;
-            float slo = mid - 0.5f * rng * c.soft_dof_pos_limit, shi = mid + 0.5f * rng * c.soft_dof_pos_limit;
-            s_pl += -fminf(st.q[k] - slo, 0.f) + fmaxf(st.q[k] - shi, 0.f);
-            s_vl += clampf(fabsf(st.qd[k]) - tbl[T_VELLIM + k] * c.soft_dof_vel_limit, 0.f, 1.f);
-            s_tl += fmaxf(fabsf(tau_org[k]) - tbl[T_EFFORT + k] * c.soft_torque_limit, 0.f);
-            s_tq += tau_org[k] * tau_org[k];
+            in.st.q[k] = d[2 * k]; in.st.qd[k] = d[2 * k + 1];
+            in.act[k] = p.actions[j]; in.raw_act[k] = p.action_hist[(int64_t)env * (QA_ACTION_BUF_LEN * 12) + 12 * (QA_ACTION_BUF_LEN - 1) + 3 * leg + k];
+            in.tau[k] = p.torques[j]; in.tau_org[k] = p.torques_org[j]; in.fimp[k] = p.foot_impulse[j];
+            in.sp[k] = c.randomize_motor ? p.motor_strength[((int64_t)0 * N + env) * 12 + 3 * leg + k] : 1.0f;
+            in.sd[k] = c.randomize_motor ? p.motor_strength[((int64_t)1 * N + env) * 12 + 3 * leg + k] : 1.0f;
         }
-        float ncol = (sqrtf(dot(thigh_f, thigh_f)) > 0.1f ? 1.f : 0.f) + (sqrtf(dot(calf_f, calf_f)) > 0.1f ? 1.f : 0.f);
-        term[QA_R_ACTION_RATE] = xsum<LPE>(s_ar); term[QA_R_COLLISION] = xsum<LPE>(ncol); term[QA_R_DELTA_TORQUES] = xsum<LPE>(s_dt);
-        term[QA_R_DOF_ACC] = xsum<LPE>(s_acc); term[QA_R_DOF_ERROR] = xsum<LPE>(s_err); term[QA_R_DOF_POS_LIMITS] = xsum<LPE>(s_pl);
-        term[QA_R_DOF_VEL_LIMITS] = xsum<LPE>(s_vl); term[QA_R_HIP_POS] = xsum<LPE>(s_hip); term[QA_R_TORQUE_LIMITS] = xsum<LPE>(s_tl);
-        term[QA_R_TORQUES] = xsum<LPE>(s_tq);
-        const float root_h = st.pos.z - scan_h;
-        float ej = sqrtf((cmd[3] - root_h) * (cmd[3] - root_h));
-        term[QA_R_JUMP_UP_HEIGHT] = (ej < 0.05f && cmd[3] >= c.jump_height[0]) ? c.jump_goal : 0.f;
-        float el = sqrtf((cmd[4] - root_h) * (cmd[4] - root_h));
-        term[QA_R_LOCOMOTION_HEIGHT] = (cmd[3] > c.jump_height[0]) ? 0.f : expf(-10.0f * (el * el) / c.tracking_sigma);
-        float ea = (cmd[2] - bav.z) * (cmd[2] - bav.z);
-        term[QA_R_TRACKING_ANG_VEL] = expf(-ea / c.tracking_sigma);
-        float elv = (cmd[0] - blv.x) * (cmd[0] - blv.x) + (cmd[1] - blv.y) * (cmd[1] - blv.y);
-        term[QA_R_TRACKING_LIN_VEL] = expf(-elv / c.tracking_sigma);
+        in.hip_f = v3(m[0], m[1], m[2]); in.thigh_f = v3(m[3], m[4], m[5]); in.calf_f = v3(m[6], m[7], m[8]); in.foot_f = v3(m[9], m[10], m[11]);
+        in.base_f = v3(cf[0], cf[1], cf[2]);
+        in.foot_w = v3(rb[0], rb[1], rb[2]);
+        in.fric = p.friction[env];
     }
-    float rew = 0.f;
-    float esum[QA_NUM_REWARDS];
-#pragma unroll
-    for (int r = 0; r < QA_NUM_REWARDS; ++r) {
-        esum[r] = p.episode_sums[(int64_t)r * N + env];
-        if (c.reward_scale_dt[r] != 0.0f) { float v = term[r] * c.reward_scale_dt[r]; rew += v; esum[r] += v; }
-    }
-    if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
-
-    QA_STAMP(6);
-    wave_lds_sync();          // physics scratch is dead from here on; the staging area takes its place
-    // ---- terminal disc obs = previous OBS_DISC row; stage it
-    float *sst = s_stage + le * S_ENV;
-    for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
-
-    // ---- reset_idx :178-240
-    V3 lav = st.vw, law = st.ww;      // last_root_vel is taken after the reset (:160)
-    if (__any(reset)) {
-        if (reset) {
-#pragma unroll
-            for (int r = 0; r < QA_NUM_REWARDS; ++r) {
-                if ((r & 3) == leg && valid) atomicAdd(&p.episode_stats[16 * (step & 1) + r], esum[r]);
-                esum[r] = 0.f;
-            }
-            if (leg == 0 && valid) atomicAdd(&p.episode_stats[16 * (step & 1) + 14], 1.0f);
-            reset_env(c, p, a.mi, env, leg, step, st, cmd, eps, gait);
-            cmd_dirty = true;
-            epl = 0;
-            lav = st.vw; law = st.ww;
-        }
-    }
-    const bool refill = epl <= 1;
-
-    QA_STAMP(7);
-    // ---- observations :261-331
-    // heading-inverse rotation of the (stale for reset envs) foot position, torch_jit_utils.py:23-76
-    V3 key;
-    {
-        V3 rd = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(1, 0, 0), 1.f);
-        float heading = atan2f(rd.y, rd.x);
-        float sh, ch; sincosf(-0.5f * heading, &sh, &ch);
-        float hn = rsqrtf(sh * sh + ch * ch);
-        V3 rel = foot_w - st.pos;
-        key = quat_rot(0.f, 0.f, sh * hn, ch * hn, rel, 1.f);
-    }
-    const float root_h = st.pos.z - scan_h;      // post-reset z, pre-reset measured height (:261-273 after :178)
-    // proprioception (57): lanes write their own joints, lane 0 the shared entries
-    {
-        float *pr = sst + S_PROP;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int j = 3 * leg + k;
-            pr[5 + j] = (st.q[k] - q0[k]) * c.s_dof_pos;
-            pr[17 + j] = st.qd[k] * c.s_dof_vel;
-            pr[29 + j] = reset ? 0.0f : raw_act[k];      // reset_idx zeroes the action history first (:227)
-            pr[45 + j] = 0.0f * (k == 0 ? key.x : (k == 1 ? key.y : key.z));
-            sst[S_DISC + 9 + j] = (st.q[k] - q0[k]) * c.s_dof_pos;
-            sst[S_DISC + 21 + j] = st.qd[k] * c.s_dof_vel;
-            sst[S_DISC + 33 + j] = (k == 0 ? key.x : (k == 1 ? key.y : key.z)) * c.s_key_pos;
-        }
-        pr[41 + leg] = (cfilt ? 1.0f : 0.0f) - 0.5f;
-        sst[S_DISC + 45 + leg] = (cfilt ? 1.0f : 0.0f) * c.s_foot_contact;
-        if (leg == 0) {
-            pr[0] = roll; pr[1] = pitch; pr[2] = bav.x * c.s_ang_vel; pr[3] = bav.y * c.s_ang_vel; pr[4] = bav.z * c.s_ang_vel;
-            sst[S_DISC + 0] = roll; sst[S_DISC + 1] = pitch; sst[S_DISC + 2] = root_h;
-            sst[S_DISC + 3] = blv.x * c.s_lin_vel_dist; sst[S_DISC + 4] = blv.y * c.s_lin_vel_dist; sst[S_DISC + 5] = blv.z * c.s_lin_vel_dist;
-            sst[S_DISC + 6] = bav.x * c.s_ang_vel_dist; sst[S_DISC + 7] = bav.y * c.s_ang_vel_dist; sst[S_DISC + 8] = bav.z * c.s_ang_vel_dist;
-            sst[S_FLAGS] = refill ? 1.0f : 0.0f;
-            sst[S_FLAGS + 1] = reset ? 1.0f : 0.0f;
-            // tail: commands, eps, one-hot gait
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { sst[S_TAIL + i] = cmd[i]; sst[S_TAIL + 6 + i] = (gait == i) ? 1.0f : 0.0f; }
-            sst[S_TAIL + 5] = eps;
-        }
-    }
-    wave_lds_sync();
-    // head of the obs row: prop + explicit + latent, with noise on the 32 noisy entries
-    {
-        float *hd = sst + S_HEAD;
-        for (int i = leg; i < QA_NUM_PROP; i += 4) hd[i] = sst[S_PROP + i];
-        if (leg == 1) { hd[57] = root_h; hd[58] = blv.x * c.s_lin_vel; hd[59] = blv.y * c.s_lin_vel; hd[60] = blv.z * c.s_lin_vel; }
-        if (leg == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hd[61 + i] = p.mass_params[(int64_t)env * 4 + i];
-            hd[65] = fric;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { hd[66 + 3 * leg + k] = sp[k] - 1.0f; hd[78 + 3 * leg + k] = sd[k] - 1.0f; }
-    }
-    wave_lds_sync();
-    if (c.add_noise) {
-        // draw i (0..31) -> obs index i (<29) or 58 + (i - 29); lane handles blocks 2*leg, 2*leg+1
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            F4 u = rng4(c.seed, env, step, RS_NOISE, 2 * leg + b);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int i = 4 * (2 * leg + b) + e;
-                int idx = i < 29 ? i : 58 + (i - 29);
-                float sc = idx < 2 ? c.noise_roll_pitch : (idx < 5 ? c.noise_ang_vel : (idx < 17 ? c.noise_dof_pos : (idx < 29 ? c.noise_dof_vel : c.noise_lin_vel)));
-                if (owner) sst[S_HEAD + idx] += (2.0f * u.v[e] - 1.0f) * sc;
-            }
-        }
-    }
-    QA_STAMP(8);
-    // ---- per-env scalars and small rows, written by the quad
-    if (valid) {
-        float *rt = p.root + (int64_t)env * 13;
-        if (leg == 0) {
-            rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
-            rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
-            if (!PLANE) p.scan_height[env] = scan_h;
-            p.rew[env] = rew; p.reset[env] = reset; p.time_out[env] = (uint8_t)timeout; p.episode_length[env] = epl;
-            float *o3;
-            o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
-            o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = bav.x; o3[1] = bav.y; o3[2] = bav.z;
-            o3 = p.proj_grav + (int64_t)env * 3; o3[0] = pg.x; o3[1] = pg.y; o3[2] = pg.z;
-            o3 = p.rpy + (int64_t)env * 3; o3[0] = roll; o3[1] = pitch; o3[2] = yaw;
-            float *lr = p.last_root_vel + (int64_t)env * 6; lr[0] = lav.x; lr[1] = lav.y; lr[2] = lav.z; lr[3] = law.x; lr[4] = law.y; lr[5] = law.z;
-            if (cmd_dirty) {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) { p.commands[(int64_t)env * 5 + i] = cmd[i]; p.latent_c[(int64_t)env * 5 + i] = (gait == i) ? 1.0f : 0.0f; }
-                p.latent_eps[env] = eps;
-            }
-        }
-        float *d = p.dof + (int64_t)env * 24 + 6 * leg;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
-            d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
-            p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k];
-            p.last_actions[j] = act[k]; p.last_dof_vel[j] = st.qd[k]; p.last_torques_org[j] = tau_org[k];   // :158-161
-        }
-        p.feet_force[(int64_t)env * 4 + leg] = ffn;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = reset ? 0.f : fimp[k];
-        p.last_contacts[(int64_t)env * 4 + leg] = contact;
-        p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
-#pragma unroll
-        for (int r = 0; r < QA_NUM_REWARDS; ++r) if ((r & 3) == leg) p.episode_sums[(int64_t)r * N + env] = esum[r];
-        if (reset) {   // action history is zeroed by reset_idx (:227)
-            float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
-#pragma unroll
-            for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
-        }
-    }
-    wave_lds_sync();
-
-    QA_STAMP(9);
-    // ---- wave-cooperative row writes.  The complete 671-float observation row of every env of the block is
-    // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
-    // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
-    const float clipo = c.clip_obs;
-    const int lane = tix;
-    // history loads run one group ahead of the assembly (double-buffered in registers): the HBM latency of group
-    // k+1's 36 loads is hidden behind the LDS assembly and the row stores of group k
-    float hvb[2][OBS_GROUP][9];
-    auto load_hist = [&](int buf, int e0) {
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {          // 8 full wave loads + 1 single-lane load per env
-            const int ge = min((int)(bix * EPB) + e0 + g, N - 1);
-            const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
-#pragma unroll
-            for (int r = 0; r < 8; ++r) hvb[buf][g][r] = hist[QA_BLOCK * r];
-            hvb[buf][g][8] = (lane == 0) ? hist[512] : 0.f;
-        }
-    };
-    load_hist(0, 0);
-#pragma unroll
-    for (int gi = 0; gi < EPB / OBS_GROUP; ++gi) {
-        const int e0 = gi * OBS_GROUP;
-        if (gi + 1 < EPB / OBS_GROUP) load_hist((gi + 1) & 1, e0 + OBS_GROUP);
-        float (&hv)[OBS_GROUP][9] = hvb[gi & 1];
-        if (e0) wave_lds_sync();                       // the previous group's row stores have read their LDS rows
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {
-            const int e = e0 + g, ge = (int)(bix * EPB) + e;
-            if (ge < N) {
-                const float *ss = s_stage + e * S_ENV;
-                const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
-                float *row = s_rows + g * S_ROW + ((4 - head) & 3);
-                const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
-                const float pr = (lane < 57) ? clampf(ss[S_PROP + lane], -clipo, clipo) : 0.f;
-                if (!rf) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) { float v = clampf(hv[g][r], -clipo, clipo); row[90 + lane + QA_BLOCK * r] = v; }
-                    if (lane == 0) { float v = clampf(hv[g][8], -clipo, clipo); row[90 + 512] = v; }
-                } else {                                 // first observation of an episode: all ten slots = current frame
-                    for (int i = lane; i < 513; i += QA_BLOCK) { float v = clampf(ss[S_PROP + (i % 57)], -clipo, clipo); row[90 + i] = v; }
-                }
-                if (lane < 57) row[603 + lane] = pr;
-                row[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
-                if (lane < 26) row[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
-                if (lane < 11) row[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
-                if (lane < QA_NUM_OBS_DISC) {
-                    float dv = ss[S_DISC + lane];
-                    p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + lane] = dv;
-                    p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
-                }
-            }
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {
-            const int ge = bix * EPB + e0 + g;
-            if (ge < N) {
-                float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
-                const int head = obs_row_head(dst);
-                store_obs_row(dst, s_rows + g * S_ROW + ((4 - head) & 3), head);
-            }
-        }
-    }
-    QA_STAMP(10);
+    TerrainView T = terrain_view(c, p, s_u);
+    post_physics_phase<PLANE, LPE>(c, p, a.mi, nullptr, in, T, s_tbl + leg * QA_LEG_TBL, s_u, s_u + EPB * S_ENV, tix, bix, env, leg, valid, true, le, step);
 }
 
 // ------------------------------------------------------------------ init / reset / simulate kernels
@@ -839,6 +1010,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     }
     cf[3 * (myb + 3)] = co.foot_f.x; cf[3 * (myb + 3) + 1] = co.foot_f.y; cf[3 * (myb + 3) + 2] = co.foot_f.z;
     { V3 w = mul(R, org[3]) + st.pos; rb[3 * (myb + 3)] = w.x; rb[3 * (myb + 3) + 1] = w.y; rb[3 * (myb + 3) + 2] = w.z; }
+    if (c.export_body_state) write_body_state(p.rbstate + (int64_t)env * (QA_NUM_BODIES_ABI * 13), st, R, org, leg);
     float *dd = p.dof + (int64_t)env * 24 + 6 * leg;
     for (int k = 0; k < 3; ++k) { dd[2 * k] = st.q[k]; dd[2 * k + 1] = st.qd[k]; p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = fimp[k]; }
     if (leg == 0) {
@@ -914,6 +1086,9 @@ static void fill_ptrs(qa_sim *s) {
     p.time_out = (uint8_t *)(a + L.off[QA_T_TIME_OUT]); p.last_contacts = (uint8_t *)(a + L.off[QA_T_LAST_CONTACTS]);
     p.contact_filt = (uint8_t *)(a + L.off[QA_T_CONTACT_FILT]);
     p.height_samples = (int16_t *)(a + L.off[QA_T_HEIGHT_SAMPLES]);
+    p.rbstate = (float *)(a + L.off[QA_T_RIGID_BODY_STATE]);
+    p.mocap_clips = (double *)(a + L.off[QA_T_MOCAP_CLIPS]);
+    p.ticket = (int32_t *)(a + L.off[QA_T_STEP_TICKET]);
 }
 
 static void build_table(float *t) {
@@ -987,14 +1162,24 @@ int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
 
 int qa_destroy(qa_sim *s) { delete s; return QA_OK; }
 
-int qa_set_mocap(qa_sim *s, const float *frames, int32_t nf, const int32_t first[QA_NUM_GAITS + 1], void *stream) {
-    if (!s || !frames || !first || nf <= 0 || nf > s->cfg.num_mocap_frames) return QA_E_ARG;
+int qa_set_mocap(qa_sim *s, const float *frames, int32_t nf, const double *clips, int32_t nc, const int32_t first[QA_NUM_GAITS + 1], void *stream) {
+    if (!s || !frames || !clips || !first || nf <= 0 || nf > s->cfg.num_mocap_frames || nc <= 0 || nc > QA_MAX_MOCAP_CLIPS) return QA_E_ARG;
+    if (first[0] != 0 || first[QA_NUM_GAITS] != nc) return QA_E_ARG;
+    for (int g = 0; g < QA_NUM_GAITS; ++g) if (first[g + 1] <= first[g]) { snprintf(g_err, sizeof(g_err), "qa_set_mocap: gait %d has no clip", g); return QA_E_ARG; }
+    for (int i = 0; i < nc; ++i) {
+        const double *r = clips + QA_MOCAP_CLIP * i;
+        if (r[0] < 0 || r[1] < 2 || r[0] + r[1] > nf || !(r[2] > 0) || !(r[3] > 0) || r[3] > r[2]) { snprintf(g_err, sizeof(g_err), "qa_set_mocap: bad clip row %d", i); return QA_E_ARG; }
+    }
     HIP_TRY(hipMemcpyAsync(s->p.mocap, frames, (size_t)nf * QA_MOCAP_FRAME * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    memset(s->clip_stage, 0, sizeof(s->clip_stage));
+    for (int i = 0; i < nc; ++i) for (int k = 0; k < 5; ++k) s->clip_stage[QA_MOCAP_CLIP * i + k] = clips[QA_MOCAP_CLIP * i + k];
+    for (int g = 0; g <= QA_NUM_GAITS; ++g) s->clip_stage[QA_MOCAP_CLIP * g + 5] = (double)first[g];
+    HIP_TRY(hipMemcpyAsync(s->p.mocap_clips, s->clip_stage, sizeof(s->clip_stage), hipMemcpyHostToDevice, (hipStream_t)stream));
     memcpy(s->mocap_first, first, sizeof(s->mocap_first));
     return QA_OK;
 }
 
-static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; memcpy(m.first, s->mocap_first, sizeof(m.first)); return m; }
+static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; m.on = s->mocap_first[QA_NUM_GAITS] > 0; return m; }
 
 static void launch_env_step(qa_sim *s, const StepArgs &a, hipStream_t st) {
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
@@ -1011,14 +1196,11 @@ int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t gl
     return QA_OK;
 }
 
-__global__ void qa_tick_kernel(int64_t *ctr) { *ctr += 1; }
-
 int qa_env_step_dev(qa_sim *s, const float *actions, int32_t delay_steps, int64_t *step_counter_dev, void *stream) {
     if (!s || !actions || !step_counter_dev || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = 0;
     a.step_ptr = step_counter_dev; a.prof = s->prof;
     launch_env_step(s, a, (hipStream_t)stream);
-    hipLaunchKernelGGL(qa_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter_dev);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }
@@ -1037,6 +1219,16 @@ int qa_simulate(qa_sim *s, const float *torques, void *stream) {
     if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_simulate_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
     else if (s->lanes == 16) hipLaunchKernelGGL((qa_simulate_kernel<true, 16>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
     else hipLaunchKernelGGL((qa_simulate_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+int qa_debug_post_physics(qa_sim *s, int64_t global_step, void *stream) {
+    if (!s) return QA_E_ARG;
+    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = nullptr; a.delay = 0; a.step = global_step; a.step_ptr = nullptr; a.prof = nullptr;
+    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_post_physics_kernel<false>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((qa_post_physics_kernel<true>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }

@@ -257,7 +257,8 @@ class LeggedRobot:
         from quadrupedal_agility_amd.rsl_rl.datasets.motion_loader import MotionLoader
         loader = MotionLoader(device="cpu", motion_files_lb=self.cfg.env.motion_files_lb, motion_files_ulb=[],
                               mocap_category=self.mocap_category, time_between_frames=self.dt, mocap_state_init=True)
-        return loader.reset_state_table(frames_per_gait=4096, seed=int(getattr(self.cfg, "seed", 1)))
+        self.mocap_source = loader.source
+        return loader.reset_clip_table()
 
     # ------------------------------------------------------------------ API
     def reset(self):
@@ -313,7 +314,12 @@ class LeggedRobot:
         """extras['episode'] / extras['time_outs'] of reset_idx (legged_robot.py:229-240) without a host sync:
         means over the envs that reset this step; when none reset the previous values are kept, like the
         reference keeps the dict of the last reset."""
-        st = self.sim.t["EPISODE_STATS"][(self.common_step_counter - 1) & 1]
+        if self._step_ctr is not None:
+            # recorded rollouts: the bin index must follow the DEVICE step counter (a host parity baked into a recording is only
+            # right when num_steps_per_env is even); the kernel accumulated into bin (step & 1) with step = counter - 1
+            st = self.sim.t["EPISODE_STATS"].index_select(0, (self._step_ctr - 1) & 1)[0]
+        else:
+            st = self.sim.t["EPISODE_STATS"][(self.common_step_counter - 1) & 1]
         cnt = st[14]
         mean = st[:_capi.NUM_REWARDS] / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
         # in place: `_episode_means` is a persistent buffer.  A recorded rollout bakes the ADDRESS of whatever tensor it

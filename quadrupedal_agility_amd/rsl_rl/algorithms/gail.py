@@ -704,15 +704,28 @@ class SSInfoGAIL:
             with torch.no_grad():
                 torch._foreach_add_([w.grad for w in reg_w[:-1]], reg_w[:-1], alpha=2.0 * self.disc_weight_decay)
                 reg_w[-1].grad.add_(reg_w[-1], alpha=2.0 * (self.disc_weight_decay + self.disc_logit_reg))
+        norm_batches = [policy_state, expert_lb, expert_ulb]
+        synced_moments = None
         if self.grad_sync is not None:
-            pred_mean = self.grad_sync(list(self.disc.parameters()), extra=[pred_mean])[0]
+            # ONE collective per discriminator step: gradients | class mean of the prior EMA | the normaliser's batch moments
+            extra = [pred_mean]
+            if self.disc_normalizer is not None and hasattr(self.disc_normalizer, "batch_moments"):
+                extra.append(self.disc_normalizer.batch_moments(norm_batches))
+            back = self.grad_sync(list(self.disc.parameters()), extra=extra)
+            pred_mean = back[0]
+            if len(back) > 1:
+                synced_moments = back[1].view(len(norm_batches), 2, -1)
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
         for o in self._step_disc:
             o.step()
         if not self._recording_disc:          # the recorded step leaves this to update(): once after the loop is the same thing
             self._clamp_std()
         if self.disc_normalizer is not None:
-            self.disc_normalizer.update_torch([policy_state, expert_lb, expert_ulb])
+            if synced_moments is not None:      # data-parallel: the moments of the GLOBAL batches, identical on every rank
+                world = self.grad_sync.world
+                self.disc_normalizer.update_from_batch_moments(synced_moments, [b.shape[0] * world for b in norm_batches])
+            else:
+                self.disc_normalizer.update_torch(norm_batches)
         if fused_heads:
             acc_lb, acc_pi, acc_exp, acc_ulb = hs[5], hs[6], hs[7], hs[8]
         else:

@@ -7,9 +7,12 @@ are 61 floats @ 30 Hz: root pos 3, root quat xyzw 4, joint pos 12, toe pos 12, l
 
 Differences: clips are concatenated into one device tensor with per-clip offsets so that batched
 frame lookup is a single gather (the reference loops over clips in Python with boolean masks);
-sampling uses a private numpy Generator instead of the global numpy RNG; `reset_state_table()`
-pre-samples the reset states that the HIP kernel draws from (qa_set_mocap).  With no files given
-(e.g. on a box without the dataset) `synthetic_clips()` provides clips of the same shape.
+sampling uses a private numpy Generator instead of the global numpy RNG; `reset_clip_table()` hands
+the labelled clips to the HIP kernel, which samples reset states from them the way
+`get_full_frame_batch` does (qa_set_mocap).  Clips come from the dataset's JSON files, or from the
+baked copy of the same dataset shipped with the package (`resources/go2_mocap.npz`,
+tools/bake_mocap.py: the reference's post-`reorder` float32 trajectories, so nothing is lost);
+`synthetic_clips()` is only the last resort when neither is there.
 """
 import json
 import os
@@ -53,6 +56,30 @@ def load_clip(path):
         js = json.load(fh)
     return {"frames": reorder_frames(js["Frames"]), "weight": float(js["MotionWeight"]), "dt": float(js["FrameDuration"]),
             "name": os.path.basename(path)}
+
+
+BAKED_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "resources", "go2_mocap.npz")
+
+
+def load_baked(path=None):
+    """The real dataset as baked by tools/bake_mocap.py: per clip the float32 (frames, 49) trajectory the reference keeps
+    after `reorder` + quaternion standardisation (columns 49:61, the toe velocities, are read by nothing), its MotionWeight,
+    FrameDuration and file name.  -> (labelled clips, unlabelled clips) or None when the file is not there."""
+    path = path or os.environ.get("QA_MOCAP_BAKED", BAKED_PATH)
+    if not os.path.exists(path):
+        return None
+    z = np.load(path, allow_pickle=False)
+    out = []
+    for tag in ("lb", "ulb"):
+        fr, cnt = z[f"{tag}_frames"], z[f"{tag}_counts"]
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        clips = []
+        for i in range(len(cnt)):
+            f = np.zeros((int(cnt[i]), 61), dtype=np.float64)
+            f[:, :49] = fr[off[i]:off[i + 1]]
+            clips.append({"frames": f, "weight": float(z[f"{tag}_weights"][i]), "dt": float(z[f"{tag}_dt"][i]), "name": str(z[f"{tag}_names"][i])})
+        out.append(clips)
+    return out[0], out[1]
 
 
 def synthetic_clips(categories, n_labeled_per_gait=3, n_unlabeled=30, frames=90, seed=0):
@@ -135,13 +162,19 @@ class MotionLoader:
         self.default_dof_pos, self.obs_scales = default_dof_pos, obs_scales
         self.rng = np.random.default_rng(seed)
         lb_files, ulb_files = list(motion_files_lb or []), list(motion_files_ulb or [])
-        self.synthetic = len(lb_files) == 0
-        if self.synthetic:
+        baked = load_baked() if len(lb_files) == 0 and os.environ.get("QA_MOCAP_SYNTHETIC") != "1" else None
+        self.synthetic = len(lb_files) == 0 and baked is None
+        self.source = "synthetic" if self.synthetic else ("baked" if baked is not None else "json")
+        if baked is not None:
+            lb, ulb = baked
+            lb = [c for c in lb if any(g in c["name"] for g in self.mocap_category)]
+        elif self.synthetic:
             lb, ulb = synthetic_clips(self.mocap_category, seed=seed)
         else:
             lb = [load_clip(p) for p in lb_files]
             ulb = [load_clip(p) for p in ulb_files] or lb
         self.mocap_label = np.array([self._label_of(c["name"]) for c in lb])
+        self.lb_names = [c["name"] for c in lb]
         self.lb = _ClipSet(lb, device, frame_duration_scale)
         # the unlabeled clips are treated as ONE long trajectory (motion_loader.py:181-187)
         merged = {"frames": np.concatenate([c["frames"] for c in ulb]), "weight": 1.0, "dt": ulb[0]["dt"], "name": "ulb"}
@@ -193,17 +226,30 @@ class MotionLoader:
                     traj[m] = self.weighted_traj_idx_sample_batch(int(m.sum()), labeled=True, target_type=i)
         return self.get_full_frame_at_time_batch(traj, self.traj_time_sample_batch(traj, labeled=True), labeled=True)
 
-    def reset_state_table(self, frames_per_gait=4096, seed=0):
-        """(G*K, 37) reset rows [root pos 3, quat 4, joint pos 12, lin vel 3, ang vel 3, joint vel 12] + row ranges per gait,
-        i.e. K pre-drawn results of get_full_frame_batch for every gait, for qa_set_mocap."""
-        saved, self.rng = self.rng, np.random.default_rng(seed)
-        rows, first = [], [0]
+    def reset_clip_table(self):
+        """What qa_set_mocap takes (include/qa_sim.h): the labelled clips' frames as (F, 37) rows [root pos 3, quat 4, joint
+        pos 12, lin vel 3, ang vel 3, joint vel 12] sorted by gait, the (C, 8) float64 clip table [first frame, frames, length,
+        sampling range, cumulative probability inside the gait] and the clip range of every gait.  The kernel then samples
+        exactly like get_full_frame_batch above (clip ~ weight inside the gait, time ~ U, frame blend) with its own generator."""
+        cs = self.lb
+        order = np.argsort(self.mocap_label, kind="stable")
+        frames, rows, first, at = [], [], [0], 0
         for g in range(len(self.mocap_category)):
-            fr = self.get_full_frame_batch(frames_per_gait, np.full(frames_per_gait, g))
-            rows.append(torch.cat([fr[:, 0:19], fr[:, 31:49]], dim=-1).cpu().numpy())
-            first.append(first[-1] + frames_per_gait)
-        self.rng = saved
-        return np.concatenate(rows).astype(np.float32), first
+            ids = [int(i) for i in order if self.mocap_label[i] == g]
+            if not ids:
+                raise ValueError(f"no labelled mocap clip for gait {self.mocap_category[g]!r}")
+            w = cs.weights[ids] / cs.weights[ids].sum()
+            cdf = np.cumsum(w); cdf /= cdf[-1]          # np.random.choice's own normalisation
+            for i, c in zip(ids, cdf):
+                n = int(cs.num_frames[i])
+                fr = cs.frames[int(cs.offset[i]):int(cs.offset[i]) + n].cpu().numpy()
+                frames.append(np.concatenate([fr[:, 0:19], fr[:, 31:49]], axis=1))
+                subst = self.time_between_frames * self.disc_obs_len + cs.dt[i]
+                rows.append([at, n, cs.lens[i], cs.lens[i] - subst, c, 0.0, 0.0, 0.0])
+                at += n
+            rows[-1][4] = 1.0
+            first.append(len(rows))
+        return np.concatenate(frames).astype(np.float32), np.asarray(rows, dtype=np.float64), first
 
     # ---- expert discriminator observations (:193-249)
     def disc_obs_from_frames(self, fr):

@@ -556,6 +556,20 @@ class OnPolicyRunner:
                     getattr(a, key).load_state_dict(d[key])
                 except Exception as e:      # e.g. a reference checkpoint whose Adam step counters live on the host
                     print(f"[load] optimizer state {key} not restored: {e}")
+        # Optimizer.load_state_dict replaces every group's 'lr' by a copy from the checkpoint (a float in a reference
+        # checkpoint): re-link the adaptive-KL learning rate tensor that qa_kl_lr_rule writes and ClipAdam / the recorded
+        # steps read, and restore the flags the loaded group dict overwrote
+        if a._on_gpu:
+            g0 = a.optim_ac.param_groups[0]
+            a._lr_ac.fill_(float(g0["lr"]))
+            for g in a.optim_ac.param_groups:
+                g["lr"] = a._lr_ac
+            for opt in (a.optim_ac, a.optim_hist_encoder, a.optim_estimator, a.optim_d, a.optim_q_eps, a.optim_q_c):
+                if isinstance(opt, torch.optim.Adam):
+                    for g in opt.param_groups:
+                        g["capturable"], g["fused"] = True, True
+        else:
+            a.lr_ac = float(a.optim_ac.param_groups[0]["lr"])
         self.current_learning_iteration = d["iter"]
         # recorded launches hold the addresses of the optimizer state they were captured with: start over
         a._ac_graph = a._dagger_graph = a._disc_graph = None

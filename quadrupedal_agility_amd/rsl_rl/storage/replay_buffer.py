@@ -15,7 +15,14 @@ class ReplayBuffer:
         self.num_samples = 0
 
     def insert(self, states, latent_eps, latent_c):
+        """Ring insert of n rows (a single env step, or a whole recorded rollout at once).  More rows than the ring holds: only
+        the newest buffer_size of them are kept; otherwise the rows go to (step + i) % size, so any number of wraps is fine."""
         n = states.shape[0]
+        if n >= self.buffer_size:
+            keep = slice(n - self.buffer_size, n)
+            self.states.copy_(states[keep]); self.latent_eps.copy_(latent_eps[keep]); self.latent_c.copy_(latent_c[keep])
+            self.step, self.num_samples = 0, self.buffer_size
+            return
         first = min(n, self.buffer_size - self.step)
         for dst, src in ((self.states, states), (self.latent_eps, latent_eps), (self.latent_c, latent_c)):
             dst[self.step:self.step + first].copy_(src[:first])

@@ -75,7 +75,7 @@ class RolloutStorage:
             adv = delta + alive * gamma * lam * adv
             self.returns[t] = adv + self.values[t]
         a = self.returns - self.values
-        self.advantages = (a - a.mean()) / (a.std() + 1e-8)
+        self.advantages.copy_((a - a.mean()) / (a.std() + 1e-8))      # in place: recorded PPO steps hold this buffer's address
 
     def get_statistics(self):
         done = self.dones.clone()

@@ -125,6 +125,32 @@ class TorchNormalizer:
     def update(self, arr):
         self.update_torch([torch.as_tensor(arr, device=self.device)])
 
+    # ---- data-parallel runs: every rank must fold the SAME (global) batch moments, otherwise the replicas normalise the
+    # discriminator's inputs differently (and only rank 0's moments reach model.pt).  The local first and second moments of
+    # the batches travel in the discriminator step's gradient bucket and come back averaged over the ranks.
+    @staticmethod
+    def batch_moments(batches):
+        """(k, 2, dim) fp32: per batch [mean, mean of squares] of the local rows"""
+        out = []
+        for b in batches:
+            b64 = b.detach().to(torch.float64)
+            out.append(torch.stack([b64.mean(dim=0), b64.square().mean(dim=0)]))
+        return torch.stack(out).to(torch.float32)
+
+    def update_from_batch_moments(self, moments, rows_per_batch):
+        """fold k batches given their (rank-averaged) [mean, mean of squares] and their GLOBAL row counts, in order --
+        RunningMeanStd.update_from_moments (utils.py:70-84) with the batch variance E[x^2] - E[x]^2"""
+        m = moments.to(torch.float64)
+        for i, n in enumerate(rows_per_batch):
+            bm = m[i, 0]
+            bv = torch.clamp(m[i, 1] - bm.square(), min=0.0)
+            delta = bm - self.mean
+            total = self.count + float(n)
+            m2 = self.var * self.count + bv * float(n) + torch.square(delta) * self.count * float(n) / total
+            self.mean.add_(delta * float(n) / total)
+            self.var.copy_(m2 / total)
+            self.count.copy_(total)
+
     def to_reference(self):
         ref = Normalizer(self.mean.shape[0], epsilon=self.epsilon, clip_obs=self.clip_obs)
         ref.mean, ref.var, ref.count = self.mean.cpu().numpy().copy(), self.var.cpu().numpy().copy(), float(self.count.item())

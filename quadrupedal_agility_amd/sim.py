@@ -11,8 +11,8 @@ import torch
 from . import _capi
 
 _TORCH_DT = {_capi.DTYPE_F32: torch.float32, _capi.DTYPE_I64: torch.int64, _capi.DTYPE_U8: torch.uint8,
-             _capi.DTYPE_I32: torch.int32, _capi.DTYPE_I16: torch.int16}
-_ITEM = {_capi.DTYPE_F32: 4, _capi.DTYPE_I64: 8, _capi.DTYPE_U8: 1, _capi.DTYPE_I32: 4, _capi.DTYPE_I16: 2}
+             _capi.DTYPE_I32: torch.int32, _capi.DTYPE_I16: torch.int16, _capi.DTYPE_F64: torch.float64}
+_ITEM = {_capi.DTYPE_F32: 4, _capi.DTYPE_I64: 8, _capi.DTYPE_U8: 1, _capi.DTYPE_I32: 4, _capi.DTYPE_I16: 2, _capi.DTYPE_F64: 8}
 
 
 def _check(rc, lib, what):
@@ -75,12 +75,19 @@ class QaSim:
         assert torques.is_cuda and torques.dtype == torch.float32 and torques.is_contiguous()
         _check(self.lib.qa_simulate(self.h, torques.data_ptr(), self._stream()), self.lib, "qa_simulate")
 
-    def set_mocap(self, frames, first_frame):
+    def set_mocap(self, frames, clips, first_clip):
+        """qa_set_mocap: frames (F,37) fp32, clip table (C,8) float64, clip ranges per gait (MotionLoader.reset_clip_table)"""
         import numpy as np
         f = np.ascontiguousarray(frames, dtype=np.float32)
-        first = (C.c_int32 * (_capi.NUM_GAITS + 1))(*[int(x) for x in first_frame])
-        _check(self.lib.qa_set_mocap(self.h, f.ctypes.data, f.shape[0], first, self._stream()), self.lib, "qa_set_mocap")
-        torch.cuda.current_stream(self.device).synchronize()   # host buffer must outlive the async copy
+        ct = np.ascontiguousarray(clips, dtype=np.float64)
+        assert f.ndim == 2 and f.shape[1] == _capi.MOCAP_FRAME and ct.ndim == 2 and ct.shape[1] == _capi.MOCAP_CLIP
+        first = (C.c_int32 * (_capi.NUM_GAITS + 1))(*[int(x) for x in first_clip])
+        _check(self.lib.qa_set_mocap(self.h, f.ctypes.data, f.shape[0], ct.ctypes.data, ct.shape[0], first, self._stream()), self.lib, "qa_set_mocap")
+        torch.cuda.current_stream(self.device).synchronize()   # host buffers must outlive the async copies
+
+    def debug_post_physics(self, step):
+        """qa_debug_post_physics: post_physics_step alone on the arena's state (verification entry)"""
+        _check(self.lib.qa_debug_post_physics(self.h, int(step), self._stream()), self.lib, "qa_debug_post_physics")
 
     def gae(self, rewards, values, dones, last_values, returns, advantages, gamma, lam, normalize=True):
         T, N = rewards.shape[0], rewards.shape[1]

@@ -26,10 +26,11 @@ class OracleBackend:
         self.o.step(actions.detach().cpu().numpy(), delay)
         self.global_step += 1
 
-    def set_mocap(self, frames, first_frame):
+    def set_mocap(self, frames, clips, first_clip):
         f = np.ascontiguousarray(frames, dtype=np.float32)
-        first = (C.c_int32 * 6)(*[int(x) for x in first_frame])
-        assert self.o.lib.qo_set_mocap(self.o.h, f.ctypes.data, f.shape[0], first, None) == 0
+        ct = np.ascontiguousarray(clips, dtype=np.float64)
+        first = (C.c_int32 * 6)(*[int(x) for x in first_clip])
+        assert self.o.lib.qo_set_mocap(self.o.h, f.ctypes.data, f.shape[0], ct.ctypes.data, ct.shape[0], first, None) == 0
 
     def gae(self, rewards, values, dones, last_values, returns, advantages, gamma, lam, normalize=True):
         T, N = rewards.shape

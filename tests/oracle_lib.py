@@ -9,7 +9,8 @@ from quadrupedal_agility_amd import _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-_NP_DT = {_capi.DTYPE_F32: np.float32, _capi.DTYPE_I64: np.int64, _capi.DTYPE_U8: np.uint8, _capi.DTYPE_I32: np.int32, _capi.DTYPE_I16: np.int16}
+_NP_DT = {_capi.DTYPE_F32: np.float32, _capi.DTYPE_I64: np.int64, _capi.DTYPE_U8: np.uint8, _capi.DTYPE_I32: np.int32, _capi.DTYPE_I16: np.int16,
+          _capi.DTYPE_F64: np.float64}
 
 _lib = None
 

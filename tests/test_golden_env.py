@@ -40,11 +40,9 @@ def test_reward_names_order(gold):
     assert list(gold["c0_ref_reward_names"]) == _capi.REWARD_NAMES     # alphabetical = the reference's summation order
 
 
-@pytest.mark.parametrize("case", range(7))
-def test_post_physics_matches_reference(gold, case):
-    assert case < int(gold["num_cases"])
-    o, step, ref = _run(gold, case)
-    t = o.t
+def check_against_reference(t, ref, step):
+    """`t`: name -> numpy array of an arena AFTER post_physics_step ran on a fixture case; `ref(key)`: the reference's outputs.
+    Used for the oracle here and for the HIP kernel's post-physics phase in tests/test_hip_parity.py (same tolerances)."""
     # integer / boolean outputs: exact
     assert (t["RESET"] == ref("reset")).all()
     assert (t["TIME_OUT"].astype(bool) == ref("time_out")).all()
@@ -82,6 +80,13 @@ def test_post_physics_matches_reference(gold, case):
         assert np.allclose(st[:14] / st[14] / 20.0, ref("extras_episode"), atol=1e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize("case", range(7))
+def test_post_physics_matches_reference(gold, case):
+    assert case < int(gold["num_cases"])
+    o, step, ref = _run(gold, case)
+    check_against_reference(o.t, ref, step)
+
+
 def test_fixture_covers_the_branches(gold):
     n_cases = int(gold["num_cases"])
     resets = sum(len(gold[f"c{i}_ref_reset_env_ids"]) for i in range(n_cases))
@@ -103,3 +108,29 @@ def test_compute_torques_matches_reference():
     assert np.allclose(tau_org, g["torques_org"], atol=1e-5, rtol=1e-6)
     assert np.allclose(tau, g["torques"], atol=1e-5, rtol=1e-6)
     assert (np.abs(g["torques"]) == np.array([20, 20, 40] * 4)).any()          # the clip is exercised
+
+
+def test_noise_scale_vec_matches_reference():
+    """noise_scale_vec (legged_robot.py:721-740) of the Go2 config, as the reference's own method returns it
+    (tools/gen_golden.py noise): the qa_config scalars the kernel / oracle use, the host mirror's vector, and what the
+    oracle actually adds with add_noise on -- inside +-vec per column, exactly zero where vec is zero."""
+    g = np.load(os.path.join(GOLD, "noise_scale_vec.npz"))
+    vec = g["noise_scale_vec"]
+    assert vec.shape == (671,) and bool(g["add_noise"])
+    q = go2_cfg(8)
+    assert q.add_noise == 1
+    for sl, val in ((slice(0, 2), q.noise_roll_pitch), (slice(2, 5), q.noise_ang_vel), (slice(5, 17), q.noise_dof_pos),
+                    (slice(17, 29), q.noise_dof_vel), (slice(58, 61), q.noise_lin_vel)):
+        assert np.all(vec[sl] == np.float32(val)), sl
+    mine = np.zeros(671, np.float32)
+    mine[0:2] = q.noise_roll_pitch; mine[2:5] = q.noise_ang_vel; mine[5:17] = q.noise_dof_pos; mine[17:29] = q.noise_dof_vel; mine[58:61] = q.noise_lin_vel
+    assert np.array_equal(mine, vec)                                   # nothing else is noisy (history, commands, latents)
+    n = 256
+    a, b = OracleSim(go2_cfg(n, seed=5, add_noise=1)), OracleSim(go2_cfg(n, seed=5, add_noise=0))
+    act = np.random.default_rng(5).normal(0, 0.5, (n, 12)).astype(np.float32)
+    for o in (a, b):
+        o.reset_all(); o.step(act); o.step(act)
+    d = a.t["OBS"] - b.t["OBS"]
+    assert (np.abs(d) <= vec[None, :] * (1 + 1e-6)).all() and (d[:, vec == 0] == 0).all()
+    assert (np.abs(d[:, vec > 0]).max(axis=0) > 0.8 * vec[vec > 0]).all()
+    assert np.array_equal(a.t["OBS"][:, 90:660], b.t["OBS"][:, 90:660])   # the history frames stay noise-free (SURVEY 8a a18 note)

@@ -100,7 +100,7 @@ def test_single_step_parity(n_envs, seed):
             assert np.allclose(st_g, st_o, atol=1e-3, rtol=1e-3)
     print("worst abs error per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
     print(f"env-steps outside tolerance (discrete-event flips): {flips} of {steps * n_envs}")
-    assert flips <= 0.01 * steps * n_envs
+    assert flips <= 0.004 * steps * n_envs            # measured 0.17 % (contact on/off flips, tools/flip_probe.py); budget ~2x
 
 
 def test_integer_outputs_exact_when_physics_agrees():
@@ -111,15 +111,24 @@ def test_integer_outputs_exact_when_physics_agrees():
     rng = np.random.default_rng(3)
     o.reset_all()
     o.t["EPISODE_LENGTH"][:] = rng.integers(990, 1002, n)       # many time-outs
-    mism = 0
+    mism = unexplained = 0
+    term_bodies = [0, 3, 7, 11, 15]                                # base + hips (legged_robot.py:168-176)
     for k in range(10):
         push_arena(o, h)
         act = rng.normal(0, 0.5, (n, 12)).astype(np.float32)
         o.step(act); h.step(torch.from_numpy(act).cuda()); torch.cuda.synchronize()
         for name in ("TIME_OUT", "EPISODE_LENGTH"):
             assert (h.t[name].cpu().numpy() == o.t[name]).all(), name
-        mism += int((h.t["RESET"].cpu().numpy() != o.t["RESET"]).sum())
-    assert mism <= 3
+        diff = np.nonzero(h.t["RESET"].cpu().numpy() != o.t["RESET"])[0]
+        mism += len(diff)
+        # a differing reset flag is only acceptable where the deciding force sits on the 1 N threshold (to 1e-3) on one of the
+        # two sides, or where the contact forces themselves disagree beyond tolerance (a counted contact flip)
+        cf_g, cf_o = h.t["CONTACT_FORCES"].cpu().numpy(), o.t["CONTACT_FORCES"]
+        flip = env_mismatch("CONTACT_FORCES", cf_g, cf_o, n)
+        for e in diff:
+            near = min(np.abs(np.linalg.norm(cf[e, term_bodies], axis=1) - 1.0).min() for cf in (cf_g, cf_o)) < 1e-3
+            unexplained += int(not (near or flip[e]))
+    assert unexplained == 0 and mism <= 3
 
 
 def test_trajectory_divergence_is_slow():
@@ -138,7 +147,7 @@ def test_trajectory_divergence_is_slow():
     dz = np.abs(h.t["ROOT_STATES"].cpu().numpy()[:, :3] - o.t["ROOT_STATES"][:, :3]).max(axis=1)
     close = (dz < 5e-3) & same_reset_hist
     print(f"{close.mean() * 100:.1f}% of envs within 5 mm after 100 physics steps; median |dpos| = {np.median(dz):.2e}")
-    assert close.mean() > 0.8
+    assert close.mean() >= 0.95                       # measured 100 %
 
 
 def test_simulate_seam_free_flight():
@@ -184,6 +193,123 @@ def test_gae_matches_oracle_and_properties():
         assert np.allclose(adv.cpu().numpy(), adv_o, atol=2e-5, rtol=1e-4)
         if T * N > 1:
             assert abs(float(adv.mean())) < 1e-4 and abs(float(adv.std()) - 1) < 1e-3
+
+
+# ------------------------------------------------------------------ the kernel's post-physics phase against the REFERENCE's fixtures
+@pytest.mark.parametrize("case", range(7))
+def test_post_physics_phase_on_gpu_matches_reference_fixtures(case):
+    """tests/golden/env_post_physics.npz holds what the reference's own post_physics_step computes (tools/gen_golden.py).  The
+    oracle is held to it on the CPU (tests/test_golden_env.py); here the DEVICE code of the fused step's post-physics phase is
+    fed the same inputs through qa_debug_post_physics and held to the same tolerances (2e-6, integers exact) -- no oracle in
+    between, so a reward / observation term that is wrong only on the device cannot hide behind the oracle comparison's 3e-3."""
+    import os
+    from quadrupedal_agility_amd import _capi
+    from quadrupedal_agility_amd.sim import QaSim
+    from tests.test_golden_env import GOLD, check_against_reference
+    gold = np.load(os.path.join(GOLD, "env_post_physics.npz"), allow_pickle=False)
+    n = int(gold["num_envs"])
+    h = QaSim(go2_cfg(n, seed=int(gold["seed"]), add_noise=0))
+    for name in _capi.TENSORS:
+        key = f"c{case}_in_{name}"
+        if key in gold.files:
+            h.t[name].copy_(torch.from_numpy(np.ascontiguousarray(gold[key])).to(h.t[name].device).view_as(h.t[name]))
+    step = int(gold[f"c{case}_in__step"])
+    h.debug_post_physics(step)
+    torch.cuda.synchronize()
+    t = {k: v.cpu().numpy() for k, v in h.t.items()}
+    check_against_reference(t, lambda k: gold[f"c{case}_ref_{k}"], step)
+
+
+def test_post_physics_phase_equals_fused_step_tail():
+    """the fused step and [qa_simulate x 4 with the same torques ... ] share the post-physics device code: running the phase
+    alone on the arena a fused step left behind (minus its own post-physics effects) is not possible, so check the other
+    direction: oracle pre-physics -> arena -> device post-physics equals the oracle's full step"""
+    import ctypes as C
+    n = 256
+    q, o, h = make_pair(n, seed=4)
+    rng = np.random.default_rng(4)
+    o.reset_all()
+    o.t["EPISODE_LENGTH"][:] = rng.integers(0, 1001, n)
+    o.global_step = 398                                            # the step before a push (common % 400 == 0)
+    o.lib.qo_debug_pre_physics.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    o.lib.qo_debug_post_physics.argtypes = [C.c_void_p, C.c_int64]
+    for k in range(4):
+        act = rng.normal(0, 1.0, (n, 12)).astype(np.float32)
+        assert o.lib.qo_debug_pre_physics(o.h, act.ctypes.data, 0) == 0
+        push_arena(o, h)
+        step = o.global_step
+        assert o.lib.qo_debug_post_physics(o.h, step) == 0
+        o.global_step += 1
+        h.debug_post_physics(step)
+        torch.cuda.synchronize()
+        for name in ("OBS", "OBS_DISC", "OBS_DISC_TERM", "REW", "EPISODE_SUMS", "COMMANDS", "ROOT_STATES", "DOF_STATE", "LAST_ROOT_VEL", "RPY", "BASE_LIN_VEL"):
+            assert np.allclose(h.t[name].cpu().numpy(), o.t[name], atol=2e-6, rtol=1e-5), (k, name)
+        for name in ("RESET", "TIME_OUT", "EPISODE_LENGTH", "CONTACT_FILT", "LAST_CONTACTS"):
+            assert (h.t[name].cpu().numpy() == o.t[name]).all(), (k, name)
+
+
+def test_noise_scale_vec_on_device():
+    """add_noise: the kernel adds (2u-1) * noise_scale_vec[i] to exactly the reference's noisy entries (legged_robot.py:721-740,
+    pinned to the reference's vector by tests/test_plumbing_cpu.py): obs - noise-free obs stays inside +-scale per column and
+    is zero elsewhere; the oracle draws the same Philox numbers, so the two agree entry by entry"""
+    n = 512
+    q, o, h = make_pair(n, seed=6, add_noise=1)
+    q0, o0, h0 = make_pair(n, seed=6, add_noise=0)
+    o.reset_all(); o0.reset_all()
+    act = np.random.default_rng(6).normal(0, 0.5, (n, 12)).astype(np.float32)
+    push_arena(o, h); push_arena(o0, h0)
+    o.step(act); h.step(torch.from_numpy(act).cuda()); h0.step(torch.from_numpy(act).cuda()); torch.cuda.synchronize()
+    d = (h.t["OBS"] - h0.t["OBS"]).cpu().numpy()
+    scale = np.zeros(671, np.float32)
+    scale[0:2] = q.noise_roll_pitch; scale[2:5] = q.noise_ang_vel; scale[5:17] = q.noise_dof_pos; scale[17:29] = q.noise_dof_vel; scale[58:61] = q.noise_lin_vel
+    assert (np.abs(d) <= scale[None, :] + 1e-6).all()
+    assert (np.abs(d[:, scale > 0]).max(axis=0) > 0.5 * scale[scale > 0]).all()        # ... and the range is actually used
+    assert np.allclose(h.t["OBS"].cpu().numpy(), o.t["OBS"], atol=3e-3, rtol=1e-3)
+
+
+def test_rigid_body_state_export_matches_oracle():
+    """QA_T_RIGID_BODY_STATE (N,19,13) -- seam 1's rigid_body_state viewed as (N, num_bodies, 13) -- from the fused step and from
+    qa_simulate, against the oracle's (which tests/test_oracle_physics.py checks against finite differences)"""
+    n = 300
+    q, o, h = make_pair(n, seed=8, export_body_state=1)
+    rng = np.random.default_rng(8)
+    o.reset_all()
+    for k in range(6):
+        push_arena(o, h)
+        act = rng.normal(0, 1.0, (n, 12)).astype(np.float32)
+        o.step(act); h.step(torch.from_numpy(act).cuda()); torch.cuda.synchronize()
+        ok = ~env_mismatch("ROOT_STATES", h.t["ROOT_STATES"].cpu().numpy(), o.t["ROOT_STATES"], n) & ~env_mismatch("DOF_STATE", h.t["DOF_STATE"].cpu().numpy(), o.t["DOF_STATE"], n)
+        g, e = h.t["RIGID_BODY_STATE"].cpu().numpy()[ok], o.t["RIGID_BODY_STATE"][ok]
+        assert ok.mean() > 0.97
+        assert np.allclose(g[..., 0:3], e[..., 0:3], atol=3e-4, rtol=1e-4)
+        assert np.allclose(g[..., 0:3], h.t["RIGID_BODY_POS"].cpu().numpy()[ok], atol=1e-6)
+        assert np.minimum(np.abs(g[..., 3:7] - e[..., 3:7]).max(-1), np.abs(g[..., 3:7] + e[..., 3:7]).max(-1)).max() < 2e-3
+        assert np.allclose(g[..., 7:13], e[..., 7:13], atol=2e-2, rtol=1e-2)
+    tau = rng.uniform(-5, 5, (n, 12)).astype(np.float32)
+    push_arena(o, h)
+    o.simulate(tau); h.simulate(torch.from_numpy(tau).cuda()); torch.cuda.synchronize()
+    ok = ~env_mismatch("DOF_STATE", h.t["DOF_STATE"].cpu().numpy(), o.t["DOF_STATE"], n)
+    assert np.allclose(h.t["RIGID_BODY_STATE"].cpu().numpy()[ok][..., 7:13], o.t["RIGID_BODY_STATE"][ok][..., 7:13], atol=2e-2, rtol=1e-2)
+
+
+def test_device_step_counter_advances_inside_the_step_kernel():
+    """qa_env_step_dev: the last workgroup to finish bumps the counter (no 1-thread tick launch); stepping through the device
+    counter gives the same envs as stepping with the host counter"""
+    n = 1000                                                       # 63 workgroups, the last one ragged
+    q, o, h = make_pair(n, seed=12)
+    q2, o2, h2 = make_pair(n, seed=12)
+    o.reset_all(); push_arena(o, h); push_arena(o, h2)
+    ctr = torch.tensor([7], dtype=torch.int64, device="cuda")
+    h2.global_step = 7
+    rng = np.random.default_rng(12)
+    for k in range(30):
+        act = torch.from_numpy(rng.normal(0, 0.5, (n, 12)).astype(np.float32)).cuda()
+        h.step_dev(act, 0, ctr)
+        h2.step(act)
+    torch.cuda.synchronize()
+    assert int(ctr.item()) == 37 and int(h.t["STEP_TICKET"][0].item()) == 0
+    for name in ("OBS", "ROOT_STATES", "REW", "EPISODE_LENGTH", "COMMANDS"):
+        assert torch.equal(h.t[name], h2.t[name]), name
 
 
 # ------------------------------------------------------------------ height-field terrain (SURVEY.md 8f row 2)
@@ -240,7 +366,7 @@ def test_single_step_parity_on_height_field(n_envs, seed):
     print("worst abs error per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
     print(f"env-steps outside tolerance on rough terrain: {flips} of {steps * n_envs}")
     assert (o.t["SCAN_HEIGHT"] != 0).mean() > 0.9                    # the field is really there
-    assert flips <= 0.02 * steps * n_envs                            # triangle / cell switches add discrete events
+    assert flips <= 0.01 * steps * n_envs                            # measured 0.5 %: triangle / cell switches add discrete events
 
 
 def test_height_field_trajectory_and_contact_forces():
@@ -257,7 +383,7 @@ def test_height_field_trajectory_and_contact_forces():
     d = np.abs(h.t["ROOT_STATES"].cpu().numpy()[:, :3] - o.t["ROOT_STATES"][:, :3]).max(axis=1)
     close = (d < 5e-3) & same
     print(f"{close.mean() * 100:.1f}% of envs within 5 mm after 100 physics steps on rough terrain; median |dpos| = {np.median(d):.2e}")
-    assert close.mean() > 0.7
+    assert close.mean() >= 0.9                        # measured 100 %
     root = h.t["ROOT_STATES"].cpu().numpy(); scan = h.t["SCAN_HEIGHT"].cpu().numpy()
     alive = h.t["EPISODE_LENGTH"].cpu().numpy() >= 25
     assert alive.mean() > 0.5

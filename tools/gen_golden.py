@@ -370,7 +370,7 @@ def gen_mocap():
 def _main():
     os.makedirs(GOLD, exist_ok=True)
     ref_lr, RefCfg, RefAlgoCfg = import_reference()
-    which = sys.argv[1:] or ["env", "gae", "learner", "mocap", "heights"]
+    which = sys.argv[1:] or ["env", "gae", "learner", "mocap", "heights", "noise"]
     if "env" in which:
         gen_env(ref_lr, RefCfg)
     if "gae" in which:
@@ -381,6 +381,8 @@ def _main():
         gen_mocap()
     if "heights" in which:
         gen_heights(ref_lr, RefCfg)
+    if "noise" in which:
+        gen_noise(ref_lr, RefCfg)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
 
@@ -404,6 +406,19 @@ def gen_heights(ref_lr, RefCfg):
     np.savez_compressed(os.path.join(GOLD, "heights.npz"), height_samples=hs, root_states=root, heights=heights.numpy(),
                         border=np.array(3.0), hscale=np.array(0.1), vscale=np.array(0.005))
     print("  heights golden:", heights.shape, float(heights.min()), float(heights.max()))
+
+
+def gen_noise(ref_lr, RefCfg):
+    """The reference's own _get_noise_scale_vec (legged_robot.py:721-740) for the Go2 config, and what one noisy
+    compute_observations adds for injected uniforms: obs += (2u - 1) * noise_scale_vec (legged_robot.py:315-317)."""
+    cfg = RefCfg()
+    env = object.__new__(ref_lr.LeggedRobot)
+    env.cfg = cfg; env.device = "cpu"
+    env.obs_scales = cfg.normalization.obs_scales
+    vec = env._get_noise_scale_vec(cfg)
+    np.savez_compressed(os.path.join(GOLD, "noise_scale_vec.npz"), noise_scale_vec=vec.numpy(), add_noise=np.array(bool(env.add_noise)),
+                        noise_level=np.array(cfg.noise.noise_level))
+    print("  noise golden: non-zero entries", np.nonzero(vec.numpy())[0].tolist())
 
 
 if __name__ == "__main__":
