@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU (weak scaling)")
-    ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator + mocap reset (synthetic clips unless QA_MOCAP_DIR)")
+    ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator + mocap reset on the real Go2 clips (baked dataset shipped with the package)")
     ap.add_argument("--terrain", default="plane", choices=["plane", "trimesh"],
                     help="plane = BASELINE configs 1-2 (flat terrain); trimesh = the reference's 10x40 tile course as a height field")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -185,7 +185,7 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("go2_locomotion BBC + AMP (synthetic mocap clips), " if args.amp else
+            "config": {"workload": (f"go2_locomotion BBC + AMP (5 mocap gaits, {getattr(env, 'mocap_source', 'none')} clips: 17 labelled + 295 unlabelled), " if args.amp else
                                     "go2_locomotion BBC, discriminator off, default-pose reset, ") +
                                    f"{args.num_envs} envs/GPU, {'plane' if args.terrain == 'plane' else 'height-field (trimesh course)'} terrain, 24 steps/iter, 5 epochs x 4 minibatches",
                        "num_envs_per_gpu": args.num_envs, "steps_per_iter": T, "parallelism": f"dp{world}"},

@@ -78,7 +78,17 @@ def test_short_training_run_on_gpu(tmp_path, amp):
     runner.load(path)
     # training goes on after a load: recorded launches and the optimizer pointer tables are rebuilt around the new state
     assert runner.alg._ac_graph is None and runner._graphs == {}
+    # ... and the adaptive-KL learning rate is still ONE device tensor shared by the LR rule, ClipAdam and the recorded steps
+    # (Optimizer.load_state_dict replaces the group's lr by a copy; load() re-links it)
+    alg = runner.alg
+    assert all(g["lr"] is alg._lr_ac for g in alg.optim_ac.param_groups) and alg.optim_ac.param_groups[0]["capturable"]
+    lr_loaded = float(alg._lr_ac)
+    assert lr_loaded == pytest.approx(float(ck["optim_ac"]["param_groups"][0]["lr"]))
+    alg._lr_ac.fill_(3.3e-4)                                # whatever the rule writes must be what the optimiser reads
+    assert float(alg.optim_ac.param_groups[0]["lr"]) == pytest.approx(3.3e-4)
+    alg._lr_ac.fill_(lr_loaded)
     runner.learn(3, init_at_random_ep_len=False)          # one eager update, then recorded again
+    assert all(g["lr"] is alg._lr_ac for g in alg.optim_ac.param_groups)
     assert runner.alg._ac_graph not in (None, False)
     assert all(torch.isfinite(v).all() for v in runner.alg.actor_critic.state_dict().values())
     st = runner.alg.optim_ac.state_dict()["state"]
