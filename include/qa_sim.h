@@ -223,6 +223,34 @@ int qa_reset_all(qa_sim *sim, int64_t global_step, void *stream);
  * RIGID_BODY_POS (and RIGID_BODY_STATE with cfg.export_body_state) only. */
 int qa_simulate(qa_sim *sim, const float *torques, void *stream);
 
+/* ---- task-level (TSC) env: the simulator half of tsc/legged_gym/envs/base/legged_robot.py ----------------------------------
+ * The task-level env's step (:113-153) is the same physics as the behaviour-level one, but its post_physics_step is different
+ * code (goals, 8 rewards, three observation rows: qa_tsc_goal_step / qa_tsc_observations below), so the fused kernel is also
+ * offered without its post-physics phase:
+ *
+ * qa_env_physics_step = :118-139: action-history roll, delay (the task-level config always delays by one step, :124-126),
+ * clip, decimation x (_compute_torques :762-795 -> gym.simulate), and the refresh_* of :231-234.  Updates ROOT_STATES,
+ * DOF_STATE, CONTACT_FORCES, RIGID_BODY_POS, RIGID_BODY_STATE (cfg.export_body_state), TORQUES, TORQUES_ORG, ACTIONS,
+ * ACTION_HISTORY, FOOT_IMPULSE; LAST_ACTIONS / LAST_DOF_VEL / LAST_TORQUES_ORG / LAST_ROOT_VEL take the values the step STARTS
+ * from, which is what :275-278 left there at the end of the previous step.  Nothing else of the arena is touched.  The
+ * obstacle course is the height-field terrain of the handle (the reference collides with separate obstacle actors). */
+int qa_env_physics_step(qa_sim *sim, const float *actions, int32_t delay_steps, void *stream);
+
+/* qa_tsc_reset = the simulator part of the task-level reset_idx (:348-410) for the envs with reset_flags[e] != 0 (device,
+ * uint8): _reset_dofs (:796-807: joints at their default angles, at rest) and _reset_root_states (:840-884): root at
+ * base_init_state with xy = start_xy[e] (the env's first goal, or the goal of a random obstacle with obstacle.randomize_start)
+ * + rand_x_range U(-1,0), rand_y_range U(-1,1); orientation quat_from_euler_xyz(0, rand_pitch_range U(-1,1), start_yaw[e] +
+ * rand_yaw_range U(-1,1)); velocities zero; last_actions / last_dof_vel / last_torques_org, the action history and the contact
+ * warm start of those envs are cleared, RESET is set; last_root_vel is cleared for ALL envs (:389).  The uniforms come from the
+ * handle's Philox generator keyed by (seed; env, global_step).  The goal / episode bookkeeping of the reset belongs to the
+ * caller (TaskLevelBookkeeping.reset_idx). */
+int qa_tsc_reset(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range,
+                 float rand_x_range, float rand_y_range, float rand_pitch_range, int64_t global_step, void *stream);
+
+/* qa_simulate only if *cond_dev != 0 (one device byte): the reference's reset_idx runs one more gym.simulate -- for EVERY env,
+ * with the actuation forces set last -- whenever at least one env resets (:382-384).  torques == NULL applies QA_T_TORQUES. */
+int qa_simulate_if(qa_sim *sim, const float *torques, const uint8_t *cond_dev, void *stream);
+
 /* Upload the labelled mocap clips for reset_mode 1 (LeggedRobot.reset_idx with mocap_state_init,
  * bbc/legged_gym/envs/base/legged_robot.py:205-214, 598-612, 660-680; MotionLoader.get_full_frame_batch,
  * bbc/rsl_rl/datasets/motion_loader.py:461-474).  `frames` is a HOST pointer to (num_frames, QA_MOCAP_FRAME) fp32: the clips'

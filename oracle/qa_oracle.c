@@ -1016,6 +1016,64 @@ int qo_simulate(qo_sim *s, const float *torques, void *stream) {
     return QA_OK;
 }
 
+int qo_simulate_if(qo_sim *s, const float *torques, const uint8_t *cond, void *stream) {
+    if (!s || !cond) return QA_E_ARG;
+    if (*cond == 0) return QA_OK;
+    return qo_simulate(s, torques ? torques : TP(s, QA_T_TORQUES, float), stream);
+}
+
+/* tsc/legged_gym/envs/base/legged_robot.py:118-139 + the refreshes of :231-234 -- the step without post_physics_step */
+int qo_env_physics_step(qo_sim *s, const float *actions, int32_t delay_steps, void *stream) {
+    (void)stream;
+    if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    const qa_config *c = &s->cfg;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < c->num_envs; ++e) {
+        float *act = TP(s, QA_T_ACTIONS, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e, *tau = TP(s, QA_T_TORQUES, float) + 12 * e;
+        const float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e, *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
+        /* last_* = what the previous step's end left (:275-278) = the values this step starts from */
+        memcpy(TP(s, QA_T_LAST_ACTIONS, float) + 12 * e, act, 48);
+        memcpy(TP(s, QA_T_LAST_TORQUES_ORG, float) + 12 * e, torg, 48);
+        for (int j = 0; j < 12; ++j) TP(s, QA_T_LAST_DOF_VEL, float)[12 * e + j] = dof[2 * j + 1];
+        memcpy(TP(s, QA_T_LAST_ROOT_VEL, float) + 6 * e, root + 7, 24);
+        float *ah = TP(s, QA_T_ACTION_HISTORY, float) + 96 * e;
+        memmove(ah, ah + 12, 7 * 12 * 4);
+        memcpy(ah + 7 * 12, actions + 12 * e, 48);
+        const float *src = ah + 12 * (QA_ACTION_BUF_LEN - 1 - delay_steps);
+        float clipa = c->clip_actions / c->action_scale;
+        for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
+        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep(s, e, tau); }
+    }
+    return QA_OK;
+}
+
+/* the simulator part of the task-level reset_idx (tsc/legged_gym/envs/base/legged_robot.py:348-410, 796-884) */
+int qo_tsc_reset(qo_sim *s, const uint8_t *flags, const float *start_xy, const float *start_yaw, float yaw_range, float x_range, float y_range,
+                 float pitch_range, int64_t step, void *stream) {
+    (void)stream;
+    if (!s || !flags || !start_xy || !start_yaw) return QA_E_ARG;
+    const qa_config *c = &s->cfg;
+    for (int e = 0; e < c->num_envs; ++e) {
+        memset(TP(s, QA_T_LAST_ROOT_VEL, float) + 6 * e, 0, 24);
+        if (!flags[e]) continue;
+        float u[4]; rng4(s, e, step, RS_RESET, 0, u);
+        float yaw = start_yaw[e] + yaw_range * (2.0f * u[0] - 1.0f), pitch = pitch_range * (2.0f * u[3] - 1.0f);
+        float *rt = TP(s, QA_T_ROOT_STATES, float) + 13 * e, *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
+        rt[0] = c->init_pos[0] + start_xy[2 * e] + x_range * (u[1] - 1.0f);
+        rt[1] = c->init_pos[1] + start_xy[2 * e + 1] + y_range * (2.0f * u[2] - 1.0f);
+        rt[2] = c->init_pos[2];
+        float sy = sinf(0.5f * yaw), cy = cosf(0.5f * yaw), sp = sinf(0.5f * pitch), cp = cosf(0.5f * pitch);
+        rt[3] = -sy * sp; rt[4] = cy * sp; rt[5] = sy * cp; rt[6] = cy * cp;
+        for (int i = 7; i < 13; ++i) rt[i] = 0.0f;
+        for (int j = 0; j < 12; ++j) { dof[2 * j] = c->default_dof_pos[j]; dof[2 * j + 1] = 0.0f; }
+        memset(TP(s, QA_T_LAST_ACTIONS, float) + 12 * e, 0, 48); memset(TP(s, QA_T_LAST_DOF_VEL, float) + 12 * e, 0, 48);
+        memset(TP(s, QA_T_LAST_TORQUES_ORG, float) + 12 * e, 0, 48); memset(TP(s, QA_T_FOOT_IMPULSE, float) + 12 * e, 0, 48);
+        memset(TP(s, QA_T_ACTION_HISTORY, float) + 96 * e, 0, 96 * 4);
+        TP(s, QA_T_RESET, int64_t)[e] = 1;
+    }
+    return QA_OK;
+}
+
 int qo_reset_all(qo_sim *s, int64_t step, void *stream) {
     (void)stream;
     if (!s) return QA_E_ARG;

@@ -94,6 +94,9 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "simulate"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "set_mocap"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "debug_post_physics"); f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "env_physics_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "tsc_reset"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "simulate_if"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "gae"); f.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "ppo_loss")
     f.argtypes = [C.c_void_p] * 10 + [C.c_int64, C.c_int32] + [C.c_float] * 5 + [C.c_int32] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
@@ -213,7 +216,7 @@ class QaTscObsIo(C.Structure):
 
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
-               "set_mocap", "debug_post_physics", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
+               "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
                "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "last_error", "abi_version"]
 
 _LIB = None

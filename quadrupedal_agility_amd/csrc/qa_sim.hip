@@ -655,7 +655,10 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
 // of one workgroup over the four SIMDs of a CU, whereas four single-wavefront workgroups of a kernel that needs <= 256
 // registers are packed two per SIMD and then share its issue slots (measured: 143 us instead of the expected ~50).
 // Each wavefront works on its own 4 envs with its own LDS region; only the constant table is shared.
-template <bool PLANE, int LPE>
+// MODE 0: the whole LeggedRobot.step of the behaviour-level (BBC) tree.  MODE 1: the physics part only -- action-history
+// roll, delay, clip, decimation x (PD torque -> substep), refresh of the simulator tensors -- for the task-level (TSC) env,
+// whose own post_physics_step (goals, termination, rewards, reset, three observation rows) are separate kernels (qa_tsc_*).
+template <bool PLANE, int LPE, int MODE = 0>
 __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_kernel(StepArgs a) {
     constexpr int WPB = LPE == 16 ? 4 : 1;             // wavefronts per workgroup
     constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
@@ -736,6 +739,14 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         const float *d = p.dof + (int64_t)env * 24 + 6 * leg;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { st.q[k] = d[2 * k]; st.qd[k] = d[2 * k + 1]; }
+    }
+    // MODE 1: last_* := the values this step starts from (tsc/.../legged_robot.py:275-278 sets them at the END of the previous
+    // step, after its reset, i.e. to exactly what the arena holds now)
+    float old_act[3], old_torg[3], old_qd[3]; V3 old_vw, old_ww;
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int64_t j = (int64_t)env * 12 + 3 * leg + k; old_act[k] = p.actions[j]; old_torg[k] = p.torques_org[j]; old_qd[k] = st.qd[k]; }
+        old_vw = st.vw; old_ww = st.ww;
     }
     float binert[10];
 #pragma unroll
@@ -831,6 +842,26 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     }
 
     if (c.export_body_state && valid) write_body_state(p.rbstate + (int64_t)env * (QA_NUM_BODIES_ABI * 13), st, R, org, leg);
+    if (MODE == 1) {
+        if (valid) {
+            if (leg == 0) {
+                float *rt = p.root + (int64_t)env * 13;
+                rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
+                rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
+                float *lr = p.last_root_vel + (int64_t)env * 6;
+                lr[0] = old_vw.x; lr[1] = old_vw.y; lr[2] = old_vw.z; lr[3] = old_ww.x; lr[4] = old_ww.y; lr[5] = old_ww.z;
+            }
+            float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+                d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
+                p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k]; p.foot_impulse[j] = fimp[k];
+                p.last_actions[j] = old_act[k]; p.last_dof_vel[j] = old_qd[k]; p.last_torques_org[j] = old_torg[k];
+            }
+        }
+        return;
+    }
     QA_STAMP(4);
     PostIn in;
     in.st = st; in.foot_f = co.foot_f; in.hip_f = hip_f; in.thigh_f = thigh_f; in.calf_f = calf_f; in.base_f = base_f; in.foot_w = foot_w; in.fric = fric;
@@ -963,7 +994,8 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_reset_all_kernel(qa_config c, Ptr
 }
 
 template <bool PLANE, int LPE>
-__global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques) {
+__global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques, const uint8_t *cond) {
+    if (cond && *cond == 0) return;               // qa_simulate_if: the whole launch is a no-op (uniform over the grid)
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     __shared__ float s_patch[PLANE ? 1 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH];
@@ -1205,6 +1237,16 @@ int qa_env_step_dev(qa_sim *s, const float *actions, int32_t delay_steps, int64_
     return QA_OK;
 }
 
+int qa_env_physics_step(qa_sim *s, const float *actions, int32_t delay_steps, void *stream) {
+    if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = 0; a.step_ptr = nullptr; a.prof = nullptr;
+    const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_env_step_kernel<false, 4, 1>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 1>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
 int qa_reset_all(qa_sim *s, int64_t global_step, void *stream) {
     if (!s) return QA_E_ARG;
     const int blocks = (s->cfg.num_envs + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
@@ -1213,12 +1255,67 @@ int qa_reset_all(qa_sim *s, int64_t global_step, void *stream) {
     return QA_OK;
 }
 
-int qa_simulate(qa_sim *s, const float *torques, void *stream) {
-    if (!s || !torques) return QA_E_ARG;
+static int launch_simulate(qa_sim *s, const float *torques, const uint8_t *cond, void *stream) {
+    if (!s) return QA_E_ARG;
+    if (!torques) torques = s->p.torques;          // the actuation forces set last (gym keeps applying them)
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
-    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_simulate_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
-    else if (s->lanes == 16) hipLaunchKernelGGL((qa_simulate_kernel<true, 16>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
-    else hipLaunchKernelGGL((qa_simulate_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques);
+    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_simulate_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques, cond);
+    else if (s->lanes == 16) hipLaunchKernelGGL((qa_simulate_kernel<true, 16>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques, cond);
+    else hipLaunchKernelGGL((qa_simulate_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques, cond);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+int qa_simulate(qa_sim *s, const float *torques, void *stream) {
+    if (!torques) return QA_E_ARG;
+    return launch_simulate(s, torques, nullptr, stream);
+}
+
+int qa_simulate_if(qa_sim *s, const float *torques, const uint8_t *cond_dev, void *stream) {
+    if (!cond_dev) return QA_E_ARG;
+    return launch_simulate(s, torques, cond_dev, stream);
+}
+
+// reset_idx of the task-level env for the flagged envs (tsc/legged_gym/envs/base/legged_robot.py:348-410, 796-884): one thread per env
+__global__ void qa_tsc_reset_kernel(qa_config c, Ptrs p, const uint8_t *flags, const float *start_xy, const float *start_yaw, float yaw_range,
+                                    float x_range, float y_range, float pitch_range, int64_t step) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= c.num_envs) return;
+    float *lr = p.last_root_vel + (int64_t)e * 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lr[i] = 0.f;                       // self.last_root_vel[:] = 0.  (ALL envs, :389)
+    if (!flags[e]) return;
+    const F4 u = rng4(c.seed, e, step, RS_RESET, 0);
+    const float yaw = start_yaw[e] + yaw_range * (2.0f * u.v[0] - 1.0f);
+    const float pitch = pitch_range * (2.0f * u.v[3] - 1.0f);
+    float *rt = p.root + (int64_t)e * 13;
+    rt[0] = c.init_pos[0] + start_xy[2 * e] + x_range * (u.v[1] - 1.0f);            // rand_x_range * U(-1, 0)
+    rt[1] = c.init_pos[1] + start_xy[2 * e + 1] + y_range * (2.0f * u.v[2] - 1.0f);
+    rt[2] = c.init_pos[2];
+    {   // quat_from_euler_xyz(0, pitch, yaw), xyzw (isaacgym torch_utils)
+        float sy, cy, sp, cp; sincosf(0.5f * yaw, &sy, &cy); sincosf(0.5f * pitch, &sp, &cp);
+        rt[3] = -sy * sp; rt[4] = cy * sp; rt[5] = sy * cp; rt[6] = cy * cp;
+    }
+#pragma unroll
+    for (int i = 7; i < 13; ++i) rt[i] = 0.f;
+    float *d = p.dof + (int64_t)e * 24;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        d[2 * j] = c.default_dof_pos[j]; d[2 * j + 1] = 0.f;
+        const int64_t k = (int64_t)e * 12 + j;
+        p.last_actions[k] = 0.f; p.last_dof_vel[k] = 0.f; p.last_torques_org[k] = 0.f; p.foot_impulse[k] = 0.f;
+    }
+    float *ah = p.action_hist + (int64_t)e * (QA_ACTION_BUF_LEN * 12);
+    for (int i = 0; i < QA_ACTION_BUF_LEN * 12; ++i) ah[i] = 0.f;
+    p.reset[e] = 1;
+}
+
+int qa_tsc_reset(qa_sim *s, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range, float rand_x_range,
+                 float rand_y_range, float rand_pitch_range, int64_t global_step, void *stream) {
+    if (!s || !reset_flags || !start_xy || !start_yaw) return QA_E_ARG;
+    const int N = s->cfg.num_envs;
+    hipLaunchKernelGGL(qa_tsc_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->cfg, s->p, reset_flags, start_xy, start_yaw,
+                       rand_yaw_range, rand_x_range, rand_y_range, rand_pitch_range, global_step);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }

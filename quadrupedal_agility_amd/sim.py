@@ -71,6 +71,22 @@ class QaSim:
         _check(self.lib.qa_env_step_dev(self.h, actions.data_ptr(), int(delay), step_counter.data_ptr(), self._stream()),
                self.lib, "qa_env_step_dev")
 
+    def physics_step(self, actions, delay=0):
+        """qa_env_physics_step: the step without post_physics_step (the task-level env brings its own)"""
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous() and actions.shape == (self.cfg.num_envs, 12)
+        _check(self.lib.qa_env_physics_step(self.h, actions.data_ptr(), int(delay), self._stream()), self.lib, "qa_env_physics_step")
+
+    def tsc_reset(self, flags, start_xy, start_yaw, yaw_range, x_range, y_range, pitch_range, step):
+        assert flags.is_cuda and flags.dtype == torch.uint8 and start_xy.is_contiguous() and start_yaw.is_contiguous()
+        _check(self.lib.qa_tsc_reset(self.h, flags.data_ptr(), start_xy.data_ptr(), start_yaw.data_ptr(), float(yaw_range), float(x_range),
+                                     float(y_range), float(pitch_range), int(step), self._stream()), self.lib, "qa_tsc_reset")
+
+    def simulate_if(self, torques, cond):
+        """one more substep for every env iff the device byte `cond` is non-zero; torques None = the ones applied last"""
+        assert cond.is_cuda and cond.dtype == torch.uint8
+        _check(self.lib.qa_simulate_if(self.h, torques.data_ptr() if torques is not None else None, cond.data_ptr(), self._stream()),
+               self.lib, "qa_simulate_if")
+
     def simulate(self, torques):
         assert torques.is_cuda and torques.dtype == torch.float32 and torques.is_contiguous()
         _check(self.lib.qa_simulate(self.h, torques.data_ptr(), self._stream()), self.lib, "qa_simulate")

@@ -1,0 +1,294 @@
+"""`LeggedRobot` of the task-level (TSC) tree -- the agility-course env the hybrid task policy is trained in
+(tsc/legged_gym/envs/base/legged_robot.py).  Same constructor, methods and attributes the task-level runner touches
+(`step(actions_bbc, action_hl_history_buf)`, `set_commands`, `get_observations(_bbc|_disc)`, `num_obs`, `num_actions_d/c`,
+`episode_length_buf`, `success_rate`, ...), built from four device pieces and no host-side arithmetic:
+
+  * `qa_env_physics_step` (include/qa_sim.h): action history / delay / clip, 4 x (PD -> articulated-body substep with contact
+    against the course's height field), refresh of root / dof / contact-force / rigid-body-state tensors   (:113-139, 231-234)
+  * `qa_tsc_goal_step`: episode clock, goal dwell + advance, 7 termination causes, 8 rewards                    (:204-262, 322-346, 412-430)
+  * `qa_tsc_reset` + `qa_simulate_if`: reset of the flagged envs and the reference's extra simulate on resets  (:348-410)
+  * `qa_tsc_observations`: 132-point scan, the 800 / 671 / 49 rows, history push                                (:432-515, 1708-1755)
+
+The course is `utils/obstacle.py::Obstacle` (bit-identical to the reference's generator).  Its int16 map is what the scan reads
+AND -- this build's physics model, DESIGN.md section 3.2 -- the collision terrain: bars, A-frame, poles, see-saw, tyre and tunnel
+are collided with as the 2.5-D surface the reference's scan map encodes, the border as 2 m walls.  What a height field cannot
+hold is stated there (tunnel roof and upper tyre ring: no contact from above; see-saw: fixed at its initial tilt)."""
+import numpy as np
+import torch
+
+from quadrupedal_agility_amd import _capi
+from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import class_to_dict
+from quadrupedal_agility_amd.tsc.legged_gym.task_level import TaskLevelBookkeeping
+from quadrupedal_agility_amd.tsc.legged_gym.utils.obstacle import Obstacle
+
+KEY_BODY_NAMES = ["FL_foot", "FR_foot", "RL_foot", "RR_foot"]
+
+
+def make_qa_config(cfg, obstacle, seed=1):
+    """qa_config for the physics-only use of the engine: simulator, PD controller, domain randomisation, the course as terrain.
+    Everything the behaviour-level post-physics phase would read (rewards, commands, noise) stays zero: that phase never runs."""
+    c = _capi.QaConfig()
+    c.abi_version, c.num_envs, c.seed = _capi.QA_ABI_VERSION, int(cfg.env.num_envs), int(seed) & 0xFFFFFFFFFFFFFFFF
+    c.sim_dt, c.decimation, c.gravity_z = float(cfg.sim.dt), int(cfg.control.decimation), float(cfg.sim.gravity[2])
+    c.solver_iterations = int(getattr(getattr(cfg.sim, "qa", None), "solver_iterations", 4))
+    c.contact_offset = float(cfg.sim.physx.contact_offset)
+    c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
+    c.ground_friction = float(cfg.terrain.static_friction)
+    c.terrain_type = 1
+    c.hf_rows, c.hf_cols = int(obstacle.tot_rows), int(obstacle.tot_cols)
+    c.hf_hscale, c.hf_vscale, c.hf_border = float(obstacle.horizontal_scale), float(obstacle.vertical_scale), float(cfg.obstacle.border_size)
+    if cfg.control.control_type != "P":
+        raise NotImplementedError("only control_type 'P' is on the hot path")
+    kp = {float(v) for v in cfg.control.stiffness.values()}
+    kd = {float(v) for v in cfg.control.damping.values()}
+    if len(kp) != 1 or len(kd) != 1:
+        raise NotImplementedError("one PD gain for every joint")
+    c.kp, c.kd = kp.pop(), kd.pop()
+    c.action_scale, c.hip_scale_reduction = float(cfg.control.action_scale), float(cfg.control.hip_scale_reduction)
+    c.clip_actions = float(cfg.normalization.clip_actions)
+    for i, name in enumerate(_capi.DOF_NAMES):
+        c.default_dof_pos[i] = float(cfg.init_state.default_joint_angles[name])
+    for i in range(3):
+        c.init_pos[i] = float(cfg.init_state.pos[i])
+    c.env_spacing, c.clip_obs = float(cfg.env.env_spacing), float(cfg.normalization.clip_observations)
+    dt = cfg.control.decimation * cfg.sim.dt
+    c.max_episode_length = int(np.ceil(cfg.env.episode_length_s / dt))
+    c.resampling_steps, c.push_interval = 1 << 30, 1 << 30
+    d = cfg.domain_rand
+    c.randomize_friction, c.randomize_base_mass = int(bool(d.randomize_friction)), int(bool(d.randomize_base_mass))
+    c.randomize_base_com, c.randomize_motor, c.use_easi = int(bool(d.randomize_base_com)), int(bool(d.randomize_motor)), 0
+    for k in range(2):
+        c.friction_range[k], c.added_mass_range[k] = float(d.friction_range[k]), float(d.added_mass_range[k])
+        c.added_com_range[k], c.motor_strength_range[k] = float(d.added_com_range[k]), float(d.motor_strength_range[k])
+    c.latent_temperature = 0.25
+    c.export_body_state = 1
+    return c
+
+
+class LeggedRobot:
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, backend=None, bookkeeping_lib=None):
+        self.cfg, self.sim_params, self.physics_engine, self.headless = cfg, sim_params, physics_engine, headless
+        if cfg.depth.use_camera:
+            raise NotImplementedError("the depth student (use_camera) is not built (SURVEY.md 8f row 3)")
+        if cfg.terrain.mesh_type != "obstacle":
+            raise NotImplementedError("the task-level env runs on the obstacle course (terrain.mesh_type 'obstacle')")
+        self.mocap_category = cfg.env.mocap_category_all
+        self.dim_c = len(self.mocap_category)
+        self.dt = cfg.control.decimation * cfg.sim.dt
+        self.obs_scales = cfg.normalization.obs_scales
+        self.command_ranges = class_to_dict(cfg.commands.ranges)
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        cfg.domain_rand.push_interval = np.ceil(cfg.domain_rand.push_interval_s / self.dt)
+        self.success_rate, self.obst_curr_count, self.bar_jump_bias, self.tire_jump_bias = 0, 0, 0, 0
+        self.num_envs = cfg.env.num_envs
+        self.num_obs, self.num_obs_bbc = cfg.env.num_observations, cfg.env.num_observations_bbc
+        self.num_privileged_obs, self.num_obs_disc = cfg.env.num_privileged_obs, cfg.env.num_obs_disc
+        self.num_actions_d, self.num_actions_c, self.num_actions = cfg.env.num_actions_d, cfg.env.num_actions_c, cfg.env.num_actions_bbc
+        self.num_bodies, self.num_dof = len(_capi.BODY_NAMES), 12
+        seed = int(getattr(cfg, "seed", 1))
+
+        # ---- course + engine
+        self.obstacle = Obstacle(cfg.obstacle, self.num_envs, seed=getattr(cfg, "course_seed", seed))
+        self.qcfg = make_qa_config(cfg, self.obstacle, seed=seed)
+        if backend is None:
+            from quadrupedal_agility_amd.sim import QaSim
+            backend = QaSim(self.qcfg, sim_device)
+        self.sim = backend
+        self.device = str(backend.device)
+        dev = self.device
+        t = self.sim.t
+        self.height_samples = torch.from_numpy(np.ascontiguousarray(self.obstacle.height_field_raw)).to(dev)
+        t["HEIGHT_SAMPLES"].copy_(self.height_samples)
+        self.x_edge_mask = torch.from_numpy(np.ascontiguousarray(self.obstacle.x_edge_mask)).to(dev)
+        self.env_origins = t["ENV_ORIGINS"]
+        self.env_origins.copy_(torch.from_numpy(self.obstacle.env_origins).to(dev, torch.float32))
+        self.env_goals = torch.from_numpy(self.obstacle.flat_goals()).to(dev, torch.float32).contiguous()     # (N, 26, 3)
+        self.obstacle_types = torch.from_numpy(self.obstacle.obstacle_types).to(dev, torch.long)
+        self.obst_angs = torch.from_numpy(self.obstacle.frame_ang).to(dev, torch.float32).unsqueeze(0).expand(self.num_envs, -1).contiguous()
+        self.custom_origins = True
+
+        # ---- buffers = views of the arena (the reference's gym tensors)
+        self.root_states = t["ROOT_STATES"]
+        self.dof_state = t["DOF_STATE"].view(self.num_envs * 12, 2)
+        self.dof_pos, self.dof_vel = t["DOF_STATE"][..., 0], t["DOF_STATE"][..., 1]
+        self.base_quat = self.root_states[:, 3:7]
+        self.contact_forces, self.rigid_body_states = t["CONTACT_FORCES"], t["RIGID_BODY_STATE"]
+        self.torques, self.torques_org, self.actions = t["TORQUES"], t["TORQUES_ORG"], t["ACTIONS"]
+        self.last_actions, self.last_dof_vel = t["LAST_ACTIONS"], t["LAST_DOF_VEL"]
+        self.last_torques_org, self.last_root_vel = t["LAST_TORQUES_ORG"], t["LAST_ROOT_VEL"]
+        self.action_history_buf = t["ACTION_HISTORY"]
+        self.motor_strength, self.mass_params_tensor, self.friction_coeffs_tensor = t["MOTOR_STRENGTH"], t["MASS_PARAMS"], t["FRICTION"]
+        q0 = [cfg.init_state.default_joint_angles[n] for n in _capi.DOF_NAMES]
+        self.default_dof_pos = torch.tensor(q0, dtype=torch.float, device=dev).unsqueeze(0)
+        self.default_dof_pos_all = self.default_dof_pos.clone()
+        names = _capi.BODY_NAMES
+        self.feet_indices = torch.tensor([i for i, n in enumerate(names) if cfg.asset.foot_name in n], device=dev)
+        self.penalised_contact_indices = torch.tensor([i for i, n in enumerate(names) if any(k in n for k in cfg.asset.penalize_contacts_on)], device=dev)
+        self.termination_contact_indices = torch.tensor([i for i, n in enumerate(names) if any(k in n for k in cfg.asset.terminate_after_contacts_on)], device=dev)
+        self.key_body_ids = torch.tensor([names.index(n) for n in KEY_BODY_NAMES], device=dev)
+        self.category_mapping = {c: i for i, c in enumerate(cfg.env.mocap_category_all)}
+        self.mocap_indices = torch.tensor([self.category_mapping[c] for c in cfg.env.mocap_category], device=dev)
+
+        # ---- goal / reward / observation bookkeeping (three HIP kernels behind one object)
+        self.bk = TaskLevelBookkeeping(cfg, self.env_goals, self.obstacle_types, self.x_edge_mask, self.feet_indices.tolist(),
+                                       self.penalised_contact_indices.tolist(), self.termination_contact_indices.tolist(), self.num_bodies,
+                                       device=dev, lib=bookkeeping_lib)
+        ys = torch.tensor(cfg.obstacle.measured_points_y, device=dev)
+        xs = torch.tensor(cfg.obstacle.measured_points_x, device=dev)
+        gx, gy = torch.meshgrid(xs, ys, indexing="ij")                                     # _init_height_points (:1686-1706)
+        self.num_height_points = gx.numel()
+        self.height_points = torch.stack([gx.flatten(), gy.flatten(), torch.zeros_like(gx.flatten())], dim=1).contiguous()
+        self.bk.init_observations(self.height_samples, self.height_points, self.default_dof_pos, self.default_dof_pos_all, self.key_body_ids.tolist())
+        self.reward_scales = dict(self.bk.reward_scales)
+        self.episode_sums = self.bk.episode_sums
+        self.extras = {}
+        self.global_counter = self.total_env_steps_counter = self.common_step_counter = 0
+        self.cur_obst_idx = torch.zeros(self.num_envs, dtype=torch.long, device=dev)
+        self._start_xy = torch.zeros(self.num_envs, 2, device=dev)
+        self._start_yaw = torch.zeros(self.num_envs, device=dev)
+        self._episode_means = torch.zeros(len(_capi.TSC_REWARD_NAMES), device=dev)
+        self._obs_disc_term = torch.zeros(self.num_envs, self.num_obs_disc, device=dev)
+        self._all = torch.ones(self.num_envs, dtype=torch.uint8, device=dev)
+        self.sync_reset_ids = True
+        self.init_done = True
+
+        # reset_idx(all); _resample_commands(all) is the reference's U(range) draw, superseded by the first set_commands
+        self._reset(self._all, first=True)
+        self.post_physics_step(None)
+
+    # ------------------------------------------------------------------ the attributes the runner / policy read live in the bookkeeping object
+    for _name in ("commands", "latent_eps", "latent_c", "cur_goal_idx", "reach_goal_timer", "cur_goals", "next_goals", "target_yaw", "next_target_yaw",
+                  "delta_yaw", "delta_next_yaw", "base_lin_vel", "base_ang_vel", "projected_gravity", "rew_buf", "obs_buf", "obs_bbc_buf",
+                  "obs_disc_buf", "obs_history_buf", "measured_heights", "cur_obstacle_types", "time_out_buf", "reach_goal_cutoff"):
+        locals()[_name] = property(lambda self, _n=_name: getattr(self.bk, _n))
+    del _name
+
+    @property
+    def reset_buf(self):
+        return self.bk.reset_buf
+
+    @property
+    def privileged_obs_buf(self):
+        return None                       # num_privileged_obs is None in the reference's config: the critic sees obs_buf
+
+    @property
+    def episode_length_buf(self):
+        return self.bk.episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):   # the runner rebinds it (on_policy_runner.py:162-163)
+        self.bk.episode_length_buf.copy_(value)
+
+    # ------------------------------------------------------------------ API
+    def set_commands(self, actions):
+        """:699-760.  The U(action_noise) multiplier comes from torch's generator like the reference's torch_rand_float."""
+        noise = None
+        if self.cfg.domain_rand.randomize_action:
+            lo, hi = self.cfg.domain_rand.action_noise
+            noise = torch.rand(self.num_envs, 5, device=self.device) * (hi - lo) + lo
+        return self.bk.set_commands(actions, noise)
+
+    def step(self, actions, action_hl_history_buf=None):
+        a = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        self.action_hl_history_buf = action_hl_history_buf
+        delay = int(self.cfg.domain_rand.action_delay_step) if self.cfg.domain_rand.action_delay else 0
+        self.global_counter += 1
+        self.total_env_steps_counter += 1
+        self.sim.physics_step(a, delay)
+        reset_env_ids, terminal = self.post_physics_step(action_hl_history_buf)
+        self.extras["delta_yaw_ok"] = torch.abs(self.bk.delta_yaw) < 0.6
+        self.extras["depth"] = None
+        return self.bk.obs_buf, self.privileged_obs_buf, self.bk.rew_buf, self.bk.reset_buf, self.extras, reset_env_ids, terminal
+
+    def post_physics_step(self, action_hl_history_buf):
+        """:226-296"""
+        bk, cfg = self.bk, self.cfg
+        self.common_step_counter += 1
+        if cfg.domain_rand.push_robots and self.common_step_counter % int(cfg.domain_rand.push_interval) == 0:
+            self._push_robots()        # before the goal step: its rewards read the pushed world velocity, as the reference's do (:643-644)
+        bk.post_physics_step(self.root_states, self.contact_forces, self.rigid_body_states, action_hl_history_buf, want_ids=False)
+        self.extras["reach_goal"] = bk.reach_goal_cutoff.view(torch.bool)
+        flags = bk.reset_buf
+        prev_disc = bk.obs_disc_buf.clone()                                  # get_observations_disc() of the envs about to reset (:263)
+        self._reset(flags)
+        upd = self.global_counter % cfg.depth.update_interval == 0
+        bk.compute_observations(self.root_states, self.dof_pos, self.dof_vel, self.action_history_buf, self.rigid_body_states,
+                                self.mass_params_tensor, self.friction_coeffs_tensor, self.motor_strength, update_yaw=upd)
+        self._obs_disc_term.copy_(torch.where(flags.view(-1, 1) != 0, prev_disc, bk.obs_disc_buf))
+        if self.sync_reset_ids:
+            env_ids = flags.nonzero(as_tuple=False).flatten()               # host sync, like the reference
+            return env_ids, prev_disc[env_ids]
+        return None, None
+
+    def _reset(self, flags, first=False):
+        """reset_idx (:348-410) of the flagged envs without a host sync: start pose, simulator state, bookkeeping, episode statistics,
+        then the reference's extra simulate (all envs, last torques) if anything was reset"""
+        bk, cfg = self.bk, self.cfg
+        ob = cfg.obstacle
+        n_goal = cfg.obstacle.num_goals
+        if ob.randomize_start:
+            draw = torch.randint(0, self.obstacle_types.shape[1], (self.num_envs,), device=self.device)
+            self.cur_obst_idx.copy_(torch.where(flags != 0, draw, self.cur_obst_idx))
+            start_goal = self.cur_obst_idx * n_goal
+            self._start_xy.copy_(self.env_goals.gather(1, start_goal[:, None, None].expand(-1, 1, 3)).squeeze(1)[:, :2])
+            self._start_yaw.copy_(self.obst_angs.gather(1, self.cur_obst_idx[:, None]).squeeze(1))
+        else:
+            start_goal = torch.zeros(self.num_envs, dtype=torch.long, device=self.device)
+            self._start_xy.copy_(self.env_goals[:, 0, :2])
+            self._start_yaw.fill_(float(self.obstacle.frame_ang[0]))
+        e = cfg.env
+        self.sim.tsc_reset(flags, self._start_xy, self._start_yaw,
+                           e.rand_yaw_range if e.randomize_start_yaw else 0.0, e.rand_x_range if e.randomize_start_x else 0.0,
+                           e.rand_y_range if e.randomize_start_y else 0.0, e.rand_pitch_range if (e.randomize_start_yaw and e.randomize_start_pitch) else 0.0,
+                           self.common_step_counter)
+        # extras["episode"]: mean episode sums of the resetting envs / episode length in seconds (:396-404), kept when nobody resets
+        f = (flags != 0).to(torch.float32)
+        cnt = f.sum()
+        mean = (bk.episode_sums_buf * f).sum(dim=1) / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
+        self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
+        snap = self._episode_means.clone()
+        self.extras["episode"] = {"rew_" + n: snap[i] for i, n in enumerate(_capi.TSC_REWARD_NAMES)}
+        if cfg.env.send_timeouts:
+            self.extras["time_outs"] = bk.time_out_buf.view(torch.bool)
+        bk.reset_where(flags, start_goal)
+        if not first:
+            self.sim.simulate_if(None, (flags != 0).any().to(torch.uint8).reshape(1))
+        else:
+            self.sim.simulate_if(None, torch.ones(1, dtype=torch.uint8, device=self.device))
+
+    def _push_robots(self):
+        """:905-915"""
+        m = self.cfg.domain_rand.max_push_vel_xy
+        self.root_states[:, 7:9] = (torch.rand(self.num_envs, 2, device=self.device) * 2 - 1) * m
+
+    def get_observations(self):
+        return self.bk.obs_buf
+
+    def get_observations_bbc(self):
+        return self.bk.obs_bbc_buf
+
+    def get_observations_disc(self):
+        return self.bk.obs_disc_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    def get_history_observations(self):
+        return self.bk.obs_history_buf
+
+    @property
+    def obs_disc_term_buf(self):
+        """obs_disc_buf with the rows of the envs that reset this step replaced by their terminal (pre-reset) observation"""
+        return self._obs_disc_term
+
+    def reset(self):
+        self._reset(self._all)
+        self.post_physics_step(None)
+        return self.bk.obs_buf, self.privileged_obs_buf
+
+    def set_camera(self, position, lookat):
+        pass
+
+    def render(self, sync_frame_time=True):
+        pass

@@ -108,8 +108,6 @@ class LeggedRobotCfg(BaseConfig):
         frame_pos = [[[5.5, 1.0], [5.5, 5.0]], [[5.5, 5.0], [5.5, 9.0]], [[3.5, 9.0], [3.5, 5.0]],
                      [[3.5, 5.0], [3.5, 1.0]], [[1.5, 1.0], [1.5, 5.0]], [[1.5, 5.0], [1.5, 9.0]]]
         frame_ang = [90, 90, -90, -90, 90, 90]
-        # seesaw_damping_range: the reference randomises the see-saw joint's damping in U(1, 10) when it creates the actors
-        seesaw_damping_range = [1.0, 10.0]
 
     class commands:
         curriculum, max_curriculum = False, 1.0

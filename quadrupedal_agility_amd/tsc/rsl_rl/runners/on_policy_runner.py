@@ -1,0 +1,214 @@
+"""`OnPolicyRunner` of the task-level tree: the two-level rollout `learn_RL` (tsc/rsl_rl/runners/on_policy_runner.py:19-276) and
+the checkpoint layout (:443-520).  Per env step: task policy (hybrid action) -> `env.set_commands` -> command block of the
+behaviour row -> FROZEN behaviour policy (history-encoder variant, mean action) -> `env.step` -> frozen style discriminator's
+reward -> `alg.process_env_step`.  Same constructor and attributes as the reference (`alg`, `actor_critic_bbc`,
+`discriminator`, `learn`, `save` / `load` / `load_bbc`); the depth-student half (`learn_vision`) is not built.
+
+MI355X: no host wait inside a rollout (`env.sync_reset_ids = False`: terminal discriminator rows come as a masked tensor,
+episode statistics stay on the device until the logger reads them); the frozen behaviour policy is ONE `qa_mlp_forward` launch
+per step (fused.PolicyChain, weights packed once -- they never change); GAE / Adam / Linear+ELU backward are the fused kernels
+the task-level PPO mirror already uses."""
+import os
+import statistics
+import time
+from collections import deque
+
+import torch
+
+from quadrupedal_agility_amd.rsl_rl.utils.utils import Normalizer, TorchNormalizer
+from quadrupedal_agility_amd.tsc.rsl_rl.algorithms import PPO, Discriminator
+from quadrupedal_agility_amd.tsc.rsl_rl.modules import ActorCriticBBC, ActorCriticTSC, Estimator
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cpu"):
+        self.cfg, self.alg_cfg = train_cfg["runner"], dict(train_cfg["algorithm"])
+        self.policy_cfg, self.estimator_cfg = train_cfg["policy"], train_cfg["estimator"]
+        self.depth_encoder_cfg = train_cfg["depth_encoder"]
+        self.device, self.env = device, env
+        e = env.cfg.env
+        self.num_obs, self.n_proprio, self.n_auxiliary, self.n_scan = env.num_obs, e.n_proprio, e.n_auxiliary, e.n_scan
+        self.n_priv, self.n_priv_latent, self.history_len = e.n_priv, e.n_priv_latent, e.history_len
+        self.num_actions_d, self.num_actions_c = env.num_actions_d, env.num_actions_c
+        self.num_actions = 1 + self.num_actions_d * self.num_actions_c
+        self.num_command, self.num_obs_bbc = e.num_command, e.num_observations_bbc
+        self.num_critic_obs = e.num_observations_bbc + e.history_len * (e.n_proprio - e.n_auxiliary)
+        self.num_actions_bbc = e.num_actions_bbc
+        self.num_disc_obs, self.disc_obs_len = e.num_obs_disc, e.disc_obs_len
+        r = self.cfg
+        self.disc_loss_function = r["disc_loss_function"]
+        if self.depth_encoder_cfg["if_depth"]:
+            raise NotImplementedError("the depth student (learn_vision) is not built (SURVEY.md 8f row 3)")
+        self.if_depth = False
+
+        self.actor_critic = ActorCriticTSC(self.n_proprio, self.n_auxiliary, self.n_scan, self.num_obs, self.n_priv_latent, self.n_priv,
+                                           self.history_len, self.num_actions_d, self.num_actions_c, device=device, **self.policy_cfg).to(device)
+        self.actor_critic_bbc = ActorCriticBBC(self.num_obs_bbc, self.num_critic_obs, self.num_actions_bbc, self.n_proprio, self.n_auxiliary,
+                                               self.history_len, self.n_priv, self.n_priv_latent, self.num_command, **self.policy_cfg).to(device)
+        self.estimator = Estimator(input_dim=self.n_proprio - self.n_auxiliary, output_dim=self.n_priv,
+                                   hidden_dims=self.estimator_cfg["hidden_dims"]).to(device)
+        self.depth_encoder = self.depth_actor = None
+        self.alg = PPO(self.actor_critic, self.actor_critic_bbc, self.estimator, self.estimator_cfg, None, self.depth_encoder_cfg, None,
+                       device=device, **self.alg_cfg)
+        self.num_steps_per_env, self.save_interval = r["num_steps_per_env"], r["save_interval"]
+        self.dagger_update_freq = self.alg_cfg["dagger_update_freq"]
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [self.num_actions])
+        on_gpu = torch.device(device).type == "cuda"
+        norm = TorchNormalizer(self.num_disc_obs * self.disc_obs_len, device) if on_gpu else Normalizer(self.num_disc_obs * self.disc_obs_len)
+        self.discriminator = Discriminator(self.num_disc_obs * self.disc_obs_len, self.num_disc_obs, env.dim_c, env.dt, self.disc_loss_function,
+                                           Normalizer(1) if self.disc_loss_function == "WassersteinLoss" else None, r["reward_i_coef"],
+                                           r["reward_us_coef"], r["reward_ss_coef"], r["reward_t_coef"], self.disc_obs_len, r["disc_hidden_units"],
+                                           norm, device).to(device)
+        self.learn = self.learn_RL
+        self.log_dir, self.writer = log_dir, None
+        self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0, 0
+        self.last_perf = {}
+        self._bbc_chain = None
+        self.use_fused_policy = on_gpu and os.environ.get("QA_FUSED_POLICY", "1") != "0"
+        env.sync_reset_ids = False              # rollouts never wait for the GPU
+
+    # ------------------------------------------------------------------ the frozen behaviour policy: one launch per env step
+    def _behaviour_policy(self):
+        bbc = self.actor_critic_bbc
+        if not self.use_fused_policy:
+            return lambda obs: bbc.act_inference(obs, hist_encoding=True).detach()
+        if self._bbc_chain is None:
+            from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
+            chain = PolicyChain.describe(bbc, None, False, hist_encoding=True, with_critic=False)
+            if chain is None:
+                self.use_fused_policy = False
+                return self._behaviour_policy()
+            with torch.inference_mode():
+                chain.pack()
+            self._bbc_chain = chain
+        return lambda obs: self._bbc_chain.forward(obs)[0]
+
+    def learn_RL(self, num_learning_iterations, init_at_random_ep_len=False):
+        env, alg, dev = self.env, self.alg, self.device
+        if self.log_dir is not None and self.writer is None:
+            from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _make_writer
+            self.writer = _make_writer(self.log_dir)
+        if init_at_random_ep_len:
+            env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        obs, obs_bbc = env.get_observations(), env.get_observations_bbc().clone()
+        disc_obs = env.get_observations_disc()
+        hist = torch.stack([disc_obs] * self.disc_obs_len, dim=1).clone()
+        action_history_buf = torch.zeros(env.num_envs, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev)
+        critic_obs = obs
+        infos = {"depth": None}
+        alg.actor_critic.train()
+        bbc = self._behaviour_policy()
+        n_cmd = 6 + env.dim_c
+        ep_infos = []
+        keys = ("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")
+        buffers = {k: deque(maxlen=1000) for k in keys}
+        reach_goal_buffer = deque(maxlen=1000)
+        cur = torch.zeros(6, env.num_envs, device=dev)
+        logging = self.log_dir is not None
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            start = time.time()
+            hist_encoding = it % self.dagger_update_freq == 0
+            fin_vals, fin_masks, fin_reach = [], [], []
+            with torch.inference_mode():
+                for _ in range(self.num_steps_per_env):
+                    actions = alg.act(obs, critic_obs, infos, hist_encoding=hist_encoding)
+                    action_history_buf = torch.cat([action_history_buf[:, 1:], actions[:, None, :]], dim=1)
+                    next_commands = env.set_commands(actions)
+                    obs_bbc[:, -n_cmd:] = next_commands
+                    actions_bbc = bbc(obs_bbc)
+                    obs, privileged_obs, rewards, dones, infos, _ids, _term = env.step(actions_bbc, action_history_buf)
+                    critic_obs = privileged_obs if privileged_obs is not None else obs
+                    next_obs_bbc, disc_obs = env.get_observations_bbc(), env.get_observations_disc()
+                    # history of discriminator observations: the terminal row for envs that reset, then restart (:219-234)
+                    hist = torch.cat([hist[:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
+                    rewards, r_i, r_us, r_ss, r_t = self.discriminator.predict_disc_reward(rewards.unsqueeze(1), obs_bbc, hist)
+                    total_rew = alg.process_env_step(rewards, dones, infos)
+                    obs_bbc = next_obs_bbc.clone()
+                    done = dones != 0
+                    hist = torch.where(done.view(-1, 1, 1), torch.stack([disc_obs] * self.disc_obs_len, dim=1), hist)
+                    if logging:
+                        if "episode" in infos:
+                            ep_infos.append(infos["episode"])
+                        cur += torch.stack([total_rew, r_i, r_us, r_ss, r_t, torch.ones_like(r_t)])
+                        fin_vals.append(cur.clone()); fin_masks.append(done); fin_reach.append(infos["reach_goal"].clone())
+                        cur *= (~done).to(cur.dtype)
+                collection_time = time.time() - start
+                start = time.time()
+                alg.compute_returns(critic_obs)
+            losses = alg.update()
+            mean_hist_latent_loss = alg.update_dagger() if hist_encoding else 0.0
+            learn_time = time.time() - start
+            if logging:            # ONE host read per iteration for the episode statistics
+                vals, masks, reach = torch.stack(fin_vals), torch.stack(fin_masks), torch.stack(fin_reach)
+                sel = vals.permute(0, 2, 1)[masks].cpu()
+                for i, k in enumerate(keys):
+                    buffers[k].extend(sel[:, i].tolist())
+                reach_goal_buffer.extend(reach[masks].float().cpu().tolist())
+                if len(reach_goal_buffer) > 0:
+                    env.success_rate = statistics.mean(reach_goal_buffer)
+                self._log(it, losses, mean_hist_latent_loss, collection_time, learn_time, buffers, ep_infos)
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, "model.pt"))
+            ep_infos.clear()
+            self.last_perf = {"collection_time": collection_time, "learn_time": learn_time,
+                              "fps": self.num_steps_per_env * env.num_envs / (collection_time + learn_time)}
+        self.current_learning_iteration = tot_iter
+        if logging:
+            self.save(os.path.join(self.log_dir, "model.pt"))
+
+    def _log(self, it, losses, hist_loss, collection_time, learn_time, buffers, ep_infos):
+        w = self.writer
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
+        self.tot_time += collection_time + learn_time
+        if ep_infos:
+            for key in ep_infos[0]:
+                vals = torch.stack([torch.as_tensor(e[key], device=self.device).reshape(()) for e in ep_infos])
+                w.add_scalar("Episode/" + key, vals.mean().item(), it)
+        for tag, v in zip(("value_function", "surrogate", "estimator", "disc", "disc_acc", "priv_reg", "priv_reg_coef"), losses):
+            w.add_scalar("Loss/" + tag, v, it)
+        w.add_scalar("Loss/hist_latent_loss", hist_loss, it)
+        w.add_scalar("Loss/learning_rate", self.alg.learning_rate, it)
+        w.add_scalar("Perf/total_fps", int(self.num_steps_per_env * self.env.num_envs / (collection_time + learn_time)), it)
+        w.add_scalar("Perf/collection time", collection_time, it)
+        w.add_scalar("Perf/learning_time", learn_time, it)
+        if len(buffers["rew"]) > 0:
+            for tag, k in (("mean_reward", "rew"), ("mean_reward_i", "rew_i"), ("mean_reward_t", "rew_t"), ("mean_episode_length", "len")):
+                w.add_scalar("Train/" + tag, statistics.mean(buffers[k]), it)
+            w.add_scalar("Train/success_rate", float(self.env.success_rate), it)
+        if hasattr(w, "flush"):
+            w.flush()
+
+    # ------------------------------------------------------------------ checkpoints (:443-520: same keys)
+    def save(self, path, infos=None):
+        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(), "estimator_state_dict": self.alg.estimator.state_dict(),
+                    "optimizer_state_dict": self.alg.optimizer.state_dict(), "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        d = torch.load(path, map_location=self.device, weights_only=False)
+        self.alg.actor_critic.load_state_dict(d["model_state_dict"])
+        self.alg.estimator.load_state_dict(d["estimator_state_dict"])
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = d["iter"]
+        return d["infos"]
+
+    def load_bbc(self, path):
+        """the frozen behaviour controller, its estimator (estimator.load_estimator_bbc) and the style discriminator with its
+        input normaliser from a behaviour-level model.pt (keys `actor_critic`, `estimator`, `disc`, `disc_normalizer`)"""
+        import quadrupedal_agility_amd
+        quadrupedal_agility_amd.install_reference_aliases()
+        d = torch.load(path, map_location=self.device, weights_only=False)
+        self.actor_critic_bbc.load_state_dict(d["actor_critic"])
+        if self.estimator_cfg.get("load_estimator_bbc", False):
+            self.alg.estimator.load_state_dict(d["estimator"])
+        self.discriminator.load_state_dict(d["disc"])
+        n = d["disc_normalizer"]
+        self.discriminator.normalizer = TorchNormalizer.from_reference(n, self.device) if torch.device(self.device).type == "cuda" else n
+        self._bbc_chain = None
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        if device is not None:
+            self.alg.actor_critic.to(device)
+        return self.alg.actor_critic.act_inference

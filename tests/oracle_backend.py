@@ -26,6 +26,18 @@ class OracleBackend:
         self.o.step(actions.detach().cpu().numpy(), delay)
         self.global_step += 1
 
+    def physics_step(self, actions, delay=0):
+        a = np.ascontiguousarray(actions.detach().cpu().numpy(), dtype=np.float32)
+        assert self.o.lib.qo_env_physics_step(self.o.h, a.ctypes.data, int(delay), None) == 0
+
+    def tsc_reset(self, flags, start_xy, start_yaw, yaw_range, x_range, y_range, pitch_range, step):
+        f, xy, yw = flags.contiguous(), start_xy.contiguous(), start_yaw.contiguous()
+        assert self.o.lib.qo_tsc_reset(self.o.h, f.data_ptr(), xy.data_ptr(), yw.data_ptr(), C.c_float(yaw_range), C.c_float(x_range),
+                                       C.c_float(y_range), C.c_float(pitch_range), C.c_int64(int(step)), None) == 0
+
+    def simulate_if(self, torques, cond):
+        assert self.o.lib.qo_simulate_if(self.o.h, torques.data_ptr() if torques is not None else None, cond.data_ptr(), None) == 0
+
     def set_mocap(self, frames, clips, first_clip):
         f = np.ascontiguousarray(frames, dtype=np.float32)
         ct = np.ascontiguousarray(clips, dtype=np.float64)
