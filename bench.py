@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator + mocap reset on the real Go2 clips (baked dataset shipped with the package)")
     ap.add_argument("--terrain", default="plane", choices=["plane", "trimesh"],
                     help="plane = BASELINE configs 1-2 (flat terrain); trimesh = the reference's 10x40 tile course as a height field")
+    ap.add_argument("--tsc", action="store_true", help="BASELINE config 4: TSC teacher on the agility course (two-level rollout, hybrid PPO); "
+                    "--num_envs is per GPU (8192 over 8 GPUs = 1024 per GPU)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch the rollout eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
@@ -65,6 +67,8 @@ def main():
         g.build()
     if world > 1:
         dist.barrier()
+    if args.tsc:
+        return bench_tsc(args, world, rank, local_rank, dev)
     from quadrupedal_agility_amd.legged_gym.envs import task_registry  # noqa: F401  (registers tasks)
     from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
     from quadrupedal_agility_amd.legged_gym.utils import get_args
@@ -220,6 +224,69 @@ def main():
         # JSON line is the LAST line of output
         import ctypes
         ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+
+
+TSC_ALG_BYTES_PER_ENV_STEP = 7300       # obs 800 x 4, 132 int16 scan lookups + 8 edge-mask lookups on top of the BBC figure
+
+
+def bench_tsc(args, world, rank, local_rank, dev):
+    """BASELINE config 4: one step = one learn_RL iteration of the task-level tree -- 24 x (task policy -> set_commands -> frozen
+    behaviour policy -> physics step on the obstacle course -> goal step -> reset -> observations -> discriminator reward),
+    GAE, 5 epochs x 4 minibatches of the hybrid PPO.  Single process per GPU; ranks are replicas of the rollout with their own
+    courses (the task-level learner's gradient exchange is not wired: `scaling` says so)."""
+    import torch
+    from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import class_to_dict
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.go2.go2_agility_config import Go2AgilityCfg, Go2AgilityCfgPPO
+    from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
+    n = args.num_envs if args.num_envs != 4096 else 1024
+    cfg = Go2AgilityCfg()
+    cfg.env.num_envs, cfg.seed = n, 1 + 7919 * rank
+    d = cfg.domain_rand                                    # the reference's command line for this config: --randomize_base_mass ... --randomize_start
+    d.randomize_base_mass = d.randomize_base_com = d.push_robots = True
+    cfg.obstacle.randomize_start = True
+    torch.manual_seed(1)
+    env = lr.LeggedRobot(cfg, sim_device=dev)
+    runner = OnPolicyRunner(env, class_to_dict(Go2AgilityCfgPPO()), log_dir=None, device=dev)
+    runner.learn(max(args.warmup, 2), init_at_random_ep_len=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    coll = []
+    for _ in range(args.steps):
+        runner.learn(1)
+        coll.append(runner.last_perf["collection_time"])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the env-side kernels of one step, timed alone with HIP events on the launch stream
+    act = torch.zeros(n, 12, device=dev)
+    hist = torch.zeros(n, 8, 19, device=dev)
+    spans = {}
+    for name, fn in (("physics", lambda: env.sim.physics_step(act, 1)),
+                     ("goal_step", lambda: env.bk.post_physics_step(env.root_states, env.contact_forces, env.rigid_body_states, hist, want_ids=False)),
+                     ("observations", lambda: env.bk.compute_observations(env.root_states, env.dof_pos, env.dof_vel, env.action_history_buf, env.rigid_body_states,
+                                                                          env.mass_params_tensor, env.friction_coeffs_tensor, env.motor_strength))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); e0.record()
+        for _ in range(40):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        spans[name] = e0.elapsed_time(e1) / 40
+    T = runner.num_steps_per_env
+    kern_ms = sum(spans.values())
+    achieved = TSC_ALG_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+    out = {"metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU", "value": n * T * args.steps * world / dt, "unit": "env-steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak (independent replicas: the task-level learner's gradient exchange is not wired)", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"TSC-teacher agility course (6 obstacles/env as height-field collision terrain, randomize_base_mass/com, push_robots, randomize_start, "
+                                  f"action noise U(0.8,1.2), frozen behaviour policy + discriminator at their initial weights), {n} envs/GPU, 24 steps/iter, 5 epochs x 4 minibatches",
+                      "num_envs_per_gpu": n, "steps_per_iter": T, "parallelism": f"replicas{world}"},
+           "collection_s": sum(coll) / len(coll), "learn_s": dt / args.steps - sum(coll) / len(coll),
+           "rollout_env_steps_per_s": n * T / (sum(coll) / len(coll)),
+           "roofline": {"kernel": "qa_env_step_kernel<false,4,1> + qa_tsc_goal_step + qa_tsc_observations", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "kernel_ms_each": spans,
+                        "algorithmic_bytes_per_launch": TSC_ALG_BYTES_PER_ENV_STEP * n}}
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
 
