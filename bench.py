@@ -36,7 +36,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU (weak scaling)")
+    ap.add_argument("--num_envs", type=int, default=4096, help="envs of the whole job with --scaling strong (BASELINE metric: 4096), envs per GPU with --scaling weak")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, the BASELINE metric and SURVEY 8e): --num_envs envs in total, rank r owns [r N/W, (r+1) N/W); "
+                         "weak: --num_envs envs on every GPU")
     ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator + mocap reset on the real Go2 clips (baked dataset shipped with the package)")
     ap.add_argument("--terrain", default="plane", choices=["plane", "trimesh"],
                     help="plane = BASELINE configs 1-2 (flat terrain); trimesh = the reference's 10x40 tile course as a height field")
@@ -73,11 +76,17 @@ def main():
     from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
     from quadrupedal_agility_amd.legged_gym.utils import get_args
 
+    if args.scaling == "strong" and args.num_envs % world:
+        raise SystemExit(f"--num_envs {args.num_envs} does not split over {world} ranks")
+    per_rank = args.num_envs // world if args.scaling == "strong" else args.num_envs
+    total_envs = per_rank * world
+    args.num_envs = per_rank                         # from here on: envs of THIS rank
     cfg = Go2LocomotionCfg()
-    cfg.env.num_envs = args.num_envs
+    cfg.env.num_envs = per_rank
+    cfg.env.env_id_offset, cfg.env.num_envs_global = rank * per_rank, total_envs      # random draws keyed by the global env id: the same job at any world size
     cfg.terrain.mesh_type = args.terrain
     cfg.env.mocap_state_init = bool(args.amp)
-    cfg.seed = 1 + 7919 * rank                       # disjoint Philox streams per rank
+    cfg.seed = 1
     tcfg = Go2LocomotionCfgAlgo()
     tcfg.runner.amp_enabled = bool(args.amp)
     tcfg.runner.rollout_graph = not args.no_graph
@@ -187,12 +196,12 @@ def main():
         out = {
             "metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"go2_locomotion BBC + AMP (5 mocap gaits, {getattr(env, 'mocap_source', 'none')} clips: 17 labelled + 295 unlabelled), " if args.amp else
                                     "go2_locomotion BBC, discriminator off, default-pose reset, ") +
-                                   f"{args.num_envs} envs/GPU, {'plane' if args.terrain == 'plane' else 'height-field (trimesh course)'} terrain, 24 steps/iter, 5 epochs x 4 minibatches",
-                       "num_envs_per_gpu": args.num_envs, "steps_per_iter": T, "parallelism": f"dp{world}"},
+                                   f"{total_envs} envs in total = {args.num_envs} envs/GPU x {world}, {'plane' if args.terrain == 'plane' else 'height-field (trimesh course)'} terrain, 24 steps/iter, 5 epochs x 4 minibatches",
+                       "num_envs_total": total_envs, "num_envs_per_gpu": args.num_envs, "steps_per_iter": T, "parallelism": f"dp{world}"},
             "wallclock_1k_iters_s": dt / args.steps * 1000.0,
             "rollout_env_steps_per_s": args.num_envs * T * world / (sum(coll) / len(coll)),
             "collection_s": sum(coll) / len(coll), "learn_s": sum(lrn) / len(lrn),

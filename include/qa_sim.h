@@ -182,7 +182,11 @@ typedef struct qa_config {
     /* mocap clips (reset_mode 1) */
     int32_t num_mocap_frames;       /* rows of QA_T_MOCAP_FRAMES */
     int32_t export_body_state;      /* != 0: step / simulate also refresh QA_T_RIGID_BODY_STATE (N,19,13) */
-    int32_t reserved_cfg[4];
+    int32_t env_id_offset;          /* GLOBAL id of local env 0: every random draw is keyed by (seed; env_id_offset + e, step, stream), and
+                                       the spawn grid is laid out over global ids, so rank r of a data-parallel run that owns envs
+                                       [r N/W, (r+1) N/W) of an N-env job reproduces exactly those envs of the one-process run */
+    int32_t num_envs_global;        /* envs of the whole job (0 = num_envs): size of the spawn grid */
+    int32_t reserved_cfg[2];
 } qa_config;
 
 typedef struct qa_sim qa_sim;
@@ -369,12 +373,12 @@ int qa_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min,
  * qa_rollout_act: a = mean + std * eps, log-prob of a under N(mean, std); writes `actions` (N,12) for the env and the
  *   step's storage rows st_actions / st_mu / st_sigma (N,12), st_logp / st_values (N).  `noise` (N,12) supplies eps;
  *   NULL draws it from the engine's Philox generator, stream 20, keyed by (seed; env, step) with step = *step_dev when
- *   step_dev != NULL (recorded launches) else `step`.
+ *   step_dev != NULL (recorded launches) else `step`; env = env_id_offset + row (the engine's global env id, qa_config).
  * qa_rollout_post: st_rewards = reward_coef * rew + gamma * values * time_out; st_dones = reset > 0; if `cur` != NULL,
  *   the six running sums cur (6,N) [total, i, us, ss, t, length] advance by [reward_coef*rew, 0, 0, 0, rew, 1], are
  *   copied to fin_vals (6,N), and are cleared where done; fin_mask (N) = done. */
 int qa_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
-                   int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                   int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
                    float *st_values, void *stream);
 int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
                     int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream);

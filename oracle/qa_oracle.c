@@ -137,6 +137,7 @@ enum { RS_INIT_BUCKET = 1, RS_INIT_FRICTION = 2, RS_INIT_MASS = 3, RS_INIT_MOTOR
 
 static void rng4(const qo_sim *s, uint32_t env, int64_t step, int stream, int block, float u[4]) {
     uint32_t o[4];
+    if (stream != RS_INIT_BUCKET) env += (uint32_t)s->cfg.env_id_offset;      /* key = GLOBAL env id (friction buckets are shared, not per env) */
     philox(s->cfg.seed, env, (uint32_t)step, (uint32_t)(stream * 256 + block), (uint32_t)((uint64_t)step >> 32), o);
     for (int i = 0; i < 4; ++i) u[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
 }
@@ -940,10 +941,11 @@ int qo_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
     memset(arena, 0, (size_t)s->L.total);
     int N = cfg->num_envs;
     /* env origins: grid (legged_robot.py:1126-1136) */
-    int ncols = (int)floor(sqrt((double)N));
+    int ncols = (int)floor(sqrt((double)(cfg->num_envs_global > 0 ? cfg->num_envs_global : N)));
     for (int e = 0; e < N; ++e) {
         float *o = TP(s, QA_T_ENV_ORIGINS, float) + 3 * e;
-        o[0] = cfg->env_spacing * (float)(e / ncols); o[1] = cfg->env_spacing * (float)(e % ncols); o[2] = 0;
+        int ge = e + cfg->env_id_offset;                      /* spawn-grid slot by global env id */
+        o[0] = cfg->env_spacing * (float)(ge / ncols); o[1] = cfg->env_spacing * (float)(ge % ncols); o[2] = 0;
         float u[4];
         /* friction: 64 buckets, legged_robot.py:386-401 */
         float fr = 1.0f;
@@ -1289,7 +1291,7 @@ int qo_clip_adam_step_hostgrads(float *const *params, const float *const *grads_
 
 /* rollout bookkeeping twins (host pointers) */
 int qo_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
-                   int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                   int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
                    float *st_values, void *stream) {
     (void)stream;
     if (!mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp || !st_values || num_envs <= 0) return QA_E_ARG;
@@ -1299,7 +1301,7 @@ int qo_rollout_act(const float *mean, const float *std, const float *value, cons
         if (noise) for (int j = 0; j < 12; ++j) eps[j] = noise[(int64_t)e * 12 + j];
         else for (int b = 0; b < 3; ++b) {
             uint32_t o[4]; float u[4];
-            philox(seed, (uint32_t)e, (uint32_t)step, (uint32_t)(20 * 256 + b), (uint32_t)((uint64_t)step >> 32), o);
+            philox(seed, (uint32_t)(e + env_id_offset), (uint32_t)step, (uint32_t)(20 * 256 + b), (uint32_t)((uint64_t)step >> 32), o);
             for (int i = 0; i < 4; ++i) u[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
             float r0 = sqrtf(-2.0f * logf(fmaxf(u[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(u[2], 1e-7f)));
             eps[4 * b] = r0 * cosf(6.28318530717958647692f * u[1]); eps[4 * b + 1] = r0 * sinf(6.28318530717958647692f * u[1]);

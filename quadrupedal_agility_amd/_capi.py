@@ -76,7 +76,8 @@ class QaConfig(C.Structure):
         ("easi_mean", C.c_float * 6), ("easi_var", C.c_float * 6),
         ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("hf_hscale", C.c_float), ("hf_vscale", C.c_float),
         ("hf_border", C.c_float), ("reset_xy_jitter", C.c_float),
-        ("num_mocap_frames", C.c_int32), ("export_body_state", C.c_int32), ("reserved_cfg", C.c_int32 * 4),
+        ("num_mocap_frames", C.c_int32), ("export_body_state", C.c_int32), ("env_id_offset", C.c_int32), ("num_envs_global", C.c_int32),
+        ("reserved_cfg", C.c_int32 * 2),
     ]
 
 
@@ -116,7 +117,7 @@ def bind(lib, prefix):
     f.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
     f = getattr(lib, prefix + "rollout_act")
-    f.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7
+    f.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     f.restype = C.c_int
     f = getattr(lib, prefix + "rollout_post")
     f.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int32] + [C.c_void_p] * 6

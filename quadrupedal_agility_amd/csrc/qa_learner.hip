@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
 constexpr int RS_ACT_NOISE = 20;
 
 __global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ value,
-                                                             const float *__restrict__ noise, uint64_t seed, const int64_t *step_ptr, int64_t step_host, int N,
+                                                             const float *__restrict__ noise, uint64_t seed, const int64_t *step_ptr, int64_t step_host, int N, int env0,
                                                              float *__restrict__ actions, float *__restrict__ st_actions, float *__restrict__ st_mu,
                                                              float *__restrict__ st_sigma, float *__restrict__ st_logp, float *__restrict__ st_values) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__rest
     } else {
 #pragma unroll
         for (int b = 0; b < 3; ++b) {          // Box-Muller on the 4 uniforms of a Philox block: 4 normals
-            F4 u = rng4(seed, (uint32_t)e, step, RS_ACT_NOISE, b);
+            F4 u = rng4(seed, (uint32_t)(e + env0), step, RS_ACT_NOISE, b);
             const float r0 = sqrtf(-2.0f * logf(fmaxf(u.v[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(u.v[2], 1e-7f)));
             float s0, c0, s1, c1;
             sincosf(6.28318530717958647692f * u.v[1], &s0, &c0);
@@ -875,12 +875,12 @@ int qa_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min,
 }
 
 int qa_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
-                   int64_t step, int32_t num_envs, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                   int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
                    float *st_values, void *stream) {
     if (!mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp || !st_values || num_envs <= 0) {
         snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: bad argument"); return QA_E_ARG; }
     hipLaunchKernelGGL(qa_rollout_act_kernel, dim3((num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, std, value, noise, seed, step_dev, step,
-                       (int)num_envs, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
+                       (int)num_envs, (int)env_id_offset, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

@@ -135,7 +135,7 @@ __device__ __forceinline__ void stage_table(float *s_tbl) {
 // legged_robot.py:532-540 + :474-530, executed redundantly by the 4 lanes of the quad
 __device__ __forceinline__ void resample_commands(const qa_config &c, const float *prior, int env, int64_t step, int stream,
                                                   float cmd[5], float &eps, int &gait) {
-    F4 u0 = rng4(c.seed, env, step, stream, 0), u1 = rng4(c.seed, env, step, stream, 1);
+    F4 u0 = rng4(c.seed, env + c.env_id_offset, step, stream, 0), u1 = rng4(c.seed, env + c.env_id_offset, step, stream, 1);
     eps = u0.v[1] * 2.0f - 1.0f;
     float z[5], zmax = -1e30f, sum = 0.f;
 #pragma unroll
@@ -199,7 +199,7 @@ __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, con
         // MotionLoader.get_full_frame_batch (motion_loader.py:461-474): clip ~ MotionWeight inside the gait, time ~ U over the
         // clip's sampling range, the two bracketing frames blended (get_full_frame_at_time_batch :410-447); index arithmetic in
         // float64 as numpy does it, the blend itself in fp32 as torch does it
-        F4 u = rng4(c.seed, env, step, RS_RESET, 0);
+        F4 u = rng4(c.seed, env + c.env_id_offset, step, RS_RESET, 0);
         const int c0 = (int)p.mocap_clips[QA_MOCAP_CLIP * gait + 5], c1 = (int)p.mocap_clips[QA_MOCAP_CLIP * (gait + 1) + 5];   // first_clip[] rides in column 5
         int clip = c1 - 1;
         for (int i = c1 - 2; i >= c0; --i) if ((double)u.v[0] < p.mocap_clips[QA_MOCAP_CLIP * i + 4]) clip = i;     // first clip with u < cdf
@@ -222,7 +222,7 @@ __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, con
     } else {
         float u[20];
 #pragma unroll
-        for (int b = 0; b < 5; ++b) { F4 t = rng4(c.seed, env, step, RS_RESET, b); u[4 * b] = t.v[0]; u[4 * b + 1] = t.v[1]; u[4 * b + 2] = t.v[2]; u[4 * b + 3] = t.v[3]; }
+        for (int b = 0; b < 5; ++b) { F4 t = rng4(c.seed, env + c.env_id_offset, step, RS_RESET, b); u[4 * b] = t.v[0]; u[4 * b + 1] = t.v[1]; u[4 * b + 2] = t.v[2]; u[4 * b + 3] = t.v[3]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float uj = leg == 0 ? u[k] : (leg == 1 ? u[3 + k] : (leg == 2 ? u[6 + k] : u[9 + k]));
@@ -381,7 +381,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         }
     }
     if (c.push_robots && (common % c.push_interval == 0)) {   // uniform over the grid
-        F4 u = rng4(c.seed, env, step, RS_PUSH, 0);
+        F4 u = rng4(c.seed, env + c.env_id_offset, step, RS_PUSH, 0);
         st.vw.x = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[0] + -c.max_push_vel_xy;
         st.vw.y = (c.max_push_vel_xy - -c.max_push_vel_xy) * u.v[1] + -c.max_push_vel_xy;
     }
@@ -527,7 +527,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         // draw i (0..31) -> obs index i (<29) or 58 + (i - 29); lane handles blocks 2*leg, 2*leg+1
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            F4 u = rng4(c.seed, env, step, RS_NOISE, 2 * leg + b);
+            F4 u = rng4(c.seed, env + c.env_id_offset, step, RS_NOISE, 2 * leg + b);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int i = 4 * (2 * leg + b) + e;
@@ -930,16 +930,17 @@ __global__ void qa_init_kernel(qa_config c, Ptrs p, BaseConst bc) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = c.num_envs;
     if (e >= N) return;
-    const int ncols = (int)floor(sqrt((double)N));
-    p.env_origins[3 * e] = c.env_spacing * (float)(e / ncols); p.env_origins[3 * e + 1] = c.env_spacing * (float)(e % ncols); p.env_origins[3 * e + 2] = 0.f;
+    const int ge = e + c.env_id_offset;                    // global env id: RNG key and spawn-grid slot
+    const int ncols = (int)floor(sqrt((double)(c.num_envs_global > 0 ? c.num_envs_global : N)));
+    p.env_origins[3 * e] = c.env_spacing * (float)(ge / ncols); p.env_origins[3 * e + 1] = c.env_spacing * (float)(ge % ncols); p.env_origins[3 * e + 2] = 0.f;
     float fr = 1.0f;
     if (c.randomize_friction) {
-        F4 u = rng4(c.seed, e, 0, RS_INIT_FRICTION, 0); int b = min((int)(u.v[0] * 64.0f), 63);
+        F4 u = rng4(c.seed, ge, 0, RS_INIT_FRICTION, 0); int b = min((int)(u.v[0] * 64.0f), 63);
         F4 ub = rng4(c.seed, b, 0, RS_INIT_BUCKET, 0);
         fr = (c.friction_range[1] - c.friction_range[0]) * ub.v[0] + c.friction_range[0];
     }
     p.friction[e] = fr;
-    F4 um = rng4(c.seed, e, 0, RS_INIT_MASS, 0);
+    F4 um = rng4(c.seed, ge, 0, RS_INIT_MASS, 0);
     float mp[4];
     mp[0] = c.randomize_base_mass ? (c.added_mass_range[1] - c.added_mass_range[0]) * um.v[0] + c.added_mass_range[0] : 0.f;
     for (int i = 0; i < 3; ++i) mp[1 + i] = c.randomize_base_com ? (c.added_com_range[1] - c.added_com_range[0]) * um.v[1 + i] + c.added_com_range[0] : 0.f;
@@ -954,7 +955,7 @@ __global__ void qa_init_kernel(qa_config c, Ptrs p, BaseConst bc) {
         bi[7] = (float)(bc.I[3] * sc - m * cx * cy); bi[8] = (float)(bc.I[4] * sc - m * cx * cz); bi[9] = (float)(bc.I[5] * sc - m * cy * cz);
     }
     float uu[48];
-    for (int b = 0; b < 12; ++b) { F4 t = rng4(c.seed, e, 0, RS_INIT_MOTOR, b); for (int i = 0; i < 4; ++i) uu[4 * b + i] = t.v[i]; }
+    for (int b = 0; b < 12; ++b) { F4 t = rng4(c.seed, ge, 0, RS_INIT_MOTOR, b); for (int i = 0; i < 4; ++i) uu[4 * b + i] = t.v[i]; }
     for (int j = 0; j < 12; ++j) {
         int pi = 2 * (j % 3); float s_p, s_d;
         if (!c.randomize_motor) { s_p = s_d = 1.0f; }
@@ -1285,7 +1286,7 @@ __global__ void qa_tsc_reset_kernel(qa_config c, Ptrs p, const uint8_t *flags, c
 #pragma unroll
     for (int i = 0; i < 6; ++i) lr[i] = 0.f;                       // self.last_root_vel[:] = 0.  (ALL envs, :389)
     if (!flags[e]) return;
-    const F4 u = rng4(c.seed, e, step, RS_RESET, 0);
+    const F4 u = rng4(c.seed, e + c.env_id_offset, step, RS_RESET, 0);
     const float yaw = start_yaw[e] + yaw_range * (2.0f * u.v[0] - 1.0f);
     const float pitch = pitch_range * (2.0f * u.v[3] - 1.0f);
     float *rt = p.root + (int64_t)e * 13;

@@ -21,6 +21,8 @@ def class_to_dict(obj):
 
 
 def make_qa_config(cfg, seed=1, sim_dt=None, terrain=None):
+    """`cfg.env.env_id_offset` / `cfg.env.num_envs_global` (optional): this process owns envs [offset, offset + num_envs) of a
+    num_envs_global-env job -- random draws and spawn slots are keyed by the GLOBAL env id"""
     c = _capi.QaConfig()
     c.abi_version = _capi.QA_ABI_VERSION
     c.num_envs = int(cfg.env.num_envs)
@@ -118,6 +120,8 @@ def make_qa_config(cfg, seed=1, sim_dt=None, terrain=None):
         c.easi_mean[k] = float(getattr(d, "easi_mean", [1.0] * 7)[k])
         c.easi_var[k] = float(getattr(d, "easi_var", [0.0] * 7)[k])
     c.num_mocap_frames = 0
+    c.env_id_offset = int(getattr(cfg.env, "env_id_offset", 0))
+    c.num_envs_global = int(getattr(cfg.env, "num_envs_global", 0))
     return c
 
 

@@ -34,11 +34,28 @@ class TaskRegistry:
         env_cfg, _ = update_cfg_from_args(env_cfg, None, args)
         if not hasattr(env_cfg, "seed"):            # a hand-built config: take the task's training seed, as get_cfgs does
             env_cfg.seed = self.train_cfgs[name].seed
+        self._shard_over_ranks(env_cfg)
         set_seed(env_cfg.seed)
         sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
         env = task_class(cfg=env_cfg, sim_params=sim_params, physics_engine=args.physics_engine, sim_device=args.sim_device,
                          headless=args.headless, **({"backend": backend} if backend is not None else {}))
         return env, env_cfg
+
+    @staticmethod
+    def _shard_over_ranks(env_cfg):
+        """train.py under `torch.distributed.run` (one process per GPU): the job's `num_envs` envs are split over the ranks,
+        rank r owns [r N/W, (r+1) N/W).  Random draws stay keyed by the GLOBAL env id (qa_config.env_id_offset), so the
+        env side of the job does not depend on the world size.  A config that already carries an offset (bench.py, tests) is left alone."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or hasattr(env_cfg.env, "env_id_offset"):
+            return
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if world > 1:
+            total = int(env_cfg.env.num_envs)
+            if total % world:
+                raise ValueError(f"num_envs {total} does not split over {world} ranks")
+            env_cfg.env.num_envs = total // world
+            env_cfg.env.env_id_offset, env_cfg.env.num_envs_global = rank * (total // world), total
 
     def make_alg_runner(self, env, name=None, args=None, train_cfg=None, log_root="default"):
         if args is None:

