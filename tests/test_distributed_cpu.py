@@ -56,7 +56,8 @@ def _runner_worker(rank, world, port, q, tmp):
     from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
     from tests.oracle_backend import OracleBackend
     cfg = Go2LocomotionCfg(); cfg.env.num_envs = 16; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = False
-    cfg.seed = 1 + 7919 * rank
+    cfg.seed = 1                                        # ONE 32-env job: rank r owns envs [16 r, 16 (r + 1)), draws keyed by the global env id
+    cfg.env.env_id_offset, cfg.env.num_envs_global = 16 * rank, 16 * world
     t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = True; t.runner.num_preload_transitions = 500; t.algorithm.disc_replay_buffer_size = 5000
     args = get_args(["--device", "cpu"])
     torch.manual_seed(100 + rank)                      # different initial weights per rank: the broadcast must fix that
@@ -67,8 +68,10 @@ def _runner_worker(rank, world, port, q, tmp):
     a = runner.alg
     flat = torch.cat([p.detach().flatten() for m in (a.actor_critic, a.estimator, a.disc) for p in m.parameters()])
     adv = a.storage.advantages
+    nm = a.disc_normalizer
+    norm = np.concatenate([np.asarray(nm.mean, dtype=np.float64).ravel(), np.asarray(nm.var, dtype=np.float64).ravel(), [float(nm.count)]])
     q.put((rank, flat.numpy(), a.lr_ac, float(adv.sum()), float((adv * adv).sum()), adv.numel(), env.prior_parameters.numpy().copy(),
-           env.root_states[:, :3].numpy().copy()))
+           env.root_states[:, :3].numpy().copy(), norm))
     dist.destroy_process_group()
 
 
@@ -78,7 +81,8 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     [p.start() for p in ps]
     out = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
-    (_, w0, lr0, s0, ss0, n0, pr0, pos0), (_, w1, lr1, s1, ss1, n1, pr1, pos1) = out
+    (_, w0, lr0, s0, ss0, n0, pr0, pos0, nm0), (_, w1, lr1, s1, ss1, n1, pr1, pos1, nm1) = out
+    assert np.array_equal(nm0, nm1) and nm0[-1] > 100   # the discriminator-input normaliser folded the GLOBAL batch moments on both ranks
     assert np.array_equal(w0, w1)                      # same broadcast start + same averaged gradients -> bit-identical replicas
     assert lr0 == lr1                                  # KL mean is all-reduced, both ranks took the same LR branch
     assert np.allclose(pr0, pr1)
@@ -86,7 +90,7 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     mean = (s0 + s1) / n
     var = ((ss0 + ss1) - n * mean * mean) / (n - 1)
     assert abs(mean) < 1e-4 and abs(var - 1.0) < 1e-3
-    assert not np.allclose(pos0, pos1)                 # the ranks simulate different envs (disjoint Philox streams)
+    assert not np.allclose(pos0, pos1)                 # the ranks simulate different envs (disjoint global env ids)
 
 
 def test_env_shards_reproduce_the_one_process_run_bit_for_bit():
