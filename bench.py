@@ -300,8 +300,11 @@ def bench_tsc(args, world, rank, local_rank, dev):
 
 
 def cpu_baseline(num_envs, budget_s):
-    """The CPU oracle's fused env step (same physics + env math, OpenMP over envs) on this box's host cores."""
+    """SURVEY 8d's host-CPU baseline on THIS box, same config / seed: (i) the CPU oracle's fused env step (same physics + env math,
+    OpenMP over envs) alone, all cores and one core; (ii) whole PPO iterations of the same trainer with CPU physics (oracle) + torch-CPU
+    learner (`torch.set_num_threads(nproc)`): 1 warm-up + 3 timed iterations -- rollout, learner and whole-iteration figures."""
     import numpy as np
+    import torch
     from tests.oracle_lib import OracleSim, go2_cfg
     cores = os.cpu_count() or 1
     q = go2_cfg(num_envs, seed=1)
@@ -310,11 +313,11 @@ def cpu_baseline(num_envs, budget_s):
     act = np.random.default_rng(0).normal(0, 0.3, (num_envs, 12)).astype(np.float32)
     o.step(act)
     t0 = time.perf_counter(); n = 0
-    while time.perf_counter() - t0 < budget_s:
+    while time.perf_counter() - t0 < budget_s / 2:
         o.step(act); n += 1
     dt = time.perf_counter() - t0
     out = {"value": num_envs * n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "sample": f"{n} fused env steps of {num_envs} envs on plane terrain (rollout physics+obs/reward only, no learner), OpenMP over envs, {dt:.1f} s"}
+           "sample": f"rollout only: {n} fused env steps of {num_envs} envs on plane terrain (physics + obs/reward, no policy, no learner), OpenMP over envs, {dt:.1f} s"}
     # the single-core figure SURVEY 8d asks for: the same steps with the OpenMP team held to one thread (~3 s)
     try:
         import ctypes
@@ -327,6 +330,34 @@ def cpu_baseline(num_envs, budget_s):
         gomp.omp_set_num_threads(cores)
     except OSError:
         pass
+    del o
+    # ---- whole iterations on the CPU: oracle physics + torch-CPU policy / GAE / PPO (BASELINE config 2's settings)
+    try:
+        from quadrupedal_agility_amd.legged_gym.envs import task_registry
+        from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+        from quadrupedal_agility_amd.legged_gym.utils import get_args
+        from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
+        from tests.oracle_backend import OracleBackend
+        torch.set_num_threads(cores)
+        cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = False; cfg.seed = 1
+        tcfg = Go2LocomotionCfgAlgo(); tcfg.runner.amp_enabled = False
+        cli = get_args(["--device", "cpu"])
+        torch.manual_seed(1)
+        env, _ = task_registry.make_env("go2_locomotion", args=cli, env_cfg=cfg, backend=OracleBackend(make_qa_config(cfg, seed=1)))
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=cli, train_cfg=tcfg, log_root=None)
+        runner.learn(1, init_at_random_ep_len=True)
+        its, coll, lrn = 3, [], []
+        t0 = time.perf_counter()
+        for _ in range(its):
+            runner.learn(1)
+            coll.append(runner.last_perf["collection_time"]); lrn.append(runner.last_perf["learn_time"])
+        dt_it = (time.perf_counter() - t0) / its
+        T = runner.num_steps_per_env
+        out["iteration"] = {"value": num_envs * T / dt_it, "unit": "env-steps/s", "iteration_s": dt_it, "rollout_s": sum(coll) / its, "learner_s": sum(lrn) / its,
+                            "sample": f"{its} whole PPO iterations after 1 warm-up: {num_envs} envs x {T} steps of oracle physics + torch-CPU policy, GAE, 5 epochs x 4 minibatches, "
+                                      f"torch.set_num_threads({cores})"}
+    except Exception as e:      # the baseline is a report, never a reason to lose the bench line
+        out["iteration"] = {"error": repr(e)}
     return out
 
 

@@ -192,3 +192,153 @@ def test_zero_gravity_kinetic_energy():
         s.simulate(np.zeros((1, 12), np.float32))
     E = np.array(E)
     assert np.abs(E / E[0] - 1).max() < 2e-3
+
+
+# ------------------------------------------------------------------ round-2 KATs: friction cone, joint stops, actuation, resting depth, body velocities
+def _ramp_sim(n, slope, ground_friction):
+    """robots standing (PD on the default pose) on a plane of slope `slope` = tan(theta) along +x, built as a height field"""
+    rows, cols = 400, 120
+    qc = go2_cfg(n, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, push_robots=0, add_noise=0,
+                 ground_friction=ground_friction)
+    qc.terrain_type = 1
+    qc.hf_rows, qc.hf_cols, qc.hf_hscale, qc.hf_vscale, qc.hf_border = rows, cols, 0.1, 0.0005, 2.0
+    s = OracleSim(qc)
+    x = np.arange(rows)[:, None] * 0.1 - 2.0
+    s.t["HEIGHT_SAMPLES"][...] = np.rint(np.repeat(-slope * x, cols, axis=1) / 0.0005).astype(np.int16)       # downhill towards +x
+    s.t["ENV_ORIGINS"][:, 0] = 3.0; s.t["ENV_ORIGINS"][:, 1] = 3.0 + 0.8 * np.arange(n); s.t["ENV_ORIGINS"][:, 2] = -slope * 3.0
+    s.reset_all()
+    s.t["ROOT_STATES"][:, 7:13] = 0
+    s.t["DOF_STATE"][:, :, 0] = np.array([0, 0.9, -1.8] * 4, np.float32)
+    return s
+
+
+@pytest.mark.parametrize("slope,mu,slides", [(0.30, 0.8, False), (0.45, 0.35, True)])
+def test_friction_cone_on_an_incline(slope, mu, slides):
+    """stick below tan(theta) = mu, slide above it with a = g (sin(theta) - mu cos(theta)): mu = 1/2 (robot + ground friction)"""
+    s = _ramp_sim(2, slope, 2 * mu - 1.0)                       # robot-shape friction is 1 without randomisation
+    vx, xs = [], []
+    for k in range(60 if slides else 200):
+        s.step(np.zeros((2, 12), np.float32))
+        vx.append(s.t["ROOT_STATES"][:, 7].copy()); xs.append(s.t["ROOT_STATES"][:, 0].copy())
+    vx, xs = np.array(vx), np.array(xs)
+    th = np.arctan(slope)
+    if not slides:                                                # the landing wobble dies out and the robot stays where it is
+        assert np.abs(vx[-40:]).max() < 0.03 and np.abs(xs[-1] - xs[-80]).max() < 0.01
+    else:
+        a = np.polyfit(np.arange(25, 60) * 0.02, vx[25:, 0] / np.cos(th), 1)[0]          # along-slope acceleration
+        assert a == pytest.approx(G * (np.sin(th) - mu * np.cos(th)), rel=0.12)
+        assert (s.t["RESET"] == 0).all()
+
+
+@pytest.mark.parametrize("joint,torque,stop", [(0, -20.0, -1.0472), (2, 40.0, -0.83776), (1, -20.0, -1.5708)])
+def test_joint_stop_holds_against_saturated_torque(joint, torque, stop):
+    """one joint driven into its stop by the full motor torque in free flight: it arrives with the speculative approach speed
+    gap/dt, overshoots by less than 1 degree and ends at rest on the stop"""
+    qc = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0)
+    s = OracleSim(qc)
+    s.t["ROOT_STATES"][0] = [0, 0, 30.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    s.t["DOF_STATE"][0, :, 0] = [0, 0.9, -1.8] * 4
+    tau = np.zeros((1, 12), np.float32); tau[0, joint] = torque
+    sgn = -1.0 if stop < s.t["DOF_STATE"][0, joint, 0] else 1.0
+    worst = 0.0
+    for k in range(120):
+        s.simulate(tau)
+        worst = max(worst, sgn * (s.t["DOF_STATE"][0, joint, 0] - stop))
+    assert worst < 0.0175
+    assert abs(s.t["DOF_STATE"][0, joint, 0] - stop) < 0.0175 and abs(s.t["DOF_STATE"][0, joint, 1]) < 0.05
+
+
+def test_coupled_joint_stops_converge_with_solver_iterations():
+    """two saturated motors of one leg pressing two stops at once is the hard case for a 4-sweep projected Gauss-Seidel (PhysX's
+    own iteration count, legged_robot_config.py:176): the leak past the stop is bounded at 4 sweeps and gone at 50"""
+    leak = {}
+    for iters in (4, 50):
+        qc = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, solver_iterations=iters)
+        s = OracleSim(qc)
+        s.t["ROOT_STATES"][0] = [0, 0, 30.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+        s.t["DOF_STATE"][0, :, 0] = [0, 0.9, -1.8] * 4
+        tau = np.zeros((1, 12), np.float32); tau[0, 2] = 40.0; tau[0, 0] = -20.0
+        w = 0.0
+        for k in range(60):
+            s.simulate(tau)
+            q = s.t["DOF_STATE"][0, :, 0]
+            w = max(w, q[2] - (-0.83776), -1.0472 - q[0])
+        leak[iters] = w
+    assert leak[50] < 0.003 and leak[4] < 0.15, leak
+
+
+def test_pd_actuation_is_internal_and_converges():
+    """zero gravity, no contact: the PD torques are internal forces -- total linear and angular momentum stay exactly where they
+    were -- and every joint settles on its target q0 + action_scale * a (hips: * hip_scale_reduction)"""
+    qc = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, gravity_z=0.0, push_robots=0, add_noise=0)
+    s = OracleSim(qc)
+    s.reset_all()
+    s.t["ROOT_STATES"][0] = [0, 0, 40.0, 0, 0, 0, 1, 0.3, -0.2, 0.1, 0.2, 0.1, -0.3]
+    s.t["DOF_STATE"][0, :, 0] = [0, 0.9, -1.8] * 4; s.t["DOF_STATE"][0, :, 1] = 0
+    s.t["EPISODE_LENGTH"][:] = 5
+
+    def momentum():
+        root = s.t["ROOT_STATES"][0].astype(np.float64); R = quat_to_mat(root[3:7])
+        ub = np.concatenate([R.T @ root[10:13], R.T @ root[7:10]])
+        com, vel, omg, mass, I = bodies(s.lib, s.t["DOF_STATE"][0, :, 0].copy(), s.t["DOF_STATE"][0, :, 1].copy(), ub)
+        p = sum(mass[b] * (R @ vel[b]) for b in range(13))
+        c = sum(mass[b] * (R @ com[b]) for b in range(13)) / mass.sum()
+        L = sum(mass[b] * np.cross(R @ com[b] - c, R @ vel[b]) + R @ (I[b] @ omg[b]) for b in range(13))
+        return p, L
+    p0, L0 = momentum()
+    act = np.zeros((1, 12), np.float32); act[0] = [1.0, 0.8, -0.6, -1.0, 0.4, 0.5, 0.5, -0.5, 0.3, -0.5, 0.2, -0.4]
+    for k in range(60):
+        s.step(act)
+    p1, L1 = momentum()
+    assert np.allclose(p1, p0, atol=5e-3) and np.allclose(L1, L0, atol=8e-3)
+    target = np.array([0, 0.9, -1.8] * 4) + 0.25 * act[0] * np.array([0.5, 1, 1] * 4)
+    assert np.allclose(s.t["DOF_STATE"][0, :, 0], target, atol=0.02) and np.abs(s.t["DOF_STATE"][0, :, 1]).max() < 0.2
+
+
+def test_resting_feet_sit_inside_the_contact_offset():
+    """standing at rest: every foot sphere floats between 0 and contact_offset above the plane (speculative contacts hold it at
+    the surface; it neither sinks nor hovers above the offset)"""
+    qc = go2_cfg(4, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, push_robots=0, add_noise=0)
+    s = OracleSim(qc)
+    s.reset_all(); s.t["ROOT_STATES"][:, 7:13] = 0
+    for _ in range(120):
+        s.step(np.zeros((4, 12), np.float32))
+    gap = s.t["RIGID_BODY_POS"][:, [6, 10, 14, 18], 2] - 0.022
+    assert (gap > -0.002).all() and (gap < qc.contact_offset).all(), gap
+
+
+def test_rigid_body_state_velocities_are_the_time_derivative_of_the_positions():
+    """QA_T_RIGID_BODY_STATE (seam 1): over one substep in free flight, (x_new - x_old) / dt of every body origin equals the reported
+    origin velocity to O(dt), the reported quaternion rotates the body like the link chain does, and base rows equal the root state"""
+    qc = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, gravity_z=0.0, export_body_state=1)
+    s = OracleSim(qc)
+    rng = np.random.default_rng(2)
+    q, qd, ub = rand_state(rng)
+    quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+    s.t["ROOT_STATES"][0] = np.concatenate([[0, 0, 20.0], quat, rng.uniform(-1, 1, 3), rng.uniform(-2, 2, 3)])
+    s.t["DOF_STATE"][0, :, 0] = q; s.t["DOF_STATE"][0, :, 1] = qd * 0.5
+    z = np.zeros((1, 12), np.float32)
+    s.simulate(z)
+    a = s.t["RIGID_BODY_STATE"][0].astype(np.float64).copy()
+    s.simulate(z)
+    b = s.t["RIGID_BODY_STATE"][0].astype(np.float64).copy()
+    fd = (b[:, :3] - a[:, :3]) / qc.sim_dt
+    vmid = 0.5 * (a[:, 7:10] + b[:, 7:10])
+    assert np.abs(fd - vmid).max() < 0.03 * max(1.0, np.abs(vmid).max())
+    assert np.allclose(np.linalg.norm(b[:, 3:7], axis=1), 1.0, atol=1e-6)
+    root = s.t["ROOT_STATES"][0]
+    assert np.allclose(b[0, :3], root[:3]) and np.allclose(b[0, 3:7], root[3:7]) and np.allclose(b[0, 7:13], root[7:13], atol=1e-6)
+    # orientation: the calf frame's x axis in the world = R_base Rx(q_hip) Ry(q_thigh + q_calf) e_x
+    qn = s.t["DOF_STATE"][0, :, 0].astype(np.float64)
+    Rb = quat_to_mat(root[3:7].astype(np.float64))
+    for l in range(4):
+        h, t2 = qn[3 * l], qn[3 * l + 1] + qn[3 * l + 2]
+        Rx = np.array([[1, 0, 0], [0, np.cos(h), -np.sin(h)], [0, np.sin(h), np.cos(h)]])
+        Ry = np.array([[np.cos(t2), 0, np.sin(t2)], [0, 1, 0], [-np.sin(t2), 0, np.cos(t2)]])
+        assert np.allclose(quat_to_mat(b[3 + 4 * l + 2, 3:7]), Rb @ Rx @ Ry, atol=2e-6)
+        assert np.allclose(b[3 + 4 * l + 3, 3:7], b[3 + 4 * l + 2, 3:7])            # the foot is fixed to the calf
+    # angular velocity of the calf: base + the three joint rates about their axes
+    for l in range(4):
+        w = Rb @ (Rb.T @ root[10:13] + np.array([1, 0, 0]) * s.t["DOF_STATE"][0, 3 * l, 1]
+                  + np.array([0, np.cos(qn[3 * l]), np.sin(qn[3 * l])]) * (s.t["DOF_STATE"][0, 3 * l + 1, 1] + s.t["DOF_STATE"][0, 3 * l + 2, 1]))
+        assert np.allclose(b[3 + 4 * l + 2, 10:13], w, atol=1e-5)
