@@ -126,6 +126,8 @@ class SSInfoGAIL:
         self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
+        self.branch_streams = self._on_gpu and os.environ.get("QA_PPO_BRANCHES", "1") != "0"     # PPO step: critic / actor / small nets on three streams
+        self._branch = None
 
     # ---- lr_ac is read by the logger and by checkpoints as a float
     @property
@@ -523,27 +525,47 @@ class SSInfoGAIL:
     def _ac_forward_backward_direct(self, obs, critic_obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hist_latent):
         """The same step on the GPU without scalar loss nodes: the kernels return every term's value AND its gradient w.r.t. the
         network outputs, which go straight into autograd.backward() of those outputs (what `loss.backward()` computes, minus the
-        ones-fills, scalings and accumulations of the scalar graph: ~10 launches per step)."""
+        ones-fills, scalings and accumulations of the scalar graph: ~10 launches per step).
+
+        The critic, the actor and the two small networks (privileged encoder, estimator) share nothing until the objective and
+        nothing again after it, so they run as three BRANCHES on three streams -- forward and, because autograd replays every node
+        on the stream its forward ran on, backward too.  A branch is a chain of dependent launches, two thirds of them <= 8 us
+        kernels that leave the GPU idle between them; side by side, one branch's small kernels fill the gaps of another's and its
+        GEMMs overlap the others' launch latencies.  Recorded into the step's hipGraph the streams become parallel graph branches."""
         ac = self.actor_critic
+        a = self.num_prop; b = a + self.num_explicit; c = b + self.num_latent; d = c + self.num_hist * self.num_prop
+        priv_reg_coef = self._priv_coef_dev if self._recording_ac else self._priv_reg_coef_now()
+        cur = torch.cuda.current_stream()
+        if self.branch_streams and self._branch is None:
+            self._branch = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        s_critic, s_small = self._branch if self.branch_streams else (cur, cur)
+        if self.branch_streams:
+            s_critic.wait_stream(cur); s_small.wait_stream(cur)
+        self.optim_estimator.zero_grad()
+        self.optim_ac.zero_grad()
+        with torch.cuda.stream(s_critic):
+            value = ac.evaluate(critic_obs.detach())
+        with torch.cuda.stream(s_small):
+            priv_latent = ac.infer_priv_latent(obs[:, b:c])
+            if hist_latent is None:
+                with torch.no_grad():
+                    hist_latent = ac.infer_hist_latent(obs[:, c:d])
+            priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
+            g_priv = g_priv * priv_reg_coef
+            est = self.estimator(obs[:, :a])
+            estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
         mu = ac._actor_mean(obs.detach(), False)
-        value = ac.evaluate(critic_obs.detach())
+        if self.branch_streams:
+            cur.wait_stream(s_critic)
         out, dmu, dstd, dvalue = fused_mod.ppo_loss_raw(mu, ac.std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
                                                         clip=self.clip_param, c_surr=self.surrogate_loss_coef, c_value=self.value_loss_coef,
                                                         c_bound=self.bounds_loss_coef, c_entropy=self.entropy_coef,
                                                         clipped_value=self.use_clipped_value_loss)
-        a = self.num_prop; b = a + self.num_explicit; c = b + self.num_latent; d = c + self.num_hist * self.num_prop
-        priv_latent = ac.infer_priv_latent(obs[:, b:c])
-        if hist_latent is None:
-            with torch.no_grad():
-                hist_latent = ac.infer_hist_latent(obs[:, c:d])
-        priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
-        priv_reg_coef = self._priv_coef_dev if self._recording_ac else self._priv_reg_coef_now()
-        est = self.estimator(obs[:, :a])
-        estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
-        self.optim_estimator.zero_grad()
-        est.backward(g_est)
-        self.optim_ac.zero_grad()
-        torch.autograd.backward([mu, value, priv_latent], [dmu, dvalue.view_as(value), g_priv * priv_reg_coef])
+        if self.branch_streams:
+            cur.wait_stream(s_small)
+        # (tried and dropped: the dW GEMMs of the Linear+ELU layers on a fourth stream, off the dX critical path -- 34.1 -> 37.8 ms:
+        # big GEMMs running side by side slow each other more than the shorter dependency chain saves)
+        torch.autograd.backward([est, mu, value, priv_latent], [g_est, dmu, dvalue.view_as(value), g_priv])
         ac.std.grad = dstd.view_as(ac.std)          # std enters the objective through qa_ppo_loss only
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         return (out[1], out[2], out[3], out[4], priv_reg_loss, estimator_loss), (out[5] if adaptive else None)
