@@ -186,7 +186,12 @@ typedef struct qa_config {
                                        the spawn grid is laid out over global ids, so rank r of a data-parallel run that owns envs
                                        [r N/W, (r+1) N/W) of an N-env job reproduces exactly those envs of the one-process run */
     int32_t num_envs_global;        /* envs of the whole job (0 = num_envs): size of the spawn grid */
-    int32_t reserved_cfg[2];
+    int32_t contact_slots;          /* non-foot contacts per leg and substep.  2 (default; 0 means 2): every body group of the leg -- hip link /
+                                       base share, thigh, calf -- has its own candidate (its lowest point) and up to two of the three
+                                       make contact at once (all three inside the contact offset: the one with the largest gap waits),
+                                       so _reward_collision and check_termination see the bodies independently; 1 = only the lowest
+                                       non-foot point of the leg (the round-1 model) */
+    int32_t reserved_cfg[1];
 } qa_config;
 
 typedef struct qa_sim qa_sim;

@@ -421,18 +421,23 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     for (int i = 0; i < 3; ++i) u[3 + i] += dt * wxv[i];
     for (int j = 0; j < 12; ++j) u[6 + j] = qd[j] + dt * acc[6 + j];
 
-    /* ---- constraint rows, in the fixed Gauss-Seidel order: for leg l: foot(n,t1,t2), extra(n,t1,t2), limits */
-    Row rows[4 * 9];
+    /* ---- constraint rows, in the fixed Gauss-Seidel order: for leg l: foot(n,t1,t2), then up to TWO "extra" contacts (n,t1,t2
+     * each) out of three candidates -- group 0 = the lowest point of the hip link or of this leg's share of the base / head points,
+     * group 1 = the lowest thigh point, group 2 = the lowest non-foot calf point; when all three are inside the contact offset the
+     * one with the largest gap waits -- then the joint-limit rows.  One candidate per body group, so thigh and calf (the 8 bodies
+     * _reward_collision counts, legged_robot.py:1275-1278) and hip / base (check_termination, :168-176) report forces
+     * independently of each other. */
+    Row rows[4 * 15];
     int nrows = 0;
-    int foot_row[4], extra_row[4], extra_body[4];
+    int foot_row[4], extra_row[4][3], extra_body[4][3];
     double mu = 0.5 * ((double)TP(s, QA_T_FRICTION, float)[e] + cfg->ground_friction);
-    double cdirs[8][3][3];      /* world-frame (n, t1, t2) of each contact slot, for the force report */
+    double cdirs[16][3][3];     /* world-frame (n, t1, t2) of each contact slot (4 per leg), for the force report */
     int row_leg_first[5] = {0, 0, 0, 0, 0};
     for (int l = 0; l < 4; ++l) {
         row_leg_first[l] = nrows;
-        foot_row[l] = extra_row[l] = -1; extra_body[l] = -1;
-        /* candidate points of this leg: slot 0 = foot; the other slot takes the min-gap non-foot point */
-        double best_gap = 1e30; v3 best_p = {0, 0, 0}, best_n = {0, 0, 1}; int best_depth = -1, best_body = -1;
+        foot_row[l] = -1;
+        double best_gap[3] = {1e30, 1e30, 1e30}; v3 best_p[3], best_n[3]; int best_depth[3] = {-1, -1, -1}, best_body[3] = {-1, -1, -1};
+        for (int sl = 0; sl < 3; ++sl) { extra_row[l][sl] = -1; extra_body[l][sl] = -1; for (int i = 0; i < 3; ++i) { best_p[sl][i] = 0; best_n[sl][i] = i == 2; } }
         double foot_gap = 0; v3 foot_p = {0, 0, 0}, foot_n = {0, 0, 1};
         for (int c = 0; c < QA_NUM_LEG_PTS; ++c) {
             int k = QA_LEG_PT_LINK[l][c];
@@ -442,23 +447,33 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             double gh; v3 gn; ground_query(s, pwld[0], pwld[1], &gh, gn);
             double gap = (pwld[2] - gh) * gn[2] - QA_LEG_PT_RAD[l][c];      /* distance to the terrain triangle's plane */
             if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); memcpy(foot_n, gn, sizeof(v3)); }
-            else if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); memcpy(best_n, gn, sizeof(v3)); best_depth = k; best_body = QA_LEG_PT_BODY[l][c]; }
+            else if (gap < best_gap[k]) { best_gap[k] = gap; memcpy(best_p[k], p, sizeof(v3)); memcpy(best_n[k], gn, sizeof(v3)); best_depth[k] = k; best_body[k] = QA_LEG_PT_BODY[l][c]; }
         }
-        for (int c = l; c < QA_NUM_BASE_PTS; c += 4) { /* base points are dealt round-robin to the four legs */
+        for (int c = l; c < QA_NUM_BASE_PTS; c += 4) { /* base points are dealt round-robin to the four legs; they share slot 0 with the hip link */
             v3 p = {QA_BASE_PT_POS[c][0], QA_BASE_PT_POS[c][1], QA_BASE_PT_POS[c][2]}, pwld;
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
             double gh; v3 gn; ground_query(s, pwld[0], pwld[1], &gh, gn);
             double gap = (pwld[2] - gh) * gn[2] - QA_BASE_PT_RAD[c];
-            if (gap < best_gap) { best_gap = gap; memcpy(best_p, p, sizeof(v3)); memcpy(best_n, gn, sizeof(v3)); best_depth = -1; best_body = QA_BASE_PT_BODY[c]; }
+            if (gap < best_gap[0]) { best_gap[0] = gap; memcpy(best_p[0], p, sizeof(v3)); memcpy(best_n[0], gn, sizeof(v3)); best_depth[0] = -1; best_body[0] = QA_BASE_PT_BODY[c]; }
         }
-        for (int slot = 0; slot < 2; ++slot) {
-            double gap = slot == 0 ? foot_gap : best_gap;
-            const double *p = slot == 0 ? foot_p : best_p;
-            int depth = slot == 0 ? 2 : best_depth;
+        if (cfg->contact_slots == 1) {      /* only the lowest non-foot point of the leg makes contact (the round-1 model) */
+            int win = 0;
+            if (best_gap[1] < best_gap[0] && !(best_gap[2] < best_gap[1])) win = 1;
+            if (best_gap[2] < best_gap[0] && best_gap[2] < best_gap[1]) win = 2;
+            for (int g = 0; g < 3; ++g) if (g != win) best_gap[g] = 1e30;
+        } else if (best_gap[0] < cfg->contact_offset && best_gap[1] < cfg->contact_offset && best_gap[2] < cfg->contact_offset) {
+            /* three candidates, two contact slots per leg: the one with the largest gap waits */
+            int drop = (best_gap[0] >= best_gap[1] && best_gap[0] >= best_gap[2]) ? 0 : (best_gap[1] >= best_gap[2] ? 1 : 2);
+            best_gap[drop] = 1e30;
+        }
+        for (int slot = 0; slot < 4; ++slot) {
+            double gap = slot == 0 ? foot_gap : best_gap[slot - 1];
+            const double *p = slot == 0 ? foot_p : best_p[slot - 1];
+            int depth = slot == 0 ? 2 : best_depth[slot - 1];
             if (!(gap < cfg->contact_offset)) continue;
-            if (slot == 0) foot_row[l] = nrows; else { extra_row[l] = nrows; extra_body[l] = best_body; }
-            double (*cw)[3] = cdirs[2 * l + slot];
-            memcpy(cw[0], slot == 0 ? foot_n : best_n, sizeof(v3));
+            if (slot == 0) foot_row[l] = nrows; else { extra_row[l][slot - 1] = nrows; extra_body[l][slot - 1] = best_body[slot - 1]; }
+            double (*cw)[3] = cdirs[4 * l + slot];
+            memcpy(cw[0], slot == 0 ? foot_n : best_n[slot - 1], sizeof(v3));
             tangent_basis(cw[0], cw[1], cw[2]);
             v3 dB[3]; for (int d = 0; d < 3; ++d) mtv(R, cw[d], dB[d]);       /* contact frame in base coordinates */
             const double *dirs[3] = {dB[0], dB[1], dB[2]};
@@ -571,11 +586,11 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     for (int l = 0; l < 4; ++l) if (foot_row[l] >= 0) for (int d = 0; d < 3; ++d) fimp[3 * l + d] = (float)rows[foot_row[l] + d].lam;
     /* ---- contact forces per body, world frame: lam_n n + lam_t1 t1 + lam_t2 t2 (plane: t1, t2, n are world x, y, z) */
     memset(cf, 0, sizeof(float) * 57);
-    for (int l = 0; l < 4; ++l) for (int slot = 0; slot < 2; ++slot) {
-        int r0 = slot == 0 ? foot_row[l] : extra_row[l];
+    for (int l = 0; l < 4; ++l) for (int slot = 0; slot < 4; ++slot) {
+        int r0 = slot == 0 ? foot_row[l] : extra_row[l][slot - 1];
         if (r0 < 0) continue;
-        int b = slot == 0 ? QA_LEG_PT_BODY[l][0] : extra_body[l];
-        double (*cw)[3] = cdirs[2 * l + slot];
+        int b = slot == 0 ? QA_LEG_PT_BODY[l][0] : extra_body[l][slot - 1];
+        double (*cw)[3] = cdirs[4 * l + slot];
         for (int i = 0; i < 3; ++i)
             cf[3 * b + i] += (float)((rows[r0].lam * cw[0][i] + rows[r0 + 1].lam * cw[1][i] + rows[r0 + 2].lam * cw[2][i]) / dt);
     }

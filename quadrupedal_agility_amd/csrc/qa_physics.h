@@ -39,6 +39,7 @@
 struct PhysParams {
     float dt, gz, contact_offset, max_depen, ground_friction;
     int iters;
+    int slots;     // extra contact slots per leg: 3 (one per body) or 1 (lowest non-foot point only)
 };
 
 // packed lower-triangular index of a symmetric 6x6
@@ -177,10 +178,18 @@ struct EnvState {
     float q[3], qd[3];                          // this lane's leg
 };
 
+// Non-foot contacts of a leg: one CANDIDATE per body group -- group 0 = the hip link or this lane's share of the base / head
+// points (whichever point is lowest), group 1 = thigh, group 2 = calf -- so that thigh and calf (the bodies _reward_collision
+// counts) and hip / base (the bodies check_termination reads) can report forces independently.  Up to QA_EXTRA_SLOTS = 2 of the
+// three candidates make contact in a substep (all three inside the contact offset: the one with the largest gap waits); the
+// active ones are compacted into slots 0..1 per lane, so a wavefront pays for max-over-lanes(#active), not for every group
+// that is active somewhere in it.
+#define QA_EXTRA_GROUPS 3
+#define QA_EXTRA_SLOTS 2
 struct ContactOut {
-    V3 foot_f;         // world-frame force on this leg's foot
-    V3 extra_f;        // world-frame force on the extra contact owned by this lane
-    int extra_body;    // body id of the extra contact (-1 none)
+    V3 foot_f;                      // world-frame force on this leg's foot
+    V3 extra_f[QA_EXTRA_SLOTS];     // world-frame force on the slot's contact
+    int extra_body[QA_EXTRA_SLOTS]; // body id the slot's contact is on (-1 none)
 };
 
 // one scalar constraint row in reduced coordinates
@@ -271,9 +280,9 @@ __device__ long long *g_subprof = nullptr;
 
 // rarely-active rows live in per-lane LDS slots: slot k of this lane is priv[k * QA_PRIV_STRIDE]
 #define QA_PRIV_STRIDE 64
-#define QA_PRIV_EXTRA 0                  // 3 rows x 20 floats: jh6 jl3 bj6 lj3 dinv bias
-#define QA_PRIV_STEP 60                  // env-step persistents parked between substeps: act3 sp3 sd3 binert10
-#define QA_PRIV_FLOATS 80
+#define QA_PRIV_EXTRA 0                  // 2 slots x 3 rows x 20 floats: jh6 jl3 bj6 lj3 dinv bias
+#define QA_PRIV_STEP 120                 // env-step persistents parked between substeps: act3 sp3 sd3 binert10
+#define QA_PRIV_FLOATS 140
 struct LRow { float *p; };               // row view in LDS
 QA_DEV float &lr(float *priv, int k) { return priv[k * QA_PRIV_STRIDE]; }
 
@@ -414,14 +423,28 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     }
 
     QA_SUBSTAMP(6);
-    // ---- contact candidates: slot 0 = foot sphere, slot 1 = closest other point owned by this lane
+    // ---- contact candidates: the foot sphere, and per extra slot (hip link + base share | thigh | calf) the point with the
+    // smallest gap.  Only (gap, point code) are tracked; position, chain depth, body and terrain normal of a winner are rebuilt
+    // when its rows are built, which only happens if some env of the wavefront has that slot in contact.
     V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);   // plane: world z, x, y
-    V3 foot_n = v3(0, 0, 1), best_n = v3(0, 0, 1);          // world-frame contact normals (height field)
+    V3 foot_n = v3(0, 0, 1);                                 // world-frame contact normal (height field)
     float foot_gap; V3 foot_p;
-    float best_gap = 1e30f; V3 best_p = v3(0, 0, 0); int best_depth = 0, best_body = -1;
+    float bgap[QA_EXTRA_GROUPS] = {1e30f, 1e30f, 1e30f};
+    int bcode[QA_EXTRA_GROUPS] = {0, 0, 0};                  // 1..QA_LEG_PTS-1: leg point, 64 + c: base point
+    auto leg_point = [&](int c, int k) {                     // base-frame position of leg point c (on link k)
+        const float *pt = tbl + T_POINTS + 4 * c;
+        // arithmetic blend over the links: any ?: between elements of Rl[] / o[] is folded by the compiler into a select of
+        // INDICES, and a dynamically indexed register array lives in scratch
+        const float w0 = k == 0 ? 1.f : 0.f, w1 = k == 1 ? 1.f : 0.f, w2 = k == 2 ? 1.f : 0.f;
+        M3 Rs;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rs.m[i] = fmaf(w0, Rl[0].m[i], fmaf(w1, Rl[1].m[i], w2 * Rl[2].m[i]));
+        const V3 os = (w0 * o[0]) + (w1 * o[1]) + (w2 * o[2]);
+        return mul(Rs, v3(pt[0], pt[1], pt[2])) + os;
+    };
     if (PLANE) {
         // On the plane only a candidate's world height matters: z_w = nB . (Rl_k pt + o_k) + z = (Rl_k^T nB) . pt + (nB . o_k + z),
-        // i.e. 3 FMAs per point after 3 per-link vectors; the full base-frame position is built for the winner only.
+        // i.e. 3 FMAs per point after 3 per-link vectors; the full base-frame position is built for winners only.
         V3 nk[3]; float hk[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { nk[k] = mulT(Rl[k], nB); hk[k] = dot(nB, o[k]) + st.pos.z; }
@@ -430,13 +453,12 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             foot_p = mul(Rl[2], v3(pt[0], pt[1], pt[2])) + o[2];
             foot_gap = dot(nB, foot_p) + st.pos.z - pt[3];
         }
-        int best_c = 0;                           // 1..QA_LEG_PTS-1: leg point, 64 + c: base point
 #pragma unroll
         for (int c = 1; c < QA_LEG_PTS; ++c) {
             const int k = (c < 3 ? 0 : (c < 11 ? 1 : 2));
             const float *pt = tbl + T_POINTS + 4 * c;
             const float gap = dot(nk[k], v3(pt[0], pt[1], pt[2])) + hk[k] - pt[3];
-            if (gap < best_gap) { best_gap = gap; best_c = c; }
+            if (gap < bgap[k]) { bgap[k] = gap; bcode[k] = c; }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -444,63 +466,87 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             if (c < QA_BASE_PTS) {
                 const float *pt = btbl + 4 * c;
                 const float gap = dot(nB, v3(pt[0], pt[1], pt[2])) + st.pos.z - pt[3];
-                if (gap < best_gap) { best_gap = gap; best_c = 64 + c; }
+                if (gap < bgap[0]) { bgap[0] = gap; bcode[0] = 64 + c; }
             }
-        }
-        if (best_c >= 64) {
-            const int c = best_c - 64;
-            const float *pt = btbl + 4 * c;
-            best_p = v3(pt[0], pt[1], pt[2]); best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2);
-        } else if (best_c > 0) {
-            const int k = (best_c < 3 ? 0 : (best_c < 11 ? 1 : 2));
-            const float *pt = tbl + T_POINTS + 4 * best_c;
-            const M3 Rs = k == 0 ? Rl[0] : (k == 1 ? Rl[1] : Rl[2]);
-            const V3 os = k == 0 ? o[0] : (k == 1 ? o[1] : o[2]);
-            best_p = mul(Rs, v3(pt[0], pt[1], pt[2])) + os; best_depth = k + 1; best_body = 3 + 4 * leg + k;
         }
     } else {
 #pragma unroll
-    for (int c = 0; c < QA_LEG_PTS; ++c) {
-        const int k = (c == 0) ? 2 : (c < 3 ? 0 : (c < 11 ? 1 : 2));
-        const float *pt = tbl + T_POINTS + 4 * c;
-        V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
-        float zw = dot(nB, p) + st.pos.z;
-        float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
-        float gap = (zw - gh) * gn.z - pt[3];          // distance to the terrain triangle's plane
-        if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; }
-        else if (gap < best_gap) { best_gap = gap; best_p = p; best_n = gn; best_depth = k + 1; best_body = 3 + 4 * leg + k; }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int c = leg + 4 * j;
-        if (c < QA_BASE_PTS) {
-            const float *pt = btbl + 4 * c;
-            V3 p = v3(pt[0], pt[1], pt[2]);
+        for (int c = 0; c < QA_LEG_PTS; ++c) {
+            const int k = (c == 0) ? 2 : (c < 3 ? 0 : (c < 11 ? 1 : 2));
+            const float *pt = tbl + T_POINTS + 4 * c;
+            V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
             float zw = dot(nB, p) + st.pos.z;
             float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
-            float gap = (zw - gh) * gn.z - pt[3];
-            if (gap < best_gap) { best_gap = gap; best_p = p; best_n = gn; best_depth = 0; best_body = c < 8 ? 0 : (c < 10 ? 1 : 2); }
+            float gap = (zw - gh) * gn.z - pt[3];          // distance to the terrain triangle's plane
+            if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; }
+            else if (gap < bgap[k]) { bgap[k] = gap; bcode[k] = c; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int c = leg + 4 * j;
+            if (c < QA_BASE_PTS) {
+                const float *pt = btbl + 4 * c;
+                V3 p = v3(pt[0], pt[1], pt[2]);
+                float zw = dot(nB, p) + st.pos.z;
+                float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
+                float gap = (zw - gh) * gn.z - pt[3];
+                if (gap < bgap[0]) { bgap[0] = gap; bcode[0] = 64 + c; }
+            }
         }
     }
-    }
     const bool foot_on = foot_gap < P.contact_offset;
-    const bool extra_on = best_gap < P.contact_offset;
+    // ---- which candidates make contact, compacted into the lane's slots 0..1 (group order)
+    float sgap[QA_EXTRA_SLOTS]; int scode[QA_EXTRA_SLOTS], slink[QA_EXTRA_SLOTS];
+    bool extra_on[QA_EXTRA_SLOTS], any_extra[QA_EXTRA_SLOTS];
+    {
+        bool on0 = bgap[0] < P.contact_offset, on1 = bgap[1] < P.contact_offset, on2 = bgap[2] < P.contact_offset;
+        if (P.slots == 1) {        // cfg.contact_slots 1: only the lowest non-foot point of the leg (the round-1 model)
+            const bool w1 = bgap[1] < bgap[0] && !(bgap[2] < bgap[1]), w2 = bgap[2] < bgap[0] && bgap[2] < bgap[1];
+            on0 = on0 && !w1 && !w2; on1 = on1 && w1; on2 = on2 && w2;
+        } else if (on0 && on1 && on2) {                      // three candidates, two slots: the largest gap waits
+            const bool d0 = bgap[0] >= bgap[1] && bgap[0] >= bgap[2], d1 = !d0 && bgap[1] >= bgap[2];
+            on0 = !d0; on1 = !d1; on2 = d0 || d1;
+        }
+        const int g0 = on0 ? 0 : (on1 ? 1 : (on2 ? 2 : -1));
+        const int g1 = (g0 == 0) ? (on1 ? 1 : (on2 ? 2 : -1)) : ((g0 == 1 && on2) ? 2 : -1);
+        // arithmetic blends, not ?: chains over the candidate arrays (see leg_point)
+        const float a0 = g0 == 0 ? 1.f : 0.f, a1 = g0 == 1 ? 1.f : 0.f, a2 = g0 == 2 ? 1.f : 0.f, b1 = g1 == 1 ? 1.f : 0.f, b2 = g1 == 2 ? 1.f : 0.f;
+        sgap[0] = g0 < 0 ? 1e30f : fmaf(a0, fminf(bgap[0], 1e20f), fmaf(a1, fminf(bgap[1], 1e20f), a2 * fminf(bgap[2], 1e20f)));
+        sgap[1] = g1 < 0 ? 1e30f : fmaf(b1, fminf(bgap[1], 1e20f), b2 * fminf(bgap[2], 1e20f));
+        scode[0] = (int)a0 * bcode[0] + (int)a1 * bcode[1] + (int)a2 * bcode[2];
+        scode[1] = (int)b1 * bcode[1] + (int)b2 * bcode[2];
+        slink[0] = g0; slink[1] = g1;
+        extra_on[0] = g0 >= 0; extra_on[1] = g1 >= 0;
+        any_extra[0] = __any(extra_on[0]); any_extra[1] = __any(extra_on[1]);
+    }
 
     QA_SUBSTAMP(7);
-    // ---- rows (all in registers; inactive ones are skipped wave-uniformly below)
+    // ---- rows (foot rows in registers; the extra slots' rows in LDS, built only when some env of the wavefront needs them)
     Row rf[3];
     V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
     if (!PLANE) { tangent_basis(foot_n, ft1_w, ft2_w); fn_b = mulT(R, foot_n); ft1_b = mulT(R, ft1_w); ft2_b = mulT(R, ft2_w); }
     contact_rows(rf, foot_p, 3, foot_gap, o, ax, fn_b, ft1_b, ft2_b, G, Linv, Binv, P);
-    const bool any_extra = __any(extra_on);
-    float re_lam[3] = {0.f, 0.f, 0.f};
-    if (any_extra) {
-        Row re[3];
-        V3 en_b = nB, et1_b = t1B, et2_b = t2B;
-        if (!PLANE) { V3 a, b; tangent_basis(best_n, a, b); en_b = mulT(R, best_n); et1_b = mulT(R, a); et2_b = mulT(R, b); }
-        contact_rows(re, best_p, best_depth, best_gap, o, ax, en_b, et1_b, et2_b, G, Linv, Binv, P);
+    float re_lam[QA_EXTRA_SLOTS][3];
+    V3 ex_n[QA_EXTRA_SLOTS];                                // world-frame normals of the extra contacts (height field)
+    int ex_body[QA_EXTRA_SLOTS];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 20 * d, re[d]);
+    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
+        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1;
+        if (any_extra[sl]) {
+            V3 p; int depth;
+            const int code = scode[sl], link = max(slink[sl], 0);
+            if (code >= 64) { const float *pt = btbl + 4 * (code - 64); p = v3(pt[0], pt[1], pt[2]); depth = 0; ex_body[sl] = (code - 64) < 8 ? 0 : ((code - 64) < 10 ? 1 : 2); }
+            else { p = leg_point(code > 0 ? code : 1, link); depth = link + 1; ex_body[sl] = 3 + 4 * leg + link; }
+            Row re[3];
+            V3 en_b = nB, et1_b = t1B, et2_b = t2B;
+            if (!PLANE) {
+                float gh; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, ex_n[sl]);
+                V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
+            }
+            contact_rows(re, p, depth, sgap[sl], o, ax, en_b, et1_b, et2_b, G, Linv, Binv, P);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
+        }
     }
     // joint limits: at most one stop per joint can be within the margin
     float lim_sgn[3], lim_bias[3], lim_lam[3], lim_bj[3][6], lim_dinv[3];   // registers: these rows run in most waves
@@ -572,13 +618,16 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                     if (!mine) { rf[0].lam = l0; rf[1].lam = l1; rf[2].lam = l2; }
                 }
             }
-            if (any_extra) {
-                if (extra_on) {
-                    Row t[3];
-                    row_load(priv, QA_PRIV_EXTRA, t[0]); row_load(priv, QA_PRIV_EXTRA + 20, t[1]); row_load(priv, QA_PRIV_EXTRA + 40, t[2]);
-                    t[0].lam = re_lam[0]; t[1].lam = re_lam[1]; t[2].lam = re_lam[2];
-                    contact_update(t, ub2, w2, mu);
-                    if (mine) { re_lam[0] = t[0].lam; re_lam[1] = t[1].lam; re_lam[2] = t[2].lam; }
+#pragma unroll
+            for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
+                if (any_extra[sl]) {
+                    if (extra_on[sl]) {
+                        Row t[3];
+                        row_load(priv, QA_PRIV_EXTRA + 60 * sl, t[0]); row_load(priv, QA_PRIV_EXTRA + 60 * sl + 20, t[1]); row_load(priv, QA_PRIV_EXTRA + 60 * sl + 40, t[2]);
+                        t[0].lam = re_lam[sl][0]; t[1].lam = re_lam[sl][1]; t[2].lam = re_lam[sl][2];
+                        contact_update(t, ub2, w2, mu);
+                        if (mine) { re_lam[sl][0] = t[0].lam; re_lam[sl][1] = t[1].lam; re_lam[sl][2] = t[2].lam; }
+                    }
                 }
             }
             if (any_lim) {
@@ -644,15 +693,15 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     QA_SUBSTAMP(10);
     // ---- contact forces, world frame (plane: t1, t2, n are world x, y, z)
     float idt = 1.0f / dt;
-    if (PLANE) {
-        co.foot_f = foot_on ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
-        co.extra_f = (any_extra && extra_on) ? v3(re_lam[1] * idt, re_lam[2] * idt, re_lam[0] * idt) : v3(0, 0, 0);
-    } else {   // lam_n n + lam_t1 t1 + lam_t2 t2 in the world frame
-        co.foot_f = foot_on ? idt * ((rf[0].lam * foot_n) + (rf[1].lam * ft1_w) + (rf[2].lam * ft2_w)) : v3(0, 0, 0);
-        V3 a, b; tangent_basis(best_n, a, b);
-        co.extra_f = (any_extra && extra_on) ? idt * ((re_lam[0] * best_n) + (re_lam[1] * a) + (re_lam[2] * b)) : v3(0, 0, 0);
+    if (PLANE) co.foot_f = foot_on ? v3(rf[1].lam * idt, rf[2].lam * idt, rf[0].lam * idt) : v3(0, 0, 0);
+    else co.foot_f = foot_on ? idt * ((rf[0].lam * foot_n) + (rf[1].lam * ft1_w) + (rf[2].lam * ft2_w)) : v3(0, 0, 0);    // lam_n n + lam_t1 t1 + lam_t2 t2, world frame
+#pragma unroll
+    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
+        const bool on = any_extra[sl] && extra_on[sl];
+        if (PLANE) co.extra_f[sl] = on ? v3(re_lam[sl][1] * idt, re_lam[sl][2] * idt, re_lam[sl][0] * idt) : v3(0, 0, 0);
+        else { V3 a, b; tangent_basis(ex_n[sl], a, b); co.extra_f[sl] = on ? idt * ((re_lam[sl][0] * ex_n[sl]) + (re_lam[sl][1] * a) + (re_lam[sl][2] * b)) : v3(0, 0, 0); }
+        co.extra_body[sl] = on ? ex_body[sl] : -1;
     }
-    co.extra_body = (any_extra && extra_on) ? best_body : -1;
 }
 
 // joint origins + foot origin of a leg in the base frame (for RIGID_BODY_POS after the last substep)

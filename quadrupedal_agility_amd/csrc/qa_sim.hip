@@ -19,7 +19,6 @@
 #include "../../include/qa_sim.h"
 #include "qa_go2_model.h"
 #include "qa_physics.h"
-#include "qa_physics16.h"
 
 #define QA_BLOCK 64
 #define ENVS_PER_BLOCK (QA_BLOCK / 4)
@@ -664,7 +663,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
     const int tix = threadIdx.x & (QA_BLOCK - 1);      // lane
     const int bix = blockIdx.x * WPB + (threadIdx.x >> 6);   // index of this wavefront's env group
-    static_assert(LPE == 4 || (LPE == 16 && PLANE), "the 16-lane substep exists for the plane only");
+    static_assert(LPE == 4, "one quad per env (the 16-lanes-per-env experiment of round 1 was slower in wall time and is gone)");
     __shared__ float s_tbl[QA_TBL_FLOATS];
     // One LDS scratch region used by two disjoint phases (a workgroup's LDS footprint decides how many of them a CU
     // holds -- 160 KB per CU -- and with it the throughput once there are more workgroups than CUs):
@@ -761,7 +760,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     const float fric = p.friction[env];
     const float mu = 0.5f * (fric + c.ground_friction);
     PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity;
-    P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
+    P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2;
 
     // ---- terrain window: staged in the rows buffer, which is idle until the observation phase
     TerrainView T = terrain_view(c, p, s_patch + le * (QA_PATCH * QA_PATCH));
@@ -802,8 +801,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
             float lim = tbl[T_EFFORT + k];
             tau[k] = clampf(t, -lim, lim);
         }
-        if (LPE == 16) phys_substep16(st, tbl, btbl, bi, tau, mu, leg, sub, P, co, fimp);
-        else phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
+        phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
@@ -814,18 +812,22 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 foot_w = mul(R, org[3]) + st.pos;
-    V3 base_f, hu_f, hl_f;   // extra contacts that landed on base / Head_upper / Head_lower, summed over the quad
+    // route the lane's (up to two) extra contacts to their bodies: base / Head_upper / Head_lower are summed over the quad
+    V3 base_f, hu_f, hl_f;
+    const int myb = 3 + 4 * leg;
+    auto on_body = [&](int b) {
+        V3 r = v3(0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < QA_EXTRA_SLOTS; ++j) if (co.extra_body[j] == b) r = r + co.extra_f[j];
+        return r;
+    };
     {
-        V3 z = v3(0, 0, 0);
-        V3 eb = co.extra_body == 0 ? co.extra_f : z, e1 = co.extra_body == 1 ? co.extra_f : z, e2 = co.extra_body == 2 ? co.extra_f : z;
+        V3 eb = on_body(0), e1 = on_body(1), e2 = on_body(2);
         base_f = v3(xsum<LPE>(eb.x), xsum<LPE>(eb.y), xsum<LPE>(eb.z));
         hu_f = v3(xsum<LPE>(e1.x), xsum<LPE>(e1.y), xsum<LPE>(e1.z));
         hl_f = v3(xsum<LPE>(e2.x), xsum<LPE>(e2.y), xsum<LPE>(e2.z));
     }
-    const int myb = 3 + 4 * leg;
-    V3 hip_f = co.extra_body == myb ? co.extra_f : v3(0, 0, 0);
-    V3 thigh_f = co.extra_body == myb + 1 ? co.extra_f : v3(0, 0, 0);
-    V3 calf_f = co.extra_body == myb + 2 ? co.extra_f : v3(0, 0, 0);
+    V3 hip_f = on_body(myb), thigh_f = on_body(myb + 1), calf_f = on_body(myb + 2);
     if (valid) {
         float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
         float *m = cf + 3 * myb;
@@ -1000,7 +1002,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     __shared__ float s_patch[PLANE ? 1 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH];
-    static_assert(LPE == 4 || (LPE == 16 && PLANE), "the 16-lane substep exists for the plane only");
+    static_assert(LPE == 4, "one quad per env");
     stage_table(s_tbl);
     const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, N = c.num_envs;
     const int leg = LPE == 4 ? (threadIdx.x & 3) : ((threadIdx.x >> 2) & 3), sub = LPE == 4 ? 0 : (threadIdx.x & 3);
@@ -1014,7 +1016,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     float tau[3], binert[10];
     for (int k = 0; k < 3; ++k) { st.q[k] = d[2 * k]; st.qd[k] = d[2 * k + 1]; float lim = tbl[T_EFFORT + k]; tau[k] = clampf(torques[(int64_t)env * 12 + 3 * leg + k], -lim, lim); }
     for (int i = 0; i < 10; ++i) binert[i] = p.base_inertia[(int64_t)env * 10 + i];
-    PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity; P.ground_friction = c.ground_friction; P.iters = c.solver_iterations;
+    PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity; P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2;
     ContactOut co;
     float fimp[3];
     for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
@@ -1026,18 +1028,22 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
         stage_patch(T, mine, leg);
         wave_lds_sync();
     }
-    if (LPE == 16) phys_substep16(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, sub, P, co, fimp);
-    else phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
+    phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
     V3 org[4]; leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 z = v3(0, 0, 0);
-    V3 eb = co.extra_body == 0 ? co.extra_f : z, e1 = co.extra_body == 1 ? co.extra_f : z, e2 = co.extra_body == 2 ? co.extra_f : z;
+    auto on_body = [&](int b) {
+        V3 r = z;
+        for (int j = 0; j < QA_EXTRA_SLOTS; ++j) if (co.extra_body[j] == b) r = r + co.extra_f[j];
+        return r;
+    };
+    V3 eb = on_body(0), e1 = on_body(1), e2 = on_body(2);
     V3 base_f = v3(xsum<LPE>(eb.x), xsum<LPE>(eb.y), xsum<LPE>(eb.z)), hu_f = v3(xsum<LPE>(e1.x), xsum<LPE>(e1.y), xsum<LPE>(e1.z)), hl_f = v3(xsum<LPE>(e2.x), xsum<LPE>(e2.y), xsum<LPE>(e2.z));
     if (!valid) return;
     const int myb = 3 + 4 * leg;
     float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
     for (int k = 0; k < 3; ++k) {
-        V3 f = co.extra_body == myb + k ? co.extra_f : z;
+        V3 f = on_body(myb + k);
         cf[3 * (myb + k)] = f.x; cf[3 * (myb + k) + 1] = f.y; cf[3 * (myb + k) + 2] = f.z;
         V3 w = mul(R, org[k]) + st.pos; rb[3 * (myb + k)] = w.x; rb[3 * (myb + k) + 1] = w.y; rb[3 * (myb + k) + 2] = w.z;
     }
@@ -1170,11 +1176,7 @@ int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
     if ((cfg->terrain_type != 0 && cfg->terrain_type != 1) || (cfg->terrain_type == 1 && (cfg->hf_rows < 2 || cfg->hf_cols < 2 || !(cfg->hf_hscale > 0.0f))) || cfg->decimation <= 0 || cfg->solver_iterations <= 0) { snprintf(g_err, sizeof(g_err), "qa_create: unsupported config"); return QA_E_ARG; }
     qa_sim *s = new qa_sim();
     s->cfg = *cfg; make_layout(cfg, &s->L); s->arena = (char *)arena;
-    // lane mapping of the step kernels: 4 lanes per env (lane&3 = leg).  QA_LANES=16 selects the experimental mapping of
-    // qa_physics16.h (an env per 16-lane DPP row, plane only): parity-green, 24 % fewer cycles per wavefront, but slower in
-    // wall time at 4096 envs (79.7 vs 72.8 us: four times as many busy SIMDs) -- DESIGN.md section 9.
-    s->lanes = 4;
-    if (const char *e = getenv("QA_LANES")) { if (atoi(e) == 4) s->lanes = 4; else if (atoi(e) == 16 && cfg->terrain_type == 0) s->lanes = 16; }
+    s->lanes = 4;                  // one quad per env (lane&3 = leg)
     memset(s->mocap_first, 0, sizeof(s->mocap_first));
     if (arena_bytes < s->L.total || ((uintptr_t)arena & 255)) { delete s; snprintf(g_err, sizeof(g_err), "qa_create: arena too small or misaligned"); return QA_E_ARENA; }
     fill_ptrs(s);
@@ -1217,7 +1219,6 @@ static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; m.on = s->mocap_first[Q
 static void launch_env_step(qa_sim *s, const StepArgs &a, hipStream_t st) {
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
     if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_env_step_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
-    else if (s->lanes == 16) hipLaunchKernelGGL((qa_env_step_kernel<true, 16>), dim3((blocks + 3) / 4), dim3(4 * QA_BLOCK), 0, st, a);
     else hipLaunchKernelGGL((qa_env_step_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
 }
 
@@ -1261,7 +1262,6 @@ static int launch_simulate(qa_sim *s, const float *torques, const uint8_t *cond,
     if (!torques) torques = s->p.torques;          // the actuation forces set last (gym keeps applying them)
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
     if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_simulate_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques, cond);
-    else if (s->lanes == 16) hipLaunchKernelGGL((qa_simulate_kernel<true, 16>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques, cond);
     else hipLaunchKernelGGL((qa_simulate_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, (hipStream_t)stream, s->cfg, s->p, torques, cond);
     HIP_TRY(hipGetLastError());
     return QA_OK;

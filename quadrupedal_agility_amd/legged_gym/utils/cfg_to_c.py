@@ -32,6 +32,7 @@ def make_qa_config(cfg, seed=1, sim_dt=None, terrain=None):
     c.gravity_z = float(cfg.sim.gravity[2])
     qa = getattr(cfg.sim, "qa", None)
     c.solver_iterations = int(getattr(qa, "solver_iterations", 4))
+    c.contact_slots = int(getattr(qa, "contact_slots", 2))
     c.contact_offset = float(cfg.sim.physx.contact_offset)
     c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
     c.ground_friction = float(cfg.terrain.static_friction)

@@ -31,6 +31,7 @@ def make_qa_config(cfg, obstacle, seed=1):
     c.abi_version, c.num_envs, c.seed = _capi.QA_ABI_VERSION, int(cfg.env.num_envs), int(seed) & 0xFFFFFFFFFFFFFFFF
     c.sim_dt, c.decimation, c.gravity_z = float(cfg.sim.dt), int(cfg.control.decimation), float(cfg.sim.gravity[2])
     c.solver_iterations = int(getattr(getattr(cfg.sim, "qa", None), "solver_iterations", 4))
+    c.contact_slots = int(getattr(getattr(cfg.sim, "qa", None), "contact_slots", 2))
     c.contact_offset = float(cfg.sim.physx.contact_offset)
     c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
     c.ground_friction = float(cfg.terrain.static_friction)

@@ -342,3 +342,24 @@ def test_rigid_body_state_velocities_are_the_time_derivative_of_the_positions():
         w = Rb @ (Rb.T @ root[10:13] + np.array([1, 0, 0]) * s.t["DOF_STATE"][0, 3 * l, 1]
                   + np.array([0, np.cos(qn[3 * l]), np.sin(qn[3 * l])]) * (s.t["DOF_STATE"][0, 3 * l + 1, 1] + s.t["DOF_STATE"][0, 3 * l + 2, 1]))
         assert np.allclose(b[3 + 4 * l + 2, 10:13], w, atol=1e-5)
+
+
+def test_every_body_of_a_leg_can_report_contact():
+    """r2 contact model: one contact per BODY of a leg (hip link / base share | thigh | calf, besides the foot).  A robot dropped
+    on its belly with the legs swept back rests on hips AND calves at once: two non-foot bodies of the SAME leg carry force in
+    the same substep -- with the single shared non-foot slot per leg of round 1 only one of them could (check_termination reads
+    the hips, _reward_collision the thighs and calves: legged_robot.py:168-176, 1275-1278)"""
+    qc = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, push_robots=0, add_noise=0)
+    s = OracleSim(qc)
+    s.reset_all()
+    s.t["ROOT_STATES"][0] = [0, 0, 0.15, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    s.t["DOF_STATE"][0, :, 0] = [0, -1.2, -0.85] * 4; s.t["DOF_STATE"][0, :, 1] = 0
+    tau = np.zeros((1, 12), np.float32)
+    most = 0
+    for _ in range(200):
+        s.simulate(tau)
+        f = np.linalg.norm(s.t["CONTACT_FORCES"][0], axis=1)
+        most = max(most, max(int((f[3 + 4 * l:3 + 4 * l + 3] > 0.1).sum()) for l in range(4)))
+    assert most >= 2
+    assert np.isfinite(s.t["ROOT_STATES"]).all() and s.t["ROOT_STATES"][0, 2] > 0.02
+    assert s.t["CONTACT_FORCES"][0, :, 2].sum() == pytest.approx(MASS * G, rel=0.15)      # at rest the contacts carry the weight

@@ -2,11 +2,15 @@
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+from quadrupedal_agility_amd import _capi
+if os.environ.get("QA_LIB"): _capi.LIB_PATH = os.environ["QA_LIB"]
 from tests.oracle_lib import go2_cfg
 from quadrupedal_agility_amd.sim import QaSim
 TERRAIN = "--terrain" in sys.argv
 for n in (4096, 16384):
     q = go2_cfg(n)
+    q.contact_slots = int(os.environ.get("QA_SLOTS", "2"))
     if TERRAIN:          # rough field, robots scattered over it
         q.terrain_type = 1; q.hf_rows, q.hf_cols, q.hf_hscale, q.hf_vscale, q.hf_border = 1600, 1600, 0.1, 0.005, 30.0
         q.reset_xy_jitter = 1.0
