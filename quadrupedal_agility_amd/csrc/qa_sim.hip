@@ -588,25 +588,26 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
     const int lane = tix;
-    // history loads run one group ahead of the assembly (double-buffered in registers): the HBM latency of group
-    // k+1's 36 loads is hidden behind the LDS assembly and the row stores of group k
-    float hvb[2][OBS_GROUP][9];
-    auto load_hist = [&](int buf, int e0) {
+    // history loads: ALL 16 rows of the block (9 values per lane and row = 144 registers -- the physics state is dead by now) are
+    // requested back to back before the first row is assembled, so the HBM latency is exposed once per launch, not once per
+    // group of rows (one wavefront per SIMD: nothing else hides it)
+    constexpr int NG = EPB / OBS_GROUP;
+    float hvb[NG][OBS_GROUP][9];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {          // 8 full wave loads + 1 single-lane load per env
-            const int ge = min((int)(bix * EPB) + e0 + g, N - 1);
+            const int ge = min((int)(bix * EPB) + gi * OBS_GROUP + g, N - 1);
             const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
 #pragma unroll
-            for (int r = 0; r < 8; ++r) hvb[buf][g][r] = hist[QA_BLOCK * r];
-            hvb[buf][g][8] = (lane == 0) ? hist[512] : 0.f;
+            for (int r = 0; r < 8; ++r) hvb[gi][g][r] = hist[QA_BLOCK * r];
+            hvb[gi][g][8] = (lane == 0) ? hist[512] : 0.f;
         }
-    };
-    load_hist(0, 0);
+    }
 #pragma unroll
-    for (int gi = 0; gi < EPB / OBS_GROUP; ++gi) {
+    for (int gi = 0; gi < NG; ++gi) {
         const int e0 = gi * OBS_GROUP;
-        if (gi + 1 < EPB / OBS_GROUP) load_hist((gi + 1) & 1, e0 + OBS_GROUP);
-        float (&hv)[OBS_GROUP][9] = hvb[gi & 1];
+        float (&hv)[OBS_GROUP][9] = hvb[gi];
         if (e0) wave_lds_sync();                       // the previous group's row stores have read their LDS rows
 #pragma unroll
         for (int g = 0; g < OBS_GROUP; ++g) {

@@ -1,0 +1,107 @@
+"""Seam 1: the reference's OWN `LeggedRobot` on this engine -- a stand-in for the Isaac Gym objects the env calls
+(`self.gym.*`, `gymtorch.wrap_tensor / unwrap_tensor`), backed by the C ABI of include/qa_sim.h.
+
+    gym = QaGym(qcfg, device)                    # replaces gymapi.acquire_gym() + create_sim / create_envs / prepare_sim
+    env.gym, env.sim = gym, gym.sim_handle
+    # the reference's _init_buffers (bbc/legged_gym/envs/base/legged_robot.py:743-770) then runs unchanged:
+    #   acquire_*_tensor -> zero-copy torch views of the engine's arena (root (N,13), dof (N*12,2), net contact force (N*19,3),
+    #   rigid body state (N*19,13) -- QA_T_RIGID_BODY_STATE, qa_config.export_body_state = 1)
+    # and its step (:78-115): set_dof_actuation_force_tensor + simulate + fetch_results + refresh_* = one qa_simulate per substep
+
+The env both reads and writes the views in place, exactly like gymtorch views; `set_*_state_tensor_indexed` therefore has nothing
+to copy and only clears the contact warm start of the reset envs.  `tests/test_seam1_reference_env.py` drives the reference's
+class over this shim in the build container.  Product use needs the HIP library and a GPU; the test injects the oracle's twin
+of the ABI (`lib=(library, "qo_")`) to run on host memory."""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+_DT = {_capi.DTYPE_F32: torch.float32, _capi.DTYPE_I64: torch.int64, _capi.DTYPE_U8: torch.uint8, _capi.DTYPE_I32: torch.int32,
+       _capi.DTYPE_I16: torch.int16, _capi.DTYPE_F64: torch.float64}
+
+
+class QaGym:
+    def __init__(self, qcfg, device="cuda:0", lib=None):
+        self._prefix = "qa_"
+        if lib is not None:
+            self.lib, self._prefix = lib
+        else:
+            self.lib = _capi.load_library()
+            if not torch.cuda.is_available():
+                raise RuntimeError("QaGym needs a GPU: quadrupedal_agility_amd has no CPU fallback")
+        if not qcfg.export_body_state:
+            raise ValueError("seam 1 needs qa_config.export_body_state = 1 (the env views rigid_body_state as (N, num_bodies, 13))")
+        self.cfg, self.device = qcfg, torch.device(device)
+        n = self._fn("arena_bytes")(C.byref(qcfg))
+        self._slab = torch.zeros(n + 256, dtype=torch.uint8, device=self.device)
+        self.arena = self._slab[(-self._slab.data_ptr()) % 256:][:n]
+        self.sim_handle = C.c_void_p()
+        rc = self._fn("create")(C.byref(qcfg), self.arena.data_ptr(), n, self._stream(), C.byref(self.sim_handle))
+        if rc != 0:
+            raise RuntimeError(f"qa_create failed with code {rc}")
+        self._tau = None
+
+    def _fn(self, name):
+        return getattr(self.lib, self._prefix + name)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else None
+
+    def view(self, name):
+        off, shape, dt = _capi.tensor_info(self.lib, self._prefix, self.cfg, _capi.T[name])
+        numel = 1
+        for s in shape:
+            numel *= s
+        t = _DT[dt]
+        return self.arena[off:off + numel * torch.empty((), dtype=t).element_size()].view(t).view(*shape)
+
+    # ---- acquire_* (legged_robot.py:747-750): the engine owns the buffers, torch holds aliases
+    def acquire_actor_root_state_tensor(self, sim):
+        return self.view("ROOT_STATES")
+
+    def acquire_dof_state_tensor(self, sim):
+        return self.view("DOF_STATE").view(-1, 2)
+
+    def acquire_net_contact_force_tensor(self, sim):
+        return self.view("CONTACT_FORCES").view(-1, 3)
+
+    def acquire_rigid_body_state_tensor(self, sim):
+        return self.view("RIGID_BODY_STATE").view(-1, 13)
+
+    # ---- step (:103-106, 129-131)
+    def set_dof_actuation_force_tensor(self, sim, torques):
+        self._tau = torques.contiguous()
+
+    def simulate(self, sim):
+        rc = self._fn("simulate")(self.sim_handle, self._tau.data_ptr(), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"qa_simulate failed with code {rc}")
+
+    def fetch_results(self, sim, wait):
+        pass                                  # results are already in the views
+
+    def refresh_dof_state_tensor(self, sim):
+        pass                                  # zero-copy: nothing to refresh
+
+    refresh_actor_root_state_tensor = refresh_net_contact_force_tensor = refresh_rigid_body_state_tensor = refresh_dof_state_tensor
+
+    # ---- reset (:594-596, 632-634, 687): the env wrote the new state through the aliased views already
+    def set_dof_state_tensor_indexed(self, sim, state, env_ids, n):
+        self.view("FOOT_IMPULSE")[env_ids.long()] = 0.0        # a reset env starts without a contact warm start
+
+    def set_actor_root_state_tensor_indexed(self, sim, state, env_ids, n):
+        pass
+
+    def set_actor_root_state_tensor(self, sim, state):
+        pass
+
+    def find_actor_rigid_body_handle(self, env, actor, name):
+        return _capi.BODY_NAMES.index(name)
+
+
+class gymtorch:
+    """`isaacgym.gymtorch` for code running over QaGym: the acquire_* results are torch tensors already"""
+    wrap_tensor = staticmethod(lambda t: t)
+    unwrap_tensor = staticmethod(lambda t: t)
