@@ -331,35 +331,52 @@ def cpu_baseline(num_envs, budget_s):
     except OSError:
         pass
     del o
-    # ---- whole iterations on the CPU: oracle physics + torch-CPU policy / GAE / PPO (BASELINE config 2's settings)
+    # ---- whole iterations on the CPU: oracle physics + torch-CPU policy / GAE / PPO (BASELINE config 2's settings).  In a child
+    # process with its own thread budget and a hard time limit: the baseline is a report, it must never cost the bench line.
+    import subprocess
+    threads = min(cores, 64)
+    env_vars = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), QA_CPU_ITER_ENVS=str(num_envs))
     try:
-        from quadrupedal_agility_amd.legged_gym.envs import task_registry
-        from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
-        from quadrupedal_agility_amd.legged_gym.utils import get_args
-        from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
-        from tests.oracle_backend import OracleBackend
-        torch.set_num_threads(cores)
-        cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = False; cfg.seed = 1
-        tcfg = Go2LocomotionCfgAlgo(); tcfg.runner.amp_enabled = False
-        cli = get_args(["--device", "cpu"])
-        torch.manual_seed(1)
-        env, _ = task_registry.make_env("go2_locomotion", args=cli, env_cfg=cfg, backend=OracleBackend(make_qa_config(cfg, seed=1)))
-        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=cli, train_cfg=tcfg, log_root=None)
-        runner.learn(1, init_at_random_ep_len=True)
-        its, coll, lrn = 3, [], []
-        t0 = time.perf_counter()
-        for _ in range(its):
-            runner.learn(1)
-            coll.append(runner.last_perf["collection_time"]); lrn.append(runner.last_perf["learn_time"])
-        dt_it = (time.perf_counter() - t0) / its
-        T = runner.num_steps_per_env
-        out["iteration"] = {"value": num_envs * T / dt_it, "unit": "env-steps/s", "iteration_s": dt_it, "rollout_s": sum(coll) / its, "learner_s": sum(lrn) / its,
-                            "sample": f"{its} whole PPO iterations after 1 warm-up: {num_envs} envs x {T} steps of oracle physics + torch-CPU policy, GAE, 5 epochs x 4 minibatches, "
-                                      f"torch.set_num_threads({cores})"}
-    except Exception as e:      # the baseline is a report, never a reason to lose the bench line
-        out["iteration"] = {"error": repr(e)}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu_iteration_child"], env=env_vars, capture_output=True, text=True, timeout=150)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        out["iteration"] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
+    except subprocess.TimeoutExpired:
+        out["iteration"] = {"error": f"torch-CPU iteration leg did not finish 1 warm-up + 2 iterations of {num_envs} envs within 150 s on {threads} threads"}
     return out
 
 
+def cpu_iteration_child():
+    """1 warm-up + 2 timed PPO iterations of BASELINE config 2 on the host: oracle physics (OpenMP) + torch-CPU learner"""
+    import torch
+    num_envs = int(os.environ.get("QA_CPU_ITER_ENVS", "4096"))
+    threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
+    torch.set_num_threads(threads)
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+    from quadrupedal_agility_amd.legged_gym.utils import get_args
+    from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
+    from tests.oracle_backend import OracleBackend
+    cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = False; cfg.seed = 1
+    tcfg = Go2LocomotionCfgAlgo(); tcfg.runner.amp_enabled = False
+    cli = get_args(["--device", "cpu"])
+    torch.manual_seed(1)
+    env, _ = task_registry.make_env("go2_locomotion", args=cli, env_cfg=cfg, backend=OracleBackend(make_qa_config(cfg, seed=1)))
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=cli, train_cfg=tcfg, log_root=None)
+    runner.learn(1, init_at_random_ep_len=True)
+    its, coll, lrn = 2, [], []
+    t0 = time.perf_counter()
+    for _ in range(its):
+        runner.learn(1)
+        coll.append(runner.last_perf["collection_time"]); lrn.append(runner.last_perf["learn_time"])
+    dt_it = (time.perf_counter() - t0) / its
+    T = runner.num_steps_per_env
+    print(json.dumps({"value": num_envs * T / dt_it, "unit": "env-steps/s", "iteration_s": dt_it, "rollout_s": sum(coll) / its, "learner_s": sum(lrn) / its,
+                      "threads": threads,
+                      "sample": f"{its} whole PPO iterations after 1 warm-up: {num_envs} envs x {T} steps of oracle physics + torch-CPU policy, GAE, 5 epochs x 4 minibatches, {threads} threads"}))
+
+
 if __name__ == "__main__":
-    main()
+    if "--cpu_iteration_child" in sys.argv:
+        cpu_iteration_child()
+    else:
+        main()
