@@ -117,12 +117,18 @@ enum qa_tensor {
                                          rigid_body_state viewed as (N, num_bodies, 13) (legged_robot.py:759-768).
                                          Written by step / simulate only when cfg.export_body_state != 0 (else one row) */
     QA_T_STEP_TICKET,         /* (4) int32: arrival counter of qa_env_step_dev's last-workgroup step-counter update */
+    QA_T_CEILING_SAMPLES,     /* (hf_rows, hf_cols) int16, only with cfg.hf_ceiling (else one element): height of the UNDERSIDE of an
+                                         overhang above the cell (tunnel roof, upper arc of the tyre), same grid and scales as
+                                         HEIGHT_SAMPLES; QA_NO_CEILING where there is none.  A contact candidate collides with the nearer of
+                                         floor and ceiling; the ceiling's contact normal points down (away from the obstacle)      */
     QA_T_COUNT
 };
 
 enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3, QA_I16 = 4, QA_F64 = 5 };
 
 #define QA_MOCAP_FRAME 37       /* root pos3, root quat4, joint pos12, lin vel3, ang vel3 (root frame), joint vel12 */
+#define QA_CEILING_SHELL 0.05f   /* m: an overhang's underside stops points up to this far above it (thin-shell rule) */
+#define QA_NO_CEILING 32767
 #define QA_MAX_MOCAP_CLIPS 64
 #define QA_MOCAP_CLIP 8         /* first frame row, number of frames n, clip length (n-1) frame_duration [s], sampling range
                                    length - (time_between_frames disc_obs_len + frame_duration) [s], cumulative sampling
@@ -191,7 +197,7 @@ typedef struct qa_config {
                                        make contact at once (all three inside the contact offset: the one with the largest gap waits),
                                        so _reward_collision and check_termination see the bodies independently; 1 = only the lowest
                                        non-foot point of the leg (the round-1 model) */
-    int32_t reserved_cfg[1];
+    int32_t hf_ceiling;             /* terrain_type 1: != 0 = QA_T_CEILING_SAMPLES holds overhangs to collide with */
 } qa_config;
 
 typedef struct qa_sim qa_sim;

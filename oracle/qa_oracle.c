@@ -100,6 +100,8 @@ static void make_layout(const qa_config *cfg, Layout *L) {
     set_t(L, QA_T_MOCAP_CLIPS, QA_F64, 2, QA_MAX_MOCAP_CLIPS, QA_MOCAP_CLIP, 1);
     set_t(L, QA_T_RIGID_BODY_STATE, QA_F32, 3, cfg->export_body_state ? N : 1, QA_NUM_BODIES_ABI, 13);
     set_t(L, QA_T_STEP_TICKET, QA_I32, 1, 4, 1, 1);
+    { int ce = cfg->terrain_type == 1 && cfg->hf_ceiling;
+      set_t(L, QA_T_CEILING_SAMPLES, QA_I16, 2, ce ? cfg->hf_rows : 1, ce ? cfg->hf_cols : 1, 1); }
     int64_t off = 0;
     for (int t = 0; t < QA_T_COUNT; ++t) {
         off = (off + 255) & ~(int64_t)255;
@@ -358,6 +360,36 @@ static void ground_query(const qo_sim *s, double x, double y, double *h, double 
     double inv = 1.0 / sqrt(gx * gx + gy * gy + 1.0);
     n[0] = -gx * inv; n[1] = -gy * inv; n[2] = inv;
 }
+/* Gap and contact normal of a sphere (radius rad, centre pw, world frame) against the terrain: the distance to the plane of the
+ * floor triangle under it, or -- with cfg.hf_ceiling -- to the plane of the CEILING triangle above it if that is nearer (tunnel roof,
+ * upper arc of the tyre; QA_T_CEILING_SAMPLES, same triangulation, a triangle with a QA_NO_CEILING corner does not exist).  The
+ * ceiling's normal points down, away from the obstacle. */
+static double contact_query(const qo_sim *s, const double pw[3], double rad, double n[3]) {
+    const qa_config *c = &s->cfg;
+    double gh; ground_query(s, pw[0], pw[1], &gh, n);
+    double gap = (pw[2] - gh) * n[2] - rad;
+    if (c->terrain_type != 1 || !c->hf_ceiling) return gap;
+    const int16_t *cs = TP(s, QA_T_CEILING_SAMPLES, int16_t);
+    double fx = (pw[0] + c->hf_border) / c->hf_hscale, fy = (pw[1] + c->hf_border) / c->hf_hscale;
+    int ix = (int)floor(fx), iy = (int)floor(fy);
+    if (ix < 0) ix = 0; if (ix > c->hf_rows - 2) ix = c->hf_rows - 2;
+    if (iy < 0) iy = 0; if (iy > c->hf_cols - 2) iy = c->hf_cols - 2;
+    double u = fx - ix, v = fy - iy;
+    if (u < 0) u = 0; if (u > 1) u = 1; if (v < 0) v = 0; if (v > 1) v = 1;
+    int16_t s00 = cs[(int64_t)ix * c->hf_cols + iy], s10 = cs[(int64_t)(ix + 1) * c->hf_cols + iy];
+    int16_t s01 = cs[(int64_t)ix * c->hf_cols + iy + 1], s11 = cs[(int64_t)(ix + 1) * c->hf_cols + iy + 1];
+    double vs = c->hf_vscale, h00 = vs * s00, h10 = vs * s10, h01 = vs * s01, h11 = vs * s11, gx, gy, ch;
+    if (u >= v) { if (s00 == QA_NO_CEILING || s10 == QA_NO_CEILING || s11 == QA_NO_CEILING) return gap; gx = h10 - h00; gy = h11 - h10; ch = h00 + u * gx + v * gy; }
+    else { if (s00 == QA_NO_CEILING || s01 == QA_NO_CEILING || s11 == QA_NO_CEILING) return gap; gy = h01 - h00; gx = h11 - h01; ch = h00 + v * gy + u * gx; }
+    gx /= c->hf_hscale; gy /= c->hf_hscale;
+    double inv = 1.0 / sqrt(gx * gx + gy * gy + 1.0);
+    double cgap = (ch - pw[2]) * inv - rad;
+    /* an overhang is a thin shell: its underside acts on points below it or at most QA_CEILING_SHELL above it (a point well above
+     * is ON the obstacle, which this field does not describe), and only where it lies above the floor map */
+    if (!(ch > gh) || (ch - pw[2]) * inv < -QA_CEILING_SHELL) return gap;
+    if (cgap < gap) { gap = cgap; n[0] = gx * inv; n[1] = gy * inv; n[2] = -inv; }
+    return gap;
+}
 /* tangent basis of a contact: t1 = x-axis projected onto the tangent plane, t2 = n x t1 */
 static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
     double d = n[0];
@@ -444,16 +476,14 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             v3 pl = {QA_LEG_PT_POS[l][c][0], QA_LEG_PT_POS[l][c][1], QA_LEG_PT_POS[l][c][2]}, p, pwld;
             mv(K.Rl[l][k], pl, p); for (int i = 0; i < 3; ++i) p[i] += K.o[l][k][i];
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
-            double gh; v3 gn; ground_query(s, pwld[0], pwld[1], &gh, gn);
-            double gap = (pwld[2] - gh) * gn[2] - QA_LEG_PT_RAD[l][c];      /* distance to the terrain triangle's plane */
+            v3 gn; double gap = contact_query(s, pwld, QA_LEG_PT_RAD[l][c], gn);      /* distance to the terrain triangle's plane (floor, or ceiling) */
             if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); memcpy(foot_n, gn, sizeof(v3)); }
             else if (gap < best_gap[k]) { best_gap[k] = gap; memcpy(best_p[k], p, sizeof(v3)); memcpy(best_n[k], gn, sizeof(v3)); best_depth[k] = k; best_body[k] = QA_LEG_PT_BODY[l][c]; }
         }
         for (int c = l; c < QA_NUM_BASE_PTS; c += 4) { /* base points are dealt round-robin to the four legs; they share slot 0 with the hip link */
             v3 p = {QA_BASE_PT_POS[c][0], QA_BASE_PT_POS[c][1], QA_BASE_PT_POS[c][2]}, pwld;
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
-            double gh; v3 gn; ground_query(s, pwld[0], pwld[1], &gh, gn);
-            double gap = (pwld[2] - gh) * gn[2] - QA_BASE_PT_RAD[c];
+            v3 gn; double gap = contact_query(s, pwld, QA_BASE_PT_RAD[c], gn);
             if (gap < best_gap[0]) { best_gap[0] = gap; memcpy(best_p[0], p, sizeof(v3)); memcpy(best_n[0], gn, sizeof(v3)); best_depth[0] = -1; best_body[0] = QA_BASE_PT_BODY[c]; }
         }
         if (cfg->contact_slots == 1) {      /* only the lowest non-foot point of the leg makes contact (the round-1 model) */
@@ -954,6 +984,7 @@ int qo_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
     s->cfg = *cfg; make_layout(cfg, &s->L); s->arena = (char *)arena;
     if (arena_bytes < s->L.total || ((uintptr_t)arena & 255)) { free(s); return QA_E_ARENA; }
     memset(arena, 0, (size_t)s->L.total);
+    if (cfg->terrain_type == 1 && cfg->hf_ceiling) { int16_t *cs = TP(s, QA_T_CEILING_SAMPLES, int16_t); for (int64_t i = 0; i < (int64_t)cfg->hf_rows * cfg->hf_cols; ++i) cs[i] = QA_NO_CEILING; }
     int N = cfg->num_envs;
     /* env origins: grid (legged_robot.py:1126-1136) */
     int ncols = (int)floor(sqrt((double)(cfg->num_envs_global > 0 ? cfg->num_envs_global : N)));

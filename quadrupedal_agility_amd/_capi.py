@@ -32,7 +32,7 @@ TENSORS = [
     "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
     "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",
     "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES", "HEIGHT_SAMPLES", "SCAN_HEIGHT", "FOOT_IMPULSE",
-    "MOCAP_CLIPS", "RIGID_BODY_STATE", "STEP_TICKET",
+    "MOCAP_CLIPS", "RIGID_BODY_STATE", "STEP_TICKET", "CEILING_SAMPLES",
 ]
 T = {name: i for i, name in enumerate(TENSORS)}
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32, DTYPE_I16, DTYPE_F64 = 0, 1, 2, 3, 4, 5
@@ -77,7 +77,7 @@ class QaConfig(C.Structure):
         ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("hf_hscale", C.c_float), ("hf_vscale", C.c_float),
         ("hf_border", C.c_float), ("reset_xy_jitter", C.c_float),
         ("num_mocap_frames", C.c_int32), ("export_body_state", C.c_int32), ("env_id_offset", C.c_int32), ("num_envs_global", C.c_int32),
-        ("contact_slots", C.c_int32), ("reserved_cfg", C.c_int32 * 1),
+        ("contact_slots", C.c_int32), ("hf_ceiling", C.c_int32),
     ]
 
 

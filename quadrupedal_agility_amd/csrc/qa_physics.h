@@ -105,6 +105,7 @@ QA_DEV void sym6_mul(const float *A, const float *x, float *y) {
 struct TerrainView {
     const float *patch;      // LDS, QA_PATCH x QA_PATCH, row-major (x major), metres
     const int16_t *samples;  // the whole field in HBM (fallback for queries outside the window)
+    const int16_t *ceil;     // undersides of overhangs on the same grid (QA_T_CEILING_SAMPLES), nullptr = none
     int ix0, iy0;            // global cell of patch[0][0]
     int rows, cols;
     float border, hscale, inv_hscale, vscale;
@@ -148,6 +149,31 @@ QA_DEV void ground_query(const TerrainView &T, float x, float y, float &h, V3 &n
     gx *= T.inv_hscale; gy *= T.inv_hscale;
     float inv = rsqrtf(gx * gx + gy * gy + 1.0f);
     n = v3(-gx * inv, -gy * inv, inv);
+}
+// Gap and contact normal of a sphere (centre (x, y, zw), radius r) against the terrain: the plane of the floor triangle under it or,
+// where QA_T_CEILING_SAMPLES has one and it is nearer, of the ceiling triangle above it (tunnel roof, upper arc of the tyre).  A
+// triangle with a QA_NO_CEILING corner does not exist; the ceiling's normal points down.  Ceiling samples are read from HBM (an
+// env is under an overhang for a few steps of an episode; the floor window in LDS is what every query needs).
+QA_DEV float contact_query(const TerrainView &T, float x, float y, float zw, float r, V3 &n) {
+    float gh; ground_query(T, x, y, gh, n);
+    float gap = (zw - gh) * n.z - r;
+    if (T.ceil) {
+        float fx = (x + T.border) * T.inv_hscale, fy = (y + T.border) * T.inv_hscale;
+        int ix = min(max((int)floorf(fx), 0), T.rows - 2), iy = min(max((int)floorf(fy), 0), T.cols - 2);
+        float u = clampf(fx - (float)ix, 0.f, 1.f), v = clampf(fy - (float)iy, 0.f, 1.f);
+        const int16_t *g = T.ceil + (int64_t)ix * T.cols + iy;
+        const int s00 = g[0], s01 = g[1], s10 = g[T.cols], s11 = g[T.cols + 1];
+        const bool lower = u >= v;                       // triangle (00, 10, 11), else (00, 01, 11)
+        const bool exists = s00 != QA_NO_CEILING && s11 != QA_NO_CEILING && (lower ? s10 : s01) != QA_NO_CEILING;
+        const float h00 = (float)s00 * T.vscale, h01 = (float)s01 * T.vscale, h10 = (float)s10 * T.vscale, h11 = (float)s11 * T.vscale;
+        float gx = lower ? h10 - h00 : h11 - h01, gy = lower ? h11 - h10 : h01 - h00;
+        const float ch = h00 + u * gx + v * gy;
+        gx *= T.inv_hscale; gy *= T.inv_hscale;
+        const float inv = rsqrtf(gx * gx + gy * gy + 1.0f), cgap = (ch - zw) * inv - r;
+        // thin shell: acts on points below it or at most QA_CEILING_SHELL above it, and only where it lies above the floor map
+        if (exists && ch > gh && (ch - zw) * inv >= -QA_CEILING_SHELL && cgap < gap) { gap = cgap; n = v3(gx * inv, gy * inv, -inv); }
+    }
+    return gap;
 }
 // legged_robot.py:1209-1228 for the one scan point the BBC env consumes: (0, 0.1) in the yaw frame, truncated to a
 // cell, min of three samples.  Integer samples are read from HBM (one env-step-level lookup per quad).
@@ -476,8 +502,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             const float *pt = tbl + T_POINTS + 4 * c;
             V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
             float zw = dot(nB, p) + st.pos.z;
-            float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
-            float gap = (zw - gh) * gn.z - pt[3];          // distance to the terrain triangle's plane
+            V3 gn; float gap = contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, zw, pt[3], gn);      // distance to the terrain triangle's plane
             if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; }
             else if (gap < bgap[k]) { bgap[k] = gap; bcode[k] = c; }
         }
@@ -488,8 +513,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                 const float *pt = btbl + 4 * c;
                 V3 p = v3(pt[0], pt[1], pt[2]);
                 float zw = dot(nB, p) + st.pos.z;
-                float gh; V3 gn; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, gn);
-                float gap = (zw - gh) * gn.z - pt[3];
+                V3 gn; float gap = contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, zw, pt[3], gn);
                 if (gap < bgap[0]) { bgap[0] = gap; bcode[0] = 64 + c; }
             }
         }
@@ -540,7 +564,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             Row re[3];
             V3 en_b = nB, et1_b = t1B, et2_b = t2B;
             if (!PLANE) {
-                float gh; ground_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, gh, ex_n[sl]);
+                (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
                 V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
             }
             contact_rows(re, p, depth, sgap[sl], o, ax, en_b, et1_b, et2_b, G, Linv, Binv, P);

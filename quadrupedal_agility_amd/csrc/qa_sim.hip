@@ -65,6 +65,7 @@ static void make_layout(const qa_config *cfg, Layout *L) {
         {QA_T_MOCAP_CLIPS, QA_F64, 2, QA_MAX_MOCAP_CLIPS, QA_MOCAP_CLIP, 1},
         {QA_T_RIGID_BODY_STATE, QA_F32, 3, cfg->export_body_state ? N : 1, QA_NUM_BODIES_ABI, 13},
         {QA_T_STEP_TICKET, QA_I32, 1, 4, 1, 1},
+        {QA_T_CEILING_SAMPLES, QA_I16, 2, (cfg->terrain_type == 1 && cfg->hf_ceiling) ? HR : 1, (cfg->terrain_type == 1 && cfg->hf_ceiling) ? HC : 1, 1},
     };
     static_assert(sizeof(specs) / sizeof(specs[0]) == QA_T_COUNT, "every tensor needs a spec");
     memset(L, 0, sizeof(*L));
@@ -87,7 +88,7 @@ struct Ptrs {
     float *rbstate;
     double *mocap_clips;
     int32_t *ticket;
-    int16_t *height_samples;
+    int16_t *height_samples, *ceil_samples;
     int64_t *reset, *episode_length;
     uint8_t *time_out, *last_contacts, *contact_filt;
 };
@@ -238,7 +239,7 @@ __device__ __forceinline__ void reset_env(const qa_config &c, const Ptrs &p, con
 
 __device__ __forceinline__ TerrainView terrain_view(const qa_config &c, const Ptrs &p, const float *patch) {
     TerrainView T;
-    T.patch = patch; T.samples = p.height_samples; T.ix0 = 0; T.iy0 = 0; T.rows = c.hf_rows; T.cols = c.hf_cols;
+    T.patch = patch; T.samples = p.height_samples; T.ceil = c.hf_ceiling ? p.ceil_samples : nullptr; T.ix0 = 0; T.iy0 = 0; T.rows = c.hf_rows; T.cols = c.hf_cols;
     T.border = c.hf_border; T.hscale = c.hf_hscale; T.inv_hscale = 1.0f / c.hf_hscale; T.vscale = c.hf_vscale;
     return T;
 }
@@ -1126,6 +1127,7 @@ static void fill_ptrs(qa_sim *s) {
     p.time_out = (uint8_t *)(a + L.off[QA_T_TIME_OUT]); p.last_contacts = (uint8_t *)(a + L.off[QA_T_LAST_CONTACTS]);
     p.contact_filt = (uint8_t *)(a + L.off[QA_T_CONTACT_FILT]);
     p.height_samples = (int16_t *)(a + L.off[QA_T_HEIGHT_SAMPLES]);
+    p.ceil_samples = (int16_t *)(a + L.off[QA_T_CEILING_SAMPLES]);
     p.rbstate = (float *)(a + L.off[QA_T_RIGID_BODY_STATE]);
     p.mocap_clips = (double *)(a + L.off[QA_T_MOCAP_CLIPS]);
     p.ticket = (int32_t *)(a + L.off[QA_T_STEP_TICKET]);
@@ -1187,6 +1189,10 @@ int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
     if (e != hipSuccess) { delete s; return fail_hip(e, "hipMemcpyToSymbol(c_tbl)"); }
     e = hipMemsetAsync(arena, 0, (size_t)s->L.total, st);
     if (e != hipSuccess) { delete s; return fail_hip(e, "hipMemsetAsync(arena)"); }
+    if (cfg->terrain_type == 1 && cfg->hf_ceiling) {     // "no overhang anywhere" until the caller writes the ceiling field
+        e = hipMemsetD16Async((hipDeviceptr_t)s->p.ceil_samples, (unsigned short)QA_NO_CEILING, (size_t)cfg->hf_rows * cfg->hf_cols, st);
+        if (e != hipSuccess) { delete s; return fail_hip(e, "hipMemsetD16Async(ceiling)"); }
+    }
     const int N = cfg->num_envs;
     BaseConst bc; bc.m = QA_BASE_MASS; for (int i = 0; i < 3; ++i) bc.com[i] = QA_BASE_COM[i]; for (int i = 0; i < 6; ++i) bc.I[i] = QA_BASE_I[i];
     hipLaunchKernelGGL(qa_init_kernel, dim3((N + 255) / 256), dim3(256), 0, st, s->cfg, s->p, bc);

@@ -11,7 +11,7 @@
 The env both reads and writes the views in place, exactly like gymtorch views; `set_*_state_tensor_indexed` therefore has nothing
 to copy and only clears the contact warm start of the reset envs.  `tests/test_seam1_reference_env.py` drives the reference's
 class over this shim in the build container.  Product use needs the HIP library and a GPU; the test injects the oracle's twin
-of the ABI (`lib=(library, "qo_")`) to run on host memory."""
+of the ABI (`lib=(library, prefix)`) to run on host memory."""
 import ctypes as C
 
 import torch

@@ -38,6 +38,7 @@ def make_qa_config(cfg, obstacle, seed=1):
     c.terrain_type = 1
     c.hf_rows, c.hf_cols = int(obstacle.tot_rows), int(obstacle.tot_cols)
     c.hf_hscale, c.hf_vscale, c.hf_border = float(obstacle.horizontal_scale), float(obstacle.vertical_scale), float(cfg.obstacle.border_size)
+    c.hf_ceiling = 1                                     # tunnel roof + upper arc of the tyre (obstacle.ceiling_raw -> CEILING_SAMPLES)
     if cfg.control.control_type != "P":
         raise NotImplementedError("only control_type 'P' is on the hot path")
     kp = {float(v) for v in cfg.control.stiffness.values()}
@@ -101,6 +102,7 @@ class LeggedRobot:
         t = self.sim.t
         self.height_samples = torch.from_numpy(np.ascontiguousarray(self.obstacle.height_field_raw)).to(dev)
         t["HEIGHT_SAMPLES"].copy_(self.height_samples)
+        t["CEILING_SAMPLES"].copy_(torch.as_tensor(self.obstacle.ceiling_raw, dtype=torch.int16))
         self.x_edge_mask = torch.from_numpy(np.ascontiguousarray(self.obstacle.x_edge_mask)).to(dev)
         self.env_origins = t["ENV_ORIGINS"]
         self.env_origins.copy_(torch.from_numpy(self.obstacle.env_origins).to(dev, torch.float32))

@@ -22,6 +22,7 @@ import random as _random
 import numpy as np
 
 TYPES = ("bar_jump", "frame", "poles", "seesaw", "tire_jump", "tunnel")
+NO_CEILING = 32767          # include/qa_sim.h QA_NO_CEILING
 
 
 def fill_polygon(rows, cols, shape):
@@ -59,6 +60,7 @@ class _Tile:
 
     def __init__(self, shape):
         self.h = np.zeros(shape, dtype=np.int16)
+        self.ceil = np.full(shape, NO_CEILING, dtype=np.int16)      # undersides of overhangs (this build's addition, see Obstacle.ceiling_raw)
         self.edge = np.zeros(shape, dtype=bool)
         self.rects, self.edge_rects = [], []
         self.goals = None
@@ -100,6 +102,9 @@ class Obstacle:
         self.tot_rows = int(self.num_rows * self.length_per_env_pixels) + 2 * self.border
         self.height_field_raw = np.zeros((self.tot_rows, self.tot_cols), dtype=np.int16)
         self.x_edge_mask = np.zeros((self.tot_rows, self.tot_cols), dtype=bool)
+        # not in the reference: the undersides of the two overhanging obstacles (tunnel roof, upper arc of the tyre) on the same
+        # grid, for this build's physics (QA_T_CEILING_SAMPLES) -- the reference collides with the obstacle meshes instead
+        self.ceiling_raw = np.full((self.tot_rows, self.tot_cols), NO_CEILING, dtype=np.int16)
 
         xx, yy = np.meshgrid(np.arange(self.num_rows), np.arange(self.num_cols))
         self.spacing_x, self.spacing_y, self.env_boarder = cfg.env_length, cfg.env_width, cfg.env_boarder
@@ -116,8 +121,9 @@ class Obstacle:
         self._create_obstacle(list(range(num_envs)))
 
     # ------------------------------------------------------------------ shapes (obstacle.py:235-517), as data
-    def _shape(self, kind, centre, joint_pos):
-        """-> _Tile with obstacle `kind` drawn axis-aligned around `centre` (metres, tile frame)"""
+    def _shape(self, kind, centre, joint_pos, true_joint=None):
+        """-> _Tile with obstacle `kind` drawn axis-aligned around `centre` (metres, tile frame).  `true_joint`: the joint
+        position without the below-ground marking offset (the ceiling field is not marked)"""
         hs, vs = self.horizontal_scale, self.vertical_scale
         t = _Tile((self.length_per_env_pixels, self.width_per_env_pixels))
         px, py = int(centre[0] / hs), int(centre[1] / hs)
@@ -172,6 +178,8 @@ class Obstacle:
             xs = np.arange(int(px - l1 / 2), int(px + l1 / 2) + 1)
             ys = np.arange(int(py - rad), int(py + rad) + 1)
             t.h[xs[0]:xs[-1] + 1, ys[0]:ys[-1] + 1] = np.tile(self.get_circle_height(ys - ys[0]) * ratio + h1, (len(xs), 1))
+            # the tyre is a ring: the map above is its LOWER inner arc (hole bottom at joint - r), this is the upper one
+            t.ceil[xs[0]:xs[-1] + 1, ys[0]:ys[-1] + 1] = np.tile(-self.get_circle_height(ys - ys[0]) * ratio + int((joint_pos if true_joint is None else true_joint) / vs), (len(xs), 1))
             t.h[int(px - l2 / 2):int(px + l2 / 2) + 1, int(py - width / 2):int(py - rad) + 1] = h2
             t.h[int(px - l2 / 2):int(px + l2 / 2) + 1, int(py + rad):int(py + width / 2) + 1] = h2
             t.rects += [_corners(int(px - l1 / 2), int(py - rad), l1, 2 * rad),
@@ -185,6 +193,8 @@ class Obstacle:
             xs = np.arange(px, int(px + length) + 1)
             ys = np.arange(int(py - rad), int(py + rad) + 1)
             t.h[xs[0]:xs[-1] + 1, ys[0]:ys[-1] + 1] = np.tile((self.get_circle_height(ys - ys[0]) + rad) * ratio, (len(xs), 1))
+            # the tunnel is a pipe of inner radius `rad`: the map above is its floor (lower half), this is the roof (upper half)
+            t.ceil[xs[0]:xs[-1] + 1, ys[0]:ys[-1] + 1] = np.tile((-self.get_circle_height(ys - ys[0]) + rad) * ratio, (len(xs), 1))
             t.rects.append(_corners(px, int(py - rad), length, 2 * rad))
             X, Y = px * hs, py * hs
             g[:] = [[X - 1.0, Y, zb], [X - 0.5, Y, zb], [X + length * hs / 2, Y, zb], [X + length * hs + 0.5, Y, zb]]
@@ -204,8 +214,8 @@ class Obstacle:
         mapped, filled as a polygon, and each covered pixel takes the value of the source pixel it came from"""
         rot = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
         shape = t.h.shape
-        out_h, out_e = np.zeros_like(t.h), np.zeros_like(t.edge)
-        for rects, src, dst in ((t.rects, t.h, out_h), (t.edge_rects, t.edge, out_e)):
+        out_h, out_e, out_c = np.zeros_like(t.h), np.zeros_like(t.edge), np.full_like(t.ceil, NO_CEILING)
+        for rects, src, dst in ((t.rects, t.h, out_h), (t.edge_rects, t.edge, out_e), (t.rects, t.ceil, out_c)):
             # the reference writes the moved corners back into the corner array itself: where that array holds integers
             # (every shape but the tyre, whose side plates have a fractional width) the corners are truncated towards zero
             integral = len(rects) > 0 and np.issubdtype(np.array(rects).dtype, np.integer)
@@ -217,7 +227,7 @@ class Obstacle:
                 r0 = np.clip(np.round((rr - target[0]) * np.cos(yaw) + (cc - target[1]) * np.sin(yaw) + pivot[0]).astype(int), 0, shape[0] - 1)
                 c0 = np.clip(np.round((cc - target[1]) * np.cos(yaw) - (rr - target[0]) * np.sin(yaw) + pivot[1]).astype(int), 0, shape[1] - 1)
                 dst[rr, cc] = src[r0, c0]
-        return out_h, out_e, rot
+        return out_h, out_e, rot, out_c
 
     def add_border(self, mat):
         hs = self.horizontal_scale
@@ -236,6 +246,7 @@ class Obstacle:
             order = list(self.obst_types)
             self._py.shuffle(order)
             tile_h = np.zeros(shape, dtype=np.int16)
+            tile_c = np.full(shape, NO_CEILING, dtype=np.int16)
             tile_e = np.zeros(shape, dtype=np.int16)
             tile_goals = np.zeros((self.num_obst_per_env, self.num_goals, 3))
             for j, kind in enumerate(order):
@@ -256,9 +267,9 @@ class Obstacle:
                     pos_z, joint = 0.26, self.seesaw_dof_pos
                 pos = pos + bias
                 centre = centre + bias
-                t = self._shape(kind, centre, joint)
+                t = self._shape(kind, centre, joint, true_joint=joint - (self.tire_jump_joint_bias if kind == "tire_jump" else 0))
                 pivot, target = (centre - bias) / hs, (pos - bias) / hs
-                new_h, new_e, rot = self._place(t, pivot, target, yaw)
+                new_h, new_e, rot, new_c = self._place(t, pivot, target, yaw)
                 for m in range(self.num_goals):
                     t.goals[m, :2] = rot @ (t.goals[m, :2] - pivot * hs) + target * hs
                 self.obstacle_types[i, j] = idx
@@ -271,9 +282,10 @@ class Obstacle:
                 self.obstacle_joint_pos[i, j] = joint
                 self.add_border(new_h)
                 tile_h |= new_h
+                tile_c = np.minimum(tile_c, new_c)
                 tile_e |= new_e.astype(np.int16)
                 tile_goals[j] = t.goals
-            self.add_terrain_to_map(tile_h, tile_e, tile_goals, i)
+            self.add_terrain_to_map(tile_h, tile_e, tile_goals, i, tile_c)
         # the movable parts were drawn 1 m (bar) / 10 m (tyre) below ground so that they can be told apart in the map
         vs = self.vertical_scale
         self.bar_jump_mask = (self.height_field_raw > int(-5 / vs)) & (self.height_field_raw < 0)
@@ -285,7 +297,7 @@ class Obstacle:
         self.env_goals[self.bar_jump_goal_mask] -= self.bar_jump_joint_bias
         self.env_goals[self.tire_jump_goal_mask] -= self.tire_jump_joint_bias
 
-    def add_terrain_to_map(self, tile_h, tile_e, tile_goals, i):
+    def add_terrain_to_map(self, tile_h, tile_e, tile_goals, i, tile_c=None):
         hs = self.horizontal_scale
         sx = int(self.border + self.env_origins[i, 0] / hs)
         sy = int(self.border + self.env_origins[i, 1] / hs)
@@ -293,6 +305,8 @@ class Obstacle:
         ey = int(self.border + self.env_origins[i, 1] / hs + self.width_per_env_pixels)
         self.height_field_raw[sx:ex, sy:ey] = tile_h
         self.x_edge_mask[sx:ex, sy:ey] = tile_e
+        if tile_c is not None:
+            self.ceiling_raw[sx:ex, sy:ey] = tile_c
         self.env_goals[i] = tile_goals + np.array([self.env_origins[i, 0], self.env_origins[i, 1], 0])
 
     # ------------------------------------------------------------------ what the env turns the arrays into

@@ -370,6 +370,44 @@ def test_single_step_parity_on_height_field(n_envs, seed):
     assert flips <= 0.01 * steps * n_envs                            # measured 0.5 %: triangle / cell switches add discrete events
 
 
+def test_single_step_parity_under_a_ceiling():
+    """overhang contacts (QA_T_CEILING_SAMPLES): rough floor, a roof 0.42 m above the local floor over most of the map; large
+    random actions throw trunks, hips and thighs into it.  Same per-step parity bar as the open field, and the roof must really
+    have been hit (downward contact forces) on both sides"""
+    n_envs, seed = 256, 5
+    q, o, h = make_terrain_pair(n_envs, seed, hf_ceiling=1)
+    hs = o.t["HEIGHT_SAMPLES"].astype(np.int32)
+    pad = np.pad(hs, 3, mode="edge")
+    local = np.max([pad[i:i + hs.shape[0], j:j + hs.shape[1]] for i in range(7) for j in range(7)], axis=0)
+    ceil = (local + 84).astype(np.int16)                           # 0.42 m over the highest floor sample within 0.3 m
+    ceil[:, ::37] = 32767; ceil[::41, :] = 32767                   # gaps: triangles with a missing corner do not exist
+    o.t["CEILING_SAMPLES"][...] = ceil
+    rng = np.random.default_rng(seed + 100)
+    o.reset_all()
+    o.t["EPISODE_LENGTH"][:] = rng.integers(0, 1000, n_envs)
+    flips = gross = 0; steps = 40; down_o = down_h = 0
+    tol = dict(TOL); tol["SCAN_HEIGHT"] = (0, 0)
+    for k in range(steps):
+        o.t["ROOT_STATES"][::3, 9] += 1.5                           # every third robot is thrown upwards each step
+        push_arena(o, h)
+        act = rng.normal(0, 2.0, (n_envs, 12)).astype(np.float32)
+        o.step(act); h.step(torch.from_numpy(act).cuda()); torch.cuda.synchronize()
+        bad_env = np.zeros(n_envs, bool)
+        for name in tol:
+            got = h.t[name].cpu().numpy(); exp = o.t[name]
+            bad_env |= (got != exp).reshape(n_envs, -1).any(1) if name == "SCAN_HEIGHT" else env_mismatch(name, got, exp, n_envs)
+        flips += int(bad_env.sum())
+        r_h, r_o = h.t["ROOT_STATES"].cpu().numpy().astype(np.float64), o.t["ROOT_STATES"].astype(np.float64)
+        gross += int((np.abs(r_h - r_o) > 10 * (3e-4 + 1e-4 * np.abs(r_o))).any(1).sum())
+        down_o += int((o.t["CONTACT_FORCES"][:, :, 2] < -1.0).sum()); down_h += int((h.t["CONTACT_FORCES"].cpu().numpy()[:, :, 2] < -1.0).sum())
+    print(f"env-steps outside tolerance under a ceiling: {flips} of {steps * n_envs} ({gross} by more than 10x); downward contact forces oracle {down_o} hip {down_h}")
+    assert down_o > 50 and abs(down_h - down_o) <= 0.1 * down_o
+    # a robot squeezed between floor and roof carries 3-7 contacts and forces of 100-300 N through 4 PGS sweeps: fp32 vs fp64
+    # round-off shows as ~7e-4 rad/s on angular velocities of several rad/s (measured: 2.6 % of env-steps outside the open-field
+    # tolerance, 0.2 % by more than 10x; the same loop without the roof: 0.3 %)
+    assert flips <= 0.04 * steps * n_envs and gross <= 0.005 * steps * n_envs
+
+
 def test_height_field_trajectory_and_contact_forces():
     """free-running on the rough field: robots stay on the surface, feet forces carry the weight, bulk stays close"""
     n = 256

@@ -363,3 +363,50 @@ def test_every_body_of_a_leg_can_report_contact():
     assert most >= 2
     assert np.isfinite(s.t["ROOT_STATES"]).all() and s.t["ROOT_STATES"][0, 2] > 0.02
     assert s.t["CONTACT_FORCES"][0, :, 2].sum() == pytest.approx(MASS * G, rel=0.15)      # at rest the contacts carry the weight
+
+
+def _ceiling_sim(make=OracleSim, height=0.45):
+    """flat height-field floor; env 0 stands under an overhang `height` m above it, env 1 under open sky"""
+    rows, cols = 160, 160
+    qc = go2_cfg(2, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, push_robots=0, add_noise=0)
+    qc.terrain_type = 1; qc.hf_ceiling = 1
+    qc.hf_rows, qc.hf_cols, qc.hf_hscale, qc.hf_vscale, qc.hf_border = rows, cols, 0.05, 0.005, 1.0
+    s = make(qc)
+    ceil = np.full((rows, cols), 32767, np.int16); ceil[:80] = int(round(height / 0.005))        # x < 3 m (map) is roofed
+    return s, ceil
+
+
+def test_a_ceiling_stops_a_robot_thrown_upwards():
+    """overhang contacts (QA_T_CEILING_SAMPLES; the course's tunnel roof and the tyre's upper arc): a robot launched upwards at
+    2.5 m/s flies to ~0.6 m under open sky, and is stopped by a 0.45 m roof -- the base reports a DOWNWARD contact force"""
+    s, ceil = _ceiling_sim()
+    assert (s.t["CEILING_SAMPLES"] == 32767).all()                  # qa_create's default: no overhang anywhere
+    s.t["CEILING_SAMPLES"][...] = ceil
+    s.t["ENV_ORIGINS"][:, 0] = [1.0, 5.0]; s.t["ENV_ORIGINS"][:, 1] = 3.0
+    s.reset_all()
+    s.t["ROOT_STATES"][:, 7:13] = 0; s.t["ROOT_STATES"][:, 9] = 2.5
+    tau = np.zeros((2, 12), np.float32)
+    top, fz = np.zeros(2), np.zeros(2)
+    for _ in range(120):
+        s.simulate(tau)
+        top = np.maximum(top, s.t["ROOT_STATES"][:, 2]); fz = np.minimum(fz, s.t["CONTACT_FORCES"][:, 0, 2])
+    assert top[1] > 0.55 and fz[1] == 0.0
+    assert top[0] < 0.43 and fz[0] < -20.0                            # the trunk (5.7 cm half height) stays under the roof
+    assert np.isfinite(s.t["ROOT_STATES"]).all()
+
+
+def test_a_point_well_above_an_overhang_does_not_feel_it():
+    """thin-shell rule (QA_CEILING_SHELL): the underside of an overhang does not act on a body more than 5 cm above it -- robots
+    standing on a 1 m platform whose ceiling field (wrongly) says 0.45 m step exactly as they do with an empty field"""
+    out = []
+    for with_field in (True, False):
+        s, ceil = _ceiling_sim()
+        s.t["HEIGHT_SAMPLES"][...] = 200                               # 1 m platform everywhere
+        s.t["ENV_ORIGINS"][:, 0] = [1.0, 5.0]; s.t["ENV_ORIGINS"][:, 1] = 3.0; s.t["ENV_ORIGINS"][:, 2] = 1.0
+        if with_field:
+            s.t["CEILING_SAMPLES"][...] = ceil
+        s.reset_all()
+        for _ in range(25):
+            s.step(np.zeros((2, 12), np.float32))
+        out.append(s.t["ROOT_STATES"].copy())
+    assert np.array_equal(out[0], out[1]) and out[0][0, 2] > 1.2

@@ -25,8 +25,18 @@ def ref():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     sys.dont_write_bytecode = True
     from gen_golden import import_reference
+    # an earlier test may have installed this package's `legged_gym` / `rsl_rl` aliases (install_reference_aliases): the
+    # REFERENCE's modules must be the ones imported here; the aliases come back when this module is done
+    mine = lambda k: k.split(".")[0] in ("legged_gym", "rsl_rl")
+    saved = {k: sys.modules.pop(k) for k in [k for k in sys.modules if mine(k)]}
+    path = list(sys.path)
     ref_lr, RefCfg, _ = import_reference()
-    return ref_lr, RefCfg
+    assert ref_lr.__file__.startswith(REF), ref_lr.__file__
+    yield ref_lr, RefCfg
+    for k in [k for k in sys.modules if mine(k)]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+    sys.path[:] = path
 
 
 def build_reference_env(ref_lr, RefCfg, n, seed=3):

@@ -93,6 +93,33 @@ def test_course_is_the_collision_terrain():
     assert (h > 0.333 * 0.5 + 0.1).all(), h                         # apex height 0.333 m: the base rests well above the ground plane
 
 
+def test_tunnel_roof_and_tyre_ring_are_collision_geometry():
+    """overhangs: the course hands its ceiling field (tunnel roof, upper arc of the tyre) to the physics; a robot thrown upwards
+    inside the tunnel is held under the roof (the pipe's inner radius is 0.4 m: the roof peaks 0.8 m over the floor line)"""
+    from quadrupedal_agility_amd.tsc.legged_gym.utils.obstacle import NO_CEILING
+    env = cpu_env(4, seed=5)
+    ob = env.obstacle
+    assert env.qcfg.hf_ceiling == 1
+    cs = env.sim.t["CEILING_SAMPLES"].numpy()
+    assert np.array_equal(cs, ob.ceiling_raw) and (cs != NO_CEILING).sum() > 500
+    roofed = cs != NO_CEILING
+    assert (cs[roofed].astype(int) >= ob.height_field_raw[roofed]).mean() > 0.95       # the roof lies over the floor it belongs to
+    tops = np.zeros(4)
+    for e in range(4):
+        j = int(np.nonzero(ob.obstacle_types[e] == 5)[0][0])      # the tunnel of this env
+        mid = ob.env_goals[e, j, 2]                                # its third goal lies inside the pipe
+        env.root_states[e, 0], env.root_states[e, 1], env.root_states[e, 2] = float(mid[0]), float(mid[1]), 0.35
+        env.root_states[e, 7:13] = 0; env.root_states[e, 9] = 4.0
+        ix, iy = int((mid[0] + 5.0) / 0.05), int((mid[1] + 5.0) / 0.05)
+        assert cs[ix, iy] != NO_CEILING, (e, mid)
+        tops[e] = cs[ix, iy] * 0.005
+    peak = torch.zeros(4)
+    for _ in range(30):
+        env.sim.physics_step(torch.zeros(4, 12), 0)
+        peak = torch.maximum(peak, env.root_states[:, 2])
+    assert (peak.numpy() < tops).all() and (peak > 0.5).all(), (peak, tops)          # free flight would reach 0.35 + 4^2 / (2 g) = 1.16 m
+
+
 def test_reset_matches_reference_formulas():
     """qo_tsc_reset against the reference's _reset_root_states / quat_from_euler_xyz expressions for the same uniforms"""
     env = cpu_env(32, seed=7, obstacle__randomize_start=True)
