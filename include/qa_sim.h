@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 8
+#define QA_ABI_VERSION 9
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -613,6 +613,50 @@ typedef struct qa_tsc_obs_io {
     float *obs_buf, *obs_bbc_buf, *obs_disc_buf;        /* (N,800), (N,671), (N,49) */
 } qa_tsc_obs_io;
 int qa_tsc_observations(const qa_tsc_obs_cfg *cfg, const qa_tsc_obs_io *io, void *stream);
+
+/* qa_tsc_depth_update  =  the depth camera of the vision student: update_depth_buffer + process_depth_image
+ * (tsc/legged_gym/envs/base/legged_robot.py:154-200) with the camera of attach_camera (:1203-1226) and the `depth` block of
+ * legged_robot_config.py:63-84.  The reference rasterises the scene with Isaac Gym's camera sensor (106 x 60 depth image, 87 deg
+ * horizontal FOV, camera at `position` on the trunk, pitched down by U(angle) degrees per env), then per env: crop [1:-1, 10:-9]
+ * -> 58 x 87, clip to [near, far], normalise to (d - near) / (far - near) - 0.5, add noise, and push the image into a
+ * `buffer_len`-deep ring (all slots = the image where episode_length <= 1).  This entry ray-casts the same image against what this
+ * engine collides with: the course's height field and its ceiling field (QA_T_HEIGHT_SAMPLES / QA_T_CEILING_SAMPLES layouts).
+ *   pixel (r, c) of the FULL image -> camera-frame ray (1, -((c + .5) / W * 2 - 1) tan(hfov / 2), -((r + .5) / H * 2 - 1) tan(hfov / 2) H / W);
+ *   camera frame = trunk frame * R_y(pitch) at trunk position + R_trunk * position; depth = the ray parameter (distance along the
+ *   optical axis, what a depth image stores);
+ *   march: steps of dt = 0.5 hscale / max(|d_xy|, 0.5) up to `far`; the floor is hit where z - floor(x, y) turns negative, a ceiling
+ *   where z - ceiling(x, y) changes sign between two samples that both have one (thin shell, seen from either side); the
+ *   bracket is halved QA_TSC_DEPTH_BISECT times (a vertical face is a one-cell ramp in a height field: without this a wall reads up
+ *   to one march step near) and the hit placed by linear interpolation inside it; no hit = far.
+ *   noise (process_depth_image :166-168): image += depth_noise * 2 (u1 - .5) + (depth_noise u0) * 2 (u_px - .5), Philox stream 64
+ *   keyed by (seed; env_id_offset + env, step): block 0 = (u0, u1), pixel p = component p & 3 of block 1 + (p >> 2).
+ * Only the cropped pixels are cast.  One thread per pixel; all pointers are device pointers. */
+#define QA_TSC_DEPTH_STREAM 64
+#define QA_TSC_DEPTH_BISECT 4
+typedef struct qa_tsc_depth_cfg {
+    int64_t num_envs;
+    int64_t step;                        /* RNG key: the env's global step counter */
+    uint64_t seed;
+    int32_t env_id_offset;
+    int32_t width, height;               /* depth.original = (106, 60) */
+    int32_t crop_top, crop_bottom, crop_left, crop_right;   /* 1, 1, 10, 9 -> (height - 2) x (width - 19) = 58 x 87 */
+    int32_t buffer_len;                  /* depth.buffer_len = 2 */
+    int32_t map_rows, map_cols;
+    int32_t reserved;
+    float horizontal_fov_deg;            /* 87 */
+    float position[3];                   /* camera position in the trunk frame */
+    float near_clip, far_clip, depth_noise;
+    float border_size, horizontal_scale, vertical_scale;
+} qa_tsc_depth_cfg;
+typedef struct qa_tsc_depth_io {
+    const float *root_states;            /* (N,13) */
+    const float *camera_pitch;           /* (N) radians, positive = down */
+    const int16_t *height_samples;       /* (map_rows,map_cols) */
+    const int16_t *ceiling_samples;      /* same grid, QA_NO_CEILING where none; NULL = no overhangs */
+    const int64_t *episode_length;       /* (N) */
+    float *depth_buffer;                 /* in/out (N, buffer_len, height - crop_top - crop_bottom, width - crop_left - crop_right) */
+} qa_tsc_depth_io;
+int qa_tsc_depth_update(const qa_tsc_depth_cfg *cfg, const qa_tsc_depth_io *io, void *stream);
 
 const char *qa_last_error(void);
 int qa_abi_version(void);

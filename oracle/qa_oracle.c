@@ -1980,3 +1980,101 @@ int qo_tsc_observations(const qa_tsc_obs_cfg *c, const qa_tsc_obs_io *io, void *
     }
     return QA_OK;
 }
+
+/* CPU twin of qa_tsc_depth_update (include/qa_sim.h): the vision student's depth camera, ray-cast against the course's height field
+ * and ceiling field; update_depth_buffer + process_depth_image (tsc/legged_gym/envs/base/legged_robot.py:154-200), camera of
+ * attach_camera (:1203-1226).  PARITY UNPINNED against the reference's images: those come out of Isaac Gym's rasteriser (absent
+ * here) looking at obstacle meshes; this restates the camera model, the crop / clip / normalise / noise / ring arithmetic, and is
+ * pinned by analytic scenes (tests/test_tsc_depth.py). */
+static double depth_surface(const int16_t *m, int rows, int cols, double border, double hs, double vs, double x, double y, int *exists) {
+    double fx = (x + border) / hs, fy = (y + border) / hs;
+    int ix = (int)floor(fx), iy = (int)floor(fy);
+    if (ix < 0) ix = 0; if (ix > rows - 2) ix = rows - 2;
+    if (iy < 0) iy = 0; if (iy > cols - 2) iy = cols - 2;
+    double u = fx - ix, v = fy - iy;
+    if (u < 0) u = 0; if (u > 1) u = 1; if (v < 0) v = 0; if (v > 1) v = 1;
+    int16_t s00 = m[(int64_t)ix * cols + iy], s10 = m[(int64_t)(ix + 1) * cols + iy], s01 = m[(int64_t)ix * cols + iy + 1], s11 = m[(int64_t)(ix + 1) * cols + iy + 1];
+    double h00 = vs * s00, h10 = vs * s10, h01 = vs * s01, h11 = vs * s11;
+    if (u >= v) { if (exists) *exists = s00 != QA_NO_CEILING && s10 != QA_NO_CEILING && s11 != QA_NO_CEILING; return h00 + u * (h10 - h00) + v * (h11 - h10); }
+    if (exists) *exists = s00 != QA_NO_CEILING && s01 != QA_NO_CEILING && s11 != QA_NO_CEILING;
+    return h00 + v * (h01 - h00) + u * (h11 - h01);
+}
+int qo_tsc_depth_update(const qa_tsc_depth_cfg *c, const qa_tsc_depth_io *io, void *stream) {
+    (void)stream;
+    if (!c || !io || !io->root_states || !io->camera_pitch || !io->height_samples || !io->episode_length || !io->depth_buffer) return QA_E_ARG;
+    const int Wc = c->width - c->crop_left - c->crop_right, Hc = c->height - c->crop_top - c->crop_bottom;
+    if (c->num_envs <= 0 || Wc <= 0 || Hc <= 0 || c->buffer_len < 1 || c->map_rows < 2 || c->map_cols < 2 || !(c->horizontal_scale > 0) ||
+        !(c->far_clip > c->near_clip) || !(c->horizontal_fov_deg > 0 && c->horizontal_fov_deg < 180)) return QA_E_ARG;
+    const double tan_h = tan(c->horizontal_fov_deg * 3.14159265358979323846 / 360.0), tan_v = tan_h * c->height / c->width;
+    const double hs = c->horizontal_scale, vs = c->vertical_scale, far = c->far_clip, near = c->near_clip;
+    const int64_t npix = (int64_t)Hc * Wc;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t e = 0; e < c->num_envs; ++e) {
+        const float *rs = io->root_states + e * 13;
+        double qx = rs[3], qy = rs[4], qz = rs[5], qw = rs[6];
+        double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                       2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                       2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+        double a = io->camera_pitch[e], ca = cos(a), sa = sin(a);
+        double o[3];
+        for (int i = 0; i < 3; ++i) o[i] = rs[i] + R[3 * i] * c->position[0] + R[3 * i + 1] * c->position[1] + R[3 * i + 2] * c->position[2];
+        uint32_t r0[4];
+        philox(c->seed, (uint32_t)(e + c->env_id_offset), (uint32_t)c->step, (uint32_t)(QA_TSC_DEPTH_STREAM * 256), (uint32_t)((uint64_t)c->step >> 32), r0);
+        const float amp = c->depth_noise * ((float)(r0[0] >> 8) * (1.0f / 16777216.0f));
+        const float offs = c->depth_noise * 2.0f * ((float)(r0[1] >> 8) * (1.0f / 16777216.0f) - 0.5f);
+        float *buf = io->depth_buffer + e * c->buffer_len * npix;
+        const int init = io->episode_length[e] <= 1;
+        for (int64_t p = 0; p < npix; ++p) {
+            int i = (int)(p / Wc), j = (int)(p % Wc);
+            double sx = ((j + c->crop_left + 0.5) / c->width * 2.0 - 1.0) * tan_h, sy = ((i + c->crop_top + 0.5) / c->height * 2.0 - 1.0) * tan_v;
+            double dt3[3] = {ca - sy * sa, -sx, -sa - sy * ca}, d[3];       /* fwd - sx left - sy up in the trunk frame */
+            for (int k = 0; k < 3; ++k) d[k] = R[3 * k] * dt3[0] + R[3 * k + 1] * dt3[1] + R[3 * k + 2] * dt3[2];
+            double dxy = sqrt(d[0] * d[0] + d[1] * d[1]), dt = 0.5 * hs / (dxy > 0.5 ? dxy : 0.5);
+            int nsteps = (int)ceil(far / dt);
+            double t_prev = 0.0, hit = far;
+            int ex_prev = 0, ex = 0;
+            double g_prev = o[2] - depth_surface(io->height_samples, c->map_rows, c->map_cols, c->border_size, hs, vs, o[0], o[1], NULL);
+            double h_prev = io->ceiling_samples ? o[2] - depth_surface(io->ceiling_samples, c->map_rows, c->map_cols, c->border_size, hs, vs, o[0], o[1], &ex_prev) : 0.0;
+            if (g_prev < 0) hit = 0.0;
+            else for (int k = 1; k <= nsteps; ++k) {
+                double t = k * dt; if (t > far) t = far;
+                double x = o[0] + t * d[0], y = o[1] + t * d[1], z = o[2] + t * d[2];
+                double g = z - depth_surface(io->height_samples, c->map_rows, c->map_cols, c->border_size, hs, vs, x, y, NULL), h = 0.0;
+                double best = 1e30;
+                if (g < 0) {                       /* the floor was crossed in (t_prev, t]: QA_TSC_DEPTH_BISECT halvings, then linear interpolation */
+                    double lo = t_prev, hi = t, flo = g_prev, fhi = g;
+                    for (int b = 0; b < QA_TSC_DEPTH_BISECT; ++b) {
+                        double tm = 0.5 * (lo + hi);
+                        double fm = o[2] + tm * d[2] - depth_surface(io->height_samples, c->map_rows, c->map_cols, c->border_size, hs, vs, o[0] + tm * d[0], o[1] + tm * d[1], NULL);
+                        if (fm < 0) { hi = tm; fhi = fm; } else { lo = tm; flo = fm; }
+                    }
+                    best = lo + (hi - lo) * flo / (flo - fhi);
+                }
+                if (io->ceiling_samples) {
+                    h = z - depth_surface(io->ceiling_samples, c->map_rows, c->map_cols, c->border_size, hs, vs, x, y, &ex);
+                    if (ex && ex_prev && ((h_prev < 0) != (h < 0))) {
+                        double lo = t_prev, hi = t, flo = h_prev, fhi = h;
+                        for (int b = 0; b < QA_TSC_DEPTH_BISECT; ++b) {
+                            double tm = 0.5 * (lo + hi); int exm;
+                            double fm = o[2] + tm * d[2] - depth_surface(io->ceiling_samples, c->map_rows, c->map_cols, c->border_size, hs, vs, o[0] + tm * d[0], o[1] + tm * d[1], &exm);
+                            if (!exm) break;                            /* a hole in the shell inside the bracket: keep the bracket */
+                            if ((fm < 0) == (flo < 0)) { lo = tm; flo = fm; } else { hi = tm; fhi = fm; }
+                        }
+                        double tc = lo + (hi - lo) * flo / (flo - fhi);
+                        if (tc < best) best = tc;
+                    }
+                }
+                if (best < 1e29) { hit = best; break; }
+                t_prev = t; g_prev = g; h_prev = h; ex_prev = ex;
+            }
+            double dd = hit < near ? near : (hit > far ? far : hit);
+            float v = (float)((dd - near) / (far - near) - 0.5);
+            uint32_t rp[4];
+            philox(c->seed, (uint32_t)(e + c->env_id_offset), (uint32_t)c->step, (uint32_t)(QA_TSC_DEPTH_STREAM * 256 + 1 + (p >> 2)), (uint32_t)((uint64_t)c->step >> 32), rp);
+            v += offs + amp * 2.0f * ((float)(rp[p & 3] >> 8) * (1.0f / 16777216.0f) - 0.5f);
+            if (init) for (int s = 0; s < c->buffer_len; ++s) buf[s * npix + p] = v;
+            else { for (int s = 0; s + 1 < c->buffer_len; ++s) buf[s * npix + p] = buf[(s + 1) * npix + p]; buf[(c->buffer_len - 1) * npix + p] = v; }
+        }
+    }
+    return QA_OK;
+}

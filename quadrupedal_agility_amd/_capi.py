@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 8
+QA_ABI_VERSION = 9
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -143,6 +143,7 @@ def bind(lib, prefix):
     f.restype = C.c_int
     f = getattr(lib, prefix + "tsc_goal_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "tsc_observations"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "tsc_depth_update"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_packed_floats"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "mlp_pack"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "mlp_forward")
@@ -216,9 +217,26 @@ class QaTscObsIo(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in TSC_OBS_IO_FIELDS]
 
 
+class QaTscDepthCfg(C.Structure):
+    """qa_tsc_depth_cfg of include/qa_sim.h"""
+    _fields_ = [("num_envs", C.c_int64), ("step", C.c_int64), ("seed", C.c_uint64), ("env_id_offset", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("crop_top", C.c_int32), ("crop_bottom", C.c_int32), ("crop_left", C.c_int32), ("crop_right", C.c_int32),
+                ("buffer_len", C.c_int32), ("map_rows", C.c_int32), ("map_cols", C.c_int32), ("reserved", C.c_int32),
+                ("horizontal_fov_deg", C.c_float), ("position", C.c_float * 3), ("near_clip", C.c_float), ("far_clip", C.c_float),
+                ("depth_noise", C.c_float), ("border_size", C.c_float), ("horizontal_scale", C.c_float), ("vertical_scale", C.c_float)]
+
+
+TSC_DEPTH_IO_FIELDS = ("root_states", "camera_pitch", "height_samples", "ceiling_samples", "episode_length", "depth_buffer")
+
+
+class QaTscDepthIo(C.Structure):
+    """qa_tsc_depth_io of include/qa_sim.h (every member is a pointer)"""
+    _fields_ = [(name, C.c_void_p) for name in TSC_DEPTH_IO_FIELDS]
+
+
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

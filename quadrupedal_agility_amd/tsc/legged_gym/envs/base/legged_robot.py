@@ -70,8 +70,6 @@ def make_qa_config(cfg, obstacle, seed=1):
 class LeggedRobot:
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, backend=None, bookkeeping_lib=None):
         self.cfg, self.sim_params, self.physics_engine, self.headless = cfg, sim_params, physics_engine, headless
-        if cfg.depth.use_camera:
-            raise NotImplementedError("the depth student (use_camera) is not built (SURVEY.md 8f row 3)")
         if cfg.terrain.mesh_type != "obstacle":
             raise NotImplementedError("the task-level env runs on the obstacle course (terrain.mesh_type 'obstacle')")
         self.mocap_category = cfg.env.mocap_category_all
@@ -145,6 +143,14 @@ class LeggedRobot:
         self.bk.init_observations(self.height_samples, self.height_points, self.default_dof_pos, self.default_dof_pos_all, self.key_body_ids.tolist())
         self.reward_scales = dict(self.bk.reward_scales)
         self.episode_sums = self.bk.episode_sums
+        if cfg.depth.use_camera:
+            # attach_camera (:1203-1226): one camera per env on the trunk, pitched down by U(depth.angle) degrees; the draw is keyed
+            # by the GLOBAL env id like every other per-env constant, so a sharded job has the cameras of the one-process job
+            lo, hi = cfg.depth.angle
+            n_glob, off = int(self.qcfg.num_envs_global) or self.num_envs, int(self.qcfg.env_id_offset)
+            ang = np.random.default_rng([seed, 0xCA3E]).uniform(lo, hi, n_glob)[off:off + self.num_envs]
+            self.bk.init_depth(self.height_samples, torch.as_tensor(self.obstacle.ceiling_raw, dtype=torch.int16),
+                               torch.as_tensor(np.radians(ang), dtype=torch.float32), seed=seed, env_id_offset=off)
         self.extras = {}
         self.global_counter = self.total_env_steps_counter = self.common_step_counter = 0
         self.cur_obst_idx = torch.zeros(self.num_envs, dtype=torch.long, device=dev)
@@ -170,6 +176,10 @@ class LeggedRobot:
     @property
     def reset_buf(self):
         return self.bk.reset_buf
+
+    @property
+    def depth_buffer(self):
+        return self.bk.depth_buffer
 
     @property
     def privileged_obs_buf(self):
@@ -201,7 +211,10 @@ class LeggedRobot:
         self.sim.physics_step(a, delay)
         reset_env_ids, terminal = self.post_physics_step(action_hl_history_buf)
         self.extras["delta_yaw_ok"] = torch.abs(self.bk.delta_yaw) < 0.6
-        self.extras["depth"] = None
+        if self.cfg.depth.use_camera and self.global_counter % self.cfg.depth.update_interval == 0:
+            self.extras["depth"] = self.bk.depth_buffer[:, -2]            # :145-146
+        else:
+            self.extras["depth"] = None
         return self.bk.obs_buf, self.privileged_obs_buf, self.bk.rew_buf, self.bk.reset_buf, self.extras, reset_env_ids, terminal
 
     def post_physics_step(self, action_hl_history_buf):
@@ -216,6 +229,8 @@ class LeggedRobot:
         prev_disc = bk.obs_disc_buf.clone()                                  # get_observations_disc() of the envs about to reset (:263)
         self._reset(flags)
         upd = self.global_counter % cfg.depth.update_interval == 0
+        if cfg.depth.use_camera and upd:
+            bk.update_depth_buffer(self.root_states, self.common_step_counter)       # :275, after the resets, before the observations
         bk.compute_observations(self.root_states, self.dof_pos, self.dof_vel, self.action_history_buf, self.rigid_body_states,
                                 self.mass_params_tensor, self.friction_coeffs_tensor, self.motor_strength, update_yaw=upd)
         self._obs_disc_term.copy_(torch.where(flags.view(-1, 1) != 0, prev_disc, bk.obs_disc_buf))

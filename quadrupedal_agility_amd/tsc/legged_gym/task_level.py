@@ -199,6 +199,41 @@ class TaskLevelBookkeeping:
         self._check(self._fn("tsc_observations")(C.byref(self._ocfg), C.byref(io), self._stream()), "qa_tsc_observations")
         return self.obs_buf
 
+    def init_depth(self, height_samples, ceiling_samples, camera_pitch, seed=1, env_id_offset=0):
+        """The depth camera of attach_camera (:1203-1226) and the `depth` config block: one camera per env on the trunk, pitched
+        down by `camera_pitch` (N) radians; `depth_buffer` (N, buffer_len, 58, 87) is the reference's ring."""
+        d, dev, n = self.cfg.depth, self.device, self.num_envs
+        self._depth_maps = (height_samples.to(dev, torch.int16).contiguous(),
+                            ceiling_samples.to(dev, torch.int16).contiguous() if ceiling_samples is not None else None)
+        self.camera_pitch = camera_pitch.to(dev, torch.float32).contiguous()
+        c = self._dcfg = _capi.QaTscDepthCfg()
+        c.num_envs, c.seed, c.env_id_offset = n, int(seed), int(env_id_offset)
+        c.width, c.height = int(d.original[0]), int(d.original[1])
+        c.crop_top, c.crop_bottom, c.crop_left, c.crop_right = 1, 1, 10, 9            # crop_depth_image :170-172
+        c.buffer_len = int(d.buffer_len)
+        c.map_rows, c.map_cols = self._depth_maps[0].shape
+        c.horizontal_fov_deg = float(d.horizontal_fov)
+        for i in range(3):
+            c.position[i] = float(d.position[i])
+        c.near_clip, c.far_clip, c.depth_noise = float(d.near_clip), float(d.far_clip), float(d.depth_noise)
+        ob = self.cfg.obstacle
+        c.border_size, c.horizontal_scale, c.vertical_scale = ob.border_size, ob.horizontal_scale, ob.vertical_scale
+        hc, wc = c.height - c.crop_top - c.crop_bottom, c.width - c.crop_left - c.crop_right
+        if (wc, hc) != tuple(d.resized):
+            raise ValueError(f"depth.resized {tuple(d.resized)} is not the cropped image {(wc, hc)}")
+        self.depth_buffer = torch.zeros(n, c.buffer_len, hc, wc, dtype=torch.float32, device=dev)
+
+    def update_depth_buffer(self, root_states, step):
+        """update_depth_buffer + process_depth_image (:154-200) for all envs in one launch; `step` keys the noise draw"""
+        rs = root_states.to(self.device, torch.float32).contiguous()
+        io = _capi.QaTscDepthIo()
+        io.root_states, io.camera_pitch, io.height_samples = rs.data_ptr(), self.camera_pitch.data_ptr(), self._depth_maps[0].data_ptr()
+        io.ceiling_samples = self._depth_maps[1].data_ptr() if self._depth_maps[1] is not None else None
+        io.episode_length, io.depth_buffer = self.episode_length_buf.data_ptr(), self.depth_buffer.data_ptr()
+        self._dcfg.step = int(step)
+        self._check(self._fn("tsc_depth_update")(C.byref(self._dcfg), C.byref(io), self._stream()), "qa_tsc_depth_update")
+        return self.depth_buffer
+
     def get_observations(self):
         return self.obs_buf
 

@@ -1,8 +1,8 @@
 """Hybrid-action PPO of the task-level controller (tsc/rsl_rl/algorithms/ppo.py:8-313).
 
 Same constructor, attributes and call protocol as the reference (`act` / `act_bbc` / `process_env_step` /
-`compute_returns` / `update` / `update_dagger`), without the depth-camera distillation heads (`depth_encoder` must be
-None: SURVEY.md 8 out of scope, vision).  One policy step draws a gait index from a categorical head and a parameter
+`compute_returns` / `update` / `update_dagger` / `update_depth_actor`); the depth-camera distillation heads are optional as in
+the reference (`depth_encoder` None = teacher training only).  One policy step draws a gait index from a categorical head and a parameter
 vector for every gait from a Gaussian head; the surrogate is the SUM of two clipped PPO terms, one per head, sharing
 the advantage (:222-234).  The entropy bonus adds the categorical entropy to the MEAN (not sum) of the Gaussian one.
 
@@ -22,8 +22,6 @@ class PPO:
                  num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95, value_loss_coef=1.0,
                  entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="fixed",
                  desired_kl=0.01, device="cpu", dagger_update_freq=20, priv_reg_coef_schedual=[0, 0, 0], **kwargs):
-        if depth_encoder is not None:
-            raise NotImplementedError("depth-camera distillation is out of scope (SURVEY.md section 8)")
         self.device = device
         self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
@@ -44,7 +42,14 @@ class PPO:
         self.num_scan = estimator_paras["num_scan"]
         self.estimator_optimizer = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"])
         self.train_with_estimated_states = estimator_paras["train_with_estimated_states"]
-        self.if_depth = False
+        # depth encoder + student actor (:82-93): the student optimiser steps BOTH nets, BYOL has its own over the shared backbone
+        self.if_depth = depth_encoder is not None
+        if self.if_depth:
+            self.depth_encoder, self.depth_encoder_paras, self.depth_actor = depth_encoder, depth_encoder_paras, depth_actor
+            self.depth_encoder_optimizer = optim.Adam(self.depth_encoder.parameters(), lr=depth_encoder_paras["learning_rate"])
+            self.depth_actor_optimizer = optim.Adam([*self.depth_actor.parameters(), *self.depth_encoder.parameters()], lr=depth_encoder_paras["learning_rate"])
+            self.byol_optimizer = optim.Adam(self.depth_encoder.byol_learner.parameters(), lr=depth_encoder_paras["learning_rate_byol"])
+        self.CE_loss = nn.CrossEntropyLoss().to(device)
         self.num_actions_d = self.actor_critic.num_actions_d
         self._step_ac = ClipAdam(self.optimizer, max_grad_norm)
         self._step_estimator = ClipAdam(self.estimator_optimizer, max_grad_norm)
@@ -184,6 +189,41 @@ class PPO:
         self.storage.clear()
         self.update_counter()
         return (total / (self.num_learning_epochs * self.num_mini_batches)).item()
+
+    def update_depth_actor(self, actions_student_batch, actions_teacher_batch, yaw_student_batch, yaw_teacher_batch,
+                           obst_type_buffer_student, obst_type_buffer_teacher, depth_batch):
+        """DAgger step of the vision student (:327-358): cross-entropy on the gait head + L2 on the parameter head against the teacher's
+        action, L2 on the predicted goal headings (weights 2, 0.5), cross-entropy on the obstacle class; ONE Adam step over student
+        actor + depth encoder (only the actor's gradients are norm-clipped, as in the reference); then 6 BYOL minibatches over the
+        rollout's depth images with the EMA target update after each.  The four losses are read from the device once."""
+        if not self.if_depth:
+            return None
+        nd = self.num_actions_d
+        d_loss = self.CE_loss(actions_student_batch[:, :nd], actions_teacher_batch[:, 0].detach().to(torch.int64))
+        c_loss = (actions_teacher_batch[:, 1:].detach() - actions_student_batch[:, nd:]).norm(p=2, dim=1).mean()
+        depth_actor_loss = d_loss + c_loss
+        scale = torch.tensor([2.0, 0.5], device=yaw_teacher_batch.device)
+        yaw_loss = ((yaw_teacher_batch.detach() - yaw_student_batch) * scale).norm(p=2, dim=1).mean()
+        obst_type_loss = self.CE_loss(obst_type_buffer_student, torch.argmax(obst_type_buffer_teacher, dim=-1))
+        loss = depth_actor_loss + yaw_loss + obst_type_loss
+        self.depth_actor_optimizer.zero_grad()
+        loss.backward()
+        nn.utils.clip_grad_norm_(self.depth_actor.parameters(), self.max_grad_norm)
+        self.depth_actor_optimizer.step()
+
+        num_samples = depth_batch.size(0)
+        batch_size = num_samples // 6
+        depth_batch = depth_batch[torch.randperm(num_samples, device=depth_batch.device)]
+        byol_sum = torch.zeros((), device=depth_batch.device)
+        for i in range(0, num_samples, batch_size):
+            byol_loss = self.depth_encoder.byol_learner(depth_batch[i:i + batch_size])
+            self.byol_optimizer.zero_grad()
+            byol_loss.backward()
+            self.byol_optimizer.step()
+            byol_sum += byol_loss.detach()
+            self.depth_encoder.byol_learner.update_moving_average()
+        out = torch.stack([depth_actor_loss.detach(), yaw_loss.detach(), obst_type_loss.detach(), byol_sum / (num_samples // batch_size)])
+        return tuple(out.tolist())
 
     def update_counter(self):
         self.counter += 1

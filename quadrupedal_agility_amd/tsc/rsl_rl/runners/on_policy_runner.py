@@ -2,7 +2,9 @@
 the checkpoint layout (:443-520).  Per env step: task policy (hybrid action) -> `env.set_commands` -> command block of the
 behaviour row -> FROZEN behaviour policy (history-encoder variant, mean action) -> `env.step` -> frozen style discriminator's
 reward -> `alg.process_env_step`.  Same constructor and attributes as the reference (`alg`, `actor_critic_bbc`,
-`discriminator`, `learn`, `save` / `load` / `load_bbc`); the depth-student half (`learn_vision`) is not built.
+`discriminator`, `learn`, `save` / `load` / `load_bbc`).  With `depth_encoder.if_depth` the runner builds the vision student
+(depth encoder + a copy of the teacher's actor) and `learn` is `learn_vision` (:278-441): DAgger on the student's own rollouts,
+depth images from `env.extras["depth"]` (csrc/qa_depth.hip).
 
 MI355X: no host wait inside a rollout (`env.sync_reset_ids = False`: terminal discriminator rows come as a masked tensor,
 episode statistics stay on the device until the logger reads them); the frozen behaviour policy is ONE `qa_mlp_forward` launch
@@ -12,12 +14,14 @@ import os
 import statistics
 import time
 from collections import deque
+from copy import deepcopy
 
 import torch
 
 from quadrupedal_agility_amd.rsl_rl.utils.utils import Normalizer, TorchNormalizer
 from quadrupedal_agility_amd.tsc.rsl_rl.algorithms import PPO, Discriminator
 from quadrupedal_agility_amd.tsc.rsl_rl.modules import ActorCriticBBC, ActorCriticTSC, Estimator
+from quadrupedal_agility_amd.tsc.rsl_rl.modules.depth_backbone import DepthOnlyFCBackbone58x87, RecurrentDepthBackbone
 
 
 class OnPolicyRunner:
@@ -37,9 +41,8 @@ class OnPolicyRunner:
         self.num_disc_obs, self.disc_obs_len = e.num_obs_disc, e.disc_obs_len
         r = self.cfg
         self.disc_loss_function = r["disc_loss_function"]
-        if self.depth_encoder_cfg["if_depth"]:
-            raise NotImplementedError("the depth student (learn_vision) is not built (SURVEY.md 8f row 3)")
-        self.if_depth = False
+        self.if_depth = bool(self.depth_encoder_cfg["if_depth"])
+        self.n_depth_latent, self.n_delta_yaw = self.policy_cfg["scan_encoder_dims"][-1], e.n_delta_yaw
 
         self.actor_critic = ActorCriticTSC(self.n_proprio, self.n_auxiliary, self.n_scan, self.num_obs, self.n_priv_latent, self.n_priv,
                                            self.history_len, self.num_actions_d, self.num_actions_c, device=device, **self.policy_cfg).to(device)
@@ -48,8 +51,13 @@ class OnPolicyRunner:
         self.estimator = Estimator(input_dim=self.n_proprio - self.n_auxiliary, output_dim=self.n_priv,
                                    hidden_dims=self.estimator_cfg["hidden_dims"]).to(device)
         self.depth_encoder = self.depth_actor = None
-        self.alg = PPO(self.actor_critic, self.actor_critic_bbc, self.estimator, self.estimator_cfg, None, self.depth_encoder_cfg, None,
-                       device=device, **self.alg_cfg)
+        if self.if_depth:                        # :88-101
+            self.depth_backbone = DepthOnlyFCBackbone58x87(self.n_proprio, self.n_depth_latent, self.depth_encoder_cfg["hidden_dims"])
+            self.depth_encoder = RecurrentDepthBackbone(self.depth_backbone, self.n_depth_latent, env.cfg).to(device)
+            self.depth_actor = deepcopy(self.actor_critic.actor)
+            self.depth_backbone.augment = self.depth_encoder.byol_learner.augment1
+        self.alg = PPO(self.actor_critic, self.actor_critic_bbc, self.estimator, self.estimator_cfg, self.depth_encoder, self.depth_encoder_cfg,
+                       self.depth_actor, device=device, **self.alg_cfg)
         self.num_steps_per_env, self.save_interval = r["num_steps_per_env"], r["save_interval"]
         self.dagger_update_freq = self.alg_cfg["dagger_update_freq"]
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [self.num_actions])
@@ -59,7 +67,7 @@ class OnPolicyRunner:
                                            Normalizer(1) if self.disc_loss_function == "WassersteinLoss" else None, r["reward_i_coef"],
                                            r["reward_us_coef"], r["reward_ss_coef"], r["reward_t_coef"], self.disc_obs_len, r["disc_hidden_units"],
                                            norm, device).to(device)
-        self.learn = self.learn_RL
+        self.learn = self.learn_vision if self.if_depth else self.learn_RL
         self.log_dir, self.writer = log_dir, None
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0, 0
         self.last_perf = {}
@@ -157,6 +165,138 @@ class OnPolicyRunner:
         if logging:
             self.save(os.path.join(self.log_dir, "model.pt"))
 
+    def learn_vision(self, num_learning_iterations, init_at_random_ep_len=False):
+        """Distillation of the teacher into the depth student (:278-441).  Per env step: the depth encoder turns the previous depth
+        image + masked proprioception into [scan latent 32 | goal headings 2 | obstacle class 6]; the student actor acts on the
+        teacher's observation with its heading / class entries replaced by the encoder's predictions (headings only where the teacher's
+        |delta_yaw| < 0.6) and the scan latent replaced by the depth latent; the STUDENT's action drives the env (DAgger); the teacher's
+        action on the same observation is the label.  One `update_depth_actor` per 24-step rollout, linear LR decay over 20 k iterations."""
+        env, alg, dev = self.env, self.alg, self.device
+        if self.log_dir is not None and self.writer is None:
+            from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _make_writer
+            self.writer = _make_writer(self.log_dir)
+        env.cfg.noise.add_noise = False
+        env.cfg.obstacle.curriculum = False
+        env.cfg.env.next_goal_threshold = 0.45
+        if hasattr(env, "bk"):
+            env.bk._cfg.next_goal_threshold = 0.45
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        n_aux, n_pro, nd = self.n_auxiliary, self.n_proprio, self.num_actions_d
+        yaw_sl, type_sl = slice(n_pro - n_aux, n_pro - n_aux + self.n_delta_yaw), slice(n_pro - n_aux + self.n_delta_yaw, n_pro)
+        action_student_history_buf = torch.zeros(env.num_envs, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev)
+        obs, obs_bbc = env.get_observations(), env.get_observations_bbc().clone()
+        infos = {"depth": env.depth_buffer[:, -1].clone(), "delta_yaw_ok": torch.ones(env.num_envs, dtype=torch.bool, device=dev)}
+        alg.depth_encoder.train(); alg.depth_actor.train()
+        bbc = self._behaviour_policy()
+        n_cmd = 6 + env.dim_c
+        keys = ("rew", "len")
+        buffers = {k: deque(maxlen=1000) for k in keys}
+        reach_goal_buffer = deque(maxlen=1000)
+        cur = torch.zeros(2, env.num_envs, device=dev)
+        logging = self.log_dir is not None
+        ep_infos = []
+        cfg_d = self.depth_encoder_cfg
+        depth_latent = delta_yaw = obst_type = None
+        for it in range(self.current_learning_iteration, tot_iter):
+            start = time.time()
+            depth_buffer, actions_teacher_buffer, actions_student_buffer = [], [], []
+            yaw_student, yaw_teacher, type_student, type_teacher, yaw_ok = [], [], [], [], []
+            fin_vals, fin_masks, fin_reach = [], [], []
+            for _ in range(cfg_d["num_steps_per_env"]):
+                obs = obs.clone()
+                if infos["depth"] is not None:
+                    with torch.no_grad():
+                        obs[:, alg._priv_slice(True)] = alg.estimator(obs[:, :alg.num_prop])
+                    obs_prop_depth = obs[:, :n_pro].clone()
+                    obs_prop_depth[:, n_pro - n_aux:n_pro] = 0                       # the student does not see headings / obstacle class
+                    out = alg.depth_encoder(infos["depth"].clone(), obs_prop_depth)
+                    depth_latent = out[:, :self.n_depth_latent]
+                    delta_yaw = 1.5 * out[:, self.n_depth_latent:self.n_depth_latent + self.n_delta_yaw]
+                    obst_type = out[:, self.n_depth_latent + self.n_delta_yaw:]
+                    depth_buffer.append(infos["depth"].clone())
+                    yaw_student.append(delta_yaw); yaw_teacher.append(obs[:, yaw_sl])
+                    type_student.append(obst_type); type_teacher.append(obs[:, type_sl])
+                with torch.no_grad():
+                    actions_teacher_buffer.append(alg.actor_critic.act_inference(obs, hist_encoding=True, scandots_latent=None))
+                obs_student = obs.clone()
+                ok = infos["delta_yaw_ok"].view(-1, 1)
+                obs_student[:, yaw_sl] = torch.where(ok, delta_yaw.detach(), obs_student[:, yaw_sl])
+                obs_student[:, type_sl] = torch.nn.functional.one_hot(torch.argmax(obst_type.detach(), dim=-1), num_classes=obst_type.shape[-1]).to(obs.dtype)
+                yaw_ok.append(ok.float().mean())
+                embedding = alg.depth_actor(obs_student, hist_encoding=True, scandots_latent=depth_latent)
+                prob, mean = self.depth_actor.actor_d(embedding), self.depth_actor.actor_c(embedding)
+                actions_student = torch.cat([torch.argmax(prob, dim=-1, keepdim=True).to(mean.dtype), mean], dim=-1)
+                actions_student_buffer.append(torch.cat([prob, mean], dim=-1))
+                action_student_history_buf = torch.cat([action_student_history_buf[:, 1:], actions_student[:, None, :].detach()], dim=1)
+                with torch.no_grad():
+                    next_commands = env.set_commands(action_student_history_buf[:, -1])
+                    obs_bbc[:, -n_cmd:] = next_commands
+                    actions_bbc = bbc(obs_bbc)
+                    obs, privileged_obs, rewards, dones, infos, _ids, _term = env.step(actions_bbc)
+                    obs_bbc = env.get_observations_bbc().clone()
+                    done = dones != 0
+                    action_student_history_buf = action_student_history_buf * (~done).view(-1, 1, 1).to(action_student_history_buf.dtype)
+                    if logging:
+                        if "episode" in infos:
+                            ep_infos.append(infos["episode"])
+                        cur += torch.stack([rewards, torch.ones_like(rewards)])
+                        fin_vals.append(cur.clone()); fin_masks.append(done); fin_reach.append(infos["reach_goal"].clone())
+                        cur *= (~done).to(cur.dtype)
+            collection_time = time.time() - start
+            start = time.time()
+            losses = alg.update_depth_actor(torch.cat(actions_student_buffer), torch.cat(actions_teacher_buffer), torch.cat(yaw_student),
+                                            torch.cat(yaw_teacher), torch.cat(type_student), torch.cat(type_teacher), torch.cat(depth_buffer))
+            learn_time = time.time() - start
+            alg.depth_encoder.detach_hidden_states()
+            decay = lambda lr0: max(lr0 - (lr0 - cfg_d["learning_rate_min"]) * it / 20000, cfg_d["learning_rate_min"])     # noqa: E731
+            for opt, lr0 in ((alg.depth_encoder_optimizer, cfg_d["learning_rate"]), (alg.depth_actor_optimizer, cfg_d["learning_rate"]),
+                             (alg.byol_optimizer, cfg_d["learning_rate_byol"])):
+                for group in opt.param_groups:
+                    group["lr"] = decay(lr0)
+            self.last_vision = dict(zip(("depth_actor_loss", "yaw_loss", "obst_type_loss", "byol_loss"), losses))
+            self.last_vision["delta_yaw_ok_percentage"] = torch.stack(yaw_ok).mean().item()
+            if logging:
+                vals, masks, reach = torch.stack(fin_vals), torch.stack(fin_masks), torch.stack(fin_reach)
+                sel = vals.permute(0, 2, 1)[masks].cpu()
+                for i, k in enumerate(keys):
+                    buffers[k].extend(sel[:, i].tolist())
+                reach_goal_buffer.extend(reach[masks].float().cpu().tolist())
+                self._log_vision(it, collection_time, learn_time, buffers, reach_goal_buffer, ep_infos)
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, "model.pt"))
+            ep_infos.clear()
+            self.last_perf = {"collection_time": collection_time, "learn_time": learn_time,
+                              "fps": cfg_d["num_steps_per_env"] * env.num_envs / (collection_time + learn_time)}
+        self.current_learning_iteration = tot_iter
+        if logging:
+            self.save(os.path.join(self.log_dir, "model.pt"))
+
+    def _log_vision(self, it, collection_time, learn_time, buffers, reach_goal_buffer, ep_infos):
+        """log_vision (:443-511): same tags"""
+        w = self.writer
+        steps = self.depth_encoder_cfg["num_steps_per_env"] * self.env.num_envs
+        self.tot_timesteps += steps
+        self.tot_time += collection_time + learn_time
+        if ep_infos:
+            for key in ep_infos[0]:
+                vals = torch.stack([torch.as_tensor(e[key], device=self.device).reshape(()) for e in ep_infos])
+                w.add_scalar("Episode/" + key, vals.mean().item(), it)
+        v = self.last_vision
+        w.add_scalar("Loss_depth/delta_yaw_ok_percent", v["delta_yaw_ok_percentage"], it)
+        w.add_scalar("Loss_depth/depth_actor", v["depth_actor_loss"], it)
+        w.add_scalar("Loss_depth/yaw", v["yaw_loss"], it)
+        w.add_scalar("Loss_depth/obst_type", v["obst_type_loss"], it)
+        w.add_scalar("Loss_depth/byol", v["byol_loss"], it)
+        w.add_scalar("Perf/total_fps", int(steps / (collection_time + learn_time)), it)
+        w.add_scalar("Perf/collection time", collection_time, it)
+        w.add_scalar("Perf/learning_time", learn_time, it)
+        if len(buffers["rew"]) > 0:
+            w.add_scalar("Train/mean_reward", statistics.mean(buffers["rew"]), it)
+            w.add_scalar("Train/mean_episode_length", statistics.mean(buffers["len"]), it)
+            w.add_scalar("Train/success_rate", statistics.mean(reach_goal_buffer), it)
+        if hasattr(w, "flush"):
+            w.flush()
+
     def _log(self, it, losses, hist_loss, collection_time, learn_time, buffers, ep_infos):
         w = self.writer
         self.tot_timesteps += self.num_steps_per_env * self.env.num_envs
@@ -181,13 +321,24 @@ class OnPolicyRunner:
 
     # ------------------------------------------------------------------ checkpoints (:443-520: same keys)
     def save(self, path, infos=None):
-        torch.save({"model_state_dict": self.alg.actor_critic.state_dict(), "estimator_state_dict": self.alg.estimator.state_dict(),
-                    "optimizer_state_dict": self.alg.optimizer.state_dict(), "iter": self.current_learning_iteration, "infos": infos}, path)
+        d = {"model_state_dict": self.alg.actor_critic.state_dict(), "estimator_state_dict": self.alg.estimator.state_dict(),
+             "optimizer_state_dict": self.alg.optimizer.state_dict(), "iter": self.current_learning_iteration, "infos": infos}
+        if self.if_depth:                        # :618-620
+            d["depth_encoder_state_dict"] = self.alg.depth_encoder.state_dict()
+            d["depth_actor_state_dict"] = self.alg.depth_actor.state_dict()
+        torch.save(d, path)
 
     def load(self, path, load_optimizer=True):
         d = torch.load(path, map_location=self.device, weights_only=False)
         self.alg.actor_critic.load_state_dict(d["model_state_dict"])
         self.alg.estimator.load_state_dict(d["estimator_state_dict"])
+        if self.if_depth:                        # :629-640: a teacher checkpoint has neither key -> the student starts as the teacher's actor
+            if "depth_encoder_state_dict" in d:
+                self.alg.depth_encoder.load_state_dict(d["depth_encoder_state_dict"])
+            if "depth_actor_state_dict" in d:
+                self.alg.depth_actor.load_state_dict(d["depth_actor_state_dict"])
+            else:
+                self.alg.depth_actor.load_state_dict(self.alg.actor_critic.actor.state_dict())
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
         self.current_learning_iteration = d["iter"]
@@ -206,6 +357,18 @@ class OnPolicyRunner:
         n = d["disc_normalizer"]
         self.discriminator.normalizer = TorchNormalizer.from_reference(n, self.device) if torch.device(self.device).type == "cuda" else n
         self._bbc_chain = None
+
+    def get_depth_actor_inference_policy(self, device=None):
+        self.alg.depth_actor.eval()
+        if device is not None:
+            self.alg.depth_actor.to(device)
+        return self.alg.depth_actor
+
+    def get_depth_encoder_inference_policy(self, device=None):
+        self.alg.depth_encoder.eval()
+        if device is not None:
+            self.alg.depth_encoder.to(device)
+        return self.alg.depth_encoder
 
     def get_inference_policy(self, device=None):
         self.alg.actor_critic.eval()
