@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator + mocap reset on the real Go2 clips (baked dataset shipped with the package)")
     ap.add_argument("--terrain", default="plane", choices=["plane", "trimesh"],
                     help="plane = BASELINE configs 1-2 (flat terrain); trimesh = the reference's 10x40 tile course as a height field")
+    ap.add_argument("--vision", action="store_true", help="with --tsc: the depth student (BASELINE configs[4]: --use_camera, 4096 envs in total)")
     ap.add_argument("--tsc", action="store_true", help="BASELINE config 4: TSC teacher on the agility course (two-level rollout, hybrid PPO); "
                     "--num_envs is per GPU (8192 over 8 GPUs = 1024 per GPU)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -236,65 +237,111 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def _barrier_sync(world):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def _max_over_ranks(dt, world, dev):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+DEPTH_ALG_BYTES_PER_ENV_STEP = 3 * 58 * 87 * 4   # the image ring: read slot 1, write slots 0 and 1 (the maps are read through L2)
 TSC_ALG_BYTES_PER_ENV_STEP = 7300       # obs 800 x 4, 132 int16 scan lookups + 8 edge-mask lookups on top of the BBC figure
 
 
 def bench_tsc(args, world, rank, local_rank, dev):
-    """BASELINE config 4: one step = one learn_RL iteration of the task-level tree -- 24 x (task policy -> set_commands -> frozen
-    behaviour policy -> physics step on the obstacle course -> goal step -> reset -> observations -> discriminator reward),
-    GAE, 5 epochs x 4 minibatches of the hybrid PPO.  Single process per GPU; ranks are replicas of the rollout with their own
-    courses (the task-level learner's gradient exchange is not wired: `scaling` says so)."""
+    """BASELINE configs 3 / 4 (indices of BASELINE.json `configs`): the task-level tree.
+      --tsc           TSC teacher, 8192 envs in total: one step = one learn_RL iteration -- 24 x (task policy -> set_commands -> frozen
+                      behaviour policy -> physics step on the obstacle course -> goal step -> reset -> observations -> discriminator
+                      reward), GAE, 5 epochs x 4 minibatches of the hybrid PPO.
+      --tsc --vision  TSC student with the depth camera, 4096 envs in total: one step = one learn_vision iteration -- 24 x (depth encoder
+                      -> student actor -> set_commands -> behaviour policy -> physics -> goal step -> reset -> depth ray-cast ->
+                      observations), one DAgger update + 6 BYOL minibatches.
+    One process per GPU; with --scaling strong (default) the job's envs are split over the ranks, which exchange ONE flat gradient
+    bucket per optimiser step (GradSync), the KL mean and the advantage moments; each rank builds the course of its own envs."""
     import torch
     from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import class_to_dict
     from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
     from quadrupedal_agility_amd.tsc.legged_gym.envs.go2.go2_agility_config import Go2AgilityCfg, Go2AgilityCfgPPO
     from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
-    n = args.num_envs if args.num_envs != 4096 else 1024
+    total = args.num_envs if args.num_envs != 4096 or args.vision else 8192
+    if args.scaling == "strong":
+        if total % world:
+            raise SystemExit(f"--num_envs {total} is not divisible by {world} ranks")
+        n = total // world
+    else:
+        n, total = total, total * world
     cfg = Go2AgilityCfg()
-    cfg.env.num_envs, cfg.seed = n, 1 + 7919 * rank
+    cfg.env.num_envs, cfg.seed, cfg.course_seed = n, 1, 1 + 7919 * rank
+    cfg.env.env_id_offset, cfg.env.num_envs_global = rank * n, total
     d = cfg.domain_rand                                    # the reference's command line for this config: --randomize_base_mass ... --randomize_start
     d.randomize_base_mass = d.randomize_base_com = d.push_robots = True
     cfg.obstacle.randomize_start = True
-    torch.manual_seed(1)
+    cfg.depth.use_camera = bool(args.vision)
+    tcfg = class_to_dict(Go2AgilityCfgPPO())
+    tcfg["depth_encoder"]["if_depth"] = bool(args.vision)
+    torch.manual_seed(1)                                   # same initial weights everywhere (and broadcast from rank 0 anyway)
     env = lr.LeggedRobot(cfg, sim_device=dev)
-    runner = OnPolicyRunner(env, class_to_dict(Go2AgilityCfgPPO()), log_dir=None, device=dev)
+    runner = OnPolicyRunner(env, tcfg, log_dir=None, device=dev)
+    torch.manual_seed(1 + 104729 * rank)                   # the ranks' action noise / start draws differ
     runner.learn(max(args.warmup, 2), init_at_random_ep_len=True)
-    torch.cuda.synchronize()
+    _barrier_sync(world)
     t0 = time.perf_counter()
     coll = []
     for _ in range(args.steps):
         runner.learn(1)
         coll.append(runner.last_perf["collection_time"])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    _barrier_sync(world)
+    dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
     # the env-side kernels of one step, timed alone with HIP events on the launch stream
     act = torch.zeros(n, 12, device=dev)
     hist = torch.zeros(n, 8, 19, device=dev)
     spans = {}
-    for name, fn in (("physics", lambda: env.sim.physics_step(act, 1)),
-                     ("goal_step", lambda: env.bk.post_physics_step(env.root_states, env.contact_forces, env.rigid_body_states, hist, want_ids=False)),
-                     ("observations", lambda: env.bk.compute_observations(env.root_states, env.dof_pos, env.dof_vel, env.action_history_buf, env.rigid_body_states,
-                                                                          env.mass_params_tensor, env.friction_coeffs_tensor, env.motor_strength))):
+    legs = [("physics", lambda: env.sim.physics_step(act, 1)),
+            ("goal_step", lambda: env.bk.post_physics_step(env.root_states, env.contact_forces, env.rigid_body_states, hist, want_ids=False)),
+            ("observations", lambda: env.bk.compute_observations(env.root_states, env.dof_pos, env.dof_vel, env.action_history_buf, env.rigid_body_states,
+                                                                 env.mass_params_tensor, env.friction_coeffs_tensor, env.motor_strength))]
+    if args.vision:
+        legs.append(("depth", lambda: env.bk.update_depth_buffer(env.root_states, 1)))
+    for name, fn in legs:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn(); e0.record()
         for _ in range(40):
             fn()
         e1.record(); torch.cuda.synchronize()
         spans[name] = e0.elapsed_time(e1) / 40
-    T = runner.num_steps_per_env
+    T = tcfg["depth_encoder"]["num_steps_per_env"] if args.vision else runner.num_steps_per_env
     kern_ms = sum(spans.values())
-    achieved = TSC_ALG_BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+    alg_bytes = TSC_ALG_BYTES_PER_ENV_STEP + (DEPTH_ALG_BYTES_PER_ENV_STEP if args.vision else 0)
+    achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
+    what = ("TSC-student with depth-camera obs (58x87 ray-cast depth image per env step, depth encoder + GRU + student actor, DAgger + BYOL)" if args.vision else
+            "TSC-teacher agility course")
     out = {"metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU", "value": n * T * args.steps * world / dt, "unit": "env-steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak (independent replicas: the task-level learner's gradient exchange is not wired)", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"TSC-teacher agility course (6 obstacles/env as height-field collision terrain, randomize_base_mass/com, push_robots, randomize_start, "
-                                  f"action noise U(0.8,1.2), frozen behaviour policy + discriminator at their initial weights), {n} envs/GPU, 24 steps/iter, 5 epochs x 4 minibatches",
-                      "num_envs_per_gpu": n, "steps_per_iter": T, "parallelism": f"replicas{world}"},
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{what} (6 obstacles/env as height-field + ceiling collision terrain, randomize_base_mass/com, push_robots, randomize_start, "
+                                  f"action noise U(0.8,1.2), frozen behaviour policy + discriminator at their initial weights), {total} envs in total = {n} envs/GPU x {world}, "
+                                  f"{T} steps/iter" + ("" if args.vision else ", 5 epochs x 4 minibatches"),
+                      "num_envs_total": total, "num_envs_per_gpu": n, "steps_per_iter": T, "parallelism": f"dp{world}"},
            "collection_s": sum(coll) / len(coll), "learn_s": dt / args.steps - sum(coll) / len(coll),
            "rollout_env_steps_per_s": n * T / (sum(coll) / len(coll)),
-           "roofline": {"kernel": "qa_env_step_kernel<false,4,1> + qa_tsc_goal_step + qa_tsc_observations", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+           "roofline": {"kernel": "qa_env_step_kernel<false,4,1> + qa_tsc_goal_step + qa_tsc_observations" + (" + qa_tsc_depth_kernel" if args.vision else ""),
+                        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "kernel_ms_each": spans,
-                        "algorithmic_bytes_per_launch": TSC_ALG_BYTES_PER_ENV_STEP * n}}
+                        "algorithmic_bytes_per_launch": alg_bytes * n}}
+    if args.vision:
+        out["vision"] = dict(runner.last_vision)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

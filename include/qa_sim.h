@@ -642,7 +642,7 @@ typedef struct qa_tsc_depth_cfg {
     int32_t crop_top, crop_bottom, crop_left, crop_right;   /* 1, 1, 10, 9 -> (height - 2) x (width - 19) = 58 x 87 */
     int32_t buffer_len;                  /* depth.buffer_len = 2 */
     int32_t map_rows, map_cols;
-    int32_t reserved;
+    int32_t coarse_log2;                 /* S: the coarse maps of the io block summarise blocks of 2^S x 2^S cells (3 = 40 cm blocks of 5 cm cells) */
     float horizontal_fov_deg;            /* 87 */
     float position[3];                   /* camera position in the trunk frame */
     float near_clip, far_clip, depth_noise;
@@ -655,6 +655,11 @@ typedef struct qa_tsc_depth_io {
     const int16_t *ceiling_samples;      /* same grid, QA_NO_CEILING where none; NULL = no overhangs */
     const int64_t *episode_length;       /* (N) */
     float *depth_buffer;                 /* in/out (N, buffer_len, height - crop_top - crop_bottom, width - crop_left - crop_right) */
+    /* optional acceleration structure (NULL = march every sample): block (I, J) = cells [I 2^S, (I + 1) 2^S) x [J 2^S, (J + 1) 2^S),
+     * (((map_rows - 2) >> S) + 1, ((map_cols - 2) >> S) + 1) int16 each: the highest height sample / the lowest ceiling sample among
+     * the (2^S + 1)^2 samples those cells touch.  It only lets the march skip samples that cannot report a hit: the image does not
+     * depend on it (the CPU twin ignores it). */
+    const int16_t *coarse_floor_max, *coarse_ceiling_min;
 } qa_tsc_depth_io;
 int qa_tsc_depth_update(const qa_tsc_depth_cfg *cfg, const qa_tsc_depth_io *io, void *stream);
 

@@ -221,12 +221,13 @@ class QaTscDepthCfg(C.Structure):
     """qa_tsc_depth_cfg of include/qa_sim.h"""
     _fields_ = [("num_envs", C.c_int64), ("step", C.c_int64), ("seed", C.c_uint64), ("env_id_offset", C.c_int32), ("width", C.c_int32),
                 ("height", C.c_int32), ("crop_top", C.c_int32), ("crop_bottom", C.c_int32), ("crop_left", C.c_int32), ("crop_right", C.c_int32),
-                ("buffer_len", C.c_int32), ("map_rows", C.c_int32), ("map_cols", C.c_int32), ("reserved", C.c_int32),
+                ("buffer_len", C.c_int32), ("map_rows", C.c_int32), ("map_cols", C.c_int32), ("coarse_log2", C.c_int32),
                 ("horizontal_fov_deg", C.c_float), ("position", C.c_float * 3), ("near_clip", C.c_float), ("far_clip", C.c_float),
                 ("depth_noise", C.c_float), ("border_size", C.c_float), ("horizontal_scale", C.c_float), ("vertical_scale", C.c_float)]
 
 
-TSC_DEPTH_IO_FIELDS = ("root_states", "camera_pitch", "height_samples", "ceiling_samples", "episode_length", "depth_buffer")
+TSC_DEPTH_IO_FIELDS = ("root_states", "camera_pitch", "height_samples", "ceiling_samples", "episode_length", "depth_buffer", "coarse_floor_max",
+                       "coarse_ceiling_min")
 
 
 class QaTscDepthIo(C.Structure):

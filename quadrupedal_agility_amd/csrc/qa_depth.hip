@@ -23,30 +23,41 @@ struct DepthArgs {
     qa_tsc_depth_cfg c;
     qa_tsc_depth_io io;
     float tan_h, tan_v, inv_hs;
-    int wc, hc;
+    int wc, hc, tiles;
 };
 
-// floor / ceiling height over (x, y): two triangles per cell split along the (i,j)-(i+1,j+1) diagonal (the collision terrain's
-// triangulation, qa_physics.h ground_query); indices clamped at the map's edge
-__device__ __forceinline__ float surface(const int16_t *__restrict__ m, int rows, int cols, float border, float inv_hs, float vs, float x, float y, bool &exists) {
+// cell of (x, y) in the maps' grid: clamped fine cell index and the position inside it (the collision terrain's lookup,
+// qa_physics.h ground_query)
+struct Cell { int ix, iy; float u, v; };
+__device__ __forceinline__ Cell cell_of(float x, float y, float border, float inv_hs, int rows, int cols) {
     const float fx = (x + border) * inv_hs, fy = (y + border) * inv_hs;
-    const int ix = min(max((int)floorf(fx), 0), rows - 2), iy = min(max((int)floorf(fy), 0), cols - 2);
-    const float u = fminf(fmaxf(fx - (float)ix, 0.f), 1.f), v = fminf(fmaxf(fy - (float)iy, 0.f), 1.f);
-    const int16_t *g = m + (int64_t)ix * cols + iy;
+    Cell c;
+    c.ix = min(max((int)floorf(fx), 0), rows - 2); c.iy = min(max((int)floorf(fy), 0), cols - 2);
+    c.u = fminf(fmaxf(fx - (float)c.ix, 0.f), 1.f); c.v = fminf(fmaxf(fy - (float)c.iy, 0.f), 1.f);
+    return c;
+}
+// floor / ceiling height in a cell: two triangles split along the (i,j)-(i+1,j+1) diagonal; a ceiling triangle with a QA_NO_CEILING
+// corner does not exist
+__device__ __forceinline__ float tri_height(const int16_t *__restrict__ m, int cols, float vs, const Cell &c, bool &exists) {
+    const int16_t *g = m + (int64_t)c.ix * cols + c.iy;
     const int s00 = g[0], s01 = g[1], s10 = g[cols], s11 = g[cols + 1];
-    const bool lower = u >= v;
+    const bool lower = c.u >= c.v;
     const int sm = lower ? s10 : s01;
     exists = s00 != QA_NO_CEILING && s11 != QA_NO_CEILING && sm != QA_NO_CEILING;
     const float h00 = vs * (float)s00, h11 = vs * (float)s11, hm = vs * (float)sm;
-    // lower: h00 + u (h10 - h00) + v (h11 - h10); upper: h00 + v (h01 - h00) + u (h11 - h01)
-    const float a = lower ? u : v, b = lower ? v : u;
+    const float a = lower ? c.u : c.v, b = lower ? c.v : c.u;       // lower: h00 + u (h10 - h00) + v (h11 - h10); upper: h00 + v (h01 - h00) + u (h11 - h01)
     return h00 + a * (hm - h00) + b * (h11 - hm);
 }
 
 __global__ void __launch_bounds__(256) qa_tsc_depth_kernel(DepthArgs a) {
     const qa_tsc_depth_cfg &c = a.c;
-    const int64_t e = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x, npix = a.wc * a.hc;
+    // workgroup id -> (env, pixel tile).  Consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2: id = 8 s + x
+    // runs on XCD x, so env = 8 (s / tiles) + x keeps all tiles of one env -- which walk the same ~100 KB of the two maps -- on ONE L2
+    const int npix = a.wc * a.hc, tiles = a.tiles;
+    const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    const int64_t e = (int64_t)(sl / tiles) * 8 + x;
+    if (e >= c.num_envs) return;
+    const int p = (sl % tiles) * 256 + threadIdx.x;
     if (p >= npix) return;
     const float *rs = a.io.root_states + e * 13;
     const float qx = rs[3], qy = rs[4], qz = rs[5], qw = rs[6];
@@ -63,36 +74,53 @@ __global__ void __launch_bounds__(256) qa_tsc_depth_kernel(DepthArgs a) {
     const float dt3[3] = {ca - sy * sa, -sx, -sa - sy * ca};              // fwd - sx left - sy up, trunk frame
 #pragma unroll
     for (int k = 0; k < 3; ++k) d[k] = R[3 * k] * dt3[0] + R[3 * k + 1] * dt3[1] + R[3 * k + 2] * dt3[2];
-    const float far = c.far_clip, near = c.near_clip, vs = c.vertical_scale, border = c.border_size;
-    const float dxy = sqrtf(d[0] * d[0] + d[1] * d[1]), dt = 0.5f * c.horizontal_scale / fmaxf(dxy, 0.5f);
-    const int nsteps = (int)ceilf(far / dt);
+    const float far = c.far_clip, near = c.near_clip, vs = c.vertical_scale, border = c.border_size, hs = c.horizontal_scale;
+    const float dxy = sqrtf(d[0] * d[0] + d[1] * d[1]), dt = 0.5f * hs / fmaxf(dxy, 0.5f);
+    const int nsteps = (int)ceilf(far / dt), rows = c.map_rows, cols = c.map_cols;
     const int16_t *hm = a.io.height_samples, *cm = a.io.ceiling_samples;
+    // empty-space skipping: per block of 2^S x 2^S cells the highest floor sample and the lowest ceiling sample (apron of one sample).
+    // While the ray's height over the samples it would take inside a block stays clear of both, none of them can report a hit:
+    // evaluate only the last one (it seeds the next step's bracket) and jump.  Conservative by construction -- the image is the
+    // full march's (the oracle's) image.
+    const int16_t *cfl = a.io.coarse_floor_max, *cce = a.io.coarse_ceiling_min;
+    const int S = c.coarse_log2, ccols = ((cols - 2) >> S) + 1, crows = ((rows - 2) >> S) + 1;
+    const float block = (float)(1 << S) * hs;
+    const float idx = d[0] != 0.f ? 1.0f / d[0] : 0.f, idy = d[1] != 0.f ? 1.0f / d[1] : 0.f;
+    int seen_cx = -1, seen_cy = -1;                                     // the block that last refused a skip: not asked again while inside it
+    int blk_cx = -1, blk_cy = -1; bool blk_roof = true;                 // the block of the current sample: has it any ceiling sample at all?
     bool ex_prev = false, ex = false, dummy;
     float t_prev = 0.f, hit = far;
-    float g_prev = o[2] - surface(hm, c.map_rows, c.map_cols, border, a.inv_hs, vs, o[0], o[1], dummy);
-    float h_prev = cm ? o[2] - surface(cm, c.map_rows, c.map_cols, border, a.inv_hs, vs, o[0], o[1], ex_prev) : 0.f;
+    Cell c0 = cell_of(o[0], o[1], border, a.inv_hs, rows, cols);
+    float g_prev = o[2] - tri_height(hm, cols, vs, c0, dummy);
+    float h_prev = cm ? o[2] - tri_height(cm, cols, vs, c0, ex_prev) : 0.f;
     if (g_prev < 0.f) hit = 0.f;
     else for (int k = 1; k <= nsteps; ++k) {
         const float t = fminf((float)k * dt, far);
         const float x = o[0] + t * d[0], y = o[1] + t * d[1], z = o[2] + t * d[2];
-        const float g = z - surface(hm, c.map_rows, c.map_cols, border, a.inv_hs, vs, x, y, dummy);
+        const Cell ck = cell_of(x, y, border, a.inv_hs, rows, cols);
+        const float g = z - tri_height(hm, cols, vs, ck, dummy);
         float h = 0.f, best = 1e30f;
         if (g < 0.f) {                      // the floor was crossed in (t_prev, t]: QA_TSC_DEPTH_BISECT halvings, then linear interpolation
             float lo = t_prev, hi = t, flo = g_prev, fhi = g;
             for (int b = 0; b < QA_TSC_DEPTH_BISECT; ++b) {
                 const float tm = 0.5f * (lo + hi);
-                const float fm = o[2] + tm * d[2] - surface(hm, c.map_rows, c.map_cols, border, a.inv_hs, vs, o[0] + tm * d[0], o[1] + tm * d[1], dummy);
+                const Cell cb = cell_of(o[0] + tm * d[0], o[1] + tm * d[1], border, a.inv_hs, rows, cols);
+                const float fm = o[2] + tm * d[2] - tri_height(hm, cols, vs, cb, dummy);
                 if (fm < 0.f) { hi = tm; fhi = fm; } else { lo = tm; flo = fm; }
             }
             best = lo + (hi - lo) * flo / (flo - fhi);
         }
-        if (cm) {
-            h = z - surface(cm, c.map_rows, c.map_cols, border, a.inv_hs, vs, x, y, ex);
+        const int cx = ck.ix >> S, cy = ck.iy >> S;
+        if (cce && (cx != blk_cx || cy != blk_cy)) { blk_cx = cx; blk_cy = cy; blk_roof = cce[cx * ccols + cy] != QA_NO_CEILING; }
+        ex = false;
+        if (cm && blk_roof) {               // a block without a single ceiling sample has no ceiling triangle: ex stays false
+            h = z - tri_height(cm, cols, vs, ck, ex);
             if (ex && ex_prev && ((h_prev < 0.f) != (h < 0.f))) {
                 float lo = t_prev, hi = t, flo = h_prev, fhi = h;
                 for (int b = 0; b < QA_TSC_DEPTH_BISECT; ++b) {
                     const float tm = 0.5f * (lo + hi); bool exm;
-                    const float fm = o[2] + tm * d[2] - surface(cm, c.map_rows, c.map_cols, border, a.inv_hs, vs, o[0] + tm * d[0], o[1] + tm * d[1], exm);
+                    const Cell cb = cell_of(o[0] + tm * d[0], o[1] + tm * d[1], border, a.inv_hs, rows, cols);
+                    const float fm = o[2] + tm * d[2] - tri_height(cm, cols, vs, cb, exm);
                     if (!exm) break;                                     // a hole in the shell inside the bracket: keep the bracket
                     if ((fm < 0.f) == (flo < 0.f)) { lo = tm; flo = fm; } else { hi = tm; fhi = fm; }
                 }
@@ -101,6 +129,29 @@ __global__ void __launch_bounds__(256) qa_tsc_depth_kernel(DepthArgs a) {
         }
         if (best < 1e29f) { hit = best; break; }
         t_prev = t; g_prev = g; h_prev = h; ex_prev = ex;
+        if (cfl && (cx != seen_cx || cy != seen_cy)) {
+            seen_cx = cx; seen_cy = cy;
+            // where the ray leaves this block's footprint (the outermost blocks extend outwards: lookups clamp to the map's edge)
+            const float x0 = (float)(cx << S) * hs - border, y0 = (float)(cy << S) * hs - border;
+            const float bx = d[0] > 0.f ? (cx == crows - 1 ? 1e30f : x0 + block) : (cx == 0 ? -1e30f : x0);
+            const float by = d[1] > 0.f ? (cy == ccols - 1 ? 1e30f : y0 + block) : (cy == 0 ? -1e30f : y0);
+            const float tx = d[0] != 0.f ? (bx - o[0]) * idx : 1e30f, ty = d[1] != 0.f ? (by - o[1]) * idy : 1e30f;
+            const float t_exit = fminf(fminf(tx, ty), far);
+            const int kl = min((int)floorf((t_exit - 1e-4f) / dt), nsteps - 1);   // the last lattice sample safely inside (the final, clamped one is always marched)
+            if (kl > k + 1) {
+                const float tl = (float)kl * dt, zl = o[2] + tl * d[2];
+                const float hmax = vs * (float)cfl[cx * ccols + cy];
+                const float cmin = (cm && cce) ? vs * (float)cce[cx * ccols + cy] : 1e30f;
+                if (fminf(z, zl) > hmax + 1e-3f && fmaxf(z, zl) < cmin - 1e-3f) {
+                    const Cell cl = cell_of(o[0] + tl * d[0], o[1] + tl * d[1], border, a.inv_hs, rows, cols);
+                    if ((cl.ix >> S) == cx && (cl.iy >> S) == cy) {          // rounding never moves it out, but the jump is only taken if it did not
+                        t_prev = tl; g_prev = zl - tri_height(hm, cols, vs, cl, dummy);
+                        h_prev = cm ? zl - tri_height(cm, cols, vs, cl, ex_prev) : 0.f;
+                        k = kl; seen_cx = -1;                                // the block after this one is asked afresh
+                    }
+                }
+            }
+        }
     }
     const float dd = fminf(fmaxf(hit, near), far);
     float v = (dd - near) / (far - near) - 0.5f;
@@ -130,15 +181,17 @@ extern "C" int qa_tsc_depth_update(const qa_tsc_depth_cfg *cfg, const qa_tsc_dep
     }
     DepthArgs a; a.c = *cfg; a.io = *io;
     a.wc = cfg->width - cfg->crop_left - cfg->crop_right; a.hc = cfg->height - cfg->crop_top - cfg->crop_bottom;
-    if (cfg->num_envs <= 0 || cfg->num_envs > 65535 || a.wc <= 0 || a.hc <= 0 || cfg->buffer_len < 1 || cfg->map_rows < 2 || cfg->map_cols < 2 || !(cfg->horizontal_scale > 0.f) ||
-        !(cfg->far_clip > cfg->near_clip) || !(cfg->horizontal_fov_deg > 0.f && cfg->horizontal_fov_deg < 180.f)) {
+    if (cfg->num_envs <= 0 || cfg->num_envs > (1 << 22) || a.wc <= 0 || a.hc <= 0 || cfg->buffer_len < 1 || cfg->map_rows < 2 || cfg->map_cols < 2 || !(cfg->horizontal_scale > 0.f) ||
+        cfg->coarse_log2 < 0 || cfg->coarse_log2 > 6 || !(cfg->far_clip > cfg->near_clip) || !(cfg->horizontal_fov_deg > 0.f && cfg->horizontal_fov_deg < 180.f)) {
         snprintf(qa_err_buf, sizeof(qa_err_buf), "qa_tsc_depth_update: inconsistent configuration"); return QA_E_ARG;
     }
     a.tan_h = (float)tan((double)cfg->horizontal_fov_deg * 3.14159265358979323846 / 360.0);
     a.tan_v = (float)(tan((double)cfg->horizontal_fov_deg * 3.14159265358979323846 / 360.0) * cfg->height / cfg->width);
     a.inv_hs = 1.0f / cfg->horizontal_scale;
     const int npix = a.wc * a.hc;
-    hipLaunchKernelGGL(qa_tsc_depth_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)cfg->num_envs), dim3(256), 0, (hipStream_t)stream, a);
+    a.tiles = (npix + 255) / 256;
+    const int64_t groups = (cfg->num_envs + 7) / 8 * 8 * a.tiles;          // envs rounded up to the 8 XCDs
+    hipLaunchKernelGGL(qa_tsc_depth_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(qa_err_buf, sizeof(qa_err_buf), "qa_tsc_depth_update: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

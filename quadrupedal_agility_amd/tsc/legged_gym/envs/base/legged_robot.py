@@ -64,6 +64,10 @@ def make_qa_config(cfg, obstacle, seed=1):
         c.added_com_range[k], c.motor_strength_range[k] = float(d.added_com_range[k]), float(d.motor_strength_range[k])
     c.latent_temperature = 0.25
     c.export_body_state = 1
+    # data parallel: this rank's envs are [env_id_offset, env_id_offset + num_envs) of a num_envs_global-env job; every Philox draw is
+    # keyed by the global env id (the BBC tree's rule, cfg_to_c.py)
+    c.env_id_offset = int(getattr(cfg.env, "env_id_offset", 0))
+    c.num_envs_global = int(getattr(cfg.env, "num_envs_global", 0)) or int(cfg.env.num_envs)
     return c
 
 

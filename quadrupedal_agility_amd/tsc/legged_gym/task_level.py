@@ -12,6 +12,20 @@ import torch
 from ... import _capi
 
 
+def coarse_depth_maps(height_samples, ceiling_samples, log2_block):
+    """The depth ray-cast's acceleration structure (qa_tsc_depth_io.coarse_floor_max / coarse_ceiling_min): per block of 2^S x 2^S
+    cells the highest height sample and the lowest ceiling sample among the (2^S + 1)^2 samples those cells touch."""
+    import torch.nn.functional as F
+    b = 1 << log2_block
+    rows, cols = height_samples.shape
+    cr, cc = ((rows - 2) >> log2_block) + 1, ((cols - 2) >> log2_block) + 1
+
+    def pooled(m, sign, fill):
+        x = F.pad(sign * m.to(torch.float32)[None, None], (0, cc * b + 1 - cols, 0, cr * b + 1 - rows), value=sign * fill)
+        return (sign * F.max_pool2d(x, kernel_size=b + 1, stride=b))[0, 0].to(torch.int16).contiguous()
+    return pooled(height_samples, 1.0, -32768.0), (pooled(ceiling_samples, -1.0, 32767.0) if ceiling_samples is not None else None)
+
+
 class TaskLevelBookkeeping:
     """State and per-step calls of one rank's task-level envs.
 
@@ -222,6 +236,8 @@ class TaskLevelBookkeeping:
         if (wc, hc) != tuple(d.resized):
             raise ValueError(f"depth.resized {tuple(d.resized)} is not the cropped image {(wc, hc)}")
         self.depth_buffer = torch.zeros(n, c.buffer_len, hc, wc, dtype=torch.float32, device=dev)
+        c.coarse_log2 = 3
+        self._depth_coarse = coarse_depth_maps(self._depth_maps[0], self._depth_maps[1], c.coarse_log2)
 
     def update_depth_buffer(self, root_states, step):
         """update_depth_buffer + process_depth_image (:154-200) for all envs in one launch; `step` keys the noise draw"""
@@ -230,6 +246,8 @@ class TaskLevelBookkeeping:
         io.root_states, io.camera_pitch, io.height_samples = rs.data_ptr(), self.camera_pitch.data_ptr(), self._depth_maps[0].data_ptr()
         io.ceiling_samples = self._depth_maps[1].data_ptr() if self._depth_maps[1] is not None else None
         io.episode_length, io.depth_buffer = self.episode_length_buf.data_ptr(), self.depth_buffer.data_ptr()
+        io.coarse_floor_max = self._depth_coarse[0].data_ptr()
+        io.coarse_ceiling_min = self._depth_coarse[1].data_ptr() if self._depth_coarse[1] is not None else None
         self._dcfg.step = int(step)
         self._check(self._fn("tsc_depth_update")(C.byref(self._dcfg), C.byref(io), self._stream()), "qa_tsc_depth_update")
         return self.depth_buffer

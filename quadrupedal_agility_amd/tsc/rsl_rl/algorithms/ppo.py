@@ -43,6 +43,7 @@ class PPO:
         self.estimator_optimizer = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"])
         self.train_with_estimated_states = estimator_paras["train_with_estimated_states"]
         # depth encoder + student actor (:82-93): the student optimiser steps BOTH nets, BYOL has its own over the shared backbone
+        self.grad_sync = None          # data-parallel runs: GradSync of the BBC tree's runner (one flat all-reduce per optimiser step)
         self.if_depth = depth_encoder is not None
         if self.if_depth:
             self.depth_encoder, self.depth_encoder_paras, self.depth_actor = depth_encoder, depth_encoder_paras, depth_actor
@@ -119,7 +120,10 @@ class PPO:
         """KL(old || new) of the Gaussian head only, as the reference (:205-219); the decision needs one scalar."""
         with torch.no_grad():
             kl = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square()) / (2.0 * sigma.square()) - 0.5,
-                           dim=-1).mean().item()
+                           dim=-1).mean()
+            if self.grad_sync is not None:      # every rank takes the same LR branch
+                kl = self.grad_sync.mean_scalar(kl)
+            kl = kl.item()
         if kl > self.desired_kl * 2.0:
             self.learning_rate = max(1e-5, self.learning_rate / 1.5)
         elif 0.0 < kl < self.desired_kl / 2.0:
@@ -149,6 +153,8 @@ class PPO:
             est_loss = (self.estimator(obs[:, :self.num_prop]) - obs[:, priv]).pow(2).mean()
             self.estimator_optimizer.zero_grad()
             est_loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(list(self.estimator.parameters()))
             self._step_estimator.step()
 
             if self.desired_kl is not None and self.schedule == "adaptive":
@@ -165,6 +171,8 @@ class PPO:
 
             self.optimizer.zero_grad()
             loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(list(ac.parameters()))
             self._step_ac.step()
             sums += torch.stack([value_loss.detach(), surrogate.detach(), est_loss.detach(), priv_reg_loss.detach()])
 
@@ -184,6 +192,8 @@ class PPO:
             loss = (priv_latent - ac.actor.infer_hist_latent(obs)).norm(p=2, dim=1).mean()
             self.hist_encoder_optimizer.zero_grad()
             loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(list(ac.actor.history_encoder.parameters()))
             self._step_hist.step()
             total += loss.detach()
         self.storage.clear()
@@ -208,6 +218,8 @@ class PPO:
         loss = depth_actor_loss + yaw_loss + obst_type_loss
         self.depth_actor_optimizer.zero_grad()
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync([*self.depth_actor.parameters(), *self.depth_encoder.parameters()])
         nn.utils.clip_grad_norm_(self.depth_actor.parameters(), self.max_grad_norm)
         self.depth_actor_optimizer.step()
 
@@ -219,6 +231,8 @@ class PPO:
             byol_loss = self.depth_encoder.byol_learner(depth_batch[i:i + batch_size])
             self.byol_optimizer.zero_grad()
             byol_loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(list(self.depth_encoder.byol_learner.parameters()))
             self.byol_optimizer.step()
             byol_sum += byol_loss.detach()
             self.depth_encoder.byol_learner.update_moving_average()

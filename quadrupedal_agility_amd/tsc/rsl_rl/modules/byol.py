@@ -54,8 +54,16 @@ class EMA:
         return new if old is None else old * self.beta + (1 - self.beta) * new
 
 
+def _batch_norm(width):
+    """MaybeSyncBatchnorm (:41-43): batch statistics over ALL ranks' samples in a data-parallel run (RCCL; GPU only)"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+        return nn.SyncBatchNorm(width)
+    return nn.BatchNorm1d(width)
+
+
 def MLP(dim, projection_size, hidden_size=4096):
-    return nn.Sequential(nn.Linear(dim, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True), nn.Linear(hidden_size, projection_size))
+    return nn.Sequential(nn.Linear(dim, hidden_size), _batch_norm(hidden_size), nn.ReLU(inplace=True), nn.Linear(hidden_size, projection_size))
 
 
 class NetWrapper(nn.Module):

@@ -17,6 +17,7 @@ from collections import deque
 from copy import deepcopy
 
 import torch
+import torch.distributed as dist
 
 from quadrupedal_agility_amd.rsl_rl.utils.utils import Normalizer, TorchNormalizer
 from quadrupedal_agility_amd.tsc.rsl_rl.algorithms import PPO, Discriminator
@@ -67,6 +68,21 @@ class OnPolicyRunner:
                                            Normalizer(1) if self.disc_loss_function == "WassersteinLoss" else None, r["reward_i_coef"],
                                            r["reward_us_coef"], r["reward_ss_coef"], r["reward_t_coef"], self.disc_obs_len, r["disc_hidden_units"],
                                            norm, device).to(device)
+        # data parallel (BASELINE configs 3 and 4 are 8-GPU jobs): one process per GPU owns num_envs envs of the job, every
+        # optimiser step all-reduces ONE flat gradient bucket, the KL mean and the advantage moments are global, all ranks start from
+        # rank 0's weights -> the replicas stay bit-identical.  The frozen nets (behaviour policy, discriminator) are loaded, not trained.
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("QA_FORCE_DATA_PARALLEL") == "1")
+        self.rank = dist.get_rank() if self.distributed else 0
+        if self.distributed:
+            from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import GradSync
+            self.alg.grad_sync = GradSync()
+            self.alg.storage.global_moments = True
+            for m in (self.actor_critic, self.actor_critic_bbc, self.estimator, self.discriminator, self.depth_encoder, self.depth_actor):
+                if m is not None:
+                    for t in list(m.parameters()) + list(m.buffers()):
+                        dist.broadcast(t.data, src=0)
+        if self.rank != 0:
+            log_dir = None                      # rank 0 logs and saves
         self.learn = self.learn_vision if self.if_depth else self.learn_RL
         self.log_dir, self.writer = log_dir, None
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0, 0

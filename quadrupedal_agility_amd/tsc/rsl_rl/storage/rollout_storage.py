@@ -39,6 +39,7 @@ class RolloutStorage:
         self.mu, self.sigma = z(actions_shape[0] - 1), z(actions_shape[0] - 1)
         self.dones = torch.zeros(T, N, 1, device=device, dtype=torch.uint8)
         self.num_transitions_per_env, self.num_envs = T, N
+        self.global_moments = False         # set by the runner in data-parallel runs
         self.saved_hidden_states_a = self.saved_hidden_states_c = None
         self.step = 0
 
@@ -62,10 +63,22 @@ class RolloutStorage:
     def clear(self):
         self.step = 0
 
+    def _normalize_global(self, a):
+        """data parallel: the reference normalises over ALL T*N samples of the job, so the moments are all-reduced"""
+        import torch.distributed as dist
+        a64 = a.to(torch.float64)
+        s = torch.stack([a64.sum(), (a64 * a64).sum(), torch.tensor(float(a64.numel()), dtype=torch.float64, device=a64.device)])
+        dist.all_reduce(s)
+        mean = s[0] / s[2]
+        std = torch.sqrt(torch.clamp((s[1] - s[2] * mean * mean) / (s[2] - 1), min=0.0))
+        return (a - mean.float()) / (std.float() + 1e-8)
+
     def compute_returns(self, last_values, gamma, lam):
         if self.rewards.is_cuda and fused.ENABLED:
             fused.gae(self.rewards, self.values, self.dones, last_values.reshape(-1).contiguous(), self.returns, self.advantages,
-                      gamma, lam)
+                      gamma, lam, normalize=not self.global_moments)
+            if self.global_moments:
+                self.advantages.copy_(self._normalize_global(self.advantages))
             return
         adv = 0
         for t in reversed(range(self.num_transitions_per_env)):
@@ -75,7 +88,7 @@ class RolloutStorage:
             adv = delta + alive * gamma * lam * adv
             self.returns[t] = adv + self.values[t]
         a = self.returns - self.values
-        self.advantages = (a - a.mean()) / (a.std() + 1e-8)
+        self.advantages = self._normalize_global(a) if self.global_moments else (a - a.mean()) / (a.std() + 1e-8)
 
     def get_statistics(self):
         done = self.dones.clone()

@@ -117,3 +117,51 @@ def test_env_shards_reproduce_the_one_process_run_bit_for_bit():
         assert np.array_equal(np.concatenate([p.t[name] for p in parts]), whole.t[name]), name
     assert np.array_equal(np.concatenate([p.t["MOTOR_STRENGTH"] for p in parts], axis=1), whole.t["MOTOR_STRENGTH"])
     assert (whole.t["RESET"] != 0).any() or True
+
+
+def _tsc_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from quadrupedal_agility_amd.legged_gym.utils.helpers import class_to_dict
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.go2.go2_agility_config import Go2AgilityCfg, Go2AgilityCfgPPO
+    from quadrupedal_agility_amd.tsc.legged_gym.utils.obstacle import Obstacle
+    from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
+    from tests.oracle_backend import OracleBackend
+    from tests.oracle_lib import load_oracle
+    n = 6
+    cfg = Go2AgilityCfg()
+    cfg.env.num_envs, cfg.seed, cfg.course_seed = n, 1, 1 + rank                      # each rank builds the course of its own envs
+    cfg.env.env_id_offset, cfg.env.num_envs_global = rank * n, world * n
+    cfg.env.episode_length_s = 0.5
+    ob = Obstacle(cfg.obstacle, n, seed=cfg.course_seed)
+    env = lr.LeggedRobot(cfg, backend=OracleBackend(lr.make_qa_config(cfg, ob, seed=1)), bookkeeping_lib=(load_oracle(), "qo_"))
+    assert env.qcfg.env_id_offset == rank * n and env.qcfg.num_envs_global == world * n
+    tcfg = class_to_dict(Go2AgilityCfgPPO())
+    tcfg["runner"]["num_steps_per_env"] = 6
+    torch.manual_seed(100 + rank)                      # different initial weights per rank: the broadcast must fix that
+    runner = OnPolicyRunner(env, tcfg, log_dir=None, device="cpu")
+    assert runner.distributed and runner.alg.grad_sync is not None and runner.alg.storage.global_moments
+    runner.learn(2, init_at_random_ep_len=True)
+    a = runner.alg
+    flat = torch.cat([p.detach().flatten() for m in (a.actor_critic, a.estimator) for p in m.parameters()])
+    adv = a.storage.advantages
+    q.put((rank, flat.numpy(), a.learning_rate, float(adv.sum()), float((adv * adv).sum()), adv.numel(), env.root_states[:, :3].numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_task_level_training_keeps_replicas_identical():
+    """BASELINE configs 3 / 4 are 8-GPU data-parallel jobs of the task-level tree: same rules as the behaviour-level runner -- rank
+    0's weights, one averaged gradient bucket per optimiser step (policy / estimator / history encoder), global KL for the LR rule,
+    advantages normalised over all ranks' samples"""
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_tsc_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=900) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    (_, w0, lr0, s0, ss0, n0, pos0), (_, w1, lr1, s1, ss1, n1, pos1) = out
+    assert np.array_equal(w0, w1) and lr0 == lr1
+    n = n0 + n1
+    mean = (s0 + s1) / n
+    var = ((ss0 + ss1) - n * mean * mean) / (n - 1)
+    assert abs(mean) < 1e-4 and abs(var - 1.0) < 1e-3
+    assert not np.allclose(pos0, pos1)
