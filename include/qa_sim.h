@@ -348,7 +348,7 @@ int qa_clip_adam_step(float *const *params, const float *const *grads, float *co
                       float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream);
 /* The same step with `grads_host` a HOST array of the num_tensors (<= QA_ADAM_MAX_INLINE) device gradient pointers: they travel
  * in the kernel arguments, so a step whose gradient tensors are re-allocated every time (autograd) needs no pointer-table copy. */
-#define QA_ADAM_MAX_INLINE 32
+#define QA_ADAM_MAX_INLINE 64
 int qa_clip_adam_step_hostgrads(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
                                 float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
                                 const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,

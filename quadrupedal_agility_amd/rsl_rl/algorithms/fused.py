@@ -357,7 +357,7 @@ class ClipAdam:
             self._build(items)          # first use, or load_state_dict() replaced the state tensors
         t = self._tab
         ptrs = [p.grad.data_ptr() for p in params]
-        inline = len(ptrs) <= 32                        # QA_ADAM_MAX_INLINE: the pointers ride in the kernel arguments, no table copy
+        inline = len(ptrs) <= 64                        # QA_ADAM_MAX_INLINE: the pointers ride in the kernel arguments, no table copy
         if not inline and ptrs != t["grad_ptrs"]:       # autograd allocated new gradient tensors: refresh the pointer table
             if t.get("copied") is not None:
                 t["copied"].synchronize()               # the pinned staging buffer may still be waiting for its last async copy

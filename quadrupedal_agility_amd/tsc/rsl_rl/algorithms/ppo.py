@@ -9,10 +9,13 @@ the advantage (:222-234).  The entropy bonus adds the categorical entropy to the
 MI355X: networks run through the fused Linear+ELU backward; the three Adam steps (policy / estimator / history
 encoder) are the 3-launch `qa_clip_adam_step`; GAE is `qa_gae`; the adaptive learning rate is decided on the device
 (no `.item()` in the minibatch loop, the losses are accumulated on the device and read once per update)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.optim as optim
 
+from quadrupedal_agility_amd.rsl_rl.algorithms import fused
 from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam
 from ..storage import RolloutStorage
 
@@ -23,16 +26,18 @@ class PPO:
                  entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="fixed",
                  desired_kl=0.01, device="cpu", dagger_update_freq=20, priv_reg_coef_schedual=[0, 0, 0], **kwargs):
         self.device = device
-        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.desired_kl, self.schedule, self._learning_rate = desired_kl, schedule, learning_rate
         self.actor_critic = actor_critic.to(device)
         self.actor_critic_bbc = actor_critic_bbc.to(device) if actor_critic_bbc is not None else None
         self.storage = None
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        # ROCm: `step` counters on the device (capturable) -- what qa_clip_adam_step needs, and what lets a step be recorded
+        adam = dict(fused=True, capturable=True) if torch.device(device).type == "cuda" else {}
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, **adam)
         self.transition = RolloutStorage.Transition()
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
-        self.hist_encoder_optimizer = optim.Adam(self.actor_critic.actor.history_encoder.parameters(), lr=learning_rate)
+        self.hist_encoder_optimizer = optim.Adam(self.actor_critic.actor.history_encoder.parameters(), lr=learning_rate, **adam)
         self.priv_reg_coef_schedual = priv_reg_coef_schedual
         self.counter = 0
         self.estimator = estimator
@@ -40,10 +45,13 @@ class PPO:
         self.num_prop = estimator_paras["num_prop"]
         self.num_auxiliary = estimator_paras["num_auxiliary"]
         self.num_scan = estimator_paras["num_scan"]
-        self.estimator_optimizer = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"])
+        self.estimator_optimizer = optim.Adam(self.estimator.parameters(), lr=estimator_paras["learning_rate"], **adam)
         self.train_with_estimated_states = estimator_paras["train_with_estimated_states"]
         # depth encoder + student actor (:82-93): the student optimiser steps BOTH nets, BYOL has its own over the shared backbone
         self.grad_sync = None          # data-parallel runs: GradSync of the BBC tree's runner (one flat all-reduce per optimiser step)
+        # the minibatch step as recorded launches (hipGraph): see _update_recorded
+        self.use_update_graph = os.environ.get("QA_TSC_UPDATE_GRAPH", "1") != "0"
+        self._graph, self._warm_updates, self._lr_dev = None, 0, None
         self.if_depth = depth_encoder is not None
         if self.if_depth:
             self.depth_encoder, self.depth_encoder_paras, self.depth_actor = depth_encoder, depth_encoder_paras, depth_actor
@@ -55,6 +63,31 @@ class PPO:
         self._step_ac = ClipAdam(self.optimizer, max_grad_norm)
         self._step_estimator = ClipAdam(self.estimator_optimizer, max_grad_norm)
         self._step_hist = ClipAdam(self.hist_encoder_optimizer, max_grad_norm)
+
+    # ---- the learning rate lives on the host until the update is recorded, then in a device scalar the recorded LR rule writes and
+    # the recorded Adam step reads (no host value decides anything inside a replay)
+    @property
+    def learning_rate(self):
+        return float(self._lr_dev) if self._lr_dev is not None else self._learning_rate
+
+    @learning_rate.setter
+    def learning_rate(self, value):
+        self._learning_rate = float(value)
+        if self._lr_dev is not None:
+            self._lr_dev.fill_(float(value))
+
+    def lr_to_host(self):
+        """param_groups carry a plain float again (checkpoints: optimizer.state_dict() must not hold a device tensor)"""
+        lr = self.learning_rate
+        self._learning_rate = lr
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+
+    def lr_to_device(self):
+        if self._lr_dev is not None:
+            self._lr_dev.fill_(float(self.optimizer.param_groups[0]["lr"]) if not torch.is_tensor(self.optimizer.param_groups[0]["lr"]) else float(self._lr_dev))
+            for g in self.optimizer.param_groups:
+                g["lr"] = self._lr_dev
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
@@ -124,17 +157,29 @@ class PPO:
             if self.grad_sync is not None:      # every rank takes the same LR branch
                 kl = self.grad_sync.mean_scalar(kl)
             kl = kl.item()
+        lr = self.learning_rate
         if kl > self.desired_kl * 2.0:
-            self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+            lr = max(1e-5, lr / 1.5)
         elif 0.0 < kl < self.desired_kl / 2.0:
-            self.learning_rate = min(1e-2, self.learning_rate * 1.5)
-        for g in self.optimizer.param_groups:
-            g["lr"] = self.learning_rate
+            lr = min(1e-2, lr * 1.5)
+        self.learning_rate = lr
+        if self._lr_dev is None:
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
 
     def update(self):
         ac = self.actor_critic
-        sums = torch.zeros(4, device=self.device)          # value, surrogate, estimator, priv_reg
         coef = self._priv_reg_coef_now()
+        if (self.use_update_graph and self._graph is not False and self._warm_updates >= 1 and fused.ENABLED and torch.device(self.device).type == "cuda"
+                and self.desired_kl is not None and self.schedule == "adaptive"):
+            sums = self._update_recorded(coef)
+            if sums is not None:
+                v, s, e, p = (sums / (self.num_learning_epochs * self.num_mini_batches)).tolist()
+                self.storage.clear()
+                self.update_counter()
+                return v, s, e, 0.0, 0.0, p, coef
+        self._warm_updates += 1
+        sums = torch.zeros(4, device=self.device)          # value, surrogate, estimator, priv_reg
         priv = self._priv_slice(True)
         for (obs, cobs, actions, target_values, adv, returns, old_logp_d, old_logp_c, old_mu, old_sigma, _h, _m) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
@@ -181,6 +226,140 @@ class PPO:
         self.storage.clear()
         self.update_counter()
         return v, s, e, 0.0, 0.0, p, coef
+
+    def _minibatch_losses(self, batch, hist_latent, coef):
+        """forward of one minibatch (the body of update(), :222-262) -> (est_loss, loss, kl, [value, surrogate, priv_reg])"""
+        ac = self.actor_critic
+        obs, cobs, actions, target_values, adv, returns, old_logp_d, old_logp_c, old_mu, old_sigma = batch
+        ac._distributions(obs, False)          # the reference calls act() here and throws the sample away (:224); no draw is recorded
+        logp_d = ac.get_actions_log_prob_d(actions[:, 0])
+        logp_c = ac.get_actions_log_prob_c(actions[:, 1:])
+        value = ac.evaluate(cobs)
+        mu, sigma = ac.action_mean, ac.action_std
+        entropy = ac.entropy_c + ac.entropy_d
+        priv_reg_loss = (ac.actor.infer_priv_latent(obs) - hist_latent).norm(p=2, dim=1).mean()
+        est_loss = (self.estimator(obs[:, :self.num_prop]) - obs[:, self._priv_slice(True)]).pow(2).mean()
+        with torch.no_grad():
+            kl = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square()) / (2.0 * sigma.square()) - 0.5, dim=-1).mean()
+        a = adv.squeeze(-1)
+        surrogate = self._clipped_surrogate(logp_d, old_logp_d, a) + self._clipped_surrogate(logp_c, old_logp_c, a)
+        if self.use_clipped_value_loss:
+            clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+        else:
+            value_loss = (returns - value).pow(2).mean()
+        loss = surrogate + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean() + coef * priv_reg_loss
+        return est_loss, loss, kl, [value_loss.detach(), surrogate.detach(), est_loss.detach(), priv_reg_loss.detach()]
+
+    def _update_recorded(self, coef):
+        """The 20 minibatch steps of update() as replays of recorded launches (hipGraph).  One step -- nine indexed reads of the
+        rollout, estimator / actor / critic forward, the two clipped surrogates, both backward passes, clipping, the KL-adaptive
+        learning rate (on the device) and the two Adam steps -- is ~400 launches of mostly small kernels: at the 1024 envs per GPU of
+        BASELINE's 8-GPU teacher job the host cannot issue them as fast as the GPU retires them.  Per step the host copies the next
+        index slice and replays.  The privileged-latent regulariser's target (history encoder, not trained by these steps) is evaluated
+        once per update for the whole rollout.  Data-parallel runs record the step as TWO graphs around the gradient collective:
+        [gather .. both backward passes, gradients + KL packed into a persistent bucket] -> all-reduce(bucket) -> [unpack, LR rule,
+        both Adam steps].  Returns the summed losses, or None when capture is not possible (the caller stays eager)."""
+        from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
+        dev, st, ac = self.device, self.storage, self.actor_critic
+        batch = st.num_envs * st.num_transitions_per_env
+        mb = batch // self.num_mini_batches
+        flat = [x.flatten(0, 1) for x in (st.observations, st.actions, st.values, st.advantages, st.returns, st.actions_log_prob_d,
+                                          st.actions_log_prob_c, st.mu, st.sigma)]
+        if self._graph is None:
+            try:
+                self._mb_idx = torch.zeros(mb, dtype=torch.int64, device=dev)
+                self._acc = torch.zeros(4, device=dev)
+                self._coef_dev = torch.zeros((), device=dev)
+                self._hist_latent_all = torch.zeros(batch, ac.actor.infer_hist_latent(flat[0][:2]).shape[1], device=dev)
+                self._lr_dev = torch.full((), float(self._learning_rate), dtype=torch.float32, device=dev)
+                for g in self.optimizer.param_groups:
+                    g["lr"] = self._lr_dev
+                sync = self.grad_sync
+                params = list(self.estimator.parameters()) + list(ac.parameters())
+
+                cflat = st.privileged_observations.flatten(0, 1) if st.privileged_observations is not None else None
+
+                def front():
+                    rows = [x[self._mb_idx] for x in flat]
+                    rows.insert(1, cflat[self._mb_idx] if cflat is not None else rows[0])
+                    est_loss, loss, kl, stats = self._minibatch_losses(rows, self._hist_latent_all[self._mb_idx], self._coef_dev)
+                    est_loss.backward()
+                    loss.backward()
+                    return kl, torch.stack(stats)
+
+                def apply(kl):
+                    self._step_estimator.step()
+                    fused.kl_lr_rule(kl, self.desired_kl, self._lr_dev)
+                    self._step_ac.step()
+
+                # autograd keeps one AccumulateGrad node per parameter, tied to the stream it was first used on and alive as long as
+                # any graph references it: drop what the eager update left (the modules' distribution objects hold a graph), then run
+                # one forward + backward on a side stream so that the nodes the capture meets were not made on the default stream
+                ac.distribution_d = ac.distribution_c = None
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.optimizer.zero_grad(set_to_none=True); self.estimator_optimizer.zero_grad(set_to_none=True)
+                    front()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                ac.distribution_d = ac.distribution_c = None
+                gc.collect()
+                self.optimizer.zero_grad(set_to_none=True); self.estimator_optimizer.zero_grad(set_to_none=True)
+                if sync is None:
+                    g = torch.cuda.CUDAGraph()
+                    with _no_gc(), torch.cuda.graph(g):
+                        kl, stats = front()
+                        apply(kl.reshape(()))
+                        self._acc.add_(stats)
+                    self._graph = (g, None)
+                else:
+                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    pool = torch.cuda.graph_pool_handle()
+                    with _no_gc(), torch.cuda.graph(ga, pool=pool):
+                        kl, self._stats_tmp = front()
+                        grads = [p.grad for p in params if p.grad is not None]
+                        packed = grads + [kl.detach().reshape(1)]
+                        self._bucket = torch._utils._flatten_dense_tensors(packed)          # lives in the graphs' pool
+                    with _no_gc(), torch.cuda.graph(gb, pool=pool):
+                        self._bucket.div_(sync.world)
+                        parts = torch._utils._unflatten_dense_tensors(self._bucket, packed)
+                        torch._foreach_copy_(grads, list(parts[:len(grads)]))
+                        apply(parts[-1].reshape(()))
+                        self._acc.add_(self._stats_tmp)
+                    self._graph = (ga, gb)
+                # the capture ran no kernels: parameters, Adam moments and the LR are untouched; the replays below do this update
+            except Exception as e:      # never fatal: the eager loop is the same arithmetic
+                print(f"[tsc ppo update graph] capture failed, staying eager: {e}")
+                if os.environ.get("QA_DEBUG_GRAPH"):
+                    import traceback
+                    traceback.print_exc()
+                self._graph = False
+                torch.cuda.synchronize()
+                if self._lr_dev is not None:
+                    lr = float(self._learning_rate)
+                    self._lr_dev = None
+                    for g in self.optimizer.param_groups:
+                        g["lr"] = lr
+                return None
+        self._coef_dev.fill_(float(coef))
+        self._acc.zero_()
+        with torch.no_grad():
+            self._hist_latent_all.copy_(ac.actor.infer_hist_latent(flat[0]))
+        ga, gb = self._graph
+        perm = torch.randperm(self.num_mini_batches * mb, device=dev)          # one permutation for all epochs (:122-170)
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                self._mb_idx.copy_(perm[i * mb:(i + 1) * mb])
+                ga.replay()
+                if gb is not None:
+                    self.grad_sync.all_reduce_(self._bucket)
+                    gb.replay()
+        return self._acc.clone()
 
     def update_dagger(self):
         ac = self.actor_critic

@@ -31,6 +31,9 @@ class OnPolicyRunner:
         self.policy_cfg, self.estimator_cfg = train_cfg["policy"], train_cfg["estimator"]
         self.depth_encoder_cfg = train_cfg["depth_encoder"]
         self.device, self.env = device, env
+        if torch.device(device).type == "cuda":          # the committed hipBLASLt / rocBLAS picks for this learner's fp32 GEMM shapes
+            from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import enable_tuned_gemms
+            self.tuned_gemms = enable_tuned_gemms()
         e = env.cfg.env
         self.num_obs, self.n_proprio, self.n_auxiliary, self.n_scan = env.num_obs, e.n_proprio, e.n_auxiliary, e.n_scan
         self.n_priv, self.n_priv_latent, self.history_len = e.n_priv, e.n_priv_latent, e.history_len
@@ -337,12 +340,14 @@ class OnPolicyRunner:
 
     # ------------------------------------------------------------------ checkpoints (:443-520: same keys)
     def save(self, path, infos=None):
+        self.alg.lr_to_host()                    # the optimiser's state dict carries a plain float learning rate, as the reference's
         d = {"model_state_dict": self.alg.actor_critic.state_dict(), "estimator_state_dict": self.alg.estimator.state_dict(),
              "optimizer_state_dict": self.alg.optimizer.state_dict(), "iter": self.current_learning_iteration, "infos": infos}
         if self.if_depth:                        # :618-620
             d["depth_encoder_state_dict"] = self.alg.depth_encoder.state_dict()
             d["depth_actor_state_dict"] = self.alg.depth_actor.state_dict()
         torch.save(d, path)
+        self.alg.lr_to_device()
 
     def load(self, path, load_optimizer=True):
         d = torch.load(path, map_location=self.device, weights_only=False)
@@ -357,6 +362,12 @@ class OnPolicyRunner:
                 self.alg.depth_actor.load_state_dict(self.alg.actor_critic.actor.state_dict())
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+            self.alg.learning_rate = float(self.alg.optimizer.param_groups[0]["lr"])      # the loaded rate, on the host and (if recorded) the device
+            self.alg.lr_to_device()
+            if torch.device(self.device).type == "cuda":      # the loaded group dict overwrote the flags; recorded launches hold the old state's addresses
+                for g in self.alg.optimizer.param_groups:
+                    g["capturable"], g["fused"] = True, True
+                self.alg._graph, self.alg._warm_updates = None, 0
         self.current_learning_iteration = d["iter"]
         return d["infos"]
 

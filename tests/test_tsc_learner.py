@@ -70,11 +70,12 @@ def test_hybrid_action_layout_and_log_probs():
     assert torch.equal(inf[:, 0], probs.argmax(-1).float())
 
 
-def test_depth_heads_are_refused_loudly():
+def test_depth_heads_are_optional_as_in_the_reference():
+    """ppo.py:82-93: depth_encoder None = teacher training only (no student optimisers); the student path is tests/test_tsc_depth.py"""
     mods, algs = _mine()
     ac, bbc, est, _ = P.build(mods, algs)
-    with pytest.raises(NotImplementedError):
-        algs.PPO(ac, bbc, est, P.ESTIMATOR, object(), {}, None)
+    alg = algs.PPO(ac, bbc, est, P.ESTIMATOR, None, {}, None)
+    assert not alg.if_depth and not hasattr(alg, "depth_actor_optimizer") and alg.update_depth_actor(*[None] * 7) is None
 
 
 @pytest.mark.gpu
@@ -113,3 +114,36 @@ def test_gpu_update_matches_cpu_mirror():
     np.testing.assert_allclose(g["update"], c["update"], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(g["probe"], c["probe"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(g["probe_est"], c["probe_est"], rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.gpu
+def test_recorded_update_equals_eager_update():
+    """PPO._update_recorded (the minibatch step as hipGraph replays, LR rule + both Adam steps on the device) against the eager
+    loop on the same stored rollout and the same permutation: same parameters, same learning rate, same loss read-out"""
+    mods, algs = _mine()
+    res, N = {}, 512                                          # minibatches of 1536 rows
+
+    for mode in ("eager", "recorded"):
+        ac, bbc, est, _ = P.build(mods, algs)
+        cfg = dict(P.ALGO, num_mini_batches=2, num_learning_epochs=3, schedule="adaptive", desired_kl=0.01)
+        est.to("cuda")
+        alg = algs.PPO(ac, bbc, est, P.ESTIMATOR, None, None, None, device="cuda", **cfg)
+        alg.use_update_graph = mode == "recorded"
+        alg.init_storage(N, P.T, [800], [None], [19])
+        for it in range(3):                                   # update 0 is eager in both (it creates the Adam state); 1 records; 2 replays
+            torch.manual_seed(5 + it)
+            with torch.inference_mode():
+                for t in range(P.T):
+                    o = P.det((N, 800), 100 + t + 50 * it).cuda()
+                    alg.act(o, o, None)
+                    alg.process_env_step(P.det((N,), 200 + t).cuda(), (P.det((N,), 300 + t) > 0.8).cuda(), {})
+                alg.compute_returns(P.det((N, 800), 500).cuda())
+            torch.manual_seed(99 + it)                        # the permutation of this update
+            out = alg.update()
+        assert (alg._graph not in (None, False)) == (mode == "recorded")
+        res[mode] = dict(update=np.asarray(out), lr=alg.learning_rate, probe=P.param_probe(ac.cpu()), probe_est=P.param_probe(est.cpu()))
+    e, r = res["eager"], res["recorded"]
+    assert r["lr"] == pytest.approx(e["lr"], rel=1e-6) and e["lr"] != P.ALGO.get("learning_rate", 1e-3)     # the rule moved it, the same way
+    np.testing.assert_allclose(r["update"], e["update"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(r["probe"], e["probe"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(r["probe_est"], e["probe_est"], rtol=2e-3, atol=2e-3)
