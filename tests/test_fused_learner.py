@@ -771,11 +771,11 @@ def test_discriminator_chain_matches_module():
 
 @pytest.mark.gpu
 def test_clip_adam_pointer_table_path_with_many_tensors():
-    """more than QA_ADAM_MAX_INLINE (32) gradient tensors: the device pointer table path (fewer: the pointers ride in the kernel
+    """more than QA_ADAM_MAX_INLINE (64) gradient tensors: the device pointer table path (fewer: the pointers ride in the kernel
     arguments) -- both against torch.optim.Adam + clip_grad_norm_"""
     from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam
     torch.manual_seed(0)
-    mk = lambda: torch.nn.ModuleList([torch.nn.Linear(7 + i % 5, 3 + i % 4) for i in range(20)]).cuda()      # 40 tensors
+    mk = lambda: torch.nn.ModuleList([torch.nn.Linear(7 + i % 5, 3 + i % 4) for i in range(40)]).cuda()      # 80 tensors
     a, b = mk(), mk()
     b.load_state_dict(a.state_dict())
     kw = dict(lr=torch.tensor(1e-3, device="cuda"), fused=True, capturable=True)
@@ -789,6 +789,6 @@ def test_clip_adam_pointer_table_path_with_many_tensors():
         torch.nn.utils.clip_grad_norm_(a.parameters(), 0.5)
         oa.step()
         stepper.step()
-    assert stepper._tab is not None and stepper._tab["n"] == 40 and stepper._tab["grad_ptrs"] is not None
+    assert stepper._tab is not None and stepper._tab["n"] == 80 and stepper._tab["grad_ptrs"] is not None
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.allclose(p, q, rtol=2e-5, atol=2e-7)
