@@ -261,6 +261,10 @@ int qa_env_physics_step(qa_sim *sim, const float *actions, int32_t delay_steps, 
  * caller (TaskLevelBookkeeping.reset_idx). */
 int qa_tsc_reset(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range,
                  float rand_x_range, float rand_y_range, float rand_pitch_range, int64_t global_step, void *stream);
+/* the same with the step key read from device memory at execution time (a recorded rollout replays this launch: a by-value key
+ * would repeat the same draws every replay) */
+int qa_tsc_reset_dev(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range,
+                     float rand_x_range, float rand_y_range, float rand_pitch_range, const int64_t *global_step_dev, void *stream);
 
 /* qa_simulate only if *cond_dev != 0 (one device byte): the reference's reset_idx runs one more gym.simulate -- for EVERY env,
  * with the actuation forces set last -- whenever at least one env resets (:382-384).  torques == NULL applies QA_T_TORQUES. */
@@ -660,6 +664,7 @@ typedef struct qa_tsc_depth_io {
      * the (2^S + 1)^2 samples those cells touch.  It only lets the march skip samples that cannot report a hit: the image does not
      * depend on it (the CPU twin ignores it). */
     const int16_t *coarse_floor_max, *coarse_ceiling_min;
+    const int64_t *step_dev;             /* optional: the noise key's step read from device memory at execution time instead of cfg.step */
 } qa_tsc_depth_io;
 int qa_tsc_depth_update(const qa_tsc_depth_cfg *cfg, const qa_tsc_depth_io *io, void *stream);
 

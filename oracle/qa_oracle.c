@@ -1097,6 +1097,13 @@ int qo_env_physics_step(qo_sim *s, const float *actions, int32_t delay_steps, vo
 
 /* the simulator part of the task-level reset_idx (tsc/legged_gym/envs/base/legged_robot.py:348-410, 796-884) */
 int qo_tsc_reset(qo_sim *s, const uint8_t *flags, const float *start_xy, const float *start_yaw, float yaw_range, float x_range, float y_range,
+                 float pitch_range, int64_t step, void *stream);
+int qo_tsc_reset_dev(qo_sim *s, const uint8_t *flags, const float *start_xy, const float *start_yaw, float yaw_range, float x_range, float y_range,
+                     float pitch_range, const int64_t *step_dev, void *stream) {
+    if (!step_dev) return QA_E_ARG;
+    return qo_tsc_reset(s, flags, start_xy, start_yaw, yaw_range, x_range, y_range, pitch_range, *step_dev, stream);
+}
+int qo_tsc_reset(qo_sim *s, const uint8_t *flags, const float *start_xy, const float *start_yaw, float yaw_range, float x_range, float y_range,
                  float pitch_range, int64_t step, void *stream) {
     (void)stream;
     if (!s || !flags || !start_xy || !start_yaw) return QA_E_ARG;
@@ -2019,7 +2026,8 @@ int qo_tsc_depth_update(const qa_tsc_depth_cfg *c, const qa_tsc_depth_io *io, vo
         double o[3];
         for (int i = 0; i < 3; ++i) o[i] = rs[i] + R[3 * i] * c->position[0] + R[3 * i + 1] * c->position[1] + R[3 * i + 2] * c->position[2];
         uint32_t r0[4];
-        philox(c->seed, (uint32_t)(e + c->env_id_offset), (uint32_t)c->step, (uint32_t)(QA_TSC_DEPTH_STREAM * 256), (uint32_t)((uint64_t)c->step >> 32), r0);
+        const int64_t kstep = io->step_dev ? *io->step_dev : c->step;
+        philox(c->seed, (uint32_t)(e + c->env_id_offset), (uint32_t)kstep, (uint32_t)(QA_TSC_DEPTH_STREAM * 256), (uint32_t)((uint64_t)kstep >> 32), r0);
         const float amp = c->depth_noise * ((float)(r0[0] >> 8) * (1.0f / 16777216.0f));
         const float offs = c->depth_noise * 2.0f * ((float)(r0[1] >> 8) * (1.0f / 16777216.0f) - 0.5f);
         float *buf = io->depth_buffer + e * c->buffer_len * npix;
@@ -2070,7 +2078,7 @@ int qo_tsc_depth_update(const qa_tsc_depth_cfg *c, const qa_tsc_depth_io *io, vo
             double dd = hit < near ? near : (hit > far ? far : hit);
             float v = (float)((dd - near) / (far - near) - 0.5);
             uint32_t rp[4];
-            philox(c->seed, (uint32_t)(e + c->env_id_offset), (uint32_t)c->step, (uint32_t)(QA_TSC_DEPTH_STREAM * 256 + 1 + (p >> 2)), (uint32_t)((uint64_t)c->step >> 32), rp);
+            philox(c->seed, (uint32_t)(e + c->env_id_offset), (uint32_t)kstep, (uint32_t)(QA_TSC_DEPTH_STREAM * 256 + 1 + (p >> 2)), (uint32_t)((uint64_t)kstep >> 32), rp);
             v += offs + amp * 2.0f * ((float)(rp[p & 3] >> 8) * (1.0f / 16777216.0f) - 0.5f);
             if (init) for (int s = 0; s < c->buffer_len; ++s) buf[s * npix + p] = v;
             else { for (int s = 0; s + 1 < c->buffer_len; ++s) buf[s * npix + p] = buf[(s + 1) * npix + p]; buf[(c->buffer_len - 1) * npix + p] = v; }

@@ -97,6 +97,7 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "debug_post_physics"); f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "env_physics_step"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "tsc_reset"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_int64, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "tsc_reset_dev"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "simulate_if"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "gae"); f.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "ppo_loss")
@@ -227,7 +228,7 @@ class QaTscDepthCfg(C.Structure):
 
 
 TSC_DEPTH_IO_FIELDS = ("root_states", "camera_pitch", "height_samples", "ceiling_samples", "episode_length", "depth_buffer", "coarse_floor_max",
-                       "coarse_ceiling_min")
+                       "coarse_ceiling_min", "step_dev")
 
 
 class QaTscDepthIo(C.Structure):
@@ -236,7 +237,7 @@ class QaTscDepthIo(C.Structure):
 
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
-               "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
+               "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "tsc_reset_dev", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "elu_backward_bias",
                "elu_backward_bias_scratch_bytes", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "last_error", "abi_version"]
 
 _LIB = None

@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(256) qa_tsc_depth_kernel(DepthArgs a) {
     const float dd = fminf(fmaxf(hit, near), far);
     float v = (dd - near) / (far - near) - 0.5f;
     // noise (process_depth_image :166-168), Philox stream QA_TSC_DEPTH_STREAM keyed by (seed; global env id, step)
-    const uint32_t env = (uint32_t)(e + c.env_id_offset), s_lo = (uint32_t)c.step, s_hi = (uint32_t)((uint64_t)c.step >> 32);
+    const int64_t step = a.io.step_dev ? *a.io.step_dev : c.step;
+    const uint32_t env = (uint32_t)(e + c.env_id_offset), s_lo = (uint32_t)step, s_hi = (uint32_t)((uint64_t)step >> 32);
     const U4 r0 = philox(c.seed, env, s_lo, (uint32_t)(QA_TSC_DEPTH_STREAM * 256), s_hi);
     const U4 rp = philox(c.seed, env, s_lo, (uint32_t)(QA_TSC_DEPTH_STREAM * 256 + 1 + (p >> 2)), s_hi);
     const float amp = c.depth_noise * ((float)(r0.v[0] >> 8) * (1.0f / 16777216.0f));

@@ -1286,7 +1286,8 @@ int qa_simulate_if(qa_sim *s, const float *torques, const uint8_t *cond_dev, voi
 
 // reset_idx of the task-level env for the flagged envs (tsc/legged_gym/envs/base/legged_robot.py:348-410, 796-884): one thread per env
 __global__ void qa_tsc_reset_kernel(qa_config c, Ptrs p, const uint8_t *flags, const float *start_xy, const float *start_yaw, float yaw_range,
-                                    float x_range, float y_range, float pitch_range, int64_t step) {
+                                    float x_range, float y_range, float pitch_range, int64_t step, const int64_t *step_ptr) {
+    if (step_ptr) step = *step_ptr;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.num_envs) return;
     float *lr = p.last_root_vel + (int64_t)e * 6;
@@ -1323,7 +1324,17 @@ int qa_tsc_reset(qa_sim *s, const uint8_t *reset_flags, const float *start_xy, c
     if (!s || !reset_flags || !start_xy || !start_yaw) return QA_E_ARG;
     const int N = s->cfg.num_envs;
     hipLaunchKernelGGL(qa_tsc_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->cfg, s->p, reset_flags, start_xy, start_yaw,
-                       rand_yaw_range, rand_x_range, rand_y_range, rand_pitch_range, global_step);
+                       rand_yaw_range, rand_x_range, rand_y_range, rand_pitch_range, global_step, (const int64_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return QA_OK;
+}
+
+int qa_tsc_reset_dev(qa_sim *s, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range, float rand_x_range,
+                     float rand_y_range, float rand_pitch_range, const int64_t *global_step_dev, void *stream) {
+    if (!s || !reset_flags || !start_xy || !start_yaw || !global_step_dev) return QA_E_ARG;
+    const int N = s->cfg.num_envs;
+    hipLaunchKernelGGL(qa_tsc_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, s->cfg, s->p, reset_flags, start_xy, start_yaw,
+                       rand_yaw_range, rand_x_range, rand_y_range, rand_pitch_range, (int64_t)0, global_step_dev);
     HIP_TRY(hipGetLastError());
     return QA_OK;
 }

@@ -77,7 +77,12 @@ class QaSim:
         _check(self.lib.qa_env_physics_step(self.h, actions.data_ptr(), int(delay), self._stream()), self.lib, "qa_env_physics_step")
 
     def tsc_reset(self, flags, start_xy, start_yaw, yaw_range, x_range, y_range, pitch_range, step):
+        """`step`: the draws' key -- an int, or a 1-element int64 device tensor read when the launch executes (recorded rollouts)"""
         assert flags.is_cuda and flags.dtype == torch.uint8 and start_xy.is_contiguous() and start_yaw.is_contiguous()
+        if torch.is_tensor(step):
+            assert step.is_cuda and step.dtype == torch.int64
+            return _check(self.lib.qa_tsc_reset_dev(self.h, flags.data_ptr(), start_xy.data_ptr(), start_yaw.data_ptr(), float(yaw_range), float(x_range),
+                                                    float(y_range), float(pitch_range), step.data_ptr(), self._stream()), self.lib, "qa_tsc_reset_dev")
         _check(self.lib.qa_tsc_reset(self.h, flags.data_ptr(), start_xy.data_ptr(), start_yaw.data_ptr(), float(yaw_range), float(x_range),
                                      float(y_range), float(pitch_range), int(step), self._stream()), self.lib, "qa_tsc_reset")
 

@@ -157,6 +157,9 @@ class LeggedRobot:
                                torch.as_tensor(np.radians(ang), dtype=torch.float32), seed=seed, env_id_offset=off)
         self.extras = {}
         self.global_counter = self.total_env_steps_counter = self.common_step_counter = 0
+        # common_step_counter's twin on the device: keys the reset / depth-noise draws and gates the push, so that a RECORDED rollout
+        # (the same launches replayed every iteration) draws fresh numbers and pushes on the right steps
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.cur_obst_idx = torch.zeros(self.num_envs, dtype=torch.long, device=dev)
         self._start_xy = torch.zeros(self.num_envs, 2, device=dev)
         self._start_yaw = torch.zeros(self.num_envs, device=dev)
@@ -225,7 +228,8 @@ class LeggedRobot:
         """:226-296"""
         bk, cfg = self.bk, self.cfg
         self.common_step_counter += 1
-        if cfg.domain_rand.push_robots and self.common_step_counter % int(cfg.domain_rand.push_interval) == 0:
+        self._step_dev.add_(1)
+        if cfg.domain_rand.push_robots:
             self._push_robots()        # before the goal step: its rewards read the pushed world velocity, as the reference's do (:643-644)
         bk.post_physics_step(self.root_states, self.contact_forces, self.rigid_body_states, action_hl_history_buf, want_ids=False)
         self.extras["reach_goal"] = bk.reach_goal_cutoff.view(torch.bool)
@@ -234,7 +238,7 @@ class LeggedRobot:
         self._reset(flags)
         upd = self.global_counter % cfg.depth.update_interval == 0
         if cfg.depth.use_camera and upd:
-            bk.update_depth_buffer(self.root_states, self.common_step_counter)       # :275, after the resets, before the observations
+            bk.update_depth_buffer(self.root_states, self._step_dev)                 # :275, after the resets, before the observations
         bk.compute_observations(self.root_states, self.dof_pos, self.dof_vel, self.action_history_buf, self.rigid_body_states,
                                 self.mass_params_tensor, self.friction_coeffs_tensor, self.motor_strength, update_yaw=upd)
         self._obs_disc_term.copy_(torch.where(flags.view(-1, 1) != 0, prev_disc, bk.obs_disc_buf))
@@ -263,7 +267,7 @@ class LeggedRobot:
         self.sim.tsc_reset(flags, self._start_xy, self._start_yaw,
                            e.rand_yaw_range if e.randomize_start_yaw else 0.0, e.rand_x_range if e.randomize_start_x else 0.0,
                            e.rand_y_range if e.randomize_start_y else 0.0, e.rand_pitch_range if (e.randomize_start_yaw and e.randomize_start_pitch) else 0.0,
-                           self.common_step_counter)
+                           self._step_dev if self._step_dev.is_cuda else self.common_step_counter)
         # extras["episode"]: mean episode sums of the resetting envs / episode length in seconds (:396-404), kept when nobody resets
         f = (flags != 0).to(torch.float32)
         cnt = f.sum()
@@ -280,9 +284,12 @@ class LeggedRobot:
             self.sim.simulate_if(None, torch.ones(1, dtype=torch.uint8, device=self.device))
 
     def _push_robots(self):
-        """:905-915"""
+        """:905-915, on the steps where common_step_counter % push_interval == 0 -- decided on the device (no host branch: the launch
+        sequence of a step is the same every step)"""
         m = self.cfg.domain_rand.max_push_vel_xy
-        self.root_states[:, 7:9] = (torch.rand(self.num_envs, 2, device=self.device) * 2 - 1) * m
+        now = (self._step_dev % int(self.cfg.domain_rand.push_interval)) == 0
+        push = (torch.rand(self.num_envs, 2, device=self.device) * 2 - 1) * m
+        self.root_states[:, 7:9] = torch.where(now, push, self.root_states[:, 7:9])
 
     def get_observations(self):
         return self.bk.obs_buf

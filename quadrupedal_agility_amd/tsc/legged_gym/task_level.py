@@ -248,7 +248,10 @@ class TaskLevelBookkeeping:
         io.episode_length, io.depth_buffer = self.episode_length_buf.data_ptr(), self.depth_buffer.data_ptr()
         io.coarse_floor_max = self._depth_coarse[0].data_ptr()
         io.coarse_ceiling_min = self._depth_coarse[1].data_ptr() if self._depth_coarse[1] is not None else None
-        self._dcfg.step = int(step)
+        if torch.is_tensor(step) and step.is_cuda:           # read when the launch executes (recorded rollouts)
+            io.step_dev = step.data_ptr()
+        else:
+            self._dcfg.step = int(step)
         self._check(self._fn("tsc_depth_update")(C.byref(self._dcfg), C.byref(io), self._stream()), "qa_tsc_depth_update")
         return self.depth_buffer
 

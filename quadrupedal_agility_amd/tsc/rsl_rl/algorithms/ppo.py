@@ -118,7 +118,13 @@ class PPO:
         tr.actions_log_prob_d = ac.get_actions_log_prob_d(tr.actions[:, 0]).detach()
         tr.actions_log_prob_c = ac.get_actions_log_prob_c(tr.actions[:, 1:]).detach()
         tr.action_mean, tr.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
-        tr.observations, tr.critic_observations = obs, critic_obs
+        # The env's observation rows are persistent buffers its kernels overwrite in place during step() (the reference's env builds a
+        # new tensor every step, so holding a reference until process_env_step works there): the rows go into the rollout NOW.
+        t = self.storage.step
+        self.storage.observations[t].copy_(obs)
+        if self.storage.privileged_observations is not None:
+            self.storage.privileged_observations[t].copy_(critic_obs)
+        tr.observations = tr.critic_observations = None
         return tr.actions
 
     def act_bbc(self, obs):

@@ -118,8 +118,16 @@ class ActorCriticTSC(nn.Module):
     def act(self, observations, hist_encoding=False, **kwargs):
         """hybrid action (B, 1 + num_actions_d * num_actions_c): [gait index, parameter vector of every gait]"""
         self._distributions(observations, hist_encoding)
-        a_d = self.distribution_d.sample()
-        return torch.cat([a_d.unsqueeze(-1), self.distribution_c.sample()], dim=-1)
+        if observations.is_cuda:
+            # torch.multinomial validates its input with a host read (`.item()`), which stalls the stream every env step and cannot be
+            # recorded into a hipGraph; this is its own one-sample fast path (argmax of p / Exp(1)) without the check
+            p = self.distribution_d.probs
+            a_d = torch.argmax(p / torch.empty_like(p).exponential_(1.0), dim=-1)
+            mean = self.distribution_c.mean                  # torch.normal(mean, std) checks std >= 0 with a host read too
+            a_c = mean + self.distribution_c.stddev * torch.randn_like(mean)
+        else:
+            a_d, a_c = self.distribution_d.sample(), self.distribution_c.sample()
+        return torch.cat([a_d.unsqueeze(-1), a_c], dim=-1)
 
     def get_actions_log_prob_d(self, actions):
         return self.distribution_d.log_prob(actions)

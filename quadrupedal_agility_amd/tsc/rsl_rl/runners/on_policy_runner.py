@@ -91,6 +91,8 @@ class OnPolicyRunner:
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0, 0
         self.last_perf = {}
         self._bbc_chain = None
+        self._rs, self._rollout_graphs, self._rollout_warm = None, {}, 0
+        self.use_rollout_graph = os.environ.get("QA_TSC_ROLLOUT_GRAPH", "1") != "0"
         self.use_fused_policy = on_gpu and os.environ.get("QA_FUSED_POLICY", "1") != "0"
         env.sync_reset_ids = False              # rollouts never wait for the GPU
 
@@ -110,6 +112,92 @@ class OnPolicyRunner:
             self._bbc_chain = chain
         return lambda obs: self._bbc_chain.forward(obs)[0]
 
+    # ------------------------------------------------------------------ the teacher's rollout: eager or as recorded launches
+    KEYS = ("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")
+
+    def _alloc_rollout_state(self):
+        """Everything a rollout carries from one env step to the next lives in persistent tensors updated in place, so that the 24
+        steps can be recorded once and replayed (the env's own rows -- obs_buf, obs_bbc_buf, ... -- already are)."""
+        env, dev, N, T = self.env, self.device, self.env.num_envs, self.num_steps_per_env
+        d = env.get_observations_disc()
+        self._rs = dict(obs_bbc=env.get_observations_bbc().clone(), hist=torch.stack([d] * self.disc_obs_len, dim=1).clone(),
+                        ahist=torch.zeros(N, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev),
+                        cur=torch.zeros(6, N, device=dev), fin_vals=torch.zeros(T, 6, N, device=dev),
+                        fin_masks=torch.zeros(T, N, dtype=torch.bool, device=dev), fin_reach=torch.zeros(T, N, dtype=torch.bool, device=dev))
+        self._rollout_graphs = {}          # hist_encoding -> (graph, ep_infos) | False
+
+    def _rollout_steps(self, hist_encoding, logging):
+        """num_steps_per_env x (task policy -> set_commands -> frozen behaviour policy -> env.step -> discriminator reward -> storage)
+        (:167-246); returns the per-step `episode` dicts (device tensors)"""
+        env, alg, rs = self.env, self.alg, self._rs
+        bbc = self._behaviour_policy()
+        n_cmd = 6 + env.dim_c
+        obs = env.get_observations()
+        infos, ep_infos = {"depth": None}, []
+        for t in range(self.num_steps_per_env):
+            actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding)
+            rs["ahist"].copy_(torch.cat([rs["ahist"][:, 1:], actions[:, None, :]], dim=1))
+            rs["obs_bbc"][:, -n_cmd:] = env.set_commands(actions)
+            obs, privileged_obs, rewards, dones, infos, _ids, _term = env.step(bbc(rs["obs_bbc"]), rs["ahist"])
+            disc_obs = env.get_observations_disc()
+            # history of discriminator observations: the terminal row for envs that reset, then restart (:219-234)
+            hist = torch.cat([rs["hist"][:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
+            rewards, r_i, r_us, r_ss, r_t = self.discriminator.predict_disc_reward(rewards.unsqueeze(1), rs["obs_bbc"], hist)
+            total_rew = alg.process_env_step(rewards, dones, infos)
+            rs["obs_bbc"].copy_(env.get_observations_bbc())
+            done = dones != 0
+            rs["hist"].copy_(torch.where(done.view(-1, 1, 1), torch.stack([disc_obs] * self.disc_obs_len, dim=1), hist))
+            if logging:
+                if "episode" in infos:
+                    ep_infos.append(infos["episode"])
+                rs["cur"] += torch.stack([total_rew, r_i, r_us, r_ss, r_t, torch.ones_like(r_t)])
+                rs["fin_vals"][t].copy_(rs["cur"]); rs["fin_masks"][t].copy_(done); rs["fin_reach"][t].copy_(infos["reach_goal"])
+                rs["cur"] *= (~done).to(rs["cur"].dtype)
+        return ep_infos
+
+    def _collect(self, hist_encoding, logging):
+        """One rollout.  On the GPU the 24 steps are recorded into ONE hipGraph per actor variant (privileged / history encoder) the
+        first time they run and replayed afterwards: an eager step is ~180 launches and 1.8 ms of host time against 0.3 ms of kernels.
+        What makes the replays differ from each other lives on the device: the step counter that keys the env's draws and gates the
+        push (`env._step_dev`), torch's generator (graph-safe Philox offsets), the policy's weights."""
+        env, alg, T = self.env, self.alg, self.num_steps_per_env
+        key = (bool(hist_encoding), bool(logging))
+        if not (self.use_rollout_graph and torch.device(self.device).type == "cuda") or self._rollout_graphs.get(key) is False:
+            with torch.inference_mode():
+                return self._rollout_steps(hist_encoding, logging)
+        if key not in self._rollout_graphs:
+            if self._rollout_warm < 1:         # one eager rollout first: lazy initialisations (policy chain packing, library handles)
+                self._rollout_warm += 1
+                with torch.inference_mode():
+                    return self._rollout_steps(hist_encoding, logging)
+            from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
+            try:
+                self._behaviour_policy()
+                torch.cuda.synchronize()
+                counters = (env.global_counter, env.total_env_steps_counter, env.common_step_counter)
+                g = torch.cuda.CUDAGraph()
+                alg.storage.step = 0
+                with _no_gc(), torch.cuda.graph(g):
+                    with torch.inference_mode():
+                        ep_infos = self._rollout_steps(hist_encoding, logging)      # host side effects run now, GPU work on replay
+                env.global_counter, env.total_env_steps_counter, env.common_step_counter = counters
+                self._rollout_graphs[key] = (g, ep_infos)
+            except Exception as e:      # never fatal: the eager loop is the same code
+                print(f"[tsc rollout graph] capture failed, staying eager: {e}")
+                if os.environ.get("QA_DEBUG_GRAPH"):
+                    import traceback
+                    traceback.print_exc()
+                self._rollout_graphs[key] = False
+                torch.cuda.synchronize()
+                alg.storage.step = 0
+                with torch.inference_mode():
+                    return self._rollout_steps(hist_encoding, logging)
+        g, ep_infos = self._rollout_graphs[key]
+        g.replay()
+        alg.storage.step = T
+        env.global_counter += T; env.total_env_steps_counter += T; env.common_step_counter += T
+        return ep_infos
+
     def learn_RL(self, num_learning_iterations, init_at_random_ep_len=False):
         env, alg, dev = self.env, self.alg, self.device
         if self.log_dir is not None and self.writer is None:
@@ -117,67 +205,37 @@ class OnPolicyRunner:
             self.writer = _make_writer(self.log_dir)
         if init_at_random_ep_len:
             env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
-        obs, obs_bbc = env.get_observations(), env.get_observations_bbc().clone()
-        disc_obs = env.get_observations_disc()
-        hist = torch.stack([disc_obs] * self.disc_obs_len, dim=1).clone()
-        action_history_buf = torch.zeros(env.num_envs, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev)
-        critic_obs = obs
-        infos = {"depth": None}
+        if getattr(self, "_rs", None) is None:
+            self._alloc_rollout_state()
         alg.actor_critic.train()
-        bbc = self._behaviour_policy()
-        n_cmd = 6 + env.dim_c
-        ep_infos = []
-        keys = ("rew", "rew_i", "rew_us", "rew_ss", "rew_t", "len")
+        keys = self.KEYS
         buffers = {k: deque(maxlen=1000) for k in keys}
         reach_goal_buffer = deque(maxlen=1000)
-        cur = torch.zeros(6, env.num_envs, device=dev)
         logging = self.log_dir is not None
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
             hist_encoding = it % self.dagger_update_freq == 0
-            fin_vals, fin_masks, fin_reach = [], [], []
+            ep_infos = self._collect(hist_encoding, logging)
+            collection_time = time.time() - start
+            start = time.time()
             with torch.inference_mode():
-                for _ in range(self.num_steps_per_env):
-                    actions = alg.act(obs, critic_obs, infos, hist_encoding=hist_encoding)
-                    action_history_buf = torch.cat([action_history_buf[:, 1:], actions[:, None, :]], dim=1)
-                    next_commands = env.set_commands(actions)
-                    obs_bbc[:, -n_cmd:] = next_commands
-                    actions_bbc = bbc(obs_bbc)
-                    obs, privileged_obs, rewards, dones, infos, _ids, _term = env.step(actions_bbc, action_history_buf)
-                    critic_obs = privileged_obs if privileged_obs is not None else obs
-                    next_obs_bbc, disc_obs = env.get_observations_bbc(), env.get_observations_disc()
-                    # history of discriminator observations: the terminal row for envs that reset, then restart (:219-234)
-                    hist = torch.cat([hist[:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
-                    rewards, r_i, r_us, r_ss, r_t = self.discriminator.predict_disc_reward(rewards.unsqueeze(1), obs_bbc, hist)
-                    total_rew = alg.process_env_step(rewards, dones, infos)
-                    obs_bbc = next_obs_bbc.clone()
-                    done = dones != 0
-                    hist = torch.where(done.view(-1, 1, 1), torch.stack([disc_obs] * self.disc_obs_len, dim=1), hist)
-                    if logging:
-                        if "episode" in infos:
-                            ep_infos.append(infos["episode"])
-                        cur += torch.stack([total_rew, r_i, r_us, r_ss, r_t, torch.ones_like(r_t)])
-                        fin_vals.append(cur.clone()); fin_masks.append(done); fin_reach.append(infos["reach_goal"].clone())
-                        cur *= (~done).to(cur.dtype)
-                collection_time = time.time() - start
-                start = time.time()
-                alg.compute_returns(critic_obs)
+                alg.compute_returns(env.get_observations())
             losses = alg.update()
             mean_hist_latent_loss = alg.update_dagger() if hist_encoding else 0.0
             learn_time = time.time() - start
             if logging:            # ONE host read per iteration for the episode statistics
-                vals, masks, reach = torch.stack(fin_vals), torch.stack(fin_masks), torch.stack(fin_reach)
-                sel = vals.permute(0, 2, 1)[masks].cpu()
+                rs = self._rs
+                masks = rs["fin_masks"]
+                sel = rs["fin_vals"].permute(0, 2, 1)[masks].cpu()
                 for i, k in enumerate(keys):
                     buffers[k].extend(sel[:, i].tolist())
-                reach_goal_buffer.extend(reach[masks].float().cpu().tolist())
+                reach_goal_buffer.extend(rs["fin_reach"][masks].float().cpu().tolist())
                 if len(reach_goal_buffer) > 0:
                     env.success_rate = statistics.mean(reach_goal_buffer)
                 self._log(it, losses, mean_hist_latent_loss, collection_time, learn_time, buffers, ep_infos)
                 if it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, "model.pt"))
-            ep_infos.clear()
             self.last_perf = {"collection_time": collection_time, "learn_time": learn_time,
                               "fps": self.num_steps_per_env * env.num_envs / (collection_time + learn_time)}
         self.current_learning_iteration = tot_iter
@@ -384,6 +442,7 @@ class OnPolicyRunner:
         n = d["disc_normalizer"]
         self.discriminator.normalizer = TorchNormalizer.from_reference(n, self.device) if torch.device(self.device).type == "cuda" else n
         self._bbc_chain = None
+        self._rollout_graphs = {}                # recorded rollouts hold the old packed weights and normaliser
 
     def get_depth_actor_inference_policy(self, device=None):
         self.alg.depth_actor.eval()

@@ -47,9 +47,10 @@ class RolloutStorage:
         if self.step >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         t = self.step
-        self.observations[t].copy_(tr.observations)
-        if self.privileged_observations is not None:
-            self.privileged_observations[t].copy_(tr.critic_observations)
+        if tr.observations is not None:                 # PPO.act stores the rows itself, at act time (see there)
+            self.observations[t].copy_(tr.observations)
+            if self.privileged_observations is not None:
+                self.privileged_observations[t].copy_(tr.critic_observations)
         self.actions[t].copy_(tr.actions)
         self.rewards[t].copy_(tr.rewards.view(-1, 1))
         self.dones[t].copy_(tr.dones.view(-1, 1))

@@ -33,7 +33,7 @@ class OracleBackend:
     def tsc_reset(self, flags, start_xy, start_yaw, yaw_range, x_range, y_range, pitch_range, step):
         f, xy, yw = flags.contiguous(), start_xy.contiguous(), start_yaw.contiguous()
         assert self.o.lib.qo_tsc_reset(self.o.h, f.data_ptr(), xy.data_ptr(), yw.data_ptr(), C.c_float(yaw_range), C.c_float(x_range),
-                                       C.c_float(y_range), C.c_float(pitch_range), C.c_int64(int(step)), None) == 0
+                                       C.c_float(y_range), C.c_float(pitch_range), C.c_int64(int(step)), None) == 0     # int(tensor) reads the 1-element step tensor
 
     def simulate_if(self, torques, cond):
         assert self.o.lib.qo_simulate_if(self.o.h, torques.data_ptr() if torques is not None else None, cond.data_ptr(), None) == 0

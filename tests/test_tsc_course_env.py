@@ -239,3 +239,33 @@ def test_task_level_training_runs_on_gpu(tmp_path):
     assert all(torch.isfinite(v).all() for v in after.values()) and any(not torch.equal(before[k], after[k]) for k in before)
     assert runner._bbc_chain is not None                    # the frozen behaviour policy ran as ONE qa_mlp_forward launch per step
     assert runner.last_perf["fps"] > 2e3 and env.common_step_counter == 1 + 3 * 24
+
+
+@pytest.mark.gpu
+def test_recorded_rollout_advances_counters_and_draws_fresh_numbers(tmp_path):
+    """the teacher's 24-step rollout as ONE hipGraph replay per iteration: the device step counter (reset / push keys) follows the
+    host's, every replay samples new actions and meets new resets, logging still gets its per-step episode statistics, and the
+    statistics agree with an eager run of the same job"""
+    from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
+    out = {}
+    for mode in ("recorded", "eager"):
+        torch.manual_seed(0)
+        cfg = make_cfg(512, 1, env__episode_length_s=1.0, domain_rand__push_robots=True, obstacle__randomize_start=True, domain_rand__push_interval=7)
+        env = lr.LeggedRobot(cfg, sim_device="cuda:0")
+        runner = OnPolicyRunner(env, class_to_dict(Go2AgilityCfgPPO()), log_dir=str(tmp_path / mode), device="cuda:0")
+        runner.use_rollout_graph = mode == "recorded"
+        acts, dones, vel = [], [], []
+        for it in range(5):
+            runner.learn(1, init_at_random_ep_len=(it == 0))
+            st = runner.alg.storage
+            acts.append(st.actions.clone()); dones.append(st.dones.float().mean().item()); vel.append(env.root_states[:, 7:9].abs().mean().item())
+            assert int(env._step_dev) == env.common_step_counter == 1 + 24 * (it + 1)
+        if mode == "recorded":
+            assert any(isinstance(v, tuple) for v in runner._rollout_graphs.values())
+            assert not torch.equal(acts[-1], acts[-2]) and not torch.equal(acts[-2], acts[-3])       # replays draw new action noise
+        else:
+            assert not runner._rollout_graphs
+        out[mode] = (np.mean(dones[1:]), np.mean(vel[1:]), [l for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))][-1] if os.path.exists(os.path.join(runner.log_dir, "scalars.jsonl")) else "")
+    (d_r, v_r, _), (d_e, v_e, _) = out["recorded"], out["eager"]
+    assert d_r > 0.005 and abs(d_r - d_e) < 0.5 * d_e + 0.01         # episodes end (1 s episodes, terminations) at the same rate
+    assert abs(v_r - v_e) < 0.35 * v_e                                 # the robots move alike (pushes every 7 steps included)

@@ -147,3 +147,21 @@ def test_recorded_update_equals_eager_update():
     np.testing.assert_allclose(r["update"], e["update"], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(r["probe"], e["probe"], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(r["probe_est"], e["probe_est"], rtol=2e-3, atol=2e-3)
+
+
+def test_rollout_keeps_the_observation_the_action_was_drawn_from():
+    """the env overwrites its observation buffer in place during step(): the row stored for step t must be the one act() saw, not
+    what the buffer holds when process_env_step() runs (regression: the rows used to be copied there, one step late)"""
+    mods, algs = _mine()
+    ac, bbc, est, _ = P.build(mods, algs)
+    alg = algs.PPO(ac, bbc, est, P.ESTIMATOR, None, None, None, device="cpu", **P.ALGO)
+    alg.init_storage(P.N, P.T, [800], [None], [19])
+    buf = P.det((P.N, 800), 1).clone()
+    seen = []
+    for t in range(3):
+        seen.append(buf.clone())
+        alg.act(buf, buf, None)
+        buf.copy_(P.det((P.N, 800), 2 + t))                 # "env.step" rewrites the same tensor
+        alg.process_env_step(P.det((P.N,), 200 + t), P.det((P.N,), 300 + t) > 0.8, {})
+    for t in range(3):
+        assert torch.equal(alg.storage.observations[t], seen[t])
