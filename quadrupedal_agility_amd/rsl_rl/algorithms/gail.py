@@ -126,7 +126,10 @@ class SSInfoGAIL:
         self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
-        self.branch_streams = self._on_gpu and os.environ.get("QA_PPO_BRANCHES", "1") != "0"     # PPO step: critic / actor / small nets on three streams
+        # PPO step: critic / actor / small nets on three streams (config 2: update 32.2 -> 28.9 ms).  Not with the discriminator: its
+        # 80 recorded steps already run beside the PPO steps on their own stream, and three more streams of GEMMs starve them
+        # (config 3: update 61 -> 90 ms with both)
+        self.branch_streams = (self._on_gpu and os.environ.get("QA_PPO_BRANCHES", "1") != "0" and not (self.amp_enabled and self.overlap_updates))
         self._branch = None
 
     # ---- lr_ac is read by the logger and by checkpoints as a float

@@ -1,34 +1,38 @@
 #!/bin/bash
-# Round-end measurement pass on the GPU box: bench lines (configs 2, 3, terrain), rocprofv3 kernel stats of the default
-# bench command, PMC FETCH_SIZE / WRITE_SIZE passes of the env-step kernel (separate passes, kernel-trace only).
-# Outputs land in gpurun_out/final/ (small CSV/JSON only).
+# Round-end measurement pass on the GPU box (every command under its own timeout, stdin closed): bench lines of the BASELINE configs,
+# rocprofv3 kernel stats of the default bench command, PMC FETCH_SIZE / WRITE_SIZE passes of the env-step kernel (separate passes,
+# kernel-trace only).  Outputs land in gpurun_out/final/ (small CSV/JSON only); copy what is to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout 400 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
-timeout 400 python bench.py --amp --no_cpu_baseline > $O/bench_cfg3_amp.json 2> $O/bench_cfg3.err
-timeout 400 python bench.py --terrain trimesh --no_cpu_baseline > $O/bench_cfg2_trimesh.json 2> $O/bench_trimesh.err
-( export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 QA_FORCE_DATA_PARALLEL=1; timeout 400 python bench.py --no_cpu_baseline > $O/bench_cfg2_dp_path_1gpu.json 2> $O/bench_dp.err )
-python tools/policy_time.py 4096 > $O/policy_time.txt 2>&1
-python tools/policy_time.py 16384 >> $O/policy_time.txt 2>&1
-python tools/mlp_profile.py 4096 > $O/mlp_profile.txt 2>&1
-python tools/quick_time.py > $O/quick_time.txt 2>&1
-python tools/quick_time.py --terrain >> $O/quick_time.txt 2>&1
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof /tmp/pmc_f /tmp/pmc_w
-timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
-f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
-rm -rf /tmp/prof
-timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no_cpu_baseline --amp < /dev/null > /tmp/prof_amp.log 2>&1
-f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_cfg3_amp_kernel_stats.csv
-rm -rf /tmp/prof
-timeout 700 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --no_cpu_baseline --steps 4 < /dev/null > /tmp/prof_tr.log 2>&1
-f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/gap_report.py "$f" 0.7 > $O/gap_report.txt 2>&1 && python $R/tools/step_sequence.py "$f" > $O/step_sequence.txt 2>&1
-cd $R
+# PMC first: bench.py reads profiles/env_step_traffic.json for roofline.traffic
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python tools/pmc_env_step.py 4096 < /dev/null > /tmp/pmc_f.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python tools/pmc_env_step.py 4096 < /dev/null > /tmp/pmc_w.log 2>&1
-python tools/pmc_summarize.py /tmp/pmc_f > $O/pmc_fetch.txt 2>&1
-python tools/pmc_summarize.py /tmp/pmc_w > $O/pmc_write.txt 2>&1
+python tools/pmc_to_json.py /tmp/pmc_f /tmp/pmc_w 4096 $O/env_step_traffic.json > $O/pmc.txt 2>&1 && cp $O/env_step_traffic.json profiles/env_step_traffic.json
+timeout 500 python bench.py 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+timeout 400 python bench.py --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_amp.json
+timeout 400 python bench.py --terrain trimesh --no_cpu_baseline 2> $O/bench_trimesh.err < /dev/null | grep '"metric"' > $O/bench_cfg2_trimesh.json
+( export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 QA_FORCE_DATA_PARALLEL=1; timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_dp.err < /dev/null | grep '"metric"' > $O/bench_cfg2_dp_path_1gpu.json )
+timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu.json
+timeout 400 python bench.py --tsc --steps 6 --warmup 3 2> $O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_8192.json
+timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024.json
+timeout 600 python bench.py --tsc --vision --num_envs 2048 --steps 3 --warmup 2 2> $O/bench_vision.err < /dev/null | grep '"metric"' > $O/bench_tsc_student_2048.json
+timeout 400 python bench.py --tsc --vision --num_envs 512 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_512.json
+timeout 400 python bench.py --tsc --vision --num_envs 256 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_256.json
+timeout 200 python tools/quick_time.py > $O/quick_time.txt 2>&1 < /dev/null
+timeout 200 python tools/quick_time.py --terrain >> $O/quick_time.txt 2>&1 < /dev/null
+timeout 200 python tools/policy_time.py 4096 > $O/policy_time.txt 2>&1 < /dev/null
+timeout 200 python tools/substep_profile.py > $O/substep_profile.txt 2>&1 < /dev/null
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
+f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/gap_report.py "$f" 0.7 > $O/gap_report.txt 2>&1 && python $R/tools/step_sequence.py "$f" > $O/step_sequence.txt 2>&1
+grep '"metric"' /tmp/prof.log > $O/bench_under_rocprof.json
+rm -rf /tmp/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 6 --warmup 3 < /dev/null > /tmp/prof2.log 2>&1
+f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_tsc_kernel_stats.csv
+rm -rf /tmp/prof
 ls -la $O

@@ -1,0 +1,28 @@
+"""FETCH_SIZE / WRITE_SIZE passes (tools/pmc_env_step.py under rocprofv3 --pmc, one counter per pass) -> profiles/env_step_traffic.json.
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of wide coalesced reads -- checked here on the calibration copy of the same run (256 MiB read + 256 MiB written)
+and applied only if the calibration shows it.  usage: pmc_to_json.py FETCH_DIR WRITE_DIR NUM_ENVS OUT.json"""
+import collections, csv, glob, json, sys
+
+
+def means(d):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r.get("Kernel_Name", "")
+            key = "env" if "qa_env_step" in name else ("copy" if "copy" in name.lower() else None)
+            if key:
+                acc[key].append(float(r["Counter_Value"]))
+    return {k: sum(v[len(v) // 4:]) / len(v[len(v) // 4:]) for k, v in acc.items()}
+
+
+f, w = means(sys.argv[1]), means(sys.argv[2])
+n = int(sys.argv[3])
+copy_kib = 256 * 1024
+fetch_corr = round(copy_kib / f["copy"]) if "copy" in f else 2        # 2 on gfx950 (the guide), 1 if the counter were exact
+write_corr = round(copy_kib / w["copy"], 2) if "copy" in w else 1.0
+out = {"kernel": "qa_env_step_kernel", "num_envs": n, "fetch_size_kib": f["env"], "write_size_kib": w["env"], "fetch_correction": fetch_corr,
+       "write_calibration": write_corr, "calibration_copy_fetch_kib": f.get("copy"), "calibration_copy_write_kib": w.get("copy"),
+       "hbm_bytes_per_launch": int((f["env"] * fetch_corr + w["env"]) * 1024), "source": "tools/final_measure.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+json.dump(out, open(sys.argv[4], "w"))
+print(json.dumps(out))
