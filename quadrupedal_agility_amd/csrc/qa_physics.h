@@ -542,6 +542,16 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         slink[0] = g0; slink[1] = g1;
         extra_on[0] = g0 >= 0; extra_on[1] = g1 >= 0;
         any_extra[0] = __any(extra_on[0]); any_extra[1] = __any(extra_on[1]);
+#ifdef QA_EXP_NO_EXTRA
+        extra_on[0] = extra_on[1] = any_extra[0] = any_extra[1] = false;
+#endif
+#ifdef QA_EXP_COUNT_EXTRA
+        {
+            const bool real = __any((extra_on[0] && sgap[0] <= 0.f) || (extra_on[1] && sgap[1] <= 0.f));
+            const bool near2 = __any((extra_on[0] && sgap[0] <= 0.002f) || (extra_on[1] && sgap[1] <= 0.002f));
+            if (g_subprof && threadIdx.x == 0) { g_subprof[blockIdx.x * 32 + 30] += any_extra[0] ? 1 : 0; g_subprof[blockIdx.x * 32 + 31] += real ? 1 : 0; g_subprof[blockIdx.x * 32 + 29] += near2 ? 1 : 0; }
+        }
+#endif
     }
 
     QA_SUBSTAMP(7);

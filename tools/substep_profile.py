@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from quadrupedal_agility_amd import _capi
 _so = "/tmp/libqa_sim_subprof.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
-                       "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-DQA_SUBPROF", "-shared", "-fPIC", "-o", _so,
+                       "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-DQA_SUBPROF", *[a for a in sys.argv[1:] if a.startswith("-D")], "-shared", "-fPIC", "-o", _so,
                        "quadrupedal_agility_amd/csrc/qa_sim.hip", "quadrupedal_agility_amd/csrc/qa_learner.hip", "quadrupedal_agility_amd/csrc/qa_policy.hip", "quadrupedal_agility_amd/csrc/qa_tsc.hip", "quadrupedal_agility_amd/csrc/qa_depth.hip"])
 _capi.LIB_PATH = _so
 from tests.oracle_lib import go2_cfg
@@ -27,3 +27,6 @@ for _ in range(K):
 names = ["kinematics+link inertia", "composite+F+L", "bias (RNEA)", "Linv,G,Schur,6x6 inverse", "unconstrained vel", "contact candidates", "rows", "warm start", "PGS sweeps", "integrate"]
 for i in range(10): print(f"{names[i]:26s} {acc[i].item()/K:9.0f} cycles")
 print("substep total", acc.sum().item() / K)
+if "-DQA_EXP_COUNT_EXTRA" in sys.argv:
+    c = buf.view(-1, 32).cpu().double()[:, 29:32].sum(0) / (buf.numel() // 32 * K * 4)
+    print(f"fraction of (wavefront, substep) with a non-foot contact row somewhere in the wavefront: {c[1]:.3f}; with one at gap <= 0: {c[2]:.3f}; at gap <= 2 mm: {c[0]:.3f}")
