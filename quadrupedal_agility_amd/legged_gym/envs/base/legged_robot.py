@@ -69,6 +69,8 @@ class LeggedRobot:
         if backend is None:
             from quadrupedal_agility_amd.sim import QaSim
             backend = QaSim(self.qcfg, sim_device)
+        elif isinstance(backend, type) or (callable(backend) and not hasattr(backend, "t")):
+            backend = backend(self.qcfg)          # a factory: the final qa_config (mocap table size, terrain) is only known here
         self.sim = backend
         self.device = str(backend.device)
         if self._mocap_table is not None:

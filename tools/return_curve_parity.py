@@ -18,20 +18,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(device, num_envs, iters, seed):
+def run(device, num_envs, iters, seed, amp=False):
     import torch
     from quadrupedal_agility_amd.legged_gym.envs import task_registry
     from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
     from quadrupedal_agility_amd.legged_gym.utils import get_args
     from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import make_qa_config
-    cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = False; cfg.seed = seed
-    t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = False; t.seed = seed; t.runner.save_interval = 10 ** 9
+    cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = bool(amp); cfg.seed = seed
+    t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = bool(amp); t.seed = seed; t.runner.save_interval = 10 ** 9
     torch.manual_seed(seed)
     log_root = tempfile.mkdtemp(prefix="qa_parity_")
     if device == "cpu":
         from tests.oracle_backend import OracleBackend
         args = get_args(["--device", "cpu"])
-        env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=OracleBackend(make_qa_config(cfg, seed=seed)))
+        env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=(OracleBackend if amp else OracleBackend(make_qa_config(cfg, seed=seed))))
     else:
         args = get_args(["--device", "gpu"])
         env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
@@ -56,7 +56,7 @@ def tail_mean(xs, k=10):
 def merge(gpu_json, cpu_json, out):
     g, c = json.load(open(gpu_json)), json.load(open(cpu_json))
     assert (g["num_envs"], g["iters"]) == (c["num_envs"], c["iters"])
-    tags = ["Train/mean_reward", "Train/mean_reward_t", "Train/mean_episode_length", "Episode/rew_tracking_lin_vel",
+    tags = ["Train/mean_reward", "Train/mean_reward_t", "Train/mean_reward_i", "Train/mean_episode_length", "Episode/rew_tracking_lin_vel",
             "Episode/rew_tracking_ang_vel", "Episode/rew_torques", "Episode/rew_dof_error", "Episode/rew_collision"]
     summary = {}
     for tag in tags:
@@ -83,16 +83,17 @@ def main():
     ap.add_argument("--side", choices=["both", "gpu", "cpu"], default="both",
                     help="run one side only (the CPU-oracle side needs no GPU) and merge later with --merge")
     ap.add_argument("--merge", nargs=2, default=None, metavar=("GPU_JSON", "CPU_JSON"))
+    ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator on, mocap-state resets (baked real clips)")
     a = ap.parse_args()
     if a.merge:
         return merge(a.merge[0], a.merge[1], a.out)
     if a.side != "both":
         rows = []
         for seed in a.seeds:
-            cur, wall, fps = run(a.side, a.num_envs, a.iters, seed)
+            cur, wall, fps = run(a.side, a.num_envs, a.iters, seed, a.amp)
             rows.append({"seed": seed, "env_steps_per_s": fps, "curves": {k: v for k, v in cur.items() if k.startswith(("Train/", "Episode/"))}})
             print(a.side, "seed", seed, "done in", round(wall, 1), "s", flush=True)
-        json.dump({"side": a.side, "num_envs": a.num_envs, "iters": a.iters, "rows": rows}, open(a.out, "w"))
+        json.dump({"side": a.side, "amp": bool(a.amp), "num_envs": a.num_envs, "iters": a.iters, "rows": rows}, open(a.out, "w"))
         return
     tags = ["Train/mean_reward", "Train/mean_reward_t", "Train/mean_episode_length", "Episode/rew_tracking_lin_vel", "Episode/rew_torques"]
     rows = []
