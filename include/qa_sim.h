@@ -328,6 +328,18 @@ int64_t qa_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols);
 int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
                          float alpha, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* Weight and bias gradient of a NARROW linear layer -- the heads of the reference's networks: critic 128 -> 1, actor 128 -> 12
+ * (bbc/rsl_rl/modules/actor_critic.py:127-139), the task-level gait / parameter heads 128 -> 3 / 18:
+ *   grad_weight[o][k] = sum_r grad_out[r][o] * x[r][k],   grad_bias[o] = sum_r grad_out[r][o]        (out_features <= 32)
+ * As a GEMM this is an (out x in) output with a rows-long reduction: one or a dozen output rows give the library nothing to
+ * parallelise over (60 us for 1 x 128 over 24,576 rows, 22 us for 12 x 128) -- it is a weighted column sum of x, i.e. one streaming
+ * pass.  Row slabs -> partial sums -> fixed-order finish (deterministic, no atomics).  grad_out (rows, out) and x (rows, in)
+ * row-major; `scratch` holds at least qa_narrow_wgrad_scratch_bytes(rows, out, in) bytes. */
+#define QA_NARROW_MAX_OUT 32
+int64_t qa_narrow_wgrad_scratch_bytes(int64_t rows, int32_t out_features, int32_t in_features);
+int qa_narrow_wgrad(const float *grad_out, const float *x, int64_t rows, int32_t out_features, int32_t in_features, float *grad_weight,
+                    float *grad_bias, void *scratch, int64_t scratch_bytes, void *stream);
+
 /* Running-moment normaliser of the discriminator inputs (bbc/rsl_rl/utils/utils.py:62-103).
  * qa_normalizer_update folds num_batches (1..4) row-major (rows[i], dim) fp32 device batches, in order, into the
  * device-resident double moments (mean[dim], var[dim], *count): each batch contributes its mean and biased variance

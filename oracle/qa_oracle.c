@@ -1269,6 +1269,25 @@ int qo_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
     return QA_OK;
 }
 
+/* CPU twin of qa_narrow_wgrad: F.linear's weight / bias gradient for a layer with few outputs, plain double loops */
+int64_t qo_narrow_wgrad_scratch_bytes(int64_t rows, int32_t out_features, int32_t in_features) { (void)rows; (void)out_features; (void)in_features; return 16; }
+int qo_narrow_wgrad(const float *grad_out, const float *x, int64_t rows, int32_t O, int32_t K, float *grad_weight, float *grad_bias,
+                    void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!grad_out || !x || !grad_weight || !grad_bias || rows <= 0 || O <= 0 || O > QA_NARROW_MAX_OUT || K <= 0) return QA_E_ARG;
+    for (int o = 0; o < O; ++o) {
+        double b = 0;
+        for (int64_t r = 0; r < rows; ++r) b += grad_out[r * O + o];
+        grad_bias[o] = (float)b;
+        for (int k = 0; k < K; ++k) {
+            double acc = 0;
+            for (int64_t r = 0; r < rows; ++r) acc += (double)grad_out[r * O + o] * x[r * K + k];
+            grad_weight[(int64_t)o * K + k] = (float)acc;
+        }
+    }
+    return QA_OK;
+}
+
 /* RunningMeanStd.update / update_from_moments (utils.py:62-84) on host memory, plain double loops */
 int qo_normalizer_update(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim,
                          double *mean, double *var, double *count, void *stream) {

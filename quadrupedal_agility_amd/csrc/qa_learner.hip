@@ -222,6 +222,71 @@ __global__ void __launch_bounds__(256) qa_colsum_finish_kernel(const float *__re
     }
 }
 
+// qa_colsum_finish_kernel with the columns split over two destinations: [0, split) -> a, [split, cols) -> b
+__global__ void __launch_bounds__(256) qa_colsum_finish2_kernel(const float *__restrict__ partial, int nblocks, int cols, int split, float *__restrict__ a,
+                                                                float *__restrict__ b) {
+    __shared__ float s_q[256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        int blk = q;
+        for (; blk + 24 < nblocks; blk += 32) {
+            a0 += partial[(int64_t)blk * cols + c]; a1 += partial[(int64_t)(blk + 8) * cols + c];
+            a2 += partial[(int64_t)(blk + 16) * cols + c]; a3 += partial[(int64_t)(blk + 24) * cols + c];
+        }
+        for (; blk < nblocks; blk += 8) a0 += partial[(int64_t)blk * cols + c];
+    }
+    s_q[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += s_q[threadIdx.x + 32 * k];
+        if (c < split) a[c] = t; else b[c - split] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight + bias gradient of a narrow linear layer (qa_narrow_wgrad): a weighted column sum of x.  One workgroup per slab of rows,
+// one thread per input column (k, k + 256, ...); the slab's grad_out rows sit in LDS and are read as broadcasts; every thread keeps
+// OMAX accumulators.  x is read once, coalesced, 4 rows in flight.  Partials [slab][out * in + out] -> qa_colsum_finish_kernel.
+constexpr int NARROW_MAX_SLAB = 128;
+template <int OMAX>
+__global__ void __launch_bounds__(256) qa_narrow_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ x, int64_t rows, int slab_rows,
+                                                              int O, int K, float *__restrict__ partial) {
+    __shared__ float s_g[NARROW_MAX_SLAB * OMAX];
+    const int64_t r0 = (int64_t)blockIdx.x * slab_rows;
+    const int n = (int)min((int64_t)slab_rows, rows - r0);
+    for (int i = threadIdx.x; i < n * O; i += 256) s_g[(i / O) * OMAX + (i % O)] = gy[r0 * O + i];
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * ((int64_t)O * K + O);
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float acc[OMAX];
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o) acc[o] = 0.f;
+        const float *xp = x + r0 * K + k;
+        int r = 0;
+        for (; r + 4 <= n; r += 4) {
+            const float x0 = xp[(int64_t)r * K], x1 = xp[(int64_t)(r + 1) * K], x2 = xp[(int64_t)(r + 2) * K], x3 = xp[(int64_t)(r + 3) * K];
+#pragma unroll
+            for (int o = 0; o < OMAX; ++o)
+                if (o < O) acc[o] = fmaf(s_g[(r + 3) * OMAX + o], x3, fmaf(s_g[(r + 2) * OMAX + o], x2, fmaf(s_g[(r + 1) * OMAX + o], x1, fmaf(s_g[r * OMAX + o], x0, acc[o]))));
+        }
+        for (; r < n; ++r) {
+            const float x0 = xp[(int64_t)r * K];
+#pragma unroll
+            for (int o = 0; o < OMAX; ++o) if (o < O) acc[o] = fmaf(s_g[r * OMAX + o], x0, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o) if (o < O) out[(int64_t)o * K + k] = acc[o];
+    }
+    if (threadIdx.x < O) {                    // bias gradient: this slab's column sums of grad_out
+        float b = 0.f;
+        for (int r = 0; r < n; ++r) b += s_g[r * OMAX + threadIdx.x];
+        out[(int64_t)O * K + threadIdx.x] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Running-moment normaliser of the discriminator inputs (bbc/rsl_rl/utils/utils.py:62-103, RunningMeanStd): fold up to
 // four (n_i, d) fp32 batches, in order, into (mean, var, count) kept in double on the device; each batch contributes
@@ -768,6 +833,36 @@ int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
     hipLaunchKernelGGL(qa_colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float *)partial, nb, (int)cols, grad_bias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+static int narrow_slabs(int64_t rows, int *slab_rows) {
+    int sr = (int)((rows + 255) / 256);                     // ~256 workgroups: one per CU
+    sr = sr < 8 ? 8 : (sr > NARROW_MAX_SLAB ? NARROW_MAX_SLAB : sr);
+    *slab_rows = sr;
+    return (int)((rows + sr - 1) / sr);
+}
+int64_t qa_narrow_wgrad_scratch_bytes(int64_t rows, int32_t out_features, int32_t in_features) {
+    int sr; const int nb = narrow_slabs(rows, &sr);
+    return (int64_t)nb * ((int64_t)out_features * in_features + out_features) * 4;
+}
+int qa_narrow_wgrad(const float *grad_out, const float *x, int64_t rows, int32_t O, int32_t K, float *grad_weight, float *grad_bias,
+                    void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!grad_out || !x || !grad_weight || !grad_bias || !scratch || rows <= 0 || O <= 0 || O > QA_NARROW_MAX_OUT || K <= 0) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_narrow_wgrad: bad argument (1 <= out_features <= %d)", QA_NARROW_MAX_OUT); return QA_E_ARG; }
+    if (scratch_bytes < qa_narrow_wgrad_scratch_bytes(rows, O, K)) { snprintf(g_lerr, sizeof(g_lerr), "qa_narrow_wgrad: scratch too small"); return QA_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    int sr; const int nb = narrow_slabs(rows, &sr);
+    float *partial = (float *)scratch;
+    if (O <= 1) hipLaunchKernelGGL(qa_narrow_wgrad_kernel<1>, dim3(nb), dim3(256), 0, st, grad_out, x, rows, sr, (int)O, (int)K, partial);
+    else if (O <= 4) hipLaunchKernelGGL(qa_narrow_wgrad_kernel<4>, dim3(nb), dim3(256), 0, st, grad_out, x, rows, sr, (int)O, (int)K, partial);
+    else if (O <= 16) hipLaunchKernelGGL(qa_narrow_wgrad_kernel<16>, dim3(nb), dim3(256), 0, st, grad_out, x, rows, sr, (int)O, (int)K, partial);
+    else hipLaunchKernelGGL(qa_narrow_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, grad_out, x, rows, sr, (int)O, (int)K, partial);
+    // [out * in | out] per slab -> grad_weight, grad_bias: two fixed-order column-sum finishes over the same partials
+    const int cols = O * K + O;
+    hipLaunchKernelGGL(qa_colsum_finish2_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float *)partial, nb, cols, O * K, grad_weight, grad_bias);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_narrow_wgrad: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

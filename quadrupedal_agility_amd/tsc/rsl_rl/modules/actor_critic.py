@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 from torch.distributions import Categorical, Normal
 
-from quadrupedal_agility_amd.rsl_rl.modules.actor_critic import StateHistoryEncoder, _mlp, _run, get_activation
+from quadrupedal_agility_amd.rsl_rl.modules.actor_critic import StateHistoryEncoder, _head, _mlp, _run, get_activation
 
 
 class Actor(nn.Module):
@@ -111,8 +111,8 @@ class ActorCriticTSC(nn.Module):
 
     def _distributions(self, observations, hist_encoding):
         emb = self.actor(observations, hist_encoding)
-        self.distribution_d = Categorical(probs=torch.softmax(self.actor.actor_d(emb), dim=-1), validate_args=False)
-        mean = self.actor.actor_c(emb)
+        self.distribution_d = Categorical(probs=torch.softmax(_head(self.actor.actor_d, emb), dim=-1), validate_args=False)
+        mean = _head(self.actor.actor_c, emb)
         self.distribution_c = Normal(mean, mean * 0.0 + self.std, validate_args=False)
 
     def act(self, observations, hist_encoding=False, **kwargs):

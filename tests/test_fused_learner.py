@@ -792,3 +792,38 @@ def test_clip_adam_pointer_table_path_with_many_tensors():
     assert stepper._tab is not None and stepper._tab["n"] == 80 and stepper._tab["grad_ptrs"] is not None
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.allclose(p, q, rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,o,k", [(24576, 1, 128), (24576, 12, 128), (49152, 18, 128), (3072, 3, 128), (5000, 29, 64), (2049, 32, 300)])
+def test_narrow_wgrad_matches_torch_and_oracle(rows, o, k):
+    """qa_narrow_wgrad: dW = gy^T x, db = sum gy for layers with <= 32 outputs (actor / critic heads), against torch in fp64 and the
+    C twin; and through autograd: fused.narrow_linear == nn.Linear on outputs and all three gradients"""
+    import ctypes as C
+    from quadrupedal_agility_amd import _capi
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    from tests.oracle_lib import load_oracle
+    torch.manual_seed(rows + o)
+    gy, x = torch.randn(rows, o), torch.randn(rows, k)
+    ref_w, ref_b = (gy.double().t() @ x.double()), gy.double().sum(0)
+    lib = _capi.load_library()
+    gw, gb = torch.empty(o, k, device="cuda"), torch.empty(o, device="cuda")
+    n = int(lib.qa_narrow_wgrad_scratch_bytes(rows, o, k)); scratch = torch.empty(n, dtype=torch.uint8, device="cuda")
+    gyc, xc = gy.cuda(), x.cuda()
+    assert lib.qa_narrow_wgrad(gyc.data_ptr(), xc.data_ptr(), rows, o, k, gw.data_ptr(), gb.data_ptr(), scratch.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    tol = 2e-5 * rows ** 0.5
+    assert (gw.cpu().double() - ref_w).abs().max() < tol and (gb.cpu().double() - ref_b).abs().max() < tol
+    orc = load_oracle()
+    ow, ob = torch.empty(o, k), torch.empty(o)
+    assert orc.qo_narrow_wgrad(gy.data_ptr(), x.data_ptr(), rows, o, k, ow.data_ptr(), ob.data_ptr(), None, 0, None) == 0
+    assert (ow.double() - ref_w).abs().max() < 1e-4 and (gw.cpu() - ow).abs().max() < tol
+    # autograd path
+    lin = torch.nn.Linear(k, o).cuda()
+    ref = torch.nn.Linear(k, o).cuda(); ref.load_state_dict(lin.state_dict())
+    xa, xb = xc.clone().requires_grad_(True), xc.clone().requires_grad_(True)
+    ya = fused.narrow_linear(lin, xa); yb = ref(xb)
+    assert type(ya.grad_fn).__name__.startswith("_NarrowLinear") and torch.allclose(ya, yb, atol=1e-5)
+    ya.backward(gyc); yb.backward(gyc)
+    assert torch.allclose(xa.grad, xb.grad, atol=1e-5)
+    assert (lin.weight.grad - ref.weight.grad).abs().max() < tol and (lin.bias.grad - ref.bias.grad).abs().max() < tol
