@@ -1,6 +1,5 @@
-"""TSC (task-level controller) tree of the reference.  Learner side: the hybrid categorical + Gaussian
-policy `ActorCriticTSC`, the frozen low-level `ActorCriticBBC`, the hybrid `PPO` and its rollout storage (`tsc.rsl_rl`).
-Env side: the command mapping, the goal / termination / reward bookkeeping, the 132-point height scan and the observation
-assembly of the task-level `LeggedRobot` (`tsc.legged_gym.TaskLevelBookkeeping`, HIP kernels `qa_tsc_set_commands` /
-`qa_tsc_goal_step` / `qa_tsc_observations`).  The obstacle-course simulation itself (obstacle contact, see-saw joints, depth
-camera) is NOT built -- DESIGN.md section 9."""
+"""TSC (task-level controller) tree of the reference.  Env: the agility course as
+height-field + ceiling collision terrain, the two-level step, goal / termination / reward bookkeeping, height scan, observation
+assembly and the depth camera (`tsc.legged_gym`; HIP kernels `qa_env_physics_step`, `qa_tsc_*`).  Learner: the hybrid categorical +
+Gaussian policy `ActorCriticTSC`, the frozen `ActorCriticBBC`, the hybrid `PPO`, the depth student and the runner with `learn_RL` /
+`learn_vision` (`tsc.rsl_rl`).  Entry point: `python -m quadrupedal_agility_amd.tsc.legged_gym.scripts.train --task go2`."""
