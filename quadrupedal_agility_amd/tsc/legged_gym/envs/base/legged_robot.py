@@ -98,6 +98,8 @@ class LeggedRobot:
         if backend is None:
             from quadrupedal_agility_amd.sim import QaSim
             backend = QaSim(self.qcfg, sim_device)
+        elif isinstance(backend, type):
+            backend = backend(self.qcfg)             # a factory: the final qa_config (course size) is only known here
         self.sim = backend
         self.device = str(backend.device)
         dev = self.device

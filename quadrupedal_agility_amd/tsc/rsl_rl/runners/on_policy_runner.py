@@ -444,6 +444,18 @@ class OnPolicyRunner:
         self._bbc_chain = None
         self._rollout_graphs = {}                # recorded rollouts hold the old packed weights and normaliser
 
+    def get_inference_policy_bbc(self, device=None):
+        self.alg.actor_critic_bbc.eval()
+        if device is not None:
+            self.alg.actor_critic_bbc.to(device)
+        return self.alg.actor_critic_bbc.act_inference
+
+    def get_estimator_inference_policy(self, device=None):
+        self.alg.estimator.eval()
+        if device is not None:
+            self.alg.estimator.to(device)
+        return self.alg.estimator
+
     def get_depth_actor_inference_policy(self, device=None):
         self.alg.depth_actor.eval()
         if device is not None:

@@ -55,3 +55,24 @@ def test_make_env_runner_train_and_resume(tmp_path, monkeypatch):
     runner2, _ = build(argv[:-1] + ["xyz789-second", "--resumeid", "abc123"])
     assert all(torch.equal(v, runner2.alg.actor_critic.state_dict()[k]) for k, v in w.items())
     assert runner2.current_learning_iteration == 1
+
+
+def test_play_resumes_a_run_and_drives_the_course(tmp_path, monkeypatch):
+    """scripts/play.py headless: the reference's test-time overrides, the runner resumed from the run directory, teacher and student
+    deployment loops; returns the success rate of the episodes that ended"""
+    from tests.oracle_backend import OracleBackend
+    from tests.oracle_lib import load_oracle
+    from quadrupedal_agility_amd.tsc.legged_gym.scripts.play import play
+    from quadrupedal_agility_amd.tsc.legged_gym.scripts.train import train
+    monkeypatch.setattr(tr_mod, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    kw = dict(backend=OracleBackend, bookkeeping_lib=(load_oracle(), "qo_"))
+    real_make_env = task_registry.make_env
+    monkeypatch.setattr(task_registry, "make_env", lambda name, args=None, env_cfg=None, **k: real_make_env(name, args=args, env_cfg=env_cfg, **kw))
+    for cam in ([], ["--use_camera"]):
+        exptid = "cam001-x" if cam else "tea001-x"
+        targs = get_args(["--task", "go2", "--device", "cpu", "--num_envs", "6", "--max_iterations", "1", "--exptid", exptid] + cam)
+        r = train(targs)
+        assert r.if_depth == bool(cam)
+        pargs = get_args(["--task", "go2", "--device", "cpu", "--num_envs", "6", "--exptid", exptid, "--resumeid", exptid] + cam)
+        sr = play(pargs, num_steps=6, quiet=True)
+        assert sr is None or 0.0 <= sr <= 1.0
