@@ -589,63 +589,25 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     // 4-byte aligned (671 and 570 are not multiples of 4), so each copy has a <=3-float head and tail.
     const float clipo = c.clip_obs;
     const int lane = tix;
-    // history loads: ALL 16 rows of the block (9 values per lane and row = 144 registers -- the physics state is dead by now) are
-    // requested back to back before the first row is assembled, so the HBM latency is exposed once per launch, not once per
-    // group of rows (one wavefront per SIMD: nothing else hides it)
-    constexpr int NG = EPB / OBS_GROUP;
-    float hvb[NG][OBS_GROUP][9];
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {          // 8 full wave loads + 1 single-lane load per env
-            const int ge = min((int)(bix * EPB) + gi * OBS_GROUP + g, N - 1);
-            const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;     // previous row's history slots 1..9
-#pragma unroll
-            for (int r = 0; r < 8; ++r) hvb[gi][g][r] = hist[QA_BLOCK * r];
-            hvb[gi][g][8] = (lane == 0) ? hist[512] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int e0 = gi * OBS_GROUP;
-        float (&hv)[OBS_GROUP][9] = hvb[gi];
-        if (e0) wave_lds_sync();                       // the previous group's row stores have read their LDS rows
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {
-            const int e = e0 + g, ge = (int)(bix * EPB) + e;
-            if (ge < N) {
-                const float *ss = s_stage + e * S_ENV;
-                const int head = obs_row_head(p.obs + (int64_t)ge * QA_NUM_OBS);
-                float *row = s_rows + g * S_ROW + ((4 - head) & 3);
-                const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
-                const float pr = (lane < 57) ? clampf(ss[S_PROP + lane], -clipo, clipo) : 0.f;
-                if (!rf) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) { float v = clampf(hv[g][r], -clipo, clipo); row[90 + lane + QA_BLOCK * r] = v; }
-                    if (lane == 0) { float v = clampf(hv[g][8], -clipo, clipo); row[90 + 512] = v; }
-                } else {                                 // first observation of an episode: all ten slots = current frame
-                    for (int i = lane; i < 513; i += QA_BLOCK) { float v = clampf(ss[S_PROP + (i % 57)], -clipo, clipo); row[90 + i] = v; }
-                }
-                if (lane < 57) row[603 + lane] = pr;
-                row[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
-                if (lane < 26) row[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
-                if (lane < 11) row[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
-                if (lane < QA_NUM_OBS_DISC) {
-                    float dv = ss[S_DISC + lane];
-                    p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + lane] = dv;
-                    p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
-                }
-            }
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int g = 0; g < OBS_GROUP; ++g) {
-            const int ge = bix * EPB + e0 + g;
-            if (ge < N) {
-                float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
-                const int head = obs_row_head(dst);
-                store_obs_row(dst, s_rows + g * S_ROW + ((4 - head) & 3), head);
-            }
+    // The history slots 0..8 of every row were written by shift_history_rows() at the start of the launch.  What is left: head
+    // (prop + explicit + latent, 90 floats), the newest history frame (slot 9) and the command tail -- 158 floats, four wave stores
+    // per env.  An env in the first step of an episode refills all ten slots with the current frame (wave-uniform, rare).
+#pragma unroll 1
+    for (int e = 0; e < EPB; ++e) {
+        const int ge = (int)(bix * EPB) + e;
+        if (ge >= N) break;
+        const float *ss = s_stage + e * S_ENV;
+        float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
+        const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
+        if (rf) for (int i = lane; i < 513; i += QA_BLOCK) dst[90 + i] = clampf(ss[S_PROP + (i % 57)], -clipo, clipo);
+        dst[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
+        if (lane < 26) dst[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
+        if (lane < 57) dst[603 + lane] = clampf(ss[S_PROP + lane], -clipo, clipo);
+        if (lane < 11) dst[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
+        if (lane < QA_NUM_OBS_DISC) {
+            float dv = ss[S_DISC + lane];
+            p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + lane] = dv;
+            p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
         }
     }
     QA_STAMP(10);
@@ -656,6 +618,35 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
 // of one workgroup over the four SIMDs of a CU, whereas four single-wavefront workgroups of a kernel that needs <= 256
 // registers are packed two per SIMD and then share its issue slots (measured: 143 us instead of the expected ~50).
 // Each wavefront works on its own 4 envs with its own LDS region; only the constant table is shared.
+// History part of the NEXT observation row, written at the start of the step: slots 0..8 of the new row are slots 1..9 of the old
+// one whatever this step does (unless the env resets: then the tail of the kernel refills all ten), so the 513-float shift of every
+// env of the block -- 3/4 of the row's bytes -- is read and written here, in the shadow of the physics, and the tail of the kernel
+// only adds the 158 floats this step produces.  In place: every lane holds its 9 values of a row before the row's first store issues.
+template <int EPB>
+QA_DEV void shift_history_load(const Ptrs &p, int bix, int lane, int N, float (&hv)[EPB][9]) {
+#pragma unroll
+    for (int g = 0; g < EPB; ++g) {                     // all rows of the block in flight: 144 registers nothing else needs yet
+        const int ge = min(bix * EPB + g, N - 1);
+        const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) hv[g][r] = hist[QA_BLOCK * r];
+        hv[g][8] = (lane == 0) ? hist[512] : 0.f;
+    }
+}
+template <int EPB>
+QA_DEV void shift_history_store(const Ptrs &p, int bix, int lane, int N, const float (&hv)[EPB][9]) {
+#pragma unroll
+    for (int g = 0; g < EPB; ++g) {
+        const int ge = bix * EPB + g;
+        if (ge < N) {
+            float *row = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) row[QA_BLOCK * r] = hv[g][r];
+            if (lane == 0) row[512] = hv[g][8];
+        }
+    }
+}
+
 // MODE 0: the whole LeggedRobot.step of the behaviour-level (BBC) tree.  MODE 1: the physics part only -- action-history
 // roll, delay, clip, decimation x (PD torque -> substep), refresh of the simulator tensors -- for the task-level (TSC) env,
 // whose own post_physics_step (goals, termination, rewards, reset, three observation rows) are separate kernels (qa_tsc_*).
@@ -681,11 +672,18 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     static_assert((EPB * S_ENV) % 4 == 0, "row buffer must stay 16-byte aligned");
     long long *const qa_prof = a.prof;
     QA_STAMP(0);
-    stage_table(s_tbl);
-    if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
     const int N = c.num_envs;
+    if (MODE == 0 && LPE == 4) {                       // the table staging runs under the history loads' latency
+        float hv[EPB][9];
+        shift_history_load<EPB>(p, bix, tix, N, hv);
+        stage_table(s_tbl);
+        shift_history_store<EPB>(p, bix, tix, N, hv);
+    } else {
+        stage_table(s_tbl);
+    }
+    if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
     const int sub = LPE == 4 ? 0 : (tix & 3);
@@ -889,10 +887,15 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_post_physics_kernel(StepArgs a) {
     __shared__ float s_tbl[QA_TBL_FLOATS];
     constexpr int U_OBS = (EPB * S_ENV + OBS_GROUP * S_ROW + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float s_u[U_OBS];
-    stage_table(s_tbl);
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
     const int N = c.num_envs, tid = bix * QA_BLOCK + tix, leg = tix & 3, env_raw = tid / LPE;
+    {
+        float hv[EPB][9];
+        shift_history_load<EPB>(p, bix, tix, N, hv);
+        stage_table(s_tbl);
+        shift_history_store<EPB>(p, bix, tix, N, hv);
+    }
     const bool valid = env_raw < N;
     const int env = valid ? env_raw : N - 1, le = tix / LPE;
     const int64_t step = a.step;
