@@ -592,10 +592,10 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     // The history slots 0..8 of every row were written by shift_history_rows() at the start of the launch.  What is left: head
     // (prop + explicit + latent, 90 floats), the newest history frame (slot 9) and the command tail -- 158 floats, four wave stores
     // per env.  An env in the first step of an episode refills all ten slots with the current frame (wave-uniform, rare).
-#pragma unroll 1
+#pragma unroll 4
     for (int e = 0; e < EPB; ++e) {
         const int ge = (int)(bix * EPB) + e;
-        if (ge >= N) break;
+        if (ge >= N) continue;
         const float *ss = s_stage + e * S_ENV;
         float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
         const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
