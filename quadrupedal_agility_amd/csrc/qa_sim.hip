@@ -95,7 +95,7 @@ struct Ptrs {
 
 struct qa_sim {
     long long *prof = nullptr;
-    int lanes = 4;                 // lanes per env of the step / simulate kernels (16 = experimental, QA_LANES)
+    int lanes = 4;                 // lanes per env of the step / simulate kernels (one quad: lane & 3 = leg)
     qa_config cfg;
     Layout L;
     char *arena;
@@ -613,11 +613,8 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     QA_STAMP(10);
 }
 
-// LPE = lanes per env: 4 (lane&3 = leg) or 16 (lane = 16 env + 4 leg + sub; plane terrain only, qa_physics16.h)
-// With 16 lanes per env a workgroup is FOUR wavefronts (16 envs, as with 4 lanes): the hardware spreads the wavefronts
-// of one workgroup over the four SIMDs of a CU, whereas four single-wavefront workgroups of a kernel that needs <= 256
-// registers are packed two per SIMD and then share its issue slots (measured: 143 us instead of the expected ~50).
-// Each wavefront works on its own 4 envs with its own LDS region; only the constant table is shared.
+// LPE = lanes per env: 4 (lane & 3 = leg).  The template parameter is what is left of round 1's 16-lanes-per-env experiment (slower in wall
+// time); the kernel asserts LPE == 4.
 // History part of the NEXT observation row, written at the start of the step: slots 0..8 of the new row are slots 1..9 of the old
 // one whatever this step does (unless the env resets: then the tail of the kernel refills all ten), so the 513-float shift of every
 // env of the block -- 3/4 of the row's bytes -- is read and written here, in the shadow of the physics, and the tail of the kernel
@@ -687,7 +684,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
     const int sub = LPE == 4 ? 0 : (tix & 3);
-    const bool owner = sub == 0;                     // with 16 lanes per env the four sub-lanes of a leg hold identical values; one writes
+    const bool owner = sub == 0;                     // always true with one quad per env
     const int env_raw = tid / LPE;
     const bool in_range = env_raw < N;
     const bool valid = in_range && owner;            // guards every global write
