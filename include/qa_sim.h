@@ -319,6 +319,24 @@ int qa_ppo_loss(const float *mu, const float *std, const float *value, const flo
                 float c_bound, float c_entropy, int32_t clipped_value, float *dmu, float *dstd, float *dvalue, float *out,
                 void *scratch, int64_t scratch_bytes, void *stream);
 
+/* The HYBRID-action objective of the task-level learner and its gradient in one pass (tsc/rsl_rl/algorithms/ppo.py:222-262 with the
+ * distributions of tsc/rsl_rl/modules/actor_critic.py:253-284): a categorical gait head and a Gaussian parameter head share the advantage,
+ *   p = softmax(logits);  logp_d = log clamp(p[a_d], eps, 1 - eps)  (torch's Categorical(probs=p));  logp_c = sum_j log N(a_j; mean_j, std_j)
+ *   surrogate = mean max(-A r_d, -A clip(r_d)) + mean max(-A r_c, -A clip(r_c)),   r_x = exp(logp_x - old_logp_x)
+ *   entropy   = H(p) + (1 / num_c) sum_j H(N(., std_j))     (the Gaussian entropy is AVERAGED over its dimensions, :245-246)
+ *   loss      = surrogate + c_value * value_loss(clipped as in qa_ppo_loss) - c_entropy * mean entropy
+ *   kl        = mean sum_j [log(std_j / old_sigma_j + 1e-5) + (old_sigma_j^2 + (old_mu_j - mean_j)^2) / (2 std_j^2) - 1/2]   (Gaussian head only)
+ * actions (B, 1 + num_c) = [gait index as a float | parameter vector].  Outputs: d loss / d logits (B, num_d), d mean (B, num_c),
+ * d std (num_c), d value (B), out[8] = {loss, surrogate, value loss, entropy, kl, surrogate_d, surrogate_c, 0} (batch means).
+ * num_d = 3 and num_c = 18 are built (Go2AgilityCfg: 3 gaits x 6 parameters); other widths return QA_E_ARG and the caller keeps its
+ * eager expression.  `scratch` holds at least qa_hybrid_ppo_loss_scratch_bytes(B) bytes; fixed-order reductions, no atomics. */
+int64_t qa_hybrid_ppo_loss_scratch_bytes(int64_t B);
+int qa_hybrid_ppo_loss(const float *logits, const float *mean, const float *std, const float *value, const float *actions, const float *old_logp_d,
+                       const float *old_logp_c, const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
+                       const float *target_values, int64_t B, int32_t num_d, int32_t num_c, float clip, float c_value, float c_entropy,
+                       int32_t clipped_value, float *dlogits, float *dmean, float *dstd, float *dvalue, float *out, void *scratch,
+                       int64_t scratch_bytes, void *stream);
+
 /* ELU backward fused with the bias-gradient column sum: the part of the backward of a Linear+ELU layer
  * (the `_mlp` blocks of bbc/rsl_rl/modules/actor_critic.py:92-139, estimator.py:12-33) that is not a GEMM:
  *   grad_in[r][c] = grad_out[r][c] * (out[r][c] > 0 ? 1 : out[r][c] + alpha),   grad_bias[c] = sum_r grad_in[r][c]

@@ -1269,6 +1269,70 @@ int qo_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
     return QA_OK;
 }
 
+/* CPU twin of qa_hybrid_ppo_loss (tsc/rsl_rl/algorithms/ppo.py:222-262), double precision, any num_d <= 8 / num_c <= 32 */
+int64_t qo_hybrid_ppo_loss_scratch_bytes(int64_t B) { (void)B; return 16; }
+static void hyb_surr(double logp, double ologp, double adv, double clip, double *surr, double *dsurr_dlogp) {
+    double ratio = exp(logp - ologp), rc = ratio < 1 - clip ? 1 - clip : (ratio > 1 + clip ? 1 + clip : ratio);
+    double s1 = -adv * ratio, s2 = -adv * rc;
+    *surr = s1 > s2 ? s1 : s2;
+    int inside = ratio >= 1 - clip && ratio <= 1 + clip;
+    double d = s1 > s2 ? -adv : (s1 == s2 ? (inside ? -adv : -0.5 * adv) : 0.0);
+    *dsurr_dlogp = d * ratio;
+}
+int qo_hybrid_ppo_loss(const float *logits, const float *mean, const float *std, const float *value, const float *actions, const float *old_logp_d,
+                       const float *old_logp_c, const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
+                       const float *target_values, int64_t B, int32_t ND, int32_t NC, float clip_f, float c_value, float c_entropy,
+                       int32_t clipped_value, float *dlogits, float *dmean, float *dstd, float *dvalue, float *out, void *scratch,
+                       int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!logits || !mean || !std || !value || !actions || B <= 0 || ND <= 0 || ND > 8 || NC <= 0 || NC > 32) return QA_E_ARG;
+    const double HALF_LOG_2PI = 0.91893853320467274178, EPS = 1.1920928955078125e-07, clip = clip_f, invB = 1.0 / (double)B;
+    double S[5] = {0, 0, 0, 0, 0}, dsd[32] = {0};
+    for (int64_t r = 0; r < B; ++r) {
+        double z[8], p[8], lp[8], fl[8], zmax = -1e300, den = 0, Hd = 0, sum_pf = 0, plp = 0;
+        for (int k = 0; k < ND; ++k) { z[k] = logits[r * ND + k]; if (z[k] > zmax) zmax = z[k]; }
+        for (int k = 0; k < ND; ++k) { p[k] = exp(z[k] - zmax); den += p[k]; }
+        for (int k = 0; k < ND; ++k) {
+            p[k] /= den; fl[k] = (p[k] > EPS && p[k] < 1 - EPS) ? 1 : 0;
+            double c = p[k] < EPS ? EPS : (p[k] > 1 - EPS ? 1 - EPS : p[k]);
+            lp[k] = log(c); Hd -= p[k] * lp[k]; sum_pf += p[k] * fl[k]; plp += p[k] * lp[k];
+        }
+        const float *act = actions + r * (1 + NC);
+        int ad = (int)act[0]; if (ad < 0) ad = 0; if (ad >= ND) ad = ND - 1;
+        double adv = advantages[r], surr_d, dd, surr_c, dc;
+        hyb_surr(lp[ad], old_logp_d[r], adv, clip, &surr_d, &dd);
+        double logp = 0, ent_c = 0, kl = 0, dmu[32], dls[32];
+        for (int j = 0; j < NC; ++j) {
+            double s = std[j], mu = mean[r * NC + j], d = act[1 + j] - mu, var = s * s, ls = log(s), osd = old_sigma[r * NC + j], dm = old_mu[r * NC + j] - mu;
+            logp += -(d * d) / (2 * var) - ls - HALF_LOG_2PI; ent_c += 0.5 + HALF_LOG_2PI + ls;
+            kl += log(s / osd + 1e-5) + (osd * osd + dm * dm) / (2 * var) - 0.5;
+            dmu[j] = d / var; dls[j] = d * d / (s * s * s) - 1 / s;
+        }
+        ent_c /= NC;
+        hyb_surr(logp, old_logp_c[r], adv, clip, &surr_c, &dc);
+        double v = value[r], ret = returns[r], tv = target_values[r], vl, dvl;
+        if (clipped_value) {
+            double dv = v - tv, dvc = dv < -clip ? -clip : (dv > clip ? clip : dv), vc = tv + dvc, l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+            double pass = (dv >= -clip && dv <= clip) ? 1 : 0;
+            vl = l1 > l2 ? l1 : l2;
+            dvl = l1 > l2 ? 2 * (v - ret) : (l1 == l2 ? (v - ret) + (vc - ret) * pass : 2 * (vc - ret) * pass);
+        } else { vl = (ret - v) * (ret - v); dvl = 2 * (v - ret); }
+        for (int k = 0; k < ND; ++k) {
+            double dlogpa = fl[ad] * ((k == ad ? 1.0 : 0.0) - p[k]);
+            double dH = -p[k] * lp[k] + p[k] * plp - p[k] * fl[k] + p[k] * sum_pf;
+            dlogits[r * ND + k] = (float)(invB * (dd * dlogpa - c_entropy * dH));
+        }
+        for (int j = 0; j < NC; ++j) { dmean[r * NC + j] = (float)(invB * dc * dmu[j]); dsd[j] += dc * dls[j] - c_entropy / (std[j] * NC); }
+        dvalue[r] = (float)(invB * c_value * dvl);
+        S[0] += surr_d; S[1] += surr_c; S[2] += vl; S[3] += Hd + ent_c; S[4] += kl;
+    }
+    out[0] = (float)((S[0] + S[1] + c_value * S[2] - c_entropy * S[3]) * invB);
+    out[1] = (float)((S[0] + S[1]) * invB); out[2] = (float)(S[2] * invB); out[3] = (float)(S[3] * invB); out[4] = (float)(S[4] * invB);
+    out[5] = (float)(S[0] * invB); out[6] = (float)(S[1] * invB); out[7] = 0.f;
+    for (int j = 0; j < NC; ++j) dstd[j] = (float)(dsd[j] * invB);
+    return QA_OK;
+}
+
 /* CPU twin of qa_narrow_wgrad: F.linear's weight / bias gradient for a layer with few outputs, plain double loops */
 int64_t qo_narrow_wgrad_scratch_bytes(int64_t rows, int32_t out_features, int32_t in_features) { (void)rows; (void)out_features; (void)in_features; return 16; }
 int qo_narrow_wgrad(const float *grad_out, const float *x, int64_t rows, int32_t O, int32_t K, float *grad_weight, float *grad_bias,

@@ -149,6 +149,138 @@ __global__ void __launch_bounds__(256) qa_ppo_finish_kernel(const float *partial
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// qa_hybrid_ppo_loss: the task-level learner's objective (categorical gait head + Gaussian parameter head) and its gradient, one
+// thread per sample, as qa_ppo_loss; in eager PyTorch it is ~100 elementwise launches forward and ~150 backward per minibatch.
+constexpr int HYB_ND = 3, HYB_NC = 18, HYB_SUMS = 5 + HYB_NC;       // surr_d, surr_c, value, entropy, kl, dstd[18]
+struct HybArgs {
+    const float *logits, *mean, *std, *value, *actions, *old_logp_d, *old_logp_c, *old_mu, *old_sigma, *adv, *returns, *target_values;
+    float *dlogits, *dmean, *dvalue, *partial;
+    int64_t B;
+    float clip, c_value, c_entropy;
+    int clipped_value;
+};
+__device__ __forceinline__ void clipped_surrogate(float logp, float ologp, float adv, float clip, float &surr, float &dsurr_dlogp) {
+    const float ratio = expf(logp - ologp), rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    const float s1 = -adv * ratio, s2 = -adv * rc;
+    surr = fmaxf(s1, s2);
+    const bool inside = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
+    const float d = s1 > s2 ? -adv : (s1 == s2 ? (inside ? -adv : -0.5f * adv) : 0.0f);
+    dsurr_dlogp = d * ratio;
+}
+__global__ void __launch_bounds__(PPO_BLOCK) qa_hybrid_ppo_loss_kernel(HybArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * PPO_BLOCK + threadIdx.x;
+    const bool live = i < a.B;
+    const int64_t r = live ? i : a.B - 1;
+    const float invB = 1.0f / (float)a.B;
+    const float HALF_LOG_2PI = 0.91893853320467274178f, EPS = 1.1920928955078125e-07f;
+    // ---- categorical head: torch.distributions.Categorical(probs = softmax(logits))
+    float z[HYB_ND], pr[HYB_ND], lp[HYB_ND], fl[HYB_ND];
+    float zmax = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < HYB_ND; ++k) { z[k] = a.logits[r * HYB_ND + k]; zmax = fmaxf(zmax, z[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < HYB_ND; ++k) { pr[k] = expf(z[k] - zmax); den += pr[k]; }
+    float Hd = 0.f, sum_pf = 0.f;
+#pragma unroll
+    for (int k = 0; k < HYB_ND; ++k) {
+        pr[k] /= den;
+        fl[k] = (pr[k] > EPS && pr[k] < 1.0f - EPS) ? 1.0f : 0.0f;              // the clamp of probs_to_logits passes no gradient outside
+        lp[k] = logf(fminf(fmaxf(pr[k], EPS), 1.0f - EPS));
+        Hd -= pr[k] * lp[k];
+        sum_pf += pr[k] * fl[k];
+    }
+    const float *act = a.actions + r * (1 + HYB_NC);
+    int ad = (int)act[0];
+    ad = ad < 0 ? 0 : (ad >= HYB_ND ? HYB_ND - 1 : ad);
+    const float lpa = ad == 0 ? lp[0] : (ad == 1 ? lp[1] : lp[2]);
+    const float fa = ad == 0 ? fl[0] : (ad == 1 ? fl[1] : fl[2]);
+    const float adv = a.adv[r];
+    float surr_d, dsd_dlogp;
+    clipped_surrogate(lpa, a.old_logp_d[r], adv, a.clip, surr_d, dsd_dlogp);
+    // ---- Gaussian head
+    float logp = 0.f, ent_c = 0.f, kl = 0.f;
+    float dlogp_dmu[HYB_NC], dlogp_dsd[HYB_NC], inv_sd[HYB_NC];
+#pragma unroll
+    for (int j = 0; j < HYB_NC; ++j) {
+        const float s = a.std[j], inv_s = 1.0f / s, mu = a.mean[r * HYB_NC + j], d = act[1 + j] - mu, var = s * s, ls = logf(s);
+        const float osd = a.old_sigma[r * HYB_NC + j], dm = a.old_mu[r * HYB_NC + j] - mu;
+        logp += -(d * d) / (2.0f * var) - ls - HALF_LOG_2PI;
+        ent_c += 0.5f + HALF_LOG_2PI + ls;
+        kl += logf(s / osd + 1.0e-5f) + (osd * osd + dm * dm) / (2.0f * var) - 0.5f;
+        dlogp_dmu[j] = d / var;
+        dlogp_dsd[j] = d * d * inv_s * inv_s * inv_s - inv_s;
+        inv_sd[j] = inv_s;
+    }
+    ent_c *= 1.0f / (float)HYB_NC;
+    float surr_c, dsc_dlogp;
+    clipped_surrogate(logp, a.old_logp_c[r], adv, a.clip, surr_c, dsc_dlogp);
+    // ---- value loss
+    const float v = a.value[r], ret = a.returns[r], tv = a.target_values[r];
+    float vl, dvl_dv;
+    if (a.clipped_value) {
+        const float dv = v - tv, dvc = fminf(fmaxf(dv, -a.clip), a.clip), vc = tv + dvc;
+        const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+        const float pass = (dv >= -a.clip && dv <= a.clip) ? 1.0f : 0.0f;
+        vl = fmaxf(l1, l2);
+        dvl_dv = l1 > l2 ? 2.0f * (v - ret) : (l1 == l2 ? (v - ret) + (vc - ret) * pass : 2.0f * (vc - ret) * pass);
+    } else {
+        vl = (ret - v) * (ret - v);
+        dvl_dv = 2.0f * (v - ret);
+    }
+    if (live) {
+        // d/dz_k of  surr_d(logp_a) - c_entropy H(p):  d logp_a = f_a (delta_ak - p_k);  dH = -p_k lp_k - p_k H_...
+        float plp = 0.f;
+#pragma unroll
+        for (int k = 0; k < HYB_ND; ++k) plp += pr[k] * lp[k];
+#pragma unroll
+        for (int k = 0; k < HYB_ND; ++k) {
+            const float dlogpa = fa * ((k == ad ? 1.0f : 0.0f) - pr[k]);
+            const float dH = -pr[k] * lp[k] + pr[k] * plp - pr[k] * fl[k] + pr[k] * sum_pf;
+            a.dlogits[r * HYB_ND + k] = invB * (dsd_dlogp * dlogpa - a.c_entropy * dH);
+        }
+#pragma unroll
+        for (int j = 0; j < HYB_NC; ++j) a.dmean[r * HYB_NC + j] = invB * dsc_dlogp * dlogp_dmu[j];
+        a.dvalue[r] = invB * a.c_value * dvl_dv;
+    }
+    const float w = live ? 1.0f : 0.0f;
+    float part[HYB_SUMS];
+    part[0] = w * surr_d; part[1] = w * surr_c; part[2] = w * vl; part[3] = w * (Hd + ent_c); part[4] = w * kl;
+#pragma unroll
+    for (int j = 0; j < HYB_NC; ++j) part[5 + j] = w * (dsc_dlogp * dlogp_dsd[j] - a.c_entropy * inv_sd[j] * (1.0f / (float)HYB_NC));
+#pragma unroll
+    for (int k = 0; k < HYB_SUMS; ++k) {
+        float s = wave_sum(part[k]);
+        if (threadIdx.x == k) a.partial[(int64_t)blockIdx.x * HYB_SUMS + k] = s;
+    }
+}
+__global__ void __launch_bounds__(256) qa_hybrid_ppo_finish_kernel(const float *partial, int nblocks, int64_t B, float c_value, float c_entropy, float *out,
+                                                                   float *dstd) {
+    constexpr int LANES = 256 / HYB_SUMS;
+    __shared__ double s_acc[256];
+    __shared__ double s_tot[HYB_SUMS];
+    const int t = threadIdx.x, k = t / LANES, l = t % LANES;
+    double acc = 0.0;
+    if (k < HYB_SUMS)
+        for (int b = l; b < nblocks; b += LANES) acc += (double)partial[(int64_t)b * HYB_SUMS + k];
+    s_acc[t] = acc;
+    __syncthreads();
+    if (k < HYB_SUMS && l == 0) {
+        double tot = 0.0;
+        for (int q = 0; q < LANES; ++q) tot += s_acc[k * LANES + q];
+        s_tot[k] = tot;
+    }
+    __syncthreads();
+    const double invB = 1.0 / (double)B;
+    if (t == 0) {
+        out[0] = (float)((s_tot[0] + s_tot[1] + c_value * s_tot[2] - c_entropy * s_tot[3]) * invB);
+        out[1] = (float)((s_tot[0] + s_tot[1]) * invB); out[2] = (float)(s_tot[2] * invB); out[3] = (float)(s_tot[3] * invB);
+        out[4] = (float)(s_tot[4] * invB); out[5] = (float)(s_tot[0] * invB); out[6] = (float)(s_tot[1] * invB); out[7] = 0.f;
+    }
+    if (t >= 8 && t < 8 + HYB_NC) dstd[t - 8] = (float)(s_tot[5 + t - 8] * invB);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // ELU backward fused with the bias-gradient column sum (the backward of  y = elu(x W^T + b)  up to the two GEMMs):
 //   grad_in[r][c] = grad_out[r][c] * (out[r][c] > 0 ? 1 : out[r][c] + alpha);   grad_bias[c] = sum_r grad_in[r][c]
 // (`out` is the ELU OUTPUT: for y <= 0, d elu/dx = alpha e^x = y + alpha.)  In eager PyTorch these are two kernels that
@@ -812,6 +944,29 @@ int qa_ppo_loss(const float *mu, const float *std, const float *value, const flo
     hipLaunchKernelGGL(qa_ppo_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)scratch, blocks, B, c_surr, c_value, c_bound, c_entropy, out, dstd);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_ppo_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int64_t qa_hybrid_ppo_loss_scratch_bytes(int64_t B) { return B <= 0 ? -1 : (int64_t)sizeof(float) * HYB_SUMS * ((B + PPO_BLOCK - 1) / PPO_BLOCK); }
+
+int qa_hybrid_ppo_loss(const float *logits, const float *mean, const float *std, const float *value, const float *actions, const float *old_logp_d,
+                       const float *old_logp_c, const float *old_mu, const float *old_sigma, const float *advantages, const float *returns,
+                       const float *target_values, int64_t B, int32_t num_d, int32_t num_c, float clip, float c_value, float c_entropy,
+                       int32_t clipped_value, float *dlogits, float *dmean, float *dstd, float *dvalue, float *out, void *scratch,
+                       int64_t scratch_bytes, void *stream) {
+    if (!logits || !mean || !std || !value || !actions || !old_logp_d || !old_logp_c || !old_mu || !old_sigma || !advantages || !returns ||
+        !target_values || !dlogits || !dmean || !dstd || !dvalue || !out || !scratch || B <= 0) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_hybrid_ppo_loss: null pointer or empty batch"); return QA_E_ARG; }
+    if (num_d != HYB_ND || num_c != HYB_NC) { snprintf(g_lerr, sizeof(g_lerr), "qa_hybrid_ppo_loss: built for num_d = %d, num_c = %d", HYB_ND, HYB_NC); return QA_E_ARG; }
+    if (scratch_bytes < qa_hybrid_ppo_loss_scratch_bytes(B)) { snprintf(g_lerr, sizeof(g_lerr), "qa_hybrid_ppo_loss: scratch too small"); return QA_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)((B + PPO_BLOCK - 1) / PPO_BLOCK);
+    HybArgs a{logits, mean, std, value, actions, old_logp_d, old_logp_c, old_mu, old_sigma, advantages, returns, target_values, dlogits, dmean, dvalue,
+              (float *)scratch, B, clip, c_value, c_entropy, clipped_value};
+    hipLaunchKernelGGL(qa_hybrid_ppo_loss_kernel, dim3(blocks), dim3(PPO_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(qa_hybrid_ppo_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)scratch, blocks, B, c_value, c_entropy, out, dstd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_hybrid_ppo_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -82,6 +82,30 @@ def ppo_loss_raw(mu, std, value, actions, old_logp, old_mu, old_sigma, advantage
     return out, dmu, dstd, dvalue
 
 
+def hybrid_ppo_loss_raw(logits, mean, std, value, actions, old_logp_d, old_logp_c, old_mu, old_sigma, advantages, returns, target_values, *,
+                        clip, c_value, c_entropy, clipped_value=True):
+    """qa_hybrid_ppo_loss (the task-level learner's categorical + Gaussian objective): (out[8], d loss/d logits (B,3), d mean (B,18),
+    d std (18), d value (B)); None when the head widths are not the built ones (the caller keeps its eager expression)."""
+    lib = _capi.load_library()
+    lg, mu_c, std_c, val_c = (_f32c(x.detach()) for x in (logits, mean, std, value))
+    B, nd, nc = lg.shape[0], lg.shape[1], mu_c.shape[1]
+    if (nd, nc) != (3, 18):
+        return None
+    fixed = [_f32c(x) for x in (actions, old_logp_d, old_logp_c, old_mu, old_sigma, advantages, returns, target_values)]
+    assert fixed[0].shape == (B, 1 + nc) and val_c.numel() == B
+    dev = lg.device
+    dlogits, dmean = torch.empty_like(lg), torch.empty_like(mu_c)
+    dstd, dvalue, out = torch.empty(nc, device=dev), torch.empty(B, device=dev), torch.empty(8, device=dev)
+    n = int(lib.qa_hybrid_ppo_loss_scratch_bytes(B))
+    scratch = torch.empty(n, dtype=torch.uint8, device=dev)
+    rc = lib.qa_hybrid_ppo_loss(_ptr(lg), _ptr(mu_c), _ptr(std_c), _ptr(val_c), *[_ptr(x) for x in fixed], B, nd, nc, float(clip), float(c_value),
+                                float(c_entropy), int(bool(clipped_value)), _ptr(dlogits), _ptr(dmean), _ptr(dstd), _ptr(dvalue), _ptr(out),
+                                _ptr(scratch), n, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"qa_hybrid_ppo_loss failed with code {rc}: {lib.qa_last_error().decode()}")
+    return out, dlogits, dmean, dstd, dvalue
+
+
 class _LinearElu(torch.autograd.Function):
     """y = elu(x W^T + b).  Forward: addmm (hipBLASLt) + in-place ELU.  Backward: ONE kernel for the ELU derivative and
     the bias gradient (qa_elu_backward_bias), then the two GEMMs.  Saves the ELU output only (elu' = y + alpha for y <= 0)."""

@@ -89,3 +89,49 @@ def test_rollout_post_amp_twin():
     np.testing.assert_allclose(fin, want_fin.numpy(), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(cur_n, (want_fin * (reset == 0)).numpy(), rtol=2e-5, atol=2e-6)
     assert np.array_equal(st_d, (reset > 0).numpy().astype(np.uint8)) and np.array_equal(mask, st_d)
+
+
+def test_hybrid_ppo_loss_twin_matches_the_eager_objective_and_its_autograd_gradient():
+    """qo_hybrid_ppo_loss (the C twin the HIP kernel is checked against) vs the task-level update's own eager expression
+    (tsc/rsl_rl/algorithms/ppo.py:222-262 through torch.distributions and autograd): every loss term and all four gradients"""
+    import ctypes as C
+    import torch
+    from torch.distributions import Categorical, Normal
+    from tests.oracle_lib import load_oracle
+    lib = load_oracle()
+    f = lib.qo_hybrid_ppo_loss
+    f.argtypes = [C.c_void_p] * 12 + [C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p]
+    torch.manual_seed(3)
+    B, ND, NC, clip, cv, ce = 777, 3, 18, 0.2, 1.0, 0.01
+    logits = (torch.randn(B, ND) * 2).requires_grad_(True)
+    mean = torch.randn(B, NC).requires_grad_(True)
+    std = (torch.rand(NC) * 0.8 + 0.3).requires_grad_(True)
+    value = torch.randn(B).requires_grad_(True)
+    a_d = torch.randint(0, ND, (B,))
+    actions = torch.cat([a_d.float().unsqueeze(1), mean.detach() + torch.randn(B, NC) * 0.7], 1)
+    old_mu, old_sigma = mean.detach() + 0.1 * torch.randn(B, NC), (std.detach() * (1 + 0.1 * torch.randn(NC))).abs().expand(B, NC).contiguous()
+    old_logp_d = torch.log_softmax(logits.detach() + 0.3 * torch.randn(B, ND), -1)[torch.arange(B), a_d]
+    old_logp_c = Normal(old_mu, old_sigma).log_prob(actions[:, 1:]).sum(-1) + 0.2 * torch.randn(B)
+    adv, ret, tv = torch.randn(B), torch.randn(B), value.detach() + 0.3 * torch.randn(B)
+    # eager expression
+    dist_d = Categorical(probs=torch.softmax(logits, -1), validate_args=False)
+    dist_c = Normal(mean, mean * 0.0 + std, validate_args=False)
+    logp_d, logp_c = dist_d.log_prob(a_d.float()), dist_c.log_prob(actions[:, 1:]).sum(-1)
+    ent = dist_c.entropy().mean(-1) + dist_d.entropy()
+    surr = lambda lp, olp: torch.max(-adv * torch.exp(lp - olp), -adv * torch.clamp(torch.exp(lp - olp), 1 - clip, 1 + clip)).mean()   # noqa: E731
+    s_d, s_c = surr(logp_d, old_logp_d), surr(logp_c, old_logp_c)
+    vclip = tv + (value - tv).clamp(-clip, clip)
+    vl = torch.max((value - ret).pow(2), (vclip - ret).pow(2)).mean()
+    loss = s_d + s_c + cv * vl - ce * ent.mean()
+    loss.backward()
+    sigma = dist_c.stddev
+    kl = torch.sum(torch.log(sigma / old_sigma + 1e-5) + (old_sigma.square() + (old_mu - mean).square()) / (2 * sigma.square()) - 0.5, -1).mean()
+    # twin
+    c = lambda t: t.detach().contiguous()                                    # noqa: E731
+    ins = [c(x) for x in (logits, mean, std, value, actions, old_logp_d, old_logp_c, old_mu, old_sigma, adv, ret, tv)]
+    dlg, dmu, dsd, dv, out = torch.empty(B, ND), torch.empty(B, NC), torch.empty(NC), torch.empty(B), torch.empty(8)
+    assert f(*[t.data_ptr() for t in ins], B, ND, NC, clip, cv, ce, 1, dlg.data_ptr(), dmu.data_ptr(), dsd.data_ptr(), dv.data_ptr(), out.data_ptr(), None, 0, None) == 0
+    ref = [loss.item(), (s_d + s_c).item(), vl.item(), ent.mean().item(), kl.item(), s_d.item(), s_c.item()]
+    assert np.allclose(out.numpy()[:7], ref, rtol=2e-5, atol=2e-6), (out, ref)
+    for got, want, name in ((dlg, logits.grad, "logits"), (dmu, mean.grad, "mean"), (dsd, std.grad, "std"), (dv, value.grad, "value")):
+        assert torch.allclose(got, want, rtol=2e-4, atol=2e-7), (name, (got - want).abs().max())
