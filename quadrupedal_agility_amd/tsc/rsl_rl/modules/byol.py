@@ -54,16 +54,11 @@ class EMA:
         return new if old is None else old * self.beta + (1 - self.beta) * new
 
 
-def _batch_norm(width):
-    """MaybeSyncBatchnorm (:41-43): batch statistics over ALL ranks' samples in a data-parallel run (RCCL; GPU only)"""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
-        return nn.SyncBatchNorm(width)
-    return nn.BatchNorm1d(width)
-
-
 def MLP(dim, projection_size, hidden_size=4096):
-    return nn.Sequential(nn.Linear(dim, hidden_size), _batch_norm(hidden_size), nn.ReLU(inplace=True), nn.Linear(hidden_size, projection_size))
+    """projector / predictor.  The reference's MaybeSyncBatchnorm (:41-43): in a data-parallel run over RCCL the runner converts these
+    BatchNorm1d layers with nn.SyncBatchNorm.convert_sync_batchnorm once the module is on its GPU (SyncBatchNorm cannot run the
+    constructor's mock forward on the host)."""
+    return nn.Sequential(nn.Linear(dim, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True), nn.Linear(hidden_size, projection_size))
 
 
 class NetWrapper(nn.Module):

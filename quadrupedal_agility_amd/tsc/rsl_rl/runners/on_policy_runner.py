@@ -58,6 +58,10 @@ class OnPolicyRunner:
         if self.if_depth:                        # :88-101
             self.depth_backbone = DepthOnlyFCBackbone58x87(self.n_proprio, self.n_depth_latent, self.depth_encoder_cfg["hidden_dims"])
             self.depth_encoder = RecurrentDepthBackbone(self.depth_backbone, self.n_depth_latent, env.cfg).to(device)
+            if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl"
+                    and torch.device(device).type == "cuda"):          # batch statistics over ALL ranks' samples (byol.py:41-43)
+                self.depth_encoder = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.depth_encoder)
+                self.depth_backbone = self.depth_encoder.base_backbone
             self.depth_actor = deepcopy(self.actor_critic.actor)
             self.depth_backbone.augment = self.depth_encoder.byol_learner.augment1
         self.alg = PPO(self.actor_critic, self.actor_critic_bbc, self.estimator, self.estimator_cfg, self.depth_encoder, self.depth_encoder_cfg,

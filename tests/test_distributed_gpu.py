@@ -78,3 +78,50 @@ def test_two_ranks_over_rccl():
     out = sorted([q.get(timeout=900) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
     _check_replicas(out, False)
+
+
+def _tsc_worker(rank, world, port, q, vision, iters):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import class_to_dict
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.go2.go2_agility_config import Go2AgilityCfg, Go2AgilityCfgPPO
+    from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
+    n = 128
+    cfg = Go2AgilityCfg()
+    cfg.env.num_envs, cfg.seed, cfg.course_seed = n, 1, 1 + rank
+    cfg.env.env_id_offset, cfg.env.num_envs_global = rank * n, world * n
+    cfg.env.episode_length_s = 1.0
+    cfg.depth.use_camera = vision
+    tcfg = class_to_dict(Go2AgilityCfgPPO())
+    tcfg["depth_encoder"]["if_depth"] = vision
+    torch.manual_seed(100 + rank)                      # different initial weights per rank: the broadcast must fix that
+    env = lr.LeggedRobot(cfg, sim_device="cuda:0")
+    runner = OnPolicyRunner(env, tcfg, log_dir=None, device="cuda:0")
+    assert runner.distributed
+    runner.learn(iters, init_at_random_ep_len=not vision)
+    torch.cuda.synchronize()
+    a = runner.alg
+    mods = (a.depth_encoder, a.depth_actor) if vision else (a.actor_critic, a.estimator)
+    flat = torch.cat([p.detach().flatten() for m in mods for p in m.parameters()]).cpu()
+    two_graphs = (not vision) and isinstance(a._graph, tuple) and a._graph[1] is not None
+    q.put((rank, flat.numpy(), float(a.learning_rate), bool(two_graphs), bool(torch.isfinite(flat).all()), env.root_states[:, :3].cpu().numpy().copy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("vision", [False, True])
+def test_task_level_two_ranks_on_one_gpu_keep_replicas_identical(vision):
+    """BASELINE configs[3] / [4] are 8-GPU jobs of the task-level tree: two ranks (sharing cuda:0, gloo moving the CUDA buckets) train
+    the teacher -- recorded rollout, the update as TWO hipGraphs around the gradient collective -- and the depth student (DAgger + BYOL
+    gradients averaged); replicas stay identical, the ranks simulate different envs"""
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    ps = [ctx.Process(target=_tsc_worker, args=(r, 2, port, q, vision, 4 if not vision else 2)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
+    [p.join(120) for p in ps]
+    (_, w0, lr0, g0, f0, pos0), (_, w1, lr1, g1, f1, pos1) = out
+    assert f0 and f1 and np.array_equal(w0, w1) and lr0 == lr1
+    if not vision:
+        assert g0 and g1                               # the update really ran as two graphs around the all-reduce
+    assert not np.allclose(pos0, pos1)
