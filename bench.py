@@ -31,6 +31,9 @@ UPDATE_FLOPS_PER_SAMPLE = 2 * (3 * _FWD - 343552 - 7296) + 2 * 28770      # fwd 
 ROLLOUT_FLOPS_PER_SAMPLE = 2 * (217088 + 3712 + 507520 + 15744)
 
 
+_RESULT_OUT = sys.stdout
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +59,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    global _RESULT_OUT
+    _RESULT_OUT, sys.stdout = sys.stdout, sys.stderr       # stdout carries the ONE JSON line; the libraries' chatter goes to stderr
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
@@ -234,7 +239,7 @@ def main():
         # JSON line is the LAST line of output
         import ctypes
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_RESULT_OUT, flush=True)
 
 
 def _barrier_sync(world):
@@ -343,7 +348,7 @@ def bench_tsc(args, world, rank, local_rank, dev):
     if args.vision:
         out["vision"] = dict(runner.last_vision)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_RESULT_OUT, flush=True)
 
 
 def cpu_baseline(num_envs, budget_s):
