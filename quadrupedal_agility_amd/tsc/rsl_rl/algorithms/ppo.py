@@ -317,9 +317,11 @@ class PPO:
                 cflat = st.privileged_observations.flatten(0, 1) if st.privileged_observations is not None else None
 
                 def front():
-                    rows = [x[self._mb_idx] for x in flat]
-                    rows.insert(1, cflat[self._mb_idx] if cflat is not None else rows[0])
-                    return self._minibatch_forward_backward(rows, self._hist_latent_all[self._mb_idx], self._coef_dev)
+                    srcs = flat + [self._hist_latent_all] + ([cflat] if cflat is not None else [])
+                    got = fused.gather_rows(self._mb_idx, srcs)          # the indexed reads of a minibatch in ONE launch
+                    rows, hl = list(got[:len(flat)]), got[len(flat)]
+                    rows.insert(1, got[-1] if cflat is not None else rows[0])
+                    return self._minibatch_forward_backward(rows, hl, self._coef_dev)
 
                 def apply(kl):
                     self._step_estimator.step()
