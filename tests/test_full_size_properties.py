@@ -86,3 +86,30 @@ def test_state_and_bookkeeping_invariants_at_4096_envs():
     assert torch.allclose(ret[m], rew[m], atol=1e-5)
     h.gae(rew, val, done, last, ret, adv, 0.99, 0.95, normalize=True)
     assert abs(float(adv.mean())) < 1e-4 and abs(float(adv.std()) - 1.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_env_shards_reproduce_the_one_process_run_bit_for_bit():
+    """SURVEY 8e on the device: two 2048-env shards (env_id_offset 0 / 2048 of a 4096-env job) are the 4096-env run, bit for bit --
+    domain randomisation, spawn slots, resets, command resampling, pushes, observation noise are keyed by the GLOBAL env id"""
+    import numpy as np
+    from quadrupedal_agility_amd.sim import QaSim
+    from tests.oracle_lib import go2_cfg
+    n, half = 4096, 2048
+    whole = QaSim(go2_cfg(n, seed=5))
+    parts = [QaSim(go2_cfg(half, seed=5, env_id_offset=off, num_envs_global=n)) for off in (0, half)]
+    for s in [whole] + parts:
+        s.reset_all()
+    ep = (torch.arange(n, device="cuda") * 37 % 1000)
+    whole.t["EPISODE_LENGTH"].copy_(ep); parts[0].t["EPISODE_LENGTH"].copy_(ep[:half]); parts[1].t["EPISODE_LENGTH"].copy_(ep[half:])
+    for s in [whole] + parts:
+        s.global_step = 395                                   # a push at common step 400 falls inside the window
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for k in range(10):
+        act = torch.randn(n, 12, device="cuda", generator=g)
+        whole.step(act); parts[0].step(act[:half].contiguous()); parts[1].step(act[half:].contiguous())
+        for name in ("ROOT_STATES", "DOF_STATE", "OBS", "REW", "RESET", "COMMANDS", "LATENT_C", "EPISODE_LENGTH", "CONTACT_FORCES"):
+            got = torch.cat([p.t[name] for p in parts])
+            assert torch.equal(got, whole.t[name]), (k, name)
+    for name in ("FRICTION", "MASS_PARAMS", "ENV_ORIGINS"):
+        assert torch.equal(torch.cat([p.t[name] for p in parts]), whole.t[name]), name
