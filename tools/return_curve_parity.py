@@ -36,6 +36,15 @@ def run(device, num_envs, iters, seed, amp=False):
         args = get_args(["--device", "gpu"])
         env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
     runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=log_root)
+    if os.environ.get("QA_PARITY_EAGER") == "1":          # GPU side without recorded launches / stream overlap (bisecting a difference)
+        runner.alg.use_update_graph = False
+        runner.alg.overlap_updates = False
+    if os.environ.get("QA_PARITY_EAGER_UPDATE") == "1":
+        runner.alg.use_update_graph = False
+    if os.environ.get("QA_PARITY_NO_DISC_GRAPH") == "1":
+        runner.alg._disc_graph = False
+    if os.environ.get("QA_PARITY_NO_AC_GRAPH") == "1":
+        runner.alg._ac_graph = False
     t0 = time.time()
     runner.learn(iters, init_at_random_ep_len=True)
     wall = time.time() - t0
@@ -91,7 +100,7 @@ def main():
         rows = []
         for seed in a.seeds:
             cur, wall, fps = run(a.side, a.num_envs, a.iters, seed, a.amp)
-            rows.append({"seed": seed, "env_steps_per_s": fps, "curves": {k: v for k, v in cur.items() if k.startswith(("Train/", "Episode/"))}})
+            rows.append({"seed": seed, "env_steps_per_s": fps, "curves": {k: v for k, v in cur.items() if k.startswith(("Train/", "Episode/", "Loss"))}})
             print(a.side, "seed", seed, "done in", round(wall, 1), "s", flush=True)
         json.dump({"side": a.side, "amp": bool(a.amp), "num_envs": a.num_envs, "iters": a.iters, "rows": rows}, open(a.out, "w"))
         return
