@@ -258,6 +258,18 @@ class SSInfoGAIL:
             if self._on_gpu and self.use_update_graph and self.grad_sync is None and self._warm_updates >= 1 and self._disc_graph is not False:
                 acc_d = self._disc_updates_recorded(n_d, mb).clone()
                 self._clamp_std()
+            elif os.environ.get("QA_DEBUG_EAGER_FROM_TABLES") == "1" and self._on_gpu:
+                # debugging aid: the eager steps on exactly the samples the recorded path would draw (same generator calls)
+                ml, rb = self.motion_loader, self.disc_storage
+                tabs = [torch.zeros(n_d, mb, dtype=torch.int64, device=dev) for _ in range(3)]
+                nsd = torch.full((), float(rb.num_samples), device=dev)
+                tabs[0].copy_((torch.rand(tabs[0].shape, device=dev) * nsd).long())
+                torch.randint(0, ml.preloaded_s_lb.shape[0], tabs[1].shape, device=dev, out=tabs[1])
+                torch.randint(0, ml.preloaded_s_ulb.shape[0], tabs[2].shape, device=dev, out=tabs[2])
+                for k in range(n_d):
+                    i_pi, i_lb, i_ulb = tabs[0][k], tabs[1][k], tabs[2][k]
+                    acc_d += torch.stack(self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
+                                                                  (ml.preloaded_s_lb[i_lb], ml.preloaded_label[i_lb]), ml.preloaded_s_ulb[i_ulb]))
             else:
                 gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
                            self.motion_loader.feed_forward_generator_lb(n_d, mb),
