@@ -779,7 +779,11 @@ class SSInfoGAIL:
         a = self.num_prop + self.num_explicit; b = a + self.num_latent; c = b + self.num_hist * self.num_prop
         with torch.no_grad():
             target = ac.infer_priv_latent(obs[:, a:b])
-        loss = (target - ac.infer_hist_latent(obs[:, b:c])).norm(p=2, dim=1).mean()
+        hist = ac.infer_hist_latent(obs[:, b:c])
+        if self._on_gpu and fused_mod.ENABLED:      # value + gradient in one pass, fixed-order row sum (no torch reduction in the recorded step)
+            loss = fused_mod.pair_loss(hist, target, fused_mod.PAIR_ROW_L2)
+        else:
+            loss = (target - hist).norm(p=2, dim=1).mean()
         self.optim_hist_encoder.zero_grad()
         loss.backward()
         params = list(ac.history_encoder.parameters())

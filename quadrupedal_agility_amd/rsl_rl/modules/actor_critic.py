@@ -73,6 +73,21 @@ class StateHistoryEncoder(nn.Module):
         equivalent (B*T_out, k*C) x (k*C, C_out) matmul is one small hipBLASLt GEMM.  Parameters stay in the Conv1d
         modules, so state_dict names/shapes are unchanged."""
         b = obs.shape[0]
+        fused = _fused_for(obs, self.activation_fn)
+        if fused is not None:
+            # training on ROCm: every layer is Linear+ELU through fused.linear_elu, whose bias gradient is our own fixed-order
+            # column sum.  torch's tall-skinny `sum(0)` (61440 x 30, 18432 x 10, ...) is a two-stage reduction whose second stage
+            # does not re-run under hipGraph replay on this ROCm -- the recorded DAgger step trained these biases on a stale
+            # gradient (profiles/r2_hipgraph_stale_reductions.md)
+            alpha = self.activation_fn.alpha
+            enc, out = self.encoder[0], self.linear_output[0]
+            x = fused.linear_elu(obs.reshape(b * self.tsteps, -1), enc.weight, enc.bias, alpha).reshape(b, self.tsteps, -1)
+            for m in self.conv_layers:
+                if isinstance(m, nn.Conv1d):
+                    win, t_out = _conv1d_windows(x, m)
+                    x = fused.linear_elu(win, m.weight.reshape(m.out_channels, -1), m.bias, alpha).reshape(b, t_out, m.out_channels)
+            x = x.permute(0, 2, 1).reshape(b, -1)
+            return fused.linear_elu(x, out.weight, out.bias, alpha)
         x = self.encoder(obs.reshape(b * self.tsteps, -1)).reshape(b, self.tsteps, -1)      # (B, T, C) channels last
         for m in self.conv_layers:
             if isinstance(m, nn.Conv1d):
@@ -83,15 +98,28 @@ class StateHistoryEncoder(nn.Module):
         return self.linear_output(x)
 
 
-def _conv1d_channels_last(x, conv):
-    """x (B, T, C_in) -> (B, T_out, C_out) for a Conv1d(C_in, C_out, k, stride) without padding/dilation."""
+def _fused_for(x, act):
+    """algorithms/fused.py when `x` is a ROCm tensor under autograd and the activation is ELU, else None"""
+    if x.is_cuda and torch.is_grad_enabled() and isinstance(act, nn.ELU) and x.dtype == torch.float32:
+        from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+        if fused.ENABLED:
+            return fused
+    return None
+
+
+def _conv1d_windows(x, conv):
+    """x (B, T, C_in) -> ((B * T_out, C_in * k) window rows in the weight's (c, k) order, T_out)"""
     k, s = conv.kernel_size[0], conv.stride[0]
     b, t, c = x.shape
     t_out = (t - k) // s + 1
-    win = x.unfold(1, k, s)                              # (B, T_out, C_in, k) view
-    w = conv.weight.reshape(conv.out_channels, c * k)    # (C_out, C_in * k), same (c, k) order as the window
-    y = torch.addmm(conv.bias, win.reshape(b * t_out, c * k), w.t())
-    return y.reshape(b, t_out, conv.out_channels)
+    return x.unfold(1, k, s).reshape(b * t_out, c * k), t_out
+
+
+def _conv1d_channels_last(x, conv):
+    """x (B, T, C_in) -> (B, T_out, C_out) for a Conv1d(C_in, C_out, k, stride) without padding/dilation."""
+    win, t_out = _conv1d_windows(x, conv)                # rows of the (B, T_out, C_in, k) unfold view
+    w = conv.weight.reshape(conv.out_channels, -1)       # (C_out, C_in * k), same (c, k) order as the window
+    return torch.addmm(conv.bias, win, w.t()).reshape(x.shape[0], t_out, conv.out_channels)
 
 
 class ActorCritic(nn.Module):

@@ -178,7 +178,9 @@ class PPO:
         ac = self.actor_critic
         coef = self._priv_reg_coef_now()
         if (self.use_update_graph and self._graph is not False and self._warm_updates >= 1 and fused.ENABLED and torch.device(self.device).type == "cuda"
-                and self.desired_kl is not None and self.schedule == "adaptive"):
+                and self.desired_kl is not None and self.schedule == "adaptive" and self.use_fused_loss):
+            # (use_fused_loss: the eager objective reduces through torch's two-stage sum / mean, which go stale under hipGraph replay
+            # at 24576+ rows -- tools/graph_reduction_audit.py; the recorded step only ever contains our own fixed-order reductions)
             sums = self._update_recorded(coef)
             if sums is not None:
                 v, s, e, p = (sums / (self.num_learning_epochs * self.num_mini_batches)).tolist()
