@@ -50,25 +50,40 @@ class Discriminator(nn.Module):
         ok = len(mods) % 2 == 0 and all(isinstance(mods[i], nn.Linear) and isinstance(mods[i + 1], nn.ReLU) for i in range(0, len(mods), 2))
         return [mods[i] for i in range(0, len(mods), 2)] if ok else None
 
-    def forward_with_input_gradient(self, x, rows, clamp=True):
+    def forward_with_input_gradient(self, x, rows, clamp=True, proxies=None):
         """Heads on all rows of x plus d logit / d x on the row slice `rows` -- the quantity the gradient penalty squares
         (gail.py:487-492 obtains it with autograd.grad(..., create_graph=True)).  For this piecewise-linear trunk it is
             g = W_1^T diag(m_1) W_2^T diag(m_2) ... w_out,      m_l = [layer l is active]
         evaluated as a chain of small GEMMs on the slice only; the masks are constants (ReLU has no curvature), so
         differentiating g w.r.t. the weights with ordinary autograd gives exactly the double-backward result, without
         making the input a leaf, without a second-order graph over the whole batch."""
+        from quadrupedal_agility_amd.rsl_rl.algorithms import fused
         lins = self._relu_trunk()
         assert lins is not None
         h, masks = x, []
+        # every reduction over the batch in this step's backward (bias gradients of the trunk and the heads, the first link of the
+        # penalty chain) goes through our fixed-order kernels: torch's `sum(0)` left the first trunk bias's gradient buffer
+        # unwritten under hipGraph replay (garbage -> Adam second moment = inf -> the 512 biases stopped training)
         for lin in lins:
-            h = torch.relu(lin(h))
+            h = fused.linear_relu(lin, h)
             masks.append(torch.sign(h[rows].detach()))   # h >= 0 after the ReLU: sign = [h > 0] as floats, one launch instead of two (a constant: detached)
-        c = torch.softmax(self.classifier(h), -1)
-        heads = (self.linear(h), self.encoder_eps(h), torch.clamp(c, 1e-20, torch.inf) if clamp else c)     # clamp=False: qa_disc_loss clamps
-        v = masks[-1] * self.linear.weight                      # (rows, H_last): d logit / d (last pre-activation)
+        head = lambda m: fused.narrow_linear(m, h, always=True)
+        c = torch.softmax(head(self.classifier), -1)
+        heads = (head(self.linear), head(self.encoder_eps), torch.clamp(c, 1e-20, torch.inf) if clamp else c)     # clamp=False: qa_disc_loss clamps
+        # `proxies` (a list to fill): the chain reads each weight through a fresh leaf that shares its storage, so that every real
+        # parameter enters the autograd graph ONCE; the caller adds proxy.grad to param.grad after backward().  Without it the
+        # engine sums the two contributions of a weight in its input buffer on the AccumulateGrad node's stream -- under a
+        # recorded step that is a second branch of the hipGraph (profiles/r2_cfg3_fast_path_vs_eager_bisect.md).
+        def leaf(w):
+            if proxies is None:
+                return w
+            q = w.detach().requires_grad_(True)
+            proxies.append((w, q))
+            return q
+        v = fused.mask_times_row(masks[-1], leaf(self.linear.weight))      # (rows, H_last): d logit / d (last pre-activation)
         for l in range(len(lins) - 1, 0, -1):
-            v = (v @ lins[l].weight) * masks[l - 1]
-        return heads, v @ lins[0].weight                        # (rows, input_dim)
+            v = (v @ leaf(lins[l].weight)) * masks[l - 1]
+        return heads, v @ leaf(lins[0].weight)                  # (rows, input_dim)
 
     def prepare_input(self, obs_disc, task_obs_weight):
         """(B, disc_obs_len, 49) -> (B, 98): task dims weighted (discriminator.py:77-87)."""

@@ -137,6 +137,71 @@ class _LinearElu(torch.autograd.Function):
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
+class _LinearRelu(torch.autograd.Function):
+    """y = relu(x W^T + b) with the same backward kernel as _LinearElu (ELU with alpha = 0 IS ReLU: derivative 1 for y > 0, y + 0 = 0
+    otherwise), i.e. the bias gradient is our fixed-order column sum, not torch's `sum(0)` (see profiles/r2_hipgraph_stale_reductions.md)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch.addmm(bias, x, weight.t())
+        torch.relu_(y)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g, gb = _masked_colsum(gy, y)
+        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        gw = weight_grad(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gb if ctx.needs_input_grad[2] else None)
+
+
+def _masked_colsum(gy, y):
+    """(gy * [y > 0], column sums of that): qa_elu_backward_bias with alpha = 0"""
+    lib = _capi.load_library()
+    gy, y = _f32c(gy), _f32c(y)
+    rows, cols = y.shape
+    g = torch.empty_like(y)
+    gb = torch.empty(cols, dtype=torch.float32, device=y.device)
+    nscratch = int(lib.qa_elu_backward_bias_scratch_bytes(rows, cols))
+    scratch = torch.empty(nscratch, dtype=torch.uint8, device=y.device)
+    rc = lib.qa_elu_backward_bias(_ptr(gy), _ptr(y), _ptr(g), _ptr(gb), rows, cols, 0.0, _ptr(scratch), nscratch,
+                                  C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"qa_elu_backward_bias failed with code {rc}: {lib.qa_last_error().decode()}")
+    return g, gb
+
+
+def linear_relu(m, x):
+    """relu(m(x)) for an nn.Linear; through _LinearRelu on ROCm tensors under autograd"""
+    if ENABLED and x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and m.bias is not None and x.dtype == torch.float32:
+        return _LinearRelu.apply(x, m.weight, m.bias)
+    return torch.relu(m(x))
+
+
+class _MaskTimesRow(torch.autograd.Function):
+    """v = mask * w for a constant 0/1 mask (rows, n) and a row vector w (1, n) (the start of the gradient-penalty chain): the
+    gradient of w is a column sum over the rows -- ours, not torch's broadcast reduction."""
+
+    @staticmethod
+    def forward(ctx, mask, w):
+        ctx.save_for_backward(mask)
+        return mask * w
+
+    @staticmethod
+    def backward(ctx, gv):
+        (mask,) = ctx.saved_tensors
+        _, gw = _masked_colsum(gv, mask)
+        return None, gw.view(1, -1)
+
+
+def mask_times_row(mask, w):
+    if ENABLED and mask.is_cuda and torch.is_grad_enabled() and w.dim() == 2 and w.shape[0] == 1 and mask.dtype == torch.float32:
+        return _MaskTimesRow.apply(mask, w)
+    return mask * w
+
+
 WGRAD_SLABS = 8
 
 
@@ -187,13 +252,14 @@ class _NarrowLinear(torch.autograd.Function):
 
 
 NARROW_MAX_OUT = 32
-NARROW_MIN_ROWS = 2048
+NARROW_MIN_ROWS = 1          # every batch size: an eager step and its recording must run the same kernels (and a recording must not contain torch's sum(0))
 
 
-def narrow_linear(m, x):
-    """`m(x)` for an nn.Linear head; through _NarrowLinear on ROCm tensors under autograd when the layer is narrow and the batch long"""
+def narrow_linear(m, x, always=False):
+    """`m(x)` for an nn.Linear head; through _NarrowLinear on ROCm tensors under autograd when the layer is narrow and the batch long
+    (`always`: whatever NARROW_MIN_ROWS says)"""
     if (ENABLED and x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and m.bias is not None and m.out_features <= NARROW_MAX_OUT
-            and x.shape[0] >= NARROW_MIN_ROWS and x.dtype == torch.float32 and m.weight.requires_grad):
+            and (x.shape[0] >= NARROW_MIN_ROWS or always) and x.dtype == torch.float32 and m.weight.requires_grad):
         return _NarrowLinear.apply(x, m.weight, m.bias)
     return m(x)
 

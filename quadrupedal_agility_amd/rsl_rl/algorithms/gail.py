@@ -12,6 +12,7 @@ constructor signature and attribute names are the reference's.  What is differen
   * `amp_enabled=False` skips the discriminator update (BASELINE config 2; the reference has no
     such switch).
 """
+import json
 import os
 
 import torch
@@ -270,6 +271,8 @@ class SSInfoGAIL:
                     i_pi, i_lb, i_ulb = tabs[0][k], tabs[1][k], tabs[2][k]
                     acc_d += torch.stack(self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
                                                                   (ml.preloaded_s_lb[i_lb], ml.preloaded_label[i_lb]), ml.preloaded_s_ulb[i_ulb]))
+                    if os.environ.get("QA_DEBUG_DISC_TRACE"):
+                        self._trace_disc(os.environ["QA_DEBUG_DISC_TRACE"])
             else:
                 gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
                            self.motion_loader.feed_forward_generator_lb(n_d, mb),
@@ -280,6 +283,30 @@ class SSInfoGAIL:
         self.priv_reg_counter += 1
         self._warm_updates += 1
         return LossReadout(torch.cat([acc_ac / n_ac, acc_d / n_d]))
+
+    def _trace_disc(self, path):
+        """debugging aid: one line of checksums per discriminator step"""
+        torch.cuda.synchronize()
+        cs = lambda ps: float(torch.cat([p.detach().flatten() for p in ps]).double().sum())
+        st = [float(sum(s_[k].double().sum() for s_ in o.state.values())) for o in (self.optim_d, self.optim_q_eps, self.optim_q_c) for k in ("exp_avg", "exp_avg_sq")]
+        if os.environ.get("QA_DEBUG_DISC_TRACE_PTRS") == "1":
+            snap = torch.cuda.memory_snapshot()
+            def where(ptr):
+                for seg in snap:
+                    if seg["address"] <= ptr < seg["address"] + seg["total_size"]:
+                        state = [b["state"] for b in seg["blocks"] if b.get("address", 0) <= ptr < b.get("address", 0) + b["size"]] if "address" in seg["blocks"][0] else "?"
+                        return (seg.get("segment_pool_id"), seg["stream"], state)
+                return None
+            names = [n for n, _ in self.disc.named_parameters()]
+            for (n, p_), o in zip(self.disc.named_parameters(), [None] * len(names)):
+                stt = next((o_.state[p_] for o_ in (self.optim_d, self.optim_q_eps, self.optim_q_c) if p_ in o_.state), None)
+                print("[disc ptr]", self.learning_steps, n, tuple(p_.shape), "grad", None if p_.grad is None else hex(p_.grad.data_ptr()),
+                      where(p_.grad.data_ptr()) if p_.grad is not None else None, "v inf" if stt is not None and bool(torch.isinf(stt["exp_avg_sq"]).any()) else "",
+                      "g max %.3g" % float(p_.grad.abs().max()) if p_.grad is not None else "", flush=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(update=self.learning_steps, disc=[float(p.detach().double().sum()) for p in self.disc.parameters()], adam=st,
+                                    norm=float(self.disc_normalizer.mean.double().sum()), count=float(self.disc_normalizer.count),
+                                    prior=float(self.env.prior_parameters.double().sum()))) + "\n")
 
     def _clamp_std(self):
         """gail.py:522-523 (inside every discriminator step there; idempotent, and nothing reads std in between)"""
@@ -421,6 +448,8 @@ class SSInfoGAIL:
                 for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
                     o.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
+                if os.environ.get("QA_DEBUG_DUMP_DISC_GRAPH"):
+                    g.enable_debug_mode()
                 from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
                 # recorded on a stream of its own: the library GEMM workspace is keyed by the stream a launch is recorded on,
                 # and this step is replayed CONCURRENTLY with the PPO step's recording (update(), "overlap")
@@ -432,6 +461,8 @@ class SSInfoGAIL:
                         one_step()
                 finally:
                     self._recording_disc = False
+                if os.environ.get("QA_DEBUG_DUMP_DISC_GRAPH"):
+                    g.debug_dump(os.environ["QA_DEBUG_DUMP_DISC_GRAPH"])
                 self._disc_graph = g
             except Exception as e:      # never fatal
                 print(f"[disc update graph] capture failed, staying eager: {e}")
@@ -445,6 +476,8 @@ class SSInfoGAIL:
                 return acc
         self._n_samples_dev.fill_(float(self.disc_storage.num_samples))
         self._info_max_dev.fill_(float(self.info_max_coef_on))
+        if self._task_w_dev is not None:        # eager rollouts keep the task-observation weight on the host: the recorded step reads this scalar
+            self._task_w_dev.fill_(float(self.env.task_obs_weight))
         self._acc_d.zero_()
         ml = self.motion_loader
         t_pi, t_lb, t_ulb, t_lab = self._d_tables
@@ -453,8 +486,16 @@ class SSInfoGAIL:
         torch.randint(0, ml.preloaded_s_ulb.shape[0], t_ulb.shape, device=dev, out=t_ulb)
         t_lab.copy_(ml.preloaded_label[t_lb.view(-1)].view(t_lb.shape))
         self._d_step.zero_()
+        step_sync = os.environ.get("QA_DEBUG_DISC_STEP_SYNC") == "1"      # debugging aid: drain the GPU between replays
+        if os.environ.get("QA_DEBUG_DISC_PRE_SYNC") == "1":
+            torch.cuda.synchronize()
+        trace = os.environ.get("QA_DEBUG_DISC_TRACE")
         for _ in range(n_steps):
             self._disc_graph.replay()
+            if step_sync:
+                torch.cuda.synchronize()
+            if trace:
+                self._trace_disc(trace)
         return self._acc_d          # persistent: the caller copies it on ITS stream after joining
 
     def _sync_grads(self, params):
@@ -659,8 +700,9 @@ class SSInfoGAIL:
         analytic_gp = self.disc._relu_trunk() is not None
         fused_heads = self._on_gpu and self.use_fused_loss and self.disc_loss_function == "MSELoss"
         if analytic_gp:      # d logit / d x on the unlabelled rows as a chain of small GEMMs (discriminator.py), no second-order graph
+            gp_proxies = [] if os.environ.get("QA_DISC_GP_PROXIES", "1") != "0" else None
             (d_all, eps_all, c_all), g = self.disc.forward_with_input_gradient(x_all if x_all is not None else torch.cat([expert_lb, policy_state, expert_ulb], dim=0),
-                                                                                slice(b_lb + b_pi, None), clamp=not fused_heads)
+                                                                                slice(b_lb + b_pi, None), clamp=not fused_heads, proxies=gp_proxies)
         else:
             x_ulb = expert_ulb.clone().requires_grad_(True)
             d_all, eps_all, c_all = self.disc(torch.cat([expert_lb, policy_state, x_ulb], dim=0))
@@ -737,6 +779,9 @@ class SSInfoGAIL:
             torch.autograd.backward([d_all, eps_all, c_all, g], [g_d, g_eps, g_c, gdet * (2.0 * self.disc_grad_penalty / gdet.shape[0])])
         else:
             loss.backward()
+        if analytic_gp and gp_proxies:
+            with torch.no_grad():       # the penalty's share of the weight gradients (see forward_with_input_gradient)
+                torch._foreach_add_([w.grad for w, _ in gp_proxies], [q.grad for _, q in gp_proxies])
         if fold_reg:
             with torch.no_grad():
                 torch._foreach_add_([w.grad for w in reg_w[:-1]], reg_w[:-1], alpha=2.0 * self.disc_weight_decay)

@@ -197,3 +197,34 @@ def test_recorded_dagger_sessions_equal_eager_sessions_on_new_data():
         for (n, _), x, y in zip(a.actor_critic.history_encoder.named_parameters(), got, want):
             assert torch.allclose(x, y, rtol=1e-5, atol=1e-7), (session, n, float((x - y).abs().max()))
         assert any(not torch.equal(x, y) for x, y in zip(got, start[0]))       # the session did train
+
+
+@pytest.mark.parametrize("rollout_graph", ["1", "0"])
+def test_recorded_discriminator_flow_equals_eager_flow_with_phase_syncs(monkeypatch, rollout_graph):
+    """Config 3, the device drained at the phase boundaries (what a run with a log directory does): recorded discriminator steps
+    against eager steps fed the same sample tables must give the SAME discriminator, optimiser state, normaliser and policy, bit for
+    bit, over several updates.  Regression for the r2 finding (profiles/r2_cfg3_fast_path_vs_eager_bisect.md): torch's `sum(0)` left
+    the first trunk bias's gradient buffer unwritten under replay -> garbage gradient -> Adam second moment = inf -> 512 biases
+    stopped training and the style reward came out ~20 % high.  The step's batch reductions are our own kernels now."""
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    monkeypatch.setenv("QA_OVERLAP_UPDATES", "0"); monkeypatch.setenv("QA_DEBUG_EAGER_FROM_TABLES", "1")
+    monkeypatch.setenv("QA_PHASE_TIMING", "1"); monkeypatch.setenv("QA_ROLLOUT_GRAPH", rollout_graph)
+    res = []
+    for recorded in (True, False):
+        torch.manual_seed(0)
+        env, args, tcfg = _make(512, True)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+        runner.phase_timing = True
+        a = runner.alg
+        if not recorded:
+            a._disc_graph = False
+        runner.learn(5, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        assert (a._disc_graph not in (None, False)) == recorded
+        state = [p.detach().clone() for p in a.disc.parameters()] + [p.detach().clone() for p in a.actor_critic.parameters()]
+        adam = [st[k].clone() for o in (a.optim_d, a.optim_q_eps, a.optim_q_c) for st in o.state.values() for k in ("exp_avg", "exp_avg_sq")]
+        assert all(torch.isfinite(t).all() for t in adam)
+        res.append((state, adam, a.disc_normalizer.mean.clone(), env.prior_parameters.clone()))
+    (sa, aa, na, pa), (sb, ab, nb, pb) = res
+    assert all(torch.equal(x, y) for x, y in zip(sa, sb)) and all(torch.equal(x, y) for x, y in zip(aa, ab))
+    assert torch.equal(na, nb) and torch.equal(pa, pb)

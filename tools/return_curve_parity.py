@@ -27,7 +27,7 @@ def run(device, num_envs, iters, seed, amp=False):
     cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = bool(amp); cfg.seed = seed
     t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = bool(amp); t.seed = seed; t.runner.save_interval = 10 ** 9
     torch.manual_seed(seed)
-    log_root = tempfile.mkdtemp(prefix="qa_parity_")
+    log_root = None if os.environ.get("QA_PARITY_NO_LOG") == "1" else tempfile.mkdtemp(prefix="qa_parity_")
     if device == "cpu":
         from tests.oracle_backend import OracleBackend
         args = get_args(["--device", "cpu"])
@@ -45,11 +45,29 @@ def run(device, num_envs, iters, seed, amp=False):
         runner.alg._disc_graph = False
     if os.environ.get("QA_PARITY_NO_AC_GRAPH") == "1":
         runner.alg._ac_graph = False
+    if os.environ.get("QA_PARITY_CHECKSUMS"):             # per-iteration state checksums (diffing two deterministic variants)
+        a, rows, orig = runner.alg, [], runner.alg.update
+        def update_and_checksum(*args, **kw):
+            r = orig(*args, **kw)
+            cs = lambda ps: float(torch.cat([p.detach().flatten() for p in ps]).double().sum())
+            rows.append(dict(policy=cs(a.actor_critic.parameters()), estimator=cs(a.estimator.parameters()),
+                             disc=cs(a.disc.parameters()) if amp else 0.0, norm=float(a.disc_normalizer.mean.double().sum()) if amp else 0.0,
+                             ring=[int(a.disc_storage.num_samples), int(a.disc_storage.step)] if amp else [],
+                             ring_sum=float(a.disc_storage.states.double().sum()) if amp else 0.0,
+                             disc_adam=[[float(sum(st[k].double().sum() for st in o.state.values())) for k in ("exp_avg", "exp_avg_sq", "step")]
+                                        for o in (a.optim_d, a.optim_q_eps, a.optim_q_c)] if amp else [],
+                             prior=float(env.prior_parameters.double().sum()) if amp else 0.0, losses=[float(v) for v in r] if amp else [],
+                             disc_each=[float(p.detach().double().sum()) for p in a.disc.parameters()] if amp else [],
+                             obs=float(a.storage.observations.double().sum()), rewards=float(a.storage.rewards.double().sum()),
+                             rng=int.from_bytes(bytes(torch.cuda.get_rng_state()[8:16].tolist()), "little") if device != "cpu" else 0))
+            json.dump(rows, open(os.environ["QA_PARITY_CHECKSUMS"], "w"))
+            return r
+        a.update = update_and_checksum
     t0 = time.time()
     runner.learn(iters, init_at_random_ep_len=True)
     wall = time.time() - t0
     curves = {}
-    path = os.path.join(runner.log_dir, "scalars.jsonl")
+    path = os.path.join(runner.log_dir or "/nonexistent", "scalars.jsonl")
     if os.path.exists(path):
         for line in open(path):
             r = json.loads(line)
