@@ -827,3 +827,46 @@ def test_narrow_wgrad_matches_torch_and_oracle(rows, o, k):
     ya.backward(gyc); yb.backward(gyc)
     assert torch.allclose(xa.grad, xb.grad, atol=1e-5)
     assert (lin.weight.grad - ref.weight.grad).abs().max() < tol and (lin.bias.grad - ref.bias.grad).abs().max() < tol
+
+
+@pytest.mark.gpu
+def test_discriminator_step_backward_through_our_reductions_matches_autograd():
+    """The discriminator's training forward (`forward_with_input_gradient`) with every batch reduction of its backward in our kernels
+    (linear_relu = qa_elu_backward_bias with alpha 0, narrow heads at 921 rows, mask_times_row, proxy leaves for the penalty chain)
+    against the same function through plain torch modules + autograd: heads, input gradient, and every parameter gradient."""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    from quadrupedal_agility_amd.rsl_rl.algorithms.discriminator import Discriminator
+
+    class Env:
+        task_obs_weight_decay, task_obs_weight = False, 1.0
+    torch.manual_seed(3)
+    d = Discriminator(Env(), 98, 49, 5, 0.02, "MSELoss", None, 1.0, 0.01, 0.2, 0.2, 2, 2, 0.0, [512, 256], "cuda").cuda()
+    for m in d.trunk:
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.normal_(m.bias, std=0.3)                  # zero-initialised biases would hide a wrong bias gradient's effect on the masks
+    x = torch.randn(921, 98, device="cuda")
+    rows = slice(614, None)
+    gd, ge, gc, gg = torch.randn(921, 1, device="cuda"), torch.randn(921, 1, device="cuda"), torch.randn(921, 5, device="cuda"), torch.randn(307, 98, device="cuda")
+    res = []
+    for enabled in (True, False):
+        keep = fused.ENABLED
+        fused.ENABLED = enabled
+        try:
+            d.zero_grad(set_to_none=True)
+            proxies = [] if enabled else None
+            (dl, eps, c), g = d.forward_with_input_gradient(x, rows, clamp=False, proxies=proxies)
+            if enabled:
+                assert type(dl.grad_fn).__name__.startswith("_NarrowLinear")
+            torch.autograd.backward([dl, eps, c, g], [gd, ge, gc, gg])
+            if proxies:
+                for w, q in proxies:
+                    w.grad.add_(q.grad)
+            res.append(([t.detach().clone() for t in (dl, eps, c, g)], {n: p.grad.detach().clone() for n, p in d.named_parameters()}))
+        finally:
+            fused.ENABLED = keep
+    (oa, ga), (ob, gb) = res
+    for a, b in zip(oa, ob):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+    for n in ga:
+        scale = float(gb[n].abs().max())
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * max(scale, 1.0) * 921 ** 0.5, n
