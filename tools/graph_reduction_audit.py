@@ -9,6 +9,10 @@ semaphores and are not affected.
      is normally recorded executes (forward and backward);
   2. replay each of them from a hipGraph on fresh data and compare with the eager result.
 
+Necessary, not sufficient: the discriminator's (921, 512) bias-gradient `sum(0)` passes step 2 stand-alone and still left its output unwritten
+inside the recorded discriminator step.  The rule the code follows is therefore "no torch reduction over the batch dimension in a gradient path
+of a recorded step"; this tool is the list to read against that rule.
+
     python tools/graph_reduction_audit.py [--envs 1024] [--json out.json]
 """
 import argparse, json, os, sys
