@@ -272,7 +272,11 @@ class LeggedRobot:
                            self._step_dev if self._step_dev.is_cuda else self.common_step_counter)
         # extras["episode"]: mean episode sums of the resetting envs / episode length in seconds (:396-404), kept when nobody resets
         f = (flags != 0).to(torch.float32)
-        cnt = f.sum()
+        # the count of resetting envs decides the extra simulate below (control, not logging) and this code is replayed from a hipGraph:
+        # an atomic scatter-add onto one slot instead of torch's tree reduction (profiles/r2_hipgraph_stale_reductions.md); integers, so exact
+        if getattr(self, "_zero_idx", None) is None or self._zero_idx.shape[0] != f.shape[0]:
+            self._zero_idx = torch.zeros(f.shape[0], dtype=torch.int64, device=f.device)
+        cnt = torch.zeros(1, dtype=torch.float32, device=f.device).index_add_(0, self._zero_idx, f)[0]
         mean = (bk.episode_sums_buf * f).sum(dim=1) / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
         self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
         snap = self._episode_means.clone()
@@ -281,7 +285,7 @@ class LeggedRobot:
             self.extras["time_outs"] = bk.time_out_buf.view(torch.bool)
         bk.reset_where(flags, start_goal)
         if not first:
-            self.sim.simulate_if(None, (flags != 0).any().to(torch.uint8).reshape(1))
+            self.sim.simulate_if(None, (cnt > 0).to(torch.uint8).reshape(1))
         else:
             self.sim.simulate_if(None, torch.ones(1, dtype=torch.uint8, device=self.device))
 
