@@ -287,22 +287,7 @@ class SSInfoGAIL:
     def _trace_disc(self, path):
         """debugging aid: one line of checksums per discriminator step"""
         torch.cuda.synchronize()
-        cs = lambda ps: float(torch.cat([p.detach().flatten() for p in ps]).double().sum())
         st = [float(sum(s_[k].double().sum() for s_ in o.state.values())) for o in (self.optim_d, self.optim_q_eps, self.optim_q_c) for k in ("exp_avg", "exp_avg_sq")]
-        if os.environ.get("QA_DEBUG_DISC_TRACE_PTRS") == "1":
-            snap = torch.cuda.memory_snapshot()
-            def where(ptr):
-                for seg in snap:
-                    if seg["address"] <= ptr < seg["address"] + seg["total_size"]:
-                        state = [b["state"] for b in seg["blocks"] if b.get("address", 0) <= ptr < b.get("address", 0) + b["size"]] if "address" in seg["blocks"][0] else "?"
-                        return (seg.get("segment_pool_id"), seg["stream"], state)
-                return None
-            names = [n for n, _ in self.disc.named_parameters()]
-            for (n, p_), o in zip(self.disc.named_parameters(), [None] * len(names)):
-                stt = next((o_.state[p_] for o_ in (self.optim_d, self.optim_q_eps, self.optim_q_c) if p_ in o_.state), None)
-                print("[disc ptr]", self.learning_steps, n, tuple(p_.shape), "grad", None if p_.grad is None else hex(p_.grad.data_ptr()),
-                      where(p_.grad.data_ptr()) if p_.grad is not None else None, "v inf" if stt is not None and bool(torch.isinf(stt["exp_avg_sq"]).any()) else "",
-                      "g max %.3g" % float(p_.grad.abs().max()) if p_.grad is not None else "", flush=True)
         with open(path, "a") as f:
             f.write(json.dumps(dict(update=self.learning_steps, disc=[float(p.detach().double().sum()) for p in self.disc.parameters()], adam=st,
                                     norm=float(self.disc_normalizer.mean.double().sum()), count=float(self.disc_normalizer.count),
@@ -487,8 +472,6 @@ class SSInfoGAIL:
         t_lab.copy_(ml.preloaded_label[t_lb.view(-1)].view(t_lb.shape))
         self._d_step.zero_()
         step_sync = os.environ.get("QA_DEBUG_DISC_STEP_SYNC") == "1"      # debugging aid: drain the GPU between replays
-        if os.environ.get("QA_DEBUG_DISC_PRE_SYNC") == "1":
-            torch.cuda.synchronize()
         trace = os.environ.get("QA_DEBUG_DISC_TRACE")
         for _ in range(n_steps):
             self._disc_graph.replay()
