@@ -135,3 +135,32 @@ def test_hybrid_ppo_loss_twin_matches_the_eager_objective_and_its_autograd_gradi
     assert np.allclose(out.numpy()[:7], ref, rtol=2e-5, atol=2e-6), (out, ref)
     for got, want, name in ((dlg, logits.grad, "logits"), (dmu, mean.grad, "mean"), (dsd, std.grad, "std"), (dv, value.grad, "value")):
         assert torch.allclose(got, want, rtol=2e-4, atol=2e-7), (name, (got - want).abs().max())
+
+
+def test_penalty_chain_through_proxy_leaves_gives_the_same_gradients():
+    """Discriminator.forward_with_input_gradient(proxies=[...]): the gradient-penalty chain reads the weights through leaves that share
+    their storage, and the caller adds proxy.grad to param.grad -- the same two addends per weight as autograd's own accumulation, so
+    heads, input gradient and every parameter gradient are bit-identical to the direct form (CPU: the fused helpers fall back to torch)."""
+    import torch
+    from quadrupedal_agility_amd.rsl_rl.algorithms.discriminator import Discriminator
+
+    class Env:
+        task_obs_weight_decay, task_obs_weight = False, 1.0
+    torch.manual_seed(1)
+    d = Discriminator(Env(), 98, 49, 5, 0.02, "MSELoss", None, 1.0, 0.01, 0.2, 0.2, 2, 2, 0.0, [64, 32], "cpu")
+    x = torch.randn(60, 98)
+    rows = slice(40, None)
+    seeds = [torch.randn(60, 1), torch.randn(60, 1), torch.randn(60, 5), torch.randn(20, 98)]
+    out = []
+    for use_proxies in (False, True):
+        d.zero_grad(set_to_none=True)
+        proxies = [] if use_proxies else None
+        (dl, eps, c), g = d.forward_with_input_gradient(x, rows, clamp=False, proxies=proxies)
+        torch.autograd.backward([dl, eps, c, g], seeds)
+        if use_proxies:
+            assert len(proxies) == 3 and all(q.data_ptr() == w.data_ptr() for w, q in proxies)
+            for w, q in proxies:
+                w.grad.add_(q.grad)
+        out.append(([t.detach().clone() for t in (dl, eps, c, g)], [p.grad.clone() for p in d.parameters()]))
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
