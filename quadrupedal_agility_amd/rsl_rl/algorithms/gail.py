@@ -124,7 +124,10 @@ class SSInfoGAIL:
         # recordings wait for one eager update since construction / checkpoint load: optimizer state and the pointer
         # tables of the fused optimizer steps must exist before a capture (building them copies from pageable host memory)
         self._warm_updates, self._dagger_warm = 0, 0
-        self.use_update_graph = True   # GPU, single process: the 80 discriminator steps per iteration replay one hipGraph
+        # GPU: the PPO / discriminator / DAgger steps replay hipGraphs -- but only when every batch reduction of their backward is one of
+        # our kernels, i.e. Linear+ELU networks, a ReLU discriminator trunk and the fused objectives: torch's own `sum(0)` goes stale or
+        # unwritten under replay on this ROCm (profiles/r2_hipgraph_stale_reductions.md).  Anything else stays eager.
+        self.use_update_graph = self._recordable_networks()
         self._disc_graph = None
         self._info_max_dev = torch.zeros((), device=device) if self._on_gpu else None
         # PPO step: critic / actor / small nets on three streams (config 2: update 32.2 -> 28.9 ms).  Not with the discriminator: its
@@ -292,6 +295,12 @@ class SSInfoGAIL:
             f.write(json.dumps(dict(update=self.learning_steps, disc=[float(p.detach().double().sum()) for p in self.disc.parameters()], adam=st,
                                     norm=float(self.disc_normalizer.mean.double().sum()), count=float(self.disc_normalizer.count),
                                     prior=float(self.env.prior_parameters.double().sum()))) + "\n")
+
+    def _recordable_networks(self):
+        other = (nn.SELU, nn.ReLU, nn.LeakyReLU, nn.Tanh, nn.Sigmoid, nn.GELU, nn.SiLU)
+        plain = not any(isinstance(m, other) for net in (self.actor_critic, self.estimator) for m in net.modules())
+        disc_ok = (not self.amp_enabled) or (self.disc._relu_trunk() is not None and self.disc_loss_function == "MSELoss")
+        return bool(fused_mod.ENABLED and plain and disc_ok)
 
     def _clamp_std(self):
         """gail.py:522-523 (inside every discriminator step there; idempotent, and nothing reads std in between)"""

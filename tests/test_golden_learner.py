@@ -180,3 +180,15 @@ def test_analytic_input_gradient_equals_autograd_double_backward():
             assert b is None or float(b.abs().max()) == 0.0
         else:
             assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+
+
+def test_only_networks_whose_backward_we_reduce_ourselves_are_recorded(fx):
+    """the recorded (hipGraph) learner steps are offered only for Linear+ELU networks / a ReLU MSE discriminator: with any other
+    activation the backward contains torch's batch `sum(0)`, which goes stale under replay (profiles/r2_hipgraph_stale_reductions.md)"""
+    env, alg = _alg(fx)
+    assert alg.use_update_graph is True and alg._recordable_networks()
+    alg.actor_critic.actor_trunk[1] = torch.nn.Tanh()
+    assert not alg._recordable_networks()
+    alg.actor_critic.actor_trunk[1] = torch.nn.ELU()
+    alg.disc_loss_function = "WassersteinLoss"
+    assert not alg._recordable_networks()
