@@ -84,3 +84,27 @@ def test_learn_two_iterations_and_checkpoint(tmp_path, amp):
     for k, v in runner2.alg.actor_critic.state_dict().items():
         assert torch.equal(v, after[k])
     assert os.path.exists(os.path.join(runner.log_dir, "scalars.jsonl")) or any(f.startswith("events") for f in os.listdir(runner.log_dir))
+
+
+def test_replay_ring_insert_handles_wraps_and_oversized_batches():
+    """ReplayBuffer.insert with whole rollouts (T*N rows per call, as the recorded rollout path does): against a plain list model of
+    the ring -- partial fill, a single wrap, an exact fit, a batch larger than the ring (only its newest rows survive)"""
+    import torch
+    from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer
+    size = 50
+    rb = ReplayBuffer(3, 5, 2, size, "cpu")          # obs_dim 3, dim_c 5, history 2 -> 6-wide rows
+    model, pos, count, nxt = [None] * size, 0, 0, 0
+    for n in (20, 20, 25, 50, 7, 120, 49, 1, 200):
+        ids = torch.arange(nxt, nxt + n, dtype=torch.float32); nxt += n
+        states = ids.view(n, 1).expand(n, 6).contiguous()
+        rb.insert(states, ids.view(n, 1).clone(), ids.view(n, 1).expand(n, 5).contiguous())
+        if n >= size:
+            model, pos, count = list(ids[n - size:].tolist()), 0, size
+        else:
+            for v in ids.tolist():
+                model[pos] = v; pos = (pos + 1) % size
+            count = min(size, count + n)
+        assert rb.num_samples == count and rb.step == pos
+        got = rb.states[:, 0].tolist()
+        assert all(m is None or g == m for g, m in zip(got, model))
+        assert torch.equal(rb.latent_eps[:count, 0], rb.states[:count, 0]) and torch.equal(rb.latent_c[:count, 4], rb.states[:count, 5])
