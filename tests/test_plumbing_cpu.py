@@ -108,3 +108,22 @@ def test_replay_ring_insert_handles_wraps_and_oversized_batches():
         got = rb.states[:, 0].tolist()
         assert all(m is None or g == m for g, m in zip(got, model))
         assert torch.equal(rb.latent_eps[:count, 0], rb.states[:count, 0]) and torch.equal(rb.latent_c[:count, 4], rb.states[:count, 5])
+
+
+def test_buffers_that_recorded_launches_read_keep_their_addresses():
+    """hipGraph replays read these tensors by address: the eager GAE fallback and the normaliser update must write them in place"""
+    import torch
+    from quadrupedal_agility_amd.rsl_rl.storage import RolloutStorage
+    from quadrupedal_agility_amd.rsl_rl.utils.utils import TorchNormalizer
+    st = RolloutStorage(8, 5, [11], [11], [3], "cpu")
+    st.rewards.normal_(); st.values.normal_(); st.dones.zero_()
+    before = (st.advantages.data_ptr(), st.returns.data_ptr())
+    for _ in range(2):
+        st.compute_returns(torch.randn(8, 1), 0.99, 0.95)
+    assert (st.advantages.data_ptr(), st.returns.data_ptr()) == before
+    assert abs(float(st.advantages.mean())) < 1e-5 and float(st.advantages.std()) == __import__("pytest").approx(1.0, abs=1e-4)
+    nz = TorchNormalizer(4, "cpu")
+    ptrs = (nz.mean.data_ptr(), nz.var.data_ptr(), nz.count.data_ptr())
+    nz.update_torch([torch.randn(50, 4) * 3 + 1, torch.randn(20, 4)])
+    assert (nz.mean.data_ptr(), nz.var.data_ptr(), nz.count.data_ptr()) == ptrs
+    assert float(nz.count) == __import__("pytest").approx(70.0001, abs=1e-3) and float(nz.mean.abs().max()) > 0.1
