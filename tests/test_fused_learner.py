@@ -147,6 +147,21 @@ def test_elu_backward_bias_oracle_matches_pytorch(rows, cols):
     assert np.allclose(gb, want.sum(0).numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(rows))
 
 
+@pytest.mark.parametrize("rows,cols", [(33, 29), (921, 512), (307, 256)])
+def test_elu_backward_bias_oracle_with_alpha_zero_is_the_relu_backward(rows, cols):
+    """alpha = 0 (fused.linear_relu, fused.mask_times_row: the discriminator's recorded step): g * [y > 0] and its column sums"""
+    g = torch.Generator().manual_seed(rows)
+    y = torch.relu(torch.randn(rows, cols, generator=g)); gy = torch.randn(rows, cols, generator=g)
+    lib = load_oracle()
+    lib.qo_elu_backward_bias.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+    yn, gn = y.numpy().copy(), gy.numpy().copy()
+    gin = np.zeros_like(yn); gb = np.zeros(cols, np.float32)
+    assert lib.qo_elu_backward_bias(gn.ctypes.data, yn.ctypes.data, gin.ctypes.data, gb.ctypes.data, rows, cols, 0.0, None, 0, None) == 0
+    want = torch.ops.aten.threshold_backward(gy, y, 0.0)
+    assert np.array_equal(gin, want.numpy())
+    assert np.allclose(gb, want.double().sum(0).numpy(), rtol=1e-5, atol=1e-5 * np.sqrt(rows))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,cols", [(1, 1), (33, 29), (1000, 64), (24576, 128), (24576, 512), (5000, 700)])
 def test_elu_backward_bias_hip(rows, cols):
