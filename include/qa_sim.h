@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 9
+#define QA_ABI_VERSION 10
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -357,6 +357,34 @@ int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
 int64_t qa_narrow_wgrad_scratch_bytes(int64_t rows, int32_t out_features, int32_t in_features);
 int qa_narrow_wgrad(const float *grad_out, const float *x, int64_t rows, int32_t out_features, int32_t in_features, float *grad_weight,
                     float *grad_bias, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* Dense layers of the learner's networks under training -- hand-written fp32-MFMA GEMMs (csrc/qa_gemm.hip; ABI 10).
+ * They replace, for the Linear(+ELU/ReLU) blocks of bbc/rsl_rl/modules/actor_critic.py:92-139,171-225 and estimator.py:12-36 as
+ * SSInfoGAIL.update_actor_critic (bbc/rsl_rl/algorithms/gail.py:328-413) and the task-level PPO.update
+ * (tsc/rsl_rl/algorithms/ppo.py:160-282) run them, what PyTorch issues as addmm + elu (forward) and elu_backward + mm + mm^T + sum(0)
+ * (backward).  All matrices fp32 row-major with explicit leading dimensions (so a column slice of a wider row -- e.g. the
+ * proprioceptive block of the 671-wide observation -- is an operand without a copy); weight = nn.Linear.weight (out, in).
+ * act: 0 none, 1 ELU(alpha), 2 ReLU.  fp32 in, fp32 accumulate: the reference's dtype.
+ *   qa_linear_forward          y[r][o]  = act( sum_k x[r][k] weight[o][k] + bias[o] )                    (bias may be NULL)
+ *   qa_linear_backward_input   gin[r][k] = ( sum_o gout[r][o] weight[o][k] ) * act'(y_prev[r][k])        act' from the activation OUTPUT
+ *                              y_prev of the layer that produced x (ELU: y > 0 ? 1 : y + alpha; ReLU: y > 0; act_prev 0: no factor,
+ *                              y_prev may be NULL) -- the elementwise half of the previous layer's backward, fused into this epilogue
+ *   qa_linear_backward_weight  gw[o][k] = sum_r gout[r][o] x[r][k],  gb[o] = sum_r gout[r][o]            split over row slabs, partial
+ *                              sums added in a fixed order (bit-reproducible, no atomics); gw is (out, in) contiguous;
+ *                              `scratch` 16-byte aligned, at least qa_linear_backward_weight_scratch_bytes(rows, in, out) bytes. */
+int qa_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
+                      int32_t in_features, int32_t out_features, int32_t act, float alpha, void *stream);
+int qa_linear_backward_input(const float *grad_out, int64_t ldg, const float *weight, int64_t ldw, const float *y_prev, int64_t ldyp,
+                             float *grad_in, int64_t ldgi, int64_t rows, int32_t in_features, int32_t out_features, int32_t act_prev, float alpha,
+                             void *stream);
+int64_t qa_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features);
+int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
+                              int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* out[i] = slabs[0][i] + slabs[1][i] + ... in that order (slab z at slabs + z * slab_stride): the fixed-order sum of split partial products
+ * (the reduction half of qa_linear_backward_weight, exposed for partial products computed elsewhere).  Replaces torch's `sum(0)` over
+ * the slab dimension in bbc/rsl_rl/algorithms/gail.py:328-413's weight gradients as this build evaluates them. */
+int qa_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int64_t n, float *out, void *stream);
 
 /* Running-moment normaliser of the discriminator inputs (bbc/rsl_rl/utils/utils.py:62-103).
  * qa_normalizer_update folds num_batches (1..4) row-major (rows[i], dim) fp32 device batches, in order, into the

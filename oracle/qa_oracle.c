@@ -1352,6 +1352,78 @@ int qo_narrow_wgrad(const float *grad_out, const float *x, int64_t rows, int32_t
     return QA_OK;
 }
 
+/* CPU twins of the learner's dense-layer kernels (csrc/qa_gemm.hip): one Linear(+activation) layer of the reference's MLPs
+ * (bbc/rsl_rl/modules/actor_critic.py:92-139, estimator.py:12-36) forward, and the two halves of its backward as autograd
+ * evaluates them for gail.py:328-413 -- plain double-precision loops, OpenMP over rows / outputs.  act: 0 none, 1 ELU(alpha), 2 ReLU. */
+int qo_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
+                      int32_t in_features, int32_t out_features, int32_t act, float alpha, void *stream) {
+    (void)stream;
+    if (!x || !weight || !y || rows <= 0 || in_features <= 0 || out_features <= 0 || ldx < in_features || ldw < in_features || ldy < out_features ||
+        act < 0 || act > 2) return QA_E_ARG;
+#pragma omp parallel for
+    for (int64_t r = 0; r < rows; ++r)
+        for (int o = 0; o < out_features; ++o) {
+            double acc = bias ? bias[o] : 0.0;
+            for (int k = 0; k < in_features; ++k) acc += (double)x[r * ldx + k] * weight[(int64_t)o * ldw + k];
+            if (act == 1) acc = acc > 0 ? acc : alpha * (exp(acc) - 1.0);
+            else if (act == 2) acc = acc > 0 ? acc : 0.0;
+            y[r * ldy + o] = (float)acc;
+        }
+    return QA_OK;
+}
+/* grad_in = (grad_out W) * act'(y_prev), the derivative taken from the previous layer's activation OUTPUT (ELU: y > 0 ? 1 : y + alpha) */
+int qo_linear_backward_input(const float *grad_out, int64_t ldg, const float *weight, int64_t ldw, const float *y_prev, int64_t ldyp,
+                             float *grad_in, int64_t ldgi, int64_t rows, int32_t in_features, int32_t out_features, int32_t act_prev, float alpha,
+                             void *stream) {
+    (void)stream;
+    if (!grad_out || !weight || !grad_in || rows <= 0 || in_features <= 0 || out_features <= 0 || ldg < out_features || ldw < in_features ||
+        ldgi < in_features || act_prev < 0 || act_prev > 2 || (act_prev != 0 && (!y_prev || ldyp < in_features))) return QA_E_ARG;
+#pragma omp parallel for
+    for (int64_t r = 0; r < rows; ++r)
+        for (int k = 0; k < in_features; ++k) {
+            double acc = 0;
+            for (int o = 0; o < out_features; ++o) acc += (double)grad_out[r * ldg + o] * weight[(int64_t)o * ldw + k];
+            if (act_prev) {
+                float yv = y_prev[r * ldyp + k];
+                acc *= act_prev == 1 ? (yv > 0.0f ? 1.0 : (double)yv + alpha) : (yv > 0.0f ? 1.0 : 0.0);
+            }
+            grad_in[r * ldgi + k] = (float)acc;
+        }
+    return QA_OK;
+}
+int64_t qo_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
+    return (rows <= 0 || in_features <= 0 || out_features <= 0) ? 0 : 16;
+}
+int qo_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
+                              int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!grad_out || !x || !grad_weight || !grad_bias || rows <= 0 || in_features <= 0 || out_features <= 0 || ldg < out_features || ldx < in_features)
+        return QA_E_ARG;
+#pragma omp parallel for
+    for (int o = 0; o < out_features; ++o) {
+        double b = 0;
+        for (int64_t r = 0; r < rows; ++r) b += grad_out[r * ldg + o];
+        grad_bias[o] = (float)b;
+        for (int k = 0; k < in_features; ++k) {
+            double acc = 0;
+            for (int64_t r = 0; r < rows; ++r) acc += (double)grad_out[r * ldg + o] * x[r * ldx + k];
+            grad_weight[(int64_t)o * in_features + k] = (float)acc;
+        }
+    }
+    return QA_OK;
+}
+
+int qo_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int64_t n, float *out, void *stream) {
+    (void)stream;
+    if (!slabs || !out || num_slabs <= 0 || n <= 0 || slab_stride < n) return QA_E_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        float s = 0.0f;                                 /* fp32, slab order: what the kernel does */
+        for (int z = 0; z < num_slabs; ++z) s += slabs[z * slab_stride + i];
+        out[i] = s;
+    }
+    return QA_OK;
+}
+
 /* RunningMeanStd.update / update_from_moments (utils.py:62-84) on host memory, plain double loops */
 int qo_normalizer_update(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim,
                          double *mean, double *var, double *count, void *stream) {

@@ -1,0 +1,542 @@
+// qa_gemm.hip -- the dense layers of the learner's networks as hand-written fp32-MFMA GEMMs for gfx950.
+//
+// What they replace: the Linear(+ELU) blocks of the reference's actor / critic / estimator / encoder MLPs under training
+// (bbc/rsl_rl/modules/actor_critic.py:92-139 `_mlp` blocks and :171-225, estimator.py:12-36; exercised by
+// SSInfoGAIL.update_actor_critic, bbc/rsl_rl/algorithms/gail.py:328-413, and by tsc/rsl_rl/algorithms/ppo.py:160-282) --
+// in PyTorch: addmm + elu forward; elu_backward, mm, mm^T and sum(0) backward, i.e. library GEMMs with aten elementwise and
+// reduction kernels between them.  Here one layer is
+//   forward            y  = act(x W^T + b)                      one launch, bias + activation in the epilogue
+//   backward (input)   gx = (g W) * act'(y_prev)                one launch, the PREVIOUS layer's activation derivative in the epilogue
+//   backward (weight)  dW = g^T x,  db = column sums of g       one split-K launch (db rides on the MFMAs against a row of ones)
+//                                                               + one fixed-order slab reduction
+// fp32 in, fp32 accumulate (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf chain -- the reference's dtype, no reduced precision).
+//
+// One kernel template covers the three products.  It computes
+//     out[b * ldo + a] = epilogue( sum_k Aop(a, k) * Bop(b, k) )
+// where the "A side" index `a` is the CONTIGUOUS index of the output (MFMA D rows: a lane holds 4 consecutive a for one b, so
+// bias / activation / derivative / store are 16-byte operations) and each operand is addressed either k-contiguous
+// (KC: P[idx * ld + k], an nn.Linear weight read along its input features, an activation matrix read along its features) or
+// index-contiguous (MC: P[k * ld + idx], the same matrices when the reduction runs over their ROWS):
+//     forward          a = out feature   A = W  (KC)   b = sample      B = x (KC)   k = in feature
+//     backward input   a = in feature    A = W  (MC)   b = sample      B = g (KC)   k = out feature
+//     backward weight  a = in feature    A = x  (MC)   b = out feature B = g (MC)   k = sample   (split over z)
+// Tiles: BA x BB outputs per 256-thread workgroup (4 wavefronts as 2 x 2, each (BA/2) x (BB/2) = TA x TB MFMA tiles), BK = 16.
+// Global -> registers -> LDS, double-buffered, one barrier per k-tile: the loads of tile t+1 are in flight while tile t is
+// multiplied (fp32 MFMA is 32 cycles per instruction: a 128 x 128 x 16 tile is 2,048 MFMA cycles per wavefront against 16 KB of
+// operands, so neither the LDS nor the L2 is near its limit and two resident workgroups per CU cover each other's barriers).
+// LDS images are padded by 4 floats per row: KC rows of 16 k (+4) are read as ONE ds_read_b128 per fragment -- the lane's four
+// values are k = 4 (lane>>4) + s for the four MFMA steps s of the tile, a permutation of k that both operands share -- and MC
+// rows of BT indices (+4) as four ds_read_b32; both are bank-conflict-free.  Workgroup ids are remapped so that consecutive
+// tiles (which share an operand tile) run on the same XCD and hit in its L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
+
+#include "../../include/qa_sim.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    const float *A, *B;
+    float *out;
+    const float *bias;       // EPI 1: per a (may be null)
+    const float *yprev;      // EPI 2: activation OUTPUT whose derivative multiplies the product, [b * ldy + a] (may be null)
+    float *ones_out;         // ONES: per-split sums of Bop(b, k) over k, [z * ones_split_stride + b]
+    int64_t lda, ldb, ldo, ldy, out_split_stride, ones_split_stride;
+    int a_count, b_count, kred, k_per_split, na, nb, nsplit;
+    int a_vec, b_vec, o_vec, act;
+    float alpha;
+};
+
+#define GEMM_BK 16
+
+// global -> staging registers.  KC: element (idx, k) at P[idx * ld + k]; MC: at P[k * ld + idx].  The loads are UNCONDITIONAL from
+// clamped (always valid) addresses; out-of-range elements are zeroed when the registers go to LDS (gemm_store), by a MULTIPLICATION with
+// a 0/1 mask.  A load inside a conditional, a select on a loaded value (hipcc sinks the load into a branch) and even a mask applied next
+// to the load in the loop body are all waited for one at a time -- 16 dependent round trips per tile instead of 16 loads in flight
+// behind the tile's MFMAs.  (The clamped address holds an element of the same row / column, so mask * value never manufactures a NaN
+// that the true operands do not contain.)
+template <int BT, bool MC, int VEC>
+static __device__ __forceinline__ void gemm_load(float (&r)[BT / 16], const float *__restrict__ P, int64_t ld, int idx0, int count, int k0,
+                                                 int kend, int tid) {
+    if (!MC) {
+        if (VEC == 4) {
+            const int kc = min(k0 + (tid & 3) * 4, kend - 4);
+#pragma unroll
+            for (int j = 0; j < BT / 64; ++j) {
+                const int row = idx0 + (tid >> 2) + 64 * j;
+                const f4 v = *(const f4 *)(P + (uint32_t)(min(row, count - 1) * (int)ld + kc));
+                r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+            }
+        } else {
+            const int kc = min(k0 + (tid & 15), kend - 1);
+#pragma unroll
+            for (int j = 0; j < BT / 16; ++j) {
+                const int row = idx0 + (tid >> 4) + 16 * j;
+                r[j] = P[(uint32_t)(min(row, count - 1) * (int)ld + kc)];
+            }
+        }
+    } else {
+        if (VEC == 4) {
+            constexpr int TPR = BT / 4, RPP = 256 / TPR;
+            const int ic = min(idx0 + (tid % TPR) * 4, count - 4);
+#pragma unroll
+            for (int j = 0; j < 16 / RPP; ++j) {
+                const int k = k0 + tid / TPR + RPP * j;
+                const f4 v = *(const f4 *)(P + (uint32_t)(min(k, kend - 1) * (int)ld + ic));
+                r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+            }
+        } else {
+            constexpr int RPP = 256 / BT;
+            const int ic = min(idx0 + tid % BT, count - 1);
+#pragma unroll
+            for (int j = 0; j < 16 / RPP; ++j) {
+                const int k = k0 + tid / BT + RPP * j;
+                r[j] = P[(uint32_t)(min(k, kend - 1) * (int)ld + ic)];
+            }
+        }
+    }
+}
+
+// staging registers -> LDS image, out-of-range elements zeroed.  KC image: [idx][k] with a row stride of 20 floats; MC image: [k][idx]
+// with a row stride of BT + 4.  Same thread -> element mapping as gemm_load.
+template <int BT, bool MC, int VEC>
+static __device__ __forceinline__ void gemm_store(const float (&r)[BT / 16], float *__restrict__ S, int idx0, int count, int k0, int kend, int tid) {
+    if (!MC) {
+        if (VEC == 4) {
+            const float kok = (k0 + (tid & 3) * 4 < kend) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < BT / 64; ++j) {
+                const float ok = (idx0 + (tid >> 2) + 64 * j < count) ? kok : 0.f;
+                f4 v = {r[4 * j] * ok, r[4 * j + 1] * ok, r[4 * j + 2] * ok, r[4 * j + 3] * ok};
+                *(f4 *)(S + ((tid >> 2) + 64 * j) * (GEMM_BK + 4) + (tid & 3) * 4) = v;
+            }
+        } else {
+            const float kok = (k0 + (tid & 15) < kend) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < BT / 16; ++j)
+                S[((tid >> 4) + 16 * j) * (GEMM_BK + 4) + (tid & 15)] = r[j] * ((idx0 + (tid >> 4) + 16 * j < count) ? kok : 0.f);
+        }
+    } else {
+        if (VEC == 4) {
+            constexpr int TPR = BT / 4, RPP = 256 / TPR;
+            const float iok = (idx0 + (tid % TPR) * 4 < count) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16 / RPP; ++j) {
+                const float ok = (k0 + tid / TPR + RPP * j < kend) ? iok : 0.f;
+                f4 v = {r[4 * j] * ok, r[4 * j + 1] * ok, r[4 * j + 2] * ok, r[4 * j + 3] * ok};
+                *(f4 *)(S + (tid / TPR + RPP * j) * (BT + 4) + (tid % TPR) * 4) = v;
+            }
+        } else {
+            constexpr int RPP = 256 / BT;
+            const float iok = (idx0 + tid % BT < count) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16 / RPP; ++j)
+                S[(tid / BT + RPP * j) * (BT + 4) + tid % BT] = r[j] * ((k0 + tid / BT + RPP * j < kend) ? iok : 0.f);
+        }
+    }
+}
+
+// the four MFMA-step values (k = 4 kq + s, s = 0..3) of the 16-index fragment starting at local index i0
+template <int BT, bool MC>
+static __device__ __forceinline__ void gemm_frag(float (&f)[4], const float *__restrict__ S, int i0, int li, int kq) {
+    if (!MC) {
+        const f4 v = *(const f4 *)(S + (i0 + li) * (GEMM_BK + 4) + kq * 4);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = S[(kq * 4 + s) * (BT + 4) + i0 + li];
+    }
+}
+
+// EPI 0: plain store (split-K partial).  1: + bias, activation (act 0 none, 1 ELU(alpha), 2 ReLU).  2: * activation derivative taken from
+// the activation's output yprev (ELU: y > 0 ? 1 : y + alpha; ReLU: y > 0; none: 1).
+// ABL (tools/gemm_probe.hip only): 1 = no global loads / LDS writes after the first tile, 2 = no MFMAs, 3 = no LDS fragment reads
+template <int BA, int BB, bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES, int ABL = 0>
+__global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
+    constexpr int TA = BA / 32, TB = BB / 32;
+    constexpr int A_TILE = A_MC ? GEMM_BK * (BA + 4) : BA * (GEMM_BK + 4);
+    constexpr int B_TILE = B_MC ? GEMM_BK * (BB + 4) : BB * (GEMM_BK + 4);
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+
+    // consecutive workgroup ids are dealt round-robin to the 8 XCDs: remap so that each XCD owns a contiguous run of tiles
+    const int total = g.na * g.nb * g.nsplit;
+    int id = blockIdx.x;
+    {
+        const int q = total >> 3, rmd = total & 7, xcd = id & 7, local = id >> 3;
+        id = (xcd < rmd) ? xcd * (q + 1) + local : rmd * (q + 1) + (xcd - rmd) * q + local;
+    }
+    const int at = id % g.na, bt = (id / g.na) % g.nb, z = id / (g.na * g.nb);
+    const int a_base = at * BA, b_base = bt * BB;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.kred, kbeg + g.k_per_split);
+    const int T = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave & 1, wb = wave >> 1, li = lane & 15, kq = lane >> 4;
+    // the bias sums (ONES) ride on extra MFMAs against a fragment of ones: k-tile t of a split belongs to the a-tile t % na, so every
+    // workgroup carries 1/na of them (all on the a-tile 0 workgroups they were +25 % on one workgroup in na -- and the launch waits for those)
+    const bool ones_wave = ONES && wa == 0;
+
+    f4 acc[TA][TB];
+    f4 oacc[TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TB; ++j) oacc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline, two tiles deep in registers: tile j is loaded into staging set j & 1 and its fragments live in fragment set
+    // j & 1.  Iteration t issues the loads of tile t+2, multiplies tile t from registers, writes tile t+1 (loaded one iteration ago) to
+    // the other LDS buffer between the two halves of its MFMAs, and after the barrier reads the fragments of tile t+1 -- so a load has
+    // almost two iterations to land, the LDS writes ride inside the MFMA stream, and the fragment reads overlap the next iteration's
+    // load issue instead of standing in front of its MFMAs.
+    float sa[2][BA / 16], sb[2][BB / 16];
+    // The 128 x 128 tile keeps ONE fragment set (the second costs 32 registers: 177 -> occupancy 2, and its 768 workgroups per
+    // 24,576 x 512 product then run as 1.5 rounds of 512): it reads tile t+1's fragments after tile t's last MFMA, three waves per SIMD
+    // covering the read latency.
+    constexpr int NF = (BA * BB >= 128 * 128) ? 1 : 2;
+    float af[NF][TA][4], bf[NF][TB][4];
+    if (T > 0) {
+        gemm_load<BA, A_MC, AV>(sa[0], g.A, g.lda, a_base, g.a_count, kbeg, kend, tid);
+        gemm_load<BB, B_MC, BV>(sb[0], g.B, g.ldb, b_base, g.b_count, kbeg, kend, tid);
+        gemm_load<BA, A_MC, AV>(sa[1], g.A, g.lda, a_base, g.a_count, kbeg + GEMM_BK, kend, tid);
+        gemm_load<BB, B_MC, BV>(sb[1], g.B, g.ldb, b_base, g.b_count, kbeg + GEMM_BK, kend, tid);
+        gemm_store<BA, A_MC, AV>(sa[0], lds, a_base, g.a_count, kbeg, kend, tid);
+        gemm_store<BB, B_MC, BV>(sb[0], lds + A_TILE, b_base, g.b_count, kbeg, kend, tid);
+    }
+    __syncthreads();
+    if (T > 0) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i) gemm_frag<BA, A_MC>(af[0][i], lds, wa * (BA / 2) + i * 16, li, kq);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) gemm_frag<BB, B_MC>(bf[0][j], lds + A_TILE, wb * (BB / 2) + j * 16, li, kq);
+    }
+    auto mfma_steps = [&](auto ptag, auto s0tag, bool do_ones) {
+        constexpr int P = decltype(ptag)::value, S0 = decltype(s0tag)::value;
+#pragma unroll
+        for (int s = S0; s < S0 + 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+                    if (ABL != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[P % NF][i][s], bf[P % NF][j][s], acc[i][j], 0, 0, 0);
+                    else acc[i][j][s] += af[P % NF][i][s] * bf[P % NF][j][s];
+            if (ONES) {
+                if (do_ones) {
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bf[P % NF][j][s], oacc[j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto body = [&](auto ptag, int t) {
+        constexpr int P = decltype(ptag)::value, Q = P ^ 1;
+        if (ABL != 1) {       // unconditional, also past the last tile (clamped addresses, result unused): a load inside `if (t + 2 < T)` makes
+                              // hipcc count the waits of the stores below for the path that did NOT issue it, i.e. drain the new loads too
+            gemm_load<BA, A_MC, AV>(sa[P], g.A, g.lda, a_base, g.a_count, kbeg + (t + 2) * GEMM_BK, kend, tid);
+            gemm_load<BB, B_MC, BV>(sb[P], g.B, g.ldb, b_base, g.b_count, kbeg + (t + 2) * GEMM_BK, kend, tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // the loads stay in front of the MFMAs ...
+        const bool do_ones = ones_wave && (t % g.na) == at;
+        mfma_steps(ptag, std::integral_constant<int, 0>{}, do_ones);
+        __builtin_amdgcn_sched_barrier(0);        // ... and nothing of the store section (its mask multiplies wait for tile t+1's loads) moves above them
+        float *An = lds + Q * (A_TILE + B_TILE);
+        if (ABL != 1) {       // past the last tile this writes zeros (k >= kend) into the idle buffer
+            gemm_store<BA, A_MC, AV>(sa[Q], An, a_base, g.a_count, kbeg + (t + 1) * GEMM_BK, kend, tid);
+            gemm_store<BB, B_MC, BV>(sb[Q], An + A_TILE, b_base, g.b_count, kbeg + (t + 1) * GEMM_BK, kend, tid);
+        }
+        if (NF == 2) {
+            // every wave has written its share of tile t+1 (and finished reading tile t's fragments an iteration ago): read tile t+1's
+            // fragments into the other register set NOW, under the second half of this tile's MFMAs
+            __syncthreads();
+            if (ABL != 3) {
+#pragma unroll
+                for (int i = 0; i < TA; ++i) gemm_frag<BA, A_MC>(af[Q % NF][i], An, wa * (BA / 2) + i * 16, li, kq);
+#pragma unroll
+                for (int j = 0; j < TB; ++j) gemm_frag<BB, B_MC>(bf[Q % NF][j], An + A_TILE, wb * (BB / 2) + j * 16, li, kq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_steps(ptag, std::integral_constant<int, 2>{}, do_ones);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_steps(ptag, std::integral_constant<int, 2>{}, do_ones);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (ABL != 3) {
+#pragma unroll
+                for (int i = 0; i < TA; ++i) gemm_frag<BA, A_MC>(af[0][i], An, wa * (BA / 2) + i * 16, li, kq);
+#pragma unroll
+                for (int j = 0; j < TB; ++j) gemm_frag<BB, B_MC>(bf[0][j], An + A_TILE, wb * (BB / 2) + j * 16, li, kq);
+            }
+        }
+    };
+    // an odd tile count runs one more (all-zero) tile: a conditional second half makes hipcc drain the load queue at the loop head
+    for (int t = 0; t < T; t += 2) {
+        body(std::integral_constant<int, 0>{}, t);
+        body(std::integral_constant<int, 1>{}, t + 1);
+    }
+
+    // epilogue: the lane holds out[b][a .. a+3] for each of its TA x TB tiles
+    float *out = g.out + (int64_t)z * g.out_split_stride;
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+        const int a = a_base + wa * (BA / 2) + i * 16 + 4 * kq;
+        if (a >= g.a_count) continue;
+        const bool full = g.o_vec == 4 && a + 3 < g.a_count;
+        f4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == 1 && g.bias) {
+            if (full) bias = *(const f4 *)(g.bias + a);
+            else {
+                bias.x = g.bias[a];
+                if (a + 1 < g.a_count) bias.y = g.bias[a + 1];
+                if (a + 2 < g.a_count) bias.z = g.bias[a + 2];
+                if (a + 3 < g.a_count) bias.w = g.bias[a + 3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b_base + wb * (BB / 2) + j * 16 + li;
+            if (b >= g.b_count) continue;
+            f4 v = acc[i][j];
+            if (EPI == 1) {
+                v += bias;
+                if (g.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : g.alpha * (expf(v[r]) - 1.f);
+                } else if (g.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+            }
+            if (EPI == 2 && g.yprev && g.act != 0) {
+                const float *yp = g.yprev + (int64_t)b * g.ldy + a;
+                f4 y = {1.f, 1.f, 1.f, 1.f};
+                if (full) y = *(const f4 *)yp;
+                else {
+                    y.x = yp[0];
+                    if (a + 1 < g.a_count) y.y = yp[1];
+                    if (a + 2 < g.a_count) y.z = yp[2];
+                    if (a + 3 < g.a_count) y.w = yp[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (g.act == 1) ? (y[r] > 0.f ? 1.f : y[r] + g.alpha) : (y[r] > 0.f ? 1.f : 0.f);
+            }
+            float *o = out + (int64_t)b * g.ldo + a;
+            if (full) *(f4 *)o = v;
+            else {
+                o[0] = v.x;
+                if (a + 1 < g.a_count) o[1] = v.y;
+                if (a + 2 < g.a_count) o[2] = v.z;
+                if (a + 3 < g.a_count) o[3] = v.w;
+            }
+        }
+    }
+    if (ONES) {
+        if (ones_wave && kq == 0) {       // D row 0 of the ones product: this workgroup's share of sum_k Bop(b, k)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int b = b_base + wb * (BB / 2) + j * 16 + li;
+                if (b < g.b_count) g.ones_out[((int64_t)z * g.na + at) * g.ones_split_stride + b] = oacc[j].x;
+            }
+        }
+    }
+}
+
+// gw[i] = sum over the nsplit_w slabs (in order) of slabs[z * stride_w + i], i < n_w;  gb[i] = sum over the nsplit_b rows of
+// bslabs[z * stride_b + i], i < n_b: the split-K partials of a weight gradient and of its bias gradient.  Fixed order: bit-reproducible,
+// no atomics.  Eight independent loads in flight per thread before the (ordered) additions: a plain accumulate loop is one dependent
+// L2 round trip per slab.
+__global__ void __launch_bounds__(256) qa_slab_reduce_kernel(const float *__restrict__ slabs, int64_t stride_w, int nsplit_w, int64_t n_w,
+                                                             const float *__restrict__ bslabs, int64_t stride_b, int nsplit_b, int64_t n_b,
+                                                             float *__restrict__ gw, float *__restrict__ gb, int vec) {
+    const int64_t nvec_w = (n_w + 3) >> 2, nvec_b = (n_b + 3) >> 2;
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nvec_w + nvec_b) return;
+    const bool is_b = t >= nvec_w;
+    const int64_t i = (is_b ? t - nvec_w : t) * 4;
+    const int64_t n = is_b ? n_b : n_w, stride = is_b ? stride_b : stride_w;
+    const int nsplit = is_b ? nsplit_b : nsplit_w;
+    const float *src = (is_b ? bslabs : slabs) + i;
+    float *dst = (is_b ? gb : gw) + i;
+    if (vec == 4 && i + 3 < n && ((uintptr_t)dst & 15) == 0) {
+        f4 s = {0.f, 0.f, 0.f, 0.f};
+        int zz = 0;
+        for (; zz + 8 <= nsplit; zz += 8) {
+            f4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const f4 *)(src + (int64_t)(zz + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; zz < nsplit; ++zz) s += *(const f4 *)(src + (int64_t)zz * stride);
+        *(f4 *)dst = s;
+    } else {
+        for (int r = 0; r < 4 && i + r < n; ++r) {
+            float s = 0.f;
+            for (int zz = 0; zz < nsplit; ++zz) s += src[(int64_t)zz * stride + r];
+            dst[r] = s;
+        }
+    }
+}
+
+extern thread_local char qa_err_buf[512];
+#define g_gerr qa_err_buf
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// tile configuration: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64, 3 = 64 x 128 (A side x B side)
+static void tile_dims(int cfg, int *ba, int *bb) {
+    *ba = (cfg == 0 || cfg == 1) ? 128 : 64;
+    *bb = (cfg == 0 || cfg == 3) ? 128 : 64;
+}
+
+template <bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES>
+static void gemm_launch_v(int cfg, GemmArgs &g, hipStream_t st) {
+    int ba, bb; tile_dims(cfg, &ba, &bb);
+    g.na = (g.a_count + ba - 1) / ba;
+    g.nb = (g.b_count + bb - 1) / bb;
+    const dim3 grid((unsigned)(g.na * g.nb * g.nsplit));
+    switch (cfg) {
+    case 0: hipLaunchKernelGGL((qa_gemm_kernel<128, 128, A_MC, B_MC, AV, BV, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    case 1: hipLaunchKernelGGL((qa_gemm_kernel<128, 64, A_MC, B_MC, AV, BV, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    case 2: hipLaunchKernelGGL((qa_gemm_kernel<64, 64, A_MC, B_MC, AV, BV, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((qa_gemm_kernel<64, 128, A_MC, B_MC, AV, BV, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    }
+}
+template <bool A_MC, bool B_MC, int EPI, bool ONES>
+static void gemm_launch(int cfg, GemmArgs &g, hipStream_t st) {
+    if (g.a_vec == 4 && g.b_vec == 4) gemm_launch_v<A_MC, B_MC, 4, 4, EPI, ONES>(cfg, g, st);
+    else if (g.a_vec == 4) gemm_launch_v<A_MC, B_MC, 4, 1, EPI, ONES>(cfg, g, st);
+    else if (g.b_vec == 4) gemm_launch_v<A_MC, B_MC, 1, 4, EPI, ONES>(cfg, g, st);
+    else gemm_launch_v<A_MC, B_MC, 1, 1, EPI, ONES>(cfg, g, st);
+}
+
+// the largest tile that still gives the chip >= 2 workgroups per CU (256 CUs); small problems take the smallest tile
+static int pick_cfg(int64_t a_count, int64_t b_count, int64_t nsplit) {
+    static const int order[3] = {0, 1, 2};
+    for (int c = 0; c < 3; ++c) {
+        int ba, bb; tile_dims(order[c], &ba, &bb);
+        if (a_count <= 64 && ba > 64) continue;
+        const int64_t wgs = ((a_count + ba - 1) / ba) * ((b_count + bb - 1) / bb) * nsplit;
+        if (wgs >= 512) return order[c];
+    }
+    return 2;
+}
+
+static int g_force_cfg = -1;      // tools/gemm_bench.py: time one tile configuration
+
+extern "C" {
+
+void qa_gemm_force_config(int32_t cfg) { g_force_cfg = cfg; }
+
+int qa_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
+                      int32_t in_features, int32_t out_features, int32_t act, float alpha, void *stream) {
+    if (!x || !weight || !y || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 || ldx < in_features || ldw < in_features ||
+        ldy < out_features || act < 0 || act > 2) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward: bad argument"); return QA_E_ARG; }
+    GemmArgs g = {};
+    g.A = weight; g.lda = ldw; g.a_count = out_features;
+    g.B = x; g.ldb = ldx; g.b_count = (int)rows;
+    g.kred = in_features; g.k_per_split = (in_features + GEMM_BK - 1) / GEMM_BK * GEMM_BK; g.nsplit = 1;
+    g.out = y; g.ldo = ldy; g.bias = bias; g.act = act; g.alpha = alpha;
+    g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
+    g.b_vec = (aligned16(x) && ldx % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
+    g.o_vec = (aligned16(y) && ldy % 4 == 0 && (!bias || aligned16(bias))) ? 4 : 1;
+    gemm_launch<false, false, 1, false>(g_force_cfg >= 0 ? g_force_cfg : pick_cfg(out_features, rows, 1), g, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_linear_backward_input(const float *grad_out, int64_t ldg, const float *weight, int64_t ldw, const float *y_prev, int64_t ldyp,
+                             float *grad_in, int64_t ldgi, int64_t rows, int32_t in_features, int32_t out_features, int32_t act_prev, float alpha,
+                             void *stream) {
+    if (!grad_out || !weight || !grad_in || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 || ldg < out_features ||
+        ldw < in_features || ldgi < in_features || act_prev < 0 || act_prev > 2 || (act_prev != 0 && (!y_prev || ldyp < in_features))) {
+        snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_input: bad argument"); return QA_E_ARG; }
+    GemmArgs g = {};
+    g.A = weight; g.lda = ldw; g.a_count = in_features;                 // MC: element (in feature a, out feature k) = W[k * ldw + a]
+    g.B = grad_out; g.ldb = ldg; g.b_count = (int)rows;
+    g.kred = out_features; g.k_per_split = (out_features + GEMM_BK - 1) / GEMM_BK * GEMM_BK; g.nsplit = 1;
+    g.out = grad_in; g.ldo = ldgi; g.yprev = act_prev ? y_prev : nullptr; g.ldy = ldyp; g.act = act_prev; g.alpha = alpha;
+    g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
+    g.b_vec = (aligned16(grad_out) && ldg % 4 == 0 && out_features % 4 == 0) ? 4 : 1;
+    g.o_vec = (aligned16(grad_in) && ldgi % 4 == 0 && (!g.yprev || (aligned16(y_prev) && ldyp % 4 == 0))) ? 4 : 1;
+    gemm_launch<true, false, 2, false>(g_force_cfg >= 0 ? g_force_cfg : pick_cfg(in_features, rows, 1), g, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_input: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+// split of the sample dimension: enough slabs for ~3 workgroups per CU, slabs of whole k-tiles and at least 256 rows
+static void wgrad_plan(int64_t rows, int32_t in_features, int32_t out_features, int *cfg, int *nsplit, int *k_per_split) {
+    // measured on MI355X at 24,576 rows (tools/own_gemm_bench.py, profiles/r3_own_gemm_bench.json): the 128 x 128 tile only pays for the
+    // widest layers (671 / 800 x 512), 128 x 64 for the 512 x 256 and 256 x 128 ones, 64 x 64 for everything narrower
+    int c = (in_features > 256 && out_features > 256) ? 0 : ((in_features >= 256 && out_features >= 128) ? 1 : 2);
+    if (g_force_cfg >= 0) c = g_force_cfg;
+    int ba, bb; tile_dims(c, &ba, &bb);
+    const int64_t tiles = (int64_t)((in_features + ba - 1) / ba) * ((out_features + bb - 1) / bb);
+    const int64_t target = (c == 0) ? 512 : 1024;       // resident workgroups: 2 per CU for the 128 x 128 tile (190-200 registers), 4 otherwise
+    int64_t s = target / tiles;                         // never a few workgroups more than one resident round: they would run alone
+    const int64_t smax = (rows + 255) / 256;
+    if (s > smax) s = smax;
+    if (s > 48) s = 48;          // the reduction reads every slab: beyond this it costs more than the extra workgroups give
+    if (s < 1) s = 1;
+    int64_t kps = ((rows + s - 1) / s + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    s = (rows + kps - 1) / kps;
+    *cfg = c; *nsplit = (int)s; *k_per_split = (int)kps;
+}
+static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+
+int64_t qa_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
+    if (rows <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    int cfg, s, kps; wgrad_plan(rows, in_features, out_features, &cfg, &s, &kps);
+    int ba, bb; tile_dims(cfg, &ba, &bb);
+    const int64_t na = (in_features + ba - 1) / ba;
+    return (int64_t)s * (pad4((int64_t)in_features * out_features) + na * pad4(out_features)) * 4;
+}
+
+int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
+                              int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!grad_out || !x || !grad_weight || !grad_bias || !scratch || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 ||
+        ldg < out_features || ldx < in_features) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: bad argument"); return QA_E_ARG; }
+    if (scratch_bytes < qa_linear_backward_weight_scratch_bytes(rows, in_features, out_features) || !aligned16(scratch)) {
+        snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: scratch too small or not 16-byte aligned"); return QA_E_ARG; }
+    int cfg, s, kps; wgrad_plan(rows, in_features, out_features, &cfg, &s, &kps);
+    int ba, bb; tile_dims(cfg, &ba, &bb);
+    const int64_t n_w = (int64_t)in_features * out_features, n_w_pad = pad4(n_w), n_b_pad = pad4(out_features), na = (in_features + ba - 1) / ba;
+    float *bslabs = (float *)scratch + (int64_t)s * n_w_pad;
+    GemmArgs g = {};
+    g.A = x; g.lda = ldx; g.a_count = in_features;                       // MC: element (in feature a, sample k) = x[k * ldx + a]
+    g.B = grad_out; g.ldb = ldg; g.b_count = out_features;               // MC: element (out feature b, sample k) = g[k * ldg + b]
+    g.kred = (int)rows; g.k_per_split = kps; g.nsplit = s;
+    g.out = (float *)scratch; g.ldo = in_features; g.out_split_stride = n_w_pad;
+    g.ones_out = bslabs; g.ones_split_stride = n_b_pad;
+    g.a_vec = (aligned16(x) && ldx % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
+    g.b_vec = (aligned16(grad_out) && ldg % 4 == 0 && out_features % 4 == 0) ? 4 : 1;
+    g.o_vec = (in_features % 4 == 0) ? 4 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    gemm_launch<true, true, 0, true>(cfg, g, st);
+    const int64_t nthreads = (n_w + 3) / 4 + (out_features + 3) / 4;
+    hipLaunchKernelGGL(qa_slab_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, (const float *)scratch, n_w_pad, s, n_w,
+                       (const float *)bslabs, n_b_pad, (int)(s * na), (int64_t)out_features, grad_weight, grad_bias, aligned16(grad_weight) ? 4 : 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int64_t n, float *out, void *stream) {
+    if (!slabs || !out || num_slabs <= 0 || n <= 0 || slab_stride < n) { snprintf(g_gerr, sizeof(g_gerr), "qa_slab_sum: bad argument"); return QA_E_ARG; }
+    const bool v4 = aligned16(slabs) && aligned16(out) && slab_stride % 4 == 0;
+    const int64_t nthreads = (n + 3) / 4;
+    hipLaunchKernelGGL(qa_slab_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, slab_stride, (int)num_slabs, n,
+                       (const float *)nullptr, (int64_t)0, 0, (int64_t)0, out, (float *)nullptr, v4 ? 4 : 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_slab_sum: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+}  // extern "C"

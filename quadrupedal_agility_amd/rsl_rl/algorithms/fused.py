@@ -3,6 +3,7 @@
 Only CUDA/ROCm tensors come here: the callers keep the plain PyTorch expression for CPU tensors (BASELINE config 1,
 "PPO on CPU physics + CPU torch"), which is also the fp32 reference the kernels are tested against."""
 import ctypes as C
+import os
 
 import torch
 
@@ -215,7 +216,7 @@ def weight_grad(g, x):
     k = x.shape[1]
     S = WGRAD_SLABS
     if ENABLED and rows >= 8192 and rows % S == 0 and n * k >= 16384 and g.stride(1) == 1 and x.stride(1) == 1:
-        return torch.bmm(g.unflatten(0, (S, rows // S)).transpose(1, 2), x.unflatten(0, (S, rows // S))).sum(0)
+        return slab_sum(torch.bmm(g.unflatten(0, (S, rows // S)).transpose(1, 2), x.unflatten(0, (S, rows // S))))   # ours, not torch's sum(0)
     return g.t().mm(x)
 
 
@@ -268,12 +269,212 @@ def linear_elu(x, weight, bias, alpha=1.0):
     return _LinearElu.apply(x, weight, bias, alpha)
 
 
+OWN_GEMM = os.environ.get("QA_OWN_GEMM", "1") != "0"      # the dense layers through csrc/qa_gemm.hip (0: library GEMMs + the r1/r2 kernels around them)
+ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}: {_capi.load_library().qa_last_error().decode()}")
+
+
+def _rows2d(t):
+    """a (rows, cols) fp32 view whose rows are contiguous (a column slice of wider rows is fine: the kernels take a leading dimension)"""
+    if t.dtype != torch.float32 or t.stride(1) != 1 or t.stride(0) < t.shape[1] or t.data_ptr() % 4:
+        t = t.contiguous().float()
+    return t
+
+
+def linear_forward_raw(x, weight, bias, act, alpha=1.0, out=None):
+    """act(x W^T + b) by qa_linear_forward (one launch, bias and activation in the GEMM's epilogue)"""
+    lib = _capi.load_library()
+    x = _rows2d(x)
+    rows, k = x.shape
+    n = weight.shape[0]
+    y = out if out is not None else torch.empty(rows, n, dtype=torch.float32, device=x.device)
+    _check(lib.qa_linear_forward(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias) if bias is not None else None, _ptr(y), y.stride(0),
+                                 rows, k, n, int(act), float(alpha), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "qa_linear_forward")
+    return y
+
+
+def linear_backward_input_raw(g, weight, y_prev, act_prev, alpha=1.0):
+    """(g W) * act'(y_prev) by qa_linear_backward_input: the input gradient of a layer with the previous layer's activation derivative"""
+    lib = _capi.load_library()
+    g = _rows2d(g)
+    rows, n = g.shape
+    k = weight.shape[1]
+    gin = torch.empty(rows, k, dtype=torch.float32, device=g.device)
+    yp = _rows2d(y_prev) if (act_prev and y_prev is not None) else None
+    _check(lib.qa_linear_backward_input(_ptr(g), g.stride(0), _ptr(weight), weight.stride(0), _ptr(yp) if yp is not None else None,
+                                        yp.stride(0) if yp is not None else 0, _ptr(gin), k, rows, k, n, int(act_prev if yp is not None else 0), float(alpha),
+                                        C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "qa_linear_backward_input")
+    return gin
+
+
+def linear_backward_weight_raw(g, x, want_bias=True):
+    """(g^T x, column sums of g) by qa_linear_backward_weight (split over row slabs, fixed-order reduction)"""
+    lib = _capi.load_library()
+    g, x = _rows2d(g), _rows2d(x)
+    rows, n = g.shape
+    k = x.shape[1]
+    gw = torch.empty(n, k, dtype=torch.float32, device=g.device)
+    gb = torch.empty(n, dtype=torch.float32, device=g.device)
+    nb = int(lib.qa_linear_backward_weight_scratch_bytes(rows, k, n))
+    scratch = torch.empty(nb, dtype=torch.uint8, device=g.device)
+    _check(lib.qa_linear_backward_weight(_ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(gw), _ptr(gb), rows, k, n, _ptr(scratch), nb,
+                                         C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)), "qa_linear_backward_weight")
+    return gw, gb
+
+
+OWN_MAX_IN, OWN_MAX_OUT_WIDE = 128, 128      # a layer goes through csrc/qa_gemm.hip when it is narrow: out <= 64, or in <= 128 and out <= 128
+ALL_OWN = os.environ.get("QA_GEMM_ALL_OWN", "0") == "1"     # every layer through our kernels (measurements, tests)
+
+
+OWN_LAYERS = os.environ.get("QA_OWN_LAYERS", "heads")      # which layers run on csrc/qa_gemm.hip: none | heads | small | narrow (= heads + small) | all
+
+
+def own_layer(k, n):
+    """Which dense layers run on the hand-written GEMMs (DESIGN.md 4.18 has the measurements behind the default)."""
+    if ALL_OWN or OWN_LAYERS == "all":
+        return True
+    head = n <= 32 and k >= 100                                   # actor / critic / gait heads: 128 -> 12 / 1 / 3 / 18
+    small = (n <= 64 or (k <= OWN_MAX_IN and n <= OWN_MAX_OUT_WIDE)) and not head     # estimator 57-128-64-4, privileged encoder 29-64-29
+    return {"none": False, "heads": head, "small": small, "narrow": head or small}.get(OWN_LAYERS, False)
+
+
+def slab_sum(parts):
+    """sum over the leading dimension of a contiguous (S, ...) tensor by qa_slab_sum (fixed order) -- not torch's sum(0)"""
+    lib = _capi.load_library()
+    S = parts.shape[0]
+    out = torch.empty(parts.shape[1:], dtype=torch.float32, device=parts.device)
+    n = out.numel()
+    _check(lib.qa_slab_sum(_ptr(parts), n, S, n, _ptr(out), C.c_void_p(torch.cuda.current_stream(parts.device).cuda_stream)), "qa_slab_sum")
+    return out
+
+
+class _MlpChain(torch.autograd.Function):
+    """y = act_L(W_L ... act_1(W_1 x + b_1) ... + b_L) for a stack of Linear(+ELU/ReLU) layers, every product one of the hand-written
+    fp32-MFMA GEMMs of csrc/qa_gemm.hip.  Forward: one launch per layer (bias + activation in the epilogue), activations saved.
+    Backward, per layer from the top: weight + bias gradient (one split launch + its fixed-order reduction), then the input gradient with
+    the layer below's activation derivative in the epilogue -- no elementwise or reduction kernel between the GEMMs, and in particular
+    none of torch's batch reductions (profiles/r2_hipgraph_stale_reductions.md)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        h = _rows2d(x)
+        acts = [h]
+        for i, (act, alpha) in enumerate(spec):
+            h = linear_forward_raw(h, params[2 * i], params[2 * i + 1], act, alpha)
+            acts.append(h)
+        ctx.spec = spec
+        ctx.save_for_backward(*acts, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, gy):
+        spec = ctx.spec
+        L = len(spec)
+        saved = ctx.saved_tensors
+        acts, params = saved[:L + 1], saved[L + 1:]
+        g = _rows2d(gy)
+        act_top, alpha_top = spec[-1]
+        if act_top != ACT_NONE:        # the chain ends in an activation (encoders): its derivative has no GEMM above it to ride on
+            g, _ = _masked_colsum(g, acts[L]) if act_top == ACT_RELU else _elu_bwd(g, acts[L], alpha_top)
+        grads = [None] * (2 * L)
+        gx = None
+        for i in range(L - 1, -1, -1):
+            w = params[2 * i]
+            need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
+            if need_w or need_b:
+                gw, gb = linear_backward_weight_raw(g, acts[i])
+                grads[2 * i], grads[2 * i + 1] = (gw if need_w else None), (gb if need_b else None)
+            if i > 0:
+                g = linear_backward_input_raw(g, w, acts[i], spec[i - 1][0], spec[i - 1][1])
+            elif ctx.needs_input_grad[0]:
+                gx = linear_backward_input_raw(g, w, None, ACT_NONE)
+        return (gx, None, *grads)
+
+
+def _elu_bwd(gy, y, alpha):
+    lib = _capi.load_library()
+    gy, y = _f32c(gy), _f32c(y)
+    rows, cols = y.shape
+    g = torch.empty_like(y)
+    gb = torch.empty(cols, dtype=torch.float32, device=y.device)
+    nscratch = int(lib.qa_elu_backward_bias_scratch_bytes(rows, cols))
+    scratch = torch.empty(nscratch, dtype=torch.uint8, device=y.device)
+    _check(lib.qa_elu_backward_bias(_ptr(gy), _ptr(y), _ptr(g), _ptr(gb), rows, cols, float(alpha), _ptr(scratch), nscratch,
+                                    C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)), "qa_elu_backward_bias")
+    return g, gb
+
+
+def _chain_spec(mods):
+    """[(Linear, act code, alpha), ...] when `mods` is a plain stack of Linear layers each optionally followed by ELU / ReLU, else None"""
+    out, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        if not (isinstance(m, torch.nn.Linear) and m.bias is not None):
+            return None
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if isinstance(nxt, torch.nn.ELU):
+            out.append((m, ACT_ELU, float(nxt.alpha))); i += 2
+        elif isinstance(nxt, torch.nn.ReLU):
+            out.append((m, ACT_RELU, 0.0)); i += 2
+        else:
+            out.append((m, ACT_NONE, 0.0)); i += 1
+    return out or None
+
+
+def _flatten(mods):
+    flat = []
+    for m in mods:
+        flat.extend(list(m) if isinstance(m, torch.nn.Sequential) else [m])
+    return flat
+
+
+def mlp_chain(mods, x):
+    """Run a stack of modules (Sequentials are flattened, so a trunk and its head are ONE stack) on a 2-D ROCm tensor under autograd.
+    Consecutive narrow layers (`own_layer`) form one _MlpChain of hand-written GEMMs; the wide trunk layers go through `linear_elu` /
+    `linear_relu` (library GEMM + our ELU-backward / bias / slab-sum kernels).  Anything the stack does not cover (other activations, CPU
+    tensors, no_grad) takes the modules as they are."""
+    flat = _flatten(mods)
+    spec = _chain_spec(flat) if (ENABLED and OWN_GEMM and x.is_cuda and torch.is_grad_enabled() and x.dim() == 2 and x.dtype == torch.float32) else None
+    if spec is None:
+        for m in mods:
+            if isinstance(m, torch.nn.Sequential):
+                x = mlp_forward(m, x)
+            elif isinstance(m, torch.nn.Linear):
+                x = narrow_linear(m, x)
+            else:
+                x = m(x)
+        return x
+    i = 0
+    while i < len(spec):
+        m, act, alpha = spec[i]
+        if own_layer(m.in_features, m.out_features):
+            j = i
+            while j < len(spec) and own_layer(spec[j][0].in_features, spec[j][0].out_features):
+                j += 1
+            params = []
+            for mm, _, _ in spec[i:j]:
+                params += [mm.weight, mm.bias]
+            x = _MlpChain.apply(x, tuple((a, al) for _, a, al in spec[i:j]), *params)
+            i = j
+        else:
+            x = linear_elu(x, m.weight, m.bias, alpha) if act == ACT_ELU else (_LinearRelu.apply(x, m.weight, m.bias) if act == ACT_RELU else narrow_linear(m, x))
+            i += 1
+    return x
+
+
 def mlp_forward(seq, x):
-    """Run an nn.Sequential of Linear / ELU modules; on ROCm tensors with gradients enabled every Linear+ELU pair goes
-    through `linear_elu`.  Anything else (CPU tensors, other activations, no_grad) takes the modules as they are."""
+    """Run an nn.Sequential of Linear / ELU modules; on ROCm tensors with gradients enabled through the hand-written GEMM chain
+    (`mlp_chain`), or with QA_OWN_GEMM=0 every Linear+ELU pair through `linear_elu` (library GEMMs).  Anything else (CPU tensors,
+    other activations, no_grad) takes the modules as they are."""
     mods = list(seq)
     if not (x.is_cuda and torch.is_grad_enabled()):
         return seq(x)
+    if ENABLED and OWN_GEMM and x.dim() == 2 and x.dtype == torch.float32 and _chain_spec(mods) is not None:
+        return mlp_chain(mods, x)
     i = 0
     while i < len(mods):
         m = mods[i]

@@ -21,6 +21,15 @@ def _head(m, x):
     return m(x)
 
 
+def _run_head(trunk, head, x):
+    """head(trunk(x)); on ROCm tensors under autograd trunk and head are ONE chain of hand-written GEMMs (algorithms/fused.py)"""
+    if x.is_cuda and torch.is_grad_enabled() and isinstance(trunk, nn.Sequential):
+        from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+        if fused.ENABLED and fused.OWN_GEMM:
+            return fused.mlp_chain([trunk, head], x)
+    return _head(head, _run(trunk, x))
+
+
 def _run(seq, x):
     """nn.Sequential forward; Linear+ELU pairs on ROCm tensors under autograd use the fused backward (algorithms/fused.py)"""
     if x.is_cuda and isinstance(seq, nn.Sequential) and torch.is_grad_enabled():
@@ -189,7 +198,7 @@ class ActorCritic(nn.Module):
         if self.train_with_estimated_latent:
             latent = self.infer_hist_latent(hist) if hist_encoding else self.infer_priv_latent(latent)
         x = torch.cat([prop, explicit, latent, command], dim=-1)
-        return _head(self.actor_head, _run(self.actor_trunk, x))
+        return _run_head(self.actor_trunk, self.actor_head, x)
 
     def update_distribution(self, observations, hist_encoding: bool):
         mean = self._actor_mean(observations, hist_encoding)
@@ -210,4 +219,4 @@ class ActorCritic(nn.Module):
         return self._actor_mean(observations, hist_encoding)
 
     def evaluate(self, critic_observations, **kwargs):
-        return _head(self.critic_head, _run(self.critic_trunk, critic_observations))
+        return _run_head(self.critic_trunk, self.critic_head, critic_observations)

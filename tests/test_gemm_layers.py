@@ -1,0 +1,192 @@
+"""The learner's dense layers (csrc/qa_gemm.hip: qa_linear_forward / _backward_input / _backward_weight).
+
+CPU: the C twins against eager PyTorch (nn.Linear + ELU / ReLU under autograd -- the reference's own expression,
+bbc/rsl_rl/modules/actor_critic.py:92-139).  GPU: the HIP kernels through the C ABI against the twins and against fp32 PyTorch
+on the shapes of the reference's networks (671/512/256/128/101/57/29 wide, heads of 1/4/12 outputs, 24,576-row minibatches),
+ragged sizes, column slices of wider rows, unaligned operands; the `_MlpChain` autograd function against the unfused modules."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_lib import load_oracle
+
+ACT = {None: 0, "elu": 1, "relu": 2}
+
+
+def _eager(x, w, b, act, alpha):
+    y = torch.nn.functional.linear(x, w, b)
+    return torch.nn.functional.elu(y, alpha) if act == "elu" else (torch.relu(y) if act == "relu" else y)
+
+
+def _case(rows, k, n, seed, ldx_extra=0):
+    g = torch.Generator().manual_seed(seed)
+    xw = torch.randn(rows, k + ldx_extra, generator=g)
+    x = xw[:, ldx_extra // 2: ldx_extra // 2 + k]            # a column slice of wider rows when ldx_extra > 0
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) * 0.1
+    gy = torch.randn(rows, n, generator=g)
+    return x, w, b, gy
+
+
+def _oracle_forward(x, w, b, act, alpha):
+    lib = load_oracle()
+    xn = x.numpy(); wn = np.ascontiguousarray(w.numpy()); bn = np.ascontiguousarray(b.numpy())
+    rows, k = x.shape; n = w.shape[0]
+    y = np.zeros((rows, n), np.float32)
+    base = xn.ctypes.data if xn.flags.c_contiguous else None
+    if base is None:                                      # column slice: hand over the view's first element and its row stride
+        base = xn.__array_interface__["data"][0]
+    rc = lib.qo_linear_forward(base, xn.strides[0] // 4, wn.ctypes.data, k, bn.ctypes.data, y.ctypes.data, n, rows, k, n, ACT[act], alpha, None)
+    assert rc == 0
+    return torch.from_numpy(y)
+
+
+@pytest.mark.parametrize("rows,k,n,act,extra", [(37, 57, 128, "elu", 0), (64, 101, 12, None, 0), (130, 29, 64, "relu", 40), (5, 671, 33, "elu", 0)])
+def test_oracle_layer_matches_eager_pytorch(rows, k, n, act, extra):
+    x, w, b, gy = _case(rows, k, n, seed=rows + k, ldx_extra=extra)
+    alpha = 0.7
+    assert torch.allclose(_oracle_forward(x, w, b, act, alpha), _eager(x, w, b, act, alpha), rtol=2e-5, atol=2e-6)
+    # backward: previous-layer derivative from its OUTPUT, weight / bias gradients
+    lib = load_oracle()
+    yprev = torch.randn(rows, k)                           # stands for the previous layer's activation output
+    xr = x.clone().contiguous().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr, br).backward(gy)
+    d = (yprev > 0).float() if act == "relu" else (torch.where(yprev > 0, torch.ones_like(yprev), yprev + alpha) if act == "elu" else torch.ones_like(yprev))
+    gin = np.zeros((rows, k), np.float32); gw = np.zeros((n, k), np.float32); gb = np.zeros(n, np.float32)
+    gyn = gy.numpy(); wn = np.ascontiguousarray(w.numpy()); ypn = yprev.numpy(); xc = np.ascontiguousarray(x.numpy())
+    assert lib.qo_linear_backward_input(gyn.ctypes.data, n, wn.ctypes.data, k, ypn.ctypes.data, k, gin.ctypes.data, k, rows, k, n, ACT[act], alpha, None) == 0
+    assert torch.allclose(torch.from_numpy(gin), xr.grad * d, rtol=2e-5, atol=2e-6)
+    assert lib.qo_linear_backward_weight(gyn.ctypes.data, n, xc.ctypes.data, k, gw.ctypes.data, gb.ctypes.data, rows, k, n, None, 0, None) == 0
+    assert torch.allclose(torch.from_numpy(gw), wr.grad, rtol=2e-5, atol=2e-5)
+    assert torch.allclose(torch.from_numpy(gb), br.grad, rtol=2e-5, atol=2e-5)
+
+
+def test_bad_arguments():
+    lib = load_oracle()
+    a = np.zeros(16, np.float32)
+    p = a.ctypes.data
+    assert lib.qo_linear_forward(None, 4, p, 4, p, p, 4, 1, 4, 4, 0, 1.0, None) != 0
+    assert lib.qo_linear_forward(p, 2, p, 4, p, p, 4, 1, 4, 4, 0, 1.0, None) != 0           # ldx < in_features
+    assert lib.qo_linear_forward(p, 4, p, 4, p, p, 4, 1, 4, 4, 3, 1.0, None) != 0           # unknown activation
+    assert lib.qo_linear_backward_input(p, 4, p, 4, None, 0, p, 4, 1, 4, 4, 1, 1.0, None) != 0   # derivative wanted, no y_prev
+
+
+# ---------------------------------------------------------------- GPU: HIP kernels through the C ABI
+SHAPES = [  # rows, in, out, act   -- the reference's layers at a 24,576-row minibatch, then ragged / tiny / unaligned cases
+    (24576, 671, 512, "elu"), (24576, 512, 256, "elu"), (24576, 256, 128, "elu"), (24576, 128, 1, None), (24576, 101, 512, "elu"),
+    (24576, 128, 12, None), (24576, 57, 128, "elu"), (24576, 64, 4, None), (24576, 29, 64, "elu"), (24576, 64, 29, "elu"),
+    (3684, 98, 512, "relu"), (1000, 300, 257, "elu"), (1, 5, 3, None), (129, 17, 130, "relu"), (6144, 800, 512, "elu"),
+]
+
+
+def _tol(k):
+    return dict(rtol=3e-5, atol=3e-6 * max(1.0, (k / 64) ** 0.5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,k,n,act", SHAPES)
+def test_hip_forward_matches_fp32_torch(rows, k, n, act):
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    x, w, b, _ = _case(rows, k, n, seed=k * 7 + n)
+    alpha = 1.0
+    ref = _eager(x.double(), w.double(), b.double(), act, alpha).float()
+    y = fused.linear_forward_raw(x.cuda(), w.cuda(), b.cuda(), ACT[act], alpha).cpu()
+    assert torch.allclose(y, ref, **_tol(k))
+    if rows <= 4096:                                       # the C twin on the sizes it finishes in seconds
+        assert torch.allclose(y, _oracle_forward(x, w, b, act, alpha), **_tol(k))
+    # without a bias, and as a column slice of wider rows (leading dimension != width, unaligned first column)
+    y0 = fused.linear_forward_raw(x.cuda(), w.cuda(), None, ACT[act], alpha).cpu()
+    assert torch.allclose(y0, _eager(x.double(), w.double(), None, act, alpha).float(), **_tol(k))
+    wide = torch.randn(rows, k + 6, generator=torch.Generator().manual_seed(k * 7 + n)).cuda()
+    ys = fused.linear_forward_raw(wide[:, 3:3 + k], w.cuda(), b.cuda(), ACT[act], alpha).cpu()
+    assert torch.allclose(ys, _eager(wide[:, 3:3 + k].cpu().double(), w.double(), b.double(), act, alpha).float(), **_tol(k))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,k,n,act", SHAPES)
+def test_hip_backward_matches_fp32_torch(rows, k, n, act):
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    x, w, b, gy = _case(rows, k, n, seed=k * 11 + n)
+    alpha = 1.0
+    yprev = torch.randn(rows, k, generator=torch.Generator().manual_seed(3))
+    d = (yprev > 0).double() if act == "relu" else (torch.where(yprev > 0, torch.ones_like(yprev), yprev + alpha).double() if act == "elu" else torch.ones_like(yprev).double())
+    gin_ref = ((gy.double() @ w.double()) * d).float()
+    gin = fused.linear_backward_input_raw(gy.cuda(), w.cuda(), yprev.cuda(), ACT[act], alpha).cpu()
+    assert torch.allclose(gin, gin_ref, **_tol(n))
+    gin0 = fused.linear_backward_input_raw(gy.cuda(), w.cuda(), None, 0).cpu()
+    assert torch.allclose(gin0, (gy.double() @ w.double()).float(), **_tol(n))
+    gw, gb = fused.linear_backward_weight_raw(gy.cuda(), x.cuda())
+    gw_ref, gb_ref = (gy.double().t() @ x.double()).float(), gy.double().sum(0).float()
+    scale = max(1.0, rows ** 0.5)        # fp32 accumulation over `rows` products of unit-variance factors: the sums are ~sqrt(rows) large
+    assert torch.allclose(gw.cpu(), gw_ref, rtol=2e-4, atol=6e-6 * scale), (gw.cpu() - gw_ref).abs().max()
+    assert torch.allclose(gb.cpu(), gb_ref, rtol=2e-4, atol=6e-6 * scale)
+    # bit-reproducible (fixed-order slab sums, no atomics)
+    gw2, gb2 = fused.linear_backward_weight_raw(gy.cuda(), x.cuda())
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    # operands as column slices of wider rows
+    wide = torch.randn(rows, k + 5, generator=torch.Generator().manual_seed(4)).cuda()
+    gws, _ = fused.linear_backward_weight_raw(gy.cuda(), wide[:, 2:2 + k])
+    assert torch.allclose(gws.cpu(), (gy.double().t() @ wide[:, 2:2 + k].cpu().double()).float(), rtol=2e-4, atol=6e-6 * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_every_tile_configuration_computes_the_same_products(cfg):
+    """pick_cfg chooses by size; force each tile shape over ragged problems"""
+    from quadrupedal_agility_amd import _capi
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    lib = _capi.load_library()
+    lib.qa_gemm_force_config.argtypes = [C.c_int32]
+    try:
+        lib.qa_gemm_force_config(cfg)
+        for rows, k, n in [(777, 201, 150), (300, 64, 64), (2049, 33, 513)]:
+            x, w, b, gy = _case(rows, k, n, seed=rows)
+            y = fused.linear_forward_raw(x.cuda(), w.cuda(), b.cuda(), 1, 1.0).cpu()
+            assert torch.allclose(y, _eager(x.double(), w.double(), b.double(), "elu", 1.0).float(), **_tol(k))
+            gin = fused.linear_backward_input_raw(gy.cuda(), w.cuda(), None, 0).cpu()
+            assert torch.allclose(gin, (gy.double() @ w.double()).float(), **_tol(n))
+            gw, gb = fused.linear_backward_weight_raw(gy.cuda(), x.cuda())
+            assert torch.allclose(gw.cpu(), (gy.double().t() @ x.double()).float(), rtol=1e-4, atol=1e-4)
+            assert torch.allclose(gb.cpu(), gy.double().sum(0).float(), rtol=1e-4, atol=1e-4)
+    finally:
+        lib.qa_gemm_force_config(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 300, 24576])
+def test_chain_autograd_matches_the_unfused_modules(rows):
+    """_MlpChain (trunk + head as one chain, input gradient included) against nn.Sequential under autograd"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    torch.manual_seed(0)
+    trunk = torch.nn.Sequential(torch.nn.Linear(101, 512), torch.nn.ELU(), torch.nn.Linear(512, 256), torch.nn.ELU(), torch.nn.Linear(256, 128), torch.nn.ELU()).cuda()
+    head = torch.nn.Linear(128, 12).cuda()
+    enc = torch.nn.Sequential(torch.nn.Linear(29, 64), torch.nn.ELU(), torch.nn.Linear(64, 29), torch.nn.ELU()).cuda()       # ends in an activation
+    x = torch.randn(rows, 101, device="cuda"); z = torch.randn(rows, 29, device="cuda")
+    gy = torch.randn(rows, 12, device="cuda"); gz = torch.randn(rows, 29, device="cuda")
+    params = list(trunk.parameters()) + list(head.parameters()) + list(enc.parameters())
+
+    def run(own):
+        for p in params:
+            p.grad = None
+        xr, zr = x.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        if own:
+            y, e = fused.mlp_chain([trunk, head], xr), fused.mlp_chain([enc], zr)
+        else:
+            y, e = head(trunk(xr)), enc(zr)
+        torch.autograd.backward([y, e], [gy, gz])
+        return [y.detach(), e.detach(), xr.grad, zr.grad] + [p.grad.clone() for p in params]
+
+    assert fused.OWN_GEMM
+    fused.ALL_OWN = True           # the trunk layers too (the product routes only the narrow layers here; fused.own_layer)
+    try:
+        a = run(True)
+    finally:
+        fused.ALL_OWN = False
+    b = run(False)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=2e-4, atol=2e-5 * max(1.0, rows ** 0.5)), (u - v).abs().max()
+    a = run(True)                  # the product's mix: narrow layers on our GEMMs, trunk layers on the library + our kernels around it
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=2e-4, atol=2e-5 * max(1.0, rows ** 0.5)), (u - v).abs().max()
