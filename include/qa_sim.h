@@ -266,6 +266,15 @@ int qa_tsc_reset(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy,
 int qa_tsc_reset_dev(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range,
                      float rand_x_range, float rand_y_range, float rand_pitch_range, const int64_t *global_step_dev, void *stream);
 
+/* Reset bookkeeping of one task-level step in a single launch (tsc/legged_gym/envs/base/legged_robot.py:382-384, 396-404):
+ *   any_reset[0]      = 1 if any reset_flags[e] != 0 (the condition of the reference's extra gym.simulate: feed it to qa_simulate_if)
+ *   episode_means[k]  = sum over the flagged envs of episode_sums[k][e] / count / max_episode_length_s   for k < num_terms,
+ *                       left untouched when no env is flagged (`extras["episode"]` keeps the last values)
+ * episode_sums is (num_terms, num_envs) row-major.  One workgroup, fixed summation order (lane t adds envs t, t + 1024, ...; then a
+ * binary tree): bit-reproducible, and bit-identical to the C twin. */
+int qa_tsc_reset_stats(const uint8_t *reset_flags, const float *episode_sums, int64_t num_envs, int32_t num_terms, float max_episode_length_s,
+                       float *episode_means, uint8_t *any_reset, void *stream);
+
 /* qa_simulate only if *cond_dev != 0 (one device byte): the reference's reset_idx runs one more gym.simulate -- for EVERY env,
  * with the actuation forces set last -- whenever at least one env resets (:382-384).  torques == NULL applies QA_T_TORQUES. */
 int qa_simulate_if(qa_sim *sim, const float *torques, const uint8_t *cond_dev, void *stream);

@@ -1424,6 +1424,33 @@ int qo_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int6
     return QA_OK;
 }
 
+/* CPU twin of qa_tsc_reset_stats (tsc/legged_gym/envs/base/legged_robot.py:382-384, 396-404): the kernel's summation order restated
+ * (1024 strided partial sums, then a binary tree), fp32, so the two agree bit for bit */
+static float tree1024(float *red) {
+    for (int w = 512; w > 0; w >>= 1) for (int t = 0; t < w; ++t) red[t] += red[t + w];
+    return red[0];
+}
+int qo_tsc_reset_stats(const uint8_t *reset_flags, const float *episode_sums, int64_t num_envs, int32_t num_terms, float max_episode_length_s,
+                       float *episode_means, uint8_t *any_reset, void *stream) {
+    (void)stream;
+    if (!reset_flags || !episode_sums || !episode_means || !any_reset || num_envs <= 0 || num_terms <= 0 || !(max_episode_length_s > 0.f)) return QA_E_ARG;
+    float red[1024];
+    for (int t = 0; t < 1024; ++t) { float c = 0.f; for (int64_t e = t; e < num_envs; e += 1024) c += reset_flags[e] ? 1.f : 0.f; red[t] = c; }
+    const float cnt = tree1024(red);
+    any_reset[0] = cnt > 0.f ? 1 : 0;
+    if (cnt <= 0.f) return QA_OK;
+    const float inv = 1.0f / max_episode_length_s;
+    for (int k = 0; k < num_terms; ++k) {
+        for (int t = 0; t < 1024; ++t) {
+            float a = 0.f;
+            for (int64_t e = t; e < num_envs; e += 1024) a += reset_flags[e] ? episode_sums[(int64_t)k * num_envs + e] : 0.f;
+            red[t] = a;
+        }
+        episode_means[k] = tree1024(red) / cnt * inv;
+    }
+    return QA_OK;
+}
+
 /* RunningMeanStd.update / update_from_moments (utils.py:62-84) on host memory, plain double loops */
 int qo_normalizer_update(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim,
                          double *mean, double *var, double *count, void *stream) {

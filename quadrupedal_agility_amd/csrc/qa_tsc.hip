@@ -432,6 +432,37 @@ __global__ void __launch_bounds__(64 * OBS_WAVES) qa_tsc_observations_kernel(qa_
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// reset bookkeeping of a step in one launch: any_reset = OR of the flags (what decides the reference's extra simulate, legged_robot.py
+// :382-384) and the `extras["episode"]` means of the resetting envs (:396-404: mean episode sum / episode length in seconds), kept from
+// the last step on which anyone reset.  ONE workgroup, fixed summation order (thread t adds envs t, t + 1024, ... then a fixed LDS
+// tree): bit-reproducible, no atomics -- it replaces torch's sum(dim=1) + an index_add_ inside the recorded rollout.
+__global__ void __launch_bounds__(1024) qa_tsc_reset_stats_kernel(const uint8_t *__restrict__ flags, const float *__restrict__ sums, int64_t n, int num_terms,
+                                                                  float inv_len_s, float *__restrict__ means, uint8_t *__restrict__ any_reset) {
+    __shared__ float red[1024];
+    __shared__ float cnt_s;
+    const int t = threadIdx.x;
+    float c = 0.f;
+    for (int64_t e = t; e < n; e += 1024) c += flags[e] ? 1.f : 0.f;
+    red[t] = c;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+    if (t == 0) { cnt_s = red[0]; any_reset[0] = red[0] > 0.f ? 1 : 0; }
+    __syncthreads();
+    const float cnt = cnt_s;
+    if (cnt <= 0.f) return;                      // nobody reset: the means keep their values
+    for (int k = 0; k < num_terms; ++k) {
+        float a = 0.f;
+        for (int64_t e = t; e < n; e += 1024) a += flags[e] ? sums[(int64_t)k * n + e] : 0.f;
+        __syncthreads();
+        red[t] = a;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+        if (t == 0) means[k] = red[0] / cnt * inv_len_s;
+    }
+}
+
 extern "C" {
 
 int qa_tsc_set_commands(const float *actions, const int64_t *episode_length, int64_t num_envs, int32_t num_d, int32_t num_c, int32_t dim_c,
@@ -512,4 +543,15 @@ int qa_tsc_observations(const qa_tsc_obs_cfg *cfg, const qa_tsc_obs_io *io, void
     return QA_OK;
 }
 
+
+int qa_tsc_reset_stats(const uint8_t *reset_flags, const float *episode_sums, int64_t num_envs, int32_t num_terms, float max_episode_length_s,
+                       float *episode_means, uint8_t *any_reset, void *stream) {
+    if (!reset_flags || !episode_sums || !episode_means || !any_reset || num_envs <= 0 || num_terms <= 0 || !(max_episode_length_s > 0.f)) {
+        snprintf(g_terr, sizeof(g_terr), "qa_tsc_reset_stats: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_tsc_reset_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, reset_flags, episode_sums, num_envs, (int)num_terms,
+                       1.0f / max_episode_length_s, episode_means, any_reset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_terr, sizeof(g_terr), "qa_tsc_reset_stats: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
 }  // extern "C"

@@ -271,21 +271,31 @@ class LeggedRobot:
                            e.rand_y_range if e.randomize_start_y else 0.0, e.rand_pitch_range if (e.randomize_start_yaw and e.randomize_start_pitch) else 0.0,
                            self._step_dev if self._step_dev.is_cuda else self.common_step_counter)
         # extras["episode"]: mean episode sums of the resetting envs / episode length in seconds (:396-404), kept when nobody resets
-        f = (flags != 0).to(torch.float32)
-        # the count of resetting envs decides the extra simulate below (control, not logging) and this code is replayed from a hipGraph:
-        # an atomic scatter-add onto one slot instead of torch's tree reduction (profiles/r2_hipgraph_stale_reductions.md); integers, so exact
-        if getattr(self, "_zero_idx", None) is None or self._zero_idx.shape[0] != f.shape[0]:
-            self._zero_idx = torch.zeros(f.shape[0], dtype=torch.int64, device=f.device)
-        cnt = torch.zeros(1, dtype=torch.float32, device=f.device).index_add_(0, self._zero_idx, f)[0]
-        mean = (bk.episode_sums_buf * f).sum(dim=1) / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
-        self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
+        if flags.is_cuda:
+            # ONE launch, fixed-order sums (qa_tsc_reset_stats): the OR of the flags decides the extra simulate below (control, not logging)
+            # and this code is replayed from a hipGraph -- no torch reduction in it (profiles/r2_hipgraph_stale_reductions.md)
+            if getattr(self, "_any_reset", None) is None:
+                self._any_reset = torch.zeros(1, dtype=torch.uint8, device=self.device)
+            lib = _capi.load_library()
+            rc = lib.qa_tsc_reset_stats(flags.data_ptr(), bk.episode_sums_buf.data_ptr(), self.num_envs, bk.episode_sums_buf.shape[0],
+                                        float(self.max_episode_length_s), self._episode_means.data_ptr(), self._any_reset.data_ptr(),
+                                        torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"qa_tsc_reset_stats failed with code {rc}: {lib.qa_last_error().decode()}")
+            any_reset = self._any_reset
+        else:
+            f = (flags != 0).to(torch.float32)
+            cnt = f.sum()
+            mean = (bk.episode_sums_buf * f).sum(dim=1) / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
+            self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
+            any_reset = (cnt > 0).to(torch.uint8).reshape(1)
         snap = self._episode_means.clone()
         self.extras["episode"] = {"rew_" + n: snap[i] for i, n in enumerate(_capi.TSC_REWARD_NAMES)}
         if cfg.env.send_timeouts:
             self.extras["time_outs"] = bk.time_out_buf.view(torch.bool)
         bk.reset_where(flags, start_goal)
         if not first:
-            self.sim.simulate_if(None, (cnt > 0).to(torch.uint8).reshape(1))
+            self.sim.simulate_if(None, any_reset)
         else:
             self.sim.simulate_if(None, torch.ones(1, dtype=torch.uint8, device=self.device))
 

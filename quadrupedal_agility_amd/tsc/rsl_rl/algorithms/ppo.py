@@ -52,7 +52,7 @@ class PPO:
         # the minibatch step as recorded launches (hipGraph): see _update_recorded
         self.use_update_graph = os.environ.get("QA_TSC_UPDATE_GRAPH", "1") != "0"
         self.use_fused_loss = os.environ.get("QA_TSC_FUSED_LOSS", "1") != "0"
-        self._graph, self._warm_updates, self._lr_dev = None, 0, None
+        self._graph, self._warm_updates, self._lr_dev, self._recordable = None, 0, None, None
         self.if_depth = depth_encoder is not None
         if self.if_depth:
             self.depth_encoder, self.depth_encoder_paras, self.depth_actor = depth_encoder, depth_encoder_paras, depth_actor
@@ -178,7 +178,7 @@ class PPO:
         ac = self.actor_critic
         coef = self._priv_reg_coef_now()
         if (self.use_update_graph and self._graph is not False and self._warm_updates >= 1 and fused.ENABLED and torch.device(self.device).type == "cuda"
-                and self.desired_kl is not None and self.schedule == "adaptive" and self.use_fused_loss):
+                and self.desired_kl is not None and self.schedule == "adaptive" and self.use_fused_loss and self._recordable_networks()):
             # (use_fused_loss: the eager objective reduces through torch's two-stage sum / mean, which go stale under hipGraph replay
             # at 24576+ rows -- tools/graph_reduction_audit.py; the recorded step only ever contains our own fixed-order reductions)
             sums = self._update_recorded(coef)
@@ -235,6 +235,17 @@ class PPO:
         self.storage.clear()
         self.update_counter()
         return v, s, e, 0.0, 0.0, p, coef
+
+    def _recordable_networks(self):
+        """the structure gate of the recorded update (the behaviour-level learner has the same one, SSInfoGAIL._recordable_networks): every
+        trainable parameter's gradient must come out of our kernels -- torch's batch reductions go stale under hipGraph replay here -- else
+        the update stays eager"""
+        if self._recordable is None:
+            self._recordable = bool(fused.recordable(self.actor_critic, self.estimator))
+            if not self._recordable:
+                print("[tsc ppo] networks outside the recorded step's whitelist (fused.recordable): the update stays eager")
+                self._graph = False
+        return self._recordable
 
     def _minibatch_losses(self, batch, hist_latent, coef):
         """forward of one minibatch (the body of update(), :222-262) -> (est_loss, loss, kl, [value, surrogate, priv_reg])"""

@@ -166,7 +166,10 @@ class OnPolicyRunner:
         push (`env._step_dev`), torch's generator (graph-safe Philox offsets), the policy's weights."""
         env, alg, T = self.env, self.alg, self.num_steps_per_env
         key = (bool(hist_encoding), bool(logging))
-        if not (self.use_rollout_graph and torch.device(self.device).type == "cuda") or self._rollout_graphs.get(key) is False:
+        # (a depth camera that does not update every step decides `update_yaw` / the depth pass from the HOST's step counter: a replay would
+        # repeat the phase seen at capture, so such a rollout is not recorded)
+        phase_on_host = bool(env.cfg.depth.use_camera) and int(env.cfg.depth.update_interval) != 1
+        if not (self.use_rollout_graph and torch.device(self.device).type == "cuda") or phase_on_host or self._rollout_graphs.get(key) is False:
             with torch.inference_mode():
                 return self._rollout_steps(hist_encoding, logging)
         if key not in self._rollout_graphs:
