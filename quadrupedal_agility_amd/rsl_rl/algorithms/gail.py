@@ -119,6 +119,7 @@ class SSInfoGAIL:
         self._ac_graph, self._recording_ac, self._priv_coef_dev = None, False, None
         self._disc_stream, self._recording_disc = None, False
         self.overlap_updates = os.environ.get("QA_OVERLAP_UPDATES", "1") != "0"     # GPU: discriminator steps on a second stream beside the PPO steps
+        self.eager_from_tables = False      # test hook: eager discriminator steps on the sample tables the recorded path draws (update())
         self._dagger_graph, self._dagger_calls = None, 0
         self._task_w_dev = None
         # recordings wait for one eager update since construction / checkpoint load: optimizer state and the pointer
@@ -262,8 +263,9 @@ class SSInfoGAIL:
             if self._on_gpu and self.use_update_graph and self.grad_sync is None and self._warm_updates >= 1 and self._disc_graph is not False:
                 acc_d = self._disc_updates_recorded(n_d, mb).clone()
                 self._clamp_std()
-            elif os.environ.get("QA_DEBUG_EAGER_FROM_TABLES") == "1" and self._on_gpu:
-                # debugging aid: the eager steps on exactly the samples the recorded path would draw (same generator calls)
+            elif self.eager_from_tables and self._on_gpu:
+                # the eager steps on exactly the samples the recorded path would draw (same generator calls): what the recorded-vs-eager
+                # regression test compares the replays with (tests/test_gpu_train.py)
                 ml, rb = self.motion_loader, self.disc_storage
                 tabs = [torch.zeros(n_d, mb, dtype=torch.int64, device=dev) for _ in range(3)]
                 nsd = torch.full((), float(rb.num_samples), device=dev)
@@ -274,8 +276,6 @@ class SSInfoGAIL:
                     i_pi, i_lb, i_ulb = tabs[0][k], tabs[1][k], tabs[2][k]
                     acc_d += torch.stack(self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
                                                                   (ml.preloaded_s_lb[i_lb], ml.preloaded_label[i_lb]), ml.preloaded_s_ulb[i_ulb]))
-                    if os.environ.get("QA_DEBUG_DISC_TRACE"):
-                        self._trace_disc(os.environ["QA_DEBUG_DISC_TRACE"])
             else:
                 gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
                            self.motion_loader.feed_forward_generator_lb(n_d, mb),
@@ -286,15 +286,6 @@ class SSInfoGAIL:
         self.priv_reg_counter += 1
         self._warm_updates += 1
         return LossReadout(torch.cat([acc_ac / n_ac, acc_d / n_d]))
-
-    def _trace_disc(self, path):
-        """debugging aid: one line of checksums per discriminator step"""
-        torch.cuda.synchronize()
-        st = [float(sum(s_[k].double().sum() for s_ in o.state.values())) for o in (self.optim_d, self.optim_q_eps, self.optim_q_c) for k in ("exp_avg", "exp_avg_sq")]
-        with open(path, "a") as f:
-            f.write(json.dumps(dict(update=self.learning_steps, disc=[float(p.detach().double().sum()) for p in self.disc.parameters()], adam=st,
-                                    norm=float(self.disc_normalizer.mean.double().sum()), count=float(self.disc_normalizer.count),
-                                    prior=float(self.env.prior_parameters.double().sum()))) + "\n")
 
     def _recordable_networks(self):
         other = (nn.SELU, nn.ReLU, nn.LeakyReLU, nn.Tanh, nn.Sigmoid, nn.GELU, nn.SiLU)
@@ -442,8 +433,6 @@ class SSInfoGAIL:
                 for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
                     o.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
-                if os.environ.get("QA_DEBUG_DUMP_DISC_GRAPH"):
-                    g.enable_debug_mode()
                 from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
                 # recorded on a stream of its own: the library GEMM workspace is keyed by the stream a launch is recorded on,
                 # and this step is replayed CONCURRENTLY with the PPO step's recording (update(), "overlap")
@@ -455,8 +444,6 @@ class SSInfoGAIL:
                         one_step()
                 finally:
                     self._recording_disc = False
-                if os.environ.get("QA_DEBUG_DUMP_DISC_GRAPH"):
-                    g.debug_dump(os.environ["QA_DEBUG_DUMP_DISC_GRAPH"])
                 self._disc_graph = g
             except Exception as e:      # never fatal
                 print(f"[disc update graph] capture failed, staying eager: {e}")
@@ -480,14 +467,8 @@ class SSInfoGAIL:
         torch.randint(0, ml.preloaded_s_ulb.shape[0], t_ulb.shape, device=dev, out=t_ulb)
         t_lab.copy_(ml.preloaded_label[t_lb.view(-1)].view(t_lb.shape))
         self._d_step.zero_()
-        step_sync = os.environ.get("QA_DEBUG_DISC_STEP_SYNC") == "1"      # debugging aid: drain the GPU between replays
-        trace = os.environ.get("QA_DEBUG_DISC_TRACE")
         for _ in range(n_steps):
             self._disc_graph.replay()
-            if step_sync:
-                torch.cuda.synchronize()
-            if trace:
-                self._trace_disc(trace)
         return self._acc_d          # persistent: the caller copies it on ITS stream after joining
 
     def _sync_grads(self, params):
@@ -611,6 +592,12 @@ class SSInfoGAIL:
                                                         clipped_value=self.use_clipped_value_loss)
         if self.branch_streams:
             cur.wait_stream(s_small)
+            if not self._recording_ac:
+                # eager (warm-up) steps: these blocks were allocated on the side streams and are read by current-stream kernels from here on;
+                # tell the caching allocator, or another allocation on a side stream could reuse them under those reads (a recording has
+                # its own private pool)
+                for t in (value, priv_latent, est, g_priv, g_est):
+                    t.record_stream(cur)
         # (tried and dropped: the dW GEMMs of the Linear+ELU layers on a fourth stream, off the dX critical path -- 34.1 -> 37.8 ms:
         # big GEMMs running side by side slow each other more than the shorter dependency chain saves)
         torch.autograd.backward([est, mu, value, priv_latent], [g_est, dmu, dvalue.view_as(value), g_priv])
@@ -783,12 +770,18 @@ class SSInfoGAIL:
         if self.grad_sync is not None:
             # ONE collective per discriminator step: gradients | class mean of the prior EMA | the normaliser's batch moments
             extra = [pred_mean]
-            if self.disc_normalizer is not None and hasattr(self.disc_normalizer, "batch_moments"):
-                extra.append(self.disc_normalizer.batch_moments(norm_batches))
+            nm = self.disc_normalizer
+            cold = nm is not None and hasattr(nm, "batch_moments") and nm.cold()
+            if nm is not None and hasattr(nm, "batch_moments") and not cold:
+                extra.append(nm.batch_moments(norm_batches))          # fp32, taken about the running mean
             back = self.grad_sync(list(self.disc.parameters()), extra=extra)
             pred_mean = back[0]
             if len(back) > 1:
                 synced_moments = back[1].view(len(norm_batches), 2, -1)
+            elif cold:      # the first folds of a fresh normaliser: raw moments in fp64 through a collective of their own (4.7 KB)
+                m64 = nm.batch_moments_exact(norm_batches)
+                self.grad_sync.all_reduce_(m64)
+                synced_moments = m64 / self.grad_sync.world
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
         for o in self._step_disc:
             o.step()

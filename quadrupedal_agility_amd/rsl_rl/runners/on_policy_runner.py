@@ -58,15 +58,7 @@ def _no_gc():
     gc.collect()
     gc.disable()
     try:
-        if os.environ.get("QA_DEBUG_CAPTURE_WARNINGS") == "1":       # debugging aid: which capture sees autograd's stream-mismatch warning
-            import traceback, warnings
-            with warnings.catch_warnings(record=True) as seen:
-                warnings.simplefilter("always")
-                yield
-            who = [f.name for f in traceback.extract_stack()[:-2]][-3:]
-            print(f"[capture {who}] warnings: {len(seen)}", [str(w.message)[:60] for w in seen[:2]], flush=True)
-        else:
-            yield
+        yield
     finally:
         if was:
             gc.enable()

@@ -128,22 +128,46 @@ class TorchNormalizer:
     # ---- data-parallel runs: every rank must fold the SAME (global) batch moments, otherwise the replicas normalise the
     # discriminator's inputs differently (and only rank 0's moments reach model.pt).  The local first and second moments of
     # the batches travel in the discriminator step's gradient bucket and come back averaged over the ranks.
-    @staticmethod
-    def batch_moments(batches):
-        """(k, 2, dim) fp32: per batch [mean, mean of squares] of the local rows"""
+    def batch_moments(self, batches):
+        """(k, 2, dim) fp32: per batch [mean, mean of squares] of the local rows TAKEN ABOUT THE RUNNING MEAN (identical on every rank
+        before the step).  The bucket they travel in is fp32: raw E[x] / E[x^2] rebuilt as E[x^2] - E[x]^2 cancel to ~1e-7 mean^2, i.e. to
+        1e-5 of the variance and worse for features whose mean is large against their spread; shifted by the running mean the
+        same rounding is relative to the spread itself, and the single-process update (qa_normalizer_update, double) is matched to 1e-6."""
+        shift = self.mean.to(torch.float64)
+        out = []
+        for b in batches:
+            d = b.detach().to(torch.float64) - shift
+            out.append(torch.stack([d.mean(dim=0), d.square().mean(dim=0)]))
+        self._moment_shift = shift.clone()
+        return torch.stack(out).to(torch.float32)
+
+    COLD_FOLDS = 3
+
+    def cold(self):
+        """the running mean is not yet a useful shift (first folds of a fresh normaliser): the caller sends `batch_moments_exact` through
+        a small fp64 all-reduce of its own instead of the fp32 bucket"""
+        return getattr(self, "_folds", 0) < self.COLD_FOLDS
+
+    def batch_moments_exact(self, batches):
+        """(k, 2, dim) fp64: per batch the raw [mean, mean of squares] of the local rows (for an fp64 collective)"""
+        self._moment_shift = torch.zeros_like(self.mean)
         out = []
         for b in batches:
             b64 = b.detach().to(torch.float64)
             out.append(torch.stack([b64.mean(dim=0), b64.square().mean(dim=0)]))
-        return torch.stack(out).to(torch.float32)
+        return torch.stack(out)
 
     def update_from_batch_moments(self, moments, rows_per_batch):
-        """fold k batches given their (rank-averaged) [mean, mean of squares] and their GLOBAL row counts, in order --
-        RunningMeanStd.update_from_moments (utils.py:70-84) with the batch variance E[x^2] - E[x]^2"""
+        """fold k batches given their (rank-averaged) shifted [mean, mean of squares] and their GLOBAL row counts, in order --
+        RunningMeanStd.update_from_moments (utils.py:70-84) with the batch variance E[d^2] - E[d]^2, d = x - shift"""
         m = moments.to(torch.float64)
+        self._folds = getattr(self, "_folds", 0) + 1
+        shift = getattr(self, "_moment_shift", None)
+        if shift is None:
+            shift = torch.zeros_like(self.mean)
         for i, n in enumerate(rows_per_batch):
-            bm = m[i, 0]
-            bv = torch.clamp(m[i, 1] - bm.square(), min=0.0)
+            bm = shift + m[i, 0]
+            bv = torch.clamp(m[i, 1] - m[i, 0].square(), min=0.0)
             delta = bm - self.mean
             total = self.count + float(n)
             m2 = self.var * self.count + bv * float(n) + torch.square(delta) * self.count * float(n) / total

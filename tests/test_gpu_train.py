@@ -207,7 +207,7 @@ def test_recorded_discriminator_flow_equals_eager_flow_with_phase_syncs(monkeypa
     the first trunk bias's gradient buffer unwritten under replay -> garbage gradient -> Adam second moment = inf -> 512 biases
     stopped training and the style reward came out ~20 % high.  The step's batch reductions are our own kernels now."""
     from quadrupedal_agility_amd.legged_gym.envs import task_registry
-    monkeypatch.setenv("QA_OVERLAP_UPDATES", "0"); monkeypatch.setenv("QA_DEBUG_EAGER_FROM_TABLES", "1")
+    monkeypatch.setenv("QA_OVERLAP_UPDATES", "0")
     monkeypatch.setenv("QA_PHASE_TIMING", "1"); monkeypatch.setenv("QA_ROLLOUT_GRAPH", rollout_graph)
     res = []
     for recorded in (True, False):
@@ -216,6 +216,7 @@ def test_recorded_discriminator_flow_equals_eager_flow_with_phase_syncs(monkeypa
         runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
         runner.phase_timing = True
         a = runner.alg
+        a.eager_from_tables = True
         if not recorded:
             a._disc_graph = False
         runner.learn(5, init_at_random_ep_len=True)

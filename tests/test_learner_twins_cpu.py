@@ -164,3 +164,34 @@ def test_penalty_chain_through_proxy_leaves_gives_the_same_gradients():
         out.append(([t.detach().clone() for t in (dl, eps, c, g)], [p.grad.clone() for p in d.parameters()]))
     for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_data_parallel_normaliser_moments_match_the_single_process_update_for_offset_features():
+    """Normalizer.batch_moments / update_from_batch_moments (the discriminator-input normaliser under data parallelism): two
+    ranks' fp32 bucket entries must reproduce the one-process RunningMeanStd.update (bbc/rsl_rl/utils/utils.py:62-84, double) also for
+    features whose mean is large against their spread -- raw E[x], E[x^2] in fp32 lose the variance there"""
+    import numpy as np
+    import torch
+    from quadrupedal_agility_amd.rsl_rl.utils.utils import TorchNormalizer
+    g = torch.Generator().manual_seed(0)
+    dim = 6
+    offset = torch.tensor([0.0, 1.0, 50.0, -300.0, 1000.0, 3.0])
+    spread = torch.tensor([1.0, 0.1, 0.05, 0.2, 0.5, 2.0])
+    single, dp = TorchNormalizer(dim, "cpu"), TorchNormalizer(dim, "cpu")
+    for step in range(8):
+        halves = [(torch.randn(614, dim, generator=g) * spread + offset).float() for _ in range(2)]        # the two ranks' rows of one batch
+        single.update_torch([torch.cat(halves)])
+        if dp.cold():            # first folds: raw moments, fp64 collective
+            moments = torch.stack([dp.batch_moments_exact([h]) for h in halves]).mean(0)
+            assert moments.dtype == torch.float64
+        else:                    # then: about the running mean, in the fp32 gradient bucket
+            moments = torch.stack([dp.batch_moments([h]) for h in halves]).mean(0)
+            assert moments.dtype == torch.float32
+        dp.update_from_batch_moments(moments, [1228])
+    assert not dp.cold()
+    np.testing.assert_allclose(dp.mean.numpy(), single.mean.numpy(), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(dp.var.numpy(), single.var.numpy(), rtol=1e-6)
+    # the raw fp32 moments this replaces: 2 % off on the feature with mean 1000 and spread 0.5
+    h = (torch.randn(1228, dim, generator=g) * spread + offset).float().double()
+    raw = torch.stack([h.mean(0), h.square().mean(0)]).float().double()
+    assert abs(float((raw[1] - raw[0] ** 2)[4] / h.var(0, unbiased=False)[4]) - 1.0) > 1e-3
