@@ -192,13 +192,7 @@ def main():
 
     if rank == 0:
         achieved = ALG_BYTES_PER_ENV_STEP * args.num_envs / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "env_step_traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = _stamped_traffic(g)
         out = {
             "metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -212,7 +206,7 @@ def main():
             "rollout_env_steps_per_s": args.num_envs * T * world / (sum(coll) / len(coll)),
             "collection_s": sum(coll) / len(coll), "learn_s": sum(lrn) / len(lrn),
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_ms_alone, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_ms_alone, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
                          "note": "not byte-bound: 4096 envs = 256 wavefronts = one per CU; by the SQ counters that wavefront spends 65 % of its time issuing instructions (21.6 k VALU) and 33 % parked on s_waitcnt with nothing else to run (profiles/r1_env_step_pmc.md, DESIGN.md 4.1); 16384 envs/GPU reach 4 wavefronts per CU and 3.4x this rate"},
         }
@@ -240,6 +234,28 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), file=_RESULT_OUT, flush=True)
+
+
+ENV_KERNEL_SOURCES = ("qa_sim.hip", "qa_physics.h", "qa_device.h", "qa_go2_model.h")
+
+
+def env_kernel_hash(g):
+    """hash of the sources the env-step kernel is compiled from (what a PMC traffic figure is valid for)"""
+    return g._src_hash([os.path.join(g.CSRC, f) for f in ENV_KERNEL_SOURCES])[:16]
+
+
+def _stamped_traffic(g):
+    """roofline.traffic: the HBM bytes per launch of the PMC passes (tools/final_measure.sh -> profiles/env_step_traffic.json), reported only
+    when that file was measured on the kernel sources this run built -- a figure from another version of the kernel is not a measurement of
+    this one.  Counter passes cannot run inside this process: rocprofv3 collects them per process, in passes of their own."""
+    prof = os.path.join(ROOT, "profiles", "env_step_traffic.json")
+    try:
+        d = json.load(open(prof))
+    except Exception:
+        return None, "no PMC pass on file"
+    if d.get("kernel_source_hash") != env_kernel_hash(g):
+        return None, f"profiles/env_step_traffic.json was measured on kernel sources {d.get('kernel_source_hash', 'unstamped')}, this build is {env_kernel_hash(g)}: re-run tools/final_measure.sh"
+    return d.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {d['kernel_source_hash']} (tools/final_measure.sh)"
 
 
 def _barrier_sync(world):
@@ -303,12 +319,21 @@ def bench_tsc(args, world, rank, local_rank, dev):
     runner.learn(max(args.warmup, 2), init_at_random_ep_len=True)
     _barrier_sync(world)
     t0 = time.perf_counter()
-    coll = []
     for _ in range(args.steps):
         runner.learn(1)
-        coll.append(runner.last_perf["collection_time"])
     _barrier_sync(world)
     dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
+    # the two phases of an iteration, measured apart AFTER the timed region between device syncs (inside it the host never waits for the
+    # GPU -- a recorded rollout returns to the host in ~1 ms -- so the runner's own host clocks are not phase times)
+    coll_s = None
+    if not args.vision:
+        roll = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            runner._collect(False, False)
+            torch.cuda.synchronize(); roll.append(time.perf_counter() - t1)
+            runner.alg.storage.clear()
+        coll_s = sorted(roll)[len(roll) // 2]
     # the env-side kernels of one step, timed alone with HIP events on the launch stream
     act = torch.zeros(n, 12, device=dev)
     hist = torch.zeros(n, 8, 19, device=dev)
@@ -339,16 +364,63 @@ def bench_tsc(args, world, rank, local_rank, dev):
                                   f"action noise U(0.8,1.2), frozen behaviour policy + discriminator at their initial weights), {total} envs in total = {n} envs/GPU x {world}, "
                                   f"{T} steps/iter" + ("" if args.vision else ", 5 epochs x 4 minibatches"),
                       "num_envs_total": total, "num_envs_per_gpu": n, "steps_per_iter": T, "parallelism": f"dp{world}"},
-           "collection_s": sum(coll) / len(coll), "learn_s": dt / args.steps - sum(coll) / len(coll),
-           "rollout_env_steps_per_s": n * T / (sum(coll) / len(coll)),
+           "collection_s": coll_s, "learn_s": (dt / args.steps - coll_s) if coll_s is not None else None,
+           "rollout_env_steps_per_s": (n * T * world / coll_s) if coll_s is not None else None,
+           "phase_split": "rollout alone between device syncs after the timed region (median of 5); update = iteration - rollout" if coll_s is not None else "not split (learn_vision interleaves env steps and the student's forward passes)",
            "roofline": {"kernel": "qa_env_step_kernel<false,4,1> + qa_tsc_goal_step + qa_tsc_observations" + (" + qa_tsc_depth_kernel" if args.vision else ""),
                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "kernel_ms_each": spans,
                         "algorithmic_bytes_per_launch": alg_bytes * n}}
     if args.vision:
         out["vision"] = dict(runner.last_vision)
+    chain = getattr(runner, "_bbc_chain", None)
+    if chain is not None and chain.packed is not None:      # the frozen behaviour policy of the two-level loop: one qa_mlp_forward launch per env step
+        obs_bbc = env.get_observations_bbc()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        chain.forward(obs_bbc); e0.record()
+        for _ in range(40):
+            chain.forward(obs_bbc)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 40
+        pf = 2 * (217088 + 28770) * n                     # actor 101-512-256-128-12 + history encoder (57->30 per frame, two temporal convolutions, 30->29), MACs x 2
+        out["policy_roofline"] = {"kernel": "qa_mlp_forward_kernel (behaviour policy, history-encoder variant, no critic)", "bound": "mfma", "dtype": "f32",
+                                  "achieved": pf / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": pf / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms, "algorithmic_flops_per_launch": pf}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_tsc(min(n, 1024), args.cpu_seconds, bool(args.vision))
     if rank == 0:
         print(json.dumps(out), file=_RESULT_OUT, flush=True)
+
+
+def cpu_baseline_tsc(num_envs, budget_s, vision):
+    """the task-level env step on the host cores of this box: the oracle's physics on the agility course (OpenMP over envs) + the C twins of
+    qa_tsc_goal_step / qa_tsc_reset / qa_tsc_observations (+ the depth ray-cast with --vision), driven through the same host code as the
+    GPU env (tsc LeggedRobot on the oracle backend); bounded sample, no policy, no learner"""
+    import torch
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.go2.go2_agility_config import Go2AgilityCfg
+    from quadrupedal_agility_amd.tsc.legged_gym.utils.obstacle import Obstacle
+    from tests.oracle_backend import OracleBackend
+    from tests.oracle_lib import load_oracle
+    cores = os.cpu_count() or 1
+    cfg = Go2AgilityCfg()
+    cfg.env.num_envs, cfg.seed = num_envs, 1
+    d = cfg.domain_rand
+    d.randomize_base_mass = d.randomize_base_com = d.push_robots = True
+    cfg.obstacle.randomize_start = True
+    cfg.depth.use_camera = bool(vision)
+    torch.manual_seed(1)
+    ob = Obstacle(cfg.obstacle, num_envs, seed=1)
+    env = lr.LeggedRobot(cfg, backend=OracleBackend(lr.make_qa_config(cfg, ob, seed=1)), bookkeeping_lib=(load_oracle(), "qo_"))
+    act, hist = torch.zeros(num_envs, 12), torch.zeros(num_envs, 8, 19)
+    env.step(act, hist)
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < budget_s:
+        env.step(act, hist); k += 1
+    dt = time.perf_counter() - t0
+    return {"value": num_envs * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} task-level env steps of {num_envs} envs (oracle physics on the course + goal step + reset + observations" +
+                      (" + depth ray-cast" if vision else "") + f", zero actions, no policy, no learner), OpenMP over envs, {dt:.1f} s"}
 
 
 def cpu_baseline(num_envs, budget_s):

@@ -24,5 +24,10 @@ write_corr = round(copy_kib / w["copy"], 2) if "copy" in w else 1.0
 out = {"kernel": "qa_env_step_kernel", "num_envs": n, "fetch_size_kib": f["env"], "write_size_kib": w["env"], "fetch_correction": fetch_corr,
        "write_calibration": write_corr, "calibration_copy_fetch_kib": f.get("copy"), "calibration_copy_write_kib": w.get("copy"),
        "hbm_bytes_per_launch": int((f["env"] * fetch_corr + w["env"]) * 1024), "source": "tools/final_measure.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+import bench
+out["kernel_source_hash"] = bench.env_kernel_hash(g)        # bench.py reports this figure only for the kernel sources it was measured on
 json.dump(out, open(sys.argv[4], "w"))
 print(json.dumps(out))
