@@ -129,8 +129,12 @@ class BYOL(nn.Module):
         with torch.no_grad():
             cur = list(self.online_encoder.parameters()); ma = list(self.target_encoder.parameters())
             beta = self.target_ema_updater.beta
+            # old * beta + (1 - beta) * new with the reference's three roundings (byol.py:72-75): a fused `add(alpha=...)` differs in the
+            # last bit, and the projector's zero-gradient pre-BatchNorm biases let Adam turn such a bit into a +-lr step
+            # (tests/tsc_student_protocol.py) -- the pinned two-step probe holds only with the same arithmetic
+            scaled = torch._foreach_mul(cur, 1 - beta)
             torch._foreach_mul_(ma, beta)
-            torch._foreach_add_(ma, cur, alpha=1 - beta)
+            torch._foreach_add_(ma, scaled)
 
     def forward(self, x, return_embedding=False, return_projection=True):
         assert not (self.training and x.shape[0] == 1), "BatchNorm in the projector needs more than one sample"

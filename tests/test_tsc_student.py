@@ -1,0 +1,87 @@
+"""The vision student's learner (SURVEY 8f row 3 / BASELINE configs[4]) against the reference's OWN classes: tests/golden/tsc_student.npz is
+tests/tsc_student_protocol.py run on tsc/rsl_rl's DepthOnlyFCBackbone58x87 / RecurrentDepthBackbone / BYOL / PPO.update_depth_actor
+(tools/gen_golden_tsc_student.py); here the same protocol runs on the mirror.  CPU: forwards, GRU state, BYOL loss, the four DAgger
+losses, and the weights after one update_depth_actor (one Adam step over actor + encoder, 6 BYOL minibatches with EMA target updates).
+GPU (-m gpu): the same protocol on the device against the same fixture."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests import tsc_student_protocol as SP
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "tsc_student.npz")
+
+
+def _mine():
+    import quadrupedal_agility_amd.tsc.rsl_rl.algorithms as algs
+    import quadrupedal_agility_amd.tsc.rsl_rl.modules as mods
+    from quadrupedal_agility_amd.tsc.rsl_rl.modules import depth_backbone as db
+    return SimpleNamespace(DepthOnlyFCBackbone58x87=db.DepthOnlyFCBackbone58x87, RecurrentDepthBackbone=db.RecurrentDepthBackbone,
+                           ActorCriticTSC=mods.ActorCriticTSC, ActorCriticBBC=mods.ActorCriticBBC, Estimator=mods.Estimator, PPO=algs.PPO)
+
+
+def _compare(out, g, tol_fwd, tol_upd, enc_names):
+    assert set(out) == set(g.files)
+    for k in g.files:
+        a, b = np.asarray(out[k], dtype=np.float64), np.asarray(g[k], dtype=np.float64)
+        assert a.shape == b.shape, k
+        tol = tol_upd if k.startswith(("probe", "update", "byol_loss")) else tol_fwd
+        if k == "probe_encoder_after":
+            # rows of the tensors the DAgger step alone trains: tight.  Rows the six BYOL minibatches train after it: Adam on the zero-gradient
+            # pre-BatchNorm biases turns fp32 rounding noise into +-lr steps (tests/tsc_student_protocol.py), so their sums agree to a few 1e-2
+            # of their size only; `probe_byol_after_2_steps` pins that arithmetic tightly from identical inputs.
+            byol = np.array([n.startswith(("base_backbone.", "byol_learner.")) for n in enc_names])
+            np.testing.assert_allclose(a[~byol], b[~byol], rtol=tol, atol=tol, err_msg=k)
+            np.testing.assert_allclose(a[byol][:, 3:5], b[byol][:, 3:5], rtol=5e-2, atol=5e-2, err_msg=k + " (BYOL-trained rows)")
+            continue
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol, err_msg=k)
+
+
+def _encoder_names(ns):
+    enc, _, _ = SP.build(ns)
+    return [n for n, _ in sorted(enc.named_parameters())]
+
+
+def test_student_protocol_matches_reference_golden():
+    g = np.load(GOLD)
+    _compare(SP.run(_mine()), g, 2e-5, 2e-4, _encoder_names(_mine()))
+    assert np.all(np.abs(g["encoder_step0"][:, 34:].sum(1) - 1.0) < 1e-5)           # the obstacle-class block is a softmax
+    assert not np.allclose(g["encoder_step0"], g["encoder_step1"])                  # and the second step sees the GRU state of the first
+
+
+def test_parameter_names_are_the_references():
+    """a reference `depth_encoder_state_dict` / `depth_actor_state_dict` loads into the mirror (on_policy_runner.py save/load)"""
+    ns = _mine()
+    enc, depth_actor, _ = SP.build(ns)
+    keys = set(enc.state_dict())
+    for k in ("base_backbone.image_compression.0.weight", "base_backbone.image_compression.3.weight", "base_backbone.image_compression.6.weight",
+              "base_backbone.image_compression.8.bias", "byol_learner.online_encoder.projector.0.weight", "byol_learner.online_encoder.projector.1.running_mean",
+              "byol_learner.online_predictor.3.weight", "byol_learner.target_encoder.net.image_compression.0.weight", "combination_mlp.0.weight",
+              "rnn.weight_ih_l0", "rnn.weight_hh_l0", "output_mlp.0.weight"):
+        assert k in keys, k
+    assert enc.state_dict()["output_mlp.0.weight"].shape == (40, 512) and enc.state_dict()["base_backbone.image_compression.6.weight"].shape == (128, 64 * 25 * 39)
+
+
+@pytest.mark.gpu
+def test_student_protocol_on_the_gpu_matches_reference_golden():
+    """the same protocol with every module and input on the device (MIOpen convolutions, rocBLAS GRU): forwards 1e-4, the DAgger-trained
+    tensors 2e-3 (fp32 convolution algorithms differ from the CPU's by summation order; one Adam step at lr 1e-3 amplifies that); the
+    BYOL-trained probes are held to a few 1e-2 of their size (Adam on the zero-gradient biases, see the protocol)"""
+    g = np.load(GOLD)
+    out = SP.run(_mine(), device="cuda")
+    names = _encoder_names(_mine())
+    for k in g.files:
+        a, b = np.asarray(out[k], dtype=np.float64), np.asarray(g[k], dtype=np.float64)
+        assert a.shape == b.shape, k
+        if k == "probe_byol_after_2_steps":
+            np.testing.assert_allclose(a[:, 3:5], b[:, 3:5], rtol=5e-2, atol=5e-2, err_msg=k)
+        elif k == "probe_encoder_after":
+            byol = np.array([n.startswith(("base_backbone.", "byol_learner.")) for n in names])
+            np.testing.assert_allclose(a[~byol], b[~byol], rtol=2e-3, atol=2e-3, err_msg=k)
+            np.testing.assert_allclose(a[byol][:, 3:5], b[byol][:, 3:5], rtol=5e-2, atol=5e-2, err_msg=k)
+        else:
+            tol = 2e-3 if k.startswith(("probe", "update", "byol_loss")) else 1e-4
+            np.testing.assert_allclose(a, b, rtol=tol, atol=tol, err_msg=k)
