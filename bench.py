@@ -290,7 +290,8 @@ def bench_tsc(args, world, rank, local_rank, dev):
                       -> student actor -> set_commands -> behaviour policy -> physics -> goal step -> reset -> depth ray-cast ->
                       observations), one DAgger update + 6 BYOL minibatches.
     One process per GPU; with --scaling strong (default) the job's envs are split over the ranks, which exchange ONE flat gradient
-    bucket per optimiser step (GradSync), the KL mean and the advantage moments; each rank builds the course of its own envs."""
+    bucket per optimiser step (GradSync), the KL mean and the advantage moments; each rank builds ITS envs of the job's one course (the
+    same obstacles at every world size)."""
     import torch
     from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import class_to_dict
     from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
@@ -304,7 +305,7 @@ def bench_tsc(args, world, rank, local_rank, dev):
     else:
         n, total = total, total * world
     cfg = Go2AgilityCfg()
-    cfg.env.num_envs, cfg.seed, cfg.course_seed = n, 1, 1 + 7919 * rank
+    cfg.env.num_envs, cfg.seed, cfg.course_seed = n, 1, 1          # one course for the job: rank r builds envs [r n, (r+1) n) of it
     cfg.env.env_id_offset, cfg.env.num_envs_global = rank * n, total
     d = cfg.domain_rand                                    # the reference's command line for this config: --randomize_base_mass ... --randomize_start
     d.randomize_base_mass = d.randomize_base_com = d.push_robots = True

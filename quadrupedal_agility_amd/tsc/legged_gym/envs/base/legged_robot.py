@@ -93,7 +93,8 @@ class LeggedRobot:
         seed = int(getattr(cfg, "seed", 1))
 
         # ---- course + engine
-        self.obstacle = Obstacle(cfg.obstacle, self.num_envs, seed=getattr(cfg, "course_seed", seed))
+        # one course for the whole job: a rank builds its own envs of it (the draws of the envs before them are skipped, not re-keyed)
+        self.obstacle = Obstacle(cfg.obstacle, self.num_envs, seed=getattr(cfg, "course_seed", seed), skip_envs=int(getattr(cfg.env, "env_id_offset", 0)))
         self.qcfg = make_qa_config(cfg, self.obstacle, seed=seed)
         if backend is None:
             from quadrupedal_agility_amd.sim import QaSim

@@ -71,7 +71,10 @@ def _corners(x0, y0, dx, dy):
 
 
 class Obstacle:
-    def __init__(self, cfg, num_envs, seed=None):
+    def __init__(self, cfg, num_envs, seed=None, skip_envs=0):
+        """`skip_envs`: this object builds envs [skip_envs, skip_envs + num_envs) of a larger job -- the generator's draws for the envs
+        before them are consumed (not rasterised) first, so a rank of a data-parallel run gets exactly the obstacles the one-process job
+        gives those envs, and the job is the same job at every world size (the sequential stream itself stays the reference's)"""
         self.cfg = cfg
         self.num_envs = self.num_robots = self.num_obstacles = num_envs
         self.num_cols = int(np.floor(np.sqrt(num_envs)))
@@ -118,6 +121,8 @@ class Obstacle:
         self.obstacle_types = np.zeros((num_envs, k), dtype=int)
         self.obstacle_joint_pos = np.zeros((num_envs, k)) - 1          # -1: no joint
         self.env_goals = np.zeros((num_envs, k, cfg.num_goals, 3))
+        for _ in range(int(skip_envs)):
+            self._burn_env_draws()
         self._create_obstacle(list(range(num_envs)))
 
     # ------------------------------------------------------------------ shapes (obstacle.py:235-517), as data
@@ -237,6 +242,19 @@ class Obstacle:
         mat[0:th, 0:width] = height
         mat[length - th:length, 0:width] = height
         mat[0:length, width - th:width] = height
+
+    def _burn_env_draws(self):
+        """consume one env's draws in _create_obstacle's order: the shuffle, then per obstacle x / y / yaw noise and the bar / tyre height"""
+        cfg = self.cfg
+        order = list(self.obst_types)
+        self._py.shuffle(order)
+        for kind in order:
+            rx = cfg.random_x[kind]
+            self._np.uniform(rx[0], rx[1]); self._np.uniform(cfg.random_y[0], cfg.random_y[1])
+            self._np.uniform(self.random_yaw[0], self.random_yaw[1])
+            if kind in ("bar_jump", "tire_jump"):
+                lo_hi = getattr(cfg, f"{kind}_init_range" if self.curriculum else f"{kind}_range")
+                self._np.uniform(lo_hi[0], lo_hi[1])
 
     def _create_obstacle(self, env_ids):
         cfg, hs = self.cfg, self.horizontal_scale

@@ -35,7 +35,7 @@ class TaskRegistry:
             raise ValueError(f"num_envs {total} is not divisible by {world} ranks")
         env_cfg.env.num_envs = total // world
         env_cfg.env.env_id_offset, env_cfg.env.num_envs_global = rank * (total // world), total
-        env_cfg.course_seed = int(getattr(env_cfg, "seed", 1)) + 7919 * rank          # every rank builds the course of its own envs
+        env_cfg.course_seed = int(getattr(env_cfg, "seed", 1))          # ONE course for the job; each rank builds its envs of it (Obstacle skip_envs = env_id_offset)
 
     def make_env(self, name, args=None, env_cfg=None, **kwargs):
         if args is None:

@@ -55,3 +55,32 @@ def test_fill_polygon_contract():
     p = (R @ (np.array([[-10, -10], [10, -10], [10, 10], [-10, 10]]).T)).T + 30
     rr, cc = fill_polygon(p[:, 0], p[:, 1], (64, 64))
     assert abs(len(rr) - 400) < 25
+
+
+@pytest.mark.parametrize("curriculum", [False, True])
+def test_shards_build_the_same_course_as_the_one_process_job(curriculum):
+    """SURVEY 8e for the task-level tree: rank r of a W-rank job builds envs [r N/W, (r+1) N/W) of the job's ONE course -- the reference's
+    sequential stream (tsc/legged_gym/utils/obstacle.py:75-203), with the draws of the envs before the shard consumed, not re-keyed -- so
+    an 8-env job has the same obstacles on 1, 2 and 4 ranks (r2: every rank seeded its own stream, seed + 7919 rank)"""
+    cfg = _cfg(curriculum)
+    whole = Obstacle(cfg, 8, seed=5)
+    L, Wd = whole.length_per_env_pixels, whole.width_per_env_pixels
+
+    def tile(ob, i, field):
+        sx = int(ob.border + ob.env_origins[i, 0] / ob.horizontal_scale); sy = int(ob.border + ob.env_origins[i, 1] / ob.horizontal_scale)
+        return getattr(ob, field)[sx:sx + L, sy:sy + Wd]
+
+    for world in (2, 4):
+        n = 8 // world
+        for r in range(world):
+            part = Obstacle(cfg, n, seed=5, skip_envs=r * n)
+            for i in range(n):
+                gi = r * n + i
+                assert np.array_equal(part.obstacle_types[i], whole.obstacle_types[gi])
+                assert np.array_equal(part.obstacle_yaws[i], whole.obstacle_yaws[gi]) and np.array_equal(part.obstacle_joint_pos[i], whole.obstacle_joint_pos[gi])
+                for f in ("height_field_raw", "x_edge_mask", "ceiling_raw", "bar_jump_mask", "tire_jump_mask"):
+                    assert np.array_equal(tile(part, i, f), tile(whole, gi, f)), (world, r, i, f)
+                # goals and obstacle origins relative to the env's own origin (the tiles sit elsewhere in a smaller grid)
+                np.testing.assert_allclose(part.env_goals[i] - part.env_origins[i], whole.env_goals[gi] - whole.env_origins[gi], rtol=0, atol=1e-9)
+                np.testing.assert_allclose(part.obstacle_origins[i] - part.env_origins[i], whole.obstacle_origins[gi] - whole.env_origins[gi], rtol=0, atol=1e-9)
+    assert not np.array_equal(Obstacle(cfg, 4, seed=5, skip_envs=4).obstacle_types, Obstacle(cfg, 4, seed=5).obstacle_types)      # the shards do differ
