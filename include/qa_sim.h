@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 10
+#define QA_ABI_VERSION 11
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -121,10 +121,37 @@ enum qa_tensor {
                                          overhang above the cell (tunnel roof, upper arc of the tyre), same grid and scales as
                                          HEIGHT_SAMPLES; QA_NO_CEILING where there is none.  A contact candidate collides with the nearer of
                                          floor and ceiling; the ceiling's contact normal points down (away from the obstacle)      */
+    QA_T_OBST_DESC,           /* (N,3,8) fp32, only with cfg.articulated_obstacles (else one row): the env's three articulated course
+                                         obstacles -- slot 0 see-saw, 1 bar jump, 2 tyre jump -- as
+                                         [origin x, origin y (world), cos yaw, sin yaw, half length (along the obstacle's x), half width,
+                                          pivot height h0 (see-saw), kind (0 none, QA_OBST_SEESAW, QA_OBST_BAR, QA_OBST_TYRE)]: the moving
+                                         part's footprint in the obstacle frame (tsc/legged_gym/envs/base/legged_robot.py:1411-1427)      */
+    QA_T_OBST_STATE,          /* (N,3,4) fp32: [q, q_dot, generalised contact force accumulated over the substeps of the running env
+                                         step, joint damping (see-saw: U(1,10) N m s/rad)]: the obstacle joints' dof state
+                                         (obst_dof_pos / obst_dof_vel of the reference, :792-794, :812-823): see-saw tilt [rad] about
+                                         the obstacle's y axis, bar / tyre vertical offset [m] from the height the course map draws them at */
     QA_T_COUNT
 };
 
 enum qa_dtype { QA_F32 = 0, QA_I64 = 1, QA_U8 = 2, QA_I32 = 3, QA_I16 = 4, QA_F64 = 5 };
+
+/* articulated course obstacles (QA_T_OBST_DESC / QA_T_OBST_STATE).  Inertias and the position drive are the reference's:
+ * the link0 inertials of tsc/resources/obstacles/{seesaw,bar_jump,tire_jump} (URDF), legged_robot.py:1411-1427 (stiffness 20000, damping 1000; see-saw: no
+ * stiffness, damping drawn per env), joint velocity limit 8 rad/s, see-saw travel +-asin(0.25 / 1.5) (utils/obstacle.py seesaw_dof_pos). */
+#define QA_OBST_PER_ENV 3
+#define QA_OBST_DESC 8
+#define QA_OBST_STATE 4
+#define QA_OBST_SEESAW 1
+#define QA_OBST_BAR 2
+#define QA_OBST_TYRE 3
+#define QA_SEESAW_INERTIA 10.833f
+#define QA_SEESAW_MAX_TILT 0.16744808f
+#define QA_SEESAW_MAX_VEL 8.0f
+#define QA_SEESAW_SHELL 0.10f    /* m: the plank's top stops points down to this far below it (its underside is not modelled) */
+#define QA_BAR_MASS 3.39292f
+#define QA_TYRE_MASS 13.038f
+#define QA_OBST_STIFFNESS 20000.0f
+#define QA_OBST_DAMPING 1000.0f
 
 #define QA_MOCAP_FRAME 37       /* root pos3, root quat4, joint pos12, lin vel3, ang vel3 (root frame), joint vel12 */
 #define QA_CEILING_SHELL 0.05f   /* m: an overhang's underside stops points up to this far above it (thin-shell rule) */
@@ -198,6 +225,10 @@ typedef struct qa_config {
                                        so _reward_collision and check_termination see the bodies independently; 1 = only the lowest
                                        non-foot point of the leg (the round-1 model) */
     int32_t hf_ceiling;             /* terrain_type 1: != 0 = QA_T_CEILING_SAMPLES holds overhangs to collide with */
+    int32_t articulated_obstacles;  /* terrain_type 1: != 0 = the see-saw is a 1-DoF revolute plank with joint damping and the bar / tyre are
+                                       1-DoF prismatic bodies under the reference's position drive, coupled to the contact rows
+                                       (QA_T_OBST_DESC / QA_T_OBST_STATE) -- instead of the static shapes the height map draws for them */
+    int32_t reserved0;
 } qa_config;
 
 typedef struct qa_sim qa_sim;

@@ -102,6 +102,9 @@ static void make_layout(const qa_config *cfg, Layout *L) {
     set_t(L, QA_T_STEP_TICKET, QA_I32, 1, 4, 1, 1);
     { int ce = cfg->terrain_type == 1 && cfg->hf_ceiling;
       set_t(L, QA_T_CEILING_SAMPLES, QA_I16, 2, ce ? cfg->hf_rows : 1, ce ? cfg->hf_cols : 1, 1); }
+    { int ao = cfg->terrain_type == 1 && cfg->articulated_obstacles;
+      set_t(L, QA_T_OBST_DESC, QA_F32, 3, ao ? N : 1, QA_OBST_PER_ENV, QA_OBST_DESC);
+      set_t(L, QA_T_OBST_STATE, QA_F32, 3, ao ? N : 1, QA_OBST_PER_ENV, QA_OBST_STATE); }
     int64_t off = 0;
     for (int t = 0; t < QA_T_COUNT; ++t) {
         off = (off + 255) & ~(int64_t)255;
@@ -364,7 +367,7 @@ static void ground_query(const qo_sim *s, double x, double y, double *h, double 
  * floor triangle under it, or -- with cfg.hf_ceiling -- to the plane of the CEILING triangle above it if that is nearer (tunnel roof,
  * upper arc of the tyre; QA_T_CEILING_SAMPLES, same triangulation, a triangle with a QA_NO_CEILING corner does not exist).  The
  * ceiling's normal points down, away from the obstacle. */
-static double contact_query(const qo_sim *s, const double pw[3], double rad, double n[3]) {
+static double terrain_contact(const qo_sim *s, const double pw[3], double rad, double n[3]) {
     const qa_config *c = &s->cfg;
     double gh; ground_query(s, pw[0], pw[1], &gh, n);
     double gap = (pw[2] - gh) * n[2] - rad;
@@ -389,6 +392,79 @@ static double contact_query(const qo_sim *s, const double pw[3], double rad, dou
     if (!(ch > gh) || (ch - pw[2]) * inv < -QA_CEILING_SHELL) return gap;
     if (cgap < gap) { gap = cgap; n[0] = gx * inv; n[1] = gy * inv; n[2] = -inv; }
     return gap;
+}
+/* Contact of a sphere with the terrain AND the env's articulated course obstacles (cfg.articulated_obstacles; DESIGN.md 3.3,
+ * tsc/legged_gym/envs/base/legged_robot.py:792-794, 812-823, 1411-1427): inside the see-saw's footprint the height map's static tent is
+ * replaced by {flat ground, the plank's top plane through the pivot at tilt q}; inside the bar's / tyre's footprint the map (and the
+ * tyre's ceiling arc) is shifted vertically by the joint offset q.  *vs = velocity of the contacted surface along n (the normal row's
+ * bias is gap/dt - vs), *ca = d vs / d q_dot (the contact's generalised force on the joint is -f_n ca), *ob = the obstacle slot or -1. */
+static double contact_query(const qo_sim *s, int e, const double pw[3], double rad, double n[3], double *vs, double *ca, int *ob) {
+    const qa_config *c = &s->cfg;
+    *vs = 0; *ca = 0; *ob = -1;
+    if (c->terrain_type != 1 || !c->articulated_obstacles) return terrain_contact(s, pw, rad, n);
+    const float *desc = TP(s, QA_T_OBST_DESC, float) + (int64_t)e * QA_OBST_PER_ENV * QA_OBST_DESC;
+    const float *stt = TP(s, QA_T_OBST_STATE, float) + (int64_t)e * QA_OBST_PER_ENV * QA_OBST_STATE;
+    int mode = 0, slot = -1; double xl = 0, cpsi = 1, spsi = 0, oq = 0, oqd = 0, oh0 = 0;
+    for (int k = 0; k < QA_OBST_PER_ENV; ++k) {
+        const float *d = desc + QA_OBST_DESC * k;
+        if (d[7] == 0.0f) continue;
+        double dx = pw[0] - d[0], dy = pw[1] - d[1];
+        double lx = d[2] * dx + d[3] * dy, ly = d[2] * dy - d[3] * dx;
+        if (fabs(lx) <= d[4] && fabs(ly) <= d[5]) {
+            mode = d[7] == (float)QA_OBST_SEESAW ? 1 : 2; slot = k; xl = lx; cpsi = d[2]; spsi = d[3]; oh0 = d[6];
+            oq = stt[QA_OBST_STATE * k]; oqd = stt[QA_OBST_STATE * k + 1];
+        }
+    }
+    if (mode == 2) {
+        double pq[3] = {pw[0], pw[1], pw[2] - oq};          /* a surface raised by q == the point lowered by q */
+        double gap = terrain_contact(s, pq, rad, n);
+        *ca = n[2]; *vs = n[2] * oqd; *ob = slot;
+        return gap;
+    }
+    if (mode == 1) {
+        double sq = sin(oq), cq = cos(oq), zl = pw[2] - oh0, pgap = xl * sq + zl * cq - rad;
+        double gap = pw[2] - rad;                            /* the ground under the see-saw (the map's tent is not collided with) */
+        n[0] = 0; n[1] = 0; n[2] = 1;
+        if (pgap >= -(double)QA_SEESAW_SHELL && pgap < gap) {
+            gap = pgap; n[0] = cpsi * sq; n[1] = spsi * sq; n[2] = cq;
+            *ca = sq * zl - cq * xl; *vs = *ca * oqd; *ob = slot;
+        }
+        return gap;
+    }
+    return terrain_contact(s, pw, rad, n);
+}
+/* joint dynamics of an articulated obstacle over one env step (h = decimation x dt) under the mean generalised contact force F of its
+ * substeps; semi-implicit in the damper and the position drive (csrc/qa_physics.h obstacle_joint_step) */
+static void obstacle_joint_step(double kind, double damping, double F, double h, double *q, double *qd) {
+    if (kind == QA_OBST_SEESAW) {
+        *qd = (*qd + h * F / QA_SEESAW_INERTIA) / (1.0 + h * damping / QA_SEESAW_INERTIA);
+        if (*qd > QA_SEESAW_MAX_VEL) *qd = QA_SEESAW_MAX_VEL;
+        if (*qd < -QA_SEESAW_MAX_VEL) *qd = -QA_SEESAW_MAX_VEL;
+        *q += h * *qd;
+        if (*q > QA_SEESAW_MAX_TILT) { *q = QA_SEESAW_MAX_TILT; *qd = 0; }
+        if (*q < -QA_SEESAW_MAX_TILT) { *q = -QA_SEESAW_MAX_TILT; *qd = 0; }
+    } else if (kind != 0) {
+        double m = kind == QA_OBST_BAR ? QA_BAR_MASS : QA_TYRE_MASS;
+        *qd = (*qd + h * (F - QA_OBST_STIFFNESS * *q) / m) / (1.0 + h * QA_OBST_DAMPING / m + h * h * QA_OBST_STIFFNESS / m);
+        *q += h * *qd;
+    }
+}
+static void obstacles_begin_step(qo_sim *s, int e) {
+    if (s->cfg.terrain_type != 1 || !s->cfg.articulated_obstacles) return;
+    float *stt = TP(s, QA_T_OBST_STATE, float) + (int64_t)e * QA_OBST_PER_ENV * QA_OBST_STATE;
+    for (int k = 0; k < QA_OBST_PER_ENV; ++k) stt[QA_OBST_STATE * k + 2] = 0.0f;
+}
+static void obstacles_end_step(qo_sim *s, int e) {
+    const qa_config *c = &s->cfg;
+    if (c->terrain_type != 1 || !c->articulated_obstacles) return;
+    const float *desc = TP(s, QA_T_OBST_DESC, float) + (int64_t)e * QA_OBST_PER_ENV * QA_OBST_DESC;
+    float *stt = TP(s, QA_T_OBST_STATE, float) + (int64_t)e * QA_OBST_PER_ENV * QA_OBST_STATE;
+    for (int k = 0; k < QA_OBST_PER_ENV; ++k) {
+        double q = stt[QA_OBST_STATE * k], qd = stt[QA_OBST_STATE * k + 1];
+        obstacle_joint_step(desc[QA_OBST_DESC * k + 7], stt[QA_OBST_STATE * k + 3], (double)stt[QA_OBST_STATE * k + 2] / c->decimation,
+                            (double)c->sim_dt * c->decimation, &q, &qd);
+        stt[QA_OBST_STATE * k] = (float)q; stt[QA_OBST_STATE * k + 1] = (float)qd;
+    }
 }
 /* tangent basis of a contact: t1 = x-axis projected onto the tangent plane, t2 = n x t1 */
 static void tangent_basis(const double n[3], double t1[3], double t2[3]) {
@@ -420,7 +496,9 @@ static float scan_center_height(const qo_sim *s, const float *root) {
     return (float)m * c->hf_vscale;
 }
 
-static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
+static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate);
+static void phys_substep(qo_sim *s, int e, const float tau_in[12]) { phys_substep_acc(s, e, tau_in, 0); }
+static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate) {
     const qa_config *cfg = &s->cfg;
     float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e;
     float *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
@@ -464,11 +542,14 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
     int foot_row[4], extra_row[4][3], extra_body[4][3];
     double mu = 0.5 * ((double)TP(s, QA_T_FRICTION, float)[e] + cfg->ground_friction);
     double cdirs[16][3][3];     /* world-frame (n, t1, t2) of each contact slot (4 per leg), for the force report */
+    double slot_ca[16]; int slot_ob[16];   /* articulated obstacle under each contact slot: joint lever, obstacle slot (-1 none) */
+    for (int i = 0; i < 16; ++i) { slot_ca[i] = 0; slot_ob[i] = -1; }
     int row_leg_first[5] = {0, 0, 0, 0, 0};
     for (int l = 0; l < 4; ++l) {
         row_leg_first[l] = nrows;
         foot_row[l] = -1;
         double best_gap[3] = {1e30, 1e30, 1e30}; v3 best_p[3], best_n[3]; int best_depth[3] = {-1, -1, -1}, best_body[3] = {-1, -1, -1};
+        double best_vs[3] = {0, 0, 0}, best_ca[3] = {0, 0, 0}, foot_vs = 0, foot_ca = 0; int best_ob[3] = {-1, -1, -1}, foot_ob = -1;
         for (int sl = 0; sl < 3; ++sl) { extra_row[l][sl] = -1; extra_body[l][sl] = -1; for (int i = 0; i < 3; ++i) { best_p[sl][i] = 0; best_n[sl][i] = i == 2; } }
         double foot_gap = 0; v3 foot_p = {0, 0, 0}, foot_n = {0, 0, 1};
         for (int c = 0; c < QA_NUM_LEG_PTS; ++c) {
@@ -476,15 +557,19 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             v3 pl = {QA_LEG_PT_POS[l][c][0], QA_LEG_PT_POS[l][c][1], QA_LEG_PT_POS[l][c][2]}, p, pwld;
             mv(K.Rl[l][k], pl, p); for (int i = 0; i < 3; ++i) p[i] += K.o[l][k][i];
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
-            v3 gn; double gap = contact_query(s, pwld, QA_LEG_PT_RAD[l][c], gn);      /* distance to the terrain triangle's plane (floor, or ceiling) */
-            if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); memcpy(foot_n, gn, sizeof(v3)); }
-            else if (gap < best_gap[k]) { best_gap[k] = gap; memcpy(best_p[k], p, sizeof(v3)); memcpy(best_n[k], gn, sizeof(v3)); best_depth[k] = k; best_body[k] = QA_LEG_PT_BODY[l][c]; }
+            v3 gn; double cvs, cca; int cob;
+            double gap = contact_query(s, e, pwld, QA_LEG_PT_RAD[l][c], gn, &cvs, &cca, &cob);      /* distance to the terrain triangle's plane (floor, or ceiling), or to an articulated obstacle */
+            if (c == 0) { foot_gap = gap; memcpy(foot_p, p, sizeof(v3)); memcpy(foot_n, gn, sizeof(v3)); foot_vs = cvs; foot_ca = cca; foot_ob = cob; }
+            else if (gap < best_gap[k]) { best_gap[k] = gap; memcpy(best_p[k], p, sizeof(v3)); memcpy(best_n[k], gn, sizeof(v3)); best_depth[k] = k; best_body[k] = QA_LEG_PT_BODY[l][c];
+                                          best_vs[k] = cvs; best_ca[k] = cca; best_ob[k] = cob; }
         }
         for (int c = l; c < QA_NUM_BASE_PTS; c += 4) { /* base points are dealt round-robin to the four legs; they share slot 0 with the hip link */
             v3 p = {QA_BASE_PT_POS[c][0], QA_BASE_PT_POS[c][1], QA_BASE_PT_POS[c][2]}, pwld;
             mv(R, p, pwld); for (int i = 0; i < 3; ++i) pwld[i] += pos[i];
-            v3 gn; double gap = contact_query(s, pwld, QA_BASE_PT_RAD[c], gn);
-            if (gap < best_gap[0]) { best_gap[0] = gap; memcpy(best_p[0], p, sizeof(v3)); memcpy(best_n[0], gn, sizeof(v3)); best_depth[0] = -1; best_body[0] = QA_BASE_PT_BODY[c]; }
+            v3 gn; double cvs, cca; int cob;
+            double gap = contact_query(s, e, pwld, QA_BASE_PT_RAD[c], gn, &cvs, &cca, &cob);
+            if (gap < best_gap[0]) { best_gap[0] = gap; memcpy(best_p[0], p, sizeof(v3)); memcpy(best_n[0], gn, sizeof(v3)); best_depth[0] = -1; best_body[0] = QA_BASE_PT_BODY[c];
+                                     best_vs[0] = cvs; best_ca[0] = cca; best_ob[0] = cob; }
         }
         if (cfg->contact_slots == 1) {      /* only the lowest non-foot point of the leg makes contact (the round-1 model) */
             int win = 0;
@@ -502,6 +587,8 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
             int depth = slot == 0 ? 2 : best_depth[slot - 1];
             if (!(gap < cfg->contact_offset)) continue;
             if (slot == 0) foot_row[l] = nrows; else { extra_row[l][slot - 1] = nrows; extra_body[l][slot - 1] = best_body[slot - 1]; }
+            const double surf_vs = slot == 0 ? foot_vs : best_vs[slot - 1];
+            slot_ca[4 * l + slot] = slot == 0 ? foot_ca : best_ca[slot - 1]; slot_ob[4 * l + slot] = slot == 0 ? foot_ob : best_ob[slot - 1];
             double (*cw)[3] = cdirs[4 * l + slot];
             memcpy(cw[0], slot == 0 ? foot_n : best_n[slot - 1], sizeof(v3));
             tangent_basis(cw[0], cw[1], cw[2]);
@@ -520,7 +607,7 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
                 r->kind = d == 0 ? 0 : 1; r->parent = nrows - d;
                 if (d == 0) {
                     double mdv = cfg->max_depenetration_velocity;
-                    r->bias = gap >= 0 ? gap / dt : (gap / dt > -mdv ? gap / dt : -mdv);
+                    r->bias = (gap >= 0 ? gap / dt : (gap / dt > -mdv ? gap / dt : -mdv)) - surf_vs;      /* a surface that moves along the normal */
                 }
                 nrows++;
             }
@@ -623,6 +710,17 @@ static void phys_substep(qo_sim *s, int e, const float tau_in[12]) {
         double (*cw)[3] = cdirs[4 * l + slot];
         for (int i = 0; i < 3; ++i)
             cf[3 * b + i] += (float)((rows[r0].lam * cw[0][i] + rows[r0 + 1].lam * cw[1][i] + rows[r0 + 2].lam * cw[2][i]) / dt);
+    }
+    /* ---- what the contacts do to the articulated obstacles' joints: generalised force -f_n ca, accumulated over the env step's substeps */
+    if (accumulate && cfg->terrain_type == 1 && cfg->articulated_obstacles) {
+        float *stt = TP(s, QA_T_OBST_STATE, float) + (int64_t)e * QA_OBST_PER_ENV * QA_OBST_STATE;
+        double ga[QA_OBST_PER_ENV] = {0, 0, 0};
+        for (int l = 0; l < 4; ++l) for (int slot = 0; slot < 4; ++slot) {
+            int r0 = slot == 0 ? foot_row[l] : extra_row[l][slot - 1];
+            if (r0 < 0 || slot_ob[4 * l + slot] < 0) continue;
+            ga[slot_ob[4 * l + slot]] += -rows[r0].lam / dt * slot_ca[4 * l + slot];
+        }
+        for (int k = 0; k < QA_OBST_PER_ENV; ++k) stt[QA_OBST_STATE * k + 2] += (float)ga[k];
     }
     /* ---- body-origin positions with the NEW state (what refresh_rigid_body_state_tensor returns) */
     {
@@ -1090,7 +1188,9 @@ int qo_env_physics_step(qo_sim *s, const float *actions, int32_t delay_steps, vo
         const float *src = ah + 12 * (QA_ACTION_BUF_LEN - 1 - delay_steps);
         float clipa = c->clip_actions / c->action_scale;
         for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
-        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep(s, e, tau); }
+        obstacles_begin_step(s, e);
+        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep_acc(s, e, tau, 1); }
+        obstacles_end_step(s, e);
     }
     return QA_OK;
 }
@@ -1155,10 +1255,12 @@ int qo_env_step(qo_sim *s, const float *actions, int32_t delay_steps, int64_t st
         float clipa = c->clip_actions / c->action_scale;
         for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
         float *tau = TP(s, QA_T_TORQUES, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e;
+        obstacles_begin_step(s, e);
         for (int d = 0; d < c->decimation; ++d) {     /* :101-106 */
             compute_torques(s, e, act, tau, torg);
-            phys_substep(s, e, tau);
+            phys_substep_acc(s, e, tau, 1);
         }
+        obstacles_end_step(s, e);
         float tmp[QA_NUM_OBS_DISC];
         post_physics(s, e, step, tmp);
     }
@@ -1862,7 +1964,9 @@ int qo_debug_pre_physics(qo_sim *s, const float *actions, int32_t delay_steps) {
         float clipa = c->clip_actions / c->action_scale;
         for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
         float *tau = TP(s, QA_T_TORQUES, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e;
-        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep(s, e, tau); }
+        obstacles_begin_step(s, e);
+        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep_acc(s, e, tau, 1); }
+        obstacles_end_step(s, e);
     }
     return QA_OK;
 }

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 10
+QA_ABI_VERSION = 11
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -17,6 +17,7 @@ ACTION_BUF_LEN = 8
 NUM_REWARDS = 14
 MOCAP_FRAME = 37
 MAX_MOCAP_CLIPS, MOCAP_CLIP = 64, 8
+OBST_SEESAW, OBST_BAR, OBST_TYRE = 1, 2, 3          # QA_OBST_* kinds of include/qa_sim.h
 
 REWARD_NAMES = [
     "action_rate", "collision", "delta_torques", "dof_acc", "dof_error", "dof_pos_limits",
@@ -32,7 +33,7 @@ TENSORS = [
     "EPISODE_STATS", "LAST_CONTACTS", "CONTACT_FILT", "FEET_FORCE", "BASE_LIN_VEL",
     "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION",
     "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS", "MOCAP_FRAMES", "HEIGHT_SAMPLES", "SCAN_HEIGHT", "FOOT_IMPULSE",
-    "MOCAP_CLIPS", "RIGID_BODY_STATE", "STEP_TICKET", "CEILING_SAMPLES",
+    "MOCAP_CLIPS", "RIGID_BODY_STATE", "STEP_TICKET", "CEILING_SAMPLES", "OBST_DESC", "OBST_STATE",
 ]
 T = {name: i for i, name in enumerate(TENSORS)}
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_I32, DTYPE_I16, DTYPE_F64 = 0, 1, 2, 3, 4, 5
@@ -77,7 +78,7 @@ class QaConfig(C.Structure):
         ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("hf_hscale", C.c_float), ("hf_vscale", C.c_float),
         ("hf_border", C.c_float), ("reset_xy_jitter", C.c_float),
         ("num_mocap_frames", C.c_int32), ("export_body_state", C.c_int32), ("env_id_offset", C.c_int32), ("num_envs_global", C.c_int32),
-        ("contact_slots", C.c_int32), ("hf_ceiling", C.c_int32),
+        ("contact_slots", C.c_int32), ("hf_ceiling", C.c_int32), ("articulated_obstacles", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

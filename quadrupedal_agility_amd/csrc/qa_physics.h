@@ -109,6 +109,10 @@ struct TerrainView {
     int ix0, iy0;            // global cell of patch[0][0]
     int rows, cols;
     float border, hscale, inv_hscale, vscale;
+    // articulated course obstacles of this env (cfg.articulated_obstacles): LDS record of QA_OBST_PER_ENV x 12 floats
+    // [QA_T_OBST_DESC row (8) | q, q_dot, -, damping] and, when the caller integrates the obstacle joints, 3 force accumulators
+    const float *ob;         // nullptr = none
+    float *ob_acc;           // nullptr = contact forces are not accumulated (single substeps: qa_simulate)
 };
 // window origin for a base at world (x, y)
 QA_DEV void patch_origin(TerrainView &T, float x, float y) {
@@ -154,9 +158,29 @@ QA_DEV void ground_query(const TerrainView &T, float x, float y, float &h, V3 &n
 // where QA_T_CEILING_SAMPLES has one and it is nearer, of the ceiling triangle above it (tunnel roof, upper arc of the tyre).  A
 // triangle with a QA_NO_CEILING corner does not exist; the ceiling's normal points down.  Ceiling samples are read from HBM (an
 // env is under an overhang for a few steps of an episode; the floor window in LDS is what every query needs).
-QA_DEV float contact_query(const TerrainView &T, float x, float y, float zw, float r, V3 &n) {
+// `vs`: velocity of the contacted surface along n (articulated obstacles move: the normal row's bias is gap/dt - vs), `ca`: d vs / d q_dot of
+// the obstacle joint (the contact's generalised force on that joint is -f_n ca), `ob`: the obstacle slot, -1 = fixed terrain.
+// Inside the see-saw's footprint the height map's static tent is replaced by {flat ground, the plank's top plane through the pivot at
+// tilt q}; inside the bar's / tyre's footprint the map (and the tyre's ceiling arc) is shifted vertically by the joint offset q.
+QA_DEV float contact_query(const TerrainView &T, float x, float y, float zw, float r, V3 &n, float &vs, float &ca, int &ob) {
+    vs = 0.f; ca = 0.f; ob = -1;
+    int mode = 0, slot = -1;                      // 1 = see-saw footprint, 2 = shifted map
+    float xl = 0.f, cpsi = 1.f, spsi = 0.f, oq = 0.f, oqd = 0.f, oh0 = 0.f;
+    if (T.ob) {
+#pragma unroll
+        for (int k = 0; k < QA_OBST_PER_ENV; ++k) {
+            const float *d = T.ob + 12 * k;
+            const float kind = d[7];
+            const float dx = x - d[0], dy = y - d[1];
+            const float lx = d[2] * dx + d[3] * dy, ly = d[2] * dy - d[3] * dx;
+            if (kind != 0.f && fabsf(lx) <= d[4] && fabsf(ly) <= d[5]) {
+                mode = kind == (float)QA_OBST_SEESAW ? 1 : 2; slot = k; xl = lx; cpsi = d[2]; spsi = d[3]; oh0 = d[6]; oq = d[8]; oqd = d[9];
+            }
+        }
+    }
+    const float zq = mode == 2 ? zw - oq : zw;      // a surface raised by q == the point lowered by q
     float gh; ground_query(T, x, y, gh, n);
-    float gap = (zw - gh) * n.z - r;
+    float gap = (zq - gh) * n.z - r;
     if (T.ceil) {
         float fx = (x + T.border) * T.inv_hscale, fy = (y + T.border) * T.inv_hscale;
         int ix = min(max((int)floorf(fx), 0), T.rows - 2), iy = min(max((int)floorf(fy), 0), T.cols - 2);
@@ -169,11 +193,26 @@ QA_DEV float contact_query(const TerrainView &T, float x, float y, float zw, flo
         float gx = lower ? h10 - h00 : h11 - h01, gy = lower ? h11 - h10 : h01 - h00;
         const float ch = h00 + u * gx + v * gy;
         gx *= T.inv_hscale; gy *= T.inv_hscale;
-        const float inv = rsqrtf(gx * gx + gy * gy + 1.0f), cgap = (ch - zw) * inv - r;
+        const float inv = rsqrtf(gx * gx + gy * gy + 1.0f), cgap = (ch - zq) * inv - r;
         // thin shell: acts on points below it or at most QA_CEILING_SHELL above it, and only where it lies above the floor map
-        if (exists && ch > gh && (ch - zw) * inv >= -QA_CEILING_SHELL && cgap < gap) { gap = cgap; n = v3(gx * inv, gy * inv, -inv); }
+        if (exists && ch > gh && (ch - zq) * inv >= -QA_CEILING_SHELL && cgap < gap) { gap = cgap; n = v3(gx * inv, gy * inv, -inv); }
+    }
+    if (mode == 2) { ca = n.z; vs = n.z * oqd; ob = slot; }
+    else if (mode == 1) {
+        float sq, cq; __sincosf(oq, &sq, &cq);
+        const float zl = zw - oh0, pgap = xl * sq + zl * cq - r;         // distance to the plank's top plane, normal (sin q, 0, cos q) in the obstacle frame
+        gap = zw - r; n = v3(0.f, 0.f, 1.f);                             // the ground under the see-saw (the map's tent is not collided with)
+        if (pgap >= -QA_SEESAW_SHELL && pgap < gap) {
+            gap = pgap; n = v3(cpsi * sq, spsi * sq, cq);
+            ca = sq * zl - cq * xl; vs = ca * oqd;                        // n . (q_dot y' x r), r from the pivot
+            ob = slot;
+        }
     }
     return gap;
+}
+QA_DEV float contact_query(const TerrainView &T, float x, float y, float zw, float r, V3 &n) {
+    float vs, ca; int ob;
+    return contact_query(T, x, y, zw, r, n, vs, ca, ob);
 }
 // legged_robot.py:1209-1228 for the one scan point the BBC env consumes: (0, 0.1) in the yaw frame, truncated to a
 // cell, min of three samples.  Integer samples are read from HBM (one env-step-level lookup per quad).
@@ -455,6 +494,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);   // plane: world z, x, y
     V3 foot_n = v3(0, 0, 1);                                 // world-frame contact normal (height field)
     float foot_gap; V3 foot_p;
+    float foot_vs = 0.f, foot_ca = 0.f; int foot_ob = -1;    // articulated obstacle under the foot (surface velocity, joint lever, slot)
     float bgap[QA_EXTRA_GROUPS] = {1e30f, 1e30f, 1e30f};
     int bcode[QA_EXTRA_GROUPS] = {0, 0, 0};                  // 1..QA_LEG_PTS-1: leg point, 64 + c: base point
     auto leg_point = [&](int c, int k) {                     // base-frame position of leg point c (on link k)
@@ -502,8 +542,9 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             const float *pt = tbl + T_POINTS + 4 * c;
             V3 p = mul(Rl[k], v3(pt[0], pt[1], pt[2])) + o[k];
             float zw = dot(nB, p) + st.pos.z;
-            V3 gn; float gap = contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, zw, pt[3], gn);      // distance to the terrain triangle's plane
-            if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; }
+            V3 gn; float cvs, cca; int cob;
+            float gap = contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, zw, pt[3], gn, cvs, cca, cob);      // distance to the terrain triangle's plane
+            if (c == 0) { foot_gap = gap; foot_p = p; foot_n = gn; foot_vs = cvs; foot_ca = cca; foot_ob = cob; }
             else if (gap < bgap[k]) { bgap[k] = gap; bcode[k] = c; }
         }
 #pragma unroll
@@ -560,12 +601,14 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
     if (!PLANE) { tangent_basis(foot_n, ft1_w, ft2_w); fn_b = mulT(R, foot_n); ft1_b = mulT(R, ft1_w); ft2_b = mulT(R, ft2_w); }
     contact_rows(rf, foot_p, 3, foot_gap, o, ax, fn_b, ft1_b, ft2_b, G, Linv, Binv, P);
+    rf[0].bias -= foot_vs;                                  // a surface that moves along the normal (articulated obstacle)
     float re_lam[QA_EXTRA_SLOTS][3];
+    float ex_ca[QA_EXTRA_SLOTS]; int ex_ob[QA_EXTRA_SLOTS];
     V3 ex_n[QA_EXTRA_SLOTS];                                // world-frame normals of the extra contacts (height field)
     int ex_body[QA_EXTRA_SLOTS];
 #pragma unroll
     for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
-        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1;
+        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1; ex_ca[sl] = 0.f; ex_ob[sl] = -1;
         if (any_extra[sl]) {
             V3 p; int depth;
             const int code = scode[sl], link = max(slink[sl], 0);
@@ -573,11 +616,13 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             else { p = leg_point(code > 0 ? code : 1, link); depth = link + 1; ex_body[sl] = 3 + 4 * leg + link; }
             Row re[3];
             V3 en_b = nB, et1_b = t1B, et2_b = t2B;
+            float ex_vs = 0.f;
             if (!PLANE) {
-                (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
+                (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl], ex_vs, ex_ca[sl], ex_ob[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
                 V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
             }
             contact_rows(re, p, depth, sgap[sl], o, ax, en_b, et1_b, et2_b, G, Linv, Binv, P);
+            re[0].bias -= ex_vs;
 #pragma unroll
             for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
         }
@@ -735,6 +780,38 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         if (PLANE) co.extra_f[sl] = on ? v3(re_lam[sl][1] * idt, re_lam[sl][2] * idt, re_lam[sl][0] * idt) : v3(0, 0, 0);
         else { V3 a, b; tangent_basis(ex_n[sl], a, b); co.extra_f[sl] = on ? idt * ((re_lam[sl][0] * ex_n[sl]) + (re_lam[sl][1] * a) + (re_lam[sl][2] * b)) : v3(0, 0, 0); }
         co.extra_body[sl] = on ? ex_body[sl] : -1;
+    }
+    // ---- what the contacts do to the articulated obstacles' joints: generalised force -f_n ca, summed over the quad, kept per env in LDS
+    if (!PLANE && T.ob_acc) {
+        float ga[QA_OBST_PER_ENV];
+#pragma unroll
+        for (int k = 0; k < QA_OBST_PER_ENV; ++k) {
+            float g = (foot_on && foot_ob == k) ? -rf[0].lam * idt * foot_ca : 0.f;
+#pragma unroll
+            for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) g += (any_extra[sl] && extra_on[sl] && ex_ob[sl] == k) ? -re_lam[sl][0] * idt * ex_ca[sl] : 0.f;
+            ga[k] = quad_sum(g);
+        }
+        if (leg == 0) {
+#pragma unroll
+            for (int k = 0; k < QA_OBST_PER_ENV; ++k) T.ob_acc[k] += ga[k];
+        }
+    }
+}
+
+// joint dynamics of an articulated obstacle over one env step (h = decimation x dt) under the mean generalised contact force F of its
+// substeps -- semi-implicit in the damper and the position drive, so the stiff bar / tyre drive (omega = 77 / 39 rad/s) is unconditionally
+// stable at h = 20 ms.  See-saw: I q'' = F - c q', |q'| <= 8 rad/s, |q| <= asin(0.25 / 1.5) (inelastic stops).  Bar / tyre: m q'' = F - k q - c q'.
+QA_DEV void obstacle_joint_step(float kind, float damping, float F, float h, float &q, float &qd) {
+    if (kind == (float)QA_OBST_SEESAW) {
+        qd = (qd + h * F / QA_SEESAW_INERTIA) / (1.0f + h * damping / QA_SEESAW_INERTIA);
+        qd = clampf(qd, -QA_SEESAW_MAX_VEL, QA_SEESAW_MAX_VEL);
+        q = fmaf(h, qd, q);
+        if (q > QA_SEESAW_MAX_TILT) { q = QA_SEESAW_MAX_TILT; qd = 0.f; }
+        if (q < -QA_SEESAW_MAX_TILT) { q = -QA_SEESAW_MAX_TILT; qd = 0.f; }
+    } else if (kind != 0.f) {
+        const float m = kind == (float)QA_OBST_BAR ? QA_BAR_MASS : QA_TYRE_MASS;
+        qd = (qd + h * (F - QA_OBST_STIFFNESS * q) / m) / (1.0f + h * QA_OBST_DAMPING / m + h * h * QA_OBST_STIFFNESS / m);
+        q = fmaf(h, qd, q);
     }
 }
 

@@ -66,6 +66,8 @@ static void make_layout(const qa_config *cfg, Layout *L) {
         {QA_T_RIGID_BODY_STATE, QA_F32, 3, cfg->export_body_state ? N : 1, QA_NUM_BODIES_ABI, 13},
         {QA_T_STEP_TICKET, QA_I32, 1, 4, 1, 1},
         {QA_T_CEILING_SAMPLES, QA_I16, 2, (cfg->terrain_type == 1 && cfg->hf_ceiling) ? HR : 1, (cfg->terrain_type == 1 && cfg->hf_ceiling) ? HC : 1, 1},
+        {QA_T_OBST_DESC, QA_F32, 3, (cfg->terrain_type == 1 && cfg->articulated_obstacles) ? N : 1, QA_OBST_PER_ENV, QA_OBST_DESC},
+        {QA_T_OBST_STATE, QA_F32, 3, (cfg->terrain_type == 1 && cfg->articulated_obstacles) ? N : 1, QA_OBST_PER_ENV, QA_OBST_STATE},
     };
     static_assert(sizeof(specs) / sizeof(specs[0]) == QA_T_COUNT, "every tensor needs a spec");
     memset(L, 0, sizeof(*L));
@@ -89,6 +91,7 @@ struct Ptrs {
     double *mocap_clips;
     int32_t *ticket;
     int16_t *height_samples, *ceil_samples;
+    float *obst_desc, *obst_state;
     int64_t *reset, *episode_length;
     uint8_t *time_out, *last_contacts, *contact_filt;
 };
@@ -241,7 +244,22 @@ __device__ __forceinline__ TerrainView terrain_view(const qa_config &c, const Pt
     TerrainView T;
     T.patch = patch; T.samples = p.height_samples; T.ceil = c.hf_ceiling ? p.ceil_samples : nullptr; T.ix0 = 0; T.iy0 = 0; T.rows = c.hf_rows; T.cols = c.hf_cols;
     T.border = c.hf_border; T.hscale = c.hf_hscale; T.inv_hscale = 1.0f / c.hf_hscale; T.vscale = c.hf_vscale;
+    T.ob = nullptr; T.ob_acc = nullptr;
     return T;
+}
+
+// articulated obstacles of an env -> LDS: lane k < 3 of the quad loads slot k (8 descriptor floats + q, q_dot, -, damping) and clears the
+// slot's force accumulator; QA_OB_LDS floats per env
+#define QA_OB_LDS (12 * QA_OBST_PER_ENV + 4)
+QA_DEV void stage_obstacles(const Ptrs &p, int env, int leg, float *rec) {
+    if (leg < QA_OBST_PER_ENV) {
+        const float *d = p.obst_desc + ((int64_t)env * QA_OBST_PER_ENV + leg) * QA_OBST_DESC;
+        const float *st = p.obst_state + ((int64_t)env * QA_OBST_PER_ENV + leg) * QA_OBST_STATE;
+#pragma unroll
+        for (int i = 0; i < QA_OBST_DESC; ++i) rec[12 * leg + i] = d[i];
+        rec[12 * leg + 8] = st[0]; rec[12 * leg + 9] = st[1]; rec[12 * leg + 10] = 0.f; rec[12 * leg + 11] = st[3];
+        rec[12 * QA_OBST_PER_ENV + leg] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------ the fused env step
@@ -659,7 +677,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     // holds -- 160 KB per CU -- and with it the throughput once there are more workgroups than CUs):
     //   physics phase:      per-lane private slots | terrain windows (height field only)
     //   observation phase:  per-env staging | OBS_GROUP assembled observation rows
-    constexpr int U_PHYS = QA_PRIV_FLOATS * QA_PRIV_STRIDE + (PLANE ? 0 : EPB * QA_PATCH * QA_PATCH);
+    constexpr int U_PHYS = QA_PRIV_FLOATS * QA_PRIV_STRIDE + (PLANE ? 0 : EPB * QA_PATCH * QA_PATCH + EPB * QA_OB_LDS);
     constexpr int U_OBS = EPB * S_ENV + OBS_GROUP * S_ROW;
     constexpr int U_ALL = ((U_PHYS > U_OBS ? U_PHYS : U_OBS) + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float s_u_all[WPB * U_ALL];
@@ -761,9 +779,11 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
 
     // ---- terrain window: staged in the rows buffer, which is idle until the observation phase
     TerrainView T = terrain_view(c, p, s_patch + le * (QA_PATCH * QA_PATCH));
+    float *ob_rec = s_patch + EPB * (QA_PATCH * QA_PATCH) + le * QA_OB_LDS;
     if (!PLANE) {
         patch_origin(T, st.pos.x, st.pos.y);
         stage_patch(T, s_patch + le * (QA_PATCH * QA_PATCH), leg);
+        if (c.articulated_obstacles) { stage_obstacles(p, env, leg, ob_rec); T.ob = ob_rec; T.ob_acc = ob_rec + 12 * QA_OBST_PER_ENV; }
         wave_lds_sync();
     }
 
@@ -802,6 +822,19 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
+    // ---- the articulated obstacles' joints: one step of h = decimation x dt under the mean contact force of the substeps (lane k: slot k)
+    if (!PLANE) {
+        if (c.articulated_obstacles) {
+            wave_lds_sync();
+            if (leg < QA_OBST_PER_ENV && valid) {
+                float q = ob_rec[12 * leg + 8], qd = ob_rec[12 * leg + 9];
+                obstacle_joint_step(ob_rec[12 * leg + 7], ob_rec[12 * leg + 11], ob_rec[12 * QA_OBST_PER_ENV + leg] / (float)c.decimation,
+                                    c.sim_dt * (float)c.decimation, q, qd);
+                float *stt = p.obst_state + ((int64_t)env * QA_OBST_PER_ENV + leg) * QA_OBST_STATE;
+                stt[0] = q; stt[1] = qd; stt[2] = ob_rec[12 * QA_OBST_PER_ENV + leg];
+            }
+        }
+    }
 
     QA_STAMP(3);
     // ---- refresh_*: body positions of the new state, contact forces per body
@@ -1004,6 +1037,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     __shared__ float s_tbl[QA_TBL_FLOATS];
     __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     __shared__ float s_patch[PLANE ? 1 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH];
+    __shared__ float s_ob[PLANE ? 1 : ENVS_PER_BLOCK * QA_OB_LDS];
     static_assert(LPE == 4, "one quad per env");
     stage_table(s_tbl);
     const int tid = blockIdx.x * QA_BLOCK + threadIdx.x, N = c.num_envs;
@@ -1028,6 +1062,10 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
         T.patch = mine;
         patch_origin(T, st.pos.x, st.pos.y);
         stage_patch(T, mine, leg);
+        if (c.articulated_obstacles) {          // the obstacles' geometry and surface velocity; their joints only move in env steps
+            float *rec = s_ob + (threadIdx.x >> 2) * QA_OB_LDS;
+            stage_obstacles(p, env, leg, rec); T.ob = rec;
+        }
         wave_lds_sync();
     }
     phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
@@ -1128,6 +1166,7 @@ static void fill_ptrs(qa_sim *s) {
     p.contact_filt = (uint8_t *)(a + L.off[QA_T_CONTACT_FILT]);
     p.height_samples = (int16_t *)(a + L.off[QA_T_HEIGHT_SAMPLES]);
     p.ceil_samples = (int16_t *)(a + L.off[QA_T_CEILING_SAMPLES]);
+    p.obst_desc = (float *)(a + L.off[QA_T_OBST_DESC]); p.obst_state = (float *)(a + L.off[QA_T_OBST_STATE]);
     p.rbstate = (float *)(a + L.off[QA_T_RIGID_BODY_STATE]);
     p.mocap_clips = (double *)(a + L.off[QA_T_MOCAP_CLIPS]);
     p.ticket = (int32_t *)(a + L.off[QA_T_STEP_TICKET]);

@@ -39,6 +39,9 @@ def make_qa_config(cfg, obstacle, seed=1):
     c.hf_rows, c.hf_cols = int(obstacle.tot_rows), int(obstacle.tot_cols)
     c.hf_hscale, c.hf_vscale, c.hf_border = float(obstacle.horizontal_scale), float(obstacle.vertical_scale), float(cfg.obstacle.border_size)
     c.hf_ceiling = 1                                     # tunnel roof + upper arc of the tyre (obstacle.ceiling_raw -> CEILING_SAMPLES)
+    # see-saw = 1-DoF revolute plank with joint damping, bar / tyre = 1-DoF prismatic bodies under the reference's position drive
+    # (QA_T_OBST_DESC / QA_T_OBST_STATE; :792-794, :812-823, :1411-1427); 0 = the static shapes of the height map (the r2 model)
+    c.articulated_obstacles = int(bool(getattr(cfg.obstacle, "articulated", True)))
     if cfg.control.control_type != "P":
         raise NotImplementedError("only control_type 'P' is on the hot path")
     kp = {float(v) for v in cfg.control.stiffness.values()}
@@ -115,6 +118,7 @@ class LeggedRobot:
         self.obstacle_types = torch.from_numpy(self.obstacle.obstacle_types).to(dev, torch.long)
         self.obst_angs = torch.from_numpy(self.obstacle.frame_ang).to(dev, torch.float32).unsqueeze(0).expand(self.num_envs, -1).contiguous()
         self.custom_origins = True
+        self._init_articulated_obstacles(seed)
 
         # ---- buffers = views of the arena (the reference's gym tensors)
         self.root_states = t["ROOT_STATES"]
@@ -202,6 +206,49 @@ class LeggedRobot:
     @episode_length_buf.setter
     def episode_length_buf(self, value):   # the runner rebinds it (on_policy_runner.py:162-163)
         self.bk.episode_length_buf.copy_(value)
+
+    # ------------------------------------------------------------------ articulated obstacles (see-saw, bar jump, tyre jump)
+    def _init_articulated_obstacles(self, seed):
+        """QA_T_OBST_DESC / QA_T_OBST_STATE from the course (tsc/legged_gym/envs/base/legged_robot.py:1411-1427): per env slot 0 = see-saw
+        (revolute about its y axis through the pivot 0.26 m up, plank 3.0 x 0.6 m, damping U(1,10) N m s/rad drawn per GLOBAL env id), slot 1 =
+        the jump bar (1.2 x 0.2 m, prismatic, vertical), slot 2 = the tyre ring (0.8 x 0.2 m, prismatic).  Origins and yaws are the
+        obstacle frames the generator placed (`obstacle_origins`, `obstacle_yaws`)."""
+        self.articulated = bool(self.qcfg.articulated_obstacles)
+        if not self.articulated:
+            return
+        ob, n, dev = self.obstacle, self.num_envs, self.device
+        kinds = {"seesaw": (0, _capi.OBST_SEESAW, 1.5, 0.3, 0.26), "bar_jump": (1, _capi.OBST_BAR, 0.1, 0.6, 0.0), "tire_jump": (2, _capi.OBST_TYRE, 0.1, 0.4, 0.0)}
+        desc = np.zeros((n, 3, 8), dtype=np.float32)
+        for name, (slot, kind, hx, hy, h0) in kinds.items():
+            t = ob.obst_types.index(name)
+            for i in range(n):
+                j = int(np.nonzero(ob.obstacle_types[i] == t)[0][0])
+                yaw = ob.obstacle_yaws[i, j]
+                desc[i, slot] = [ob.obstacle_origins[i, j, 0], ob.obstacle_origins[i, j, 1], np.cos(yaw), np.sin(yaw), hx, hy, h0, kind]
+        n_glob, off = int(self.qcfg.num_envs_global) or n, int(self.qcfg.env_id_offset)
+        damping = np.random.default_rng([seed, 0x5EE5]).uniform(1.0, 10.0, n_glob)[off:off + n]       # :1413 np.random.uniform(1, 10) per see-saw
+        state = np.zeros((n, 3, 4), dtype=np.float32)
+        state[:, 0, 0], state[:, 0, 3] = ob.seesaw_dof_pos, damping
+        self.sim.t["OBST_DESC"].copy_(torch.from_numpy(desc))
+        self.obst_state = self.sim.t["OBST_STATE"]
+        self.obst_state.copy_(torch.from_numpy(state))
+        # order of the see-saw along the env's course: a robot that starts behind it meets the plank from the far side (:812-823)
+        self._seesaw_order = (self.obstacle_types == ob.obst_types.index("seesaw")).int().argmax(dim=1)
+
+    def _reset_articulated_obstacles(self, flags, any_reset):
+        """:812-823 without a host sync: the resetting envs' see-saw goes to its rest tilt on the side the robot will meet (randomize_start:
+        a start past the see-saw flips it), their bar / tyre to the drive's target; every env's obstacle velocities are zeroed when anyone
+        resets (`self.obst_dof_vel[:] = 0.0`)"""
+        if not self.articulated:
+            return
+        st = self.obst_state
+        f = flags != 0
+        rest = torch.full((self.num_envs,), float(self.obstacle.seesaw_dof_pos), device=self.device)
+        if self.cfg.obstacle.randomize_start:
+            rest = torch.where(self.cur_obst_idx > self._seesaw_order, -rest, rest)
+        st[:, 0, 0] = torch.where(f, rest, st[:, 0, 0])
+        st[:, 1:, 0] = torch.where(f.view(-1, 1), torch.zeros_like(st[:, 1:, 0]), st[:, 1:, 0])
+        st[:, :, 1] *= (1.0 - any_reset.to(torch.float32))
 
     # ------------------------------------------------------------------ API
     def set_commands(self, actions):
@@ -295,6 +342,7 @@ class LeggedRobot:
         if cfg.env.send_timeouts:
             self.extras["time_outs"] = bk.time_out_buf.view(torch.bool)
         bk.reset_where(flags, start_goal)
+        self._reset_articulated_obstacles(flags, any_reset)
         if not first:
             self.sim.simulate_if(None, any_reset)
         else:

@@ -63,6 +63,12 @@ class OracleSim:
         assert rc == 0, rc
         self.global_step += 1
 
+    def physics_step(self, actions, delay=0):
+        """qo_env_physics_step: the physics part of an env step alone (action roll / delay / clip, decimation x (PD -> substep), refresh)"""
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        assert a.shape == (self.cfg.num_envs, 12)
+        assert self.lib.qo_env_physics_step(self.h, a.ctypes.data, int(delay), None) == 0
+
     def simulate(self, torques):
         t = np.ascontiguousarray(torques, dtype=np.float32)
         assert self.lib.qo_simulate(self.h, t.ctypes.data, None) == 0

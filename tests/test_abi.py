@@ -61,7 +61,7 @@ def test_layout_agrees_between_library_and_oracle(hip_lib):
 def test_config_struct_size_matches_c():
     # the oracle is plain C: ask it how big it thinks qa_config is by probing an out-of-range read guard
     q = go2_cfg(8)
-    assert C.sizeof(q) == 600          # ABI v4: + hf_rows/cols/hscale/vscale/border, reset_xy_jitter
+    assert C.sizeof(q) == 608          # ABI v11: + articulated_obstacles, reserved0
     lib = load_oracle()
     assert lib.qo_arena_bytes(C.byref(q)) > 0
     assert q.max_episode_length == 1000 and q.resampling_steps == 300 and q.push_interval == 400
