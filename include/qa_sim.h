@@ -228,7 +228,10 @@ typedef struct qa_config {
     int32_t articulated_obstacles;  /* terrain_type 1: != 0 = the see-saw is a 1-DoF revolute plank with joint damping and the bar / tyre are
                                        1-DoF prismatic bodies under the reference's position drive, coupled to the contact rows
                                        (QA_T_OBST_DESC / QA_T_OBST_STATE) -- instead of the static shapes the height map draws for them */
-    int32_t reserved0;
+    int32_t self_collision;         /* != 0: the lower legs (knee-to-foot capsules) of neighbouring legs collide -- left/right and front/rear pairs,
+                                       one frictionless row per pair at the closest points; the reference's assets enable self-collision
+                                       (`self_collisions = 0`, bbc/legged_gym/envs/go2/go2_locomotion_config.py:72,
+                                       tsc/legged_gym/envs/go2/go2_agility_config.py:43).  The force is reported on the calf bodies. */
 } qa_config;
 
 typedef struct qa_sim qa_sim;

@@ -496,6 +496,20 @@ static float scan_center_height(const qo_sim *s, const float *root) {
     return (float)m * c->hf_vscale;
 }
 
+/* closest points of segments A0 + s (A1 - A0), B0 + t (B1 - B0), s, t in [0, 1] (Ericson, Real-Time Collision Detection 5.1.9) */
+static void segment_closest(const double A0[3], const double A1[3], const double B0[3], const double B1[3], double *sp, double *tp) {
+    double d1[3], d2[3], r[3];
+    for (int i = 0; i < 3; ++i) { d1[i] = A1[i] - A0[i]; d2[i] = B1[i] - B0[i]; r[i] = A0[i] - B0[i]; }
+    double a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2), den = a * e - b * b;
+    double s = den > 1e-12 ? (b * f - c * e) / den : 0.0;
+    s = s < 0 ? 0 : (s > 1 ? 1 : s);
+    double t = (b * s + f) / e;
+    if (t < 0) { t = 0; s = -c / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+    else if (t > 1) { t = 1; s = (b - c) / a; s = s < 0 ? 0 : (s > 1 ? 1 : s); }
+    *sp = s; *tp = t;
+}
+#define CALF_RADIUS 0.013
+#define FOOT_RADIUS 0.022
 static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate);
 static void phys_substep(qo_sim *s, int e, const float tau_in[12]) { phys_substep_acc(s, e, tau_in, 0); }
 static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate) {
@@ -537,7 +551,7 @@ static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accum
      * one with the largest gap waits -- then the joint-limit rows.  One candidate per body group, so thigh and calf (the 8 bodies
      * _reward_collision counts, legged_robot.py:1275-1278) and hip / base (check_termination, :168-176) report forces
      * independently of each other. */
-    Row rows[4 * 15];
+    Row rows[4 * 15 + 4];
     int nrows = 0;
     int foot_row[4], extra_row[4][3], extra_body[4][3];
     double mu = 0.5 * ((double)TP(s, QA_T_FRICTION, float)[e] + cfg->ground_friction);
@@ -625,6 +639,38 @@ static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accum
         }
     }
     row_leg_first[4] = nrows;
+    /* ---- self-collision (cfg.self_collision; csrc/qa_physics.h): the lower legs as capsules (knee -> foot centre, radius 13 mm at the knee
+     * growing to the foot sphere's 22 mm), left/right pairs (0,1), (2,3) and front/rear pairs (0,2), (1,3); one frictionless row per pair
+     * at the closest points, normal from the second capsule to the first.  The points move with the same base: J has leg columns only. */
+    static const int PAIRS[4][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}};
+    int pair_row[4] = {-1, -1, -1, -1}; double pair_n[4][3];
+    if (cfg->self_collision) {
+        for (int pi = 0; pi < 4; ++pi) {
+            const int la = PAIRS[pi][0], lb = PAIRS[pi][1];
+            v3 fa, fb, pl = {QA_LEG_PT_POS[la][0][0], QA_LEG_PT_POS[la][0][1], QA_LEG_PT_POS[la][0][2]}, pl2 = {QA_LEG_PT_POS[lb][0][0], QA_LEG_PT_POS[lb][0][1], QA_LEG_PT_POS[lb][0][2]};
+            mv(K.Rl[la][2], pl, fa); mv(K.Rl[lb][2], pl2, fb);
+            for (int i = 0; i < 3; ++i) { fa[i] += K.o[la][2][i]; fb[i] += K.o[lb][2][i]; }
+            double sa, tb; segment_closest(K.o[la][2], fa, K.o[lb][2], fb, &sa, &tb);
+            v3 pA, pB, dv;
+            for (int i = 0; i < 3; ++i) { pA[i] = K.o[la][2][i] + sa * (fa[i] - K.o[la][2][i]); pB[i] = K.o[lb][2][i] + tb * (fb[i] - K.o[lb][2][i]); dv[i] = pA[i] - pB[i]; }
+            double dist = sqrt(dot3(dv, dv)), n[3] = {0, 1, 0};
+            if (dist > 1e-6) for (int i = 0; i < 3; ++i) n[i] = dv[i] / dist;
+            double gap = dist - (CALF_RADIUS + sa * (FOOT_RADIUS - CALF_RADIUS)) - (CALF_RADIUS + tb * (FOOT_RADIUS - CALF_RADIUS));
+            if (!(gap < cfg->contact_offset)) continue;
+            Row *r = &rows[nrows];
+            memset(r, 0, sizeof(*r));
+            for (int k = 0; k < 3; ++k) {
+                v3 ra = {pA[0] - K.o[la][k][0], pA[1] - K.o[la][k][1], pA[2] - K.o[la][k][2]}, rb = {pB[0] - K.o[lb][k][0], pB[1] - K.o[lb][k][1], pB[2] - K.o[lb][k][2]}, axr;
+                cross(K.a[la][k], ra, axr); r->J[6 + 3 * la + k] = dot3(n, axr);
+                cross(K.a[lb][k], rb, axr); r->J[6 + 3 * lb + k] = -dot3(n, axr);
+            }
+            double mdv = cfg->max_depenetration_velocity;
+            r->bias = gap >= 0 ? gap / dt : (gap / dt > -mdv ? gap / dt : -mdv);
+            r->kind = 0;
+            memcpy(pair_n[pi], n, sizeof(v3));
+            pair_row[pi] = nrows++;
+        }
+    }
     for (int i = 0; i < nrows; ++i) {
         chol_solve(Lc, 18, rows[i].J, rows[i].W);
         double d = 0; for (int k = 0; k < 18; ++k) d += rows[i].J[k] * rows[i].W[k];
@@ -676,6 +722,19 @@ static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accum
             }
             for (int k = 0; k < 18; ++k) u[k] = u0[k] + du[k];
         }
+        /* self-collision pairs: the two left/right pairs from the same velocity (changes summed), then the two front/rear pairs */
+        for (int ph = 0; ph < 2; ++ph) {
+            double u0[18], du[18]; memcpy(u0, u, sizeof(u0)); memset(du, 0, sizeof(du));
+            for (int pi = 2 * ph; pi < 2 * ph + 2; ++pi) {
+                if (pair_row[pi] < 0) continue;
+                Row *r = &rows[pair_row[pi]];
+                double res = r->bias; for (int k = 0; k < 18; ++k) res += r->J[k] * u0[k];
+                double lam = r->lam - res * r->dinv; if (lam < 0) lam = 0;
+                double dl = lam - r->lam; r->lam = lam;
+                for (int k = 0; k < 18; ++k) du[k] += r->W[k] * dl;
+            }
+            for (int k = 0; k < 18; ++k) u[k] = u0[k] + du[k];
+        }
     }
     /* joint velocity clamp (PhysX maxJointVelocity = URDF velocity limit) */
     for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) {
@@ -710,6 +769,11 @@ static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accum
         double (*cw)[3] = cdirs[4 * l + slot];
         for (int i = 0; i < 3; ++i)
             cf[3 * b + i] += (float)((rows[r0].lam * cw[0][i] + rows[r0 + 1].lam * cw[1][i] + rows[r0 + 2].lam * cw[2][i]) / dt);
+    }
+    for (int pi = 0; pi < 4; ++pi) if (pair_row[pi] >= 0) {      /* self-collision: +n on the first leg's calf, -n on the second's */
+        v3 nw; mv(R, pair_n[pi], nw);
+        const int ba = QA_LEG_PT_BODY[PAIRS[pi][0]][11], bb = QA_LEG_PT_BODY[PAIRS[pi][1]][11];
+        for (int i = 0; i < 3; ++i) { cf[3 * ba + i] += (float)(rows[pair_row[pi]].lam * nw[i] / dt); cf[3 * bb + i] -= (float)(rows[pair_row[pi]].lam * nw[i] / dt); }
     }
     /* ---- what the contacts do to the articulated obstacles' joints: generalised force -f_n ca, accumulated over the env step's substeps */
     if (accumulate && cfg->terrain_type == 1 && cfg->articulated_obstacles) {

@@ -78,7 +78,7 @@ class QaConfig(C.Structure):
         ("hf_rows", C.c_int32), ("hf_cols", C.c_int32), ("hf_hscale", C.c_float), ("hf_vscale", C.c_float),
         ("hf_border", C.c_float), ("reset_xy_jitter", C.c_float),
         ("num_mocap_frames", C.c_int32), ("export_body_state", C.c_int32), ("env_id_offset", C.c_int32), ("num_envs_global", C.c_int32),
-        ("contact_slots", C.c_int32), ("hf_ceiling", C.c_int32), ("articulated_obstacles", C.c_int32), ("reserved0", C.c_int32),
+        ("contact_slots", C.c_int32), ("hf_ceiling", C.c_int32), ("articulated_obstacles", C.c_int32), ("self_collision", C.c_int32),
     ]
 
 

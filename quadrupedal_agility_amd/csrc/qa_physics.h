@@ -40,6 +40,7 @@ struct PhysParams {
     float dt, gz, contact_offset, max_depen, ground_friction;
     int iters;
     int slots;     // extra contact slots per leg: 3 (one per body) or 1 (lowest non-foot point only)
+    int self_collision;   // calf capsules of neighbouring legs collide (cfg.self_collision)
 };
 
 // packed lower-triangular index of a symmetric 6x6
@@ -255,7 +256,28 @@ struct ContactOut {
     V3 foot_f;                      // world-frame force on this leg's foot
     V3 extra_f[QA_EXTRA_SLOTS];     // world-frame force on the slot's contact
     int extra_body[QA_EXTRA_SLOTS]; // body id the slot's contact is on (-1 none)
+    V3 self_f;                      // world-frame force of this leg's self-collisions (both partners), on its calf
 };
+
+// Self-collision (the reference enables it: bbc/.../go2_locomotion_config.py:72, tsc/.../go2_agility_config.py:43 `self_collisions = 0`): the
+// lower legs as capsules -- knee to foot centre, radius QA_CALF_RADIUS at the knee growing to the foot sphere's -- tested against the
+// capsules of the left/right neighbour (lane ^ 1) and of the front/rear neighbour (lane ^ 2): the pairs that can meet under the joint
+// limits (a leg cannot reach its diagonal partner, and the thigh / trunk pairs are out of reach of the calf's -0.84 rad upper stop).
+// One frictionless row per pair at the capsules' closest points.  The two points move with the SAME base, so the row has no base
+// Jacobian of its own (n is along pA - pB): in the reduced coordinates it is jl_A . w_A - jl_B . w_B + (G_A^T jl_A - G_B^T jl_B) . u_b.
+#define QA_CALF_RADIUS 0.013f
+#define QA_FOOT_RADIUS 0.022f
+#define QA_PRIV_SELF 140                 // 2 pair rows x 20 floats
+// closest points of segments A0 + s (A1 - A0), B0 + t (B1 - B0), s, t in [0, 1] (Ericson, Real-Time Collision Detection 5.1.9)
+QA_DEV void segment_closest(V3 A0, V3 A1, V3 B0, V3 B1, float &s, float &t) {
+    const V3 d1 = A1 - A0, d2 = B1 - B0, r = A0 - B0;
+    const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+    const float den = a * e - b * b;
+    s = den > 1e-12f ? clampf((b * f - c * e) / den, 0.f, 1.f) : 0.f;
+    t = (b * s + f) / e;
+    if (t < 0.f) { t = 0.f; s = clampf(-c / a, 0.f, 1.f); }
+    else if (t > 1.f) { t = 1.f; s = clampf((b - c) / a, 0.f, 1.f); }
+}
 
 // one scalar constraint row in reduced coordinates
 struct Row {
@@ -347,7 +369,7 @@ __device__ long long *g_subprof = nullptr;
 #define QA_PRIV_STRIDE 64
 #define QA_PRIV_EXTRA 0                  // 2 slots x 3 rows x 20 floats: jh6 jl3 bj6 lj3 dinv bias
 #define QA_PRIV_STEP 120                 // env-step persistents parked between substeps: act3 sp3 sd3 binert10
-#define QA_PRIV_FLOATS 140
+#define QA_PRIV_FLOATS 180
 struct LRow { float *p; };               // row view in LDS
 QA_DEV float &lr(float *priv, int k) { return priv[k * QA_PRIV_STRIDE]; }
 
@@ -627,6 +649,53 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
         }
     }
+    // ---- self-collision rows: partner 0 = lane ^ 1 (left / right), partner 1 = lane ^ 2 (front / rear).  Both lanes of a pair evaluate the
+    // SAME expressions on the same (canonically ordered) segments, so they agree bit for bit on gap, normal and effective mass.
+    bool sc_on[2] = {false, false}, any_sc[2] = {false, false}, sc_low[2] = {false, false};
+    float sc_lam[2] = {0.f, 0.f};
+    V3 sc_nw[2];
+    if (P.self_collision) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const V3 a0 = o[2], a1 = foot_p;
+            V3 b0, b1;
+            if (pr == 0) { b0 = v3(dpp_f<0xB1>(a0.x), dpp_f<0xB1>(a0.y), dpp_f<0xB1>(a0.z)); b1 = v3(dpp_f<0xB1>(a1.x), dpp_f<0xB1>(a1.y), dpp_f<0xB1>(a1.z)); }
+            else { b0 = v3(dpp_f<0x4E>(a0.x), dpp_f<0x4E>(a0.y), dpp_f<0x4E>(a0.z)); b1 = v3(dpp_f<0x4E>(a1.x), dpp_f<0x4E>(a1.y), dpp_f<0x4E>(a1.z)); }
+            const bool low = pr == 0 ? ((leg & 1) == 0) : ((leg & 2) == 0);          // this lane holds the pair's first capsule
+            const V3 A0 = low ? a0 : b0, A1 = low ? a1 : b1, B0 = low ? b0 : a0, B1 = low ? b1 : a1;
+            float sa, tb; segment_closest(A0, A1, B0, B1, sa, tb);
+            const V3 pA = A0 + sa * (A1 - A0), pB = B0 + tb * (B1 - B0), dv = pA - pB;
+            const float dist = sqrtf(dot(dv, dv));
+            const V3 nrm = dist > 1e-6f ? (1.0f / dist) * dv : v3(0.f, 1.f, 0.f);
+            const float gap = dist - (QA_CALF_RADIUS + sa * (QA_FOOT_RADIUS - QA_CALF_RADIUS)) - (QA_CALF_RADIUS + tb * (QA_FOOT_RADIUS - QA_CALF_RADIUS));
+            sc_on[pr] = gap < P.contact_offset; sc_low[pr] = low;
+            any_sc[pr] = __any(sc_on[pr]);
+            sc_nw[pr] = low ? nrm : v3(-nrm.x, -nrm.y, -nrm.z);          // base frame: direction of the force on THIS leg
+            if (any_sc[pr]) {
+                Row r;
+                const V3 pm = low ? pA : pB;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r.jl[k] = dot(sc_nw[pr], cross(ax[k], pm - o[k]));
+                float h[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) h[i] = G[0 * 6 + i] * r.jl[0] + G[1 * 6 + i] * r.jl[1] + G[2 * 6 + i] * r.jl[2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) r.jh[i] = h[i] + (pr == 0 ? dpp_f<0xB1>(h[i]) : dpp_f<0x4E>(h[i]));
+                sym6_mul(Binv, r.jh, r.bj);
+                r.lj[0] = Linv[0] * r.jl[0] + Linv[1] * r.jl[1] + Linv[2] * r.jl[2];
+                r.lj[1] = Linv[1] * r.jl[0] + Linv[3] * r.jl[1] + Linv[4] * r.jl[2];
+                r.lj[2] = Linv[2] * r.jl[0] + Linv[4] * r.jl[1] + Linv[5] * r.jl[2];
+                const float dleg = r.jl[0] * r.lj[0] + r.jl[1] * r.lj[1] + r.jl[2] * r.lj[2];
+                float d = dleg + (pr == 0 ? dpp_f<0xB1>(dleg) : dpp_f<0x4E>(dleg));
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d = fmaf(r.jh[i], r.bj[i], d);
+                r.dinv = 1.0f / (d + QA_CFM);
+                const float g = gap / dt;
+                r.bias = gap >= 0.f ? g : fmaxf(g, -P.max_depen);
+                row_store(priv, QA_PRIV_SELF + 20 * pr, r);
+            }
+        }
+    }
     // joint limits: at most one stop per joint can be within the margin
     float lim_sgn[3], lim_bias[3], lim_lam[3], lim_bj[3][6], lim_dinv[3];   // registers: these rows run in most waves
     bool lim_on[3];
@@ -735,6 +804,31 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #pragma unroll
             for (int i = 0; i < 6; ++i) ub[i] += quad_sum(mine ? (ub2[i] - ub[i]) : 0.f);
         }
+        // self-collision pairs: the two left/right pairs from the same base velocity (their base-velocity changes summed, one lane of a
+        // pair reporting it), then the two front/rear pairs
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            if (any_sc[pr]) {
+                float dub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (sc_on[pr]) {
+                    Row r; row_load(priv, QA_PRIV_SELF + 20 * pr, r);
+                    const float tl = r.jl[0] * w[0] + r.jl[1] * w[1] + r.jl[2] * w[2];
+                    float res = r.bias + tl + (pr == 0 ? dpp_f<0xB1>(tl) : dpp_f<0x4E>(tl));
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) res = fmaf(r.jh[i], ub[i], res);
+                    const float lam = fmaxf(sc_lam[pr] - res * r.dinv, 0.f), dl = lam - sc_lam[pr];
+                    sc_lam[pr] = lam;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) w[k] = fmaf(r.lj[k], dl, w[k]);
+                    if (sc_low[pr]) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) dub[i] = r.bj[i] * dl;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ub[i] += quad_sum(dub[i]);
+            }
+        }
     }
 
     QA_SUBSTAMP(9);
@@ -780,6 +874,11 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         if (PLANE) co.extra_f[sl] = on ? v3(re_lam[sl][1] * idt, re_lam[sl][2] * idt, re_lam[sl][0] * idt) : v3(0, 0, 0);
         else { V3 a, b; tangent_basis(ex_n[sl], a, b); co.extra_f[sl] = on ? idt * ((re_lam[sl][0] * ex_n[sl]) + (re_lam[sl][1] * a) + (re_lam[sl][2] * b)) : v3(0, 0, 0); }
         co.extra_body[sl] = on ? ex_body[sl] : -1;
+    }
+    co.self_f = v3(0, 0, 0);
+    if (P.self_collision) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) if (any_sc[pr] && sc_on[pr]) co.self_f = co.self_f + (sc_lam[pr] * idt) * mul(R, sc_nw[pr]);
     }
     // ---- what the contacts do to the articulated obstacles' joints: generalised force -f_n ca, summed over the quad, kept per env in LDS
     if (!PLANE && T.ob_acc) {

@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     const float fric = p.friction[env];
     const float mu = 0.5f * (fric + c.ground_friction);
     PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity;
-    P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2;
+    P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2; P.self_collision = c.self_collision;
 
     // ---- terrain window: staged in the rows buffer, which is idle until the observation phase
     TerrainView T = terrain_view(c, p, s_patch + le * (QA_PATCH * QA_PATCH));
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         hu_f = v3(xsum<LPE>(e1.x), xsum<LPE>(e1.y), xsum<LPE>(e1.z));
         hl_f = v3(xsum<LPE>(e2.x), xsum<LPE>(e2.y), xsum<LPE>(e2.z));
     }
-    V3 hip_f = on_body(myb), thigh_f = on_body(myb + 1), calf_f = on_body(myb + 2);
+    V3 hip_f = on_body(myb), thigh_f = on_body(myb + 1), calf_f = on_body(myb + 2) + co.self_f;
     if (valid) {
         float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
         float *m = cf + 3 * myb;
@@ -1052,7 +1052,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     float tau[3], binert[10];
     for (int k = 0; k < 3; ++k) { st.q[k] = d[2 * k]; st.qd[k] = d[2 * k + 1]; float lim = tbl[T_EFFORT + k]; tau[k] = clampf(torques[(int64_t)env * 12 + 3 * leg + k], -lim, lim); }
     for (int i = 0; i < 10; ++i) binert[i] = p.base_inertia[(int64_t)env * 10 + i];
-    PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity; P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2;
+    PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity; P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2; P.self_collision = c.self_collision;
     ContactOut co;
     float fimp[3];
     for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
@@ -1084,6 +1084,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
     float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
     for (int k = 0; k < 3; ++k) {
         V3 f = on_body(myb + k);
+        if (k == 2) f = f + co.self_f;
         cf[3 * (myb + k)] = f.x; cf[3 * (myb + k) + 1] = f.y; cf[3 * (myb + k) + 2] = f.z;
         V3 w = mul(R, org[k]) + st.pos; rb[3 * (myb + k)] = w.x; rb[3 * (myb + k) + 1] = w.y; rb[3 * (myb + k) + 2] = w.z;
     }

@@ -33,6 +33,8 @@ def make_qa_config(cfg, seed=1, sim_dt=None, terrain=None):
     qa = getattr(cfg.sim, "qa", None)
     c.solver_iterations = int(getattr(qa, "solver_iterations", 4))
     c.contact_slots = int(getattr(qa, "contact_slots", 2))
+    # asset.self_collisions: 0 = ENABLED, 1 = disabled (the reference's bitwise filter flag, go2_locomotion_config.py:72)
+    c.self_collision = int(getattr(cfg.asset, "self_collisions", 0) == 0)
     c.contact_offset = float(cfg.sim.physx.contact_offset)
     c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
     c.ground_friction = float(cfg.terrain.static_friction)

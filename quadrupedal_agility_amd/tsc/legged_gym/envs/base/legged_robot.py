@@ -32,6 +32,7 @@ def make_qa_config(cfg, obstacle, seed=1):
     c.sim_dt, c.decimation, c.gravity_z = float(cfg.sim.dt), int(cfg.control.decimation), float(cfg.sim.gravity[2])
     c.solver_iterations = int(getattr(getattr(cfg.sim, "qa", None), "solver_iterations", 4))
     c.contact_slots = int(getattr(getattr(cfg.sim, "qa", None), "contact_slots", 2))
+    c.self_collision = int(getattr(cfg.asset, "self_collisions", 0) == 0)      # 0 = enabled (go2_agility_config.py:43)
     c.contact_offset = float(cfg.sim.physx.contact_offset)
     c.max_depenetration_velocity = float(cfg.sim.physx.max_depenetration_velocity)
     c.ground_friction = float(cfg.terrain.static_friction)

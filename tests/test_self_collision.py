@@ -1,0 +1,147 @@
+"""Robot self-collision (enabled by the reference's assets: bbc/legged_gym/envs/go2/go2_locomotion_config.py:72,
+tsc/legged_gym/envs/go2/go2_agility_config.py:43 `self_collisions = 0`): the lower legs as capsules, left/right and front/rear pairs, one
+frictionless contact row per pair.
+
+CPU: known-answer tests on the oracle -- legs driven into each other stop at the capsule surfaces (and pass through with the flag off), the
+contact is an internal force (zero gravity: total linear and angular momentum unchanged), the force is reported on the two calves with
+opposite signs, an ordinary stance / gait never triggers it.  GPU (-m gpu): HIP vs oracle from identical arenas on poses with crossing legs."""
+import numpy as np
+import pytest
+
+from tests.oracle_lib import OracleSim, go2_cfg
+from tests.test_oracle_physics import bodies, quat_to_mat
+
+CALF, FOOT = [5 + 4 * l for l in range(4)], [6 + 4 * l for l in range(4)]          # body ids (base, 2 head, then hip/thigh/calf/foot per leg)
+PAIRS = [(0, 1), (2, 3), (0, 2), (1, 3)]
+
+
+def seg_dist(a0, a1, b0, b1):
+    """distance of two segments and the parameters of the closest points (dense sampling: independent of the code under test)"""
+    s = np.linspace(0, 1, 201)
+    pa = a0[None] + s[:, None] * (a1 - a0)[None]; pb = b0[None] + s[:, None] * (b1 - b0)[None]
+    d = np.linalg.norm(pa[:, None] - pb[None], axis=-1)
+    i, j = np.unravel_index(np.argmin(d), d.shape)
+    return d[i, j], s[i], s[j]
+
+
+def capsule_gaps(sim, e=0):
+    rb = sim.t["RIGID_BODY_POS"][e].astype(np.float64)
+    out = []
+    for a, b in PAIRS:
+        d, sa, tb = seg_dist(rb[CALF[a]], rb[FOOT[a]], rb[CALF[b]], rb[FOOT[b]])
+        out.append(d - (0.013 + 0.009 * sa) - (0.013 + 0.009 * tb))
+    return np.array(out)
+
+
+def _free_robot(self_collision, gravity=-9.81):
+    q = go2_cfg(1, randomize_base_mass=0, randomize_base_com=0, randomize_motor=0, randomize_friction=0, gravity_z=gravity, push_robots=0, add_noise=0,
+                self_collision=self_collision)
+    s = OracleSim(q)
+    s.reset_all()
+    s.t["ROOT_STATES"][0] = [0, 0, 40.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    s.t["DOF_STATE"][0, :, 0] = [0, 0.9, -1.8] * 4; s.t["DOF_STATE"][0, :, 1] = 0
+    s.t["EPISODE_LENGTH"][:] = 5
+    return s
+
+
+CROSS = np.array([-4.0, 0.0, 0.0, 4.0, 0.0, 0.0, -4.0, 0.0, 0.0, 4.0, 0.0, 0.0], np.float32)      # hips abducted inwards to their stops: the feet cross under the trunk
+FOLD = np.array([0.0, 3.0, 1.0, 0.0, 3.0, 1.0, 0.0, -4.0, -1.0, 0.0, -4.0, -1.0], np.float32)     # front legs swept back, rear legs swept forward: front / rear pairs meet
+
+
+@pytest.mark.parametrize("act,pairs", [(CROSS, (0, 1)), (FOLD, (2, 3))])
+def test_legs_driven_into_each_other_stop_at_the_capsule_surfaces(act, pairs):
+    gaps = {}
+    for flag in (1, 0):
+        s = _free_robot(flag)
+        g = []
+        for _ in range(50):
+            s.step(act[None])
+            g.append(capsule_gaps(s))
+        gaps[flag] = np.asarray(g)
+    for p in pairs:
+        assert gaps[0][:, p].min() < -0.01, (p, gaps[0][:, p].min())           # without self-collision these capsules interpenetrate ...
+        assert gaps[1][:, p].min() > -0.004, (p, gaps[1][:, p].min())          # ... with it they stop at the surfaces (4 mm of slop: 4 sweeps, 5 ms steps)
+    assert np.isfinite(gaps[1]).all()
+
+
+def test_self_contact_is_an_internal_force():
+    """zero gravity, no ground: legs colliding with each other exchange momentum inside the robot -- its total linear and angular momentum
+    stay where they were (the pair row has leg columns only; a formulation that pushed on one leg alone would fail this)"""
+    s = _free_robot(1, gravity=0.0)
+    s.t["ROOT_STATES"][0, 7:13] = [0.3, -0.2, 0.1, 0.2, 0.1, -0.3]
+
+    def momentum():
+        root = s.t["ROOT_STATES"][0].astype(np.float64); R = quat_to_mat(root[3:7])
+        ub = np.concatenate([R.T @ root[10:13], R.T @ root[7:10]])
+        com, vel, omg, mass, I = bodies(s.lib, s.t["DOF_STATE"][0, :, 0].copy(), s.t["DOF_STATE"][0, :, 1].copy(), ub)
+        p = sum(mass[b] * (R @ vel[b]) for b in range(13))
+        c = sum(mass[b] * (R @ com[b]) for b in range(13)) / mass.sum()
+        L = sum(mass[b] * np.cross(R @ com[b] - c, R @ vel[b]) + R @ (I[b] @ omg[b]) for b in range(13))
+        return p, L
+    for _ in range(10):                # the hips slam into their stops first (the joint-velocity clamp of that transient is not momentum-neutral,
+        s.step(CROSS[None])            # with or without self-collision); from here on the legs rest against each other with ~9 N
+    p0, L0 = momentum()
+    touched = 0.0
+    for _ in range(50):
+        s.step(CROSS[None])
+        cf = s.t["CONTACT_FORCES"][0]
+        touched = max(touched, float(np.abs(cf[CALF]).max()))
+        assert np.allclose(cf[CALF[0]], -cf[CALF[1]], atol=1e-4) and np.allclose(cf[CALF[2]], -cf[CALF[3]], atol=1e-4)     # equal and opposite on the two calves
+        assert np.abs(np.delete(cf, CALF, axis=0)).max() == 0.0                                                                # and on nothing else (no ground here)
+    assert touched > 5.0                                                   # the legs did collide (N)
+    p1, L1 = momentum()
+    assert np.allclose(p1, p0, atol=5e-3) and np.allclose(L1, L0, atol=8e-3)
+
+
+def test_an_ordinary_stance_and_gait_never_touch():
+    """the default pose and the mocap gaits keep the lower legs > 5 cm apart: self-collision changes nothing on the reference's normal
+    operating range (bit-identical arenas with and without the flag)"""
+    a, b = (OracleSim(go2_cfg(16, seed=3, self_collision=f)) for f in (1, 0))
+    rng = np.random.default_rng(0)
+    a.reset_all(); b.reset_all()
+    for _ in range(40):
+        act = rng.normal(0, 0.5, (16, 12)).astype(np.float32)
+        a.step(act); b.step(act)
+    assert np.array_equal(a.arena, b.arena)
+    assert min(capsule_gaps(a, e).min() for e in range(16)) > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 4096])
+def test_hip_matches_oracle_with_crossing_legs(n):
+    """single-step parity from identical arenas with the joints of a third of the envs driven towards crossing poses (hips inwards, front
+    legs back / rear legs forward) and random poses in free fall for the rest: robot state within the physics tolerances, and the kernel
+    does report self-contact forces"""
+    import torch
+    from quadrupedal_agility_amd.sim import QaSim
+    from tests.test_hip_parity import env_mismatch
+    q = go2_cfg(n, seed=2, self_collision=1)
+    o, h = OracleSim(q), QaSim(q, "cuda:0")
+    o.reset_all()
+    rng = np.random.default_rng(1)
+    rs, ds = o.t["ROOT_STATES"], o.t["DOF_STATE"]
+    rs[:, 2] = rng.uniform(0.28, 3.0, n)                                   # some standing, some in the air
+    flips = hits = 0
+    steps = 30
+    for k in range(steps):
+        if k % 10 == 0:
+            kind = np.arange(n) % 3
+            ds[:, :, 0] = np.array([0, 0.9, -1.8] * 4) + rng.uniform(-0.3, 0.3, (n, 12))
+            ds[kind == 0, 0::3, 0] = rng.uniform(0.6, 1.0, ((kind == 0).sum(), 4)) * np.array([-1, 1, -1, 1])     # hips inwards
+            ds[kind == 1, 1, 0] = ds[kind == 1, 4, 0] = 2.6; ds[kind == 1, 7, 0] = ds[kind == 1, 10, 0] = -0.9       # front back, rear forward
+            ds[:, :, 1] = rng.uniform(-3, 3, (n, 12))
+        h.arena.copy_(torch.from_numpy(o.arena.copy()).cuda()); h.global_step = o.global_step
+        act = (CROSS[None] * (np.arange(n) % 3 == 0)[:, None] + FOLD[None] * (np.arange(n) % 3 == 1)[:, None] + rng.normal(0, 0.5, (n, 12))).astype(np.float32)
+        o.step(act); h.step(torch.from_numpy(act).cuda())
+        torch.cuda.synchronize()
+        bad = np.zeros(n, bool)
+        for name in ("ROOT_STATES", "DOF_STATE", "CONTACT_FORCES", "TORQUES", "REW", "RESET"):
+            bad |= env_mismatch(name, h.t[name].cpu().numpy(), o.t[name], n)
+        flips += int(bad.sum())
+        rb = o.t["RIGID_BODY_POS"]
+        cfh = h.t["CONTACT_FORCES"].cpu().numpy()
+        air = rb[:, FOOT, 2].min(axis=1) > 0.1                             # feet off the ground: any calf force is a self-contact force
+        hits += int((np.abs(cfh[air][:, CALF]).max(axis=(1, 2)) > 1.0).sum())
+    print(f"self-collision, {n} envs x {steps} steps: outside the physics tolerances {flips}, airborne env-steps with a self-contact force {hits}")
+    assert flips <= 0.02 * steps * n + 2
+    assert hits > 0.01 * steps * n
