@@ -18,7 +18,6 @@ timeout 400 python bench.py --terrain trimesh --no_cpu_baseline 2> $O/bench_trim
 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu.json
 timeout 400 python bench.py --tsc --steps 6 --warmup 3 2> $O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_8192.json
 timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024.json
-timeout 600 python bench.py --tsc --vision --num_envs 2048 --steps 3 --warmup 2 2> $O/bench_vision.err < /dev/null | grep '"metric"' > $O/bench_tsc_student_2048.json
 timeout 400 python bench.py --tsc --vision --num_envs 512 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_512.json
 timeout 400 python bench.py --tsc --vision --num_envs 256 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_256.json
 timeout 200 python tools/quick_time.py > $O/quick_time.txt 2>&1 < /dev/null
@@ -29,7 +28,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
-f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/gap_report.py "$f" 0.7 > $O/gap_report.txt 2>&1 && python $R/tools/step_sequence.py "$f" > $O/step_sequence.txt 2>&1
+f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/gap_report.py "$f" 0.7 > $O/gap_report.txt 2>&1; [ -n "$f" ] && python $R/tools/step_sequence.py "$f" > $O/step_sequence.txt 2>&1
 grep '"metric"' /tmp/prof.log > $O/bench_under_rocprof.json
 rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 6 --warmup 3 < /dev/null > /tmp/prof2.log 2>&1
