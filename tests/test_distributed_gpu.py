@@ -42,7 +42,7 @@ def _worker(rank, world, port, q, amp, iters, backend="gloo"):
     torch.cuda.synchronize()
     a = runner.alg
     flat = torch.cat([p.detach().flatten() for m in (a.actor_critic, a.estimator, a.disc) for p in m.parameters()]).cpu()
-    two_graphs = isinstance(a._ac_graph, tuple) and a._ac_graph[1] is not None
+    two_graphs = isinstance(a._ac_graph, list) and all(gb is not None for _, gb, _ in a._ac_graph)
     norm = torch.cat([a.disc_normalizer.mean, a.disc_normalizer.var, a.disc_normalizer.count.reshape(1)]).cpu().numpy() if amp else np.zeros(1)
     q.put((rank, flat.numpy(), float(a.lr_ac), bool(two_graphs), bool(torch.isfinite(flat).all()), env.root_states[:, :3].cpu().numpy().copy(), norm))
     dist.destroy_process_group()

@@ -302,8 +302,8 @@ def test_data_parallel_update_as_two_graphs_around_the_collective(monkeypatch):
             runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
             assert (runner.alg.grad_sync is not None) == dp
             runner.learn(3, init_at_random_ep_len=True)
-            ga, gb = runner.alg._ac_graph
-            assert (gb is not None) == dp
+            assert len(runner.alg._ac_graph) == runner.alg.num_mini_batches      # one recorded step per minibatch slot
+            assert all((gb is not None) == dp for _, gb, _ in runner.alg._ac_graph)
             res.append({k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()})
             res.append(float(runner.alg.lr_ac))
         finally:

@@ -8,7 +8,7 @@ runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args,
 runner.learn(4, init_at_random_ep_len=True)
 torch.cuda.synchronize()
 a = runner.alg
-for name, g, n in (("disc step", a._disc_graph, 80), ("ppo step", a._ac_graph[0], 20), ("rollout", runner._graph, 3)):
+for name, g, n in (("disc step", a._disc_graph, 80), ("ppo step", a._ac_graph[0][0], 20), ("rollout", runner._graph, 3)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n):
         g.replay()
