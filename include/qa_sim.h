@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 11
+#define QA_ABI_VERSION 12
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -428,6 +428,45 @@ int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
  * (the reduction half of qa_linear_backward_weight, exposed for partial products computed elsewhere).  Replaces torch's `sum(0)` over
  * the slab dimension in bbc/rsl_rl/algorithms/gail.py:328-413's weight gradients as this build evaluates them. */
 int qa_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int64_t n, float *out, void *stream);
+
+/* Image stem of the vision student's depth encoder under training (csrc/qa_conv.hip, csrc/qa_gemm.hip; ABI 12).  They replace, for
+ * `DepthOnlyFCBackbone58x87.image_compression[0:5]` (tsc/rsl_rl/modules/depth_backbone.py:63-75: Conv2d(1, 32, 5) -> MaxPool2d(2, 2) -> ELU
+ * -> Conv2d(32, 64, 3) -> ELU) as learn_vision / update_depth_actor / BYOL run it (tsc/rsl_rl/runners/on_policy_runner.py:278-441,
+ * algorithms/ppo.py:327-358, modules/byol.py:242-317), what PyTorch issues as MIOpen convolution / pooling / aten elu kernels, forward
+ * and backward.  Activations are CHANNELS-LAST fp32 ([image][y][x][channel]); weights of the generic convolution are
+ * [out channel][ky][kx][in channel] (nn.Conv2d.weight permuted (0, 2, 3, 1)); act: 0 none, 1 ELU(alpha), 2 ReLU.
+ *   qa_depth_stem_forward      y[n][py][px][c] = ELU( max over the 2x2 window of (conv5x5(images[n], weight[c]) + bias[c]) ), 32 channels,
+ *                              images [n][ih][iw], weight [32][25] (= nn.Conv2d(1, 32, 5).weight), pooled size ((ih - 4) / 2, (iw - 4) / 2)
+ *                              rounded down (MaxPool2d's floor mode); argmax[n][py][px][c] = 2 dy + dx of the window's FIRST maximum in
+ *                              row-major order (PyTorch's tie rule), one byte each.  6 <= ih, 6 <= iw <= 126.
+ *   qa_depth_stem_backward     grad_wb[0:800] = d loss / d weight, grad_wb[800:832] = d loss / d bias from grad_pre = the gradient at the
+ *                              pooled pre-activation ([n][ph][pw][32]: what qa_conv_nhwc_backward_input with act_prev = 1 returns);
+ *                              fixed work assignment and summation order; scratch >= qa_depth_stem_backward_scratch_bytes(), 16-byte aligned.
+ *   qa_conv_nhwc_forward       y[n][oy][ox][o] = act( sum_{ky,kx,c} x[n][oy+ky][ox+kx][c] weight[o][ky][kx][c] + bias[o] )   ("valid", stride 1)
+ *                              as one fp32-MFMA GEMM that reads the windows in place.  cin a power of two >= 16, cout % 4 == 0, more than
+ *                              256 output pixels per image, all pointers 16-byte aligned.
+ *   qa_conv_nhwc_backward_input  grad_in = conv(grad_padded, weight_flipped) * act'(x_act): the same GEMM over the output gradient
+ *                              padded with kh - 1 / kw - 1 zeros on every side ([n][ihp][iwp][cout]: qa_elu_backward_pad writes it) and
+ *                              weight_flipped[c][ky][kx][o] = weight[o][kh-1-ky][kw-1-kx][c]; x_act = the activation OUTPUT that was
+ *                              this convolution's input ([n][ihp-kh+1][iwp-kw+1][cin]; act_prev 0: no factor, may be NULL).
+ *   qa_conv_nhwc_backward_weight  grad_weight[o][ky][kx][c] = sum over images and output pixels of grad_out * x window, grad_bias[o] = sum
+ *                              of grad_out; split over pixel slabs, fixed-order sum; scratch >= ..._scratch_bytes(...), 16-byte aligned.
+ *   qa_elu_backward_pad        grad_pre = grad_out * act'(y) ([n][oh][ow][c], c % 4 == 0), written a second time into grad_pre_padded
+ *                              [n][oh + 2 pad][ow + 2 pad][c] whose border is zeroed. */
+int qa_depth_stem_forward(const float *images, const float *weight, const float *bias, float *y, uint8_t *argmax, int64_t n_img, int32_t ih, int32_t iw,
+                          float alpha, void *stream);
+int64_t qa_depth_stem_backward_scratch_bytes(void);
+int qa_depth_stem_backward(const float *images, const uint8_t *argmax, const float *grad_pre, float *grad_wb, int64_t n_img, int32_t ih, int32_t iw,
+                           void *scratch, int64_t scratch_bytes, void *stream);
+int qa_conv_nhwc_forward(const float *x, const float *weight, const float *bias, float *y, int64_t n_img, int32_t ih, int32_t iw, int32_t cin,
+                         int32_t kh, int32_t kw, int32_t cout, int32_t act, float alpha, void *stream);
+int qa_conv_nhwc_backward_input(const float *grad_padded, const float *weight_flipped, const float *x_act, float *grad_in, int64_t n_img, int32_t ihp,
+                                int32_t iwp, int32_t cout, int32_t kh, int32_t kw, int32_t cin, int32_t act_prev, float alpha, void *stream);
+int64_t qa_conv_nhwc_backward_weight_scratch_bytes(int64_t n_img, int32_t ih, int32_t iw, int32_t cin, int32_t kh, int32_t kw, int32_t cout);
+int qa_conv_nhwc_backward_weight(const float *x, const float *grad_out, float *grad_weight, float *grad_bias, int64_t n_img, int32_t ih, int32_t iw,
+                                 int32_t cin, int32_t kh, int32_t kw, int32_t cout, void *scratch, int64_t scratch_bytes, void *stream);
+int qa_elu_backward_pad(const float *grad_out, const float *y, float *grad_pre, float *grad_pre_padded, int64_t n_img, int32_t oh, int32_t ow,
+                        int32_t channels, int32_t pad, int32_t act, float alpha, void *stream);
 
 /* Running-moment normaliser of the discriminator inputs (bbc/rsl_rl/utils/utils.py:62-103).
  * qa_normalizer_update folds num_batches (1..4) row-major (rows[i], dim) fp32 device batches, in order, into the

@@ -1590,6 +1590,152 @@ int qo_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int6
     return QA_OK;
 }
 
+/* CPU twins of the depth encoder's image stem (csrc/qa_conv.hip, csrc/qa_gemm.hip), restating
+ * tsc/rsl_rl/modules/depth_backbone.py:63-75 (Conv2d(1, 32, 5) -> MaxPool2d(2, 2) -> ELU -> Conv2d(32, 64, 3) -> ELU) and its gradients as
+ * plain loops over channels-last tensors; double accumulation (the kernels accumulate in fp32 in a different order: the tests compare at a
+ * tolerance).  Pinned against torch's conv2d / max_pool2d / elu forward and autograd by tests/test_depth_stem.py. */
+static float act_fwd(int act, float alpha, float v) { return act == 1 ? (v > 0.f ? v : alpha * (expf(v) - 1.f)) : (act == 2 ? (v > 0.f ? v : 0.f) : v); }
+static float act_deriv_from_output(int act, float alpha, float y) { return act == 1 ? (y > 0.f ? 1.f : y + alpha) : (act == 2 ? (y > 0.f ? 1.f : 0.f) : 1.f); }
+
+int qo_depth_stem_forward(const float *images, const float *weight, const float *bias, float *y, uint8_t *argmax, int64_t n_img, int32_t ih, int32_t iw,
+                          float alpha, void *stream) {
+    (void)stream;
+    if (!images || !weight || !bias || !y || !argmax || n_img <= 0 || ih < 6 || iw < 6 || iw > 126) return QA_E_ARG;
+    const int ph = (ih - 4) / 2, pw = (iw - 4) / 2;
+    for (int64_t n = 0; n < n_img; ++n)
+        for (int py = 0; py < ph; ++py)
+            for (int px = 0; px < pw; ++px)
+                for (int c = 0; c < 32; ++c) {
+                    float best = 0.f; int arg = 0;
+                    for (int d = 0; d < 4; ++d) {
+                        const int cy = 2 * py + (d >> 1), cx = 2 * px + (d & 1);
+                        double acc = 0.0;
+                        for (int ky = 0; ky < 5; ++ky)
+                            for (int kx = 0; kx < 5; ++kx) acc += (double)weight[c * 25 + ky * 5 + kx] * images[(n * ih + cy + ky) * iw + cx + kx];
+                        const float v = (float)acc + bias[c];
+                        if (d == 0 || v > best) { best = v; arg = d; }          /* first maximum in row-major window order (PyTorch) */
+                    }
+                    const int64_t o = ((n * ph + py) * pw + px) * 32 + c;
+                    y[o] = act_fwd(1, alpha, best);
+                    argmax[o] = (uint8_t)arg;
+                }
+    return QA_OK;
+}
+
+int64_t qo_depth_stem_backward_scratch_bytes(void) { return 16; }
+
+int qo_depth_stem_backward(const float *images, const uint8_t *argmax, const float *grad_pre, float *grad_wb, int64_t n_img, int32_t ih, int32_t iw,
+                           void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)stream; (void)scratch; (void)scratch_bytes;
+    if (!images || !argmax || !grad_pre || !grad_wb || n_img <= 0 || ih < 6 || iw < 6 || iw > 126) return QA_E_ARG;
+    const int ph = (ih - 4) / 2, pw = (iw - 4) / 2;
+    double acc[832];
+    for (int i = 0; i < 832; ++i) acc[i] = 0.0;
+    for (int64_t n = 0; n < n_img; ++n)
+        for (int py = 0; py < ph; ++py)
+            for (int px = 0; px < pw; ++px)
+                for (int c = 0; c < 32; ++c) {
+                    const int64_t o = ((n * ph + py) * pw + px) * 32 + c;
+                    const double g = grad_pre[o];
+                    const int cy = 2 * py + (argmax[o] >> 1), cx = 2 * px + (argmax[o] & 1);
+                    acc[800 + c] += g;
+                    for (int ky = 0; ky < 5; ++ky)
+                        for (int kx = 0; kx < 5; ++kx) acc[c * 25 + ky * 5 + kx] += g * images[(n * ih + cy + ky) * iw + cx + kx];
+                }
+    for (int i = 0; i < 832; ++i) grad_wb[i] = (float)acc[i];
+    return QA_OK;
+}
+
+static int conv_args_ok(int64_t n_img, int ih, int iw, int cin, int kh, int kw, int cout) {
+    const int oh = ih - kh + 1, ow = iw - kw + 1;
+    return n_img > 0 && cin >= 16 && !(cin & (cin - 1)) && kh >= 1 && kw >= 2 && oh >= 1 && ow >= 2 && (int64_t)oh * ow > 256 && cout > 0 && cout % 4 == 0;
+}
+/* mode 0: act(conv + bias); mode 1: conv * act'(deriv_of) */
+static void conv_nhwc(int mode, const float *x, const float *w, const float *bias, const float *deriv_of, float *y, int64_t n_img, int ih, int iw, int cin,
+                      int kh, int kw, int cout, int act, float alpha) {
+    const int oh = ih - kh + 1, ow = iw - kw + 1;
+    for (int64_t n = 0; n < n_img; ++n)
+        for (int oy = 0; oy < oh; ++oy)
+            for (int ox = 0; ox < ow; ++ox)
+                for (int o = 0; o < cout; ++o) {
+                    double acc = 0.0;
+                    for (int ky = 0; ky < kh; ++ky)
+                        for (int kx = 0; kx < kw; ++kx) {
+                            const float *xp = x + ((n * ih + oy + ky) * iw + ox + kx) * cin, *wp = w + ((int64_t)(o * kh + ky) * kw + kx) * cin;
+                            for (int c = 0; c < cin; ++c) acc += (double)xp[c] * wp[c];
+                        }
+                    const int64_t i = ((n * oh + oy) * ow + ox) * cout + o;
+                    y[i] = mode == 0 ? act_fwd(act, alpha, (float)acc + (bias ? bias[o] : 0.f))
+                                     : (float)acc * ((deriv_of && act) ? act_deriv_from_output(act, alpha, deriv_of[i]) : 1.f);
+                }
+}
+int qo_conv_nhwc_forward(const float *x, const float *weight, const float *bias, float *y, int64_t n_img, int32_t ih, int32_t iw, int32_t cin,
+                         int32_t kh, int32_t kw, int32_t cout, int32_t act, float alpha, void *stream) {
+    (void)stream;
+    if (!x || !weight || !y || act < 0 || act > 2 || !conv_args_ok(n_img, ih, iw, cin, kh, kw, cout)) return QA_E_ARG;
+    conv_nhwc(0, x, weight, bias, NULL, y, n_img, ih, iw, cin, kh, kw, cout, act, alpha);
+    return QA_OK;
+}
+int qo_conv_nhwc_backward_input(const float *grad_padded, const float *weight_flipped, const float *x_act, float *grad_in, int64_t n_img, int32_t ihp,
+                                int32_t iwp, int32_t cout, int32_t kh, int32_t kw, int32_t cin, int32_t act_prev, float alpha, void *stream) {
+    (void)stream;
+    if (!grad_padded || !weight_flipped || !grad_in || act_prev < 0 || act_prev > 2 || (act_prev && !x_act) || !conv_args_ok(n_img, ihp, iwp, cout, kh, kw, cin))
+        return QA_E_ARG;
+    conv_nhwc(1, grad_padded, weight_flipped, NULL, x_act, grad_in, n_img, ihp, iwp, cout, kh, kw, cin, act_prev, alpha);
+    return QA_OK;
+}
+int64_t qo_conv_nhwc_backward_weight_scratch_bytes(int64_t n_img, int32_t ih, int32_t iw, int32_t cin, int32_t kh, int32_t kw, int32_t cout) {
+    return conv_args_ok(n_img, ih, iw, cin, kh, kw, cout) ? (int64_t)kh * kw * cin * cout * 8 + cout * 8 : 0;
+}
+int qo_conv_nhwc_backward_weight(const float *x, const float *grad_out, float *grad_weight, float *grad_bias, int64_t n_img, int32_t ih, int32_t iw,
+                                 int32_t cin, int32_t kh, int32_t kw, int32_t cout, void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)stream;
+    if (!x || !grad_out || !grad_weight || !grad_bias || !scratch || !conv_args_ok(n_img, ih, iw, cin, kh, kw, cout) ||
+        scratch_bytes < qo_conv_nhwc_backward_weight_scratch_bytes(n_img, ih, iw, cin, kh, kw, cout)) return QA_E_ARG;
+    const int oh = ih - kh + 1, ow = iw - kw + 1, kred = kh * kw * cin;
+    double *aw = (double *)scratch, *ab = aw + (int64_t)kred * cout;
+    for (int64_t i = 0; i < (int64_t)kred * cout + cout; ++i) aw[i] = 0.0;
+    for (int64_t n = 0; n < n_img; ++n)
+        for (int oy = 0; oy < oh; ++oy)
+            for (int ox = 0; ox < ow; ++ox) {
+                const float *gp = grad_out + ((n * oh + oy) * ow + ox) * cout;
+                for (int o = 0; o < cout; ++o) {
+                    const double g = gp[o];
+                    ab[o] += g;
+                    for (int ky = 0; ky < kh; ++ky)
+                        for (int kx = 0; kx < kw; ++kx) {
+                            const float *xp = x + ((n * ih + oy + ky) * iw + ox + kx) * cin;
+                            double *wp = aw + ((int64_t)(o * kh + ky) * kw + kx) * cin;
+                            for (int c = 0; c < cin; ++c) wp[c] += g * xp[c];
+                        }
+                }
+            }
+    for (int64_t i = 0; i < (int64_t)kred * cout; ++i) grad_weight[i] = (float)aw[i];
+    for (int o = 0; o < cout; ++o) grad_bias[o] = (float)ab[o];
+    return QA_OK;
+}
+int qo_elu_backward_pad(const float *grad_out, const float *y, float *grad_pre, float *grad_pre_padded, int64_t n_img, int32_t oh, int32_t ow,
+                        int32_t channels, int32_t pad, int32_t act, float alpha, void *stream) {
+    (void)stream;
+    if (!grad_out || !y || !grad_pre || !grad_pre_padded || n_img <= 0 || oh <= 0 || ow <= 0 || channels <= 0 || channels % 4 || pad < 0 || act < 0 || act > 2)
+        return QA_E_ARG;
+    const int ph = oh + 2 * pad, pw = ow + 2 * pad;
+    for (int64_t n = 0; n < n_img; ++n)
+        for (int yy = 0; yy < ph; ++yy)
+            for (int xx = 0; xx < pw; ++xx)
+                for (int c = 0; c < channels; ++c) {
+                    const int iy = yy - pad, ix = xx - pad;
+                    float v = 0.f;
+                    if (iy >= 0 && iy < oh && ix >= 0 && ix < ow) {
+                        const int64_t o = ((n * oh + iy) * ow + ix) * channels + c;
+                        v = grad_out[o] * act_deriv_from_output(act, alpha, y[o]);
+                        grad_pre[o] = v;
+                    }
+                    grad_pre_padded[((n * ph + yy) * pw + xx) * channels + c] = v;
+                }
+    return QA_OK;
+}
+
 /* CPU twin of qa_tsc_reset_stats (tsc/legged_gym/envs/base/legged_robot.py:382-384, 396-404): the kernel's summation order restated
  * (1024 strided partial sums, then a binary tree), fp32, so the two agree bit for bit */
 static float tree1024(float *red) {

@@ -36,6 +36,29 @@
 #include "../../include/qa_sim.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Convolution as a GEMM over a channels-last image: operand rows are the windows of an [image][y][x][channel] tensor, read in
+// place -- row p (an output pixel) starts at element rowbase(p) = ((img * ipix) + oy * iw + ox) * cin, reduction index k = (tap, channel)
+// adds koff(k) = ((tap / kw) * iw + tap % kw) * cin + channel.  cin is a power of two >= 16, so a 16-wide k-tile lies inside one tap.
+// Divisions by the per-call constants are multiplications: p / opix with m = ceil(2^40 / opix) (256 < opix, exact for p < 2^40 / opix), the
+// in-image ones with m = ceil(2^32 / d) and the high half of the product (2 <= d, exact for n < 2^32 / d).
+struct ConvGeom {
+    int opix, ow, iw, ipix, cin, cs, kw;
+    uint32_t m_opix, m_ow, m_kw;
+};
+static __device__ __forceinline__ uint32_t conv_div(uint32_t n, uint32_t m) { return (uint32_t)(((uint64_t)n * m) >> 40); }
+static __device__ __forceinline__ uint32_t conv_div_small(uint32_t n, uint32_t m) { return __umulhi(n, m); }      // m = ceil(2^32 / d), n < 2^32 / d
+static __device__ __forceinline__ uint32_t conv_rowbase(const ConvGeom &c, int p) {
+    const uint32_t img = conv_div((uint32_t)p, c.m_opix), r = (uint32_t)p - img * (uint32_t)c.opix;
+    const uint32_t oy = conv_div_small(r, c.m_ow), ox = r - oy * (uint32_t)c.ow;
+    return (img * (uint32_t)c.ipix + oy * (uint32_t)c.iw + ox) << c.cs;
+}
+static __device__ __forceinline__ uint32_t conv_koff(const ConvGeom &c, int k) {
+    const uint32_t tap = (uint32_t)k >> c.cs, ch = (uint32_t)k & (uint32_t)(c.cin - 1);
+    const uint32_t ky = conv_div_small(tap, c.m_kw), kx = tap - ky * (uint32_t)c.kw;
+    return ((ky * (uint32_t)c.iw + kx) << c.cs) + ch;
+}
 
 struct GemmArgs {
     const float *A, *B;
@@ -47,6 +70,7 @@ struct GemmArgs {
     int a_count, b_count, kred, k_per_split, na, nb, nsplit;
     int a_vec, b_vec, o_vec, act;
     float alpha;
+    ConvGeom cg;             // CONV 1: the B side (k-contiguous) is a window matrix; CONV 2: the A side (index-contiguous, reduction over pixels)
 };
 
 #define GEMM_BK 16
@@ -61,7 +85,11 @@ template <int BT, bool MC, int VEC>
 static __device__ __forceinline__ void gemm_load(float (&r)[BT / 16], const float *__restrict__ P, int64_t ld, int idx0, int count, int k0,
                                                  int kend, int tid) {
     if (!MC) {
-        if (VEC == 4) {
+        if (VEC == 4 && BT == 32) {          // 32 rows x 16 k = two floats per thread (the 32-channel input gradient of the window GEMM)
+            const int kc = min(k0 + (tid & 7) * 2, kend - 2);
+            const f2 v = *(const f2 *)(P + (uint32_t)(min(idx0 + (tid >> 3), count - 1) * (int)ld + kc));
+            r[0] = v.x; r[1] = v.y;
+        } else if (VEC == 4) {
             const int kc = min(k0 + (tid & 3) * 4, kend - 4);
 #pragma unroll
             for (int j = 0; j < BT / 64; ++j) {
@@ -99,12 +127,46 @@ static __device__ __forceinline__ void gemm_load(float (&r)[BT / 16], const floa
     }
 }
 
+// CONV 1: k-contiguous window rows, 16-byte loads.  rb[j] = rowbase of the thread's j-th row (fixed for the whole launch); the k-tile's
+// tap offset is uniform over the workgroup (16 | cin).
+template <int BT>
+static __device__ __forceinline__ void gemm_conv_rows(uint32_t (&rb)[BT / 64], const ConvGeom &cg, int idx0, int count, int tid) {
+#pragma unroll
+    for (int j = 0; j < BT / 64; ++j) rb[j] = conv_rowbase(cg, min(idx0 + (tid >> 2) + 64 * j, count - 1));
+}
+template <int BT>
+static __device__ __forceinline__ void gemm_load_conv_kc(float (&r)[BT / 16], const float *__restrict__ P, const uint32_t (&rb)[BT / 64],
+                                                         const ConvGeom &cg, int k0, int kend, int tid) {
+    const uint32_t ko = conv_koff(cg, min(k0, kend - GEMM_BK)) + (tid & 3) * 4;
+#pragma unroll
+    for (int j = 0; j < BT / 64; ++j) {
+        const f4 v = *(const f4 *)(P + (rb[j] + ko));
+        r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+    }
+}
+// CONV 2: the reduction runs over the pixels (rows of the window matrix), the thread's four consecutive (tap, channel) columns are fixed
+template <int BT>
+static __device__ __forceinline__ void gemm_load_conv_mc(float (&r)[BT / 16], const float *__restrict__ P, uint32_t coloff, const ConvGeom &cg,
+                                                         int k0, int kend, int tid) {
+    constexpr int TPR = BT / 4, RPP = 256 / TPR;
+#pragma unroll
+    for (int j = 0; j < 16 / RPP; ++j) {
+        const int k = min(k0 + tid / TPR + RPP * j, kend - 1);
+        const f4 v = *(const f4 *)(P + (conv_rowbase(cg, k) + coloff));
+        r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w;
+    }
+}
+
 // staging registers -> LDS image, out-of-range elements zeroed.  KC image: [idx][k] with a row stride of 20 floats; MC image: [k][idx]
 // with a row stride of BT + 4.  Same thread -> element mapping as gemm_load.
 template <int BT, bool MC, int VEC>
 static __device__ __forceinline__ void gemm_store(const float (&r)[BT / 16], float *__restrict__ S, int idx0, int count, int k0, int kend, int tid) {
     if (!MC) {
-        if (VEC == 4) {
+        if (VEC == 4 && BT == 32) {
+            const float ok = (k0 + (tid & 7) * 2 < kend && idx0 + (tid >> 3) < count) ? 1.f : 0.f;
+            f2 v = {r[0] * ok, r[1] * ok};
+            *(f2 *)(S + (tid >> 3) * (GEMM_BK + 4) + (tid & 7) * 2) = v;
+        } else if (VEC == 4) {
             const float kok = (k0 + (tid & 3) * 4 < kend) ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < BT / 64; ++j) {
@@ -153,8 +215,9 @@ static __device__ __forceinline__ void gemm_frag(float (&f)[4], const float *__r
 // EPI 0: plain store (split-K partial).  1: + bias, activation (act 0 none, 1 ELU(alpha), 2 ReLU).  2: * activation derivative taken from
 // the activation's output yprev (ELU: y > 0 ? 1 : y + alpha; ReLU: y > 0; none: 1).
 // ABL (tools/gemm_probe.hip only): 1 = no global loads / LDS writes after the first tile, 2 = no MFMAs, 3 = no LDS fragment reads
-template <int BA, int BB, bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES, int ABL = 0>
+template <int BA, int BB, bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES, int ABL = 0, int CONV = 0>
 __global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
+    static_assert(CONV == 0 || (CONV == 1 && !B_MC && BV == 4) || (CONV == 2 && A_MC && AV == 4), "window operands are read with 16-byte loads");
     constexpr int TA = BA / 32, TB = BB / 32;
     constexpr int A_TILE = A_MC ? GEMM_BK * (BA + 4) : BA * (GEMM_BK + 4);
     constexpr int B_TILE = B_MC ? GEMM_BK * (BB + 4) : BB * (GEMM_BK + 4);
@@ -199,11 +262,23 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
     // covering the read latency.
     constexpr int NF = (BA * BB >= 128 * 128) ? 1 : 2;
     float af[NF][TA][4], bf[NF][TB][4];
+    uint32_t conv_rb[CONV == 1 ? BB / 64 : 1];
+    uint32_t conv_col = 0;
+    if (CONV == 1) gemm_conv_rows<CONV == 1 ? BB : 64>(conv_rb, g.cg, b_base, g.b_count, tid);
+    if (CONV == 2) conv_col = conv_koff(g.cg, min(a_base + (tid % (BA / 4)) * 4, g.a_count - 4));
+    auto load_a = [&](float (&r)[BA / 16], int k0) {
+        if constexpr (CONV == 2) gemm_load_conv_mc<BA>(r, g.A, conv_col, g.cg, k0, kend, tid);
+        else gemm_load<BA, A_MC, AV>(r, g.A, g.lda, a_base, g.a_count, k0, kend, tid);
+    };
+    auto load_b = [&](float (&r)[BB / 16], int k0) {
+        if constexpr (CONV == 1) gemm_load_conv_kc<BB>(r, g.B, conv_rb, g.cg, k0, kend, tid);
+        else gemm_load<BB, B_MC, BV>(r, g.B, g.ldb, b_base, g.b_count, k0, kend, tid);
+    };
     if (T > 0) {
-        gemm_load<BA, A_MC, AV>(sa[0], g.A, g.lda, a_base, g.a_count, kbeg, kend, tid);
-        gemm_load<BB, B_MC, BV>(sb[0], g.B, g.ldb, b_base, g.b_count, kbeg, kend, tid);
-        gemm_load<BA, A_MC, AV>(sa[1], g.A, g.lda, a_base, g.a_count, kbeg + GEMM_BK, kend, tid);
-        gemm_load<BB, B_MC, BV>(sb[1], g.B, g.ldb, b_base, g.b_count, kbeg + GEMM_BK, kend, tid);
+        load_a(sa[0], kbeg);
+        load_b(sb[0], kbeg);
+        load_a(sa[1], kbeg + GEMM_BK);
+        load_b(sb[1], kbeg + GEMM_BK);
         gemm_store<BA, A_MC, AV>(sa[0], lds, a_base, g.a_count, kbeg, kend, tid);
         gemm_store<BB, B_MC, BV>(sb[0], lds + A_TILE, b_base, g.b_count, kbeg, kend, tid);
     }
@@ -236,8 +311,8 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
         constexpr int P = decltype(ptag)::value, Q = P ^ 1;
         if (ABL != 1) {       // unconditional, also past the last tile (clamped addresses, result unused): a load inside `if (t + 2 < T)` makes
                               // hipcc count the waits of the stores below for the path that did NOT issue it, i.e. drain the new loads too
-            gemm_load<BA, A_MC, AV>(sa[P], g.A, g.lda, a_base, g.a_count, kbeg + (t + 2) * GEMM_BK, kend, tid);
-            gemm_load<BB, B_MC, BV>(sb[P], g.B, g.ldb, b_base, g.b_count, kbeg + (t + 2) * GEMM_BK, kend, tid);
+            load_a(sa[P], kbeg + (t + 2) * GEMM_BK);
+            load_b(sb[P], kbeg + (t + 2) * GEMM_BK);
         }
         __builtin_amdgcn_sched_barrier(0);        // the loads stay in front of the MFMAs ...
         const bool do_ones = ones_wave && (t % g.na) == at;
@@ -388,10 +463,10 @@ extern thread_local char qa_err_buf[512];
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-// tile configuration: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64, 3 = 64 x 128 (A side x B side)
+// tile configuration: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64, 3 = 64 x 128, 4 = 32 x 128 (A side x B side; 4: window GEMMs with <= 32 outputs)
 static void tile_dims(int cfg, int *ba, int *bb) {
-    *ba = (cfg == 0 || cfg == 1) ? 128 : 64;
-    *bb = (cfg == 0 || cfg == 3) ? 128 : 64;
+    *ba = (cfg == 0 || cfg == 1) ? 128 : (cfg == 4 ? 32 : 64);
+    *bb = (cfg == 0 || cfg == 3 || cfg == 4) ? 128 : 64;
 }
 
 template <bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES>
@@ -406,6 +481,16 @@ static void gemm_launch_v(int cfg, GemmArgs &g, hipStream_t st) {
     case 2: hipLaunchKernelGGL((qa_gemm_kernel<64, 64, A_MC, B_MC, AV, BV, EPI, ONES>), grid, dim3(256), 0, st, g); break;
     default: hipLaunchKernelGGL((qa_gemm_kernel<64, 128, A_MC, B_MC, AV, BV, EPI, ONES>), grid, dim3(256), 0, st, g); break;
     }
+}
+template <bool A_MC, bool B_MC, int EPI, bool ONES, int CONV>
+static void gemm_launch_conv(int cfg, GemmArgs &g, hipStream_t st) {
+    int ba, bb; tile_dims(cfg, &ba, &bb);
+    g.na = (g.a_count + ba - 1) / ba;
+    g.nb = (g.b_count + bb - 1) / bb;
+    const dim3 grid((unsigned)(g.na * g.nb * g.nsplit));
+    if (cfg == 2) hipLaunchKernelGGL((qa_gemm_kernel<64, 64, A_MC, B_MC, 4, 4, EPI, ONES, 0, CONV>), grid, dim3(256), 0, st, g);
+    else if (cfg == 3) hipLaunchKernelGGL((qa_gemm_kernel<64, 128, A_MC, B_MC, 4, 4, EPI, ONES, 0, CONV>), grid, dim3(256), 0, st, g);
+    else if constexpr (!A_MC) hipLaunchKernelGGL((qa_gemm_kernel<32, 128, A_MC, B_MC, 4, 4, EPI, ONES, 0, CONV>), grid, dim3(256), 0, st, g);
 }
 template <bool A_MC, bool B_MC, int EPI, bool ONES>
 static void gemm_launch(int cfg, GemmArgs &g, hipStream_t st) {
@@ -536,6 +621,105 @@ int qa_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int6
                        (const float *)nullptr, (int64_t)0, 0, (int64_t)0, out, (float *)nullptr, v4 ? 4 : 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_slab_sum: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+}  // extern "C"
+
+// ---- convolutions over channels-last images (the depth student's second convolution) ----
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+static bool conv_geom(ConvGeom *c, int64_t n_img, int ih, int iw, int cin, int kh, int kw) {
+    const int oh = ih - kh + 1, ow = iw - kw + 1;
+    if (n_img <= 0 || cin < 16 || (cin & (cin - 1)) || kh < 1 || kw < 2 || oh < 1 || ow < 2) return false;
+    const int64_t opix = (int64_t)oh * ow, ipix = (int64_t)ih * iw;
+    if (opix <= 256 || n_img * opix > INT32_MAX || n_img * ipix * cin >= ((int64_t)1 << 32)) return false;
+    c->opix = (int)opix; c->ow = ow; c->iw = iw; c->ipix = (int)ipix; c->cin = cin; c->cs = ilog2(cin); c->kw = kw;
+    c->m_opix = (uint32_t)((((uint64_t)1 << 40) + opix - 1) / opix);
+    c->m_ow = (uint32_t)((((uint64_t)1 << 32) + ow - 1) / ow);
+    c->m_kw = (uint32_t)((((uint64_t)1 << 32) + kw - 1) / kw);
+    return true;
+}
+// mode 0: y = act(conv(x, w) + bias);  mode 1: y = conv(x, w) * act'(deriv_of)
+static int conv_forward_like(const char *who, int mode, const float *x, const float *w, const float *bias, const float *deriv_of, float *y, int64_t n_img,
+                             int ih, int iw, int cin, int kh, int kw, int cout, int act, float alpha, void *stream) {
+    GemmArgs g = {};
+    if (!x || !w || !y || cout <= 0 || cout % 4 || act < 0 || act > 2 || !conv_geom(&g.cg, n_img, ih, iw, cin, kh, kw) || !aligned16(x) || !aligned16(w) ||
+        !aligned16(y) || (bias && !aligned16(bias)) || (deriv_of && !aligned16(deriv_of)) || (mode == 1 && act != 0 && !deriv_of)) {
+        snprintf(g_gerr, sizeof(g_gerr), "%s: bad argument (channels-last fp32, 16-byte aligned, in channels a power of two >= 16, out channels a multiple of 4, "
+                 "more than 256 output pixels per image)", who); return QA_E_ARG; }
+    const int kred = kh * kw * cin;
+    g.A = w; g.lda = kred; g.a_count = cout;
+    g.B = x; g.ldb = 0; g.b_count = (int)(n_img * g.cg.opix);
+    g.kred = kred; g.k_per_split = kred; g.nsplit = 1;
+    g.out = y; g.ldo = cout; g.bias = bias; g.yprev = (mode == 1 && act) ? deriv_of : nullptr; g.ldy = cout; g.act = act; g.alpha = alpha;
+    g.a_vec = g.b_vec = g.o_vec = 4;
+    int cfg = cout <= 32 ? 4 : (((int64_t)((cout + 63) / 64) * ((g.b_count + 127) / 128) >= 512) ? 3 : 2);
+    if (g_force_cfg >= 2 && g_force_cfg <= 4) cfg = g_force_cfg;
+    if (mode == 0) gemm_launch_conv<false, false, 1, false, 1>(cfg, g, (hipStream_t)stream);
+    else gemm_launch_conv<false, false, 2, false, 1>(cfg, g, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "%s: %s", who, hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+static void conv_wgrad_plan(int64_t pixels, int kred, int cout, int *nsplit, int *k_per_split) {
+    const int64_t tiles = (int64_t)((kred + 63) / 64) * ((cout + 63) / 64);
+    int64_t s = 1024 / tiles;
+    const int64_t smax = (pixels + 1023) / 1024;
+    if (s > smax) s = smax;
+    if (s > 192) s = 192;
+    if (s < 1) s = 1;
+    int64_t kps = ((pixels + s - 1) / s + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    s = (pixels + kps - 1) / kps;
+    *nsplit = (int)s; *k_per_split = (int)kps;
+}
+
+extern "C" {
+
+int qa_conv_nhwc_forward(const float *x, const float *weight, const float *bias, float *y, int64_t n_img, int32_t ih, int32_t iw, int32_t cin,
+                         int32_t kh, int32_t kw, int32_t cout, int32_t act, float alpha, void *stream) {
+    return conv_forward_like("qa_conv_nhwc_forward", 0, x, weight, bias, nullptr, y, n_img, ih, iw, cin, kh, kw, cout, act, alpha, stream);
+}
+
+int qa_conv_nhwc_backward_input(const float *grad_padded, const float *weight_flipped, const float *x_act, float *grad_in, int64_t n_img, int32_t ihp,
+                                int32_t iwp, int32_t cout, int32_t kh, int32_t kw, int32_t cin, int32_t act_prev, float alpha, void *stream) {
+    return conv_forward_like("qa_conv_nhwc_backward_input", 1, grad_padded, weight_flipped, nullptr, x_act, grad_in, n_img, ihp, iwp, cout, kh, kw, cin,
+                             act_prev, alpha, stream);
+}
+
+int64_t qa_conv_nhwc_backward_weight_scratch_bytes(int64_t n_img, int32_t ih, int32_t iw, int32_t cin, int32_t kh, int32_t kw, int32_t cout) {
+    ConvGeom c;
+    if (cout <= 0 || !conv_geom(&c, n_img, ih, iw, cin, kh, kw)) return 0;
+    const int kred = kh * kw * cin;
+    int s, kps; conv_wgrad_plan(n_img * c.opix, kred, cout, &s, &kps);
+    const int64_t na = (kred + 63) / 64;
+    return (int64_t)s * (pad4((int64_t)kred * cout) + na * pad4(cout)) * 4;
+}
+
+int qa_conv_nhwc_backward_weight(const float *x, const float *grad_out, float *grad_weight, float *grad_bias, int64_t n_img, int32_t ih, int32_t iw,
+                                 int32_t cin, int32_t kh, int32_t kw, int32_t cout, void *scratch, int64_t scratch_bytes, void *stream) {
+    GemmArgs g = {};
+    if (!x || !grad_out || !grad_weight || !grad_bias || !scratch || cout <= 0 || cout % 4 || !conv_geom(&g.cg, n_img, ih, iw, cin, kh, kw) || !aligned16(x) ||
+        !aligned16(grad_out) || !aligned16(grad_weight)) { snprintf(g_gerr, sizeof(g_gerr), "qa_conv_nhwc_backward_weight: bad argument"); return QA_E_ARG; }
+    if (scratch_bytes < qa_conv_nhwc_backward_weight_scratch_bytes(n_img, ih, iw, cin, kh, kw, cout) || !aligned16(scratch)) {
+        snprintf(g_gerr, sizeof(g_gerr), "qa_conv_nhwc_backward_weight: scratch too small or not 16-byte aligned"); return QA_E_ARG; }
+    const int kred = kh * kw * cin;
+    const int64_t pixels = n_img * g.cg.opix;
+    int s, kps; conv_wgrad_plan(pixels, kred, cout, &s, &kps);
+    const int64_t n_w = (int64_t)kred * cout, n_w_pad = pad4(n_w), n_b_pad = pad4(cout), na = (kred + 63) / 64;
+    float *bslabs = (float *)scratch + (int64_t)s * n_w_pad;
+    g.A = x; g.lda = 0; g.a_count = kred;                                  // window matrix, element ((tap, channel) a, pixel k)
+    g.B = grad_out; g.ldb = cout; g.b_count = cout;                        // MC: element (out channel b, pixel k) = g[k * cout + b]
+    g.kred = (int)pixels; g.k_per_split = kps; g.nsplit = s;
+    g.out = (float *)scratch; g.ldo = kred; g.out_split_stride = n_w_pad;
+    g.ones_out = bslabs; g.ones_split_stride = n_b_pad;
+    g.a_vec = g.b_vec = g.o_vec = 4;
+    hipStream_t st = (hipStream_t)stream;
+    gemm_launch_conv<true, true, 0, true, 2>(2, g, st);
+    const int64_t nthreads = (n_w + 3) / 4 + (cout + 3) / 4;
+    hipLaunchKernelGGL(qa_slab_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, (const float *)scratch, n_w_pad, s, n_w,
+                       (const float *)bslabs, n_b_pad, (int)(s * na), (int64_t)cout, grad_weight, grad_bias, 4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_conv_nhwc_backward_weight: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

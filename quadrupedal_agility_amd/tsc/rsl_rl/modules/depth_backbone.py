@@ -1,11 +1,13 @@
 """Depth encoder of the vision student (tsc/rsl_rl/modules/depth_backbone.py:7-109): `DepthOnlyFCBackbone58x87` (conv 5x5 x 32,
 max-pool 2, conv 3x3 x 64, two linears -> 32-d latent) inside `RecurrentDepthBackbone` (latent + proprioception -> MLP -> GRU(512)
 -> [latent 32 | delta yaws 2 | softmax obstacle class 6]) with its BYOL head.  Module and parameter names are the reference's.
-Convolutions and the GRU go through MIOpen / rocBLAS (plumbing here; the env-side hot op of this path is the depth ray-cast,
-csrc/qa_depth.hip)."""
+On a GPU the image stem (both convolutions, the pool and their ELUs, forward and backward) runs on the hand-written kernels of
+csrc/qa_conv.hip / qa_gemm.hip through `depth_stem` (r3; MIOpen's per-process kernel search made the iteration time a lottery); the
+linears and the GRU stay library calls.  The env-side hot op of this path is the depth ray-cast, csrc/qa_depth.hip."""
 import torch
 import torch.nn as nn
 
+from . import depth_stem
 from .byol import BYOL
 
 
@@ -30,6 +32,8 @@ class DepthOnlyFCBackbone58x87(nn.Module):
     def forward(self, images):
         if self.augment:
             images = self.augment(images.clone())
+        if depth_stem.ENABLED and images.is_cuda and images.dim() == 3 and depth_stem.stem_matches(self.image_compression):
+            return self.output_activation(depth_stem.image_compression(self.image_compression, images))
         return self.output_activation(self.image_compression(images.unsqueeze(1)))
 
 

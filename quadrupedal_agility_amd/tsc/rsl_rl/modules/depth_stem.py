@@ -1,0 +1,161 @@
+"""The image stem of `DepthOnlyFCBackbone58x87` (tsc/rsl_rl/modules/depth_backbone.py:63-75) on the hand-written kernels of
+csrc/qa_conv.hip / csrc/qa_gemm.hip: Conv2d(1, 32, 5) -> MaxPool2d(2, 2) -> ELU -> Conv2d(32, 64, 3) -> ELU -> Flatten as ONE autograd
+node over channels-last activations (forward 2 launches, backward 6).  The modules keep the reference's parameters and layouts (state
+dicts load either way); the layout change is absorbed where the flattened activation meets the first Linear: its weight is read through a
+(c, y, x) -> (y, x, c) permutation (differentiable, so its gradient lands in the reference's layout).
+
+The calls go through the C ABI (include/qa_sim.h, ABI 12); there is no fallback: on a GPU the stem either runs these kernels or raises.
+`ENABLED = False` (tests) sends the encoder through the aten / MIOpen modules for comparison."""
+import ctypes as C
+
+import torch
+
+from quadrupedal_agility_amd import _capi
+
+ENABLED = True
+_scratch = {}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc}: {_capi.load_library().qa_last_error().decode()}")
+
+
+def _scratch_for(dev, nbytes):
+    """per device AND stream: two encoders running on two streams must not share partial sums"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _scratch[key] = buf
+    return buf
+
+
+def stem_forward_raw(images, w1, b1, alpha=1.0):
+    """(ELU(maxpool(conv5x5 + b)) channels-last [n][ph][pw][32], the pool's argmax bytes)"""
+    lib = _capi.load_library()
+    n, ih, iw = images.shape
+    ph, pw = (ih - 4) // 2, (iw - 4) // 2
+    y = torch.empty(n, ph, pw, 32, dtype=torch.float32, device=images.device)
+    am = torch.empty(n, ph, pw, 32, dtype=torch.uint8, device=images.device)
+    _check(lib.qa_depth_stem_forward(_ptr(images), _ptr(w1), _ptr(b1), _ptr(y), _ptr(am), n, ih, iw, float(alpha), _stream(images)), "qa_depth_stem_forward")
+    return y, am
+
+
+def stem_backward_raw(images, argmax, grad_pre):
+    lib = _capi.load_library()
+    n, ih, iw = images.shape
+    nb = lib.qa_depth_stem_backward_scratch_bytes()
+    sc = _scratch_for(images.device, nb)
+    out = torch.empty(832, dtype=torch.float32, device=images.device)
+    _check(lib.qa_depth_stem_backward(_ptr(images), _ptr(argmax), _ptr(grad_pre), _ptr(out), n, ih, iw, _ptr(sc), sc.numel(), _stream(images)), "qa_depth_stem_backward")
+    return out
+
+
+def conv_forward_raw(x, w_khwc, bias, act, alpha=1.0):
+    """act(conv(x, w) + bias): x [n][ih][iw][cin] channels-last, w [cout][kh][kw][cin]"""
+    lib = _capi.load_library()
+    n, ih, iw, cin = x.shape
+    cout, kh, kw, _ = w_khwc.shape
+    y = torch.empty(n, ih - kh + 1, iw - kw + 1, cout, dtype=torch.float32, device=x.device)
+    _check(lib.qa_conv_nhwc_forward(_ptr(x), _ptr(w_khwc), _ptr(bias) if bias is not None else None, _ptr(y), n, ih, iw, cin, kh, kw, cout, int(act), float(alpha),
+                                    _stream(x)), "qa_conv_nhwc_forward")
+    return y
+
+
+def conv_backward_input_raw(g_padded, w_flipped, x_act, act_prev, alpha=1.0):
+    """conv(g_padded, w_flipped) * act'(x_act): g_padded [n][oh + 2 (kh-1)][ow + 2 (kw-1)][cout], w_flipped [cin][kh][kw][cout]"""
+    lib = _capi.load_library()
+    n, ihp, iwp, cout = g_padded.shape
+    cin, kh, kw, _ = w_flipped.shape
+    gin = torch.empty(n, ihp - kh + 1, iwp - kw + 1, cin, dtype=torch.float32, device=g_padded.device)
+    _check(lib.qa_conv_nhwc_backward_input(_ptr(g_padded), _ptr(w_flipped), _ptr(x_act) if x_act is not None else None, _ptr(gin), n, ihp, iwp, cout, kh, kw, cin,
+                                           int(act_prev if x_act is not None else 0), float(alpha), _stream(g_padded)), "qa_conv_nhwc_backward_input")
+    return gin
+
+
+def conv_backward_weight_raw(x, g, kh, kw):
+    """(d loss / d w [cout][kh][kw][cin], d loss / d bias [cout]) from x [n][ih][iw][cin] and g [n][oh][ow][cout]"""
+    lib = _capi.load_library()
+    n, ih, iw, cin = x.shape
+    cout = g.shape[3]
+    nb = lib.qa_conv_nhwc_backward_weight_scratch_bytes(n, ih, iw, cin, kh, kw, cout)
+    sc = _scratch_for(x.device, nb)
+    gw = torch.empty(cout, kh, kw, cin, dtype=torch.float32, device=x.device)
+    gb = torch.empty(cout, dtype=torch.float32, device=x.device)
+    _check(lib.qa_conv_nhwc_backward_weight(_ptr(x), _ptr(g), _ptr(gw), _ptr(gb), n, ih, iw, cin, kh, kw, cout, _ptr(sc), sc.numel(), _stream(x)),
+           "qa_conv_nhwc_backward_weight")
+    return gw, gb
+
+
+def elu_backward_pad_raw(g, y, pad, act=1, alpha=1.0):
+    """(g * act'(y), the same with a zero border of `pad` pixels), both channels-last"""
+    lib = _capi.load_library()
+    n, oh, ow, c = y.shape
+    dy = torch.empty_like(y)
+    dyp = torch.empty(n, oh + 2 * pad, ow + 2 * pad, c, dtype=torch.float32, device=y.device)
+    _check(lib.qa_elu_backward_pad(_ptr(g), _ptr(y), _ptr(dy), _ptr(dyp), n, oh, ow, c, int(pad), int(act), float(alpha), _stream(y)), "qa_elu_backward_pad")
+    return dy, dyp
+
+
+class _ImageStem(torch.autograd.Function):
+    """images [n][58][87] -> ELU(conv3x3(ELU(maxpool(conv5x5)))) flattened channels-last, [n][25 * 39 * 64]"""
+
+    @staticmethod
+    def forward(ctx, images, w1, b1, w2, b2, alpha1, alpha2):
+        images = images.contiguous().float()
+        w2k = w2.detach().permute(0, 2, 3, 1).contiguous()                 # [64][3][3][32]
+        y1, am = stem_forward_raw(images, w1.detach().contiguous(), b1.detach().contiguous(), alpha1)
+        y2 = conv_forward_raw(y1, w2k, b2.detach().contiguous(), 1, alpha2)
+        ctx.save_for_backward(images, am, y1, y2, w2)
+        ctx.alphas = (alpha1, alpha2)
+        return y2.view(y2.shape[0], -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        images, am, y1, y2, w2 = ctx.saved_tensors
+        a1, a2 = ctx.alphas
+        kh, kw = w2.shape[2], w2.shape[3]
+        g = g.contiguous().view_as(y2)
+        dy, dyp = elu_backward_pad_raw(g, y2, kh - 1, 1, a2)
+        gw2k, gb2 = conv_backward_weight_raw(y1, dy, kh, kw)
+        w2f = w2.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()       # [32][3][3][64]: w2f[c][ky][kx][o] = w2[o][c][2-ky][2-kx]
+        gpre1 = conv_backward_input_raw(dyp, w2f, y1, 1, a1)
+        gwb = stem_backward_raw(images, am, gpre1)
+        return None, gwb[:800].view(32, 1, 5, 5), gwb[800:], gw2k.permute(0, 3, 1, 2).contiguous(), gb2, None, None
+
+
+def stem_matches(seq):
+    """the reference's image_compression layout: Conv2d(1, 32, 5), MaxPool2d(2, 2), ELU, Conv2d(32, 64, 3), ELU, Flatten, Linear, ..."""
+    import torch.nn as nn
+    m = list(seq)
+    if len(m) < 7:
+        return False
+    c1, mp, e1, c2, e2, fl, fc = m[:7]
+    ok = (isinstance(c1, nn.Conv2d) and c1.in_channels == 1 and c1.out_channels == 32 and c1.kernel_size == (5, 5) and c1.stride == (1, 1) and
+          c1.padding == (0, 0) and c1.bias is not None and isinstance(mp, nn.MaxPool2d) and mp.kernel_size in (2, (2, 2)) and mp.stride in (2, (2, 2)) and
+          isinstance(e1, nn.ELU) and isinstance(c2, nn.Conv2d) and c2.in_channels == 32 and c2.out_channels % 4 == 0 and c2.stride == (1, 1) and
+          c2.padding == (0, 0) and c2.bias is not None and isinstance(e2, nn.ELU) and isinstance(fl, nn.Flatten) and isinstance(fc, nn.Linear))
+    return bool(ok)
+
+
+def image_compression(seq, images):
+    """`seq(images.unsqueeze(1))` for the reference's `image_compression` Sequential, its first six modules on the hand-written stem"""
+    c1, _mp, e1, c2, e2, _fl, fc = list(seq)[:7]
+    flat = _ImageStem.apply(images, c1.weight, c1.bias, c2.weight, c2.bias, float(e1.alpha), float(e2.alpha))
+    n = images.shape[0]
+    oh, ow = flat.shape[1] // c2.out_channels // ((images.shape[2] - 4) // 2 - c2.kernel_size[1] + 1), (images.shape[2] - 4) // 2 - c2.kernel_size[1] + 1
+    # nn.Flatten over (c, y, x) feeds fc in the reference; the stem's rows are (y, x, c): read fc.weight through the same permutation
+    wp = fc.weight.view(fc.out_features, c2.out_channels, oh, ow).permute(0, 2, 3, 1).reshape(fc.out_features, -1)
+    x = torch.nn.functional.linear(flat, wp, fc.bias)
+    for mod in list(seq)[7:]:
+        x = mod(x)
+    return x

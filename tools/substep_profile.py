@@ -6,7 +6,7 @@ from quadrupedal_agility_amd import _capi
 _so = "/tmp/libqa_sim_subprof.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
                        "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-DQA_SUBPROF", *[a for a in sys.argv[1:] if a.startswith("-D")], "-shared", "-fPIC", "-o", _so,
-                       "quadrupedal_agility_amd/csrc/qa_sim.hip", "quadrupedal_agility_amd/csrc/qa_learner.hip", "quadrupedal_agility_amd/csrc/qa_gemm.hip", "quadrupedal_agility_amd/csrc/qa_policy.hip", "quadrupedal_agility_amd/csrc/qa_tsc.hip", "quadrupedal_agility_amd/csrc/qa_depth.hip"])
+                       "quadrupedal_agility_amd/csrc/qa_sim.hip", "quadrupedal_agility_amd/csrc/qa_learner.hip", "quadrupedal_agility_amd/csrc/qa_gemm.hip", "quadrupedal_agility_amd/csrc/qa_conv.hip", "quadrupedal_agility_amd/csrc/qa_policy.hip", "quadrupedal_agility_amd/csrc/qa_tsc.hip", "quadrupedal_agility_amd/csrc/qa_depth.hip"])
 _capi.LIB_PATH = _so
 from tests.oracle_lib import go2_cfg
 from quadrupedal_agility_amd.sim import QaSim
