@@ -57,6 +57,82 @@ def test_fill_polygon_contract():
     assert abs(len(rr) - 400) < 25
 
 
+def _skimage_polygon_rule(rows, cols, shape):
+    """skimage.draw.polygon as scikit-image 0.21.0 (the reference's pin, requirements.txt:5; NOT installed here) publishes it, restated:
+    `_polygon` (skimage/draw/_draw.pyx) visits the pixels of the box [max(0, min), ceil(max)] clipped to `shape` and keeps those for
+    which `point_in_polygon` (skimage/_shared/geometry.pxd) is non-zero.  That test is O'Rourke's InPoly1 (Computational Geometry in C,
+    1998, 7.4): translate the polygon so that the query is the origin; a vertex within 1e-12 -> VERTEX; count the edges that cross the
+    positive x half-axis (strict straddle on y > 0) and those that cross the negative one (strict straddle on y < 0); different parities
+    -> EDGE, odd -> INSIDE, else OUTSIDE.  Vertex, edge and inside pixels are all drawn.  Scalar loops: an independent restatement, not
+    the vectorised crossing-number + on-segment test `fill_polygon` uses."""
+    xp, yp = [float(v) for v in cols], [float(v) for v in rows]
+    r0, r1 = int(max(0, min(yp))), int(np.ceil(max(yp)))
+    c0, c1 = int(max(0, min(xp))), int(np.ceil(max(xp)))
+    r1, c1 = min(r1, shape[0] - 1), min(c1, shape[1] - 1)
+    out = []
+    n = len(xp)
+    for r in range(r0, r1 + 1):
+        for c in range(c0, c1 + 1):
+            x1, y1 = xp[n - 1] - c, yp[n - 1] - r
+            rc = lc = 0
+            code = None
+            for i in range(n):
+                x0, y0 = xp[i] - c, yp[i] - r
+                if -1e-12 < x0 < 1e-12 and -1e-12 < y0 < 1e-12:
+                    code = 2
+                    break
+                if (y0 > 0) != (y1 > 0) and (x0 * y1 - x1 * y0) / (y1 - y0) > 0:
+                    rc += 1
+                if (y0 < 0) != (y1 < 0) and (x0 * y1 - x1 * y0) / (y1 - y0) < 0:
+                    lc += 1
+                x1, y1 = x0, y0
+            if code is None:
+                code = 3 if (rc & 1) != (lc & 1) else (1 if rc & 1 else 0)
+            if code:
+                out.append((r, c))
+    return set(out)
+
+
+def test_fill_polygon_is_the_published_skimage_rule():
+    """the rasterisation rule behind the course (tsc/legged_gym/utils/obstacle.py:151,166 call skimage.draw.polygon): the build's scan
+    fill against the restated library rule on (a) integer rectangles and triangles whose boundary passes through pixel centres,
+    (b) random simple (convex and star-shaped concave) polygons with integer and fractional vertices, (c) EVERY polygon the course generator draws"""
+    rng = np.random.default_rng(0)
+    cases = [([1, 2, 8], [1, 7, 4]), ([1, 1, 4, 4], [2, 6, 6, 2]), ([0, 0, 20, 20], [-5, 3, 3, -5]), ([3, 3, 9, 9, 6], [2, 9, 9, 2, 5]),
+             ([2.5, 2.5, 2.9, 2.9], [2.2, 2.8, 2.8, 2.2]), ([0, 5, 10, 5], [5, 0, 5, 10])]
+    for _ in range(80):                         # SIMPLE polygons (what the generator draws): vertices ordered by angle about an interior point
+        k = int(rng.integers(3, 8))
+        ang = np.sort(rng.random(k) * 2 * np.pi)
+        if np.max(np.diff(np.concatenate([ang, ang[:1] + 2 * np.pi]))) >= np.pi:
+            continue                            # the centre must be inside
+        rad = rng.random(k) * 11 + 2
+        pr, pc = 12 + rad * np.sin(ang), 13 + rad * np.cos(ang)
+        if rng.random() < 0.5:
+            pr, pc = np.round(pr), np.round(pc)     # integer vertices: boundaries through pixel centres
+        cases.append((pr.tolist(), pc.tolist()))
+    for rows, cols in cases:
+        rr, cc = fill_polygon(rows, cols, (26, 28))
+        assert set(zip(rr.tolist(), cc.tolist())) == _skimage_polygon_rule(rows, cols, (26, 28)), (rows, cols)
+    # (c) the generator's own polygons (rotated bars, planks, poles ...)
+    import quadrupedal_agility_amd.tsc.legged_gym.utils.obstacle as ob
+    seen = []
+    real = ob.fill_polygon
+
+    def spy(rows, cols, shape):
+        seen.append((np.asarray(rows, dtype=np.float64).copy(), np.asarray(cols, dtype=np.float64).copy(), tuple(shape)))
+        return real(rows, cols, shape)
+
+    ob.fill_polygon = spy
+    try:
+        Obstacle(_cfg(False), 6, seed=11)
+    finally:
+        ob.fill_polygon = real
+    assert len(seen) >= 6
+    for rows, cols, shape in seen:
+        rr, cc = real(rows, cols, shape)
+        assert set(zip(rr.tolist(), cc.tolist())) == _skimage_polygon_rule(rows, cols, shape), (rows, cols)
+
+
 @pytest.mark.parametrize("curriculum", [False, True])
 def test_shards_build_the_same_course_as_the_one_process_job(curriculum):
     """SURVEY 8e for the task-level tree: rank r of a W-rank job builds envs [r N/W, (r+1) N/W) of the job's ONE course -- the reference's
