@@ -420,6 +420,13 @@ int qa_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t 
 int qa_linear_backward_input(const float *grad_out, int64_t ldg, const float *weight, int64_t ldw, const float *y_prev, int64_t ldyp,
                              float *grad_in, int64_t ldgi, int64_t rows, int32_t in_features, int32_t out_features, int32_t act_prev, float alpha,
                              void *stream);
+/* qa_linear_forward with the reduction (input-feature) dimension split over workgroups and the partial products added in a fixed order
+ * before bias and activation: for layers with few outputs and very long rows (the depth encoder's Linear(62,400, 128),
+ * tsc/rsl_rl/modules/depth_backbone.py:69, has 2 x rows/64 output tiles -- without the split 32-64 workgroups on 256 CUs).
+ * out_features % 4 == 0, ldy % 4 == 0; scratch >= qa_linear_forward_split_scratch_bytes(...), 16-byte aligned.  (ABI 12) */
+int64_t qa_linear_forward_split_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features);
+int qa_linear_forward_split(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
+                            int32_t in_features, int32_t out_features, int32_t act, float alpha, void *scratch, int64_t scratch_bytes, void *stream);
 int64_t qa_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features);
 int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
                               int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream);

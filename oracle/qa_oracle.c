@@ -1579,6 +1579,17 @@ int qo_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
     return QA_OK;
 }
 
+int64_t qo_linear_forward_split_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
+    (void)in_features; return (rows > 0 && out_features > 0) ? 16 : 0;
+}
+/* twin of qa_linear_forward_split: the same layer as qo_linear_forward (the split only changes the summation order on the device) */
+int qo_linear_forward_split(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
+                            int32_t in_features, int32_t out_features, int32_t act, float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes;
+    if (out_features % 4 || ldy % 4) return QA_E_ARG;
+    return qo_linear_forward(x, ldx, weight, ldw, bias, y, ldy, rows, in_features, out_features, act, alpha, stream);
+}
+
 int qo_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int64_t n, float *out, void *stream) {
     (void)stream;
     if (!slabs || !out || num_slabs <= 0 || n <= 0 || slab_stride < n) return QA_E_ARG;

@@ -458,6 +458,32 @@ __global__ void __launch_bounds__(256) qa_slab_reduce_kernel(const float *__rest
     }
 }
 
+// y[r][o] = act( sum over the nsplit slabs (in order) of slabs[z * stride + r * n + o] + bias[o] ): the second half of a forward layer whose
+// reduction dimension was split (few output tiles, very long rows: the depth encoder's 62,400 -> 128 layer)
+__global__ void __launch_bounds__(256) qa_slab_bias_act_kernel(const float *__restrict__ slabs, int64_t stride, int nsplit, int64_t rows, int n,
+                                                               const float *__restrict__ bias, int act, float alpha, float *__restrict__ y, int64_t ldy) {
+    const int n4 = n >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * n4) return;
+    const int64_t r = t / n4;
+    const int o = (int)(t - r * n4) * 4;
+    const float *src = slabs + r * n + o;
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= nsplit; z += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f4 *)(src + (int64_t)(z + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < nsplit; ++z) s += *(const f4 *)(src + (int64_t)z * stride);
+    if (bias) s += *(const f4 *)(bias + o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = act == 1 ? (s[k] > 0.f ? s[k] : alpha * (expf(s[k]) - 1.f)) : (act == 2 ? fmaxf(s[k], 0.f) : s[k]);
+    *(f4 *)(y + r * ldy + o) = s;
+}
+
 extern thread_local char qa_err_buf[512];
 #define g_gerr qa_err_buf
 
@@ -720,6 +746,57 @@ int qa_conv_nhwc_backward_weight(const float *x, const float *grad_out, float *g
                        (const float *)bslabs, n_b_pad, (int)(s * na), (int64_t)cout, grad_weight, grad_bias, 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_conv_nhwc_backward_weight: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+}  // extern "C"
+
+// split of the reduction (input-feature) dimension of a forward layer with few output tiles
+static void fwd_split_plan(int64_t rows, int32_t in_features, int32_t out_features, int *nsplit, int *k_per_split) {
+    const int64_t tiles = ((rows + 63) / 64) * ((out_features + 63) / 64);
+    int64_t s = (1024 + tiles - 1) / tiles;
+    const int64_t smax = in_features / 256;
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    int64_t kps = ((in_features + s - 1) / s + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    s = (in_features + kps - 1) / kps;
+    *nsplit = (int)s; *k_per_split = (int)kps;
+}
+
+extern "C" {
+
+int64_t qa_linear_forward_split_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
+    if (rows <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    int s, kps; fwd_split_plan(rows, in_features, out_features, &s, &kps);
+    return (int64_t)s * pad4(rows * out_features) * 4;
+}
+
+int qa_linear_forward_split(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
+                            int32_t in_features, int32_t out_features, int32_t act, float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!x || !weight || !y || !scratch || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 || out_features % 4 || ldx < in_features ||
+        ldw < in_features || ldy < out_features || ldy % 4 || act < 0 || act > 2 || !aligned16(y) || (bias && !aligned16(bias)) ||
+        rows * ldx >= ((int64_t)1 << 31)) {
+        snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward_split: bad argument (out features and ldy multiples of 4, y / bias 16-byte aligned)"); return QA_E_ARG; }
+    if (scratch_bytes < qa_linear_forward_split_scratch_bytes(rows, in_features, out_features) || !aligned16(scratch)) {
+        snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward_split: scratch too small or not 16-byte aligned"); return QA_E_ARG; }
+    int s, kps; fwd_split_plan(rows, in_features, out_features, &s, &kps);
+    const int64_t n_pad = pad4(rows * out_features);
+    GemmArgs g = {};
+    g.A = weight; g.lda = ldw; g.a_count = out_features;
+    g.B = x; g.ldb = ldx; g.b_count = (int)rows;
+    g.kred = in_features; g.k_per_split = kps; g.nsplit = s;
+    g.out = (float *)scratch; g.ldo = out_features; g.out_split_stride = n_pad;
+    g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
+    g.b_vec = (aligned16(x) && ldx % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
+    g.o_vec = 4;
+    hipStream_t st = (hipStream_t)stream;
+    gemm_launch<false, false, 0, false>(g_force_cfg >= 0 ? g_force_cfg : 2, g, st);
+    const int64_t nthreads = rows * (out_features / 4);
+    hipLaunchKernelGGL(qa_slab_bias_act_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, (const float *)scratch, n_pad, s, rows,
+                       (int)out_features, bias, (int)act, alpha, y, ldy);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward_split: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

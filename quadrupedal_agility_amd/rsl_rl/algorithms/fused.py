@@ -308,6 +308,28 @@ def linear_forward_raw(x, weight, bias, act, alpha=1.0, out=None):
     return y
 
 
+_split_scratch = {}
+
+
+def linear_forward_split_raw(x, weight, bias, act, alpha=1.0):
+    """act(x W^T + b) by qa_linear_forward_split: the reduction dimension split over workgroups (few outputs, very long rows)"""
+    lib = _capi.load_library()
+    x = _rows2d(x)
+    rows, k = x.shape
+    n = weight.shape[0]
+    nb = lib.qa_linear_forward_split_scratch_bytes(rows, k, n)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    sc = _split_scratch.get(key)
+    if sc is None or sc.numel() < nb:
+        sc = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        _split_scratch[key] = sc
+    y = torch.empty(rows, n, dtype=torch.float32, device=x.device)
+    _check(lib.qa_linear_forward_split(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias) if bias is not None else None, _ptr(y), n, rows, k, n,
+                                       int(act), float(alpha), _ptr(sc), sc.numel(), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
+           "qa_linear_forward_split")
+    return y
+
+
 def linear_backward_input_raw(g, weight, y_prev, act_prev, alpha=1.0):
     """(g W) * act'(y_prev) by qa_linear_backward_input: the input gradient of a layer with the previous layer's activation derivative"""
     lib = _capi.load_library()

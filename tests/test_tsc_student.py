@@ -65,6 +65,13 @@ def test_parameter_names_are_the_references():
     assert enc.state_dict()["output_mlp.0.weight"].shape == (40, 512) and enc.state_dict()["base_backbone.image_compression.6.weight"].shape == (128, 64 * 25 * 39)
 
 
+def _probe_after_one_adam_step(a, b, k):
+    """parameter probes (entries | sum | abs-sum | numel) of tensors trained by ONE Adam step at lr 1e-3, device vs the CPU fixture"""
+    np.testing.assert_allclose(a[:, :3], b[:, :3], rtol=5e-3, atol=5e-3, err_msg=k)
+    allow = 5e-3 * np.abs(b[:, 3:5]) + 5e-3 + 2e-6 * b[:, 5:6]
+    assert np.all(np.abs(a[:, 3:5] - b[:, 3:5]) <= allow), k
+
+
 @pytest.mark.gpu
 def test_student_protocol_on_the_gpu_matches_reference_golden():
     """the same protocol with every module and input on the device (the hand-written image stem of csrc/qa_conv.hip / qa_gemm.hip, rocBLAS
@@ -82,11 +89,17 @@ def test_student_protocol_on_the_gpu_matches_reference_golden():
             np.testing.assert_allclose(a[:, 3:5], b[:, 3:5], rtol=5e-2, atol=5e-2, err_msg=k)
         elif k == "probe_encoder_after":
             byol = np.array([n.startswith(("base_backbone.", "byol_learner.")) for n in names])
-            np.testing.assert_allclose(a[~byol], b[~byol], rtol=5e-3, atol=5e-3, err_msg=k)
+            # single entries at 5e-3; the sums get 2 lr x 0.1 % of the tensor's elements on top: the first Adam step moves EVERY element by
+            # +-lr = 1e-3 whatever its gradient's size, so the few elements whose gradient is ~0 may step the other way under another
+            # summation order (r3, split 62,400 -> 128 layer: one signed sum of a 786 k-element tensor off by 0.099 = ~50 elements; a wrong
+            # gradient would flip about half of them, 400 x this allowance)
+            _probe_after_one_adam_step(a[~byol], b[~byol], k)
             # |sum| within 5 %; the SIGNED sum on the scale of |sum| (it cancels: N elements moved by +-lr each change it by ~lr sqrt(N), which is
             # not small against a sum that happens to be near zero -- r3's stem moved one of 68 such sums by 0.13 at |sum| = 80)
             np.testing.assert_allclose(a[byol][:, 4], b[byol][:, 4], rtol=5e-2, atol=5e-2, err_msg=k)
             assert np.all(np.abs(a[byol][:, 3] - b[byol][:, 3]) <= 5e-2 * np.abs(b[byol][:, 3]) + 5e-2 + 5e-3 * b[byol][:, 4]), k
+        elif k == "probe_actor_after":
+            _probe_after_one_adam_step(a, b, k)
         else:
             tol = 2e-3 if k.startswith(("probe", "update", "byol_loss")) else 1e-4
             np.testing.assert_allclose(a, b, rtol=tol, atol=tol, err_msg=k)
