@@ -573,6 +573,19 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
                  int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
                  float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* Tail of a discriminator step (bbc/rsl_rl/algorithms/gail.py:486-504, 520-533): the logged values that are sums of squares, assembled with
+ * qa_disc_loss's head statistics into the 11 values update_ss_info_gail returns
+ *   out = {ss, info_max, disc, us  (head_stats[1..4]),  sum(input_grad^2) / grad_rows  (gradient penalty),  sum(weights[last]^2)  (logit
+ *          regulariser),  sum over all weights of sum(w^2)  (weight decay),  acc_lb, acc_pi, acc_exp, acc_ulb  (head_stats[5..8])}
+ * and, if given, acc[0..10] += out and *step_counter += 1 (the recorded step's accumulator and device-side step counter).  One launch, partial
+ * sums added in a fixed order.  `weights` / `weight_counts` are HOST arrays of 1..7 device pointers / element counts.  `scratch`:
+ * qa_disc_step_tail_scratch_bytes() bytes, 16-byte aligned, ZEROED once by the caller (it holds the arrival counter, which the kernel
+ * leaves at zero).  (ABI 12) */
+int64_t qa_disc_step_tail_scratch_bytes(void);
+int qa_disc_step_tail(const float *head_stats, const float *input_grad, int64_t grad_rows, int32_t grad_cols, const float *const *weights,
+                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, void *scratch,
+                      int64_t scratch_bytes, void *stream);
+
 /* Discriminator input preparation (bbc/rsl_rl/algorithms/discriminator.py:77-87, utils.py:97-103): 1..3 row-major
  * (rows[i], dim) fp32 device batches are written one under the other into out (sum rows, dim):
  *   y = ((x * (task_mask[c] ? *task_weight_dev : 1)) * frame_mult[c] - (float)mean[c]) / sqrt((float)(var[c] + epsilon)), clipped to +-clip

@@ -1590,6 +1590,27 @@ int qo_linear_forward_split(const float *x, int64_t ldx, const float *weight, in
     return qo_linear_forward(x, ldx, weight, ldw, bias, y, ldy, rows, in_features, out_features, act, alpha, stream);
 }
 
+int64_t qo_disc_step_tail_scratch_bytes(void) { return 16; }
+/* twin of qa_disc_step_tail (bbc/rsl_rl/algorithms/gail.py:486-504, 520-533): double sums */
+int qo_disc_step_tail(const float *head_stats, const float *input_grad, int64_t grad_rows, int32_t grad_cols, const float *const *weights,
+                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, void *scratch,
+                      int64_t scratch_bytes, void *stream) {
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    if (!head_stats || !input_grad || grad_rows <= 0 || grad_cols <= 0 || !weights || !weight_counts || num_weights <= 0 || num_weights > 7 || !out) return QA_E_ARG;
+    double gp = 0.0, wd = 0.0, last = 0.0;
+    for (int64_t i = 0; i < grad_rows * grad_cols; ++i) gp += (double)input_grad[i] * input_grad[i];
+    for (int t = 0; t < num_weights; ++t) {
+        double s = 0.0;
+        for (int64_t i = 0; i < weight_counts[t]; ++i) s += (double)weights[t][i] * weights[t][i];
+        wd += s; last = s;
+    }
+    float o[11] = {head_stats[1], head_stats[2], head_stats[3], head_stats[4], (float)(gp * (double)(1.0f / (float)grad_rows)), (float)last, (float)wd,
+                   head_stats[5], head_stats[6], head_stats[7], head_stats[8]};
+    for (int k = 0; k < 11; ++k) { out[k] = o[k]; if (acc) acc[k] += o[k]; }
+    if (step_counter) step_counter[0] += 1;
+    return QA_OK;
+}
+
 int qo_slab_sum(const float *slabs, int64_t slab_stride, int32_t num_slabs, int64_t n, float *out, void *stream) {
     (void)stream;
     if (!slabs || !out || num_slabs <= 0 || n <= 0 || slab_stride < n) return QA_E_ARG;

@@ -891,6 +891,61 @@ __global__ void qa_disc_finish_kernel(const float *partial, int nblocks, int b_l
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Tail of a discriminator step: the logged values that are sums of squares -- gradient penalty sum g^2 / rows (gail.py:486-492), logit
+// regulariser |W_out|^2 and weight decay sum |W_i|^2 (:497-504) -- assembled with the head statistics of qa_disc_loss into the 11 values
+// update_ss_info_gail returns, added to the update's accumulator, and the device-side step counter of the recorded step bumped.  Eager
+// PyTorch: pow + sum + div, _foreach_norm (2 launches) + stack + pow + sum + index, stack of 11 scalars, add, counter add = 13 launches
+// of a step that is a chain of ~75 launch-latency-sized kernels.  16 workgroups per tensor write partial sums; the last one to arrive
+// (ticket) adds them in index order: fixed order, bit-reproducible.
+constexpr int TAIL_MAX = 8, TAIL_WG = 16;
+struct TailArgs { const float *t[TAIL_MAX]; int64_t n[TAIL_MAX]; int nt; const float *hs; float inv_rows; float *out, *acc; int64_t *step; float *partial; unsigned *ticket; };
+
+__global__ void __launch_bounds__(256) qa_disc_step_tail_kernel(TailArgs a) {
+    __shared__ float red[256];
+    __shared__ bool last;
+    const int ti = blockIdx.x / TAIL_WG, w = blockIdx.x % TAIL_WG, tid = threadIdx.x;
+    const float *p = a.t[ti];
+    const int64_t n = a.n[ti];
+    const int64_t per = ((n + TAIL_WG - 1) / TAIL_WG + 3) & ~(int64_t)3, lo = w * per, hi = lo + per < n ? lo + per : n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (((uintptr_t)p & 15) == 0) {
+        int64_t i = lo + 4 * tid;
+        for (; i + 3 < hi; i += 1024) { const float4 v = *(const float4 *)(p + i); s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3); }
+        for (; i < hi; ++i) s0 = fmaf(p[i], p[i], s0);          // the tensor's last (< 4) elements: one thread
+    } else {
+        for (int64_t i = lo + tid; i < hi; i += 256) s0 = fmaf(p[i], p[i], s0);
+    }
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    if (tid == 0) {
+        a.partial[blockIdx.x] = red[0];
+        __threadfence();
+        last = atomicAdd(a.ticket, 1u) == (unsigned)(a.nt * TAIL_WG - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (tid == 0) {
+        double tot[TAIL_MAX];
+        for (int t = 0; t < a.nt; ++t) {
+            double s = 0.0;
+            for (int k = 0; k < TAIL_WG; ++k) s += (double)__hip_atomic_load(a.partial + t * TAIL_WG + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot[t] = s;
+        }
+        double wd = 0.0;
+        for (int t = 1; t < a.nt; ++t) wd += tot[t];
+        float o[11];
+        o[0] = a.hs[1]; o[1] = a.hs[2]; o[2] = a.hs[3]; o[3] = a.hs[4];
+        o[4] = (float)(tot[0] * (double)a.inv_rows); o[5] = (float)tot[a.nt - 1]; o[6] = (float)wd;
+        o[7] = a.hs[5]; o[8] = a.hs[6]; o[9] = a.hs[7]; o[10] = a.hs[8];
+        for (int k = 0; k < 11; ++k) { a.out[k] = o[k]; if (a.acc) a.acc[k] += o[k]; }
+        if (a.step) a.step[0] += 1;
+        *a.ticket = 0u;                 // ready for the next launch (replays of a recorded step included)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Discriminator input preparation (bbc/rsl_rl/algorithms/discriminator.py:77-87 + utils.py:97-103) for up to three
 // (rows_i, dim) batches written one under the other into one (sum rows_i, dim) matrix:
 //   y = clamp(((x * (task_mask ? w : 1)) * frame_mult - (float)mean) / sqrt((float)(var + eps)), -clip, clip)
@@ -1178,6 +1233,29 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
     hipLaunchKernelGGL(qa_disc_finish_kernel, dim3(1), dim3(64), 0, st, (const float *)scratch, blocks, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int64_t qa_disc_step_tail_scratch_bytes(void) { return (int64_t)(TAIL_MAX * TAIL_WG + 4) * 4; }
+
+int qa_disc_step_tail(const float *head_stats, const float *input_grad, int64_t grad_rows, int32_t grad_cols, const float *const *weights,
+                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, void *scratch,
+                      int64_t scratch_bytes, void *stream) {
+    if (!head_stats || !input_grad || grad_rows <= 0 || grad_cols <= 0 || !weights || !weight_counts || num_weights <= 0 || num_weights > TAIL_MAX - 1 ||
+        !out || !scratch || scratch_bytes < qa_disc_step_tail_scratch_bytes() || ((uintptr_t)scratch & 15)) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_disc_step_tail: bad argument (1..%d weight tensors, scratch >= qa_disc_step_tail_scratch_bytes(), zeroed once)", TAIL_MAX - 1);
+        return QA_E_ARG; }
+    TailArgs a{};
+    a.t[0] = input_grad; a.n[0] = grad_rows * grad_cols;
+    for (int i = 0; i < num_weights; ++i) {
+        if (!weights[i] || weight_counts[i] <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_step_tail: empty weight tensor"); return QA_E_ARG; }
+        a.t[1 + i] = weights[i]; a.n[1 + i] = weight_counts[i];
+    }
+    a.nt = 1 + num_weights; a.hs = head_stats; a.inv_rows = 1.0f / (float)grad_rows; a.out = out; a.acc = acc; a.step = step_counter;
+    a.partial = (float *)scratch; a.ticket = (unsigned *)((float *)scratch + TAIL_MAX * TAIL_WG);
+    hipLaunchKernelGGL(qa_disc_step_tail_kernel, dim3((unsigned)(a.nt * TAIL_WG)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_step_tail: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

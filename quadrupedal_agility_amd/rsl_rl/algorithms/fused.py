@@ -856,6 +856,30 @@ def disc_loss_raw(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, 
     return out, gd.view(d.shape), ge.view(eps.shape), gc.view(c.shape)
 
 
+_tail_scratch = {}
+
+
+def disc_step_tail(head_stats, input_grad, weights, acc=None, step=None):
+    """the 11 logged values of a discriminator step by qa_disc_step_tail (sums of squares of the penalty's input gradient and of the
+    regularised weights + the head statistics), optionally added to `acc` and `step` bumped, in ONE launch"""
+    lib = _capi.load_library()
+    dev = head_stats.device
+    sc = _tail_scratch.get(dev)
+    if sc is None:
+        sc = torch.zeros(int(lib.qa_disc_step_tail_scratch_bytes()), dtype=torch.uint8, device=dev)      # holds the arrival counter: zeroed ONCE
+        _tail_scratch[dev] = sc
+    g = _f32c(input_grad)
+    ws = [w.detach() for w in weights]
+    assert all(w.dtype == torch.float32 and w.is_contiguous() for w in ws)
+    wp = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    wn = (C.c_int64 * len(ws))(*[w.numel() for w in ws])
+    out = torch.empty(11, dtype=torch.float32, device=dev)
+    _check(lib.qa_disc_step_tail(_ptr(head_stats), _ptr(g), g.shape[0], g.numel() // g.shape[0], wp, wn, len(ws), _ptr(out), _ptr(acc) if acc is not None else None,
+                                 _ptr(step) if step is not None else None, _ptr(sc), sc.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+           "qa_disc_step_tail")
+    return out
+
+
 def disc_loss(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, *, c_ss, info_coef_dev, c_disc, c_us):
     return _DiscLoss.apply(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us)
 

@@ -25,6 +25,10 @@ from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam, disc_loss,
 from quadrupedal_agility_amd.rsl_rl.storage import ReplayBuffer, RolloutStorage
 
 
+def _vec11(out):
+    return out if torch.is_tensor(out) else torch.stack(out)
+
+
 class LossReadout:
     """The 17 loss / accuracy means of one update() (same order as the reference's return tuple, gail.py:318-326), still on
     the device: the ONE host read of the update happens when somebody looks at a value (the logger), not at the end of
@@ -274,14 +278,14 @@ class SSInfoGAIL:
                 torch.randint(0, ml.preloaded_s_ulb.shape[0], tabs[2].shape, device=dev, out=tabs[2])
                 for k in range(n_d):
                     i_pi, i_lb, i_ulb = tabs[0][k], tabs[1][k], tabs[2][k]
-                    acc_d += torch.stack(self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
+                    acc_d += _vec11(self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
                                                                   (ml.preloaded_s_lb[i_lb], ml.preloaded_label[i_lb]), ml.preloaded_s_ulb[i_ulb]))
             else:
                 gens = zip(self.disc_storage.feed_forward_generator(n_d, mb),
                            self.motion_loader.feed_forward_generator_lb(n_d, mb),
                            self.motion_loader.feed_forward_generator_ulb(n_d, mb))
                 for s_pi, s_lb, s_ulb in gens:
-                    acc_d += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
+                    acc_d += _vec11(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
         self.storage.clear()
         self.priv_reg_counter += 1
         self._warm_updates += 1
@@ -431,9 +435,10 @@ class SSInfoGAIL:
                         i_pi, i_lb, i_ulb = sel(t_pi), sel(t_lb), sel(t_ulb)
                         s_pi, e_pi, c_pi, s_lb, s_ulb = rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi], ml.preloaded_s_lb[i_lb], ml.preloaded_s_ulb[i_ulb]
                     label = t_lab.index_select(0, self._d_step.view(1)).view(-1)
-                    out = self.update_ss_info_gail((s_pi, e_pi, c_pi), (s_lb, label), s_ulb)
-                    self._acc_d.add_(torch.stack(out))
-                    self._d_step.add_(1)
+                    out = self.update_ss_info_gail((s_pi, e_pi, c_pi), (s_lb, label), s_ulb, acc=self._acc_d, step=self._d_step)
+                    if not self._tail_folded:
+                        self._acc_d.add_(_vec11(out))
+                        self._d_step.add_(1)
                 self._n_samples_dev.fill_(float(rb.num_samples))
                 self._info_max_dev.fill_(float(self.info_max_coef_on))
                 torch.cuda.synchronize()
@@ -460,7 +465,7 @@ class SSInfoGAIL:
                 gens = zip(self.disc_storage.feed_forward_generator(n_steps, mb), self.motion_loader.feed_forward_generator_lb(n_steps, mb),
                            self.motion_loader.feed_forward_generator_ulb(n_steps, mb))
                 for s_pi, s_lb, s_ulb in gens:
-                    acc += torch.stack(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
+                    acc += _vec11(self.update_ss_info_gail(s_pi, s_lb, s_ulb))
                 return acc
         self._n_samples_dev.fill_(float(self.disc_storage.num_samples))
         self._info_max_dev.fill_(float(self.info_max_coef_on))
@@ -649,7 +654,10 @@ class SSInfoGAIL:
             for g in self.optim_ac.param_groups:
                 g["lr"] = self._lr_ac
 
-    def update_ss_info_gail(self, sample_disc_policy, sample_disc_expert_lb, sample_disc_expert_ulb):
+    def update_ss_info_gail(self, sample_disc_policy, sample_disc_expert_lb, sample_disc_expert_ulb, acc=None, step=None):
+        """returns the 11 logged values (a tuple of scalars, or ONE 11-vector from qa_disc_step_tail -- `_vec11` takes either); with `acc` / `step`
+        (the recorded step) the fused tail also adds them to the accumulator and bumps the device-side step counter: `self._tail_folded`"""
+        self._tail_folded = False
         policy_state, policy_eps, policy_c = sample_disc_policy
         expert_lb, label_lb = sample_disc_expert_lb
         expert_ulb = sample_disc_expert_ulb
@@ -732,7 +740,12 @@ class SSInfoGAIL:
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
         if not analytic_gp:
             g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
-        if direct:      # value for the log; its gradient w.r.t. g, 2 c_gp g / rows, is fed to backward() directly
+        reg_w = [m.weight for m in self.disc.trunk.modules() if isinstance(m, nn.Linear)] + [self.disc.linear.weight]
+        fused_tail = direct and len(reg_w) <= 7 and all(w.is_cuda and w.is_contiguous() for w in reg_w)
+        if fused_tail:  # the three sums of squares, the 11-vector, the accumulator and the step counter: one launch at the end of the step
+            gdet = g.detach()
+            grad_pen_loss = None
+        elif direct:    # value for the log; its gradient w.r.t. g, 2 c_gp g / rows, is fed to backward() directly
             with torch.no_grad():
                 gdet = g.detach()
                 grad_pen_loss = gdet.square().sum() / gdet.shape[0]
@@ -741,9 +754,15 @@ class SSInfoGAIL:
         # The two weight regularisers (gail.py:497-504) are functions of the weights alone: c_logit |W_out|^2 + c_wd (|W_1|^2 +
         # |W_2|^2 + |W_out|^2).  On the GPU their values come from one multi-tensor norm and their gradient 2 c W is added to
         # .grad after backward() with one multi-tensor launch, instead of ~15 autograd launches; same numbers.
-        reg_w = [m.weight for m in self.disc.trunk.modules() if isinstance(m, nn.Linear)] + [self.disc.linear.weight]
         fold_reg = fused_heads and all(w.is_cuda for w in reg_w)
-        if fold_reg:
+        if fused_tail:
+            # issued HERE, before the optimiser step below changes the weights it reads
+            with torch.no_grad():
+                out11 = fused_mod.disc_step_tail(hs, gdet, reg_w, acc=acc, step=step)
+            self._tail_folded = acc is not None
+            disc_logit_loss = disc_weight_decay = None
+            rest = None
+        elif fold_reg:
             with torch.no_grad():
                 sq = torch.stack(torch._foreach_norm(reg_w)).square()
                 disc_logit_loss, disc_weight_decay = sq[-1], sq.sum()
@@ -800,6 +819,8 @@ class SSInfoGAIL:
                 self.disc_normalizer.update_from_batch_moments(synced_moments, [b.shape[0] * world for b in norm_batches])
             else:
                 self.disc_normalizer.update_torch(norm_batches)
+        if fused_tail:
+            return out11
         if fused_heads:
             acc_lb, acc_pi, acc_exp, acc_ulb = hs[5], hs[6], hs[7], hs[8]
         else:
