@@ -573,18 +573,39 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
                  int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
                  float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* Sampling front of a discriminator step: what three `feed_forward_generator`s (bbc/rsl_rl/storage/replay_buffer.py:38-47,
+ * bbc/rsl_rl/datasets/motion_loader.py feed_forward_generator_lb / _ulb) hand to update_ss_info_gail, drawn from index tables made once per
+ * update, and qa_disc_prepare's arithmetic applied on the way: rows index[b][*block_dev * rows[b] + r] of src[b] (b = 0 labelled expert,
+ * 1 policy replay ring, 2 unlabelled expert) land prepared in out ((rows[0] + rows[1] + rows[2]), dim), in that order; the policy rows'
+ * latent targets eps_out[r] = eps_src[row], c_out[r][:] = c_src[row][:] (c_dim columns) and the labelled rows' classes
+ * label_out[r] = label_src[*block_dev * rows[0] + r] alongside (eps_src / label_src may be NULL).  One launch; `block_dev` is a DEVICE
+ * scalar so that a recorded step can be replayed for successive minibatches.  (ABI 12) */
+typedef struct {
+    const float *src[3];
+    const int64_t *index[3];
+    int64_t rows[3];
+    const float *eps_src, *c_src;
+    float *eps_out, *c_out;
+    const int64_t *label_src;
+    int64_t *label_out;
+    const int64_t *block_dev;
+} qa_disc_sample_io;
+int qa_disc_sample_prepare(const qa_disc_sample_io *io, int32_t dim, int32_t c_dim, const float *task_mask, const float *frame_mult,
+                           const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip, float *out, void *stream);
+
 /* Tail of a discriminator step (bbc/rsl_rl/algorithms/gail.py:486-504, 520-533): the logged values that are sums of squares, assembled with
  * qa_disc_loss's head statistics into the 11 values update_ss_info_gail returns
  *   out = {ss, info_max, disc, us  (head_stats[1..4]),  sum(input_grad^2) / grad_rows  (gradient penalty),  sum(weights[last]^2)  (logit
  *          regulariser),  sum over all weights of sum(w^2)  (weight decay),  acc_lb, acc_pi, acc_exp, acc_ulb  (head_stats[5..8])}
- * and, if given, acc[0..10] += out and *step_counter += 1 (the recorded step's accumulator and device-side step counter).  One launch, partial
+ * and, if given, acc[0..10] += out, *step_counter += 1 (the recorded step's accumulator and device-side step counter) and the class prior's
+ * EMA prior[k] = prior[k] (1 - prior_soft_coef) + prior_soft_coef head_stats[9 + k], k < prior_dim <= 5 (:463-464).  One launch, partial
  * sums added in a fixed order.  `weights` / `weight_counts` are HOST arrays of 1..7 device pointers / element counts.  `scratch`:
  * qa_disc_step_tail_scratch_bytes() bytes, 16-byte aligned, ZEROED once by the caller (it holds the arrival counter, which the kernel
  * leaves at zero).  (ABI 12) */
 int64_t qa_disc_step_tail_scratch_bytes(void);
 int qa_disc_step_tail(const float *head_stats, const float *input_grad, int64_t grad_rows, int32_t grad_cols, const float *const *weights,
-                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, void *scratch,
-                      int64_t scratch_bytes, void *stream);
+                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, float *prior, int32_t prior_dim,
+                      float prior_soft_coef, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Discriminator input preparation (bbc/rsl_rl/algorithms/discriminator.py:77-87, utils.py:97-103): 1..3 row-major
  * (rows[i], dim) fp32 device batches are written one under the other into out (sum rows, dim):

@@ -1590,13 +1590,46 @@ int qo_linear_forward_split(const float *x, int64_t ldx, const float *weight, in
     return qo_linear_forward(x, ldx, weight, ldw, bias, y, ldy, rows, in_features, out_features, act, alpha, stream);
 }
 
+/* twin of qa_disc_sample_prepare: the generators' row selection (bbc/rsl_rl/storage/replay_buffer.py:38-47, motion_loader feed_forward_generator_lb / _ulb)
+ * from index tables + qo_disc_prepare's arithmetic */
+int qo_disc_sample_prepare(const qa_disc_sample_io *io, int32_t dim, int32_t c_dim, const float *task_mask, const float *frame_mult,
+                           const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip, float *out, void *stream) {
+    (void)stream;
+    if (!io || !task_mask || !frame_mult || !out || dim <= 0 || c_dim < 0 || ((mean == NULL) != (var == NULL)) || !io->block_dev) return QA_E_ARG;
+    const int64_t blk = io->block_dev[0];
+    int64_t o = 0;
+    for (int b = 0; b < 3; ++b) {
+        if (!io->src[b] || !io->index[b] || io->rows[b] <= 0) return QA_E_ARG;
+        for (int64_t r = 0; r < io->rows[b]; ++r) {
+            const int64_t row = io->index[b][blk * io->rows[b] + r];
+            for (int c = 0; c < dim; ++c) {
+                float x = io->src[b][row * dim + c];
+                if (task_weight_dev && task_mask[c] != 0.0f) x *= task_weight_dev[0];
+                x *= frame_mult[c];
+                if (mean) { float m = (float)mean[c], sd = sqrtf((float)(var[c] + (double)epsilon)); x = (x - m) / sd; x = x < -clip ? -clip : (x > clip ? clip : x); }
+                out[o++] = x;
+            }
+        }
+    }
+    if (io->eps_src)
+        for (int64_t j = 0; j < io->rows[1]; ++j) {
+            const int64_t row = io->index[1][blk * io->rows[1] + j];
+            io->eps_out[j] = io->eps_src[row];
+            for (int k = 0; k < c_dim; ++k) io->c_out[j * c_dim + k] = io->c_src[row * c_dim + k];
+        }
+    if (io->label_src)
+        for (int64_t j = 0; j < io->rows[0]; ++j) io->label_out[j] = io->label_src[blk * io->rows[0] + j];
+    return QA_OK;
+}
+
 int64_t qo_disc_step_tail_scratch_bytes(void) { return 16; }
 /* twin of qa_disc_step_tail (bbc/rsl_rl/algorithms/gail.py:486-504, 520-533): double sums */
 int qo_disc_step_tail(const float *head_stats, const float *input_grad, int64_t grad_rows, int32_t grad_cols, const float *const *weights,
-                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, void *scratch,
-                      int64_t scratch_bytes, void *stream) {
+                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, float *prior, int32_t prior_dim,
+                      float prior_soft_coef, void *scratch, int64_t scratch_bytes, void *stream) {
     (void)scratch; (void)scratch_bytes; (void)stream;
-    if (!head_stats || !input_grad || grad_rows <= 0 || grad_cols <= 0 || !weights || !weight_counts || num_weights <= 0 || num_weights > 7 || !out) return QA_E_ARG;
+    if (!head_stats || !input_grad || grad_rows <= 0 || grad_cols <= 0 || !weights || !weight_counts || num_weights <= 0 || num_weights > 7 || !out ||
+        (prior && (prior_dim <= 0 || prior_dim > 5))) return QA_E_ARG;
     double gp = 0.0, wd = 0.0, last = 0.0;
     for (int64_t i = 0; i < grad_rows * grad_cols; ++i) gp += (double)input_grad[i] * input_grad[i];
     for (int t = 0; t < num_weights; ++t) {
@@ -1608,6 +1641,7 @@ int qo_disc_step_tail(const float *head_stats, const float *input_grad, int64_t 
                    head_stats[5], head_stats[6], head_stats[7], head_stats[8]};
     for (int k = 0; k < 11; ++k) { out[k] = o[k]; if (acc) acc[k] += o[k]; }
     if (step_counter) step_counter[0] += 1;
+    if (prior) for (int k = 0; k < prior_dim; ++k) prior[k] = fmaf(prior_soft_coef, head_stats[9 + k], prior[k] * (1.0f - prior_soft_coef));
     return QA_OK;
 }
 

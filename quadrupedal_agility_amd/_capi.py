@@ -82,6 +82,11 @@ class QaConfig(C.Structure):
     ]
 
 
+class QaDiscSampleIo(C.Structure):
+    _fields_ = [("src", C.c_void_p * 3), ("index", C.c_void_p * 3), ("rows", C.c_int64 * 3), ("eps_src", C.c_void_p), ("c_src", C.c_void_p),
+                ("eps_out", C.c_void_p), ("c_out", C.c_void_p), ("label_src", C.c_void_p), ("label_out", C.c_void_p), ("block_dev", C.c_void_p)]
+
+
 def bind(lib, prefix):
     """Declare argtypes/restypes of the C ABI of include/qa_sim.h on a loaded library whose
     symbols carry `prefix` (the product library uses "qa_")."""
@@ -174,8 +179,9 @@ def bind(lib, prefix):
     P, I64, I32, FL = C.c_void_p, C.c_int64, C.c_int32, C.c_float
     f = getattr(lib, prefix + "linear_forward_split_scratch_bytes"); f.argtypes = [I64, I32, I32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "linear_forward_split"); f.argtypes = [P, I64, P, I64, P, P, I64, I64, I32, I32, I32, FL, P, I64, P]; f.restype = C.c_int
+    f = getattr(lib, prefix + "disc_sample_prepare"); f.argtypes = [C.POINTER(QaDiscSampleIo), I32, I32, P, P, P, P, P, FL, FL, P, P]; f.restype = C.c_int
     f = getattr(lib, prefix + "disc_step_tail_scratch_bytes"); f.argtypes = []; f.restype = C.c_int64
-    f = getattr(lib, prefix + "disc_step_tail"); f.argtypes = [P, P, I64, I32, P, P, I32, P, P, P, P, I64, P]; f.restype = C.c_int
+    f = getattr(lib, prefix + "disc_step_tail"); f.argtypes = [P, P, I64, I32, P, P, I32, P, P, P, P, I32, FL, P, I64, P]; f.restype = C.c_int
     f = getattr(lib, prefix + "depth_stem_forward"); f.argtypes = [P, P, P, P, P, I64, I32, I32, FL, P]; f.restype = C.c_int
     f = getattr(lib, prefix + "depth_stem_backward_scratch_bytes"); f.argtypes = []; f.restype = C.c_int64
     f = getattr(lib, prefix + "depth_stem_backward"); f.argtypes = [P, P, P, P, I64, I32, I32, P, I64, P]; f.restype = C.c_int
@@ -270,7 +276,7 @@ class QaTscDepthIo(C.Structure):
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "tsc_reset_dev", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "hybrid_ppo_loss", "hybrid_ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "rollout_act", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "mlp_packed_floats", "mlp_pack", "mlp_forward", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "last_error", "abi_version"]
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libqa_sim.so")

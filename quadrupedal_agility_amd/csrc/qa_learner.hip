@@ -898,7 +898,7 @@ __global__ void qa_disc_finish_kernel(const float *partial, int nblocks, int b_l
 // of a step that is a chain of ~75 launch-latency-sized kernels.  16 workgroups per tensor write partial sums; the last one to arrive
 // (ticket) adds them in index order: fixed order, bit-reproducible.
 constexpr int TAIL_MAX = 8, TAIL_WG = 16;
-struct TailArgs { const float *t[TAIL_MAX]; int64_t n[TAIL_MAX]; int nt; const float *hs; float inv_rows; float *out, *acc; int64_t *step; float *partial; unsigned *ticket; };
+struct TailArgs { const float *t[TAIL_MAX]; int64_t n[TAIL_MAX]; int nt; const float *hs; float inv_rows; float *out, *acc; int64_t *step; float *prior; int prior_dim; float prior_c; float *partial; unsigned *ticket; };
 
 __global__ void __launch_bounds__(256) qa_disc_step_tail_kernel(TailArgs a) {
     __shared__ float red[256];
@@ -941,6 +941,8 @@ __global__ void __launch_bounds__(256) qa_disc_step_tail_kernel(TailArgs a) {
         o[7] = a.hs[5]; o[8] = a.hs[6]; o[9] = a.hs[7]; o[10] = a.hs[8];
         for (int k = 0; k < 11; ++k) { a.out[k] = o[k]; if (a.acc) a.acc[k] += o[k]; }
         if (a.step) a.step[0] += 1;
+        // the class prior's EMA towards this step's mean class probabilities of the unlabelled batch (gail.py:463-464)
+        if (a.prior) for (int k = 0; k < a.prior_dim; ++k) a.prior[k] = fmaf(a.prior_c, a.hs[9 + k], a.prior[k] * (1.0f - a.prior_c));
         *a.ticket = 0u;                 // ready for the next launch (replays of a recorded step included)
     }
 }
@@ -969,6 +971,48 @@ __global__ void __launch_bounds__(256) qa_disc_prepare_kernel(PrepArgs a) {
         x = fminf(fmaxf((x - m) / sd, -a.clip), a.clip);
     }
     a.out[i] = x;
+}
+
+// The sampling front of a recorded discriminator step: minibatch `*block_dev` of the update's index tables is read straight from the
+// replay ring / the two mocap tables INTO the prepared (3 mb, dim) matrix (same arithmetic as qa_disc_prepare_kernel, element for element),
+// with the policy rows' latent targets and the labelled rows' classes alongside.  Replaces three row gathers, an index_select and the prepare
+// launch of a step that is a chain of launch-latency-sized kernels.
+struct SampleArgs {
+    qa_disc_sample_io io;
+    int dim, c_dim;
+    const float *task_mask, *frame_mult, *task_w; const double *mean, *var; float eps, clip; float *out;
+    int64_t main_blocks;
+};
+
+__global__ void __launch_bounds__(256) qa_disc_sample_prepare_kernel(SampleArgs a) {
+    const qa_disc_sample_io &io = a.io;
+    const int64_t blk = io.block_dev[0];
+    if ((int64_t)blockIdx.x < a.main_blocks) {
+        const int64_t total = (io.rows[0] + io.rows[1] + io.rows[2]) * a.dim;
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= total) return;
+        const int64_t r = i / a.dim; const int c = (int)(i - r * a.dim);
+        int b = 0; int64_t rr = r;
+        if (rr >= io.rows[0]) { rr -= io.rows[0]; b = 1; if (rr >= io.rows[1]) { rr -= io.rows[1]; b = 2; } }
+        const int64_t row = io.index[b][blk * io.rows[b] + rr];
+        float x = io.src[b][row * a.dim + c];
+        if (a.task_w && a.task_mask[c] != 0.f) x *= a.task_w[0];
+        x *= a.frame_mult[c];
+        if (a.mean) {
+            const float m = (float)a.mean[c], sd = sqrtf((float)(a.var[c] + (double)a.eps));
+            x = fminf(fmaxf((x - m) / sd, -a.clip), a.clip);
+        }
+        a.out[i] = x;
+        return;
+    }
+    // the small rows: one thread per policy sample / labelled sample
+    const int64_t j = ((int64_t)blockIdx.x - a.main_blocks) * 256 + threadIdx.x;
+    if (j < io.rows[1] && io.eps_src) {
+        const int64_t row = io.index[1][blk * io.rows[1] + j];
+        io.eps_out[j] = io.eps_src[row];
+        for (int k = 0; k < a.c_dim; ++k) io.c_out[j * a.c_dim + k] = io.c_src[row * a.c_dim + k];
+    }
+    if (j < io.rows[0] && io.label_src) io.label_out[j] = io.label_src[blk * io.rows[0] + j];
 }
 
 }  // namespace
@@ -1236,13 +1280,34 @@ int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t
     return QA_OK;
 }
 
+int qa_disc_sample_prepare(const qa_disc_sample_io *io, int32_t dim, int32_t c_dim, const float *task_mask, const float *frame_mult,
+                           const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip, float *out, void *stream) {
+    if (!io || !task_mask || !frame_mult || !out || dim <= 0 || c_dim < 0 || ((mean == nullptr) != (var == nullptr)) || !io->block_dev ||
+        (io->eps_src && (!io->c_src || !io->eps_out || !io->c_out || c_dim <= 0)) || (io->label_src && !io->label_out)) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_disc_sample_prepare: bad argument"); return QA_E_ARG; }
+    int64_t total = 0, small = 0;
+    for (int b = 0; b < 3; ++b) {
+        if (!io->src[b] || !io->index[b] || io->rows[b] <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_sample_prepare: empty batch"); return QA_E_ARG; }
+        total += io->rows[b] * dim;
+    }
+    small = io->rows[0] > io->rows[1] ? io->rows[0] : io->rows[1];
+    SampleArgs a{};
+    a.io = *io; a.dim = dim; a.c_dim = c_dim; a.task_mask = task_mask; a.frame_mult = frame_mult; a.task_w = task_weight_dev; a.mean = mean; a.var = var;
+    a.eps = epsilon; a.clip = clip; a.out = out; a.main_blocks = (total + 255) / 256;
+    const int64_t extra = (io->eps_src || io->label_src) ? (small + 255) / 256 : 0;
+    hipLaunchKernelGGL(qa_disc_sample_prepare_kernel, dim3((unsigned)(a.main_blocks + extra)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_sample_prepare: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
 int64_t qa_disc_step_tail_scratch_bytes(void) { return (int64_t)(TAIL_MAX * TAIL_WG + 4) * 4; }
 
 int qa_disc_step_tail(const float *head_stats, const float *input_grad, int64_t grad_rows, int32_t grad_cols, const float *const *weights,
-                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, void *scratch,
-                      int64_t scratch_bytes, void *stream) {
+                      const int64_t *weight_counts, int32_t num_weights, float *out, float *acc, int64_t *step_counter, float *prior, int32_t prior_dim,
+                      float prior_soft_coef, void *scratch, int64_t scratch_bytes, void *stream) {
     if (!head_stats || !input_grad || grad_rows <= 0 || grad_cols <= 0 || !weights || !weight_counts || num_weights <= 0 || num_weights > TAIL_MAX - 1 ||
-        !out || !scratch || scratch_bytes < qa_disc_step_tail_scratch_bytes() || ((uintptr_t)scratch & 15)) {
+        !out || !scratch || (prior && (prior_dim <= 0 || prior_dim > 5)) || scratch_bytes < qa_disc_step_tail_scratch_bytes() || ((uintptr_t)scratch & 15)) {
         snprintf(g_lerr, sizeof(g_lerr), "qa_disc_step_tail: bad argument (1..%d weight tensors, scratch >= qa_disc_step_tail_scratch_bytes(), zeroed once)", TAIL_MAX - 1);
         return QA_E_ARG; }
     TailArgs a{};
@@ -1251,7 +1316,7 @@ int qa_disc_step_tail(const float *head_stats, const float *input_grad, int64_t 
         if (!weights[i] || weight_counts[i] <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_step_tail: empty weight tensor"); return QA_E_ARG; }
         a.t[1 + i] = weights[i]; a.n[1 + i] = weight_counts[i];
     }
-    a.nt = 1 + num_weights; a.hs = head_stats; a.inv_rows = 1.0f / (float)grad_rows; a.out = out; a.acc = acc; a.step = step_counter;
+    a.nt = 1 + num_weights; a.hs = head_stats; a.inv_rows = 1.0f / (float)grad_rows; a.out = out; a.acc = acc; a.step = step_counter; a.prior = prior; a.prior_dim = prior_dim; a.prior_c = prior_soft_coef;
     a.partial = (float *)scratch; a.ticket = (unsigned *)((float *)scratch + TAIL_MAX * TAIL_WG);
     hipLaunchKernelGGL(qa_disc_step_tail_kernel, dim3((unsigned)(a.nt * TAIL_WG)), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();

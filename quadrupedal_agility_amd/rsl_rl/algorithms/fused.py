@@ -856,12 +856,39 @@ def disc_loss_raw(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, 
     return out, gd.view(d.shape), ge.view(eps.shape), gc.view(c.shape)
 
 
+def disc_sample_prepare(tables, block_dev, srcs, eps_src, c_src, label_table, task_mask, frame_mult, task_weight_dev, normalizer, outs=None):
+    """minibatch `block_dev` of the update's index tables, read from (labelled expert, policy ring, unlabelled expert) straight into the
+    prepared (3 mb, dim) matrix + the policy rows' (eps, c) + the labelled rows' classes: qa_disc_sample_prepare, one launch.
+    `tables` = (t_lb, t_pi, t_ulb) int64 (steps, mb); returns (x_all, eps, c, label)."""
+    lib = _capi.load_library()
+    dev = srcs[0].device
+    mb = [t.shape[1] for t in tables]
+    d = srcs[0].shape[1]
+    assert all(x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and x.shape[1] == d for x in srcs)
+    assert all(t.dtype == torch.int64 and t.is_contiguous() for t in tables) and label_table.dtype == torch.int64 and label_table.is_contiguous()
+    cd = c_src.shape[-1]
+    if outs is None:
+        outs = (torch.empty(sum(mb), d, device=dev), torch.empty(mb[1], 1, device=dev), torch.empty(mb[1], cd, device=dev), torch.empty(mb[0], dtype=torch.int64, device=dev))
+    x_all, eps, c, label = outs
+    io = _capi.QaDiscSampleIo()
+    for b in range(3):
+        io.src[b] = srcs[b].data_ptr(); io.index[b] = tables[b].data_ptr(); io.rows[b] = mb[b]
+    io.eps_src, io.c_src, io.eps_out, io.c_out = eps_src.data_ptr(), c_src.data_ptr(), eps.data_ptr(), c.data_ptr()
+    io.label_src, io.label_out, io.block_dev = label_table.data_ptr(), label.data_ptr(), block_dev.data_ptr()
+    mean = _ptr(normalizer.mean) if normalizer is not None else None
+    var = _ptr(normalizer.var) if normalizer is not None else None
+    _check(lib.qa_disc_sample_prepare(C.byref(io), d, cd, _ptr(task_mask), _ptr(frame_mult), _ptr(task_weight_dev) if task_weight_dev is not None else None, mean, var,
+                                      float(normalizer.epsilon) if normalizer is not None else 0.0, float(normalizer.clip_obs) if normalizer is not None else 0.0,
+                                      _ptr(x_all), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "qa_disc_sample_prepare")
+    return x_all, eps, c, label
+
+
 _tail_scratch = {}
 
 
-def disc_step_tail(head_stats, input_grad, weights, acc=None, step=None):
+def disc_step_tail(head_stats, input_grad, weights, acc=None, step=None, prior=None, prior_soft_coef=0.0):
     """the 11 logged values of a discriminator step by qa_disc_step_tail (sums of squares of the penalty's input gradient and of the
-    regularised weights + the head statistics), optionally added to `acc` and `step` bumped, in ONE launch"""
+    regularised weights + the head statistics), optionally added to `acc`, `step` bumped and the class prior's EMA stepped, in ONE launch"""
     lib = _capi.load_library()
     dev = head_stats.device
     sc = _tail_scratch.get(dev)
@@ -875,7 +902,8 @@ def disc_step_tail(head_stats, input_grad, weights, acc=None, step=None):
     wn = (C.c_int64 * len(ws))(*[w.numel() for w in ws])
     out = torch.empty(11, dtype=torch.float32, device=dev)
     _check(lib.qa_disc_step_tail(_ptr(head_stats), _ptr(g), g.shape[0], g.numel() // g.shape[0], wp, wn, len(ws), _ptr(out), _ptr(acc) if acc is not None else None,
-                                 _ptr(step) if step is not None else None, _ptr(sc), sc.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                 _ptr(step) if step is not None else None, _ptr(prior) if prior is not None else None, prior.numel() if prior is not None else 0,
+                                 float(prior_soft_coef), _ptr(sc), sc.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
            "qa_disc_step_tail")
     return out
 

@@ -426,6 +426,18 @@ class SSInfoGAIL:
 
                 def one_step():
                     t_pi, t_lb, t_ulb, t_lab = self._d_tables
+                    if self.use_fused_loss and self._fused_prep_ok(flat2(rb.states).shape[1]):
+                        # sampling + preparation of the step's three batches in ONE launch (was: 3 row gathers, an index_select, the prepare launch)
+                        w = self._task_weight_dev() if self.env.task_obs_weight_decay else None
+                        x_all, e_pi, c_pi, label = fused_mod.disc_sample_prepare(
+                            (t_lb, t_pi, t_ulb), self._d_step, (flat2(ml.preloaded_s_lb), flat2(rb.states), flat2(ml.preloaded_s_ulb)), flat2(rb.latent_eps),
+                            flat2(rb.latent_c), t_lab, self.disc._task_mask, self.disc._frame_mult.view(-1), w, self.disc_normalizer)
+                        out = self.update_ss_info_gail((None, e_pi, c_pi), (None, label), None, acc=self._acc_d, step=self._d_step,
+                                                       prepared=(x_all, t_lb.shape[1], t_pi.shape[1]))
+                        if not self._tail_folded:
+                            self._acc_d.add_(_vec11(out))
+                            self._d_step.add_(1)
+                        return
                     if self.use_fused_loss:
                         s_pi, e_pi, c_pi = fused_mod.gather_rows(t_pi, [flat2(rb.states), flat2(rb.latent_eps), flat2(rb.latent_c)], block_dev=self._d_step)
                         (s_lb,) = fused_mod.gather_rows(t_lb, [flat2(ml.preloaded_s_lb)], block_dev=self._d_step)
@@ -654,7 +666,22 @@ class SSInfoGAIL:
             for g in self.optim_ac.param_groups:
                 g["lr"] = self._lr_ac
 
-    def update_ss_info_gail(self, sample_disc_policy, sample_disc_expert_lb, sample_disc_expert_ulb, acc=None, step=None):
+    def _fused_prep_ok(self, width):
+        nm = self.disc_normalizer
+        return bool(self._on_gpu and self.use_fused_loss and nm is not None and hasattr(nm, "count") and torch.is_tensor(getattr(nm, "mean", None))
+                    and self.disc.disc_obs_len * self.disc.num_disc_obs == width)
+
+    def _task_weight_dev(self):
+        w = getattr(self.env, "task_obs_weight_dev", None)
+        if w is None:
+            if self._task_w_dev is None:
+                self._task_w_dev = torch.ones((), device=self.device)
+            if not torch.cuda.is_current_stream_capturing():
+                self._task_w_dev.fill_(float(self.env.task_obs_weight))
+            w = self._task_w_dev
+        return w
+
+    def update_ss_info_gail(self, sample_disc_policy, sample_disc_expert_lb, sample_disc_expert_ulb, acc=None, step=None, prepared=None):
         """returns the 11 logged values (a tuple of scalars, or ONE 11-vector from qa_disc_step_tail -- `_vec11` takes either); with `acc` / `step`
         (the recorded step) the fused tail also adds them to the accumulator and bumps the device-side step counter: `self._tail_folded`"""
         self._tail_folded = False
@@ -662,16 +689,13 @@ class SSInfoGAIL:
         expert_lb, label_lb = sample_disc_expert_lb
         expert_ulb = sample_disc_expert_ulb
         w = getattr(self.env, "task_obs_weight_dev", None)
-        fused_prep = (self._on_gpu and self.use_fused_loss and self.disc_normalizer is not None and hasattr(self.disc_normalizer, "count")
-                      and torch.is_tensor(getattr(self.disc_normalizer, "mean", None)) and self.disc.disc_obs_len * self.disc.num_disc_obs == policy_state.shape[-1])
-        if fused_prep:
+        fused_prep = prepared is None and self._fused_prep_ok(policy_state.shape[-1])
+        if prepared is not None:        # the recorded step's sampling front wrote the prepared matrix already (qa_disc_sample_prepare)
+            x_all, nl, npi = prepared
+            expert_lb, policy_state, expert_ulb = x_all[:nl], x_all[nl:nl + npi], x_all[nl + npi:]
+        elif fused_prep:
             # task weighting, frame weighting, normalisation + clip of the three batches, written as ONE (3B, 98) matrix
-            if w is None:
-                if self._task_w_dev is None:
-                    self._task_w_dev = torch.ones((), device=self.device)
-                if not torch.cuda.is_current_stream_capturing():
-                    self._task_w_dev.fill_(float(self.env.task_obs_weight))
-                w = self._task_w_dev
+            w = self._task_weight_dev()
             x_all = disc_prepare([expert_lb.reshape(len(expert_lb), -1), policy_state.reshape(len(policy_state), -1), expert_ulb.reshape(len(expert_ulb), -1)],
                                  self.disc._task_mask, self.disc._frame_mult.view(-1), w if self.env.task_obs_weight_decay else None, self.disc_normalizer)
             nl, npi = len(expert_lb), len(policy_state)
@@ -731,7 +755,11 @@ class SSInfoGAIL:
                 raise ValueError("Unexpected loss function specified")
             disc_loss_v = 0.5 * (l_pi + l_exp)
             us_loss = F.l1_loss(eps, policy_eps)
-        if self.grad_sync is None:      # data-parallel: the vector rides in the gradient bucket below (one collective per step)
+        reg_w = [m.weight for m in self.disc.trunk.modules() if isinstance(m, nn.Linear)] + [self.disc.linear.weight]
+        fused_tail = direct and len(reg_w) <= 7 and all(w.is_cuda and w.is_contiguous() for w in reg_w)
+        prior_in_tail = (fused_tail and self.grad_sync is None and torch.is_tensor(self.env.prior_parameters) and self.env.prior_parameters.is_cuda
+                         and self.env.prior_parameters.dtype == torch.float32 and self.env.prior_parameters.is_contiguous() and self.env.prior_parameters.numel() <= 5)
+        if self.grad_sync is None and not prior_in_tail:      # data-parallel: the vector rides in the gradient bucket below (one collective per step)
             prior = self.env.prior_parameters
             if torch.is_tensor(prior) and prior.is_cuda:    # the arena's own tensor: the EMA (gail.py:463-464) in place, 2 launches
                 prior.mul_(1 - self.prior_soft_coef).add_(pred_mean, alpha=self.prior_soft_coef)
@@ -740,8 +768,6 @@ class SSInfoGAIL:
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
         if not analytic_gp:
             g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
-        reg_w = [m.weight for m in self.disc.trunk.modules() if isinstance(m, nn.Linear)] + [self.disc.linear.weight]
-        fused_tail = direct and len(reg_w) <= 7 and all(w.is_cuda and w.is_contiguous() for w in reg_w)
         if fused_tail:  # the three sums of squares, the 11-vector, the accumulator and the step counter: one launch at the end of the step
             gdet = g.detach()
             grad_pen_loss = None
@@ -758,7 +784,8 @@ class SSInfoGAIL:
         if fused_tail:
             # issued HERE, before the optimiser step below changes the weights it reads
             with torch.no_grad():
-                out11 = fused_mod.disc_step_tail(hs, gdet, reg_w, acc=acc, step=step)
+                out11 = fused_mod.disc_step_tail(hs, gdet, reg_w, acc=acc, step=step, prior=self.env.prior_parameters if prior_in_tail else None,
+                                                 prior_soft_coef=self.prior_soft_coef)
             self._tail_folded = acc is not None
             disc_logit_loss = disc_weight_decay = None
             rest = None
