@@ -492,7 +492,9 @@ int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, con
  * params / grads / exp_avg / exp_avg_sq / steps are DEVICE arrays of num_tensors device pointers (steps: one float
  * counter per tensor, all set to t); the work list is num_chunks (tensor, start, length <= 2048) triples in device
  * memory; weight_decay is per tensor, lr one device float.  scratch >= 4 + num_chunks floats; scratch[3] = ||g||_2 (0 when
- * max_norm <= 0: the norm is then not computed and the step is two launches). */
+ * max_norm <= 0: the norm is then not computed and the step is two launches -- ONE when scratch has a fifth spare float,
+ * scratch_floats >= 5 + num_chunks, zeroed before the first call: scratch[4 + num_chunks] is then the arrival counter of the
+ * update kernel's workgroups, the last of which writes the step counters; the kernel leaves it at zero). */
 int qa_clip_adam_step(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
                       float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
                       const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,

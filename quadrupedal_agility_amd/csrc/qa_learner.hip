@@ -646,11 +646,18 @@ __global__ void qa_kl_lr_rule_kernel(const float *kl, float desired_kl, float fa
     lr[0] = out;
 }
 
+// SELF: no clipping, so nothing has to be known about the whole gradient before the update -- the step count is read (old value) by every
+// workgroup, the bias corrections are recomputed per workgroup (the finalize kernel's expressions), and the LAST workgroup to arrive writes
+// the incremented counters and the scratch head: one launch instead of finalize + update (the discriminator's three optimisers, 80 steps
+// per iteration of a launch-latency-bound chain).
+template <bool SELF>
 __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
     const int c = blockIdx.x, t = a.chunk_tensor[c], s0 = a.chunk_start[c], n = a.chunk_len[c];
     float *p = a.params[t] + s0, *m = a.exp_avg[t] + s0, *v = a.exp_avg_sq[t] + s0;
     const float *g = adam_grad(a, t) + s0;
-    const float coef = a.scratch[0], bc1 = a.scratch[1], bc2s = a.scratch[2], wd = a.weight_decay[t];
+    const float step = SELF ? a.steps[0][0] + 1.0f : 0.f;
+    const float coef = SELF ? 1.0f : a.scratch[0], bc1 = SELF ? 1.0f - powf(a.beta1, step) : a.scratch[1],
+                bc2s = SELF ? sqrtf(1.0f - powf(a.beta2, step)) : a.scratch[2], wd = a.weight_decay[t];
     const float step_size = a.lr[0] / bc1;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float pi = p[i];
@@ -659,6 +666,18 @@ __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
         const float vi = a.beta2 * v[i] + (1.0f - a.beta2) * gi * gi;
         m[i] = mi; v[i] = vi;
         p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + a.eps);
+    }
+    if (SELF) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned *ticket = (unsigned *)(a.scratch + 4 + a.num_chunks);
+            __threadfence();
+            if (atomicAdd(ticket, 1u) == (unsigned)(a.num_chunks - 1)) {      // every workgroup has read the old step count by now
+                for (int k = 0; k < a.num_tensors; ++k) a.steps[k][0] = step;
+                a.scratch[0] = 1.0f; a.scratch[1] = bc1; a.scratch[2] = bc2s; a.scratch[3] = 0.f;
+                *ticket = 0u;
+            }
+        }
     }
 }
 
@@ -1158,9 +1177,14 @@ static int clip_adam_launch(float *const *params, const float *const *grads_dev,
                beta1, beta2, eps, max_norm, grads_host ? 1 : 0, {}};
     if (grads_host) for (int t = 0; t < num_tensors; ++t) a.gin[t] = grads_host[t];
     hipStream_t st = (hipStream_t)stream;
-    if (max_norm > 0.f) hipLaunchKernelGGL(qa_adam_sumsq_kernel, dim3(num_chunks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(qa_adam_finalize_kernel, dim3(1), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(qa_adam_update_kernel, dim3(num_chunks), dim3(256), 0, st, a);
+    if (!(max_norm > 0.f) && scratch_floats >= 5 + (int64_t)num_chunks) {
+        // no clipping and room for the arrival counter (scratch[4 + num_chunks], zero at the first call: the kernel leaves it at zero)
+        hipLaunchKernelGGL(qa_adam_update_kernel<true>, dim3(num_chunks), dim3(256), 0, st, a);
+    } else {
+        if (max_norm > 0.f) hipLaunchKernelGGL(qa_adam_sumsq_kernel, dim3(num_chunks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(qa_adam_finalize_kernel, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(qa_adam_update_kernel<false>, dim3(num_chunks), dim3(256), 0, st, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "%s: %s", who, hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

@@ -138,14 +138,21 @@ class _LinearElu(torch.autograd.Function):
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
+# the discriminator's trunk (3 x 1228 rows, 98 -> 1024 -> 512): its step is a chain of launch-latency-sized kernels, a launch saved is 5 us saved
+RELU_OWN_MAX_ROWS = 8192
+
+
 class _LinearRelu(torch.autograd.Function):
     """y = relu(x W^T + b) with the same backward kernel as _LinearElu (ELU with alpha = 0 IS ReLU: derivative 1 for y > 0, y + 0 = 0
     otherwise), i.e. the bias gradient is our fixed-order column sum, not torch's `sum(0)` (see profiles/r2_hipgraph_stale_reductions.md)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        y = torch.addmm(bias, x, weight.t())
-        torch.relu_(y)
+        if OWN_GEMM and x.shape[0] <= RELU_OWN_MAX_ROWS and weight.is_contiguous() and bias.is_contiguous():
+            y = linear_forward_raw(x, weight.detach(), bias.detach(), ACT_RELU)      # bias + ReLU in the GEMM's epilogue: one launch instead of two
+        else:
+            y = torch.addmm(bias, x, weight.t())
+            torch.relu_(y)
         ctx.save_for_backward(x, weight, y)
         return y
 
@@ -746,7 +753,7 @@ class ClipAdam:
                    grads_host=torch.zeros(len(items), dtype=torch.int64).pin_memory(), grad_ptrs=None,
                    chunk_tensor=i32(ct), chunk_start=i32(cs), chunk_len=i32(cl), num_chunks=len(ct),
                    wd=torch.tensor([g["weight_decay"] for _, g in items], dtype=torch.float32, device=dev),
-                   scratch=torch.zeros(4 + len(ct), dtype=torch.float32, device=dev),
+                   scratch=torch.zeros(5 + len(ct), dtype=torch.float32, device=dev),      # [4 + chunks]: the single-launch (no clipping) step's arrival counter
                    betas=g0["betas"], eps=g0["eps"], lr_dev=None, lr_val=None)
         self._tab = tab
 

@@ -138,7 +138,8 @@ class SSInfoGAIL:
         # PPO step: critic / actor / small nets on three streams (config 2: update 32.2 -> 28.9 ms).  Not with the discriminator: its
         # 80 recorded steps already run beside the PPO steps on their own stream, and three more streams of GEMMs starve them
         # (config 3: update 61 -> 90 ms with both)
-        self.branch_streams = (self._on_gpu and os.environ.get("QA_PPO_BRANCHES", "1") != "0" and not (self.amp_enabled and self.overlap_updates))
+        self.branch_streams = (self._on_gpu and os.environ.get("QA_PPO_BRANCHES", "1") != "0" and
+                               (not (self.amp_enabled and self.overlap_updates) or os.environ.get("QA_PPO_BRANCHES_AMP", "0") == "1"))
         self._branch = None
 
     # ---- lr_ac is read by the logger and by checkpoints as a float

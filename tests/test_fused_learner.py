@@ -885,3 +885,42 @@ def test_discriminator_step_backward_through_our_reductions_matches_autograd():
     for n in ga:
         scale = float(gb[n].abs().max())
         assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * max(scale, 1.0) * 921 ** 0.5, n
+
+
+@pytest.mark.gpu
+def test_single_launch_adam_step_equals_the_two_launch_step_bit_for_bit():
+    """without clipping, a scratch with the spare counter slot takes the one-launch path (the last workgroup writes the step counters);
+    the same call with the short scratch takes finalize + update: identical parameters, moments, counters, over several steps"""
+    from quadrupedal_agility_amd import _capi
+    lib = _capi.load_library()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [(1024, 98), (1024,), (512, 1024), (512,), (1, 512), (1,)]
+    ct, cs, cl = [], [], []
+    for t, s in enumerate(shapes):
+        n = int(np.prod(s))
+        for s0 in range(0, n, 2048):
+            ct.append(t); cs.append(s0); cl.append(min(2048, n - s0))
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device="cuda")
+    ctd, csd, cld = i32(ct), i32(cs), i32(cl)
+    wd = torch.full((len(shapes),), 1e-3, device="cuda"); lr = torch.tensor([1e-3], device="cuda")
+    runs = []
+    for extra in (0, 1):
+        torch.manual_seed(1)
+        p = [torch.randn(s, device="cuda") for s in shapes]
+        m = [torch.zeros_like(x) for x in p]; v = [torch.zeros_like(x) for x in p]; st = [torch.zeros(1, device="cuda") for _ in p]
+        scratch = torch.zeros(4 + len(ct) + extra, device="cuda")
+        tab = lambda xs: torch.tensor([x.data_ptr() for x in xs], dtype=torch.int64, device="cuda")
+        pt, mt, vt, stt = tab(p), tab(m), tab(v), tab(st)
+        for k in range(5):
+            gg = [torch.randn(s, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 + k)) for s in shapes]
+            gt = tab(gg)
+            pp = lambda t: C.c_void_p(t.data_ptr())
+            rc = lib.qa_clip_adam_step(pp(pt), pp(gt), pp(mt), pp(vt), pp(stt), len(shapes), pp(ctd), pp(csd), pp(cld), len(ct), pp(wd), pp(lr),
+                                       0.9, 0.999, 1e-8, 0.0, pp(scratch), scratch.numel(), None)
+            assert rc == 0
+            torch.cuda.synchronize()
+        runs.append((p, m, v, st, scratch[:4].clone()))
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(runs[0][4], runs[1][4]) and float(runs[1][3][0]) == 5.0
