@@ -231,3 +231,29 @@ def test_stem_is_skipped_under_no_grad_bookkeeping_and_for_other_layouts():
     with torch.no_grad():
         out = net(torch.rand(4, 58, 87, device="cuda"))
     assert out.shape == (4, 32) and not out.requires_grad
+
+
+@pytest.mark.gpu
+def test_hip_entries_reject_what_the_twins_reject():
+    """argument contract of the new entry points: same refusals on both sides of the ABI, and a readable qa_last_error()"""
+    from quadrupedal_agility_amd import _capi
+    lib, lo = _capi.load_library(), load_oracle()
+    z = torch.zeros(1 << 16, device="cuda"); zc = np.zeros(1 << 16, np.float32)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    cases = [dict(ih=27, iw=41, cin=24, kh=3, kw=3, cout=64),        # in channels not a power of two
+             dict(ih=10, iw=10, cin=32, kh=3, kw=3, cout=64),        # 64 output pixels per image
+             dict(ih=27, iw=41, cin=32, kh=3, kw=3, cout=6),         # out channels not a multiple of 4
+             dict(ih=27, iw=41, cin=8, kh=3, kw=3, cout=64)]         # fewer than 16 in channels
+    for c in cases:
+        a = (1, c["ih"], c["iw"], c["cin"], c["kh"], c["kw"], c["cout"])
+        assert lib.qa_conv_nhwc_forward(P(z), P(z), None, P(z), *a, 1, ALPHA, None) != 0 and b"qa_conv_nhwc_forward" in lib.qa_last_error()
+        assert lo.qo_conv_nhwc_forward(_ptr(zc), _ptr(zc), None, _ptr(zc), *a, 1, ALPHA, None) != 0
+        assert lib.qa_conv_nhwc_backward_weight_scratch_bytes(*a) == 0 and lo.qo_conv_nhwc_backward_weight_scratch_bytes(*a) == 0
+    off = z[1:]                                                      # 4-byte aligned only
+    assert lib.qa_conv_nhwc_forward(P(off), P(z), None, P(z), 1, 27, 41, 32, 3, 3, 64, 1, ALPHA, None) != 0
+    nb = lib.qa_conv_nhwc_backward_weight_scratch_bytes(1, 27, 41, 32, 3, 3, 64)
+    assert nb > 0 and lib.qa_conv_nhwc_backward_weight(P(z), P(z), P(z), P(z), 1, 27, 41, 32, 3, 3, 64, P(z), nb - 16, None) != 0
+    assert lib.qa_depth_stem_forward(P(z), P(z), P(z), P(z), P(z), 1, 58, 200, ALPHA, None) != 0                   # wider than the LDS rows
+    assert lib.qa_depth_stem_forward(P(z), P(z), P(z), P(z), P(z), 0, 58, 87, ALPHA, None) != 0                    # no images
+    assert lib.qa_elu_backward_pad(P(z), P(z), P(z), P(z), 1, 5, 5, 6, 2, 1, ALPHA, None) != 0                      # channels not a multiple of 4
+    torch.cuda.synchronize()

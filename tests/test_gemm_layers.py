@@ -204,3 +204,28 @@ def test_split_forward_matches_the_unsplit_layer(rows, k, n):
     ref = torch.nn.functional.elu(x.double() @ w.double().t() + b.double()).float()
     assert torch.equal(y, y2)
     assert torch.allclose(y, ref, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,k,n", [(1, 300, 4), (3, 16, 8), (70, 257, 12)])
+def test_split_forward_edge_shapes(rows, k, n):
+    """one row, a reduction shorter than one split, features not a multiple of the tile: against torch in double"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(rows, k, device="cuda", generator=g); w = torch.randn(n, k, device="cuda", generator=g) / k ** 0.5; b = torch.randn(n, device="cuda", generator=g)
+    for act, f in ((0, lambda t: t), (1, torch.nn.functional.elu), (2, torch.relu)):
+        y = fused.linear_forward_split_raw(x, w, b, act, 1.0)
+        ref = f(x.double() @ w.double().t() + b.double()).float()
+        assert torch.allclose(y, ref, rtol=1e-4, atol=2e-5), (act, float((y - ref).abs().max()))
+
+
+@pytest.mark.gpu
+def test_split_forward_rejects_bad_arguments():
+    from quadrupedal_agility_amd import _capi
+    lib = _capi.load_library()
+    z = torch.zeros(4096, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.qa_linear_forward_split(P(z), 64, P(z), 64, P(z), P(z), 6, 8, 64, 6, 1, 1.0, P(z), 4096 * 4, None) != 0          # out features not a multiple of 4
+    nb = lib.qa_linear_forward_split_scratch_bytes(8, 64, 8)
+    assert nb > 0 and lib.qa_linear_forward_split(P(z), 64, P(z), 64, P(z), P(z), 8, 8, 64, 8, 1, 1.0, P(z), nb - 4, None) != 0  # scratch too small
+    assert b"qa_linear_forward_split" in lib.qa_last_error()
