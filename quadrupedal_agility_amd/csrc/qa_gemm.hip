@@ -714,7 +714,7 @@ int qa_conv_nhwc_backward_input(const float *grad_padded, const float *weight_fl
 
 int64_t qa_conv_nhwc_backward_weight_scratch_bytes(int64_t n_img, int32_t ih, int32_t iw, int32_t cin, int32_t kh, int32_t kw, int32_t cout) {
     ConvGeom c;
-    if (cout <= 0 || !conv_geom(&c, n_img, ih, iw, cin, kh, kw)) return 0;
+    if (cout <= 0 || cout % 4 || !conv_geom(&c, n_img, ih, iw, cin, kh, kw)) return 0;
     const int kred = kh * kw * cin;
     int s, kps; conv_wgrad_plan(n_img * c.opix, kred, cout, &s, &kps);
     const int64_t na = (kred + 63) / 64;
