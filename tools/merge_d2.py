@@ -42,7 +42,9 @@ for ck in [c for c in (250, 500, 750, 1000) if c <= iters]:
         cs = [tail(r["curves"][tag], ck) for r in cpu if tag in r["curves"] and len(r["curves"][tag]) >= ck]
         if hs and cs:
             a, b = statistics.mean(hs), statistics.mean(cs)
-            e = {"hip_mean": a, "cpu_oracle_mean": b, "rel_diff": (a - b) / (abs(b) + 1e-12), "hip_per_seed": hs, "cpu_per_seed": cs}
+            e = {"hip_mean": a, "cpu_oracle_mean": b, "rel_diff": (a - b) / (abs(b) + 1e-12), "hip_median": statistics.median(hs), "cpu_oracle_median": statistics.median(cs),
+                 "cpu_seeds_rank_among_hip_seeds": [sum(1 for h in hs if h < c) / len(hs) for c in cs],        # 0.5 = the HIP median
+                 "hip_per_seed": hs, "cpu_per_seed": cs}
             if len(hs) > 1 and len(cs) > 1:
                 se = (statistics.variance(hs) / len(hs) + statistics.variance(cs) / len(cs)) ** 0.5
                 e["rel_diff_standard_error"] = se / (abs(b) + 1e-12)
