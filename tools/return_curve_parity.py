@@ -27,8 +27,10 @@ def run(device, num_envs, iters, seed, amp=False):
     cfg = Go2LocomotionCfg(); cfg.env.num_envs = num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = bool(amp); cfg.seed = seed
     t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = bool(amp); t.seed = seed; t.runner.save_interval = 10 ** 9
     torch.manual_seed(seed)
-    log_root = None if os.environ.get("QA_PARITY_NO_LOG") == "1" else tempfile.mkdtemp(prefix="qa_parity_")
+    log_root = None if os.environ.get("QA_PARITY_NO_LOG") == "1" else (os.environ.get("QA_PARITY_LOG_ROOT") or tempfile.mkdtemp(prefix="qa_parity_"))
     if device == "cpu":
+        if os.environ.get("QA_CPU_THREADS"):
+            torch.set_num_threads(int(os.environ["QA_CPU_THREADS"]))
         from tests.oracle_backend import OracleBackend
         args = get_args(["--device", "cpu"])
         env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=(OracleBackend if amp else OracleBackend(make_qa_config(cfg, seed=seed))))
