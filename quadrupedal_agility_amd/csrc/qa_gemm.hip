@@ -212,6 +212,76 @@ static __device__ __forceinline__ void gemm_frag(float (&f)[4], const float *__r
     }
 }
 
+// the epilogue of both kernels: the lane holds out[b][a .. a+3] for each of its TA x TB tiles (MFMA D rows = 4 consecutive a)
+template <int BA, int BB, int EPI, bool ONES>
+static __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f4 (&acc)[BA / 32][BB / 32], const f4 (&oacc)[BB / 32], int a_base, int b_base,
+                                                     int at, int z, int wa, int wb, int li, int kq, bool ones_wave) {
+    constexpr int TA = BA / 32, TB = BB / 32;
+    float *out = g.out + (int64_t)z * g.out_split_stride;
+#pragma unroll
+    for (int i = 0; i < TA; ++i) {
+        const int a = a_base + wa * (BA / 2) + i * 16 + 4 * kq;
+        if (a >= g.a_count) continue;
+        const bool full = g.o_vec == 4 && a + 3 < g.a_count;
+        f4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == 1 && g.bias) {
+            if (full) bias = *(const f4 *)(g.bias + a);
+            else {
+                bias.x = g.bias[a];
+                if (a + 1 < g.a_count) bias.y = g.bias[a + 1];
+                if (a + 2 < g.a_count) bias.z = g.bias[a + 2];
+                if (a + 3 < g.a_count) bias.w = g.bias[a + 3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b_base + wb * (BB / 2) + j * 16 + li;
+            if (b >= g.b_count) continue;
+            f4 v = acc[i][j];
+            if (EPI == 1) {
+                v += bias;
+                if (g.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : g.alpha * (expf(v[r]) - 1.f);
+                } else if (g.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+            }
+            if (EPI == 2 && g.yprev && g.act != 0) {
+                const float *yp = g.yprev + (int64_t)b * g.ldy + a;
+                f4 y = {1.f, 1.f, 1.f, 1.f};
+                if (full) y = *(const f4 *)yp;
+                else {
+                    y.x = yp[0];
+                    if (a + 1 < g.a_count) y.y = yp[1];
+                    if (a + 2 < g.a_count) y.z = yp[2];
+                    if (a + 3 < g.a_count) y.w = yp[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (g.act == 1) ? (y[r] > 0.f ? 1.f : y[r] + g.alpha) : (y[r] > 0.f ? 1.f : 0.f);
+            }
+            float *o = out + (int64_t)b * g.ldo + a;
+            if (full) *(f4 *)o = v;
+            else {
+                o[0] = v.x;
+                if (a + 1 < g.a_count) o[1] = v.y;
+                if (a + 2 < g.a_count) o[2] = v.z;
+                if (a + 3 < g.a_count) o[3] = v.w;
+            }
+        }
+    }
+    if (ONES) {
+        if (ones_wave && kq == 0) {       // D row 0 of the ones product: this workgroup's share of sum_k Bop(b, k)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int b = b_base + wb * (BB / 2) + j * 16 + li;
+                if (b < g.b_count) g.ones_out[((int64_t)z * g.na + at) * g.ones_split_stride + b] = oacc[j].x;
+            }
+        }
+    }
+}
+
 // EPI 0: plain store (split-K partial).  1: + bias, activation (act 0 none, 1 ELU(alpha), 2 ReLU).  2: * activation derivative taken from
 // the activation's output yprev (ELU: y > 0 ? 1 : y + alpha; ReLU: y > 0; none: 1).
 // ABL (tools/gemm_probe.hip only): 1 = no global loads / LDS writes after the first tile, 2 = no MFMAs, 3 = no LDS fragment reads
@@ -355,70 +425,148 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
         body(std::integral_constant<int, 1>{}, t + 1);
     }
 
-    // epilogue: the lane holds out[b][a .. a+3] for each of its TA x TB tiles
-    float *out = g.out + (int64_t)z * g.out_split_stride;
+    gemm_epilogue<BA, BB, EPI, ONES>(g, acc, oacc, a_base, b_base, at, z, wa, wb, li, kq, ones_wave);
+}
+
+// ---- the same products with LDS-DMA staging (r4) ----
+// For the wide trunk products (K and both index dimensions 16-byte friendly) the operand tiles go global -> LDS directly
+// (`global_load_lds_dwordx4`: a wave-instruction lands 64 x 16 B as ONE contiguous KiB of LDS, wave-uniform base + 16 lane): no staging
+// registers, no mask multiplies, no ds_write pass (a ds_write_b128 occupies the LDS data path for 13 cycles), and the loads of tile t+2
+// are in flight across the barrier of tile t (three LDS stages, counted `s_waitcnt vmcnt`, raw `s_barrier` -- `__syncthreads()` would
+// drain the DMA queue).  The LDS image is lane-linear, so it cannot be padded; bank conflicts of the fragment reads are removed by an
+// XOR swizzle applied to the SOURCE address and to the read address alike (the destination stays linear):
+//   KC image [row][16 k] (64-B rows, four 16-B chunks): slot = chunk ^ G[(row >> 2) & 3], G = {0, 3, 2, 1}  ->  every ds_read_b128 lane
+//   group ({0-3,12-15,20-27}, ...) touches 16 distinct 4-bank runs;
+//   MC image [16 k][BT idx]: chunk(idx / 4) ^ 4 * ((k >> 2) & 1), i.e. idx ^ 16 on the k rows of odd kq  ->  the two kq halves of a
+//   32-lane ds_read_b32 group use disjoint banks.
+// Requirements (checked by dma_ok(); everything else takes the register-staged kernel above): both operands 16-byte aligned with
+// leading dimensions and index counts that are multiples of 4, the reduction length of every split a multiple of 16.  Out-of-range
+// rows / columns of the last tiles are loaded from clamped (valid) addresses and only ever reach outputs that are not stored.
+typedef const __attribute__((address_space(1))) void *qa_glb_ptr;
+typedef __attribute__((address_space(3))) void *qa_lds_ptr;
+static __device__ __forceinline__ void glds16(const float *src, float *dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((qa_glb_ptr)src, (qa_lds_ptr)dst_wave_uniform, 16, 0, 0);
+}
+static __device__ __forceinline__ int kc_swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }      // G = {0, 3, 2, 1}
+
+// per-lane element offsets (without the k-tile term) of the wave's DMA pieces of one operand tile: BT / 64 pieces per wave
+template <int BT, bool MC>
+static __device__ __forceinline__ void dma_offsets(uint32_t (&off)[BT / 64], int64_t ld, int idx0, int count, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < TA; ++i) {
-        const int a = a_base + wa * (BA / 2) + i * 16 + 4 * kq;
-        if (a >= g.a_count) continue;
-        const bool full = g.o_vec == 4 && a + 3 < g.a_count;
-        f4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (EPI == 1 && g.bias) {
-            if (full) bias = *(const f4 *)(g.bias + a);
-            else {
-                bias.x = g.bias[a];
-                if (a + 1 < g.a_count) bias.y = g.bias[a + 1];
-                if (a + 2 < g.a_count) bias.z = g.bias[a + 2];
-                if (a + 3 < g.a_count) bias.w = g.bias[a + 3];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TB; ++j) {
-            const int b = b_base + wb * (BB / 2) + j * 16 + li;
-            if (b >= g.b_count) continue;
-            f4 v = acc[i][j];
-            if (EPI == 1) {
-                v += bias;
-                if (g.act == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : g.alpha * (expf(v[r]) - 1.f);
-                } else if (g.act == 2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-            }
-            if (EPI == 2 && g.yprev && g.act != 0) {
-                const float *yp = g.yprev + (int64_t)b * g.ldy + a;
-                f4 y = {1.f, 1.f, 1.f, 1.f};
-                if (full) y = *(const f4 *)yp;
-                else {
-                    y.x = yp[0];
-                    if (a + 1 < g.a_count) y.y = yp[1];
-                    if (a + 2 < g.a_count) y.z = yp[2];
-                    if (a + 3 < g.a_count) y.w = yp[3];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= (g.act == 1) ? (y[r] > 0.f ? 1.f : y[r] + g.alpha) : (y[r] > 0.f ? 1.f : 0.f);
-            }
-            float *o = out + (int64_t)b * g.ldo + a;
-            if (full) *(f4 *)o = v;
-            else {
-                o[0] = v.x;
-                if (a + 1 < g.a_count) o[1] = v.y;
-                if (a + 2 < g.a_count) o[2] = v.z;
-                if (a + 3 < g.a_count) o[3] = v.w;
-            }
+    for (int p = 0; p < BT / 64; ++p) {
+        const int j = wave + 4 * p;                     // piece j of the tile: floats [256 j, 256 j + 256) of the LDS image
+        if (!MC) {
+            const int row = 16 * j + (lane >> 2), slot = lane & 3;
+            const int chunk = slot ^ kc_swz(row);
+            off[p] = (uint32_t)min(idx0 + row, count - 1) * (uint32_t)ld + (uint32_t)(4 * chunk);
+        } else {
+            const int f = 256 * j + 4 * lane, k = f / BT, pos = f - k * BT;
+            const int idx = pos ^ (((k >> 2) & 1) << 4);
+            off[p] = (uint32_t)k * (uint32_t)ld + (uint32_t)min(idx0 + idx, count - 4);
         }
     }
-    if (ONES) {
-        if (ones_wave && kq == 0) {       // D row 0 of the ones product: this workgroup's share of sum_k Bop(b, k)
+}
+template <int BT>
+static __device__ __forceinline__ void dma_issue(const float *__restrict__ P, const uint32_t (&off)[BT / 64], uint32_t tile_off, float *stage, int wave) {
 #pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                const int b = b_base + wb * (BB / 2) + j * 16 + li;
-                if (b < g.b_count) g.ones_out[((int64_t)z * g.na + at) * g.ones_split_stride + b] = oacc[j].x;
+    for (int p = 0; p < BT / 64; ++p) glds16(P + (off[p] + tile_off), stage + 256 * (wave + 4 * p));
+}
+template <int BT, bool MC>
+static __device__ __forceinline__ void dma_frag(float (&f)[4], const float *__restrict__ S, int i0, int li, int kq) {
+    if (!MC) {
+        const f4 v = *(const f4 *)(S + (i0 + li) * 16 + ((kq ^ kc_swz(li)) << 2));
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        const int pos = (i0 + li) ^ ((kq & 1) << 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = S[(kq * 4 + s) * BT + pos];
+    }
+}
+
+template <int BA, int BB, bool A_MC, bool B_MC, int EPI, bool ONES>
+__global__ void __launch_bounds__(256, 2) qa_gemm_dma_kernel(GemmArgs g) {
+    static_assert(BA % 64 == 0 && BB % 64 == 0, "every wave issues the same number of DMA pieces per tile");
+    constexpr int TA = BA / 32, TB = BB / 32;
+    constexpr int STAGE = GEMM_BK * (BA + BB), NSTAGE = 3;
+    constexpr int NLOAD = BA / 64 + BB / 64;            // DMA pieces per wave and tile
+    __shared__ __attribute__((aligned(16))) float lds[NSTAGE * STAGE];      // ONE LDS object (a second one makes hipcc drain the DMA queue before every ds_read)
+
+    const int total = g.na * g.nb * g.nsplit;
+    int id = blockIdx.x;
+    {
+        const int q = total >> 3, rmd = total & 7, xcd = id & 7, local = id >> 3;
+        id = (xcd < rmd) ? xcd * (q + 1) + local : rmd * (q + 1) + (xcd - rmd) * q + local;
+    }
+    const int at = id % g.na, bt = (id / g.na) % g.nb, z = id / (g.na * g.nb);
+    const int a_base = at * BA, b_base = bt * BB;
+    const int kbeg = z * g.k_per_split;
+    const int kend = min(g.kred, kbeg + g.k_per_split);
+    const int T = (kend - kbeg) / GEMM_BK;              // exact: dma_ok()
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave & 1, wb = wave >> 1, li = lane & 15, kq = lane >> 4;
+    const bool ones_wave = ONES && wa == 0;
+
+    f4 acc[TA][TB];
+    f4 oacc[TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TB; ++j) oacc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    uint32_t offa[BA / 64], offb[BB / 64];
+    dma_offsets<BA, A_MC>(offa, g.lda, a_base, g.a_count, wave, lane);
+    dma_offsets<BB, B_MC>(offb, g.ldb, b_base, g.b_count, wave, lane);
+    const uint32_t stepa = A_MC ? (uint32_t)GEMM_BK * (uint32_t)g.lda : (uint32_t)GEMM_BK;
+    const uint32_t stepb = B_MC ? (uint32_t)GEMM_BK * (uint32_t)g.ldb : (uint32_t)GEMM_BK;
+    const uint32_t basea = A_MC ? (uint32_t)kbeg * (uint32_t)g.lda : (uint32_t)kbeg;
+    const uint32_t baseb = B_MC ? (uint32_t)kbeg * (uint32_t)g.ldb : (uint32_t)kbeg;
+    auto issue = [&](int t, int stage) {       // past the last tile: the last tile again, into a stage nobody reads any more (keeps the wait counts uniform)
+        const uint32_t tt = (uint32_t)min(t, T - 1);
+        float *S = lds + stage * STAGE;
+        dma_issue<BA>(g.A, offa, basea + tt * stepa, S, wave);
+        dma_issue<BB>(g.B, offb, baseb + tt * stepb, S + GEMM_BK * BA, wave);
+    };
+    if (T > 0) {
+        issue(0, 0);
+        issue(1, 1);
+    }
+    int stage = 0;
+    for (int t = 0; t < T; ++t) {
+        // this wave's pieces of tile t have landed (tile t+1's stay in flight) ...
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+        // ... and after the barrier so have everybody's; everybody has also finished reading tile t-1, whose stage tile t+2 now takes
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const float *As = lds + stage * STAGE, *Bs = As + GEMM_BK * BA;
+        float af[TA][4], bf[TB][4];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) dma_frag<BA, A_MC>(af[i], As, wa * (BA / 2) + i * 16, li, kq);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) dma_frag<BB, B_MC>(bf[j], Bs, wb * (BB / 2) + j * 16, li, kq);
+        issue(t + 2, stage == 0 ? 2 : stage - 1);       // (t + 2) % 3
+        __builtin_amdgcn_sched_barrier(0);
+        const bool do_ones = ones_wave && (t % g.na) == at;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            if (ONES) {
+                if (do_ones) {
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bf[j][s], oacc[j], 0, 0, 0);
+                }
             }
         }
+        stage = stage == 2 ? 0 : stage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the two dummy tiles: no DMA may outlive the workgroup's LDS allocation
+    gemm_epilogue<BA, BB, EPI, ONES>(g, acc, oacc, a_base, b_base, at, z, wa, wb, li, kq, ones_wave);
 }
 
 // gw[i] = sum over the nsplit_w slabs (in order) of slabs[z * stride_w + i], i < n_w;  gb[i] = sum over the nsplit_b rows of
@@ -488,15 +636,44 @@ extern thread_local char qa_err_buf[512];
 #define g_gerr qa_err_buf
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+// operand element offsets are 32-bit inside the kernels (gemm_load: 64-bit row pointers cost 32 registers): the largest offset an
+// operand of `count` rows with leading dimension ld can produce must stay below 2^32 (it used to wrap silently)
+static inline bool fits_u32(int64_t count, int64_t ld) { return count > 0 && ld >= 0 && count * ld < ((int64_t)1 << 32); }
 
-// tile configuration: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64, 3 = 64 x 128, 4 = 32 x 128 (A side x B side; 4: window GEMMs with <= 32 outputs)
+// tile configuration: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64, 3 = 64 x 128, 4 = 32 x 128 (A side x B side; 4: window GEMMs with <= 32 outputs);
+// 10.. = the LDS-DMA kernel: 10 = 128 x 192, 11 = 128 x 128, 12 = 128 x 64, 13 = 64 x 64, 14 = 64 x 192
 static void tile_dims(int cfg, int *ba, int *bb) {
+    if (cfg >= 10) {
+        static const int dims[5][2] = {{128, 192}, {128, 128}, {128, 64}, {64, 64}, {64, 192}};
+        const int c = cfg - 10 > 4 ? 1 : cfg - 10;
+        *ba = dims[c][0]; *bb = dims[c][1];
+        return;
+    }
     *ba = (cfg == 0 || cfg == 1) ? 128 : (cfg == 4 ? 32 : 64);
     *bb = (cfg == 0 || cfg == 3 || cfg == 4) ? 128 : 64;
+}
+// may this product run on qa_gemm_dma_kernel?  (16-byte operands; for k-contiguous operands the reduction in whole 16-wide tiles per split)
+static bool dma_ok(const GemmArgs &g) {
+    return g.a_vec == 4 && g.b_vec == 4 && g.a_count >= 4 && g.b_count >= 4 && g.kred % GEMM_BK == 0 && g.k_per_split % GEMM_BK == 0 && g.kred >= GEMM_BK;
+}
+template <bool A_MC, bool B_MC, int EPI, bool ONES>
+static void gemm_launch_dma(int cfg, GemmArgs &g, hipStream_t st) {
+    int ba, bb; tile_dims(cfg, &ba, &bb);
+    g.na = (g.a_count + ba - 1) / ba;
+    g.nb = (g.b_count + bb - 1) / bb;
+    const dim3 grid((unsigned)(g.na * g.nb * g.nsplit));
+    switch (cfg) {
+    case 10: hipLaunchKernelGGL((qa_gemm_dma_kernel<128, 192, A_MC, B_MC, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    case 12: hipLaunchKernelGGL((qa_gemm_dma_kernel<128, 64, A_MC, B_MC, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    case 13: hipLaunchKernelGGL((qa_gemm_dma_kernel<64, 64, A_MC, B_MC, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    case 14: hipLaunchKernelGGL((qa_gemm_dma_kernel<64, 192, A_MC, B_MC, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((qa_gemm_dma_kernel<128, 128, A_MC, B_MC, EPI, ONES>), grid, dim3(256), 0, st, g); break;
+    }
 }
 
 template <bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES>
 static void gemm_launch_v(int cfg, GemmArgs &g, hipStream_t st) {
+    if (cfg < 0 || cfg > 3) cfg = 2;          // 4 (32 x 128) exists for the window GEMMs only (gemm_launch_conv); a forced 4 here used to size the grid for 32 x 128 and launch 64 x 128
     int ba, bb; tile_dims(cfg, &ba, &bb);
     g.na = (g.a_count + ba - 1) / ba;
     g.nb = (g.b_count + bb - 1) / bb;
@@ -520,6 +697,8 @@ static void gemm_launch_conv(int cfg, GemmArgs &g, hipStream_t st) {
 }
 template <bool A_MC, bool B_MC, int EPI, bool ONES>
 static void gemm_launch(int cfg, GemmArgs &g, hipStream_t st) {
+    if (cfg >= 10 && dma_ok(g)) { gemm_launch_dma<A_MC, B_MC, EPI, ONES>(cfg, g, st); return; }
+    if (cfg >= 10) cfg = cfg == 10 || cfg == 11 ? 0 : (cfg == 12 ? 1 : (cfg == 14 ? 3 : 2));      // not DMA-able: the register-staged kernel's nearest tile
     if (g.a_vec == 4 && g.b_vec == 4) gemm_launch_v<A_MC, B_MC, 4, 4, EPI, ONES>(cfg, g, st);
     else if (g.a_vec == 4) gemm_launch_v<A_MC, B_MC, 4, 1, EPI, ONES>(cfg, g, st);
     else if (g.b_vec == 4) gemm_launch_v<A_MC, B_MC, 1, 4, EPI, ONES>(cfg, g, st);
@@ -548,6 +727,7 @@ int qa_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t 
                       int32_t in_features, int32_t out_features, int32_t act, float alpha, void *stream) {
     if (!x || !weight || !y || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 || ldx < in_features || ldw < in_features ||
         ldy < out_features || act < 0 || act > 2) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward: bad argument"); return QA_E_ARG; }
+    if (!fits_u32(rows, ldx) || !fits_u32(out_features, ldw)) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward: rows * ldx (or out_features * ldw) >= 2^32 elements"); return QA_E_ARG; }
     GemmArgs g = {};
     g.A = weight; g.lda = ldw; g.a_count = out_features;
     g.B = x; g.ldb = ldx; g.b_count = (int)rows;
@@ -568,6 +748,7 @@ int qa_linear_backward_input(const float *grad_out, int64_t ldg, const float *we
     if (!grad_out || !weight || !grad_in || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 || ldg < out_features ||
         ldw < in_features || ldgi < in_features || act_prev < 0 || act_prev > 2 || (act_prev != 0 && (!y_prev || ldyp < in_features))) {
         snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_input: bad argument"); return QA_E_ARG; }
+    if (!fits_u32(rows, ldg) || !fits_u32(out_features, ldw)) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_input: rows * ldg (or out_features * ldw) >= 2^32 elements"); return QA_E_ARG; }
     GemmArgs g = {};
     g.A = weight; g.lda = ldw; g.a_count = in_features;                 // MC: element (in feature a, out feature k) = W[k * ldw + a]
     g.B = grad_out; g.ldb = ldg; g.b_count = (int)rows;
@@ -590,7 +771,8 @@ static void wgrad_plan(int64_t rows, int32_t in_features, int32_t out_features, 
     if (g_force_cfg >= 0) c = g_force_cfg;
     int ba, bb; tile_dims(c, &ba, &bb);
     const int64_t tiles = (int64_t)((in_features + ba - 1) / ba) * ((out_features + bb - 1) / bb);
-    const int64_t target = (c == 0) ? 512 : 1024;       // resident workgroups: 2 per CU for the 128 x 128 tile (190-200 registers), 4 otherwise
+    // resident workgroups: 2 per CU for the 128 x 128 tile (190-200 registers), 4 otherwise; LDS-DMA tiles: 2 (128 x 192: 60 KB of LDS), 3 (48 KB), 4
+    const int64_t target = (c == 0 || c == 10) ? 512 : ((c == 11 || c == 14) ? 768 : 1024);
     int64_t s = target / tiles;                         // never a few workgroups more than one resident round: they would run alone
     const int64_t smax = (rows + 255) / 256;
     if (s > smax) s = smax;
@@ -614,6 +796,7 @@ int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
                               int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream) {
     if (!grad_out || !x || !grad_weight || !grad_bias || !scratch || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 ||
         ldg < out_features || ldx < in_features) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: bad argument"); return QA_E_ARG; }
+    if (!fits_u32(rows, ldg) || !fits_u32(rows, ldx)) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: rows * ldg (or rows * ldx) >= 2^32 elements"); return QA_E_ARG; }
     if (scratch_bytes < qa_linear_backward_weight_scratch_bytes(rows, in_features, out_features) || !aligned16(scratch)) {
         snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: scratch too small or not 16-byte aligned"); return QA_E_ARG; }
     int cfg, s, kps; wgrad_plan(rows, in_features, out_features, &cfg, &s, &kps);
@@ -776,7 +959,7 @@ int qa_linear_forward_split(const float *x, int64_t ldx, const float *weight, in
                             int32_t in_features, int32_t out_features, int32_t act, float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
     if (!x || !weight || !y || !scratch || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 || out_features % 4 || ldx < in_features ||
         ldw < in_features || ldy < out_features || ldy % 4 || act < 0 || act > 2 || !aligned16(y) || (bias && !aligned16(bias)) ||
-        rows * ldx >= ((int64_t)1 << 31)) {
+        !fits_u32(rows, ldx) || !fits_u32(out_features, ldw)) {
         snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward_split: bad argument (out features and ldy multiples of 4, y / bias 16-byte aligned)"); return QA_E_ARG; }
     if (scratch_bytes < qa_linear_forward_split_scratch_bytes(rows, in_features, out_features) || !aligned16(scratch)) {
         snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward_split: scratch too small or not 16-byte aligned"); return QA_E_ARG; }

@@ -813,7 +813,10 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                 if (sc_on[pr]) {
                     Row r; row_load(priv, QA_PRIV_SELF + 20 * pr, r);
                     const float tl = r.jl[0] * w[0] + r.jl[1] * w[1] + r.jl[2] * w[2];
-                    float res = r.bias + tl + (pr == 0 ? dpp_f<0xB1>(tl) : dpp_f<0x4E>(tl));
+                    // own + partner term FIRST: the sum is commutative, so both lanes of the pair hold identical bits before the (identical) bias
+                    // and base chain are added -- (bias + own) + partner rounds differently on the two sides and lets their lam drift apart
+                    const float tls = tl + (pr == 0 ? dpp_f<0xB1>(tl) : dpp_f<0x4E>(tl));
+                    float res = r.bias + tls;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) res = fmaf(r.jh[i], ub[i], res);
                     const float lam = fmaxf(sc_lam[pr] - res * r.dinv, 0.f), dl = lam - sc_lam[pr];

@@ -325,11 +325,16 @@ def linear_forward_split_raw(x, weight, bias, act, alpha=1.0):
     rows, k = x.shape
     n = weight.shape[0]
     nb = lib.qa_linear_forward_split_scratch_bytes(rows, k, n)
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
-    sc = _split_scratch.get(key)
-    if sc is None or sc.numel() < nb:
-        sc = torch.empty(nb, dtype=torch.uint8, device=x.device)
-        _split_scratch[key] = sc
+    if torch.cuda.is_current_stream_capturing():
+        # a recording bakes the address in: allocate from the graph's pool (as linear_backward_weight_raw does), never from a cache whose
+        # buffer a later, larger request replaces -- the replays would write partial sums into freed memory
+        sc = torch.empty(max(nb, 16), dtype=torch.uint8, device=x.device)
+    else:
+        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        sc = _split_scratch.get(key)
+        if sc is None or sc.numel() < nb:
+            sc = torch.empty(nb, dtype=torch.uint8, device=x.device)
+            _split_scratch[key] = sc
     y = torch.empty(rows, n, dtype=torch.float32, device=x.device)
     _check(lib.qa_linear_forward_split(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias) if bias is not None else None, _ptr(y), n, rows, k, n,
                                        int(act), float(alpha), _ptr(sc), sc.numel(), C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)),
@@ -573,6 +578,31 @@ def recordable(*nets):
     return True
 
 
+# autograd nodes whose backward is one of torch's batch reductions (bias gradient of F.linear / addmm / conv, broadcast gradients, loss means,
+# batch-norm statistics): exactly what must not end up in a recorded step (profiles/r2_hipgraph_stale_reductions.md)
+_TORCH_BATCH_REDUCTION_NODES = ("AddmmBackward", "LinearBackward", "SumBackward", "MeanBackward", "ConvolutionBackward", "NativeBatchNormBackward",
+                                "MiopenBatchNormBackward", "CudnnBatchNormBackward", "NormBackward", "LinalgVectorNormBackward", "NativeLayerNormBackward")
+
+
+def assert_recordable_graph(outputs, what="step"):
+    """`recordable()` judges the MODULES; this judges the autograd graph a step actually built (a bare `self.fc(x)` in a custom
+    network passes the module whitelist and still puts torch's `sum(0)` into the recording).  Called while a step is being captured, on the
+    tensors whose gradients start the backward pass; raises -- the capture blocks then keep the step eager -- when a node of the graph is one
+    of torch's batch reductions."""
+    seen, stack, bad = set(), [t.grad_fn for t in outputs if torch.is_tensor(t) and t.grad_fn is not None], []
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        name = type(fn).__name__
+        if name.startswith(_TORCH_BATCH_REDUCTION_NODES):
+            bad.append(name)
+        stack.extend(f for f, _ in fn.next_functions)
+    if bad:
+        raise RuntimeError(f"{what}: the autograd graph contains torch batch reductions {sorted(set(bad))}; not recorded (they go stale under hipGraph replay)")
+
+
 def ppo_loss(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values, *, clip,
              c_surr, c_value, c_bound, c_entropy, clipped_value=True):
     return _PpoLoss.apply(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
@@ -778,6 +808,12 @@ class ClipAdam:
         t = self._tab
         ptrs = [p.grad.data_ptr() for p in params]
         inline = len(ptrs) <= 64                        # QA_ADAM_MAX_INLINE: the pointers ride in the kernel arguments, no table copy
+        if not inline and torch.cuda.is_current_stream_capturing():
+            # The table path uploads ONE shared pinned host table; a captured copy of it reads the host memory at REPLAY time, so every
+            # recording but the last would step with the last recording's (or freed) gradient addresses.  Refuse: the
+            # callers' capture blocks catch this and keep the step eager.
+            raise RuntimeError(f"ClipAdam: {len(ptrs)} gradient tensors (> 64) cannot ride in the kernel arguments, and the pointer-table "
+                               "upload cannot be recorded into a hipGraph; this step stays eager")
         if not inline and ptrs != t["grad_ptrs"]:       # autograd allocated new gradient tensors: refresh the pointer table
             if t.get("copied") is not None:
                 t["copied"].synchronize()               # the pinned staging buffer may still be waiting for its last async copy

@@ -625,6 +625,8 @@ class SSInfoGAIL:
                     t.record_stream(cur)
         # (tried and dropped: the dW GEMMs of the Linear+ELU layers on a fourth stream, off the dX critical path -- 34.1 -> 37.8 ms:
         # big GEMMs running side by side slow each other more than the shorter dependency chain saves)
+        if self._recording_ac:
+            fused_mod.assert_recordable_graph([est, mu, value, priv_latent], "PPO step")
         torch.autograd.backward([est, mu, value, priv_latent], [g_est, dmu, dvalue.view_as(value), g_priv])
         ac.std.grad = dstd.view_as(ac.std)          # std enters the objective through qa_ppo_loss only
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
@@ -809,6 +811,8 @@ class SSInfoGAIL:
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.zero_grad()
         if direct:
+            if self._recording_disc:
+                fused_mod.assert_recordable_graph([d_all, eps_all, c_all, g], "discriminator step")
             torch.autograd.backward([d_all, eps_all, c_all, g], [g_d, g_eps, g_c, gdet * (2.0 * self.disc_grad_penalty / gdet.shape[0])])
         else:
             loss.backward()
@@ -871,6 +875,8 @@ class SSInfoGAIL:
         else:
             loss = (target - hist).norm(p=2, dim=1).mean()
         self.optim_hist_encoder.zero_grad()
+        if self._on_gpu and torch.cuda.is_current_stream_capturing():
+            fused_mod.assert_recordable_graph([hist], "DAgger step")
         loss.backward()
         params = list(ac.history_encoder.parameters())
         self._sync_grads(params)

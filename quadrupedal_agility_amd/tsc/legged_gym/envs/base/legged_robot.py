@@ -238,8 +238,8 @@ class LeggedRobot:
 
     def _reset_articulated_obstacles(self, flags, any_reset):
         """:812-823 without a host sync: the resetting envs' see-saw goes to its rest tilt on the side the robot will meet (randomize_start:
-        a start past the see-saw flips it), their bar / tyre to the drive's target; every env's obstacle velocities are zeroed when anyone
-        resets (`self.obst_dof_vel[:] = 0.0`)"""
+        a start past the see-saw flips it); their bar / tyre keep their offsets (the reference writes the see-saw's position only); every
+        env's obstacle velocities are zeroed when anyone resets (`self.obst_dof_vel[:] = 0.0`)"""
         if not self.articulated:
             return
         st = self.obst_state
@@ -248,7 +248,6 @@ class LeggedRobot:
         if self.cfg.obstacle.randomize_start:
             rest = torch.where(self.cur_obst_idx > self._seesaw_order, -rest, rest)
         st[:, 0, 0] = torch.where(f, rest, st[:, 0, 0])
-        st[:, 1:, 0] = torch.where(f.view(-1, 1), torch.zeros_like(st[:, 1:, 0]), st[:, 1:, 0])
         st[:, :, 1] *= (1.0 - any_reset.to(torch.float32))
 
     # ------------------------------------------------------------------ API

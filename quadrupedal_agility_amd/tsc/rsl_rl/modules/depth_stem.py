@@ -31,6 +31,10 @@ def _check(rc, name):
 
 def _scratch_for(dev, nbytes):
     """per device AND stream: two encoders running on two streams must not share partial sums"""
+    if torch.cuda.is_current_stream_capturing():
+        # a recording bakes the address in: the buffer must belong to the graph's pool, not to a cache that a later, larger request replaces
+        # (the old block would go back to the allocator under the graph's replays; ADVICE r3)
+        return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -810,6 +810,37 @@ def test_clip_adam_pointer_table_path_with_many_tensors():
 
 
 @pytest.mark.gpu
+def test_clip_adam_refuses_to_record_the_pointer_table_path():
+    """with more than 64 gradient tensors the step uploads a shared pinned host table; recorded, that copy would read the host
+    memory at replay time (another slot's or freed addresses).  The step refuses to be captured -- the callers then stay eager -- and the
+    same object keeps stepping correctly outside a capture."""
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import ClipAdam
+    torch.manual_seed(1)
+    mk = lambda: torch.nn.ModuleList([torch.nn.Linear(5, 3) for _ in range(35)]).cuda()      # 70 tensors
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    kw = dict(lr=torch.tensor(1e-3, device="cuda"), fused=True, capturable=True)
+    oa, ob = torch.optim.Adam(a.parameters(), **kw), torch.optim.Adam(b.parameters(), **kw)
+    stepper = ClipAdam(ob, 1.0)
+
+    def grads(k):
+        g = torch.Generator(device="cuda").manual_seed(k)
+        for p, q in zip(a.parameters(), b.parameters()):
+            p.grad = torch.randn(p.shape, device="cuda", generator=g); q.grad = p.grad.clone()
+    grads(0); torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0); oa.step(); stepper.step()      # state exists from here on
+    grads(1)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="cannot be recorded|stays eager"):
+        with torch.cuda.graph(graph):
+            stepper.step()
+    torch.cuda.synchronize()
+    torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0); oa.step(); stepper.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,o,k", [(24576, 1, 128), (24576, 12, 128), (49152, 18, 128), (3072, 3, 128), (5000, 29, 64), (2049, 32, 300)])
 def test_narrow_wgrad_matches_torch_and_oracle(rows, o, k):
     """qa_narrow_wgrad: dW = gy^T x, db = sum gy for layers with <= 32 outputs (actor / critic heads), against torch in fp64 and the
