@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 12
+#define QA_ABI_VERSION 13
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -531,6 +531,15 @@ int qa_gather_rows(const int64_t *idx, const int64_t *idx_block, int64_t rows, i
  * step never reads the KL on the host:  *lr = max(lr_min, *lr / factor) if *kl > 2 desired_kl;  min(lr_max, *lr * factor) if
  * 0 < *kl < desired_kl / 2;  unchanged otherwise.  The reference uses factor 1.5, lr_min 1e-5, lr_max 1e-2. */
 int qa_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr, void *stream);
+
+/* extras["episode"] of reset_idx (bbc/legged_gym/envs/base/legged_robot.py:229-240: per reward term, the mean over the envs that reset this
+ * step of episode_sum / max_episode_length_s) from QA_T_EPISODE_STATS without a host sync and in ONE launch (ABI 13; it was ten eager
+ * launches per env step inside the recorded rollout): bin = (step - 1) & 1 with step = *step_dev when step_dev != NULL (the DEVICE step
+ * counter AFTER the step; recorded rollouts) else `step`; cnt = stats[bin][14]; for i < num_terms (<= 14):
+ *   means[i] = cnt > 0 ? stats[bin][i] / cnt / max_episode_length_s : means[i]   (kept when nobody reset, as the reference keeps its dict)
+ *   snapshot[i] = means[i]                                                         (the per-step values the runner averages over a rollout) */
+int qa_episode_means(const float *episode_stats, const int64_t *step_dev, int64_t step, int32_t num_terms, float max_episode_length_s, float *means,
+                     float *snapshot, void *stream);
 
 /* Rollout bookkeeping around qa_env_step (SSInfoGAIL.act / process_env_step, bbc/rsl_rl/algorithms/gail.py:176-212;
  * RolloutStorage.add_transitions, rollout_storage.py:60-74; the runner's episode sums, on_policy_runner.py:187-206).

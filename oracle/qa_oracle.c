@@ -2104,6 +2104,20 @@ int qo_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min,
     return QA_OK;
 }
 
+int qo_episode_means(const float *episode_stats, const int64_t *step_dev, int64_t step, int32_t num_terms, float max_episode_length_s, float *means,
+                     float *snapshot, void *stream) {
+    (void)stream;                                           /* legged_robot.py:229-240 */
+    if (!episode_stats || !means || !snapshot || num_terms <= 0 || num_terms > 14 || !(max_episode_length_s > 0.f)) return QA_E_ARG;
+    const int64_t st = step_dev ? step_dev[0] : step;
+    const float *b = episode_stats + 16 * (int)((st - 1) & 1);
+    const float cnt = b[14];
+    for (int i = 0; i < num_terms; ++i) {
+        if (cnt > 0.f) means[i] = b[i] / (cnt > 1.0f ? cnt : 1.0f) / max_episode_length_s;
+        snapshot[i] = means[i];
+    }
+    return QA_OK;
+}
+
 /* ---- policy inference chain (include/qa_sim.h "policy inference"): Estimator.forward (bbc/rsl_rl/modules/estimator.py:35-36),
  * ActorCritic.update_distribution / evaluate (actor_critic.py:171-196,222-225) as nn.Linear + ELU layers and column copies.
  * The twin keeps the weights row-major inside `packed` (the caller's offsets leave room: the device layout is padded) and

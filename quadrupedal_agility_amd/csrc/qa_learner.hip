@@ -646,6 +646,19 @@ __global__ void qa_kl_lr_rule_kernel(const float *kl, float desired_kl, float fa
     lr[0] = out;
 }
 
+/* extras["episode"] (legged_robot.py:229-240) from the step's EPISODE_STATS bin: one wavefront */
+__global__ void qa_episode_means_kernel(const float *__restrict__ stats, const int64_t *__restrict__ step_dev, int64_t step, int num_terms,
+                                        float max_len_s, float *__restrict__ means, float *__restrict__ snapshot) {
+    const int i = threadIdx.x;
+    if (i >= num_terms) return;
+    const int64_t st = step_dev ? step_dev[0] : step;
+    const float *b = stats + 16 * (int)((st - 1) & 1);
+    const float cnt = b[14];
+    const float m = cnt > 0.f ? b[i] / fmaxf(cnt, 1.0f) / max_len_s : means[i];
+    means[i] = m;
+    snapshot[i] = m;
+}
+
 // SELF: no clipping, so nothing has to be known about the whole gradient before the update -- the step count is read (old value) by every
 // workgroup, the bias corrections are recomputed per workgroup (the finalize kernel's expressions), and the LAST workgroup to arrive writes
 // the incremented counters and the scratch head: one launch instead of finalize + update (the discriminator's three optimisers, 80 steps
@@ -1244,6 +1257,17 @@ int qa_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min,
     hipLaunchKernelGGL(qa_kl_lr_rule_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, kl, desired_kl, factor, lr_min, lr_max, lr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_kl_lr_rule: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_episode_means(const float *episode_stats, const int64_t *step_dev, int64_t step, int32_t num_terms, float max_episode_length_s, float *means,
+                     float *snapshot, void *stream) {
+    if (!episode_stats || !means || !snapshot || num_terms <= 0 || num_terms > 14 || !(max_episode_length_s > 0.f)) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_episode_means: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_episode_means_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, episode_stats, step_dev, step, (int)num_terms,
+                       max_episode_length_s, means, snapshot);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_episode_means: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -10,6 +10,8 @@ Nothing here computes physics, rewards or observations on the host: if the HIP l
 built the constructor raises.
 """
 import numpy as np
+import ctypes as C
+
 import torch
 
 from quadrupedal_agility_amd import _capi
@@ -316,19 +318,30 @@ class LeggedRobot:
         """extras['episode'] / extras['time_outs'] of reset_idx (legged_robot.py:229-240) without a host sync:
         means over the envs that reset this step; when none reset the previous values are kept, like the
         reference keeps the dict of the last reset."""
-        if self._step_ctr is not None:
-            # recorded rollouts: the bin index must follow the DEVICE step counter (a host parity baked into a recording is only
-            # right when num_steps_per_env is even); the kernel accumulated into bin (step & 1) with step = counter - 1
-            st = self.sim.t["EPISODE_STATS"].index_select(0, (self._step_ctr - 1) & 1)[0]
-        else:
-            st = self.sim.t["EPISODE_STATS"][(self.common_step_counter - 1) & 1]
-        cnt = st[14]
-        mean = st[:_capi.NUM_REWARDS] / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
         # in place: `_episode_means` is a persistent buffer.  A recorded rollout bakes the ADDRESS of whatever tensor it
         # read first; rebinding the attribute to a fresh tensor every step let the pre-capture one be freed and reused,
         # and replays then read foreign data whenever no env reset in their first steps.
-        self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
-        snap = self._episode_means.clone()          # per-step values for the runner's per-iteration mean over the 24 steps
+        stats = self.sim.t["EPISODE_STATS"]
+        if stats.is_cuda and self._episode_means.is_contiguous():
+            # ONE launch (qa_episode_means; r4) for what used to be ten eager ones per env step inside the recorded rollout.  Recorded
+            # rollouts: the bin index follows the DEVICE step counter (a host parity baked into a recording is only right when
+            # num_steps_per_env is even); the kernel accumulated into bin (step & 1) with step = counter - 1
+            snap = torch.empty_like(self._episode_means)      # per-step values for the runner's per-iteration mean over the 24 steps
+            lib = _capi.load_library()
+            P = lambda t: C.c_void_p(t.data_ptr())
+            rc = lib.qa_episode_means(P(stats), P(self._step_ctr) if self._step_ctr is not None else None, int(self.common_step_counter), _capi.NUM_REWARDS,
+                                      float(self.max_episode_length_s), P(self._episode_means), P(snap), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"qa_episode_means failed with code {rc}: {lib.qa_last_error().decode()}")
+        else:
+            if self._step_ctr is not None:
+                st = stats.index_select(0, (self._step_ctr - 1) & 1)[0]
+            else:
+                st = stats[(self.common_step_counter - 1) & 1]
+            cnt = st[14]
+            mean = st[:_capi.NUM_REWARDS] / torch.clamp(cnt, min=1.0) / self.max_episode_length_s
+            self._episode_means.copy_(torch.where(cnt > 0, mean, self._episode_means))
+            snap = self._episode_means.clone()
         self.extras["episode"] = {"rew_" + n: snap[_capi.REWARD_NAMES.index(n)] for n in self.reward_names}
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
