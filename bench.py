@@ -497,9 +497,9 @@ def cpu_iteration_child():
     T = runner.num_steps_per_env
     print(json.dumps({"value": num_envs * T / dt_it, "unit": "env-steps/s", "iteration_s": dt_it, "rollout_s": sum(coll) / its, "learner_s": sum(lrn) / its,
                       "threads": threads,
-                      "why_these_threads": "capped at 64: torch's CPU GEMMs on (24,576 x 671) minibatches stop scaling beyond ~64 threads on this host "
-                                           "(more threads measured slower), and the learner is 90 % of the CPU iteration; the rollout-only figure above uses every core "
-                                           "because the oracle's env step is embarrassingly parallel over envs",
+                      "why_these_threads": "this leg is capped at min(cores, 64) threads (one NUMA-sized group for torch's intra-op pool; chosen in r2 to bound the "
+                                           "leg inside its 150 s limit, not a measured optimum) while the rollout-only figure above uses every core: the oracle's env "
+                                           "step is embarrassingly parallel over envs, the torch-CPU learner (90 % of this leg) is not",
                       "sample": f"{its} whole PPO iterations after 1 warm-up: {num_envs} envs x {T} steps of oracle physics + torch-CPU policy, GAE, 5 epochs x 4 minibatches, {threads} threads"}))
 
 
