@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""How often would the self-collision pairs this build does NOT model be in contact?  
+
+The reference enables self-collision on the Go2 asset (`self_collisions = 0`, bbc/legged_gym/envs/go2/go2_locomotion_config.py:72,
+tsc/.../go2_agility_config.py:43): PhysX then collides every pair of links that is not joined by a joint.  With fixed joints
+collapsed the robot is base (+ heads) and 4 x {hip, thigh, calf (+ lower calf, foot)}; the kernel models the calf-calf pairs of
+neighbouring legs (csrc/qa_physics.h) and nothing else.  This tool trains a policy with the product path and, over the WHOLE
+training run (exploration noise included: sampled rollouts from iteration 0 on), evaluates the URDF's collision shapes of every
+unmodelled pair by forward kinematics of the joint angles the env actually visits (self-collision depends on the joint angles only):
+per pair class the smallest gap seen and the fraction of env-steps with a gap below the contact offset (0.01 m, where a PhysX contact
+would be generated) and below 0 (penetration).
+
+Shapes (go2.urdf): base box 0.3762 x 0.0935 x 0.114; head cylinder r 0.05 / sphere r 0.047; hip cylinder r 0.046, length 0.04 along y;
+thigh box 0.034 x 0.0245 x 0.11 as its circumscribed capsule (r 0.021: conservative); calf / lower-calf cylinders as capsules, foot
+sphere r 0.022.  Capsule-capsule gaps are exact (segment-segment distance); gaps to the base box use its signed distance function at
+17 points per segment.
+
+  python tools/self_collision_proximity.py [--amp] [--num_envs 1024] [--iters 1000] [--every 10] [--out profiles/r4_self_collision_proximity.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+LEGS = ["FL", "FR", "RL", "RR"]
+HIP_XY = {"FL": (0.1934, 0.0465), "FR": (0.1934, -0.0465), "RL": (-0.1934, 0.0465), "RR": (-0.1934, -0.0465)}
+
+
+def rot_x(a):
+    c, s, o, z = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+    return torch.stack([torch.stack([o, z, z], -1), torch.stack([z, c, -s], -1), torch.stack([z, s, c], -1)], -2)
+
+
+def rot_y(a):
+    c, s, o, z = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+    return torch.stack([torch.stack([c, z, s], -1), torch.stack([z, o, z], -1), torch.stack([-s, z, c], -1)], -2)
+
+
+def seg_seg(p1, q1, p2, q2):
+    """distance between segments [p1,q1] and [p2,q2] (batched, (...,3)); Ericson 5.1.9"""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f = (d1 * d1).sum(-1), (d2 * d2).sum(-1), (d2 * r).sum(-1)
+    c, b = (d1 * r).sum(-1), (d1 * d2).sum(-1)
+    den = a * e - b * b
+    eps = 1e-12
+    s = torch.where(den > eps, ((b * f - c * e) / den.clamp_min(eps)).clamp(0, 1), torch.zeros_like(den))
+    s = torch.where(a > eps, s, torch.zeros_like(s))
+    t = torch.where(e > eps, (b * s + f) / e.clamp_min(eps), torch.zeros_like(s))
+    s = torch.where(t < 0, (-c / a.clamp_min(eps)).clamp(0, 1), torch.where(t > 1, ((b - c) / a.clamp_min(eps)).clamp(0, 1), s))
+    s = torch.where(a > eps, s, torch.zeros_like(s))
+    t = t.clamp(0, 1)
+    c1, c2 = p1 + d1 * s.unsqueeze(-1), p2 + d2 * t.unsqueeze(-1)
+    return (c1 - c2).norm(dim=-1)
+
+
+def box_sdf(p, half):
+    q = p.abs() - half
+    return q.clamp_min(0).norm(dim=-1) + q.max(dim=-1).values.clamp_max(0)
+
+
+def capsules(dof_pos):
+    """collision capsules of the 12 leg bodies in the base frame: dict name -> list of (p0, p1, radius)"""
+    out = {}
+    dev = dof_pos.device
+    v = lambda *x: torch.tensor(x, dtype=torch.float32, device=dev)
+    for i, leg in enumerate(LEGS):
+        q = dof_pos[:, 3 * i:3 * i + 3]
+        sy = 1.0 if leg[1] == "L" else -1.0
+        hx, hy = HIP_XY[leg]
+        Rh = rot_x(q[:, 0])
+        ph = v(hx, hy, 0.0).expand(len(q), 3)
+        T = lambda R, p, x: (R @ x.unsqueeze(-1)).squeeze(-1) + p
+        # hip cylinder: axis y, centre (0, +-0.08, 0), length 0.04, radius 0.046
+        out[leg + "_hip"] = [(T(Rh, ph, v(0, sy * 0.06, 0).expand_as(ph)), T(Rh, ph, v(0, sy * 0.10, 0).expand_as(ph)), 0.046)]
+        pt = T(Rh, ph, v(0, sy * 0.0955, 0).expand_as(ph))
+        Rt = Rh @ rot_y(q[:, 1])
+        out[leg + "_thigh"] = [(T(Rt, pt, v(0, 0, -0.0515).expand_as(ph)), T(Rt, pt, v(0, 0, -0.1615).expand_as(ph)), 0.021)]
+        pc = T(Rt, pt, v(0, 0, -0.213).expand_as(ph))
+        Rc = Rt @ rot_y(q[:, 2])
+        caps = []
+        # calf cylinder: centre (0.01, 0, -0.06), pitch -0.2, length 0.12, radius 0.013
+        ax = rot_y(torch.tensor(-0.2, device=dev)) @ v(0, 0, 1.0)
+        c0 = v(0.01, 0, -0.06)
+        caps.append((T(Rc, pc, (c0 - 0.06 * ax).expand_as(ph)), T(Rc, pc, (c0 + 0.06 * ax).expand_as(ph)), 0.013))
+        # lower calf: joint (0.02, 0, -0.148) pitch 0.05, cylinder length 0.065 r 0.011; then (-0.01, 0, -0.04) pitch 0.48, length 0.03 r 0.0155
+        R1 = rot_y(torch.tensor(0.05, device=dev)); p1 = v(0.02, 0, -0.148)
+        a1 = R1 @ v(0, 0, 1.0)
+        caps.append((T(Rc, pc, (p1 - 0.0325 * a1).expand_as(ph)), T(Rc, pc, (p1 + 0.0325 * a1).expand_as(ph)), 0.011))
+        R2 = R1 @ rot_y(torch.tensor(0.48, device=dev)); p2 = p1 + R1 @ v(-0.01, 0, -0.04)
+        a2 = R2 @ v(0, 0, 1.0)
+        caps.append((T(Rc, pc, (p2 - 0.015 * a2).expand_as(ph)), T(Rc, pc, (p2 + 0.015 * a2).expand_as(ph)), 0.0155))
+        f = T(Rc, pc, v(-0.002, 0, -0.213).expand_as(ph))
+        caps.append((f, f, 0.022))
+        out[leg + "_calf"] = caps
+    return out
+
+
+def base_gap(caps):
+    """smallest gap of a body's capsules to the base box and the two head shapes"""
+    g = None
+    for p0, p1, r in caps:
+        ts = torch.linspace(0, 1, 17, device=p0.device).view(1, -1, 1)
+        pts = p0.unsqueeze(1) + (p1 - p0).unsqueeze(1) * ts
+        d = box_sdf(pts, torch.tensor([0.1881, 0.04675, 0.057], device=p0.device)).min(dim=1).values - r
+        hu0 = torch.tensor([0.285, 0.0, 0.01 - 0.045], device=p0.device).expand_as(p0); hu1 = torch.tensor([0.285, 0.0, 0.01 + 0.045], device=p0.device).expand_as(p0)
+        d = torch.minimum(d, seg_seg(p0, p1, hu0, hu1) - r - 0.05)
+        hl = torch.tensor([0.293, 0.0, -0.06], device=p0.device).expand_as(p0)
+        d = torch.minimum(d, seg_seg(p0, p1, hl, hl) - r - 0.047)
+        g = d if g is None else torch.minimum(g, d)
+    return g
+
+
+def body_gap(ca, cb):
+    g = None
+    for p0, p1, r in ca:
+        for s0, s1, rr in cb:
+            d = seg_seg(p0, p1, s0, s1) - r - rr
+            g = d if g is None else torch.minimum(g, d)
+    return g
+
+
+NEIGHBOURS = {("FL", "FR"), ("RL", "RR"), ("FL", "RL"), ("FR", "RR")}
+
+
+def pair_gaps(dof_pos):
+    """{pair class: (N,) smallest gap over the pairs of the class} for every pair the kernel does not model (+ the modelled class for reference)"""
+    c = capsules(dof_pos)
+    out = {}
+    def put(k, g):
+        out[k] = g if k not in out else torch.minimum(out[k], g)
+    for leg in LEGS:
+        put("base - thigh", base_gap(c[leg + "_thigh"]))
+        put("base - calf", base_gap(c[leg + "_calf"]))
+        put("hip - calf (same leg)", body_gap(c[leg + "_hip"], c[leg + "_calf"]))
+    for i, a in enumerate(LEGS):
+        for b in LEGS[i + 1:]:
+            near = (a, b) in NEIGHBOURS
+            tag = "neighbouring legs" if near else "diagonal legs"
+            for x in ("hip", "thigh", "calf"):
+                for y in ("hip", "thigh", "calf"):
+                    if x == "calf" and y == "calf" and near:
+                        put("calf - calf, neighbouring legs (MODELLED, for reference)", body_gap(c[a + "_calf"], c[b + "_calf"]))
+                        continue
+                    kx, ky = sorted([x, y])
+                    put(f"{kx} - {ky}, {tag}", body_gap(c[a + "_" + x], c[b + "_" + y]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_envs", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--every", type=int, default=10, help="evaluate the rollouts of every k-th iteration")
+    ap.add_argument("--amp", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+    from quadrupedal_agility_amd.legged_gym.utils import get_args
+    cfg = Go2LocomotionCfg(); cfg.env.num_envs = a.num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = bool(a.amp); cfg.seed = a.seed
+    t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = bool(a.amp); t.seed = a.seed; t.runner.save_interval = 10 ** 9
+    torch.manual_seed(a.seed)
+    args = get_args(["--device", "gpu"])
+    env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
+    runner.use_rollout_graph = False
+    os.environ["QA_ROLLOUT_GRAPH"] = "0"            # eager rollouts: the wrapped step below must run on every step it samples
+    stats, state = {}, {"it": 0, "on": False, "n": 0}
+    orig = env.step
+
+    def step(actions):
+        r = orig(actions)
+        if state["on"]:
+            gaps = pair_gaps(env.dof_pos.clone())
+            for k, g in gaps.items():
+                s = stats.setdefault(k, {"min": float("inf"), "below_offset": 0, "below_zero": 0, "env_steps": 0, "per_phase": {}})
+                s["min"] = min(s["min"], float(g.min())); s["below_offset"] += int((g < 0.01).sum()); s["below_zero"] += int((g < 0).sum()); s["env_steps"] += g.numel()
+                ph = s["per_phase"].setdefault(state["phase"], [0, 0])
+                ph[0] += int((g < 0.01).sum()); ph[1] += g.numel()
+            state["n"] += 1
+        return r
+    env.step = step
+    for it in range(a.iters):
+        state["on"] = it % a.every == 0
+        state["phase"] = "iterations 0-99" if it < 100 else ("iterations 100-499" if it < 500 else "iterations 500+")
+        runner.learn(1, init_at_random_ep_len=(it == 0))
+    res = {"what": "gap between the URDF collision shapes of body pairs the env kernel does not collide (and the modelled calf-calf class for reference), "
+                   "evaluated by forward kinematics on the joint angles visited during a whole training run (sampled rollouts, exploration noise included)",
+           "config": "BASELINE config 3 (AMP, mocap resets)" if a.amp else "BASELINE config 2", "num_envs": a.num_envs, "iterations": a.iters,
+           "sampled_env_steps_per_pair_class": state["n"] * a.num_envs, "contact_offset_m": 0.01, "pairs": {}}
+    for k, s in sorted(stats.items()):
+        res["pairs"][k] = {"min_gap_m": round(s["min"], 4), "fraction_below_contact_offset": s["below_offset"] / s["env_steps"],
+                           "fraction_penetrating": s["below_zero"] / s["env_steps"],
+                           "fraction_below_contact_offset_by_phase": {p: v[0] / max(v[1], 1) for p, v in s["per_phase"].items()}}
+    txt = json.dumps(res, indent=1)
+    if a.out:
+        open(a.out, "w").write(txt)
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()
