@@ -387,6 +387,18 @@ def own_layer(k, n):
     return {"none": False, "heads": head, "small": small, "narrow": head or small}.get(OWN_LAYERS, False)
 
 
+def pad16(k):
+    return (int(k) + 15) // 16 * 16
+
+
+def pad_k():
+    """First layers whose input width is not a multiple of 16 (critic 671, actor 101) run on rows the CALLER has zero-padded to whole 16-wide
+    k-tiles (rollout storage / minibatch copy: 672; the actor's concatenation: 112) against a zero-padded copy of the weight: every operand
+    of the wide products is then 16-byte aligned with whole k-tiles, i.e. eligible for the LDS-DMA GEMM (csrc/qa_gemm.hip).  Only when
+    every layer runs on our kernels (QA_OWN_LAYERS=all): the library path multiplies by the unpadded weight."""
+    return ENABLED and OWN_GEMM and (ALL_OWN or OWN_LAYERS == "all") and os.environ.get("QA_PAD_K", "1") != "0"
+
+
 def slab_sum(parts):
     """sum over the leading dimension of a contiguous (S, ...) tensor by qa_slab_sum (fixed order) -- not torch's sum(0)"""
     lib = _capi.load_library()
@@ -408,19 +420,24 @@ class _MlpChain(torch.autograd.Function):
     def forward(ctx, x, spec, *params):
         h = _rows2d(x)
         acts = [h]
+        # zero-padded input rows (`pad_k`): the first weight is padded to the same width, once per forward (1.4 MB for the critic)
+        kpad = h.shape[1] - params[0].shape[1]
+        assert 0 <= kpad < 16, (h.shape, params[0].shape)
+        w0 = torch.nn.functional.pad(params[0].detach(), (0, kpad)) if kpad else params[0]
         for i, (act, alpha) in enumerate(spec):
-            h = linear_forward_raw(h, params[2 * i], params[2 * i + 1], act, alpha)
+            h = linear_forward_raw(h, w0 if i == 0 else params[2 * i], params[2 * i + 1], act, alpha)
             acts.append(h)
-        ctx.spec = spec
-        ctx.save_for_backward(*acts, *params)
+        ctx.spec, ctx.kpad = spec, kpad
+        ctx.save_for_backward(*acts, *params, *([w0] if kpad else []))
         return h
 
     @staticmethod
     def backward(ctx, gy):
-        spec = ctx.spec
+        spec, kpad = ctx.spec, ctx.kpad
         L = len(spec)
         saved = ctx.saved_tensors
-        acts, params = saved[:L + 1], saved[L + 1:]
+        acts, params = saved[:L + 1], saved[L + 1:L + 1 + 2 * L]
+        w0p = saved[-1] if kpad else None
         g = _rows2d(gy)
         act_top, alpha_top = spec[-1]
         if act_top != ACT_NONE:        # the chain ends in an activation (encoders): its derivative has no GEMM above it to ride on
@@ -432,11 +449,13 @@ class _MlpChain(torch.autograd.Function):
             need_w, need_b = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
             if need_w or need_b:
                 gw, gb = linear_backward_weight_raw(g, acts[i])
+                if i == 0 and kpad:             # the padded columns' gradient is exactly zero (their inputs are): drop them
+                    gw = gw[:, :w.shape[1]].contiguous()
                 grads[2 * i], grads[2 * i + 1] = (gw if need_w else None), (gb if need_b else None)
             if i > 0:
                 g = linear_backward_input_raw(g, w, acts[i], spec[i - 1][0], spec[i - 1][1])
             elif ctx.needs_input_grad[0]:
-                gx = linear_backward_input_raw(g, w, None, ACT_NONE)
+                gx = linear_backward_input_raw(g, w0p if kpad else w, None, ACT_NONE)       # (rows, padded k): zero in the padded columns
         return (gx, None, *grads)
 
 

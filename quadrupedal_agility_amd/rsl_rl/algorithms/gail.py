@@ -327,6 +327,8 @@ class SSInfoGAIL:
                 self._priv_coef_dev = torch.zeros((), device=dev)
                 flat = [x.flatten(0, 1) for x in (st.observations, st.actions, st.values, st.advantages, st.returns,
                                                   st.actions_log_prob, st.mu, st.sigma)]
+                if fused_mod.pad_k() and getattr(st, "_obs_padded", None) is not None:
+                    flat[0] = st._obs_padded.flatten(0, 1)      # the minibatch copy keeps the zero padding (672 columns): 16-byte aligned GEMM rows
                 sync = self.grad_sync
                 all_params = list(self.estimator.parameters()) + list(self.actor_critic.parameters())
 

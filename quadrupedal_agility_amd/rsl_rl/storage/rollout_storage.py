@@ -33,7 +33,11 @@ class RolloutStorage:
         self.obs_shape, self.privileged_obs_shape, self.actions_shape = obs_shape, privileged_obs_shape, actions_shape
         T, N = num_transitions_per_env, num_envs
         z = lambda *s: torch.zeros(T, N, *s, device=device)
-        self.observations = z(*obs_shape)
+        # rows padded with zeros to whole 16-float k-tiles (671 -> 672): `observations` is the reference's (T, N, obs) view of it, the padded slab is
+        # what the learner's first-layer GEMMs read (16-byte aligned rows; fused.pad_k)
+        width = int(obs_shape[-1])
+        self._obs_padded = torch.zeros(T, N, *obs_shape[:-1], (width + 15) // 16 * 16, device=device)
+        self.observations = self._obs_padded[..., :width]
         self.privileged_observations = self.observations if privileged_obs_shape[0] is not None else None
         self.rewards, self.values, self.returns, self.advantages, self.actions_log_prob = z(1), z(1), z(1), z(1), z(1)
         self.actions, self.mu, self.sigma = z(*actions_shape), z(*actions_shape), z(*actions_shape)

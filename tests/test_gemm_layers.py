@@ -155,6 +155,76 @@ def test_every_tile_configuration_computes_the_same_products(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 14])
+def test_lds_dma_tile_configurations(cfg):
+    """qa_gemm_dma_kernel (r4: global_load_lds staging, three LDS stages, swizzled images) behind tile configurations 10-14: aligned problems with
+    whole 16-wide k-tiles run on it -- full tiles, ragged last tiles in both index dimensions, one k-tile, rows that are a column slice of
+    wider (aligned) rows -- and problems it cannot take (k or the sample count not a multiple of 16, unaligned rows) fall back to the
+    register-staged kernel; all against torch in double.  Weight gradients bit-reproducible."""
+    from quadrupedal_agility_amd import _capi
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    lib = _capi.load_library()
+    lib.qa_gemm_force_config.argtypes = [C.c_int32]
+    try:
+        lib.qa_gemm_force_config(cfg)
+        for rows, k, n in [(768, 256, 384), (784, 672, 512), (400, 16, 68), (1040, 112, 20), (3072, 128, 128), (777, 201, 150), (776, 208, 150)]:
+            x, w, b, gy = _case(rows, k, n, seed=rows + cfg)
+            yprev = torch.randn(rows, k, generator=torch.Generator().manual_seed(cfg))
+            y = fused.linear_forward_raw(x.cuda(), w.cuda(), b.cuda(), 1, 1.0).cpu()
+            assert torch.allclose(y, _eager(x.double(), w.double(), b.double(), "elu", 1.0).float(), **_tol(k)), (rows, k, n)
+            gin = fused.linear_backward_input_raw(gy.cuda(), w.cuda(), yprev.cuda(), 1, 1.0).cpu()
+            ref = (gy.double() @ w.double()) * torch.where(yprev.double() > 0, torch.ones((), dtype=torch.float64), yprev.double() + 1.0)
+            assert torch.allclose(gin, ref.float(), **_tol(n)), (rows, k, n)
+            gw, gb = fused.linear_backward_weight_raw(gy.cuda(), x.cuda())
+            gw2, gb2 = fused.linear_backward_weight_raw(gy.cuda(), x.cuda())
+            assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+            assert torch.allclose(gw.cpu(), (gy.double().t() @ x.double()).float(), rtol=1e-4, atol=1e-4 * max(1.0, (rows / 1024) ** 0.5)), (rows, k, n)
+            assert torch.allclose(gb.cpu(), gy.double().sum(0).float(), rtol=1e-4, atol=1e-4 * max(1.0, (rows / 1024) ** 0.5))
+        # aligned column slices of wider rows (the minibatch copy's 672-column rows: columns 64..320)
+        wide = torch.randn(1024, 672, generator=torch.Generator().manual_seed(9)).cuda()
+        x = wide[:, 64:320]
+        _, w, b, gy = _case(1024, 256, 128, seed=3)
+        y = fused.linear_forward_raw(x, w.cuda(), b.cuda(), 0, 1.0).cpu()
+        assert torch.allclose(y, (x.cpu().double() @ w.double().t() + b.double()).float(), **_tol(256))
+        gw, _ = fused.linear_backward_weight_raw(gy.cuda(), x)
+        assert torch.allclose(gw.cpu(), (gy.double().t() @ x.cpu().double()).float(), rtol=1e-4, atol=1e-4)
+    finally:
+        lib.qa_gemm_force_config(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,pad", [(671, 1), (101, 11)])
+def test_chain_on_zero_padded_rows_equals_the_unpadded_modules(k, pad):
+    """fused.pad_k: the critic's 671-wide and the actor's 101-wide first layers run on rows the caller has zero-padded to whole 16-wide k-tiles,
+    against a zero-padded copy of the weight.  Outputs, every parameter gradient and the input gradient (zero in the padded columns) against
+    nn.Sequential on the unpadded rows."""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    torch.manual_seed(k)
+    rows = 3072
+    net = torch.nn.Sequential(torch.nn.Linear(k, 512), torch.nn.ELU(), torch.nn.Linear(512, 256), torch.nn.ELU(), torch.nn.Linear(256, 12)).cuda()
+    x = torch.randn(rows, k, device="cuda")
+    xp = torch.nn.functional.pad(x, (0, pad)).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    gy = torch.randn(rows, 12, device="cuda")
+    net(xr).backward(gy)
+    ref = [p.grad.clone() for p in net.parameters()] + [xr.grad.clone()]
+    for p in net.parameters():
+        p.grad = None
+    fused.ALL_OWN = True
+    try:
+        y = fused.mlp_chain([net], xp)
+        y.backward(gy)
+    finally:
+        fused.ALL_OWN = False
+    assert torch.allclose(y, net(x), rtol=2e-4, atol=2e-4)
+    got = [p.grad for p in net.parameters()] + [xp.grad[:, :k]]
+    for u, v in zip(got, ref):
+        assert u.shape == v.shape and u.is_contiguous()
+        assert torch.allclose(u, v, rtol=2e-4, atol=2e-5 * rows ** 0.5), float((u - v).abs().max())
+    assert float(xp.grad[:, k:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows", [1, 300, 24576])
 def test_chain_autograd_matches_the_unfused_modules(rows):
     """_MlpChain (trunk + head as one chain, input gradient included) against nn.Sequential under autograd"""
