@@ -64,10 +64,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    # QA_BENCH_SHARED_GPU=1 (a harness, NOT a scaling measurement): every rank of the job runs on GPU 0 and the buckets travel over gloo.
+    # What it bounds on a 1-GPU box: the cost of the data-parallel code path itself -- the PPO step as two graphs around a collective, the
+    # per-rank shards, 20 collectives per iteration -- when no multi-GPU node is available.  The line says so (`shared_gpu_harness`).
+    shared = os.environ.get("QA_BENCH_SHARED_GPU") == "1" and world > 1
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     forced_dp = os.environ.get("QA_FORCE_DATA_PARALLEL") == "1" and "MASTER_ADDR" in os.environ     # dev: DP code path on one GPU
-    if world > 1 or forced_dp:
+    if shared:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1 or forced_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(dev), rank=rank, world_size=world)
 
@@ -203,6 +211,8 @@ def main():
                                    f"{total_envs} envs in total = {args.num_envs} envs/GPU x {world}, {'plane' if args.terrain == 'plane' else 'height-field (trimesh course)'} terrain, 24 steps/iter, 5 epochs x 4 minibatches",
                        "num_envs_total": total_envs, "num_envs_per_gpu": args.num_envs, "steps_per_iter": T, "parallelism": f"dp{world}"},
             "wallclock_1k_iters_s": dt / args.steps * 1000.0,
+            **({"shared_gpu_harness": f"{world} ranks on ONE GPU, gloo collectives through host memory: bounds the data-parallel code path's own cost, says nothing about xGMI scaling",
+                "n_gpus": 1, "ranks": world} if shared else {}),
             "rollout_env_steps_per_s": args.num_envs * T * world / (sum(coll) / len(coll)),
             "collection_s": sum(coll) / len(coll), "learn_s": sum(lrn) / len(lrn),
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

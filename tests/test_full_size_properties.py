@@ -113,3 +113,62 @@ def test_hip_env_shards_reproduce_the_one_process_run_bit_for_bit():
             assert torch.equal(got, whole.t[name]), (k, name)
     for name in ("FRICTION", "MASS_PARAMS", "ENV_ORIGINS"):
         assert torch.equal(torch.cat([p.t[name] for p in parts]), whole.t[name]), name
+
+
+def _run_mocap(n, steps, seed=2):
+    """BASELINE config 3's env path (reset_mode 1: resets sample the real clips) at `n` envs: actions and the extra time-outs are drawn 4096 wide,
+    so env i sees the same inputs at any n"""
+    from quadrupedal_agility_amd.sim import QaSim
+    from tests.test_mocap_reset import real_clip_table
+    _, (frames, clips, first) = real_clip_table()
+    q = go2_cfg(n, seed=seed, reset_mode=1, num_mocap_frames=int(frames.shape[0]))
+    h = QaSim(q)
+    h.set_mocap(frames, clips, first)
+    h.reset_all()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    acts = torch.randn(steps, 4096, 12, device="cuda", generator=g) * 0.4
+    force = torch.rand(steps, 4096, device="cuda", generator=g) < 0.03           # ~3 % of the envs time out per step -> ~120 mocap resets per step at 4096
+    snaps, resets = [], 0
+    for k in range(steps):
+        h.t["EPISODE_LENGTH"][force[k, :n]] = 1000
+        h.step(acts[k, :n].contiguous())
+        resets += int(h.t["RESET"].sum())
+        if k % 8 == 7:
+            snaps.append({name: h.t[name].clone() for name in ("ROOT_STATES", "DOF_STATE", "OBS", "OBS_DISC", "REW", "RESET", "EPISODE_LENGTH", "COMMANDS", "LATENT_C")})
+    return h, snaps, resets, (frames, clips, first)
+
+
+def test_mocap_reset_env_at_4096_envs():
+    """config 3's env path (mocap_state_init=True) was compared with the oracle at 64 / 1000 envs only.  At the full size:
+    two runs are bit-identical; the first 64 envs equal a 64-env run bit for bit (the clip / frame draws are keyed by the global env id); every
+    reset lands between two neighbouring frames of a clip of the env's gait; the invariants of the default-pose test hold."""
+    h, a, resets, (frames, clips, first) = _run_mocap(4096, 48)
+    _, b, _, _ = _run_mocap(4096, 48)
+    assert resets > 48 * 4096 * 0.025
+    for sa, sb in zip(a, b):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    hs, small, _, _ = _run_mocap(64, 48)
+    ob, os_ = h.t["ENV_ORIGINS"][:64], hs.t["ENV_ORIGINS"]
+    for sb, ss in zip(a, small):
+        for k in ("DOF_STATE", "REW", "RESET", "EPISODE_LENGTH", "COMMANDS", "LATENT_C", "OBS", "OBS_DISC"):
+            assert torch.equal(sb[k][:64], ss[k]), k
+        assert torch.equal(sb["ROOT_STATES"][:64, 2:], ss["ROOT_STATES"][:, 2:])
+        assert torch.allclose(sb["ROOT_STATES"][:64, :2] - ob[:, :2], ss["ROOT_STATES"][:, :2] - os_[:, :2], atol=2e-4)
+    # envs that reset in the last step sit on a blend of two neighbouring frames of one of their gait's clips
+    last = a[-1]
+    rs = (last["RESET"] > 0).nonzero().flatten().cpu().numpy()
+    assert len(rs) > 20
+    dof = last["DOF_STATE"][:, :, 0].cpu().numpy(); gait = last["LATENT_C"].argmax(1).cpu().numpy()
+    for e in rs[:200]:
+        lo, hi = int(clips[first[gait[e]], 0]), int(clips[first[gait[e] + 1] - 1, 0] + clips[first[gait[e] + 1] - 1, 1])
+        d = np.abs(frames[lo:hi, 7:19] - dof[e]).max(axis=1)
+        step = np.abs(np.diff(frames[lo:hi, 7:19], axis=0)).max()
+        assert d.min() <= step + 1e-5, (e, d.min(), step)
+    for s in a:
+        root, obs = s["ROOT_STATES"], s["OBS"]
+        assert torch.isfinite(root).all() and torch.isfinite(obs).all() and torch.isfinite(s["OBS_DISC"]).all()
+        q = root[:, 3:7].norm(dim=1)
+        assert (q > 0.99).all() and (q < 1.01).all()            # the reference's slerp (1 / angle weights) leaves reset quaternions slightly non-unit, as in the reference
+        assert (obs.abs() <= 100.0 + 1e-4).all() and (s["REW"] >= 0).all()
+        assert (s["EPISODE_LENGTH"][s["RESET"] > 0] == 0).all()
