@@ -262,6 +262,16 @@ int qa_env_step(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t 
  * steps replays without host-side arguments (the reference keeps `common_step_counter` on the host, legged_robot.py:134). */
 int qa_env_step_dev(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t *step_counter_dev, void *stream);
 
+/* Training-mode exports (ABI 13).  Every step the reference's env refreshes tensors that nothing between two steps of a TRAINING run reads
+ * (they serve seam 1, play / logging and the task-level tree): 920 B of the 4,680 B an env-step writes.  mask bit 0: qa_env_step
+ * / qa_env_step_dev stop writing QA_T_CONTACT_FORCES, _RIGID_BODY_POS, _TORQUES, _TORQUES_ORG, _ACTIONS, _BASE_LIN_VEL, _BASE_ANG_VEL,
+ * _PROJECTED_GRAVITY, _RPY, _FEET_FORCE, _CONTACT_FILT, _SCAN_HEIGHT (they keep their last values) and maintain only the two newest slots of
+ * QA_T_ACTION_HISTORY (what a delay <= 1 can reach; a larger delay is refused while the mode is on).  mask bit 1 (only with bit 0: mask 3):
+ * QA_T_OBS_DISC / _OBS_DISC_TERM are not written either (the AMP runner is their only reader).  Everything the learner consumes --
+ * observations, rewards, resets, time-outs, commands, episode statistics, the simulator state -- is bit-identical with and without the mode.
+ * mask 0 (default) = the reference's behaviour.  The CPU twin accepts the call and keeps exporting. */
+int qa_set_lean_exports(qa_sim *sim, int32_t mask);
+
 /* reset_idx(all) followed by nothing else (legged_robot.py:67-69).  The reference's reset()
  * then takes one zero-action step; the host mirror does that through qa_env_step. */
 int qa_reset_all(qa_sim *sim, int64_t global_step, void *stream);

@@ -2104,6 +2104,12 @@ int qo_kl_lr_rule(const float *kl, float desired_kl, float factor, float lr_min,
     return QA_OK;
 }
 
+int qo_set_lean_exports(qa_sim *sim, int32_t mask) {
+    /* the twin always exports (tests compare lean HIP runs with it on the tensors the mode keeps) */
+    if (!sim || (mask != 0 && mask != 1 && mask != 3)) return QA_E_ARG;
+    return QA_OK;
+}
+
 int qo_episode_means(const float *episode_stats, const int64_t *step_dev, int64_t step, int32_t num_terms, float max_episode_length_s, float *means,
                      float *snapshot, void *stream) {
     (void)stream;                                           /* legged_robot.py:229-240 */

@@ -99,6 +99,7 @@ struct Ptrs {
 struct qa_sim {
     long long *prof = nullptr;
     int lanes = 4;                 // lanes per env of the step / simulate kernels (one quad: lane & 3 = leg)
+    int lean = 0;                  // qa_set_lean_exports
     qa_config cfg;
     Layout L;
     char *arena;
@@ -264,6 +265,10 @@ QA_DEV void stage_obstacles(const Ptrs &p, int env, int leg, float *rec) {
 
 // ------------------------------------------------------------------ the fused env step
 struct StepArgs { qa_config c; Ptrs p; MocapIdx mi; const float *actions; int delay; int64_t step; int64_t *step_ptr; long long *prof; };
+// LEAN (qa_set_lean_exports, MODE 0 only): bit 0 = do not write the tensors nothing between two steps of a training run reads (seam-1 / logging
+// exports: CONTACT_FORCES, RIGID_BODY_POS, TORQUES, TORQUES_ORG, ACTIONS, BASE_LIN_VEL, BASE_ANG_VEL, PROJECTED_GRAVITY, RPY, FEET_FORCE,
+// CONTACT_FILT, SCAN_HEIGHT) and keep only the two newest slots of the action ring (all a delay <= 1 can reach); bit 1 = no discriminator
+// observations either (OBS_DISC, OBS_DISC_TERM: read by the AMP runner only)
 #ifdef QA_SUBPROF
 #define QA_STAMP(k) do { } while (0)      // the substep stamps own the buffer in this build
 #else
@@ -353,7 +358,7 @@ struct PostIn {
     float fric;
 };
 
-template <bool PLANE, int LPE>
+template <bool PLANE, int LPE, int LEAN = 0>
 __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptrs &p, const MocapIdx &mi, long long *qa_prof, PostIn &in, const TerrainView &T,
                                                    const float *tbl, float *s_stage, float *s_rows, const int tix, const int bix, const int env,
                                                    const int leg, const bool valid, const bool owner, const int le, const int64_t step) {
@@ -464,7 +469,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     wave_lds_sync();          // physics scratch is dead from here on; the staging area takes its place
     // ---- terminal disc obs = previous OBS_DISC row; stage it
     float *sst = s_stage + le * S_ENV;
-    for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
+    if (!(LEAN & 2)) for (int i = leg; i < QA_NUM_OBS_DISC; i += 4) sst[S_DISCT + i] = p.obs_disc[(int64_t)env * QA_NUM_OBS_DISC + i];
 
     // ---- reset_idx :178-240
     V3 lav = st.vw, law = st.ww;      // last_root_vel is taken after the reset (:160)
@@ -564,13 +569,15 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         if (leg == 0) {
             rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
             rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
-            if (!PLANE) p.scan_height[env] = scan_h;
+            if (!PLANE && !(LEAN & 1)) p.scan_height[env] = scan_h;
             p.rew[env] = rew; p.reset[env] = reset; p.time_out[env] = (uint8_t)timeout; p.episode_length[env] = epl;
-            float *o3;
-            o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
-            o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = bav.x; o3[1] = bav.y; o3[2] = bav.z;
-            o3 = p.proj_grav + (int64_t)env * 3; o3[0] = pg.x; o3[1] = pg.y; o3[2] = pg.z;
-            o3 = p.rpy + (int64_t)env * 3; o3[0] = roll; o3[1] = pitch; o3[2] = yaw;
+            if (!(LEAN & 1)) {
+                float *o3;
+                o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
+                o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = bav.x; o3[1] = bav.y; o3[2] = bav.z;
+                o3 = p.proj_grav + (int64_t)env * 3; o3[0] = pg.x; o3[1] = pg.y; o3[2] = pg.z;
+                o3 = p.rpy + (int64_t)env * 3; o3[0] = roll; o3[1] = pitch; o3[2] = yaw;
+            }
             float *lr = p.last_root_vel + (int64_t)env * 6; lr[0] = lav.x; lr[1] = lav.y; lr[2] = lav.z; lr[3] = law.x; lr[4] = law.y; lr[5] = law.z;
             if (cmd_dirty) {
 #pragma unroll
@@ -583,20 +590,20 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         for (int k = 0; k < 3; ++k) {
             const int64_t j = (int64_t)env * 12 + 3 * leg + k;
             d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
-            p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k];
+            if (!(LEAN & 1)) { p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k]; }
             p.last_actions[j] = act[k]; p.last_dof_vel[j] = st.qd[k]; p.last_torques_org[j] = tau_org[k];   // :158-161
         }
-        p.feet_force[(int64_t)env * 4 + leg] = ffn;
+        if (!(LEAN & 1)) p.feet_force[(int64_t)env * 4 + leg] = ffn;
 #pragma unroll
         for (int k = 0; k < 3; ++k) p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = reset ? 0.f : fimp[k];
         p.last_contacts[(int64_t)env * 4 + leg] = contact;
-        p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
+        if (!(LEAN & 1)) p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
 #pragma unroll
         for (int r = 0; r < QA_NUM_REWARDS; ++r) if ((r & 3) == leg) p.episode_sums[(int64_t)r * N + env] = esum[r];
         if (reset) {   // action history is zeroed by reset_idx (:227)
             float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
 #pragma unroll
-            for (int r = 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
+            for (int r = (LEAN & 1) ? QA_ACTION_BUF_LEN - 2 : 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
         }
     }
     wave_lds_sync();
@@ -622,7 +629,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         if (lane < 26) dst[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
         if (lane < 57) dst[603 + lane] = clampf(ss[S_PROP + lane], -clipo, clipo);
         if (lane < 11) dst[660 + lane] = clampf(ss[S_TAIL + lane], -clipo, clipo);
-        if (lane < QA_NUM_OBS_DISC) {
+        if (!(LEAN & 2) && lane < QA_NUM_OBS_DISC) {
             float dv = ss[S_DISC + lane];
             p.obs_disc[(int64_t)ge * QA_NUM_OBS_DISC + lane] = dv;
             p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
@@ -665,8 +672,9 @@ QA_DEV void shift_history_store(const Ptrs &p, int bix, int lane, int N, const f
 // MODE 0: the whole LeggedRobot.step of the behaviour-level (BBC) tree.  MODE 1: the physics part only -- action-history
 // roll, delay, clip, decimation x (PD torque -> substep), refresh of the simulator tensors -- for the task-level (TSC) env,
 // whose own post_physics_step (goals, termination, rewards, reset, three observation rows) are separate kernels (qa_tsc_*).
-template <bool PLANE, int LPE, int MODE = 0>
+template <bool PLANE, int LPE, int MODE = 0, int LEAN = 0>
 __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_kernel(StepArgs a) {
+    static_assert(LEAN == 0 || MODE == 0, "the task-level tree reads every tensor the physics step exports");
     constexpr int WPB = LPE == 16 ? 4 : 1;             // wavefronts per workgroup
     constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
     const int tix = threadIdx.x & (QA_BLOCK - 1);      // lane
@@ -718,6 +726,19 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     float act[3], raw_act[3];
     {
         float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
+        const float clipa = c.clip_actions / c.action_scale;
+        if (LEAN & 1) {
+            // the two newest slots only (the host refuses a delay > 1 in this mode): 48 B read + 96 B written per env instead of 336 + 384
+            float prev[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { prev[k] = ah[12 * (QA_ACTION_BUF_LEN - 1) + k]; raw_act[k] = a.actions[(int64_t)env * 12 + 3 * leg + k]; }
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ah[12 * (QA_ACTION_BUF_LEN - 2) + k] = prev[k]; ah[12 * (QA_ACTION_BUF_LEN - 1) + k] = raw_act[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) act[k] = clampf(a.delay == 0 ? raw_act[k] : prev[k], -clipa, clipa);
+        } else {
         float h[QA_ACTION_BUF_LEN][3];
 #pragma unroll
         for (int r = 1; r < QA_ACTION_BUF_LEN; ++r)
@@ -731,7 +752,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ah[12 * r + k] = h[r][k];
         }
-        const float clipa = c.clip_actions / c.action_scale;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float src = a.delay == 0 ? h[QA_ACTION_BUF_LEN - 1][k] : h[QA_ACTION_BUF_LEN - 2][k];
@@ -740,6 +760,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
                 for (int r = 0; r < QA_ACTION_BUF_LEN - 2; ++r) if (QA_ACTION_BUF_LEN - 1 - r == a.delay) src = h[r][k];
             }
             act[k] = clampf(src, -clipa, clipa);
+        }
         }
     }
 
@@ -858,7 +879,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         hl_f = v3(xsum<LPE>(e2.x), xsum<LPE>(e2.y), xsum<LPE>(e2.z));
     }
     V3 hip_f = on_body(myb), thigh_f = on_body(myb + 1), calf_f = on_body(myb + 2) + co.self_f;
-    if (valid) {
+    if (valid && !(LEAN & 1)) {
         float *cf = p.cforce + (int64_t)env * 57, *rb = p.rbpos + (int64_t)env * 57;
         float *m = cf + 3 * myb;
         m[0] = hip_f.x; m[1] = hip_f.y; m[2] = hip_f.z; m[3] = thigh_f.x; m[4] = thigh_f.y; m[5] = thigh_f.z;
@@ -899,7 +920,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     in.st = st; in.foot_f = co.foot_f; in.hip_f = hip_f; in.thigh_f = thigh_f; in.calf_f = calf_f; in.base_f = base_f; in.foot_w = foot_w; in.fric = fric;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { in.act[k] = act[k]; in.raw_act[k] = raw_act[k]; in.tau[k] = tau[k]; in.tau_org[k] = tau_org[k]; in.sp[k] = sp[k]; in.sd[k] = sd[k]; in.fimp[k] = fimp[k]; }
-    post_physics_phase<PLANE, LPE>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step);
+    post_physics_phase<PLANE, LPE, LEAN>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step);
     // the device-side step counter advances once every wavefront of the launch is done with it (they all read it at their
     // start): the last one to arrive resets the arrival counter and bumps the step -- no separate 1-thread launch per env step
     if (a.step_ptr && tix == 0) {
@@ -1265,12 +1286,28 @@ static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; m.on = s->mocap_first[Q
 
 static void launch_env_step(qa_sim *s, const StepArgs &a, hipStream_t st) {
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
-    if (s->cfg.terrain_type == 1) hipLaunchKernelGGL((qa_env_step_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((qa_env_step_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+    const bool hf = s->cfg.terrain_type == 1;
+    if (s->lean == 3) {
+        if (hf) hipLaunchKernelGGL((qa_env_step_kernel<false, 4, 0, 3>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 3>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+    } else if (s->lean == 1) {
+        if (hf) hipLaunchKernelGGL((qa_env_step_kernel<false, 4, 0, 1>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 1>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+    } else {
+        if (hf) hipLaunchKernelGGL((qa_env_step_kernel<false, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((qa_env_step_kernel<true, 4>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
+    }
+}
+
+int qa_set_lean_exports(qa_sim *s, int32_t mask) {
+    if (!s || (mask != 0 && mask != 1 && mask != 3)) { snprintf(g_err, sizeof(g_err), "qa_set_lean_exports: mask must be 0, 1 or 3"); return QA_E_ARG; }
+    s->lean = mask;
+    return QA_OK;
 }
 
 int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t global_step, void *stream) {
     if (!s || !actions || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    if (s->lean && delay_steps > 1) { snprintf(g_err, sizeof(g_err), "qa_env_step: lean exports keep two action slots (delay <= 1)"); return QA_E_ARG; }
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = global_step; a.step_ptr = nullptr; a.prof = s->prof;
     launch_env_step(s, a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1279,6 +1316,7 @@ int qa_env_step(qa_sim *s, const float *actions, int32_t delay_steps, int64_t gl
 
 int qa_env_step_dev(qa_sim *s, const float *actions, int32_t delay_steps, int64_t *step_counter_dev, void *stream) {
     if (!s || !actions || !step_counter_dev || delay_steps < 0 || delay_steps >= QA_ACTION_BUF_LEN) return QA_E_ARG;
+    if (s->lean && delay_steps > 1) { snprintf(g_err, sizeof(g_err), "qa_env_step_dev: lean exports keep two action slots (delay <= 1)"); return QA_E_ARG; }
     StepArgs a; a.c = s->cfg; a.p = s->p; a.mi = mocap_idx(s); a.actions = actions; a.delay = delay_steps; a.step = 0;
     a.step_ptr = step_counter_dev; a.prof = s->prof;
     launch_env_step(s, a, (hipStream_t)stream);

@@ -296,6 +296,13 @@ class LeggedRobot:
             env_ids, terminal = None, None
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras, env_ids, terminal
 
+    def set_lean_exports(self, mask):
+        """Training mode of the fused step (qa_set_lean_exports, include/qa_sim.h): 1 = the tensors only seam 1 / play / logging read (contact_forces,
+        rigid_body_pos, torques, base_lin_vel, ..., all but the two newest action-history slots) are no longer refreshed; 3 = the discriminator
+        observations neither (no AMP).  0 restores the reference's behaviour.  The runner switches it on for learn(); everything the learner
+        consumes is bit-identical either way (tests/test_full_size_properties.py)."""
+        self.sim.set_lean_exports(mask)
+
     def use_device_step_counter(self):
         """Keep `common_step_counter` ALSO in device memory so that recorded (hipGraph) rollouts can replay without
         host arguments; the host integer stays the authority for logging and is advanced by the caller on replay."""

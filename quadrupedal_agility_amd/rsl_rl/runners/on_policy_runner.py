@@ -440,6 +440,10 @@ class OnPolicyRunner:
                 env.use_device_step_counter()
                 if self.amp_enabled:
                     env.task_obs_weight_dev = torch.tensor(float(env.task_obs_weight), device=dev)
+            # training never reads the per-step exports of the env (seam 1 / play / logging tensors): the fused step stops writing them
+            # (r4: measured traffic 1.37x -> see profiles/env_step_traffic.json); QA_LEAN_EXPORTS=0 keeps the reference's behaviour
+            if on_gpu and hasattr(env, "set_lean_exports") and os.environ.get("QA_LEAN_EXPORTS", "1") != "0" and not getattr(env, "sync_reset_ids", False):
+                env.set_lean_exports(1 if self.amp_enabled else 3)
         alg.actor_critic.train()
         alg.disc.train()
         N, T = env.num_envs, self.num_steps_per_env

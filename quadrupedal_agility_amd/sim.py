@@ -64,6 +64,12 @@ class QaSim:
                self.lib, "qa_env_step")
         self.global_step += 1
 
+    def set_lean_exports(self, mask):
+        """qa_set_lean_exports: 0 = every tensor refreshed each step (default), 1 = seam-1 / logging exports skipped + two-slot action ring,
+        3 = discriminator observations skipped too (training without AMP)"""
+        _check(self.lib.qa_set_lean_exports(self.h, int(mask)), self.lib, "qa_set_lean_exports")
+        self.lean_exports = int(mask)
+
     def step_dev(self, actions, delay, step_counter):
         """qa_env_step_dev: the step counter lives in device memory (graph-replayable)."""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()

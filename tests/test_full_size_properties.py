@@ -172,3 +172,58 @@ def test_mocap_reset_env_at_4096_envs():
         assert (q > 0.99).all() and (q < 1.01).all()            # the reference's slerp (1 / angle weights) leaves reset quaternions slightly non-unit, as in the reference
         assert (obs.abs() <= 100.0 + 1e-4).all() and (s["REW"] >= 0).all()
         assert (s["EPISODE_LENGTH"][s["RESET"] > 0] == 0).all()
+
+
+@pytest.mark.parametrize("mask,terrain", [(1, False), (3, False), (3, True)])
+def test_lean_exports_change_nothing_the_learner_reads(mask, terrain):
+    """qa_set_lean_exports (ABI 13): with the training-mode masks the fused step skips the seam-1 / logging exports and keeps two action-history
+    slots; observations, rewards, resets, time-outs, commands, episode statistics, the simulator state and the warm start stay bit-identical
+    to the default mode over 60 steps at 4096 envs (resets, pushes, command resampling included), and the skipped tensors keep their values."""
+    from quadrupedal_agility_amd.sim import QaSim
+
+    def make():
+        q = go2_cfg(4096, seed=4)
+        if not terrain:
+            h = QaSim(q)
+        else:               # a rough height field with the envs spread over it (tests/test_hip_parity.py's recipe, device side only)
+            from tests.test_hip_parity import rough_field
+            rows = cols = 400
+            q.terrain_type = 1
+            q.hf_rows, q.hf_cols, q.hf_hscale, q.hf_vscale, q.hf_border = rows, cols, 0.1, 0.005, 2.0
+            q.reset_xy_jitter = 1.0
+            h = QaSim(q)
+            rng = np.random.default_rng(4)
+            hs = rough_field(rows, cols, rng)
+            h.t["HEIGHT_SAMPLES"].copy_(torch.from_numpy(hs).cuda())
+            ox = rng.uniform(3.0, rows * 0.1 - 9.0, 4096); oy = rng.uniform(3.0, cols * 0.1 - 9.0, 4096)
+            ix = np.rint((ox + 2.0) / 0.1).astype(int); iy = np.rint((oy + 2.0) / 0.1).astype(int)
+            oz = np.array([hs[i - 12:i + 13, j - 12:j + 13].max() for i, j in zip(ix, iy)]) * 0.005
+            h.t["ENV_ORIGINS"].copy_(torch.from_numpy(np.stack([ox, oy, oz], 1).astype(np.float32)).cuda())
+        h.reset_all()
+        return h
+    a, b = make(), make()
+    b.set_lean_exports(mask)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    skipped = ["CONTACT_FORCES", "RIGID_BODY_POS", "TORQUES", "TORQUES_ORG", "ACTIONS", "BASE_LIN_VEL", "BASE_ANG_VEL", "PROJECTED_GRAVITY", "RPY", "FEET_FORCE",
+               "CONTACT_FILT"] + (["OBS_DISC", "OBS_DISC_TERM"] if mask & 2 else []) + (["SCAN_HEIGHT"] if terrain else [])
+    kept = ["ROOT_STATES", "DOF_STATE", "OBS", "REW", "RESET", "TIME_OUT", "EPISODE_LENGTH", "EPISODE_SUMS", "EPISODE_STATS", "COMMANDS", "LATENT_C", "LATENT_EPS",
+            "LAST_ACTIONS", "LAST_DOF_VEL", "LAST_TORQUES_ORG", "LAST_ROOT_VEL", "LAST_CONTACTS", "FOOT_IMPULSE"] + ([] if mask & 2 else ["OBS_DISC", "OBS_DISC_TERM"])
+    frozen = {k: b.t[k].clone() for k in skipped}
+    for k in range(60):
+        if k == 20:
+            for s in (a, b):
+                s.t["EPISODE_LENGTH"][::7] = 1000            # a burst of time-outs
+        act = torch.randn(4096, 12, device="cuda", generator=g) * (3.0 if k % 9 == 4 else 0.5)
+        delay = 1 if k >= 30 else 0
+        a.step(act, delay); b.step(act, delay)
+        for name in kept:
+            assert torch.equal(a.t[name], b.t[name]), (k, name)
+        assert torch.equal(a.t["ACTION_HISTORY"][:, -2:], b.t["ACTION_HISTORY"][:, -2:])
+    for name in skipped:
+        assert torch.equal(b.t[name], frozen[name]), name
+        assert not torch.equal(a.t[name], frozen[name]), name
+    # a delay the two-slot ring cannot serve is refused while the mode is on
+    with pytest.raises(RuntimeError):
+        b.step(act, 2)
+    b.set_lean_exports(0)
+    b.step(act, 0)
