@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/qa_sim.h"
@@ -74,6 +75,9 @@ struct GemmArgs {
 };
 
 #define GEMM_BK 16
+#ifndef QA_GEMM_DMA_DEFAULT
+#define QA_GEMM_DMA_DEFAULT 0
+#endif
 
 // global -> staging registers.  KC: element (idx, k) at P[idx * ld + k]; MC: at P[k * ld + idx].  The loads are UNCONDITIONAL from
 // clamped (always valid) addresses; out-of-range elements are zeroed when the registers go to LDS (gemm_store), by a MULTIPLICATION with
@@ -719,6 +723,26 @@ static int pick_cfg(int64_t a_count, int64_t b_count, int64_t nsplit) {
 
 static int g_force_cfg = -1;      // tools/gemm_bench.py: time one tile configuration
 
+// QA_GEMM_DMA: 1 = products that qualify (dma_ok) take the LDS-DMA kernel with the tile chosen below, 0 = register-staged kernel only
+static int dma_mode() {
+    static int m = -1;
+    if (m < 0) { const char *e = getenv("QA_GEMM_DMA"); m = e ? atoi(e) : QA_GEMM_DMA_DEFAULT; }
+    return m;
+}
+// LDS-DMA tile for an (a_count x b_count) output computed in nsplit slices: the largest tile that still gives every CU two workgroups
+// (128 x 192 is resident twice per CU, the smaller ones three or four times); narrow outputs take the 64-wide tiles
+static int pick_cfg_dma(int64_t a_count, int64_t b_count, int64_t nsplit) {
+    static const int order[5] = {10, 11, 14, 12, 13};
+    for (int c = 0; c < 5; ++c) {
+        int ba, bb; tile_dims(order[c], &ba, &bb);
+        if (a_count <= 64 && ba > 64) continue;
+        if (b_count <= 64 && bb > 64) continue;
+        const int64_t wgs = ((a_count + ba - 1) / ba) * ((b_count + bb - 1) / bb) * nsplit;
+        if (wgs >= 512) return order[c];
+    }
+    return 13;
+}
+
 extern "C" {
 
 void qa_gemm_force_config(int32_t cfg) { g_force_cfg = cfg; }
@@ -736,7 +760,8 @@ int qa_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t 
     g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
     g.b_vec = (aligned16(x) && ldx % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
     g.o_vec = (aligned16(y) && ldy % 4 == 0 && (!bias || aligned16(bias))) ? 4 : 1;
-    gemm_launch<false, false, 1, false>(g_force_cfg >= 0 ? g_force_cfg : pick_cfg(out_features, rows, 1), g, (hipStream_t)stream);
+    gemm_launch<false, false, 1, false>(g_force_cfg >= 0 ? g_force_cfg : ((dma_mode() && dma_ok(g)) ? pick_cfg_dma(out_features, rows, 1) : pick_cfg(out_features, rows, 1)),
+                                         g, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
@@ -757,7 +782,8 @@ int qa_linear_backward_input(const float *grad_out, int64_t ldg, const float *we
     g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
     g.b_vec = (aligned16(grad_out) && ldg % 4 == 0 && out_features % 4 == 0) ? 4 : 1;
     g.o_vec = (aligned16(grad_in) && ldgi % 4 == 0 && (!g.yprev || (aligned16(y_prev) && ldyp % 4 == 0))) ? 4 : 1;
-    gemm_launch<true, false, 2, false>(g_force_cfg >= 0 ? g_force_cfg : pick_cfg(in_features, rows, 1), g, (hipStream_t)stream);
+    gemm_launch<true, false, 2, false>(g_force_cfg >= 0 ? g_force_cfg : ((dma_mode() && dma_ok(g)) ? pick_cfg_dma(in_features, rows, 1) : pick_cfg(in_features, rows, 1)),
+                                        g, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_input: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
@@ -768,6 +794,8 @@ static void wgrad_plan(int64_t rows, int32_t in_features, int32_t out_features, 
     // measured on MI355X at 24,576 rows (tools/own_gemm_bench.py, profiles/r3_own_gemm_bench.json): the 128 x 128 tile only pays for the
     // widest layers (671 / 800 x 512), 128 x 64 for the 512 x 256 and 256 x 128 ones, 64 x 64 for everything narrower
     int c = (in_features > 256 && out_features > 256) ? 0 : ((in_features >= 256 && out_features >= 128) ? 1 : 2);
+    if (dma_mode() && rows % GEMM_BK == 0 && in_features % 4 == 0 && out_features % 4 == 0)        // (alignment of the operands is checked at launch: dma_ok)
+        c = (in_features > 256 && out_features > 256) ? 11 : ((in_features >= 128 && out_features >= 64) ? 12 : 13);
     if (g_force_cfg >= 0) c = g_force_cfg;
     int ba, bb; tile_dims(c, &ba, &bb);
     const int64_t tiles = (int64_t)((in_features + ba - 1) / ba) * ((out_features + bb - 1) / bb);

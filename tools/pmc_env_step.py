@@ -6,7 +6,9 @@ sys.path.insert(0, ".")
 from tests.oracle_lib import go2_cfg
 from quadrupedal_agility_amd.sim import QaSim
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+lean = int(sys.argv[2]) if len(sys.argv) > 2 else 3        # 3 = what a training run without AMP launches (qa_set_lean_exports); 0 = the reference's exports
 h = QaSim(go2_cfg(n)); h.reset_all()
+h.set_lean_exports(lean)
 act = torch.randn(n, 12, device="cuda") * 0.3
 for _ in range(60):
     h.step(act)

@@ -21,7 +21,7 @@ n = int(sys.argv[3])
 copy_kib = 256 * 1024
 fetch_corr = round(copy_kib / f["copy"]) if "copy" in f else 2        # 2 on gfx950 (the guide), 1 if the counter were exact
 write_corr = round(copy_kib / w["copy"], 2) if "copy" in w else 1.0
-out = {"kernel": "qa_env_step_kernel", "num_envs": n, "fetch_size_kib": f["env"], "write_size_kib": w["env"], "fetch_correction": fetch_corr,
+out = {"kernel": "qa_env_step_kernel", "num_envs": n, "lean_exports": int(sys.argv[5]) if len(sys.argv) > 5 else 3, "fetch_size_kib": f["env"], "write_size_kib": w["env"], "fetch_correction": fetch_corr,
        "write_calibration": write_corr, "calibration_copy_fetch_kib": f.get("copy"), "calibration_copy_write_kib": w.get("copy"),
        "hbm_bytes_per_launch": int((f["env"] * fetch_corr + w["env"]) * 1024), "source": "tools/final_measure.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 import os
