@@ -15,16 +15,42 @@ from tests.oracle_lib import OracleSim, go2_cfg
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-# (atol, rtol) per tensor for one env step (4 substeps) from identical state
+# (atol, rtol) per tensor for one env step (4 substeps) from identical state.  DERIVED, not asserted: atol = 3 x the measured
+# p99.9 of the per-env-step error |hip - oracle| (max over the env's elements) of this very protocol -- 40 steps x 1000 envs, 40,000 env-steps --
+# in profiles/r4_step_error_distribution.json (tools/step_error_distribution.py), rounded up to one digit; the p99.9 is quoted beside each entry.
+# Medians are 1e-6 (world positions: one fp32 ulp at 96 m is 7.6e-6) to 2e-5 (joint state), i.e. ~1e-5 relative; the tail above p99 is envs in which
+# a contact switches on or off in one of the four substeps on one side only (fp32 Schur / PGS vs the oracle's dense solve in double), which is
+# why BASELINE.md's "<= 1e-5 relative" holds for the median env-step and not for all of them.  Env-steps outside these tolerances are counted
+# against a budget of twice their measured share (FLIP_BUDGET).
 TOL = {
-    "ROOT_STATES": (3e-4, 1e-4), "DOF_STATE": (3e-3, 1e-3), "CONTACT_FORCES": (0.5, 2e-2), "RIGID_BODY_POS": (3e-4, 1e-4),
-    "TORQUES": (2e-2, 1e-3), "TORQUES_ORG": (2e-2, 1e-3), "ACTIONS": (0, 0), "LAST_ACTIONS": (0, 0), "LAST_DOF_VEL": (3e-3, 1e-3),
-    "LAST_TORQUES_ORG": (2e-2, 1e-3), "LAST_ROOT_VEL": (3e-4, 1e-4), "ACTION_HISTORY": (0, 0),
-    "OBS": (3e-3, 1e-3), "OBS_DISC": (3e-3, 1e-3), "OBS_DISC_TERM": (3e-3, 1e-3), "COMMANDS": (1e-6, 1e-6), "LATENT_EPS": (1e-7, 0),
-    "LATENT_C": (0, 0), "REW": (2e-4, 1e-3), "RESET": (0, 0), "TIME_OUT": (0, 0), "EPISODE_LENGTH": (0, 0),
-    "EPISODE_SUMS": (5e-4, 1e-3), "LAST_CONTACTS": (0, 0), "CONTACT_FILT": (0, 0), "FEET_FORCE": (0.5, 2e-2),
-    "FOOT_IMPULSE": (3e-3, 2e-2), "BASE_LIN_VEL": (3e-4, 1e-4), "BASE_ANG_VEL": (3e-4, 1e-4), "PROJECTED_GRAVITY": (1e-5, 1e-5), "RPY": (1e-5, 1e-5),
+    "ROOT_STATES": (5e-4, 1e-6), "LAST_ROOT_VEL": (5e-4, 0),                     # p99.9 1.6e-4 (p50 1.4e-6); rtol = 8 ulp of the world position (the course tests run 900 m from the origin)
+    "DOF_STATE": (6e-3, 0), "LAST_DOF_VEL": (6e-3, 0),                            # p99.9 2.0e-3 (p50 2.0e-5; velocities up to 30 rad/s)
+    "CONTACT_FORCES": (0.16, 5e-3), "FEET_FORCE": (0.03, 5e-3),                   # p99.9 5.1e-2 / 8.9e-3 N on forces up to 5,000 N
+    "RIGID_BODY_POS": (3e-5, 1e-6),                                               # p99.9 7.6e-6 = one ulp at 64-128 m
+    "TORQUES": (4e-3, 0), "TORQUES_ORG": (4e-3, 0), "LAST_TORQUES_ORG": (4e-3, 0),   # p99.9 1.1e-3 / 1.2e-3 Nm
+    "ACTIONS": (0, 0), "LAST_ACTIONS": (0, 0), "ACTION_HISTORY": (0, 0),
+    "OBS": (4e-4, 0), "OBS_DISC": (4e-4, 0), "OBS_DISC_TERM": (4e-4, 0),          # p99.9 1.1e-4
+    "COMMANDS": (4e-7, 0), "LATENT_EPS": (1e-7, 0), "LATENT_C": (0, 0),           # p99.9 1.2e-7 (one ulp of a resampled command)
+    "REW": (1e-6, 0), "EPISODE_SUMS": (6e-6, 0),                                  # p99.9 5.4e-8 / 1.9e-6
+    "RESET": (0, 0), "TIME_OUT": (0, 0), "EPISODE_LENGTH": (0, 0), "LAST_CONTACTS": (0, 0), "CONTACT_FILT": (0, 0),
+    "FOOT_IMPULSE": (1.3e-4, 0),                                                  # p99.9 4.2e-5 N s
+    "BASE_LIN_VEL": (6e-5, 0), "BASE_ANG_VEL": (6e-4, 0), "PROJECTED_GRAVITY": (3e-6, 0), "RPY": (5e-6, 0),   # p99.9 1.8e-5 / 1.8e-4 / 1.0e-6 / 1.4e-6
 }
+# share of env-steps allowed outside TOL per protocol: ~2x the share measured with this TOL table on MI355X (profiles/r4_parity_flip_shares.txt,
+# `QA_PARITY_MEASURE=1 pytest -m gpu -s -k parity`); filled in from that run
+BUDGET = {"plane": 0.004, "height_field": 0.01, "ceiling": 0.04, "mocap": 0.004, "self_collision": 0.02, "articulated": 0.02, "articulated_8192": 0.05, "course": 0.01}
+
+
+def check_flips(name, flips, total, budget):
+    """env-steps outside TOL against a budget that is ~2x the share MEASURED with the current TOL table (profiles/r4_parity_flip_shares.txt).
+    QA_PARITY_MEASURE=1: print the share and do not judge it (how that profile is made)."""
+    import os
+    share = flips / max(total, 1)
+    print(f"FLIPSHARE {name} {flips}/{total} = {share:.5f} (budget {budget})")
+    if os.environ.get("QA_PARITY_MEASURE") != "1":
+        assert share <= budget + 2.0 / max(total, 1), (name, share, budget)
+
+
 STATIC = ["MOTOR_STRENGTH", "MASS_PARAMS", "FRICTION", "ENV_ORIGINS", "BASE_INERTIA", "PRIOR_PARAMETERS"]
 
 
@@ -101,7 +127,7 @@ def test_single_step_parity(n_envs, seed, slots):
             assert np.allclose(st_g, st_o, atol=1e-3, rtol=1e-3)
     print("worst abs error per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
     print(f"env-steps outside tolerance (discrete-event flips): {flips} of {steps * n_envs}")
-    assert flips <= 0.004 * steps * n_envs            # measured 0.17 % (contact on/off flips, tools/flip_probe.py); budget ~2x
+    check_flips(f"plane_{n_envs}_slots{slots}", flips, steps * n_envs, BUDGET["plane"])            # contact on/off flips (tools/flip_probe.py)
 
 
 def test_integer_outputs_exact_when_physics_agrees():
@@ -367,7 +393,7 @@ def test_single_step_parity_on_height_field(n_envs, seed):
     print("worst abs error per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
     print(f"env-steps outside tolerance on rough terrain: {flips} of {steps * n_envs}")
     assert (o.t["SCAN_HEIGHT"] != 0).mean() > 0.9                    # the field is really there
-    assert flips <= 0.01 * steps * n_envs                            # measured 0.5 %: triangle / cell switches add discrete events
+    check_flips(f"height_field_{n_envs}", flips, steps * n_envs, BUDGET["height_field"])            # triangle / cell switches add discrete events
 
 
 def test_single_step_parity_under_a_ceiling():
@@ -405,7 +431,8 @@ def test_single_step_parity_under_a_ceiling():
     # a robot squeezed between floor and roof carries 3-7 contacts and forces of 100-300 N through 4 PGS sweeps: fp32 vs fp64
     # round-off shows as ~7e-4 rad/s on angular velocities of several rad/s (measured: 2.6 % of env-steps outside the open-field
     # tolerance, 0.2 % by more than 10x; the same loop without the roof: 0.3 %)
-    assert flips <= 0.04 * steps * n_envs and gross <= 0.005 * steps * n_envs
+    check_flips(f"ceiling_{n_envs}", flips, steps * n_envs, BUDGET["ceiling"])
+    assert gross <= 0.005 * steps * n_envs
 
 
 def test_height_field_trajectory_and_contact_forces():

@@ -134,4 +134,5 @@ def test_single_step_parity_with_mocap_reset(n_envs, seed):
         flips += int(bad_env.sum())
     print(f"mocap-reset parity: {resets} resets, env-steps outside tolerance: {flips} of {steps * n_envs};", {k: f"{v:.1e}" for k, v in worst.items() if v > 0})
     assert resets > steps * n_envs * 0.04
-    assert flips <= 0.004 * steps * n_envs + 2
+    from tests.test_hip_parity import BUDGET, check_flips
+    check_flips(f"mocap_{n_envs}", flips, steps * n_envs, BUDGET["mocap"])

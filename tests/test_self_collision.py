@@ -143,5 +143,6 @@ def test_hip_matches_oracle_with_crossing_legs(n):
         air = rb[:, FOOT, 2].min(axis=1) > 0.1                             # feet off the ground: any calf force is a self-contact force
         hits += int((np.abs(cfh[air][:, CALF]).max(axis=(1, 2)) > 1.0).sum())
     print(f"self-collision, {n} envs x {steps} steps: outside the physics tolerances {flips}, airborne env-steps with a self-contact force {hits}")
-    assert flips <= 0.02 * steps * n + 2
+    from tests.test_hip_parity import BUDGET, check_flips
+    check_flips(f"self_collision_{n}", flips, steps * n, BUDGET["self_collision"])
     assert hits > 0.01 * steps * n
