@@ -41,6 +41,10 @@ def run(device, num_envs, iters, seed, amp=False):
     if os.environ.get("QA_PARITY_EAGER") == "1":          # GPU side without recorded launches / stream overlap (bisecting a difference)
         runner.alg.use_update_graph = False
         runner.alg.overlap_updates = False
+    if os.environ.get("QA_PARITY_EAGER_TABLES") == "1":   # eager update steps on EXACTLY the samples the recorded path draws (same generator calls): bit-comparable with it
+        runner.alg.use_update_graph = False
+        runner.alg.overlap_updates = False
+        runner.alg.eager_from_tables = True
     if os.environ.get("QA_PARITY_EAGER_UPDATE") == "1":
         runner.alg.use_update_graph = False
     if os.environ.get("QA_PARITY_NO_DISC_GRAPH") == "1":
