@@ -66,7 +66,8 @@ def run(device, num_envs, iters, seed, amp=False):
                              disc_each=[float(p.detach().double().sum()) for p in a.disc.parameters()] if amp else [],
                              obs=float(a.storage.observations.double().sum()), rewards=float(a.storage.rewards.double().sum()),
                              rng=int.from_bytes(bytes(torch.cuda.get_rng_state()[8:16].tolist()), "little") if device != "cpu" else 0))
-            json.dump(rows, open(os.environ["QA_PARITY_CHECKSUMS"], "w"))
+            if len(rows) % 50 == 0 or len(rows) >= iters:
+                json.dump(rows, open(os.environ["QA_PARITY_CHECKSUMS"], "w"))
             return r
         a.update = update_and_checksum
     t0 = time.time()
