@@ -151,8 +151,11 @@ def test_mocap_reset_env_at_4096_envs():
     hs, small, _, _ = _run_mocap(64, 48)
     ob, os_ = h.t["ENV_ORIGINS"][:64], hs.t["ENV_ORIGINS"]
     for sb, ss in zip(a, small):
-        for k in ("DOF_STATE", "REW", "RESET", "EPISODE_LENGTH", "COMMANDS", "LATENT_C", "OBS", "OBS_DISC"):
+        for k in ("DOF_STATE", "REW", "RESET", "EPISODE_LENGTH", "COMMANDS", "LATENT_C", "OBS"):
             assert torch.equal(sb[k][:64], ss[k]), k
+        # the discriminator row carries the feet positions relative to the root, formed from WORLD coordinates: the spawn grid of a 4096-env job
+        # puts env i elsewhere than a 64-env job does, so these entries agree to the fp32 resolution of the world position only
+        assert torch.allclose(sb["OBS_DISC"][:64], ss["OBS_DISC"], atol=1e-4, rtol=0), float((sb["OBS_DISC"][:64] - ss["OBS_DISC"]).abs().max())
         assert torch.equal(sb["ROOT_STATES"][:64, 2:], ss["ROOT_STATES"][:, 2:])
         assert torch.allclose(sb["ROOT_STATES"][:64, :2] - ob[:, :2], ss["ROOT_STATES"][:, :2] - os_[:, :2], atol=2e-4)
     # envs that reset in the last step sit on a blend of two neighbouring frames of one of their gait's clips
