@@ -642,7 +642,7 @@ int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
  * behind play.py / the exported policy).  The chain is a HOST array of ops run in order on every tile:
  *   QA_MLP_COPY : dst_buf[:, dst_col : dst_col+n] = src_buf[:, src_col : src_col+n]
  *   QA_MLP_LAYER: y = src_buf[:, src_col : src_col+k] @ W^T + b, W (n,k) row-major as nn.Linear stores it; act 1 applies
- *                 ELU(alpha 1), act 2 ReLU.  y goes to dst_buf[:, dst_col : dst_col+n], or with dst_buf = -1 to rows of the global
+ *                 ELU(alpha 1), act 2 ReLU, act 3 tanh (ABI 13: the task-level scan encoder's last layer).  y goes to dst_buf[:, dst_col : dst_col+n], or with dst_buf = -1 to rows of the global
  *                 output `out_index`.
  * Buffer 0 holds the tile of the input rows x (x_cols <= QA_MLP_BUF0_COLS) and is read-only; buffers 1..3 are scratch
  * with QA_MLP_BUFn_COLS columns, zero at the start of the chain.  A layer's src_col must be a multiple of 4 and its
@@ -655,7 +655,7 @@ int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
 #define QA_MLP_LAYER 1
 #define QA_MLP_MAX_OPS 24
 #define QA_MLP_MAX_OUTPUTS 4
-#define QA_MLP_BUF0_COLS 672
+#define QA_MLP_BUF0_COLS 800      /* the task-level policy's 800-wide observation row (ABI 13; 672 before) */
 #define QA_MLP_BUF1_COLS 576
 #define QA_MLP_BUF2_COLS 320
 #define QA_MLP_BUF3_COLS 128

@@ -2185,6 +2185,7 @@ int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
                 float v = (float)acc;
                 if (o->act == 1) v = v > 0.0f ? v : (float)(exp((double)v) - 1.0);
                 else if (o->act == 2) v = v > 0.0f ? v : 0.0f;
+                else if (o->act == 3) v = (float)tanh((double)v);
                 if (o->dst_buf > 0) buf[o->dst_buf][o->dst_col + c] = v;
                 else outs[o->out_index][r * out_strides[o->out_index] + c] = v;
             }

@@ -204,7 +204,7 @@ class QaMlpOp(C.Structure):
 
 
 MLP_COPY, MLP_LAYER, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 24, 4
-MLP_BUF_COLS = (672, 576, 320, 128)
+MLP_BUF_COLS = (800, 576, 320, 128)
 
 TSC_REWARD_NAMES = ("action_hl_rate", "collision", "feet_edge", "latent_c_rate", "reach_goal", "tracking_goal_vel", "tracking_yaw",
                     "termination")          # QA_TSC_REW_* order

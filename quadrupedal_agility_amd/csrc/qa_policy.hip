@@ -154,7 +154,7 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[i][r] + bias[i];
-                    d[r * ds + col] = act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : v;
+                    d[r * ds + col] = act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : act == 3 ? tanhf(v) : v;
                 }
             }
         }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[i][r] + bias[i];
-                    if (r < live) g[r * os + col] = act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : v;
+                    if (r < live) g[r * os + col] = act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : act == 3 ? tanhf(v) : v;
                 }
             }
         }
@@ -262,7 +262,7 @@ static int mlp_check(const qa_mlp_op *ops, int32_t num_ops, const char *who) {
         if (ok && layer) {
             const int kpad = mlp_kb(o.k, o.n) * 16;         /* columns the layer reads (beyond k: against zero weights) */
             /* reading past the row's padding lands in the next row / buffer (finite activations, zero weights): allowed while inside LDS */
-            ok = o.k > 0 && o.act >= 0 && o.act <= 2 && (o.src_col % 4) == 0 && o.src_col + o.k <= buf_cols(o.src_buf) + 4 &&
+            ok = o.k > 0 && o.act >= 0 && o.act <= 3 && (o.src_col % 4) == 0 && o.src_col + o.k <= buf_cols(o.src_buf) + 4 &&
                  lds_base(o.src_buf) + (MLP_ROWS - 1) * (buf_cols(o.src_buf) + 4) + o.src_col + kpad <= MLP_LDS_FLOATS && o.w_off >= 0 && o.b_off >= 0 && (o.w_off % 4) == 0 &&
                  (o.n + 15) / 16 <= 4 * MLP_WAVES;
             if (ok && o.dst_buf >= 0) ok = o.dst_buf > 0 && o.dst_buf < MLP_NBUF && o.dst_buf != o.src_buf && o.dst_col >= 0 && o.dst_col + o.n <= buf_cols(o.dst_buf);

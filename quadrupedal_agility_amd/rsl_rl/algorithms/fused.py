@@ -1243,6 +1243,99 @@ class PolicyChain:
         self.packed_floats = woff[0]
         return self
 
+    @classmethod
+    def describe_task_level(cls, actor_critic, estimator, use_estimator):
+        """The task-level teacher's networks of one env step (tsc/rsl_rl/algorithms/ppo.py:101-125 `act`: Estimator.forward on the first 57
+        proprioception entries written over the privileged-explicit columns, Actor.forward -- scan encoder (last layer tanh), privileged
+        encoder, trunk -- with the two heads `actor_d` / `actor_c`, and the critic on the TRUE 800-wide row; tsc/rsl_rl/modules/
+        actor_critic.py:59-284) as one qa_mlp_forward chain: -> (gait logits (N, nd), parameter means (N, nd * nc), value (N, 1)).
+        Privileged-encoder variant only (19 of 20 iterations; the history-encoder rollouts keep the module path).  None when the modules do
+        not fit the kernel (other activations, widths beyond the LDS buffers)."""
+        import torch.nn as nn
+        ac = actor_critic
+        actor = ac.actor
+        a, n_scan, n_exp, n_lat = actor.num_prop, actor.num_scan, actor.num_priv_explicit, actor.num_priv_latent
+        scan0, exp0, lat0 = a, a + n_scan, a + n_scan + n_exp
+
+        def stack(seq, tanh_last=False):
+            mods = list(seq) if isinstance(seq, nn.Sequential) else None
+            if mods is None:
+                return None
+            if tanh_last and mods and isinstance(mods[-1], nn.Tanh):
+                body = cls._linears(nn.Sequential(*mods[:-1]))
+                if body is None or body[-1][1] != 0:
+                    return None
+                body[-1][1] = 3
+                return body
+            return cls._linears(seq)
+        crit = stack(ac.critic)
+        st = dict(scan=stack(actor.scan_encoder, tanh_last=True) if actor.if_scan_encode else None, priv=stack(actor.priv_encoder), trunk=stack(actor.actor_trunk), critic=crit)
+        if use_estimator:
+            st["est"] = stack(estimator.estimator)
+        if not actor.if_scan_encode or any(v is None for v in st.values()) or isinstance(actor.priv_encoder, nn.Identity):
+            return None
+        n_obs = crit[0][0].in_features
+        n_in = a + st["scan"][-1][0].out_features + n_exp + n_lat
+        Z = 2                                               # the trunk's input is assembled in scratch buffer 2
+        if n_obs > cls.BUF_COLS[0] or n_in > cls.BUF_COLS[Z] or st["trunk"][0][0].in_features != n_in or lat0 + n_lat > n_obs:
+            return None
+        ops, params, woff = [], [], [0]
+        lds_end = sum(16 * (c + 4) for c in cls.BUF_COLS)
+
+        def copy(src, scol, dst, dcol, n):
+            ops.append(_capi.QaMlpOp(kind=_capi.MLP_COPY, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=0, n=n))
+            params.append(None)
+
+        def layer(src, scol, k, dst, dcol, n, act, oi, w, bias):
+            if dst == src or (dst >= 0 and dcol + n > cls.BUF_COLS[dst]) or scol % 4 or scol + k > cls.BUF_COLS[src] + 4:
+                return False
+            nt, kb = (n + 15) // 16, cls.k_blocks(k, n)
+            base = sum(16 * (c + 4) for c in cls.BUF_COLS[:src])
+            if base + 15 * (cls.BUF_COLS[src] + 4) + scol + 16 * kb > lds_end or nt > 32:
+                return False
+            w_off = woff[0]; b_off = w_off + nt * kb * 256; woff[0] = b_off + nt * 16
+            ops.append(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=k, n=n, act=act, out_index=oi, w_off=w_off, b_off=b_off))
+            params.append((w, bias))
+            return True
+
+        def chain(layers, src, scol, k, final, reserved):
+            for i, (lin, act) in enumerate(layers):
+                if lin.in_features != k:
+                    return False
+                n = lin.out_features
+                if i == len(layers) - 1:
+                    dst, dcol, oi = (final[1], final[2], 0) if final[0] == "buf" else (-1, 0, final[1])
+                else:
+                    fit = [b for b in (3, 2, 1) if b != src and b not in reserved and cls.BUF_COLS[b] >= n]
+                    if not fit:
+                        return False
+                    dst, dcol, oi = fit[0], 0, 0
+                if not layer(src, scol, k, dst, dcol, n, act, oi, lin.weight, lin.bias):
+                    return False
+                src, scol, k = dst, 0, n
+            return True
+
+        ok = chain(st["critic"], 0, 0, n_obs, ("out", 2), set()) and st["critic"][-1][0].out_features == 1      # first: it may use every scratch buffer
+        copy(0, 0, Z, 0, a)
+        copy(0, scan0, 1, 0, n_scan)                        # a layer's source column must be 16-byte aligned: the scan starts at column 65
+        ok = ok and chain(st["scan"], 1, 0, n_scan, ("buf", Z, a), {Z})
+        lat_dst = a + st["scan"][-1][0].out_features
+        if use_estimator:
+            ok = ok and chain(st["est"], 0, 0, st["est"][0][0].in_features, ("buf", Z, lat_dst), {Z}) and st["est"][-1][0].out_features == n_exp
+        else:
+            copy(0, exp0, Z, lat_dst, n_exp)
+        copy(0, lat0, 1, 0, n_lat)
+        ok = ok and chain(st["priv"], 1, 0, n_lat, ("buf", Z, lat_dst + n_exp), {Z}) and st["priv"][-1][0].out_features == n_lat
+        ok = ok and chain(st["trunk"], Z, 0, n_in, ("buf", 3, 0), set())
+        k = st["trunk"][-1][0].out_features
+        ok = ok and layer(3, 0, k, -1, 0, actor.actor_d.out_features, 0, 0, actor.actor_d.weight, actor.actor_d.bias)
+        ok = ok and layer(3, 0, k, -1, 0, actor.actor_c.out_features, 0, 1, actor.actor_c.weight, actor.actor_c.bias)
+        if not ok or len(ops) > _capi.MLP_MAX_OPS or k > cls.BUF_COLS[3]:
+            return None
+        self = cls(ops, params, actor.actor_c.out_features, out_widths=[actor.actor_d.out_features, actor.actor_c.out_features, 1])
+        self.packed_floats = woff[0]
+        return self
+
     # ---------------------------------------------------------------- device side
     def _ptr_arrays(self):
         """device pointers of every layer's (weight, bias); entries of `params` may be callables that build the tensor from the

@@ -111,11 +111,24 @@ class PPO:
         est[:, self._priv_slice(with_auxiliary)] = self.estimator(est[:, :self.num_prop])
         return est
 
-    def act(self, obs, critic_obs, info=None, hist_encoding=False):
-        """:101-125 -- the policy sees ESTIMATED privileged states, the storage keeps the true ones."""
+    def act(self, obs, critic_obs, info=None, hist_encoding=False, chain=None):
+        """:101-125 -- the policy sees ESTIMATED privileged states, the storage keeps the true ones.  `chain` (fused.PolicyChain.describe_task_level,
+        privileged-encoder variant): estimator, encoders, trunk, heads and critic of the step as ONE launch; the distributions, the samples and
+        the transition record are the same objects either way."""
         tr, ac = self.transition, self.actor_critic
-        tr.actions = ac.act(self._with_estimated_states(obs, True), hist_encoding).detach()
-        tr.values = ac.evaluate(critic_obs).detach()
+        if chain is not None and not hist_encoding:
+            from torch.distributions import Categorical, Normal
+            logits, mean, value = chain.forward(obs)
+            ac.distribution_d = Categorical(probs=torch.softmax(logits, dim=-1), validate_args=False)
+            ac.distribution_c = Normal(mean, mean * 0.0 + ac.std, validate_args=False)
+            p = ac.distribution_d.probs                   # ActorCriticTSC.act's sampling (no host read: see there)
+            a_d = torch.argmax(p / torch.empty_like(p).exponential_(1.0), dim=-1)
+            a_c = mean + ac.distribution_c.stddev * torch.randn_like(mean)
+            tr.actions = torch.cat([a_d.unsqueeze(-1), a_c], dim=-1).detach()
+            tr.values = value
+        else:
+            tr.actions = ac.act(self._with_estimated_states(obs, True), hist_encoding).detach()
+            tr.values = ac.evaluate(critic_obs).detach()
         tr.actions_log_prob_d = ac.get_actions_log_prob_d(tr.actions[:, 0]).detach()
         tr.actions_log_prob_c = ac.get_actions_log_prob_c(tr.actions[:, 1:]).detach()
         tr.action_mean, tr.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
@@ -131,6 +144,20 @@ class PPO:
     def act_bbc(self, obs):
         """:127-137 -- joint targets of the frozen behaviour controller (history branch, mean action)."""
         return self.actor_critic_bbc.act_inference(self._with_estimated_states(obs, False), hist_encoding=True).detach()
+
+    def store_transition_rows(self):
+        """the transition's rows other than reward / done go into the storage now (add_transitions' copies); the caller's kernel writes those
+        two (qa_rollout_post_amp) -- returns the storage step it must write to"""
+        tr, st = self.transition, self.storage
+        if st.step >= st.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        t = st.step
+        st.actions[t].copy_(tr.actions); st.values[t].copy_(tr.values)
+        st.actions_log_prob_d[t].copy_(tr.actions_log_prob_d.view(-1, 1)); st.actions_log_prob_c[t].copy_(tr.actions_log_prob_c.view(-1, 1))
+        st.mu[t].copy_(tr.action_mean); st.sigma[t].copy_(tr.action_sigma)
+        st.step += 1
+        self.transition.clear()
+        return t
 
     def process_env_step(self, rewards, dones, infos):
         total = rewards.clone()

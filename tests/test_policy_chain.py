@@ -208,3 +208,80 @@ def test_discriminator_description_and_twin_match_the_module():
     np.testing.assert_allclose(outs[0], d.numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(outs[1], eps.numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(torch.softmax(torch.from_numpy(outs[2]), -1).numpy(), c.numpy(), rtol=1e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ the task-level teacher (r4)
+def tsc_modules(seed=0):
+    from quadrupedal_agility_amd.tsc.rsl_rl.modules.actor_critic import ActorCriticTSC
+    torch.manual_seed(seed)
+    n_prop, n_aux, n_scan, n_lat, n_exp, hist = 65, 8, 132, 29, 4, 10
+    n_obs = n_prop + n_scan + n_lat + n_exp + hist * (n_prop - n_aux)
+    ac = ActorCriticTSC(n_prop, n_aux, n_scan, n_obs, n_lat, n_exp, hist, 6, 3, scan_encoder_dims=[128, 64, 32], actor_hidden_dims=[512, 256, 128],
+                        critic_hidden_dims=[512, 256, 128], priv_encoder_dims=[64], activation="elu")
+    est = Estimator(n_prop - n_aux, n_exp, hidden_dims=[128, 64])
+    with torch.no_grad():
+        for p in list(ac.parameters()) + list(est.parameters()):
+            if p.dim() == 1:
+                p.uniform_(-0.2, 0.2)
+    return ac, est, n_obs
+
+
+def tsc_reference(ac, est, obs, use_estimator):
+    """tsc/rsl_rl/algorithms/ppo.py:101-125: the policy sees the estimated privileged states, the critic the true row"""
+    with torch.no_grad():
+        x = obs.clone()
+        if use_estimator:
+            x[:, 65 + 132:65 + 132 + 4] = est(x[:, :57])
+        emb = ac.actor(x, False)
+        return ac.actor.actor_d(emb), ac.actor.actor_c(emb), ac.evaluate(obs)
+
+
+def run_oracle_outputs(chain, obs):
+    from tests.oracle_lib import load_oracle
+    lib = load_oracle()
+    n = obs.shape[0]
+    with torch.no_grad():
+        w, b = chain._ptr_arrays()
+    packed = np.zeros(chain.packed_floats, np.float32)
+    assert lib.qo_mlp_packed_floats(chain.ops, chain.n_ops) == chain.packed_floats
+    assert lib.qo_mlp_pack(chain.ops, chain.n_ops, w, b, packed.ctypes.data, packed.size, None) == 0
+    outs_np = [np.zeros((n, wd), np.float32) for wd in chain.out_widths]
+    x = np.ascontiguousarray(obs.numpy())
+    k = len(outs_np)
+    outs = (C.c_void_p * k)(*[o.ctypes.data for o in outs_np])
+    strides = (C.c_int64 * k)(*chain.out_widths)
+    assert lib.qo_mlp_forward(x.ctypes.data, x.shape[1], n, x.shape[1], chain.ops, chain.n_ops, packed.ctypes.data, outs, strides, k, None) == 0
+    return outs_np
+
+
+@pytest.mark.parametrize("use_estimator", [True, False])
+def test_task_level_description_matches_the_modules(use_estimator):
+    """PolicyChain.describe_task_level: estimator -> explicit columns, scan encoder (tanh), privileged encoder, trunk, both heads, critic on the
+    true 800-wide row -- the op list through the C twin against the modules"""
+    ac, est, n_obs = tsc_modules()
+    assert n_obs == 800
+    chain = PolicyChain.describe_task_level(ac, est, use_estimator)
+    assert chain is not None and chain.n_ops <= _capi.MLP_MAX_OPS and chain.out_widths == [6, 18, 1]
+    obs = torch.randn(29, n_obs)
+    logits, mean, value = run_oracle_outputs(chain, obs)
+    rl, rm, rv = tsc_reference(ac, est, obs, use_estimator)
+    np.testing.assert_allclose(logits, rl.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(mean, rm.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(value, rv.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 100, 1024, 8192])
+def test_task_level_chain_on_the_gpu(rows):
+    ac, est, n_obs = tsc_modules(seed=3)
+    obs = torch.randn(rows, n_obs)
+    want = run_oracle_outputs(PolicyChain.describe_task_level(ac, est, True), obs[:64])
+    ac, est = ac.cuda(), est.cuda()
+    chain = PolicyChain.describe_task_level(ac, est, True)
+    chain.pack()
+    got = chain.forward(obs.cuda())
+    torch.cuda.synchronize()
+    rl, rm, rv = tsc_reference(ac, est, obs.cuda(), True)
+    for g, w, r in zip(got, want, (rl, rm, rv)):
+        np.testing.assert_allclose(g[:64].cpu().numpy(), w[:rows], rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(g.cpu().numpy(), r.cpu().numpy(), rtol=2e-4, atol=5e-5)

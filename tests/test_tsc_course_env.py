@@ -283,3 +283,51 @@ def test_recorded_rollout_equals_eager_rollout_bit_for_bit(tmp_path, n, sync_pha
     assert not torch.equal(r[-1]["actions"], r[-2]["actions"]) and not torch.equal(r[-2]["actions"], r[-3]["actions"])       # replays draw new action noise
     assert all(s["dones"].float().mean().item() > 0.005 for s in r[1:])                                                    # episodes end in every replay
     assert any(not torch.equal(r[i]["means"], r[i - 1]["means"]) for i in range(2, 5))                                     # extras["episode"] follows the resets
+
+
+@pytest.mark.gpu
+def test_fused_teacher_rollout_equals_the_module_rollout(tmp_path):
+    """r4: the teacher's networks (estimator, scan / privileged encoders, trunk, heads, critic) as one qa_mlp_forward chain and the style reward as
+    qa_disc_prepare + chain + qa_rollout_post_amp, against the module path (13 library GEMMs + Discriminator.predict_disc_reward +
+    process_env_step) on the same job: one eager 24-step rollout each from identical state and generator -- values, means, log-probs, rewards,
+    dones and observations of the stored rollout agree to GEMM rounding (the two paths sum in different orders); the categorical choice, an
+    argmax over perturbed probabilities, on all but a handful of samples; the logged episode sums likewise."""
+    from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
+    out = {}
+    for mode in ("fused", "modules"):
+        torch.manual_seed(0)
+        cfg = make_cfg(1024, 1, env__episode_length_s=1.0, domain_rand__push_robots=True, obstacle__randomize_start=True, domain_rand__push_interval=7)
+        env = lr.LeggedRobot(cfg, sim_device="cuda:0")
+        runner = OnPolicyRunner(env, class_to_dict(Go2AgilityCfgPPO()), log_dir=str(tmp_path / mode), device="cuda:0")
+        runner.use_rollout_graph = False
+        if mode == "modules":
+            runner._teacher_chain_obj = runner._style_chain_obj = False
+        env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        runner._alloc_rollout_state()
+        torch.manual_seed(1)
+        with torch.inference_mode():
+            runner._rollout_steps(False, True)
+        torch.cuda.synchronize()
+        st = runner.alg.storage
+        assert st.step == 24
+        if mode == "fused":
+            assert runner._teacher_chain_obj not in (None, False) and runner._style_chain_obj not in (None, False)
+        out[mode] = dict(values=st.values.clone(), mu=st.mu.clone(), sigma=st.sigma.clone(), rewards=st.rewards.clone(), dones=st.dones.clone(),
+                         a_d=st.actions[..., 0].clone(), a_c=st.actions[..., 1:].clone(), logp_d=st.actions_log_prob_d.clone(), logp_c=st.actions_log_prob_c.clone(),
+                         obs0=st.observations[0].clone(), fin=runner._rs["fin_vals"].clone(), mask=runner._rs["fin_masks"].clone())
+    f, m = out["fused"], out["modules"]
+    # step 0 starts from identical observations: the networks' outputs agree to rounding there ...
+    assert torch.equal(f["obs0"], m["obs0"])
+    assert torch.allclose(f["values"][0], m["values"][0], rtol=2e-4, atol=2e-4) and torch.allclose(f["mu"][0], m["mu"][0], rtol=2e-4, atol=2e-4)
+    assert torch.equal(f["sigma"], m["sigma"])
+    same0 = (f["a_d"][0] == m["a_d"][0])
+    assert same0.float().mean() > 0.995
+    assert torch.allclose(f["a_c"][0][same0], m["a_c"][0][same0], rtol=2e-4, atol=2e-4) and torch.allclose(f["logp_c"][0][same0], m["logp_c"][0][same0], rtol=1e-3, atol=2e-3)
+    assert torch.allclose(f["logp_d"][0][same0], m["logp_d"][0][same0], rtol=1e-3, atol=1e-3)
+    # ... and where the two jobs still took the same gait decisions, rewards (style reward through the discriminator chain) and dones agree step by step;
+    # a differing categorical draw forks an env's trajectory, so later steps are compared statistically
+    assert torch.allclose(f["rewards"][0][same0], m["rewards"][0][same0], rtol=1e-3, atol=2e-4)
+    assert torch.equal(f["dones"][0][same0], m["dones"][0][same0])
+    assert abs(float(f["rewards"].mean()) - float(m["rewards"].mean())) < 0.05 * abs(float(m["rewards"].mean())) + 1e-3
+    assert abs(float(f["dones"].float().mean()) - float(m["dones"].float().mean())) < 0.01
+    assert f["mask"].any() and abs(float(f["fin"][-1, 0].mean()) - float(m["fin"][-1, 0].mean())) < 0.1 * abs(float(m["fin"][-1, 0].mean())) + 1e-2
