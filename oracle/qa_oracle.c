@@ -1931,6 +1931,59 @@ int qo_rollout_act(const float *mean, const float *std, const float *value, cons
     }
     return QA_OK;
 }
+int qo_rollout_act_hybrid(const float *logits, const float *mean, const float *std, const float *value, uint64_t seed, const int64_t *step_dev, int64_t step,
+                          int32_t num_envs, int32_t env_id_offset, int32_t nd, int32_t nc_all, float *actions, float *st_actions, float *st_mu, float *st_sigma,
+                          float *st_logp_d, float *st_logp_c, float *st_values, float *action_history, int32_t hist_len, void *stream) {
+    (void)stream;       /* tsc/rsl_rl/modules/actor_critic.py:252-261, algorithms/ppo.py:101-125 */
+    if (!logits || !mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp_d || !st_logp_c || !st_values || num_envs <= 0 ||
+        nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0)) return QA_E_ARG;
+    if (step_dev) step = *step_dev;
+    const int w = 1 + nc_all;
+    const float EPS = 1.1920928955078125e-07f;
+    for (int e = 0; e < num_envs; ++e) {
+        const float *lg = logits + (int64_t)e * nd;
+        float mx = lg[0], p[16], sum = 0.0f;
+        for (int i = 1; i < nd; ++i) if (lg[i] > mx) mx = lg[i];
+        for (int i = 0; i < nd; ++i) { p[i] = expf(lg[i] - mx); sum += p[i]; }
+        const float inv = 1.0f / sum;
+        uint32_t o[4];
+        philox(seed, (uint32_t)(e + env_id_offset), (uint32_t)step, (uint32_t)(21 * 256 + 0), (uint32_t)((uint64_t)step >> 32), o);
+        const float u = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+        int choice = nd - 1; float cdf = 0.0f, pa = 0.0f; int found = 0;
+        for (int i = 0; i < nd; ++i) {
+            const float pi = p[i] * inv;
+            cdf += pi;
+            if (!found && (u < cdf || i == nd - 1)) { choice = i; pa = pi; found = 1; }
+        }
+        float cl = pa < EPS ? EPS : (pa > 1.0f - EPS ? 1.0f - EPS : pa);
+        float *act = actions + (int64_t)e * w, *sa = st_actions + (int64_t)e * w;
+        act[0] = (float)choice; sa[0] = (float)choice;
+        float logp_c = 0.0f;
+        for (int b = 0; 4 * b < nc_all; ++b) {
+            float uu[4];
+            philox(seed, (uint32_t)(e + env_id_offset), (uint32_t)step, (uint32_t)(20 * 256 + b), (uint32_t)((uint64_t)step >> 32), o);
+            for (int i = 0; i < 4; ++i) uu[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
+            const float r0 = sqrtf(-2.0f * logf(fmaxf(uu[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(uu[2], 1e-7f)));
+            const float eps4[4] = {r0 * cosf(6.28318530717958647692f * uu[1]), r0 * sinf(6.28318530717958647692f * uu[1]),
+                                   r1 * cosf(6.28318530717958647692f * uu[3]), r1 * sinf(6.28318530717958647692f * uu[3])};
+            for (int k = 0; k < 4; ++k) {
+                const int j = 4 * b + k;
+                if (j >= nc_all) break;
+                const float m = mean[(int64_t)e * nc_all + j], s = std[j], v = m + s * eps4[k], d = v - m;
+                logp_c += -(d * d) / (2.0f * s * s) - logf(s) - 0.91893853320467274178f;
+                act[1 + j] = v; sa[1 + j] = v;
+                st_mu[(int64_t)e * nc_all + j] = m; st_sigma[(int64_t)e * nc_all + j] = s;
+            }
+        }
+        st_logp_d[e] = logf(cl); st_logp_c[e] = logp_c; st_values[e] = value[e];
+        if (action_history) {
+            float *h = action_history + (int64_t)e * hist_len * w;
+            memmove(h, h + w, sizeof(float) * (size_t)(hist_len - 1) * (size_t)w);
+            memcpy(h + (int64_t)(hist_len - 1) * w, act, sizeof(float) * (size_t)w);
+        }
+    }
+    return QA_OK;
+}
 int qo_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
                     int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream) {
     (void)stream;

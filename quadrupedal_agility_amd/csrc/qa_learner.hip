@@ -739,6 +739,72 @@ __global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__rest
     st_values[e] = value[e];
 }
 
+constexpr int RS_ACT_CHOICE = 21;
+struct HybridActArgs {
+    const float *logits, *mean, *std, *value;
+    uint64_t seed; const int64_t *step_ptr; int64_t step_host;
+    int N, env0, nd, nc;
+    float *actions, *st_actions, *st_mu, *st_sigma, *st_logp_d, *st_logp_c, *st_values, *hist;
+    int hist_len;
+};
+/* one thread per env: softmax over <= 16 logits, inverse-CDF choice, <= 32 Gaussian parameters, the storage rows and the action-history roll */
+__global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArgs a) {
+    const int e = blockIdx.x * 128 + threadIdx.x;
+    if (e >= a.N) return;
+    const int64_t step = a.step_ptr ? *a.step_ptr : a.step_host;
+    const int nd = a.nd, nc = a.nc, w = 1 + nc;
+    const float HALF_LOG_2PI = 0.91893853320467274178f, EPS = 1.1920928955078125e-07f;
+    const float *lg = a.logits + (int64_t)e * nd;
+    float mx = lg[0];
+    for (int i = 1; i < nd; ++i) mx = fmaxf(mx, lg[i]);
+    float p[16], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { p[i] = i < nd ? expf(lg[i] - mx) : 0.f; sum += p[i]; }
+    const float inv = 1.0f / sum;
+    const F4 uc = rng4(a.seed, (uint32_t)(e + a.env0), step, RS_ACT_CHOICE, 0);
+    const float u = uc.v[0];
+    int choice = nd - 1;
+    float cdf = 0.f, pa = 0.f;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < nd) {
+            const float pi = p[i] * inv;
+            cdf += pi;
+            if (!found && (u < cdf || i == nd - 1)) { choice = i; pa = pi; found = true; }
+        }
+    }
+    const float logp_d = logf(fminf(fmaxf(pa, EPS), 1.0f - EPS));
+    float *act = a.actions + (int64_t)e * w, *sa = a.st_actions + (int64_t)e * w;
+    act[0] = (float)choice; sa[0] = (float)choice;
+    float logp_c = 0.f;
+    for (int b = 0; 4 * b < nc; ++b) {          // Box-Muller on the 4 uniforms of a Philox block: 4 normals (as qa_rollout_act)
+        const F4 q = rng4(a.seed, (uint32_t)(e + a.env0), step, RS_ACT_NOISE, b);
+        const float r0 = sqrtf(-2.0f * logf(fmaxf(q.v[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(q.v[2], 1e-7f)));
+        float s0, c0, s1, c1;
+        sincosf(6.28318530717958647692f * q.v[1], &s0, &c0);
+        sincosf(6.28318530717958647692f * q.v[3], &s1, &c1);
+        const float eps4[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = 4 * b + k;
+            if (j < nc) {
+                const float m = a.mean[(int64_t)e * nc + j], s = a.std[j], v = m + s * eps4[k], d = v - m;
+                logp_c += -(d * d) / (2.0f * s * s) - logf(s) - HALF_LOG_2PI;
+                act[1 + j] = v; sa[1 + j] = v;
+                a.st_mu[(int64_t)e * nc + j] = m; a.st_sigma[(int64_t)e * nc + j] = s;
+            }
+        }
+    }
+    a.st_logp_d[e] = logp_d; a.st_logp_c[e] = logp_c; a.st_values[e] = a.value[e];
+    if (a.hist) {       // roll by one slot (oldest first), newest slot = this action; the thread owns the env's whole history block
+        float *h = a.hist + (int64_t)e * a.hist_len * w;
+        for (int r = 0; r + 1 < a.hist_len; ++r)
+            for (int j = 0; j < w; ++j) h[r * w + j] = h[(r + 1) * w + j];
+        for (int j = 0; j < w; ++j) h[(a.hist_len - 1) * w + j] = act[j];
+    }
+}
+
 __global__ void __launch_bounds__(256) qa_rollout_post_kernel(const float *__restrict__ rew, const int64_t *__restrict__ reset, const uint8_t *__restrict__ time_out,
                                                               const float *__restrict__ values, float reward_coef, float gamma, int N, float *__restrict__ st_rewards,
                                                               uint8_t *__restrict__ st_dones, float *__restrict__ cur, float *__restrict__ fin_vals, uint8_t *__restrict__ fin_mask) {
@@ -1280,6 +1346,20 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
                        (int)num_envs, (int)env_id_offset, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_rollout_act_hybrid(const float *logits, const float *mean, const float *std, const float *value, uint64_t seed, const int64_t *step_dev, int64_t step,
+                          int32_t num_envs, int32_t env_id_offset, int32_t nd, int32_t nc_all, float *actions, float *st_actions, float *st_mu, float *st_sigma,
+                          float *st_logp_d, float *st_logp_c, float *st_values, float *action_history, int32_t hist_len, void *stream) {
+    if (!logits || !mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp_d || !st_logp_c || !st_values || num_envs <= 0 ||
+        nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0)) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_hybrid: bad argument (nd <= 16, nc_all <= 32)"); return QA_E_ARG; }
+    HybridActArgs a{logits, mean, std, value, seed, step_dev, step, (int)num_envs, (int)env_id_offset, (int)nd, (int)nc_all, actions, st_actions, st_mu, st_sigma,
+                    st_logp_d, st_logp_c, st_values, action_history, (int)hist_len};
+    hipLaunchKernelGGL(qa_rollout_act_hybrid_kernel, dim3((num_envs + 127) / 128), dim3(128), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_hybrid: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -111,11 +111,36 @@ class PPO:
         est[:, self._priv_slice(with_auxiliary)] = self.estimator(est[:, :self.num_prop])
         return est
 
-    def act(self, obs, critic_obs, info=None, hist_encoding=False, chain=None):
+    def act(self, obs, critic_obs, info=None, hist_encoding=False, chain=None, action_history=None, rng=None):
         """:101-125 -- the policy sees ESTIMATED privileged states, the storage keeps the true ones.  `chain` (fused.PolicyChain.describe_task_level,
         privileged-encoder variant): estimator, encoders, trunk, heads and critic of the step as ONE launch; the distributions, the samples and
         the transition record are the same objects either way."""
         tr, ac = self.transition, self.actor_critic
+        if chain is not None and not hist_encoding and rng is not None and obs.is_cuda and self.storage.step < self.storage.num_transitions_per_env:
+            # networks = one launch (the chain); sampling, both log-probs, the storage rows of the step and the runner's action-history roll = one
+            # more (qa_rollout_act_hybrid; ~25 eager launches before).  `rng` = (seed, device step counter, global id of env 0): the draws are
+            # Philox-keyed by (seed; env, step) like every other draw of the engine, so recorded rollouts sample afresh on every replay.
+            import ctypes as C
+            from quadrupedal_agility_amd import _capi
+            logits, mean, value = chain.forward(obs)
+            st, t, lib = self.storage, self.storage.step, _capi.load_library()
+            P = lambda x: C.c_void_p(x.data_ptr())
+            n, nd, nc = obs.shape[0], logits.shape[1], mean.shape[1]
+            if getattr(self, "_act_buf", None) is None or self._act_buf.shape[0] != n:
+                self._act_buf = torch.zeros(n, 1 + nc, device=obs.device)
+            seed, step_dev, env0 = rng
+            rc = lib.qa_rollout_act_hybrid(P(logits), P(mean), P(ac.std), P(value), int(seed), P(step_dev), 0, n, int(env0), nd, nc, P(self._act_buf), P(st.actions[t]),
+                                           P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob_d[t]), P(st.actions_log_prob_c[t]), P(st.values[t]),
+                                           P(action_history) if action_history is not None else None, int(action_history.shape[1]) if action_history is not None else 0,
+                                           C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"qa_rollout_act_hybrid failed with code {rc}: {lib.qa_last_error().decode()}")
+            st.observations[t].copy_(obs)
+            if st.privileged_observations is not None:
+                st.privileged_observations[t].copy_(critic_obs)
+            tr.actions, tr.rows_stored = self._act_buf, True
+            tr.observations = tr.critic_observations = None
+            return tr.actions
         if chain is not None and not hist_encoding:
             from torch.distributions import Categorical, Normal
             logits, mean, value = chain.forward(obs)
@@ -152,9 +177,11 @@ class PPO:
         if st.step >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         t = st.step
-        st.actions[t].copy_(tr.actions); st.values[t].copy_(tr.values)
-        st.actions_log_prob_d[t].copy_(tr.actions_log_prob_d.view(-1, 1)); st.actions_log_prob_c[t].copy_(tr.actions_log_prob_c.view(-1, 1))
-        st.mu[t].copy_(tr.action_mean); st.sigma[t].copy_(tr.action_sigma)
+        if not getattr(tr, "rows_stored", False):           # qa_rollout_act_hybrid wrote them at act time
+            st.actions[t].copy_(tr.actions); st.values[t].copy_(tr.values)
+            st.actions_log_prob_d[t].copy_(tr.actions_log_prob_d.view(-1, 1)); st.actions_log_prob_c[t].copy_(tr.actions_log_prob_c.view(-1, 1))
+            st.mu[t].copy_(tr.action_mean); st.sigma[t].copy_(tr.action_sigma)
+        tr.rows_stored = False
         st.step += 1
         self.transition.clear()
         return t

@@ -99,6 +99,7 @@ class OnPolicyRunner:
         self._rs, self._rollout_graphs, self._rollout_warm = None, {}, 0
         self.use_rollout_graph = os.environ.get("QA_TSC_ROLLOUT_GRAPH", "1") != "0"
         self.use_fused_policy = on_gpu and os.environ.get("QA_FUSED_POLICY", "1") != "0"
+        self.use_hybrid_act = os.environ.get("QA_TSC_HYBRID_ACT", "1") != "0"      # sampling + log-probs + storage rows + action history: qa_rollout_act_hybrid
         env.sync_reset_ids = False              # rollouts never wait for the GPU
 
     # ------------------------------------------------------------------ the frozen behaviour policy: one launch per env step
@@ -179,8 +180,13 @@ class OnPolicyRunner:
             lib, disc, st, N = _capi.load_library(), self.discriminator, alg.storage, env.num_envs
             P = lambda x: C.c_void_p(x.data_ptr())
         for t in range(self.num_steps_per_env):
-            actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding, chain=tchain)
-            rs["ahist"].copy_(torch.cat([rs["ahist"][:, 1:], actions[:, None, :]], dim=1))
+            hybrid = tchain is not None and dchain is not None and self.use_hybrid_act and getattr(env, "_step_dev", None) is not None and env._step_dev.is_cuda
+            if hybrid:
+                actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding, chain=tchain, action_history=rs["ahist"],
+                                  rng=(int(env.sim.cfg.seed) + 7919, env._step_dev, int(getattr(env.sim.cfg, "env_id_offset", 0))))
+            else:
+                actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding, chain=tchain)
+                rs["ahist"].copy_(torch.cat([rs["ahist"][:, 1:], actions[:, None, :]], dim=1))
             rs["obs_bbc"][:, -n_cmd:] = env.set_commands(actions)
             obs, privileged_obs, rewards, dones, infos, _ids, _term = env.step(bbc(rs["obs_bbc"]), rs["ahist"])
             disc_obs = env.get_observations_disc()

@@ -233,3 +233,73 @@ def test_hybrid_ppo_loss_kernel_matches_its_c_twin():
         assert np.allclose(o.cpu().numpy()[:7], out.numpy()[:7], rtol=3e-5, atol=3e-6)
         for got, want in ((gl, dlg), (gm, dmu), (gs, dsd), (gv, dv)):
             assert torch.allclose(got.cpu(), want, rtol=3e-4, atol=1e-7 + 3e-4 / B)
+
+
+def _hybrid_case(n=4096, nd=6, nc=18, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(n, nd, generator=g) * 1.5
+    logits[:64, 0] += 40.0                                   # near-deterministic rows: the eps clamp of Categorical(probs) matters
+    mean = torch.randn(n, nc, generator=g)
+    std = torch.rand(nc, generator=g) * 0.8 + 0.2
+    value = torch.randn(n, generator=g)
+    hist = torch.randn(n, 8, 1 + nc, generator=g)
+    return logits, mean, std, value, hist
+
+
+def _run_hybrid(lib, prefix, t, step, dev=None):
+    logits, mean, std, value, hist = (x.clone().to(dev) if dev else x.clone() for x in t)
+    n, nd = logits.shape; nc = mean.shape[1]
+    z = lambda *s: torch.zeros(*s, device=dev) if dev else torch.zeros(*s)
+    out = dict(actions=z(n, 1 + nc), st_actions=z(n, 1 + nc), mu=z(n, nc), sigma=z(n, nc), logp_d=z(n), logp_c=z(n), values=z(n), hist=hist)
+    ctr = torch.tensor([step], dtype=torch.int64, device=dev) if dev else torch.tensor([step], dtype=torch.int64)
+    P = lambda x: x.data_ptr()
+    rc = getattr(lib, prefix + "rollout_act_hybrid")(P(logits), P(mean), P(std), P(value), 12345, P(ctr), 0, n, 100, nd, nc, P(out["actions"]), P(out["st_actions"]), P(out["mu"]),
+                                                      P(out["sigma"]), P(out["logp_d"]), P(out["logp_c"]), P(out["values"]), P(hist), 8, None)
+    assert rc == 0
+    return out
+
+
+def test_hybrid_act_twin_matches_torch_distributions():
+    """qa_rollout_act_hybrid's C twin: the log-probabilities are torch's Categorical(probs=softmax(logits)) / Normal log_prob of the sampled action,
+    the choice follows the softmax probabilities (chi-square over 4096 x 8 draws), the Gaussian part has the right moments, storage rows and the
+    action-history roll are what PPO.act / add_transitions / the runner wrote with ten-odd torch ops"""
+    from torch.distributions import Categorical, Normal
+    from tests.oracle_lib import load_oracle
+    lib = load_oracle()
+    t = _hybrid_case()
+    logits, mean, std, value, hist = t
+    counts = torch.zeros(6)
+    for step in range(8):
+        o = _run_hybrid(lib, "qo_", t, step)
+        a_d, a_c = o["actions"][:, 0].long(), o["actions"][:, 1:]
+        assert torch.equal(o["actions"], o["st_actions"]) and torch.equal(o["mu"], mean) and torch.equal(o["sigma"], std.expand_as(mean)) and torch.equal(o["values"], value)
+        dist_d = Categorical(probs=torch.softmax(logits, -1), validate_args=False)
+        assert torch.allclose(o["logp_d"], dist_d.log_prob(a_d), rtol=1e-5, atol=2e-6)
+        assert torch.allclose(o["logp_c"], Normal(mean, std.expand_as(mean)).log_prob(a_c).sum(-1), rtol=1e-5, atol=2e-5)
+        assert torch.equal(o["hist"][:, :-1], hist[:, 1:]) and torch.equal(o["hist"][:, -1], o["actions"])
+        counts += torch.bincount(a_d[64:], minlength=6).float()
+        z = (a_c - mean) / std
+        assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+        assert (a_d[:64] == 0).all()
+    expect = torch.softmax(logits[64:], -1).sum(0) * 8
+    chi2 = float(((counts - expect) ** 2 / expect).sum())
+    assert chi2 < 25.0, chi2                                  # 5 degrees of freedom: p < 1e-4 beyond 25
+    o2 = _run_hybrid(lib, "qo_", t, 3)
+    assert torch.equal(o2["actions"], _run_hybrid(lib, "qo_", t, 3)["actions"]) and not torch.equal(o2["actions"], o["actions"])     # keyed by the step
+
+
+@pytest.mark.gpu
+def test_hybrid_act_kernel_matches_twin():
+    from quadrupedal_agility_amd import _capi
+    from tests.oracle_lib import load_oracle
+    t = _hybrid_case(n=5000, seed=2)
+    for step in (0, 7):
+        a = _run_hybrid(_capi.load_library(), "qa_", t, step, dev="cuda")
+        torch.cuda.synchronize()
+        b = _run_hybrid(load_oracle(), "qo_", t, step)
+        same = a["actions"][:, 0].cpu() == b["actions"][:, 0]
+        assert same.float().mean() > 0.999                   # a uniform within rounding of a CDF edge may fall on the other side (expf ulps)
+        for k in ("actions", "st_actions", "mu", "sigma", "logp_d", "logp_c", "values", "hist"):
+            x, y = a[k].cpu(), b[k]
+            m = same if x.dim() == 1 else same.view(-1, *([1] * (x.dim() - 1))).expand_as(x)
+            assert torch.allclose(x[m], y[m], rtol=2e-5, atol=2e-5), k
