@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(seed, iters, num_envs, mode, out_dir):
     cs = os.path.join(out_dir, f"checksums_{mode}_s{seed}.json")
     env = dict(os.environ, QA_PARITY_CHECKSUMS=cs)
+    env["QA_PARITY_TABLES_IN_WARMUP"] = "1"        # both modes draw the discriminator's samples through the tables from the first update on
     if mode == "eager":
         env["QA_PARITY_EAGER_TABLES"] = "1"
     curves = os.path.join(out_dir, f"curves_{mode}_s{seed}.json")

@@ -45,6 +45,8 @@ def run(device, num_envs, iters, seed, amp=False):
         runner.alg.use_update_graph = False
         runner.alg.overlap_updates = False
         runner.alg.eager_from_tables = True
+    if os.environ.get("QA_PARITY_TABLES_IN_WARMUP") == "1":   # the recorded path's ONE eager warm-up update samples through the tables too (it uses the generators otherwise)
+        runner.alg.eager_from_tables = True
     if os.environ.get("QA_PARITY_EAGER_UPDATE") == "1":
         runner.alg.use_update_graph = False
     if os.environ.get("QA_PARITY_NO_DISC_GRAPH") == "1":
@@ -65,7 +67,7 @@ def run(device, num_envs, iters, seed, amp=False):
                              prior=float(env.prior_parameters.double().sum()) if amp else 0.0, losses=[float(v) for v in r] if amp else [],
                              disc_each=[float(p.detach().double().sum()) for p in a.disc.parameters()] if amp else [],
                              obs=float(a.storage.observations.double().sum()), rewards=float(a.storage.rewards.double().sum()),
-                             rng=int.from_bytes(bytes(torch.cuda.get_rng_state()[8:16].tolist()), "little") if device != "cpu" else 0))
+                             ))      # (the generator state is NOT read: get_rng_state() on a graph-registered generator may move its offset)
             if len(rows) % 50 == 0 or len(rows) >= iters:
                 json.dump(rows, open(os.environ["QA_PARITY_CHECKSUMS"], "w"))
             return r
