@@ -831,10 +831,15 @@ def test_clip_adam_refuses_to_record_the_pointer_table_path():
     grads(1)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with pytest.raises(RuntimeError, match="cannot be recorded|stays eager"):
-        with torch.cuda.graph(graph):
+    refused = None
+    with torch.cuda.graph(graph):              # the refusal is caught INSIDE the capture: an exception leaving the context while capturing is replaced by HIP's
+        try:
             stepper.step()
+            refused = False
+        except RuntimeError as e:
+            refused = "stays eager" in str(e)
     torch.cuda.synchronize()
+    assert refused is True
     torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0); oa.step(); stepper.step()
     for p, q in zip(a.parameters(), b.parameters()):
         assert torch.allclose(p, q, rtol=2e-5, atol=2e-7)

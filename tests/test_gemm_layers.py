@@ -218,8 +218,8 @@ def test_chain_on_zero_padded_rows_equals_the_unpadded_modules(k, pad):
         fused.ALL_OWN = False
     assert torch.allclose(y, net(x), rtol=2e-4, atol=2e-4)
     got = [p.grad for p in net.parameters()] + [xp.grad[:, :k]]
-    for u, v in zip(got, ref):
-        assert u.shape == v.shape and u.is_contiguous()
+    for i, (u, v) in enumerate(zip(got, ref)):
+        assert u.shape == v.shape and (u.is_contiguous() or i == len(got) - 1)          # parameter gradients are dense (ClipAdam needs that); the last entry is a column slice
         assert torch.allclose(u, v, rtol=2e-4, atol=2e-5 * rows ** 0.5), float((u - v).abs().max())
     assert float(xp.grad[:, k:].abs().max()) == 0.0
 

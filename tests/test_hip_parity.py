@@ -38,7 +38,9 @@ TOL = {
 }
 # share of env-steps allowed outside TOL per protocol: ~2x the share measured with this TOL table on MI355X (profiles/r4_parity_flip_shares.txt,
 # `QA_PARITY_MEASURE=1 pytest -m gpu -s -k parity`); filled in from that run
-BUDGET = {"plane": 0.004, "height_field": 0.01, "ceiling": 0.04, "mocap": 0.004, "self_collision": 0.02, "articulated": 0.02, "articulated_8192": 0.05, "course": 0.01}
+# measured (r4, MI355X): plane 0.08 %, height field 1.1-1.5 %, ceiling 3.75 %, mocap 0.04 %, self-collision 0.10 %, articulated 0.1 % (64 envs) / 3.7 % (8192 envs,
+# fp32 world coordinates 900 m from the origin), course 0.003 %
+BUDGET = {"plane": 0.002, "height_field": 0.03, "ceiling": 0.075, "mocap": 0.001, "self_collision": 0.002, "articulated": 0.004, "articulated_8192": 0.075, "course": 0.001}
 
 
 def check_flips(name, flips, total, budget):
