@@ -570,11 +570,13 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
  *   logp_d = log(clamp(p[a_d], eps, 1 - eps)), eps = 2^-23 (torch's Categorical(probs=...) through probs_to_logits);
  *   a_c = mean + std * N(0,1) (stream 20);  logp_c = sum_j log N(a_c_j; mean_j, std_j);
  *   actions (N, 1 + nc_all) = [a_d as float | a_c], also to st_actions; st_mu = mean, st_sigma = std, st_logp_d, st_logp_c, st_values = value;
- *   action_history (N, hist_len, 1 + nc_all), if not NULL, is rolled by one slot (oldest first) and its newest slot set to `actions`.
+ *   action_history (N, hist_len, 1 + nc_all), if not NULL, = action_history_in rolled by one slot (oldest first) with its newest slot set to
+ *   `actions`; action_history_in NULL or == action_history rolls in place (slower: a thread per env), a second buffer is copied coalesced.
  * nd <= 16, nc_all <= 32. */
 int qa_rollout_act_hybrid(const float *logits, const float *mean, const float *std, const float *value, uint64_t seed, const int64_t *step_dev, int64_t step,
                           int32_t num_envs, int32_t env_id_offset, int32_t nd, int32_t nc_all, float *actions, float *st_actions, float *st_mu, float *st_sigma,
-                          float *st_logp_d, float *st_logp_c, float *st_values, float *action_history, int32_t hist_len, void *stream);
+                          float *st_logp_d, float *st_logp_c, float *st_values, const float *action_history_in, float *action_history, int32_t hist_len,
+                          void *stream);
 int qa_rollout_post(const float *rew, const int64_t *reset, const uint8_t *time_out, const float *values, float reward_coef, float gamma,
                     int32_t num_envs, float *st_rewards, uint8_t *st_dones, float *cur, float *fin_vals, uint8_t *fin_mask, void *stream);
 /* The same with the discriminator's rewards (Discriminator.predict_disc_reward, bbc/rsl_rl/algorithms/discriminator.py:88-118,

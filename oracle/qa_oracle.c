@@ -1933,10 +1933,12 @@ int qo_rollout_act(const float *mean, const float *std, const float *value, cons
 }
 int qo_rollout_act_hybrid(const float *logits, const float *mean, const float *std, const float *value, uint64_t seed, const int64_t *step_dev, int64_t step,
                           int32_t num_envs, int32_t env_id_offset, int32_t nd, int32_t nc_all, float *actions, float *st_actions, float *st_mu, float *st_sigma,
-                          float *st_logp_d, float *st_logp_c, float *st_values, float *action_history, int32_t hist_len, void *stream) {
+                          float *st_logp_d, float *st_logp_c, float *st_values, const float *action_history_in, float *action_history, int32_t hist_len,
+                          void *stream) {
     (void)stream;       /* tsc/rsl_rl/modules/actor_critic.py:252-261, algorithms/ppo.py:101-125 */
     if (!logits || !mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp_d || !st_logp_c || !st_values || num_envs <= 0 ||
-        nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0)) return QA_E_ARG;
+        nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0) || (action_history_in && !action_history)) return QA_E_ARG;
+    if (!action_history_in) action_history_in = action_history;
     if (step_dev) step = *step_dev;
     const int w = 1 + nc_all;
     const float EPS = 1.1920928955078125e-07f;
@@ -1978,7 +1980,7 @@ int qo_rollout_act_hybrid(const float *logits, const float *mean, const float *s
         st_logp_d[e] = logf(cl); st_logp_c[e] = logp_c; st_values[e] = value[e];
         if (action_history) {
             float *h = action_history + (int64_t)e * hist_len * w;
-            memmove(h, h + w, sizeof(float) * (size_t)(hist_len - 1) * (size_t)w);
+            memmove(h, action_history_in + (int64_t)e * hist_len * w + w, sizeof(float) * (size_t)(hist_len - 1) * (size_t)w);
             memcpy(h + (int64_t)(hist_len - 1) * w, act, sizeof(float) * (size_t)w);
         }
     }

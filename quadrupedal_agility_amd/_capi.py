@@ -150,7 +150,7 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "gather_rows"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5; f.restype = C.c_int
     f = getattr(lib, prefix + "kl_lr_rule"); f.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "rollout_act_hybrid")
-    f.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+    f.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 9 + [C.c_int32, C.c_void_p]
     f.restype = C.c_int
     f = getattr(lib, prefix + "set_lean_exports"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int
     f = getattr(lib, prefix + "episode_means"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int

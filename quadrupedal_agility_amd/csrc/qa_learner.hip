@@ -745,14 +745,15 @@ struct HybridActArgs {
     uint64_t seed; const int64_t *step_ptr; int64_t step_host;
     int N, env0, nd, nc;
     float *actions, *st_actions, *st_mu, *st_sigma, *st_logp_d, *st_logp_c, *st_values, *hist;
+    const float *hist_in;
     int hist_len;
 };
 /* one thread per env: softmax over <= 16 logits, inverse-CDF choice, <= 32 Gaussian parameters, the storage rows and the action-history roll */
 __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArgs a) {
     const int e = blockIdx.x * 128 + threadIdx.x;
-    if (e >= a.N) return;
     const int64_t step = a.step_ptr ? *a.step_ptr : a.step_host;
     const int nd = a.nd, nc = a.nc, w = 1 + nc;
+    if (e < a.N) {
     const float HALF_LOG_2PI = 0.91893853320467274178f, EPS = 1.1920928955078125e-07f;
     const float *lg = a.logits + (int64_t)e * nd;
     float mx = lg[0];
@@ -797,11 +798,25 @@ __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArg
         }
     }
     a.st_logp_d[e] = logp_d; a.st_logp_c[e] = logp_c; a.st_values[e] = a.value[e];
-    if (a.hist) {       // roll by one slot (oldest first), newest slot = this action; the thread owns the env's whole history block
-        float *h = a.hist + (int64_t)e * a.hist_len * w;
-        for (int r = 0; r + 1 < a.hist_len; ++r)
-            for (int j = 0; j < w; ++j) h[r * w + j] = h[(r + 1) * w + j];
-        for (int j = 0; j < w; ++j) h[(a.hist_len - 1) * w + j] = act[j];
+    }
+    if (a.hist) {
+        // roll by one slot (oldest first), newest slot = this step's action.  Out of place when the caller gives a second buffer (hist_in != hist):
+        // the workgroup's 128 envs are one contiguous run of both buffers, copied with coalesced accesses by all threads; in place (hist_in == hist)
+        // every thread moves its own env's block front to back.
+        __syncthreads();                       // the block's `actions` rows are written
+        const int e0 = blockIdx.x * 128, ne = min(128, a.N - e0), per = a.hist_len * w;
+        if (a.hist_in != a.hist) {
+            const float *src = a.hist_in + (int64_t)e0 * per;
+            float *dst = a.hist + (int64_t)e0 * per;
+            for (int i = threadIdx.x; i < ne * per; i += 128) {
+                const int le = i / per, o = i - le * per;
+                dst[i] = o < per - w ? src[i + w] : a.actions[(int64_t)(e0 + le) * w + (o - (per - w))];
+            }
+        } else if (e < a.N) {
+            float *h = a.hist + (int64_t)e * per;
+            for (int o = 0; o < per - w; ++o) h[o] = h[o + w];
+            for (int j = 0; j < w; ++j) h[per - w + j] = a.actions[(int64_t)e * w + j];
+        }
     }
 }
 
@@ -1351,12 +1366,13 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
 
 int qa_rollout_act_hybrid(const float *logits, const float *mean, const float *std, const float *value, uint64_t seed, const int64_t *step_dev, int64_t step,
                           int32_t num_envs, int32_t env_id_offset, int32_t nd, int32_t nc_all, float *actions, float *st_actions, float *st_mu, float *st_sigma,
-                          float *st_logp_d, float *st_logp_c, float *st_values, float *action_history, int32_t hist_len, void *stream) {
+                          float *st_logp_d, float *st_logp_c, float *st_values, const float *action_history_in, float *action_history, int32_t hist_len,
+                          void *stream) {
     if (!logits || !mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp_d || !st_logp_c || !st_values || num_envs <= 0 ||
-        nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0)) {
+        nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0) || (action_history_in && !action_history)) {
         snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_hybrid: bad argument (nd <= 16, nc_all <= 32)"); return QA_E_ARG; }
     HybridActArgs a{logits, mean, std, value, seed, step_dev, step, (int)num_envs, (int)env_id_offset, (int)nd, (int)nc_all, actions, st_actions, st_mu, st_sigma,
-                    st_logp_d, st_logp_c, st_values, action_history, (int)hist_len};
+                    st_logp_d, st_logp_c, st_values, action_history, action_history_in ? action_history_in : action_history, (int)hist_len};
     hipLaunchKernelGGL(qa_rollout_act_hybrid_kernel, dim3((num_envs + 127) / 128), dim3(128), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_hybrid: %s", hipGetErrorString(e)); return QA_E_DEVICE; }

@@ -131,7 +131,8 @@ class PPO:
             seed, step_dev, env0 = rng
             rc = lib.qa_rollout_act_hybrid(P(logits), P(mean), P(ac.std), P(value), int(seed), P(step_dev), 0, n, int(env0), nd, nc, P(self._act_buf), P(st.actions[t]),
                                            P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob_d[t]), P(st.actions_log_prob_c[t]), P(st.values[t]),
-                                           P(action_history) if action_history is not None else None, int(action_history.shape[1]) if action_history is not None else 0,
+                                           P(action_history[0]) if action_history is not None else None, P(action_history[1]) if action_history is not None else None,
+                                           int(action_history[1].shape[1]) if action_history is not None else 0,
                                            C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
             if rc != 0:
                 raise RuntimeError(f"qa_rollout_act_hybrid failed with code {rc}: {lib.qa_last_error().decode()}")

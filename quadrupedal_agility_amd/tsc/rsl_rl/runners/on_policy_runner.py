@@ -182,8 +182,12 @@ class OnPolicyRunner:
         for t in range(self.num_steps_per_env):
             hybrid = tchain is not None and dchain is not None and self.use_hybrid_act and getattr(env, "_step_dev", None) is not None and env._step_dev.is_cuda
             if hybrid:
-                actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding, chain=tchain, action_history=rs["ahist"],
+                if "ahist2" not in rs:
+                    rs["ahist2"] = torch.zeros_like(rs["ahist"])
+                # the history is rolled OUT of place into the other of two buffers (coalesced copy); `ahist` names the current one
+                actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding, chain=tchain, action_history=(rs["ahist"], rs["ahist2"]),
                                   rng=(int(env.sim.cfg.seed) + 7919, env._step_dev, int(getattr(env.sim.cfg, "env_id_offset", 0))))
+                rs["ahist"], rs["ahist2"] = rs["ahist2"], rs["ahist"]
             else:
                 actions = alg.act(obs, obs, infos, hist_encoding=hist_encoding, chain=tchain)
                 rs["ahist"].copy_(torch.cat([rs["ahist"][:, 1:], actions[:, None, :]], dim=1))

@@ -246,15 +246,18 @@ def _hybrid_case(n=4096, nd=6, nc=18, seed=0):
     return logits, mean, std, value, hist
 
 
-def _run_hybrid(lib, prefix, t, step, dev=None):
+def _run_hybrid(lib, prefix, t, step, dev=None, out_of_place=False):
     logits, mean, std, value, hist = (x.clone().to(dev) if dev else x.clone() for x in t)
+    hist_in = None
+    if out_of_place:
+        hist_in, hist = hist, torch.zeros_like(hist)
     n, nd = logits.shape; nc = mean.shape[1]
     z = lambda *s: torch.zeros(*s, device=dev) if dev else torch.zeros(*s)
     out = dict(actions=z(n, 1 + nc), st_actions=z(n, 1 + nc), mu=z(n, nc), sigma=z(n, nc), logp_d=z(n), logp_c=z(n), values=z(n), hist=hist)
     ctr = torch.tensor([step], dtype=torch.int64, device=dev) if dev else torch.tensor([step], dtype=torch.int64)
     P = lambda x: x.data_ptr()
     rc = getattr(lib, prefix + "rollout_act_hybrid")(P(logits), P(mean), P(std), P(value), 12345, P(ctr), 0, n, 100, nd, nc, P(out["actions"]), P(out["st_actions"]), P(out["mu"]),
-                                                      P(out["sigma"]), P(out["logp_d"]), P(out["logp_c"]), P(out["values"]), P(hist), 8, None)
+                                                      P(out["sigma"]), P(out["logp_d"]), P(out["logp_c"]), P(out["values"]), P(hist_in) if hist_in is not None else None, P(hist), 8, None)
     assert rc == 0
     return out
 
@@ -295,8 +298,12 @@ def test_hybrid_act_kernel_matches_twin():
     t = _hybrid_case(n=5000, seed=2)
     for step in (0, 7):
         a = _run_hybrid(_capi.load_library(), "qa_", t, step, dev="cuda")
+        a2 = _run_hybrid(_capi.load_library(), "qa_", t, step, dev="cuda", out_of_place=True)
         torch.cuda.synchronize()
+        assert all(torch.equal(a[k], a2[k]) for k in a)          # in-place and out-of-place history rolls agree
         b = _run_hybrid(load_oracle(), "qo_", t, step)
+        b2 = _run_hybrid(load_oracle(), "qo_", t, step, out_of_place=True)
+        assert all(torch.equal(b[k], b2[k]) for k in b)
         same = a["actions"][:, 0].cpu() == b["actions"][:, 0]
         assert same.float().mean() > 0.999                   # a uniform within rounding of a CDF edge may fall on the other side (expf ulps)
         for k in ("actions", "st_actions", "mu", "sigma", "logp_d", "logp_c", "values", "hist"):

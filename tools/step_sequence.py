@@ -5,7 +5,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 MARK = sys.argv[2] if len(sys.argv) > 2 else "qa_ppo_loss_kernel"        # "qa_disc_loss_kernel": one discriminator step
 idx = [i for i, e in enumerate(ev) if MARK in e[2]]
-a, b = idx[-6], idx[-5]
+# "mid" (argv[3]): a marker pair from the middle of the trace (the bench's tail times single kernels back to back: no step lives there)
+a, b = (idx[len(idx) // 2], idx[len(idx) // 2 + 1]) if len(sys.argv) > 3 and sys.argv[3] == "mid" else (idx[-6], idx[-5])
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"void at::native::", "", n)
