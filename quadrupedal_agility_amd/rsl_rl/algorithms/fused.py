@@ -113,8 +113,14 @@ class _LinearElu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, alpha):
-        y = torch.addmm(bias, x, weight.t())
-        torch.nn.functional.elu(y, alpha=alpha, inplace=True)
+        # r4 (profiles/r4_gemm_dma_bench.json, 24,576 rows): for the narrow trunk layers (256 -> 128) the hand-written GEMM with bias + ELU in its
+        # epilogue is one 22 us launch against the library's 26 us product + a 6 us ELU pass; the wider products stay on the tuned library
+        if (OWN_GEMM and OWN_FWD_NARROW and x.shape[0] >= 8192 and weight.shape[0] <= 128 and 64 < weight.shape[1] <= 256 and weight.is_contiguous()
+                and bias.is_contiguous() and x.stride(1) == 1):
+            y = linear_forward_raw(x, weight.detach(), bias.detach(), ACT_ELU, alpha)
+        else:
+            y = torch.addmm(bias, x, weight.t())
+            torch.nn.functional.elu(y, alpha=alpha, inplace=True)
         ctx.save_for_backward(x, weight, y)
         ctx.alpha = alpha
         return y
@@ -287,6 +293,7 @@ def linear_elu(x, weight, bias, alpha=1.0):
     return _LinearElu.apply(x, weight, bias, alpha)
 
 
+OWN_FWD_NARROW = os.environ.get("QA_OWN_FWD_NARROW", "1") != "0"
 OWN_GEMM = os.environ.get("QA_OWN_GEMM", "1") != "0"      # the dense layers through csrc/qa_gemm.hip (0: library GEMMs + the r1/r2 kernels around them)
 ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 

@@ -8,9 +8,16 @@ O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
 # PMC first: bench.py reads profiles/env_step_traffic.json for roofline.traffic
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python tools/pmc_env_step.py 4096 < /dev/null > /tmp/pmc_f.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python tools/pmc_env_step.py 4096 < /dev/null > /tmp/pmc_w.log 2>&1
-python tools/pmc_to_json.py /tmp/pmc_f /tmp/pmc_w 4096 $O/env_step_traffic.json > $O/pmc.txt 2>&1 && cp $O/env_step_traffic.json profiles/env_step_traffic.json
+# (r4) lean = 3: the kernel a training run without AMP launches (qa_set_lean_exports); lean = 0: the reference's exports, for comparison
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_w.log 2>&1
+python tools/pmc_to_json.py /tmp/pmc_f /tmp/pmc_w 4096 $O/env_step_traffic.json 3 > $O/pmc.txt 2>&1 && cp $O/env_step_traffic.json profiles/env_step_traffic.json
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f0 -- python tools/pmc_env_step.py 4096 0 < /dev/null > /tmp/pmc_f0.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w0 -- python tools/pmc_env_step.py 4096 0 < /dev/null > /tmp/pmc_w0.log 2>&1
+python tools/pmc_to_json.py /tmp/pmc_f0 /tmp/pmc_w0 4096 $O/env_step_traffic_full_exports.json 0 >> $O/pmc.txt 2>&1
+SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
+timeout 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d /tmp/pmc_sq -- python tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_sq.log 2>&1
+python tools/pmc_tsc_env.py summarize /tmp/pmc_sq > $O/env_step_sq_counters.txt 2>&1
 timeout 500 python bench.py 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
 timeout 400 python bench.py --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_amp.json
 timeout 400 python bench.py --terrain trimesh --no_cpu_baseline 2> $O/bench_trimesh.err < /dev/null | grep '"metric"' > $O/bench_cfg2_trimesh.json

@@ -33,10 +33,10 @@ else:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 name = r.get("Kernel_Name", "")
-                key = "qa_env_step_kernel<false,4,1>" if "qa_env_step" in name else ("copy (256 MiB calibration)" if "copy" in name.lower() else None)
+                key = name.split("(")[0].replace("void ", "")[:40] if "qa_env_step" in name else ("copy (256 MiB calibration)" if "copy" in name.lower() else None)
                 if key:
                     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, dd in acc.items():
         for c, v in sorted(dd.items()):
             v2 = v[len(v) // 4:]
-            print(f"{k:32s} {c:28s} n={len(v2):3d} mean={sum(v2) / len(v2):16.1f}")
+            print(f"{k:42s} {c:28s} n={len(v2):3d} mean={sum(v2) / len(v2):16.1f}")
