@@ -806,11 +806,21 @@ __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArg
         __syncthreads();                       // the block's `actions` rows are written
         const int e0 = blockIdx.x * 128, ne = min(128, a.N - e0), per = a.hist_len * w;
         if (a.hist_in != a.hist) {
-            const float *src = a.hist_in + (int64_t)e0 * per;
-            float *dst = a.hist + (int64_t)e0 * per;
-            for (int i = threadIdx.x; i < ne * per; i += 128) {
-                const int le = i / per, o = i - le * per;
-                dst[i] = o < per - w ? src[i + w] : a.actions[(int64_t)(e0 + le) * w + (o - (per - w))];
+            const float *__restrict__ src = a.hist_in + (int64_t)e0 * per;
+            const float *__restrict__ newest = a.actions + (int64_t)e0 * w;
+            float *__restrict__ dst = a.hist + (int64_t)e0 * per;
+            const int total = ne * per;
+            // eight independent loads in flight per thread before the first store (a plain loop waits for every load: 152 dependent round trips)
+            for (int i0 = threadIdx.x; i0 < total; i0 += 128 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(i0 + 128 * u, total - 1);
+                    const int le = i / per, o = i - le * per;
+                    v[u] = o < per - w ? src[i + w] : newest[le * w + (o - (per - w))];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + 128 * u; if (i < total) dst[i] = v[u]; }
             }
         } else if (e < a.N) {
             float *h = a.hist + (int64_t)e * per;

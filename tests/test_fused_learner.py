@@ -827,8 +827,9 @@ def test_clip_adam_refuses_to_record_the_pointer_table_path():
         g = torch.Generator(device="cuda").manual_seed(k)
         for p, q in zip(a.parameters(), b.parameters()):
             p.grad = torch.randn(p.shape, device="cuda", generator=g); q.grad = p.grad.clone()
-    grads(0); torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0); oa.step(); stepper.step()      # state exists from here on
-    grads(1)
+    for k in (0, 1):         # the first step creates the optimiser state (torch path), the second builds the kernel's pointer tables
+        grads(k); torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0); oa.step(); stepper.step()
+    grads(2)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     refused = None
