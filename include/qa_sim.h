@@ -310,6 +310,29 @@ int qa_tsc_reset(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy,
 int qa_tsc_reset_dev(qa_sim *sim, const uint8_t *reset_flags, const float *start_xy, const float *start_yaw, float rand_yaw_range,
                      float rand_x_range, float rand_y_range, float rand_pitch_range, const int64_t *global_step_dev, void *stream);
 
+/* The torch glue of the task-level env step between its kernels, as three launches (ABI 13; it was ~40 eager launches per env step inside the recorded
+ * rollout).  All three key their draws like the engine: Philox (seed; env_id_offset + env, step, stream) with step = the device step counter.
+ *
+ * qa_tsc_push  =  `common_step_counter += 1` + `_push_robots` (tsc/legged_gym/envs/base/legged_robot.py:905-915): s = *step_dev + 1 is written back by the
+ *   launch's last workgroup (`ticket`: one int32, zero before the first call, zero again after every call); on the steps with s % push_interval == 0
+ *   (and push_interval > 0) root_states[e, 7:9] = (2 U - 1) max_push_vel_xy, U from stream 22.
+ * qa_tsc_start_pose  =  the first lines of reset_idx (:352-366) for EVERY env (the reset kernel reads them where flagged): with randomize_start the
+ *   envs with flags != 0 draw a new start obstacle (uniform over num_obstacles, stream 23) into cur_obst_idx; start_goal = cur_obst_idx * goals_per_obstacle
+ *   (0 without randomize_start), start_xy = env_goals[e, start_goal, 0:2], start_yaw = obst_angs[e, cur_obst_idx] (frame_yaw0 without randomize_start).
+ * qa_tsc_reset_where  =  reset_idx's bookkeeping (:367-376, 396-404) + `_reset_dofs`' obstacle part (:812-823), masked, no index list: for flags != 0
+ *   cur_goal_idx = start_goal, reach_goal_timer = 0, episode_sums[:, e] = 0, episode_length = 0; for every env cur_goals / next_goals are re-gathered
+ *   (indices clamped to the goal slots); with obst_state != NULL the flagged envs' see-saw goes to +-seesaw_rest (minus when cur_obst_idx >
+ *   seesaw_order[e], seesaw_order != NULL) and every env's obstacle velocities are zeroed when *any_reset != 0. */
+int qa_tsc_push(float *root_states, int64_t num_envs, int64_t *step_dev, int32_t *ticket, int32_t push_interval, float max_push_vel_xy, uint64_t seed,
+                int32_t env_id_offset, void *stream);
+int qa_tsc_start_pose(const uint8_t *flags, int64_t *cur_obst_idx, const float *env_goals, const float *obst_angs, int64_t num_envs, int32_t num_goal_slots,
+                      int32_t num_obstacles, int32_t goals_per_obstacle, int32_t randomize_start, float frame_yaw0, uint64_t seed, const int64_t *step_dev,
+                      int32_t env_id_offset, float *start_xy, float *start_yaw, int64_t *start_goal, void *stream);
+int qa_tsc_reset_where(const uint8_t *flags, const uint8_t *any_reset, const int64_t *start_goal, int64_t *cur_goal_idx, float *reach_goal_timer,
+                       float *episode_sums, int32_t num_terms, int64_t *episode_length, const float *env_goals, int32_t num_goal_slots, float *cur_goals,
+                       float *next_goals, float *obst_state, float seesaw_rest, const int64_t *cur_obst_idx, const int64_t *seesaw_order, int64_t num_envs,
+                       void *stream);
+
 /* Reset bookkeeping of one task-level step in a single launch (tsc/legged_gym/envs/base/legged_robot.py:382-384, 396-404):
  *   any_reset[0]      = 1 if any reset_flags[e] != 0 (the condition of the reference's extra gym.simulate: feed it to qa_simulate_if)
  *   episode_means[k]  = sum over the flagged envs of episode_sums[k][e] / count / max_episode_length_s   for k < num_terms,

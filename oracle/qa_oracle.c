@@ -1931,6 +1931,72 @@ int qo_rollout_act(const float *mean, const float *std, const float *value, cons
     }
     return QA_OK;
 }
+int qo_tsc_push(float *root_states, int64_t num_envs, int64_t *step_dev, int32_t *ticket, int32_t push_interval, float max_push_vel_xy, uint64_t seed,
+                int32_t env_id_offset, void *stream) {
+    (void)stream; (void)ticket;         /* tsc/legged_gym/envs/base/legged_robot.py:905-915 */
+    if (!root_states || !step_dev || !ticket || num_envs <= 0) return QA_E_ARG;
+    const int64_t s = *step_dev + 1;
+    if (push_interval > 0 && s % push_interval == 0)
+        for (int64_t e = 0; e < num_envs; ++e) {
+            uint32_t o[4];
+            philox(seed, (uint32_t)(e + env_id_offset), (uint32_t)s, (uint32_t)(22 * 256 + 0), (uint32_t)((uint64_t)s >> 32), o);
+            root_states[e * 13 + 7] = ((float)(o[0] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f) * max_push_vel_xy;
+            root_states[e * 13 + 8] = ((float)(o[1] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f) * max_push_vel_xy;
+        }
+    *step_dev = s;
+    return QA_OK;
+}
+
+int qo_tsc_start_pose(const uint8_t *flags, int64_t *cur_obst_idx, const float *env_goals, const float *obst_angs, int64_t num_envs, int32_t num_goal_slots,
+                      int32_t num_obstacles, int32_t goals_per_obstacle, int32_t randomize_start, float frame_yaw0, uint64_t seed, const int64_t *step_dev,
+                      int32_t env_id_offset, float *start_xy, float *start_yaw, int64_t *start_goal, void *stream) {
+    (void)stream;                       /* :352-366 */
+    if (!flags || !env_goals || !start_xy || !start_yaw || !start_goal || num_envs <= 0 || num_goal_slots <= 0 ||
+        (randomize_start && (!cur_obst_idx || !obst_angs || !step_dev || num_obstacles <= 0 || goals_per_obstacle <= 0))) return QA_E_ARG;
+    for (int64_t e = 0; e < num_envs; ++e) {
+        int64_t sg = 0; float yaw = frame_yaw0;
+        if (randomize_start) {
+            int64_t ob = cur_obst_idx[e];
+            if (flags[e]) {
+                uint32_t o[4];
+                philox(seed, (uint32_t)(e + env_id_offset), (uint32_t)*step_dev, (uint32_t)(23 * 256 + 0), (uint32_t)((uint64_t)*step_dev >> 32), o);
+                int d = (int)((float)(o[0] >> 8) * (1.0f / 16777216.0f) * (float)num_obstacles);
+                ob = d >= num_obstacles ? num_obstacles - 1 : d;
+                cur_obst_idx[e] = ob;
+            }
+            sg = ob * goals_per_obstacle; yaw = obst_angs[e * num_obstacles + ob];
+        }
+        const int64_t g = sg < 0 ? 0 : (sg >= num_goal_slots ? num_goal_slots - 1 : sg);
+        start_xy[2 * e] = env_goals[(e * num_goal_slots + g) * 3]; start_xy[2 * e + 1] = env_goals[(e * num_goal_slots + g) * 3 + 1];
+        start_yaw[e] = yaw; start_goal[e] = sg;
+    }
+    return QA_OK;
+}
+
+int qo_tsc_reset_where(const uint8_t *flags, const uint8_t *any_reset, const int64_t *start_goal, int64_t *cur_goal_idx, float *reach_goal_timer,
+                       float *episode_sums, int32_t num_terms, int64_t *episode_length, const float *env_goals, int32_t num_goal_slots, float *cur_goals,
+                       float *next_goals, float *obst_state, float seesaw_rest, const int64_t *cur_obst_idx, const int64_t *seesaw_order, int64_t num_envs,
+                       void *stream) {
+    (void)stream;                       /* :367-376, 396-404, 812-823 */
+    if (!flags || !start_goal || !cur_goal_idx || !reach_goal_timer || !episode_sums || !episode_length || !env_goals || !cur_goals || !next_goals ||
+        num_envs <= 0 || num_terms <= 0 || num_goal_slots <= 0 || (obst_state && (!any_reset || (seesaw_order && !cur_obst_idx)))) return QA_E_ARG;
+    for (int64_t e = 0; e < num_envs; ++e) {
+        int64_t g = cur_goal_idx[e];
+        if (flags[e]) {
+            g = start_goal[e]; cur_goal_idx[e] = g; reach_goal_timer[e] = 0.0f; episode_length[e] = 0;
+            for (int k = 0; k < num_terms; ++k) episode_sums[(int64_t)k * num_envs + e] = 0.0f;
+        }
+        const int64_t g0 = g < 0 ? 0 : (g >= num_goal_slots ? num_goal_slots - 1 : g), g1 = g + 1 < 0 ? 0 : (g + 1 >= num_goal_slots ? num_goal_slots - 1 : g + 1);
+        for (int k = 0; k < 3; ++k) { cur_goals[e * 3 + k] = env_goals[(e * num_goal_slots + g0) * 3 + k]; next_goals[e * 3 + k] = env_goals[(e * num_goal_slots + g1) * 3 + k]; }
+        if (obst_state) {
+            float *st = obst_state + e * 12;
+            if (flags[e]) st[0] = (seesaw_order && cur_obst_idx[e] > seesaw_order[e]) ? -seesaw_rest : seesaw_rest;
+            if (any_reset[0]) { st[1] = 0.0f; st[5] = 0.0f; st[9] = 0.0f; }
+        }
+    }
+    return QA_OK;
+}
+
 int qo_rollout_act_hybrid(const float *logits, const float *mean, const float *std, const float *value, uint64_t seed, const int64_t *step_dev, int64_t step,
                           int32_t num_envs, int32_t env_id_offset, int32_t nd, int32_t nc_all, float *actions, float *st_actions, float *st_mu, float *st_sigma,
                           float *st_logp_d, float *st_logp_c, float *st_values, const float *action_history_in, float *action_history, int32_t hist_len,

@@ -739,6 +739,73 @@ __global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__rest
     st_values[e] = value[e];
 }
 
+constexpr int RS_TSC_PUSH = 22, RS_TSC_START = 23;
+
+/* the task-level env step's torch glue as kernels (include/qa_sim.h: qa_tsc_push / qa_tsc_start_pose / qa_tsc_reset_where); one thread per env */
+__global__ void __launch_bounds__(64) qa_tsc_push_kernel(float *__restrict__ root, int64_t n, int64_t *step_dev, int *ticket, int interval, float vmax, uint64_t seed, int env0) {
+    const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t s = *step_dev + 1;                    // every workgroup reads the old counter; the last one to arrive writes the new one
+    if (e < n && interval > 0 && s % interval == 0) {
+        const F4 u = rng4(seed, (uint32_t)(e + env0), s, RS_TSC_PUSH, 0);
+        root[e * 13 + 7] = (u.v[0] * 2.0f - 1.0f) * vmax;
+        root[e * 13 + 8] = (u.v[1] * 2.0f - 1.0f) * vmax;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) { *ticket = 0; *step_dev = s; __threadfence(); }
+    }
+}
+
+struct StartPoseArgs {
+    const uint8_t *flags; int64_t *cur_obst; const float *goals, *angs; int64_t n; int slots, nobst, gpo, randomize; float yaw0; uint64_t seed;
+    const int64_t *step_dev; int env0; float *xy, *yaw; int64_t *start_goal;
+};
+__global__ void __launch_bounds__(64) qa_tsc_start_pose_kernel(StartPoseArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (e >= a.n) return;
+    int64_t sg = 0;
+    float yaw = a.yaw0;
+    if (a.randomize) {
+        int64_t ob = a.cur_obst[e];
+        if (a.flags[e]) {
+            const F4 u = rng4(a.seed, (uint32_t)(e + a.env0), *a.step_dev, RS_TSC_START, 0);
+            int d = (int)(u.v[0] * (float)a.nobst);
+            ob = d >= a.nobst ? a.nobst - 1 : d;
+            a.cur_obst[e] = ob;
+        }
+        sg = ob * a.gpo;
+        yaw = a.angs[e * a.nobst + ob];
+    }
+    const int64_t g = sg < 0 ? 0 : (sg >= a.slots ? a.slots - 1 : sg);
+    a.xy[2 * e] = a.goals[(e * a.slots + g) * 3]; a.xy[2 * e + 1] = a.goals[(e * a.slots + g) * 3 + 1];
+    a.yaw[e] = yaw;
+    a.start_goal[e] = sg;
+}
+
+struct ResetWhereArgs {
+    const uint8_t *flags, *any_reset; const int64_t *start_goal; int64_t *cur_goal; float *timer, *sums; int terms; int64_t *ep_len; const float *goals; int slots;
+    float *cur_goals, *next_goals, *obst; float rest; const int64_t *cur_obst, *order; int64_t n;
+};
+__global__ void __launch_bounds__(64) qa_tsc_reset_where_kernel(ResetWhereArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (e >= a.n) return;
+    const bool f = a.flags[e] != 0;
+    int64_t g = a.cur_goal[e];
+    if (f) {
+        g = a.start_goal[e];
+        a.cur_goal[e] = g; a.timer[e] = 0.f; a.ep_len[e] = 0;
+        for (int k = 0; k < a.terms; ++k) a.sums[(int64_t)k * a.n + e] = 0.f;
+    }
+    const int64_t g0 = g < 0 ? 0 : (g >= a.slots ? a.slots - 1 : g), g1 = g + 1 < 0 ? 0 : (g + 1 >= a.slots ? a.slots - 1 : g + 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.cur_goals[e * 3 + k] = a.goals[(e * a.slots + g0) * 3 + k]; a.next_goals[e * 3 + k] = a.goals[(e * a.slots + g1) * 3 + k]; }
+    if (a.obst) {
+        float *st = a.obst + e * 12;                   // (3 obstacles, 4 floats): [position, velocity, ...]
+        if (f) st[0] = (a.order && a.cur_obst[e] > a.order[e]) ? -a.rest : a.rest;
+        if (a.any_reset[0]) { st[1] = 0.f; st[5] = 0.f; st[9] = 0.f; }
+    }
+}
+
 constexpr int RS_ACT_CHOICE = 21;
 struct HybridActArgs {
     const float *logits, *mean, *std, *value;
@@ -1371,6 +1438,45 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
                        (int)num_envs, (int)env_id_offset, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_tsc_push(float *root_states, int64_t num_envs, int64_t *step_dev, int32_t *ticket, int32_t push_interval, float max_push_vel_xy, uint64_t seed,
+                int32_t env_id_offset, void *stream) {
+    if (!root_states || !step_dev || !ticket || num_envs <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_tsc_push: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_tsc_push_kernel, dim3((unsigned)((num_envs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, root_states, num_envs, step_dev, (int *)ticket,
+                       (int)push_interval, max_push_vel_xy, seed, (int)env_id_offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_tsc_push: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_tsc_start_pose(const uint8_t *flags, int64_t *cur_obst_idx, const float *env_goals, const float *obst_angs, int64_t num_envs, int32_t num_goal_slots,
+                      int32_t num_obstacles, int32_t goals_per_obstacle, int32_t randomize_start, float frame_yaw0, uint64_t seed, const int64_t *step_dev,
+                      int32_t env_id_offset, float *start_xy, float *start_yaw, int64_t *start_goal, void *stream) {
+    if (!flags || !env_goals || !start_xy || !start_yaw || !start_goal || num_envs <= 0 || num_goal_slots <= 0 ||
+        (randomize_start && (!cur_obst_idx || !obst_angs || !step_dev || num_obstacles <= 0 || goals_per_obstacle <= 0))) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_tsc_start_pose: bad argument"); return QA_E_ARG; }
+    StartPoseArgs a{flags, cur_obst_idx, env_goals, obst_angs, num_envs, (int)num_goal_slots, (int)num_obstacles, (int)goals_per_obstacle, (int)(randomize_start != 0),
+                    frame_yaw0, seed, step_dev, (int)env_id_offset, start_xy, start_yaw, start_goal};
+    hipLaunchKernelGGL(qa_tsc_start_pose_kernel, dim3((unsigned)((num_envs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_tsc_start_pose: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_tsc_reset_where(const uint8_t *flags, const uint8_t *any_reset, const int64_t *start_goal, int64_t *cur_goal_idx, float *reach_goal_timer,
+                       float *episode_sums, int32_t num_terms, int64_t *episode_length, const float *env_goals, int32_t num_goal_slots, float *cur_goals,
+                       float *next_goals, float *obst_state, float seesaw_rest, const int64_t *cur_obst_idx, const int64_t *seesaw_order, int64_t num_envs,
+                       void *stream) {
+    if (!flags || !start_goal || !cur_goal_idx || !reach_goal_timer || !episode_sums || !episode_length || !env_goals || !cur_goals || !next_goals ||
+        num_envs <= 0 || num_terms <= 0 || num_goal_slots <= 0 || (obst_state && (!any_reset || (seesaw_order && !cur_obst_idx)))) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_tsc_reset_where: bad argument"); return QA_E_ARG; }
+    ResetWhereArgs a{flags, any_reset, start_goal, cur_goal_idx, reach_goal_timer, episode_sums, (int)num_terms, episode_length, env_goals, (int)num_goal_slots,
+                     cur_goals, next_goals, obst_state, seesaw_rest, cur_obst_idx, seesaw_order, num_envs};
+    hipLaunchKernelGGL(qa_tsc_reset_where_kernel, dim3((unsigned)((num_envs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_tsc_reset_where: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -278,9 +278,21 @@ class LeggedRobot:
         """:226-296"""
         bk, cfg = self.bk, self.cfg
         self.common_step_counter += 1
-        self._step_dev.add_(1)
-        if cfg.domain_rand.push_robots:
-            self._push_robots()        # before the goal step: its rewards read the pushed world velocity, as the reference's do (:643-644)
+        if self._glue_kernels():
+            # r4: the counter's increment and the push as ONE launch (qa_tsc_push; Philox draws keyed by the step instead of torch's generator)
+            lib = _capi.load_library()
+            if getattr(self, "_ticket", None) is None:
+                self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+            d = cfg.domain_rand
+            rc = lib.qa_tsc_push(self.root_states.data_ptr(), self.num_envs, self._step_dev.data_ptr(), self._ticket.data_ptr(),
+                                 int(d.push_interval) if d.push_robots else 0, float(d.max_push_vel_xy), int(self.sim.cfg.seed) + 104729, int(self.sim.cfg.env_id_offset),
+                                 torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"qa_tsc_push failed with code {rc}: {lib.qa_last_error().decode()}")
+        else:
+            self._step_dev.add_(1)
+            if cfg.domain_rand.push_robots:
+                self._push_robots()        # before the goal step: its rewards read the pushed world velocity, as the reference's do (:643-644)
         bk.post_physics_step(self.root_states, self.contact_forces, self.rigid_body_states, action_hl_history_buf, want_ids=False)
         self.extras["reach_goal"] = bk.reach_goal_cutoff.view(torch.bool)
         flags = bk.reset_buf
@@ -303,7 +315,19 @@ class LeggedRobot:
         bk, cfg = self.bk, self.cfg
         ob = cfg.obstacle
         n_goal = cfg.obstacle.num_goals
-        if ob.randomize_start:
+        glue = self._glue_kernels() and flags.is_cuda
+        if glue:
+            lib = _capi.load_library()
+            if getattr(self, "_start_goal", None) is None:
+                self._start_goal = torch.zeros(self.num_envs, dtype=torch.long, device=self.device)
+            rc = lib.qa_tsc_start_pose(flags.data_ptr(), self.cur_obst_idx.data_ptr(), self.env_goals.data_ptr(), self.obst_angs.data_ptr(), self.num_envs,
+                                       int(self.env_goals.shape[1]), int(self.obstacle_types.shape[1]), int(n_goal), int(bool(ob.randomize_start)),
+                                       float(self.obstacle.frame_ang[0]), int(self.sim.cfg.seed) + 104729, self._step_dev.data_ptr(), int(self.sim.cfg.env_id_offset),
+                                       self._start_xy.data_ptr(), self._start_yaw.data_ptr(), self._start_goal.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"qa_tsc_start_pose failed with code {rc}: {lib.qa_last_error().decode()}")
+            start_goal = self._start_goal
+        elif ob.randomize_start:
             draw = torch.randint(0, self.obstacle_types.shape[1], (self.num_envs,), device=self.device)
             self.cur_obst_idx.copy_(torch.where(flags != 0, draw, self.cur_obst_idx))
             start_goal = self.cur_obst_idx * n_goal
@@ -341,12 +365,30 @@ class LeggedRobot:
         self.extras["episode"] = {"rew_" + n: snap[i] for i, n in enumerate(_capi.TSC_REWARD_NAMES)}
         if cfg.env.send_timeouts:
             self.extras["time_outs"] = bk.time_out_buf.view(torch.bool)
-        bk.reset_where(flags, start_goal)
-        self._reset_articulated_obstacles(flags, any_reset)
+        if glue:
+            rc = lib.qa_tsc_reset_where(flags.data_ptr(), any_reset.data_ptr(), start_goal.data_ptr(), bk.cur_goal_idx.data_ptr(), bk.reach_goal_timer.data_ptr(),
+                                        bk.episode_sums_buf.data_ptr(), int(bk.episode_sums_buf.shape[0]), bk.episode_length_buf.data_ptr(), self.env_goals.data_ptr(),
+                                        int(self.env_goals.shape[1]), bk.cur_goals.data_ptr(), bk.next_goals.data_ptr(),
+                                        self.obst_state.data_ptr() if self.articulated else None, float(self.obstacle.seesaw_dof_pos) if self.articulated else 0.0,
+                                        self.cur_obst_idx.data_ptr(), self._seesaw_order.data_ptr() if (self.articulated and ob.randomize_start) else None,
+                                        self.num_envs, torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"qa_tsc_reset_where failed with code {rc}: {lib.qa_last_error().decode()}")
+        else:
+            bk.reset_where(flags, start_goal)
+            self._reset_articulated_obstacles(flags, any_reset)
         if not first:
             self.sim.simulate_if(None, any_reset)
         else:
             self.sim.simulate_if(None, torch.ones(1, dtype=torch.uint8, device=self.device))
+
+    def _glue_kernels(self):
+        """r4: the torch glue between the step's kernels (counter + push, start pose of the resetting envs, reset bookkeeping + obstacle reset) as
+        three launches of its own (qa_tsc_push / _start_pose / _reset_where) on the GPU; QA_TSC_GLUE=0 keeps the torch ops"""
+        if getattr(self, "_glue", None) is None:
+            import os
+            self._glue = bool(self._step_dev.is_cuda and os.environ.get("QA_TSC_GLUE", "1") != "0" and self.env_goals.is_contiguous() and self.obst_angs.is_contiguous())
+        return self._glue
 
     def _push_robots(self):
         """:905-915, on the steps where common_step_counter % push_interval == 0 -- decided on the device (no host branch: the launch

@@ -1,0 +1,105 @@
+"""qa_tsc_push / qa_tsc_start_pose / qa_tsc_reset_where (ABI 13): the torch glue of the task-level env step between its kernels
+(tsc/legged_gym/envs/base/legged_robot.py:905-915 push, :352-366 start pose, :367-376 / 396-404 / 812-823 reset bookkeeping) as three launches.
+CPU: the C twins against the torch expressions the env used (draws: distribution + determinism, everything else exact).  GPU: kernels == twins."""
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_lib import load_oracle
+
+
+def _case(n=500, seed=0, dev=None):
+    g = torch.Generator().manual_seed(seed)
+    t = dict(root=torch.randn(n, 13, generator=g), flags=(torch.rand(n, generator=g) < 0.3).to(torch.uint8), cur_obst=torch.randint(0, 6, (n,), generator=g),
+             goals=torch.randn(n, 26, 3, generator=g), angs=torch.randn(n, 6, generator=g), cur_goal=torch.randint(0, 26, (n,), generator=g),
+             timer=torch.rand(n, generator=g), sums=torch.randn(8, n, generator=g), ep_len=torch.randint(1, 500, (n,), generator=g),
+             obst=torch.randn(n, 3, 4, generator=g), order=torch.randint(0, 6, (n,), generator=g))
+    return {k: (v.to(dev) if dev else v) for k, v in t.items()}
+
+
+def _push(lib, pre, t, step, interval, dev=None):
+    root = t["root"].clone()
+    ctr = torch.tensor([step], dtype=torch.int64, device=dev); ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert getattr(lib, pre + "tsc_push")(root.data_ptr(), root.shape[0], ctr.data_ptr(), ticket.data_ptr(), interval, 0.5, 77, 10, None) == 0
+    return root, ctr, ticket
+
+
+def _start(lib, pre, t, step, randomize, dev=None):
+    n = t["flags"].shape[0]
+    cur = t["cur_obst"].clone(); xy = torch.zeros(n, 2, device=dev); yaw = torch.zeros(n, device=dev); sg = torch.zeros(n, dtype=torch.int64, device=dev)
+    ctr = torch.tensor([step], dtype=torch.int64, device=dev)
+    assert getattr(lib, pre + "tsc_start_pose")(t["flags"].data_ptr(), cur.data_ptr(), t["goals"].data_ptr(), t["angs"].data_ptr(), n, 26, 6, 4, int(randomize), 0.25, 77,
+                                                 ctr.data_ptr(), 10, xy.data_ptr(), yaw.data_ptr(), sg.data_ptr(), None) == 0
+    return cur, xy, yaw, sg
+
+
+def _where(lib, pre, t, sg, any_reset, with_obst=True, with_order=True, dev=None):
+    o = {k: t[k].clone() for k in ("cur_goal", "timer", "sums", "ep_len", "obst")}
+    n = t["flags"].shape[0]
+    cg, ng = torch.zeros(n, 3, device=dev), torch.zeros(n, 3, device=dev)
+    ar = torch.tensor([any_reset], dtype=torch.uint8, device=dev)
+    assert getattr(lib, pre + "tsc_reset_where")(t["flags"].data_ptr(), ar.data_ptr(), sg.data_ptr(), o["cur_goal"].data_ptr(), o["timer"].data_ptr(), o["sums"].data_ptr(), 8,
+                                                  o["ep_len"].data_ptr(), t["goals"].data_ptr(), 26, cg.data_ptr(), ng.data_ptr(), o["obst"].data_ptr() if with_obst else None, 0.17,
+                                                  t["cur_obst"].data_ptr(), t["order"].data_ptr() if with_order else None, n, None) == 0
+    o["cur_goals"], o["next_goals"] = cg, ng
+    return o
+
+
+def test_twins_match_the_torch_expressions():
+    lib = load_oracle()
+    t = _case()
+    n = 500
+    # push: only on the interval's steps, uniform in +-max, counter advanced, keyed by the step
+    root, ctr, _ = _push(lib, "qo_", t, 13, 7)
+    assert int(ctr) == 14 and not torch.equal(root[:, 7:9], t["root"][:, 7:9]) and torch.equal(root[:, :7], t["root"][:, :7]) and torch.equal(root[:, 9:], t["root"][:, 9:])
+    assert (root[:, 7:9].abs() <= 0.5).all() and abs(float(root[:, 7:9].mean())) < 0.03 and abs(float(root[:, 7:9].std()) - 0.5 / 3 ** 0.5) < 0.02
+    root2, ctr2, _ = _push(lib, "qo_", t, 14, 7)
+    assert int(ctr2) == 15 and torch.equal(root2, t["root"])
+    assert torch.equal(_push(lib, "qo_", t, 13, 7)[0], root) and not torch.equal(_push(lib, "qo_", t, 20, 7)[0], root)
+    assert torch.equal(_push(lib, "qo_", t, 13, 0)[0], t["root"])                    # push_robots off
+    # start pose
+    f = t["flags"].bool()
+    cur, xy, yaw, sg = _start(lib, "qo_", t, 5, True)
+    assert torch.equal(cur[~f], t["cur_obst"][~f]) and (cur >= 0).all() and (cur < 6).all()
+    assert torch.bincount(cur[f], minlength=6).min() > 0.5 * f.sum() / 6            # uniform over the obstacles
+    assert torch.equal(sg, cur * 4)
+    want_xy = t["goals"].gather(1, sg[:, None, None].expand(-1, 1, 3)).squeeze(1)[:, :2]
+    assert torch.equal(xy, want_xy) and torch.equal(yaw, t["angs"].gather(1, cur[:, None]).squeeze(1))
+    cur0, xy0, yaw0, sg0 = _start(lib, "qo_", t, 5, False)
+    assert torch.equal(cur0, t["cur_obst"]) and (sg0 == 0).all() and torch.equal(xy0, t["goals"][:, 0, :2]) and (yaw0 == 0.25).all()
+    # reset bookkeeping: TaskLevelBookkeeping.reset_where + _reset_articulated_obstacles
+    for any_reset in (1, 0):
+        o = _where(lib, "qo_", t, sg, any_reset)
+        cg = torch.where(f, sg, t["cur_goal"])
+        assert torch.equal(o["cur_goal"], cg)
+        assert torch.equal(o["timer"], t["timer"] * (~f)) and torch.equal(o["sums"], t["sums"] * (~f)) and torch.equal(o["ep_len"], t["ep_len"] * (~f))
+        gather = lambda idx: t["goals"].gather(1, idx.clamp(0, 25)[:, None, None].expand(-1, 1, 3)).squeeze(1)
+        assert torch.equal(o["cur_goals"], gather(cg)) and torch.equal(o["next_goals"], gather(cg + 1))
+        rest = torch.where(t["cur_obst"] > t["order"], torch.tensor(-0.17), torch.tensor(0.17))
+        assert torch.equal(o["obst"][:, 0, 0], torch.where(f, rest, t["obst"][:, 0, 0])) and torch.equal(o["obst"][:, 1:, 0], t["obst"][:, 1:, 0])
+        assert torch.equal(o["obst"][:, :, 1], t["obst"][:, :, 1] * (1 - any_reset)) and torch.equal(o["obst"][:, :, 2:], t["obst"][:, :, 2:])
+    o = _where(lib, "qo_", t, sg, 1, with_order=False)
+    assert (o["obst"][f][:, 0, 0] == np.float32(0.17)).all()
+    o = _where(lib, "qo_", t, sg, 1, with_obst=False)
+    assert torch.equal(o["obst"], t["obst"])
+
+
+@pytest.mark.gpu
+def test_kernels_match_twins():
+    from quadrupedal_agility_amd import _capi
+    lib, olib = _capi.load_library(), load_oracle()
+    for n in (64, 5000):
+        t, td = _case(n, seed=n), _case(n, seed=n, dev="cuda")
+        for step, interval in ((13, 7), (14, 7), (20, 0)):
+            a = _push(lib, "qa_", td, step, interval, dev="cuda"); b = _push(olib, "qo_", t, step, interval)
+            torch.cuda.synchronize()
+            assert torch.allclose(a[0].cpu(), b[0], rtol=0, atol=1e-7) and int(a[1]) == int(b[1]) and int(a[2]) == 0
+        for rnd in (True, False):
+            a = _start(lib, "qa_", td, 9, rnd, dev="cuda"); b = _start(olib, "qo_", t, 9, rnd)
+            torch.cuda.synchronize()
+            assert all(torch.equal(x.cpu(), y) for x, y in zip(a, b))
+        sg = b[3]
+        for any_reset in (1, 0):
+            a = _where(lib, "qa_", td, sg.cuda(), any_reset, dev="cuda"); b2 = _where(olib, "qo_", t, sg, any_reset)
+            torch.cuda.synchronize()
+            assert all(torch.equal(a[k].cpu(), b2[k]) for k in a)
