@@ -23,6 +23,9 @@ timeout 400 python bench.py --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/
 timeout 400 python bench.py --terrain trimesh --no_cpu_baseline 2> $O/bench_trimesh.err < /dev/null | grep '"metric"' > $O/bench_cfg2_trimesh.json
 ( export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 QA_FORCE_DATA_PARALLEL=1; timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_dp.err < /dev/null | grep '"metric"' > $O/bench_cfg2_dp_path_1gpu.json )
 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu.json
+# (r4) the data-parallel code path with TWO ranks sharing this one GPU (gloo through host memory): a bound on the path's own cost, not a scaling measurement
+QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --scaling strong --no_cpu_baseline 2> $O/bench_shared_strong.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_strong.json
+QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 2 --scaling weak --num_envs 2048 --no_cpu_baseline 2> $O/bench_shared_weak.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_weak.json
 timeout 400 python bench.py --tsc --steps 6 --warmup 3 2> $O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_8192.json
 timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024.json
 timeout 400 python bench.py --tsc --vision --num_envs 512 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_512.json
