@@ -267,8 +267,7 @@ class LeggedRobot:
         self.total_env_steps_counter += 1
         self.sim.physics_step(a, delay)
         reset_env_ids, terminal = self.post_physics_step(action_hl_history_buf)
-        if self.cfg.depth.use_camera:          # read by learn_vision only (tsc/rsl_rl/runners/on_policy_runner.py:319-322): two launches the teacher's rollout does not need
-            self.extras["delta_yaw_ok"] = torch.abs(self.bk.delta_yaw) < 0.6
+        self.extras["delta_yaw_ok"] = torch.abs(self.bk.delta_yaw) < 0.6
         if self.cfg.depth.use_camera and self.global_counter % self.cfg.depth.update_interval == 0:
             self.extras["depth"] = self.bk.depth_buffer[:, -2]            # :145-146
         else:
