@@ -225,7 +225,8 @@ class OnPolicyRunner:
                     rs["fin_vals"][t].copy_(rs["cur"]); rs["fin_masks"][t].copy_(done); rs["fin_reach"][t].copy_(infos["reach_goal"])
                     rs["cur"] *= (~done).to(rs["cur"].dtype)
             rs["obs_bbc"].copy_(env.get_observations_bbc())
-            rs["hist"].copy_(torch.where(done.view(-1, 1, 1), torch.stack([disc_obs] * self.disc_obs_len, dim=1), hist))
+            # one launch: the restart row broadcast over the history slots, written straight into the persistent buffer (`hist` is a fresh tensor)
+            torch.where(done.view(-1, 1, 1), disc_obs.unsqueeze(1), hist, out=rs["hist"])
         return ep_infos
 
     def _collect(self, hist_encoding, logging):

@@ -39,9 +39,11 @@ rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_kernel_stats.csv
 f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/gap_report.py "$f" 0.7 > $O/gap_report.txt 2>&1; [ -n "$f" ] && python $R/tools/step_sequence.py "$f" > $O/step_sequence.txt 2>&1
+[ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid > $O/rollout_step_sequence.txt 2>&1      # (r4) every launch of ONE env step of the recorded rollout
 grep '"metric"' /tmp/prof.log > $O/bench_under_rocprof.json
 rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 6 --warmup 3 < /dev/null > /tmp/prof2.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_tsc_kernel_stats.csv
+f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid > $O/tsc_env_step_sequence.txt 2>&1
 rm -rf /tmp/prof
 ls -la $O
