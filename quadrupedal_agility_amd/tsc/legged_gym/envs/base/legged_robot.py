@@ -256,7 +256,7 @@ class LeggedRobot:
         noise = None
         if self.cfg.domain_rand.randomize_action:
             lo, hi = self.cfg.domain_rand.action_noise
-            noise = torch.rand(self.num_envs, 5, device=self.device) * (hi - lo) + lo
+            noise = torch.empty(self.num_envs, 5, device=self.device).uniform_(lo, hi)      # one launch, the same draws as rand() * (hi - lo) + lo
         return self.bk.set_commands(actions, noise)
 
     def step(self, actions, action_hl_history_buf=None):
