@@ -13,6 +13,7 @@ PRE-REGISTERED STATISTICS (written in r4 BEFORE the 48-vs-48 seed runs were look
       Train/mean_reward_i (style reward) and Train/mean_episode_length;
   (4) reported, not judged: the means with their standard error (the r2 / r3 statistic), and the same at iterations 250 / 500 / 750.
   verdict "pass" = (1) and (2) "same" and (3) inside the bar on all three tags.
+  (5) added AFTER the data were seen and therefore reported, never judged: paired-by-seed statistics for the seeds both arms ran (see the code).
 """
 import json, math, statistics, sys
 
@@ -135,6 +136,28 @@ res["verdict"] = {"pre_registered": {"transition_time_same (Mann-Whitney p >= 0.
                   "means_at_horizon (r2 / r3 statistic, reported)": {t: ("pass" if final[t]["pass_on_means"] else "FAIL") + f" ({100 * final[t]['rel_diff']:+.1f} % +- {100 * final[t].get('rel_diff_standard_error', float('nan')):.1f} %)"
                                                                     for t in BAR if t in final},
                   "medians_at_horizon": {t: f"{100 * final[t]['median_rel_diff']:+.1f} %" for t in BAR if t in final}}
+# (5) POST HOC, reported and not judged (added in r4 AFTER the data were seen, because the data showed it): a seed fixes the initial weights and the
+# env's randomisation in BOTH arms, so per-seed outcomes are correlated between the arms (Spearman ~0.4-0.5 on 22 pairs) and an unpaired test on
+# different seed sets also measures which seeds each arm happened to get.  For the seeds present in both arms: rank correlation and Wilcoxon signed-rank.
+try:
+    from scipy.stats import spearmanr, wilcoxon
+    by_h = {r["seed"]: r["curves"] for r in hip}
+    by_c = {r["seed"]: r["curves"] for r in cpu}
+    both = sorted(set(by_h) & set(by_c))
+    if len(both) >= 6:
+        ph = [transition_time(by_h[s][tag], iters) for s in both]
+        pc = [transition_time(by_c[s][tag], iters) for s in both]
+        paired = {"seeds": both, "transition_time": {"hip": ph, "cpu_oracle": pc, "spearman_rho": float(spearmanr(ph, pc)[0]),
+                                                     "wilcoxon_signed_rank_p": float(wilcoxon([a - b for a, b in zip(ph, pc)]).pvalue) if any(a != b for a, b in zip(ph, pc)) else 1.0}}
+        for t in BAR:
+            a = [tail(by_h[s][t], iters) for s in both]; b = [tail(by_c[s][t], iters) for s in both]
+            dlt = [x - y for x, y in zip(a, b)]
+            paired[t] = {"spearman_rho": float(spearmanr(a, b)[0]), "wilcoxon_signed_rank_p": float(wilcoxon(dlt).pvalue),
+                         "mean_paired_difference_rel": statistics.mean(dlt) / (abs(statistics.mean(b)) + 1e-12),
+                         "median_paired_difference_rel": statistics.median(dlt) / (abs(statistics.median(b)) + 1e-12)}
+        res["paired_by_seed (post hoc, not judged)"] = paired
+except ImportError:
+    pass
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({"verdict": res["verdict"], "transition": {k: v for k, v in res["transition"].items() if k not in ("hip", "cpu_oracle")},
                   "final": {t: [round(final[t]["hip_mean"], 4), round(final[t]["cpu_oracle_mean"], 4)] for t in final}}, indent=1))
