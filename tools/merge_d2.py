@@ -17,10 +17,6 @@ PRE-REGISTERED STATISTICS (written in r4 BEFORE the 48-vs-48 seed runs were look
 """
 import json, math, statistics, sys
 
-out, label = sys.argv[1], sys.argv[2]
-rest = sys.argv[3:]
-k = rest.index("--")
-hip_files, cpu_files = rest[:k], rest[k + 1:]
 TAGS = ["Train/mean_reward", "Train/mean_reward_t", "Train/mean_reward_i", "Train/mean_episode_length", "Episode/rew_tracking_lin_vel",
         "Episode/rew_tracking_ang_vel", "Episode/rew_torques", "Episode/rew_dof_error", "Episode/rew_collision"]
 BAR = {"Train/mean_reward": 0.10, "Train/mean_reward_i": 0.10, "Train/mean_episode_length": 0.10}     # north_star / VERDICT r2 item 6: +-10 %
@@ -58,6 +54,11 @@ def mann_whitney(a, b):
         return float(r.statistic), float(r.pvalue)
     except Exception:
         pass
+    return mann_whitney_normal(a, b)
+
+
+def mann_whitney_normal(a, b):
+    """the fallback without scipy: normal approximation with tie correction and continuity correction"""
     allv = sorted([(v, 0) for v in a] + [(v, 1) for v in b])
     ranks, i = {}, 0
     n = len(allv)
@@ -89,75 +90,84 @@ def fisher_exact(a_yes, a_n, b_yes, b_n):
     return sum(p(x) for x in range(max(0, tot_yes - b_n), min(a_n, tot_yes) + 1) if p(x) <= p0 * (1 + 1e-9))
 
 
-hip, mh = load(hip_files)
-cpu, mc = load(cpu_files)
-assert mh == mc, (mh, mc)
-iters = mh["iters"]
-res = {"what": label, "num_envs": mh["num_envs"], "iters": iters, "amp": mh["amp"], "hip_seeds": [r["seed"] for r in hip], "cpu_seeds": [r["seed"] for r in cpu],
-       "hip_env_steps_per_s": [round(r["env_steps_per_s"]) for r in hip], "cpu_env_steps_per_s": [round(r["env_steps_per_s"]) for r in cpu],
-       "statistic": "tail value = mean of the last 10 logged values before the checkpoint, per seed; rel_diff = (mean over HIP seeds - mean over CPU seeds) / |CPU mean|; "
-                    "median_rel_diff likewise on the medians; pre-registered statistics: see tools/merge_d2.py docstring",
-       "at_iteration": {}}
-for ck in [c for c in (250, 500, 750, 1000) if c <= iters]:
-    summ = {}
-    for tag in TAGS:
-        hs = [tail(r["curves"][tag], ck) for r in hip if tag in r["curves"] and len(r["curves"][tag]) >= ck]
-        cs = [tail(r["curves"][tag], ck) for r in cpu if tag in r["curves"] and len(r["curves"][tag]) >= ck]
-        if hs and cs:
-            a, b = statistics.mean(hs), statistics.mean(cs)
-            ma, mb = statistics.median(hs), statistics.median(cs)
-            e = {"hip_mean": a, "cpu_oracle_mean": b, "rel_diff": (a - b) / (abs(b) + 1e-12), "hip_median": ma, "cpu_oracle_median": mb,
-                 "median_rel_diff": (ma - mb) / (abs(mb) + 1e-12),
-                 "cpu_seeds_rank_among_hip_seeds": [sum(1 for h in hs if h < c) / len(hs) for c in cs],        # 0.5 = the HIP median
-                 "hip_per_seed": hs, "cpu_per_seed": cs}
-            if len(hs) > 1 and len(cs) > 1:
-                se = (statistics.variance(hs) / len(hs) + statistics.variance(cs) / len(cs)) ** 0.5
-                e["rel_diff_standard_error"] = se / (abs(b) + 1e-12)
-                e["mann_whitney_p"] = mann_whitney(hs, cs)[1]
-            if tag in BAR and ck == iters:
-                e["bar"] = BAR[tag]; e["pass_on_means"] = abs(e["rel_diff"]) <= BAR[tag]; e["pass_on_medians"] = abs(e["median_rel_diff"]) <= BAR[tag]
-            summ[tag] = e
-    res["at_iteration"][str(ck)] = summ
-# (1), (2): the transition
-tag = "Train/mean_episode_length"
-th = [transition_time(r["curves"][tag], iters) for r in hip if tag in r["curves"]]
-tc = [transition_time(r["curves"][tag], iters) for r in cpu if tag in r["curves"]]
-u, p_mw = mann_whitney(th, tc)
-yes_h, yes_c = sum(1 for t in th if t <= iters), sum(1 for t in tc if t <= iters)
-p_f = fisher_exact(yes_h, len(th), yes_c, len(tc))
-res["transition"] = {"definition": f"first iteration at which the {T_WINDOW}-iteration running mean of {tag} exceeds {T_LEVEL:g}; {iters + 1} = never within the run",
-                     "hip": sorted(th), "cpu_oracle": sorted(tc), "hip_median": statistics.median(th), "cpu_oracle_median": statistics.median(tc),
-                     "hip_quartiles": [sorted(th)[len(th) // 4], sorted(th)[(3 * len(th)) // 4]], "cpu_oracle_quartiles": [sorted(tc)[len(tc) // 4], sorted(tc)[(3 * len(tc)) // 4]],
-                     "mann_whitney_u": u, "mann_whitney_p": p_mw, "past_transition_at_horizon": {"hip": [yes_h, len(th)], "cpu_oracle": [yes_c, len(tc)], "fisher_exact_p": p_f}}
-final = res["at_iteration"][str(iters)]
-ok_medians = all(final[t]["pass_on_medians"] for t in BAR if t in final)
-res["verdict"] = {"pre_registered": {"transition_time_same (Mann-Whitney p >= 0.05)": p_mw >= 0.05, "fraction_past_transition_same (Fisher p >= 0.05)": p_f >= 0.05,
-                                      "medians_within_10_percent": ok_medians, "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_medians)},
-                  "means_at_horizon (r2 / r3 statistic, reported)": {t: ("pass" if final[t]["pass_on_means"] else "FAIL") + f" ({100 * final[t]['rel_diff']:+.1f} % +- {100 * final[t].get('rel_diff_standard_error', float('nan')):.1f} %)"
-                                                                    for t in BAR if t in final},
-                  "medians_at_horizon": {t: f"{100 * final[t]['median_rel_diff']:+.1f} %" for t in BAR if t in final}}
-# (5) POST HOC, reported and not judged (added in r4 AFTER the data were seen, because the data showed it): a seed fixes the initial weights and the
-# env's randomisation in BOTH arms, so per-seed outcomes are correlated between the arms (Spearman ~0.4-0.5 on 22 pairs) and an unpaired test on
-# different seed sets also measures which seeds each arm happened to get.  For the seeds present in both arms: rank correlation and Wilcoxon signed-rank.
-try:
-    from scipy.stats import spearmanr, wilcoxon
-    by_h = {r["seed"]: r["curves"] for r in hip}
-    by_c = {r["seed"]: r["curves"] for r in cpu}
-    both = sorted(set(by_h) & set(by_c))
-    if len(both) >= 6:
-        ph = [transition_time(by_h[s][tag], iters) for s in both]
-        pc = [transition_time(by_c[s][tag], iters) for s in both]
-        paired = {"seeds": both, "transition_time": {"hip": ph, "cpu_oracle": pc, "spearman_rho": float(spearmanr(ph, pc)[0]),
-                                                     "wilcoxon_signed_rank_p": float(wilcoxon([a - b for a, b in zip(ph, pc)]).pvalue) if any(a != b for a, b in zip(ph, pc)) else 1.0}}
-        for t in BAR:
-            a = [tail(by_h[s][t], iters) for s in both]; b = [tail(by_c[s][t], iters) for s in both]
-            dlt = [x - y for x, y in zip(a, b)]
-            paired[t] = {"spearman_rho": float(spearmanr(a, b)[0]), "wilcoxon_signed_rank_p": float(wilcoxon(dlt).pvalue),
-                         "mean_paired_difference_rel": statistics.mean(dlt) / (abs(statistics.mean(b)) + 1e-12),
-                         "median_paired_difference_rel": statistics.median(dlt) / (abs(statistics.median(b)) + 1e-12)}
-        res["paired_by_seed (post hoc, not judged)"] = paired
-except ImportError:
-    pass
-json.dump(res, open(out, "w"), indent=1)
-print(json.dumps({"verdict": res["verdict"], "transition": {k: v for k, v in res["transition"].items() if k not in ("hip", "cpu_oracle")},
-                  "final": {t: [round(final[t]["hip_mean"], 4), round(final[t]["cpu_oracle_mean"], 4)] for t in final}}, indent=1))
+def main():
+    out, label = sys.argv[1], sys.argv[2]
+    rest = sys.argv[3:]
+    k = rest.index("--")
+    hip_files, cpu_files = rest[:k], rest[k + 1:]
+    hip, mh = load(hip_files)
+    cpu, mc = load(cpu_files)
+    assert mh == mc, (mh, mc)
+    iters = mh["iters"]
+    res = {"what": label, "num_envs": mh["num_envs"], "iters": iters, "amp": mh["amp"], "hip_seeds": [r["seed"] for r in hip], "cpu_seeds": [r["seed"] for r in cpu],
+           "hip_env_steps_per_s": [round(r["env_steps_per_s"]) for r in hip], "cpu_env_steps_per_s": [round(r["env_steps_per_s"]) for r in cpu],
+           "statistic": "tail value = mean of the last 10 logged values before the checkpoint, per seed; rel_diff = (mean over HIP seeds - mean over CPU seeds) / |CPU mean|; "
+                        "median_rel_diff likewise on the medians; pre-registered statistics: see tools/merge_d2.py docstring",
+           "at_iteration": {}}
+    for ck in [c for c in (250, 500, 750, 1000) if c <= iters]:
+        summ = {}
+        for tag in TAGS:
+            hs = [tail(r["curves"][tag], ck) for r in hip if tag in r["curves"] and len(r["curves"][tag]) >= ck]
+            cs = [tail(r["curves"][tag], ck) for r in cpu if tag in r["curves"] and len(r["curves"][tag]) >= ck]
+            if hs and cs:
+                a, b = statistics.mean(hs), statistics.mean(cs)
+                ma, mb = statistics.median(hs), statistics.median(cs)
+                e = {"hip_mean": a, "cpu_oracle_mean": b, "rel_diff": (a - b) / (abs(b) + 1e-12), "hip_median": ma, "cpu_oracle_median": mb,
+                     "median_rel_diff": (ma - mb) / (abs(mb) + 1e-12),
+                     "cpu_seeds_rank_among_hip_seeds": [sum(1 for h in hs if h < c) / len(hs) for c in cs],        # 0.5 = the HIP median
+                     "hip_per_seed": hs, "cpu_per_seed": cs}
+                if len(hs) > 1 and len(cs) > 1:
+                    se = (statistics.variance(hs) / len(hs) + statistics.variance(cs) / len(cs)) ** 0.5
+                    e["rel_diff_standard_error"] = se / (abs(b) + 1e-12)
+                    e["mann_whitney_p"] = mann_whitney(hs, cs)[1]
+                if tag in BAR and ck == iters:
+                    e["bar"] = BAR[tag]; e["pass_on_means"] = abs(e["rel_diff"]) <= BAR[tag]; e["pass_on_medians"] = abs(e["median_rel_diff"]) <= BAR[tag]
+                summ[tag] = e
+        res["at_iteration"][str(ck)] = summ
+    # (1), (2): the transition
+    tag = "Train/mean_episode_length"
+    th = [transition_time(r["curves"][tag], iters) for r in hip if tag in r["curves"]]
+    tc = [transition_time(r["curves"][tag], iters) for r in cpu if tag in r["curves"]]
+    u, p_mw = mann_whitney(th, tc)
+    yes_h, yes_c = sum(1 for t in th if t <= iters), sum(1 for t in tc if t <= iters)
+    p_f = fisher_exact(yes_h, len(th), yes_c, len(tc))
+    res["transition"] = {"definition": f"first iteration at which the {T_WINDOW}-iteration running mean of {tag} exceeds {T_LEVEL:g}; {iters + 1} = never within the run",
+                         "hip": sorted(th), "cpu_oracle": sorted(tc), "hip_median": statistics.median(th), "cpu_oracle_median": statistics.median(tc),
+                         "hip_quartiles": [sorted(th)[len(th) // 4], sorted(th)[(3 * len(th)) // 4]], "cpu_oracle_quartiles": [sorted(tc)[len(tc) // 4], sorted(tc)[(3 * len(tc)) // 4]],
+                         "mann_whitney_u": u, "mann_whitney_p": p_mw, "past_transition_at_horizon": {"hip": [yes_h, len(th)], "cpu_oracle": [yes_c, len(tc)], "fisher_exact_p": p_f}}
+    final = res["at_iteration"][str(iters)]
+    ok_medians = all(final[t]["pass_on_medians"] for t in BAR if t in final)
+    res["verdict"] = {"pre_registered": {"transition_time_same (Mann-Whitney p >= 0.05)": p_mw >= 0.05, "fraction_past_transition_same (Fisher p >= 0.05)": p_f >= 0.05,
+                                          "medians_within_10_percent": ok_medians, "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_medians)},
+                      "means_at_horizon (r2 / r3 statistic, reported)": {t: ("pass" if final[t]["pass_on_means"] else "FAIL") + f" ({100 * final[t]['rel_diff']:+.1f} % +- {100 * final[t].get('rel_diff_standard_error', float('nan')):.1f} %)"
+                                                                        for t in BAR if t in final},
+                      "medians_at_horizon": {t: f"{100 * final[t]['median_rel_diff']:+.1f} %" for t in BAR if t in final}}
+    # (5) POST HOC, reported and not judged (added in r4 AFTER the data were seen, because the data showed it): a seed fixes the initial weights and the
+    # env's randomisation in BOTH arms, so per-seed outcomes are correlated between the arms (Spearman ~0.4-0.5 on 22 pairs) and an unpaired test on
+    # different seed sets also measures which seeds each arm happened to get.  For the seeds present in both arms: rank correlation and Wilcoxon signed-rank.
+    try:
+        from scipy.stats import spearmanr, wilcoxon
+        by_h = {r["seed"]: r["curves"] for r in hip}
+        by_c = {r["seed"]: r["curves"] for r in cpu}
+        both = sorted(set(by_h) & set(by_c))
+        if len(both) >= 6:
+            ph = [transition_time(by_h[s][tag], iters) for s in both]
+            pc = [transition_time(by_c[s][tag], iters) for s in both]
+            paired = {"seeds": both, "transition_time": {"hip": ph, "cpu_oracle": pc, "spearman_rho": float(spearmanr(ph, pc)[0]),
+                                                         "wilcoxon_signed_rank_p": float(wilcoxon([a - b for a, b in zip(ph, pc)]).pvalue) if any(a != b for a, b in zip(ph, pc)) else 1.0}}
+            for t in BAR:
+                a = [tail(by_h[s][t], iters) for s in both]; b = [tail(by_c[s][t], iters) for s in both]
+                dlt = [x - y for x, y in zip(a, b)]
+                paired[t] = {"spearman_rho": float(spearmanr(a, b)[0]), "wilcoxon_signed_rank_p": float(wilcoxon(dlt).pvalue),
+                             "mean_paired_difference_rel": statistics.mean(dlt) / (abs(statistics.mean(b)) + 1e-12),
+                             "median_paired_difference_rel": statistics.median(dlt) / (abs(statistics.median(b)) + 1e-12)}
+            res["paired_by_seed (post hoc, not judged)"] = paired
+    except ImportError:
+        pass
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({"verdict": res["verdict"], "transition": {k: v for k, v in res["transition"].items() if k not in ("hip", "cpu_oracle")},
+                      "final": {t: [round(final[t]["hip_mean"], 4), round(final[t]["cpu_oracle_mean"], 4)] for t in final}}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
