@@ -25,7 +25,7 @@ timeout 400 python bench.py --terrain trimesh --no_cpu_baseline 2> $O/bench_trim
 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu.json
 # (r4) the data-parallel code path with TWO ranks sharing this one GPU (gloo through host memory): a bound on the path's own cost, not a scaling measurement
 QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --scaling strong --no_cpu_baseline 2> $O/bench_shared_strong.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_strong.json
-QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 2 --scaling weak --num_envs 2048 --no_cpu_baseline 2> $O/bench_shared_weak.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_weak.json
+QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 2 --scaling weak --num_envs 4096 --no_cpu_baseline 2> $O/bench_shared_weak.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_weak.json
 timeout 400 python bench.py --tsc --steps 6 --warmup 3 2> $O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_8192.json
 timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024.json
 timeout 400 python bench.py --tsc --vision --num_envs 512 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_512.json
