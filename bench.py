@@ -218,7 +218,7 @@ def main():
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_ms_alone, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
-                         "note": "not byte-bound: 4096 envs = 256 wavefronts = one per CU; by the SQ counters that wavefront spends 65 % of its time issuing instructions (21.6 k VALU) and 33 % parked on s_waitcnt with nothing else to run (profiles/r1_env_step_pmc.md, DESIGN.md 4.1); 16384 envs/GPU: 164.8 us per launch = 2.1x this rate (profiles/r3_final_env_kernel_timing.txt; 3 workgroups per CU since the self-collision rows took 10 KB of LDS)"},
+                         "note": "not byte-bound: 4096 envs = 256 wavefronts = one per CU; by the SQ counters that wavefront spends 67 % of its cycles issuing instructions (22.1 k VALU) and 31 % waiting with nothing else to run (profiles/r4_env_step_sq_counters.txt, DESIGN.md 4.1); traffic is the PMC figure of the lean-export kernel a training run launches (1.06x algorithmic; full exports 1.37x); 16384 envs/GPU: 163.7 us per launch = 2.1x this rate (profiles/r4_final_env_kernel_timing.txt; 3 workgroups per CU)"},
         }
         if mlp_ms is not None:
             pf = ROLLOUT_FLOPS_PER_SAMPLE * args.num_envs
