@@ -1251,14 +1251,17 @@ class PolicyChain:
         return self
 
     @classmethod
-    def describe_task_level(cls, actor_critic, estimator, use_estimator):
+    def describe_task_level(cls, actor_critic, estimator, use_estimator, part="all"):
         """The task-level teacher's networks of one env step (tsc/rsl_rl/algorithms/ppo.py:101-125 `act`: Estimator.forward on the first 57
         proprioception entries written over the privileged-explicit columns, Actor.forward -- scan encoder (last layer tanh), privileged
         encoder, trunk -- with the two heads `actor_d` / `actor_c`, and the critic on the TRUE 800-wide row; tsc/rsl_rl/modules/
         actor_critic.py:59-284) as one qa_mlp_forward chain: -> (gait logits (N, nd), parameter means (N, nd * nc), value (N, 1)).
         Privileged-encoder variant only (19 of 20 iterations; the history-encoder rollouts keep the module path).  None when the modules do
-        not fit the kernel (other activations, widths beyond the LDS buffers)."""
+        not fit the kernel (other activations, widths beyond the LDS buffers).
+        `part`: "all" (one launch, three outputs), "actor" (-> logits, means) or "critic" (-> value): the two halves as separate programs, for
+        SplitTeacherChain (few row tiles: the halves run side by side instead of one after the other)."""
         import torch.nn as nn
+        assert part in ("all", "actor", "critic")
         ac = actor_critic
         actor = ac.actor
         a, n_scan, n_exp, n_lat = actor.num_prop, actor.num_scan, actor.num_priv_explicit, actor.num_priv_latent
@@ -1322,7 +1325,15 @@ class PolicyChain:
                 src, scol, k = dst, 0, n
             return True
 
-        ok = chain(st["critic"], 0, 0, n_obs, ("out", 2), set()) and st["critic"][-1][0].out_features == 1      # first: it may use every scratch buffer
+        ok = st["critic"][-1][0].out_features == 1
+        if part != "actor":
+            ok = ok and chain(st["critic"], 0, 0, n_obs, ("out", 2 if part == "all" else 0), set())      # first: it may use every scratch buffer
+        if part == "critic":
+            if not ok or len(ops) > _capi.MLP_MAX_OPS:
+                return None
+            self = cls(ops, params, 1, out_widths=[1])
+            self.packed_floats = woff[0]
+            return self
         copy(0, 0, Z, 0, a)
         copy(0, scan0, 1, 0, n_scan)                        # a layer's source column must be 16-byte aligned: the scan starts at column 65
         ok = ok and chain(st["scan"], 1, 0, n_scan, ("buf", Z, a), {Z})
@@ -1339,7 +1350,7 @@ class PolicyChain:
         ok = ok and layer(3, 0, k, -1, 0, actor.actor_c.out_features, 0, 1, actor.actor_c.weight, actor.actor_c.bias)
         if not ok or len(ops) > _capi.MLP_MAX_OPS or k > cls.BUF_COLS[3]:
             return None
-        self = cls(ops, params, actor.actor_c.out_features, out_widths=[actor.actor_d.out_features, actor.actor_c.out_features, 1])
+        self = cls(ops, params, actor.actor_c.out_features, out_widths=[actor.actor_d.out_features, actor.actor_c.out_features] + ([1] if part == "all" else []))
         self.packed_floats = woff[0]
         return self
 
@@ -1381,3 +1392,35 @@ class PolicyChain:
         if rc != 0:
             raise RuntimeError(f"qa_mlp_forward failed with code {rc}: {lib.qa_last_error().decode()}")
         return tuple(out[0])
+
+
+class SplitTeacherChain:
+    """The task-level teacher's chain as TWO programs -- actor side (estimator, encoders, trunk, heads) and critic -- launched side by side, the
+    critic on a second stream.  A chain kernel's time is one 16-row tile's serial walk through its layers whatever the number of tiles, so with
+    few tiles (1024 envs = 64 workgroups on 256 CUs: the per-GPU share of BASELINE configs[3]) two half-depth launches next to each other take the
+    longer half's time instead of the sum.  Same ops per output as the one-launch chain: the outputs are bit-identical.  Capturable (the side
+    stream forks from and joins the calling stream inside forward)."""
+
+    def __init__(self, actor_chain, critic_chain):
+        self.actor, self.critic = actor_chain, critic_chain
+        self._side = None
+
+    @classmethod
+    def describe(cls, actor_critic, estimator, use_estimator):
+        a = PolicyChain.describe_task_level(actor_critic, estimator, use_estimator, part="actor")
+        c = PolicyChain.describe_task_level(actor_critic, estimator, use_estimator, part="critic")
+        return cls(a, c) if (a is not None and c is not None) else None
+
+    def pack(self):
+        self.actor.pack(); self.critic.pack()
+
+    def forward(self, obs):
+        cur = torch.cuda.current_stream(obs.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=obs.device)
+        self._side.wait_stream(cur)                 # the observation row and the packed weights are ready on `cur`
+        with torch.cuda.stream(self._side):
+            (value,) = self.critic.forward(obs)
+        logits, mean = self.actor.forward(obs)
+        cur.wait_stream(self._side)
+        return logits, mean, value

@@ -126,8 +126,11 @@ class OnPolicyRunner:
         if not self.use_fused_policy:
             return None
         if self._teacher_chain_obj is None:
-            from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain
-            self._teacher_chain_obj = PolicyChain.describe_task_level(self.actor_critic, self.estimator, self.alg.train_with_estimated_states) or False
+            from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain, SplitTeacherChain
+            # few row tiles (<= 2048 envs = 128 workgroups on 256 CUs): actor side and critic as two launches side by side (QA_TSC_SPLIT_CHAIN=0: one launch)
+            split = self.env.num_envs <= 2048 and os.environ.get("QA_TSC_SPLIT_CHAIN", "1") != "0"
+            ch = SplitTeacherChain.describe(self.actor_critic, self.estimator, self.alg.train_with_estimated_states) if split else None
+            self._teacher_chain_obj = ch or PolicyChain.describe_task_level(self.actor_critic, self.estimator, self.alg.train_with_estimated_states) or False
         return self._teacher_chain_obj or None
 
     def _style_chain(self):

@@ -285,3 +285,51 @@ def test_task_level_chain_on_the_gpu(rows):
     for g, w, r in zip(got, want, (rl, rm, rv)):
         np.testing.assert_allclose(g[:64].cpu().numpy(), w[:rows], rtol=2e-4, atol=5e-5)
         np.testing.assert_allclose(g.cpu().numpy(), r.cpu().numpy(), rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("use_estimator", [True, False])
+def test_task_level_chain_halves_equal_the_whole(use_estimator):
+    """describe_task_level(part="actor" / "critic") -- the two programs of fused.SplitTeacherChain: the same ops per output as the one-launch
+    chain (the twin's outputs are bit-identical), fewer ops each"""
+    ac, est, n_obs = tsc_modules(seed=5)
+    whole = PolicyChain.describe_task_level(ac, est, use_estimator)
+    actor = PolicyChain.describe_task_level(ac, est, use_estimator, part="actor")
+    critic = PolicyChain.describe_task_level(ac, est, use_estimator, part="critic")
+    assert actor.out_widths == [6, 18] and critic.out_widths == [1] and actor.n_ops + critic.n_ops == whole.n_ops
+    obs = torch.randn(37, n_obs)
+    logits, mean, value = run_oracle_outputs(whole, obs)
+    l2, m2 = run_oracle_outputs(actor, obs)
+    (v2,) = run_oracle_outputs(critic, obs)
+    assert np.array_equal(logits, l2) and np.array_equal(mean, m2) and np.array_equal(value, v2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 1024, 2048])
+def test_split_teacher_chain_equals_the_one_launch_chain(rows):
+    """fused.SplitTeacherChain (critic on a second stream beside the actor side): bit-identical outputs, eagerly and replayed from a hipGraph"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms.fused import SplitTeacherChain
+    ac, est, n_obs = tsc_modules(seed=4)
+    ac, est = ac.cuda(), est.cuda()
+    whole = PolicyChain.describe_task_level(ac, est, True); whole.pack()
+    split = SplitTeacherChain.describe(ac, est, True); split.pack()
+    obs = torch.randn(rows, n_obs, device="cuda")
+    want = [t.clone() for t in whole.forward(obs)]
+    got = [t.clone() for t in split.forward(obs)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
+    # recorded: new observations in the same buffer, replay, compare with the one-launch chain on them
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        split.forward(obs)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = split.forward(obs)
+    obs.copy_(torch.randn(rows, n_obs, device="cuda"))
+    g.replay()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in outs]
+    want = [t.clone() for t in whole.forward(obs)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
