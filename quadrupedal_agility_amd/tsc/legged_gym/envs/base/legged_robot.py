@@ -303,7 +303,8 @@ class LeggedRobot:
             bk.update_depth_buffer(self.root_states, self._step_dev)                 # :275, after the resets, before the observations
         bk.compute_observations(self.root_states, self.dof_pos, self.dof_vel, self.action_history_buf, self.rigid_body_states,
                                 self.mass_params_tensor, self.friction_coeffs_tensor, self.motor_strength, update_yaw=upd)
-        torch.where(flags.view(-1, 1) != 0, prev_disc, bk.obs_disc_buf, out=self._obs_disc_term)
+        # (the goal-step kernel writes the flags as 0 / 1 bytes: reinterpreting them as bool is free, `!= 0` is a launch)
+        torch.where(flags.view(torch.bool).view(-1, 1) if flags.dtype == torch.uint8 else flags.view(-1, 1) != 0, prev_disc, bk.obs_disc_buf, out=self._obs_disc_term)
         if self.sync_reset_ids:
             env_ids = flags.nonzero(as_tuple=False).flatten()               # host sync, like the reference
             return env_ids, prev_disc[env_ids]

@@ -199,7 +199,7 @@ class OnPolicyRunner:
             disc_obs = env.get_observations_disc()
             # history of discriminator observations: the terminal row for envs that reset, then restart (:219-234)
             hist = torch.cat([rs["hist"][:, 1:], env.obs_disc_term_buf.unsqueeze(1)], dim=1)
-            done = dones != 0
+            done = dones.view(torch.bool) if dones.dtype == torch.uint8 else dones != 0      # 0 / 1 bytes from the goal-step kernel
             if dchain is not None:
                 # Discriminator.predict_disc_reward (:71-118) + PPO.process_env_step (:139-147): prepare (normalise + clip) -> trunk + heads ->
                 # reward mapping, mixing, time-out bootstrap, reward / done rows of the storage and the episode sums, three launches
