@@ -26,7 +26,7 @@ def run(seed, iters, num_envs, mode, out_dir):
     cs = os.path.join(out_dir, f"checksums_{mode}_s{seed}.json")
     env = dict(os.environ, QA_PARITY_CHECKSUMS=cs)
     env["QA_PARITY_TABLES_IN_WARMUP"] = "1"        # both modes draw the discriminator's samples through the tables from the first update on
-    if mode == "eager":
+    if mode.startswith("eager"):
         env["QA_PARITY_EAGER_TABLES"] = "1"
     curves = os.path.join(out_dir, f"curves_{mode}_s{seed}.json")
     t0 = time.time()
@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--num_envs", type=int, default=1024)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--eager_twice_iters", type=int, default=0, help="also run the EAGER mode twice for this many iterations and report whether it repeats itself "
+                    "(is the eager path deterministic run to run? the recorded path is)")
     a = ap.parse_args()
     out_dir = os.path.dirname(os.path.abspath(a.out))
     os.makedirs(out_dir, exist_ok=True)
@@ -78,8 +80,22 @@ def main():
             for k in bad:
                 if isinstance(fr[k], float) and isinstance(fe.get(k), float):
                     worst = max(worst, abs(fr[k] - fe[k]) / (abs(fe[k]) + 1e-30))
+        # state (what the next iteration depends on) separately from read-outs (the update's returned mean losses: the recorded path accumulates
+        # them on the device, the eager path in Python floats -- a logged number, not state), and the size of the state difference over time
+        is_state = lambda k: not k.startswith("losses")
+        first_state, state_fields = None, []
+        rel_at = {}
+        for i in range(n):
+            fr, fe = flat(rec[i]), flat(eag[i])
+            bad = [k for k in fr if is_state(k) and fr[k] != fe.get(k)]
+            if bad and first_state is None:
+                first_state, state_fields = i + 1, bad[:12]
+            if i + 1 in (1, 2, 5, 10, 20, 50, 100, 200, 500, 1000, n):
+                rel_at[str(i + 1)] = {k: abs(fr[k] - fe[k]) / (abs(fe[k]) + 1e-30) for k in ("policy", "estimator", "disc", "norm", "obs", "rewards") if k in fr and k in fe}
         tail = lambda c, tag: sum(c["rows"][0]["curves"][tag][-10:]) / 10
         res["seeds"][str(seed)] = {"iterations_compared": n, "first_differing_iteration": first, "fields_differing_there": fields, "largest_relative_checksum_difference": worst,
+                                   "first_iteration_with_a_state_difference": first_state, "state_fields_differing_there": state_fields,
+                                   "relative_checksum_difference_at_iteration": rel_at,
                                    "identical_for_all_iterations": first is None and n == a.iters,
                                    "episode_length_at_horizon": {"recorded": tail(cur_r, "Train/mean_episode_length"), "eager": tail(cur_e, "Train/mean_episode_length")},
                                    "mean_reward_at_horizon": {"recorded": tail(cur_r, "Train/mean_reward"), "eager": tail(cur_e, "Train/mean_reward")},
@@ -91,6 +107,23 @@ def main():
                     os.remove(os.path.join(out_dir, f"{kind}_{mode}_s{seed}.json"))
                 except OSError:
                     pass
+    if a.eager_twice_iters > 0:
+        seed = a.seeds[0]
+        e1, _, _ = run(seed, a.eager_twice_iters, a.num_envs, "eager", out_dir)
+        e2, _, _ = run(seed, a.eager_twice_iters, a.num_envs, "eager_again", out_dir)
+        r1, _, _ = run(seed, a.eager_twice_iters, a.num_envs, "recorded", out_dir)
+        r2, _, _ = run(seed, a.eager_twice_iters, a.num_envs, "recorded_again", out_dir)
+        def first_diff(x, y, state_only):
+            for i in range(min(len(x), len(y))):
+                fx, fy = flat(x[i]), flat(y[i])
+                bad = [k for k in fx if fx[k] != fy.get(k) and (not state_only or not k.startswith("losses"))]
+                if bad:
+                    return {"iteration": i + 1, "fields": bad[:8]}
+            return None
+        res["run_to_run"] = {"seed": seed, "iters": a.eager_twice_iters,
+                             "eager_vs_eager_first_difference": first_diff(e1, e2, False), "recorded_vs_recorded_first_difference": first_diff(r1, r2, False),
+                             "recorded_vs_eager_first_state_difference": first_diff(r1, e1, True), "recorded_vs_eager_first_difference_any_field": first_diff(r1, e1, False)}
+        print(json.dumps(res["run_to_run"]), flush=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
 
