@@ -127,8 +127,10 @@ class OnPolicyRunner:
             return None
         if self._teacher_chain_obj is None:
             from quadrupedal_agility_amd.rsl_rl.algorithms.fused import PolicyChain, SplitTeacherChain
-            # few row tiles (<= 2048 envs = 128 workgroups on 256 CUs): actor side and critic as two launches side by side (QA_TSC_SPLIT_CHAIN=0: one launch)
-            split = self.env.num_envs <= 2048 and os.environ.get("QA_TSC_SPLIT_CHAIN", "1") != "0"
+            # QA_TSC_SPLIT_CHAIN=1 (opt-in), few row tiles (<= 2048 envs = 128 workgroups on 256 CUs): actor side and critic as two launches side by
+            # side.  Measured at 1024 envs (r4 GPU call 10): critic 55.5 us beside actor 48.6 us instead of 98 us in one launch, but the fork / join
+            # waits put 16 us of gaps around them: 9 us per env step, 31.97 vs 31.82 ms per iteration = noise.  Correct (bit-identical), not worth a default.
+            split = self.env.num_envs <= 2048 and os.environ.get("QA_TSC_SPLIT_CHAIN", "0") == "1"
             ch = SplitTeacherChain.describe(self.actor_critic, self.estimator, self.alg.train_with_estimated_states) if split else None
             self._teacher_chain_obj = ch or PolicyChain.describe_task_level(self.actor_critic, self.estimator, self.alg.train_with_estimated_states) or False
         return self._teacher_chain_obj or None
