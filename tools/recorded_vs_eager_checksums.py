@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--num_envs", type=int, default=1024)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--keep_rows_around", type=int, default=0, help="keep both modes' full checksum rows for the 6 iterations around this one (diagnostics)")
     ap.add_argument("--eager_twice_iters", type=int, default=0, help="also run the EAGER mode twice for this many iterations and report whether it repeats itself "
                     "(is the eager path deterministic run to run? the recorded path is)")
     a = ap.parse_args()
@@ -92,6 +93,9 @@ def main():
                 first_state, state_fields = i + 1, bad[:12]
             if i + 1 in (1, 2, 5, 10, 20, 50, 100, 200, 500, 1000, n):
                 rel_at[str(i + 1)] = {k: abs(fr[k] - fe[k]) / (abs(fe[k]) + 1e-30) for k in ("policy", "estimator", "disc", "norm", "obs", "rewards") if k in fr and k in fe}
+        if a.keep_rows_around > 0:
+            lo = max(0, (first_state or a.keep_rows_around) - 4)
+            res.setdefault("rows_around_first_state_difference", {})[str(seed)] = {"from_iteration": lo + 1, "recorded": [flat(r) for r in rec[lo:lo + 6]], "eager": [flat(r) for r in eag[lo:lo + 6]]}
         tail = lambda c, tag: sum(c["rows"][0]["curves"][tag][-10:]) / 10
         res["seeds"][str(seed)] = {"iterations_compared": n, "first_differing_iteration": first, "fields_differing_there": fields, "largest_relative_checksum_difference": worst,
                                    "first_iteration_with_a_state_difference": first_state, "state_fields_differing_there": state_fields,

@@ -67,6 +67,9 @@ def run(device, num_envs, iters, seed, amp=False):
                              prior=float(env.prior_parameters.double().sum()) if amp else 0.0, losses=[float(v) for v in r] if amp else [],
                              disc_each=[float(p.detach().double().sum()) for p in a.disc.parameters()] if amp else [],
                              obs=float(a.storage.observations.double().sum()), rewards=float(a.storage.rewards.double().sum()),
+                             policy_each=[float(p.detach().double().sum()) for p in a.actor_critic.parameters()],       # which tensor of the policy moves first
+                             lr_ac=float(a.lr_ac), std=[float(v) for v in a.actor_critic.std.detach().flatten().tolist()] if hasattr(a.actor_critic, "std") else [],
+                             ac_adam=[float(sum(st[k].double().sum() for st in a.optim_ac.state.values())) for k in ("exp_avg", "exp_avg_sq", "step")],
                              ))      # (the generator state is NOT read: get_rng_state() on a graph-registered generator may move its offset)
             if len(rows) % 50 == 0 or len(rows) >= iters:
                 json.dump(rows, open(os.environ["QA_PARITY_CHECKSUMS"], "w"))
