@@ -143,6 +143,8 @@ def main():
     # which leaves no place for per-kernel events; profiles/ holds the rocprofv3 per-kernel average of the same command)
     act = torch.zeros(args.num_envs, 12, device=dev)
     sim.global_step = env.common_step_counter
+    if hasattr(runner, "_lean_mask_for"):              # learn() restores the full exports when it returns (r5); time the kernel variant it launched
+        env.set_lean_exports(runner._lean_mask_for(env))
     reps, per = 5, 40
     spans = []
     for _ in range(reps):
@@ -200,7 +202,7 @@ def main():
 
     if rank == 0:
         achieved = ALG_BYTES_PER_ENV_STEP * args.num_envs / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_note = _stamped_traffic(g)
+        traffic, traffic_note = _stamped_traffic(g, args.num_envs)
         out = {
             "metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,17 +256,20 @@ def env_kernel_hash(g):
     return g._src_hash([os.path.join(g.CSRC, f) for f in ENV_KERNEL_SOURCES])[:16]
 
 
-def _stamped_traffic(g):
+def _stamped_traffic(g, num_envs, name="env_step_traffic.json"):
     """roofline.traffic: the HBM bytes per launch of the PMC passes (tools/final_measure.sh -> profiles/env_step_traffic.json), reported only
-    when that file was measured on the kernel sources this run built -- a figure from another version of the kernel is not a measurement of
-    this one.  Counter passes cannot run inside this process: rocprofv3 collects them per process, in passes of their own."""
-    prof = os.path.join(ROOT, "profiles", "env_step_traffic.json")
+    when that file was measured on the kernel sources this run built AND at this run's env count -- a figure from another version of the
+    kernel, or from another launch size, is not a measurement of this one.  Counter passes cannot run inside
+    this process: rocprofv3 collects them per process, in passes of their own."""
+    prof = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(prof))
     except Exception:
         return None, "no PMC pass on file"
+    if int(d.get("num_envs", -1)) != int(num_envs):
+        return None, f"profiles/{name} was measured at {d.get('num_envs')} envs per launch, this run launches {num_envs}: no traffic figure for this size"
     if d.get("kernel_source_hash") != env_kernel_hash(g):
-        return None, f"profiles/env_step_traffic.json was measured on kernel sources {d.get('kernel_source_hash', 'unstamped')}, this build is {env_kernel_hash(g)}: re-run tools/final_measure.sh"
+        return None, f"profiles/{name} was measured on kernel sources {d.get('kernel_source_hash', 'unstamped')}, this build is {env_kernel_hash(g)}: re-run tools/final_measure.sh"
     return d.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {d['kernel_source_hash']} (tools/final_measure.sh)"
 
 
@@ -413,7 +418,7 @@ def cpu_baseline_tsc(num_envs, budget_s, vision):
     from quadrupedal_agility_amd.tsc.legged_gym.utils.obstacle import Obstacle
     from tests.oracle_backend import OracleBackend
     from tests.oracle_lib import load_oracle
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     cfg = Go2AgilityCfg()
     cfg.env.num_envs, cfg.seed = num_envs, 1
     d = cfg.domain_rand
@@ -441,7 +446,7 @@ def cpu_baseline(num_envs, budget_s):
     import numpy as np
     import torch
     from tests.oracle_lib import OracleSim, go2_cfg
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     q = go2_cfg(num_envs, seed=1)
     o = OracleSim(q)
     o.reset_all()
@@ -466,24 +471,61 @@ def cpu_baseline(num_envs, budget_s):
     except OSError:
         pass
     del o
-    # ---- whole iterations on the CPU: oracle physics + torch-CPU policy / GAE / PPO (BASELINE config 2's settings).  In a child
-    # process with its own thread budget and a hard time limit: the baseline is a report, it must never cost the bench line.
-    import subprocess
+    # ---- whole iterations on the CPU: oracle physics + torch-CPU policy / GAE / PPO (BASELINE config 2's settings).  In child
+    # processes with their own thread budget and hard time limits: the baseline is a report, it must never cost the bench line and it
+    # must never come back as an error record: a 512-env probe (1 warm-up + 1 iteration, seconds) runs first; the
+    # full-size leg runs only if the probe says it fits its limit, and otherwise the probe's own rate is reported, labelled as such.
     threads = min(cores, 64)
-    env_vars = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), QA_CPU_ITER_ENVS=str(num_envs))
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu_iteration_child"], env=env_vars, capture_output=True, text=True, timeout=150)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        out["iteration"] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-300:]}
-    except subprocess.TimeoutExpired:
-        out["iteration"] = {"error": f"torch-CPU iteration leg did not finish 1 warm-up + 2 iterations of {num_envs} envs within 150 s on {threads} threads"}
+    probe = _cpu_iteration_leg(512, 1, threads, 90)
+    full = None
+    if "iteration_s" in probe:
+        est = probe["iteration_s"] * (num_envs / 512.0) * 3 + probe.get("startup_s", 10.0)      # 1 warm-up + 2 timed iterations
+        if num_envs <= 512:
+            full = probe
+        elif est <= 100.0:
+            full = _cpu_iteration_leg(num_envs, 2, threads, 150)
+    if full is not None and "iteration_s" in full:
+        out["iteration"] = full
+    elif "iteration_s" in probe:
+        out["iteration"] = dict(probe, extrapolated=True, iteration_s=probe["iteration_s"] * num_envs / 512.0,
+                                rollout_s=probe["rollout_s"] * num_envs / 512.0, learner_s=probe["learner_s"] * num_envs / 512.0,
+                                note=f"EXTRAPOLATED from a 512-env iteration on this box (env-steps/s taken as size-independent, times scaled by {num_envs}/512): "
+                                     f"the {num_envs}-env leg would not fit its 150 s limit on {threads} threads here" +
+                                     ("" if full is None else f" (it was tried: {full.get('why', 'no result')})"))
+    else:
+        out["iteration"] = {"value": None, "unit": "env-steps/s", "note": "the torch-CPU iteration leg produced no figure on this box, not even at 512 envs: " + probe.get("why", "?")}
     return out
+
+
+def _usable_cores():
+    """cores this process may run on (affinity mask / cpuset), not the machine's count"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def _cpu_iteration_leg(num_envs, its, threads, limit_s):
+    import subprocess
+    env_vars = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), QA_CPU_ITER_ENVS=str(num_envs), QA_CPU_ITER_ITS=str(its))
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu_iteration_child"], env=env_vars, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"why": f"1 warm-up + {its} iterations of {num_envs} envs did not finish within {limit_s} s on {threads} threads"}
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        return {"why": (r.stderr or "no output")[-300:]}
+    d = json.loads(line[-1])
+    d["startup_s"] = max(0.0, (time.perf_counter() - t0) - d["iteration_s"] * (its + 1))
+    return d
 
 
 def cpu_iteration_child():
     """1 warm-up + 2 timed PPO iterations of BASELINE config 2 on the host: oracle physics (OpenMP) + torch-CPU learner"""
     import torch
     num_envs = int(os.environ.get("QA_CPU_ITER_ENVS", "4096"))
+    its = int(os.environ.get("QA_CPU_ITER_ITS", "2"))
     threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
     torch.set_num_threads(threads)
     from quadrupedal_agility_amd.legged_gym.envs import task_registry
@@ -498,7 +540,7 @@ def cpu_iteration_child():
     env, _ = task_registry.make_env("go2_locomotion", args=cli, env_cfg=cfg, backend=OracleBackend(make_qa_config(cfg, seed=1)))
     runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=cli, train_cfg=tcfg, log_root=None)
     runner.learn(1, init_at_random_ep_len=True)
-    its, coll, lrn = 2, [], []
+    coll, lrn = [], []
     t0 = time.perf_counter()
     for _ in range(its):
         runner.learn(1)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 13
+#define QA_ABI_VERSION 14
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -417,7 +417,10 @@ int qa_hybrid_ppo_loss(const float *logits, const float *mean, const float *std,
  * (the `_mlp` blocks of bbc/rsl_rl/modules/actor_critic.py:92-139, estimator.py:12-33) that is not a GEMM:
  *   grad_in[r][c] = grad_out[r][c] * (out[r][c] > 0 ? 1 : out[r][c] + alpha),   grad_bias[c] = sum_r grad_in[r][c]
  * `out` is the layer's ELU OUTPUT (rows, cols) row-major; grad_in may not alias grad_out.  `scratch` holds at least
- * qa_elu_backward_bias_scratch_bytes(rows, cols) bytes. */
+ * qa_elu_backward_bias_scratch_bytes(rows, cols) bytes.
+ * grad_bias == NULL (ABI 14): the column sums are left IN PARTS -- on return `scratch` holds ceil(rows / 64) rows of `cols` floats, row b =
+ * the column sums of grad_in's rows [64 b, 64 b + 64) -- for a consumer that adds them in row order itself (qa_clip_adam_step_reduce,
+ * qa_grad_reduce); the finishing launch is not made. */
 int64_t qa_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols);
 int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
                          float alpha, void *scratch, int64_t scratch_bytes, void *stream);
@@ -539,6 +542,25 @@ int qa_clip_adam_step_hostgrads(float *const *params, const float *const *grads_
                                 float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
                                 const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
                                 float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream);
+/* r5 (ABI 14): the same step for gradients that are still IN PARTS.  The weight gradient of a Linear layer leaves its split-K product as S
+ * slabs (gail.py:328-413's backward through `torch.mm`; here fused.weight_grad's batched product) and its bias gradient leaves
+ * qa_elu_backward_bias as one row of column sums per 64-row block: tensor t with red_parts_host[t] > 0 is
+ *     grad[t][i] = sum_z red_src_host[t][z * red_stride_host[t] + i],  z = 0 .. parts - 1 in order (bit-reproducible)
+ * and the sums-of-squares pass of the step adds the parts, WRITES the result to grads_host[t] (so whatever reads `.grad` after the step sees
+ * the finished gradient) and squares it: the ~19 fixed-order finish launches of a PPO minibatch step (qa_colsum_finish, qa_slab_reduce) are
+ * not made.  red_parts_host[t] == 0: the gradient is already final.  All three red_* arrays are HOST arrays of num_tensors entries
+ * (<= QA_ADAM_MAX_INLINE); max_norm must be > 0 (the parts are added by the clipping pass).  Chunks of a tensor whose parts exceed 16 must
+ * be at most 32 elements long (the eight thread rows of a workgroup share the parts): the caller's chunk table gives small tensors -- the
+ * biases -- 32-element chunks. */
+int qa_clip_adam_step_reduce(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                             float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                             const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                             float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
+                             const float *const *red_src_host, const int64_t *red_stride_host, const int32_t *red_parts_host, void *stream);
+/* The parts of up to QA_ADAM_MAX_INLINE gradients added in ONE launch without an optimiser step (the data-parallel step packs finished
+ * gradients into its all-reduce bucket; tests): dst_host[t][i] = sum_z src_host[t][z stride_host[t] + i], i < numel_host[t]. */
+int qa_grad_reduce(float *const *dst_host, const float *const *src_host, const int64_t *stride_host, const int32_t *parts_host,
+                   const int32_t *numel_host, int32_t num_tensors, void *stream);
 
 /* Two small losses of the PPO step with their gradient in the same pass (a (rows, cols) contiguous, b (rows, cols) with row
  * stride b_stride, fp32 device pointers; grad_a (rows, cols); out[1]):

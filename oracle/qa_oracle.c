@@ -1423,14 +1423,14 @@ int64_t qo_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols) { return 
 int qo_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
                          float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
     (void)scratch; (void)scratch_bytes; (void)stream;
-    if (!grad_out || !out || !grad_in || !grad_bias || rows <= 0 || cols <= 0) return QA_E_ARG;
+    if (!grad_out || !out || !grad_in || rows <= 0 || cols <= 0) return QA_E_ARG;
     for (int c = 0; c < cols; ++c) {
         double acc = 0;
         for (int64_t r = 0; r < rows; ++r) {
             float y = out[r * cols + c], g = grad_out[r * cols + c] * (y > 0.0f ? 1.0f : y + alpha);
             grad_in[r * cols + c] = g; acc += g;
         }
-        grad_bias[c] = (float)acc;
+        if (grad_bias) grad_bias[c] = (float)acc;           /* NULL (r5): the caller adds the parts itself; this twin keeps none */
     }
     return QA_OK;
 }
@@ -1898,6 +1898,38 @@ int qo_clip_adam_step_hostgrads(float *const *params, const float *const *grads_
                                 const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
                                 float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
     if (num_tensors > QA_ADAM_MAX_INLINE) return QA_E_ARG;          /* on the host both forms read the same array */
+    return qo_clip_adam_step(params, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay, lr,
+                             beta1, beta2, eps, max_norm, scratch, scratch_floats, stream);
+}
+
+/* r5: gradients still in parts (split-K slabs of a weight gradient, row-block column sums of a bias gradient) added in order, then the step */
+int qo_grad_reduce(float *const *dst, const float *const *src, const int64_t *stride, const int32_t *parts, const int32_t *numel, int32_t num_tensors, void *stream) {
+    (void)stream;
+    if (!dst || !src || !stride || !parts || !numel || num_tensors <= 0 || num_tensors > QA_ADAM_MAX_INLINE) return QA_E_ARG;
+    for (int t = 0; t < num_tensors; ++t) {
+        if (!dst[t] || !src[t] || stride[t] <= 0 || parts[t] <= 0 || numel[t] <= 0) return QA_E_ARG;
+        for (int32_t i = 0; i < numel[t]; ++i) {
+            double acc = 0;
+            for (int32_t z = 0; z < parts[t]; ++z) acc += src[t][(int64_t)z * stride[t] + i];
+            dst[t][i] = (float)acc;
+        }
+    }
+    return QA_OK;
+}
+int qo_clip_adam_step_reduce(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                             float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                             const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                             float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
+                             const float *const *red_src, const int64_t *red_stride, const int32_t *red_parts, void *stream) {
+    if (!red_src || !red_stride || !red_parts || num_tensors > QA_ADAM_MAX_INLINE || !(max_norm > 0.f)) return QA_E_ARG;
+    for (int t = 0; t < num_tensors; ++t) {
+        if (red_parts[t] <= 0) continue;
+        int64_t n = 0;
+        for (int c = 0; c < num_chunks; ++c) if (chunk_tensor[c] == t && chunk_start[c] + chunk_len[c] > n) n = chunk_start[c] + chunk_len[c];
+        float *dst[1] = {(float *)grads_host[t]}; const float *src[1] = {red_src[t]}; int32_t numel[1] = {(int32_t)n};
+        int rc = qo_grad_reduce(dst, src, &red_stride[t], &red_parts[t], numel, 1, stream);
+        if (rc != QA_OK) return rc;
+    }
     return qo_clip_adam_step(params, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay, lr,
                              beta1, beta2, eps, max_norm, scratch, scratch_floats, stream);
 }

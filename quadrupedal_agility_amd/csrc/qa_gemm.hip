@@ -465,8 +465,7 @@ static __device__ __forceinline__ void dma_offsets(uint32_t (&off)[BT / 64], int
             off[p] = (uint32_t)min(idx0 + row, count - 1) * (uint32_t)ld + (uint32_t)(4 * chunk);
         } else {
             const int f = 256 * j + 4 * lane, k = f / BT, pos = f - k * BT;
-            const int idx = pos ^ (((k >> 2) & 1) << 4);
-            off[p] = (uint32_t)k * (uint32_t)ld + (uint32_t)min(idx0 + idx, count - 4);
+            off[p] = (uint32_t)k * (uint32_t)ld + (uint32_t)min(idx0 + pos, count - 4);      // r5: laid down as it lies (see dma_frags)
         }
     }
 }
@@ -475,15 +474,120 @@ static __device__ __forceinline__ void dma_issue(const float *__restrict__ P, co
 #pragma unroll
     for (int p = 0; p < BT / 64; ++p) glds16(P + (off[p] + tile_off), stage + 256 * (wave + 4 * p));
 }
+// The T = BT / 32 fragments of a wave's half of an operand tile (w0 = first local index of the half), f[tile][MFMA step s].
+// KC image: tile i covers the 16 consecutive indices w0 + 16 i + li, one ds_read_b128 along k per tile (k = 4 kq + s).
+// MC image [16 k][BT idx] (r5): the image is index-contiguous, so a 16-byte read along the INDEX serves four TILES at once if tile c of a
+// group of four is made of the indices w0 + 64 g + 4 li + c (a permutation of the output's rows / columns that the epilogue undoes for
+// free -- it only renames which accumulator an output lives in).  Four ds_read_b128 per k-tile and group instead of sixteen ds_read_b32:
+// r4's counter pass showed the index-contiguous products' wavefronts living 40 % longer on exactly those round trips.  With a row pitch
+// of BT floats (a multiple of 64) the 16 lanes of every b128 service group ({0-3, 12-15, 20-27}, ...) fall on 16 different bank quads
+// without a swizzle.  A half of 6 or 2 tiles ends in a group of two: indices w0 + 64 g + 2 li + c, ds_read_b64.
 template <int BT, bool MC>
-static __device__ __forceinline__ void dma_frag(float (&f)[4], const float *__restrict__ S, int i0, int li, int kq) {
+static __device__ __forceinline__ void dma_frags(float (&f)[BT / 32][4], const float *__restrict__ S, int w0, int li, int kq) {
+    constexpr int T = BT / 32;
     if (!MC) {
-        const f4 v = *(const f4 *)(S + (i0 + li) * 16 + ((kq ^ kc_swz(li)) << 2));
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    } else {
-        const int pos = (i0 + li) ^ ((kq & 1) << 4);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f[s] = S[(kq * 4 + s) * BT + pos];
+        for (int i = 0; i < T; ++i) {
+            const f4 v = *(const f4 *)(S + (w0 + 16 * i + li) * 16 + ((kq ^ kc_swz(li)) << 2));
+            f[i][0] = v.x; f[i][1] = v.y; f[i][2] = v.z; f[i][3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float *row = S + (kq * 4 + s) * BT + w0;
+#pragma unroll
+            for (int g = 0; g < T / 4; ++g) {
+                const f4 v = *(const f4 *)(row + 64 * g + 4 * li);
+                f[4 * g][s] = v.x; f[4 * g + 1][s] = v.y; f[4 * g + 2][s] = v.z; f[4 * g + 3][s] = v.w;
+            }
+            if (T % 4 == 2) {
+                const f2 v = *(const f2 *)(row + 64 * (T / 4) + 2 * li);
+                f[T - 2][s] = v.x; f[T - 1][s] = v.y;
+            }
+        }
+    }
+}
+// where the outputs of the DMA kernel's accumulators live.  The lane holds, per B tile j, 4 T values on the A side: T chunks of four
+// CONSECUTIVE a.  chunk q, element e  ->  (A tile, D row r) and the chunk's first a (relative to the wave's half).
+template <int T, bool MC>
+struct DmaAMap {
+    static __device__ __forceinline__ int tile(int q, int e) { return !MC ? q : (q < 4 * (T / 4) ? 4 * (q / 4) + e : T - 2 + (e & 1)); }
+    static __device__ __forceinline__ int row(int q, int e) { return !MC ? e : (q < 4 * (T / 4) ? (q & 3) : 2 * (q - 4 * (T / 4)) + (e >> 1)); }
+    static __device__ __forceinline__ int a0(int q, int kq) {
+        return !MC ? 16 * q + 4 * kq : (q < 4 * (T / 4) ? 64 * (q / 4) + 16 * kq + 4 * (q & 3) : 64 * (T / 4) + 8 * kq + 4 * (q - 4 * (T / 4)));
+    }
+};
+template <int T, bool MC>
+static __device__ __forceinline__ int dma_b_of(int j, int li) {       // the b (relative to the wave's half) of D column li of B tile j
+    return !MC ? 16 * j + li : (j < 4 * (T / 4) ? 64 * (j / 4) + 4 * li + (j & 3) : 64 * (T / 4) + 2 * li + (j - 4 * (T / 4)));
+}
+template <int BA, int BB, bool A_MC, bool B_MC, int EPI, bool ONES>
+static __device__ __forceinline__ void dma_epilogue(const GemmArgs &g, const f4 (&acc)[BA / 32][BB / 32], const f4 (&oacc)[BB / 32], int a_base, int b_base,
+                                                    int at, int z, int wa, int wb, int li, int kq, bool ones_wave) {
+    constexpr int TA = BA / 32, TB = BB / 32;
+    typedef DmaAMap<TA, A_MC> AM;
+    float *out = g.out + (int64_t)z * g.out_split_stride;
+#pragma unroll
+    for (int q = 0; q < TA; ++q) {
+        const int a = a_base + wa * (BA / 2) + AM::a0(q, kq);
+        if (a >= g.a_count) continue;
+        const bool full = g.o_vec == 4 && a + 3 < g.a_count;
+        f4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == 1 && g.bias) {
+            if (full) bias = *(const f4 *)(g.bias + a);
+            else {
+                bias.x = g.bias[a];
+                if (a + 1 < g.a_count) bias.y = g.bias[a + 1];
+                if (a + 2 < g.a_count) bias.z = g.bias[a + 2];
+                if (a + 3 < g.a_count) bias.w = g.bias[a + 3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int b = b_base + wb * (BB / 2) + dma_b_of<TB, B_MC>(j, li);
+            if (b >= g.b_count) continue;
+            f4 v = {acc[AM::tile(q, 0)][j][AM::row(q, 0)], acc[AM::tile(q, 1)][j][AM::row(q, 1)], acc[AM::tile(q, 2)][j][AM::row(q, 2)], acc[AM::tile(q, 3)][j][AM::row(q, 3)]};
+            if (EPI == 1) {
+                v += bias;
+                if (g.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : g.alpha * (expf(v[r]) - 1.f);
+                } else if (g.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+            }
+            if (EPI == 2 && g.yprev && g.act != 0) {
+                const float *yp = g.yprev + (int64_t)b * g.ldy + a;
+                f4 y = {1.f, 1.f, 1.f, 1.f};
+                if (full) y = *(const f4 *)yp;
+                else {
+                    y.x = yp[0];
+                    if (a + 1 < g.a_count) y.y = yp[1];
+                    if (a + 2 < g.a_count) y.z = yp[2];
+                    if (a + 3 < g.a_count) y.w = yp[3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (g.act == 1) ? (y[r] > 0.f ? 1.f : y[r] + g.alpha) : (y[r] > 0.f ? 1.f : 0.f);
+            }
+            float *o = out + (int64_t)b * g.ldo + a;
+            if (full) *(f4 *)o = v;
+            else {
+                o[0] = v.x;
+                if (a + 1 < g.a_count) o[1] = v.y;
+                if (a + 2 < g.a_count) o[2] = v.z;
+                if (a + 3 < g.a_count) o[3] = v.w;
+            }
+        }
+    }
+    if (ONES) {
+        if (ones_wave && kq == 0) {       // D row 0 of the ones product: this workgroup's share of sum_k Bop(b, k)
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const int b = b_base + wb * (BB / 2) + dma_b_of<TB, B_MC>(j, li);
+                if (b < g.b_count) g.ones_out[((int64_t)z * g.na + at) * g.ones_split_stride + b] = oacc[j].x;
+            }
+        }
     }
 }
 
@@ -547,10 +651,8 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_dma_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         const float *As = lds + stage * STAGE, *Bs = As + GEMM_BK * BA;
         float af[TA][4], bf[TB][4];
-#pragma unroll
-        for (int i = 0; i < TA; ++i) dma_frag<BA, A_MC>(af[i], As, wa * (BA / 2) + i * 16, li, kq);
-#pragma unroll
-        for (int j = 0; j < TB; ++j) dma_frag<BB, B_MC>(bf[j], Bs, wb * (BB / 2) + j * 16, li, kq);
+        dma_frags<BA, A_MC>(af, As, wa * (BA / 2), li, kq);
+        dma_frags<BB, B_MC>(bf, Bs, wb * (BB / 2), li, kq);
         issue(t + 2, stage == 0 ? 2 : stage - 1);       // (t + 2) % 3
         __builtin_amdgcn_sched_barrier(0);
         const bool do_ones = ones_wave && (t % g.na) == at;
@@ -570,7 +672,7 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_dma_kernel(GemmArgs g) {
         stage = stage == 2 ? 0 : stage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the two dummy tiles: no DMA may outlive the workgroup's LDS allocation
-    gemm_epilogue<BA, BB, EPI, ONES>(g, acc, oacc, a_base, b_base, at, z, wa, wb, li, kq, ones_wave);
+    dma_epilogue<BA, BB, A_MC, B_MC, EPI, ONES>(g, acc, oacc, a_base, b_base, at, z, wa, wb, li, kq, ones_wave);
 }
 
 // gw[i] = sum over the nsplit_w slabs (in order) of slabs[z * stride_w + i], i < n_w;  gb[i] = sum over the nsplit_b rows of
@@ -657,8 +759,11 @@ static void tile_dims(int cfg, int *ba, int *bb) {
     *bb = (cfg == 0 || cfg == 3 || cfg == 4) ? 128 : 64;
 }
 // may this product run on qa_gemm_dma_kernel?  (16-byte operands; for k-contiguous operands the reduction in whole 16-wide tiles per split)
-static bool dma_ok(const GemmArgs &g) {
-    return g.a_vec == 4 && g.b_vec == 4 && g.a_count >= 4 && g.b_count >= 4 && g.kred % GEMM_BK == 0 && g.k_per_split % GEMM_BK == 0 && g.kred >= GEMM_BK;
+// An index-contiguous (MC) operand is fetched in 16-byte chunks ALONG its index and the last chunk is clamped to count - 4: its index count
+// has to be a multiple of 4 (this used to be implied by how each caller computes a_vec / b_vec; now it is checked here).
+static bool dma_ok(const GemmArgs &g, bool a_mc, bool b_mc) {
+    return g.a_vec == 4 && g.b_vec == 4 && g.a_count >= 4 && g.b_count >= 4 && g.kred % GEMM_BK == 0 && g.k_per_split % GEMM_BK == 0 && g.kred >= GEMM_BK &&
+           (!a_mc || g.a_count % 4 == 0) && (!b_mc || g.b_count % 4 == 0);
 }
 template <bool A_MC, bool B_MC, int EPI, bool ONES>
 static void gemm_launch_dma(int cfg, GemmArgs &g, hipStream_t st) {
@@ -701,7 +806,7 @@ static void gemm_launch_conv(int cfg, GemmArgs &g, hipStream_t st) {
 }
 template <bool A_MC, bool B_MC, int EPI, bool ONES>
 static void gemm_launch(int cfg, GemmArgs &g, hipStream_t st) {
-    if (cfg >= 10 && dma_ok(g)) { gemm_launch_dma<A_MC, B_MC, EPI, ONES>(cfg, g, st); return; }
+    if (cfg >= 10 && dma_ok(g, A_MC, B_MC)) { gemm_launch_dma<A_MC, B_MC, EPI, ONES>(cfg, g, st); return; }
     if (cfg >= 10) cfg = cfg == 10 || cfg == 11 ? 0 : (cfg == 12 ? 1 : (cfg == 14 ? 3 : 2));      // not DMA-able: the register-staged kernel's nearest tile
     if (g.a_vec == 4 && g.b_vec == 4) gemm_launch_v<A_MC, B_MC, 4, 4, EPI, ONES>(cfg, g, st);
     else if (g.a_vec == 4) gemm_launch_v<A_MC, B_MC, 4, 1, EPI, ONES>(cfg, g, st);
@@ -725,8 +830,7 @@ static int g_force_cfg = -1;      // tools/gemm_bench.py: time one tile configur
 
 // QA_GEMM_DMA: 1 = products that qualify (dma_ok) take the LDS-DMA kernel with the tile chosen below, 0 = register-staged kernel only
 static int dma_mode() {
-    static int m = -1;
-    if (m < 0) { const char *e = getenv("QA_GEMM_DMA"); m = e ? atoi(e) : QA_GEMM_DMA_DEFAULT; }
+    static const int m = [] { const char *e = getenv("QA_GEMM_DMA"); return e ? atoi(e) : QA_GEMM_DMA_DEFAULT; }();      // initialised once, thread-safe (C++11 magic static)
     return m;
 }
 // LDS-DMA tile for an (a_count x b_count) output computed in nsplit slices: the largest tile that still gives every CU two workgroups
@@ -760,7 +864,7 @@ int qa_linear_forward(const float *x, int64_t ldx, const float *weight, int64_t 
     g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
     g.b_vec = (aligned16(x) && ldx % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
     g.o_vec = (aligned16(y) && ldy % 4 == 0 && (!bias || aligned16(bias))) ? 4 : 1;
-    gemm_launch<false, false, 1, false>(g_force_cfg >= 0 ? g_force_cfg : ((dma_mode() && dma_ok(g)) ? pick_cfg_dma(out_features, rows, 1) : pick_cfg(out_features, rows, 1)),
+    gemm_launch<false, false, 1, false>(g_force_cfg >= 0 ? g_force_cfg : ((dma_mode() && dma_ok(g, false, false)) ? pick_cfg_dma(out_features, rows, 1) : pick_cfg(out_features, rows, 1)),
                                          g, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_forward: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
@@ -782,7 +886,7 @@ int qa_linear_backward_input(const float *grad_out, int64_t ldg, const float *we
     g.a_vec = (aligned16(weight) && ldw % 4 == 0 && in_features % 4 == 0) ? 4 : 1;
     g.b_vec = (aligned16(grad_out) && ldg % 4 == 0 && out_features % 4 == 0) ? 4 : 1;
     g.o_vec = (aligned16(grad_in) && ldgi % 4 == 0 && (!g.yprev || (aligned16(y_prev) && ldyp % 4 == 0))) ? 4 : 1;
-    gemm_launch<true, false, 2, false>(g_force_cfg >= 0 ? g_force_cfg : ((dma_mode() && dma_ok(g)) ? pick_cfg_dma(in_features, rows, 1) : pick_cfg(in_features, rows, 1)),
+    gemm_launch<true, false, 2, false>(g_force_cfg >= 0 ? g_force_cfg : ((dma_mode() && dma_ok(g, true, false)) ? pick_cfg_dma(in_features, rows, 1) : pick_cfg(in_features, rows, 1)),
                                         g, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_input: %s", hipGetErrorString(e)); return QA_E_DEVICE; }

@@ -531,16 +531,72 @@ struct AdamArgs {
     float beta1, beta2, eps, max_norm;
     int inline_grads;                     // 1: the gradient pointers travel in the kernel arguments (gin), not in a device table
     const float *gin[QA_ADAM_MAX_INLINE];
+    // r5 (qa_clip_adam_step_reduce): tensor t's gradient is still in PARTS -- red_parts[t] > 0 slabs red_src[t] + z red_stride[t], z < parts, to be
+    // added in order: the split-K slabs of a weight gradient, the per-row-block column sums of a bias gradient.  The first pass of the step
+    // (the sums of squares) adds them, writes the gradient where autograd put its tensor, and squares it -- the fixed-order finish kernels
+    // (qa_colsum_finish x 12, qa_slab_reduce x 7 per PPO minibatch step, ~5 us each) are launches this step no longer makes.
+    int has_reduce;
+    const float *red_src[QA_ADAM_MAX_INLINE];
+    int64_t red_stride[QA_ADAM_MAX_INLINE];
+    int32_t red_parts[QA_ADAM_MAX_INLINE];
 };
 __device__ __forceinline__ const float *adam_grad(const AdamArgs &a, int t) { return a.inline_grads ? a.gin[t] : a.grads[t]; }
 
+// one chunk of a gradient that is still in parts: element i = sum_z src[z stride + i], z ascending (bit-reproducible), written to g and
+// returned squared-and-summed per thread.  Few parts (split-K slabs, <= QA_REDUCE_WIDE): a thread owns elements tid, tid + 256, ...; many
+// parts (column partials of 24,576 / 64 = 384 row blocks): the chunk is <= 32 elements wide (the host's chunk table guarantees it for
+// every tensor that can carry such parts) and the 8 thread rows of 32 share the parts like qa_colsum_finish_kernel does.
+constexpr int QA_REDUCE_WIDE = 16;
+__device__ __forceinline__ float adam_reduce_chunk(const float *__restrict__ src, int64_t stride, int parts, float *__restrict__ g, int n, float *s_q) {
+    float acc = 0.f;
+    if (parts <= QA_REDUCE_WIDE) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            float v[QA_REDUCE_WIDE];
+#pragma unroll
+            for (int z = 0; z < QA_REDUCE_WIDE; ++z) v[z] = z < parts ? src[(int64_t)z * stride + i] : 0.f;      // all loads in flight, then the ordered sum
+            float s = v[0];
+#pragma unroll
+            for (int z = 1; z < QA_REDUCE_WIDE; ++z) if (z < parts) s += v[z];
+            g[i] = s;
+            acc = fmaf(s, s, acc);
+        }
+    } else {
+        const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (c < n) {
+            int b = q;
+            for (; b + 24 < parts; b += 32) {
+                a0 += src[(int64_t)b * stride + c]; a1 += src[(int64_t)(b + 8) * stride + c];
+                a2 += src[(int64_t)(b + 16) * stride + c]; a3 += src[(int64_t)(b + 24) * stride + c];
+            }
+            for (; b < parts; b += 8) a0 += src[(int64_t)b * stride + c];
+        }
+        s_q[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (q == 0 && c < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += s_q[threadIdx.x + 32 * k];
+            g[c] = t;
+            acc = t * t;
+        }
+        __syncthreads();
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) qa_adam_sumsq_kernel(AdamArgs a) {
     __shared__ float s_w[4];
-    const int c = blockIdx.x;
-    const float *g = adam_grad(a, a.chunk_tensor[c]) + a.chunk_start[c];
+    __shared__ float s_q[256];
+    const int c = blockIdx.x, t = a.chunk_tensor[c];
+    const float *g = adam_grad(a, t) + a.chunk_start[c];
     const int n = a.chunk_len[c];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) { const float v = g[i]; acc = fmaf(v, v, acc); }
+    if (a.has_reduce && a.red_parts[t] > 0) {
+        acc = adam_reduce_chunk(a.red_src[t] + a.chunk_start[c], a.red_stride[t], a.red_parts[t], const_cast<float *>(g), n, s_q);
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) { const float v = g[i]; acc = fmaf(v, v, acc); }
+    }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -1265,7 +1321,9 @@ int64_t qa_elu_backward_bias_scratch_bytes(int64_t rows, int32_t cols) {
 
 int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in, float *grad_bias, int64_t rows, int32_t cols,
                          float alpha, void *scratch, int64_t scratch_bytes, void *stream) {
-    if (!grad_out || !out || !grad_in || !grad_bias || !scratch || rows <= 0 || cols <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: bad argument"); return QA_E_ARG; }
+    // grad_bias == NULL (r5): the column sums stay in parts -- scratch holds ceil(rows / 64) rows of `cols` partial sums, to be added in row
+    // order by whoever consumes the bias gradient (qa_clip_adam_step_reduce / qa_grad_reduce); the finish launch is not made
+    if (!grad_out || !out || !grad_in || !scratch || rows <= 0 || cols <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: bad argument"); return QA_E_ARG; }
     if (scratch_bytes < qa_elu_backward_bias_scratch_bytes(rows, cols)) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: scratch too small"); return QA_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)((rows + ELU_ROWS - 1) / ELU_ROWS);
@@ -1274,7 +1332,7 @@ int qa_elu_backward_bias(const float *grad_out, const float *out, float *grad_in
     else if (cols > 64) hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<128>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
     else if (cols > 32) hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<64>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
     else hipLaunchKernelGGL(qa_elu_bwd_bias_kernel<32>, dim3(nb), dim3(256), 0, st, grad_out, out, grad_in, partial, rows, (int)cols, alpha);
-    hipLaunchKernelGGL(qa_colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float *)partial, nb, (int)cols, grad_bias);
+    if (grad_bias) hipLaunchKernelGGL(qa_colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float *)partial, nb, (int)cols, grad_bias);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_elu_backward_bias: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
@@ -1340,13 +1398,24 @@ int qa_normalizer_apply(const float *x, float *y, int64_t rows, int32_t dim, con
 static int clip_adam_launch(float *const *params, const float *const *grads_dev, const float *const *grads_host, float *const *exp_avg,
                             float *const *exp_avg_sq, float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
                             const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1, float beta2, float eps,
-                            float max_norm, float *scratch, int64_t scratch_floats, void *stream, const char *who) {
+                            float max_norm, float *scratch, int64_t scratch_floats, void *stream, const char *who,
+                            const float *const *red_src = nullptr, const int64_t *red_stride = nullptr, const int32_t *red_parts = nullptr) {
     if (!params || (!grads_dev && !grads_host) || !exp_avg || !exp_avg_sq || !steps || !chunk_tensor || !chunk_start || !chunk_len || !weight_decay || !lr ||
         !scratch || num_tensors <= 0 || num_chunks <= 0 || scratch_floats < 4 + (int64_t)num_chunks || (grads_host && num_tensors > QA_ADAM_MAX_INLINE)) {
         snprintf(g_lerr, sizeof(g_lerr), "%s: bad argument", who); return QA_E_ARG; }
     AdamArgs a{params, grads_dev, exp_avg, exp_avg_sq, steps, chunk_tensor, chunk_start, chunk_len, weight_decay, lr, scratch, num_chunks, num_tensors,
-               beta1, beta2, eps, max_norm, grads_host ? 1 : 0, {}};
+               beta1, beta2, eps, max_norm, grads_host ? 1 : 0, {}, 0, {}, {}, {}};
     if (grads_host) for (int t = 0; t < num_tensors; ++t) a.gin[t] = grads_host[t];
+    if (red_src) {
+        if (!grads_host || !(max_norm > 0.f) || !red_parts || !red_stride) {
+            snprintf(g_lerr, sizeof(g_lerr), "%s: gradients in parts need the host pointer form and a clipping step (max_norm > 0): the parts are added by the sums-of-squares pass", who);
+            return QA_E_ARG; }
+        for (int t = 0; t < num_tensors; ++t) {
+            if (red_parts[t] < 0 || (red_parts[t] > 0 && (!red_src[t] || red_stride[t] <= 0))) { snprintf(g_lerr, sizeof(g_lerr), "%s: bad parts record of tensor %d", who, t); return QA_E_ARG; }
+            a.red_src[t] = red_src[t]; a.red_stride[t] = red_stride[t]; a.red_parts[t] = red_parts[t];
+            if (red_parts[t] > 0) a.has_reduce = 1;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (!(max_norm > 0.f) && scratch_floats >= 5 + (int64_t)num_chunks) {
         // no clipping and room for the arrival counter (scratch[4 + num_chunks], zero at the first call: the kernel leaves it at zero)
@@ -1375,6 +1444,51 @@ int qa_clip_adam_step_hostgrads(float *const *params, const float *const *grads_
                                 float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats, void *stream) {
     return clip_adam_launch(params, nullptr, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay,
                             lr, beta1, beta2, eps, max_norm, scratch, scratch_floats, stream, "qa_clip_adam_step_hostgrads");
+}
+
+int qa_clip_adam_step_reduce(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                             float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                             const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                             float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
+                             const float *const *red_src_host, const int64_t *red_stride_host, const int32_t *red_parts_host, void *stream) {
+    if (!red_src_host || !red_stride_host || !red_parts_host) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step_reduce: bad argument"); return QA_E_ARG; }
+    return clip_adam_launch(params, nullptr, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay,
+                            lr, beta1, beta2, eps, max_norm, scratch, scratch_floats, stream, "qa_clip_adam_step_reduce", red_src_host, red_stride_host, red_parts_host);
+}
+
+// dst[t][i] = sum_z src[t][z stride[t] + i], z < parts[t] ascending, for a handful of tensors in ONE launch: the gradients-in-parts of a step
+// whose optimiser is not qa_clip_adam_step_reduce (the data-parallel step packs its gradients into a bucket first)
+struct ReduceArgs { float *dst[QA_ADAM_MAX_INLINE]; const float *src[QA_ADAM_MAX_INLINE]; int64_t stride[QA_ADAM_MAX_INLINE]; int32_t parts[QA_ADAM_MAX_INLINE];
+                    int32_t numel[QA_ADAM_MAX_INLINE]; int32_t first_block[QA_ADAM_MAX_INLINE + 1]; int32_t n; };
+__global__ void __launch_bounds__(256) qa_grad_reduce_kernel(ReduceArgs a) {
+    __shared__ float s_q[256];
+    int t = 0;
+    while (t + 1 < a.n && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+    const int wide = a.parts[t] > QA_REDUCE_WIDE;
+    const int per = wide ? 32 : ADAM_CHUNK;
+    const int s0 = ((int)blockIdx.x - a.first_block[t]) * per;
+    const int n = min(per, a.numel[t] - s0);
+    if (n > 0) (void)adam_reduce_chunk(a.src[t] + s0, a.stride[t], a.parts[t], a.dst[t] + s0, n, s_q);
+}
+int qa_grad_reduce(float *const *dst_host, const float *const *src_host, const int64_t *stride_host, const int32_t *parts_host, const int32_t *numel_host,
+                   int32_t num_tensors, void *stream) {
+    if (!dst_host || !src_host || !stride_host || !parts_host || !numel_host || num_tensors <= 0 || num_tensors > QA_ADAM_MAX_INLINE) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_grad_reduce: bad argument"); return QA_E_ARG; }
+    ReduceArgs a = {};
+    a.n = num_tensors;
+    int blocks = 0;
+    for (int t = 0; t < num_tensors; ++t) {
+        if (!dst_host[t] || !src_host[t] || stride_host[t] <= 0 || parts_host[t] <= 0 || numel_host[t] <= 0) { snprintf(g_lerr, sizeof(g_lerr), "qa_grad_reduce: bad record %d", t); return QA_E_ARG; }
+        a.dst[t] = dst_host[t]; a.src[t] = src_host[t]; a.stride[t] = stride_host[t]; a.parts[t] = parts_host[t]; a.numel[t] = numel_host[t];
+        a.first_block[t] = blocks;
+        const int per = parts_host[t] > QA_REDUCE_WIDE ? 32 : ADAM_CHUNK;
+        blocks += (numel_host[t] + per - 1) / per;
+    }
+    a.first_block[num_tensors] = blocks;
+    hipLaunchKernelGGL(qa_grad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_grad_reduce: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
 }
 
 int64_t qa_pair_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * ((rows + PAIR_BLOCK - 1) / PAIR_BLOCK); }

@@ -35,6 +35,7 @@
 #define QA_LIMIT_MARGIN 0.2f     // rad: beyond 30.1 rad/s x 5 ms = 0.15 rad a stop cannot bind within one substep
 #define QA_LIMIT_DEPEN 1.0f      // rad/s
 #define QA_CFM 1e-6f
+#define QA_OPEN_BIAS 1e30f      // bias of a row whose contact is open: the residual stays positive, the impulse stays 0
 
 struct PhysParams {
     float dt, gz, contact_offset, max_depen, ground_friction;
@@ -388,6 +389,155 @@ QA_DEV void row_load(float *priv, int base, Row &r) {
     r.dinv = lr(priv, base + 18); r.bias = lr(priv, base + 19);
 }
 
+// ---------------------------------------------------------------------------------------------
+// r5: the constraint rows and the Gauss-Seidel sweeps in PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).
+// Why (tools/valu_rate.hip, profiles/r5_valu_issue_rate.txt): at 4096 envs the kernel is ONE wavefront per CU, and a wavefront alone
+// on a SIMD issues one VALU instruction per ~4.5 cycles whether the next one depends on it or not and whether it is v_fma_f32 or
+// v_pk_fma_f32 -- so the time is the instruction count and a packed instruction carries two FMAs in one issue slot.  A row is
+//     j = (jh0 jh1 | jh2 jh3 | jh4 jh5 | jl0 jl1 | jl2 bias),   m = (bj0 bj1 | bj2 bj3 | bj4 bj5 | lj0 lj1 | lj2 0)
+// against the state x = (ub0 ub1 | ub2 ub3 | ub4 ub5 | w0 w1 | w2 1): residual = sum of both halves of sum_i j_i x_i (5 packed ops + 2),
+// update x_i += m_i dl (5 packed ops) -- 15 instructions per row instead of 25.  The SLP vectoriser is still off for this file (its
+// ad-hoc packing costs more moves than it saves, __graft_entry__.py); here the data is laid out in pairs from the start.
+// -DQA_PGS_SCALAR builds the round-4 scalar rows and sweeps instead (A/B measurements; same mathematics, different rounding order).
+#ifndef QA_PGS_SCALAR
+#define QA_PGS_PACKED 1
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+QA_DEV f2 f2s(float s) { return f2{s, s}; }
+QA_DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+QA_DEV float hsum(f2 a) { return a.x + a.y; }
+struct PRow { f2 j[5]; f2 m[5]; float dinv, lam; };
+// what the rows of a substep are built from, in pairs: G2[k][p] = (G[k][2p], G[k][2p+1]); Bc[p][c] = (Binv[2p][c], Binv[2p+1][c]);
+// L01[k] = (Linv[0][k], Linv[1][k]), L2[k] = Linv[2][k]
+struct PSolve { f2 G2[3][3]; f2 Bc[3][6]; f2 L01[3]; float L2[3]; };
+QA_DEV void psolve_make(PSolve &S, const float *G, const float *Linv, const float *Binv) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) S.G2[k][q] = f2{G[k * 6 + 2 * q], G[k * 6 + 2 * q + 1]};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) S.Bc[q][c] = f2{Binv[SIDX(2 * q, c)], Binv[SIDX(2 * q + 1, c)]};
+    // Linv packed: 00 01 02 11 12 22
+    S.L01[0] = f2{Linv[0], Linv[1]}; S.L01[1] = f2{Linv[1], Linv[3]}; S.L01[2] = f2{Linv[2], Linv[4]};
+    S.L2[0] = Linv[2]; S.L2[1] = Linv[4]; S.L2[2] = Linv[5];
+}
+// bj = Binv jh, two accumulators per output pair (one wave per SIMD: short chains)
+QA_DEV void pbinv_mul(const PSolve &S, const f2 *jh, f2 *bj) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        f2 a = S.Bc[q][0] * f2s(jh[0].x), b = S.Bc[q][1] * f2s(jh[0].y);
+        a = pfma(S.Bc[q][2], f2s(jh[1].x), a); b = pfma(S.Bc[q][3], f2s(jh[1].y), b);
+        a = pfma(S.Bc[q][4], f2s(jh[2].x), a); b = pfma(S.Bc[q][5], f2s(jh[2].y), b);
+        bj[q] = a + b;
+    }
+}
+QA_DEV void prow_finish(PRow &r, const PSolve &S, const float *jb, const float *jl, float bias) {
+    f2 jh[3], bj[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        jh[q] = pfma(S.G2[2][q], f2s(jl[2]), pfma(S.G2[1][q], f2s(jl[1]), pfma(S.G2[0][q], f2s(jl[0]), f2{jb[2 * q], jb[2 * q + 1]})));
+    pbinv_mul(S, jh, bj);
+    const f2 lj01 = pfma(S.L01[2], f2s(jl[2]), pfma(S.L01[1], f2s(jl[1]), S.L01[0] * f2s(jl[0])));
+    const float lj2 = fmaf(S.L2[2], jl[2], fmaf(S.L2[1], jl[1], S.L2[0] * jl[0]));
+    const f2 jl01 = f2{jl[0], jl[1]};
+    f2 dd = pfma(jh[1], bj[1], jh[0] * bj[0]), de = pfma(jl01, lj01, jh[2] * bj[2]);
+    const float d = fmaf(jl[2], lj2, hsum(dd + de));
+    r.dinv = 1.0f / (d + QA_CFM);
+    r.lam = 0.f;
+    r.j[0] = jh[0]; r.j[1] = jh[1]; r.j[2] = jh[2]; r.j[3] = jl01; r.j[4] = f2{jl[2], bias};
+    r.m[0] = bj[0]; r.m[1] = bj[1]; r.m[2] = bj[2]; r.m[3] = lj01; r.m[4] = f2{lj2, 0.f};
+}
+QA_DEV float prow_residual(const PRow &r, const f2 *x) {
+    f2 a = r.j[0] * x[0], b = r.j[1] * x[1];
+    a = pfma(r.j[2], x[2], a); b = pfma(r.j[3], x[3], b); a = pfma(r.j[4], x[4], a);
+    return hsum(a + b);
+}
+// Gauss-Seidel update of one contact on the lane-local state x: normal row, then the two tangent rows TOGETHER from the velocity the normal
+// row left (pyramid friction |lam_t| <= mu lam_n) -- contact_update() in pairs
+QA_DEV void pcontact_update(PRow *r, f2 *x, float mu) {
+    {
+        const float lam = fmaxf(fmaf(-prow_residual(r[0], x), r[0].dinv, r[0].lam), 0.f);
+        const f2 dl = f2s(lam - r[0].lam);
+        r[0].lam = lam;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) x[i] = pfma(r[0].m[i], dl, x[i]);
+    }
+    const float lim = mu * r[0].lam;
+    const float l1 = clampf(fmaf(-prow_residual(r[1], x), r[1].dinv, r[1].lam), -lim, lim);
+    const float l2 = clampf(fmaf(-prow_residual(r[2], x), r[2].dinv, r[2].lam), -lim, lim);
+    const f2 d1 = f2s(l1 - r[1].lam), d2 = f2s(l2 - r[2].lam);
+    r[1].lam = l1; r[2].lam = l2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) x[i] = pfma(r[2].m[i], d2, pfma(r[1].m[i], d1, x[i]));
+}
+// the three rows (normal, tangent 1, tangent 2) of a contact at base-frame point p of chain depth `depth` -- contact_rows() in pairs
+QA_DEV void pcontact_rows(PRow *rows, V3 p, int depth, float gap, float vs, const V3 *o, const V3 *ax, V3 nB, V3 t1B, V3 t2B, const PSolve &S, const PhysParams &P) {
+    const V3 dirs[3] = {nB, t1B, t2B};
+    V3 lever[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lever[k] = cross(ax[k], p - o[k]);
+    const float g = gap / P.dt;
+    const float bias0 = (gap >= 0.f ? g : fmaxf(g, -P.max_depen)) - vs;        // a surface that moves along the normal (articulated obstacle): - vs
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const V3 pxd = cross(p, dirs[d]);
+        const float jb[6] = {pxd.x, pxd.y, pxd.z, dirs[d].x, dirs[d].y, dirs[d].z};
+        float jl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jl[k] = (k < depth) ? dot(dirs[d], lever[k]) : 0.f;
+        prow_finish(rows[d], S, jb, jl, d == 0 ? bias0 : 0.f);
+    }
+}
+// A lane's private LDS region is CONTIGUOUS in the packed build (QA_PRIV_FLOATS floats per lane, 16-byte records, every access a
+// ds_read_b128 / ds_write_b128: lane stride 180 dwords = 45 x 16 B puts the 16 lanes of a b128 service group on 16 different bank
+// quads) -- one wave alone pays ~10 cycles of issue per LDS instruction whatever its width (tools/valu_rate.hip), so a row is 5 reads
+// instead of 20.  Record of a row: j0 j1 | j2 j3 | j4 m0 | m1 m2 | m3 (m4.x, dinv).
+QA_DEV void prow_store(float *rec, const PRow &r) {
+    f4 *q = reinterpret_cast<f4 *>(rec);
+    q[0] = f4{r.j[0].x, r.j[0].y, r.j[1].x, r.j[1].y}; q[1] = f4{r.j[2].x, r.j[2].y, r.j[3].x, r.j[3].y};
+    q[2] = f4{r.j[4].x, r.j[4].y, r.m[0].x, r.m[0].y}; q[3] = f4{r.m[1].x, r.m[1].y, r.m[2].x, r.m[2].y};
+    q[4] = f4{r.m[3].x, r.m[3].y, r.m[4].x, r.dinv};
+}
+QA_DEV void prow_load(const float *rec, PRow &r) {
+    const f4 *q = reinterpret_cast<const f4 *>(rec);
+    const f4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    r.j[0] = f2{a.x, a.y}; r.j[1] = f2{a.z, a.w}; r.j[2] = f2{b.x, b.y}; r.j[3] = f2{b.z, b.w}; r.j[4] = f2{c.x, c.y};
+    r.m[0] = f2{c.z, c.w}; r.m[1] = f2{d.x, d.y}; r.m[2] = f2{d.z, d.w}; r.m[3] = f2{e.x, e.y}; r.m[4] = f2{e.z, 0.f}; r.dinv = e.w;
+}
+#ifdef QA_PGS_PACKED
+QA_DEV float *priv_of(float *s_priv, int tix) { return s_priv + tix * QA_PRIV_FLOATS; }
+// env-step persistents parked between substeps (act3 sp3 sd3 binert10) as five 16-byte records at QA_PRIV_STEP
+QA_DEV void priv_park(float *priv, const float *act, const float *sp, const float *sd, const float *bi) {
+    f4 *q = reinterpret_cast<f4 *>(priv + QA_PRIV_STEP);
+    q[0] = f4{act[0], act[1], act[2], sp[0]}; q[1] = f4{sp[1], sp[2], sd[0], sd[1]}; q[2] = f4{sd[2], bi[0], bi[1], bi[2]};
+    q[3] = f4{bi[3], bi[4], bi[5], bi[6]}; q[4] = f4{bi[7], bi[8], bi[9], 0.f};
+}
+QA_DEV void priv_unpark(const float *priv, float *act, float *sp, float *sd, float *bi) {
+    const f4 *q = reinterpret_cast<const f4 *>(priv + QA_PRIV_STEP);
+    const f4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    act[0] = a.x; act[1] = a.y; act[2] = a.z; sp[0] = a.w; sp[1] = b.x; sp[2] = b.y; sd[0] = b.z; sd[1] = b.w; sd[2] = c.x;
+    bi[0] = c.y; bi[1] = c.z; bi[2] = c.w; bi[3] = d.x; bi[4] = d.y; bi[5] = d.z; bi[6] = d.w; bi[7] = e.x; bi[8] = e.y; bi[9] = e.z;
+}
+#else
+QA_DEV float *priv_of(float *s_priv, int tix) { return s_priv + tix; }
+QA_DEV void priv_park(float *priv, const float *act, const float *sp, const float *sd, const float *bi) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lr(priv, QA_PRIV_STEP + k) = act[k]; lr(priv, QA_PRIV_STEP + 3 + k) = sp[k]; lr(priv, QA_PRIV_STEP + 6 + k) = sd[k]; }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) lr(priv, QA_PRIV_STEP + 9 + i) = bi[i];
+}
+QA_DEV void priv_unpark(const float *priv, float *act, float *sp, float *sd, float *bi) {
+    float *pp = const_cast<float *>(priv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { act[k] = lr(pp, QA_PRIV_STEP + k); sp[k] = lr(pp, QA_PRIV_STEP + 3 + k); sd[k] = lr(pp, QA_PRIV_STEP + 6 + k); }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) bi[i] = lr(pp, QA_PRIV_STEP + 9 + i);
+}
+#endif
+
 template <bool PLANE>
 QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
                          float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3], const TerrainView &T) {
@@ -617,6 +767,238 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #endif
     }
 
+#ifdef QA_PGS_PACKED
+    QA_SUBSTAMP(7);
+    // ---- rows, packed (see PRow): foot rows in registers; the extra slots' and the self-collision rows in the lane's LDS records, built only
+    // when some env of the wavefront needs them
+    PSolve PS;
+    psolve_make(PS, G, Linv, Binv);
+    PRow rf[3];
+    V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
+    if (!PLANE) { tangent_basis(foot_n, ft1_w, ft2_w); fn_b = mulT(R, foot_n); ft1_b = mulT(R, ft1_w); ft2_b = mulT(R, ft2_w); }
+    pcontact_rows(rf, foot_p, 3, foot_gap, foot_vs, o, ax, fn_b, ft1_b, ft2_b, PS, P);
+    // Per-LANE activity is carried by the rows' data, not by branches: a row whose contact is open gets a bias no velocity overcomes
+    // (residual > 0 => lam stays 0 => x + m 0 = x exactly), so the sweeps below branch on wave-uniform votes only -- a lane-divergent `if`
+    // costs ~8 scalar instructions of exec-mask bookkeeping per block and saves nothing (the idle lanes' slots are issued anyway).
+    rf[0].j[4].y = foot_on ? rf[0].j[4].y : QA_OPEN_BIAS;
+    float re_lam[QA_EXTRA_SLOTS][3];
+    float ex_ca[QA_EXTRA_SLOTS]; int ex_ob[QA_EXTRA_SLOTS];
+    V3 ex_n[QA_EXTRA_SLOTS];                                // world-frame normals of the extra contacts (height field)
+    int ex_body[QA_EXTRA_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
+        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1; ex_ca[sl] = 0.f; ex_ob[sl] = -1;
+        if (any_extra[sl]) {
+            V3 p; int depth;
+            const int code = scode[sl], link = max(slink[sl], 0);
+            if (code >= 64) { const float *pt = btbl + 4 * (code - 64); p = v3(pt[0], pt[1], pt[2]); depth = 0; ex_body[sl] = (code - 64) < 8 ? 0 : ((code - 64) < 10 ? 1 : 2); }
+            else { p = leg_point(code > 0 ? code : 1, link); depth = link + 1; ex_body[sl] = 3 + 4 * leg + link; }
+            PRow re[3];
+            V3 en_b = nB, et1_b = t1B, et2_b = t2B;
+            float ex_vs = 0.f;
+            if (!PLANE) {
+                (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl], ex_vs, ex_ca[sl], ex_ob[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
+                V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
+            }
+            pcontact_rows(re, p, depth, sgap[sl], ex_vs, o, ax, en_b, et1_b, et2_b, PS, P);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) prow_store(priv + QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
+        }
+    }
+    // ---- self-collision rows: partner 0 = lane ^ 1 (left / right), partner 1 = lane ^ 2 (front / rear).  Both lanes of a pair evaluate the
+    // SAME expressions on the same (canonically ordered) segments, so they agree bit for bit on gap, normal and effective mass.  This path is
+    // rare (4e-6 of the env-steps of a training run) and stays in scalar arithmetic; only its LDS record is the packed one.
+    bool sc_on[2] = {false, false}, any_sc[2] = {false, false}, sc_low[2] = {false, false};
+    float sc_lam[2] = {0.f, 0.f};
+    V3 sc_nw[2];
+    if (P.self_collision) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const V3 a0 = o[2], a1 = foot_p;
+            V3 b0, b1;
+            if (pr == 0) { b0 = v3(dpp_f<0xB1>(a0.x), dpp_f<0xB1>(a0.y), dpp_f<0xB1>(a0.z)); b1 = v3(dpp_f<0xB1>(a1.x), dpp_f<0xB1>(a1.y), dpp_f<0xB1>(a1.z)); }
+            else { b0 = v3(dpp_f<0x4E>(a0.x), dpp_f<0x4E>(a0.y), dpp_f<0x4E>(a0.z)); b1 = v3(dpp_f<0x4E>(a1.x), dpp_f<0x4E>(a1.y), dpp_f<0x4E>(a1.z)); }
+            const bool low = pr == 0 ? ((leg & 1) == 0) : ((leg & 2) == 0);          // this lane holds the pair's first capsule
+            const V3 A0 = low ? a0 : b0, A1 = low ? a1 : b1, B0 = low ? b0 : a0, B1 = low ? b1 : a1;
+            float sa, tb; segment_closest(A0, A1, B0, B1, sa, tb);
+            const V3 pA = A0 + sa * (A1 - A0), pB = B0 + tb * (B1 - B0), dv = pA - pB;
+            const float dist = sqrtf(dot(dv, dv));
+            const V3 nrm = dist > 1e-6f ? (1.0f / dist) * dv : v3(0.f, 1.f, 0.f);
+            const float gap = dist - (QA_CALF_RADIUS + sa * (QA_FOOT_RADIUS - QA_CALF_RADIUS)) - (QA_CALF_RADIUS + tb * (QA_FOOT_RADIUS - QA_CALF_RADIUS));
+            sc_on[pr] = gap < P.contact_offset; sc_low[pr] = low;
+            any_sc[pr] = __any(sc_on[pr]);
+            sc_nw[pr] = low ? nrm : v3(-nrm.x, -nrm.y, -nrm.z);          // base frame: direction of the force on THIS leg
+            if (any_sc[pr]) {
+                Row r;
+                const V3 pm = low ? pA : pB;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r.jl[k] = dot(sc_nw[pr], cross(ax[k], pm - o[k]));
+                float h[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) h[i] = G[0 * 6 + i] * r.jl[0] + G[1 * 6 + i] * r.jl[1] + G[2 * 6 + i] * r.jl[2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) r.jh[i] = h[i] + (pr == 0 ? dpp_f<0xB1>(h[i]) : dpp_f<0x4E>(h[i]));
+                sym6_mul(Binv, r.jh, r.bj);
+                r.lj[0] = Linv[0] * r.jl[0] + Linv[1] * r.jl[1] + Linv[2] * r.jl[2];
+                r.lj[1] = Linv[1] * r.jl[0] + Linv[3] * r.jl[1] + Linv[4] * r.jl[2];
+                r.lj[2] = Linv[2] * r.jl[0] + Linv[4] * r.jl[1] + Linv[5] * r.jl[2];
+                const float dleg = r.jl[0] * r.lj[0] + r.jl[1] * r.lj[1] + r.jl[2] * r.lj[2];
+                float d = dleg + (pr == 0 ? dpp_f<0xB1>(dleg) : dpp_f<0x4E>(dleg));
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d = fmaf(r.jh[i], r.bj[i], d);
+                const float g = gap / dt;
+                PRow pr_;
+                pr_.j[0] = f2{r.jh[0], r.jh[1]}; pr_.j[1] = f2{r.jh[2], r.jh[3]}; pr_.j[2] = f2{r.jh[4], r.jh[5]}; pr_.j[3] = f2{r.jl[0], r.jl[1]};
+                pr_.j[4] = f2{r.jl[2], gap >= 0.f ? g : fmaxf(g, -P.max_depen)};
+                pr_.m[0] = f2{r.bj[0], r.bj[1]}; pr_.m[1] = f2{r.bj[2], r.bj[3]}; pr_.m[2] = f2{r.bj[4], r.bj[5]}; pr_.m[3] = f2{r.lj[0], r.lj[1]}; pr_.m[4] = f2{r.lj[2], 0.f};
+                pr_.dinv = 1.0f / (d + QA_CFM);
+                prow_store(priv + QA_PRIV_SELF + 20 * pr, pr_);
+            }
+        }
+    }
+    // joint limits: at most one stop per joint can be within the margin.  jl = sgn e_k  =>  jh = sgn G[k,:], lj = sgn Linv[:,k]
+    float lim_sgn[3], lim_bias[3], lim_lam[3], lim_dinv[3];   // registers: these rows run in most waves
+    f2 lim_m[3][3];
+    bool lim_on[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float glo = st.q[k] - tbl[T_LOWER + k], ghi = tbl[T_UPPER + k] - st.q[k];
+        bool lo = glo < QA_LIMIT_MARGIN, hi = !lo && (ghi < QA_LIMIT_MARGIN);
+        lim_on[k] = lo || hi;
+        lim_sgn[k] = lo ? 1.f : -1.f;
+        float gap = lo ? glo : ghi, g = gap / dt;
+        lim_bias[k] = lim_on[k] ? (gap >= 0.f ? g : fmaxf(g, -QA_LIMIT_DEPEN)) : QA_OPEN_BIAS;
+        lim_lam[k] = 0.f;
+    }
+    const bool any_limk[3] = {(bool)__any(lim_on[0]), (bool)__any(lim_on[1]), (bool)__any(lim_on[2])};
+    const bool any_lim = any_limk[0] || any_limk[1] || any_limk[2];
+    if (any_lim) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            f2 jh[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) jh[q] = f2s(lim_sgn[k]) * PS.G2[k][q];
+            pbinv_mul(PS, jh, lim_m[k]);
+            const float lkk = (k == 0) ? Linv[0] : (k == 1 ? Linv[3] : Linv[5]);
+            const f2 dd = pfma(jh[2], lim_m[k][2], pfma(jh[1], lim_m[k][1], jh[0] * lim_m[k][0]));
+            lim_dinv[k] = 1.0f / (lkk + hsum(dd) + QA_CFM);
+        }
+    }
+
+    QA_SUBSTAMP(8);
+    // ---- the sweeps' state: x = (ub | w, 1).  Warm start: the foot rows start from the previous substep's impulses, applied to x first
+    // (the base part summed over the quad, the leg part local)
+    f2 x[5] = {f2{ub[0], ub[1]}, f2{ub[2], ub[3]}, f2{ub[4], ub[5]}, f2{w[0], w[1]}, f2{w[2], 1.0f}};
+    {
+        f2 dx[5] = {f2s(0.f), f2s(0.f), f2s(0.f), x[3], x[4]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float l0 = foot_on ? fimp[d] : 0.f;
+            rf[d].lam = l0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) dx[i] = pfma(rf[d].m[i], f2s(l0), dx[i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) x[q] += f2{quad_sum(dx[q].x), quad_sum(dx[q].y)};
+        x[3] = dx[3]; x[4] = dx[4];
+    }
+    QA_SUBSTAMP(4);
+    // ---- projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs {FL, RR} and {FR, RL} are
+    // updated from the same base velocity and their base-velocity changes are summed; colours follow each other Gauss-Seidel fashion.  Every
+    // lane runs its own rows in both passes and only the lanes of the active colour commit (the lanes of a quad run in lockstep: the idle
+    // colour's instructions are issued anyway).  Commit: the base takes d[a] + d[b] of the two active lanes a, b through two quad_perm
+    // broadcasts per component, in the same order on all four lanes (they must keep bit-identical copies of ub).
+    const bool any_foot = __any(foot_on);
+    const bool colour_a = ((leg + 1) & 2) == 0;          // legs 0 and 3, without a short-circuit
+    for (int it = 0; it < P.iters; ++it) {
+#pragma unroll
+        for (int colour = 0; colour < 2; ++colour) {
+            const bool mine = (colour == 0) == colour_a;
+            f2 x2[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) x2[i] = x[i];
+            if (any_foot) {
+                const float l0 = rf[0].lam, l1 = rf[1].lam, l2 = rf[2].lam;
+                pcontact_update(rf, x2, mu);
+                rf[0].lam = mine ? rf[0].lam : l0; rf[1].lam = mine ? rf[1].lam : l1; rf[2].lam = mine ? rf[2].lam : l2;
+            }
+#pragma unroll
+            for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
+                if (any_extra[sl]) {          // a lane without this slot's contact holds rows with gap 1e30: they leave x alone
+                    PRow t[3];
+                    prow_load(priv + QA_PRIV_EXTRA + 60 * sl, t[0]); prow_load(priv + QA_PRIV_EXTRA + 60 * sl + 20, t[1]); prow_load(priv + QA_PRIV_EXTRA + 60 * sl + 40, t[2]);
+                    t[0].lam = re_lam[sl][0]; t[1].lam = re_lam[sl][1]; t[2].lam = re_lam[sl][2];
+                    pcontact_update(t, x2, mu);
+                    re_lam[sl][0] = mine ? t[0].lam : re_lam[sl][0]; re_lam[sl][1] = mine ? t[1].lam : re_lam[sl][1]; re_lam[sl][2] = mine ? t[2].lam : re_lam[sl][2];
+                }
+            }
+            {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (any_limk[k]) {
+                        // residual = bias + sgn * u_k,   u_k = w_k + G[k,:] ub
+                        const f2 gu = pfma(PS.G2[k][2], x2[2], pfma(PS.G2[k][1], x2[1], PS.G2[k][0] * x2[0]));
+                        const float wk = k == 0 ? x2[3].x : (k == 1 ? x2[3].y : x2[4].x);
+                        const float uk = hsum(gu) + wk;
+                        const float res = fmaf(lim_sgn[k], uk, lim_bias[k]);
+                        const float lam = fmaxf(fmaf(-res, lim_dinv[k], lim_lam[k]), 0.f);
+                        const float dl = lam - lim_lam[k];
+                        lim_lam[k] = mine ? lam : lim_lam[k];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) x2[q] = pfma(lim_m[k][q], f2s(dl), x2[q]);
+                        const float sd = lim_sgn[k] * dl;
+                        x2[3] = pfma(PS.L01[k], f2s(sd), x2[3]);
+                        x2[4].x = fmaf(PS.L2[k], sd, x2[4].x);
+                    }
+                }
+            }
+            // commit: lanes of the active colour keep their w; the base takes the SUM of the two active lanes' velocity changes.
+            // Selects, not `if (mine) { x[3] = x2[3]; x[4].x = x2[4].x; }`: hipcc 7.2 (-O1 and -O3 alike) turns that element-wise conditional
+            // copy of a 2-vector under `leg == 0 || leg == 3` into two nested exec regions and restores x[4].x for leg 0 as well -- the calf
+            // joint of the front-left leg then never receives its contact impulse (found by tools/ab_lockstep.py: every first touchdown
+            // that diverged from the scalar build was an FL foot; profiles/r5_packed_sweeps_debug.txt)
+            x[3].x = mine ? x2[3].x : x[3].x; x[3].y = mine ? x2[3].y : x[3].y; x[4].x = mine ? x2[4].x : x[4].x;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f2 d = x2[q] - x[q];
+                if (colour == 0) {
+                    x[q].x = (x[q].x + dpp_f<0x00>(d.x)) + dpp_f<0xFF>(d.x);      // lanes 0 and 3 (FL, RR)
+                    x[q].y = (x[q].y + dpp_f<0x00>(d.y)) + dpp_f<0xFF>(d.y);
+                } else {
+                    x[q].x = (x[q].x + dpp_f<0x55>(d.x)) + dpp_f<0xAA>(d.x);      // lanes 1 and 2 (FR, RL)
+                    x[q].y = (x[q].y + dpp_f<0x55>(d.y)) + dpp_f<0xAA>(d.y);
+                }
+            }
+        }
+        // self-collision pairs: the two left/right pairs from the same base velocity (their base-velocity changes summed, one lane of a
+        // pair reporting it), then the two front/rear pairs
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            if (any_sc[pr]) {
+                // every lane of the wavefront runs the row it stored (built under the same vote); a lane whose pair is apart takes dl = 0 -- no
+                // lane-divergent region around vector-element writes (see the commit above)
+                PRow r; prow_load(priv + QA_PRIV_SELF + 20 * pr, r);
+                const float tl = r.j[3].x * x[3].x + r.j[3].y * x[3].y + r.j[4].x * x[4].x;
+                // own + partner term FIRST: the sum is commutative, so both lanes of the pair hold identical bits before the (identical) bias
+                // and base chain are added -- (bias + own) + partner rounds differently on the two sides and lets their lam drift apart
+                const float tls = tl + (pr == 0 ? dpp_f<0xB1>(tl) : dpp_f<0x4E>(tl));
+                float res = r.j[4].y + tls;
+                res = fmaf(r.j[0].x, x[0].x, res); res = fmaf(r.j[0].y, x[0].y, res); res = fmaf(r.j[1].x, x[1].x, res);
+                res = fmaf(r.j[1].y, x[1].y, res); res = fmaf(r.j[2].x, x[2].x, res); res = fmaf(r.j[2].y, x[2].y, res);
+                const float lam = sc_on[pr] ? fmaxf(sc_lam[pr] - res * r.dinv, 0.f) : sc_lam[pr], dl = lam - sc_lam[pr];
+                sc_lam[pr] = lam;
+                x[3] = pfma(r.m[3], f2s(dl), x[3]);
+                x[4].x = fmaf(r.m[4].x, dl, x[4].x);
+                const float dlb = sc_low[pr] ? dl : 0.f;
+                const f2 db0 = r.m[0] * f2s(dlb), db1 = r.m[1] * f2s(dlb), db2 = r.m[2] * f2s(dlb);
+                x[0] += f2{quad_sum(db0.x), quad_sum(db0.y)}; x[1] += f2{quad_sum(db1.x), quad_sum(db1.y)}; x[2] += f2{quad_sum(db2.x), quad_sum(db2.y)};
+            }
+        }
+    }
+    ub[0] = x[0].x; ub[1] = x[0].y; ub[2] = x[1].x; ub[3] = x[1].y; ub[4] = x[2].x; ub[5] = x[2].y;
+    w[0] = x[3].x; w[1] = x[3].y; w[2] = x[4].x;
+
+#else
     QA_SUBSTAMP(7);
     // ---- rows (foot rows in registers; the extra slots' rows in LDS, built only when some env of the wavefront needs them)
     Row rf[3];
@@ -834,6 +1216,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         }
     }
 
+#endif
     QA_SUBSTAMP(9);
     // ---- leg velocity, clamp, integrate
     float ul[3];

@@ -812,11 +812,8 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
     // per-step constants are parked in per-lane LDS slots between substeps so that they do not hold VGPRs
     // through the substep (the substep alone needs ~340 registers)
-    float *priv = s_priv + tix;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { lr(priv, QA_PRIV_STEP + k) = act[k]; lr(priv, QA_PRIV_STEP + 3 + k) = sp[k]; lr(priv, QA_PRIV_STEP + 6 + k) = sd[k]; }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) lr(priv, QA_PRIV_STEP + 9 + i) = binert[i];
+    float *priv = priv_of(s_priv, tix);
+    priv_park(priv, act, sp, sd, binert);
     float tau[3], tau_org[3];
     ContactOut co;
     float fimp[3];
@@ -826,14 +823,13 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         // compiler fence: without it LICM hoists the ~120 loop-invariant LDS table reads of the substep out of this
         // loop and keeps them in registers across it, which is what pushed the kernel into scratch
         asm volatile("" ::: "memory");
-        float bi[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) bi[i] = lr(priv, QA_PRIV_STEP + 9 + i);
+        float bi[10], pa[3], psp[3], psd[3];
+        priv_unpark(priv, pa, psp, psd, bi);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float as = lr(priv, QA_PRIV_STEP + k) * c.action_scale;
+            float as = pa[k] * c.action_scale;
             if (k == 0) as *= c.hip_scale_reduction;
-            float t = c.randomize_motor ? lr(priv, QA_PRIV_STEP + 3 + k) * c.kp * (as + q0[k] - st.q[k]) - lr(priv, QA_PRIV_STEP + 6 + k) * c.kd * st.qd[k]
+            float t = c.randomize_motor ? psp[k] * c.kp * (as + q0[k] - st.q[k]) - psd[k] * c.kd * st.qd[k]
                                         : c.kp * (as + q0[k] - st.q[k]) - c.kd * st.qd[k];
             tau_org[k] = t;
             float lim = tbl[T_EFFORT + k];
@@ -841,8 +837,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         }
         phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { act[k] = lr(priv, QA_PRIV_STEP + k); sp[k] = lr(priv, QA_PRIV_STEP + 3 + k); sd[k] = lr(priv, QA_PRIV_STEP + 6 + k); }
+    { float bi_[10]; priv_unpark(priv, act, sp, sd, bi_); }
     // ---- the articulated obstacles' joints: one step of h = decimation x dt under the mean contact force of the substeps (lane k: slot k)
     if (!PLANE) {
         if (c.articulated_obstacles) {
@@ -1056,7 +1051,7 @@ template <bool PLANE, int LPE>
 __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs p, const float *torques, const uint8_t *cond) {
     if (cond && *cond == 0) return;               // qa_simulate_if: the whole launch is a no-op (uniform over the grid)
     __shared__ float s_tbl[QA_TBL_FLOATS];
-    __shared__ float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_priv[QA_PRIV_FLOATS * QA_PRIV_STRIDE];
     __shared__ float s_patch[PLANE ? 1 : ENVS_PER_BLOCK * QA_PATCH * QA_PATCH];
     __shared__ float s_ob[PLANE ? 1 : ENVS_PER_BLOCK * QA_OB_LDS];
     static_assert(LPE == 4, "one quad per env");
@@ -1089,7 +1084,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
         }
         wave_lds_sync();
     }
-    phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, s_priv + threadIdx.x, fimp, T);
+    phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, priv_of(s_priv, threadIdx.x), fimp, T);
     V3 org[4]; leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 z = v3(0, 0, 0);

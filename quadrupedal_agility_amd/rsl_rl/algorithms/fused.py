@@ -107,6 +107,73 @@ def hybrid_ppo_loss_raw(logits, mean, std, value, actions, old_logp_d, old_logp_
     return out, dlogits, dmean, dstd, dvalue
 
 
+# ---- gradients left in parts (r5) ---------------------------------------------------------------------------------------------------
+# The weight gradient of a wide Linear layer comes out of `weight_grad` as S slabs and its bias gradient out of qa_elu_backward_bias as one
+# row of column sums per 64-row block; each used to be finished by its own fixed-order launch (qa_slab_reduce x 7, qa_colsum_finish x 12 per
+# PPO minibatch step, ~5 us each, between GEMMs that wait for nothing they produce).  Inside `deferred_grad_finishes()` the backward
+# functions hand autograd an UNWRITTEN gradient tensor and register the parts here, keyed by the parameter; ClipAdam.step() passes them to
+# qa_clip_adam_step_reduce, whose first pass (the clipping norm) adds the parts in the same fixed order, writes the finished gradient into
+# `param.grad` and squares it.  Whoever needs finished gradients before the optimiser runs (the data-parallel bucket, tests) calls
+# `flush_pending_grads()` -- ONE launch for all of them.  Nothing may read `.grad` of a registered parameter before one of the two ran.
+_DEFER = [False]
+_PENDING = {}          # parameter data_ptr -> (parameter, parts tensor, number of parts, stride between parts in elements)
+_RETIRED = []          # parts tensors of the step before: see _retire
+
+
+def _retire(parts):
+    """The parts were written on the stream their backward node ran on (a branch stream of the PPO step) and are read by the optimiser's
+    kernel on the CURRENT stream: the caching allocator must not hand the block back to the branch stream while that kernel can still be
+    reading it.  Eager: record the consumer stream on the block.  Always: keep the tensor until the next step opens (by then every branch
+    stream has been told to wait for the stream the optimiser ran on)."""
+    if not torch.cuda.is_current_stream_capturing():
+        parts.record_stream(torch.cuda.current_stream(parts.device))
+    _RETIRED.append(parts)
+
+
+class deferred_grad_finishes:
+    def __enter__(self):
+        self.prev = _DEFER[0]
+        _DEFER[0] = ENABLED and os.environ.get("QA_DEFER_GRAD_FINISH", "1") != "0"
+        del _RETIRED[:]
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER[0] = self.prev
+        return False
+
+
+def _defer_ok(param):
+    return _DEFER[0] and param is not None and param.is_cuda and param.is_leaf and param.requires_grad and param.data_ptr() not in _PENDING
+
+
+def _register_parts(param, parts, nparts, stride):
+    _PENDING[param.data_ptr()] = (param, parts, int(nparts), int(stride))
+
+
+def pending_grads():
+    return len(_PENDING)
+
+
+def flush_pending_grads(params=None):
+    """finish the gradients still in parts (all of them, or those of `params`) into their `.grad` tensors: one launch (qa_grad_reduce)"""
+    keys = list(_PENDING) if params is None else [p.data_ptr() for p in params if p.data_ptr() in _PENDING]
+    if not keys:
+        return
+    lib = _capi.load_library()
+    ent = [_PENDING.pop(k) for k in keys]
+    for p, *_ in ent:
+        if p.grad is None or not p.grad.is_contiguous():
+            raise RuntimeError("a gradient registered in parts has no contiguous .grad tensor to be finished into")
+    for i in range(0, len(ent), 64):
+        e = ent[i:i + 64]
+        n = len(e)
+        dst = (C.c_void_p * n)(*[p.grad.data_ptr() for p, *_ in e]); src = (C.c_void_p * n)(*[t.data_ptr() for _, t, _, _ in e])
+        stride = (C.c_int64 * n)(*[st for *_, st in e]); parts = (C.c_int32 * n)(*[k for _, _, k, _ in e]); numel = (C.c_int32 * n)(*[p.numel() for p, *_ in e])
+        _check(lib.qa_grad_reduce(dst, src, stride, parts, numel, n, C.c_void_p(torch.cuda.current_stream(e[0][0].device).cuda_stream)), "qa_grad_reduce")
+    for _, t, _, _ in ent:
+        _retire(t)
+
+
 class _LinearElu(torch.autograd.Function):
     """y = elu(x W^T + b).  Forward: addmm (hipBLASLt) + in-place ELU.  Backward: ONE kernel for the ELU derivative and
     the bias gradient (qa_elu_backward_bias), then the two GEMMs.  Saves the ELU output only (elu' = y + alpha for y <= 0)."""
@@ -123,11 +190,13 @@ class _LinearElu(torch.autograd.Function):
             torch.nn.functional.elu(y, alpha=alpha, inplace=True)
         ctx.save_for_backward(x, weight, y)
         ctx.alpha = alpha
+        ctx.bias_param = bias
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
+        bias = ctx.bias_param
         lib = _capi.load_library()
         gy = _f32c(gy)
         rows, cols = y.shape
@@ -136,11 +205,14 @@ class _LinearElu(torch.autograd.Function):
         nscratch = int(lib.qa_elu_backward_bias_scratch_bytes(rows, cols))
         scratch = torch.empty(nscratch, dtype=torch.uint8, device=y.device)
         stream = C.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
-        rc = lib.qa_elu_backward_bias(_ptr(gy), _ptr(y), _ptr(g), _ptr(gb), rows, cols, float(ctx.alpha), _ptr(scratch), nscratch, stream)
+        defer_b = ctx.needs_input_grad[2] and _defer_ok(bias) and bias.numel() == cols
+        rc = lib.qa_elu_backward_bias(_ptr(gy), _ptr(y), _ptr(g), None if defer_b else _ptr(gb), rows, cols, float(ctx.alpha), _ptr(scratch), nscratch, stream)
         if rc != 0:
             raise RuntimeError(f"qa_elu_backward_bias failed with code {rc}: {lib.qa_last_error().decode()}")
+        if defer_b:           # gb stays unwritten: the optimiser's first pass adds the (rows / 64) rows of column sums
+            _register_parts(bias, scratch, (rows + 63) // 64, cols)
         gx = g.mm(weight) if ctx.needs_input_grad[0] else None
-        gw = weight_grad(g, x) if ctx.needs_input_grad[1] else None
+        gw = weight_grad(g, x, param=weight) if ctx.needs_input_grad[1] else None
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None
 
 
@@ -219,7 +291,7 @@ def mask_times_row(mask, w):
 WGRAD_SLABS = 8
 
 
-def weight_grad(g, x):
+def weight_grad(g, x, param=None):
     """dW = g^T x for g (rows, n), x (rows, k).  The output is small (<= 512 x 671) and the reduction long (24,576 rows): the
     library's picks for that shape run split-K kernels on a few dozen workgroups (32 TFLOP/s for 128 x 256).  Splitting the rows
     into 8 slabs through ONE batched GEMM gives it 8x the workgroups; the 8 partial products are added in a fixed order
@@ -229,7 +301,11 @@ def weight_grad(g, x):
     k = x.shape[1]
     S = WGRAD_SLABS
     if ENABLED and rows >= 8192 and rows % S == 0 and n * k >= 16384 and g.stride(1) == 1 and x.stride(1) == 1:
-        return slab_sum(torch.bmm(g.unflatten(0, (S, rows // S)).transpose(1, 2), x.unflatten(0, (S, rows // S))))   # ours, not torch's sum(0)
+        slabs = torch.bmm(g.unflatten(0, (S, rows // S)).transpose(1, 2), x.unflatten(0, (S, rows // S)))
+        if _defer_ok(param) and param.shape == (n, k) and param.is_contiguous():
+            _register_parts(param, slabs, S, n * k)          # the S slabs are added by the optimiser's first pass (deferred_grad_finishes)
+            return torch.empty(n, k, dtype=torch.float32, device=g.device)
+        return slab_sum(slabs)   # ours, not torch's sum(0)
     return g.t().mm(x)
 
 
@@ -779,6 +855,8 @@ class ClipAdam:
     yet, groups with different learning rates, non-contiguous gradients)."""
 
     CHUNK = 2048
+    SMALL_CHUNK = 32
+    WIDE_PARTS = 16         # QA_REDUCE_WIDE of csrc/qa_learner.hip
 
     def __init__(self, optimizer, max_norm=None):
         self.opt = optimizer
@@ -799,8 +877,11 @@ class ClipAdam:
         ct, cs, cl = [], [], []
         for t, (p, _) in enumerate(items):
             n = p.numel()
-            for s0 in range(0, n, self.CHUNK):
-                ct.append(t); cs.append(s0); cl.append(min(self.CHUNK, n - s0))
+            # small tensors (biases, std, heads) in 32-element chunks: a gradient that arrives as MANY parts (the 384 row-block column sums
+            # of a bias gradient, qa_clip_adam_step_reduce) is added by the eight thread rows of a workgroup over a chunk of <= 32 elements
+            chunk = self.SMALL_CHUNK if n <= self.CHUNK else self.CHUNK
+            for s0 in range(0, n, chunk):
+                ct.append(t); cs.append(s0); cl.append(min(chunk, n - s0))
         i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device=dev)
         tab = dict(items=[p for p, _ in items], n=len(items), params=i64([p.data_ptr() for p, _ in items]),
                    exp_avg=i64([s["exp_avg"].data_ptr() for s in st]), exp_avg_sq=i64([s["exp_avg_sq"].data_ptr() for s in st]),
@@ -825,6 +906,16 @@ class ClipAdam:
               and all(g["lr"] is g0["lr"] or (not torch.is_tensor(g["lr"]) and not torch.is_tensor(g0["lr"]) and g["lr"] == g0["lr"]) for _, g in items)
               and all(g["betas"] == g0["betas"] and g["eps"] == g0["eps"] for _, g in items)
               and all(p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32 and p.grad.dtype == torch.float32 for p in params))
+        # gradients still in parts (deferred_grad_finishes): added by this step's first pass when the kernel can take them, else finished now
+        pend = [_PENDING.get(p.data_ptr()) for p in params] if _PENDING else None
+        if pend is not None and any(e is not None for e in pend):
+            can = (ok and self.max_norm > 0 and len(params) <= 64 and
+                   all(e is None or e[2] <= self.WIDE_PARTS or p.numel() <= self.CHUNK for p, e in zip(params, pend)))
+            if not can:
+                flush_pending_grads(params)
+                pend = None
+        else:
+            pend = None
         if not ok:
             return self._torch_step(params)
         tab = self._tab
@@ -861,6 +952,22 @@ class ClipAdam:
             lr_dev = t["lr_dev"]
         lib = _capi.load_library()
         stream = C.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
+        if pend is not None:
+            n = len(params)
+            src = (C.c_void_p * n)(*[(e[1].data_ptr() if e is not None else 0) for e in pend])
+            stride = (C.c_int64 * n)(*[(e[3] if e is not None else 0) for e in pend])
+            parts = (C.c_int32 * n)(*[(e[2] if e is not None else 0) for e in pend])
+            rc = lib.qa_clip_adam_step_reduce(_ptr(t["params"]), (C.c_void_p * n)(*ptrs), _ptr(t["exp_avg"]), _ptr(t["exp_avg_sq"]), _ptr(t["steps"]), t["n"],
+                                              _ptr(t["chunk_tensor"]), _ptr(t["chunk_start"]), _ptr(t["chunk_len"]), t["num_chunks"], _ptr(t["wd"]),
+                                              _ptr(lr_dev), float(t["betas"][0]), float(t["betas"][1]), float(t["eps"]), self.max_norm,
+                                              _ptr(t["scratch"]), t["scratch"].numel(), src, stride, parts, stream)
+            for p in params:
+                e = _PENDING.pop(p.data_ptr(), None)
+                if e is not None:
+                    _retire(e[1])
+            if rc != 0:
+                raise RuntimeError(f"qa_clip_adam_step_reduce failed with code {rc}: {lib.qa_last_error().decode()}")
+            return
         fn, garg = (lib.qa_clip_adam_step_hostgrads, (C.c_void_p * len(ptrs))(*ptrs)) if inline else (lib.qa_clip_adam_step, _ptr(t["grads"]))
         rc = fn(_ptr(t["params"]), garg, _ptr(t["exp_avg"]), _ptr(t["exp_avg_sq"]), _ptr(t["steps"]), t["n"],
                                    _ptr(t["chunk_tensor"]), _ptr(t["chunk_start"]), _ptr(t["chunk_len"]), t["num_chunks"], _ptr(t["wd"]),

@@ -629,7 +629,13 @@ class SSInfoGAIL:
         # big GEMMs running side by side slow each other more than the shorter dependency chain saves)
         if self._recording_ac:
             fused_mod.assert_recordable_graph([est, mu, value, priv_latent], "PPO step")
-        torch.autograd.backward([est, mu, value, priv_latent], [g_est, dmu, dvalue.view_as(value), g_priv])
+        # r5: the weight / bias gradients of the wide layers stay in parts (split-K slabs, row-block column sums) and are added by the first
+        # pass of the optimiser steps that follow (_ac_apply -> ClipAdam -> qa_clip_adam_step_reduce): 19 finish launches fewer per step.
+        # The data-parallel step needs finished gradients for its bucket: one launch adds them all (flush_pending_grads).
+        with fused_mod.deferred_grad_finishes():
+            torch.autograd.backward([est, mu, value, priv_latent], [g_est, dmu, dvalue.view_as(value), g_priv])
+        if self.grad_sync is not None:
+            fused_mod.flush_pending_grads()
         ac.std.grad = dstd.view_as(ac.std)          # std enters the objective through qa_ppo_loss only
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         return (out[1], out[2], out[3], out[4], priv_reg_loss, estimator_loss), (out[5] if adaptive else None)
@@ -640,6 +646,8 @@ class SSInfoGAIL:
         if kl_mean is not None:
             self._apply_kl_schedule(kl_mean)
         self._step_ac.step()
+        if fused_mod.pending_grads():                # a parameter outside both optimisers had its gradient left in parts: finish it now
+            fused_mod.flush_pending_grads()
 
     def update_actor_critic(self, sample):
         stats, kl_mean = self._ac_forward_backward(sample)

@@ -440,10 +440,34 @@ class OnPolicyRunner:
                 env.use_device_step_counter()
                 if self.amp_enabled:
                     env.task_obs_weight_dev = torch.tensor(float(env.task_obs_weight), device=dev)
-            # training never reads the per-step exports of the env (seam 1 / play / logging tensors): the fused step stops writing them
-            # (r4: measured traffic 1.37x -> see profiles/env_step_traffic.json); QA_LEAN_EXPORTS=0 keeps the reference's behaviour
-            if on_gpu and hasattr(env, "set_lean_exports") and os.environ.get("QA_LEAN_EXPORTS", "1") != "0" and not getattr(env, "sync_reset_ids", False):
-                env.set_lean_exports(1 if self.amp_enabled else 3)
+        # training never reads the per-step exports of the env (seam 1 / play / logging tensors): the fused step stops writing them WHILE
+        # learn() runs (r4: measured traffic 1.37x -> see profiles/env_step_traffic.json); QA_LEAN_EXPORTS=0 keeps the reference's behaviour.
+        # r5: the lean kernel keeps a two-slot action ring, so it is only chosen when neither the current action delay nor any
+        # delay still in the schedule exceeds one step, and the full exports come back when learn() returns (eval / play / seam-1 readers in
+        # the same process must not see frozen tensors).  The rollout recordings bake the kernel variant in: they are dropped if the mask changes.
+        lean = self._lean_mask_for(env)
+        if lean != getattr(self, "_lean_recorded", lean):
+            self._graph, self._graphs = None, {}
+        self._lean_recorded = lean
+        if hasattr(env, "set_lean_exports") and torch.device(dev).type == "cuda":
+            env.set_lean_exports(lean)
+        try:
+            self._learn_loop(num_learning_iterations)
+        finally:
+            if lean and hasattr(env, "set_lean_exports"):
+                env.set_lean_exports(0)
+
+    def _lean_mask_for(self, env):
+        if (torch.device(self.device).type != "cuda" or not hasattr(env, "set_lean_exports") or os.environ.get("QA_LEAN_EXPORTS", "1") == "0"
+                or getattr(env, "sync_reset_ids", False)):
+            return 0
+        delays = [int(getattr(env, "delay", 0))] + [int(d) for d in getattr(env, "_delay_schedule", [])]
+        if env.cfg.domain_rand.action_delay and max(delays) > 1:
+            return 0
+        return 1 if self.amp_enabled else 3
+
+    def _learn_loop(self, num_learning_iterations):
+        env, alg, dev = self.env, self.alg, self.device
         alg.actor_critic.train()
         alg.disc.train()
         N, T = env.num_envs, self.num_steps_per_env

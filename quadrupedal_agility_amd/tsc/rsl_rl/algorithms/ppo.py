@@ -171,10 +171,13 @@ class PPO:
         """:127-137 -- joint targets of the frozen behaviour controller (history branch, mean action)."""
         return self.actor_critic_bbc.act_inference(self._with_estimated_states(obs, False), hist_encoding=True).detach()
 
-    def store_transition_rows(self):
+    def store_transition_rows(self, dones=None):
         """the transition's rows other than reward / done go into the storage now (add_transitions' copies); the caller's kernel writes those
-        two (qa_rollout_post_amp) -- returns the storage step it must write to"""
+        two (qa_rollout_post_amp) -- returns the storage step it must write to.  `dones`: process_env_step's actor_critic.reset(dones)
+        (a no-op for the feed-forward policy; kept so that the two paths cannot diverge if a recurrent policy is plugged in -- ADVICE r4)"""
         tr, st = self.transition, self.storage
+        if dones is not None:
+            self.actor_critic.reset(dones)
         if st.step >= st.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         t = st.step

@@ -185,7 +185,10 @@ class OnPolicyRunner:
             lib, disc, st, N = _capi.load_library(), self.discriminator, alg.storage, env.num_envs
             P = lambda x: C.c_void_p(x.data_ptr())
         for t in range(self.num_steps_per_env):
-            hybrid = tchain is not None and dchain is not None and self.use_hybrid_act and getattr(env, "_step_dev", None) is not None and env._step_dev.is_cuda
+            #  the two history buffers swap ROLES on the host every step and a recording bakes both addresses in: with an odd number of
+            # steps the newest history would end in the other buffer than the one the next replay starts reading -- the hybrid launch needs an even T
+            hybrid = (tchain is not None and dchain is not None and self.use_hybrid_act and getattr(env, "_step_dev", None) is not None and env._step_dev.is_cuda
+                      and self.num_steps_per_env % 2 == 0)
             if hybrid:
                 if "ahist2" not in rs:
                     rs["ahist2"] = torch.zeros_like(rs["ahist"])
@@ -207,9 +210,11 @@ class OnPolicyRunner:
                 # reward mapping, mixing, time-out bootstrap, reward / done rows of the storage and the episode sums, three launches
                 x = fused.disc_prepare([hist.view(N, -1)], disc._task_mask, disc._frame_mult.view(-1), None, disc.normalizer)
                 d, eps, logits = dchain.forward(x)
-                ts = alg.store_transition_rows()
+                ts = alg.store_transition_rows(dones)
                 log_ptrs = (P(rs["cur"]), P(rs["fin_vals"][ts]), P(rs["fin_masks"][ts])) if logging else (None, None, None)
-                rc = lib.qa_rollout_post_amp(P(rewards), P(dones.to(torch.int64)), P(env.bk.time_out_buf), P(st.values[ts]), P(d), P(eps), P(logits), int(disc.dim_c),
+                #  the reference bootstraps time-outs only when the env sends them (`'time_outs' in infos` <=> cfg.env.send_timeouts)
+                tout = env.bk.time_out_buf if "time_outs" in infos else self._no_timeouts(env)
+                rc = lib.qa_rollout_post_amp(P(rewards), P(dones.to(torch.int64)), P(tout), P(st.values[ts]), P(d), P(eps), P(logits), int(disc.dim_c),
                                              P(rs["obs_bbc"]), int(rs["obs_bbc"].stride(0)), int(rs["obs_bbc"].shape[1]),
                                              float(disc.reward_i_coef), float(disc.reward_us_coef), float(disc.reward_ss_coef), float(disc.reward_t_coef),
                                              float(disc.dt), float(alg.gamma), N, P(st.rewards[ts]), P(st.dones[ts]), *log_ptrs,
@@ -234,6 +239,12 @@ class OnPolicyRunner:
             torch.where(done.view(-1, 1, 1), disc_obs.unsqueeze(1), hist, out=rs["hist"])
         return ep_infos
 
+    def _no_timeouts(self, env):
+        z = getattr(self, "_zero_timeouts", None)
+        if z is None or z.shape != env.bk.time_out_buf.shape:
+            z = self._zero_timeouts = torch.zeros_like(env.bk.time_out_buf)
+        return z
+
     def _collect(self, hist_encoding, logging):
         """One rollout.  On the GPU the 24 steps are recorded into ONE hipGraph per actor variant (privileged / history encoder) the
         first time they run and replayed afterwards: an eager step is ~180 launches and 1.8 ms of host time against 0.3 ms of kernels.
@@ -248,7 +259,13 @@ class OnPolicyRunner:
             with torch.inference_mode():
                 return self._rollout_steps(hist_encoding, logging)
         if key not in self._rollout_graphs:
-            if self._rollout_warm < 1:         # one eager rollout first: lazy initialisations (policy chain packing, library handles)
+            # one eager rollout of THIS variant first (it used to be one per runner, so the first privileged-encoder rollout built its
+            # chain description, its action buffers and the second history buffer INSIDE the capture): lazy initialisations happen eagerly
+            warm = getattr(self, "_rollout_warm_keys", None)
+            if warm is None:
+                warm = self._rollout_warm_keys = set()
+            if key not in warm:
+                warm.add(key)
                 self._rollout_warm += 1
                 with torch.inference_mode():
                     return self._rollout_steps(hist_encoding, logging)

@@ -36,6 +36,39 @@ TOL = {
     "FOOT_IMPULSE": (1.3e-4, 0),                                                  # p99.9 4.2e-5 N s
     "BASE_LIN_VEL": (6e-5, 0), "BASE_ANG_VEL": (6e-4, 0), "PROJECTED_GRAVITY": (3e-6, 0), "RPY": (5e-6, 0),   # p99.9 1.8e-5 / 1.8e-4 / 1.0e-6 / 1.4e-6
 }
+# The ACCURACY statement: TOL above is a fence around the kernel's own error TAIL -- a defect that was present when the
+# distribution was taken sits inside it by construction.  What says "this env step is computed to ~1e-5 relative" is the MEDIAN env-step error,
+# asserted here per tensor over all env-steps of the test: 3 x the p50 of profiles/r4_step_error_distribution.json (quoted beside each entry),
+# floored at one fp32 ulp of the tensor's largest value.  A systematic error (a wrong term, a stale operand) moves the median of every env, not the tail.
+MEDIAN_TOL = {
+    "ROOT_STATES": 5e-6, "LAST_ROOT_VEL": 5e-6,            # p50 1.4e-6 on positions up to 96 m (one ulp 7.6e-6) and velocities up to 41 m/s
+    "DOF_STATE": 6e-5, "LAST_DOF_VEL": 6e-5,               # p50 2.0e-5 on velocities up to 30 rad/s (7e-7 relative)
+    "CONTACT_FORCES": 5e-4, "FEET_FORCE": 4e-4,            # p50 1.7e-4 / 1.2e-4 N on forces up to 5,000 N
+    "RIGID_BODY_POS": 8e-6,                                # p50 6e-8; floor: one ulp at 64-128 m
+    "TORQUES": 7e-5, "TORQUES_ORG": 8e-5, "LAST_TORQUES_ORG": 8e-5,   # p50 2.1e-5 / 2.4e-5 Nm
+    "OBS": 4e-6, "OBS_DISC": 4e-6, "OBS_DISC_TERM": 4e-6,  # p50 1.2e-6
+    "REW": 1e-8, "EPISODE_SUMS": 2e-6,                     # p50 0 / 1.5e-8 (floor: one ulp of a 32-point sum)
+    "FOOT_IMPULSE": 3e-6,                                  # p50 7.2e-7 N s
+    "BASE_LIN_VEL": 8e-7, "BASE_ANG_VEL": 5e-6, "PROJECTED_GRAVITY": 4e-7, "RPY": 3e-7,   # p50 2.4e-7 / 1.7e-6 / 1.2e-7 / 4.5e-8
+}
+
+
+def env_errors(name, a, b, n_envs):
+    """per-env error of one tensor: max over the env's elements of |a - b|"""
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    if name == "EPISODE_SUMS":
+        a = a.T; b = b.T
+    return np.abs(a - b).reshape(n_envs, -1).max(axis=1)
+
+
+def check_medians(per_tensor_errors):
+    """per_tensor_errors: {tensor: [per-env error arrays, one per step]}"""
+    med = {k: float(np.median(np.concatenate(v))) for k, v in per_tensor_errors.items()}
+    print("median env-step error per tensor:", {k: f"{v:.2e}" for k, v in med.items()})
+    bad = {k: (v, MEDIAN_TOL[k]) for k, v in med.items() if v > MEDIAN_TOL[k]}
+    assert not bad, f"median env-step error above 3 x the measured p50: {bad}"
+
+
 # share of env-steps allowed outside TOL per protocol: ~2x the share measured with this TOL table on MI355X (profiles/r4_parity_flip_shares.txt,
 # `QA_PARITY_MEASURE=1 pytest -m gpu -s -k parity`); filled in from that run
 # measured (r4, MI355X): plane 0.08 %, height field 1.1-1.5 %, ceiling 3.75 %, mocap 0.04 %, self-collision 0.10 %, articulated 0.1 % (64 envs) / 3.7 % (8192 envs,
@@ -106,6 +139,7 @@ def test_single_step_parity(n_envs, seed, slots):
     o.t["EPISODE_LENGTH"][:] = rng.integers(0, 1000, n_envs)
     o.global_step = 380
     worst = {}
+    per_env = {k: [] for k in MEDIAN_TOL}
     flips = 0
     steps = 40
     for k in range(steps):
@@ -122,6 +156,8 @@ def test_single_step_parity(n_envs, seed, slots):
             err = np.abs(got.astype(np.float64) - exp.astype(np.float64)).max()
             worst[name] = max(worst.get(name, 0.0), float(err))
             bad_env |= env_mismatch(name, got, exp, n_envs)
+            if name in per_env:
+                per_env[name].append(env_errors(name, got, exp, n_envs))
         flips += int(bad_env.sum())
         # reduction over resetting envs: atomics in any order
         st_g = h.t["EPISODE_STATS"].cpu().numpy()[(o.global_step - 1) & 1]; st_o = o.t["EPISODE_STATS"][(o.global_step - 1) & 1]
@@ -130,6 +166,7 @@ def test_single_step_parity(n_envs, seed, slots):
     print("worst abs error per tensor:", {k: f"{v:.2e}" for k, v in worst.items()})
     print(f"env-steps outside tolerance (discrete-event flips): {flips} of {steps * n_envs}")
     check_flips(f"plane_{n_envs}_slots{slots}", flips, steps * n_envs, BUDGET["plane"])            # contact on/off flips (tools/flip_probe.py)
+    check_medians(per_env)
 
 
 def test_integer_outputs_exact_when_physics_agrees():

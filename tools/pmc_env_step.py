@@ -3,6 +3,9 @@ calibration stream of known size (a 256 MiB float32 copy: 256 MiB read + 256 MiB
 import sys
 import torch
 sys.path.insert(0, ".")
+import os
+from quadrupedal_agility_amd import _capi
+if os.environ.get("QA_LIB"): _capi.LIB_PATH = os.environ["QA_LIB"]        # an alternative build of the library (A/B counter passes)
 from tests.oracle_lib import go2_cfg
 from quadrupedal_agility_amd.sim import QaSim
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

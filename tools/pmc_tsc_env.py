@@ -19,8 +19,13 @@ if sys.argv[1] != "summarize":
     for _ in range(30):                                    # robots on and between the obstacles, some fallen
         env.sim.physics_step(torch.randn(n, 12, device="cuda", generator=g) * 0.5, 1)
     act = torch.randn(n, 12, device="cuda", generator=g) * 0.3
-    for _ in range(40):
-        env.sim.physics_step(act, 1)
+    if len(sys.argv) > 2 and sys.argv[2] == "full":       # (r5) the whole task-level env step: physics + goal step + reset + observations (bench.py --tsc's roofline kernels)
+        hist = torch.zeros(n, 8, 19, device="cuda")
+        for _ in range(40):
+            env.step(act, hist)
+    else:
+        for _ in range(40):
+            env.sim.physics_step(act, 1)
     x = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
     for _ in range(5):
         y = x.clone()

@@ -1,0 +1,97 @@
+#!/bin/bash
+# Round 5: the GPU calls as they were run, one case per call (gpurun -- 'bash tools/r5_call.sh <case>').  Outputs under gpurun_out/r5/<case>/.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+C=${1:-none}
+O=$R/gpurun_out/r5/$C
+mkdir -p $O
+cd $R
+case $C in
+valu)      # what one wavefront alone can issue (tools/valu_rate.hip) + today's baseline lines
+    timeout 120 tools/_prof/valu_rate > $O/valu_rate.txt 2>&1
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512.json
+    timeout 200 python tools/substep_profile.py > $O/substep_profile.txt 2>&1 < /dev/null
+    timeout 200 python tools/quick_time.py > $O/quick_time.txt 2>&1 < /dev/null
+    ;;
+envpk)     # packed rows + sweeps (r5) against the round-4 scalar build (tools/_prof/libqa_sim_scalar.so = -DQA_PGS_SCALAR): parity first, then timing, stamps, SQ counters
+    timeout 900 python -m pytest tests/test_hip_parity.py tests/test_self_collision.py tests/test_articulated_obstacles.py tests/test_full_size_properties.py tests/test_mocap_reset.py -m gpu -x -q > $O/pytest_env.log 2>&1; tail -5 $O/pytest_env.log
+    for i in 1 2; do
+      timeout 200 python tools/quick_time.py > $O/quick_time_packed_$i.txt 2>&1 < /dev/null
+      QA_LIB=$R/tools/_prof/libqa_sim_scalar.so timeout 200 python tools/quick_time.py > $O/quick_time_scalar_$i.txt 2>&1 < /dev/null
+    done
+    timeout 300 python tools/substep_profile.py > $O/substep_profile_packed.txt 2>&1 < /dev/null
+    timeout 300 python tools/substep_profile.py -DQA_PGS_SCALAR > $O/substep_profile_scalar.txt 2>&1 < /dev/null
+    export TMPDIR=/tmp
+    SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
+    rm -rf /tmp/pmc_sq; timeout 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d /tmp/pmc_sq -- python $R/tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_sq.log 2>&1
+    python $R/tools/pmc_tsc_env.py summarize /tmp/pmc_sq > $O/env_step_sq_counters_packed.txt 2>&1
+    rm -rf /tmp/pmc_sq2; QA_LIB=$R/tools/_prof/libqa_sim_scalar.so timeout 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d /tmp/pmc_sq2 -- python $R/tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_sq2.log 2>&1
+    python $R/tools/pmc_tsc_env.py summarize /tmp/pmc_sq2 > $O/env_step_sq_counters_scalar.txt 2>&1
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_scalar.so $R/tools/_prof/libqa_sim_packed.so 30 1024 1.0 > $O/lockstep.txt 2>&1; tail -4 $O/lockstep.txt | cut -c1-200
+    ;;
+dbg)       # bisect the packed sweeps' parity failure: unit test of the building blocks, then arenas after K steps per build against the scalar build
+    timeout 60 tools/_prof/pgs_unit > $O/pgs_unit.txt 2>&1; cat $O/pgs_unit.txt
+    for v in scalar packed lanebr quadsum both; do for K in 1 6; do QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 120 python tools/ab_step.py run /tmp/ab_${v}_$K.npy $K > /dev/null 2>&1; done; done
+    for v in packed lanebr quadsum both; do for K in 1 6; do echo "== $v vs scalar, $K steps" >> $O/ab.txt; python tools/ab_step.py cmp /tmp/ab_scalar_$K.npy /tmp/ab_${v}_$K.npy >> $O/ab.txt 2>&1; done; done
+    cat $O/ab.txt
+    # the DMA GEMM with 16-byte fragment reads on index-contiguous operands
+    timeout 600 python -m pytest tests/test_gemm_layers.py -m gpu -x -q > $O/pytest_gemm.log 2>&1; tail -5 $O/pytest_gemm.log
+    timeout 600 python tools/gemm_dma_bench.py --json $O/gemm_dma_bench.json > $O/gemm_dma_bench.txt 2>&1; tail -40 $O/gemm_dma_bench.txt
+    ;;
+dbg2)      # which rare path: small actions (no joint stops), one contact slot, no self-collision
+    for cfgs in "1.0:" "0.2:" "1.0:contact_slots=1" "1.0:self_collision=0" "3.0:" "3.0:contact_slots=1,self_collision=0"; do
+      act=${cfgs%%:*}; cf=${cfgs#*:}
+      for v in scalar packed; do AB_ACT=$act AB_CFG=$cf QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 120 python tools/ab_step.py run /tmp/ab_$v.npy 12 256 > /dev/null 2>&1; done
+      echo "== actions x $act, cfg [$cf], 12 steps, 256 envs" >> $O/ab.txt; python tools/ab_step.py cmp /tmp/ab_scalar.npy /tmp/ab_packed.npy >> $O/ab.txt 2>&1
+    done
+    cat $O/ab.txt
+    ;;
+dbg3)      # scalar rows / scalar warm start inside the packed build, and an -O1 build
+    for v in scalar packed srows swarm sboth o1; do AB_ACT=0.2 QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 120 python tools/ab_step.py run /tmp/ab_$v.npy 12 256 > /dev/null 2>&1; done
+    for v in packed srows swarm sboth o1; do echo "== $v vs scalar (actions x 0.2, 12 steps, 256 envs)" >> $O/ab.txt; python tools/ab_step.py cmp /tmp/ab_scalar.npy /tmp/ab_$v.npy >> $O/ab.txt 2>&1; done
+    cat $O/ab.txt
+    ;;
+dbg4)      # scalar and packed builds in lockstep from the scalar build's arena: the first step in which they part
+    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_scalar.so $R/tools/_prof/libqa_sim_packed.so 20 256 0.2 > $O/lockstep.txt 2>&1; cat $O/lockstep.txt
+    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_scalar.so $R/tools/_prof/libqa_sim_scalar.so 20 256 0.2 > $O/lockstep_self.txt 2>&1; tail -3 $O/lockstep_self.txt
+    QA_LIB=$R/tools/_prof/libqa_sim_scalar.so timeout 300 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "single_step_parity and 64" 2>&1 | tail -5
+    ;;
+dbg5)      # the joint-limit rows: unit test, and both builds with the limit rows compiled out
+    timeout 60 tools/_prof/pgs_unit > $O/pgs_unit.txt 2>&1; cat $O/pgs_unit.txt
+    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_nolim_sc.so $R/tools/_prof/libqa_sim_nolim_pk.so 20 256 0.2 > $O/lockstep_nolimits.txt 2>&1; cat $O/lockstep_nolimits.txt | cut -c1-250
+    ;;
+dbg6)      # packed rows + LDS layout, SCALAR sweeps, no limit rows, against the scalar build without limit rows
+    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_nolim_sc.so $R/tools/_prof/libqa_sim_ssweep.so 20 256 0.2 > $O/lockstep.txt 2>&1; cat $O/lockstep.txt | cut -c1-250
+    ;;
+learn1)    # gradients left in parts, finished by the optimiser's first pass: tests, then the bench line with and without
+    timeout 1500 python -m pytest tests/test_grad_parts.py tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_gemm_layers.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log
+    for i in 1 2; do
+      QA_DEFER_GRAD_FINISH=0 timeout 400 python bench.py --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_finish_launches_$i.json
+      timeout 400 python bench.py --no_cpu_baseline 2> $O/bench.err < /dev/null | grep '"metric"' > $O/bench_cfg2_deferred_$i.json
+    done
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5/learn1/bench_*.json")):
+    try:
+        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round(d["collection_s"] * 1e3, 2), "update", round(d["learn_s"] * 1e3, 2))
+    except Exception as e: print(f, "no line", e)
+PY
+    ;;
+phase)     # where the env-step kernel's wavefront waits: s_memtime stamps per phase; the learner tests; the 512-env share with / without deferred finishes
+    timeout 300 python tools/phase_profile.py > $O/phase_profile.txt 2>&1; cat $O/phase_profile.txt
+    timeout 1500 python -m pytest tests/test_grad_parts.py tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py -m gpu -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log
+    QA_DEFER_GRAD_FINISH=0 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_finish_launches.json
+    timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_deferred.json
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5/phase/bench_*.json")):
+    try:
+        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round(d["collection_s"] * 1e3, 2), "update", round(d["learn_s"] * 1e3, 2))
+    except Exception as e: print(f, "no line", e)
+PY
+    ;;
+*) echo "unknown case $C"; exit 2;;
+esac
+ls -la $O
