@@ -371,6 +371,12 @@ def bench_tsc(args, world, rank, local_rank, dev):
     kern_ms = sum(spans.values())
     alg_bytes = TSC_ALG_BYTES_PER_ENV_STEP + (DEPTH_ALG_BYTES_PER_ENV_STEP if args.vision else 0)
     achieved = alg_bytes * n / (kern_ms * 1e-3) / 1e9
+    # r5: the task-level env step's HBM bytes from a stamped PMC pass of the same three kernels at THIS env count
+    # (tools/final_measure.sh -> profiles/tsc_env_step_traffic.json), or null with the reason
+    import __graft_entry__ as g
+    sized = f"tsc_env_step_traffic_{n}.json"
+    tsc_traffic, tsc_traffic_note = ((None, "no PMC pass of the depth kernel on file") if args.vision else
+                                     _stamped_traffic(g, n, sized if os.path.exists(os.path.join(ROOT, "profiles", sized)) else "tsc_env_step_traffic.json"))
     what = ("TSC-student with depth-camera obs (58x87 ray-cast depth image per env step, depth encoder + GRU + student actor, DAgger + BYOL)" if args.vision else
             "TSC-teacher agility course")
     out = {"metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU", "value": n * T * args.steps * world / dt, "unit": "env-steps/s",
@@ -385,7 +391,7 @@ def bench_tsc(args, world, rank, local_rank, dev):
            "phase_split": "rollout alone between device syncs after the timed region (median of 5); update = iteration - rollout" if coll_s is not None else "not split (learn_vision interleaves env steps and the student's forward passes)",
            "roofline": {"kernel": "qa_env_step_kernel<false,4,1> + qa_tsc_goal_step + qa_tsc_observations" + (" + qa_tsc_depth_kernel" if args.vision else ""),
                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms, "kernel_ms_each": spans,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tsc_traffic, "traffic_source": tsc_traffic_note, "kernel_ms": kern_ms, "kernel_ms_each": spans,
                         "algorithmic_bytes_per_launch": alg_bytes * n}}
     if args.vision:
         out["vision"] = dict(runner.last_vision)

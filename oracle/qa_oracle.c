@@ -510,9 +510,15 @@ static void segment_closest(const double A0[3], const double A1[3], const double
 }
 #define CALF_RADIUS 0.013
 #define FOOT_RADIUS 0.022
-static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate);
-static void phys_substep(qo_sim *s, int e, const float tau_in[12]) { phys_substep_acc(s, e, tau_in, 0); }
-static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate) {
+/* r5: the horizontal position of the root is carried across the substeps of ONE env step as an offset from the world position the step
+ * starts at (double), not re-read from the fp32 arena after every substep: 900 m from the origin -- where the 8192-env course puts its last
+ * envs -- an fp32 world coordinate resolves 6e-5 m, and four roundings per env step moved contact gaps by more than the kernel's and this
+ * restatement's arithmetic ever differ.  The kernel does the same in fp32 offsets (csrc/qa_physics.h, TerrainView); the arena still
+ * receives the rounded world position after every substep (it is what the gym tensors show), it is just not read back. */
+typedef struct { double ax, ay, lx, ly; } StepAnchor;
+static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate, StepAnchor *an);
+static void phys_substep(qo_sim *s, int e, const float tau_in[12]) { phys_substep_acc(s, e, tau_in, 0, NULL); }
+static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accumulate, StepAnchor *an) {
     const qa_config *cfg = &s->cfg;
     float *root = TP(s, QA_T_ROOT_STATES, float) + 13 * e;
     float *dof = TP(s, QA_T_DOF_STATE, float) + 24 * e;
@@ -520,7 +526,7 @@ static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accum
     float *rbp = TP(s, QA_T_RIGID_BODY_POS, float) + 57 * e;
     const float *binert = TP(s, QA_T_BASE_INERTIA, float) + 10 * e;
     double dt = cfg->sim_dt;
-    double pos[3] = {root[0], root[1], root[2]}, quat[4] = {root[3], root[4], root[5], root[6]};
+    double pos[3] = {an ? an->ax + an->lx : (double)root[0], an ? an->ay + an->ly : (double)root[1], root[2]}, quat[4] = {root[3], root[4], root[5], root[6]};
     m3 R; quat_to_mat(quat, R);
     v3 vw = {root[7], root[8], root[9]}, ww = {root[10], root[11], root[12]}, gw = {0, 0, cfg->gravity_z}, gB;
     double ub[6]; mtv(R, ww, ub); mtv(R, vw, ub + 3); mtv(R, gw, gB);
@@ -755,6 +761,7 @@ static void phys_substep_acc(qo_sim *s, int e, const float tau_in[12], int accum
         quat[3] * dq[2] + quat[0] * dq[1] - quat[1] * dq[0] + quat[2] * dq[3],
         quat[3] * dq[3] - quat[0] * dq[0] - quat[1] * dq[1] - quat[2] * dq[2]};
     double nn = 1.0 / sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    if (an) { an->lx = pos[0] - an->ax; an->ly = pos[1] - an->ay; }
     for (int i = 0; i < 3; ++i) { root[i] = (float)pos[i]; root[7 + i] = (float)vn[i]; root[10 + i] = (float)wn[i]; }
     for (int i = 0; i < 4; ++i) root[3 + i] = (float)(qn[i] * nn);
     for (int j = 0; j < 12; ++j) { dof[2 * j] = (float)(q[j] + dt * u[6 + j]); dof[2 * j + 1] = (float)u[6 + j]; }
@@ -1253,7 +1260,8 @@ int qo_env_physics_step(qo_sim *s, const float *actions, int32_t delay_steps, vo
         float clipa = c->clip_actions / c->action_scale;
         for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
         obstacles_begin_step(s, e);
-        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep_acc(s, e, tau, 1); }
+        StepAnchor an = {(double)(TP(s, QA_T_ROOT_STATES, float) + 13 * e)[0], (double)(TP(s, QA_T_ROOT_STATES, float) + 13 * e)[1], 0.0, 0.0};
+        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep_acc(s, e, tau, 1, &an); }
         obstacles_end_step(s, e);
     }
     return QA_OK;
@@ -1320,9 +1328,10 @@ int qo_env_step(qo_sim *s, const float *actions, int32_t delay_steps, int64_t st
         for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
         float *tau = TP(s, QA_T_TORQUES, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e;
         obstacles_begin_step(s, e);
+        StepAnchor an = {(double)(TP(s, QA_T_ROOT_STATES, float) + 13 * e)[0], (double)(TP(s, QA_T_ROOT_STATES, float) + 13 * e)[1], 0.0, 0.0};
         for (int d = 0; d < c->decimation; ++d) {     /* :101-106 */
             compute_torques(s, e, act, tau, torg);
-            phys_substep_acc(s, e, tau, 1);
+            phys_substep_acc(s, e, tau, 1, &an);
         }
         obstacles_end_step(s, e);
         float tmp[QA_NUM_OBS_DISC];
@@ -2415,7 +2424,8 @@ int qo_debug_pre_physics(qo_sim *s, const float *actions, int32_t delay_steps) {
         for (int j = 0; j < 12; ++j) act[j] = clipf(src[j], -clipa, clipa);
         float *tau = TP(s, QA_T_TORQUES, float) + 12 * e, *torg = TP(s, QA_T_TORQUES_ORG, float) + 12 * e;
         obstacles_begin_step(s, e);
-        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep_acc(s, e, tau, 1); }
+        StepAnchor an = {(double)(TP(s, QA_T_ROOT_STATES, float) + 13 * e)[0], (double)(TP(s, QA_T_ROOT_STATES, float) + 13 * e)[1], 0.0, 0.0};
+        for (int d = 0; d < c->decimation; ++d) { compute_torques(s, e, act, tau, torg); phys_substep_acc(s, e, tau, 1, &an); }
         obstacles_end_step(s, e);
     }
     return QA_OK;

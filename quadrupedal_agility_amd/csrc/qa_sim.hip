@@ -246,18 +246,21 @@ __device__ __forceinline__ TerrainView terrain_view(const qa_config &c, const Pt
     T.patch = patch; T.samples = p.height_samples; T.ceil = c.hf_ceiling ? p.ceil_samples : nullptr; T.ix0 = 0; T.iy0 = 0; T.rows = c.hf_rows; T.cols = c.hf_cols;
     T.border = c.hf_border; T.hscale = c.hf_hscale; T.inv_hscale = 1.0f / c.hf_hscale; T.vscale = c.hf_vscale;
     T.ob = nullptr; T.ob_acc = nullptr;
+    T.cax = 0; T.cay = 0; T.fax = 0.f; T.fay = 0.f; T.ancx = 0.f; T.ancy = 0.f;
     return T;
 }
 
 // articulated obstacles of an env -> LDS: lane k < 3 of the quad loads slot k (8 descriptor floats + q, q_dot, -, damping) and clears the
 // slot's force accumulator; QA_OB_LDS floats per env
 #define QA_OB_LDS (12 * QA_OBST_PER_ENV + 4)
-QA_DEV void stage_obstacles(const Ptrs &p, int env, int leg, float *rec) {
+QA_DEV void stage_obstacles(const Ptrs &p, int env, int leg, float *rec, float ancx, float ancy) {
     if (leg < QA_OBST_PER_ENV) {
         const float *d = p.obst_desc + ((int64_t)env * QA_OBST_PER_ENV + leg) * QA_OBST_DESC;
         const float *st = p.obst_state + ((int64_t)env * QA_OBST_PER_ENV + leg) * QA_OBST_STATE;
 #pragma unroll
         for (int i = 0; i < QA_OBST_DESC; ++i) rec[12 * leg + i] = d[i];
+        // the obstacle's centre relative to the step's anchor (the contact queries work in env-local coordinates, qa_physics.h)
+        rec[12 * leg] = (float)((double)d[0] - (double)ancx); rec[12 * leg + 1] = (float)((double)d[1] - (double)ancy);
         rec[12 * leg + 8] = st[0]; rec[12 * leg + 9] = st[1]; rec[12 * leg + 10] = 0.f; rec[12 * leg + 11] = st[3];
         rec[12 * QA_OBST_PER_ENV + leg] = 0.f;
     }
@@ -698,11 +701,17 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
     const int N = c.num_envs;
-    if (MODE == 0 && LPE == 4) {                       // the table staging runs under the history loads' latency
-        float hv[EPB][9];
+    // r5: the history shift's 144 loads per lane are issued here and its stores AFTER the physics (QA_SHIFT_EARLY_STORE restores r2's
+    // load -> stage table -> store prologue).  All 256 wavefronts of a 4096-env launch start together, so the prologue's 17 MB read + 17 MB
+    // write was a burst nobody overlapped: 9.7 k of the kernel's 136 k ticks waiting for it (profiles/r5_env_step_phase_profile.txt).  The
+    // values wait in registers the substeps do not use (the compiler parks them in AGPRs: 2 x 144 v_accvgpr moves, ~1.3 k ticks).
+    float hv[EPB][9];
+    if (MODE == 0 && LPE == 4) {
         shift_history_load<EPB>(p, bix, tix, N, hv);
         stage_table(s_tbl);
+#ifdef QA_SHIFT_EARLY_STORE
         shift_history_store<EPB>(p, bix, tix, N, hv);
+#endif
     } else {
         stage_table(s_tbl);
     }
@@ -804,9 +813,12 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     if (!PLANE) {
         patch_origin(T, st.pos.x, st.pos.y);
         stage_patch(T, s_patch + le * (QA_PATCH * QA_PATCH), leg);
-        if (c.articulated_obstacles) { stage_obstacles(p, env, leg, ob_rec); T.ob = ob_rec; T.ob_acc = ob_rec + 12 * QA_OBST_PER_ENV; }
+        if (c.articulated_obstacles) { stage_obstacles(p, env, leg, ob_rec, T.ancx, T.ancy); T.ob = ob_rec; T.ob_acc = ob_rec + 12 * QA_OBST_PER_ENV; }
         wave_lds_sync();
     }
+    // env-local horizontal coordinates for the substeps (TerrainView): offsets from the world position the step starts at
+    const float anc_x = st.pos.x, anc_y = st.pos.y;
+    st.pos.x = 0.f; st.pos.y = 0.f;
 
     QA_STAMP(2);
     // ---- decimation x (PD torque -> physics)   legged_robot.py:101-106, :547-579
@@ -838,6 +850,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
     }
     { float bi_[10]; priv_unpark(priv, act, sp, sd, bi_); }
+    st.pos.x += anc_x; st.pos.y += anc_y;               // back to world coordinates: ONE rounding per step, like the oracle's double -> float store
     // ---- the articulated obstacles' joints: one step of h = decimation x dt under the mean contact force of the substeps (lane k: slot k)
     if (!PLANE) {
         if (c.articulated_obstacles) {
@@ -853,6 +866,9 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     }
 
     QA_STAMP(3);
+#ifndef QA_SHIFT_EARLY_STORE
+    if (MODE == 0 && LPE == 4) shift_history_store<EPB>(p, bix, tix, N, hv);     // in place: every lane loaded its 9 values of a row long ago; the tail's writes to the same rows come after these in program order
+#endif
     // ---- refresh_*: body positions of the new state, contact forces per body
     V3 org[4];
     leg_origins(st.q, tbl, org);
@@ -1080,11 +1096,14 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_simulate_kernel(qa_config c, Ptrs
         stage_patch(T, mine, leg);
         if (c.articulated_obstacles) {          // the obstacles' geometry and surface velocity; their joints only move in env steps
             float *rec = s_ob + (threadIdx.x >> 2) * QA_OB_LDS;
-            stage_obstacles(p, env, leg, rec); T.ob = rec;
+            stage_obstacles(p, env, leg, rec, T.ancx, T.ancy); T.ob = rec;
         }
         wave_lds_sync();
     }
+    const float anc_x = st.pos.x, anc_y = st.pos.y;     // env-local horizontal coordinates inside the substep (TerrainView)
+    st.pos.x = 0.f; st.pos.y = 0.f;
     phys_substep<PLANE>(st, tbl, btbl, binert, tau, 0.5f * (p.friction[env] + c.ground_friction), leg, P, co, priv_of(s_priv, threadIdx.x), fimp, T);
+    st.pos.x += anc_x; st.pos.y += anc_y;
     V3 org[4]; leg_origins(st.q, tbl, org);
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     V3 z = v3(0, 0, 0);

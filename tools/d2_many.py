@@ -25,6 +25,7 @@ ARM_ENV = {
     "nodisc": {"QA_PARITY_NO_DISC_GRAPH": "1"},
     "noac": {"QA_PARITY_NO_AC_GRAPH": "1"},
     "eagerupd": {"QA_PARITY_EAGER_UPDATE": "1"},
+    "hybrid": {"QA_D2_SIDE": "hybrid"},        # r5: oracle physics on the host cores + the GPU learner (tools/hybrid_backend.py); OMP threads per job = --hybrid_threads
 }
 KEEP = ("Train/mean_reward", "Train/mean_reward_t", "Train/mean_reward_i", "Train/mean_episode_length", "Episode/rew_tracking_lin_vel",
         "Episode/rew_tracking_ang_vel", "Episode/rew_collision", "Episode/rew_dof_error", "Episode/rew_torques")
@@ -59,6 +60,7 @@ def main():
     ap.add_argument("--job_timeout", type=int, default=1500)
     ap.add_argument("--budget_s", type=int, default=10 ** 9, help="stop STARTING jobs after this many seconds")
     ap.add_argument("--plain", action="store_true", help="config 2 (no --amp)")
+    ap.add_argument("--hybrid_threads", type=int, default=24, help="OpenMP threads of one hybrid-arm job (oracle physics)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     jobs = []
@@ -98,7 +100,10 @@ def main():
             if os.path.exists(out):
                 continue
             env = dict(os.environ, **ARM_ENV[arm])
-            cmd = [sys.executable, os.path.join(ROOT, "tools", "return_curve_parity.py"), "--side", "gpu", "--num_envs", str(a.num_envs), "--iters", str(a.iters),
+            side = env.pop("QA_D2_SIDE", "gpu")
+            if side == "hybrid":
+                env["OMP_NUM_THREADS"] = str(a.hybrid_threads)
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "return_curve_parity.py"), "--side", side, "--num_envs", str(a.num_envs), "--iters", str(a.iters),
                    "--seeds", str(s), "--out", out] + amp
             p = subprocess.Popen(cmd, env=env, stdout=open(out.replace(".json", ".log"), "w"), stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
             running.append((arm, s, out, p, time.time()))

@@ -15,6 +15,13 @@ python tools/pmc_to_json.py /tmp/pmc_f /tmp/pmc_w 4096 $O/env_step_traffic.json 
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f0 -- python tools/pmc_env_step.py 4096 0 < /dev/null > /tmp/pmc_f0.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w0 -- python tools/pmc_env_step.py 4096 0 < /dev/null > /tmp/pmc_w0.log 2>&1
 python tools/pmc_to_json.py /tmp/pmc_f0 /tmp/pmc_w0 4096 $O/env_step_traffic_full_exports.json 0 >> $O/pmc.txt 2>&1
+# (r5) the task-level env step (physics + goal step + observations, the three launches of bench.py --tsc's roofline object) at the two env counts its bench lines use
+for NE in 8192 1024; do
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tf$NE -- python tools/pmc_tsc_env.py $NE full < /dev/null > /tmp/pmc_tf.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tw$NE -- python tools/pmc_tsc_env.py $NE full < /dev/null > /tmp/pmc_tw.log 2>&1
+  python tools/pmc_to_json.py /tmp/pmc_tf$NE /tmp/pmc_tw$NE $NE $O/tsc_env_step_traffic_$NE.json 0 qa_env_step,qa_tsc_goal_step,qa_tsc_observations >> $O/pmc.txt 2>&1
+done
+for NE in 8192 1024; do [ -f $O/tsc_env_step_traffic_$NE.json ] && cp $O/tsc_env_step_traffic_$NE.json profiles/tsc_env_step_traffic_$NE.json; done
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
 timeout 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d /tmp/pmc_sq -- python tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_sq.log 2>&1
 python tools/pmc_tsc_env.py summarize /tmp/pmc_sq > $O/env_step_sq_counters.txt 2>&1

@@ -92,6 +92,64 @@ for f in sorted(glob.glob("gpurun_out/r5/phase/bench_*.json")):
     except Exception as e: print(f, "no line", e)
 PY
     ;;
+late)      # history-shift stores after the physics: parity, timing, phases
+    timeout 900 python -m pytest tests/test_hip_parity.py tests/test_full_size_properties.py tests/test_mocap_reset.py tests/test_golden_env.py -m gpu -x -q > $O/pytest_env.log 2>&1; tail -3 $O/pytest_env.log
+    for i in 1 2; do timeout 200 python tools/quick_time.py > $O/quick_time_$i.txt 2>&1 < /dev/null; grep "N=" $O/quick_time_$i.txt; done
+    QA_LIB=$R/tools/_prof/libqa_sim_packed.so timeout 200 python tools/quick_time.py 2>&1 < /dev/null | grep "N=" > $O/quick_time_early_store.txt; cat $O/quick_time_early_store.txt
+    timeout 300 python tools/phase_profile.py > $O/phase_profile.txt 2>&1; tail -12 $O/phase_profile.txt
+    ;;
+skip)      # exact early-outs for idle non-foot contacts / joint-limit rows: parity, timing, how often the rows exist
+    timeout 900 python -m pytest tests/test_hip_parity.py tests/test_self_collision.py tests/test_articulated_obstacles.py tests/test_full_size_properties.py tests/test_mocap_reset.py tests/test_golden_env.py -m gpu -x -q > $O/pytest_env.log 2>&1; tail -3 $O/pytest_env.log
+    for i in 1 2; do timeout 200 python tools/quick_time.py > $O/quick_time_$i.txt 2>&1 < /dev/null; grep "N=" $O/quick_time_$i.txt; done
+    timeout 300 python tools/substep_profile.py -DQA_EXP_COUNT_EXTRA > $O/substep_profile.txt 2>&1; tail -13 $O/substep_profile.txt
+    timeout 300 python tools/phase_profile.py > $O/phase_profile.txt 2>&1; tail -12 $O/phase_profile.txt
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    python -c "
+import json; d=json.loads(open('$O/bench_cfg2.json').read()); print('bench', round(d['ms_per_step'],2), 'ms rollout', round(d['collection_s']*1e3,2), 'update', round(d['learn_s']*1e3,2), 'kernel us', round(d['roofline']['kernel_ms']*1e3,1), round(d['roofline']['kernel_ms_back_to_back']*1e3,1), 'frac', round(d['roofline']['frac'],4))"
+    ;;
+skipab)    # the early-outs inside the bench's own scenario (robots under the initial policy), A/B with a build without them; hybrid arm smoke
+    for i in 1 2; do
+      for v in product noskip scalar; do
+        L=""; [ $v != product ] && L=$R/tools/_prof/libqa_sim_$v.so
+        QA_LIB=$L timeout 400 python bench.py --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_${v}_$i.json
+        python -c "
+import json; d=json.loads(open('$O/bench_${v}_$i.json').read()); print('$v $i', round(d['ms_per_step'],2), 'ms rollout', round(d['collection_s']*1e3,2), 'kernel us in-rollout', round(d['roofline']['kernel_ms']*1e3,1), 'back to back', round(d['roofline']['kernel_ms_back_to_back']*1e3,1))"
+      done
+    done
+    QA_PARITY_NO_LOG=0 timeout 600 python tools/return_curve_parity.py --side hybrid --num_envs 256 --iters 6 --seeds 1 --out $O/hybrid_smoke_cfg2.json > $O/hybrid_smoke_cfg2.log 2>&1; tail -3 $O/hybrid_smoke_cfg2.log
+    timeout 900 python tools/return_curve_parity.py --side hybrid --amp --num_envs 256 --iters 6 --seeds 1 --out $O/hybrid_smoke_cfg3.json > $O/hybrid_smoke_cfg3.log 2>&1; tail -3 $O/hybrid_smoke_cfg3.log
+    timeout 600 python tools/return_curve_parity.py --side gpu --amp --num_envs 256 --iters 6 --seeds 1 --out $O/gpu_smoke_cfg3.json > $O/gpu_smoke_cfg3.log 2>&1; tail -2 $O/gpu_smoke_cfg3.log
+    python - <<'PY'
+import json
+for f in ("hybrid_smoke_cfg2", "hybrid_smoke_cfg3", "gpu_smoke_cfg3"):
+    try:
+        d = json.load(open(f"gpurun_out/r5/skipab/{f}.json")); r = d["rows"][0]
+        print(f, "env-steps/s", round(r["env_steps_per_s"]), {k: [round(x, 3) for x in v[-3:]] for k, v in r["curves"].items() if k in ("Train/mean_reward", "Train/mean_episode_length")})
+    except Exception as e: print(f, "failed", e)
+PY
+    ;;
+local)     # env-local coordinates inside a step: flip shares of every parity protocol (r4: profiles/r4_parity_flip_shares.txt), then the tests as judged
+    QA_PARITY_MEASURE=1 timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py -m gpu -s -q 2>&1 | grep "FLIPSHARE\|passed\|failed\|median env-step" > $O/flip_shares.txt; cat $O/flip_shares.txt | cut -c1-400
+    timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_tsc_depth.py tests/test_seam1_reference_env.py -m gpu -q > $O/pytest.log 2>&1; tail -4 $O/pytest.log
+    timeout 900 python tools/return_curve_parity.py --side hybrid --amp --num_envs 256 --iters 6 --seeds 1 --out $O/hybrid_smoke_cfg3.json > $O/hybrid_smoke_cfg3.log 2>&1; tail -2 $O/hybrid_smoke_cfg3.log
+    python - <<'PY'
+import json
+for f in ("hybrid_smoke_cfg3",):
+    try:
+        d = json.load(open(f"gpurun_out/r5/local/{f}.json")); r = d["rows"][0]
+        print(f, "env-steps/s", round(r["env_steps_per_s"]), {k: [round(x, 3) for x in v[-3:]] for k, v in r["curves"].items() if k in ("Train/mean_reward", "Train/mean_episode_length")})
+    except Exception as e: print(f, "failed", e)
+PY
+    timeout 200 python tools/quick_time.py --terrain > $O/quick_time_terrain.txt 2>&1; grep "N=" $O/quick_time_terrain.txt
+    timeout 200 python tools/quick_time.py > $O/quick_time.txt 2>&1; grep "N=" $O/quick_time.txt
+    ;;
+local2)    # env-local coordinates in kernel AND oracle: the flip shares again
+    QA_PARITY_MEASURE=1 timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py -m gpu -s -q 2>&1 | grep "FLIPSHARE\|passed\|failed" > $O/flip_shares.txt; cat $O/flip_shares.txt | cut -c1-300
+    ;;
+hybrid)    # config 3, 1024 envs x 1,000 iterations: this round's fast arm and the hybrid arm (oracle physics on the host cores + GPU learner), many seeds side by side
+    timeout 3500 python tools/d2_many.py --out $O --arms fast:1-24 hybrid:1-24 --workers 9 --hybrid_threads 28 --job_timeout 1800 --budget_s 2400 > $O/d2_many.log 2>&1
+    tail -30 $O/d2_many.log
+    ;;
 *) echo "unknown case $C"; exit 2;;
 esac
 ls -la $O

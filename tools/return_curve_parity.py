@@ -34,6 +34,13 @@ def run(device, num_envs, iters, seed, amp=False):
         from tests.oracle_backend import OracleBackend
         args = get_args(["--device", "cpu"])
         env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=(OracleBackend if amp else OracleBackend(make_qa_config(cfg, seed=seed))))
+    elif device == "hybrid":
+        # r5: the oracle's physics on the host cores under the PRODUCT's GPU learner (tools/hybrid_backend.py): the arm that separates
+        # "physics route" from "learner arithmetic" in the comparison with the all-CPU arm
+        os.environ["QA_ROLLOUT_GRAPH"] = "0"
+        from tools.hybrid_backend import HybridBackend
+        args = get_args(["--device", "gpu"])
+        env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg, backend=(HybridBackend if amp else HybridBackend(make_qa_config(cfg, seed=seed))))
     else:
         args = get_args(["--device", "gpu"])
         env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
@@ -119,7 +126,7 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3])
     ap.add_argument("--out", type=str, default=None)
-    ap.add_argument("--side", choices=["both", "gpu", "cpu"], default="both",
+    ap.add_argument("--side", choices=["both", "gpu", "cpu", "hybrid"], default="both",
                     help="run one side only (the CPU-oracle side needs no GPU) and merge later with --merge")
     ap.add_argument("--merge", nargs=2, default=None, metavar=("GPU_JSON", "CPU_JSON"))
     ap.add_argument("--amp", action="store_true", help="BASELINE config 3: discriminator on, mocap-state resets (baked real clips)")
