@@ -359,7 +359,26 @@ struct PostIn {
     V3 foot_f, hip_f, thigh_f, calf_f, base_f;
     V3 foot_w;
     float fric;
+    // r5: what the post-physics phase reads of the PREVIOUS step (last_* for three rate rewards, the running episode sums) is loaded with the
+    // rest of the state in front of the physics, not in the middle of the reward phase where a wavefront alone on its SIMD has nothing to do
+    // for the ~2 us of each round trip
+    float last_act[3], last_torg[3], last_qd[3], esum[QA_NUM_REWARDS];
+    float cmd[5], latc[5], eps; int64_t epl0; uint8_t last_contact;
 };
+// (the height-field build has no registers to spare for these ~40 values across the substeps -- they would spill to scratch -- and loads them
+// right in front of the post-physics phase, as r4 did)
+QA_DEV void post_in_preload(PostIn &in, const Ptrs &p, int env, int leg, int N) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+        in.last_act[k] = p.last_actions[j]; in.last_torg[k] = p.last_torques_org[j]; in.last_qd[k] = p.last_dof_vel[j];
+    }
+#pragma unroll
+    for (int r = 0; r < QA_NUM_REWARDS; ++r) in.esum[r] = p.episode_sums[(int64_t)r * N + env];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { in.cmd[i] = p.commands[(int64_t)env * 5 + i]; in.latc[i] = p.latent_c[(int64_t)env * 5 + i]; }
+    in.eps = p.latent_eps[env]; in.epl0 = p.episode_length[env]; in.last_contact = p.last_contacts[(int64_t)env * 4 + leg];
+}
 
 template <bool PLANE, int LPE, int LEAN = 0>
 __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptrs &p, const MocapIdx &mi, long long *qa_prof, PostIn &in, const TerrainView &T,
@@ -375,7 +394,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     const float q0[3] = {c.default_dof_pos[0], c.default_dof_pos[1], c.default_dof_pos[2]};
     QA_STAMP(4);
     // =========================== post_physics_step (legged_robot.py:124-166) ===========================
-    int64_t epl = p.episode_length[env] + 1;
+    int64_t epl = in.epl0 + 1;
     const int64_t common = step + 1;
     V3 blv = quat_rot(st.qx, st.qy, st.qz, st.qw, st.vw, -1.f), bav = quat_rot(st.qx, st.qy, st.qz, st.qw, st.ww, -1.f);
     V3 pg = quat_rot(st.qx, st.qy, st.qz, st.qw, v3(0, 0, -1), -1.f);
@@ -384,17 +403,17 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     float yaw = atan2f(2.0f * (st.qw * st.qz + st.qx * st.qy), 1.0f - 2.0f * (st.qy * st.qy + st.qz * st.qz));
     const float ffn = sqrtf(dot(foot_f, foot_f));
     const uint8_t contact = ffn > 2.0f;
-    const uint8_t cfilt = contact | p.last_contacts[(int64_t)env * 4 + leg];
+    const uint8_t cfilt = contact | in.last_contact;
 
     // commands / latents in registers (replicated)
     float cmd[5], eps; int gait = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) cmd[i] = p.commands[(int64_t)env * 5 + i];
-    eps = p.latent_eps[env];
+    for (int i = 0; i < 5; ++i) cmd[i] = in.cmd[i];
+    eps = in.eps;
     {
-        float best = p.latent_c[(int64_t)env * 5];
+        float best = in.latc[0];
 #pragma unroll
-        for (int g = 1; g < 5; ++g) { float v = p.latent_c[(int64_t)env * 5 + g]; if (v > best) { best = v; gait = g; } }
+        for (int g = 1; g < 5; ++g) { float v = in.latc[g]; if (v > best) { best = v; gait = g; } }
     }
     bool cmd_dirty = false;
     if (__any(epl % c.resampling_steps == 0)) {
@@ -433,9 +452,9 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         for (int k = 0; k < 3; ++k) {
             const int64_t j = (int64_t)env * 12 + 3 * leg + k;
             float d;
-            d = p.last_actions[j] - act[k]; s_ar += d * d;
-            d = tau_org[k] - p.last_torques_org[j]; s_dt += d * d;
-            d = (p.last_dof_vel[j] - st.qd[k]) / dtp; s_acc += d * d;
+            d = in.last_act[k] - act[k]; s_ar += d * d;
+            d = tau_org[k] - in.last_torg[k]; s_dt += d * d;
+            d = (in.last_qd[k] - st.qd[k]) / dtp; s_acc += d * d;
             d = st.q[k] - q0[k]; s_err += d * d; if (k == 0) s_hip += d * d;
             float lo = tbl[T_LOWER + k], hi = tbl[T_UPPER + k], mid = (lo + hi) / 2, rng = hi - lo;
             float slo = mid - 0.5f * rng * c.soft_dof_pos_limit, shi = mid + 0.5f * rng * c.soft_dof_pos_limit;
@@ -463,7 +482,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     float esum[QA_NUM_REWARDS];
 #pragma unroll
     for (int r = 0; r < QA_NUM_REWARDS; ++r) {
-        esum[r] = p.episode_sums[(int64_t)r * N + env];
+        esum[r] = in.esum[r];
         if (c.reward_scale_dt[r] != 0.0f) { float v = term[r] * c.reward_scale_dt[r]; rew += v; esum[r] += v; }
     }
     if (c.only_positive_rewards) rew = fmaxf(rew, 0.f);
@@ -620,14 +639,16 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     // The history slots 0..8 of every row were written by shift_history_rows() at the start of the launch.  What is left: head
     // (prop + explicit + latent, 90 floats), the newest history frame (slot 9) and the command tail -- 158 floats, four wave stores
     // per env.  An env in the first step of an episode refills all ten slots with the current frame (wave-uniform, rare).
+    // which envs of the block refill their whole history (first step of an episode): ONE LDS read per lane and a vote, instead of a
+    // read + readfirstlane + branch in front of every env's stores (r5: the loop below then has no control dependence on LDS data and
+    // its reads for several envs go out together)
+    const unsigned long long refill_mask = __ballot(lane < EPB && s_stage[(lane < EPB ? lane : 0) * S_ENV + S_FLAGS] != 0.f);
 #pragma unroll 4
     for (int e = 0; e < EPB; ++e) {
         const int ge = (int)(bix * EPB) + e;
         if (ge >= N) continue;
         const float *ss = s_stage + e * S_ENV;
         float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
-        const bool rf = __builtin_amdgcn_readfirstlane(__float_as_int(ss[S_FLAGS])) != 0;      // wave-uniform
-        if (rf) for (int i = lane; i < 513; i += QA_BLOCK) dst[90 + i] = clampf(ss[S_PROP + (i % 57)], -clipo, clipo);
         dst[lane] = clampf(ss[S_HEAD + lane], -clipo, clipo);
         if (lane < 26) dst[64 + lane] = clampf(ss[S_HEAD + 64 + lane], -clipo, clipo);
         if (lane < 57) dst[603 + lane] = clampf(ss[S_PROP + lane], -clipo, clipo);
@@ -638,6 +659,13 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
             p.obs_disc_term[(int64_t)ge * QA_NUM_OBS_DISC + lane] = (ss[S_FLAGS + 1] != 0.f) ? ss[S_DISCT + lane] : dv;
         }
     }
+    for (unsigned long long m = refill_mask; m != 0; m &= m - 1) {          // rare: slots 0..8 <- the current frame (slot 9 was written above)
+        const int e = __builtin_ctzll(m), ge = (int)(bix * EPB) + e;
+        if (ge >= N) continue;
+        const float *ss = s_stage + e * S_ENV;
+        float *dst = p.obs + (int64_t)ge * QA_NUM_OBS;
+        for (int i = lane; i < 513; i += QA_BLOCK) dst[90 + i] = clampf(ss[S_PROP + (i % 57)], -clipo, clipo);
+    }
     QA_STAMP(10);
 }
 
@@ -647,27 +675,36 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
 // one whatever this step does (unless the env resets: then the tail of the kernel refills all ten), so the 513-float shift of every
 // env of the block -- 3/4 of the row's bytes -- is read and written here, in the shadow of the physics, and the tail of the kernel
 // only adds the 158 floats this step produces.  In place: every lane holds its 9 values of a row before the row's first store issues.
+// r5: the loads and stores are written as inline assembly with ACCUMULATOR registers as their data operands ("a" constraint; gfx950 loads /
+// stores address the unified file directly).  The 144 values of a lane must stay out of the way of the physics for the whole step; left to the
+// compiler, a few of them were loaded into VGPRs and moved to AGPRs behind an `s_waitcnt vmcnt(0)` in front of the substep loop -- the very wait
+// the late stores were meant to remove.  The compiler does not count these loads in its own `s_waitcnt vmcnt` arithmetic: its waits only become
+// stricter (the counter is in-order), and the stores below are preceded by an explicit vmcnt(0).
+#define QA_HLOAD(dst, ptr, OFF) asm volatile("global_load_dword %0, %1, off offset:" #OFF : "=a"(dst) : "v"(ptr) : "memory")
+#define QA_HSTORE(ptr, src, OFF) asm volatile("global_store_dword %0, %1, off offset:" #OFF :: "v"(ptr), "a"(src) : "memory")
 template <int EPB>
 QA_DEV void shift_history_load(const Ptrs &p, int bix, int lane, int N, float (&hv)[EPB][9]) {
 #pragma unroll
     for (int g = 0; g < EPB; ++g) {                     // all rows of the block in flight: 144 registers nothing else needs yet
         const int ge = min(bix * EPB + g, N - 1);
         const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + lane;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) hv[g][r] = hist[QA_BLOCK * r];
-        hv[g][8] = (lane == 0) ? hist[512] : 0.f;
+        QA_HLOAD(hv[g][0], hist, 0); QA_HLOAD(hv[g][1], hist, 256); QA_HLOAD(hv[g][2], hist, 512); QA_HLOAD(hv[g][3], hist, 768);
+        QA_HLOAD(hv[g][4], hist, 1024); QA_HLOAD(hv[g][5], hist, 1280); QA_HLOAD(hv[g][6], hist, 1536); QA_HLOAD(hv[g][7], hist, 1792);
+        const float *last = lane == 0 ? hist + 512 : hist;          // only lane 0's ninth value is stored; the others re-read a valid address
+        QA_HLOAD(hv[g][8], last, 0);
     }
 }
 template <int EPB>
-QA_DEV void shift_history_store(const Ptrs &p, int bix, int lane, int N, const float (&hv)[EPB][9]) {
+QA_DEV void shift_history_store(const Ptrs &p, int bix, int lane, int N, float (&hv)[EPB][9]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int g = 0; g < EPB; ++g) {
         const int ge = bix * EPB + g;
         if (ge < N) {
             float *row = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + lane;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) row[QA_BLOCK * r] = hv[g][r];
-            if (lane == 0) row[512] = hv[g][8];
+            QA_HSTORE(row, hv[g][0], 0); QA_HSTORE(row, hv[g][1], 256); QA_HSTORE(row, hv[g][2], 512); QA_HSTORE(row, hv[g][3], 768);
+            QA_HSTORE(row, hv[g][4], 1024); QA_HSTORE(row, hv[g][5], 1280); QA_HSTORE(row, hv[g][6], 1536); QA_HSTORE(row, hv[g][7], 1792);
+            if (lane == 0) { float *r8 = row + 512; QA_HSTORE(r8, hv[g][8], 0); }
         }
     }
 }
@@ -706,15 +743,14 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     // write was a burst nobody overlapped: 9.7 k of the kernel's 136 k ticks waiting for it (profiles/r5_env_step_phase_profile.txt).  The
     // values wait in registers the substeps do not use (the compiler parks them in AGPRs: 2 x 144 v_accvgpr moves, ~1.3 k ticks).
     float hv[EPB][9];
+#ifdef QA_SHIFT_EARLY_STORE
     if (MODE == 0 && LPE == 4) {
         shift_history_load<EPB>(p, bix, tix, N, hv);
         stage_table(s_tbl);
-#ifdef QA_SHIFT_EARLY_STORE
         shift_history_store<EPB>(p, bix, tix, N, hv);
+    } else
 #endif
-    } else {
-        stage_table(s_tbl);
-    }
+    stage_table(s_tbl);
     if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
@@ -792,6 +828,8 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         for (int k = 0; k < 3; ++k) { const int64_t j = (int64_t)env * 12 + 3 * leg + k; old_act[k] = p.actions[j]; old_torg[k] = p.torques_org[j]; old_qd[k] = st.qd[k]; }
         old_vw = st.vw; old_ww = st.ww;
     }
+    PostIn in;
+    if (MODE == 0 && PLANE) post_in_preload(in, p, env, leg, N);
     float binert[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) binert[i] = p.base_inertia[(int64_t)env * 10 + i];
@@ -831,6 +869,21 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     float fimp[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
+#ifndef QA_SHIFT_EARLY_STORE
+    // the history loads go out LAST, behind every load the substeps wait for: the wait counter is in-order (and 6 bits wide), so loads issued
+    // in front of the state's would have to land before the physics could start; nothing waits for these until the stores after the loop
+    if (MODE == 0 && LPE == 4) {
+        // every value loaded so far is "used" here, so that the compiler waits for it NOW (nothing is outstanding behind it yet) and not
+        // at its first real use inside the loop, where the 6-bit counter could only say "all but the newest 62 loads" = 82 history loads
+        asm volatile("" :: "v"(fimp[0]), "v"(fimp[1]), "v"(fimp[2]), "v"(mu), "v"(st.q[0]), "v"(st.qd[2]), "v"(st.pos.z), "v"(st.ww.z) : "memory");
+        if (PLANE) {
+        asm volatile("" :: "v"(in.last_act[0]), "v"(in.last_act[2]), "v"(in.last_torg[0]), "v"(in.last_torg[2]), "v"(in.last_qd[0]), "v"(in.last_qd[2]) : "memory");
+        asm volatile("" :: "v"(in.esum[0]), "v"(in.esum[3]), "v"(in.esum[6]), "v"(in.esum[9]), "v"(in.esum[13]) : "memory");
+        asm volatile("" :: "v"(in.cmd[0]), "v"(in.cmd[4]), "v"(in.latc[0]), "v"(in.latc[4]), "v"(in.eps), "v"((int)in.epl0), "v"((int)in.last_contact) : "memory");
+        }
+        shift_history_load<EPB>(p, bix, tix, N, hv);
+    }
+#endif
     for (int d = 0; d < c.decimation; ++d) {
         // compiler fence: without it LICM hoists the ~120 loop-invariant LDS table reads of the substep out of this
         // loop and keeps them in registers across it, which is what pushed the kernel into scratch
@@ -927,7 +980,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         return;
     }
     QA_STAMP(4);
-    PostIn in;
+    if (!PLANE) post_in_preload(in, p, env, leg, N);
     in.st = st; in.foot_f = co.foot_f; in.hip_f = hip_f; in.thigh_f = thigh_f; in.calf_f = calf_f; in.base_f = base_f; in.foot_w = foot_w; in.fric = fric;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { in.act[k] = act[k]; in.raw_act[k] = raw_act[k]; in.tau[k] = tau[k]; in.tau_org[k] = tau_org[k]; in.sp[k] = sp[k]; in.sd[k] = sd[k]; in.fimp[k] = fimp[k]; }
@@ -963,6 +1016,7 @@ __global__ void __launch_bounds__(QA_BLOCK) qa_post_physics_kernel(StepArgs a) {
     const int64_t step = a.step;
     if (bix == 0 && tix < 16) p.episode_stats[16 * ((step + 1) & 1) + tix] = 0.f;
     PostIn in;
+    post_in_preload(in, p, env, leg, N);
     {
         const float *r = p.root + (int64_t)env * 13;
         in.st.pos = v3(r[0], r[1], r[2]); in.st.qx = r[3]; in.st.qy = r[4]; in.st.qz = r[5]; in.st.qw = r[6];
