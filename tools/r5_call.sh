@@ -31,40 +31,9 @@ envpk)     # packed rows + sweeps (r5) against the round-4 scalar build (tools/_
     timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
     timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_scalar.so $R/tools/_prof/libqa_sim_packed.so 30 1024 1.0 > $O/lockstep.txt 2>&1; tail -4 $O/lockstep.txt | cut -c1-200
     ;;
-dbg)       # bisect the packed sweeps' parity failure: unit test of the building blocks, then arenas after K steps per build against the scalar build
-    timeout 60 tools/_prof/pgs_unit > $O/pgs_unit.txt 2>&1; cat $O/pgs_unit.txt
-    for v in scalar packed lanebr quadsum both; do for K in 1 6; do QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 120 python tools/ab_step.py run /tmp/ab_${v}_$K.npy $K > /dev/null 2>&1; done; done
-    for v in packed lanebr quadsum both; do for K in 1 6; do echo "== $v vs scalar, $K steps" >> $O/ab.txt; python tools/ab_step.py cmp /tmp/ab_scalar_$K.npy /tmp/ab_${v}_$K.npy >> $O/ab.txt 2>&1; done; done
-    cat $O/ab.txt
-    # the DMA GEMM with 16-byte fragment reads on index-contiguous operands
-    timeout 600 python -m pytest tests/test_gemm_layers.py -m gpu -x -q > $O/pytest_gemm.log 2>&1; tail -5 $O/pytest_gemm.log
-    timeout 600 python tools/gemm_dma_bench.py --json $O/gemm_dma_bench.json > $O/gemm_dma_bench.txt 2>&1; tail -40 $O/gemm_dma_bench.txt
-    ;;
-dbg2)      # which rare path: small actions (no joint stops), one contact slot, no self-collision
-    for cfgs in "1.0:" "0.2:" "1.0:contact_slots=1" "1.0:self_collision=0" "3.0:" "3.0:contact_slots=1,self_collision=0"; do
-      act=${cfgs%%:*}; cf=${cfgs#*:}
-      for v in scalar packed; do AB_ACT=$act AB_CFG=$cf QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 120 python tools/ab_step.py run /tmp/ab_$v.npy 12 256 > /dev/null 2>&1; done
-      echo "== actions x $act, cfg [$cf], 12 steps, 256 envs" >> $O/ab.txt; python tools/ab_step.py cmp /tmp/ab_scalar.npy /tmp/ab_packed.npy >> $O/ab.txt 2>&1
-    done
-    cat $O/ab.txt
-    ;;
-dbg3)      # scalar rows / scalar warm start inside the packed build, and an -O1 build
-    for v in scalar packed srows swarm sboth o1; do AB_ACT=0.2 QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 120 python tools/ab_step.py run /tmp/ab_$v.npy 12 256 > /dev/null 2>&1; done
-    for v in packed srows swarm sboth o1; do echo "== $v vs scalar (actions x 0.2, 12 steps, 256 envs)" >> $O/ab.txt; python tools/ab_step.py cmp /tmp/ab_scalar.npy /tmp/ab_$v.npy >> $O/ab.txt 2>&1; done
-    cat $O/ab.txt
-    ;;
-dbg4)      # scalar and packed builds in lockstep from the scalar build's arena: the first step in which they part
-    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_scalar.so $R/tools/_prof/libqa_sim_packed.so 20 256 0.2 > $O/lockstep.txt 2>&1; cat $O/lockstep.txt
-    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_scalar.so $R/tools/_prof/libqa_sim_scalar.so 20 256 0.2 > $O/lockstep_self.txt 2>&1; tail -3 $O/lockstep_self.txt
-    QA_LIB=$R/tools/_prof/libqa_sim_scalar.so timeout 300 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "single_step_parity and 64" 2>&1 | tail -5
-    ;;
-dbg5)      # the joint-limit rows: unit test, and both builds with the limit rows compiled out
-    timeout 60 tools/_prof/pgs_unit > $O/pgs_unit.txt 2>&1; cat $O/pgs_unit.txt
-    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_nolim_sc.so $R/tools/_prof/libqa_sim_nolim_pk.so 20 256 0.2 > $O/lockstep_nolimits.txt 2>&1; cat $O/lockstep_nolimits.txt | cut -c1-250
-    ;;
-dbg6)      # packed rows + LDS layout, SCALAR sweeps, no limit rows, against the scalar build without limit rows
-    timeout 200 python tools/ab_lockstep.py $R/tools/_prof/libqa_sim_nolim_sc.so $R/tools/_prof/libqa_sim_ssweep.so 20 256 0.2 > $O/lockstep.txt 2>&1; cat $O/lockstep.txt | cut -c1-250
-    ;;
+# (dbg .. dbg6, removed: the six bisect calls behind profiles/r5_packed_sweeps_debug.txt; they drove debug switches in qa_physics.h that were
+#  deleted with the fix -- a hipcc miscompile of a lane-divergent vector-element copy, DESIGN 4.1b.  tools/ab_step.py, tools/ab_lockstep.py and
+#  tools/pgs_unit.hip, the tools they ran, are kept.)
 learn1)    # gradients left in parts, finished by the optimiser's first pass: tests, then the bench line with and without
     timeout 1500 python -m pytest tests/test_grad_parts.py tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_gemm_layers.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log
     for i in 1 2; do
@@ -149,6 +118,20 @@ local2)    # env-local coordinates in kernel AND oracle: the flip shares again
 hybrid)    # config 3, 1024 envs x 1,000 iterations: this round's fast arm and the hybrid arm (oracle physics on the host cores + GPU learner), many seeds side by side
     timeout 3500 python tools/d2_many.py --out $O --arms fast:1-24 hybrid:1-24 --workers 9 --hybrid_threads 28 --job_timeout 1800 --budget_s 2400 > $O/d2_many.log 2>&1
     tail -30 $O/d2_many.log
+    ;;
+pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
+    timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
+    for i in 1 2; do
+      timeout 200 python tools/quick_time.py > $O/quick_time_$i.txt 2>&1; grep "N=" $O/quick_time_$i.txt
+      QA_LIB=$R/tools/_prof/libqa_sim_local.so timeout 200 python tools/quick_time.py > $O/quick_time_before_$i.txt 2>&1; grep "N=" $O/quick_time_before_$i.txt     # the build of commit ad4fa6b
+    done
+    timeout 200 python tools/quick_time.py --terrain > $O/quick_time_terrain.txt 2>&1; grep "N=" $O/quick_time_terrain.txt
+    timeout 200 python tools/phase_profile.py > $O/phase_profile.txt 2>&1; tail -12 $O/phase_profile.txt
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json; cut -c1-700 $O/bench_cfg2.json
+    ;;
+prox)      # the self-collision pairs the kernel does not model, on configs 3 and 4: smallest gaps over whole training runs
+    timeout 1500 python tools/self_collision_proximity.py --amp --num_envs 1024 --iters 600 --out $O/self_collision_proximity_cfg3_1024x600.json > $O/cfg3.log 2>&1; tail -3 $O/cfg3.log
+    timeout 2400 python tools/self_collision_proximity.py --tsc --num_envs 1024 --iters 300 --every 5 --out $O/self_collision_proximity_cfg4_1024x300.json > $O/cfg4.log 2>&1; tail -3 $O/cfg4.log
     ;;
 *) echo "unknown case $C"; exit 2;;
 esac

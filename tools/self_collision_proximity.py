@@ -151,31 +151,71 @@ def pair_gaps(dof_pos):
     return out
 
 
+def train_behaviour_policy(iters, seed):
+    """config 3 for `iters` iterations at 4096 envs on the product path -> model.pt of the behaviour level (the TSC runner's load_bbc input)"""
+    import tempfile
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+    from quadrupedal_agility_amd.legged_gym.utils import get_args
+    cfg = Go2LocomotionCfg(); cfg.env.num_envs = 4096; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = True; cfg.seed = seed
+    t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = True; t.seed = seed; t.runner.save_interval = 10 ** 9
+    torch.manual_seed(seed)
+    args = get_args(["--device", "gpu"])
+    env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
+    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
+    runner.learn(iters, init_at_random_ep_len=True)
+    path = os.path.join(tempfile.mkdtemp(), "bbc_model.pt")
+    runner.save(path)
+    mean_len = float(env.episode_length_buf.float().mean())
+    print(f"behaviour policy: {iters} iterations of config 3 at 4096 envs; mean running episode length now {mean_len:.0f} steps", flush=True)
+    del runner, env
+    torch.cuda.empty_cache()
+    return path
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num_envs", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--every", type=int, default=10, help="evaluate the rollouts of every k-th iteration")
-    ap.add_argument("--amp", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="BASELINE config 3 (AMP, mocap state init) instead of config 2")
+    ap.add_argument("--tsc", action="store_true", help="BASELINE config 4: the TSC teacher on the agility course (tunnel crawl, bar / tyre jumps, see-saw ...)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--bbc_iters", type=int, default=1500, help="with --tsc: iterations of config-3 training (4096 envs, recorded rollouts) that make the "
+                    "behaviour policy the task level then drives FROZEN (there is no checkpoint to download here); 0 = a random-init behaviour policy")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    from quadrupedal_agility_amd.legged_gym.envs import task_registry
-    from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
-    from quadrupedal_agility_amd.legged_gym.utils import get_args
-    cfg = Go2LocomotionCfg(); cfg.env.num_envs = a.num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = bool(a.amp); cfg.seed = a.seed
-    t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = bool(a.amp); t.seed = a.seed; t.runner.save_interval = 10 ** 9
-    torch.manual_seed(a.seed)
-    args = get_args(["--device", "gpu"])
-    env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
-    runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
-    runner.use_rollout_graph = False
-    os.environ["QA_ROLLOUT_GRAPH"] = "0"            # eager rollouts: the wrapped step below must run on every step it samples
+    if a.tsc:
+        os.environ["QA_TSC_ROLLOUT_GRAPH"] = "0"        # eager rollouts: the wrapped step below must run on every step it samples
+        from quadrupedal_agility_amd.legged_gym.utils.cfg_to_c import class_to_dict
+        from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
+        from quadrupedal_agility_amd.tsc.legged_gym.envs.go2.go2_agility_config import Go2AgilityCfg, Go2AgilityCfgPPO
+        from quadrupedal_agility_amd.tsc.rsl_rl.runners import OnPolicyRunner
+        cfg = Go2AgilityCfg(); cfg.env.num_envs, cfg.seed, cfg.course_seed = a.num_envs, a.seed, a.seed
+        d = cfg.domain_rand; d.randomize_base_mass = d.randomize_base_com = d.push_robots = True
+        cfg.obstacle.randomize_start = True
+        torch.manual_seed(a.seed)
+        env = lr.LeggedRobot(cfg, sim_device="cuda:0")
+        runner = OnPolicyRunner(env, class_to_dict(Go2AgilityCfgPPO()), log_dir=None, device="cuda:0")
+        if a.bbc_iters:
+            runner.load_bbc(train_behaviour_policy(a.bbc_iters, a.seed))
+    else:
+        from quadrupedal_agility_amd.legged_gym.envs import task_registry
+        from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
+        from quadrupedal_agility_amd.legged_gym.utils import get_args
+        cfg = Go2LocomotionCfg(); cfg.env.num_envs = a.num_envs; cfg.terrain.mesh_type = "plane"; cfg.env.mocap_state_init = bool(a.amp); cfg.seed = a.seed
+        t = Go2LocomotionCfgAlgo(); t.runner.amp_enabled = bool(a.amp); t.seed = a.seed; t.runner.save_interval = 10 ** 9
+        torch.manual_seed(a.seed)
+        args = get_args(["--device", "gpu"])
+        env, _ = task_registry.make_env("go2_locomotion", args=args, env_cfg=cfg)
+        runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=t, log_root=None)
+        runner.use_rollout_graph = False
+        os.environ["QA_ROLLOUT_GRAPH"] = "0"            # eager rollouts: the wrapped step below must run on every step it samples
     stats, state = {}, {"it": 0, "on": False, "n": 0}
     orig = env.step
 
-    def step(actions):
-        r = orig(actions)
+    def step(actions, *more):
+        r = orig(actions, *more)
         if state["on"]:
             gaps = pair_gaps(env.dof_pos.clone())
             for k, g in gaps.items():
@@ -190,14 +230,19 @@ def main():
         state["on"] = it % a.every == 0
         state["phase"] = "iterations 0-99" if it < 100 else ("iterations 100-499" if it < 500 else "iterations 500+")
         runner.learn(1, init_at_random_ep_len=(it == 0))
+    if a.tsc:
+        res_extra = {"behaviour_policy": f"{a.bbc_iters} iterations of config 3 at 4096 envs (this tool), then frozen" if a.bbc_iters else "random init, frozen"}
     res = {"what": "gap between the URDF collision shapes of body pairs the env kernel does not collide (and the modelled calf-calf class for reference), "
                    "evaluated by forward kinematics on the joint angles visited during a whole training run (sampled rollouts, exploration noise included)",
-           "config": "BASELINE config 3 (AMP, mocap resets)" if a.amp else "BASELINE config 2", "num_envs": a.num_envs, "iterations": a.iters,
+           "config": ("BASELINE config 4 (TSC teacher on the agility course: frozen behaviour policy under a learning task policy)" if a.tsc else
+                      "BASELINE config 3 (AMP, mocap resets)" if a.amp else "BASELINE config 2"), "num_envs": a.num_envs, "iterations": a.iters,
            "sampled_env_steps_per_pair_class": state["n"] * a.num_envs, "contact_offset_m": 0.01, "pairs": {}}
     for k, s in sorted(stats.items()):
         res["pairs"][k] = {"min_gap_m": round(s["min"], 4), "fraction_below_contact_offset": s["below_offset"] / s["env_steps"],
                            "fraction_penetrating": s["below_zero"] / s["env_steps"],
                            "fraction_below_contact_offset_by_phase": {p: v[0] / max(v[1], 1) for p, v in s["per_phase"].items()}}
+    if a.tsc:
+        res.update(res_extra)
     txt = json.dumps(res, indent=1)
     if a.out:
         open(a.out, "w").write(txt)
