@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 14
+#define QA_ABI_VERSION 15
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -733,6 +733,14 @@ int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weigh
                 int64_t packed_floats, void *stream);
 int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops,
                    const float *packed, float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream);
+/* r5 (ABI 15): launches with few row tiles.  A launch of <= 128 tiles (2048 rows) leaves CUs idle while each busy one walks the whole chain, so
+ * qa_mlp_forward gives every tile to up to min(4, 256 / tiles) workgroups, each running the ops of one STRAND: ops are grouped by flow dependence
+ * through the scratch buffers (an op belongs with the last writer of every scratch column it reads; the input tile is shared), the groups dealt to
+ * strands largest first onto the least loaded (cost = k * n per layer + a constant per op).  SSInfoGAIL.act has two groups (critic | estimator ->
+ * privileged / history encoder -> actor).  Per-op arithmetic is unchanged, so outputs are bit-identical to the unsplit launch.  QA_MLP_STRANDS=1
+ * in the environment switches the split off.  qa_mlp_strands is the (host-only) partition itself: strand_of[i] = strand of op i, return value =
+ * number of strands used (1 = not split), or a negative QA_E_* code. */
+int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, int32_t *strand_of);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Task-level (TSC) env-side math of SURVEY 8a row a18: the two per-step pieces of tsc/legged_gym/envs/base/legged_robot.py

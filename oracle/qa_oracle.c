@@ -2317,6 +2317,52 @@ int qo_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weigh
     return QA_OK;
 }
 
+/* The partition of a chain into strands (include/qa_sim.h, ABI 15): checker-side restatement by label propagation.  Op i DEPENDS on op j < i when
+ * i reads a scratch column whose most recent write before i was j's; a group is a connected set of ops, named by its earliest op; groups are dealt
+ * largest cost first (ties: earliest group first) to the least loaded strand (ties: lowest strand).  cost(op) = k n for a layer, + 4096 per op. */
+int qo_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, int32_t *strand_of) {
+    if (!ops || !strand_of || num_ops <= 0 || num_ops > QA_MLP_MAX_OPS || max_strands < 1) return QA_E_ARG;
+    if (max_strands > 4) max_strands = 4;
+    int label[QA_MLP_MAX_OPS];
+    unsigned char dep[QA_MLP_MAX_OPS][QA_MLP_MAX_OPS];
+    memset(dep, 0, sizeof(dep));
+    for (int i = 0; i < num_ops; ++i) {
+        label[i] = i; strand_of[i] = 0;
+        if (ops[i].src_buf <= 0) continue;                       /* the input tile is everybody's */
+        const int rd = ops[i].kind == QA_MLP_LAYER ? ops[i].k : ops[i].n;
+        for (int c = ops[i].src_col; c < ops[i].src_col + rd; ++c)
+            for (int j = i - 1; j >= 0; --j)                     /* the most recent earlier op that wrote column c of that buffer */
+                if (ops[j].dst_buf == ops[i].src_buf && c >= ops[j].dst_col && c < ops[j].dst_col + ops[j].n) { dep[i][j] = 1; break; }
+    }
+    for (int changed = 1; changed;) {
+        changed = 0;
+        for (int i = 0; i < num_ops; ++i)
+            for (int j = 0; j < num_ops; ++j)
+                if ((dep[i][j] || dep[j][i]) && label[j] < label[i]) { label[i] = label[j]; changed = 1; }
+    }
+    double cost[QA_MLP_MAX_OPS];
+    int ngroups = 0;
+    for (int g = 0; g < num_ops; ++g) {
+        cost[g] = -1.0;
+        for (int i = 0; i < num_ops; ++i)
+            if (label[i] == g) cost[g] = (cost[g] < 0 ? 0.0 : cost[g]) + (ops[i].kind == QA_MLP_LAYER ? (double)ops[i].k * ops[i].n : 0.0) + 4096.0;
+        if (cost[g] >= 0) ++ngroups;
+    }
+    if (max_strands < 2 || ngroups < 2) return 1;
+    const int ns = ngroups < max_strands ? ngroups : max_strands;
+    double load[4] = {0, 0, 0, 0};
+    int group_strand[QA_MLP_MAX_OPS];
+    for (int dealt = 0; dealt < ngroups; ++dealt) {
+        int g = -1;
+        for (int c = 0; c < num_ops; ++c) if (cost[c] >= 0 && (g < 0 || cost[c] > cost[g])) g = c;      /* largest left; ties keep the earliest */
+        int best = 0;
+        for (int t = 1; t < ns; ++t) if (load[t] < load[best]) best = t;
+        group_strand[g] = best; load[best] += cost[g]; cost[g] = -1.0;
+    }
+    for (int i = 0; i < num_ops; ++i) strand_of[i] = group_strand[label[i]];
+    return ns;
+}
+
 int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops, const float *packed,
                    float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream) {
     (void)stream;

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/qa_sim.h"
 
@@ -49,12 +50,13 @@ __host__ __device__ constexpr int mlp_kb(int k, int n) { return ((k + 15) / 16 +
 struct MlpDevOp {
     int32_t kind, src_buf, src_col, dst_buf, dst_col, k, n, act, out_index, nt, kb, tpw;
     int64_t w_off, b_off;
+    int32_t strand, pad_;       /* which workgroup of a tile's group runs the op (blockIdx.y); see mlp_strands */
 };
 
 struct MlpArgs {
     const float *x;
     int64_t x_stride;
-    int32_t rows, x_cols, num_ops;
+    int32_t rows, x_cols, num_ops, strands;
     const float *packed;
     float *out[QA_MLP_MAX_OUTPUTS];
     int64_t out_stride[QA_MLP_MAX_OUTPUTS];
@@ -178,7 +180,7 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
 
 /* -DQA_MLP_PROF (tools/mlp_profile.py): s_memtime after every op of workgroup 0 into output 3, read as int64[] */
 #ifdef QA_MLP_PROF
-#define MLP_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long *>(a.out[3])[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define MLP_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) reinterpret_cast<long long *>(a.out[3])[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MLP_STAMP(i) do { } while (0)
 #endif
@@ -205,8 +207,10 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs 
     __syncthreads();
     MLP_STAMP(0);
     MlpDevOp op = a.ops[0];
+    const int strand = blockIdx.y;                 /* > 0 only when the launch has too few row tiles to fill the chip (mlp_strands) */
     for (int o = 0; o < a.num_ops; ++o) {
         const MlpDevOp nxt = a.ops[o + 1 < a.num_ops ? o + 1 : o];      /* scalar loads of the next descriptor fly during this op */
+        if (op.strand != strand) { op = nxt; continue; }                  /* workgroup-uniform: another workgroup of this tile runs it */
         if (op.kind == QA_MLP_COPY) {
             const int ss = mlp_stride(op.src_buf), ds = mlp_stride(op.dst_buf);
             for (int i = tid; i < MLP_ROWS * op.n; i += MLP_WAVES * 64) {
@@ -224,6 +228,50 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs 
         MLP_STAMP(o + 1);
         op = nxt;
     }
+}
+
+/* Few rows = few 16-row tiles = most CUs idle while each busy one walks the whole chain (80 us whether the launch has 1 row or 4096).
+ * The chain is usually several chains that share nothing but the input tile (SSInfoGAIL.act: the critic is 68 % of the flops and feeds nobody),
+ * so when tiles * strands still fits the chip each tile is given to `strands` workgroups (blockIdx.y), every one of which stages the input tile
+ * and runs only ITS ops, in program order.  Ops are grouped by FLOW dependence through the LDS scratch buffers (an op joins the strand of the
+ * last writer of every column it reads; buffer re-use between unrelated chains is no dependence here, each workgroup has its own LDS); the
+ * groups are dealt to strands largest first onto the least loaded.  Same arithmetic per op => the outputs are bit-identical to strands = 1. */
+int mlp_strands(const qa_mlp_op *ops, int num_ops, int max_strands, int32_t *strand_of) {
+    for (int i = 0; i < num_ops; ++i) strand_of[i] = 0;
+    if (max_strands < 2) return 1;
+    int parent[QA_MLP_MAX_OPS];
+    for (int i = 0; i < num_ops; ++i) parent[i] = i;
+    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+    constexpr int MAXC = QA_MLP_BUF1_COLS > QA_MLP_BUF2_COLS ? (QA_MLP_BUF1_COLS > QA_MLP_BUF3_COLS ? QA_MLP_BUF1_COLS : QA_MLP_BUF3_COLS)
+                                                             : (QA_MLP_BUF2_COLS > QA_MLP_BUF3_COLS ? QA_MLP_BUF2_COLS : QA_MLP_BUF3_COLS);
+    int last_writer[MLP_NBUF][MAXC + 4];
+    for (int b = 0; b < MLP_NBUF; ++b) for (int c = 0; c < MAXC + 4; ++c) last_writer[b][c] = -1;
+    for (int i = 0; i < num_ops; ++i) {
+        const qa_mlp_op &o = ops[i];
+        const int rd = o.kind == QA_MLP_LAYER ? o.k : o.n;
+        if (o.src_buf > 0)
+            for (int c = o.src_col; c < o.src_col + rd && c < MAXC + 4; ++c)
+                if (last_writer[o.src_buf][c] >= 0) parent[find(i)] = find(last_writer[o.src_buf][c]);
+        if (o.dst_buf > 0)
+            for (int c = o.dst_col; c < o.dst_col + o.n && c < MAXC + 4; ++c) last_writer[o.dst_buf][c] = i;
+    }
+    double cost[QA_MLP_MAX_OPS] = {0};              /* per root: MFMA work (copies and the latency of narrow layers as a small constant) */
+    for (int i = 0; i < num_ops; ++i) cost[find(i)] += (ops[i].kind == QA_MLP_LAYER ? (double)ops[i].k * ops[i].n : 0.0) + 4096.0;
+    int roots[QA_MLP_MAX_OPS], nroots = 0;
+    for (int i = 0; i < num_ops; ++i) if (find(i) == i) roots[nroots++] = i;
+    if (nroots < 2) return 1;
+    for (int i = 1; i < nroots; ++i)                /* insertion sort, largest first (ties: program order) */
+        for (int j = i; j > 0 && cost[roots[j]] > cost[roots[j - 1]]; --j) { const int t = roots[j]; roots[j] = roots[j - 1]; roots[j - 1] = t; }
+    const int ns = nroots < max_strands ? nroots : max_strands;
+    double load[8] = {0};
+    int strand_of_root[QA_MLP_MAX_OPS];
+    for (int r = 0; r < nroots; ++r) {
+        int best = 0;
+        for (int g = 1; g < ns; ++g) if (load[g] < load[best]) best = g;
+        strand_of_root[roots[r]] = best; load[best] += cost[roots[r]];
+    }
+    for (int i = 0; i < num_ops; ++i) strand_of[i] = strand_of_root[find(i)];
+    return ns;
 }
 
 int lds_base(int b) { return b == 0 ? 0 : b == 1 ? B1 : b == 2 ? B2 : B3; }
@@ -277,6 +325,13 @@ static int mlp_check(const qa_mlp_op *ops, int32_t num_ops, const char *who) {
     return QA_OK;
 }
 
+int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, int32_t *strand_of) {
+    int rc = mlp_check(ops, num_ops, "qa_mlp_strands");
+    if (rc != QA_OK) return rc;
+    if (!strand_of || max_strands < 1) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_strands: bad argument"); return QA_E_ARG; }
+    return mlp_strands(ops, num_ops, max_strands > 4 ? 4 : max_strands, strand_of);
+}
+
 int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weights, const float *const *biases, float *packed, int64_t packed_floats,
                 void *stream) {
     int rc = mlp_check(ops, num_ops, "qa_mlp_pack");
@@ -316,7 +371,15 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
                 snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: op %d writes output %d which is missing or too narrow", i, o.out_index); return QA_E_ARG; }
         }
     }
-    hipLaunchKernelGGL(qa_mlp_forward_kernel, dim3((rows + MLP_ROWS - 1) / MLP_ROWS), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);
+    const int tiles = (rows + MLP_ROWS - 1) / MLP_ROWS;
+    static const int strands_switch = [] { const char *e = getenv("QA_MLP_STRANDS"); return e ? atoi(e) : 4; }();      /* 1: never split (A/B runs) */
+    int max_strands = 256 / tiles;                  /* one workgroup per CU (117 KB of LDS each): split only into CUs that would idle */
+    if (max_strands > strands_switch) max_strands = strands_switch;
+    if (max_strands > 4) max_strands = 4;
+    int32_t strand_of[QA_MLP_MAX_OPS];
+    a.strands = mlp_strands(ops, num_ops, max_strands, strand_of);
+    for (int i = 0; i < num_ops; ++i) a.ops[i].strand = strand_of[i];
+    hipLaunchKernelGGL(qa_mlp_forward_kernel, dim3(tiles, a.strands), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

@@ -120,6 +120,69 @@ def test_hip_chain_matches_twin_and_torch(n):
     np.testing.assert_allclose(m2.cpu().numpy(), 0.5 * rm.cpu().numpy(), rtol=2e-4, atol=5e-5)
 
 
+def _strands(lib, prefix, chain, max_strands):
+    out = (C.c_int32 * chain.n_ops)()
+    ns = getattr(lib, prefix + "mlp_strands")(chain.ops, chain.n_ops, max_strands, out)
+    return ns, list(out)
+
+
+def test_strand_partition_of_the_chains_host_side():
+    """r5 / ABI 15: qa_mlp_strands (host-only, no GPU needed) against the oracle's restatement on every chain the runners describe, and what the
+    partition has to mean: an op and the last writer of every scratch column it reads are in one strand; the critic runs beside the actor."""
+    from quadrupedal_agility_amd import _capi
+    from tests.oracle_lib import load_oracle
+    qa, qo = _capi.load_library(), load_oracle()
+    ac, est, _ = modules(seed=1)
+    tac, test_ = tsc_modules(seed=1)[:2]
+    chains = [PolicyChain.describe(ac, est, True), PolicyChain.describe(ac, est, False), PolicyChain.describe(ac, est, True, hist_encoding=True),
+              PolicyChain.describe(ac, est, True, hist_encoding=True, with_critic=False), PolicyChain.describe_task_level(tac, test_, True),
+              PolicyChain.describe_task_level(tac, test_, True, part="critic")]
+    assert all(c is not None for c in chains)
+    for ci, ch in enumerate(chains):
+        for ms in (1, 2, 3, 4):
+            ns, st = _strands(qa, "qa_", ch, ms)
+            ns_o, st_o = _strands(qo, "qo_", ch, ms)
+            assert (ns, st) == (ns_o, st_o), (ci, ms)
+            assert 1 <= ns <= ms and set(st) == set(range(ns))
+            ops = [ch.ops[i] for i in range(ch.n_ops)]
+            for i, o in enumerate(ops):                       # flow dependences stay inside a strand
+                rd = o.k if o.kind == _capi.MLP_LAYER else o.n
+                if o.src_buf <= 0:
+                    continue
+                for c in range(o.src_col, o.src_col + rd):
+                    w = [j for j in range(i) if ops[j].dst_buf == o.src_buf and ops[j].dst_col <= c < ops[j].dst_col + ops[j].n]
+                    if w:
+                        assert st[w[-1]] == st[i], (ci, ms, i, w[-1])
+    # SSInfoGAIL.act: the critic's four layers (the ops that end in global output 1) are one strand, the actor's head (output 0) the other
+    ns, st = _strands(qa, "qa_", chains[0], 2)
+    ops = [chains[0].ops[i] for i in range(chains[0].n_ops)]
+    head = {o.out_index: st[i] for i, o in enumerate(ops) if o.kind == _capi.MLP_LAYER and o.dst_buf < 0}
+    assert ns == 2 and head[0] != head[1]
+    cost = [sum((o.k * o.n if o.kind == _capi.MLP_LAYER else 0) for i, o in enumerate(ops) if st[i] == g) for g in range(2)]
+    assert max(cost) < 0.75 * sum(cost)                        # the critic is ~68 % of the chain
+    assert _strands(qa, "qa_", chains[3], 4)[0] == 1          # the actor alone is one dependence chain: nothing to split
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hist", [False, True])
+def test_few_rows_split_over_strands_equal_the_same_rows_in_a_full_launch(hist):
+    """r5: a launch with few 16-row tiles gives each tile to up to 4 workgroups that run the chain's independent strands (critic | estimator ->
+    actor) side by side (csrc/qa_policy.hip mlp_strands); at 4096 rows (256 tiles) nothing is split.  Same arithmetic per op: the first rows
+    of a full launch and the same rows launched alone (512 rows: 32 tiles x strands; 1040: 65 tiles, a ragged last tile, up to 3 strands;
+    2048: 2 strands) must agree bit for bit."""
+    ac, est, n_obs = modules(seed=5)
+    ac, est = ac.cuda(), est.cuda()
+    chain = PolicyChain.describe(ac, est, True, hist_encoding=hist) if hist else PolicyChain.describe(ac, est, True)
+    chain.pack()
+    g = (torch.randn(4096, n_obs) * 1.5).cuda()
+    full = [t.clone() for t in chain.forward(g)]
+    for rows in (1, 512, 1040, 2048):
+        part = chain.forward(g[:rows].clone())
+        torch.cuda.synchronize()
+        for a, b in zip(part, full):
+            assert torch.equal(a, b[:rows]), rows
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 100, 4096])
 def test_hip_chain_history_encoder_variant(n):

@@ -128,6 +128,25 @@ pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn pr
     timeout 200 python tools/quick_time.py --terrain > $O/quick_time_terrain.txt 2>&1; grep "N=" $O/quick_time_terrain.txt
     timeout 200 python tools/phase_profile.py > $O/phase_profile.txt 2>&1; tail -12 $O/phase_profile.txt
     timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json; cut -c1-700 $O/bench_cfg2.json
+    # (ABI 15) few row tiles: the chain's strands on separate workgroups (qa_policy.hip mlp_strands); QA_MLP_STRANDS=1 = unsplit
+    timeout 300 python -m pytest tests/test_policy_chain.py -m gpu -q > $O/pytest_policy.log 2>&1; tail -3 $O/pytest_policy.log
+    for n in 512 1024 2048 4096; do
+      echo "rows $n split:   $(timeout 120 python tools/policy_time.py $n 2>&1 | tail -1)" >> $O/policy_time_strands.txt
+      echo "rows $n unsplit: $(QA_MLP_STRANDS=1 timeout 120 python tools/policy_time.py $n 2>&1 | tail -1)" >> $O/policy_time_strands.txt
+    done; cat $O/policy_time_strands.txt
+    # the 8-GPU share of config 2 is launch-bound in the update (3,072-row minibatches): every dense layer on this build's GEMMs (one launch per
+    # layer forward, ELU' in the input-gradient's epilogue) against the default (library products for the wide layers)
+    for v in heads all; do
+      QA_OWN_LAYERS=$v timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_own_$v.json
+      QA_OWN_LAYERS=$v timeout 300 python bench.py --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_1024_own_$v.json
+    done
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5/pro/bench_*own*.json")):
+    try:
+        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round(d["collection_s"] * 1e3, 2), "update", round(d["learn_s"] * 1e3, 2))
+    except Exception as e: print(f, "no line", e)
+PY
     ;;
 prox)      # the self-collision pairs the kernel does not model, on configs 3 and 4: smallest gaps over whole training runs
     timeout 1500 python tools/self_collision_proximity.py --amp --num_envs 1024 --iters 600 --out $O/self_collision_proximity_cfg3_1024x600.json > $O/cfg3.log 2>&1; tail -3 $O/cfg3.log
