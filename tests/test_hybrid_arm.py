@@ -21,7 +21,7 @@ def test_hybrid_env_steps_are_the_oracles_env_steps():
     for k in range(5):
         a = torch.randn(n, 12, generator=g)
         if k == 2:          # the learner's side of the seam writes on the DEVICE: it must reach the oracle before its next step
-            h.t["EPISODE_LENGTH"].fill_(999); o.t["EPISODE_LENGTH"][:] = 999
+            h.t["EPISODE_LENGTH"].fill_(10 ** 6); o.t["EPISODE_LENGTH"][:] = 10 ** 6
         h.step(a.cuda()); o.global_step = k; o.step(a.numpy())
         for name in ("OBS", "REW", "RESET", "ROOT_STATES", "DOF_STATE", "EPISODE_LENGTH", "OBS_DISC"):
             assert np.array_equal(h.t[name].cpu().numpy(), o.t[name]), (k, name)
@@ -33,6 +33,5 @@ def test_short_training_run_on_the_hybrid_arm(amp, monkeypatch):
     monkeypatch.setenv("QA_PARITY_NO_LOG", "0")
     from tools.return_curve_parity import run
     curves, wall, fps = run("hybrid", 128, 3, seed=2, amp=amp)
-    assert len(curves.get("Train/mean_episode_length", [])) >= 1 or True      # (no episode may have finished in 3 iterations of a fresh policy)
     losses = [v for k, vs in curves.items() if k.startswith("Loss/") for v in vs]
     assert losses and all(np.isfinite(losses)), "the learner's losses on the hybrid arm must be finite"

@@ -139,12 +139,13 @@ pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn pr
     for v in heads all; do
       QA_OWN_LAYERS=$v timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_own_$v.json
       QA_OWN_LAYERS=$v timeout 300 python bench.py --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_1024_own_$v.json
+      QA_OWN_LAYERS=$v timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_own_$v.json
     done
     python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r5/pro/bench_*own*.json")):
     try:
-        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round(d["collection_s"] * 1e3, 2), "update", round(d["learn_s"] * 1e3, 2))
+        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round((d.get("collection_s") or 0) * 1e3, 2), "update", round((d.get("learn_s") or 0) * 1e3, 2))
     except Exception as e: print(f, "no line", e)
 PY
     ;;
