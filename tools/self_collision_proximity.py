@@ -198,7 +198,12 @@ def main():
         env = lr.LeggedRobot(cfg, sim_device="cuda:0")
         runner = OnPolicyRunner(env, class_to_dict(Go2AgilityCfgPPO()), log_dir=None, device="cuda:0")
         if a.bbc_iters:
-            runner.load_bbc(train_behaviour_policy(a.bbc_iters, a.seed))
+            try:
+                runner.load_bbc(train_behaviour_policy(a.bbc_iters, a.seed))
+                runner.alg.actor_critic_bbc.eval()
+            except Exception as e:          # a GPU call is too dear to lose to a shape mismatch: say so and measure the random-init behaviour policy
+                print(f"behaviour policy NOT loaded ({type(e).__name__}: {e}); continuing with the random-init one", flush=True)
+                a.bbc_iters = 0
     else:
         from quadrupedal_agility_amd.legged_gym.envs import task_registry
         from quadrupedal_agility_amd.legged_gym.envs.go2.go2_locomotion_config import Go2LocomotionCfg, Go2LocomotionCfgAlgo
