@@ -69,15 +69,17 @@ def check_medians(per_tensor_errors):
     assert not bad, f"median env-step error above 3 x the measured p50: {bad}"
 
 
-# share of env-steps allowed outside TOL per protocol: ~2x the share measured with this TOL table on MI355X (profiles/r4_parity_flip_shares.txt,
+# share of env-steps allowed outside TOL per protocol: ~2x the share measured with this TOL table on MI355X (profiles/r5_parity_flip_shares.txt,
 # `QA_PARITY_MEASURE=1 pytest -m gpu -s -k parity`); filled in from that run
-# measured (r4, MI355X): plane 0.08 %, height field 1.1-1.5 %, ceiling 3.75 %, mocap 0.04 %, self-collision 0.10 %, articulated 0.1 % (64 envs) / 3.7 % (8192 envs,
-# fp32 world coordinates 900 m from the origin), course 0.003 %
-BUDGET = {"plane": 0.002, "height_field": 0.03, "ceiling": 0.075, "mocap": 0.001, "self_collision": 0.002, "articulated": 0.004, "articulated_8192": 0.075, "course": 0.001}
+# measured (r5, MI355X, env-local coordinates inside a step in kernel and oracle): plane 0.08-0.10 %, height field 0.35 % (64 envs) / 0.13 % (600), ceiling 1.27 %,
+# mocap 0.04 %, self-collision 0.10 %, articulated obstacles 0 of 1,024 (64 envs) and 0 of 49,152 (8192 envs), course 0 of 1,920 / 0 of 98,304.
+# (r4, world coordinates in fp32: height field 1.1-1.5 %, ceiling 3.75 %, articulated at 8192 envs 3.7 % -- an ulp 900 m from the origin is 6e-5 m;
+# budgets then: 0.03 / 0.075 / 0.075.)
+BUDGET = {"plane": 0.002, "height_field": 0.008, "ceiling": 0.026, "mocap": 0.001, "self_collision": 0.002, "articulated": 0.002, "articulated_8192": 0.002, "course": 0.001}
 
 
 def check_flips(name, flips, total, budget):
-    """env-steps outside TOL against a budget that is ~2x the share MEASURED with the current TOL table (profiles/r4_parity_flip_shares.txt).
+    """env-steps outside TOL against a budget that is ~2x the share MEASURED with the current TOL table (profiles/r5_parity_flip_shares.txt).
     QA_PARITY_MEASURE=1: print the share and do not judge it (how that profile is made)."""
     import os
     share = flips / max(total, 1)

@@ -18,6 +18,7 @@ def test_hybrid_env_steps_are_the_oracles_env_steps():
     h, o = HybridBackend(q), OracleSim(go2_cfg(n, seed=3))
     h.reset_all(); o.reset_all()
     g = torch.Generator().manual_seed(0)
+    fired = False
     for k in range(5):
         a = torch.randn(n, 12, generator=g)
         if k == 2:          # the learner's side of the seam writes on the DEVICE: it must reach the oracle before its next step

@@ -119,6 +119,13 @@ hybrid)    # config 3, 1024 envs x 1,000 iterations: this round's fast arm and t
     timeout 3500 python tools/d2_many.py --out $O --arms fast:1-24 hybrid:1-24 --workers 9 --hybrid_threads 28 --job_timeout 1800 --budget_s 2400 > $O/d2_many.log 2>&1
     tail -30 $O/d2_many.log
     ;;
+hybrid2)   # second batch: the hybrid seeds the first call did not finish (one job per seed, all at once: the oracle's OpenMP scaling is poor, so
+           # many jobs x few threads uses the 256 host cores better than few x many) and fast-arm seeds 16-30 beside them
+    ( timeout 3000 python tools/d2_many.py --out $O --arms fast:16-30 --workers 2 --job_timeout 1200 --budget_s 2400 > $O/d2_many_fast.log 2>&1 ) &
+    timeout 3100 python tools/d2_many.py --out $O --arms hybrid:6-8,15-24 --workers 13 --hybrid_threads 18 --job_timeout 2900 --budget_s 600 > $O/d2_many.log 2>&1
+    wait
+    tail -15 $O/d2_many.log; tail -4 $O/d2_many_fast.log
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
