@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 15
+#define QA_ABI_VERSION 16
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -741,6 +741,17 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
  * in the environment switches the split off.  qa_mlp_strands is the (host-only) partition itself: strand_of[i] = strand of op i, return value =
  * number of strands used (1 = not split), or a negative QA_E_* code. */
 int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, int32_t *strand_of);
+/* r5 (ABI 16): launches with a tile per CU or more (> 2048 rows).  There is nothing to split over CUs, and one workgroup walking the chain layer by
+ * layer pays a cold weight stream, an epilogue and a workgroup barrier per layer (~30 % of a tile's cycles for SSInfoGAIL.act's 13 layers) while the
+ * CU does nothing else.  When the chain has two strands (qa_mlp_strands with max_strands 2) and their buffers fit the CU's 160 KB of LDS, qa_mlp_forward
+ * runs them SIDE BY SIDE in every workgroup: wavefronts 0..3 strand 0, wavefronts 4..7 strand 1, each group with its own copy of scratch buffers 1..3
+ * (as wide as its ops touch them) behind the shared input tile, and its own barrier.  Per-tile arithmetic is unchanged => bit-identical outputs.
+ * qa_mlp_groups is the (host-only) plan: strand_of[num_ops]; base / stride [2][4] = LDS offset and row stride (floats) of buffer b as group g sees it
+ * (stride 0: the group does not touch the buffer); *lds_floats = the launch's LDS size.  Returns 1 when the two-group launch applies to this chain,
+ * 0 when it does not (one strand, or no fit), negative QA_E_* on a malformed chain.  qa_mlp_set_groups(1) keeps the one-group kernel, (2) restores the
+ * default (also QA_MLP_GROUPS in the environment); returns the previous setting. */
+int qa_mlp_groups(const qa_mlp_op *ops, int32_t num_ops, int32_t x_cols, int32_t *strand_of, int32_t *base, int32_t *stride, int32_t *lds_floats);
+int qa_mlp_set_groups(int32_t groups);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Task-level (TSC) env-side math of SURVEY 8a row a18: the two per-step pieces of tsc/legged_gym/envs/base/legged_robot.py

@@ -2363,6 +2363,58 @@ int qo_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, i
     return ns;
 }
 
+/* The two-group launch's LDS plan (include/qa_sim.h, ABI 16), checker-side restatement: buffer 0 as wide as anyone reads it (at least x_cols); then,
+ * group by group, buffers 1, 2, 3 in that order, each as wide as the furthest column one of the group's ops reads or writes; 16 rows per buffer, row
+ * stride = width rounded up to 32 floats, + 4; a buffer that is first touched after an earlier (and at least as wide) buffer of its group was last
+ * touched takes that buffer's place instead of new room; behind everything, room for the padded k-blocks of the layer that reads furthest.  The kernel's k-block
+ * padding rule (qa_policy.hip mlp_kb) is restated here too. */
+static int qo_mlp_kblocks(int k, int n) {
+    const int tiles = (n + 15) / 16, per_wave = (tiles + 7) / 8, depth = per_wave > 2 ? 4 : 8, blocks = (k + 15) / 16;
+    return (blocks + depth - 1) / depth * depth;
+}
+int qo_mlp_groups(const qa_mlp_op *ops, int32_t num_ops, int32_t x_cols, int32_t *strand_of, int32_t *base, int32_t *stride, int32_t *lds_floats) {
+    if (!ops || !strand_of || !base || !stride || !lds_floats || num_ops <= 0 || num_ops > QA_MLP_MAX_OPS || x_cols <= 0 || x_cols > QA_MLP_BUF0_COLS) return QA_E_ARG;
+    if (qo_mlp_strands(ops, num_ops, 2, strand_of) != 2) return 0;
+    int far[2][4];
+    memset(far, 0, sizeof(far));
+    int far0 = x_cols;
+    for (int i = 0; i < num_ops; ++i) {
+        const int g = strand_of[i], reach_src = ops[i].src_col + (ops[i].kind == QA_MLP_LAYER ? ops[i].k : ops[i].n);
+        if (ops[i].src_buf == 0) { if (reach_src > far0) far0 = reach_src; }
+        else if (reach_src > far[g][ops[i].src_buf]) far[g][ops[i].src_buf] = reach_src;
+        if (ops[i].dst_buf > 0 && ops[i].dst_col + ops[i].n > far[g][ops[i].dst_buf]) far[g][ops[i].dst_buf] = ops[i].dst_col + ops[i].n;
+    }
+    const int s0 = (far0 + 31) / 32 * 32 + 4;
+    int at = 16 * s0;
+    for (int g = 0; g < 2; ++g) {
+        base[4 * g] = 0; stride[4 * g] = s0;
+        int busy_until[4] = {0, 0, 0, 0};                      /* index of the last op that needs what lies in the buffer's region */
+        for (int b = 1; b < 4; ++b) {
+            stride[4 * g + b] = far[g][b] ? (far[g][b] + 31) / 32 * 32 + 4 : 0;
+            int born = num_ops, dies = -1;
+            for (int i = 0; i < num_ops; ++i)
+                if (strand_of[i] == g && (ops[i].src_buf == b || ops[i].dst_buf == b)) { if (i < born) born = i; dies = i; }
+            /* laid over the lowest-numbered buffer of the group that is at least as wide and whose contents nobody needs any more when this one is
+             * first touched */
+            int host = 0;
+            for (int e = 1; e < b && !host; ++e)
+                if (stride[4 * g + b] > 0 && stride[4 * g + e] >= stride[4 * g + b] && busy_until[e] < born) host = e;
+            if (host) { base[4 * g + b] = base[4 * g + host]; busy_until[host] = dies; busy_until[b] = dies; }
+            else { base[4 * g + b] = at; at += 16 * stride[4 * g + b]; busy_until[b] = dies; }
+        }
+    }
+    for (int i = 0; i < num_ops; ++i) {
+        if (ops[i].kind != QA_MLP_LAYER) continue;
+        const int g = strand_of[i], b = ops[i].src_buf;
+        const int last_read = base[4 * g + b] + 15 * stride[4 * g + b] + ops[i].src_col + 16 * qo_mlp_kblocks(ops[i].k, ops[i].n);
+        if (last_read > at) at = last_read;
+    }
+    *lds_floats = (at + 3) / 4 * 4;
+    return *lds_floats * 4 <= 160 * 1024 - 256;
+}
+static int qo_groups_setting = 2;
+int qo_mlp_set_groups(int32_t groups) { const int prev = qo_groups_setting; qo_groups_setting = groups >= 2 ? 2 : 1; return prev; }
+
 int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_cols, const qa_mlp_op *ops, int32_t num_ops, const float *packed,
                    float *const *outs, const int64_t *out_strides, int32_t num_outs, void *stream) {
     (void)stream;

@@ -61,6 +61,9 @@ struct MlpArgs {
     float *out[QA_MLP_MAX_OUTPUTS];
     int64_t out_stride[QA_MLP_MAX_OUTPUTS];
     MlpDevOp ops[QA_MLP_MAX_OPS];
+    /* two-group launch (qa_mlp_forward_groups_kernel): LDS base / row stride (floats) of buffers 0..3 as group g sees them, the LDS size and
+     * where the scratch part (zeroed at the start) begins */
+    int32_t g_base[2][MLP_NBUF], g_stride[2][MLP_NBUF], g_lds_floats, g_scratch0;
 };
 
 struct PackLayer { const float *w, *b; int32_t n, k; int64_t w_off, b_off; };
@@ -90,14 +93,14 @@ __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) 
  * The weight fragments are fetched PF-1 k-blocks ahead of their use into a ring of PF register stages (the L2 round trip is
  * several hundred cycles; one k-block of MFMAs is 128 * TPW cycles).  The sched_barriers keep the compiler from sinking the
  * prefetch back down to its use, which it otherwise does to shorten live ranges. */
-template <int TPW>
-__device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packed, float *lds, const MlpArgs &a, int row0, int wave, int lane) {
-    constexpr int PF = mlp_pf(TPW);
+struct MlpPlace { int src_base, src_stride, dst_base, dst_stride; };      /* where the op's source / destination buffers are in LDS (floats) */
+template <int TPW, int PF = mlp_pf(TPW)>
+__device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packed, float *lds, const MlpArgs &a, int row0, int wave, int lane, const MlpPlace pl) {
     const int nt = op.nt, kb = op.kb;
     const int t0 = wave * TPW;
     if (t0 >= nt) return;
     const int m = lane & 15, kq = lane >> 4;
-    const float *src = lds + mlp_base(op.src_buf) + m * mlp_stride(op.src_buf) + op.src_col + 4 * kq;
+    const float *src = lds + pl.src_base + m * pl.src_stride + op.src_col + 4 * kq;
     const f4 *wp = reinterpret_cast<const f4 *>(packed + op.w_off) + lane;
     int toff[TPW];
 #pragma unroll
@@ -147,8 +150,8 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
     /* D layout: register r of lane l = D[row 4 (l / 16) + r][column l % 16].  Destination resolved once per layer. */
     const int act = op.act;
     if (op.dst_buf >= 0) {
-        const int ds = mlp_stride(op.dst_buf);
-        float *d = lds + mlp_base(op.dst_buf) + (4 * kq) * ds + op.dst_col + m;
+        const int ds = pl.dst_stride;
+        float *d = lds + pl.dst_base + (4 * kq) * ds + op.dst_col + m;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int col = (t0 + i) * 16;
@@ -218,15 +221,78 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs 
                 lds[mlp_base(op.dst_buf) + r * ds + op.dst_col + c] = lds[mlp_base(op.src_buf) + r * ss + op.src_col + c];
             }
         } else {
+            const MlpPlace pl{mlp_base(op.src_buf), mlp_stride(op.src_buf), op.dst_buf >= 0 ? mlp_base(op.dst_buf) : 0, op.dst_buf >= 0 ? mlp_stride(op.dst_buf) : 0};
             switch (op.tpw) {
-                case 1: mlp_layer<1>(op, a.packed, lds, a, row0, wave, lane); break;
-                case 2: mlp_layer<2>(op, a.packed, lds, a, row0, wave, lane); break;
-                default: mlp_layer<4>(op, a.packed, lds, a, row0, wave, lane); break;
+                case 1: mlp_layer<1>(op, a.packed, lds, a, row0, wave, lane, pl); break;
+                case 2: mlp_layer<2>(op, a.packed, lds, a, row0, wave, lane, pl); break;
+                default: mlp_layer<4>(op, a.packed, lds, a, row0, wave, lane, pl); break;
             }
         }
         __syncthreads();
         MLP_STAMP(o + 1);
         op = nxt;
+    }
+}
+
+/* Many rows (a tile per CU and more): the chain's independent strands side by side INSIDE the workgroup.  At 4096 rows the launch above is one
+ * workgroup per CU walking 13 layers one after the other, a workgroup barrier behind each: every layer pays ~3.3 k cycles of cold weight stream +
+ * epilogue + barrier whether it is 671 -> 512 or 64 -> 4 (30 % of the 186 k cycles of a tile, profiles/r1_policy_kernel_timing.md), and nothing else
+ * runs on the CU meanwhile.  Here waves 0..3 (one per SIMD) run strand 0 and waves 4..7 strand 1 (mlp_strands: critic | estimator -> encoder ->
+ * actor), each group with its own LDS scratch buffers and its own barrier (an LDS arrival counter), so that one strand's narrow layers and pipeline
+ * fills hide behind the other's MFMA work; with four waves per group a 512-wide layer is 8 column tiles per wave (one A fragment per 32 MFMAs).
+ * Per-tile arithmetic is the one-group kernel's (same k order per output), so the outputs are bit-identical. */
+constexpr int GRP_WAVES = MLP_WAVES / 2;
+__device__ __forceinline__ void group_barrier(int *ctr, int &target, int lane) {
+    /* the LDS unit serves a CU's requests in order: once this wave's writes have returned (lgkmcnt 0) its arrival is behind them for every reader */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    target += GRP_WAVES;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_groups_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_arrive[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * MLP_ROWS;
+    if (tid < 2) s_arrive[tid] = 0;
+    for (int i = a.g_scratch0 + tid; i < a.g_lds_floats; i += MLP_WAVES * 64) lds[i] = 0.f;
+    {   /* input tile: one wavefront per row at a time; columns beyond x_cols (row padding, read against zero weights) are zero */
+        const int s0 = a.g_stride[0][0];
+        for (int r = wave; r < MLP_ROWS; r += MLP_WAVES) {
+            const bool live = row0 + r < a.rows;
+            const float *xr = a.x + (int64_t)(row0 + r) * a.x_stride;
+            for (int c0 = 0; c0 < s0; c0 += 256) {          /* four loads in flight per lane */
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int c = c0 + lane + 64 * q; v[q] = (live && c < a.x_cols) ? xr[c] : 0.f; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int c = c0 + lane + 64 * q; if (c < s0) lds[r * s0 + c] = v[q]; }
+            }
+        }
+    }
+    __syncthreads();
+    const int grp = wave / GRP_WAVES, gw = wave % GRP_WAVES, gtid = tid % (GRP_WAVES * 64);
+    int target = 0;
+    for (int o = 0; o < a.num_ops; ++o) {
+        if (a.ops[o].strand != grp) continue;                     /* group-uniform */
+        const MlpDevOp op = a.ops[o];
+        const MlpPlace pl{a.g_base[grp][op.src_buf], a.g_stride[grp][op.src_buf], op.dst_buf >= 0 ? a.g_base[grp][op.dst_buf] : 0,
+                          op.dst_buf >= 0 ? a.g_stride[grp][op.dst_buf] : 0};
+        if (op.kind == QA_MLP_COPY) {
+            for (int i = gtid; i < MLP_ROWS * op.n; i += GRP_WAVES * 64) {
+                const int r = i / op.n, c = i - r * op.n;
+                lds[pl.dst_base + r * pl.dst_stride + op.dst_col + c] = lds[pl.src_base + r * pl.src_stride + op.src_col + c];
+            }
+        } else {
+            const int per = (op.nt + GRP_WAVES - 1) / GRP_WAVES;      /* column tiles per wave of the group */
+            if (per <= 1) mlp_layer<1, 8>(op, a.packed, lds, a, row0, gw, lane, pl);
+            else if (per <= 2) mlp_layer<2, 8>(op, a.packed, lds, a, row0, gw, lane, pl);
+            else if (per <= 4) mlp_layer<4, 4>(op, a.packed, lds, a, row0, gw, lane, pl);
+            else mlp_layer<8, 4>(op, a.packed, lds, a, row0, gw, lane, pl);
+        }
+        group_barrier(&s_arrive[grp], target, lane);
     }
 }
 
@@ -272,6 +338,56 @@ int mlp_strands(const qa_mlp_op *ops, int num_ops, int max_strands, int32_t *str
     }
     for (int i = 0; i < num_ops; ++i) strand_of[i] = strand_of_root[find(i)];
     return ns;
+}
+
+/* LDS geometry of the two-group launch: buffer 0 (the input tile, shared) as wide as the chain reads it; behind it each group's scratch buffers
+ * 1..3, each as wide as the group's ops touch them (row stride = 4 mod 32 floats, as in the one-group layout), and enough room behind the last row
+ * for the padded k-blocks of every layer (read against zero weights; what lies there is finite: zeroed scratch or activations).  false when
+ * the chain does not fit the CU's LDS this way. */
+constexpr int MLP_LDS_LIMIT_FLOATS = (160 * 1024 - 256) / 4;
+bool mlp_group_geometry(const qa_mlp_op *ops, int num_ops, const int32_t *strand_of, int x_cols, MlpArgs &a) {
+    int width[2][MLP_NBUF] = {{0}};
+    int w0 = x_cols;
+    for (int i = 0; i < num_ops; ++i) {
+        const qa_mlp_op &o = ops[i];
+        const int g = strand_of[i], rd = o.kind == QA_MLP_LAYER ? o.k : o.n;
+        if (g < 0 || g > 1) return false;
+        if (o.src_buf == 0) w0 = w0 > o.src_col + rd ? w0 : o.src_col + rd;
+        else width[g][o.src_buf] = width[g][o.src_buf] > o.src_col + rd ? width[g][o.src_buf] : o.src_col + rd;
+        if (o.dst_buf > 0) width[g][o.dst_buf] = width[g][o.dst_buf] > o.dst_col + o.n ? width[g][o.dst_buf] : o.dst_col + o.n;
+    }
+    /* first / last op of the group that touches the buffer: a buffer first used after another one's last use is laid over it (the critic's third
+     * layer writes where its first layer's output was) */
+    int first[2][MLP_NBUF], last[2][MLP_NBUF];
+    for (int g = 0; g < 2; ++g) for (int b = 0; b < MLP_NBUF; ++b) { first[g][b] = num_ops; last[g][b] = -1; }
+    for (int i = 0; i < num_ops; ++i) {
+        const int g = strand_of[i];
+        for (int b : {ops[i].src_buf, ops[i].dst_buf})
+            if (b > 0) { first[g][b] = first[g][b] < i ? first[g][b] : i; last[g][b] = i; }
+    }
+    auto stride_of = [](int w) { return (w + 31) / 32 * 32 + 4; };
+    int cur = MLP_ROWS * stride_of(w0);
+    a.g_scratch0 = cur;
+    for (int g = 0; g < 2; ++g) {
+        a.g_base[g][0] = 0; a.g_stride[g][0] = stride_of(w0);
+        for (int b = 1; b < MLP_NBUF; ++b) {
+            a.g_stride[g][b] = width[g][b] > 0 ? stride_of(width[g][b]) : 0;
+            int over = 0;
+            for (int e = 1; e < b && !over; ++e)
+                if (a.g_stride[g][b] > 0 && a.g_stride[g][e] >= a.g_stride[g][b] && last[g][e] < first[g][b]) over = e;
+            if (over) { a.g_base[g][b] = a.g_base[g][over]; last[g][over] = last[g][b]; }      /* the region stays taken until b's last use */
+            else { a.g_base[g][b] = cur; cur += MLP_ROWS * a.g_stride[g][b]; }
+        }
+    }
+    for (int i = 0; i < num_ops; ++i) {
+        const qa_mlp_op &o = ops[i];
+        if (o.kind != QA_MLP_LAYER) continue;
+        const int g = strand_of[i];
+        const int end = a.g_base[g][o.src_buf] + (MLP_ROWS - 1) * a.g_stride[g][o.src_buf] + o.src_col + 16 * mlp_kb(o.k, o.n);
+        cur = cur > end ? cur : end;
+    }
+    a.g_lds_floats = (cur + 3) & ~3;
+    return a.g_lds_floats <= MLP_LDS_LIMIT_FLOATS;
 }
 
 int lds_base(int b) { return b == 0 ? 0 : b == 1 ? B1 : b == 2 ? B2 : B3; }
@@ -332,6 +448,30 @@ int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, i
     return mlp_strands(ops, num_ops, max_strands > 4 ? 4 : max_strands, strand_of);
 }
 
+static int g_mlp_groups = -1;           /* -1: not decided yet (QA_MLP_GROUPS in the environment, default 2) */
+static int mlp_groups_switch() {
+    if (g_mlp_groups < 0) { const char *e = getenv("QA_MLP_GROUPS"); g_mlp_groups = e ? (atoi(e) >= 2 ? 2 : 1) : 2; }
+    return g_mlp_groups;
+}
+
+int qa_mlp_set_groups(int32_t groups) {
+    const int prev = mlp_groups_switch();
+    g_mlp_groups = groups >= 2 ? 2 : 1;
+    return prev;
+}
+
+int qa_mlp_groups(const qa_mlp_op *ops, int32_t num_ops, int32_t x_cols, int32_t *strand_of, int32_t *base, int32_t *stride, int32_t *lds_floats) {
+    int rc = mlp_check(ops, num_ops, "qa_mlp_groups");
+    if (rc != QA_OK) return rc;
+    if (!strand_of || !base || !stride || !lds_floats || x_cols <= 0 || x_cols > QA_MLP_BUF0_COLS) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_groups: bad argument"); return QA_E_ARG; }
+    MlpArgs a{};
+    if (mlp_strands(ops, num_ops, 2, strand_of) != 2) return 0;
+    const bool fits = mlp_group_geometry(ops, num_ops, strand_of, x_cols, a);
+    for (int g = 0; g < 2; ++g) for (int b = 0; b < MLP_NBUF; ++b) { base[g * MLP_NBUF + b] = a.g_base[g][b]; stride[g * MLP_NBUF + b] = a.g_stride[g][b]; }
+    *lds_floats = a.g_lds_floats;
+    return fits ? 1 : 0;
+}
+
 int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weights, const float *const *biases, float *packed, int64_t packed_floats,
                 void *stream) {
     int rc = mlp_check(ops, num_ops, "qa_mlp_pack");
@@ -377,6 +517,20 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
     if (max_strands > strands_switch) max_strands = strands_switch;
     if (max_strands > 4) max_strands = 4;
     int32_t strand_of[QA_MLP_MAX_OPS];
+    /* a tile per CU or more: nothing to split over CUs -- two strands side by side inside every workgroup instead (qa_mlp_forward_groups_kernel),
+     * when the chain has two and their buffers fit the CU's LDS; QA_MLP_GROUPS=1 in the environment / qa_mlp_set_groups(1) keeps the one-group kernel (A/B runs) */
+    if (max_strands < 2 && mlp_groups_switch() >= 2 && mlp_strands(ops, num_ops, 2, strand_of) == 2 && mlp_group_geometry(ops, num_ops, strand_of, x_cols, a)) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(qa_mlp_forward_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                            MLP_LDS_LIMIT_FLOATS * 4);
+        if (attr == hipSuccess) {
+            a.strands = 2;
+            for (int i = 0; i < num_ops; ++i) a.ops[i].strand = strand_of[i];
+            hipLaunchKernelGGL(qa_mlp_forward_groups_kernel, dim3(tiles), dim3(MLP_WAVES * 64), (size_t)a.g_lds_floats * 4, (hipStream_t)stream, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward (groups): %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+            return QA_OK;
+        }
+    }
     a.strands = mlp_strands(ops, num_ops, max_strands, strand_of);
     for (int i = 0; i < num_ops; ++i) a.ops[i].strand = strand_of[i];
     hipLaunchKernelGGL(qa_mlp_forward_kernel, dim3(tiles, a.strands), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);

@@ -126,14 +126,21 @@ static int fail_hip(hipError_t e, const char *what) {
 // observation phase alone.
 static_assert(QA_BLOCK == 64, "wave_lds_sync() assumes single-wavefront workgroups");
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void stage_table(float *s_tbl) {
-    constexpr int PER = (QA_TBL_FLOATS + QA_BLOCK - 1) / QA_BLOCK;
-    float v[PER];
+constexpr int QA_TBL_PER = (QA_TBL_FLOATS + QA_BLOCK - 1) / QA_BLOCK;
+// the table's way into LDS in two halves, so that a kernel can put its other loads between them (one round trip instead of two)
+__device__ __forceinline__ void stage_table_load(float (&v)[QA_TBL_PER]) {
 #pragma unroll
-    for (int r = 0; r < PER; ++r) { int i = threadIdx.x + QA_BLOCK * r; v[r] = (i < QA_TBL_FLOATS) ? c_tbl[i] : 0.f; }   // loads in flight together
+    for (int r = 0; r < QA_TBL_PER; ++r) { int i = (threadIdx.x & (QA_BLOCK - 1)) + QA_BLOCK * r; v[r] = (i < QA_TBL_FLOATS) ? c_tbl[i] : 0.f; }   // loads in flight together
+}
+__device__ __forceinline__ void stage_table_store(float *s_tbl, const float (&v)[QA_TBL_PER]) {
 #pragma unroll
-    for (int r = 0; r < PER; ++r) { int i = threadIdx.x + QA_BLOCK * r; if (i < QA_TBL_FLOATS) s_tbl[i] = v[r]; }
+    for (int r = 0; r < QA_TBL_PER; ++r) { int i = (threadIdx.x & (QA_BLOCK - 1)) + QA_BLOCK * r; if (i < QA_TBL_FLOATS) s_tbl[i] = v[r]; }
     wave_lds_sync();
+}
+__device__ __forceinline__ void stage_table(float *s_tbl) {
+    float v[QA_TBL_PER];
+    stage_table_load(v);
+    stage_table_store(s_tbl, v);
 }
 
 // legged_robot.py:532-540 + :474-530, executed redundantly by the 4 lanes of the quad
@@ -709,6 +716,58 @@ QA_DEV void shift_history_store(const Ptrs &p, int bix, int lane, int N, float (
     }
 }
 
+// The stores with a scalar row base + one lane offset (saddr form): issued INSIDE the substep loop (QA_STORE_BEFORE_LAST) the 64-bit per-row
+// addresses of the form above are loop invariants the compiler hoists -- 32 VGPRs across the loop, 74 spilled values
+#define QA_HSTORE_S(voff, src, base, OFF) asm volatile("global_store_dword %0, %1, %2 offset:" #OFF :: "v"(voff), "a"(src), "s"(base) : "memory")
+template <int EPB>
+QA_DEV void shift_history_store_s(const Ptrs &p, int bix, int lane, int N, float (&hv)[EPB][9]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int voff = lane * 4;
+#pragma unroll
+    for (int g = 0; g < EPB; ++g) {
+        const int ge = bix * EPB + g;
+        if (ge < N) {
+            const uint64_t ra = (uint64_t)(p.obs + (int64_t)ge * QA_NUM_OBS + 90);
+            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ra);
+            QA_HSTORE_S(voff, hv[g][0], row, 0); QA_HSTORE_S(voff, hv[g][1], row, 256); QA_HSTORE_S(voff, hv[g][2], row, 512); QA_HSTORE_S(voff, hv[g][3], row, 768);
+            QA_HSTORE_S(voff, hv[g][4], row, 1024); QA_HSTORE_S(voff, hv[g][5], row, 1280); QA_HSTORE_S(voff, hv[g][6], row, 1536); QA_HSTORE_S(voff, hv[g][7], row, 1792);
+            if (lane == 0) QA_HSTORE_S(voff, hv[g][8], row, 2048);
+        }
+    }
+}
+// QA_HIST_X4: the same shift as two 16-byte accesses + one dword per lane and row (rows are only 4-byte aligned, 671 floats: the accesses are
+// dword-aligned 16-byte ones, which the unaligned access mode of HSA queues permits) -- 48 memory instructions per wavefront and direction
+// instead of 144
+#define QA_HLOAD4(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=a"(dst) : "v"(ptr) : "memory")
+#define QA_HSTORE4(voff, src, base, OFF) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #OFF :: "v"(voff), "a"(src), "s"(base) : "memory")
+struct HistRegs4 { f4 q[QA_BLOCK / 4][2]; float last[QA_BLOCK / 4]; };
+template <int EPB>
+QA_DEV void shift_history_load4(const Ptrs &p, int bix, int lane, int N, HistRegs4 &h) {
+#pragma unroll
+    for (int g = 0; g < EPB; ++g) {
+        const int ge = min(bix * EPB + g, N - 1);
+        const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + 4 * lane;
+        QA_HLOAD4(h.q[g][0], hist, 0); QA_HLOAD4(h.q[g][1], hist, 1024);
+        const float *last = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + 512;          // float 512 of the 513: every lane reads it, lane 0 stores it
+        QA_HLOAD(h.last[g], last, 0);
+    }
+}
+template <int EPB>
+QA_DEV void shift_history_store4(const Ptrs &p, int bix, int lane, int N, HistRegs4 &h) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int voff = lane * 16;
+#pragma unroll
+    for (int g = 0; g < EPB; ++g) {
+        const int ge = bix * EPB + g;
+        if (ge < N) {
+            const uint64_t ra = (uint64_t)(p.obs + (int64_t)ge * QA_NUM_OBS + 90);
+            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ra);
+            QA_HSTORE4(voff, h.q[g][0], row, 0); QA_HSTORE4(voff, h.q[g][1], row, 1024);
+            if (lane == 0) QA_HSTORE_S(voff, h.last[g], row, 2048);
+        }
+    }
+}
+
 // MODE 0: the whole LeggedRobot.step of the behaviour-level (BBC) tree.  MODE 1: the physics part only -- action-history
 // roll, delay, clip, decimation x (PD torque -> substep), refresh of the simulator tensors -- for the task-level (TSC) env,
 // whose own post_physics_step (goals, termination, rewards, reset, three observation rows) are separate kernels (qa_tsc_*).
@@ -743,6 +802,19 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     // write was a burst nobody overlapped: 9.7 k of the kernel's 136 k ticks waiting for it (profiles/r5_env_step_phase_profile.txt).  The
     // values wait in registers the substeps do not use (the compiler parks them in AGPRs: 2 x 144 v_accvgpr moves, ~1.3 k ticks).
     float hv[EPB][9];
+#ifdef QA_HIST_X4
+    HistRegs4 hv4;
+    static_assert(EPB == QA_BLOCK / 4, "HistRegs4 is sized for one quad per env");
+#define QA_SHIFT_LOAD() shift_history_load4<EPB>(p, bix, tix, N, hv4)
+#define QA_SHIFT_STORE() shift_history_store4<EPB>(p, bix, tix, N, hv4)
+#else
+#define QA_SHIFT_LOAD() shift_history_load<EPB>(p, bix, tix, N, hv)
+#ifdef QA_STORE_BEFORE_LAST
+#define QA_SHIFT_STORE() shift_history_store_s<EPB>(p, bix, tix, N, hv)
+#else
+#define QA_SHIFT_STORE() shift_history_store<EPB>(p, bix, tix, N, hv)
+#endif
+#endif
 #ifdef QA_SHIFT_EARLY_STORE
     if (MODE == 0 && LPE == 4) {
         shift_history_load<EPB>(p, bix, tix, N, hv);
@@ -750,7 +822,14 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         shift_history_store<EPB>(p, bix, tix, N, hv);
     } else
 #endif
+#ifdef QA_SPLIT_TABLE
+    // the table's loads go out first and its LDS writes wait until the step's other loads (actions, state, the post-physics inputs) are in
+    // flight too: one memory round trip in front of the physics instead of two
+    float tblv[QA_TBL_PER];
+    stage_table_load(tblv);
+#else
     stage_table(s_tbl);
+#endif
     if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
@@ -854,6 +933,9 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         if (c.articulated_obstacles) { stage_obstacles(p, env, leg, ob_rec, T.ancx, T.ancy); T.ob = ob_rec; T.ob_acc = ob_rec + 12 * QA_OBST_PER_ENV; }
         wave_lds_sync();
     }
+#ifdef QA_SPLIT_TABLE
+    stage_table_store(s_tbl, tblv);
+#endif
     // env-local horizontal coordinates for the substeps (TerrainView): offsets from the world position the step starts at
     const float anc_x = st.pos.x, anc_y = st.pos.y;
     st.pos.x = 0.f; st.pos.y = 0.f;
@@ -881,7 +963,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         asm volatile("" :: "v"(in.esum[0]), "v"(in.esum[3]), "v"(in.esum[6]), "v"(in.esum[9]), "v"(in.esum[13]) : "memory");
         asm volatile("" :: "v"(in.cmd[0]), "v"(in.cmd[4]), "v"(in.latc[0]), "v"(in.latc[4]), "v"(in.eps), "v"((int)in.epl0), "v"((int)in.last_contact) : "memory");
         }
-        shift_history_load<EPB>(p, bix, tix, N, hv);
+        QA_SHIFT_LOAD();
     }
 #endif
     for (int d = 0; d < c.decimation; ++d) {
@@ -900,6 +982,11 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
             float lim = tbl[T_EFFORT + k];
             tau[k] = clampf(t, -lim, lim);
         }
+#ifdef QA_STORE_BEFORE_LAST
+        // the history shift's stores go out in front of the LAST substep (the loads landed substeps ago): 17 MB from 256 wavefronts at once
+        // drain beside ~12 us of arithmetic instead of in front of the tail's own stores
+        if (MODE == 0 && LPE == 4 && d == c.decimation - 1) QA_SHIFT_STORE();
+#endif
         phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
     }
     { float bi_[10]; priv_unpark(priv, act, sp, sd, bi_); }
@@ -919,8 +1006,8 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     }
 
     QA_STAMP(3);
-#ifndef QA_SHIFT_EARLY_STORE
-    if (MODE == 0 && LPE == 4) shift_history_store<EPB>(p, bix, tix, N, hv);     // in place: every lane loaded its 9 values of a row long ago; the tail's writes to the same rows come after these in program order
+#if !defined(QA_SHIFT_EARLY_STORE) && !defined(QA_STORE_BEFORE_LAST)
+    if (MODE == 0 && LPE == 4) QA_SHIFT_STORE();     // in place: every lane loaded its 9 values of a row long ago; the tail's writes to the same rows come after these in program order
 #endif
     // ---- refresh_*: body positions of the new state, contact forces per body
     V3 org[4];

@@ -163,6 +163,89 @@ def test_strand_partition_of_the_chains_host_side():
     assert _strands(qa, "qa_", chains[3], 4)[0] == 1          # the actor alone is one dependence chain: nothing to split
 
 
+def _groups(lib, prefix, chain, x_cols):
+    st = (C.c_int32 * chain.n_ops)()
+    base, stride, lds = (C.c_int32 * 8)(), (C.c_int32 * 8)(), C.c_int32(0)
+    rc = getattr(lib, prefix + "mlp_groups")(chain.ops, chain.n_ops, x_cols, st, base, stride, C.byref(lds))
+    return rc, list(st), list(base), list(stride), lds.value
+
+
+def test_two_group_plan_of_the_chains_host_side():
+    """r5 / ABI 16: qa_mlp_groups (host-only) -- the LDS plan of the launch that runs a chain's two strands side by side inside every workgroup --
+    against the oracle's restatement, and what the plan has to guarantee: the two groups' scratch buffers and the input tile are pairwise
+    disjoint, every column an op touches lies inside its buffer's row, every layer's padded k-blocks are read from inside the launch's LDS,
+    and the whole fits a CU (160 KB).  SSInfoGAIL.act's chains (both actor variants) must qualify: that is the 4096-env rollout's launch."""
+    from tests.oracle_lib import load_oracle
+    qa, qo = _capi.load_library(), load_oracle()
+    ac, est, n_obs = modules(seed=1)
+    tac, test_ = tsc_modules(seed=1)[:2]
+    chains = [(PolicyChain.describe(ac, est, True), n_obs), (PolicyChain.describe(ac, est, False), n_obs), (PolicyChain.describe(ac, est, True, hist_encoding=True), n_obs),
+              (PolicyChain.describe(ac, est, True, hist_encoding=True, with_critic=False), n_obs), (PolicyChain.describe_task_level(tac, test_, True), 800)]
+    applies = []
+    for ci, (ch, x_cols) in enumerate(chains):
+        got, ref = _groups(qa, "qa_", ch, x_cols), _groups(qo, "qo_", ch, x_cols)
+        assert got[0] == ref[0] and got[0] in (0, 1), ci
+        applies.append(got[0])
+        if _strands(qa, "qa_", ch, 2)[0] != 2:
+            assert got[0] == 0
+            continue
+        assert got == ref, ci
+        rc, st, base, stride, lds = got
+        ops = [ch.ops[i] for i in range(ch.n_ops)]
+        # regions (start, end, group, first op, last op).  Two regions may only overlap inside ONE group, and then only if the buffers' lifetimes do
+        # not (a buffer first touched after another's last use is laid over it: the critic's third layer writes where its first layer's output was)
+        regions = [(0, 16 * stride[0], -1, -1, ch.n_ops)]                # the shared input tile
+        for g in range(2):
+            assert base[4 * g] == 0 and stride[4 * g] == stride[0] >= x_cols and stride[4 * g] % 32 == 4
+            for b in range(1, 4):
+                if stride[4 * g + b]:
+                    assert stride[4 * g + b] % 32 == 4
+                    touch = [i for i, o in enumerate(ops) if st[i] == g and b in (o.src_buf, o.dst_buf)]
+                    regions.append((base[4 * g + b], base[4 * g + b] + 16 * stride[4 * g + b], g, touch[0], touch[-1]))
+        assert max(r[1] for r in regions) <= lds, ci
+        for x in range(len(regions)):
+            for y in range(x + 1, len(regions)):
+                A, B = regions[x], regions[y]
+                if A[0] < B[1] and B[0] < A[1]:
+                    assert A[2] == B[2] >= 0 and (A[4] < B[3] or B[4] < A[3]), (ci, A, B)
+        for i, o in enumerate(ops):
+            g = st[i]
+            rd = o.k if o.kind == _capi.MLP_LAYER else o.n
+            assert o.src_col + rd <= stride[4 * g + o.src_buf], (ci, i)
+            if o.dst_buf > 0:
+                assert o.dst_col + o.n <= stride[4 * g + o.dst_buf], (ci, i)
+            if o.kind == _capi.MLP_LAYER:
+                assert base[4 * g + o.src_buf] + 15 * stride[4 * g + o.src_buf] + o.src_col + 16 * PolicyChain.k_blocks(o.k, o.n) <= lds, (ci, i)
+        assert (lds * 4 <= 160 * 1024 - 256) == bool(rc)
+    assert applies == [1, 1, 1, 0, 1]          # the actor alone (no critic) is one strand; everything else the runners launch at full size qualifies
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hist", [False, True])
+def test_two_groups_in_a_workgroup_equal_the_one_group_kernel(hist):
+    """r5 / ABI 16: at a tile per CU and more (> 2048 rows) the chain's two strands run side by side inside every workgroup (waves 0-3 | waves 4-7,
+    own scratch buffers, own barrier; csrc/qa_policy.hip qa_mlp_forward_groups_kernel).  Same arithmetic per output element: bit-identical to the
+    one-group kernel on the same rows (4096 rows; 5000 rows with a ragged last tile; 16,384 rows: more tiles than CUs)."""
+    lib = _capi.load_library()
+    ac, est, n_obs = modules(seed=6)
+    ac, est = ac.cuda(), est.cuda()
+    chain = PolicyChain.describe(ac, est, True, hist_encoding=hist) if hist else PolicyChain.describe(ac, est, True)
+    chain.pack()
+    assert _groups(lib, "qa_", chain, n_obs)[0] == 1
+    x = (torch.randn(16384, n_obs) * 1.5).cuda()
+    prev = lib.qa_mlp_set_groups(1)
+    try:
+        one = {rows: [t.clone() for t in chain.forward(x[:rows].clone())] for rows in (4096, 5000, 16384)}
+        lib.qa_mlp_set_groups(2)
+        for rows in (4096, 5000, 16384):
+            two = chain.forward(x[:rows].clone())
+            torch.cuda.synchronize()
+            for a, b in zip(two, one[rows]):
+                assert torch.equal(a, b), rows
+    finally:
+        lib.qa_mlp_set_groups(prev)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hist", [False, True])
 def test_few_rows_split_over_strands_equal_the_same_rows_in_a_full_launch(hist):
