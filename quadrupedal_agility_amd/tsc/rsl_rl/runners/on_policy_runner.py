@@ -341,6 +341,63 @@ class OnPolicyRunner:
         if logging:
             self.save(os.path.join(self.log_dir, "model.pt"))
 
+    # ------------------------------------------------------------------ the vision student's env step: the part without autograd as recorded launches
+    def _vision_env_step(self, vs, n_cmd):
+        """One env step of `learn_vision` behind the student's action (:392-411): set_commands -> frozen behaviour policy -> env.step -> next behaviour
+        observation, action-history restart of the envs that reset.  No autograd reaches in here (the student's action enters detached), and every
+        value that crosses a step lives in a persistent tensor (`vs`, the env's own rows), so on the GPU the segment is recorded ONCE per camera phase
+        -- the depth camera fires every `depth.update_interval`-th step, decided from the host's step counter -- and replayed: ~100 eager launches
+        and their host time per env step become one graph launch.  The student's networks, which carry autograd through the 24 steps, stay eager
+        (their batch reductions must not be recorded: profiles/r2_hipgraph_stale_reductions.md).  Returns (obs, rewards, infos)."""
+        env = self.env
+        upd = bool(env.cfg.depth.use_camera) and (env.global_counter + 1) % int(env.cfg.depth.update_interval) == 0
+
+        def body():
+            with torch.no_grad():
+                vs["obs_bbc"][:, -n_cmd:] = env.set_commands(vs["ahist"][:, -1])
+                obs, _priv, rewards, dones, infos, _ids, _term = env.step(vs["bbc"](vs["obs_bbc"]))
+                vs["obs_bbc"].copy_(env.get_observations_bbc())
+                done = dones.view(torch.bool) if dones.dtype == torch.uint8 else dones != 0
+                vs["done"].copy_(done)
+                vs["ahist"].mul_((~done).view(-1, 1, 1).to(vs["ahist"].dtype))
+                vs["yaw_ok"].copy_(infos["delta_yaw_ok"])
+                return obs, rewards, infos.get("episode"), infos["reach_goal"]
+
+        graphs = vs["graphs"]
+        recordable = self.use_rollout_graph and torch.device(self.device).type == "cuda" and graphs.get(upd) is not False
+        if recordable and upd not in graphs:
+            if upd not in vs["warm"]:                     # one eager step of this phase first: lazy allocations happen outside the recording
+                vs["warm"].add(upd)
+                recordable = False
+            else:
+                from quadrupedal_agility_amd.rsl_rl.runners.on_policy_runner import _no_gc
+                counters = (env.global_counter, env.total_env_steps_counter, env.common_step_counter)
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with _no_gc(), torch.cuda.graph(g):
+                        out = body()                      # host side effects run now, GPU work on replay
+                    graphs[upd] = (g, out)
+                except Exception as e:                    # never fatal: the eager step is the same code
+                    print(f"[tsc vision env-step graph] capture failed, staying eager: {e}")
+                    if os.environ.get("QA_DEBUG_GRAPH"):
+                        import traceback
+                        traceback.print_exc()
+                    graphs[upd] = False
+                    torch.cuda.synchronize()
+                    recordable = False
+                env.global_counter, env.total_env_steps_counter, env.common_step_counter = counters
+        if recordable:
+            g, (obs, rewards, episode, reach) = graphs[upd]
+            g.replay()
+            env.global_counter += 1; env.total_env_steps_counter += 1; env.common_step_counter += 1
+        else:
+            obs, rewards, episode, reach = body()
+        infos = {"depth": env.depth_buffer[:, -2] if upd else None, "delta_yaw_ok": vs["yaw_ok"], "reach_goal": reach}
+        if episode is not None:
+            infos["episode"] = episode
+        return obs, rewards, infos
+
     def learn_vision(self, num_learning_iterations, init_at_random_ep_len=False):
         """Distillation of the teacher into the depth student (:278-441).  Per env step: the depth encoder turns the previous depth
         image + masked proprioception into [scan latent 32 | goal headings 2 | obstacle class 6]; the student actor acts on the
@@ -361,9 +418,15 @@ class OnPolicyRunner:
         yaw_sl, type_sl = slice(n_pro - n_aux, n_pro - n_aux + self.n_delta_yaw), slice(n_pro - n_aux + self.n_delta_yaw, n_pro)
         action_student_history_buf = torch.zeros(env.num_envs, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev)
         obs, obs_bbc = env.get_observations(), env.get_observations_bbc().clone()
+        # r5: what the env half of a step carries from one step to the next, in place (`_vision_env_step`)
+        vs = getattr(self, "_vs", None)
+        if vs is None:
+            vs = self._vs = dict(graphs={}, warm=set(), yaw_ok=torch.ones(env.num_envs, dtype=torch.bool, device=dev),
+                                 done=torch.zeros(env.num_envs, dtype=torch.bool, device=dev))
+        vs["ahist"], vs["obs_bbc"] = action_student_history_buf, obs_bbc
         infos = {"depth": env.depth_buffer[:, -1].clone(), "delta_yaw_ok": torch.ones(env.num_envs, dtype=torch.bool, device=dev)}
         alg.depth_encoder.train(); alg.depth_actor.train()
-        bbc = self._behaviour_policy()
+        vs["bbc"] = self._behaviour_policy()
         n_cmd = 6 + env.dim_c
         keys = ("rew", "len")
         buffers = {k: deque(maxlen=1000) for k in keys}
@@ -403,20 +466,15 @@ class OnPolicyRunner:
                 prob, mean = self.depth_actor.actor_d(embedding), self.depth_actor.actor_c(embedding)
                 actions_student = torch.cat([torch.argmax(prob, dim=-1, keepdim=True).to(mean.dtype), mean], dim=-1)
                 actions_student_buffer.append(torch.cat([prob, mean], dim=-1))
-                action_student_history_buf = torch.cat([action_student_history_buf[:, 1:], actions_student[:, None, :].detach()], dim=1)
                 with torch.no_grad():
-                    next_commands = env.set_commands(action_student_history_buf[:, -1])
-                    obs_bbc[:, -n_cmd:] = next_commands
-                    actions_bbc = bbc(obs_bbc)
-                    obs, privileged_obs, rewards, dones, infos, _ids, _term = env.step(actions_bbc)
-                    obs_bbc = env.get_observations_bbc().clone()
-                    done = dones != 0
-                    action_student_history_buf = action_student_history_buf * (~done).view(-1, 1, 1).to(action_student_history_buf.dtype)
+                    vs["ahist"].copy_(torch.cat([vs["ahist"][:, 1:], actions_student[:, None, :].detach()], dim=1))
+                    obs, rewards, infos = self._vision_env_step(vs, n_cmd)
+                    done = vs["done"]
                     if logging:
-                        if "episode" in infos:
-                            ep_infos.append(infos["episode"])
+                        if "episode" in infos:          # (a replayed step rewrites the same tensors: keep this step's values)
+                            ep_infos.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in infos["episode"].items()})
                         cur += torch.stack([rewards, torch.ones_like(rewards)])
-                        fin_vals.append(cur.clone()); fin_masks.append(done); fin_reach.append(infos["reach_goal"].clone())
+                        fin_vals.append(cur.clone()); fin_masks.append(done.clone()); fin_reach.append(infos["reach_goal"].clone())
                         cur *= (~done).to(cur.dtype)
             collection_time = time.time() - start
             start = time.time()

@@ -333,3 +333,37 @@ def test_learn_vision_runs_on_gpu(tmp_path):
     assert all(np.isfinite(v) for d in losses for v in d.values())
     assert losses[-1]["obst_type_loss"] < losses[0]["obst_type_loss"] + 0.05          # the class head starts learning at once
     assert env.depth_buffer.std() > 0.05 and runner.last_perf["fps"] > 1e3
+
+
+@pytest.mark.gpu
+def test_recorded_vision_env_step_equals_the_eager_one(tmp_path, monkeypatch):
+    """r5: the env half of a `learn_vision` step (set_commands -> behaviour policy -> env.step -> next behaviour observation, action-history
+    restart) is recorded once per camera phase and replayed (`OnPolicyRunner._vision_env_step`); the student's networks stay eager.  Same seeds,
+    3 iterations x 24 steps (72 env steps: both camera phases recorded and replayed many times): the robots' state, the depth images and the
+    student's weights after the third update must equal the all-eager run's (env state and images bit for bit; the weights to 1e-6: the
+    update is eager torch in both runs)."""
+    import random
+    from quadrupedal_agility_amd.tsc.legged_gym.envs.base import legged_robot as lr
+    from tests.test_tsc_course_env import make_cfg
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QA_TSC_ROLLOUT_GRAPH", mode)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        cfg = make_cfg(128, 1, env__episode_length_s=1.0, depth__use_camera=True)
+        env = lr.LeggedRobot(cfg, sim_device="cuda:0")
+        runner = _vision_runner(env, tmp_path / mode, "cuda:0", steps=24)
+        runner.log_dir = None                                   # no logging: the bench's mode
+        runner.learn(3)
+        torch.cuda.synchronize()
+        if mode == "1":
+            g = runner._vs["graphs"]
+            assert set(g) == {False, True} and all(v is not False for v in g.values()), g          # both camera phases were recorded
+        res[mode] = dict(root=env.root_states.clone(), depth=env.depth_buffer.clone(), obs=env.get_observations().clone(),
+                         enc={k: v.clone() for k, v in runner.alg.depth_encoder.state_dict().items()},
+                         act={k: v.clone() for k, v in runner.alg.depth_actor.state_dict().items()}, losses=dict(runner.last_vision))
+    a, b = res["0"], res["1"]
+    assert torch.equal(a["root"], b["root"]) and torch.equal(a["depth"], b["depth"]) and torch.equal(a["obs"], b["obs"])
+    for part in ("enc", "act"):
+        for k in a[part]:
+            assert torch.allclose(a[part][k].float(), b[part][k].float(), rtol=1e-6, atol=1e-6), (part, k)
+    assert all(abs(a["losses"][k] - b["losses"][k]) <= 1e-5 * max(1.0, abs(a["losses"][k])) for k in a["losses"])

@@ -126,6 +126,24 @@ hybrid2)   # second batch: the hybrid seeds the first call did not finish (one j
     wait
     tail -15 $O/d2_many.log; tail -4 $O/d2_many_fast.log
     ;;
+grp)       # (ABI 16) policy chain: two strands side by side in a workgroup at >= a tile per CU; env-step variants (tools/build_variant.py): history stores in
+           # front of the last substep, split table staging, 16-byte history accesses -- timing of all, parity of the candidates
+    timeout 600 python -m pytest tests/test_policy_chain.py -m gpu -q > $O/pytest_policy.log 2>&1; tail -4 $O/pytest_policy.log
+    for n in 4096 16384; do
+      echo "rows $n two groups: $(timeout 120 python tools/policy_time.py $n 2>&1 | tail -1)" >> $O/policy_time_groups.txt
+      echo "rows $n one group:  $(QA_MLP_GROUPS=1 timeout 120 python tools/policy_time.py $n 2>&1 | tail -1)" >> $O/policy_time_groups.txt
+    done; cat $O/policy_time_groups.txt
+    for i in 1 2; do
+      for v in base last split lastsplit x4 x4last all3; do
+        echo "$v $i: $(QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 100 python tools/quick_time.py 2>&1 | grep 'N=' | tr '\n' ' ')" >> $O/quick_time_variants.txt
+      done
+    done; cat $O/quick_time_variants.txt
+    for v in lastsplit all3; do
+      QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 600 python -m pytest tests/test_hip_parity.py tests/test_mocap_reset.py tests/test_golden_env.py -m gpu -x -q > $O/pytest_env_$v.log 2>&1; echo "$v: $(tail -1 $O/pytest_env_$v.log)"
+    done
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json; cut -c1-600 $O/bench_cfg2.json
+    QA_MLP_GROUPS=1 timeout 400 python bench.py --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_one_group.json; cut -c1-300 $O/bench_cfg2_one_group.json
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
