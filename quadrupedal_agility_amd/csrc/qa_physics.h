@@ -557,9 +557,27 @@ QA_DEV void priv_unpark(const float *priv, float *act, float *sp, float *sd, flo
 }
 #endif
 
-template <bool PLANE>
+// Helper wavefronts (qa_env_step_kernel<..., HELP>): with one wavefront per CU three SIMDs of every CU idle, and the front half of a substep is
+// three chains that meet only at the rows -- (composite inertias -> Schur complement), (bias forces), (contact candidates); all three need
+// nothing but the kinematics of the state the substep starts from.  ROLE 1 (the env's own wavefront) publishes that state in LDS and keeps the
+// first chain, ROLE 2 computes the bias forces and ROLE 3 the contact candidates from the same state on two other SIMDs and mail their results
+// back: 19 + 9 + 10 floats per lane as 16-byte records, two workgroup barriers per substep.  ROLE 0 is the one-wavefront substep.  The same
+// expressions on the same inputs: what ROLE 1 continues with is what ROLE 0 computed in place.
+#define QA_MAIL_F4 13                    // 16-byte records per lane (odd: the 16 lanes of a b128 service group on different bank quads); 11 used
+QA_DEV void mail_put_state(f4 *m, const EnvState &st) {
+    m[0] = f4{st.pos.x, st.pos.y, st.pos.z, st.qx}; m[1] = f4{st.qy, st.qz, st.qw, st.vw.x}; m[2] = f4{st.vw.y, st.vw.z, st.ww.x, st.ww.y};
+    m[3] = f4{st.ww.z, st.q[0], st.q[1], st.q[2]}; m[4] = f4{st.qd[0], st.qd[1], st.qd[2], 0.f};
+}
+QA_DEV void mail_get_state(const f4 *m, EnvState &st) {
+    const f4 a = m[0], b = m[1], c = m[2], d = m[3], e = m[4];
+    st.pos = v3(a.x, a.y, a.z); st.qx = a.w; st.qy = b.x; st.qz = b.y; st.qw = b.z; st.vw = v3(b.w, c.x, c.y); st.ww = v3(c.z, c.w, d.x);
+    st.q[0] = d.y; st.q[1] = d.z; st.q[2] = d.w; st.qd[0] = e.x; st.qd[1] = e.y; st.qd[2] = e.z;
+}
+
+template <bool PLANE, int ROLE = 0>
 QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
-                         float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3], const TerrainView &T) {
+                         float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3], const TerrainView &T, f4 *mail = nullptr) {
+    static_assert(ROLE == 0 || PLANE, "helper wavefronts: plane kernels only (the height-field candidates carry six more values per contact)");
     const float dt = P.dt;
     M3 R = quat_to_mat(st.qx, st.qy, st.qz, st.qw);
     S6 V0 = s6(mulT(R, st.ww), mulT(R, st.vw));
@@ -588,16 +606,10 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                           tbl + T_INERTIA + 6 * k, Rl[k], o[k]);
     }
     QA_SUBSTAMP(1);
-    // ---- composite inertias, mass-matrix blocks
-    RB Ic2 = link[2], Ic1 = link[1] + Ic2, Ic0 = link[0] + Ic1;
-    S6 F[3] = {apply(Ic0, S[0]), apply(Ic1, S[1]), apply(Ic2, S[2])};
-    float L00 = dot(S[0], F[0]), L01 = dot(S[0], F[1]), L02 = dot(S[0], F[2]);
-    float L11 = dot(S[1], F[1]), L12 = dot(S[1], F[2]), L22 = dot(S[2], F[2]);
     RB base; base.m = binert[0]; base.h = v3(binert[1], binert[2], binert[3]);
     base.xx = binert[4]; base.yy = binert[5]; base.zz = binert[6]; base.xy = binert[7]; base.xz = binert[8]; base.yz = binert[9];
-    RB tot = base + quad_sum(Ic0);
-
-    QA_SUBSTAMP(2);
+    float hl[3]; S6 f0;
+    if (ROLE == 0 || ROLE == 2) {
     // ---- bias forces: Newton-Euler with zero joint acceleration, base acceleration = -gravity
     S6 A0 = s6(v3(0, 0, 0), v3(-gB.x, -gB.y, -gB.z));
     S6 fl[3];
@@ -612,79 +624,21 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         }
     }
     fl[1] = fl[1] + fl[2]; fl[0] = fl[0] + fl[1];
-    float hl[3] = {dot(S[0], fl[0]), dot(S[1], fl[1]), dot(S[2], fl[2])};
-    S6 f0 = apply(base, A0) + crf(V0, apply(base, V0)) + quad_sum(fl[0]);
-
-    QA_SUBSTAMP(3);
-    // ---- leg elimination: Linv (packed 00 01 02 11 12 22), G = -Linv F^T (3x6 row-major)
-    float Linv[6];
-    {
-        float cA = L11 * L22 - L12 * L12, cB = L02 * L12 - L01 * L22, cC = L01 * L12 - L02 * L11;
-        float cD = L00 * L22 - L02 * L02, cE = L01 * L02 - L00 * L12, cF = L00 * L11 - L01 * L01;
-        float idet = 1.0f / (L00 * cA + L01 * cB + L02 * cC);
-        Linv[0] = cA * idet; Linv[1] = cB * idet; Linv[2] = cC * idet; Linv[3] = cD * idet; Linv[4] = cE * idet; Linv[5] = cF * idet;
+    hl[0] = dot(S[0], fl[0]); hl[1] = dot(S[1], fl[1]); hl[2] = dot(S[2], fl[2]);
+    f0 = apply(base, A0) + crf(V0, apply(base, V0)) + quad_sum(fl[0]);
     }
-    float Fm[3][6];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { Fm[k][0] = F[k].a.x; Fm[k][1] = F[k].a.y; Fm[k][2] = F[k].a.z; Fm[k][3] = F[k].l.x; Fm[k][4] = F[k].l.y; Fm[k][5] = F[k].l.z; }
-    float G[18];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        G[0 * 6 + i] = -(Linv[0] * Fm[0][i] + Linv[1] * Fm[1][i] + Linv[2] * Fm[2][i]);
-        G[1 * 6 + i] = -(Linv[1] * Fm[0][i] + Linv[3] * Fm[1][i] + Linv[4] * Fm[2][i]);
-        G[2 * 6 + i] = -(Linv[2] * Fm[0][i] + Linv[4] * Fm[1][i] + Linv[5] * Fm[2][i]);
+    if (ROLE == 2) {
+        mail[5] = f4{hl[0], hl[1], hl[2], f0.a.x}; mail[6] = f4{f0.a.y, f0.a.z, f0.l.x, f0.l.y}; mail[7] = f4{f0.l.z, 0.f, 0.f, 0.f};
+        __syncthreads();
+        return;
     }
-    // Schur complement of the base: Mbb + sum_legs F G   (packed symmetric 6x6)
-    float Bm[21];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j)
-            Bm[SIDX(i, j)] = quad_sum(Fm[0][i] * G[0 * 6 + j] + Fm[1][i] * G[1 * 6 + j] + Fm[2][i] * G[2 * 6 + j]);
-    Bm[SIDX(0, 0)] += tot.xx; Bm[SIDX(1, 1)] += tot.yy; Bm[SIDX(2, 2)] += tot.zz;
-    Bm[SIDX(1, 0)] += tot.xy; Bm[SIDX(2, 0)] += tot.xz; Bm[SIDX(2, 1)] += tot.yz;
-    Bm[SIDX(3, 3)] += tot.m; Bm[SIDX(4, 4)] += tot.m; Bm[SIDX(5, 5)] += tot.m;
-    // lower-left block M[3+j][i] = hx[i][j], hx = [h]x
-    Bm[SIDX(3, 1)] += tot.h.z; Bm[SIDX(3, 2)] += -tot.h.y;
-    Bm[SIDX(4, 0)] += -tot.h.z; Bm[SIDX(4, 2)] += tot.h.x;
-    Bm[SIDX(5, 0)] += tot.h.y; Bm[SIDX(5, 1)] += -tot.h.x;
-    float Binv[21];
-    spd6_inverse(Bm, Binv);
-
-    QA_SUBSTAMP(5);
-    // ---- unconstrained velocity
-    float rl[3] = {tau[0] - hl[0], tau[1] - hl[1], tau[2] - hl[2]};
-    float rb[6] = {-f0.a.x, -f0.a.y, -f0.a.z, -f0.l.x, -f0.l.y, -f0.l.z};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rb[i] += quad_sum(G[0 * 6 + i] * rl[0] + G[1 * 6 + i] * rl[1] + G[2 * 6 + i] * rl[2]);
-    float ab[6];
-    sym6_mul(Binv, rb, ab);
-    V3 wxv = cross(V0.a, V0.l);
-    float ub[6] = {V0.a.x + dt * ab[0], V0.a.y + dt * ab[1], V0.a.z + dt * ab[2],
-                   V0.l.x + dt * (ab[3] + wxv.x), V0.l.y + dt * (ab[4] + wxv.y), V0.l.z + dt * (ab[5] + wxv.z)};
-    float w[3];   // w = u_leg* - G ub*  with u_leg* = qd + dt (Linv r + G ab)  =>  w = qd + dt Linv r + G (dt ab - ub*)... keep it explicit:
-    {
-        float lr0 = Linv[0] * rl[0] + Linv[1] * rl[1] + Linv[2] * rl[2];
-        float lr1 = Linv[1] * rl[0] + Linv[3] * rl[1] + Linv[4] * rl[2];
-        float lr2 = Linv[2] * rl[0] + Linv[4] * rl[1] + Linv[5] * rl[2];
-        float lr[3] = {lr0, lr1, lr2};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float gab = 0.f, gub = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { gab = fmaf(G[k * 6 + i], ab[i], gab); gub = fmaf(G[k * 6 + i], ub[i], gub); }
-            float ul = st.qd[k] + dt * (lr[k] + gab);
-            w[k] = ul - gub;
-        }
-    }
-
     QA_SUBSTAMP(6);
     // ---- contact candidates: the foot sphere, and per extra slot (hip link + base share | thigh | calf) the point with the
     // smallest gap.  Only (gap, point code) are tracked; position, chain depth, body and terrain normal of a winner are rebuilt
     // when its rows are built, which only happens if some env of the wavefront has that slot in contact.
     V3 nB = v3(R.m[6], R.m[7], R.m[8]), t1B = v3(R.m[0], R.m[1], R.m[2]), t2B = v3(R.m[3], R.m[4], R.m[5]);   // plane: world z, x, y
     V3 foot_n = v3(0, 0, 1);                                 // world-frame contact normal (height field)
-    float foot_gap; V3 foot_p;
+    float foot_gap = 0.f; V3 foot_p = v3(0, 0, 0);
     float foot_vs = 0.f, foot_ca = 0.f; int foot_ob = -1;    // articulated obstacle under the foot (surface velocity, joint lever, slot)
     float bgap[QA_EXTRA_GROUPS] = {1e30f, 1e30f, 1e30f};
     int bcode[QA_EXTRA_GROUPS] = {0, 0, 0};                  // 1..QA_LEG_PTS-1: leg point, 64 + c: base point
@@ -699,6 +653,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         const V3 os = (w0 * o[0]) + (w1 * o[1]) + (w2 * o[2]);
         return mul(Rs, v3(pt[0], pt[1], pt[2])) + os;
     };
+    if (ROLE != 1) {
     if (PLANE) {
         // On the plane only a candidate's world height matters: z_w = nB . (Rl_k pt + o_k) + z = (Rl_k^T nB) . pt + (nB . o_k + z),
         // i.e. 3 FMAs per point after 3 per-link vectors; the full base-frame position is built for winners only.
@@ -750,11 +705,13 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             }
         }
     }
-    const bool foot_on = foot_gap < P.contact_offset;
+    }
     // ---- which candidates make contact, compacted into the lane's slots 0..1 (group order)
     float sgap[QA_EXTRA_SLOTS]; int scode[QA_EXTRA_SLOTS], slink[QA_EXTRA_SLOTS];
     bool extra_on[QA_EXTRA_SLOTS], any_extra[QA_EXTRA_SLOTS];
-    {
+    bool foot_on = false;
+    if (ROLE != 1) {
+        foot_on = foot_gap < P.contact_offset;
         bool on0 = bgap[0] < P.contact_offset, on1 = bgap[1] < P.contact_offset, on2 = bgap[2] < P.contact_offset;
         if (P.slots == 1) {        // cfg.contact_slots 1: only the lowest non-foot point of the leg (the round-1 model)
             const bool w1 = bgap[1] < bgap[0] && !(bgap[2] < bgap[1]), w2 = bgap[2] < bgap[0] && bgap[2] < bgap[1];
@@ -784,6 +741,95 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             if (g_subprof && threadIdx.x == 0) { g_subprof[blockIdx.x * 32 + 30] += any_extra[0] ? 1 : 0; g_subprof[blockIdx.x * 32 + 31] += real ? 1 : 0; g_subprof[blockIdx.x * 32 + 29] += near2 ? 1 : 0; }
         }
 #endif
+    }
+
+    if (ROLE == 3) {
+        mail[8] = f4{foot_gap, foot_p.x, foot_p.y, foot_p.z};
+        mail[9] = f4{sgap[0], sgap[1], __int_as_float(scode[0]), __int_as_float(scode[1])};
+        mail[10] = f4{__int_as_float(slink[0]), __int_as_float(slink[1]), 0.f, 0.f};
+        __syncthreads();
+        return;
+    }
+    QA_SUBSTAMP(2);
+    // ---- composite inertias, mass-matrix blocks
+    RB Ic2 = link[2], Ic1 = link[1] + Ic2, Ic0 = link[0] + Ic1;
+    S6 F[3] = {apply(Ic0, S[0]), apply(Ic1, S[1]), apply(Ic2, S[2])};
+    float L00 = dot(S[0], F[0]), L01 = dot(S[0], F[1]), L02 = dot(S[0], F[2]);
+    float L11 = dot(S[1], F[1]), L12 = dot(S[1], F[2]), L22 = dot(S[2], F[2]);
+    RB tot = base + quad_sum(Ic0);
+
+    QA_SUBSTAMP(3);
+    // ---- leg elimination: Linv (packed 00 01 02 11 12 22), G = -Linv F^T (3x6 row-major)
+    float Linv[6];
+    {
+        float cA = L11 * L22 - L12 * L12, cB = L02 * L12 - L01 * L22, cC = L01 * L12 - L02 * L11;
+        float cD = L00 * L22 - L02 * L02, cE = L01 * L02 - L00 * L12, cF = L00 * L11 - L01 * L01;
+        float idet = 1.0f / (L00 * cA + L01 * cB + L02 * cC);
+        Linv[0] = cA * idet; Linv[1] = cB * idet; Linv[2] = cC * idet; Linv[3] = cD * idet; Linv[4] = cE * idet; Linv[5] = cF * idet;
+    }
+    float Fm[3][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Fm[k][0] = F[k].a.x; Fm[k][1] = F[k].a.y; Fm[k][2] = F[k].a.z; Fm[k][3] = F[k].l.x; Fm[k][4] = F[k].l.y; Fm[k][5] = F[k].l.z; }
+    float G[18];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        G[0 * 6 + i] = -(Linv[0] * Fm[0][i] + Linv[1] * Fm[1][i] + Linv[2] * Fm[2][i]);
+        G[1 * 6 + i] = -(Linv[1] * Fm[0][i] + Linv[3] * Fm[1][i] + Linv[4] * Fm[2][i]);
+        G[2 * 6 + i] = -(Linv[2] * Fm[0][i] + Linv[4] * Fm[1][i] + Linv[5] * Fm[2][i]);
+    }
+    // Schur complement of the base: Mbb + sum_legs F G   (packed symmetric 6x6)
+    float Bm[21];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            Bm[SIDX(i, j)] = quad_sum(Fm[0][i] * G[0 * 6 + j] + Fm[1][i] * G[1 * 6 + j] + Fm[2][i] * G[2 * 6 + j]);
+    Bm[SIDX(0, 0)] += tot.xx; Bm[SIDX(1, 1)] += tot.yy; Bm[SIDX(2, 2)] += tot.zz;
+    Bm[SIDX(1, 0)] += tot.xy; Bm[SIDX(2, 0)] += tot.xz; Bm[SIDX(2, 1)] += tot.yz;
+    Bm[SIDX(3, 3)] += tot.m; Bm[SIDX(4, 4)] += tot.m; Bm[SIDX(5, 5)] += tot.m;
+    // lower-left block M[3+j][i] = hx[i][j], hx = [h]x
+    Bm[SIDX(3, 1)] += tot.h.z; Bm[SIDX(3, 2)] += -tot.h.y;
+    Bm[SIDX(4, 0)] += -tot.h.z; Bm[SIDX(4, 2)] += tot.h.x;
+    Bm[SIDX(5, 0)] += tot.h.y; Bm[SIDX(5, 1)] += -tot.h.x;
+    float Binv[21];
+    spd6_inverse(Bm, Binv);
+    if (ROLE == 1) {
+        __syncthreads();                                     // the helpers' results of THIS substep are in the mail
+        const f4 a = mail[5], b = mail[6], c = mail[7], d = mail[8], e = mail[9], g = mail[10];
+        hl[0] = a.x; hl[1] = a.y; hl[2] = a.z; f0 = s6(v3(a.w, b.x, b.y), v3(b.z, b.w, c.x));
+        foot_gap = d.x; foot_p = v3(d.y, d.z, d.w);
+        sgap[0] = e.x; sgap[1] = e.y; scode[0] = __float_as_int(e.z); scode[1] = __float_as_int(e.w);
+        slink[0] = __float_as_int(g.x); slink[1] = __float_as_int(g.y);
+        foot_on = foot_gap < P.contact_offset;
+        extra_on[0] = slink[0] >= 0; extra_on[1] = slink[1] >= 0;
+        any_extra[0] = __any(extra_on[0]); any_extra[1] = __any(extra_on[1]);
+    }
+
+    QA_SUBSTAMP(5);
+    // ---- unconstrained velocity
+    float rl[3] = {tau[0] - hl[0], tau[1] - hl[1], tau[2] - hl[2]};
+    float rb[6] = {-f0.a.x, -f0.a.y, -f0.a.z, -f0.l.x, -f0.l.y, -f0.l.z};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rb[i] += quad_sum(G[0 * 6 + i] * rl[0] + G[1 * 6 + i] * rl[1] + G[2 * 6 + i] * rl[2]);
+    float ab[6];
+    sym6_mul(Binv, rb, ab);
+    V3 wxv = cross(V0.a, V0.l);
+    float ub[6] = {V0.a.x + dt * ab[0], V0.a.y + dt * ab[1], V0.a.z + dt * ab[2],
+                   V0.l.x + dt * (ab[3] + wxv.x), V0.l.y + dt * (ab[4] + wxv.y), V0.l.z + dt * (ab[5] + wxv.z)};
+    float w[3];   // w = u_leg* - G ub*  with u_leg* = qd + dt (Linv r + G ab)  =>  w = qd + dt Linv r + G (dt ab - ub*)... keep it explicit:
+    {
+        float lr0 = Linv[0] * rl[0] + Linv[1] * rl[1] + Linv[2] * rl[2];
+        float lr1 = Linv[1] * rl[0] + Linv[3] * rl[1] + Linv[4] * rl[2];
+        float lr2 = Linv[2] * rl[0] + Linv[4] * rl[1] + Linv[5] * rl[2];
+        float lr[3] = {lr0, lr1, lr2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float gab = 0.f, gub = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { gab = fmaf(G[k * 6 + i], ab[i], gab); gub = fmaf(G[k * 6 + i], ub[i], gub); }
+            float ul = st.qd[k] + dt * (lr[k] + gab);
+            w[k] = ul - gub;
+        }
     }
 
 #ifdef QA_PGS_PACKED

@@ -124,6 +124,9 @@ static int fail_hip(hipError_t e, const char *what) {
 // (b) that the compiler does not move LDS accesses across the point.  __syncthreads() would additionally wait for
 // vmcnt(0), i.e. drain every outstanding global load and store at each exchange -- 8 full memory drains in the
 // observation phase alone.
+#ifndef QA_ENV_HELPERS_DEFAULT
+#define QA_ENV_HELPERS_DEFAULT 0
+#endif
 static_assert(QA_BLOCK == 64, "wave_lds_sync() assumes single-wavefront workgroups");
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 constexpr int QA_TBL_PER = (QA_TBL_FLOATS + QA_BLOCK - 1) / QA_BLOCK;
@@ -771,13 +774,19 @@ QA_DEV void shift_history_store4(const Ptrs &p, int bix, int lane, int N, HistRe
 // MODE 0: the whole LeggedRobot.step of the behaviour-level (BBC) tree.  MODE 1: the physics part only -- action-history
 // roll, delay, clip, decimation x (PD torque -> substep), refresh of the simulator tensors -- for the task-level (TSC) env,
 // whose own post_physics_step (goals, termination, rewards, reset, three observation rows) are separate kernels (qa_tsc_*).
-template <bool PLANE, int LPE, int MODE = 0, int LEAN = 0>
-__global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_kernel(StepArgs a) {
+// HELP = 1 (plane kernels): two helper wavefronts per workgroup take the bias forces and the contact candidates of every substep off the env's own
+// wavefront (phys_substep ROLE 1 / 2 / 3, qa_physics.h) -- three of a CU's four SIMDs idle otherwise at one wavefront per CU.
+template <bool PLANE, int LPE, int MODE = 0, int LEAN = 0, int HELP = 0>
+__global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(StepArgs a) {
     static_assert(LEAN == 0 || MODE == 0, "the task-level tree reads every tensor the physics step exports");
-    constexpr int WPB = LPE == 16 ? 4 : 1;             // wavefronts per workgroup
+    static_assert(HELP == 0 || (PLANE && MODE == 0), "helper wavefronts: the behaviour-level plane kernels");
+    constexpr int WPB = 1;                             // env groups (wavefronts with envs of their own) per workgroup
     constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
     const int tix = threadIdx.x & (QA_BLOCK - 1);      // lane
-    const int bix = blockIdx.x * WPB + (threadIdx.x >> 6);   // index of this wavefront's env group
+    const int role = HELP ? (int)(threadIdx.x >> 6) : 0;     // 0: the envs' own wavefront; 1, 2: its helpers
+    const int bix = blockIdx.x;                        // index of this workgroup's env group
+    __shared__ __attribute__((aligned(16))) f4 s_mail[HELP ? QA_BLOCK * QA_MAIL_F4 : 1];
+    f4 *const mail = s_mail + (HELP ? tix * QA_MAIL_F4 : 0);
     static_assert(LPE == 4, "one quad per env (the 16-lanes-per-env experiment of round 1 was slower in wall time and is gone)");
     __shared__ float s_tbl[QA_TBL_FLOATS];
     // One LDS scratch region used by two disjoint phases (a workgroup's LDS footprint decides how many of them a CU
@@ -788,7 +797,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     constexpr int U_OBS = EPB * S_ENV + OBS_GROUP * S_ROW;
     constexpr int U_ALL = ((U_PHYS > U_OBS ? U_PHYS : U_OBS) + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float s_u_all[WPB * U_ALL];
-    float *s_u = s_u_all + (threadIdx.x >> 6) * U_ALL;
+    float *s_u = s_u_all;
     float *s_priv = s_u, *s_patch = s_u + QA_PRIV_FLOATS * QA_PRIV_STRIDE;
     float *s_stage = s_u, *s_rows = s_u + EPB * S_ENV;
     static_assert((EPB * S_ENV) % 4 == 0, "row buffer must stay 16-byte aligned");
@@ -801,6 +810,29 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
     // load -> stage table -> store prologue).  All 256 wavefronts of a 4096-env launch start together, so the prologue's 17 MB read + 17 MB
     // write was a burst nobody overlapped: 9.7 k of the kernel's 136 k ticks waiting for it (profiles/r5_env_step_phase_profile.txt).  The
     // values wait in registers the substeps do not use (the compiler parks them in AGPRs: 2 x 144 v_accvgpr moves, ~1.3 k ticks).
+    if (HELP && role != 0) {
+        // ---- a helper wavefront: per substep, the state the env's wavefront published -> bias forces (role 1) / contact candidates (role 2) -> mail
+        const int leg = tix & 3, env = min((bix * QA_BLOCK + tix) / LPE, a.c.num_envs - 1);
+        (void)env;
+        const float *tbl = s_tbl + leg * QA_LEG_TBL, *btbl = s_tbl + 4 * QA_LEG_TBL;
+        const qa_config &c = a.c;
+        PhysParams P; P.dt = c.sim_dt; P.gz = c.gravity_z; P.contact_offset = c.contact_offset; P.max_depen = c.max_depenetration_velocity;
+        P.ground_friction = c.ground_friction; P.iters = c.solver_iterations; P.slots = c.contact_slots == 1 ? 1 : 2; P.self_collision = c.self_collision;
+        TerrainView T = terrain_view(c, a.p, s_u);
+        float *priv = priv_of(s_u, tix);
+        EnvState st; ContactOut co;
+        float fimp[3] = {0.f, 0.f, 0.f}, tau[3] = {0.f, 0.f, 0.f};
+        for (int d = 0; d < c.decimation; ++d) {
+            __syncthreads();                                   // the state of this substep is in the mail (first time: the table and the parked persistents too)
+            asm volatile("" ::: "memory");
+            mail_get_state(mail, st);
+            float bi[10], pa[3], psp[3], psd[3];
+            priv_unpark(priv, pa, psp, psd, bi);
+            if (role == 1) phys_substep<PLANE, HELP ? 2 : 0>(st, tbl, btbl, bi, tau, 0.f, leg, P, co, priv, fimp, T, mail);
+            else phys_substep<PLANE, HELP ? 3 : 0>(st, tbl, btbl, bi, tau, 0.f, leg, P, co, priv, fimp, T, mail);
+        }
+        return;
+    }
     float hv[EPB][9];
 #ifdef QA_HIST_X4
     HistRegs4 hv4;
@@ -830,7 +862,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
 #else
     stage_table(s_tbl);
 #endif
-    if (WPB > 1) __syncthreads();                      // the table is shared by the wavefronts of the workgroup
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
     const int sub = LPE == 4 ? 0 : (tix & 3);
@@ -987,7 +1018,8 @@ __global__ void __launch_bounds__(QA_BLOCK * (LPE == 16 ? 4 : 1)) qa_env_step_ke
         // drain beside ~12 us of arithmetic instead of in front of the tail's own stores
         if (MODE == 0 && LPE == 4 && d == c.decimation - 1) QA_SHIFT_STORE();
 #endif
-        phys_substep<PLANE>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T);
+        if (HELP) { mail_put_state(mail, st); __syncthreads(); }       // the helpers start on this substep's state
+        phys_substep<PLANE, HELP ? 1 : 0>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T, mail);
     }
     { float bi_[10]; priv_unpark(priv, act, sp, sd, bi_); }
     st.pos.x += anc_x; st.pos.y += anc_y;               // back to world coordinates: ONE rounding per step, like the oracle's double -> float store
@@ -1442,6 +1474,14 @@ static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; m.on = s->mocap_first[Q
 static void launch_env_step(qa_sim *s, const StepArgs &a, hipStream_t st) {
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
     const bool hf = s->cfg.terrain_type == 1;
+    // helper wavefronts on the plane kernels (QA_ENV_HELPERS=0 in the environment: the one-wavefront kernels, for A/B runs)
+    static const bool helpers = [] { const char *e = getenv("QA_ENV_HELPERS"); return e ? atoi(e) != 0 : QA_ENV_HELPERS_DEFAULT != 0; }();
+    if (!hf && helpers) {
+        if (s->lean == 3) hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 3, 1>), dim3(blocks), dim3(3 * QA_BLOCK), 0, st, a);
+        else if (s->lean == 1) hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 1, 1>), dim3(blocks), dim3(3 * QA_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 0, 1>), dim3(blocks), dim3(3 * QA_BLOCK), 0, st, a);
+        return;
+    }
     if (s->lean == 3) {
         if (hf) hipLaunchKernelGGL((qa_env_step_kernel<false, 4, 0, 3>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);
         else hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 3>), dim3(blocks), dim3(QA_BLOCK), 0, st, a);

@@ -133,16 +133,33 @@ grp)       # (ABI 16) policy chain: two strands side by side in a workgroup at >
       echo "rows $n two groups: $(timeout 120 python tools/policy_time.py $n 2>&1 | tail -1)" >> $O/policy_time_groups.txt
       echo "rows $n one group:  $(QA_MLP_GROUPS=1 timeout 120 python tools/policy_time.py $n 2>&1 | tail -1)" >> $O/policy_time_groups.txt
     done; cat $O/policy_time_groups.txt
+    # help = two helper wavefronts per workgroup (bias forces | contact candidates of every substep, qa_physics.h phys_substep ROLE 1 / 2 / 3)
     for i in 1 2; do
-      for v in base last split lastsplit x4 x4last all3; do
+      for v in base lastsplit all3 help helplastsplit helpall3; do
         echo "$v $i: $(QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 100 python tools/quick_time.py 2>&1 | grep 'N=' | tr '\n' ' ')" >> $O/quick_time_variants.txt
       done
+    done
+    for v in last split x4; do
+      echo "$v 1: $(QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 100 python tools/quick_time.py 2>&1 | grep 'N=' | tr '\n' ' ')" >> $O/quick_time_variants.txt
     done; cat $O/quick_time_variants.txt
-    for v in lastsplit all3; do
-      QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 600 python -m pytest tests/test_hip_parity.py tests/test_mocap_reset.py tests/test_golden_env.py -m gpu -x -q > $O/pytest_env_$v.log 2>&1; echo "$v: $(tail -1 $O/pytest_env_$v.log)"
+    for v in help helplastsplit helpall3; do
+      QA_LIB=$R/tools/_prof/libqa_sim_$v.so timeout 600 python -m pytest tests/test_hip_parity.py tests/test_mocap_reset.py tests/test_golden_env.py tests/test_self_collision.py -m gpu -x -q > $O/pytest_env_$v.log 2>&1; echo "$v: $(tail -1 $O/pytest_env_$v.log)"
     done
     timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json; cut -c1-600 $O/bench_cfg2.json
     QA_MLP_GROUPS=1 timeout 400 python bench.py --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_one_group.json; cut -c1-300 $O/bench_cfg2_one_group.json
+    # learn_vision: the env half of a step recorded per camera phase
+    timeout 900 python -m pytest tests/test_tsc_depth.py -m gpu -q -k "vision" > $O/pytest_vision.log 2>&1; tail -15 $O/pytest_vision.log | cut -c1-300
+    for ne in 256 512; do
+      timeout 400 python bench.py --tsc --vision --num_envs $ne --steps 5 --warmup 3 --no_cpu_baseline 2> $O/bench_student_$ne.err < /dev/null | grep '"metric"' > $O/bench_student_${ne}_recorded.json
+    done
+    QA_TSC_ROLLOUT_GRAPH=0 timeout 400 python bench.py --tsc --vision --num_envs 256 --steps 5 --warmup 3 --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_student_256_eager.json
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5/grp/bench_*.json")):
+    try:
+        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms;", {k: round(v * 1e3, 2) for k, v in d.items() if k in ("collection_s", "learn_s")})
+    except Exception as e: print(f, "no line", e)
+PY
     ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
