@@ -748,8 +748,9 @@ int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, i
  * (as wide as its ops touch them) behind the shared input tile, and its own barrier.  Per-tile arithmetic is unchanged => bit-identical outputs.
  * qa_mlp_groups is the (host-only) plan: strand_of[num_ops]; base / stride [2][4] = LDS offset and row stride (floats) of buffer b as group g sees it
  * (stride 0: the group does not touch the buffer); *lds_floats = the launch's LDS size.  Returns 1 when the two-group launch applies to this chain,
- * 0 when it does not (one strand, or no fit), negative QA_E_* on a malformed chain.  qa_mlp_set_groups(1) keeps the one-group kernel, (2) restores the
- * default (also QA_MLP_GROUPS in the environment); returns the previous setting. */
+ * 0 when it does not (one strand, or no fit), negative QA_E_* on a malformed chain.  MEASURED SLOWER than the one-group kernel (87.7 v 85.5 us at 4096
+ * rows): it ships off.  qa_mlp_set_groups(2) (or QA_MLP_GROUPS=2 in the environment) turns the two-group launch on, (1) off again; returns the
+ * previous setting. */
 int qa_mlp_groups(const qa_mlp_op *ops, int32_t num_ops, int32_t x_cols, int32_t *strand_of, int32_t *base, int32_t *stride, int32_t *lds_floats);
 int qa_mlp_set_groups(int32_t groups);
 

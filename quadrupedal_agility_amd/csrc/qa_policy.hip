@@ -448,9 +448,12 @@ int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, i
     return mlp_strands(ops, num_ops, max_strands > 4 ? 4 : max_strands, strand_of);
 }
 
-static int g_mlp_groups = -1;           /* -1: not decided yet (QA_MLP_GROUPS in the environment, default 2) */
+/* Measured (profiles/r5_policy_groups.txt): 87.7 us against the one-group kernel's 85.5 us at 4096 rows, 336.7 against 320.6 at 16,384 -- the strands
+ * share the MFMA pipes they were meant to keep busy, and a lone four-wave strand hides its weight stream worse than eight waves do.  The two-group
+ * launch therefore ships OFF (default 1); QA_MLP_GROUPS=2 / qa_mlp_set_groups(2) turn it on (the tests do, it is bit-identical). */
+static int g_mlp_groups = -1;           /* -1: not decided yet (QA_MLP_GROUPS in the environment, default 1) */
 static int mlp_groups_switch() {
-    if (g_mlp_groups < 0) { const char *e = getenv("QA_MLP_GROUPS"); g_mlp_groups = e ? (atoi(e) >= 2 ? 2 : 1) : 2; }
+    if (g_mlp_groups < 0) { const char *e = getenv("QA_MLP_GROUPS"); g_mlp_groups = e ? (atoi(e) >= 2 ? 2 : 1) : 1; }
     return g_mlp_groups;
 }
 

@@ -100,6 +100,7 @@ struct qa_sim {
     long long *prof = nullptr;
     int lanes = 4;                 // lanes per env of the step / simulate kernels (one quad: lane & 3 = leg)
     int lean = 0;                  // qa_set_lean_exports
+    int num_cus = 256;             // compute units of the device the arena lives on (launch_env_step: helper wavefronts by launch size)
     qa_config cfg;
     Layout L;
     char *arena;
@@ -125,7 +126,7 @@ static int fail_hip(hipError_t e, const char *what) {
 // vmcnt(0), i.e. drain every outstanding global load and store at each exchange -- 8 full memory drains in the
 // observation phase alone.
 #ifndef QA_ENV_HELPERS_DEFAULT
-#define QA_ENV_HELPERS_DEFAULT 0
+#define QA_ENV_HELPERS_DEFAULT (-1)      // -1: by launch size (launch_env_step), 0: never, 1: always
 #endif
 static_assert(QA_BLOCK == 64, "wave_lds_sync() assumes single-wavefront workgroups");
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -1433,6 +1434,7 @@ int qa_create(const qa_config *cfg, void *arena, int64_t arena_bytes, void *stre
     fill_ptrs(s);
     hipStream_t st = (hipStream_t)stream;
     float tbl[QA_TBL_FLOATS]; build_table(tbl);
+    { int dev = 0, cus = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) s->num_cus = cus; }
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_tbl), tbl, sizeof(tbl));
     if (e != hipSuccess) { delete s; return fail_hip(e, "hipMemcpyToSymbol(c_tbl)"); }
     e = hipMemsetAsync(arena, 0, (size_t)s->L.total, st);
@@ -1474,8 +1476,11 @@ static MocapIdx mocap_idx(const qa_sim *s) { MocapIdx m; m.on = s->mocap_first[Q
 static void launch_env_step(qa_sim *s, const StepArgs &a, hipStream_t st) {
     const int epb = QA_BLOCK / s->lanes, blocks = (s->cfg.num_envs + epb - 1) / epb;
     const bool hf = s->cfg.terrain_type == 1;
-    // helper wavefronts on the plane kernels (QA_ENV_HELPERS=0 in the environment: the one-wavefront kernels, for A/B runs)
-    static const bool helpers = [] { const char *e = getenv("QA_ENV_HELPERS"); return e ? atoi(e) != 0 : QA_ENV_HELPERS_DEFAULT != 0; }();
+    // helper wavefronts on the plane kernels while a launch has at most one workgroup per CU (<= 4096 envs: three of a CU's four SIMDs would idle;
+    // measured 69.3 -> 63.1 us at 4096 envs, 135 -> 162 us at 16,384 where every SIMD has work of its own).  QA_ENV_HELPERS in the environment:
+    // 0 = never (the one-wavefront kernels, A/B runs), 1 = always, unset = by launch size
+    static const int helpers_switch = [] { const char *e = getenv("QA_ENV_HELPERS"); return e ? (atoi(e) != 0 ? 1 : 0) : QA_ENV_HELPERS_DEFAULT; }();
+    const bool helpers = helpers_switch == 1 || (helpers_switch < 0 && blocks <= s->num_cus);
     if (!hf && helpers) {
         if (s->lean == 3) hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 3, 1>), dim3(blocks), dim3(3 * QA_BLOCK), 0, st, a);
         else if (s->lean == 1) hipLaunchKernelGGL((qa_env_step_kernel<true, 4, 0, 1, 1>), dim3(blocks), dim3(3 * QA_BLOCK), 0, st, a);

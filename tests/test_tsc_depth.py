@@ -339,7 +339,7 @@ def test_learn_vision_runs_on_gpu(tmp_path):
 def test_recorded_vision_env_step_equals_the_eager_one(tmp_path, monkeypatch):
     """r5: the env half of a `learn_vision` step (set_commands -> behaviour policy -> env.step -> next behaviour observation, action-history
     restart) is recorded once per camera phase and replayed (`OnPolicyRunner._vision_env_step`); the student's networks stay eager.  Same seeds,
-    3 iterations x 24 steps (72 env steps: both camera phases recorded and replayed many times): the robots' state, the depth images and the
+    3 iterations x 24 steps, depth.update_interval 2 (both camera phases recorded and replayed many times): the robots' state, the depth images and the
     student's weights after the third update must equal the all-eager run's (env state and images bit for bit; the weights to 1e-6: the
     update is eager torch in both runs)."""
     import random
@@ -349,7 +349,7 @@ def test_recorded_vision_env_step_equals_the_eager_one(tmp_path, monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("QA_TSC_ROLLOUT_GRAPH", mode)
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
-        cfg = make_cfg(128, 1, env__episode_length_s=1.0, depth__use_camera=True)
+        cfg = make_cfg(128, 1, env__episode_length_s=1.0, depth__use_camera=True, depth__update_interval=2)
         env = lr.LeggedRobot(cfg, sim_device="cuda:0")
         runner = _vision_runner(env, tmp_path / mode, "cuda:0", steps=24)
         runner.log_dir = None                                   # no logging: the bench's mode

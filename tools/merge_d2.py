@@ -104,7 +104,7 @@ def main():
            "statistic": "tail value = mean of the last 10 logged values before the checkpoint, per seed; rel_diff = (mean over HIP seeds - mean over CPU seeds) / |CPU mean|; "
                         "median_rel_diff likewise on the medians; pre-registered statistics: see tools/merge_d2.py docstring",
            "at_iteration": {}}
-    for ck in [c for c in (250, 500, 750, 1000) if c <= iters]:
+    for ck in sorted(set([c for c in (250, 500, 750, 1000) if c <= iters] + [iters])):      # the horizon itself is always a checkpoint
         summ = {}
         for tag in TAGS:
             hs = [tail(r["curves"][tag], ck) for r in hip if tag in r["curves"] and len(r["curves"][tag]) >= ck]

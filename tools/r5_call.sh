@@ -161,6 +161,46 @@ for f in sorted(glob.glob("gpurun_out/r5/grp/bench_*.json")):
     except Exception as e: print(f, "no line", e)
 PY
     ;;
+fin1)      # helper wavefronts by launch size (default), policy two-group launch off (default): timing lines first, then the whole GPU suite with the config-2
+           # hybrid arm (4096 envs x 300 iterations, oracle physics on the host cores + GPU learner; VERDICT r4 item 4, second half) on the host cores beside it
+    for i in 1 2; do
+      for v in "" helpx4 base; do
+        L=""; [ -n "$v" ] && L=$R/tools/_prof/libqa_sim_$v.so
+        echo "${v:-product} $i: $(QA_LIB=$L timeout 100 python tools/quick_time.py 2>&1 | grep 'N=' | tr '\n' ' ')" >> $O/quick_time_variants.txt
+      done
+    done; cat $O/quick_time_variants.txt
+    QA_LIB=$R/tools/_prof/libqa_sim_helpx4.so timeout 600 python -m pytest tests/test_hip_parity.py tests/test_mocap_reset.py tests/test_golden_env.py tests/test_self_collision.py -m gpu -x -q > $O/pytest_env_helpx4.log 2>&1; echo "helpx4: $(tail -1 $O/pytest_env_helpx4.log)"
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    QA_ENV_HELPERS=0 timeout 400 python bench.py --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_no_helpers.json
+    QA_LIB=$R/tools/_prof/libqa_sim_helpx4.so timeout 400 python bench.py --no_cpu_baseline 2> /dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_helpx4.json
+    timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512.json
+    QA_ENV_HELPERS=0 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_no_helpers.json
+    timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp.json
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5/fin1/bench_*.json")):
+    try:
+        d = json.loads(open(f).read()); r = d.get("roofline") or {}
+        print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round((d.get("collection_s") or 0) * 1e3, 2), "update", round((d.get("learn_s") or 0) * 1e3, 2),
+              "kernel us", round((r.get("kernel_ms") or 0) * 1e3, 1), "frac", round(r.get("frac") or 0, 4))
+    except Exception as e: print(f, "no line", e)
+PY
+    export TMPDIR=/tmp
+    rm -rf /tmp/prof_st; ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_st -- python $R/bench.py --tsc --vision --num_envs 256 --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof_st.log 2>&1 )
+    f=$(find /tmp/prof_st -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/student_256_kernel_stats.csv; grep '"metric"' /tmp/prof_st.log > $O/bench_student_256_under_rocprof.json
+    [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("student 256 envs, 5 iterations under rocprofv3: kernel time total %.1f ms, %d launches" % (tot / 1e6, sum(int(r["Calls"]) for r in rows)))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:14]:
+    print("  %6.1f ms %7s calls  %s" % (float(r["TotalDurationNs"]) / 1e6, r["Calls"], r["Name"][:110]))
+PY
+    ( timeout 1500 python tools/d2_many.py --out $O/cfg2 --plain --num_envs 4096 --iters 300 --arms fast:1-6 hybrid:1-6 --workers 4 --hybrid_threads 60 --job_timeout 1400 --budget_s 700 > $O/d2_many_cfg2.log 2>&1 ) &
+    timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log
+    wait
+    tail -14 $O/d2_many_cfg2.log
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
