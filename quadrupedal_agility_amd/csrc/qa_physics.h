@@ -574,6 +574,46 @@ QA_DEV void mail_get_state(const f4 *m, EnvState &st) {
     st.q[0] = d.y; st.q[1] = d.z; st.q[2] = d.w; st.qd[0] = e.x; st.qd[1] = e.y; st.qd[2] = e.z;
 }
 
+#ifndef QA_PGS_SCALAR
+// QA_HELP_ROWS (default on with helper wavefronts): the contact helper also builds the rows of the lane's non-foot contacts -- up to six rows, in the
+// lane's LDS records where the sweeps read them anyway -- from the solve data (G, Binv, Linv in pairs: 63 floats as 16 records) the env's wavefront
+// mails at the second barrier; a third barrier in front of the sweeps.
+#ifndef QA_HELP_ROWS
+#define QA_HELP_ROWS 1
+#endif
+#define QA_MAIL_PS 11                    // first record of the solve data in a lane's mail
+#undef QA_MAIL_F4
+#define QA_MAIL_F4 (QA_HELP_ROWS ? 29 : 13)
+QA_DEV void mail_put_solve(f4 *m, const PSolve &S) {
+    const f2 *g = &S.G2[0][0], *b = &S.Bc[0][0];
+    // 9 + 18 + 3 pairs = 30 pairs = 15 records, + L2 (3 floats)
+    f2 q[30];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i] = g[i];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) q[9 + i] = b[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[27 + i] = S.L01[i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) m[QA_MAIL_PS + i] = f4{q[2 * i].x, q[2 * i].y, q[2 * i + 1].x, q[2 * i + 1].y};
+    m[QA_MAIL_PS + 15] = f4{S.L2[0], S.L2[1], S.L2[2], 0.f};
+}
+QA_DEV void mail_get_solve(const f4 *m, PSolve &S) {
+    f2 q[30];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) { const f4 v = m[QA_MAIL_PS + i]; q[2 * i] = f2{v.x, v.y}; q[2 * i + 1] = f2{v.z, v.w}; }
+    f2 *g = &S.G2[0][0], *b = &S.Bc[0][0];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i] = q[i];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) b[i] = q[9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) S.L01[i] = q[27 + i];
+    const f4 l = m[QA_MAIL_PS + 15];
+    S.L2[0] = l.x; S.L2[1] = l.y; S.L2[2] = l.z;
+}
+#endif
+
 template <bool PLANE, int ROLE = 0>
 QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
                          float mu, int leg, const PhysParams &P, ContactOut &co, float *priv, float fimp[3], const TerrainView &T, f4 *mail = nullptr) {
@@ -630,6 +670,9 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     if (ROLE == 2) {
         mail[5] = f4{hl[0], hl[1], hl[2], f0.a.x}; mail[6] = f4{f0.a.y, f0.a.z, f0.l.x, f0.l.y}; mail[7] = f4{f0.l.z, 0.f, 0.f, 0.f};
         __syncthreads();
+#if defined(QA_PGS_PACKED) && QA_HELP_ROWS
+        __syncthreads();                                     // (the contact helper's rows)
+#endif
         return;
     }
     QA_SUBSTAMP(6);
@@ -743,11 +786,47 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
 #endif
     }
 
+#ifdef QA_PGS_PACKED
+    // ---- the rows of the lane's non-foot contacts (built by whoever holds the solve data PS: the one-wavefront substep and the env's wavefront
+    // further down, or -- QA_HELP_ROWS -- the contact helper right here, from the mail)
+    PSolve PS;
+    float re_lam[QA_EXTRA_SLOTS][3];
+    float ex_ca[QA_EXTRA_SLOTS]; int ex_ob[QA_EXTRA_SLOTS];
+    V3 ex_n[QA_EXTRA_SLOTS];                                // world-frame normals of the extra contacts (height field)
+    int ex_body[QA_EXTRA_SLOTS];
+    auto extra_rows = [&](int sl, bool build) {
+        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1; ex_ca[sl] = 0.f; ex_ob[sl] = -1;
+        if (any_extra[sl]) {
+            V3 p; int depth;
+            const int code = scode[sl], link = max(slink[sl], 0);
+            if (code >= 64) { const float *pt = btbl + 4 * (code - 64); p = v3(pt[0], pt[1], pt[2]); depth = 0; ex_body[sl] = (code - 64) < 8 ? 0 : ((code - 64) < 10 ? 1 : 2); }
+            else { if (build) p = leg_point(code > 0 ? code : 1, link); depth = link + 1; ex_body[sl] = 3 + 4 * leg + link; }
+            if (build) {
+                PRow re[3];
+                V3 en_b = nB, et1_b = t1B, et2_b = t2B;
+                float ex_vs = 0.f;
+                if (!PLANE) {
+                    (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl], ex_vs, ex_ca[sl], ex_ob[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
+                    V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
+                }
+                pcontact_rows(re, p, depth, sgap[sl], ex_vs, o, ax, en_b, et1_b, et2_b, PS, P);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) prow_store(priv + QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
+            }
+        }
+    };
+#endif
     if (ROLE == 3) {
         mail[8] = f4{foot_gap, foot_p.x, foot_p.y, foot_p.z};
         mail[9] = f4{sgap[0], sgap[1], __int_as_float(scode[0]), __int_as_float(scode[1])};
         mail[10] = f4{__int_as_float(slink[0]), __int_as_float(slink[1]), 0.f, 0.f};
         __syncthreads();
+#if defined(QA_PGS_PACKED) && QA_HELP_ROWS
+        mail_get_solve(mail, PS);                            // the env's wavefront wrote it in front of the barrier
+#pragma unroll
+        for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) extra_rows(sl, true);
+        __syncthreads();                                     // the rows are in the lane's LDS records: the sweeps may start
+#endif
         return;
     }
     QA_SUBSTAMP(2);
@@ -793,6 +872,12 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     Bm[SIDX(5, 0)] += tot.h.y; Bm[SIDX(5, 1)] += -tot.h.x;
     float Binv[21];
     spd6_inverse(Bm, Binv);
+#ifdef QA_PGS_PACKED
+    psolve_make(PS, G, Linv, Binv);
+#if QA_HELP_ROWS
+    if (ROLE == 1) mail_put_solve(mail, PS);
+#endif
+#endif
     if (ROLE == 1) {
         __syncthreads();                                     // the helpers' results of THIS substep are in the mail
         const f4 a = mail[5], b = mail[6], c = mail[7], d = mail[8], e = mail[9], g = mail[10];
@@ -836,8 +921,6 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     QA_SUBSTAMP(7);
     // ---- rows, packed (see PRow): foot rows in registers; the extra slots' and the self-collision rows in the lane's LDS records, built only
     // when some env of the wavefront needs them
-    PSolve PS;
-    psolve_make(PS, G, Linv, Binv);
     PRow rf[3];
     V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
     if (!PLANE) { tangent_basis(foot_n, ft1_w, ft2_w); fn_b = mulT(R, foot_n); ft1_b = mulT(R, ft1_w); ft2_b = mulT(R, ft2_w); }
@@ -846,30 +929,8 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     // (residual > 0 => lam stays 0 => x + m 0 = x exactly), so the sweeps below branch on wave-uniform votes only -- a lane-divergent `if`
     // costs ~8 scalar instructions of exec-mask bookkeeping per block and saves nothing (the idle lanes' slots are issued anyway).
     rf[0].j[4].y = foot_on ? rf[0].j[4].y : QA_OPEN_BIAS;
-    float re_lam[QA_EXTRA_SLOTS][3];
-    float ex_ca[QA_EXTRA_SLOTS]; int ex_ob[QA_EXTRA_SLOTS];
-    V3 ex_n[QA_EXTRA_SLOTS];                                // world-frame normals of the extra contacts (height field)
-    int ex_body[QA_EXTRA_SLOTS];
 #pragma unroll
-    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
-        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1; ex_ca[sl] = 0.f; ex_ob[sl] = -1;
-        if (any_extra[sl]) {
-            V3 p; int depth;
-            const int code = scode[sl], link = max(slink[sl], 0);
-            if (code >= 64) { const float *pt = btbl + 4 * (code - 64); p = v3(pt[0], pt[1], pt[2]); depth = 0; ex_body[sl] = (code - 64) < 8 ? 0 : ((code - 64) < 10 ? 1 : 2); }
-            else { p = leg_point(code > 0 ? code : 1, link); depth = link + 1; ex_body[sl] = 3 + 4 * leg + link; }
-            PRow re[3];
-            V3 en_b = nB, et1_b = t1B, et2_b = t2B;
-            float ex_vs = 0.f;
-            if (!PLANE) {
-                (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl], ex_vs, ex_ca[sl], ex_ob[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
-                V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
-            }
-            pcontact_rows(re, p, depth, sgap[sl], ex_vs, o, ax, en_b, et1_b, et2_b, PS, P);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) prow_store(priv + QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
-        }
-    }
+    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) extra_rows(sl, !(ROLE == 1 && QA_HELP_ROWS));      // with helpers: the contact helper is building them meanwhile
     // ---- self-collision rows: partner 0 = lane ^ 1 (left / right), partner 1 = lane ^ 2 (front / rear).  Both lanes of a pair evaluate the
     // SAME expressions on the same (canonically ordered) segments, so they agree bit for bit on gap, normal and effective mass.  This path is
     // rare (4e-6 of the env-steps of a training run) and stays in scalar arithmetic; only its LDS record is the packed one.
@@ -967,6 +1028,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         for (int q = 0; q < 3; ++q) x[q] += f2{quad_sum(dx[q].x), quad_sum(dx[q].y)};
         x[3] = dx[3]; x[4] = dx[4];
     }
+    if (ROLE == 1 && QA_HELP_ROWS) __syncthreads();         // the contact helper's rows of this substep are in the lane's LDS records
     QA_SUBSTAMP(4);
     // ---- projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs {FL, RR} and {FR, RL} are
     // updated from the same base velocity and their base-velocity changes are summed; colours follow each other Gauss-Seidel fashion.  Every

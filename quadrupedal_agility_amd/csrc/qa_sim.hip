@@ -391,7 +391,7 @@ QA_DEV void post_in_preload(PostIn &in, const Ptrs &p, int env, int leg, int N) 
     in.eps = p.latent_eps[env]; in.epl0 = p.episode_length[env]; in.last_contact = p.last_contacts[(int64_t)env * 4 + leg];
 }
 
-template <bool PLANE, int LPE, int LEAN = 0>
+template <bool PLANE, int LPE, int LEAN = 0, int HELP = 0>
 __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptrs &p, const MocapIdx &mi, long long *qa_prof, PostIn &in, const TerrainView &T,
                                                    const float *tbl, float *s_stage, float *s_rows, const int tix, const int bix, const int env,
                                                    const int leg, const bool valid, const bool owner, const int le, const int64_t step) {
@@ -641,6 +641,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
     }
     wave_lds_sync();
 
+    if (HELP) __syncthreads();          // the helper's history-shift stores of these rows have been acknowledged (qa_env_step_kernel)
     QA_STAMP(9);
     // ---- wave-cooperative row writes.  The complete 671-float observation row of every env of the block is
     // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
@@ -823,6 +824,18 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         float *priv = priv_of(s_u, tix);
         EnvState st; ContactOut co;
         float fimp[3] = {0.f, 0.f, 0.f}, tau[3] = {0.f, 0.f, 0.f};
+        // The history shift of the observation rows (513 floats per env read and written, 3/4 of the launch's bytes) is pure data movement: the bias
+        // helper (the one with time to spare in every substep) issues its loads now and its stores after the last substep, and the env's own
+        // wavefront issues none of those 288 memory instructions and keeps none of the 144 values.  Ordering against that wavefront's own writes to
+        // the same rows (the new frame in slot 9, the refill of a reset env's slots): the stores have been acknowledged (vmcnt 0) before the
+        // workgroup's last barrier, which the env's wavefront passes before it writes a row.
+#ifdef QA_HIST_X4
+        HistRegs4 hvh;
+        if (role == 1) shift_history_load4<EPB>(a.p, bix, tix, c.num_envs, hvh);
+#else
+        float hvh[EPB][9];
+        if (role == 1) shift_history_load<EPB>(a.p, bix, tix, c.num_envs, hvh);
+#endif
         for (int d = 0; d < c.decimation; ++d) {
             __syncthreads();                                   // the state of this substep is in the mail (first time: the table and the parked persistents too)
             asm volatile("" ::: "memory");
@@ -832,6 +845,15 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
             if (role == 1) phys_substep<PLANE, HELP ? 2 : 0>(st, tbl, btbl, bi, tau, 0.f, leg, P, co, priv, fimp, T, mail);
             else phys_substep<PLANE, HELP ? 3 : 0>(st, tbl, btbl, bi, tau, 0.f, leg, P, co, priv, fimp, T, mail);
         }
+        if (role == 1) {
+#ifdef QA_HIST_X4
+            shift_history_store4<EPB>(a.p, bix, tix, c.num_envs, hvh);
+#else
+            shift_history_store<EPB>(a.p, bix, tix, c.num_envs, hvh);
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                       // the rows' history is in place: the env's wavefront may write them
         return;
     }
     float hv[EPB][9];
@@ -995,7 +1017,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         asm volatile("" :: "v"(in.esum[0]), "v"(in.esum[3]), "v"(in.esum[6]), "v"(in.esum[9]), "v"(in.esum[13]) : "memory");
         asm volatile("" :: "v"(in.cmd[0]), "v"(in.cmd[4]), "v"(in.latc[0]), "v"(in.latc[4]), "v"(in.eps), "v"((int)in.epl0), "v"((int)in.last_contact) : "memory");
         }
-        QA_SHIFT_LOAD();
+        if (!HELP) QA_SHIFT_LOAD();
     }
 #endif
     for (int d = 0; d < c.decimation; ++d) {
@@ -1017,7 +1039,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
 #ifdef QA_STORE_BEFORE_LAST
         // the history shift's stores go out in front of the LAST substep (the loads landed substeps ago): 17 MB from 256 wavefronts at once
         // drain beside ~12 us of arithmetic instead of in front of the tail's own stores
-        if (MODE == 0 && LPE == 4 && d == c.decimation - 1) QA_SHIFT_STORE();
+        if (MODE == 0 && LPE == 4 && !HELP && d == c.decimation - 1) QA_SHIFT_STORE();
 #endif
         if (HELP) { mail_put_state(mail, st); __syncthreads(); }       // the helpers start on this substep's state
         phys_substep<PLANE, HELP ? 1 : 0>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T, mail);
@@ -1040,7 +1062,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
 
     QA_STAMP(3);
 #if !defined(QA_SHIFT_EARLY_STORE) && !defined(QA_STORE_BEFORE_LAST)
-    if (MODE == 0 && LPE == 4) QA_SHIFT_STORE();     // in place: every lane loaded its 9 values of a row long ago; the tail's writes to the same rows come after these in program order
+    if (MODE == 0 && LPE == 4 && !HELP) QA_SHIFT_STORE();     // in place: every lane loaded its 9 values of a row long ago; the tail's writes to the same rows come after these in program order
 #endif
     // ---- refresh_*: body positions of the new state, contact forces per body
     V3 org[4];
@@ -1104,7 +1126,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
     in.st = st; in.foot_f = co.foot_f; in.hip_f = hip_f; in.thigh_f = thigh_f; in.calf_f = calf_f; in.base_f = base_f; in.foot_w = foot_w; in.fric = fric;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { in.act[k] = act[k]; in.raw_act[k] = raw_act[k]; in.tau[k] = tau[k]; in.tau_org[k] = tau_org[k]; in.sp[k] = sp[k]; in.sd[k] = sd[k]; in.fimp[k] = fimp[k]; }
-    post_physics_phase<PLANE, LPE, LEAN>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step);
+    post_physics_phase<PLANE, LPE, LEAN, HELP>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step);
     // the device-side step counter advances once every wavefront of the launch is done with it (they all read it at their
     // start): the last one to arrive resets the arrival counter and bumps the step -- no separate 1-thread launch per env step
     if (a.step_ptr && tix == 0) {
