@@ -125,6 +125,9 @@ static int fail_hip(hipError_t e, const char *what) {
 // (b) that the compiler does not move LDS accesses across the point.  __syncthreads() would additionally wait for
 // vmcnt(0), i.e. drain every outstanding global load and store at each exchange -- 8 full memory drains in the
 // observation phase alone.
+#ifndef QA_HELP_SCALARS
+#define QA_HELP_SCALARS 1                // with helper wavefronts: the step's closing scalar stores by the contact helper (0: by the env's own wavefront, A/B builds)
+#endif
 #ifndef QA_ENV_HELPERS_DEFAULT
 #define QA_ENV_HELPERS_DEFAULT (-1)      // -1: by launch size (launch_env_step), 0: never, 1: always
 #endif
@@ -361,6 +364,66 @@ __device__ __forceinline__ void write_body_state(float *rows, const EnvState &st
     }
 }
 
+// The per-env scalars and small rows a step ends with, as 4-byte words (integers as bit patterns): one record, so that the wavefront that
+// computed them and the wavefront that stores them (qa_env_step_kernel with helper wavefronts) need not be the same
+enum { SO_ST = 0, SO_Q = 13, SO_QD = 16, SO_TAU = 19, SO_TORG = 22, SO_ACT = 25, SO_FIMP = 28, SO_SCANH = 31, SO_REW = 32, SO_RESET = 33, SO_TIMEOUT = 34, SO_EPL = 35,
+       SO_BLV = 37, SO_BAV = 40, SO_PG = 43, SO_RPY = 46, SO_LAV = 49, SO_LAW = 52, SO_CMDDIRTY = 55, SO_GAIT = 56, SO_EPS = 57, SO_CMD = 58, SO_FFN = 63, SO_CONTACT = 64,
+       SO_CFILT = 65, SO_ESUM = 66, SO_WORDS = (66 + QA_NUM_REWARDS + 3) / 4 * 4 };
+static_assert(SO_WORDS == 66 + QA_NUM_REWARDS, "pad the record to whole 16-byte records (and zero the padding) when the reward count changes");
+struct ScalarOut { float w[SO_WORDS]; };
+static_assert(SO_WORDS / 4 <= QA_MAIL_F4, "the record travels in a lane's mail");
+template <bool PLANE, int LEAN>
+__device__ __forceinline__ void write_scalars(const Ptrs &p, const int N, const int env, const int leg, const bool valid, const ScalarOut &so) {
+    const float *w = so.w;
+    const int reset = __float_as_int(w[SO_RESET]);
+    if (valid) {
+        float *rt = p.root + (int64_t)env * 13;
+        if (leg == 0) {
+#pragma unroll
+            for (int i = 0; i < 13; ++i) rt[i] = w[SO_ST + i];
+            if (!PLANE && !(LEAN & 1)) p.scan_height[env] = w[SO_SCANH];
+            p.rew[env] = w[SO_REW]; p.reset[env] = reset; p.time_out[env] = (uint8_t)__float_as_int(w[SO_TIMEOUT]);
+            p.episode_length[env] = (int64_t)(((uint64_t)(uint32_t)__float_as_int(w[SO_EPL + 1]) << 32) | (uint64_t)(uint32_t)__float_as_int(w[SO_EPL]));
+            if (!(LEAN & 1)) {
+                float *o3;
+                o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = w[SO_BLV]; o3[1] = w[SO_BLV + 1]; o3[2] = w[SO_BLV + 2];
+                o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = w[SO_BAV]; o3[1] = w[SO_BAV + 1]; o3[2] = w[SO_BAV + 2];
+                o3 = p.proj_grav + (int64_t)env * 3; o3[0] = w[SO_PG]; o3[1] = w[SO_PG + 1]; o3[2] = w[SO_PG + 2];
+                o3 = p.rpy + (int64_t)env * 3; o3[0] = w[SO_RPY]; o3[1] = w[SO_RPY + 1]; o3[2] = w[SO_RPY + 2];
+            }
+            float *lr = p.last_root_vel + (int64_t)env * 6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { lr[i] = w[SO_LAV + i]; lr[3 + i] = w[SO_LAW + i]; }
+            if (__float_as_int(w[SO_CMDDIRTY])) {
+                const int gait = __float_as_int(w[SO_GAIT]);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { p.commands[(int64_t)env * 5 + i] = w[SO_CMD + i]; p.latent_c[(int64_t)env * 5 + i] = (gait == i) ? 1.0f : 0.0f; }
+                p.latent_eps[env] = w[SO_EPS];
+            }
+        }
+        float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
+            d[2 * k] = w[SO_Q + k]; d[2 * k + 1] = w[SO_QD + k];
+            if (!(LEAN & 1)) { p.torques[j] = w[SO_TAU + k]; p.torques_org[j] = w[SO_TORG + k]; p.actions[j] = w[SO_ACT + k]; }
+            p.last_actions[j] = w[SO_ACT + k]; p.last_dof_vel[j] = w[SO_QD + k]; p.last_torques_org[j] = w[SO_TORG + k];   // :158-161
+        }
+        if (!(LEAN & 1)) p.feet_force[(int64_t)env * 4 + leg] = w[SO_FFN];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = reset ? 0.f : w[SO_FIMP + k];
+        p.last_contacts[(int64_t)env * 4 + leg] = (uint8_t)__float_as_int(w[SO_CONTACT]);
+        if (!(LEAN & 1)) p.contact_filt[(int64_t)env * 4 + leg] = (uint8_t)__float_as_int(w[SO_CFILT]);
+#pragma unroll
+        for (int r = 0; r < QA_NUM_REWARDS; ++r) if ((r & 3) == leg) p.episode_sums[(int64_t)r * N + env] = w[SO_ESUM + r];
+        if (reset) {   // action history is zeroed by reset_idx (:227)
+            float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
+#pragma unroll
+            for (int r = (LEAN & 1) ? QA_ACTION_BUF_LEN - 2 : 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
+        }
+    }
+}
+
 // What the physics phase of the fused step hands to post_physics_step, per lane (lane = leg): the new state, the torques of
 // the LAST substep, the contact forces of the leg's bodies and of the base.  qa_post_physics_kernel fills the same record from
 // the arena instead, which makes the post-physics device code testable on its own against the reference's fixtures.
@@ -394,7 +457,7 @@ QA_DEV void post_in_preload(PostIn &in, const Ptrs &p, int env, int leg, int N) 
 template <bool PLANE, int LPE, int LEAN = 0, int HELP = 0>
 __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptrs &p, const MocapIdx &mi, long long *qa_prof, PostIn &in, const TerrainView &T,
                                                    const float *tbl, float *s_stage, float *s_rows, const int tix, const int bix, const int env,
-                                                   const int leg, const bool valid, const bool owner, const int le, const int64_t step) {
+                                                   const int leg, const bool valid, const bool owner, const int le, const int64_t step, f4 *mail = nullptr) {
     // (the kernel argument record is NOT passed as a whole: a reference to it makes the compiler keep a 1 KB private copy)
     constexpr int EPB = QA_BLOCK / LPE;                // envs per wavefront
     const int N = c.num_envs;
@@ -596,52 +659,38 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         }
     }
     QA_STAMP(8);
-    // ---- per-env scalars and small rows, written by the quad
-    if (valid) {
-        float *rt = p.root + (int64_t)env * 13;
-        if (leg == 0) {
-            rt[0] = st.pos.x; rt[1] = st.pos.y; rt[2] = st.pos.z; rt[3] = st.qx; rt[4] = st.qy; rt[5] = st.qz; rt[6] = st.qw;
-            rt[7] = st.vw.x; rt[8] = st.vw.y; rt[9] = st.vw.z; rt[10] = st.ww.x; rt[11] = st.ww.y; rt[12] = st.ww.z;
-            if (!PLANE && !(LEAN & 1)) p.scan_height[env] = scan_h;
-            p.rew[env] = rew; p.reset[env] = reset; p.time_out[env] = (uint8_t)timeout; p.episode_length[env] = epl;
-            if (!(LEAN & 1)) {
-                float *o3;
-                o3 = p.base_lin_vel + (int64_t)env * 3; o3[0] = blv.x; o3[1] = blv.y; o3[2] = blv.z;
-                o3 = p.base_ang_vel + (int64_t)env * 3; o3[0] = bav.x; o3[1] = bav.y; o3[2] = bav.z;
-                o3 = p.proj_grav + (int64_t)env * 3; o3[0] = pg.x; o3[1] = pg.y; o3[2] = pg.z;
-                o3 = p.rpy + (int64_t)env * 3; o3[0] = roll; o3[1] = pitch; o3[2] = yaw;
-            }
-            float *lr = p.last_root_vel + (int64_t)env * 6; lr[0] = lav.x; lr[1] = lav.y; lr[2] = lav.z; lr[3] = law.x; lr[4] = law.y; lr[5] = law.z;
-            if (cmd_dirty) {
+    // ---- per-env scalars and small rows, written by the quad (write_scalars).  With helper wavefronts the ~45 scattered dword stores -- 9.7 k of the
+    // launch's 112 k cycles on a wavefront that has nothing else to issue -- go through the mail to the contact helper, which is idle by now
+    {
+        ScalarOut so;
+        float *w = so.w;
+        w[SO_ST + 0] = st.pos.x; w[SO_ST + 1] = st.pos.y; w[SO_ST + 2] = st.pos.z; w[SO_ST + 3] = st.qx; w[SO_ST + 4] = st.qy; w[SO_ST + 5] = st.qz; w[SO_ST + 6] = st.qw;
+        w[SO_ST + 7] = st.vw.x; w[SO_ST + 8] = st.vw.y; w[SO_ST + 9] = st.vw.z; w[SO_ST + 10] = st.ww.x; w[SO_ST + 11] = st.ww.y; w[SO_ST + 12] = st.ww.z;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) { p.commands[(int64_t)env * 5 + i] = cmd[i]; p.latent_c[(int64_t)env * 5 + i] = (gait == i) ? 1.0f : 0.0f; }
-                p.latent_eps[env] = eps;
-            }
-        }
-        float *d = p.dof + (int64_t)env * 24 + 6 * leg;
+        for (int k = 0; k < 3; ++k) { w[SO_Q + k] = st.q[k]; w[SO_QD + k] = st.qd[k]; w[SO_TAU + k] = tau[k]; w[SO_TORG + k] = tau_org[k]; w[SO_ACT + k] = act[k]; w[SO_FIMP + k] = fimp[k]; }
+        w[SO_SCANH] = scan_h; w[SO_REW] = rew; w[SO_RESET] = __int_as_float((int)reset); w[SO_TIMEOUT] = __int_as_float((int)timeout);
+        w[SO_EPL] = __int_as_float((int)(uint32_t)((uint64_t)epl & 0xffffffffu)); w[SO_EPL + 1] = __int_as_float((int)(uint32_t)((uint64_t)epl >> 32));
+        w[SO_BLV] = blv.x; w[SO_BLV + 1] = blv.y; w[SO_BLV + 2] = blv.z; w[SO_BAV] = bav.x; w[SO_BAV + 1] = bav.y; w[SO_BAV + 2] = bav.z;
+        w[SO_PG] = pg.x; w[SO_PG + 1] = pg.y; w[SO_PG + 2] = pg.z; w[SO_RPY] = roll; w[SO_RPY + 1] = pitch; w[SO_RPY + 2] = yaw;
+        w[SO_LAV] = lav.x; w[SO_LAV + 1] = lav.y; w[SO_LAV + 2] = lav.z; w[SO_LAW] = law.x; w[SO_LAW + 1] = law.y; w[SO_LAW + 2] = law.z;
+        w[SO_CMDDIRTY] = __int_as_float(cmd_dirty ? 1 : 0); w[SO_GAIT] = __int_as_float(gait); w[SO_EPS] = eps;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int64_t j = (int64_t)env * 12 + 3 * leg + k;
-            d[2 * k] = st.q[k]; d[2 * k + 1] = st.qd[k];
-            if (!(LEAN & 1)) { p.torques[j] = tau[k]; p.torques_org[j] = tau_org[k]; p.actions[j] = act[k]; }
-            p.last_actions[j] = act[k]; p.last_dof_vel[j] = st.qd[k]; p.last_torques_org[j] = tau_org[k];   // :158-161
-        }
-        if (!(LEAN & 1)) p.feet_force[(int64_t)env * 4 + leg] = ffn;
+        for (int i = 0; i < 5; ++i) w[SO_CMD + i] = cmd[i];
+        w[SO_FFN] = ffn; w[SO_CONTACT] = __int_as_float((int)contact); w[SO_CFILT] = __int_as_float((int)cfilt);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p.foot_impulse[(int64_t)env * 12 + 3 * leg + k] = reset ? 0.f : fimp[k];
-        p.last_contacts[(int64_t)env * 4 + leg] = contact;
-        if (!(LEAN & 1)) p.contact_filt[(int64_t)env * 4 + leg] = cfilt;
+        for (int r = 0; r < QA_NUM_REWARDS; ++r) w[SO_ESUM + r] = esum[r];
+        if (HELP && QA_HELP_SCALARS) {
 #pragma unroll
-        for (int r = 0; r < QA_NUM_REWARDS; ++r) if ((r & 3) == leg) p.episode_sums[(int64_t)r * N + env] = esum[r];
-        if (reset) {   // action history is zeroed by reset_idx (:227)
-            float *ah = p.action_hist + (int64_t)env * (QA_ACTION_BUF_LEN * 12) + 3 * leg;
-#pragma unroll
-            for (int r = (LEAN & 1) ? QA_ACTION_BUF_LEN - 2 : 0; r < QA_ACTION_BUF_LEN; ++r) { ah[12 * r] = 0.f; ah[12 * r + 1] = 0.f; ah[12 * r + 2] = 0.f; }
+            for (int i = 0; i < SO_WORDS / 4; ++i) mail[i] = f4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+        } else {
+            write_scalars<PLANE, LEAN>(p, N, env, leg, valid, so);
         }
     }
     wave_lds_sync();
 
-    if (HELP) __syncthreads();          // the helper's history-shift stores of these rows have been acknowledged (qa_env_step_kernel)
+    // the workgroup's last barrier: behind it the bias helper's history-shift stores of these rows have been acknowledged, and the contact helper finds
+    // this wavefront's scalars in the mail (qa_env_step_kernel)
+    if (HELP) __syncthreads();
     QA_STAMP(9);
     // ---- wave-cooperative row writes.  The complete 671-float observation row of every env of the block is
     // assembled in LDS (s_rows), then streamed out with 16-byte stores (1 KiB per wave instruction); rows are only
@@ -854,6 +903,13 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();                                       // the rows' history is in place: the env's wavefront may write them
+        if (role == 2 && QA_HELP_SCALARS) {                    // ... and its scalars are in the mail: the idle contact helper stores them
+            ScalarOut so;
+#pragma unroll
+            for (int i = 0; i < SO_WORDS / 4; ++i) { const f4 v = mail[i]; so.w[4 * i] = v.x; so.w[4 * i + 1] = v.y; so.w[4 * i + 2] = v.z; so.w[4 * i + 3] = v.w; }
+            const int env_raw = (bix * QA_BLOCK + tix) / LPE;
+            write_scalars<PLANE, LEAN>(a.p, c.num_envs, env_raw < c.num_envs ? env_raw : c.num_envs - 1, leg, env_raw < c.num_envs, so);
+        }
         return;
     }
     float hv[EPB][9];
@@ -1126,7 +1182,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
     in.st = st; in.foot_f = co.foot_f; in.hip_f = hip_f; in.thigh_f = thigh_f; in.calf_f = calf_f; in.base_f = base_f; in.foot_w = foot_w; in.fric = fric;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { in.act[k] = act[k]; in.raw_act[k] = raw_act[k]; in.tau[k] = tau[k]; in.tau_org[k] = tau_org[k]; in.sp[k] = sp[k]; in.sd[k] = sd[k]; in.fimp[k] = fimp[k]; }
-    post_physics_phase<PLANE, LPE, LEAN, HELP>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step);
+    post_physics_phase<PLANE, LPE, LEAN, HELP>(c, p, a.mi, a.prof, in, T, tbl, s_stage, s_rows, tix, bix, env, leg, valid, owner, le, step, mail);
     // the device-side step counter advances once every wavefront of the launch is done with it (they all read it at their
     // start): the last one to arrive resets the arrival counter and bumps the step -- no separate 1-thread launch per env step
     if (a.step_ptr && tix == 0) {
