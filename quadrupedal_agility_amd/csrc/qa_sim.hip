@@ -878,6 +878,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         // wavefront issues none of those 288 memory instructions and keeps none of the 144 values.  Ordering against that wavefront's own writes to
         // the same rows (the new frame in slot 9, the refill of a reset env's slots): the stores have been acknowledged (vmcnt 0) before the
         // workgroup's last barrier, which the env's wavefront passes before it writes a row.
+        if (role == 2) stage_table(s_tbl);                     // (the env's wavefront meets it behind the first barrier)
 #ifdef QA_HIST_X4
         HistRegs4 hvh;
         if (role == 1) shift_history_load4<EPB>(a.p, bix, tix, c.num_envs, hvh);
@@ -893,15 +894,18 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
             priv_unpark(priv, pa, psp, psd, bi);
             if (role == 1) phys_substep<PLANE, HELP ? 2 : 0>(st, tbl, btbl, bi, tau, 0.f, leg, P, co, priv, fimp, T, mail);
             else phys_substep<PLANE, HELP ? 3 : 0>(st, tbl, btbl, bi, tau, 0.f, leg, P, co, priv, fimp, T, mail);
-        }
-        if (role == 1) {
+            // the history stores go out behind the second-to-last substep's last barrier, while the env's wavefront runs that substep's sweeps
+            // (~10 k cycles in which this helper has nothing to do): 17 MB of writes from 256 CUs need ~5 us to be acknowledged, and the env's
+            // wavefront must not find itself waiting for that at the workgroup's last barrier
+            if (role == 1 && d == (c.decimation > 1 ? c.decimation - 2 : 0)) {
 #ifdef QA_HIST_X4
-            shift_history_store4<EPB>(a.p, bix, tix, c.num_envs, hvh);
+                shift_history_store4<EPB>(a.p, bix, tix, c.num_envs, hvh);
 #else
-            shift_history_store<EPB>(a.p, bix, tix, c.num_envs, hvh);
+                shift_history_store<EPB>(a.p, bix, tix, c.num_envs, hvh);
 #endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
+        if (role == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // the rows' history is in place: the env's wavefront may write them
         if (role == 2 && QA_HELP_SCALARS) {                    // ... and its scalars are in the mail: the idle contact helper stores them
             ScalarOut so;
@@ -939,7 +943,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
     float tblv[QA_TBL_PER];
     stage_table_load(tblv);
 #else
-    stage_table(s_tbl);
+    if (!HELP) stage_table(s_tbl);
 #endif
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
@@ -1080,6 +1084,9 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         // compiler fence: without it LICM hoists the ~120 loop-invariant LDS table reads of the substep out of this
         // loop and keeps them in registers across it, which is what pushed the kernel into scratch
         asm volatile("" ::: "memory");
+        // the helpers start on this substep's state; behind the FIRST of these barriers the constant table is in LDS too (with helpers the
+        // contact helper stages it while this wavefront loads its state)
+        if (HELP) { mail_put_state(mail, st); __syncthreads(); }
         float bi[10], pa[3], psp[3], psd[3];
         priv_unpark(priv, pa, psp, psd, bi);
 #pragma unroll
@@ -1097,7 +1104,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         // drain beside ~12 us of arithmetic instead of in front of the tail's own stores
         if (MODE == 0 && LPE == 4 && !HELP && d == c.decimation - 1) QA_SHIFT_STORE();
 #endif
-        if (HELP) { mail_put_state(mail, st); __syncthreads(); }       // the helpers start on this substep's state
         phys_substep<PLANE, HELP ? 1 : 0>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T, mail);
     }
     { float bi_[10]; priv_unpark(priv, act, sp, sd, bi_); }

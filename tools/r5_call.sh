@@ -247,6 +247,26 @@ for f in sorted(glob.glob("gpurun_out/r5/fin3/bench_*.json")):
     except Exception as e: print(f, "no line", e)
 PY
     ;;
+fin4)      # helper wavefronts, stage 5: the contact helper stages the constant table, the bias helper's history stores go out one substep earlier
+    for i in 1 2 3; do
+      for v in "" base; do
+        L=""; [ -n "$v" ] && L=$R/tools/_prof/libqa_sim_$v.so
+        echo "${v:-product} $i: $(QA_LIB=$L timeout 100 python tools/quick_time.py 2>&1 | grep 'N=' | tr '\n' ' ')" >> $O/quick_time_variants.txt
+      done
+    done; cat $O/quick_time_variants.txt
+    timeout 900 python -m pytest tests/test_hip_parity.py tests/test_mocap_reset.py tests/test_golden_env.py tests/test_self_collision.py tests/test_full_size_properties.py tests/test_gpu_train.py tests/test_seam1_reference_env.py -m gpu -x -q > $O/pytest_env_product.log 2>&1; echo "product: $(tail -1 $O/pytest_env_product.log)"
+    timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512.json
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5/fin4/bench_*.json")):
+    try:
+        d = json.loads(open(f).read()); r = d.get("roofline") or {}
+        print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round((d.get("collection_s") or 0) * 1e3, 2), "update", round((d.get("learn_s") or 0) * 1e3, 2),
+              "kernel us", round((r.get("kernel_ms") or 0) * 1e3, 1), "frac", round(r.get("frac") or 0, 4))
+    except Exception as e: print(f, "no line", e)
+PY
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
