@@ -267,6 +267,11 @@ for f in sorted(glob.glob("gpurun_out/r5/fin4/bench_*.json")):
     except Exception as e: print(f, "no line", e)
 PY
     ;;
+final)     # the round's measurement pass (tools/final_measure.sh -> gpurun_out/final/), then the whole GPU suite and smoke() on the code as measured
+    timeout 3000 bash tools/final_measure.sh > $O/final_measure.log 2>&1; tail -30 $O/final_measure.log
+    timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
