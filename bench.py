@@ -202,7 +202,12 @@ def main():
 
     if rank == 0:
         achieved = ALG_BYTES_PER_ENV_STEP * args.num_envs / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_note = _stamped_traffic(g, args.num_envs)
+        # the PMC pass on file is of the PLANE kernel with the lean export mask of a run without the discriminator (3); config 3 launches mask 1, the
+        # trimesh course the height-field kernel: neither is the kernel that was counted
+        if args.terrain != "plane" or args.amp:
+            traffic, traffic_note = None, "the PMC pass on file is of the plane kernel with lean exports 3 (config 2); this run launches another variant of the kernel"
+        else:
+            traffic, traffic_note = _stamped_traffic(g, args.num_envs)
         out = {
             "metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,7 +225,7 @@ def main():
             "roofline": {"kernel": "qa_env_step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": kern_ms, "kernel_ms_back_to_back": kern_ms_alone, "rollout_graph": bool(getattr(runner, "_graph", None) is not None),
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * args.num_envs,
-                         "note": "not byte-bound: 4096 envs = 256 wavefronts = one per CU; by the SQ counters that wavefront spends 67 % of its cycles issuing instructions (22.1 k VALU) and 31 % waiting with nothing else to run (profiles/r4_env_step_sq_counters.txt, DESIGN.md 4.1); traffic is the PMC figure of the lean-export kernel a training run launches (1.06x algorithmic; full exports 1.37x); 16384 envs/GPU: 163.7 us per launch = 2.1x this rate (profiles/r4_final_env_kernel_timing.txt; 3 workgroups per CU)"},
+                         "note": "not byte-bound: 4096 envs = 256 workgroups = one per CU; the env's own wavefront is instruction-issue-bound (a Gauss-Seidel chain), r5 gives each workgroup two helper wavefronts on the CU's idle SIMDs for the substep's side chains, the non-foot rows, the history shift and the closing stores (69 -> 56 us back to back, DESIGN.md 4.1c, profiles/r5_env_step_helper_wavefronts.txt); traffic is the PMC figure of the lean-export kernel a training run launches (1.09x algorithmic); 16384 envs/GPU: 136 us per launch = 1.65x this rate (one-wavefront kernels: every SIMD has an env wavefront of its own there)"},
         }
         if mlp_ms is not None:
             pf = ROLLOUT_FLOPS_PER_SAMPLE * args.num_envs
