@@ -272,6 +272,10 @@ final)     # the round's measurement pass (tools/final_measure.sh -> gpurun_out/
     timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -6 $O/pytest_gpu.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
     ;;
+fast3)     # config 3 fast arm on the round's FINAL code (helper wavefronts are active at 1024 envs): eight more seeds, beside the 29 of the earlier builds
+    timeout 1700 python tools/d2_many.py --out $O --arms fast:31-38 --workers 3 --job_timeout 1200 --budget_s 1300 > $O/d2_many.log 2>&1
+    tail -10 $O/d2_many.log
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
