@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "../../include/qa_sim.h"
 
@@ -451,16 +452,21 @@ int qa_mlp_strands(const qa_mlp_op *ops, int32_t num_ops, int32_t max_strands, i
 /* Measured (profiles/r5_policy_groups.txt): 87.7 us against the one-group kernel's 85.5 us at 4096 rows, 336.7 against 320.6 at 16,384 -- the strands
  * share the MFMA pipes they were meant to keep busy, and a lone four-wave strand hides its weight stream worse than eight waves do.  The two-group
  * launch therefore ships OFF (default 1); QA_MLP_GROUPS=2 / qa_mlp_set_groups(2) turn it on (the tests do, it is bit-identical). */
-static int g_mlp_groups = -1;           /* -1: not decided yet (QA_MLP_GROUPS in the environment, default 1) */
+static std::atomic<int> g_mlp_groups{-1};           /* -1: not decided yet (QA_MLP_GROUPS in the environment, default 1) */
 static int mlp_groups_switch() {
-    if (g_mlp_groups < 0) { const char *e = getenv("QA_MLP_GROUPS"); g_mlp_groups = e ? (atoi(e) >= 2 ? 2 : 1) : 1; }
-    return g_mlp_groups;
+    int v = g_mlp_groups.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("QA_MLP_GROUPS");
+        int expected = -1;
+        g_mlp_groups.compare_exchange_strong(expected, e ? (atoi(e) >= 2 ? 2 : 1) : 1);       /* a concurrent qa_mlp_set_groups wins */
+        v = g_mlp_groups.load(std::memory_order_relaxed);
+    }
+    return v;
 }
 
 int qa_mlp_set_groups(int32_t groups) {
-    const int prev = mlp_groups_switch();
-    g_mlp_groups = groups >= 2 ? 2 : 1;
-    return prev;
+    mlp_groups_switch();
+    return g_mlp_groups.exchange(groups >= 2 ? 2 : 1);
 }
 
 int qa_mlp_groups(const qa_mlp_op *ops, int32_t num_ops, int32_t x_cols, int32_t *strand_of, int32_t *base, int32_t *stride, int32_t *lds_floats) {
