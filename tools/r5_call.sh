@@ -276,6 +276,11 @@ fast3)     # config 3 fast arm on the round's FINAL code (helper wavefronts are 
     timeout 1700 python tools/d2_many.py --out $O --arms fast:31-38 --workers 3 --job_timeout 1200 --budget_s 1300 > $O/d2_many.log 2>&1
     tail -10 $O/d2_many.log
     ;;
+fast4)     # the helper-vs-one-wavefront test, then 24 more config-3 fast-arm seeds on the final code (with fast3's eight: a fast arm of the shipped kernels only)
+    timeout 900 python -m pytest tests/test_env_helpers.py -m gpu -s -q > $O/pytest_env_helpers.log 2>&1; grep -E "worst|passed|failed|Error" $O/pytest_env_helpers.log | cut -c1-400
+    timeout 2300 python tools/d2_many.py --out $O --arms fast:39-62 --workers 3 --job_timeout 1200 --budget_s 1750 > $O/d2_many.log 2>&1
+    tail -6 $O/d2_many.log
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
