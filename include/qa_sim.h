@@ -254,7 +254,11 @@ int qa_tensor_info(const qa_config *cfg, int which, int64_t *byte_offset, int64_
  * legged_robot.py:87-93), clip, `decimation` x (PD torque -> forward dynamics -> contact ->
  * integrate), post_physics_step (termination, 14 rewards, reset of done envs, observations).
  * `actions` is a device pointer to (N,12) fp32.  `global_step` is the env's step counter
- * before this call (common_step_counter); it keys the RNG and triggers pushes. */
+ * before this call (common_step_counter); it keys the RNG and triggers pushes.
+ * Launch shape (r5, no ABI change): one workgroup per 16 envs; on plane terrain, while the launch has at most one
+ * workgroup per compute unit (N <= 16 x CUs = 4096 on an MI355X), every workgroup carries two HELPER wavefronts beside the
+ * envs' own one (substep side chains, non-foot contact rows, the observation rows' history shift, the closing scalar stores);
+ * same arithmetic, same outputs to rounding.  QA_ENV_HELPERS=0 / 1 in the environment forces them off / on. */
 int qa_env_step(qa_sim *sim, const float *actions, int32_t delay_steps, int64_t global_step, void *stream);
 
 /* qa_env_step for recorded launches: the step counter is read from DEVICE memory (one int64) and incremented by the
