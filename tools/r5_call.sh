@@ -281,6 +281,11 @@ fast4)     # the helper-vs-one-wavefront test, then 24 more config-3 fast-arm se
     timeout 2300 python tools/d2_many.py --out $O --arms fast:39-62 --workers 3 --job_timeout 1200 --budget_s 1750 > $O/d2_many.log 2>&1
     tail -6 $O/d2_many.log
     ;;
+last)      # the round's last call, on HEAD: the driver's own commands (default bench line, the whole GPU suite, smoke)
+    timeout 600 python bench.py 2> $O/bench.err < /dev/null | grep '"metric"' > $O/bench_default.json; cut -c1-400 $O/bench_default.json
+    timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    ;;
 pro)       # history loads through AGPRs issued last, obs-tail ballot, PostIn preload: parity as judged, then timing / phases / the bench line
     timeout 1200 python -m pytest tests/test_hip_parity.py tests/test_articulated_obstacles.py tests/test_tsc_course_env.py tests/test_self_collision.py tests/test_mocap_reset.py tests/test_full_size_properties.py tests/test_tsc_env.py tests/test_hybrid_arm.py -m gpu -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log
     for i in 1 2; do
