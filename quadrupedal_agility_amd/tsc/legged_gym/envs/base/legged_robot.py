@@ -175,6 +175,7 @@ class LeggedRobot:
         self._obs_disc_term = torch.zeros(self.num_envs, self.num_obs_disc, device=dev)
         self._all = torch.ones(self.num_envs, dtype=torch.uint8, device=dev)
         self.sync_reset_ids = True
+        self.want_delta_yaw_ok = True     # extras["delta_yaw_ok"] every step, as the reference does (a runner that never reads it may switch it off)
         self.init_done = True
 
         # reset_idx(all); _resample_commands(all) is the reference's U(range) draw, superseded by the first set_commands
@@ -267,7 +268,8 @@ class LeggedRobot:
         self.total_env_steps_counter += 1
         self.sim.physics_step(a, delay)
         reset_env_ids, terminal = self.post_physics_step(action_hl_history_buf)
-        self.extras["delta_yaw_ok"] = torch.abs(self.bk.delta_yaw) < 0.6
+        # (only the vision student reads it: the teacher's runner switches it off -- two launches per env step of its recorded rollout)
+        self.extras["delta_yaw_ok"] = (torch.abs(self.bk.delta_yaw) < 0.6) if self.want_delta_yaw_ok else None
         if self.cfg.depth.use_camera and self.global_counter % self.cfg.depth.update_interval == 0:
             self.extras["depth"] = self.bk.depth_buffer[:, -2]            # :145-146
         else:

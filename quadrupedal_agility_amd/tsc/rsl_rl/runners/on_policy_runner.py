@@ -101,6 +101,7 @@ class OnPolicyRunner:
         self.use_fused_policy = on_gpu and os.environ.get("QA_FUSED_POLICY", "1") != "0"
         self.use_hybrid_act = os.environ.get("QA_TSC_HYBRID_ACT", "1") != "0"      # sampling + log-probs + storage rows + action history: qa_rollout_act_hybrid
         env.sync_reset_ids = False              # rollouts never wait for the GPU
+        env.want_delta_yaw_ok = self.if_depth   # infos["delta_yaw_ok"] is the student's (learn_vision); the teacher's rollout never reads it
 
     # ------------------------------------------------------------------ the frozen behaviour policy: one launch per env step
     def _behaviour_policy(self):
