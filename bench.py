@@ -34,6 +34,56 @@ ROLLOUT_FLOPS_PER_SAMPLE = 2 * (217088 + 3712 + 507520 + 15744)
 _RESULT_OUT = sys.stdout
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher (how the driver calls it: BENCH_r05.json `cmd`): start the N ranks ourselves, one process
+    per GPU under torch.distributed.run on 127.0.0.1, and pass their output through -- rank 0 prints the one JSON line.  Refuses, with the
+    reason, when the box has fewer than N GPUs (unless QA_BENCH_SHARED_GPU=1: the N-ranks-on-one-GPU harness, gloo collectives)."""
+    import socket
+    import subprocess
+    check = "--launch_check" in sys.argv
+    if not check:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n and os.environ.get("QA_BENCH_SHARED_GPU") != "1":
+            print(f"bench.py --gpus {n}: this box has {have} GPU(s).  One process per GPU needs {n}; QA_BENCH_SHARED_GPU=1 runs the {n} ranks on GPU 0 "
+                  "over gloo (a harness for the data-parallel code path, not a scaling measurement).", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:           # a free port for the rendezvous (the container's hostname may not resolve: 127.0.0.1 throughout)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _launch_check(world, rank):
+    """--launch_check: the ranks meet over gloo, agree on who is there, rank 0 prints one line.  No GPU, no library build."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.zeros(world, dtype=torch.int64)
+    t[rank] = os.getpid()
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": world, "pids": t.tolist(), "launcher": "bench.py self-launch" if os.environ.get("TORCHELASTIC_RUN_ID") else "external"}),
+              file=_RESULT_OUT, flush=True)
+
+
+def _collective_name(shared):
+    """what carried the buckets: 'rccl <version>' or 'gloo'"""
+    import torch
+    if shared:
+        return "gloo (host memory)"
+    try:
+        v = torch.cuda.nccl.version()
+        return "rccl " + ".".join(str(x) for x in v)
+    except Exception as e:      # never fatal for a bench line
+        return f"rccl (version unavailable: {e})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,7 +102,10 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch the rollout eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu_seconds", type=float, default=12.0)
+    ap.add_argument("--launch_check", action="store_true", help="plumbing check without a GPU: launch the ranks, rendezvous over gloo, print one line, exit")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -62,8 +115,9 @@ def main():
     global _RESULT_OUT
     _RESULT_OUT, sys.stdout = sys.stdout, sys.stderr       # stdout carries the ONE JSON line; the libraries' chatter goes to stderr
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: one process per GPU (plain `python bench.py --gpus N` launches them itself)")
+    if args.launch_check:
+        return _launch_check(world, rank)
     # QA_BENCH_SHARED_GPU=1 (a harness, NOT a scaling measurement): every rank of the job runs on GPU 0 and the buckets travel over gloo.
     # What it bounds on a 1-GPU box: the cost of the data-parallel code path itself -- the PPO step as two graphs around a collective, the
     # per-rank shards, 20 collectives per iteration -- when no multi-GPU node is available.  The line says so (`shared_gpu_harness`).
@@ -218,6 +272,7 @@ def main():
                                    f"{total_envs} envs in total = {args.num_envs} envs/GPU x {world}, {'plane' if args.terrain == 'plane' else 'height-field (trimesh course)'} terrain, 24 steps/iter, 5 epochs x 4 minibatches",
                        "num_envs_total": total_envs, "num_envs_per_gpu": args.num_envs, "steps_per_iter": T, "parallelism": f"dp{world}"},
             "wallclock_1k_iters_s": dt / args.steps * 1000.0,
+            **({"ranks": world, "collective": _collective_name(shared)} if world > 1 else {}),
             **({"shared_gpu_harness": f"{world} ranks on ONE GPU, gloo collectives through host memory: bounds the data-parallel code path's own cost, says nothing about xGMI scaling",
                 "n_gpus": 1, "ranks": world} if shared else {}),
             "rollout_env_steps_per_s": args.num_envs * T * world / (sum(coll) / len(coll)),
@@ -398,6 +453,8 @@ def bench_tsc(args, world, rank, local_rank, dev):
                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tsc_traffic, "traffic_source": tsc_traffic_note, "kernel_ms": kern_ms, "kernel_ms_each": spans,
                         "algorithmic_bytes_per_launch": alg_bytes * n}}
+    if world > 1:
+        out["ranks"], out["collective"] = world, _collective_name(os.environ.get("QA_BENCH_SHARED_GPU") == "1")
     if args.vision:
         out["vision"] = dict(runner.last_vision)
     chain = getattr(runner, "_bbc_chain", None)
@@ -527,7 +584,12 @@ def _cpu_iteration_leg(num_envs, its, threads, limit_s):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
         return {"why": (r.stderr or "no output")[-300:]}
-    d = json.loads(line[-1])
+    try:
+        d = json.loads(line[-1])
+    except ValueError:
+        return {"why": "unparsable child output: " + line[-1][-200:]}
+    if not isinstance(d, dict) or not isinstance(d.get("iteration_s"), (int, float)):      # e.g. an error record: never a KeyError in the baseline report
+        return {"why": "the child printed no iteration_s: " + line[-1][-200:]}
     d["startup_s"] = max(0.0, (time.perf_counter() - t0) - d["iteration_s"] * (its + 1))
     return d
 

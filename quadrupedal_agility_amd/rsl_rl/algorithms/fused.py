@@ -116,8 +116,9 @@ def hybrid_ppo_loss_raw(logits, mean, std, value, actions, old_logp_d, old_logp_
 # `param.grad` and squares it.  Whoever needs finished gradients before the optimiser runs (the data-parallel bucket, tests) calls
 # `flush_pending_grads()` -- ONE launch for all of them.  Nothing may read `.grad` of a registered parameter before one of the two ran.
 _DEFER = [False]
-_PENDING = {}          # parameter data_ptr -> (parameter, parts tensor, number of parts, stride between parts in elements)
+_PENDING = {}          # parameter data_ptr -> (parameter, parts tensor, number of parts, stride between parts in elements, placeholder alias, stream)
 _RETIRED = []          # parts tensors of the step before: see _retire
+_NO_DEFER = set()      # parameters that already received a second gradient in this deferral context: finished gradients only from here on
 
 
 def _retire(parts):
@@ -135,6 +136,7 @@ class deferred_grad_finishes:
         self.prev = _DEFER[0]
         _DEFER[0] = ENABLED and os.environ.get("QA_DEFER_GRAD_FINISH", "1") != "0"
         del _RETIRED[:]
+        _NO_DEFER.clear()
         return self
 
     def __exit__(self, *exc):
@@ -143,11 +145,51 @@ class deferred_grad_finishes:
 
 
 def _defer_ok(param):
-    return _DEFER[0] and param is not None and param.is_cuda and param.is_leaf and param.requires_grad and param.data_ptr() not in _PENDING
+    """May this backward node leave `param`'s gradient in parts?  Only when the placeholder it hands autograd is the ONLY thing that can
+    reach `.grad` before a finish runs: no gradient accumulated earlier (`.grad is None`: autograd would add the unwritten placeholder to
+    it), no double-backward graph (autograd clones instead of adopting the placeholder), and no second gradient for the same parameter --
+    a parameter used twice in one graph (the privileged encoder under `train_with_estimated_latent`: once for the regulariser, once inside
+    the actor) or met again by a later backward call.  The second arrival is what `_second_gradient` handles."""
+    if not (_DEFER[0] and param is not None and param.is_cuda and param.is_leaf and param.requires_grad):
+        return False
+    key = param.data_ptr()
+    return key not in _PENDING and key not in _NO_DEFER and param.grad is None and not torch.is_grad_enabled()
 
 
-def _register_parts(param, parts, nparts, stride):
-    _PENDING[param.data_ptr()] = (param, parts, int(nparts), int(stride))
+def _gradient_arriving(*params):
+    """every backward node of this module that produces a gradient for a Parameter says so BEFORE it decides about deferral"""
+    for param in params:
+        if param is not None and _PENDING and param.data_ptr() in _PENDING:
+            _second_gradient(param)
+
+
+def _second_gradient(param):
+    """`param` has a gradient in parts and another one is about to be produced.  Autograd will ADD the two tensors, so the first must hold
+    its finished value by then: the parts are summed NOW (one qa_grad_reduce launch) into the memory of the placeholder the first node
+    returned -- which is either still waiting in the engine's input buffer (same backward call: the engine adds after this node returns, and
+    orders that after everything launched here) or has become `.grad` (an earlier backward call: autograd adopts the placeholder's
+    storage, or cloned it, in which case `.grad` itself is the destination).  From here on the parameter gets finished gradients only."""
+    lib = _capi.load_library()
+    p, parts, nparts, stride, alias, stream = _PENDING.pop(param.data_ptr())
+    _NO_DEFER.add(param.data_ptr())
+    dst = alias if (p.grad is None or p.grad.data_ptr() == alias.data_ptr()) else p.grad
+    if not dst.is_contiguous() or dst.numel() != p.numel():
+        raise RuntimeError("a gradient registered in parts cannot be finished: its destination is not a contiguous tensor of the parameter's size")
+    cur = torch.cuda.current_stream(p.device)
+    if stream is not None and stream != cur:
+        cur.wait_stream(stream)          # the parts were written on the stream the first node ran on
+    _check(lib.qa_grad_reduce((C.c_void_p * 1)(dst.data_ptr()), (C.c_void_p * 1)(parts.data_ptr()), (C.c_int64 * 1)(stride), (C.c_int32 * 1)(nparts),
+                              (C.c_int32 * 1)(p.numel()), 1, C.c_void_p(cur.cuda_stream)), "qa_grad_reduce")
+    _retire(parts)
+
+
+def _register_parts(param, parts, nparts, stride, shape=None):
+    """-> the placeholder to hand autograd for `param`'s gradient (unwritten; the finish writes where autograd keeps it: `.grad` adopts the
+    placeholder's storage).  `_PENDING` keeps a second tensor object on the same storage, not the placeholder itself: autograd adopts a
+    gradient only when nobody else holds the tensor object, and would clone it (one launch per parameter) otherwise."""
+    buf = torch.empty(tuple(param.shape) if shape is None else shape, dtype=torch.float32, device=param.device)
+    _PENDING[param.data_ptr()] = (param, parts, int(nparts), int(stride), buf, torch.cuda.current_stream(param.device))
+    return buf.detach()
 
 
 def pending_grads():
@@ -167,11 +209,11 @@ def flush_pending_grads(params=None):
     for i in range(0, len(ent), 64):
         e = ent[i:i + 64]
         n = len(e)
-        dst = (C.c_void_p * n)(*[p.grad.data_ptr() for p, *_ in e]); src = (C.c_void_p * n)(*[t.data_ptr() for _, t, _, _ in e])
-        stride = (C.c_int64 * n)(*[st for *_, st in e]); parts = (C.c_int32 * n)(*[k for _, _, k, _ in e]); numel = (C.c_int32 * n)(*[p.numel() for p, *_ in e])
+        dst = (C.c_void_p * n)(*[x[0].grad.data_ptr() for x in e]); src = (C.c_void_p * n)(*[x[1].data_ptr() for x in e])
+        stride = (C.c_int64 * n)(*[x[3] for x in e]); parts = (C.c_int32 * n)(*[x[2] for x in e]); numel = (C.c_int32 * n)(*[x[0].numel() for x in e])
         _check(lib.qa_grad_reduce(dst, src, stride, parts, numel, n, C.c_void_p(torch.cuda.current_stream(e[0][0].device).cuda_stream)), "qa_grad_reduce")
-    for _, t, _, _ in ent:
-        _retire(t)
+    for e in ent:
+        _retire(e[1])
 
 
 class _LinearElu(torch.autograd.Function):
@@ -198,6 +240,7 @@ class _LinearElu(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         bias = ctx.bias_param
         lib = _capi.load_library()
+        _gradient_arriving(weight, bias)
         gy = _f32c(gy)
         rows, cols = y.shape
         g = torch.empty_like(y)
@@ -209,8 +252,8 @@ class _LinearElu(torch.autograd.Function):
         rc = lib.qa_elu_backward_bias(_ptr(gy), _ptr(y), _ptr(g), None if defer_b else _ptr(gb), rows, cols, float(ctx.alpha), _ptr(scratch), nscratch, stream)
         if rc != 0:
             raise RuntimeError(f"qa_elu_backward_bias failed with code {rc}: {lib.qa_last_error().decode()}")
-        if defer_b:           # gb stays unwritten: the optimiser's first pass adds the (rows / 64) rows of column sums
-            _register_parts(bias, scratch, (rows + 63) // 64, cols)
+        if defer_b:           # the optimiser's first pass adds the (rows / 64) rows of column sums; autograd gets an unwritten placeholder
+            gb = _register_parts(bias, scratch, (rows + 63) // 64, cols)
         gx = g.mm(weight) if ctx.needs_input_grad[0] else None
         gw = weight_grad(g, x, param=weight) if ctx.needs_input_grad[1] else None
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None
@@ -237,6 +280,7 @@ class _LinearRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
+        _gradient_arriving(weight)
         g, gb = _masked_colsum(gy, y)
         gx = g.mm(weight) if ctx.needs_input_grad[0] else None
         gw = weight_grad(g, x) if ctx.needs_input_grad[1] else None
@@ -303,8 +347,7 @@ def weight_grad(g, x, param=None):
     if ENABLED and rows >= 8192 and rows % S == 0 and n * k >= 16384 and g.stride(1) == 1 and x.stride(1) == 1:
         slabs = torch.bmm(g.unflatten(0, (S, rows // S)).transpose(1, 2), x.unflatten(0, (S, rows // S)))
         if _defer_ok(param) and param.shape == (n, k) and param.is_contiguous():
-            _register_parts(param, slabs, S, n * k)          # the S slabs are added by the optimiser's first pass (deferred_grad_finishes)
-            return torch.empty(n, k, dtype=torch.float32, device=g.device)
+            return _register_parts(param, slabs, S, n * k)   # the S slabs are added by the optimiser's first pass (deferred_grad_finishes)
         return slab_sum(slabs)   # ours, not torch's sum(0)
     return g.t().mm(x)
 
@@ -322,6 +365,7 @@ class _NarrowLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
+        _gradient_arriving(weight)
         gy = _f32c(gy)
         gx = gy.mm(weight) if ctx.needs_input_grad[0] else None
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
@@ -520,6 +564,7 @@ class _MlpChain(torch.autograd.Function):
         L = len(spec)
         saved = ctx.saved_tensors
         acts, params = saved[:L + 1], saved[L + 1:L + 1 + 2 * L]
+        _gradient_arriving(*params)
         w0p = saved[-1] if kpad else None
         g = _rows2d(gy)
         act_top, alpha_top = spec[-1]

@@ -101,7 +101,6 @@ class OnPolicyRunner:
         self.use_fused_policy = on_gpu and os.environ.get("QA_FUSED_POLICY", "1") != "0"
         self.use_hybrid_act = os.environ.get("QA_TSC_HYBRID_ACT", "1") != "0"      # sampling + log-probs + storage rows + action history: qa_rollout_act_hybrid
         env.sync_reset_ids = False              # rollouts never wait for the GPU
-        env.want_delta_yaw_ok = self.if_depth   # infos["delta_yaw_ok"] is the student's (learn_vision); the teacher's rollout never reads it
 
     # ------------------------------------------------------------------ the frozen behaviour policy: one launch per env step
     def _behaviour_policy(self):
@@ -247,6 +246,18 @@ class OnPolicyRunner:
         return z
 
     def _collect(self, hist_encoding, logging):
+        """`_collect_rollout` with extras['delta_yaw_ok'] switched off for its duration only: the flag is the student's (learn_vision), the
+        teacher's rollout never reads it (two launches per env step), and every other user of the same env -- play / eval scripts, a student
+        runner built later -- keeps getting the tensor the reference always provides."""
+        env = self.env
+        prev = getattr(env, "want_delta_yaw_ok", True)
+        env.want_delta_yaw_ok = False
+        try:
+            return self._collect_rollout(hist_encoding, logging)
+        finally:
+            env.want_delta_yaw_ok = prev
+
+    def _collect_rollout(self, hist_encoding, logging):
         """One rollout.  On the GPU the 24 steps are recorded into ONE hipGraph per actor variant (privileged / history encoder) the
         first time they run and replayed afterwards: an eager step is ~180 launches and 1.8 ms of host time against 0.3 ms of kernels.
         What makes the replays differ from each other lives on the device: the step counter that keys the env's draws and gates the
@@ -417,17 +428,28 @@ class OnPolicyRunner:
         tot_iter = self.current_learning_iteration + num_learning_iterations
         n_aux, n_pro, nd = self.n_auxiliary, self.n_proprio, self.num_actions_d
         yaw_sl, type_sl = slice(n_pro - n_aux, n_pro - n_aux + self.n_delta_yaw), slice(n_pro - n_aux + self.n_delta_yaw, n_pro)
-        action_student_history_buf = torch.zeros(env.num_envs, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev)
-        obs, obs_bbc = env.get_observations(), env.get_observations_bbc().clone()
-        # r5: what the env half of a step carries from one step to the next, in place (`_vision_env_step`)
+        obs = env.get_observations()
+        # r5: what the env half of a step carries from one step to the next, in place (`_vision_env_step`).  The recorded env steps hold the
+        # ADDRESSES of these tensors, so they are allocated once per runner and re-initialised in place when learn_vision() is entered again
+        # (rebinding them to fresh tensors left the replays reading the first call's action history -- the student's commands
+        # never reached the env from the second call on -- and writing into freed blocks)
         vs = getattr(self, "_vs", None)
         if vs is None:
             vs = self._vs = dict(graphs={}, warm=set(), yaw_ok=torch.ones(env.num_envs, dtype=torch.bool, device=dev),
-                                 done=torch.zeros(env.num_envs, dtype=torch.bool, device=dev))
-        vs["ahist"], vs["obs_bbc"] = action_student_history_buf, obs_bbc
+                                 done=torch.zeros(env.num_envs, dtype=torch.bool, device=dev),
+                                 ahist=torch.zeros(env.num_envs, env.cfg.domain_rand.action_buf_len, self.num_actions, device=dev),
+                                 obs_bbc=env.get_observations_bbc().clone())
+        else:
+            with torch.no_grad():
+                vs["ahist"].zero_()
+                vs["obs_bbc"].copy_(env.get_observations_bbc())
+                vs["yaw_ok"].fill_(True); vs["done"].fill_(False)
         infos = {"depth": env.depth_buffer[:, -1].clone(), "delta_yaw_ok": torch.ones(env.num_envs, dtype=torch.bool, device=dev)}
         alg.depth_encoder.train(); alg.depth_actor.train()
         vs["bbc"] = self._behaviour_policy()
+        bbc_key = self._bbc_chain if self._bbc_chain is not None else self.actor_critic_bbc
+        if vs.get("bbc_key") is not bbc_key:         # another behaviour policy object (load_bbc): the recorded steps call the old one
+            vs["bbc_key"], vs["graphs"], vs["warm"] = bbc_key, {}, set()
         n_cmd = 6 + env.dim_c
         keys = ("rew", "len")
         buffers = {k: deque(maxlen=1000) for k in keys}
@@ -601,6 +623,8 @@ class OnPolicyRunner:
         self.discriminator.normalizer = TorchNormalizer.from_reference(n, self.device) if torch.device(self.device).type == "cuda" else n
         self._bbc_chain = None
         self._rollout_graphs = {}                # recorded rollouts hold the old packed weights and normaliser
+        if getattr(self, "_vs", None) is not None:   # and so do the student's recorded env steps
+            self._vs["graphs"], self._vs["warm"] = {}, set()
 
     def get_inference_policy_bbc(self, device=None):
         self.alg.actor_critic_bbc.eval()

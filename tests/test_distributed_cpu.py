@@ -165,3 +165,33 @@ def test_two_rank_task_level_training_keeps_replicas_identical():
     var = ((ss0 + ss1) - n * mean * mean) / (n - 1)
     assert abs(mean) < 1e-4 and abs(var - 1.0) < 1e-3
     assert not np.allclose(pos0, pos1)
+
+
+def test_bench_launches_its_own_ranks():
+    """the driver runs `python bench.py --gpus N ...` with no launcher around it; bench.py must start the N ranks itself
+    (one process per GPU under torch.distributed.run on 127.0.0.1) and rank 0 must print the one JSON line.  --launch_check is that plumbing
+    without a GPU: launch, rendezvous over gloo, one line.  (The reference has no multi-GPU launcher to mirror: `--horovod` is parsed and
+    never read, bbc/legged_gym/utils/helpers.py:183.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch_check"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[-1])
+    assert d["launch_check"] and d["n_gpus"] == 2 and d["ranks"] == 2 and len(set(d["pids"])) == 2 and d["launcher"] == "bench.py self-launch"
+    assert r.stdout.rstrip().splitlines()[-1] == lines[-1]           # the JSON line is the LAST line of stdout
+
+
+def test_bench_refuses_more_gpus_than_the_box_has_with_a_reason():
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("a box with 64 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QA_BENCH_SHARED_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "QA_BENCH_SHARED_GPU" in r.stderr and "GPU(s)" in r.stderr and not r.stdout.strip()

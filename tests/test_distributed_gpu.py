@@ -125,3 +125,20 @@ def test_task_level_two_ranks_on_one_gpu_keep_replicas_identical(vision):
     if not vision:
         assert g0 and g1                               # the update really ran as two graphs around the all-reduce
     assert not np.allclose(pos0, pos1)
+
+
+def test_bench_gpus_2_runs_without_a_launcher_on_the_shared_gpu_harness():
+    """`python bench.py --gpus 2` exactly as the driver types it, on a one-GPU box with QA_BENCH_SHARED_GPU=1: bench.py starts
+    its two ranks, they share cuda:0 and move the buckets over gloo, rank 0 prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["QA_BENCH_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--num_envs", "512", "--no_cpu_baseline"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ranks"] == 2 and d["n_gpus"] == 1 and "shared_gpu_harness" in d and d["config"]["num_envs_per_gpu"] == 256 and d["config"]["num_envs_total"] == 512
+    assert d["collective"].startswith("gloo") and d["value"] > 0 and d["scaling"] == "strong"

@@ -124,3 +124,66 @@ def test_flush_finishes_gradients_for_readers_other_than_the_optimiser():
     ref(x).backward(gy)
     for p, q in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=2e-4 * q.grad.abs().max().item())
+
+
+def _twice_nets():
+    torch.manual_seed(2)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(64, 512), torch.nn.ELU(), torch.nn.Linear(512, 64), torch.nn.ELU()).cuda()
+    net, ref = mk(), mk()
+    ref.load_state_dict(net.state_dict())
+    return net, ref
+
+
+def _close_grads(net, ref):
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+        assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=2e-4 * q.grad.abs().max().item()), (p.shape, (p.grad - q.grad).abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_a_module_used_twice_in_one_backward_keeps_both_gradients(side_stream):
+    """the privileged encoder runs twice in a PPO minibatch step (`train_with_estimated_latent`: once for the regulariser, once
+    inside the actor; gail.py:341-349 in the reference, where both terms reach its parameters).  The first backward node leaves its
+    gradient in parts; the second arrival must find a FINISHED first gradient to be added to."""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    net, ref = _twice_nets()
+    x1 = torch.randn(8192, 64, device="cuda"); x2 = torch.randn(8192, 64, device="cuda")
+    g1 = torch.randn(8192, 64, device="cuda"); g2 = torch.randn(8192, 64, device="cuda") * 0.3
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if side_stream else cur
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        y1 = fused.mlp_forward(net, x1)          # like the step's small-nets branch: forward (and therefore backward) on another stream
+    y2 = fused.mlp_forward(net, x2)
+    cur.wait_stream(side)
+    with fused.deferred_grad_finishes():
+        torch.autograd.backward([y1, y2], [g1, g2])
+    assert fused.pending_grads() == 0, "a parameter with two gradients must not stay in parts"
+    torch.autograd.backward([ref(x1), ref(x2)], [g1, g2])
+    torch.cuda.synchronize()
+    _close_grads(net, ref)
+    # and the optimiser step that follows sees finished gradients (nothing left for qa_clip_adam_step_reduce to overwrite them with)
+    fused.flush_pending_grads()
+    _close_grads(net, ref)
+
+
+@pytest.mark.gpu
+def test_gradient_accumulation_over_backward_calls_and_preexisting_grads():
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    net, ref = _twice_nets()
+    xs = [torch.randn(8192, 64, device="cuda") for _ in range(3)]
+    gs = [torch.randn(8192, 64, device="cuda") for _ in range(3)]
+    for x, g in zip(xs, gs):          # three backward calls, no zero_grad between them: the first may defer, the later ones add to `.grad`
+        with fused.deferred_grad_finishes():
+            fused.mlp_forward(net, x).backward(g)
+        ref(x).backward(g)
+    fused.flush_pending_grads()
+    torch.cuda.synchronize()
+    _close_grads(net, ref)
+    # a gradient that exists BEFORE the step (never deferred: autograd adds to it in place)
+    with fused.deferred_grad_finishes():
+        fused.mlp_forward(net, xs[0]).backward(gs[1])
+    assert fused.pending_grads() == 0
+    ref(xs[0]).backward(gs[1])
+    _close_grads(net, ref)

@@ -336,8 +336,12 @@ def test_learn_vision_runs_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_recorded_vision_env_step_equals_the_eager_one(tmp_path, monkeypatch):
-    """r5: the env half of a `learn_vision` step (set_commands -> behaviour policy -> env.step -> next behaviour observation, action-history
+@pytest.mark.parametrize("calls", [(3,), (2, 1, 1)])
+def test_recorded_vision_env_step_equals_the_eager_one(tmp_path, monkeypatch, calls):
+    """(`calls` = (2, 1, 1), ADVICE r5: learn() entered three times, as bench.py --tsc --vision and a resumed training do -- the replays of the
+    later calls must read the action history and behaviour observation THAT call uses, i.e. the persistent ones.)
+
+    r5: the env half of a `learn_vision` step (set_commands -> behaviour policy -> env.step -> next behaviour observation, action-history
     restart) is recorded once per camera phase and replayed (`OnPolicyRunner._vision_env_step`); the student's networks stay eager.  Same seeds,
     3 iterations x 24 steps, depth.update_interval 2 (both camera phases recorded and replayed many times): the robots' state, the depth images and the
     student's weights after the third update must equal the all-eager run's (env state and images bit for bit; the weights to 1e-6: the
@@ -353,7 +357,8 @@ def test_recorded_vision_env_step_equals_the_eager_one(tmp_path, monkeypatch):
         env = lr.LeggedRobot(cfg, sim_device="cuda:0")
         runner = _vision_runner(env, tmp_path / mode, "cuda:0", steps=24)
         runner.log_dir = None                                   # no logging: the bench's mode
-        runner.learn(3)
+        for n in calls:
+            runner.learn(n)
         torch.cuda.synchronize()
         if mode == "1":
             g = runner._vs["graphs"]
