@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 6: the GPU calls as they were run, one case per call (gpurun -- 'bash tools/r6_call.sh <case>').  Outputs under gpurun_out/r6/<case>/.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+C=${1:-none}
+O=$R/gpurun_out/r6/$C
+mkdir -p $O
+cd $R
+line() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read()); print(f.split("/")[-1], round(d["ms_per_step"], 2), "ms; rollout", round((d.get("collection_s") or 0) * 1e3, 2), "update", round((d.get("learn_s") or 0) * 1e3, 2), "value", round(d["value"]))
+    except Exception as e: print(f, "no line", e)
+PY
+}
+case $C in
+base)      # the ADVICE r5 fixes (second gradient of a parameter in parts, learn_vision entered twice), bench.py launching its own ranks, then the whole suite and the default line
+    timeout 900 python -m pytest tests/test_grad_parts.py tests/test_distributed_gpu.py -m gpu -x -q > $O/pytest_new.log 2>&1; tail -4 $O/pytest_new.log
+    timeout 900 python -m pytest tests/test_tsc_depth.py -m gpu -x -q -k "recorded_vision" > $O/pytest_vision.log 2>&1; tail -4 $O/pytest_vision.log
+    timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
+    timeout 600 python bench.py 2> $O/bench.err < /dev/null | grep '"metric"' > $O/bench_default.json; cut -c1-300 $O/bench_default.json
+    QA_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --no_cpu_baseline 2> $O/bench_gpus2.err < /dev/null | grep '"metric"' > $O/bench_gpus2_shared.json; cut -c1-300 $O/bench_gpus2_shared.json
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    ;;
+*) echo "unknown case $C"; exit 2;;
+esac
+ls -la $O
