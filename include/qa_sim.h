@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 16
+#define QA_ABI_VERSION 17
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -468,6 +468,10 @@ int64_t qa_linear_forward_split_scratch_bytes(int64_t rows, int32_t in_features,
 int qa_linear_forward_split(const float *x, int64_t ldx, const float *weight, int64_t ldw, const float *bias, float *y, int64_t ldy, int64_t rows,
                             int32_t in_features, int32_t out_features, int32_t act, float alpha, void *scratch, int64_t scratch_bytes, void *stream);
 int64_t qa_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features);
+/* ABI 17: qa_linear_backward_weight with grad_weight == NULL and grad_bias == NULL leaves the gradient IN PARTS in `scratch` (no reduction
+ * launch): layout[0] weight parts, each in_features * out_features floats, layout[1] floats apart, from scratch + 0; layout[2] bias parts, each
+ * out_features floats, layout[3] floats apart, from scratch + layout[4] floats -- what qa_clip_adam_step_reduce / qa_grad_reduce add in order. */
+int qa_linear_backward_weight_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]);
 int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
                               int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream);
 
@@ -713,11 +717,28 @@ int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
  * library GEMM, so results agree with torch to rounding, not bit for bit).
  * qa_mlp_pack repacks the layers' weights into `packed` (w_off / b_off: float offsets chosen by the caller, w_off a
  * multiple of 4; qa_mlp_packed_floats gives the size the chosen offsets need); it must be re-run after the weights change.
- * weights[i] / biases[i] are DEVICE pointers for op i (ignored for copies; a NULL bias is zero). */
+ * weights[i] / biases[i] are DEVICE pointers for op i (ignored for copies; a NULL bias is zero).
+ * ABI 17 -- the same launch as the two chain halves of a TRAINING step (bbc/rsl_rl/algorithms/gail.py:328-413 through
+ * autograd: the forward of every network of a PPO minibatch step, then the input-gradient path):
+ *   QA_MLP_F_SAVE        the op's result ALSO goes to outs[out_index][:, out_col : out_col+n] (layers into a scratch buffer, copies): the
+ *                        activations the backward pass and the weight-gradient GEMMs read.  Every global write starts at column out_col.
+ *   QA_MLP_F_TRANSPOSED  the matrix handed to qa_mlp_pack for this op is the FORWARD layer's own (k, n) row-major weight; the op
+ *                        multiplies by its transpose: gx = g W (an input-gradient layer; give it a NULL bias).
+ *   act 4 / 5 / 6        the product is SCALED by the derivative of ELU(alpha 1) / ReLU / tanh taken from the forward layer's saved
+ *                        output y = outs[aux_index][:, aux_col : aux_col+n] (y > 0 ? 1 : y + 1;  y > 0;  1 - y^2) -- the elementwise half of
+ *                        the layer below's backward, in this layer's epilogue.  `outs[aux_index]` is only read.
+ *   QA_MLP_GRAD          elementwise: dst[:, dst_col : +n] = (src[:, src_col : +n] (+ dst with QA_MLP_F_ADD)) * act'(y) with act 0 (no
+ *                        factor) or 4..6; QA_MLP_F_SAVE as above.  Where two gradients meet at an activation (the privileged encoder's output
+ *                        feeds the actor AND the regulariser).
+ * Ops written before ABI 17 (new fields zero) mean what they meant. */
 #define QA_MLP_COPY 0
 #define QA_MLP_LAYER 1
+#define QA_MLP_GRAD 2
+#define QA_MLP_F_SAVE 1
+#define QA_MLP_F_TRANSPOSED 2
+#define QA_MLP_F_ADD 4
 #define QA_MLP_MAX_OPS 24
-#define QA_MLP_MAX_OUTPUTS 4
+#define QA_MLP_MAX_OUTPUTS 8      /* ABI 17 (4 before) */
 #define QA_MLP_BUF0_COLS 800      /* the task-level policy's 800-wide observation row (ABI 13; 672 before) */
 #define QA_MLP_BUF1_COLS 576
 #define QA_MLP_BUF2_COLS 320
@@ -729,8 +750,11 @@ typedef struct qa_mlp_op {
     int32_t k, n;
     int32_t act;
     int32_t out_index;
-    int32_t reserved;
+    int32_t flags;                         /* QA_MLP_F_* (ABI 17; `reserved`, zero, before) */
     int64_t w_off, b_off;
+    int32_t out_col;                       /* ABI 17: first column of outs[out_index] the op writes */
+    int32_t aux_index, aux_col;            /* ABI 17: act 4..6: the saved activation */
+    int32_t pad_;
 } qa_mlp_op;
 int64_t qa_mlp_packed_floats(const qa_mlp_op *ops, int32_t num_ops);
 int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weights, const float *const *biases, float *packed,

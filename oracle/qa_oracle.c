@@ -1567,11 +1567,24 @@ int qo_linear_backward_input(const float *grad_out, int64_t ldg, const float *we
     return QA_OK;
 }
 int64_t qo_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
-    return (rows <= 0 || in_features <= 0 || out_features <= 0) ? 0 : 16;
+    return (rows <= 0 || in_features <= 0 || out_features <= 0) ? 0 : 16 + 4 * ((int64_t)in_features * out_features + out_features + 8);
+}
+/* twin of qa_linear_backward_weight_layout (ABI 17): the twin's "parts" are ONE finished weight gradient and ONE finished bias gradient */
+int qo_linear_backward_weight_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]) {
+    if (!layout || rows <= 0 || in_features <= 0 || out_features <= 0) return QA_E_ARG;
+    const int64_t nw = ((int64_t)in_features * out_features + 3) & ~(int64_t)3;
+    layout[0] = 1; layout[1] = nw; layout[2] = 1; layout[3] = (out_features + 3) & ~3; layout[4] = nw;
+    return QA_OK;
 }
 int qo_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
                               int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream) {
-    (void)scratch; (void)scratch_bytes; (void)stream;
+    (void)stream;
+    if (!grad_weight && !grad_bias) {          /* ABI 17: in parts, inside `scratch` (qo_linear_backward_weight_layout) */
+        int64_t lay[5];
+        if (!scratch || qo_linear_backward_weight_layout(rows, in_features, out_features, lay) != QA_OK ||
+            scratch_bytes < qo_linear_backward_weight_scratch_bytes(rows, in_features, out_features)) return QA_E_ARG;
+        grad_weight = (float *)scratch; grad_bias = (float *)scratch + lay[4];
+    }
     if (!grad_out || !x || !grad_weight || !grad_bias || rows <= 0 || in_features <= 0 || out_features <= 0 || ldg < out_features || ldx < in_features)
         return QA_E_ARG;
 #pragma omp parallel for
@@ -2311,7 +2324,11 @@ int qo_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weigh
     for (int i = 0; i < num_ops; ++i) {
         if (ops[i].kind != QA_MLP_LAYER) continue;
         if (!weights[i]) return QA_E_ARG;
-        memcpy(packed + ops[i].w_off, weights[i], sizeof(float) * (size_t)ops[i].n * (size_t)ops[i].k);
+        if (ops[i].flags & QA_MLP_F_TRANSPOSED) {         /* the forward layer's (k, n) matrix, used transposed: keep (n, k) row-major here */
+            for (int r = 0; r < ops[i].n; ++r)
+                for (int c = 0; c < ops[i].k; ++c) packed[ops[i].w_off + (int64_t)r * ops[i].k + c] = weights[i][(int64_t)c * ops[i].n + r];
+        } else
+            memcpy(packed + ops[i].w_off, weights[i], sizeof(float) * (size_t)ops[i].n * (size_t)ops[i].k);
         for (int c = 0; c < ops[i].n; ++c) packed[ops[i].b_off + c] = biases[i] ? biases[i][c] : 0.0f;
     }
     return QA_OK;
@@ -2430,9 +2447,24 @@ int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
         for (int i = 0; i < num_ops; ++i) {
             const qa_mlp_op *o = &ops[i];
             if (o->src_buf < 0 || o->src_buf > 3 || o->dst_buf > 3 || o->n <= 0) { rc = QA_E_ARG; break; }
-            if (o->kind == QA_MLP_COPY) {
-                if (o->dst_buf < 1 || o->src_col + o->n > cols[o->src_buf] || o->dst_col + o->n > cols[o->dst_buf]) { rc = QA_E_ARG; break; }
-                memmove(buf[o->dst_buf] + o->dst_col, buf[o->src_buf] + o->src_col, sizeof(float) * (size_t)o->n);
+            const int save = (o->flags & QA_MLP_F_SAVE) != 0;
+            if (save && (o->out_index < 0 || o->out_index >= num_outs || !outs || !outs[o->out_index] || out_strides[o->out_index] < o->out_col + o->n)) { rc = QA_E_ARG; break; }
+            const int deriv = (o->kind == QA_MLP_LAYER || o->kind == QA_MLP_GRAD) && o->act >= 4;
+            if (deriv && (o->act > 6 || o->aux_index < 0 || o->aux_index >= num_outs || !outs || !outs[o->aux_index] || out_strides[o->aux_index] < o->aux_col + o->n)) { rc = QA_E_ARG; break; }
+            const float *ysaved = deriv ? outs[o->aux_index] + r * out_strides[o->aux_index] + o->aux_col : NULL;
+            if (o->kind == QA_MLP_COPY || o->kind == QA_MLP_GRAD) {       /* ABI 17: QA_MLP_GRAD = copy (+ dst) x act'(saved y) */
+                if (o->dst_buf < 1 || o->src_col + o->n > cols[o->src_buf] || o->dst_col + o->n > cols[o->dst_buf] ||
+                    (o->kind == QA_MLP_GRAD && o->act != 0 && !deriv)) { rc = QA_E_ARG; break; }
+                if (o->kind == QA_MLP_COPY) memmove(buf[o->dst_buf] + o->dst_col, buf[o->src_buf] + o->src_col, sizeof(float) * (size_t)o->n);
+                else
+                    for (int c = 0; c < o->n; ++c) {
+                        double v = buf[o->src_buf][o->src_col + c];
+                        if (o->flags & QA_MLP_F_ADD) v = (double)(float)v + (double)buf[o->dst_buf][o->dst_col + c];
+                        float f = (float)v;
+                        if (deriv) { const float y = ysaved[c]; f *= o->act == 4 ? (y > 0.0f ? 1.0f : y + 1.0f) : o->act == 5 ? (y > 0.0f ? 1.0f : 0.0f) : (1.0f - y * y); }
+                        buf[o->dst_buf][o->dst_col + c] = f;
+                    }
+                if (save) memcpy(outs[o->out_index] + r * out_strides[o->out_index] + o->out_col, buf[o->dst_buf] + o->dst_col, sizeof(float) * (size_t)o->n);
                 continue;
             }
             if (o->kind != QA_MLP_LAYER || o->src_col + o->k > cols[o->src_buf] || o->dst_buf == o->src_buf || o->dst_buf == 0 ||
@@ -2446,8 +2478,9 @@ int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
                 if (o->act == 1) v = v > 0.0f ? v : (float)(exp((double)v) - 1.0);
                 else if (o->act == 2) v = v > 0.0f ? v : 0.0f;
                 else if (o->act == 3) v = (float)tanh((double)v);
+                else if (deriv) { const float y = ysaved[c]; v = (float)(acc * (o->act == 4 ? (y > 0.0f ? 1.0 : (double)y + 1.0) : o->act == 5 ? (y > 0.0f ? 1.0 : 0.0) : 1.0 - (double)y * y)); }
                 if (o->dst_buf > 0) buf[o->dst_buf][o->dst_col + c] = v;
-                else outs[o->out_index][r * out_strides[o->out_index] + c] = v;
+                if (o->dst_buf < 0 || save) outs[o->out_index][r * out_strides[o->out_index] + o->out_col + c] = v;
             }
         }
     }

@@ -6,7 +6,7 @@ __graft_entry__.build()).  It never falls back to a CPU path: a missing library 
 import ctypes as C
 import os
 
-QA_ABI_VERSION = 16
+QA_ABI_VERSION = 17
 NUM_DOF = 12
 NUM_GAITS = 5
 NUM_PROP = 57
@@ -190,6 +190,7 @@ def bind(lib, prefix):
     f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
     f.restype = C.c_int
     f = getattr(lib, prefix + "linear_backward_weight_scratch_bytes"); f.argtypes = [C.c_int64, C.c_int32, C.c_int32]; f.restype = C.c_int64
+    f = getattr(lib, prefix + "linear_backward_weight_layout"); f.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "linear_backward_weight")
     f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
@@ -216,11 +217,13 @@ def bind(lib, prefix):
 class QaMlpOp(C.Structure):
     """qa_mlp_op of include/qa_sim.h"""
     _fields_ = [("kind", C.c_int32), ("src_buf", C.c_int32), ("src_col", C.c_int32), ("dst_buf", C.c_int32), ("dst_col", C.c_int32),
-                ("k", C.c_int32), ("n", C.c_int32), ("act", C.c_int32), ("out_index", C.c_int32), ("reserved", C.c_int32),
-                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+                ("k", C.c_int32), ("n", C.c_int32), ("act", C.c_int32), ("out_index", C.c_int32), ("flags", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64), ("out_col", C.c_int32), ("aux_index", C.c_int32), ("aux_col", C.c_int32), ("pad_", C.c_int32)]
 
 
-MLP_COPY, MLP_LAYER, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 24, 4
+MLP_COPY, MLP_LAYER, MLP_GRAD, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 2, 24, 8
+MLP_F_SAVE, MLP_F_TRANSPOSED, MLP_F_ADD = 1, 2, 4
+MLP_ACT_ELU_GRAD, MLP_ACT_RELU_GRAD, MLP_ACT_TANH_GRAD = 4, 5, 6
 MLP_BUF_COLS = (800, 576, 320, 128)
 
 TSC_REWARD_NAMES = ("action_hl_rate", "collision", "feet_edge", "latent_c_rate", "reach_goal", "tracking_goal_vel", "tracking_yaw",
@@ -295,7 +298,7 @@ class QaTscDepthIo(C.Structure):
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "tsc_reset_dev", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "hybrid_ppo_loss", "hybrid_ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "grad_reduce", "rollout_act", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "grad_reduce", "rollout_act", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
 
 _LIB = None
 # QA_LIB: another build of the SAME library (A/B measurements of a kernel variant, tools/r5_call.sh); there is still no fallback -- a missing file raises

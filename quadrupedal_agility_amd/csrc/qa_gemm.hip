@@ -924,9 +924,19 @@ int64_t qa_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_feature
     return (int64_t)s * (pad4((int64_t)in_features * out_features) + na * pad4(out_features)) * 4;
 }
 
+int qa_linear_backward_weight_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]) {
+    if (!layout || rows <= 0 || in_features <= 0 || out_features <= 0) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight_layout: bad argument"); return QA_E_ARG; }
+    int cfg, s, kps; wgrad_plan(rows, in_features, out_features, &cfg, &s, &kps);
+    int ba, bb; tile_dims(cfg, &ba, &bb);
+    const int64_t na = (in_features + ba - 1) / ba;
+    layout[0] = s; layout[1] = pad4((int64_t)in_features * out_features); layout[2] = s * na; layout[3] = pad4(out_features); layout[4] = (int64_t)s * layout[1];
+    return QA_OK;
+}
+
 int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
                               int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream) {
-    if (!grad_out || !x || !grad_weight || !grad_bias || !scratch || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 ||
+    const bool parts_only = !grad_weight && !grad_bias;          // ABI 17: the slabs stay in `scratch` (qa_linear_backward_weight_layout)
+    if (!grad_out || !x || (!parts_only && (!grad_weight || !grad_bias)) || !scratch || rows <= 0 || rows > INT32_MAX || in_features <= 0 || out_features <= 0 ||
         ldg < out_features || ldx < in_features) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: bad argument"); return QA_E_ARG; }
     if (!fits_u32(rows, ldg) || !fits_u32(rows, ldx)) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: rows * ldg (or rows * ldx) >= 2^32 elements"); return QA_E_ARG; }
     if (scratch_bytes < qa_linear_backward_weight_scratch_bytes(rows, in_features, out_features) || !aligned16(scratch)) {
@@ -947,8 +957,9 @@ int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
     hipStream_t st = (hipStream_t)stream;
     gemm_launch<true, true, 0, true>(cfg, g, st);
     const int64_t nthreads = (n_w + 3) / 4 + (out_features + 3) / 4;
-    hipLaunchKernelGGL(qa_slab_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, (const float *)scratch, n_w_pad, s, n_w,
-                       (const float *)bslabs, n_b_pad, (int)(s * na), (int64_t)out_features, grad_weight, grad_bias, aligned16(grad_weight) ? 4 : 1);
+    if (!parts_only)
+        hipLaunchKernelGGL(qa_slab_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, (const float *)scratch, n_w_pad, s, n_w,
+                           (const float *)bslabs, n_b_pad, (int)(s * na), (int64_t)out_features, grad_weight, grad_bias, aligned16(grad_weight) ? 4 : 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

@@ -51,7 +51,8 @@ __host__ __device__ constexpr int mlp_kb(int k, int n) { return ((k + 15) / 16 +
 struct MlpDevOp {
     int32_t kind, src_buf, src_col, dst_buf, dst_col, k, n, act, out_index, nt, kb, tpw;
     int64_t w_off, b_off;
-    int32_t strand, pad_;       /* which workgroup of a tile's group runs the op (blockIdx.y); see mlp_strands */
+    int32_t strand, flags;      /* strand: which workgroup of a tile's group runs the op (blockIdx.y), see mlp_strands; flags: QA_MLP_F_* */
+    int32_t out_col, aux_index, aux_col, pad_;      /* ABI 17: first column of the global output; the saved activation an act >= 4 reads */
 };
 
 struct MlpArgs {
@@ -67,7 +68,7 @@ struct MlpArgs {
     int32_t g_base[2][MLP_NBUF], g_stride[2][MLP_NBUF], g_lds_floats, g_scratch0;
 };
 
-struct PackLayer { const float *w, *b; int32_t n, k; int64_t w_off, b_off; };
+struct PackLayer { const float *w, *b; int32_t n, k; int64_t w_off, b_off; int32_t trans, pad_; };
 struct PackArgs { PackLayer l[QA_MLP_MAX_OPS]; int32_t num; float *packed; };
 
 /* packed[w_off + ((j * nt + t) * 64 + lane) * 4 + s] = W[16 t + lane % 16][16 j + 4 (lane / 16) + s], zero outside (n, k) */
@@ -80,7 +81,8 @@ __global__ void qa_mlp_pack_kernel(PackArgs a) {
         const int64_t jt = i >> 8;
         const int t = (int)(jt % nt), j = (int)(jt / nt);
         const int row = 16 * t + (lane & 15), col = 16 * j + 4 * (lane >> 4) + s;
-        a.packed[L.w_off + i] = (row < L.n && col < L.k) ? L.w[(int64_t)row * L.k + col] : 0.f;
+        /* trans (QA_MLP_F_TRANSPOSED): the source is the FORWARD layer's (k, n) row-major matrix, this op multiplies by its transpose */
+        a.packed[L.w_off + i] = (row < L.n && col < L.k) ? (L.trans ? L.w[(int64_t)col * L.n + row] : L.w[(int64_t)row * L.k + col]) : 0.f;
     }
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nt * 16; i += blockDim.x) a.packed[L.b_off + i] = (i < L.n && L.b) ? L.b[i] : 0.f;
@@ -89,13 +91,20 @@ __global__ void qa_mlp_pack_kernel(PackArgs a) {
 /* ELU(alpha 1).  __expf = v_exp_f32(v * log2 e), 2 instructions, relative error ~2^-22 of exp(v) <= 1: the same size as
  * the rounding noise of the fp32 dot product in front of it; expf() is ~35 instructions x 16 values per lane per wide layer */
 __device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : __expf(v) - 1.f; }
+/* epilogue of a layer: bias, then the activation (act 1..3) or, on input-gradient chains, the DERIVATIVE of the forward layer's activation taken
+ * from its saved output y (act 4: ELU, y > 0 ? 1 : y + 1; 5: ReLU; 6: tanh, 1 - y^2) */
+__device__ __forceinline__ float mlp_act(int act, float v, float y) {
+    return act == 0 ? v : act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : act == 3 ? tanhf(v) :
+           act == 4 ? v * (y > 0.f ? 1.f : y + 1.f) : act == 5 ? (y > 0.f ? v : 0.f) : v * (1.f - y * y);
+}
 
 /* one layer for this wavefront: TPW column tiles starting at tile t0.
  * The weight fragments are fetched PF-1 k-blocks ahead of their use into a ring of PF register stages (the L2 round trip is
  * several hundred cycles; one k-block of MFMAs is 128 * TPW cycles).  The sched_barriers keep the compiler from sinking the
  * prefetch back down to its use, which it otherwise does to shorten live ranges. */
 struct MlpPlace { int src_base, src_stride, dst_base, dst_stride; };      /* where the op's source / destination buffers are in LDS (floats) */
-template <int TPW, int PF = mlp_pf(TPW)>
+/* EXT: the ABI 17 features (saved copies, derivative epilogues); the rollout's launches compile without them */
+template <int TPW, int PF = mlp_pf(TPW), bool EXT = false>
 __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packed, float *lds, const MlpArgs &a, int row0, int wave, int lane, const MlpPlace pl) {
     const int nt = op.nt, kb = op.kb;
     const int t0 = wave * TPW;
@@ -113,6 +122,29 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
     float bias[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) bias[i] = packed[op.b_off + (toff[i] >> 2) + m];       /* padded to whole tiles by qa_mlp_pack */
+    /* (issued before the k-loop: the round trip of these loads hides behind the layer's MFMAs) */
+    const int act = op.act;
+    const int live = a.rows - (row0 + 4 * kq);              /* rows of this lane's group of 4 that exist */
+    float yv[TPW][4];
+    if (EXT && act >= 4) {         /* the saved forward activation whose derivative scales the product (rows beyond the batch: the last row's, unused) */
+        const int64_t as = a.out_stride[op.aux_index];
+        const float *y = a.out[op.aux_index] + op.aux_col + m;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int col = (t0 + i < nt ? t0 + i : nt - 1) * 16;
+            const bool in = col + m < op.n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * kq + r;
+                yv[i][r] = in ? y[(int64_t)(row < a.rows ? row : a.rows - 1) * as + col] : 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[i][r] = 0.f;
+    }
     f4 bw[PF][TPW], av[PF];
 #pragma unroll
     for (int u = 0; u < PF - 1; ++u) {
@@ -149,36 +181,39 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
         }
     }
     /* D layout: register r of lane l = D[row 4 (l / 16) + r][column l % 16].  Destination resolved once per layer. */
-    const int act = op.act;
-    if (op.dst_buf >= 0) {
-        const int ds = pl.dst_stride;
-        float *d = lds + pl.dst_base + (4 * kq) * ds + op.dst_col + m;
+    const bool to_global = op.dst_buf < 0 || (EXT && (op.flags & QA_MLP_F_SAVE));
+    const int64_t os = to_global ? a.out_stride[op.out_index] : 0;
+    float *g = to_global ? a.out[op.out_index] + (int64_t)(row0 + 4 * kq) * os + op.out_col + m : nullptr;
+    const int ds = pl.dst_stride;
+    float *d = op.dst_buf >= 0 ? lds + pl.dst_base + (4 * kq) * ds + op.dst_col + m : nullptr;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int col = (t0 + i) * 16;
-            if (t0 + i < nt && col + m < op.n) {
+    for (int i = 0; i < TPW; ++i) {
+        const int col = (t0 + i) * 16;
+        if (t0 + i < nt && col + m < op.n) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][r] + bias[i];
-                    d[r * ds + col] = act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : act == 3 ? tanhf(v) : v;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float v = mlp_act(EXT ? act : (act > 3 ? 0 : act), acc[i][r] + bias[i], yv[i][r]);
+                if (d) d[r * ds + col] = v;
+                if (g && r < live) g[r * os + col] = v;
             }
         }
-    } else {
-        const int64_t os = a.out_stride[op.out_index];
-        float *g = a.out[op.out_index] + (int64_t)(row0 + 4 * kq) * os + m;
-        const int live = a.rows - (row0 + 4 * kq);          /* rows of this lane's group of 4 that exist */
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int col = (t0 + i) * 16;
-            if (t0 + i < nt && col + m < op.n) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[i][r] + bias[i];
-                    if (r < live) g[r * os + col] = act == 1 ? elu1(v) : act == 2 ? fmaxf(v, 0.f) : act == 3 ? tanhf(v) : v;
-                }
-            }
-        }
+    }
+}
+
+/* QA_MLP_GRAD (ABI 17), elementwise over the tile: v = src (+ dst with QA_MLP_F_ADD), times the activation derivative of `act` (4..6; 0: none)
+ * taken from the saved output; to dst and, with QA_MLP_F_SAVE, to the global output.  QA_MLP_COPY with QA_MLP_F_SAVE writes its copy out too. */
+__device__ __forceinline__ void mlp_elementwise(const MlpDevOp &op, float *lds, const MlpArgs &a, int row0, int tid, int nthreads, const MlpPlace pl) {
+    const bool save = (op.flags & QA_MLP_F_SAVE) != 0, add = op.kind == QA_MLP_GRAD && (op.flags & QA_MLP_F_ADD);
+    const int act = op.kind == QA_MLP_GRAD ? op.act : 0;
+    for (int i = tid; i < MLP_ROWS * op.n; i += nthreads) {
+        const int r = i / op.n, c = i - r * op.n;
+        float v = lds[pl.src_base + r * pl.src_stride + op.src_col + c];
+        float *d = lds + pl.dst_base + r * pl.dst_stride + op.dst_col + c;
+        if (add) v += *d;
+        const bool live = row0 + r < a.rows;
+        if (act >= 4) v = mlp_act(act, v, live ? a.out[op.aux_index][(int64_t)(row0 + r) * a.out_stride[op.aux_index] + op.aux_col + c] : 0.f);
+        *d = v;
+        if (save && live) a.out[op.out_index][(int64_t)(row0 + r) * a.out_stride[op.out_index] + op.out_col + c] = v;
     }
 }
 
@@ -189,6 +224,7 @@ __device__ __forceinline__ void mlp_layer(const MlpDevOp &op, const float *packe
 #define MLP_STAMP(i) do { } while (0)
 #endif
 
+template <bool EXT>
 __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[MLP_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,18 +251,14 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_kernel(MlpArgs 
     for (int o = 0; o < a.num_ops; ++o) {
         const MlpDevOp nxt = a.ops[o + 1 < a.num_ops ? o + 1 : o];      /* scalar loads of the next descriptor fly during this op */
         if (op.strand != strand) { op = nxt; continue; }                  /* workgroup-uniform: another workgroup of this tile runs it */
-        if (op.kind == QA_MLP_COPY) {
-            const int ss = mlp_stride(op.src_buf), ds = mlp_stride(op.dst_buf);
-            for (int i = tid; i < MLP_ROWS * op.n; i += MLP_WAVES * 64) {
-                const int r = i / op.n, c = i - r * op.n;
-                lds[mlp_base(op.dst_buf) + r * ds + op.dst_col + c] = lds[mlp_base(op.src_buf) + r * ss + op.src_col + c];
-            }
+        if (op.kind != QA_MLP_LAYER) {
+            mlp_elementwise(op, lds, a, row0, tid, MLP_WAVES * 64, MlpPlace{mlp_base(op.src_buf), mlp_stride(op.src_buf), mlp_base(op.dst_buf), mlp_stride(op.dst_buf)});
         } else {
             const MlpPlace pl{mlp_base(op.src_buf), mlp_stride(op.src_buf), op.dst_buf >= 0 ? mlp_base(op.dst_buf) : 0, op.dst_buf >= 0 ? mlp_stride(op.dst_buf) : 0};
             switch (op.tpw) {
-                case 1: mlp_layer<1>(op, a.packed, lds, a, row0, wave, lane, pl); break;
-                case 2: mlp_layer<2>(op, a.packed, lds, a, row0, wave, lane, pl); break;
-                default: mlp_layer<4>(op, a.packed, lds, a, row0, wave, lane, pl); break;
+                case 1: mlp_layer<1, mlp_pf(1), EXT>(op, a.packed, lds, a, row0, wave, lane, pl); break;
+                case 2: mlp_layer<2, mlp_pf(2), EXT>(op, a.packed, lds, a, row0, wave, lane, pl); break;
+                default: mlp_layer<4, mlp_pf(4), EXT>(op, a.packed, lds, a, row0, wave, lane, pl); break;
             }
         }
         __syncthreads();
@@ -281,11 +313,8 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void qa_mlp_forward_groups_kernel(M
         const MlpDevOp op = a.ops[o];
         const MlpPlace pl{a.g_base[grp][op.src_buf], a.g_stride[grp][op.src_buf], op.dst_buf >= 0 ? a.g_base[grp][op.dst_buf] : 0,
                           op.dst_buf >= 0 ? a.g_stride[grp][op.dst_buf] : 0};
-        if (op.kind == QA_MLP_COPY) {
-            for (int i = gtid; i < MLP_ROWS * op.n; i += GRP_WAVES * 64) {
-                const int r = i / op.n, c = i - r * op.n;
-                lds[pl.dst_base + r * pl.dst_stride + op.dst_col + c] = lds[pl.src_base + r * pl.src_stride + op.src_col + c];
-            }
+        if (op.kind != QA_MLP_LAYER) {
+            mlp_elementwise(op, lds, a, row0, gtid, GRP_WAVES * 64, pl);
         } else {
             const int per = (op.nt + GRP_WAVES - 1) / GRP_WAVES;      /* column tiles per wave of the group */
             if (per <= 1) mlp_layer<1, 8>(op, a.packed, lds, a, row0, gw, lane, pl);
@@ -319,6 +348,9 @@ int mlp_strands(const qa_mlp_op *ops, int num_ops, int max_strands, int32_t *str
         if (o.src_buf > 0)
             for (int c = o.src_col; c < o.src_col + rd && c < MAXC + 4; ++c)
                 if (last_writer[o.src_buf][c] >= 0) parent[find(i)] = find(last_writer[o.src_buf][c]);
+        if (o.dst_buf > 0 && o.kind == QA_MLP_GRAD && (o.flags & QA_MLP_F_ADD))       /* dst += ...: a read of what was there */
+            for (int c = o.dst_col; c < o.dst_col + o.n && c < MAXC + 4; ++c)
+                if (last_writer[o.dst_buf][c] >= 0) parent[find(i)] = find(last_writer[o.dst_buf][c]);
         if (o.dst_buf > 0)
             for (int c = o.dst_col; c < o.dst_col + o.n && c < MAXC + 4; ++c) last_writer[o.dst_buf][c] = i;
     }
@@ -423,11 +455,15 @@ static int mlp_check(const qa_mlp_op *ops, int32_t num_ops, const char *who) {
     for (int i = 0; i < num_ops; ++i) {
         const qa_mlp_op &o = ops[i];
         const bool layer = o.kind == QA_MLP_LAYER;
-        bool ok = (layer || o.kind == QA_MLP_COPY) && o.src_buf >= 0 && o.src_buf < MLP_NBUF && o.src_col >= 0 && o.n > 0;
+        bool ok = (layer || o.kind == QA_MLP_COPY || o.kind == QA_MLP_GRAD) && o.src_buf >= 0 && o.src_buf < MLP_NBUF && o.src_col >= 0 && o.n > 0 &&
+                  (o.flags & ~(QA_MLP_F_SAVE | QA_MLP_F_TRANSPOSED | QA_MLP_F_ADD)) == 0 && o.out_col >= 0;
+        if (ok && (o.flags & QA_MLP_F_SAVE)) ok = o.out_index >= 0 && o.out_index < QA_MLP_MAX_OUTPUTS;
+        if (ok && ((layer && o.act >= 4) || (o.kind == QA_MLP_GRAD && o.act != 0)))
+            ok = o.act >= 4 && o.act <= 6 && o.aux_index >= 0 && o.aux_index < QA_MLP_MAX_OUTPUTS && o.aux_col >= 0;
         if (ok && layer) {
             const int kpad = mlp_kb(o.k, o.n) * 16;         /* columns the layer reads (beyond k: against zero weights) */
             /* reading past the row's padding lands in the next row / buffer (finite activations, zero weights): allowed while inside LDS */
-            ok = o.k > 0 && o.act >= 0 && o.act <= 3 && (o.src_col % 4) == 0 && o.src_col + o.k <= buf_cols(o.src_buf) + 4 &&
+            ok = o.k > 0 && o.act >= 0 && o.act <= 6 && (o.src_col % 4) == 0 && o.src_col + o.k <= buf_cols(o.src_buf) + 4 &&
                  lds_base(o.src_buf) + (MLP_ROWS - 1) * (buf_cols(o.src_buf) + 4) + o.src_col + kpad <= MLP_LDS_FLOATS && o.w_off >= 0 && o.b_off >= 0 && (o.w_off % 4) == 0 &&
                  (o.n + 15) / 16 <= 4 * MLP_WAVES;
             if (ok && o.dst_buf >= 0) ok = o.dst_buf > 0 && o.dst_buf < MLP_NBUF && o.dst_buf != o.src_buf && o.dst_col >= 0 && o.dst_col + o.n <= buf_cols(o.dst_buf);
@@ -491,7 +527,7 @@ int qa_mlp_pack(const qa_mlp_op *ops, int32_t num_ops, const float *const *weigh
     for (int i = 0; i < num_ops; ++i) {
         if (ops[i].kind != QA_MLP_LAYER) continue;
         if (!weights[i]) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_pack: op %d has no weight", i); return QA_E_ARG; }
-        a.l[a.num++] = PackLayer{weights[i], biases[i], ops[i].n, ops[i].k, ops[i].w_off, ops[i].b_off};
+        a.l[a.num++] = PackLayer{weights[i], biases[i], ops[i].n, ops[i].k, ops[i].w_off, ops[i].b_off, (ops[i].flags & QA_MLP_F_TRANSPOSED) ? 1 : 0, 0};
     }
     if (a.num == 0) return QA_OK;
     hipLaunchKernelGGL(qa_mlp_pack_kernel, dim3(64, a.num), dim3(256), 0, (hipStream_t)stream, a);
@@ -514,10 +550,15 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
         MlpDevOp &d = a.ops[i];
         d.kind = o.kind; d.src_buf = o.src_buf; d.src_col = o.src_col; d.dst_buf = o.dst_buf; d.dst_col = o.dst_col; d.k = o.k; d.n = o.n; d.act = o.act;
         d.out_index = o.out_index; d.w_off = o.w_off; d.b_off = o.b_off;
-        if (o.kind == QA_MLP_LAYER) {
-            d.nt = (o.n + 15) / 16; d.kb = mlp_kb(o.k, o.n); d.tpw = mlp_tpw(d.nt);
-            if (o.dst_buf < 0 && (o.out_index >= num_outs || !outs[o.out_index] || out_strides[o.out_index] < o.n)) {
+        d.flags = o.flags; d.out_col = o.out_col; d.aux_index = o.aux_index; d.aux_col = o.aux_col;
+        if (o.kind == QA_MLP_LAYER) { d.nt = (o.n + 15) / 16; d.kb = mlp_kb(o.k, o.n); d.tpw = mlp_tpw(d.nt); }
+        if ((o.kind == QA_MLP_LAYER && o.dst_buf < 0) || (o.flags & QA_MLP_F_SAVE)) {
+            if (o.out_index >= num_outs || !outs[o.out_index] || out_strides[o.out_index] < o.out_col + o.n) {
                 snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: op %d writes output %d which is missing or too narrow", i, o.out_index); return QA_E_ARG; }
+        }
+        if ((o.kind == QA_MLP_LAYER || o.kind == QA_MLP_GRAD) && o.act >= 4) {
+            if (o.aux_index >= num_outs || !outs[o.aux_index] || out_strides[o.aux_index] < o.aux_col + o.n) {
+                snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: op %d reads the saved activation %d which is missing or too narrow", i, o.aux_index); return QA_E_ARG; }
         }
     }
     const int tiles = (rows + MLP_ROWS - 1) / MLP_ROWS;
@@ -528,7 +569,9 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
     int32_t strand_of[QA_MLP_MAX_OPS];
     /* a tile per CU or more: nothing to split over CUs -- two strands side by side inside every workgroup instead (qa_mlp_forward_groups_kernel),
      * when the chain has two and their buffers fit the CU's LDS; QA_MLP_GROUPS=1 in the environment / qa_mlp_set_groups(1) keeps the one-group kernel (A/B runs) */
-    if (max_strands < 2 && mlp_groups_switch() >= 2 && mlp_strands(ops, num_ops, 2, strand_of) == 2 && mlp_group_geometry(ops, num_ops, strand_of, x_cols, a)) {
+    bool ext = false;           /* any ABI 17 feature in the program: the kernel variant that has them (the two-group launch does not) */
+    for (int i = 0; i < num_ops; ++i) ext |= ops[i].flags != 0 || ops[i].kind == QA_MLP_GRAD || ops[i].act >= 4 || ops[i].out_col != 0;
+    if (!ext && max_strands < 2 && mlp_groups_switch() >= 2 && mlp_strands(ops, num_ops, 2, strand_of) == 2 && mlp_group_geometry(ops, num_ops, strand_of, x_cols, a)) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(qa_mlp_forward_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             MLP_LDS_LIMIT_FLOATS * 4);
         if (attr == hipSuccess) {
@@ -542,7 +585,8 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
     }
     a.strands = mlp_strands(ops, num_ops, max_strands, strand_of);
     for (int i = 0; i < num_ops; ++i) a.ops[i].strand = strand_of[i];
-    hipLaunchKernelGGL(qa_mlp_forward_kernel, dim3(tiles, a.strands), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);
+    if (ext) hipLaunchKernelGGL(qa_mlp_forward_kernel<true>, dim3(tiles, a.strands), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(qa_mlp_forward_kernel<false>, dim3(tiles, a.strands), dim3(MLP_WAVES * 64), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

@@ -126,6 +126,8 @@ def _retire(parts):
     kernel on the CURRENT stream: the caching allocator must not hand the block back to the branch stream while that kernel can still be
     reading it.  Eager: record the consumer stream on the block.  Always: keep the tensor until the next step opens (by then every branch
     stream has been told to wait for the stream the optimiser ran on)."""
+    if getattr(parts, "_qa_persistent", False):       # a buffer its owner keeps for good (train_chain): it never goes back to the allocator
+        return
     if not torch.cuda.is_current_stream_capturing():
         parts.record_stream(torch.cuda.current_stream(parts.device))
     _RETIRED.append(parts)
@@ -190,6 +192,16 @@ def _register_parts(param, parts, nparts, stride, shape=None):
     buf = torch.empty(tuple(param.shape) if shape is None else shape, dtype=torch.float32, device=param.device)
     _PENDING[param.data_ptr()] = (param, parts, int(nparts), int(stride), buf, torch.cuda.current_stream(param.device))
     return buf.detach()
+
+
+def register_grad_parts(param, parts, nparts, stride, grad):
+    """A gradient computed OUTSIDE autograd, left in parts (train_chain.PpoTrainChain.backward): `grad` is the tensor the finish writes
+    (the caller has made it `param.grad`), `parts` a buffer the caller keeps.  A parameter that already has a gradient in parts gets that one
+    finished first and this one ADDED would need a second buffer -- not a case the chain produces (one product per parameter per step)."""
+    if param.data_ptr() in _PENDING:
+        raise RuntimeError("register_grad_parts: the parameter already has a gradient in parts")
+    parts._qa_persistent = True
+    _PENDING[param.data_ptr()] = (param, parts, int(nparts), int(stride), grad, torch.cuda.current_stream(param.device))
 
 
 def pending_grads():

@@ -1,0 +1,253 @@
+"""The networks of one PPO minibatch step as TWO chain launches (include/qa_sim.h, ABI 17): forward with saved activations, then the
+input-gradient path on transposed weights; weight gradients stay GEMMs.
+
+What it replaces: SSInfoGAIL.update_actor_critic's forward and backward passes (bbc/rsl_rl/algorithms/gail.py:328-413 through autograd):
+estimator, privileged encoder, actor trunk + head, critic trunk + head -- 13 Linear layers, i.e. ~25 launches forward (GEMMs, ELUs,
+concatenations) and ~45 backward (ELU', two GEMMs and a bias reduction per layer) over three streams.  With few rows per minibatch (the
+per-GPU share of the 8-GPU job: 512 envs = 3,072 rows) every one of those is launch-latency sized and the step is a serial chain of them
+(profiles/r5_final_ppo_step_kernel_sequence.txt: 95 launches, ~0.5 ms for 14 GFLOP).  `qa_mlp_forward` already walks a 16-row tile through
+the whole network with the activations in LDS for the rollout; here the same launch also SAVES every hidden layer's output to a (rows, 2160)
+tape, and a second program walks the tile back from the heads' gradients: each input-gradient layer multiplies by the forward layer's
+transposed matrix and scales by the activation derivative taken from the tape (ELU: y > 0 ? 1 : y + 1), writing the gradient at every
+layer's pre-activation to a second tape.  The 13 weight (+ bias) gradients are `qa_linear_backward_weight` products of tape columns, left in
+parts for the optimiser's first pass (fused.deferred parts).
+
+Only used below `MAX_ROWS` rows per step: at 24,576 rows the library's GEMMs run the 512-wide trunk layers at 0.7-0.85 of the MFMA peak and
+a 16-row tile walk does not."""
+import ctypes as C
+import os
+
+import torch
+
+from quadrupedal_agility_amd import _capi
+from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+
+MAX_ROWS = int(os.environ.get("QA_TRAIN_CHAIN_MAX_ROWS", "8192"))
+ENABLED = os.environ.get("QA_TRAIN_CHAIN", "1") != "0"
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _pad4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+def _ok(rc, name, prog):
+    if rc != 0:
+        msg = _capi.load_library().qa_last_error().decode() if prog.prefix == "qa_" else "(oracle twin)"
+        raise RuntimeError(f"{prog.prefix}{name} failed with code {rc}: {msg}")
+
+
+class _Program:
+    """an op list + its packed weights (fused.PolicyChain's pack / launch halves, with explicit output tables)"""
+
+    def __init__(self, lib=None, prefix="qa_"):
+        self.ops, self.params, self.woff = [], [], 0
+        self.packed = None
+        self.lib, self.prefix = lib, prefix          # the checker runs the same programs through the oracle's twins (lib = oracle, "qo_")
+
+    def _fn(self, name):
+        return getattr(self.lib or _capi.load_library(), self.prefix + name)
+
+    def _stream(self, t):
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else None
+
+    def _add(self, op, param):
+        self.ops.append(op); self.params.append(param)
+
+    def copy(self, src, scol, dst, dcol, n, save=None):
+        kw = dict(flags=_capi.MLP_F_SAVE, out_index=save[0], out_col=save[1]) if save else {}
+        self._add(_capi.QaMlpOp(kind=_capi.MLP_COPY, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=0, n=n, **kw), None)
+
+    def grad(self, src, scol, dst, dcol, n, act=0, aux=None, add=False, save=None):
+        flags = (_capi.MLP_F_ADD if add else 0) | (_capi.MLP_F_SAVE if save else 0)
+        kw = dict(out_index=save[0], out_col=save[1]) if save else {}
+        if aux:
+            kw.update(aux_index=aux[0], aux_col=aux[1])
+        self._add(_capi.QaMlpOp(kind=_capi.MLP_GRAD, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=0, n=n, act=act, flags=flags, **kw), None)
+
+    def layer(self, src, scol, k, dst, dcol, n, act, weight, bias, out=None, save=None, aux=None, transposed=False):
+        """dst >= 0: into scratch buffer dst (and, with `save` = (output, column), to that global output too); dst = -1: to `out` = (output, column)"""
+        cols = _capi.MLP_BUF_COLS
+        assert dst != src and scol % 4 == 0 and scol + k <= cols[src] + 4 and (dst < 0 or dcol + n <= cols[dst]), (src, scol, k, dst, dcol, n)
+        nt, kb = (n + 15) // 16, fused.PolicyChain.k_blocks(k, n)
+        base = sum(16 * (c + 4) for c in cols[:src])
+        assert base + 15 * (cols[src] + 4) + scol + 16 * kb <= sum(16 * (c + 4) for c in cols), "padded k-blocks beyond the kernel's LDS"
+        w_off = self.woff; b_off = w_off + nt * kb * 256; self.woff = b_off + nt * 16
+        flags = (_capi.MLP_F_SAVE if (save and dst >= 0) else 0) | (_capi.MLP_F_TRANSPOSED if transposed else 0)
+        oi, oc = (out if dst < 0 else save) or (0, 0)
+        ai, acol = aux or (0, 0)
+        self._add(_capi.QaMlpOp(kind=_capi.MLP_LAYER, src_buf=src, src_col=scol, dst_buf=dst, dst_col=dcol, k=k, n=n, act=act, out_index=oi, flags=flags,
+                                w_off=w_off, b_off=b_off, out_col=oc, aux_index=ai, aux_col=acol), (weight, bias))
+
+    def finish(self):
+        assert len(self.ops) <= _capi.MLP_MAX_OPS, len(self.ops)
+        self.n_ops = len(self.ops)
+        self.c_ops = (_capi.QaMlpOp * self.n_ops)(*self.ops)
+        self.w_ptrs = (C.c_void_p * self.n_ops)(*[(p[0].data_ptr() if p else None) for p in self.params])
+        self.b_ptrs = (C.c_void_p * self.n_ops)(*[(p[1].data_ptr() if p and p[1] is not None else None) for p in self.params])
+        for p in self.params:
+            if p and not ((p[0].is_cuda or self.prefix != "qa_") and p[0].is_contiguous() and p[0].dtype == torch.float32):
+                raise RuntimeError("train chain: parameters must be contiguous fp32 ROCm tensors")
+        dev = next(p[0] for p in self.params if p).device
+        self.packed = torch.zeros(self.woff, dtype=torch.float32, device=dev)
+
+    def pack(self):
+        _ok(self._fn("mlp_pack")(self.c_ops, self.n_ops, self.w_ptrs, self.b_ptrs, _ptr(self.packed), self.woff, self._stream(self.packed)), "mlp_pack", self)
+
+    def launch(self, x, x_cols, outs):
+        k = len(outs)
+        ptrs = (C.c_void_p * k)(*[o.data_ptr() for o in outs]); strides = (C.c_int64 * k)(*[o.stride(0) for o in outs])
+        _ok(self._fn("mlp_forward")(_ptr(x), x.stride(0), x.shape[0], x_cols, self.c_ops, self.n_ops, _ptr(self.packed), ptrs, strides, k, self._stream(x)),
+            "mlp_forward", self)
+
+
+class PpoTrainChain:
+    """forward(obs) -> (est, mu, value, priv_latent); backward(g_est, dmu, dvalue, g_priv) -> every parameter's `.grad` (wide ones in parts,
+    registered with fused's deferred finishes).  Buffers are persistent per instance: one instance per minibatch size, recordable."""
+
+    ELU, DELU = 1, _capi.MLP_ACT_ELU_GRAD
+
+    @classmethod
+    def describe(cls, ac, estimator, rows, lib=None, prefix="qa_"):
+        import torch.nn as nn
+        lin = fused.PolicyChain._linears
+        st = dict(actor=lin(ac.actor_trunk), critic=lin(ac.critic_trunk), est=lin(estimator.estimator),
+                  priv=None if isinstance(ac.priv_encoder, nn.Identity) else lin(ac.priv_encoder))
+        if not ENABLED or rows > MAX_ROWS or any(v is None for v in st.values()) or not ac.train_with_estimated_latent or ac.fixed_std:
+            return None
+        if (any(a != 1 for k in ("actor", "critic", "priv") for _, a in st[k]) or any(a != 1 for _, a in st["est"][:-1]) or st["est"][-1][1] != 0
+                or len(st["actor"]) != 3 or len(st["critic"]) != 3 or len(st["priv"]) != 2 or len(st["est"]) != 3):
+            return None
+        sl = ac._sl
+        n_prop, n_exp, n_lat = ac.num_prop, ac.num_explicit, ac.num_latent
+        cmd0, n_obs = sl[4].start, ac.num_critic_obs
+        n_cmd, lat_col = n_obs - cmd0, n_prop + n_exp
+        n_in = n_prop + n_exp + n_lat + n_cmd
+        cols = _capi.MLP_BUF_COLS
+        a_w, c_w, p_w, e_w = ([l.out_features for l, _ in st[k]] for k in ("actor", "critic", "priv", "est"))
+        n_act = ac.actor_head.out_features
+        if (n_obs > cols[0] or n_in > cols[3] or a_w[0] > cols[1] or a_w[1] > cols[2] or a_w[2] > cols[3] or c_w[0] > cols[1] or c_w[1] > cols[2] or c_w[2] > cols[3]
+                or p_w[0] > cols[1] or p_w[1] != n_lat or e_w[0] > cols[3] or e_w[1] > cols[2] or e_w[2] != n_exp or st["actor"][0][0].in_features != n_in
+                or st["critic"][0][0].in_features != n_obs or st["est"][0][0].in_features != n_prop or st["priv"][0][0].in_features != n_lat
+                or ac.critic_head.out_features != 1 or n_in > cols[2]):
+            return None
+        self = cls()
+        self.ac, self.estimator, self.rows = ac, estimator, rows
+        self.dims = dict(n_prop=n_prop, n_exp=n_exp, n_lat=n_lat, n_cmd=n_cmd, lat_col=lat_col, cmd0=cmd0, n_obs=n_obs, n_in=n_in, n_act=n_act)
+        # ---- the tape of saved activations (forward) and of pre-activation gradients (backward): column offsets, each a multiple of 4
+        t, off = {}, 0
+        for name, w in (("ain", n_in), ("p1", p_w[0]), ("a1", a_w[0]), ("a2", a_w[1]), ("a3", a_w[2]), ("c1", c_w[0]), ("c2", c_w[1]), ("c3", c_w[2]),
+                        ("e1", e_w[0]), ("e2", e_w[1])):
+            t[name] = (off, w); off += _pad4(w)
+        self.tape_cols, self.t = off, t
+        g, off = {}, 0
+        for name, w in (("c3", c_w[2]), ("c2", c_w[1]), ("c1", c_w[0]), ("a3", a_w[2]), ("a2", a_w[1]), ("a1", a_w[0]), ("p2", n_lat), ("p1", p_w[0]),
+                        ("e2", e_w[1]), ("e1", e_w[0])):
+            g[name] = (off, w); off += _pad4(w)
+        self.gtape_cols, self.g = off, g
+        # the backward chain's input row: [d mu | d value | d est | d priv_latent], each part 16-byte aligned
+        self.gin_cols = {"mu": 0, "value": _pad4(n_act), "est": _pad4(n_act) + 4, "priv": _pad4(n_act) + 4 + _pad4(n_exp)}
+        self.gin_width = self.gin_cols["priv"] + _pad4(n_lat)
+        T, MU, VAL, EST = 0, 1, 2, 3          # output slots of the forward launch
+        E, D = cls.ELU, cls.DELU
+        (a1, a2, a3), (c1, c2, c3), (p1, p2), (e1, e2, e3) = ([l for l, _ in st[k]] for k in ("actor", "critic", "priv", "est"))
+        ain = t["ain"][0]
+        # ---- forward program (what PolicyChain.describe builds for the rollout, plus the saves; the actor's explicit-state columns are the
+        # OBSERVATION's: update_actor_critic feeds the true privileged state, only act() substitutes the estimate)
+        f = _Program(lib, prefix)
+        Z = 3
+        f.copy(0, 0, Z, 0, lat_col, save=(T, ain))                                     # proprio + explicit
+        f.copy(0, lat_col, 2, 0, n_lat)                                                # (a layer's source starts 16-byte aligned)
+        f.layer(2, 0, n_lat, 1, 0, p_w[0], E, p1.weight, p1.bias, save=(T, t["p1"][0]))
+        f.layer(1, 0, p_w[0], Z, lat_col, n_lat, E, p2.weight, p2.bias, save=(T, ain + lat_col))      # = the privileged latent, in the actor's input row
+        f.copy(0, cmd0, Z, lat_col + n_lat, n_cmd, save=(T, ain + lat_col + n_lat))
+        f.layer(Z, 0, n_in, 1, 0, a_w[0], E, a1.weight, a1.bias, save=(T, t["a1"][0]))
+        f.layer(1, 0, a_w[0], 2, 0, a_w[1], E, a2.weight, a2.bias, save=(T, t["a2"][0]))
+        f.layer(2, 0, a_w[1], Z, 0, a_w[2], E, a3.weight, a3.bias, save=(T, t["a3"][0]))
+        f.layer(Z, 0, a_w[2], -1, 0, n_act, 0, ac.actor_head.weight, ac.actor_head.bias, out=(MU, 0))
+        f.layer(0, 0, n_obs, 1, 0, c_w[0], E, c1.weight, c1.bias, save=(T, t["c1"][0]))
+        f.layer(1, 0, c_w[0], 2, 0, c_w[1], E, c2.weight, c2.bias, save=(T, t["c2"][0]))
+        f.layer(2, 0, c_w[1], Z, 0, c_w[2], E, c3.weight, c3.bias, save=(T, t["c3"][0]))
+        f.layer(Z, 0, c_w[2], -1, 0, 1, 0, ac.critic_head.weight, ac.critic_head.bias, out=(VAL, 0))
+        f.layer(0, 0, n_prop, Z, 0, e_w[0], E, e1.weight, e1.bias, save=(T, t["e1"][0]))
+        f.layer(Z, 0, e_w[0], 2, 0, e_w[1], E, e2.weight, e2.bias, save=(T, t["e2"][0]))
+        f.layer(2, 0, e_w[1], -1, 0, n_exp, 0, e3.weight, e3.bias, out=(EST, 0))
+        f.finish()
+        # ---- backward program: outputs 0 = gradient tape (written), 1 = activation tape (read)
+        G, A = 0, 1
+        gc = self.gin_cols
+        b = _Program(lib, prefix)
+        b.layer(0, gc["value"], 1, Z, 0, c_w[2], D, ac.critic_head.weight, None, save=(G, g["c3"][0]), aux=(A, t["c3"][0]), transposed=True)
+        b.layer(Z, 0, c_w[2], 2, 0, c_w[1], D, c3.weight, None, save=(G, g["c2"][0]), aux=(A, t["c2"][0]), transposed=True)
+        b.layer(2, 0, c_w[1], 1, 0, c_w[0], D, c2.weight, None, save=(G, g["c1"][0]), aux=(A, t["c1"][0]), transposed=True)
+        b.layer(0, gc["mu"], n_act, Z, 0, a_w[2], D, ac.actor_head.weight, None, save=(G, g["a3"][0]), aux=(A, t["a3"][0]), transposed=True)
+        b.layer(Z, 0, a_w[2], 2, 0, a_w[1], D, a3.weight, None, save=(G, g["a2"][0]), aux=(A, t["a2"][0]), transposed=True)
+        b.layer(2, 0, a_w[1], 1, 0, a_w[0], D, a2.weight, None, save=(G, g["a1"][0]), aux=(A, t["a1"][0]), transposed=True)
+        b.layer(1, 0, a_w[0], 2, 0, n_in, 0, a1.weight, None, transposed=True)                    # d loss / d actor input (only its latent columns are needed)
+        b.copy(0, gc["priv"], Z, 0, n_lat)                                                          # the regulariser's gradient at the privileged latent ...
+        b.grad(2, lat_col, Z, 0, n_lat, act=D, aux=(A, ain + lat_col), add=True, save=(G, g["p2"][0]))   # ... + the actor's, times ELU' of the latent
+        b.layer(Z, 0, n_lat, 2, 0, p_w[0], D, p2.weight, None, save=(G, g["p1"][0]), aux=(A, t["p1"][0]), transposed=True)
+        b.layer(0, gc["est"], n_exp, Z, 0, e_w[1], D, e3.weight, None, save=(G, g["e2"][0]), aux=(A, t["e2"][0]), transposed=True)
+        b.layer(Z, 0, e_w[1], 2, 0, e_w[0], D, e2.weight, None, save=(G, g["e1"][0]), aux=(A, t["e1"][0]), transposed=True)
+        b.finish()
+        self.fwd, self.bwd = f, b
+        dev = a1.weight.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.tape, self.gtape, self.gin = z(rows, self.tape_cols), z(rows, self.gtape_cols), z(rows, self.gin_width)
+        self.mu, self.value, self.est = z(rows, n_act), z(rows, 1), z(rows, n_exp)
+        # ---- weight-gradient products: (parameter pair, gradient columns, input columns); `obs` inputs are resolved per call
+        tc = lambda name: ("tape", t[name][0], t[name][1])
+        gcol = lambda name: ("gtape", g[name][0], g[name][1])
+        self.wgrads = [
+            (c1, gcol("c1"), ("obs", 0, n_obs)), (c2, gcol("c2"), tc("c1")), (c3, gcol("c3"), tc("c2")), (ac.critic_head, ("gin", gc["value"], 1), tc("c3")),
+            (a1, gcol("a1"), ("tape", ain, n_in)), (a2, gcol("a2"), tc("a1")), (a3, gcol("a3"), tc("a2")), (ac.actor_head, ("gin", gc["mu"], n_act), tc("a3")),
+            (p1, gcol("p1"), ("obs", lat_col, n_lat)), (p2, gcol("p2"), tc("p1")),
+            (e1, gcol("e1"), ("obs", 0, n_prop)), (e2, gcol("e2"), tc("e1")), (e3, ("gin", gc["est"], n_exp), tc("e2"))]
+        self._wg = []
+        for lin_, _, _ in self.wgrads:
+            n, k = lin_.out_features, lin_.in_features
+            nb = int(f._fn("linear_backward_weight_scratch_bytes")(rows, k, n))
+            lay = (C.c_int64 * 5)()
+            _ok(f._fn("linear_backward_weight_layout")(rows, k, n, lay), "linear_backward_weight_layout", f)
+            scratch = torch.zeros(nb // 4 + 4, dtype=torch.float32, device=dev)
+            gw, gb = torch.zeros_like(lin_.weight), torch.zeros_like(lin_.bias)
+            self._wg.append((scratch, nb, [int(v) for v in lay], gw, gb))
+        return self
+
+    def pack(self):
+        self.fwd.pack(); self.bwd.pack()
+
+    def forward(self, obs):
+        assert obs.shape[0] == self.rows and obs.stride(1) == 1 and obs.shape[1] >= self.dims["n_obs"]
+        self._obs = obs
+        self.fwd.launch(obs, self.dims["n_obs"], [self.tape, self.mu, self.value, self.est])
+        d = self.dims
+        a0 = self.t["ain"][0] + d["lat_col"]
+        return self.est, self.mu, self.value, self.tape[:, a0:a0 + d["n_lat"]]
+
+    def backward(self, g_est, dmu, dvalue, g_priv, defer=True):
+        """the four gradients at the chains' outputs -> `.grad` of all 26 parameters.  With `defer` the weight / bias gradients stay in parts,
+        registered with fused's deferred finishes: ClipAdam.step() (or fused.flush_pending_grads()) adds them."""
+        d, gc, gin = self.dims, self.gin_cols, self.gin
+        gin[:, gc["mu"]:gc["mu"] + d["n_act"]].copy_(dmu)
+        gin[:, gc["value"]:gc["value"] + 1].copy_(dvalue.view(-1, 1))
+        gin[:, gc["est"]:gc["est"] + d["n_exp"]].copy_(g_est)
+        gin[:, gc["priv"]:gc["priv"] + d["n_lat"]].copy_(g_priv)
+        self.bwd.launch(gin, self.gin_width, [self.gtape, self.tape])
+        src = {"tape": self.tape, "gtape": self.gtape, "gin": gin, "obs": self._obs}
+        stream = self.bwd._stream(gin)
+        wgrad = self.bwd._fn("linear_backward_weight")
+        defer = defer and gin.is_cuda and fused.ENABLED and os.environ.get("QA_DEFER_GRAD_FINISH", "1") != "0"
+        for (lin_, (gs, g0, gn), (xs, x0, xk)), (scratch, nb, lay, gw, gb) in zip(self.wgrads, self._wg):
+            gt, xt = src[gs], src[xs]
+            gp = gt.data_ptr() + 4 * g0
+            xp = xt.data_ptr() + 4 * x0
+            _ok(wgrad(C.c_void_p(gp), gt.stride(0), C.c_void_p(xp), xt.stride(0), None if defer else _ptr(gw), None if defer else _ptr(gb),
+                      self.rows, xk, gn, _ptr(scratch), nb, stream), "linear_backward_weight", self.bwd)
+            lin_.weight.grad, lin_.bias.grad = gw, gb
+            if defer:
+                fused.register_grad_parts(lin_.weight, scratch, lay[0], lay[1], gw)
+                fused.register_grad_parts(lin_.bias, scratch[lay[4]:], lay[2], lay[3], gb)

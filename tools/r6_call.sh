@@ -34,6 +34,17 @@ lock)      # the learner lockstep (GPU learner vs torch-CPU l
     grep "^it " $O/lockstep.log | tail -12 | cut -c1-700; tail -1 $O/lockstep.log | cut -c1-600
     tail -3 $O/prox_cfg3.log | cut -c1-400; tail -3 $O/prox_cfg4.log | cut -c1-400
     ;;
+chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (train_chain.py): parity, then the small-share bench lines with / without
+    timeout 900 python -m pytest tests/test_train_chain.py tests/test_policy_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; tail -5 $O/pytest_chain.log
+    timeout 1500 python -m pytest tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_grad_parts.py tests/test_distributed_gpu.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log
+    for n in 512 1024; do
+      timeout 300 python bench.py --num_envs $n --no_cpu_baseline 2>$O/bench_${n}_chain.err < /dev/null | grep '"metric"' > $O/bench_${n}_chain.json
+      QA_TRAIN_CHAIN=0 timeout 300 python bench.py --num_envs $n --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_${n}_autograd.json
+    done
+    timeout 400 python bench.py --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_4096.json
+    line $O/bench_*.json
+    timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
+    ;;
 *) echo "unknown case $C"; exit 2;;
 esac
 ls -la $O
