@@ -36,7 +36,7 @@ def _pad4(n):
 
 def _ok(rc, name, prog):
     if rc != 0:
-        msg = _capi.load_library().qa_last_error().decode() if prog.prefix == "qa_" else "(oracle twin)"
+        msg = _capi.load_library().qa_last_error().decode() if prog.prefix == "qa_" else "(an injected library: no error text)"
         raise RuntimeError(f"{prog.prefix}{name} failed with code {rc}: {msg}")
 
 
@@ -46,7 +46,7 @@ class _Program:
     def __init__(self, lib=None, prefix="qa_"):
         self.ops, self.params, self.woff = [], [], 0
         self.packed = None
-        self.lib, self.prefix = lib, prefix          # the checker runs the same programs through the oracle's twins (lib = oracle, "qo_")
+        self.lib, self.prefix = lib, prefix          # injection point of the tests (another library exporting the same entry points under another prefix); the default is libqa_sim.so, and it is required
 
     def _fn(self, name):
         return getattr(self.lib or _capi.load_library(), self.prefix + name)

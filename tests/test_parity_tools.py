@@ -27,7 +27,16 @@ def test_extension_without_new_seeds_reproduces_the_profile(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "merge_d2_extend.py"), out, old, "--"], check=True, capture_output=True, timeout=120)
     a, b = json.load(open(old)), json.load(open(out))
     assert b["hip_seeds"] == a["hip_seeds"] and b["cpu_seeds"] == a["cpu_seeds"]
-    assert b["verdict"] == a["verdict"]
+    # the profile was written under the r4 / r5 registration; the tool now judges under the r6 amendment (tools/merge_d2.py docstring) and keeps the
+    # old verdict under its own key: every clause the old file judged must come out the same
+    old_v, new_v = a["verdict"]["pre_registered"], b["verdict"]["pre_registered"]
+    sup = [v for k, v in b["verdict"].items() if k.startswith("r4_r5_registration")][0]
+    for k in ("transition_time_same (Mann-Whitney p >= 0.05)", "fraction_past_transition_same (Fisher p >= 0.05)"):
+        assert new_v[k] == old_v[k], k
+    assert sup["medians_within_10_percent"] == old_v["medians_within_10_percent"] and sup["pass"] == old_v["pass"]
+    assert "tail_values_same (Mann-Whitney p >= 0.05 on every tag)" in new_v and set(new_v["tail_values_mann_whitney_p"]) == {"Train/mean_reward", "Train/mean_reward_i", "Train/mean_episode_length"}
+    for k in ("means_at_horizon (r2 / r3 statistic, reported)", "medians_at_horizon"):
+        assert b["verdict"][k] == a["verdict"][k], k
     for k in ("hip", "cpu_oracle", "mann_whitney_u", "mann_whitney_p", "hip_median", "cpu_oracle_median", "past_transition_at_horizon"):
         assert b["transition"][k] == a["transition"][k], k
     for ck, tags in a["at_iteration"].items():

@@ -168,7 +168,16 @@ def draw_tables(gen, alg):
 def run(a):
     import torch
     threads = int(os.environ.get("QA_CPU_THREADS", "0")) or min(64, len(os.sched_getaffinity(0)))
+    prev_threads = torch.get_num_threads()
     torch.set_num_threads(threads)
+    try:
+        return _run(a, threads)
+    finally:
+        torch.set_num_threads(prev_threads)          # (a caller in the same process, e.g. the test suite, keeps its own setting)
+
+
+def _run(a, threads):
+    import torch
     gpu, genv = build(a.driver, a.num_envs, a.seed, a.amp, a.physics, a.ring)
     sync = torch.cuda.synchronize if a.driver == "gpu" else (lambda: None)
     arms = {}
