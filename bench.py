@@ -330,6 +330,8 @@ def _stamped_traffic(g, num_envs, name="env_step_traffic.json"):
         return None, f"profiles/{name} was measured at {d.get('num_envs')} envs per launch, this run launches {num_envs}: no traffic figure for this size"
     if d.get("kernel_source_hash") != env_kernel_hash(g):
         return None, f"profiles/{name} was measured on kernel sources {d.get('kernel_source_hash', 'unstamped')}, this build is {env_kernel_hash(g)}: re-run tools/final_measure.sh"
+    if d.get("fetch_correction") not in (1, 2):
+        return None, f"profiles/{name} derives a fetch correction of {d.get('fetch_correction')} (the guide's factor is 2, an exact counter would give 1): its calibration was misread, the figure is void"
     return d.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on kernel sources {d['kernel_source_hash']} (tools/final_measure.sh)"
 
 
@@ -437,6 +439,8 @@ def bench_tsc(args, world, rank, local_rank, dev):
     sized = f"tsc_env_step_traffic_{n}.json"
     tsc_traffic, tsc_traffic_note = ((None, "no PMC pass of the depth kernel on file") if args.vision else
                                      _stamped_traffic(g, n, sized if os.path.exists(os.path.join(ROOT, "profiles", sized)) else "tsc_env_step_traffic.json"))
+    if tsc_traffic is not None and tsc_traffic / (kern_ms * 1e-3) / 1e9 > HBM_PEAK_GBS:      # a figure that implies more than the HBM peak is not a measurement
+        tsc_traffic, tsc_traffic_note = None, f"the figure on file ({tsc_traffic} B per env step) over {kern_ms * 1e3:.0f} us would be {tsc_traffic / (kern_ms * 1e-3) / 1e12:.1f} TB/s: void"
     what = ("TSC-student with depth-camera obs (58x87 ray-cast depth image per env step, depth encoder + GRU + student actor, DAgger + BYOL)" if args.vision else
             "TSC-teacher agility course")
     out = {"metric": "env-steps/sec (4096 Go2 envs) + wall-clock to 1k PPO iters, 1/2/4/8 GPU", "value": n * T * args.steps * world / dt, "unit": "env-steps/s",

@@ -7,6 +7,9 @@ import numpy as np
 # (atol, rtol) per tensor for one env step (4 substeps) from identical state.  DERIVED, not asserted: atol = 3 x the measured
 # p99.9 of the per-env-step error |hip - oracle| (max over the env's elements) of this very protocol -- 40 steps x 1000 envs, 40,000 env-steps --
 # in profiles/r4_step_error_distribution.json (tools/step_error_distribution.py), rounded up to one digit; the p99.9 is quoted beside each entry.
+# r6: re-measured on HEAD's kernel (packed rows, env-local coordinates, three-wavefront data flow) --
+# profiles/r6_step_error_distribution.json: every p50 equals r4's to three digits, the p99.9 are within 2-10 % of r4's (same arithmetic per value: the
+# r5 changes re-arranged WHERE the work runs, not the order of the sums), so the tables stand; one entry moved: PROJECTED_GRAVITY p99.9 1.04e-6 -> 1.13e-6.
 # Medians are 1e-6 (world positions: one fp32 ulp at 96 m is 7.6e-6) to 2e-5 (joint state), i.e. ~1e-5 relative; the tail above p99 is envs in which
 # a contact switches on or off in one of the four substeps on one side only (fp32 Schur / PGS vs the oracle's dense solve in double), which is
 # why BASELINE.md's "<= 1e-5 relative" holds for the median env-step and not for all of them.  Env-steps outside these tolerances are counted
@@ -23,11 +26,11 @@ TOL = {
     "REW": (1e-6, 0), "EPISODE_SUMS": (6e-6, 0),                                  # p99.9 5.4e-8 / 1.9e-6
     "RESET": (0, 0), "TIME_OUT": (0, 0), "EPISODE_LENGTH": (0, 0), "LAST_CONTACTS": (0, 0), "CONTACT_FILT": (0, 0),
     "FOOT_IMPULSE": (1.3e-4, 0),                                                  # p99.9 4.2e-5 N s
-    "BASE_LIN_VEL": (6e-5, 0), "BASE_ANG_VEL": (6e-4, 0), "PROJECTED_GRAVITY": (3e-6, 0), "RPY": (5e-6, 0),   # p99.9 1.8e-5 / 1.8e-4 / 1.0e-6 / 1.4e-6
+    "BASE_LIN_VEL": (6e-5, 0), "BASE_ANG_VEL": (6e-4, 0), "PROJECTED_GRAVITY": (4e-6, 0), "RPY": (5e-6, 0),   # p99.9 1.9e-5 / 1.9e-4 / 1.1e-6 / 1.6e-6 (r6)
 }
 # The ACCURACY statement: TOL above is a fence around the kernel's own error TAIL -- a defect that was present when the
 # distribution was taken sits inside it by construction.  What says "this env step is computed to ~1e-5 relative" is the MEDIAN env-step error,
-# asserted here per tensor over all env-steps of the test: 3 x the p50 of profiles/r4_step_error_distribution.json (quoted beside each entry),
+# asserted here per tensor over all env-steps of the test: 3 x the p50 of profiles/r4_step_error_distribution.json = of profiles/r6_step_error_distribution.json (quoted beside each entry),
 # floored at one fp32 ulp of the tensor's largest value.  A systematic error (a wrong term, a stale operand) moves the median of every env, not the tail.
 MEDIAN_TOL = {
     "ROOT_STATES": 5e-6, "LAST_ROOT_VEL": 5e-6,            # p50 1.4e-6 on positions up to 96 m (one ulp 7.6e-6) and velocities up to 41 m/s

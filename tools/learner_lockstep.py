@@ -181,8 +181,9 @@ def _run(a, threads):
     gpu, genv = build(a.driver, a.num_envs, a.seed, a.amp, a.physics, a.ring)
     sync = torch.cuda.synchronize if a.driver == "gpu" else (lambda: None)
     arms = {}
-    for name in (["forced", "free"] if a.free else ["forced"]):
+    for name in ["forced"] + (["free"] if a.free else []) + (["control"] if a.control > 0 else []):
         arms[name] = build("cpu", a.num_envs, a.seed, a.amp, a.physics, a.ring)
+    noise_gen = torch.Generator().manual_seed(77 + a.seed)
     ga = gpu.alg
     dev = ga.device
     for r, e in arms.values():
@@ -212,6 +213,16 @@ def _run(a, threads):
         sync()
         if "forced" in arms:
             sync_state(ga, genv, arms["forced"][0].alg, arms["forced"][1])
+        if "control" in arms:
+            # the CONTROL: a torch-CPU learner started from the same state with every parameter moved by ~one fp32 ulp (relative N(0, control^2)).  Its
+            # difference from the `forced` arm after the iteration is what ONE iteration does to a rounding-sized difference in its input: the
+            # yardstick for reading the GPU-vs-CPU difference (a learner with another arithmetic cannot agree better than this)
+            ca, ce = arms["control"][0].alg, arms["control"][1]
+            sync_state(ga, genv, ca, ce)
+            with torch.no_grad():
+                for m in (ca.actor_critic, ca.estimator, ca.disc):
+                    for p in m.parameters():
+                        p.mul_(1.0 + a.control * torch.randn(p.shape, generator=noise_gen))
         for r, e in arms.values():
             copy_rollout(ga, r.alg)
             e.task_obs_weight = genv.task_obs_weight
@@ -242,6 +253,11 @@ def _run(a, threads):
             d = rel_l2(sg, sc)
             d["returns"] = float((ret_g - ret_c).norm() / ret_c.norm())
             d["advantages"] = float((adv_g - adv_c).norm() / adv_c.norm())
+            if name == "control":        # against the UNPERTURBED torch-CPU learner, not the GPU learner
+                d = rel_l2(sc, forced_state)
+                d["returns"] = float((ret_c - forced_ra[0]).norm() / forced_ra[0].norm()); d["advantages"] = float((adv_c - forced_ra[1]).norm() / forced_ra[1].norm())
+            if name == "forced":
+                forced_state, forced_ra = sc, (ret_c, adv_c)
             row[name] = {"state_rel_l2": d, "cpu_update_s": round(time.time() - t0, 2),
                          "losses_gpu": losses_g, "losses_cpu": losses_c,
                          "losses_max_abs_diff": max(abs(x - y) for x, y in zip(losses_g, losses_c)),
@@ -269,9 +285,11 @@ def summarise(a, rows, threads):
                    "(same class on device cpu) on the SAME state, rollout and sample tables; relative L2 difference |gpu - cpu| / |cpu| per group after every iteration",
            "config": {"amp": bool(a.amp), "num_envs": a.num_envs, "iters": len(rows), "seed": a.seed, "physics": a.physics, "driver": a.driver, "cpu_threads": threads,
                       "replay_ring": a.ring or "config default"},
-           "arms": {"forced": "CPU learner re-synchronised to the GPU learner's state before every iteration: the difference ONE iteration makes",
+           "arms": {"control": "torch-CPU learner vs torch-CPU learner: both from the GPU learner's state, one with every parameter moved by ~1 fp32 ulp (relative N(0, "
+                               f"{a.control:g}^2)) -- what one iteration does to a rounding-sized input difference (the floor for any two arithmetics)",
+                    "forced": "CPU learner re-synchronised to the GPU learner's state before every iteration: the difference ONE iteration makes",
                     "free": "CPU learner synchronised at iteration 0 only, same rollouts and tables: what the differences accumulate to"}}
-    for name in ("forced", "free"):
+    for name in ("forced", "free", "control"):
         if not rows or name not in rows[0]:
             continue
         groups = sorted({g for r in rows for g in r[name]["state_rel_l2"]})
@@ -291,6 +309,17 @@ def summarise(a, rows, threads):
                      "parameters_within_bound_for_all_iterations": first_over is None,
                      "logged_scalars_max_abs_diff": max(r[name]["losses_max_abs_diff"] for r in rows),
                      "cpu_update_s_median": sorted(r[name]["cpu_update_s"] for r in rows)[len(rows) // 2]}
+    if rows and "control" in rows[0]:
+        # per group and iteration: (GPU vs CPU) / (CPU vs perturbed CPU).  ~1 = the GPU learner differs from the CPU learner by what a one-ulp change of
+        # the weights would do; >> 1 in a group = something other than rounding
+        ratio = {}
+        for g in sorted(rows[0]["forced"]["state_rel_l2"]):
+            rs = sorted(r["forced"]["state_rel_l2"].get(g, 0.0) / r["control"]["state_rel_l2"][g] for r in rows if r["control"]["state_rel_l2"].get(g, 0.0) > 0)
+            if rs:
+                ratio[g] = {"median": rs[len(rs) // 2], "p90": rs[int(0.9 * (len(rs) - 1))], "max": rs[-1], "n": len(rs)}
+        out["gpu_vs_cpu_over_control"] = ratio
+        out["lr_ac_differs_at_iterations"] = [r["iteration"] for r in rows if r["forced"]["state_rel_l2"].get("lr_ac", 0.0) > 1e-6]
+        out["control_lr_ac_differs_at_iterations"] = [r["iteration"] for r in rows if r["control"]["state_rel_l2"].get("lr_ac", 0.0) > 1e-6]
     out["gpu_update_s_median"] = sorted(r["gpu_update_s"] for r in rows)[len(rows) // 2] if rows else None
     out["gpu_path_last"] = rows[-1]["gpu_path"] if rows else None
     if a.keep_rows:
@@ -307,6 +336,7 @@ def main():
     ap.add_argument("--physics", choices=["oracle", "hip"], default="oracle", help="who produces the rollouts: the oracle's physics under the GPU learner (hybrid arm) or the HIP env")
     ap.add_argument("--driver", choices=["gpu", "cpu"], default="gpu", help="cpu: the driving learner is a torch-CPU learner too (self-test of this tool: every difference must be exactly 0)")
     ap.add_argument("--free", type=int, default=1, help="also run the never-resynchronised CPU learner")
+    ap.add_argument("--control", type=float, default=0.0, help="> 0: the sensitivity control arm, relative size of its parameter perturbation (1e-7 ~ one fp32 ulp)")
     ap.add_argument("--ring", type=int, default=0, help="replay ring size (0: the config's)")
     ap.add_argument("--bound", type=float, default=1e-5, help="the state agreement asked for (relative L2 of a parameter group)")
     ap.add_argument("--keep_rows", type=int, default=0)
@@ -318,7 +348,7 @@ def main():
         json.dump(res, open(a.out, "w"), indent=1)
     brief = {k: {"within_bound": res[k]["parameters_within_bound_for_all_iterations"], "first_over": res[k]["first_iteration_with_a_parameter_group_over_the_bound"],
                  "worst_param": max(((v["rel_l2"], g) for g, v in res[k]["worst_over_iterations"].items() if g in STATE_GROUPS_PARAMS), default=None)}
-             for k in ("forced", "free") if k in res}
+             for k in ("forced", "free", "control") if k in res}
     print(json.dumps(brief))
 
 

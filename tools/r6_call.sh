@@ -34,6 +34,13 @@ lock)      # the learner lockstep (GPU learner vs torch-CPU l
     grep "^it " $O/lockstep.log | tail -12 | cut -c1-700; tail -1 $O/lockstep.log | cut -c1-600
     tail -3 $O/prox_cfg3.log | cut -c1-400; tail -3 $O/prox_cfg4.log | cut -c1-400
     ;;
+lock2)     # the lockstep's CONTROL arm (torch-CPU vs torch-CPU from a one-ulp perturbed state) beside the forced arm, 200 iterations; in the foreground the chain case
+    ( QA_CPU_THREADS=48 timeout 3000 python tools/learner_lockstep.py --amp --num_envs 1024 --iters 200 --free 0 --control 1e-7 --out $O/learner_lockstep_cfg3_control.json > $O/lockstep.log 2>&1 ) &
+    timeout 600 python -m pytest tests/test_learner_lockstep.py -m gpu -x -q -s > $O/pytest_lockstep.log 2>&1; tail -4 $O/pytest_lockstep.log | cut -c1-600
+    bash tools/r6_call.sh chain
+    wait
+    grep "^it " $O/lockstep.log | tail -12 | cut -c1-900; tail -1 $O/lockstep.log | cut -c1-600
+    ;;
 chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (train_chain.py): parity, then the small-share bench lines with / without
     timeout 900 python -m pytest tests/test_train_chain.py tests/test_policy_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; tail -5 $O/pytest_chain.log
     timeout 1500 python -m pytest tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_grad_parts.py tests/test_distributed_gpu.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log
