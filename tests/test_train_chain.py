@@ -172,3 +172,113 @@ def test_training_with_chain_steps_equals_training_with_autograd_steps(graph):
         assert torch.allclose(wa[k], wb[k], atol=3e-4, rtol=3e-3), (k, float((wa[k] - wb[k]).abs().max()))
     for k in ea:
         assert torch.allclose(ea[k], eb[k], atol=3e-4, rtol=3e-3), k
+
+
+# ------------------------------------------------------------------ the discriminator step's three chain launches
+def _disc(seed=0):
+    from quadrupedal_agility_amd.rsl_rl.algorithms.discriminator import Discriminator
+
+    class _Env:
+        task_obs_weight_decay = False
+    torch.manual_seed(seed)
+    d = Discriminator(_Env(), 98, 49, 5, 0.02, "MSELoss", None, 1.0, 1.0, 1.0, 1.0, 2, 2, 0.0, [512, 256], "cpu")
+    with torch.no_grad():
+        for p in d.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    return d
+
+
+def _disc_reference(disc, x, n_u, g_d, g_eps, g_l, c_gp):
+    """autograd, with the penalty's input gradient by DOUBLE BACKWARD as the reference takes it (gail.py:487-492)"""
+    for p in disc.parameters():
+        p.grad = None
+    xu = x[-n_u:].clone().requires_grad_(True)
+    xa = torch.cat([x[:-n_u], xu], 0)
+    h = disc.trunk(xa)
+    d, eps, logits = disc.linear(h), disc.encoder_eps(h), disc.classifier(h)
+    g = torch.autograd.grad(d[-n_u:], xu, grad_outputs=torch.ones_like(d[-n_u:]), create_graph=True, retain_graph=True)[0]
+    loss = (d * g_d).sum() + (eps * g_eps).sum() + (logits * g_l).sum() + c_gp * g.square().sum(-1).mean()
+    loss.backward()
+    return d.detach(), eps.detach(), logits.detach(), g.detach()
+
+
+def _disc_inputs(rows, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, 98, generator=gen)
+    return x, torch.randn(rows, 1, generator=gen) / rows, torch.randn(rows, 1, generator=gen) / rows, torch.randn(rows, 5, generator=gen) / rows
+
+
+def test_discriminator_chain_programs_equal_double_backward_through_the_oracle_twins():
+    from quadrupedal_agility_amd.rsl_rl.algorithms import train_chain
+    lib = load_oracle()
+    disc = _disc()
+    rows, n_u, c_gp = 3 * 23, 23, 0.2
+    x, g_d, g_eps, g_l = _disc_inputs(rows, 4)
+    d_ref, e_ref, l_ref, g_ref = _disc_reference(disc, x, n_u, g_d, g_eps, g_l, c_gp)
+    ref = {n: p.grad.clone() for n, p in disc.named_parameters()}
+    chain = train_chain.DiscTrainChain.describe(disc, rows, n_u, lib=lib, prefix="qo_")
+    assert chain is not None
+    chain.pack()
+    d, e, l = chain.forward(x)
+    g = chain.penalty_gradient()
+    for got, exp, tag in ((d, d_ref, "logit"), (e, e_ref, "eps"), (l, l_ref, "class logits"), (g, g_ref, "d logit / d x")):
+        assert torch.allclose(got, exp, rtol=1e-5, atol=2e-6), (tag, float((got - exp).abs().max()))
+    for p in disc.parameters():
+        p.grad = None
+    chain.backward(g_d, g_eps, g_l, c_gp)
+    for n, p in disc.named_parameters():
+        scale = float(ref[n].abs().max()) + 1e-30
+        assert p.grad is not None and p.grad.shape == p.shape and float((p.grad - ref[n]).abs().max()) <= 2e-5 * scale, (n, float((p.grad - ref[n]).abs().max()), scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mb", [16, 307, 1228])
+def test_hip_discriminator_chain_equals_double_backward(mb):
+    from quadrupedal_agility_amd.rsl_rl.algorithms import train_chain
+    disc_r, disc = _disc(5), _disc(5).cuda()
+    rows, n_u, c_gp = 3 * mb, mb, 0.2
+    x, g_d, g_eps, g_l = _disc_inputs(rows, mb)
+    d_ref, e_ref, l_ref, g_ref = _disc_reference(disc_r, x, n_u, g_d, g_eps, g_l, c_gp)
+    chain = train_chain.DiscTrainChain.describe(disc, rows, n_u)
+    assert chain is not None
+    chain.pack()
+    d, e, l = chain.forward(x.cuda())
+    g = chain.penalty_gradient()
+    torch.cuda.synchronize()
+    for got, exp, tag in ((d, d_ref, "logit"), (e, e_ref, "eps"), (l, l_ref, "class logits"), (g, g_ref, "d logit / d x")):
+        assert torch.allclose(got.cpu(), exp, rtol=2e-4, atol=2e-5), (tag, float((got.cpu() - exp).abs().max()))
+    chain.backward(g_d.cuda(), g_eps.cuda(), g_l.cuda(), c_gp)
+    torch.cuda.synchronize()
+    _check_grads(list(disc_r.named_parameters()), list(disc.parameters()), 3e-4, "disc")
+
+
+@pytest.mark.gpu
+def test_amp_training_with_the_discriminator_chain_equals_training_without_it():
+    """2 iterations of config 3 at 256 envs (iteration 1: 80 eager discriminator steps; iteration 2: recorded ones): same rollouts, same sample
+    tables (same generator calls).  The discriminator's iteration amplifies rounding by orders of magnitude (tests/test_learner_lockstep.py's
+    control arm), so its weights are held to a relative L2, the PPO side -- which does not see the discriminator's weights until the next
+    rollout -- elementwise."""
+    from tests.test_gpu_train import _make
+    from quadrupedal_agility_amd.legged_gym.envs import task_registry
+    from quadrupedal_agility_amd.rsl_rl.algorithms import train_chain
+    res = []
+    try:
+        for chain in (True, False):
+            train_chain.DISC_ENABLED = chain
+            torch.manual_seed(0)
+            env, args, tcfg = _make(256, True)
+            runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
+            runner.alg.eager_from_tables = True            # the eager warm-up update draws its samples the way the recorded ones do
+            runner.learn(2, init_at_random_ep_len=True)
+            assert bool(getattr(runner.alg, "_disc_train_chains", {})) == chain
+            a = runner.alg
+            res.append((torch.cat([p.detach().flatten() for p in a.disc.parameters()]), {k: v.clone() for k, v in a.actor_critic.state_dict().items()},
+                        a.disc_normalizer.mean.clone(), float(a.lr_ac)))
+    finally:
+        train_chain.DISC_ENABLED = True
+    (da, wa, na, lra), (db, wb, nb, lrb) = res
+    rel = float((da - db).norm() / db.norm())
+    print("discriminator weights, relative L2 after 160 steps:", rel)
+    assert torch.isfinite(da).all() and rel < 2e-3
+    assert torch.allclose(na, nb, rtol=1e-9, atol=1e-12) and lra == lrb

@@ -52,6 +52,17 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+dchain)    # the discriminator step's three chain launches (train_chain.DiscTrainChain): parity, the AMP tests, config 3 with / without
+    timeout 900 python -m pytest tests/test_train_chain.py -m gpu -x -q -s > $O/pytest_chain.log 2>&1; tail -6 $O/pytest_chain.log | cut -c1-400
+    timeout 1800 python -m pytest tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_disc_step_tail.py tests/test_distributed_gpu.py tests/test_hybrid_arm.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log | cut -c1-400
+    for i in 1 2; do
+      timeout 400 python bench.py --amp --no_cpu_baseline 2>$O/bench_amp_chain.err < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_$i.json
+      QA_DISC_TRAIN_CHAIN=0 timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_autograd_$i.json
+    done
+    timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_chain.json
+    QA_DISC_TRAIN_CHAIN=0 timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_autograd.json
+    line $O/bench_*.json
+    ;;
 *) echo "unknown case $C"; exit 2;;
 esac
 ls -la $O
