@@ -417,10 +417,7 @@ QA_DEV void row_load(float *priv, int base, Row &r) {
 // against the state x = (ub0 ub1 | ub2 ub3 | ub4 ub5 | w0 w1 | w2 1): residual = sum of both halves of sum_i j_i x_i (5 packed ops + 2),
 // update x_i += m_i dl (5 packed ops) -- 15 instructions per row instead of 25.  The SLP vectoriser is still off for this file (its
 // ad-hoc packing costs more moves than it saves, __graft_entry__.py); here the data is laid out in pairs from the start.
-// -DQA_PGS_SCALAR builds the round-4 scalar rows and sweeps instead (A/B measurements; same mathematics, different rounding order).
-#ifndef QA_PGS_SCALAR
-#define QA_PGS_PACKED 1
-#endif
+// (the round-4 scalar rows and sweeps, 85 us against 69 us per launch, were removed in r6: profiles/r5_env_step_packed_vs_scalar.txt has the A/B.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 QA_DEV f2 f2s(float s) { return f2{s, s}; }
@@ -526,7 +523,6 @@ QA_DEV void prow_load(const float *rec, PRow &r) {
     r.j[0] = f2{a.x, a.y}; r.j[1] = f2{a.z, a.w}; r.j[2] = f2{b.x, b.y}; r.j[3] = f2{b.z, b.w}; r.j[4] = f2{c.x, c.y};
     r.m[0] = f2{c.z, c.w}; r.m[1] = f2{d.x, d.y}; r.m[2] = f2{d.z, d.w}; r.m[3] = f2{e.x, e.y}; r.m[4] = f2{e.z, 0.f}; r.dinv = e.w;
 }
-#ifdef QA_PGS_PACKED
 QA_DEV float *priv_of(float *s_priv, int tix) { return s_priv + tix * QA_PRIV_FLOATS; }
 // env-step persistents parked between substeps (act3 sp3 sd3 binert10) as five 16-byte records at QA_PRIV_STEP
 QA_DEV void priv_park(float *priv, const float *act, const float *sp, const float *sd, const float *bi) {
@@ -540,22 +536,6 @@ QA_DEV void priv_unpark(const float *priv, float *act, float *sp, float *sd, flo
     act[0] = a.x; act[1] = a.y; act[2] = a.z; sp[0] = a.w; sp[1] = b.x; sp[2] = b.y; sd[0] = b.z; sd[1] = b.w; sd[2] = c.x;
     bi[0] = c.y; bi[1] = c.z; bi[2] = c.w; bi[3] = d.x; bi[4] = d.y; bi[5] = d.z; bi[6] = d.w; bi[7] = e.x; bi[8] = e.y; bi[9] = e.z;
 }
-#else
-QA_DEV float *priv_of(float *s_priv, int tix) { return s_priv + tix; }
-QA_DEV void priv_park(float *priv, const float *act, const float *sp, const float *sd, const float *bi) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { lr(priv, QA_PRIV_STEP + k) = act[k]; lr(priv, QA_PRIV_STEP + 3 + k) = sp[k]; lr(priv, QA_PRIV_STEP + 6 + k) = sd[k]; }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) lr(priv, QA_PRIV_STEP + 9 + i) = bi[i];
-}
-QA_DEV void priv_unpark(const float *priv, float *act, float *sp, float *sd, float *bi) {
-    float *pp = const_cast<float *>(priv);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { act[k] = lr(pp, QA_PRIV_STEP + k); sp[k] = lr(pp, QA_PRIV_STEP + 3 + k); sd[k] = lr(pp, QA_PRIV_STEP + 6 + k); }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) bi[i] = lr(pp, QA_PRIV_STEP + 9 + i);
-}
-#endif
 
 // Helper wavefronts (qa_env_step_kernel<..., HELP>): with one wavefront per CU three SIMDs of every CU idle, and the front half of a substep is
 // three chains that meet only at the rows -- (composite inertias -> Schur complement), (bias forces), (contact candidates); all three need
@@ -574,16 +554,12 @@ QA_DEV void mail_get_state(const f4 *m, EnvState &st) {
     st.q[0] = d.y; st.q[1] = d.z; st.q[2] = d.w; st.qd[0] = e.x; st.qd[1] = e.y; st.qd[2] = e.z;
 }
 
-#ifndef QA_PGS_SCALAR
-// QA_HELP_ROWS (default on with helper wavefronts): the contact helper also builds the rows of the lane's non-foot contacts -- up to six rows, in the
+// With helper wavefronts the contact helper also builds the rows of the lane's non-foot contacts -- up to six rows, in the
 // lane's LDS records where the sweeps read them anyway -- from the solve data (G, Binv, Linv in pairs: 63 floats as 16 records) the env's wavefront
 // mails at the second barrier; a third barrier in front of the sweeps.
-#ifndef QA_HELP_ROWS
-#define QA_HELP_ROWS 1
-#endif
 #define QA_MAIL_PS 11                    // first record of the solve data in a lane's mail
 #undef QA_MAIL_F4
-#define QA_MAIL_F4 (QA_HELP_ROWS ? 29 : 13)
+#define QA_MAIL_F4 29
 QA_DEV void mail_put_solve(f4 *m, const PSolve &S) {
     const f2 *g = &S.G2[0][0], *b = &S.Bc[0][0];
     // 9 + 18 + 3 pairs = 30 pairs = 15 records, + L2 (3 floats)
@@ -612,7 +588,6 @@ QA_DEV void mail_get_solve(const f4 *m, PSolve &S) {
     const f4 l = m[QA_MAIL_PS + 15];
     S.L2[0] = l.x; S.L2[1] = l.y; S.L2[2] = l.z;
 }
-#endif
 
 template <bool PLANE, int ROLE = 0>
 QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, const float *binert, const float tau[3],
@@ -670,9 +645,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     if (ROLE == 2) {
         mail[5] = f4{hl[0], hl[1], hl[2], f0.a.x}; mail[6] = f4{f0.a.y, f0.a.z, f0.l.x, f0.l.y}; mail[7] = f4{f0.l.z, 0.f, 0.f, 0.f};
         __syncthreads();
-#if defined(QA_PGS_PACKED) && QA_HELP_ROWS
         __syncthreads();                                     // (the contact helper's rows)
-#endif
         return;
     }
     QA_SUBSTAMP(6);
@@ -774,21 +747,10 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         slink[0] = g0; slink[1] = g1;
         extra_on[0] = g0 >= 0; extra_on[1] = g1 >= 0;
         any_extra[0] = __any(extra_on[0]); any_extra[1] = __any(extra_on[1]);
-#ifdef QA_EXP_NO_EXTRA
-        extra_on[0] = extra_on[1] = any_extra[0] = any_extra[1] = false;
-#endif
-#ifdef QA_EXP_COUNT_EXTRA
-        {
-            const bool real = __any((extra_on[0] && sgap[0] <= 0.f) || (extra_on[1] && sgap[1] <= 0.f));
-            const bool near2 = __any((extra_on[0] && sgap[0] <= 0.002f) || (extra_on[1] && sgap[1] <= 0.002f));
-            if (g_subprof && threadIdx.x == 0) { g_subprof[blockIdx.x * 32 + 30] += any_extra[0] ? 1 : 0; g_subprof[blockIdx.x * 32 + 31] += real ? 1 : 0; g_subprof[blockIdx.x * 32 + 29] += near2 ? 1 : 0; }
-        }
-#endif
     }
 
-#ifdef QA_PGS_PACKED
     // ---- the rows of the lane's non-foot contacts (built by whoever holds the solve data PS: the one-wavefront substep and the env's wavefront
-    // further down, or -- QA_HELP_ROWS -- the contact helper right here, from the mail)
+    // further down, or the contact helper right here, from the mail)
     PSolve PS;
     float re_lam[QA_EXTRA_SLOTS][3];
     float ex_ca[QA_EXTRA_SLOTS]; int ex_ob[QA_EXTRA_SLOTS];
@@ -815,18 +777,15 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
             }
         }
     };
-#endif
     if (ROLE == 3) {
         mail[8] = f4{foot_gap, foot_p.x, foot_p.y, foot_p.z};
         mail[9] = f4{sgap[0], sgap[1], __int_as_float(scode[0]), __int_as_float(scode[1])};
         mail[10] = f4{__int_as_float(slink[0]), __int_as_float(slink[1]), 0.f, 0.f};
         __syncthreads();
-#if defined(QA_PGS_PACKED) && QA_HELP_ROWS
         mail_get_solve(mail, PS);                            // the env's wavefront wrote it in front of the barrier
 #pragma unroll
         for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) extra_rows(sl, true);
         __syncthreads();                                     // the rows are in the lane's LDS records: the sweeps may start
-#endif
         return;
     }
     QA_SUBSTAMP(2);
@@ -872,12 +831,8 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     Bm[SIDX(5, 0)] += tot.h.y; Bm[SIDX(5, 1)] += -tot.h.x;
     float Binv[21];
     spd6_inverse(Bm, Binv);
-#ifdef QA_PGS_PACKED
     psolve_make(PS, G, Linv, Binv);
-#if QA_HELP_ROWS
     if (ROLE == 1) mail_put_solve(mail, PS);
-#endif
-#endif
     if (ROLE == 1) {
         __syncthreads();                                     // the helpers' results of THIS substep are in the mail
         const f4 a = mail[5], b = mail[6], c = mail[7], d = mail[8], e = mail[9], g = mail[10];
@@ -917,7 +872,6 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         }
     }
 
-#ifdef QA_PGS_PACKED
     QA_SUBSTAMP(7);
     // ---- rows, packed (see PRow): foot rows in registers; the extra slots' and the self-collision rows in the lane's LDS records, built only
     // when some env of the wavefront needs them
@@ -930,7 +884,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     // costs ~8 scalar instructions of exec-mask bookkeeping per block and saves nothing (the idle lanes' slots are issued anyway).
     rf[0].j[4].y = foot_on ? rf[0].j[4].y : QA_OPEN_BIAS;
 #pragma unroll
-    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) extra_rows(sl, !(ROLE == 1 && QA_HELP_ROWS));      // with helpers: the contact helper is building them meanwhile
+    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) extra_rows(sl, ROLE != 1);      // with helpers: the contact helper is building them meanwhile
     // ---- self-collision rows: partner 0 = lane ^ 1 (left / right), partner 1 = lane ^ 2 (front / rear).  Both lanes of a pair evaluate the
     // SAME expressions on the same (canonically ordered) segments, so they agree bit for bit on gap, normal and effective mass.  This path is
     // rare (4e-6 of the env-steps of a training run) and stays in scalar arithmetic; only its LDS record is the packed one.
@@ -1028,7 +982,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
         for (int q = 0; q < 3; ++q) x[q] += f2{quad_sum(dx[q].x), quad_sum(dx[q].y)};
         x[3] = dx[3]; x[4] = dx[4];
     }
-    if (ROLE == 1 && QA_HELP_ROWS) __syncthreads();         // the contact helper's rows of this substep are in the lane's LDS records
+    if (ROLE == 1) __syncthreads();         // the contact helper's rows of this substep are in the lane's LDS records
     QA_SUBSTAMP(4);
     // ---- projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs {FL, RR} and {FR, RL} are
     // updated from the same base velocity and their base-velocity changes are summed; colours follow each other Gauss-Seidel fashion.  Every
@@ -1060,11 +1014,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                     t[0].lam = re_lam[sl][0];
                     const float lam_try = fmaxf(fmaf(-prow_residual(t[0], x2), t[0].dinv, t[0].lam), 0.f);
                     const bool live = lam_try != 0.f || t[0].lam != 0.f || re_lam[sl][1] != 0.f || re_lam[sl][2] != 0.f;
-#ifdef QA_PGS_NO_SKIP
-                    if (true) {
-#else
                     if (__any(live)) {
-#endif
                         prow_load(priv + QA_PRIV_EXTRA + 60 * sl + 20, t[1]); prow_load(priv + QA_PRIV_EXTRA + 60 * sl + 40, t[2]);
                         t[1].lam = re_lam[sl][1]; t[2].lam = re_lam[sl][2];
                         pcontact_update(t, x2, mu);
@@ -1083,11 +1033,7 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
                         const float res = fmaf(lim_sgn[k], uk, lim_bias[k]);
                         const float lam = fmaxf(fmaf(-res, lim_dinv[k], lim_lam[k]), 0.f);
                         const float dl = lam - lim_lam[k];
-#ifdef QA_PGS_NO_SKIP
-                        if (true) {
-#else
                         if (__any(dl != 0.f)) {          // a joint inside the margin but not at its stop: nothing to apply (exact skip, as above)
-#endif
                             lim_lam[k] = mine ? lam : lim_lam[k];
 #pragma unroll
                             for (int q = 0; q < 3; ++q) x2[q] = pfma(lim_m[k][q], f2s(dl), x2[q]);
@@ -1144,225 +1090,6 @@ QA_DEV void phys_substep(EnvState &st, const float *tbl, const float *btbl, cons
     ub[0] = x[0].x; ub[1] = x[0].y; ub[2] = x[1].x; ub[3] = x[1].y; ub[4] = x[2].x; ub[5] = x[2].y;
     w[0] = x[3].x; w[1] = x[3].y; w[2] = x[4].x;
 
-#else
-    QA_SUBSTAMP(7);
-    // ---- rows (foot rows in registers; the extra slots' rows in LDS, built only when some env of the wavefront needs them)
-    Row rf[3];
-    V3 fn_b = nB, ft1_b = t1B, ft2_b = t2B, ft1_w = v3(1, 0, 0), ft2_w = v3(0, 1, 0);
-    if (!PLANE) { tangent_basis(foot_n, ft1_w, ft2_w); fn_b = mulT(R, foot_n); ft1_b = mulT(R, ft1_w); ft2_b = mulT(R, ft2_w); }
-    contact_rows(rf, foot_p, 3, foot_gap, o, ax, fn_b, ft1_b, ft2_b, G, Linv, Binv, P);
-    rf[0].bias -= foot_vs;                                  // a surface that moves along the normal (articulated obstacle)
-    float re_lam[QA_EXTRA_SLOTS][3];
-    float ex_ca[QA_EXTRA_SLOTS]; int ex_ob[QA_EXTRA_SLOTS];
-    V3 ex_n[QA_EXTRA_SLOTS];                                // world-frame normals of the extra contacts (height field)
-    int ex_body[QA_EXTRA_SLOTS];
-#pragma unroll
-    for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
-        re_lam[sl][0] = re_lam[sl][1] = re_lam[sl][2] = 0.f; ex_n[sl] = v3(0, 0, 1); ex_body[sl] = -1; ex_ca[sl] = 0.f; ex_ob[sl] = -1;
-        if (any_extra[sl]) {
-            V3 p; int depth;
-            const int code = scode[sl], link = max(slink[sl], 0);
-            if (code >= 64) { const float *pt = btbl + 4 * (code - 64); p = v3(pt[0], pt[1], pt[2]); depth = 0; ex_body[sl] = (code - 64) < 8 ? 0 : ((code - 64) < 10 ? 1 : 2); }
-            else { p = leg_point(code > 0 ? code : 1, link); depth = link + 1; ex_body[sl] = 3 + 4 * leg + link; }
-            Row re[3];
-            V3 en_b = nB, et1_b = t1B, et2_b = t2B;
-            float ex_vs = 0.f;
-            if (!PLANE) {
-                (void)contact_query(T, dot(t1B, p) + st.pos.x, dot(t2B, p) + st.pos.y, dot(nB, p) + st.pos.z, 0.f, ex_n[sl], ex_vs, ex_ca[sl], ex_ob[sl]);   // the winner's normal: floor or ceiling (both gaps carry the same -r, so the radius does not decide which is nearer)
-                V3 a, b; tangent_basis(ex_n[sl], a, b); en_b = mulT(R, ex_n[sl]); et1_b = mulT(R, a); et2_b = mulT(R, b);
-            }
-            contact_rows(re, p, depth, sgap[sl], o, ax, en_b, et1_b, et2_b, G, Linv, Binv, P);
-            re[0].bias -= ex_vs;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) row_store(priv, QA_PRIV_EXTRA + 60 * sl + 20 * d, re[d]);
-        }
-    }
-    // ---- self-collision rows: partner 0 = lane ^ 1 (left / right), partner 1 = lane ^ 2 (front / rear).  Both lanes of a pair evaluate the
-    // SAME expressions on the same (canonically ordered) segments, so they agree bit for bit on gap, normal and effective mass.
-    bool sc_on[2] = {false, false}, any_sc[2] = {false, false}, sc_low[2] = {false, false};
-    float sc_lam[2] = {0.f, 0.f};
-    V3 sc_nw[2];
-    if (P.self_collision) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const V3 a0 = o[2], a1 = foot_p;
-            V3 b0, b1;
-            if (pr == 0) { b0 = v3(dpp_f<0xB1>(a0.x), dpp_f<0xB1>(a0.y), dpp_f<0xB1>(a0.z)); b1 = v3(dpp_f<0xB1>(a1.x), dpp_f<0xB1>(a1.y), dpp_f<0xB1>(a1.z)); }
-            else { b0 = v3(dpp_f<0x4E>(a0.x), dpp_f<0x4E>(a0.y), dpp_f<0x4E>(a0.z)); b1 = v3(dpp_f<0x4E>(a1.x), dpp_f<0x4E>(a1.y), dpp_f<0x4E>(a1.z)); }
-            const bool low = pr == 0 ? ((leg & 1) == 0) : ((leg & 2) == 0);          // this lane holds the pair's first capsule
-            const V3 A0 = low ? a0 : b0, A1 = low ? a1 : b1, B0 = low ? b0 : a0, B1 = low ? b1 : a1;
-            float sa, tb; segment_closest(A0, A1, B0, B1, sa, tb);
-            const V3 pA = A0 + sa * (A1 - A0), pB = B0 + tb * (B1 - B0), dv = pA - pB;
-            const float dist = sqrtf(dot(dv, dv));
-            const V3 nrm = dist > 1e-6f ? (1.0f / dist) * dv : v3(0.f, 1.f, 0.f);
-            const float gap = dist - (QA_CALF_RADIUS + sa * (QA_FOOT_RADIUS - QA_CALF_RADIUS)) - (QA_CALF_RADIUS + tb * (QA_FOOT_RADIUS - QA_CALF_RADIUS));
-            sc_on[pr] = gap < P.contact_offset; sc_low[pr] = low;
-            any_sc[pr] = __any(sc_on[pr]);
-            sc_nw[pr] = low ? nrm : v3(-nrm.x, -nrm.y, -nrm.z);          // base frame: direction of the force on THIS leg
-            if (any_sc[pr]) {
-                Row r;
-                const V3 pm = low ? pA : pB;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) r.jl[k] = dot(sc_nw[pr], cross(ax[k], pm - o[k]));
-                float h[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) h[i] = G[0 * 6 + i] * r.jl[0] + G[1 * 6 + i] * r.jl[1] + G[2 * 6 + i] * r.jl[2];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) r.jh[i] = h[i] + (pr == 0 ? dpp_f<0xB1>(h[i]) : dpp_f<0x4E>(h[i]));
-                sym6_mul(Binv, r.jh, r.bj);
-                r.lj[0] = Linv[0] * r.jl[0] + Linv[1] * r.jl[1] + Linv[2] * r.jl[2];
-                r.lj[1] = Linv[1] * r.jl[0] + Linv[3] * r.jl[1] + Linv[4] * r.jl[2];
-                r.lj[2] = Linv[2] * r.jl[0] + Linv[4] * r.jl[1] + Linv[5] * r.jl[2];
-                const float dleg = r.jl[0] * r.lj[0] + r.jl[1] * r.lj[1] + r.jl[2] * r.lj[2];
-                float d = dleg + (pr == 0 ? dpp_f<0xB1>(dleg) : dpp_f<0x4E>(dleg));
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d = fmaf(r.jh[i], r.bj[i], d);
-                r.dinv = 1.0f / (d + QA_CFM);
-                const float g = gap / dt;
-                r.bias = gap >= 0.f ? g : fmaxf(g, -P.max_depen);
-                row_store(priv, QA_PRIV_SELF + 20 * pr, r);
-            }
-        }
-    }
-    // joint limits: at most one stop per joint can be within the margin
-    float lim_sgn[3], lim_bias[3], lim_lam[3], lim_bj[3][6], lim_dinv[3];   // registers: these rows run in most waves
-    bool lim_on[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float glo = st.q[k] - tbl[T_LOWER + k], ghi = tbl[T_UPPER + k] - st.q[k];
-        bool lo = glo < QA_LIMIT_MARGIN, hi = !lo && (ghi < QA_LIMIT_MARGIN);
-        lim_on[k] = lo || hi;
-        lim_sgn[k] = lo ? 1.f : -1.f;
-        float gap = lo ? glo : ghi, g = gap / dt;
-        lim_bias[k] = gap >= 0.f ? g : fmaxf(g, -QA_LIMIT_DEPEN);
-        lim_lam[k] = 0.f;
-    }
-    const bool any_lim = __any(lim_on[0] || lim_on[1] || lim_on[2]);
-    if (any_lim) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            // jl = sgn e_k  =>  jh = sgn G[k,:],  lj = sgn Linv[:,k]
-            float jh[6], bj[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) jh[i] = lim_sgn[k] * G[k * 6 + i];
-            sym6_mul(Binv, jh, bj);
-            float lkk = (k == 0) ? Linv[0] : (k == 1 ? Linv[3] : Linv[5]);
-            float d = lkk;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { d = fmaf(jh[i], bj[i], d); lim_bj[k][i] = bj[i]; }
-            lim_dinv[k] = 1.0f / (d + QA_CFM);
-        }
-    }
-
-    QA_SUBSTAMP(8);
-    // ---- warm start: the foot rows start from the previous substep's impulses, applied to (ub, w) first
-    {
-        float dub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float l0 = foot_on ? fimp[d] : 0.f;
-            rf[d].lam = l0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) dub[i] = fmaf(rf[d].bj[i], l0, dub[i]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w[k] = fmaf(rf[d].lj[k], l0, w[k]);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ub[i] += quad_sum(dub[i]);
-    }
-    QA_SUBSTAMP(4);
-    // ---- projected Gauss-Seidel with a two-colour ordering over the legs: the diagonal pairs
-    // {FL, RR} and {FR, RL} are updated from the same base velocity (their coupling through the base is weak: the
-    // lever arms cancel in the rotational term) and their base-velocity changes are quad-summed; colours follow each
-    // other Gauss-Seidel fashion.  2 serial passes per sweep instead of 4; every lane runs its own rows in both
-    // passes and only the lanes of the active colour commit.
-    const bool any_foot = __any(foot_on);
-    const bool colour_a = (leg == 0) || (leg == 3);
-    for (int it = 0; it < P.iters; ++it) {
-#pragma unroll
-        for (int colour = 0; colour < 2; ++colour) {
-            const bool mine = (colour == 0) == colour_a;
-            float ub2[6], w2[3];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ub2[i] = ub[i];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w2[k] = w[k];
-            if (any_foot) {
-                if (foot_on) {
-                    const float l0 = rf[0].lam, l1 = rf[1].lam, l2 = rf[2].lam;
-                    contact_update(rf, ub2, w2, mu);
-                    if (!mine) { rf[0].lam = l0; rf[1].lam = l1; rf[2].lam = l2; }
-                }
-            }
-#pragma unroll
-            for (int sl = 0; sl < QA_EXTRA_SLOTS; ++sl) {
-                if (any_extra[sl]) {
-                    if (extra_on[sl]) {
-                        Row t[3];
-                        row_load(priv, QA_PRIV_EXTRA + 60 * sl, t[0]); row_load(priv, QA_PRIV_EXTRA + 60 * sl + 20, t[1]); row_load(priv, QA_PRIV_EXTRA + 60 * sl + 40, t[2]);
-                        t[0].lam = re_lam[sl][0]; t[1].lam = re_lam[sl][1]; t[2].lam = re_lam[sl][2];
-                        contact_update(t, ub2, w2, mu);
-                        if (mine) { re_lam[sl][0] = t[0].lam; re_lam[sl][1] = t[1].lam; re_lam[sl][2] = t[2].lam; }
-                    }
-                }
-            }
-            if (any_lim) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    if (lim_on[k]) {
-                        // residual = bias + sgn * u_k,   u_k = w_k + G[k,:] ub
-                        float uk = w2[k];
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) uk = fmaf(G[k * 6 + i], ub2[i], uk);
-                        float res = lim_bias[k] + lim_sgn[k] * uk;
-                        float lam = fmaxf(lim_lam[k] - res * lim_dinv[k], 0.f);
-                        float dl = lam - lim_lam[k];
-                        if (mine) lim_lam[k] = lam;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) ub2[i] = fmaf(lim_bj[k][i], dl, ub2[i]);
-                        float sd = lim_sgn[k] * dl;
-                        w2[0] = fmaf(k == 0 ? Linv[0] : (k == 1 ? Linv[1] : Linv[2]), sd, w2[0]);
-                        w2[1] = fmaf(k == 0 ? Linv[1] : (k == 1 ? Linv[3] : Linv[4]), sd, w2[1]);
-                        w2[2] = fmaf(k == 0 ? Linv[2] : (k == 1 ? Linv[4] : Linv[5]), sd, w2[2]);
-                    }
-                }
-            }
-            // commit: lanes of the active colour keep their w; the base takes the SUM of their velocity changes
-            if (mine) { w[0] = w2[0]; w[1] = w2[1]; w[2] = w2[2]; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ub[i] += quad_sum(mine ? (ub2[i] - ub[i]) : 0.f);
-        }
-        // self-collision pairs: the two left/right pairs from the same base velocity (their base-velocity changes summed, one lane of a
-        // pair reporting it), then the two front/rear pairs
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            if (any_sc[pr]) {
-                float dub[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (sc_on[pr]) {
-                    Row r; row_load(priv, QA_PRIV_SELF + 20 * pr, r);
-                    const float tl = r.jl[0] * w[0] + r.jl[1] * w[1] + r.jl[2] * w[2];
-                    // own + partner term FIRST: the sum is commutative, so both lanes of the pair hold identical bits before the (identical) bias
-                    // and base chain are added -- (bias + own) + partner rounds differently on the two sides and lets their lam drift apart
-                    const float tls = tl + (pr == 0 ? dpp_f<0xB1>(tl) : dpp_f<0x4E>(tl));
-                    float res = r.bias + tls;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) res = fmaf(r.jh[i], ub[i], res);
-                    const float lam = fmaxf(sc_lam[pr] - res * r.dinv, 0.f), dl = lam - sc_lam[pr];
-                    sc_lam[pr] = lam;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) w[k] = fmaf(r.lj[k], dl, w[k]);
-                    if (sc_low[pr]) {
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) dub[i] = r.bj[i] * dl;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) ub[i] += quad_sum(dub[i]);
-            }
-        }
-    }
-
-#endif
     QA_SUBSTAMP(9);
     // ---- leg velocity, clamp, integrate
     float ul[3];

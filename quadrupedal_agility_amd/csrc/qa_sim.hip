@@ -125,9 +125,6 @@ static int fail_hip(hipError_t e, const char *what) {
 // (b) that the compiler does not move LDS accesses across the point.  __syncthreads() would additionally wait for
 // vmcnt(0), i.e. drain every outstanding global load and store at each exchange -- 8 full memory drains in the
 // observation phase alone.
-#ifndef QA_HELP_SCALARS
-#define QA_HELP_SCALARS 1                // with helper wavefronts: the step's closing scalar stores by the contact helper (0: by the env's own wavefront, A/B builds)
-#endif
 #ifndef QA_ENV_HELPERS_DEFAULT
 #define QA_ENV_HELPERS_DEFAULT (-1)      // -1: by launch size (launch_env_step), 0: never, 1: always
 #endif
@@ -679,7 +676,7 @@ __device__ __forceinline__ void post_physics_phase(const qa_config &c, const Ptr
         w[SO_FFN] = ffn; w[SO_CONTACT] = __int_as_float((int)contact); w[SO_CFILT] = __int_as_float((int)cfilt);
 #pragma unroll
         for (int r = 0; r < QA_NUM_REWARDS; ++r) w[SO_ESUM + r] = esum[r];
-        if (HELP && QA_HELP_SCALARS) {
+        if (HELP) {
 #pragma unroll
             for (int i = 0; i < SO_WORDS / 4; ++i) mail[i] = f4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
         } else {
@@ -770,57 +767,9 @@ QA_DEV void shift_history_store(const Ptrs &p, int bix, int lane, int N, float (
     }
 }
 
-// The stores with a scalar row base + one lane offset (saddr form): issued INSIDE the substep loop (QA_STORE_BEFORE_LAST) the 64-bit per-row
-// addresses of the form above are loop invariants the compiler hoists -- 32 VGPRs across the loop, 74 spilled values
-#define QA_HSTORE_S(voff, src, base, OFF) asm volatile("global_store_dword %0, %1, %2 offset:" #OFF :: "v"(voff), "a"(src), "s"(base) : "memory")
-template <int EPB>
-QA_DEV void shift_history_store_s(const Ptrs &p, int bix, int lane, int N, float (&hv)[EPB][9]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int voff = lane * 4;
-#pragma unroll
-    for (int g = 0; g < EPB; ++g) {
-        const int ge = bix * EPB + g;
-        if (ge < N) {
-            const uint64_t ra = (uint64_t)(p.obs + (int64_t)ge * QA_NUM_OBS + 90);
-            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ra);
-            QA_HSTORE_S(voff, hv[g][0], row, 0); QA_HSTORE_S(voff, hv[g][1], row, 256); QA_HSTORE_S(voff, hv[g][2], row, 512); QA_HSTORE_S(voff, hv[g][3], row, 768);
-            QA_HSTORE_S(voff, hv[g][4], row, 1024); QA_HSTORE_S(voff, hv[g][5], row, 1280); QA_HSTORE_S(voff, hv[g][6], row, 1536); QA_HSTORE_S(voff, hv[g][7], row, 1792);
-            if (lane == 0) QA_HSTORE_S(voff, hv[g][8], row, 2048);
-        }
-    }
-}
-// QA_HIST_X4: the same shift as two 16-byte accesses + one dword per lane and row (rows are only 4-byte aligned, 671 floats: the accesses are
-// dword-aligned 16-byte ones, which the unaligned access mode of HSA queues permits) -- 48 memory instructions per wavefront and direction
-// instead of 144
-#define QA_HLOAD4(dst, ptr, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=a"(dst) : "v"(ptr) : "memory")
-#define QA_HSTORE4(voff, src, base, OFF) asm volatile("global_store_dwordx4 %0, %1, %2 offset:" #OFF :: "v"(voff), "a"(src), "s"(base) : "memory")
-struct HistRegs4 { f4 q[QA_BLOCK / 4][2]; float last[QA_BLOCK / 4]; };
-template <int EPB>
-QA_DEV void shift_history_load4(const Ptrs &p, int bix, int lane, int N, HistRegs4 &h) {
-#pragma unroll
-    for (int g = 0; g < EPB; ++g) {
-        const int ge = min(bix * EPB + g, N - 1);
-        const float *hist = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + 4 * lane;
-        QA_HLOAD4(h.q[g][0], hist, 0); QA_HLOAD4(h.q[g][1], hist, 1024);
-        const float *last = p.obs + (int64_t)ge * QA_NUM_OBS + 90 + 57 + 512;          // float 512 of the 513: every lane reads it, lane 0 stores it
-        QA_HLOAD(h.last[g], last, 0);
-    }
-}
-template <int EPB>
-QA_DEV void shift_history_store4(const Ptrs &p, int bix, int lane, int N, HistRegs4 &h) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int voff = lane * 16;
-#pragma unroll
-    for (int g = 0; g < EPB; ++g) {
-        const int ge = bix * EPB + g;
-        if (ge < N) {
-            const uint64_t ra = (uint64_t)(p.obs + (int64_t)ge * QA_NUM_OBS + 90);
-            const uint64_t row = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ra >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ra);
-            QA_HSTORE4(voff, h.q[g][0], row, 0); QA_HSTORE4(voff, h.q[g][1], row, 1024);
-            if (lane == 0) QA_HSTORE_S(voff, h.last[g], row, 2048);
-        }
-    }
-}
+// (r6: the variants that lost their A/B -- stores inside the substep loop through a scalar row base, 16-byte history accesses, the history stores in
+// front of the physics, the constant table staged in two halves, sweeps without the idle-row early-outs -- were deleted with their switches; what each
+// measured is in DESIGN.md 4.1c / 9 and profiles/r5_env_step_*.txt.)
 
 // MODE 0: the whole LeggedRobot.step of the behaviour-level (BBC) tree.  MODE 1: the physics part only -- action-history
 // roll, delay, clip, decimation x (PD torque -> substep), refresh of the simulator tensors -- for the task-level (TSC) env,
@@ -857,7 +806,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
     const qa_config &c = a.c;
     const Ptrs &p = a.p;
     const int N = c.num_envs;
-    // r5: the history shift's 144 loads per lane are issued here and its stores AFTER the physics (QA_SHIFT_EARLY_STORE restores r2's
+    // r5: the history shift's 144 loads per lane are issued here and its stores AFTER the physics (r2 had a
     // load -> stage table -> store prologue).  All 256 wavefronts of a 4096-env launch start together, so the prologue's 17 MB read + 17 MB
     // write was a burst nobody overlapped: 9.7 k of the kernel's 136 k ticks waiting for it (profiles/r5_env_step_phase_profile.txt).  The
     // values wait in registers the substeps do not use (the compiler parks them in AGPRs: 2 x 144 v_accvgpr moves, ~1.3 k ticks).
@@ -879,13 +828,8 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         // the same rows (the new frame in slot 9, the refill of a reset env's slots): the stores have been acknowledged (vmcnt 0) before the
         // workgroup's last barrier, which the env's wavefront passes before it writes a row.
         if (role == 2) stage_table(s_tbl);                     // (the env's wavefront meets it behind the first barrier)
-#ifdef QA_HIST_X4
-        HistRegs4 hvh;
-        if (role == 1) shift_history_load4<EPB>(a.p, bix, tix, c.num_envs, hvh);
-#else
         float hvh[EPB][9];
         if (role == 1) shift_history_load<EPB>(a.p, bix, tix, c.num_envs, hvh);
-#endif
         for (int d = 0; d < c.decimation; ++d) {
             __syncthreads();                                   // the state of this substep is in the mail (first time: the table and the parked persistents too)
             asm volatile("" ::: "memory");
@@ -898,16 +842,12 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
             // (~10 k cycles in which this helper has nothing to do): 17 MB of writes from 256 CUs need ~5 us to be acknowledged, and the env's
             // wavefront must not find itself waiting for that at the workgroup's last barrier
             if (role == 1 && d == (c.decimation > 1 ? c.decimation - 2 : 0)) {
-#ifdef QA_HIST_X4
-                shift_history_store4<EPB>(a.p, bix, tix, c.num_envs, hvh);
-#else
                 shift_history_store<EPB>(a.p, bix, tix, c.num_envs, hvh);
-#endif
             }
         }
         if (role == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // the rows' history is in place: the env's wavefront may write them
-        if (role == 2 && QA_HELP_SCALARS) {                    // ... and its scalars are in the mail: the idle contact helper stores them
+        if (role == 2) {                    // ... and its scalars are in the mail: the idle contact helper stores them
             ScalarOut so;
 #pragma unroll
             for (int i = 0; i < SO_WORDS / 4; ++i) { const f4 v = mail[i]; so.w[4 * i] = v.x; so.w[4 * i + 1] = v.y; so.w[4 * i + 2] = v.z; so.w[4 * i + 3] = v.w; }
@@ -917,34 +857,9 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         return;
     }
     float hv[EPB][9];
-#ifdef QA_HIST_X4
-    HistRegs4 hv4;
-    static_assert(EPB == QA_BLOCK / 4, "HistRegs4 is sized for one quad per env");
-#define QA_SHIFT_LOAD() shift_history_load4<EPB>(p, bix, tix, N, hv4)
-#define QA_SHIFT_STORE() shift_history_store4<EPB>(p, bix, tix, N, hv4)
-#else
 #define QA_SHIFT_LOAD() shift_history_load<EPB>(p, bix, tix, N, hv)
-#ifdef QA_STORE_BEFORE_LAST
-#define QA_SHIFT_STORE() shift_history_store_s<EPB>(p, bix, tix, N, hv)
-#else
 #define QA_SHIFT_STORE() shift_history_store<EPB>(p, bix, tix, N, hv)
-#endif
-#endif
-#ifdef QA_SHIFT_EARLY_STORE
-    if (MODE == 0 && LPE == 4) {
-        shift_history_load<EPB>(p, bix, tix, N, hv);
-        stage_table(s_tbl);
-        shift_history_store<EPB>(p, bix, tix, N, hv);
-    } else
-#endif
-#ifdef QA_SPLIT_TABLE
-    // the table's loads go out first and its LDS writes wait until the step's other loads (actions, state, the post-physics inputs) are in
-    // flight too: one memory round trip in front of the physics instead of two
-    float tblv[QA_TBL_PER];
-    stage_table_load(tblv);
-#else
     if (!HELP) stage_table(s_tbl);
-#endif
     const int tid = bix * QA_BLOCK + tix;
     const int leg = LPE == 4 ? (tix & 3) : ((tix >> 2) & 3);
     const int sub = LPE == 4 ? 0 : (tix & 3);
@@ -1047,9 +962,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         if (c.articulated_obstacles) { stage_obstacles(p, env, leg, ob_rec, T.ancx, T.ancy); T.ob = ob_rec; T.ob_acc = ob_rec + 12 * QA_OBST_PER_ENV; }
         wave_lds_sync();
     }
-#ifdef QA_SPLIT_TABLE
-    stage_table_store(s_tbl, tblv);
-#endif
     // env-local horizontal coordinates for the substeps (TerrainView): offsets from the world position the step starts at
     const float anc_x = st.pos.x, anc_y = st.pos.y;
     st.pos.x = 0.f; st.pos.y = 0.f;
@@ -1065,7 +977,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
     float fimp[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) fimp[k] = p.foot_impulse[(int64_t)env * 12 + 3 * leg + k];
-#ifndef QA_SHIFT_EARLY_STORE
     // the history loads go out LAST, behind every load the substeps wait for: the wait counter is in-order (and 6 bits wide), so loads issued
     // in front of the state's would have to land before the physics could start; nothing waits for these until the stores after the loop
     if (MODE == 0 && LPE == 4) {
@@ -1079,7 +990,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
         }
         if (!HELP) QA_SHIFT_LOAD();
     }
-#endif
     for (int d = 0; d < c.decimation; ++d) {
         // compiler fence: without it LICM hoists the ~120 loop-invariant LDS table reads of the substep out of this
         // loop and keeps them in registers across it, which is what pushed the kernel into scratch
@@ -1099,11 +1009,6 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
             float lim = tbl[T_EFFORT + k];
             tau[k] = clampf(t, -lim, lim);
         }
-#ifdef QA_STORE_BEFORE_LAST
-        // the history shift's stores go out in front of the LAST substep (the loads landed substeps ago): 17 MB from 256 wavefronts at once
-        // drain beside ~12 us of arithmetic instead of in front of the tail's own stores
-        if (MODE == 0 && LPE == 4 && !HELP && d == c.decimation - 1) QA_SHIFT_STORE();
-#endif
         phys_substep<PLANE, HELP ? 1 : 0>(st, tbl, btbl, bi, tau, mu, leg, P, co, priv, fimp, T, mail);
     }
     { float bi_[10]; priv_unpark(priv, act, sp, sd, bi_); }
@@ -1123,9 +1028,7 @@ __global__ void __launch_bounds__(QA_BLOCK * (HELP ? 3 : 1)) qa_env_step_kernel(
     }
 
     QA_STAMP(3);
-#if !defined(QA_SHIFT_EARLY_STORE) && !defined(QA_STORE_BEFORE_LAST)
     if (MODE == 0 && LPE == 4 && !HELP) QA_SHIFT_STORE();     // in place: every lane loaded its 9 values of a row long ago; the tail's writes to the same rows come after these in program order
-#endif
     // ---- refresh_*: body positions of the new state, contact forces per body
     V3 org[4];
     leg_origins(st.q, tbl, org);

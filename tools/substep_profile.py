@@ -27,6 +27,3 @@ for _ in range(K):
 names = ["kinematics+link inertia", "composite+F+L", "bias (RNEA)", "Linv,G,Schur,6x6 inverse", "unconstrained vel", "contact candidates", "rows", "warm start", "PGS sweeps", "integrate"]
 for i in range(10): print(f"{names[i]:26s} {acc[i].item()/K:9.0f} cycles")
 print("substep total", acc.sum().item() / K)
-if "-DQA_EXP_COUNT_EXTRA" in sys.argv:
-    c = buf.view(-1, 32).cpu().double()[:, 29:32].sum(0) / (buf.numel() // 32 * K * 4)
-    print(f"fraction of (wavefront, substep) with a non-foot contact row somewhere in the wavefront: {c[1]:.3f}; with one at gap <= 0: {c[2]:.3f}; at gap <= 2 mm: {c[0]:.3f}")
