@@ -61,6 +61,11 @@ dchain)    # the discriminator step's three chain launches (train_chain.DiscTrai
     done
     timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_chain.json
     QA_DISC_TRAIN_CHAIN=0 timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_autograd.json
+    # where the PPO step's chain stops paying: 2048 envs (12,288-row minibatches) and the 4096-env headline (24,576 rows) with the row limit lifted
+    QA_TRAIN_CHAIN_MAX_ROWS=32768 timeout 300 python bench.py --num_envs 2048 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_2048_chain.json
+    timeout 300 python bench.py --num_envs 2048 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_2048_autograd.json
+    QA_TRAIN_CHAIN_MAX_ROWS=32768 timeout 400 python bench.py --no_cpu_baseline 2>$O/bench_4096_chain.err < /dev/null | grep '"metric"' > $O/bench_cfg2_4096_chain.json
+    timeout 400 python bench.py --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_4096_autograd.json
     line $O/bench_*.json
     ;;
 *) echo "unknown case $C"; exit 2;;
