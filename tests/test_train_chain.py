@@ -138,9 +138,9 @@ def test_hip_chain_equals_autograd(rows):
     assert fused.pending_grads() == 0
     torch.cuda.synchronize()
     _check_grads(ref, got, 3e-4, "parts")
-    for a, b in zip(first, got):          # the same partial products, added in the same order by either finish
+    for a, b in zip(first, got):          # the same partial products, added by either finish (qa_slab_reduce / qa_grad_reduce: fixed orders, not the same one)
         if a is not None:
-            assert torch.allclose(a, b.grad, rtol=1e-6, atol=1e-9 * float(a.abs().max() + 1e-30) + 1e-12)
+            assert torch.allclose(a, b.grad, rtol=1e-5, atol=1e-6 * float(a.abs().max() + 1e-30))
 
 
 @pytest.mark.gpu

@@ -52,6 +52,14 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+dchain2)   # dchain + the PPO chain's small-share lines on a quiet box (the `chain` lines of call lock2 ran beside a 48-thread CPU job)
+    bash tools/r6_call.sh dchain
+    for n in 512 1024; do
+      timeout 300 python bench.py --num_envs $n --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_${n}_chain.json
+      QA_TRAIN_CHAIN=0 timeout 300 python bench.py --num_envs $n --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_${n}_autograd.json
+    done
+    line $O/bench_*.json
+    ;;
 dchain)    # the discriminator step's three chain launches (train_chain.DiscTrainChain): parity, the AMP tests, config 3 with / without
     timeout 900 python -m pytest tests/test_train_chain.py -m gpu -x -q -s > $O/pytest_chain.log 2>&1; tail -6 $O/pytest_chain.log | cut -c1-400
     timeout 1800 python -m pytest tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_disc_step_tail.py tests/test_distributed_gpu.py tests/test_hybrid_arm.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -5 $O/pytest_learner.log | cut -c1-400
