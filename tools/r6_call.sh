@@ -52,6 +52,18 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+trace)     # what one chain step is made of: kernel traces of the 512-env config-2 line and of config 3, one step each
+    timeout 600 python -m pytest tests/test_train_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; tail -3 $O/pytest_chain.log | cut -c1-300
+    cd /tmp && export TMPDIR=/tmp
+    rm -rf /tmp/prof; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_chain_step_sequence_512.txt 2>&1
+    f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $O/ppo_chain_512_kernel_stats_head.csv
+    rm -rf /tmp/prof; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_disc_loss_kernel mid > $O/disc_chain_step_sequence_4096.txt 2>&1
+    [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_step_sequence_cfg3_4096.txt 2>&1
+    cd $R
+    cat $O/ppo_chain_step_sequence_512.txt | cut -c1-150; cat $O/disc_chain_step_sequence_4096.txt | cut -c1-150
+    ;;
 dchain2)   # dchain + the PPO chain's small-share lines on a quiet box (the `chain` lines of call lock2 ran beside a 48-thread CPU job)
     bash tools/r6_call.sh dchain
     for n in 512 1024; do
