@@ -730,10 +730,14 @@ int qa_disc_prepare(const float *const *batches, const int64_t *rows, int32_t nu
  *   QA_MLP_GRAD          elementwise: dst[:, dst_col : +n] = (src[:, src_col : +n] (+ dst with QA_MLP_F_ADD)) * act'(y) with act 0 (no
  *                        factor) or 4..6; QA_MLP_F_SAVE as above.  Where two gradients meet at an activation (the privileged encoder's output
  *                        feeds the actor AND the regulariser).
+ *   QA_MLP_LOAD          dst[:, dst_col : +n] = outs[aux_index][:, aux_col : aux_col+n]: a second (third, ...) input of the chain read from global memory
+ *                        into a scratch buffer (the gradients at several heads arrive as separate tensors); QA_MLP_F_SAVE writes the loaded columns
+ *                        out again at (out_index, out_col), e.g. to assemble them into one matrix for a weight-gradient product.
  * Ops written before ABI 17 (new fields zero) mean what they meant. */
 #define QA_MLP_COPY 0
 #define QA_MLP_LAYER 1
 #define QA_MLP_GRAD 2
+#define QA_MLP_LOAD 3
 #define QA_MLP_F_SAVE 1
 #define QA_MLP_F_TRANSPOSED 2
 #define QA_MLP_F_ADD 4

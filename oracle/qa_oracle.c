@@ -2452,6 +2452,13 @@ int qo_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
             const int deriv = (o->kind == QA_MLP_LAYER || o->kind == QA_MLP_GRAD) && o->act >= 4;
             if (deriv && (o->act > 6 || o->aux_index < 0 || o->aux_index >= num_outs || !outs || !outs[o->aux_index] || out_strides[o->aux_index] < o->aux_col + o->n)) { rc = QA_E_ARG; break; }
             const float *ysaved = deriv ? outs[o->aux_index] + r * out_strides[o->aux_index] + o->aux_col : NULL;
+            if (o->kind == QA_MLP_LOAD) {                                 /* ABI 17: global -> scratch buffer */
+                if (o->dst_buf < 1 || o->dst_col + o->n > cols[o->dst_buf] || o->aux_index < 0 || o->aux_index >= num_outs || !outs || !outs[o->aux_index] ||
+                    out_strides[o->aux_index] < o->aux_col + o->n || o->act != 0) { rc = QA_E_ARG; break; }
+                memcpy(buf[o->dst_buf] + o->dst_col, outs[o->aux_index] + r * out_strides[o->aux_index] + o->aux_col, sizeof(float) * (size_t)o->n);
+                if (save) memcpy(outs[o->out_index] + r * out_strides[o->out_index] + o->out_col, buf[o->dst_buf] + o->dst_col, sizeof(float) * (size_t)o->n);
+                continue;
+            }
             if (o->kind == QA_MLP_COPY || o->kind == QA_MLP_GRAD) {       /* ABI 17: QA_MLP_GRAD = copy (+ dst) x act'(saved y) */
                 if (o->dst_buf < 1 || o->src_col + o->n > cols[o->src_buf] || o->dst_col + o->n > cols[o->dst_buf] ||
                     (o->kind == QA_MLP_GRAD && o->act != 0 && !deriv)) { rc = QA_E_ARG; break; }

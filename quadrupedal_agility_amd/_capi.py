@@ -221,7 +221,7 @@ class QaMlpOp(C.Structure):
                 ("w_off", C.c_int64), ("b_off", C.c_int64), ("out_col", C.c_int32), ("aux_index", C.c_int32), ("aux_col", C.c_int32), ("pad_", C.c_int32)]
 
 
-MLP_COPY, MLP_LAYER, MLP_GRAD, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 2, 24, 8
+MLP_COPY, MLP_LAYER, MLP_GRAD, MLP_LOAD, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 2, 3, 24, 8
 MLP_F_SAVE, MLP_F_TRANSPOSED, MLP_F_ADD = 1, 2, 4
 MLP_ACT_ELU_GRAD, MLP_ACT_RELU_GRAD, MLP_ACT_TANH_GRAD = 4, 5, 6
 MLP_BUF_COLS = (800, 576, 320, 128)

@@ -207,10 +207,11 @@ __device__ __forceinline__ void mlp_elementwise(const MlpDevOp &op, float *lds, 
     const int act = op.kind == QA_MLP_GRAD ? op.act : 0;
     for (int i = tid; i < MLP_ROWS * op.n; i += nthreads) {
         const int r = i / op.n, c = i - r * op.n;
-        float v = lds[pl.src_base + r * pl.src_stride + op.src_col + c];
+        const bool live = row0 + r < a.rows;
+        float v = op.kind == QA_MLP_LOAD ? (live ? a.out[op.aux_index][(int64_t)(row0 + r) * a.out_stride[op.aux_index] + op.aux_col + c] : 0.f)
+                                         : lds[pl.src_base + r * pl.src_stride + op.src_col + c];
         float *d = lds + pl.dst_base + r * pl.dst_stride + op.dst_col + c;
         if (add) v += *d;
-        const bool live = row0 + r < a.rows;
         if (act >= 4) v = mlp_act(act, v, live ? a.out[op.aux_index][(int64_t)(row0 + r) * a.out_stride[op.aux_index] + op.aux_col + c] : 0.f);
         *d = v;
         if (save && live) a.out[op.out_index][(int64_t)(row0 + r) * a.out_stride[op.out_index] + op.out_col + c] = v;
@@ -455,11 +456,17 @@ static int mlp_check(const qa_mlp_op *ops, int32_t num_ops, const char *who) {
     for (int i = 0; i < num_ops; ++i) {
         const qa_mlp_op &o = ops[i];
         const bool layer = o.kind == QA_MLP_LAYER;
-        bool ok = (layer || o.kind == QA_MLP_COPY || o.kind == QA_MLP_GRAD) && o.src_buf >= 0 && o.src_buf < MLP_NBUF && o.src_col >= 0 && o.n > 0 &&
+        bool ok = (layer || o.kind == QA_MLP_COPY || o.kind == QA_MLP_GRAD || o.kind == QA_MLP_LOAD) && o.src_buf >= 0 && o.src_buf < MLP_NBUF && o.src_col >= 0 && o.n > 0 &&
                   (o.flags & ~(QA_MLP_F_SAVE | QA_MLP_F_TRANSPOSED | QA_MLP_F_ADD)) == 0 && o.out_col >= 0;
         if (ok && (o.flags & QA_MLP_F_SAVE)) ok = o.out_index >= 0 && o.out_index < QA_MLP_MAX_OUTPUTS;
         if (ok && ((layer && o.act >= 4) || (o.kind == QA_MLP_GRAD && o.act != 0)))
             ok = o.act >= 4 && o.act <= 6 && o.aux_index >= 0 && o.aux_index < QA_MLP_MAX_OUTPUTS && o.aux_col >= 0;
+        if (ok && o.kind == QA_MLP_LOAD) {        /* global -> scratch buffer: no LDS source, no activation */
+            ok = o.aux_index >= 0 && o.aux_index < QA_MLP_MAX_OUTPUTS && o.aux_col >= 0 && o.act == 0 && o.dst_buf > 0 && o.dst_buf < MLP_NBUF && o.dst_col >= 0 &&
+                 o.dst_col + o.n <= buf_cols(o.dst_buf);
+            if (!ok) { snprintf(g_perr, sizeof(g_perr), "%s: op %d (load) is malformed", who, i); return QA_E_ARG; }
+            continue;
+        }
         if (ok && layer) {
             const int kpad = mlp_kb(o.k, o.n) * 16;         /* columns the layer reads (beyond k: against zero weights) */
             /* reading past the row's padding lands in the next row / buffer (finite activations, zero weights): allowed while inside LDS */
@@ -556,7 +563,7 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
             if (o.out_index >= num_outs || !outs[o.out_index] || out_strides[o.out_index] < o.out_col + o.n) {
                 snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: op %d writes output %d which is missing or too narrow", i, o.out_index); return QA_E_ARG; }
         }
-        if ((o.kind == QA_MLP_LAYER || o.kind == QA_MLP_GRAD) && o.act >= 4) {
+        if (((o.kind == QA_MLP_LAYER || o.kind == QA_MLP_GRAD) && o.act >= 4) || o.kind == QA_MLP_LOAD) {
             if (o.aux_index >= num_outs || !outs[o.aux_index] || out_strides[o.aux_index] < o.aux_col + o.n) {
                 snprintf(g_perr, sizeof(g_perr), "qa_mlp_forward: op %d reads the saved activation %d which is missing or too narrow", i, o.aux_index); return QA_E_ARG; }
         }
@@ -570,7 +577,7 @@ int qa_mlp_forward(const float *x, int64_t x_stride, int32_t rows, int32_t x_col
     /* a tile per CU or more: nothing to split over CUs -- two strands side by side inside every workgroup instead (qa_mlp_forward_groups_kernel),
      * when the chain has two and their buffers fit the CU's LDS; QA_MLP_GROUPS=1 in the environment / qa_mlp_set_groups(1) keeps the one-group kernel (A/B runs) */
     bool ext = false;           /* any ABI 17 feature in the program: the kernel variant that has them (the two-group launch does not) */
-    for (int i = 0; i < num_ops; ++i) ext |= ops[i].flags != 0 || ops[i].kind == QA_MLP_GRAD || ops[i].act >= 4 || ops[i].out_col != 0;
+    for (int i = 0; i < num_ops; ++i) ext |= ops[i].flags != 0 || ops[i].kind == QA_MLP_GRAD || ops[i].kind == QA_MLP_LOAD || ops[i].act >= 4 || ops[i].out_col != 0;
     if (!ext && max_strands < 2 && mlp_groups_switch() >= 2 && mlp_strands(ops, num_ops, 2, strand_of) == 2 && mlp_group_geometry(ops, num_ops, strand_of, x_cols, a)) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(qa_mlp_forward_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                             MLP_LDS_LIMIT_FLOATS * 4);

@@ -604,6 +604,7 @@ class SSInfoGAIL:
         a = self.num_prop; b = a + self.num_explicit; c = b + self.num_latent; d = c + self.num_hist * self.num_prop
         priv_reg_coef = self._priv_coef_dev if self._recording_ac else self._priv_reg_coef_now()
         chain = self._train_chain(obs, critic_obs)
+        self._chain_sides = None
         if chain is not None:
             return self._ac_forward_backward_chain(chain, obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hist_latent, priv_reg_coef)
         cur = torch.cuda.current_stream()
@@ -697,6 +698,7 @@ class SSInfoGAIL:
                                                         c_bound=self.bounds_loss_coef, c_entropy=self.entropy_coef,
                                                         clipped_value=self.use_clipped_value_loss)
         chain.backward(g_est, dmu, dvalue, g_priv)
+        self._chain_sides = chain.sides if self.grad_sync is None else None
         if self.grad_sync is not None:
             fused_mod.flush_pending_grads()
         ac.std.grad = dstd.view_as(ac.std)
@@ -705,10 +707,17 @@ class SSInfoGAIL:
 
     def _ac_apply(self, kl_mean):
         """Second half of the step: clip + step the estimator, the KL-adaptive learning rate, clip + step the actor-critic."""
-        self._step_estimator.step()                  # clip_grad_norm_(max_grad_norm) + Adam, three launches on the GPU
+        sides = getattr(self, "_chain_sides", None)
+        if sides is not None:                        # chain steps (few rows): the estimator's optimiser beside the actor-critic's, disjoint parameters
+            with sides.fork(0):
+                self._step_estimator.step()
+        else:
+            self._step_estimator.step()              # clip_grad_norm_(max_grad_norm) + Adam, three launches on the GPU
         if kl_mean is not None:
             self._apply_kl_schedule(kl_mean)
         self._step_ac.step()
+        if sides is not None:
+            sides.join()
         if fused_mod.pending_grads():                # a parameter outside both optimisers had its gradient left in parts: finish it now
             fused_mod.flush_pending_grads()
 
@@ -793,7 +802,7 @@ class SSInfoGAIL:
         b_lb, b_pi = expert_lb.shape[0], policy_state.shape[0]
         analytic_gp = self.disc._relu_trunk() is not None
         fused_heads = self._on_gpu and self.use_fused_loss and self.disc_loss_function == "MSELoss"
-        dchain = None
+        dchain, normaliser_done = None, False
         if analytic_gp and fused_heads and x_all is not None:
             dchain = self._disc_train_chain(x_all.shape[0], expert_ulb.shape[0])
         if dchain is not None:
@@ -801,8 +810,14 @@ class SSInfoGAIL:
             gp_proxies = None
             dchain.pack()
             d_all, eps_all, logits_all = dchain.forward(x_all)
-            g = dchain.penalty_gradient()
+            g = dchain.penalty_gradient()                       # (on a side stream, with its three weight-gradient products: `wait_penalty`)
             c_all = torch.softmax(logits_all, -1)               # (the objective kernel clamps)
+            if self.disc_normalizer is not None and self.grad_sync is None:
+                # the input normaliser folds in this step's batches (gail.py:524-528, at the end of the step there): nothing else in the step reads or
+                # writes its moments, so the fold runs beside the step instead of behind it
+                nb_ = [policy_state, expert_lb, expert_ulb]          # (slices of the prepared matrix, in the order the reference folds them)
+                dchain.beside(lambda: self.disc_normalizer.update_torch(nb_))
+                normaliser_done = True
         elif analytic_gp:      # d logit / d x on the unlabelled rows as a chain of small GEMMs (discriminator.py), no second-order graph
             gp_proxies = [] if os.environ.get("QA_DISC_GP_PROXIES", "1") != "0" else None
             (d_all, eps_all, c_all), g = self.disc.forward_with_input_gradient(x_all if x_all is not None else torch.cat([expert_lb, policy_state, expert_ulb], dim=0),
@@ -854,6 +869,8 @@ class SSInfoGAIL:
         # gradient penalty on the unlabelled expert samples (double backward through the shared pass)
         if not analytic_gp:
             g = torch.autograd.grad(logits_exp, x_ulb, grad_outputs=torch.ones_like(logits_exp), create_graph=True, retain_graph=True, only_inputs=True)[0]
+        if dchain is not None:
+            dchain.wait_penalty()
         if fused_tail:  # the three sums of squares, the 11-vector, the accumulator and the step counter: one launch at the end of the step
             gdet = g.detach()
             grad_pen_loss = None
@@ -894,8 +911,8 @@ class SSInfoGAIL:
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.zero_grad()
         if dchain is not None:
-            with torch.no_grad():       # softmax backward on (rows, 5): d loss / d logits = c * (g_c - <g_c, c>)
-                g_logits = c_all * (g_c - (g_c * c_all).sum(-1, keepdim=True))
+            with torch.no_grad():       # softmax backward on (rows, 5): d loss / d logits = c * (g_c - <g_c, c>), one launch
+                g_logits = torch._softmax_backward_data(g_c, c_all, -1, torch.float32)
             dchain.backward(g_d, g_eps, g_logits, self.disc_grad_penalty)
         elif direct:
             if self._recording_disc:
@@ -928,11 +945,14 @@ class SSInfoGAIL:
                 self.grad_sync.all_reduce_(m64)
                 synced_moments = m64 / self.grad_sync.world
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
-        for o in self._step_disc:
-            o.step()
+        if dchain is not None:          # three optimisers over disjoint parameter sets: side by side
+            dchain.parallel([o.step for o in self._step_disc])
+        else:
+            for o in self._step_disc:
+                o.step()
         if not self._recording_disc:          # the recorded step leaves this to update(): once after the loop is the same thing
             self._clamp_std()
-        if self.disc_normalizer is not None:
+        if self.disc_normalizer is not None and not normaliser_done:
             if synced_moments is not None:      # data-parallel: the moments of the GLOBAL batches, identical on every rank
                 world = self.grad_sync.world
                 self.disc_normalizer.update_from_batch_moments(synced_moments, [b.shape[0] * world for b in norm_batches])

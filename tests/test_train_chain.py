@@ -106,7 +106,7 @@ def test_describe_declines_what_the_programs_do_not_cover():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", [48, 3072, 6144])
+@pytest.mark.parametrize("rows", [48, 3072, 4096])
 def test_hip_chain_equals_autograd(rows):
     from quadrupedal_agility_amd.rsl_rl.algorithms import fused, train_chain
     ac, est, n_obs = _modules(3)

@@ -52,6 +52,28 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+sides)     # chain steps with side streams, loads instead of copies: parity, the learner suites, the lines, one step of each in the trace
+    timeout 900 python -m pytest tests/test_train_chain.py tests/test_policy_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; tail -3 $O/pytest_chain.log | cut -c1-300
+    timeout 1800 python -m pytest tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_grad_parts.py tests/test_disc_step_tail.py tests/test_distributed_gpu.py tests/test_hybrid_arm.py tests/test_learner_lockstep.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -3 $O/pytest_learner.log | cut -c1-300
+    for i in 1 2; do
+      timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>$O/bench_512.err < /dev/null | grep '"metric"' > $O/bench_512_chain_$i.json
+      timeout 400 python bench.py --amp --no_cpu_baseline 2>$O/bench_amp.err < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_$i.json
+    done
+    QA_TRAIN_CHAIN_SIDES=0 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_chain_one_stream.json
+    QA_TRAIN_CHAIN_SIDES=0 timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_one_stream.json
+    QA_TRAIN_CHAIN=0 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_autograd.json
+    QA_TRAIN_CHAIN=0 timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_autograd.json
+    timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_chain.json
+    timeout 400 python bench.py --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_4096.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp
+    rm -rf /tmp/prof; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_chain_step_sequence_512.txt 2>&1
+    rm -rf /tmp/prof; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_disc_loss_kernel mid > $O/disc_chain_step_sequence_4096.txt 2>&1
+    cd $R
+    tail -1 $O/ppo_chain_step_sequence_512.txt; tail -1 $O/disc_chain_step_sequence_4096.txt
+    ;;
 trace)     # what one chain step is made of: kernel traces of the 512-env config-2 line and of config 3, one step each
     timeout 600 python -m pytest tests/test_train_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; tail -3 $O/pytest_chain.log | cut -c1-300
     cd /tmp && export TMPDIR=/tmp
