@@ -472,6 +472,23 @@ int64_t qa_linear_backward_weight_scratch_bytes(int64_t rows, int32_t in_feature
  * launch): layout[0] weight parts, each in_features * out_features floats, layout[1] floats apart, from scratch + 0; layout[2] bias parts, each
  * out_features floats, layout[3] floats apart, from scratch + layout[4] floats -- what qa_clip_adam_step_reduce / qa_grad_reduce add in order. */
 int qa_linear_backward_weight_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]);
+/* ABI 17: several weight (+ bias) gradient products in as few launches as their operands' alignments allow (one per combination of 16-byte /
+ * 4-byte readable x and grad_out: at most four), each product what qa_linear_backward_weight computes -- the dozen small products of a chain
+ * training step (csrc/qa_policy.hip, ABI 17) side by side instead of one after the other.  Per product: grad_weight and grad_bias both NULL leaves
+ * the parts in `scratch` as qa_linear_backward_weight_batch_layout describes (same meaning as qa_linear_backward_weight_layout; the batch plans its
+ * own split, so sizes and layout come from the _batch_ functions); otherwise every finished product of the batch is added up by ONE qa_grad_reduce
+ * launch at the end.  Fixed work assignment and summation order (bit-reproducible). */
+typedef struct qa_wgrad_desc {
+    const float *grad_out; int64_t ldg;        /* (rows, out_features), row stride ldg */
+    const float *x; int64_t ldx;               /* (rows, in_features), row stride ldx */
+    float *grad_weight, *grad_bias;            /* (out_features, in_features) contiguous, (out_features); both NULL: in parts */
+    int64_t rows;
+    int32_t in_features, out_features;
+    void *scratch; int64_t scratch_bytes;      /* 16-byte aligned, >= qa_linear_backward_weight_batch_scratch_bytes(rows, in, out) */
+} qa_wgrad_desc;
+int64_t qa_linear_backward_weight_batch_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features);
+int qa_linear_backward_weight_batch_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]);
+int qa_linear_backward_weight_batch(const qa_wgrad_desc *descs, int32_t count, void *stream);
 int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x, int64_t ldx, float *grad_weight, float *grad_bias, int64_t rows,
                               int32_t in_features, int32_t out_features, void *scratch, int64_t scratch_bytes, void *stream);
 

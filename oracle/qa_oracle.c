@@ -1601,6 +1601,24 @@ int qo_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
     return QA_OK;
 }
 
+/* twins of the batch entry points (ABI 17): the same products, one after the other */
+int64_t qo_linear_backward_weight_batch_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
+    return qo_linear_backward_weight_scratch_bytes(rows, in_features, out_features);
+}
+int qo_linear_backward_weight_batch_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]) {
+    return qo_linear_backward_weight_layout(rows, in_features, out_features, layout);
+}
+int qo_linear_backward_weight_batch(const qa_wgrad_desc *descs, int32_t count, void *stream) {
+    if (!descs || count <= 0 || count > 32) return QA_E_ARG;
+    for (int i = 0; i < count; ++i) {
+        const qa_wgrad_desc *d = &descs[i];
+        int rc = qo_linear_backward_weight(d->grad_out, d->ldg, d->x, d->ldx, d->grad_weight, d->grad_bias, d->rows, d->in_features, d->out_features, d->scratch,
+                                           d->scratch_bytes, stream);
+        if (rc != QA_OK) return rc;
+    }
+    return QA_OK;
+}
+
 int64_t qo_linear_forward_split_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
     (void)in_features; return (rows > 0 && out_features > 0) ? 16 : 0;
 }

@@ -191,6 +191,9 @@ def bind(lib, prefix):
     f.restype = C.c_int
     f = getattr(lib, prefix + "linear_backward_weight_scratch_bytes"); f.argtypes = [C.c_int64, C.c_int32, C.c_int32]; f.restype = C.c_int64
     f = getattr(lib, prefix + "linear_backward_weight_layout"); f.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "linear_backward_weight_batch_layout"); f.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "linear_backward_weight_batch_scratch_bytes"); f.argtypes = [C.c_int64, C.c_int32, C.c_int32]; f.restype = C.c_int64
+    f = getattr(lib, prefix + "linear_backward_weight_batch"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "linear_backward_weight")
     f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     f.restype = C.c_int
@@ -219,6 +222,12 @@ class QaMlpOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("src_buf", C.c_int32), ("src_col", C.c_int32), ("dst_buf", C.c_int32), ("dst_col", C.c_int32),
                 ("k", C.c_int32), ("n", C.c_int32), ("act", C.c_int32), ("out_index", C.c_int32), ("flags", C.c_int32),
                 ("w_off", C.c_int64), ("b_off", C.c_int64), ("out_col", C.c_int32), ("aux_index", C.c_int32), ("aux_col", C.c_int32), ("pad_", C.c_int32)]
+
+
+class QaWgradDesc(C.Structure):
+    """qa_wgrad_desc of include/qa_sim.h"""
+    _fields_ = [("grad_out", C.c_void_p), ("ldg", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("grad_weight", C.c_void_p), ("grad_bias", C.c_void_p),
+                ("rows", C.c_int64), ("in_features", C.c_int32), ("out_features", C.c_int32), ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)]
 
 
 MLP_COPY, MLP_LAYER, MLP_GRAD, MLP_LOAD, MLP_MAX_OPS, MLP_MAX_OUTPUTS = 0, 1, 2, 3, 24, 8
@@ -298,7 +307,7 @@ class QaTscDepthIo(C.Structure):
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "tsc_reset_dev", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "hybrid_ppo_loss", "hybrid_ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "grad_reduce", "rollout_act", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "linear_backward_weight_batch", "linear_backward_weight_batch_layout", "linear_backward_weight_batch_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "grad_reduce", "rollout_act", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
 
 _LIB = None
 # QA_LIB: another build of the SAME library (A/B measurements of a kernel variant, tools/r5_call.sh); there is still no fallback -- a missing file raises

@@ -33,6 +33,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 
 #include "../../include/qa_sim.h"
 
@@ -290,7 +291,7 @@ static __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f4
 // the activation's output yprev (ELU: y > 0 ? 1 : y + alpha; ReLU: y > 0; none: 1).
 // ABL (tools/gemm_probe.hip only): 1 = no global loads / LDS writes after the first tile, 2 = no MFMAs, 3 = no LDS fragment reads
 template <int BA, int BB, bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES, int ABL = 0, int CONV = 0>
-__global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
+static __device__ __forceinline__ void qa_gemm_body(const GemmArgs &g, const int block_id) {
     static_assert(CONV == 0 || (CONV == 1 && !B_MC && BV == 4) || (CONV == 2 && A_MC && AV == 4), "window operands are read with 16-byte loads");
     constexpr int TA = BA / 32, TB = BB / 32;
     constexpr int A_TILE = A_MC ? GEMM_BK * (BA + 4) : BA * (GEMM_BK + 4);
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
 
     // consecutive workgroup ids are dealt round-robin to the 8 XCDs: remap so that each XCD owns a contiguous run of tiles
     const int total = g.na * g.nb * g.nsplit;
-    int id = blockIdx.x;
+    int id = block_id;
     {
         const int q = total >> 3, rmd = total & 7, xcd = id & 7, local = id >> 3;
         id = (xcd < rmd) ? xcd * (q + 1) + local : rmd * (q + 1) + (xcd - rmd) * q + local;
@@ -430,6 +431,24 @@ __global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
     }
 
     gemm_epilogue<BA, BB, EPI, ONES>(g, acc, oacc, a_base, b_base, at, z, wa, wb, li, kq, ones_wave);
+}
+template <int BA, int BB, bool A_MC, bool B_MC, int AV, int BV, int EPI, bool ONES, int ABL = 0, int CONV = 0>
+__global__ void __launch_bounds__(256, 2) qa_gemm_kernel(GemmArgs g) {
+    qa_gemm_body<BA, BB, A_MC, B_MC, AV, BV, EPI, ONES, ABL, CONV>(g, (int)blockIdx.x);
+}
+// r6 (ABI 17): SEVERAL weight-gradient products in ONE launch (qa_linear_backward_weight_batch).  The products of a chain training step are a dozen
+// (out x in) outputs over a few thousand rows -- 16-190 workgroups and ~15 us each when launched one after the other
+// (profiles/r6_ppo_chain_step_sequence_512_one_stream.txt: 13 launches, 215 us of a 517 us step); side by side they are one launch of a few thousand
+// workgroups.  Workgroup -> (product, tile) by a scan of the cumulative tile counts in the kernel arguments; every product of a launch shares the
+// kernel's template instance (64 x 64 tiles, the operands' vector widths), its own GemmArgs otherwise.
+constexpr int GEMM_GROUP_MAX = 12;
+struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int n; };
+static_assert(sizeof(GemmGroup) <= 3800, "the group travels in the kernel arguments (4 KB)");
+template <int AV, int BV>
+__global__ void __launch_bounds__(256, 2) qa_wgrad_group_kernel(GemmGroup G) {
+    int j = 0;
+    while (j + 1 < G.n && (int)blockIdx.x >= G.start[j + 1]) ++j;
+    qa_gemm_body<64, 64, true, true, AV, BV, 0, true>(G.g[j], (int)blockIdx.x - G.start[j]);
 }
 
 // ---- the same products with LDS-DMA staging (r4) ----
@@ -962,6 +981,89 @@ int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
                            (const float *)bslabs, n_b_pad, (int)(s * na), (int64_t)out_features, grad_weight, grad_bias, aligned16(grad_weight) ? 4 : 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+// the batch's split of the sample dimension: 64 x 64 tiles for every product, ~256 workgroups each (a dozen of them fill the chip together)
+static void wgrad_batch_plan(int64_t rows, int32_t in_features, int32_t out_features, int *nsplit, int *k_per_split) {
+    const int64_t tiles = (int64_t)((in_features + 63) / 64) * ((out_features + 63) / 64);
+    int64_t s = 256 / tiles;
+    const int64_t smax = (rows + 255) / 256;
+    if (s > smax) s = smax;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    int64_t kps = ((rows + s - 1) / s + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    s = (rows + kps - 1) / kps;
+    *nsplit = (int)s; *k_per_split = (int)kps;
+}
+int qa_linear_backward_weight_batch_layout(int64_t rows, int32_t in_features, int32_t out_features, int64_t layout[5]) {
+    if (!layout || rows <= 0 || in_features <= 0 || out_features <= 0) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight_batch_layout: bad argument"); return QA_E_ARG; }
+    int s, kps; wgrad_batch_plan(rows, in_features, out_features, &s, &kps);
+    const int64_t na = (in_features + 63) / 64;
+    layout[0] = s; layout[1] = pad4((int64_t)in_features * out_features); layout[2] = s * na; layout[3] = pad4(out_features); layout[4] = (int64_t)s * layout[1];
+    return QA_OK;
+}
+int64_t qa_linear_backward_weight_batch_scratch_bytes(int64_t rows, int32_t in_features, int32_t out_features) {
+    int64_t lay[5];
+    if (qa_linear_backward_weight_batch_layout(rows, in_features, out_features, lay) != QA_OK) return 0;
+    return (lay[4] + lay[2] * lay[3]) * 4;
+}
+
+int qa_linear_backward_weight_batch(const qa_wgrad_desc *descs, int32_t count, void *stream) {
+    if (!descs || count <= 0 || count > 32) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight_batch: 1..32 products expected"); return QA_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    static GemmGroup groups[4];          // by (a_vec == 4, b_vec == 4); filled and launched under the lock below
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int v = 0; v < 4; ++v) { groups[v].n = 0; groups[v].start[0] = 0; }
+    auto flush = [&](int v) {
+        GemmGroup &G = groups[v];
+        if (G.n == 0) return;
+        const dim3 grid((unsigned)G.start[G.n]);
+        switch (v) {
+        case 3: hipLaunchKernelGGL((qa_wgrad_group_kernel<4, 4>), grid, dim3(256), 0, st, G); break;
+        case 2: hipLaunchKernelGGL((qa_wgrad_group_kernel<4, 1>), grid, dim3(256), 0, st, G); break;
+        case 1: hipLaunchKernelGGL((qa_wgrad_group_kernel<1, 4>), grid, dim3(256), 0, st, G); break;
+        default: hipLaunchKernelGGL((qa_wgrad_group_kernel<1, 1>), grid, dim3(256), 0, st, G); break;
+        }
+        G.n = 0; G.start[0] = 0;
+    };
+    float *red_dst[64]; const float *red_src[64]; int64_t red_stride[64]; int32_t red_parts[64], red_numel[64];
+    int nred = 0;
+    for (int i = 0; i < count; ++i) {
+        const qa_wgrad_desc &d = descs[i];
+        const bool parts_only = !d.grad_weight && !d.grad_bias;
+        if (!d.grad_out || !d.x || (!parts_only && (!d.grad_weight || !d.grad_bias)) || !d.scratch || d.rows <= 0 || d.rows > INT32_MAX || d.in_features <= 0 ||
+            d.out_features <= 0 || d.ldg < d.out_features || d.ldx < d.in_features || !fits_u32(d.rows, d.ldg) || !fits_u32(d.rows, d.ldx) || !aligned16(d.scratch) ||
+            d.scratch_bytes < qa_linear_backward_weight_batch_scratch_bytes(d.rows, d.in_features, d.out_features)) {
+            snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight_batch: product %d: bad argument", i); return QA_E_ARG; }
+        int s, kps; wgrad_batch_plan(d.rows, d.in_features, d.out_features, &s, &kps);
+        const int64_t n_w_pad = pad4((int64_t)d.in_features * d.out_features), n_b_pad = pad4(d.out_features), na = (d.in_features + 63) / 64;
+        float *bslabs = (float *)d.scratch + (int64_t)s * n_w_pad;
+        GemmArgs g = {};
+        g.A = d.x; g.lda = d.ldx; g.a_count = d.in_features;
+        g.B = d.grad_out; g.ldb = d.ldg; g.b_count = d.out_features;
+        g.kred = (int)d.rows; g.k_per_split = kps; g.nsplit = s;
+        g.out = (float *)d.scratch; g.ldo = d.in_features; g.out_split_stride = n_w_pad;
+        g.ones_out = bslabs; g.ones_split_stride = n_b_pad;
+        g.a_vec = (aligned16(d.x) && d.ldx % 4 == 0 && d.in_features % 4 == 0) ? 4 : 1;
+        g.b_vec = (aligned16(d.grad_out) && d.ldg % 4 == 0 && d.out_features % 4 == 0) ? 4 : 1;
+        g.o_vec = (d.in_features % 4 == 0) ? 4 : 1;
+        g.na = (int)na; g.nb = (d.out_features + 63) / 64;
+        const int v = (g.a_vec == 4 ? 2 : 0) + (g.b_vec == 4 ? 1 : 0);
+        GemmGroup &G = groups[v];
+        if (G.n == GEMM_GROUP_MAX) flush(v);
+        G.g[G.n] = g; G.start[G.n + 1] = G.start[G.n] + g.na * g.nb * g.nsplit; ++G.n;
+        if (!parts_only) {
+            if (nred + 2 > 64) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight_batch: too many finished products in one batch"); return QA_E_ARG; }
+            red_dst[nred] = d.grad_weight; red_src[nred] = (const float *)d.scratch; red_stride[nred] = n_w_pad; red_parts[nred] = s; red_numel[nred] = d.in_features * d.out_features; ++nred;
+            red_dst[nred] = d.grad_bias; red_src[nred] = bslabs; red_stride[nred] = n_b_pad; red_parts[nred] = (int32_t)(s * na); red_numel[nred] = d.out_features; ++nred;
+        }
+    }
+    for (int v = 0; v < 4; ++v) flush(v);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_gerr, sizeof(g_gerr), "qa_linear_backward_weight_batch: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    if (nred) return qa_grad_reduce(red_dst, red_src, red_stride, red_parts, red_numel, nred, stream);       // ONE launch finishes every product that asked for it
     return QA_OK;
 }
 

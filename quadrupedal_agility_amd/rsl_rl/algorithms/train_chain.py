@@ -133,7 +133,10 @@ class _Sides:
         self.open.clear()
 
 
-SIDE_STREAMS = os.environ.get("QA_TRAIN_CHAIN_SIDES", "1") != "0"
+# Measured (profiles/r6_chain_side_streams.txt): as parallel branches of a step's hipGraph the side streams LOSE -- every fork / join is a cross-branch
+# dependency the graph executes with a 10-140 us gap (512-env PPO step 517 -> 621 us, config 3's iteration 53.4 -> 64.2 ms).  Off by default; the
+# independent products go side by side inside ONE launch instead (qa_linear_backward_weight_batch).
+SIDE_STREAMS = os.environ.get("QA_TRAIN_CHAIN_SIDES", "0") == "1"
 
 
 class PpoTrainChain:
@@ -241,20 +244,13 @@ class PpoTrainChain:
         self._wg = []
         for lin_, _, _ in self.wgrads:
             n, k = lin_.out_features, lin_.in_features
-            nb = int(f._fn("linear_backward_weight_scratch_bytes")(rows, k, n))
+            nb = int(f._fn("linear_backward_weight_batch_scratch_bytes")(rows, k, n))
             lay = (C.c_int64 * 5)()
-            _ok(f._fn("linear_backward_weight_layout")(rows, k, n, lay), "linear_backward_weight_layout", f)
+            _ok(f._fn("linear_backward_weight_batch_layout")(rows, k, n, lay), "linear_backward_weight_batch_layout", f)
             scratch = torch.zeros(nb // 4 + 4, dtype=torch.float32, device=dev)
             gw, gb = torch.zeros_like(lin_.weight), torch.zeros_like(lin_.bias)
             self._wg.append((scratch, nb, [int(v) for v in lay], gw, gb))
-        # the 13 products are independent and, at these row counts, a few dozen workgroups each: four at a time (profiles/r6_ppo_chain_step_sequence_512.txt:
-        # 215 us of the step's 517 one after the other).  Longest first onto the least loaded stream; stream 0 = the caller's.
-        self.sides = _Sides(dev, 3) if (SIDE_STREAMS and prefix == "qa_") else None
-        cost = [lin_.out_features * lin_.in_features + 40000 for lin_, _, _ in self.wgrads]
-        load, self._wg_stream = [0, 0, 0, 0], [0] * len(cost)
-        for i in sorted(range(len(cost)), key=lambda j: -cost[j]):
-            k = min(range(4), key=lambda q: load[q])
-            self._wg_stream[i] = k; load[k] += cost[i]
+        self.sides = _Sides(dev, 1) if (SIDE_STREAMS and prefix == "qa_") else None          # (the estimator's optimiser beside the actor-critic's: gail._ac_apply)
         return self
 
     def pack(self):
@@ -275,26 +271,15 @@ class PpoTrainChain:
         gin = dmu
         self.bwd.launch(dmu, d["n_act"], [self.gtape, self.tape, dvalue, g_est, g_priv])
         src = {"tape": self.tape, "gtape": self.gtape, "dmu": dmu, "dvalue": dvalue, "g_est": g_est, "obs": self._obs}
-        wgrad = self.bwd._fn("linear_backward_weight")
         defer = defer and gin.is_cuda and fused.ENABLED and os.environ.get("QA_DEFER_GRAD_FINISH", "1") != "0"
-        def product(i):
-            (lin_, (gs, g0, gn), (xs, x0, xk)), (scratch, nb, lay, gw, gb) = self.wgrads[i], self._wg[i]
+        # the 13 weight (+ bias) gradient products of the step in ONE call: qa_linear_backward_weight_batch groups them by operand alignment into at
+        # most four launches of a few thousand workgroups (one after the other they were 13 launches of 16-190 workgroups, 215 of the step's 517 us)
+        descs = (_capi.QaWgradDesc * len(self.wgrads))()
+        for i, ((lin_, (gs, g0, gn), (xs, x0, xk)), (scratch, nb, lay, gw, gb)) in enumerate(zip(self.wgrads, self._wg)):
             gt, xt = src[gs], src[xs]
-            _ok(wgrad(C.c_void_p(gt.data_ptr() + 4 * g0), gt.stride(0), C.c_void_p(xt.data_ptr() + 4 * x0), xt.stride(0), None if defer else _ptr(gw), None if defer else _ptr(gb),
-                      self.rows, xk, gn, _ptr(scratch), nb, self.bwd._stream(gin)), "linear_backward_weight", self.bwd)
-
-        sides = self.sides if (self.sides is not None and gin.is_cuda) else None
-        for k in range(4 if sides else 1):
-            mine = [i for i in range(len(self.wgrads)) if (self._wg_stream[i] == k or not sides)]
-            if k == 0:
-                for i in mine:
-                    product(i)
-            else:
-                with sides.fork(k - 1):
-                    for i in mine:
-                        product(i)
-        if sides:
-            sides.join()
+            descs[i] = _capi.QaWgradDesc(gt.data_ptr() + 4 * g0, gt.stride(0), xt.data_ptr() + 4 * x0, xt.stride(0), None if defer else gw.data_ptr(),
+                                         None if defer else gb.data_ptr(), self.rows, xk, gn, scratch.data_ptr(), nb)
+        _ok(self.bwd._fn("linear_backward_weight_batch")(descs, len(self.wgrads), self.bwd._stream(gin)), "linear_backward_weight_batch", self.bwd)
         for (lin_, _, _), (scratch, nb, lay, gw, gb) in zip(self.wgrads, self._wg):
             lin_.weight.grad, lin_.bias.grad = gw, gb
             if defer:
@@ -371,14 +356,12 @@ class DiscTrainChain:
         b.layer(2, 0, w2, -1, 0, w1, DR, l2.weight, None, out=(0, GH1), aux=(1, H1), transposed=True)
         b.finish()
         self.fwd, self.pen, self.bwd = f, p, b
-        # side streams: 0 = the penalty path (its launch and its three products need nothing of the objective), 1 / 2 = a product each beside the
-        # caller's, 3 = whatever the caller hands to `beside()` (the input normaliser's update)
+        # opt-in side streams (QA_TRAIN_CHAIN_SIDES=1; measured slower): 1 / 2 = the second and third optimiser, 3 = what `beside()` is handed
         self.sides = _Sides(dev, 4) if (SIDE_STREAMS and prefix == "qa_") else None
-        self._ev_pen = None
         # weight-gradient products: (rows, g tensor, g col, n, x tensor, x col, k)
         self._wg = {}
         for name, (r, n, k) in dict(w1=(rows, w1, k0), w2=(rows, w2, w1), wh=(rows, 8, w2), p1=(n_u, w1, k0), p2=(n_u, w2, w1), p3=(n_u, w2, 1)).items():
-            nb = int(f._fn("linear_backward_weight_scratch_bytes")(r, k, n))
+            nb = int(f._fn("linear_backward_weight_batch_scratch_bytes")(r, k, n))
             self._wg[name] = (torch.zeros(nb // 4 + 4, dtype=torch.float32, device=dev), nb, z(n, k), z(n))
         return self
 
@@ -396,25 +379,12 @@ class DiscTrainChain:
 
     def penalty_gradient(self):
         """d logit / d x on the unlabelled expert rows (the LAST n_u rows of x), (n_u, input_dim)"""
-        U, (k0, w1, w2, nh) = self.n_u, self.dims
-        def path():
-            self.pen.launch(self.ones, 4, [self.vu, self.tape[self.rows - self.n_u:], self.g])
-            if self.sides:
-                self._ev_pen = torch.cuda.Event(); self._ev_pen.record()
-            self._pen_products = (self._wgrad("p1", U, self.vu, self.vcol["v1"], w1, self.g, 0, k0)[0],
-                                  self._wgrad("p2", U, self.vu, self.vcol["v2"], w2, self.vu, self.vcol["u1"], w1)[0],
-                                  self._wgrad("p3", U, self.vu, self.vcol["u2"], w2, self.ones, 0, 1)[0])
-        if self.sides:
-            with self.sides.fork(0):
-                path()
-        else:
-            path()
+        self.pen.launch(self.ones, 4, [self.vu, self.tape[self.rows - self.n_u:], self.g])
         return self.g
 
     def wait_penalty(self):
         """before the first reader of `penalty_gradient()`'s result on the calling stream"""
-        if self.sides and self._ev_pen is not None:
-            torch.cuda.current_stream().wait_event(self._ev_pen)
+        return None          # (the penalty path runs on the calling stream: nothing to wait for)
 
     def parallel(self, fns):
         """independent pieces of work side by side: the first on the calling stream, the others on side streams 1, 2, ...; joined before returning"""
@@ -436,12 +406,6 @@ class DiscTrainChain:
         else:
             fn()
 
-    def _wgrad(self, name, rows, g, g0, n, x, x0, k):
-        scratch, nb, gw, gb = self._wg[name]
-        _ok(self.fwd._fn("linear_backward_weight")(C.c_void_p(g.data_ptr() + 4 * g0), g.stride(0), C.c_void_p(x.data_ptr() + 4 * x0), x.stride(0), _ptr(gw), _ptr(gb),
-                                                    rows, k, n, _ptr(scratch), nb, self.fwd._stream(g)), "linear_backward_weight", self.fwd)
-        return gw, gb
-
     def backward(self, g_d, g_eps, g_logits, penalty_coef):
         """gradients at the three heads' outputs (R rows) + the penalty's coefficient c (loss term c * mean_U |g|^2) -> `.grad` of the 10 parameters"""
         k0, w1, w2, nh = self.dims
@@ -451,18 +415,18 @@ class DiscTrainChain:
         g_d, g_eps, g_logits = f32c(g_d, (self.rows, 1)), f32c(g_eps, (self.rows, 1)), f32c(g_logits, (self.rows, nh - 2))
         self.bwd.launch(g_d, 1, [self.gt, self.tape, g_eps, g_logits, gin])
         R, U = self.rows, self.n_u
-        if self.sides:
-            with self.sides.fork(1):
-                gw2, gb2 = self._wgrad("w2", R, self.gt, self.gcol["gh2"], w2, self.tape, self.tcol["h1"], w1)
-            with self.sides.fork(2):
-                gwh, gbh = self._wgrad("wh", R, gin, 0, 8, self.tape, self.tcol["h2"], w2)
-        else:
-            gw2, gb2 = self._wgrad("w2", R, self.gt, self.gcol["gh2"], w2, self.tape, self.tcol["h1"], w1)
-            gwh, gbh = self._wgrad("wh", R, gin, 0, 8, self.tape, self.tcol["h2"], w2)
-        gw1, gb1 = self._wgrad("w1", R, self.gt, self.gcol["gh1"], w1, self._x, 0, k0)
-        if self.sides:
-            self.sides.join()
-        t1, t2, t3 = self._pen_products
+        # six products -- trunk 1, trunk 2, the stacked heads over the R rows; the penalty's three over the U rows -- in one call (<= 4 launches + one
+        # reduction for all of them)
+        jobs = [("w1", R, self.gt, self.gcol["gh1"], w1, self._x, 0, k0), ("w2", R, self.gt, self.gcol["gh2"], w2, self.tape, self.tcol["h1"], w1),
+                ("wh", R, gin, 0, 8, self.tape, self.tcol["h2"], w2), ("p1", U, self.vu, self.vcol["v1"], w1, self.g, 0, k0),
+                ("p2", U, self.vu, self.vcol["v2"], w2, self.vu, self.vcol["u1"], w1), ("p3", U, self.vu, self.vcol["u2"], w2, self.ones, 0, 1)]
+        descs = (_capi.QaWgradDesc * len(jobs))()
+        for i, (name, rows, g, g0, n, x, x0, k) in enumerate(jobs):
+            scratch, nb, gw, gb = self._wg[name]
+            descs[i] = _capi.QaWgradDesc(g.data_ptr() + 4 * g0, g.stride(0), x.data_ptr() + 4 * x0, x.stride(0), gw.data_ptr(), gb.data_ptr(), rows, k, n, scratch.data_ptr(), nb)
+        _ok(self.fwd._fn("linear_backward_weight_batch")(descs, len(jobs), self.fwd._stream(gin)), "linear_backward_weight_batch", self.fwd)
+        (gw1, gb1), (gw2, gb2), (gwh, gbh) = (self._wg[k_][2:] for k_ in ("w1", "w2", "wh"))
+        t1, t2, t3 = (self._wg[k_][2] for k_ in ("p1", "p2", "p3"))
         a = 2.0 * float(penalty_coef) / U
         with torch.no_grad():
             torch._foreach_add_([gw1, gw2, gwh[0]], [t1, t2, t3.view(-1)], alpha=a)

@@ -174,7 +174,7 @@ def test_training_with_chain_steps_equals_training_with_autograd_steps(graph):
         a, b = (wa[k], wb[k]) if k in wa else (ea[k[10:]], eb[k[10:]])
         if a.dtype.is_floating_point and a.numel() > 1:
             rel = float((a - b).norm() / (b.norm() + 1e-12))
-            assert rel < 2e-3 and float((a - b).abs().max()) < 3e-3, (k, rel, float((a - b).abs().max()))
+            assert float((a - b).abs().max()) < 3e-3 and (rel < 2e-3 or float(b.norm()) < 1.0), (k, rel, float((a - b).abs().max()))      # (zero-initialised biases: no norm to be relative to)
 
 
 # ------------------------------------------------------------------ the discriminator step's three chain launches
@@ -285,3 +285,64 @@ def test_amp_training_with_the_discriminator_chain_equals_training_without_it():
     print("discriminator weights, relative L2 after 160 steps:", rel)
     assert torch.isfinite(da).all() and rel < 2e-3
     assert torch.allclose(na, nb, rtol=1e-9, atol=1e-12) and lra == lrb
+
+
+# ------------------------------------------------------------------ several weight-gradient products in one call
+WG_SHAPES = [(3072, 671, 512), (3072, 512, 256), (3072, 101, 512), (3072, 128, 12), (3072, 128, 1), (3072, 29, 64), (3072, 64, 4), (1228, 98, 512), (1228, 1, 256), (77, 57, 128)]
+
+
+def _wg_case(seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(r, k + 3, generator=gen)[:, :k] for r, k, n in WG_SHAPES]           # row strides that are not the width: column slices of wider rows
+    gs = [torch.randn(r, n + 5, generator=gen)[:, 1:1 + n] / r for r, k, n in WG_SHAPES]     # ... and a start that is not 16-byte aligned
+    return xs, gs
+
+
+def _run_batch(lib, prefix, xs, gs, dev, finished):
+    import ctypes as C
+    from quadrupedal_agility_amd import _capi
+    fn = lambda name: getattr(lib, prefix + name)
+    descs = (_capi.QaWgradDesc * len(xs))()
+    keep, out = [], []
+    for i, ((r, k, n), x, g) in enumerate(zip(WG_SHAPES, xs, gs)):
+        nb = int(fn("linear_backward_weight_batch_scratch_bytes")(r, k, n))
+        lay = (C.c_int64 * 5)()
+        assert fn("linear_backward_weight_batch_layout")(r, k, n, lay) == 0
+        sc = torch.zeros(nb // 4 + 4, device=dev); gw = torch.full((n, k), float("nan"), device=dev); gb = torch.full((n,), float("nan"), device=dev)
+        descs[i] = _capi.QaWgradDesc(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr() if finished else None, gb.data_ptr() if finished else None, r, k, n, sc.data_ptr(), nb)
+        keep.append((sc, list(lay))); out.append((gw, gb))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if dev != "cpu" else None
+    assert fn("linear_backward_weight_batch")(descs, len(xs), stream) == 0
+    if not finished:          # add the parts up here: what qa_grad_reduce / the optimiser's first pass do
+        out = []
+        for (sc, lay), (r, k, n) in zip(keep, WG_SHAPES):
+            w = torch.stack([sc[j * lay[1]: j * lay[1] + n * k] for j in range(lay[0])]).sum(0).view(n, k)
+            b = torch.stack([sc[lay[4] + j * lay[3]: lay[4] + j * lay[3] + n] for j in range(lay[2])]).sum(0)
+            out.append((w, b))
+    return out
+
+
+def test_wgrad_batch_twin_equals_the_products():
+    xs, gs = _wg_case()
+    for finished in (True, False):
+        for (gw, gb), x, g in zip(_run_batch(load_oracle(), "qo_", xs, gs, "cpu", finished), xs, gs):
+            assert torch.allclose(gw, g.t().double().mm(x.double()).float(), rtol=1e-5, atol=1e-7) and torch.allclose(gb, g.double().sum(0).float(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("finished", [True, False])
+def test_hip_wgrad_batch_equals_the_products_one_by_one(finished):
+    """qa_linear_backward_weight_batch (<= 4 launches for the ten products: 16-byte / 4-byte readable operands in every combination, a 1-column input,
+    a 1-column gradient, 77 rows) against float64 products, finished by its one reduction or left in parts"""
+    from quadrupedal_agility_amd import _capi
+    xs, gs = _wg_case(1)
+    dx, dg = [], []          # device copies that keep the strides and the misalignment
+    for x, g in zip(xs, gs):
+        bx = torch.zeros(x.shape[0], x.shape[1] + 3, device="cuda"); bx[:, :x.shape[1]] = x.cuda(); dx.append(bx[:, :x.shape[1]])
+        bg = torch.zeros(g.shape[0], g.shape[1] + 5, device="cuda"); bg[:, 1:1 + g.shape[1]] = g.cuda(); dg.append(bg[:, 1:1 + g.shape[1]])
+    res = _run_batch(_capi.load_library(), "qa_", dx, dg, "cuda", finished)
+    torch.cuda.synchronize()
+    for (gw, gb), x, g, shape in zip(res, xs, gs, WG_SHAPES):
+        rw, rb = g.t().double().mm(x.double()), g.double().sum(0)
+        assert torch.allclose(gw.cpu().double(), rw, rtol=2e-4, atol=2e-6 * float(rw.abs().max())), shape
+        assert torch.allclose(gb.cpu().double(), rb, rtol=2e-4, atol=2e-6 * float(rb.abs().max()) + 1e-9), shape

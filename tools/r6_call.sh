@@ -52,6 +52,9 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+batch)     # the chain steps' weight-gradient products in one call (qa_linear_backward_weight_batch): parity, suites, lines, traces
+    QA_TRAIN_CHAIN_SIDES=0 bash tools/r6_call.sh sides
+    ;;
 sides)     # chain steps with side streams, loads instead of copies: parity, the learner suites, the lines, one step of each in the trace
     timeout 900 python -m pytest tests/test_train_chain.py tests/test_policy_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; tail -3 $O/pytest_chain.log | cut -c1-300
     timeout 1800 python -m pytest tests/test_fused_learner.py tests/test_golden_learner.py tests/test_gpu_train.py tests/test_grad_parts.py tests/test_disc_step_tail.py tests/test_distributed_gpu.py tests/test_hybrid_arm.py tests/test_learner_lockstep.py -m gpu -x -q > $O/pytest_learner.log 2>&1; tail -3 $O/pytest_learner.log | cut -c1-300
@@ -59,8 +62,8 @@ sides)     # chain steps with side streams, loads instead of copies: parity, the
       timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>$O/bench_512.err < /dev/null | grep '"metric"' > $O/bench_512_chain_$i.json
       timeout 400 python bench.py --amp --no_cpu_baseline 2>$O/bench_amp.err < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_$i.json
     done
-    QA_TRAIN_CHAIN_SIDES=0 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_chain_one_stream.json
-    QA_TRAIN_CHAIN_SIDES=0 timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_one_stream.json
+    timeout 300 python bench.py --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_1024.json
+    QA_TRAIN_CHAIN_MAX_ROWS=8192 timeout 300 python bench.py --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_1024_chain.json
     QA_TRAIN_CHAIN=0 timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_autograd.json
     QA_TRAIN_CHAIN=0 timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_autograd.json
     timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_chain.json
