@@ -477,7 +477,9 @@ int qa_linear_backward_weight_layout(int64_t rows, int32_t in_features, int32_t 
  * training step (csrc/qa_policy.hip, ABI 17) side by side instead of one after the other.  Per product: grad_weight and grad_bias both NULL leaves
  * the parts in `scratch` as qa_linear_backward_weight_batch_layout describes (same meaning as qa_linear_backward_weight_layout; the batch plans its
  * own split, so sizes and layout come from the _batch_ functions); otherwise every finished product of the batch is added up by ONE qa_grad_reduce
- * launch at the end.  Fixed work assignment and summation order (bit-reproducible). */
+ * launch at the end.  Fixed work assignment and summation order (bit-reproducible).  When in_features is not a multiple of 4 but ldx leaves
+ * room for it (ldx >= in_features rounded up to 4, x 16-byte aligned, ldx % 4 == 0) the rows are READ up to that multiple -- the columns behind
+ * in_features must be readable memory of the same rows (any finite or non-finite values: they reach no output). */
 typedef struct qa_wgrad_desc {
     const float *grad_out; int64_t ldg;        /* (rows, out_features), row stride ldg */
     const float *x; int64_t ldx;               /* (rows, in_features), row stride ldx */

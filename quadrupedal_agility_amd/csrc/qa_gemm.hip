@@ -71,6 +71,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldo, ldy, out_split_stride, ones_split_stride;
     int a_count, b_count, kred, k_per_split, na, nb, nsplit;
     int a_vec, b_vec, o_vec, act;
+    int a_ld_count;          // > 0: the A operand's index count AS LOADED (a_count rounded up to 4: the rows have readable padding); products into a >= a_count are never stored
     float alpha;
     ConvGeom cg;             // CONV 1: the B side (k-contiguous) is a window matrix; CONV 2: the A side (index-contiguous, reduction over pixels)
 };
@@ -341,9 +342,10 @@ static __device__ __forceinline__ void qa_gemm_body(const GemmArgs &g, const int
     uint32_t conv_col = 0;
     if (CONV == 1) gemm_conv_rows<CONV == 1 ? BB : 64>(conv_rb, g.cg, b_base, g.b_count, tid);
     if (CONV == 2) conv_col = conv_koff(g.cg, min(a_base + (tid % (BA / 4)) * 4, g.a_count - 4));
+    const int a_ldc = g.a_ld_count > 0 ? g.a_ld_count : g.a_count;
     auto load_a = [&](float (&r)[BA / 16], int k0) {
         if constexpr (CONV == 2) gemm_load_conv_mc<BA>(r, g.A, conv_col, g.cg, k0, kend, tid);
-        else gemm_load<BA, A_MC, AV>(r, g.A, g.lda, a_base, g.a_count, k0, kend, tid);
+        else gemm_load<BA, A_MC, AV>(r, g.A, g.lda, a_base, a_ldc, k0, kend, tid);
     };
     auto load_b = [&](float (&r)[BB / 16], int k0) {
         if constexpr (CONV == 1) gemm_load_conv_kc<BB>(r, g.B, conv_rb, g.cg, k0, kend, tid);
@@ -354,7 +356,7 @@ static __device__ __forceinline__ void qa_gemm_body(const GemmArgs &g, const int
         load_b(sb[0], kbeg);
         load_a(sa[1], kbeg + GEMM_BK);
         load_b(sb[1], kbeg + GEMM_BK);
-        gemm_store<BA, A_MC, AV>(sa[0], lds, a_base, g.a_count, kbeg, kend, tid);
+        gemm_store<BA, A_MC, AV>(sa[0], lds, a_base, a_ldc, kbeg, kend, tid);
         gemm_store<BB, B_MC, BV>(sb[0], lds + A_TILE, b_base, g.b_count, kbeg, kend, tid);
     }
     __syncthreads();
@@ -395,7 +397,7 @@ static __device__ __forceinline__ void qa_gemm_body(const GemmArgs &g, const int
         __builtin_amdgcn_sched_barrier(0);        // ... and nothing of the store section (its mask multiplies wait for tile t+1's loads) moves above them
         float *An = lds + Q * (A_TILE + B_TILE);
         if (ABL != 1) {       // past the last tile this writes zeros (k >= kend) into the idle buffer
-            gemm_store<BA, A_MC, AV>(sa[Q], An, a_base, g.a_count, kbeg + (t + 1) * GEMM_BK, kend, tid);
+            gemm_store<BA, A_MC, AV>(sa[Q], An, a_base, a_ldc, kbeg + (t + 1) * GEMM_BK, kend, tid);
             gemm_store<BB, B_MC, BV>(sb[Q], An + A_TILE, b_base, g.b_count, kbeg + (t + 1) * GEMM_BK, kend, tid);
         }
         if (NF == 2) {
@@ -1046,7 +1048,11 @@ int qa_linear_backward_weight_batch(const qa_wgrad_desc *descs, int32_t count, v
         g.kred = (int)d.rows; g.k_per_split = kps; g.nsplit = s;
         g.out = (float *)d.scratch; g.ldo = d.in_features; g.out_split_stride = n_w_pad;
         g.ones_out = bslabs; g.ones_split_stride = n_b_pad;
-        g.a_vec = (aligned16(d.x) && d.ldx % 4 == 0 && d.in_features % 4 == 0) ? 4 : 1;
+        // x rows with readable padding up to the next multiple of 4 columns (a column slice of wider rows, e.g. the 671 observation columns of 672-wide
+        // rows): read in 16-byte pieces all the same; what the extra columns multiply into lies beyond in_features and is never stored
+        const bool x_pad = d.in_features % 4 != 0 && d.ldx >= pad4(d.in_features);
+        g.a_vec = (aligned16(d.x) && d.ldx % 4 == 0 && (d.in_features % 4 == 0 || x_pad)) ? 4 : 1;
+        g.a_ld_count = (g.a_vec == 4 && x_pad) ? (int)pad4(d.in_features) : 0;
         g.b_vec = (aligned16(d.grad_out) && d.ldg % 4 == 0 && d.out_features % 4 == 0) ? 4 : 1;
         g.o_vec = (d.in_features % 4 == 0) ? 4 : 1;
         g.na = (int)na; g.nb = (d.out_features + 63) / 64;

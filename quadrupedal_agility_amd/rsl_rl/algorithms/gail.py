@@ -336,7 +336,9 @@ class SSInfoGAIL:
                 self._priv_coef_dev = torch.zeros((), device=dev)
                 flat = [x.flatten(0, 1) for x in (st.observations, st.actions, st.values, st.advantages, st.returns,
                                                   st.actions_log_prob, st.mu, st.sigma)]
-                if fused_mod.pad_k() and getattr(st, "_obs_padded", None) is not None:
+                # (r6: also when the steps of this size run as chain launches: the first layers' weight-gradient products then read the 671 observation
+                # columns of 672-wide rows in 16-byte pieces, qa_linear_backward_weight_batch)
+                if (fused_mod.pad_k() or self._train_chain_rows(mb) is not None) and getattr(st, "_obs_padded", None) is not None:
                     flat[0] = st._obs_padded.flatten(0, 1)      # the minibatch copy keeps the zero padding (672 columns): 16-byte aligned GEMM rows
                 sync = self.grad_sync
                 all_params = list(self.estimator.parameters()) + list(self.actor_critic.parameters())
@@ -669,9 +671,13 @@ class SSInfoGAIL:
         """train_chain.PpoTrainChain for this minibatch size, or None: few rows per step (the per-GPU share of the 8-GPU job), where the
         step is a serial chain of launch-latency-sized kernels; actor and critic reading the same observation rows (they do: the reference
         stores the row twice, legged_robot.py:321)."""
+        if obs.data_ptr() != critic_obs.data_ptr() or obs.stride(1) != 1:
+            return None
+        return self._train_chain_rows(obs.shape[0])
+
+    def _train_chain_rows(self, rows):
         from quadrupedal_agility_amd.rsl_rl.algorithms import train_chain
-        rows = obs.shape[0]
-        if not train_chain.ENABLED or rows > train_chain.MAX_ROWS or obs.data_ptr() != critic_obs.data_ptr() or obs.stride(1) != 1:
+        if not (train_chain.ENABLED and self._on_gpu and self.use_fused_loss) or rows > train_chain.MAX_ROWS or self.actor_critic.fixed_std:
             return None
         cache = self.__dict__.setdefault("_train_chains", {})
         if rows not in cache:

@@ -22,7 +22,7 @@ import torch
 from quadrupedal_agility_amd import _capi
 from quadrupedal_agility_amd.rsl_rl.algorithms import fused
 
-MAX_ROWS = int(os.environ.get("QA_TRAIN_CHAIN_MAX_ROWS", "4096"))      # measured (r6): 3,072-row steps 16 % faster, 6,144-row steps 5 % slower than the three-stream autograd step
+MAX_ROWS = int(os.environ.get("QA_TRAIN_CHAIN_MAX_ROWS", "8192"))      # measured (r6, profiles/r6_chain_steps.txt): 3,072-row steps 30 % faster, 6,144-row steps 17 % faster than the three-stream autograd step; 12,288 rows and up: slower
 ENABLED = os.environ.get("QA_TRAIN_CHAIN", "1") != "0"
 DISC_ENABLED = os.environ.get("QA_DISC_TRAIN_CHAIN", "1") != "0"
 
@@ -108,6 +108,34 @@ class _Program:
         ptrs = (C.c_void_p * k)(*[o.data_ptr() for o in outs]); strides = (C.c_int64 * k)(*[o.stride(0) for o in outs])
         _ok(self._fn("mlp_forward")(_ptr(x), x.stride(0), x.shape[0], x_cols, self.c_ops, self.n_ops, _ptr(self.packed), ptrs, strides, k, self._stream(x)),
             "mlp_forward", self)
+
+
+class _Packer:
+    """qa_mlp_pack for SEVERAL programs in one launch: their layers as one op list over one packed buffer (each program's `packed` becomes its slice).
+    The weights change with every optimiser step, so a chain step repacks before it runs: one launch instead of one per program."""
+
+    def __init__(self, programs):
+        p0 = programs[0]
+        self.prog = p0
+        total = sum(p.woff for p in programs)
+        self.buf = torch.zeros(total, dtype=torch.float32, device=p0.packed.device)
+        ops, w, b, off = [], [], [], 0
+        for p in programs:
+            p.packed = self.buf[off:off + p.woff]
+            for op, param in zip(p.ops, p.params):
+                if op.kind == _capi.MLP_LAYER:
+                    o2 = _capi.QaMlpOp.from_buffer_copy(op)
+                    o2.w_off += off; o2.b_off += off
+                    ops.append(o2); w.append(param[0].data_ptr()); b.append(param[1].data_ptr() if param[1] is not None else None)
+            off += p.woff
+        assert len(ops) <= _capi.MLP_MAX_OPS and off == total
+        self.n = len(ops)
+        self.ops = (_capi.QaMlpOp * self.n)(*ops)
+        self.w = (C.c_void_p * self.n)(*w); self.b = (C.c_void_p * self.n)(*b)
+        self.total = total
+
+    def pack(self):
+        _ok(self.prog._fn("mlp_pack")(self.ops, self.n, self.w, self.b, _ptr(self.buf), self.total, self.prog._stream(self.buf)), "mlp_pack", self.prog)
 
 
 class _Sides:
@@ -229,6 +257,7 @@ class PpoTrainChain:
         b.layer(Z, 0, e_w[1], 2, 0, e_w[0], D, e2.weight, None, save=(G, g["e1"][0]), aux=(A, t["e1"][0]), transposed=True)
         b.finish()
         self.fwd, self.bwd = f, b
+        self._packer = _Packer([f, b])
         dev = a1.weight.device
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.tape, self.gtape = z(rows, self.tape_cols), z(rows, self.gtape_cols)
@@ -254,7 +283,7 @@ class PpoTrainChain:
         return self
 
     def pack(self):
-        self.fwd.pack(); self.bwd.pack()
+        self._packer.pack()
 
     def forward(self, obs):
         assert obs.shape[0] == self.rows and obs.stride(1) == 1 and obs.shape[1] >= self.dims["n_obs"]
@@ -356,6 +385,7 @@ class DiscTrainChain:
         b.layer(2, 0, w2, -1, 0, w1, DR, l2.weight, None, out=(0, GH1), aux=(1, H1), transposed=True)
         b.finish()
         self.fwd, self.pen, self.bwd = f, p, b
+        self._packer = _Packer([f, p, b])
         # opt-in side streams (QA_TRAIN_CHAIN_SIDES=1; measured slower): 1 / 2 = the second and third optimiser, 3 = what `beside()` is handed
         self.sides = _Sides(dev, 4) if (SIDE_STREAMS and prefix == "qa_") else None
         # weight-gradient products: (rows, g tensor, g col, n, x tensor, x col, k)
@@ -368,7 +398,7 @@ class DiscTrainChain:
     def pack(self):
         with torch.no_grad():
             torch.cat([h.weight for h in self.heads], dim=0, out=self.wh[:self.dims[3]])
-        self.fwd.pack(); self.pen.pack(); self.bwd.pack()
+        self._packer.pack()
 
     def forward(self, x):
         """-> logit (R, 1), epsilon (R, 1), class LOGITS (R, dim_c); then `penalty_gradient()`"""

@@ -106,7 +106,7 @@ def test_describe_declines_what_the_programs_do_not_cover():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", [48, 3072, 4096])
+@pytest.mark.parametrize("rows", [48, 3072, 6144])
 def test_hip_chain_equals_autograd(rows):
     from quadrupedal_agility_amd.rsl_rl.algorithms import fused, train_chain
     ac, est, n_obs = _modules(3)
@@ -291,9 +291,19 @@ def test_amp_training_with_the_discriminator_chain_equals_training_without_it():
 WG_SHAPES = [(3072, 671, 512), (3072, 512, 256), (3072, 101, 512), (3072, 128, 12), (3072, 128, 1), (3072, 29, 64), (3072, 64, 4), (1228, 98, 512), (1228, 1, 256), (77, 57, 128)]
 
 
+def _x_width(i, k):
+    """row width of product i's x: the first three are rows padded to the next multiple of 4 (the 671 observation columns of 672-wide rows, the actor's 101
+    input columns of a 104-wide tape region: read in 16-byte pieces INCLUDING the padding), the others k + 3 (rows that are not 16-byte aligned)"""
+    return (k + 3) // 4 * 4 if i < 3 else k + 3
+
+
 def _wg_case(seed=0):
     gen = torch.Generator().manual_seed(seed)
-    xs = [torch.randn(r, k + 3, generator=gen)[:, :k] for r, k, n in WG_SHAPES]           # row strides that are not the width: column slices of wider rows
+    xs = []
+    for i, (r, k, n) in enumerate(WG_SHAPES):
+        full = torch.randn(r, _x_width(i, k), generator=gen)
+        full[:, k:] = float("nan")                    # whatever lies behind in_features must reach no output
+        xs.append(full[:, :k])
     gs = [torch.randn(r, n + 5, generator=gen)[:, 1:1 + n] / r for r, k, n in WG_SHAPES]     # ... and a start that is not 16-byte aligned
     return xs, gs
 
@@ -337,8 +347,8 @@ def test_hip_wgrad_batch_equals_the_products_one_by_one(finished):
     from quadrupedal_agility_amd import _capi
     xs, gs = _wg_case(1)
     dx, dg = [], []          # device copies that keep the strides and the misalignment
-    for x, g in zip(xs, gs):
-        bx = torch.zeros(x.shape[0], x.shape[1] + 3, device="cuda"); bx[:, :x.shape[1]] = x.cuda(); dx.append(bx[:, :x.shape[1]])
+    for i, (x, g) in enumerate(zip(xs, gs)):
+        bx = torch.full((x.shape[0], _x_width(i, x.shape[1])), float("nan"), device="cuda"); bx[:, :x.shape[1]] = x.cuda(); dx.append(bx[:, :x.shape[1]])
         bg = torch.zeros(g.shape[0], g.shape[1] + 5, device="cuda"); bg[:, 1:1 + g.shape[1]] = g.cuda(); dg.append(bg[:, 1:1 + g.shape[1]])
     res = _run_batch(_capi.load_library(), "qa_", dx, dg, "cuda", finished)
     torch.cuda.synchronize()

@@ -52,6 +52,15 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+pad)       # batch + padded-row 16-byte loads + one pack launch + row limit 8192; crossover at 2048 envs
+    QA_TRAIN_CHAIN_SIDES=0 bash tools/r6_call.sh sides
+    O=$R/gpurun_out/r6/sides
+    timeout 300 python bench.py --num_envs 2048 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_2048.json
+    QA_TRAIN_CHAIN_MAX_ROWS=16384 timeout 300 python bench.py --num_envs 2048 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_2048_chain.json
+    QA_TRAIN_CHAIN=0 timeout 300 python bench.py --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_1024_autograd.json
+    QA_DISC_TRAIN_CHAIN=0 timeout 300 python bench.py --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_ppo_chain_only.json
+    line $O/bench_2048*.json $O/bench_1024*.json $O/bench_cfg3_512*.json
+    ;;
 batch)     # the chain steps' weight-gradient products in one call (qa_linear_backward_weight_batch): parity, suites, lines, traces
     QA_TRAIN_CHAIN_SIDES=0 bash tools/r6_call.sh sides
     ;;
