@@ -52,6 +52,22 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+quick)     # a plan change in the batched products: parity + the lines + one step each
+    timeout 900 python -m pytest tests/test_train_chain.py tests/test_grad_parts.py tests/test_golden_learner.py -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
+    for i in 1 2; do
+      timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_chain_$i.json
+      timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_$i.json
+    done
+    timeout 300 python bench.py --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_1024_chain.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp
+    rm -rf /tmp/prof; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_chain_step_sequence_512.txt 2>&1
+    rm -rf /tmp/prof; timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_disc_loss_kernel mid > $O/disc_chain_step_sequence_4096.txt 2>&1
+    cd $R
+    grep -E "wgrad|launches" $O/ppo_chain_step_sequence_512.txt $O/disc_chain_step_sequence_4096.txt | cut -c1-160
+    ;;
 pad)       # batch + padded-row 16-byte loads + one pack launch + row limit 8192; crossover at 2048 envs
     QA_TRAIN_CHAIN_SIDES=0 bash tools/r6_call.sh sides
     O=$R/gpurun_out/r6/sides
