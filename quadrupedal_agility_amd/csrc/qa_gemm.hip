@@ -986,12 +986,15 @@ int qa_linear_backward_weight(const float *grad_out, int64_t ldg, const float *x
     return QA_OK;
 }
 
-// the batch's split of the sample dimension: 64 x 64 tiles for every product and slabs of ~512 rows whatever the product's size -- the products of a
-// launch run side by side, so the launch takes what its LONGEST workgroup takes (r6: with ~256 workgroups per product the 512 x 671 one had two
-// 1,536-row slabs and took 55 us of the launch's 68 while the small products' workgroups had long finished)
+// the batch's split of the sample dimension: 64 x 64 tiles for every product, ~256 workgroups each (a dozen of them fill the chip together).
+// (r6, measured: slabs of ~512 rows for every product instead -- the launch takes what its longest workgroup takes -- moved the 512 x 671 product's
+// group 68 -> 59 us and the small products' groups 14 -> 24 us each: 371 -> 379 us per step, config 3 47.5 -> 48.0 ms; this plan stays.  The three
+// launches of a 3,072-row PPO step are 4.5 GFLOP in ~97 us.)
 static void wgrad_batch_plan(int64_t rows, int32_t in_features, int32_t out_features, int *nsplit, int *k_per_split) {
-    (void)in_features; (void)out_features;
-    int64_t s = (rows + 511) / 512;
+    const int64_t tiles = (int64_t)((in_features + 63) / 64) * ((out_features + 63) / 64);
+    int64_t s = 256 / tiles;
+    const int64_t smax = (rows + 255) / 256;
+    if (s > smax) s = smax;
     if (s > 16) s = 16;
     if (s < 1) s = 1;
     int64_t kps = ((rows + s - 1) / s + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
