@@ -128,14 +128,15 @@ class _Packer:
                     o2.w_off += off; o2.b_off += off
                     ops.append(o2); w.append(param[0].data_ptr()); b.append(param[1].data_ptr() if param[1] is not None else None)
             off += p.woff
-        assert len(ops) <= _capi.MLP_MAX_OPS and off == total
-        self.n = len(ops)
-        self.ops = (_capi.QaMlpOp * self.n)(*ops)
-        self.w = (C.c_void_p * self.n)(*w); self.b = (C.c_void_p * self.n)(*b)
+        assert off == total
+        M = _capi.MLP_MAX_OPS            # (a pack call takes at most this many layers: the task-level step's 30 go in two)
+        self.calls = [((_capi.QaMlpOp * len(ops[i:i + M]))(*ops[i:i + M]), len(ops[i:i + M]), (C.c_void_p * len(ops[i:i + M]))(*w[i:i + M]),
+                       (C.c_void_p * len(ops[i:i + M]))(*b[i:i + M])) for i in range(0, len(ops), M)]
         self.total = total
 
     def pack(self):
-        _ok(self.prog._fn("mlp_pack")(self.ops, self.n, self.w, self.b, _ptr(self.buf), self.total, self.prog._stream(self.buf)), "mlp_pack", self.prog)
+        for ops, n, w, b in self.calls:
+            _ok(self.prog._fn("mlp_pack")(ops, n, w, b, _ptr(self.buf), self.total, self.prog._stream(self.buf)), "mlp_pack", self.prog)
 
 
 class _Sides:
@@ -466,3 +467,180 @@ class DiscTrainChain:
             n = h.out_features
             h.weight.grad, h.bias.grad = gwh[r:r + n], gbh[r:r + n]
             r += n
+
+
+class TscTrainChain:
+    """PpoTrainChain's counterpart for the task-level learner's minibatch step (tsc/rsl_rl/algorithms/ppo.py:222-262 through autograd; modules
+    tsc/rsl_rl/modules/actor_critic.py:59-284): estimator 57-128-64-4, scan encoder 132-128-64-32 (tanh), privileged encoder 29-64-29, trunk
+    130-512-256-128 with the categorical (3) and the Gaussian (18) head, critic 800-512-256-128-1 -- 17 Linear layers.  forward(obs) -> (est, logits,
+    mean, value, priv_latent); backward(g_est, dlogits, dmean, dvalue, g_priv) -> `.grad` of the 34 parameters (the two heads' as row views of one
+    stacked (21, 128) product).  6,144-row steps (1024 envs per GPU, BASELINE configs[3]'s share) are inside the row limit."""
+
+    @classmethod
+    def describe(cls, ac, estimator, rows, est_in, lib=None, prefix="qa_"):
+        import torch.nn as nn
+        actor = ac.actor
+        lin = fused.PolicyChain._linears
+
+        def stack(seq, tanh_last=False):
+            mods = list(seq) if isinstance(seq, nn.Sequential) else None
+            if mods is None:
+                return None
+            if tanh_last:
+                if not isinstance(mods[-1], nn.Tanh):
+                    return None
+                body = lin(nn.Sequential(*mods[:-1]))
+                if body is None or body[-1][1] != 0:
+                    return None
+                body[-1][1] = 3
+                return body
+            return lin(seq)
+        if not ENABLED or rows > MAX_ROWS or not actor.if_scan_encode or isinstance(actor.priv_encoder, nn.Identity) or not isinstance(ac.std, nn.Parameter):
+            return None
+        st = dict(scan=stack(actor.scan_encoder, True), priv=stack(actor.priv_encoder), trunk=stack(actor.actor_trunk), critic=stack(ac.critic), est=stack(estimator.estimator))
+        if any(v is None for v in st.values()):
+            return None
+        acts = {k: [a for _, a in v] for k, v in st.items()}
+        if (acts["scan"] != [1, 1, 3] or acts["priv"] != [1, 1] or acts["trunk"] != [1, 1, 1] or acts["critic"] != [1, 1, 1, 0] or acts["est"] != [1, 1, 0]):
+            return None
+        a, n_scan, n_exp, n_lat = actor.num_prop, actor.num_scan, actor.num_priv_explicit, actor.num_priv_latent
+        scan0, exp0, lat0 = a, a + n_scan, a + n_scan + n_exp
+        (s1, s2, s3), (p1, p2), (t1, t2, t3), (c1, c2, c3, c4), (e1, e2, e3) = ([l for l, _ in st[k]] for k in ("scan", "priv", "trunk", "critic", "est"))
+        hd, hc = actor.actor_d, actor.actor_c
+        n_obs, n_lats = c1.in_features, s3.out_features
+        n_in = a + n_lats + n_exp + n_lat
+        nh = hd.out_features + hc.out_features
+        cols = _capi.MLP_BUF_COLS
+        sw, pw, tw, cw, ew = ([l.out_features for l in ls] for ls in ((s1, s2, s3), (p1, p2), (t1, t2, t3), (c1, c2, c3, c4), (e1, e2, e3)))
+        ok = (n_obs <= cols[0] and lat0 + n_lat <= n_obs and t1.in_features == n_in and n_in <= cols[2] and tw[0] <= cols[1] and tw[1] <= cols[2] and tw[2] <= cols[3]
+              and cw[0] <= cols[1] and cw[1] <= cols[2] and cw[2] <= cols[3] and cw[3] == 1 and sw[0] <= cols[3] and sw[1] <= cols[1] and n_scan <= cols[1]
+              and pw[0] <= cols[3] and pw[1] == n_lat and ew[0] <= cols[3] and ew[1] <= cols[2] and ew[2] == n_exp and e1.in_features == est_in and est_in <= a
+              and s1.in_features == n_scan and p1.in_features == n_lat and nh <= 24 and hd.in_features == tw[2] and hc.in_features == tw[2] and _pad4(nh) <= cols[3])
+        if not ok:
+            return None
+        self = cls()
+        self.ac, self.estimator, self.rows = ac, estimator, rows
+        self.dims = dict(a=a, n_scan=n_scan, n_exp=n_exp, n_lat=n_lat, n_obs=n_obs, n_in=n_in, nh=nh, nd=hd.out_features, nc=hc.out_features, est_in=est_in,
+                         scan0=scan0, exp0=exp0, lat0=lat0)
+        t, off = {}, 0
+        for name, w in (("tin", n_in), ("s1", sw[0]), ("s2", sw[1]), ("p1", pw[0]), ("t1", tw[0]), ("t2", tw[1]), ("t3", tw[2]), ("c1", cw[0]), ("c2", cw[1]), ("c3", cw[2]),
+                        ("e1", ew[0]), ("e2", ew[1])):
+            t[name] = (off, w); off += _pad4(w)
+        self.tape_cols, self.t = off, t
+        g, off = {}, 0
+        for name, w in (("t3", tw[2]), ("t2", tw[1]), ("t1", tw[0]), ("s3", sw[2]), ("s2", sw[1]), ("s1", sw[0]), ("p2", n_lat), ("p1", pw[0]), ("c3", cw[2]), ("c2", cw[1]),
+                        ("c1", cw[0]), ("e2", ew[1]), ("e1", ew[0])):
+            g[name] = (off, w); off += _pad4(w)
+        self.gtape_cols, self.g = off, g
+        E, D, TANH, DTANH = 1, _capi.MLP_ACT_ELU_GRAD, 3, _capi.MLP_ACT_TANH_GRAD
+        T, LG, MU, VAL, EST, PRIV = 0, 1, 2, 3, 4, 5
+        tin = t["tin"][0]
+        c_lats, c_exp, c_lat = a, a + n_lats, a + n_lats + n_exp          # columns of the trunk's input row
+        f = _Program(lib, prefix)
+        # critic first: it may use every scratch buffer
+        f.layer(0, 0, n_obs, 1, 0, cw[0], E, c1.weight, c1.bias, save=(T, t["c1"][0]))
+        f.layer(1, 0, cw[0], 2, 0, cw[1], E, c2.weight, c2.bias, save=(T, t["c2"][0]))
+        f.layer(2, 0, cw[1], 3, 0, cw[2], E, c3.weight, c3.bias, save=(T, t["c3"][0]))
+        f.layer(3, 0, cw[2], -1, 0, 1, 0, c4.weight, c4.bias, out=(VAL, 0))
+        f.layer(0, 0, est_in, 3, 0, ew[0], E, e1.weight, e1.bias, save=(T, t["e1"][0]))
+        f.layer(3, 0, ew[0], 2, 0, ew[1], E, e2.weight, e2.bias, save=(T, t["e2"][0]))
+        f.layer(2, 0, ew[1], -1, 0, n_exp, 0, e3.weight, e3.bias, out=(EST, 0))
+        # the trunk's input row in buffer 2: proprioception | scan latent | true privileged-explicit state | privileged latent
+        f.copy(0, 0, 2, 0, a, save=(T, tin))
+        f.copy(0, scan0, 1, 0, n_scan)                                                # (a layer's source starts 16-byte aligned)
+        f.layer(1, 0, n_scan, 3, 0, sw[0], E, s1.weight, s1.bias, save=(T, t["s1"][0]))
+        f.layer(3, 0, sw[0], 1, 0, sw[1], E, s2.weight, s2.bias, save=(T, t["s2"][0]))
+        f.layer(1, 0, sw[1], 2, c_lats, n_lats, TANH, s3.weight, s3.bias, save=(T, tin + c_lats))
+        f.copy(0, exp0, 2, c_exp, n_exp, save=(T, tin + c_exp))
+        f.copy(0, lat0, 1, 0, n_lat)
+        f.layer(1, 0, n_lat, 3, 0, pw[0], E, p1.weight, p1.bias, save=(T, t["p1"][0]))
+        f.layer(3, 0, pw[0], 2, c_lat, n_lat, E, p2.weight, p2.bias, save=(T, tin + c_lat))
+        f.copy(2, c_lat, 3, 0, n_lat, save=(PRIV, 0))                                 # the privileged latent once more, dense, for the regulariser's kernel
+        f.layer(2, 0, n_in, 1, 0, tw[0], E, t1.weight, t1.bias, save=(T, t["t1"][0]))
+        f.layer(1, 0, tw[0], 2, 0, tw[1], E, t2.weight, t2.bias, save=(T, t["t2"][0]))
+        f.layer(2, 0, tw[1], 3, 0, tw[2], E, t3.weight, t3.bias, save=(T, t["t3"][0]))
+        f.layer(3, 0, tw[2], -1, 0, hd.out_features, 0, hd.weight, hd.bias, out=(LG, 0))
+        f.layer(3, 0, tw[2], -1, 0, hc.out_features, 0, hc.weight, hc.bias, out=(MU, 0))
+        f.finish()
+        # ---- backward.  Input tile = d loss / d gait logits; outputs: 0 = gradient tape (written), 1 = activation tape, 2 = d mean, 3 = d latent, 4 = d value, 5 = d
+        # estimate (read), 6 = [d logits | d mean] side by side (written: the stacked heads' weight-gradient product reads it)
+        G, A, DM, DP, DV, DE, GH = 0, 1, 2, 3, 4, 5, 6
+        dev = t1.weight.device
+        self.wh = torch.zeros(_pad4(nh), tw[2], dtype=torch.float32, device=dev)      # the two heads' weights stacked; refreshed by pack()
+        nd = hd.out_features
+        b = _Program(lib, prefix)
+        b.copy(0, 0, 3, 0, nd, save=(GH, 0))
+        b.load((DM, 0), 3, nd, hc.out_features, save=(GH, nd))
+        b.layer(3, 0, _pad4(nh), 1, 0, tw[2], D, self.wh, None, save=(G, g["t3"][0]), aux=(A, t["t3"][0]), transposed=True)
+        b.layer(1, 0, tw[2], 2, 0, tw[1], D, t3.weight, None, save=(G, g["t2"][0]), aux=(A, t["t2"][0]), transposed=True)
+        b.layer(2, 0, tw[1], 1, 0, tw[0], D, t2.weight, None, save=(G, g["t1"][0]), aux=(A, t["t1"][0]), transposed=True)
+        b.layer(1, 0, tw[0], 2, 0, n_in, 0, t1.weight, None, transposed=True)                         # d loss / d trunk input: its scan-latent and latent columns go on
+        b.grad(2, c_lats, 3, 0, n_lats, act=DTANH, aux=(A, tin + c_lats), save=(G, g["s3"][0]))
+        b.layer(3, 0, n_lats, 1, 0, sw[1], D, s3.weight, None, save=(G, g["s2"][0]), aux=(A, t["s2"][0]), transposed=True)
+        b.layer(1, 0, sw[1], 3, 0, sw[0], D, s2.weight, None, save=(G, g["s1"][0]), aux=(A, t["s1"][0]), transposed=True)
+        b.load((DP, 0), 1, 0, n_lat)
+        b.grad(2, c_lat, 1, 0, n_lat, act=D, aux=(A, tin + c_lat), add=True, save=(G, g["p2"][0]))
+        b.layer(1, 0, n_lat, 3, 0, pw[0], D, p2.weight, None, save=(G, g["p1"][0]), aux=(A, t["p1"][0]), transposed=True)
+        b.load((DV, 0), 1, 0, 1)
+        b.layer(1, 0, 1, 3, 0, cw[2], D, c4.weight, None, save=(G, g["c3"][0]), aux=(A, t["c3"][0]), transposed=True)
+        b.layer(3, 0, cw[2], 2, 0, cw[1], D, c3.weight, None, save=(G, g["c2"][0]), aux=(A, t["c2"][0]), transposed=True)
+        b.layer(2, 0, cw[1], 1, 0, cw[0], D, c2.weight, None, save=(G, g["c1"][0]), aux=(A, t["c1"][0]), transposed=True)
+        b.load((DE, 0), 3, 0, n_exp)
+        b.layer(3, 0, n_exp, 2, 0, ew[1], D, e3.weight, None, save=(G, g["e2"][0]), aux=(A, t["e2"][0]), transposed=True)
+        b.layer(2, 0, ew[1], 3, 0, ew[0], D, e2.weight, None, save=(G, g["e1"][0]), aux=(A, t["e1"][0]), transposed=True)
+        b.finish()
+        self.fwd, self.bwd = f, b
+        self._packer = _Packer([f, b])
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.tape, self.gtape, self.gh = z(rows, self.tape_cols), z(rows, self.gtape_cols), z(rows, _pad4(nh))
+        self.logits, self.mean, self.value, self.est, self.priv = z(rows, nd), z(rows, hc.out_features), z(rows, 1), z(rows, n_exp), z(rows, n_lat)
+        tc = lambda name: ("tape", t[name][0], t[name][1])
+        gcol = lambda name: ("gtape", g[name][0], g[name][1])
+        # (module or None for the stacked heads, gradient columns, input columns)
+        self.wgrads = [(c1, gcol("c1"), ("obs", 0, n_obs)), (c2, gcol("c2"), tc("c1")), (c3, gcol("c3"), tc("c2")), (c4, ("dvalue", 0, 1), tc("c3")),
+                       (t1, gcol("t1"), ("tape", tin, n_in)), (t2, gcol("t2"), tc("t1")), (t3, gcol("t3"), tc("t2")), (None, ("gh", 0, nh), tc("t3")),
+                       (s1, gcol("s1"), ("obs", scan0, n_scan)), (s2, gcol("s2"), tc("s1")), (s3, gcol("s3"), tc("s2")),
+                       (p1, gcol("p1"), ("obs", lat0, n_lat)), (p2, gcol("p2"), tc("p1")),
+                       (e1, gcol("e1"), ("obs", 0, est_in)), (e2, gcol("e2"), tc("e1")), (e3, ("g_est", 0, n_exp), tc("e2"))]
+        self._wg = []
+        for lin_, (_, _, n), (_, _, k) in self.wgrads:
+            nb = int(f._fn("linear_backward_weight_batch_scratch_bytes")(rows, k, n))
+            lay = (C.c_int64 * 5)()
+            _ok(f._fn("linear_backward_weight_batch_layout")(rows, k, n, lay), "linear_backward_weight_batch_layout", f)
+            self._wg.append((torch.zeros(nb // 4 + 4, dtype=torch.float32, device=dev), nb, [int(v) for v in lay], z(n, k), z(n)))
+        return self
+
+    def pack(self):
+        with torch.no_grad():
+            torch.cat([self.ac.actor.actor_d.weight, self.ac.actor.actor_c.weight], dim=0, out=self.wh[:self.dims["nh"]])
+        self._packer.pack()
+
+    def forward(self, obs):
+        assert obs.shape[0] == self.rows and obs.stride(1) == 1 and obs.shape[1] >= self.dims["n_obs"]
+        self._obs = obs
+        self.fwd.launch(obs, self.dims["n_obs"], [self.tape, self.logits, self.mean, self.value, self.est, self.priv])
+        return self.est, self.logits, self.mean, self.value, self.priv
+
+    def backward(self, g_est, dlogits, dmean, dvalue, g_priv, defer=True):
+        d = self.dims
+        f32c = lambda x, shape: (x if (x.dtype == torch.float32 and x.is_contiguous()) else x.contiguous().float()).view(shape)
+        dlogits, dmean = f32c(dlogits, (self.rows, d["nd"])), f32c(dmean, (self.rows, d["nc"]))
+        dvalue, g_est, g_priv = f32c(dvalue, (self.rows, 1)), f32c(g_est, (self.rows, d["n_exp"])), f32c(g_priv, (self.rows, d["n_lat"]))
+        self.bwd.launch(dlogits, d["nd"], [self.gtape, self.tape, dmean, g_priv, dvalue, g_est, self.gh])
+        src = {"tape": self.tape, "gtape": self.gtape, "gh": self.gh, "dvalue": dvalue, "g_est": g_est, "obs": self._obs}
+        defer = defer and dlogits.is_cuda and fused.ENABLED and os.environ.get("QA_DEFER_GRAD_FINISH", "1") != "0"
+        descs = (_capi.QaWgradDesc * len(self.wgrads))()
+        for i, ((lin_, (gs, g0, gn), (xs, x0, xk)), (scratch, nb, lay, gw, gb)) in enumerate(zip(self.wgrads, self._wg)):
+            gt, xt = src[gs], src[xs]
+            descs[i] = _capi.QaWgradDesc(gt.data_ptr() + 4 * g0, gt.stride(0), xt.data_ptr() + 4 * x0, xt.stride(0), None if defer else gw.data_ptr(),
+                                         None if defer else gb.data_ptr(), self.rows, xk, gn, scratch.data_ptr(), nb)
+        _ok(self.bwd._fn("linear_backward_weight_batch")(descs, len(self.wgrads), self.bwd._stream(dlogits)), "linear_backward_weight_batch", self.bwd)
+        hd, hc = self.ac.actor.actor_d, self.ac.actor.actor_c
+        for (lin_, (_, _, n), (_, _, k)), (scratch, nb, lay, gw, gb) in zip(self.wgrads, self._wg):
+            # the stacked heads' product: each head's gradient is a run of its rows -- of the finished product and of every part alike
+            pieces = [(lin_, 0, n)] if lin_ is not None else [(hd, 0, d["nd"]), (hc, d["nd"], d["nc"])]
+            for m, r0, rn in pieces:
+                m.weight.grad, m.bias.grad = gw[r0:r0 + rn], gb[r0:r0 + rn]
+                if defer:
+                    fused.register_grad_parts(m.weight, scratch[r0 * k:], lay[0], lay[1], m.weight.grad)
+                    fused.register_grad_parts(m.bias, scratch[lay[4] + r0:], lay[2], lay[3], m.bias.grad)

@@ -109,4 +109,5 @@ class RolloutStorage:
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
                 idx = perm[i * mb:(i + 1) * mb]
-                yield (obs[idx], cobs[idx], *(x[idx] for x in rest), (None, None), None)
+                o = obs[idx]
+                yield (o, o if cobs is obs else cobs[idx], *(x[idx] for x in rest), (None, None), None)      # (one gather when the critic sees the actor's row)

@@ -356,3 +356,89 @@ def test_hip_wgrad_batch_equals_the_products_one_by_one(finished):
         rw, rb = g.t().double().mm(x.double()), g.double().sum(0)
         assert torch.allclose(gw.cpu().double(), rw, rtol=2e-4, atol=2e-6 * float(rw.abs().max())), shape
         assert torch.allclose(gb.cpu().double(), rb, rtol=2e-4, atol=2e-6 * float(rb.abs().max()) + 1e-9), shape
+
+
+# ------------------------------------------------------------------ the task-level learner's step
+def _tsc_reference(ac, est, obs, g_est, dlogits, dmean, dvalue, g_priv):
+    """autograd through the modules as tsc/rsl_rl/algorithms/ppo.py:_minibatch_forward_backward calls them"""
+    from quadrupedal_agility_amd.rsl_rl.modules.actor_critic import _head
+    for p in list(ac.parameters()) + list(est.parameters()):
+        p.grad = None
+    emb = ac.actor(obs, False)
+    logits, mean = _head(ac.actor.actor_d, emb), _head(ac.actor.actor_c, emb)
+    value = ac.evaluate(obs)
+    priv = ac.actor.infer_priv_latent(obs)
+    e = est(obs[:, :57])
+    torch.autograd.backward([e, logits, mean, value, priv], [g_est, dlogits, dmean, dvalue.view_as(value), g_priv])
+    return e.detach(), logits.detach(), mean.detach(), value.detach(), priv.detach()
+
+
+def _tsc_inputs(rows, n_obs, nd, nc, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return r(rows, n_obs) * 0.7, r(rows, 4) / rows, r(rows, nd) / rows, r(rows, nc) / rows, r(rows) / rows, r(rows, 29) * 0.1 / rows
+
+
+def test_task_level_chain_programs_equal_autograd_through_the_oracle_twins():
+    from tests.test_policy_chain import tsc_modules
+    from quadrupedal_agility_amd.rsl_rl.algorithms import train_chain
+    lib = load_oracle()
+    ac, est, n_obs = tsc_modules(4)
+    rows = 21
+    chain = train_chain.TscTrainChain.describe(ac, est, rows, 57, lib=lib, prefix="qo_")
+    assert chain is not None and chain.fwd.n_ops <= 24 and chain.bwd.n_ops <= 24
+    nd, nc = chain.dims["nd"], chain.dims["nc"]
+    obs, g_est, dlogits, dmean, dvalue, g_priv = _tsc_inputs(rows, n_obs, nd, nc)
+    refs = _tsc_reference(ac, est, obs, g_est, dlogits, dmean, dvalue, g_priv)
+    named = list(ac.named_parameters()) + list(est.named_parameters())
+    grads_ref = {n: (p.grad.clone() if p.grad is not None else None) for n, p in named}
+    chain.pack()
+    outs = chain.forward(obs)
+    for got, exp, tag in zip(outs, refs, ("est", "logits", "mean", "value", "priv")):
+        assert torch.allclose(got, exp, rtol=1e-5, atol=2e-6), (tag, float((got - exp).abs().max()))
+    for p in list(ac.parameters()) + list(est.parameters()):
+        p.grad = None
+    chain.backward(g_est, dlogits, dmean, dvalue, g_priv, defer=False)
+    checked = 0
+    for n, p in named:
+        gr = grads_ref[n]
+        if gr is None:
+            continue               # history encoder, std: not the chain's
+        scale = float(gr.abs().max()) + 1e-30
+        assert p.grad is not None and p.grad.shape == p.shape, n
+        assert float((p.grad - gr).abs().max()) <= 2e-5 * scale, (n, float((p.grad - gr).abs().max()), scale)
+        checked += 1
+    assert checked == 34
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [40, 6144])
+def test_hip_task_level_chain_equals_autograd(rows):
+    from tests.test_policy_chain import tsc_modules
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused, train_chain
+    ac_r, est_r, n_obs = tsc_modules(6)
+    ac, est, _ = tsc_modules(6)
+    ac, est = ac.cuda(), est.cuda()
+    chain = train_chain.TscTrainChain.describe(ac, est, rows, 57)
+    assert chain is not None
+    ins = _tsc_inputs(rows, n_obs, chain.dims["nd"], chain.dims["nc"], seed=rows)
+    refs = _tsc_reference(ac_r, est_r, *ins)
+    dv = [x.cuda() for x in ins]
+    chain.pack()
+    outs = chain.forward(dv[0])
+    torch.cuda.synchronize()
+    for got, exp, tag in zip(outs, refs, ("est", "logits", "mean", "value", "priv")):
+        assert torch.allclose(got.cpu(), exp, rtol=2e-4, atol=2e-5), (tag, float((got.cpu() - exp).abs().max()))
+    ref = list(ac_r.named_parameters()) + list(est_r.named_parameters())
+    got = list(ac.parameters()) + list(est.parameters())
+    chain.backward(*dv[1:], defer=False)
+    torch.cuda.synchronize()
+    _check_grads(ref, got, 3e-4, "finished")
+    for p in got:
+        p.grad = None
+    chain.forward(dv[0])
+    chain.backward(*dv[1:], defer=True)
+    assert fused.pending_grads() == 34
+    fused.flush_pending_grads()
+    torch.cuda.synchronize()
+    _check_grads(ref, got, 3e-4, "parts")

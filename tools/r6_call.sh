@@ -52,6 +52,17 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+tsc)       # the task-level learner's step as chain launches: parity, its suites, the 1024-env line with / without
+    timeout 900 python -m pytest tests/test_train_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; grep -E "passed|failed" $O/pytest_chain.log | tail -2
+    timeout 1800 python -m pytest tests/test_tsc_learner.py tests/test_tsc_env.py tests/test_tsc_course_env.py tests/test_tsc_glue.py tests/test_tsc_student.py tests/test_tsc_depth.py -m gpu -q > $O/pytest_tsc.log 2>&1; grep -E "passed|failed|^FAILED" $O/pytest_tsc.log | tail -5
+    for i in 1 2; do
+      timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 --no_cpu_baseline 2>$O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc1024_chain_$i.json
+    done
+    QA_TRAIN_CHAIN=0 timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_autograd.json
+    timeout 400 python bench.py --tsc --num_envs 512 --steps 8 --warmup 3 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc512_chain.json
+    QA_TRAIN_CHAIN=0 timeout 400 python bench.py --tsc --num_envs 512 --steps 8 --warmup 3 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc512_autograd.json
+    line $O/bench_*.json
+    ;;
 quick)     # a plan change in the batched products: parity + the lines + one step each
     timeout 900 python -m pytest tests/test_train_chain.py tests/test_grad_parts.py tests/test_golden_learner.py -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
     for i in 1 2; do
