@@ -196,10 +196,10 @@ def _register_parts(param, parts, nparts, stride, shape=None):
 
 def register_grad_parts(param, parts, nparts, stride, grad):
     """A gradient computed OUTSIDE autograd, left in parts (train_chain.PpoTrainChain.backward): `grad` is the tensor the finish writes
-    (the caller has made it `param.grad`), `parts` a buffer the caller keeps.  A parameter that already has a gradient in parts gets that one
-    finished first and this one ADDED would need a second buffer -- not a case the chain produces (one product per parameter per step)."""
-    if param.data_ptr() in _PENDING:
-        raise RuntimeError("register_grad_parts: the parameter already has a gradient in parts")
+    (the caller has made it `param.grad`), `parts` a buffer the caller keeps.  One product per parameter per step, assigned, never accumulated."""
+    # a chain step's gradient REPLACES what a previous call left unfinished (the recorded update's warm-up pass runs the step without the
+    # optimiser; a step whose capture failed is run again eagerly): these gradients are never accumulated, the newest product is the gradient
+    _PENDING.pop(param.data_ptr(), None)
     parts._qa_persistent = True
     _PENDING[param.data_ptr()] = (param, parts, int(nparts), int(stride), grad, torch.cuda.current_stream(param.device))
 
