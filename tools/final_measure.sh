@@ -25,18 +25,21 @@ for NE in 8192 1024; do [ -f $O/tsc_env_step_traffic_$NE.json ] && cp $O/tsc_env
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
 timeout 300 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d /tmp/pmc_sq -- python tools/pmc_env_step.py 4096 3 < /dev/null > /tmp/pmc_sq.log 2>&1
 python tools/pmc_tsc_env.py summarize /tmp/pmc_sq > $O/env_step_sq_counters.txt 2>&1
-timeout 500 python bench.py 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json
-timeout 400 python bench.py --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_amp.json
-timeout 400 python bench.py --terrain trimesh --no_cpu_baseline 2> $O/bench_trimesh.err < /dev/null | grep '"metric"' > $O/bench_cfg2_trimesh.json
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench_cfg2.err < /dev/null | grep '"metric"' > $O/bench_cfg2.json        # the driver's own command (BENCH_rNN.json `cmd`)
+timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_amp.json
+timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --terrain trimesh --no_cpu_baseline 2> $O/bench_trimesh.err < /dev/null | grep '"metric"' > $O/bench_cfg2_trimesh.json
 ( export MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 QA_FORCE_DATA_PARALLEL=1; timeout 400 python bench.py --no_cpu_baseline 2> $O/bench_dp.err < /dev/null | grep '"metric"' > $O/bench_cfg2_dp_path_1gpu.json )
-timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu.json
+for NE in 2048 1024 512; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs $NE --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_${NE}_per_gpu.json; done
+QA_TRAIN_CHAIN=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu_autograd_steps.json
+QA_TRAIN_CHAIN=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_autograd_steps.json
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_512_per_gpu.json
 # (r4) the data-parallel code path with TWO ranks sharing this one GPU (gloo through host memory): a bound on the path's own cost, not a scaling measurement
-QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --scaling strong --no_cpu_baseline 2> $O/bench_shared_strong.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_strong.json
-QA_BENCH_SHARED_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 2 --scaling weak --num_envs 4096 --no_cpu_baseline 2> $O/bench_shared_weak.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_weak.json
-timeout 400 python bench.py --tsc --steps 6 --warmup 3 2> $O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_8192.json
-timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024.json
-timeout 400 python bench.py --tsc --vision --num_envs 512 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_512.json
-timeout 400 python bench.py --tsc --vision --num_envs 256 --steps 5 --warmup 2 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_256.json
+QA_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --scaling strong --no_cpu_baseline 2> $O/bench_shared_strong.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_strong.json
+QA_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --scaling weak --num_envs 4096 --no_cpu_baseline 2> $O/bench_shared_weak.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_weak.json
+timeout 600 python bench.py --tsc --steps 20 --warmup 5 2> $O/bench_tsc.err < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_8192.json
+timeout 500 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024.json
+timeout 600 python bench.py --tsc --vision --num_envs 512 --steps 20 --warmup 5 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_512.json
+timeout 600 python bench.py --tsc --vision --num_envs 256 --steps 20 --warmup 5 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_student_256.json
 timeout 200 python tools/quick_time.py > $O/quick_time.txt 2>&1 < /dev/null
 timeout 200 python tools/quick_time.py --terrain >> $O/quick_time.txt 2>&1 < /dev/null
 timeout 200 python tools/policy_time.py 4096 > $O/policy_time.txt 2>&1 < /dev/null

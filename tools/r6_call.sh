@@ -52,6 +52,12 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+flaky)     # is the 8192-env recorded-vs-eager difference run-to-run noise?  the same test four times, chains on / off
+    for i in 1 2; do
+      timeout 600 python -m pytest "tests/test_tsc_learner.py::test_recorded_update_equals_eager_update[8192-False]" -m gpu -q 2>&1 | grep -E "differ by|passed|failed" | head -3
+      QA_TRAIN_CHAIN=0 timeout 600 python -m pytest "tests/test_tsc_learner.py::test_recorded_update_equals_eager_update[8192-False]" -m gpu -q 2>&1 | grep -E "differ by|passed|failed" | head -3
+    done
+    ;;
 tsc)       # the task-level learner's step as chain launches: parity, its suites, the 1024-env line with / without
     timeout 900 python -m pytest tests/test_train_chain.py -m gpu -x -q > $O/pytest_chain.log 2>&1; grep -E "passed|failed" $O/pytest_chain.log | tail -2
     timeout 1800 python -m pytest tests/test_tsc_learner.py tests/test_tsc_env.py tests/test_tsc_course_env.py tests/test_tsc_glue.py tests/test_tsc_student.py tests/test_tsc_depth.py -m gpu -q > $O/pytest_tsc.log 2>&1; grep -E "passed|failed|^FAILED" $O/pytest_tsc.log | tail -5
