@@ -52,6 +52,11 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+suite)     # the driver's round-end tiers on HEAD: the whole GPU suite, smoke(), the default bench line
+    timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err < /dev/null | grep '"metric"' > $O/bench_default.json; cut -c1-300 $O/bench_default.json
+    ;;
 flaky)     # is the 8192-env recorded-vs-eager difference run-to-run noise?  the same test four times, chains on / off
     for i in 1 2; do
       timeout 600 python -m pytest "tests/test_tsc_learner.py::test_recorded_update_equals_eager_update[8192-False]" -m gpu -q 2>&1 | grep -E "differ by|passed|failed" | head -3
