@@ -394,11 +394,23 @@ def bench_tsc(args, world, rank, local_rank, dev):
     env = lr.LeggedRobot(cfg, sim_device=dev)
     runner = OnPolicyRunner(env, tcfg, log_dir=None, device=dev)
     torch.manual_seed(1 + 104729 * rank)                   # the ranks' action noise / start draws differ
-    runner.learn(max(args.warmup, 2), init_at_random_ep_len=True)
+    # as in the behaviour-level bench: the teacher's every-20th-iteration DAgger variant of the rollout is recorded at its second use (iteration 20);
+    # those one-off captures run untimed whatever W is, and the timed region measures steady state -- with its share of DAgger iterations
+    # (r6: `--steps 20 --warmup 5` had the capture inside the timed region: 31.2 ms per iteration against 24.5 with 8 + 3)
+    pre = 0 if args.vision else max(0, 21 - max(args.warmup, 2))
+    if pre:
+        runner.learn(pre, init_at_random_ep_len=True)
+    runner.learn(max(args.warmup, 2), init_at_random_ep_len=(pre == 0))
     _barrier_sync(world)
     t0 = time.perf_counter()
+    iter_ms = []
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         runner.learn(1)
+        if os.environ.get("QA_BENCH_TRACE"):
+            torch.cuda.synchronize(); iter_ms.append((time.perf_counter() - t1) * 1e3)
+    if iter_ms and rank == 0:
+        print("per-iteration ms:", " ".join(f"{v:.1f}" for v in iter_ms), file=sys.stderr)
     _barrier_sync(world)
     dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
     # the two phases of an iteration, measured apart AFTER the timed region between device syncs (inside it the host never waits for the

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QA_ABI_VERSION 17
+#define QA_ABI_VERSION 18
 #define QA_NUM_DOF 12
 #define QA_NUM_BODIES_ABI 19
 #define QA_NUM_GAITS 5          /* walk, pace, trot, canter, jump (go2_locomotion_config.py:24) */
@@ -588,6 +588,34 @@ int qa_clip_adam_step_reduce(float *const *params, const float *const *grads_hos
  * gradients into its all-reduce bucket; tests): dst_host[t][i] = sum_z src_host[t][z stride_host[t] + i], i < numel_host[t]. */
 int qa_grad_reduce(float *const *dst_host, const float *const *src_host, const int64_t *stride_host, const int32_t *parts_host,
                    const int32_t *numel_host, int32_t num_tensors, void *stream);
+
+/* ABI 18: the optimiser half of a DISCRIMINATOR step in one launch.  The reference steps three Adam optimisers one after the other
+ * (bbc/rsl_rl/algorithms/gail.py:518-520), each over the trunk's parameters plus one head's (gail.py:107-132): the trunk is stepped THREE times per
+ * minibatch from the same gradient, each time with that optimiser's own moments and step counter, the later ones seeing the weights the earlier
+ * ones left (their weight decay reads them).  An element's updates depend on nothing but that element, so one pass applies a tensor's states in
+ * order; the gradient it starts from is put together in the same pass:
+ *     grad[i] = sum_z src1[z stride1 + i]  (parts1 > 0; else grad[i] as it is)        the head losses' product, still in parts
+ *             + alpha2 * sum_z src2[z stride2 + i]  (parts2 > 0; summed into tmp first)   the gradient penalty's product (gail.py:487-501)
+ *             + reg * param[i]                                                       the weight regularisers 2 c W (gail.py:503-511)
+ *     for s < num_states:  g = weight_decay_s * param[i] + grad[i];  Adam moments, bias corrections from step_s + 1, param[i] -= lr_s ...
+ * grad is WRITTEN (what reads `.grad` after the step sees the finished gradient).  Sums in part order (bit-reproducible), fused multiply-adds
+ * for the three additions.  Tensors with more than 16 parts in either source are walked in 32-element chunks (bias gradients), the others in
+ * 512-element chunks.  All pointers are device pointers (lr included: one float each); `ticket` is one zeroed device word the launch leaves at
+ * zero (the last workgroup to arrive writes the incremented step counters).  At most QA_ADAM_STACK_MAX_TENSORS tensors: they travel in the
+ * kernel arguments. */
+#define QA_ADAM_STACK_MAX_TENSORS 16
+#define QA_ADAM_STACK_MAX_STATES 3
+typedef struct qa_adam_stack_state { float *exp_avg, *exp_avg_sq, *step; const float *lr; float weight_decay; int32_t pad_; } qa_adam_stack_state;
+typedef struct qa_adam_stack_tensor {
+    float *param, *grad, *tmp;                 /* tmp: numel floats, needed when parts2 > 0 */
+    const float *src1, *src2;
+    int64_t stride1, stride2;
+    int32_t parts1, parts2;
+    float alpha2, reg;
+    int32_t numel, num_states;
+    qa_adam_stack_state state[QA_ADAM_STACK_MAX_STATES];
+} qa_adam_stack_tensor;
+int qa_adam_stack_step(const qa_adam_stack_tensor *tensors_host, int32_t count, float beta1, float beta2, float eps, uint32_t *ticket, void *stream);
 
 /* Two small losses of the PPO step with their gradient in the same pass (a (rows, cols) contiguous, b (rows, cols) with row
  * stride b_stride, fp32 device pointers; grad_a (rows, cols); out[1]):

@@ -1974,6 +1974,41 @@ int qo_clip_adam_step_reduce(float *const *params, const float *const *grads_hos
                              beta1, beta2, eps, max_norm, scratch, scratch_floats, stream);
 }
 
+/* ABI 18: a tensor's gradient put together (parts + alpha2 * second parts + reg * W), then its Adam states in order (the three optimisers of
+ * bbc/rsl_rl/algorithms/gail.py:107-132 stepped one after the other, gail.py:518-520; regularisers gail.py:503-511, penalty gail.py:487-501) */
+int qo_adam_stack_step(const qa_adam_stack_tensor *tensors, int32_t count, float beta1, float beta2, float eps, uint32_t *ticket, void *stream) {
+    (void)stream;
+    if (!tensors || count <= 0 || count > QA_ADAM_STACK_MAX_TENSORS || !ticket) return QA_E_ARG;
+    for (int t = 0; t < count; ++t) {
+        const qa_adam_stack_tensor *T = &tensors[t];
+        if (!T->param || !T->grad || T->numel <= 0 || T->num_states < 1 || T->num_states > QA_ADAM_STACK_MAX_STATES || T->parts1 < 0 || T->parts2 < 0 ||
+            (T->parts1 > 0 && (!T->src1 || T->stride1 < T->numel)) || (T->parts2 > 0 && (!T->src2 || !T->tmp || T->stride2 < T->numel))) return QA_E_ARG;
+        for (int s = 0; s < T->num_states; ++s) if (!T->state[s].exp_avg || !T->state[s].exp_avg_sq || !T->state[s].step || !T->state[s].lr) return QA_E_ARG;
+    }
+    for (int t = 0; t < count; ++t) {
+        const qa_adam_stack_tensor *T = &tensors[t];
+        for (int32_t i = 0; i < T->numel; ++i) {
+            float gi = T->grad[i];
+            if (T->parts1 > 0) { double acc = 0; for (int z = 0; z < T->parts1; ++z) acc += T->src1[(int64_t)z * T->stride1 + i]; gi = (float)acc; }
+            if (T->parts2 > 0) { double acc = 0; for (int z = 0; z < T->parts2; ++z) acc += T->src2[(int64_t)z * T->stride2 + i]; T->tmp[i] = (float)acc; gi = fmaf(T->alpha2, T->tmp[i], gi); }
+            gi = fmaf(T->reg, T->param[i], gi);
+            T->grad[i] = gi;
+            float pi = T->param[i];
+            for (int s = 0; s < T->num_states; ++s) {
+                const qa_adam_stack_state *S = &T->state[s];
+                float step = S->step[0] + 1.0f, bc1 = 1.0f - powf(beta1, step), bc2s = sqrtf(1.0f - powf(beta2, step)), step_size = S->lr[0] / bc1;
+                float ge = S->weight_decay * pi + gi;
+                S->exp_avg[i] = beta1 * S->exp_avg[i] + (1.0f - beta1) * ge;
+                S->exp_avg_sq[i] = beta2 * S->exp_avg_sq[i] + (1.0f - beta2) * ge * ge;
+                pi -= step_size * S->exp_avg[i] / (sqrtf(S->exp_avg_sq[i]) / bc2s + eps);
+            }
+            T->param[i] = pi;
+        }
+    }
+    for (int t = 0; t < count; ++t) for (int s = 0; s < tensors[t].num_states; ++s) tensors[t].state[s].step[0] += 1.0f;
+    return QA_OK;
+}
+
 /* rollout bookkeeping twins (host pointers) */
 int qo_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
                    int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,

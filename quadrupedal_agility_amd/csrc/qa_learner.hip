@@ -1491,6 +1491,84 @@ int qa_grad_reduce(float *const *dst_host, const float *const *src_host, const i
     return QA_OK;
 }
 
+// r6 (ABI 18): the optimiser half of a discriminator step in ONE launch -- a tensor's gradient put together from its parts (the head losses' product, the
+// gradient penalty's product times alpha2, the weight regulariser reg * W) and then the tensor's Adam states applied in order: the trunk's parameters sit in
+// all three of the reference's optimisers (gail.py:107-132, 518-520).  Replaces per step: qa_grad_reduce, two multi-tensor adds, one add, three
+// qa_adam_update<true> launches.  Element i of a chunk belongs to thread i % 256 in both adam_reduce_chunk branches and in the update loop.
+constexpr int STACK_CHUNK = 512;      // two elements per thread: ~450 workgroups for the discriminator's 190 k parameters (2048-element chunks: 47 us; these: see DESIGN 4.21)
+struct StackArgs { qa_adam_stack_tensor t[QA_ADAM_STACK_MAX_TENSORS]; int32_t first_block[QA_ADAM_STACK_MAX_TENSORS + 1]; int32_t n, blocks; float beta1, beta2, eps; unsigned *ticket; };
+__global__ void __launch_bounds__(256) qa_adam_stack_kernel(StackArgs a) {
+    __shared__ float s_q[256];
+    int t = 0;
+    while (t + 1 < a.n && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+    const int parts1 = a.t[t].parts1, parts2 = a.t[t].parts2, ns = a.t[t].num_states;
+    const int per = (parts1 > QA_REDUCE_WIDE || parts2 > QA_REDUCE_WIDE) ? 32 : STACK_CHUNK;
+    const int s0 = ((int)blockIdx.x - a.first_block[t]) * per;
+    const int n = min(per, a.t[t].numel - s0);
+    float *p = a.t[t].param + s0, *g = a.t[t].grad + s0, *tmp = a.t[t].tmp + s0;
+    const float alpha2 = a.t[t].alpha2, reg = a.t[t].reg;
+    float *m[QA_ADAM_STACK_MAX_STATES], *v[QA_ADAM_STACK_MAX_STATES], step_size[QA_ADAM_STACK_MAX_STATES], bc2s[QA_ADAM_STACK_MAX_STATES], wd[QA_ADAM_STACK_MAX_STATES];
+#pragma unroll
+    for (int s = 0; s < QA_ADAM_STACK_MAX_STATES; ++s) {
+        const bool on = s < ns;
+        m[s] = on ? a.t[t].state[s].exp_avg + s0 : nullptr; v[s] = on ? a.t[t].state[s].exp_avg_sq + s0 : nullptr;
+        const float step = on ? a.t[t].state[s].step[0] + 1.0f : 1.0f;
+        step_size[s] = on ? a.t[t].state[s].lr[0] / (1.0f - powf(a.beta1, step)) : 0.f;
+        bc2s[s] = sqrtf(1.0f - powf(a.beta2, step)); wd[s] = a.t[t].state[s].weight_decay;
+    }
+    if (parts1 > 0) (void)adam_reduce_chunk(a.t[t].src1 + s0, a.t[t].stride1, parts1, g, n, s_q);
+    if (parts2 > 0) (void)adam_reduce_chunk(a.t[t].src2 + s0, a.t[t].stride2, parts2, tmp, n, s_q);
+    const bool rewrite = parts1 > 0 || parts2 > 0 || reg != 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float pi = p[i], gi = g[i];
+        if (parts2 > 0) gi = fmaf(alpha2, tmp[i], gi);
+        gi = fmaf(reg, pi, gi);
+        if (rewrite) g[i] = gi;
+#pragma unroll
+        for (int s = 0; s < QA_ADAM_STACK_MAX_STATES; ++s) {
+            if (s < ns) {
+                const float ge = fmaf(wd[s], pi, gi);
+                const float mi = a.beta1 * m[s][i] + (1.0f - a.beta1) * ge;
+                const float vi = a.beta2 * v[s][i] + (1.0f - a.beta2) * ge * ge;
+                m[s][i] = mi; v[s][i] = vi;
+                pi = pi - step_size[s] * mi / (sqrtf(vi) / bc2s[s] + a.eps);
+            }
+        }
+        p[i] = pi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(a.ticket, 1u) == (unsigned)(a.blocks - 1)) {          // every workgroup has read the old step counts by now
+            for (int k = 0; k < a.n; ++k)
+                for (int s = 0; s < a.t[k].num_states; ++s) a.t[k].state[s].step[0] += 1.0f;
+            *a.ticket = 0u;
+        }
+    }
+}
+int qa_adam_stack_step(const qa_adam_stack_tensor *tensors_host, int32_t count, float beta1, float beta2, float eps, uint32_t *ticket, void *stream) {
+    if (!tensors_host || count <= 0 || count > QA_ADAM_STACK_MAX_TENSORS || !ticket) { snprintf(g_lerr, sizeof(g_lerr), "qa_adam_stack_step: 1..%d tensors and a ticket word expected", QA_ADAM_STACK_MAX_TENSORS); return QA_E_ARG; }
+    StackArgs a = {};
+    int blocks = 0;
+    for (int t = 0; t < count; ++t) {
+        const qa_adam_stack_tensor &T = tensors_host[t];
+        bool ok = T.param && T.grad && T.numel > 0 && T.num_states >= 1 && T.num_states <= QA_ADAM_STACK_MAX_STATES && T.parts1 >= 0 && T.parts2 >= 0 &&
+                  (T.parts1 == 0 || (T.src1 && T.stride1 >= T.numel)) && (T.parts2 == 0 || (T.src2 && T.tmp && T.stride2 >= T.numel));
+        for (int s = 0; ok && s < T.num_states; ++s) ok = T.state[s].exp_avg && T.state[s].exp_avg_sq && T.state[s].step && T.state[s].lr;
+        if (!ok) { snprintf(g_lerr, sizeof(g_lerr), "qa_adam_stack_step: bad record %d", t); return QA_E_ARG; }
+        a.t[t] = T;
+        if (!a.t[t].tmp) a.t[t].tmp = T.grad;          // never read (parts2 == 0)
+        a.first_block[t] = blocks;
+        const int per = (T.parts1 > QA_REDUCE_WIDE || T.parts2 > QA_REDUCE_WIDE) ? 32 : STACK_CHUNK;
+        blocks += (T.numel + per - 1) / per;
+    }
+    a.first_block[count] = blocks; a.n = count; a.blocks = blocks; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.ticket = ticket;
+    hipLaunchKernelGGL(qa_adam_stack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_adam_stack_step: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
 int64_t qa_pair_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * ((rows + PAIR_BLOCK - 1) / PAIR_BLOCK); }
 
 int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int64_t b_stride, int32_t mode, float *grad_a, float *out,

@@ -1034,6 +1034,101 @@ class ClipAdam:
             raise RuntimeError(f"qa_clip_adam_step failed with code {rc}: {lib.qa_last_error().decode()}")
 
 
+class StackedAdam:
+    """SEVERAL torch.optim.Adam optimisers that are stepped one after the other from the same gradients (the discriminator's three, gail.py:518-520,
+    each over the trunk plus one head, gail.py:107-132: a trunk parameter has three sets of moments) as ONE launch (qa_adam_stack_step, ABI 18).  The
+    launch also puts each gradient together -- parts of the loss's product, alpha * parts of the penalty's product, reg * weight -- and writes it to
+    `.grad`, which is what qa_grad_reduce, two multi-tensor adds, an add and three optimiser launches did before.  The torch optimisers stay the owners
+    of the state; `ready()` says whether the launch can take the step (else the caller steps them as before)."""
+
+    def __init__(self, optimizers, lib=None, prefix="qa_"):
+        self.opts = list(optimizers)
+        self._lib, self._prefix = lib, prefix
+        self._lr = {}
+        self._ticket = None
+        self._keep = None
+
+    def _members(self):
+        """param -> [(optimizer index, group)], optimiser order"""
+        out = {}
+        for k, o in enumerate(self.opts):
+            for g in o.param_groups:
+                for p in g["params"]:
+                    out.setdefault(p, []).append((k, g))
+        return out
+
+    def ready(self):
+        if not ENABLED or not self.opts or not all(type(o) is torch.optim.Adam for o in self.opts):
+            return False
+        g0 = self.opts[0].param_groups[0]
+        mem = self._members()
+        if len(mem) > _capi.ADAM_STACK_MAX_TENSORS or any(len(v) > _capi.ADAM_STACK_MAX_STATES for v in mem.values()):
+            return False
+        for o in self.opts:
+            for g in o.param_groups:
+                if g.get("amsgrad", False) or g.get("maximize", False) or g["betas"] != g0["betas"] or g["eps"] != g0["eps"]:
+                    return False
+                if torch.is_tensor(g["lr"]) and (g["lr"].dtype != torch.float32 or g["lr"].numel() != 1):
+                    return False
+                for p in g["params"]:
+                    st = o.state.get(p, {})
+                    if ("exp_avg" not in st or not torch.is_tensor(st["step"]) or st["step"].dtype != torch.float32 or st["step"].device != p.device
+                            or p.dtype != torch.float32 or not p.is_contiguous()):
+                        return False
+        return True
+
+    def _lr_dev(self, k, g, dev):
+        lr = g["lr"]
+        if torch.is_tensor(lr):
+            return lr
+        key = (k, id(g))
+        e = self._lr.get(key)
+        if e is None:
+            e = self._lr[key] = [torch.zeros((), dtype=torch.float32, device=dev), None]
+        if e[1] != float(lr):
+            e[0].fill_(float(lr)); e[1] = float(lr)
+        return e[0]
+
+    def step(self, sources, reg=None):
+        """sources: {param: dict(grad=, src1=, stride1=, parts1=, src2=, stride2=, parts2=, alpha2=, tmp=)} -- `grad` a contiguous fp32 tensor of the
+        parameter's size (it becomes / is `.grad`), the rest optional (tensors for src / tmp: a parameter's first part starts at the tensor's first
+        element); reg: {param: coefficient}.  Every parameter of the optimisers needs an entry."""
+        mem = self._members()
+        items = list(mem.items())
+        n = len(items)
+        dev = items[0][0].device
+        if self._ticket is None:
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        recs = (_capi.QaAdamStackTensor * n)()
+        keep = []
+        for i, (p, ms) in enumerate(items):
+            src = sources[p]
+            g = src["grad"]
+            assert g.is_contiguous() and g.dtype == torch.float32 and g.numel() == p.numel()
+            r = recs[i]
+            r.param, r.grad, r.numel, r.num_states = p.data_ptr(), g.data_ptr(), p.numel(), len(ms)
+            if src.get("parts1", 0):
+                r.src1, r.stride1, r.parts1 = src["src1"].data_ptr(), int(src["stride1"]), int(src["parts1"])
+            if src.get("parts2", 0):
+                r.src2, r.stride2, r.parts2, r.alpha2, r.tmp = src["src2"].data_ptr(), int(src["stride2"]), int(src["parts2"]), float(src["alpha2"]), src["tmp"].data_ptr()
+                assert src["tmp"].numel() >= p.numel()
+            r.reg = float(reg.get(p, 0.0)) if reg else 0.0
+            for s_, (k, grp) in enumerate(ms):
+                st = self.opts[k].state[p]
+                lr = self._lr_dev(k, grp, dev)
+                e = r.state[s_]
+                e.exp_avg, e.exp_avg_sq, e.step, e.lr, e.weight_decay = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), lr.data_ptr(), float(grp["weight_decay"])
+                keep.append(lr)
+            p.grad = g
+        self._keep = keep
+        g0 = self.opts[0].param_groups[0]
+        lib = self._lib or _capi.load_library()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+        rc = getattr(lib, self._prefix + "adam_stack_step")(C.cast(recs, C.c_void_p), n, float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _ptr(self._ticket), stream)
+        if rc != 0:
+            raise RuntimeError(f"adam_stack_step failed with code {rc}" + (f": {lib.qa_last_error().decode()}" if self._prefix == "qa_" else ""))
+
+
 class _DiscLoss(torch.autograd.Function):
     """loss, stats = f(d (B,1), eps (B,1), c (B,5) | labels, policy latents): the head losses of the discriminator step
     (MSELoss variant) and their gradient in one pass (qa_disc_loss); backward only scales the stored gradients.

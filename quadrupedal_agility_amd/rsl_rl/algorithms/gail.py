@@ -109,6 +109,8 @@ class SSInfoGAIL:
         self._step_estimator = ClipAdam(self.optim_estimator, max_grad_norm)
         self._step_hist_encoder = ClipAdam(self.optim_hist_encoder, max_grad_norm)
         self._step_disc = [ClipAdam(o, None) if isinstance(o, optim.Adam) else o for o in (self.optim_d, self.optim_q_eps, self.optim_q_c)]
+        self._disc_stack = (fused_mod.StackedAdam([self.optim_d, self.optim_q_eps, self.optim_q_c])
+                            if (self._on_gpu and isinstance(self.optim_d, optim.Adam) and os.environ.get("QA_DISC_STACKED_ADAM", "1") != "0") else None)
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.surrogate_loss_coef, self.value_loss_coef, self.entropy_coef = surrogate_loss_coef, value_loss_coef, entropy_coef
         self.bounds_loss_coef, self.disc_coef, self.disc_logit_reg = bounds_loss_coef, disc_coef, disc_logit_reg
@@ -368,7 +370,20 @@ class SSInfoGAIL:
                 graphs = []
                 pool = torch.cuda.graph_pool_handle()
                 try:
-                    for i in range(nmb):
+                    # r6: steps that run as chain launches are short (~0.37 ms), and two consecutive replays are ~8.5 us apart on the device: the
+                    # nmb slots of an epoch as ONE recording (one replay per epoch)
+                    epoch_graph = sync is None and self._train_chain_rows(mb) is not None and os.environ.get("QA_STEP_UNROLL", "1") != "0"
+                    if epoch_graph:
+                        g = torch.cuda.CUDAGraph()
+                        with _no_gc(), torch.cuda.graph(g, pool=pool):
+                            for i in range(nmb):
+                                stats, kl = front(i)
+                                self._ac_apply(kl)
+                                self._acc_ac.add_(torch.stack(stats))
+                                for o in (self.optim_ac, self.optim_estimator):
+                                    o.zero_grad(set_to_none=True)
+                        graphs.append((g, None, None))
+                    for i in range(0 if epoch_graph else nmb):
                         if sync is None:
                             g = torch.cuda.CUDAGraph()
                             with _no_gc(), torch.cuda.graph(g, pool=pool):
@@ -412,7 +427,7 @@ class SSInfoGAIL:
             perm = torch.randperm(nmb * mb, device=dev)   # one permutation for all epochs (rollout_storage.py:122-157)
         fused_mod.gather_rows(perm, self._gather_srcs, dsts=self._perm_bufs)
         for _ in range(self.num_learning_epochs):
-            for i in range(nmb):
+            for i in range(len(self._ac_graph)):            # nmb recordings of one step each, or one of the whole epoch
                 ga, gb, bucket = self._ac_graph[i]
                 ga.replay()
                 if gb is not None:
@@ -478,11 +493,15 @@ class SSInfoGAIL:
                     self._disc_stream = torch.cuda.Stream(device=dev)
                 self._recording_disc = True
                 try:
+                    # r6: `unroll` steps per recording (a divisor of n_steps): two consecutive replays are ~8.5 us apart on the device, 0.7 ms of an
+                    # 80-step chain whose steps are ~0.26 ms; the steps read their row block through the device-side counter, so a replay is k steps
+                    unroll = max((k for k in (8, 5, 4, 2, 1) if n_steps % k == 0), default=1) if os.environ.get("QA_STEP_UNROLL", "1") != "0" else 1
                     with _no_gc(), torch.cuda.graph(g, stream=self._disc_stream):
-                        one_step()
+                        for _ in range(unroll):
+                            one_step()
                 finally:
                     self._recording_disc = False
-                self._disc_graph = g
+                self._disc_graph, self._disc_unroll, self._disc_graph_steps = g, unroll, n_steps
             except Exception as e:      # never fatal
                 print(f"[disc update graph] capture failed, staying eager: {e}")
                 self._disc_graph = False
@@ -508,7 +527,8 @@ class SSInfoGAIL:
             torch.randint(0, ml.preloaded_s_ulb.shape[0], t_ulb.shape, device=dev, out=t_ulb)
         t_lab.copy_(ml.preloaded_label[t_lb.view(-1)].view(t_lb.shape))
         self._d_step.zero_()
-        for _ in range(n_steps):
+        assert n_steps == self._disc_graph_steps
+        for _ in range(n_steps // self._disc_unroll):
             self._disc_graph.replay()
         return self._acc_d          # persistent: the caller copies it on ITS stream after joining
 
@@ -916,10 +936,14 @@ class SSInfoGAIL:
             loss = self.ss_coef * ss_loss + info_coef * info_max_loss + self.disc_coef * disc_loss_v + self.us_coef * us_loss + rest
         for o in (self.optim_d, self.optim_q_eps, self.optim_q_c):
             o.zero_grad()
+        stack_src = None
         if dchain is not None:
             with torch.no_grad():       # softmax backward on (rows, 5): d loss / d logits = c * (g_c - <g_c, c>), one launch
                 g_logits = torch._softmax_backward_data(g_c, c_all, -1, torch.float32)
-            dchain.backward(g_d, g_eps, g_logits, self.disc_grad_penalty)
+            # r6 (ABI 18): the products stay in parts and ONE launch adds them (the penalty's with its factor, the regularisers' 2 c W), writes `.grad`
+            # and applies the three optimisers' states in order (fused.StackedAdam) -- unless gradients travel between ranks first
+            stack = self._disc_stack if (fold_reg and self.grad_sync is None and self._disc_stack is not None and self._disc_stack.ready()) else None
+            stack_src = dchain.backward(g_d, g_eps, g_logits, self.disc_grad_penalty, finish=stack is None)
         elif direct:
             if self._recording_disc:
                 fused_mod.assert_recordable_graph([d_all, eps_all, c_all, g], "discriminator step")
@@ -929,7 +953,7 @@ class SSInfoGAIL:
         if analytic_gp and gp_proxies:
             with torch.no_grad():       # the penalty's share of the weight gradients (see forward_with_input_gradient)
                 torch._foreach_add_([w.grad for w, _ in gp_proxies], [q.grad for _, q in gp_proxies])
-        if fold_reg:
+        if fold_reg and stack_src is None:
             with torch.no_grad():
                 torch._foreach_add_([w.grad for w in reg_w[:-1]], reg_w[:-1], alpha=2.0 * self.disc_weight_decay)
                 reg_w[-1].grad.add_(reg_w[-1], alpha=2.0 * (self.disc_weight_decay + self.disc_logit_reg))
@@ -951,9 +975,11 @@ class SSInfoGAIL:
                 self.grad_sync.all_reduce_(m64)
                 synced_moments = m64 / self.grad_sync.world
             self.env.prior_parameters = pred_mean * self.prior_soft_coef + self.env.prior_parameters * (1 - self.prior_soft_coef)
-        if dchain is not None:          # three optimisers over disjoint parameter sets: side by side
-            dchain.parallel([o.step for o in self._step_disc])
-        else:
+        if stack_src is not None:
+            reg = {w: 2.0 * self.disc_weight_decay for w in reg_w[:-1]}
+            reg[reg_w[-1]] = 2.0 * (self.disc_weight_decay + self.disc_logit_reg)
+            stack.step(stack_src, reg)
+        else:                           # one after the other: the trunk's parameters are in all three (gail.py:107-132)
             for o in self._step_disc:
                 o.step()
         if not self._recording_disc:          # the recorded step leaves this to update(): once after the loop is the same thing

@@ -401,6 +401,18 @@ class DiscTrainChain:
             torch.cat([h.weight for h in self.heads], dim=0, out=self.wh[:self.dims[3]])
         self._packer.pack()
 
+    def _layouts(self):
+        """product name -> qa_linear_backward_weight_batch_layout (parts, weight slab stride, bias parts, bias stride, bias slabs' offset; floats)"""
+        if getattr(self, "_lay", None) is None:
+            k0, w1, w2, nh = self.dims
+            R, U = self.rows, self.n_u
+            self._lay = {}
+            for name, (r, n, k) in dict(w1=(R, w1, k0), w2=(R, w2, w1), wh=(R, 8, w2), p1=(U, w1, k0), p2=(U, w2, w1), p3=(U, w2, 1)).items():
+                lay = (C.c_int64 * 5)()
+                _ok(self.fwd._fn("linear_backward_weight_batch_layout")(r, k, n, lay), "linear_backward_weight_batch_layout", self.fwd)
+                self._lay[name] = [int(v) for v in lay]
+        return self._lay
+
     def forward(self, x):
         """-> logit (R, 1), epsilon (R, 1), class LOGITS (R, dim_c); then `penalty_gradient()`"""
         assert x.shape[0] == self.rows and x.stride(1) == 1 and x.shape[1] >= self.dims[0]
@@ -437,8 +449,10 @@ class DiscTrainChain:
         else:
             fn()
 
-    def backward(self, g_d, g_eps, g_logits, penalty_coef):
-        """gradients at the three heads' outputs (R rows) + the penalty's coefficient c (loss term c * mean_U |g|^2) -> `.grad` of the 10 parameters"""
+    def backward(self, g_d, g_eps, g_logits, penalty_coef, finish=True):
+        """gradients at the three heads' outputs (R rows) + the penalty's coefficient c (loss term c * mean_U |g|^2) -> `.grad` of the 10 parameters.
+        finish=False leaves the six products IN PARTS and returns {parameter: record} for fused.StackedAdam.step, whose launch adds the parts (the
+        penalty's with the factor a), writes `.grad` and steps the optimisers: no reduction launch, no multi-tensor adds here."""
         k0, w1, w2, nh = self.dims
         l1, l2 = self.disc._relu_trunk()
         gin = self.gin
@@ -454,11 +468,33 @@ class DiscTrainChain:
         descs = (_capi.QaWgradDesc * len(jobs))()
         for i, (name, rows, g, g0, n, x, x0, k) in enumerate(jobs):
             scratch, nb, gw, gb = self._wg[name]
-            descs[i] = _capi.QaWgradDesc(g.data_ptr() + 4 * g0, g.stride(0), x.data_ptr() + 4 * x0, x.stride(0), gw.data_ptr(), gb.data_ptr(), rows, k, n, scratch.data_ptr(), nb)
+            descs[i] = _capi.QaWgradDesc(g.data_ptr() + 4 * g0, g.stride(0), x.data_ptr() + 4 * x0, x.stride(0), gw.data_ptr() if finish else None,
+                                         gb.data_ptr() if finish else None, rows, k, n, scratch.data_ptr(), nb)
         _ok(self.fwd._fn("linear_backward_weight_batch")(descs, len(jobs), self.fwd._stream(gin)), "linear_backward_weight_batch", self.fwd)
         (gw1, gb1), (gw2, gb2), (gwh, gbh) = (self._wg[k_][2:] for k_ in ("w1", "w2", "wh"))
         t1, t2, t3 = (self._wg[k_][2] for k_ in ("p1", "p2", "p3"))
         a = 2.0 * float(penalty_coef) / U
+        if not finish:
+            lay = self._layouts()
+
+            def rec(grad, name, col0=0, bias=False, pen=None, tmp=None):
+                L = lay[name]
+                sc = self._wg[name][0]
+                d = dict(grad=grad, src1=sc[(L[4] if bias else 0) + col0:], stride1=L[3] if bias else L[1], parts1=L[2] if bias else L[0])
+                if pen is not None:
+                    P = lay[pen]
+                    d.update(src2=self._wg[pen][0], stride2=P[1], parts2=P[0], alpha2=a, tmp=tmp)
+                return d
+            out = {l1.weight: rec(gw1, "w1", pen="p1", tmp=t1), l1.bias: rec(gb1, "w1", bias=True),
+                   l2.weight: rec(gw2, "w2", pen="p2", tmp=t2), l2.bias: rec(gb2, "w2", bias=True)}
+            r = 0
+            for h in self.heads:
+                n = h.out_features
+                first = h is self.disc.linear
+                out[h.weight] = rec(gwh[r:r + n], "wh", col0=r * w2, pen="p3" if first else None, tmp=t3 if first else None)
+                out[h.bias] = rec(gbh[r:r + n], "wh", col0=r, bias=True)
+                r += n
+            return out
         with torch.no_grad():
             torch._foreach_add_([gw1, gw2, gwh[0]], [t1, t2, t3.view(-1)], alpha=a)
         l1.weight.grad, l1.bias.grad, l2.weight.grad, l2.bias.grad = gw1, gb1, gw2, gb2

@@ -287,6 +287,73 @@ def test_amp_training_with_the_discriminator_chain_equals_training_without_it():
     assert torch.allclose(na, nb, rtol=1e-9, atol=1e-12) and lra == lrb
 
 
+def _stacked_case(dev, lib=None, prefix="qa_", steps=3):
+    """the discriminator step's optimiser half both ways: chain backward finished + regulariser adds + three torch Adam steps, one after the other
+    (gail.py:503-520), against chain backward in parts + ONE stacked launch"""
+    import copy
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused, train_chain
+    c_gp, c_wd, c_lr = 0.2, 1e-4, 0.05
+    out = []
+    for stacked in (False, True):
+        disc = _disc(7).to(dev)
+        adam = dict(fused=True, capturable=True) if dev == "cuda" else {}
+        groups = lambda head: [{"params": disc.trunk.parameters(), "weight_decay": 1e-3}, {"params": head.parameters(), "weight_decay": 1e-3}]
+        opts = [torch.optim.Adam(groups(disc.linear), lr=1e-3, **adam), torch.optim.Adam(groups(disc.encoder_eps), lr=3e-4, **adam),
+                torch.optim.Adam(groups(disc.classifier), lr=3e-4, **adam)]
+        rows, n_u = 3 * 41, 41
+        chain = train_chain.DiscTrainChain.describe(disc, rows, n_u, lib=lib, prefix=prefix)
+        stack = fused.StackedAdam(opts, lib=lib, prefix=prefix)
+        reg_w = [m.weight for m in disc.trunk.modules() if isinstance(m, torch.nn.Linear)] + [disc.linear.weight]
+        for it in range(steps):
+            x, g_d, g_eps, g_l = (t.to(dev) for t in _disc_inputs(rows, 20 + it))
+            chain.pack()
+            chain.forward(x)
+            chain.penalty_gradient()
+            for o in opts:
+                o.zero_grad()
+            use = stacked and it > 0                     # (the first step creates the optimisers' state)
+            assert stack.ready() == (it > 0)
+            src = chain.backward(g_d, g_eps, g_l, c_gp, finish=not use)
+            if use:
+                reg = {w: 2.0 * c_wd for w in reg_w[:-1]}
+                reg[reg_w[-1]] = 2.0 * (c_wd + c_lr)
+                stack.step(src, reg)
+            else:
+                assert src is None
+                with torch.no_grad():
+                    torch._foreach_add_([w.grad for w in reg_w[:-1]], reg_w[:-1], alpha=2.0 * c_wd)
+                    reg_w[-1].grad.add_(reg_w[-1], alpha=2.0 * (c_wd + c_lr))
+                for o in opts:
+                    o.step()
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        state = {}
+        for n, p in disc.named_parameters():
+            state["p." + n], state["g." + n] = p.detach().cpu().clone(), p.grad.detach().cpu().clone()
+            for k, o in enumerate(opts):
+                if p in o.state:
+                    st = o.state[p]
+                    state[f"m{k}." + n], state[f"v{k}." + n], state[f"s{k}." + n] = st["exp_avg"].cpu().clone(), st["exp_avg_sq"].cpu().clone(), st["step"].cpu().clone().float()
+        out.append(state)
+    a, b = out
+    assert a.keys() == b.keys() and sum(k.startswith("m") for k in a) == 3 * 4 + 6
+    for k in a:
+        scale = float(a[k].abs().max()) + 1e-30
+        tol = 0.0 if k[0] == "s" else (2e-5 if k[0] in "gmv" else 2e-6)        # (parameters: lr x O(1) x the moments' relative difference)
+        assert float((a[k] - b[k]).abs().max()) <= tol * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+        if k[0] == "s":
+            assert float(a[k]) == steps
+
+
+def test_stacked_adam_twin_equals_three_optimisers_one_after_the_other():
+    _stacked_case("cpu", lib=load_oracle(), prefix="qo_")
+
+
+@pytest.mark.gpu
+def test_hip_stacked_adam_equals_three_optimisers_one_after_the_other():
+    _stacked_case("cuda")
+
+
 # ------------------------------------------------------------------ several weight-gradient products in one call
 WG_SHAPES = [(3072, 671, 512), (3072, 512, 256), (3072, 101, 512), (3072, 128, 12), (3072, 128, 1), (3072, 29, 64), (3072, 64, 4), (1228, 98, 512), (1228, 1, 256), (77, 57, 128)]
 

@@ -124,7 +124,7 @@ def test_recorded_update_equals_eager_update(N, sync_phases):
     Adam state --, 1 records, 2-4 are replay sessions), with the host reading nothing between updates and with a device sync after
     every phase (torch's stale batch reductions only showed without syncs and only from the second replay session on:
     profiles/r2_hipgraph_stale_reductions.md).  Both runs issue the same kernels in the same order, so the parameters, the learning
-    rate and the loss read-out are held to 1e-6 (2e-5 at 8,192 envs: see the assertion) -- not to the 2e-3 of a check that would pass on a frozen bias."""
+    rate and the loss read-out are held to 1e-6 (2e-4 at 8,192 envs: see the assertion) -- not to the 2e-3 of a check that would pass on a frozen bias."""
     mods, algs = _mine()
     res = {}
     for mode in ("eager", "recorded"):
@@ -160,12 +160,50 @@ def test_recorded_update_equals_eager_update(N, sync_phases):
         for k, (pe, pr) in enumerate(zip(e["snaps"][it], r["snaps"][it])):
             d = (pe.double().cpu() - pr.double().cpu()).abs().max().item()
             # 1024 envs: both runs launch the same kernels (r6: the chain step, eager and recorded alike) -> 1e-6.  8192 envs (49,152-row steps on the library's
-            # GEMMs): the first difference is 7e-7 .. 1.1e-6 after update 1 and grows with the Adam steps (6.6e-6 after update 2 on one box; it depends on
-            # the box, not on the run: four runs on one box gave the same digits) -- held to 2e-5, a hundredth of what a frozen gradient would show
-            assert d <= (1e-6 if N <= 1024 else 2e-5), f"update {it}, tensor {k}: recorded and eager differ by {d}"
+            # GEMMs, whose split of a product can differ between an eager call and a recorded one): the first difference is 7e-7 .. 1.1e-6 after update 1
+            # and grows with the Adam steps -- an element whose gradient is rounding-sized moves by up to the learning rate (1e-3) in EITHER direction.  It
+            # depends on the box, not on the run (four runs on one box gave the same digits): 1.1e-6, 6.6e-6 and 4.2e-5 after update 2 on three r6 boxes.
+            # Held to 2e-4 = a tenth of the learning rate and of what a frozen gradient shows (2e-3, the r2 stale-reduction finding this test guards)
+            assert d <= (1e-6 if N <= 1024 else 2e-4), f"update {it}, tensor {k}: recorded and eager differ by {d}"
         if it:           # every tensor these steps train moved (the history encoder is the DAgger step's: 8 tensors stay) -- no frozen gradient
             moved = sum(int(not torch.equal(a, b)) for a, b in zip(r["snaps"][it][:-1], r["snaps"][it - 1][:-1]))
             assert moved == len(r["snaps"][it]) - 1 - 8, f"update {it}: {moved} tensors moved"
+
+
+@pytest.mark.gpu
+def test_recorded_dagger_update_equals_eager_dagger_update():
+    """PPO.update_dagger (the history-encoder regression of every 20th iteration) as replays of one recorded step against the eager loop: the same
+    stored rollouts, the same permutations, four updates (0 eager in both, 1 records, 2-3 replay sessions)."""
+    mods, algs = _mine()
+    res = {}
+    N = 1024
+    for mode in ("eager", "recorded"):
+        ac, bbc, est, _ = P.build(mods, algs)
+        est.to("cuda")
+        alg = algs.PPO(ac, bbc, est, P.ESTIMATOR, None, None, None, device="cuda", **dict(P.ALGO, num_mini_batches=4, num_learning_epochs=2))
+        alg.init_storage(N, P.T, [800], [None], [19])
+        if mode == "eager":
+            alg._dagger_graph = False
+        hp = list(ac.actor.history_encoder.parameters())
+        snaps = []
+        for it in range(4):
+            torch.manual_seed(5 + it)
+            with torch.inference_mode():
+                for t in range(P.T):
+                    o = P.det((N, 800), 100 + t + 50 * it).cuda()
+                    alg.act(o, o, None)
+                    alg.process_env_step(P.det((N,), 200 + t + 7 * it).cuda(), (P.det((N,), 300 + t + 3 * it) > 0.8).cuda(), {})
+            torch.manual_seed(99 + it)
+            loss = alg.update_dagger()
+            snaps.append(([p.detach().clone() for p in hp], loss))
+        assert (alg.__dict__.get("_dagger_graph") not in (None, False)) == (mode == "recorded")
+        res[mode] = snaps
+    for it, ((pe, le), (pr, lr_)) in enumerate(zip(res["eager"], res["recorded"])):
+        assert lr_ == pytest.approx(le, rel=1e-5), (it, le, lr_)
+        for k, (a, b) in enumerate(zip(pe, pr)):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (it, k, float((a - b).abs().max()))
+        if it:
+            assert all(not torch.equal(a, b) for a, b in zip(pr, res["recorded"][it - 1][0]))       # every tensor of the encoder moved
 
 
 @pytest.mark.gpu

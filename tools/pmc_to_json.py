@@ -44,6 +44,9 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 import bench
+if len(KERNELS) > 1:      # (r6) which of the launches moves the bytes
+    out["per_kernel_hbm_bytes"] = {k: int((f.get("env:" + k, 0.0) * fetch_corr + w.get("env:" + k, 0.0)) * 1024) for k in KERNELS}
+    out["per_kernel_fetch_write_kib"] = {k: [round(f.get("env:" + k, 0.0) * fetch_corr, 1), round(w.get("env:" + k, 0.0), 1)] for k in KERNELS}
 out["kernel_source_hash"] = bench.env_kernel_hash(g)        # bench.py reports this figure only for the kernel sources it was measured on
 json.dump(out, open(sys.argv[4], "w"))
 print(json.dumps(out))

@@ -52,6 +52,51 @@ chain)     # ABI 17: the PPO minibatch step's networks as two chain launches (tr
     line $O/bench_*.json
     timeout 200 python tools/policy_time.py 4096 > $O/policy_time_4096.txt 2>&1; tail -2 $O/policy_time_4096.txt
     ;;
+stack)     # ABI 18: the discriminator step's optimiser half as one launch; and why the 1024-env task-level line of final_measure read like autograd steps
+    timeout 900 python -m pytest tests/test_train_chain.py tests/test_fused_learner.py -m gpu -x -q -k "stacked or discriminator or adam" > $O/pytest_stack.log 2>&1; grep -E "passed|failed" $O/pytest_stack.log | tail -2; grep -E "^FAILED|Error" $O/pytest_stack.log | head -5
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_stack.json
+    QA_DISC_STACKED_ADAM=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_three_optimisers.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512_stack.json
+    timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline > $O/tsc_20_5_nocpu.log 2>&1 < /dev/null; grep '"metric"' $O/tsc_20_5_nocpu.log > $O/bench_tsc1024_20_5_nocpu.json; grep -v '"metric"' $O/tsc_20_5_nocpu.log | grep -i "graph\|capture\|eager\|chain" | head -5
+    timeout 400 python bench.py --tsc --num_envs 1024 --steps 8 --warmup 3 > $O/tsc_8_3_cpu.log 2>&1 < /dev/null; grep '"metric"' $O/tsc_8_3_cpu.log > $O/bench_tsc1024_8_3_cpu.json; grep -v '"metric"' $O/tsc_8_3_cpu.log | grep -i "graph\|capture\|eager\|chain" | head -5
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 3 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_disc_loss_kernel" mid > $O/disc_step_sequence.txt 2>&1; tail -30 $O/disc_step_sequence.txt
+    ;;
+stack2)    # 512-element chunks in the stacked optimiser launch; the task-level line with the one-off captures outside the timed region; per-kernel traffic
+    timeout 900 python -m pytest tests/test_train_chain.py -m gpu -x -q -k "stacked or discriminator" > $O/pytest_stack.log 2>&1; grep -E "passed|failed" $O/pytest_stack.log | tail -2
+    for i in 1 2; do timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_stack_$i.json; done
+    QA_BENCH_TRACE=1 timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2> $O/tsc_trace.err < /dev/null | grep '"metric"' > $O/bench_tsc1024_20_5.json; grep "per-iteration" $O/tsc_trace.err
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 3 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_disc_loss_kernel" mid > $O/disc_step_sequence.txt 2>&1; grep -E "stack|launches" $O/disc_step_sequence.txt
+    for NE in 1024; do
+      timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tf$NE -- python $R/tools/pmc_tsc_env.py $NE full < /dev/null > /tmp/pmc_tf.log 2>&1
+      timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tw$NE -- python $R/tools/pmc_tsc_env.py $NE full < /dev/null > /tmp/pmc_tw.log 2>&1
+      cd $R; python tools/pmc_to_json.py /tmp/pmc_tf$NE /tmp/pmc_tw$NE $NE $O/tsc_env_step_traffic_$NE.json 0 qa_env_step,qa_tsc_goal_step,qa_tsc_observations
+    done
+    ;;
+stack3)    # several steps per recorded graph (QA_STEP_UNROLL) + the task-level DAgger update as replays
+    timeout 2400 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py tests/test_grad_parts.py -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR|Error" $O/pytest.log | head -5
+    for i in 1 2; do timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_$i.json; done
+    QA_STEP_UNROLL=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_one_step_per_replay.json
+    for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
+    QA_STEP_UNROLL=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_one_step_per_replay.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    QA_BENCH_TRACE=1 timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2> $O/tsc_trace.err < /dev/null | grep '"metric"' > $O/bench_tsc1024_20_5.json; grep "per-iteration\|capture" $O/tsc_trace.err
+    line $O/bench_*.json
+    ;;
+traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
+    cd /tmp && export TMPDIR=/tmp
+    for NE in 1024; do
+      timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tf$NE -- python $R/tools/pmc_tsc_env.py $NE full < /dev/null > /tmp/pmc_tf.log 2>&1
+      timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tw$NE -- python $R/tools/pmc_tsc_env.py $NE full < /dev/null > /tmp/pmc_tw.log 2>&1
+      cd $R; python tools/pmc_to_json.py /tmp/pmc_tf$NE /tmp/pmc_tw$NE $NE $O/tsc_env_step_traffic_$NE.json 0 qa_env_step,qa_tsc_goal_step,qa_tsc_observations
+    done
+    ;;
 suite)     # the driver's round-end tiers on HEAD: the whole GPU suite, smoke(), the default bench line
     timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "passed|failed" $O/pytest_gpu.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
