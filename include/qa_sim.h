@@ -584,6 +584,23 @@ int qa_clip_adam_step_reduce(float *const *params, const float *const *grads_hos
                              const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
                              float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
                              const float *const *red_src_host, const int64_t *red_stride_host, const int32_t *red_parts_host, void *stream);
+/* ABI 18: TWO clipping optimisers and the KL rule between them in the same three launches.  A PPO minibatch step ends with
+ * clip + Adam on the estimator, the KL-adaptive learning rate, clip + Adam on the actor-critic (bbc/rsl_rl/algorithms/gail.py:359-362, 367-379, 405-408;
+ * tsc/rsl_rl/algorithms/ppo.py:243-262): seven launches of this library, ~35 us of a 370 us chain step.  The tables are those of
+ * qa_clip_adam_step_reduce over BOTH optimisers' tensors, the first optimiser's first (tensors [0, split_tensor), chunks [0, split_chunk)); each half
+ * has its own clipping norm (max_norm / pair->max_norm2, both > 0), step counter and learning rate (lr / pair->lr2, device floats); when pair->kl is
+ * not NULL the finalize launch applies qa_kl_lr_rule(kl, desired_kl, kl_factor, lr_min, lr_max) to *lr2 before the update reads it.  The red_*
+ * arrays may be NULL (every gradient final).  scratch: >= num_chunks + 9 floats (second head behind the single-launch step's counter). */
+typedef struct qa_adam_pair {
+    int32_t split_tensor, split_chunk;
+    float *lr2; float max_norm2;
+    const float *kl; float desired_kl, kl_factor, lr_min, lr_max;
+} qa_adam_pair;
+int qa_clip_adam_pair_step(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                           float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                           const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                           float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
+                           const float *const *red_src_host, const int64_t *red_stride_host, const int32_t *red_parts_host, const qa_adam_pair *pair, void *stream);
 /* The parts of up to QA_ADAM_MAX_INLINE gradients added in ONE launch without an optimiser step (the data-parallel step packs finished
  * gradients into its all-reduce bucket; tests): dst_host[t][i] = sum_z src_host[t][z stride_host[t] + i], i < numel_host[t]. */
 int qa_grad_reduce(float *const *dst_host, const float *const *src_host, const int64_t *stride_host, const int32_t *parts_host,
@@ -627,6 +644,18 @@ int qa_adam_stack_step(const qa_adam_stack_tensor *tensors_host, int32_t count, 
 int64_t qa_pair_loss_scratch_bytes(int64_t rows);
 int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int64_t b_stride, int32_t mode, float *grad_a, float *out,
                  void *scratch, int64_t scratch_bytes, void *stream);
+/* ABI 18: up to QA_PAIR_MAX_JOBS of those losses in ONE launch (the last workgroup to arrive adds each job's partial sums in qa_pair_loss's fixed order):
+ * out[0] as qa_pair_loss gives it; grad_a the same, times *grad_scale when that device scalar is given (the regulariser's scheduled coefficient,
+ * gail.py:353-357 -- the value in `out` stays unscaled, as the reference logs it).  scratch: >= qa_pair_losses_scratch_bytes(jobs, count), its FIRST
+ * word zero before the first call (the launch leaves it at zero). */
+#define QA_PAIR_MAX_JOBS 4
+typedef struct qa_pair_job {
+    const float *a, *b; int64_t rows; int32_t cols, mode; int64_t b_stride;
+    const float *grad_scale;       /* NULL: 1 */
+    float *grad_a, *out;
+} qa_pair_job;
+int64_t qa_pair_losses_scratch_bytes(const qa_pair_job *jobs, int32_t count);
+int qa_pair_losses(const qa_pair_job *jobs, int32_t count, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Minibatch gather (RolloutStorage.mini_batch_generator, bbc/rsl_rl/storage/rollout_storage.py:122-157): for t < num_tensors,
  * dst[t][r, 0:widths[t]] = src[t][idx[b rows + r], 0:widths[t]] with b = *idx_block (a DEVICE scalar; NULL = 0: idx is then

@@ -1974,6 +1974,38 @@ int qo_clip_adam_step_reduce(float *const *params, const float *const *grads_hos
                              beta1, beta2, eps, max_norm, scratch, scratch_floats, stream);
 }
 
+/* ABI 18: two clipping optimisers with the KL rule between them (gail.py:359-362, 367-379, 405-408) over one pair of tables: the first optimiser's
+ * tensors / chunks first */
+int qo_clip_adam_pair_step(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                           float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                           const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                           float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
+                           const float *const *red_src, const int64_t *red_stride, const int32_t *red_parts, const qa_adam_pair *pair, void *stream) {
+    if (!pair || pair->split_tensor <= 0 || pair->split_tensor >= num_tensors || pair->split_chunk <= 0 || pair->split_chunk >= num_chunks || !pair->lr2 ||
+        !(max_norm > 0.f) || !(pair->max_norm2 > 0.f) || num_tensors > QA_ADAM_MAX_INLINE || scratch_floats < 4 + (int64_t)num_chunks + 1 + 4) return QA_E_ARG;
+    const int nt = pair->split_tensor, nc = pair->split_chunk;
+    int32_t ct2[4096];
+    if (num_chunks - nc > 4096) return QA_E_ARG;
+    for (int c = nc; c < num_chunks; ++c) ct2[c - nc] = chunk_tensor[c] - nt;
+    int32_t zero_parts[QA_ADAM_MAX_INLINE] = {0}; int64_t zero_stride[QA_ADAM_MAX_INLINE] = {0}; const float *zero_src[QA_ADAM_MAX_INLINE] = {0};
+    const float *const *rs = red_src ? red_src : zero_src; const int64_t *rst = red_stride ? red_stride : zero_stride; const int32_t *rp = red_parts ? red_parts : zero_parts;
+    int rc = qo_clip_adam_step_reduce(params, grads_host, exp_avg, exp_avg_sq, steps, nt, chunk_tensor, chunk_start, chunk_len, nc, weight_decay, lr, beta1, beta2, eps,
+                                      max_norm, scratch, scratch_floats, rs, rst, rp, stream);
+    if (rc != QA_OK) return rc;
+    if (pair->kl) {
+        float k = pair->kl[0], cur = pair->lr2[0], out = cur;
+        if (k > pair->desired_kl * 2.0f) out = fmaxf(pair->lr_min, cur / pair->kl_factor);
+        else if (k < pair->desired_kl / 2.0f && k > 0.0f) out = fminf(pair->lr_max, cur * pair->kl_factor);
+        pair->lr2[0] = out;
+    }
+    float head1[4] = {scratch[0], scratch[1], scratch[2], scratch[3]};
+    rc = qo_clip_adam_step_reduce(params + nt, grads_host + nt, exp_avg + nt, exp_avg_sq + nt, steps + nt, num_tensors - nt, ct2, chunk_start + nc, chunk_len + nc,
+                                  num_chunks - nc, weight_decay + nt, pair->lr2, beta1, beta2, eps, pair->max_norm2, scratch, scratch_floats, rs + nt, rst + nt, rp + nt, stream);
+    float *h2 = scratch + 4 + num_chunks + 1;
+    for (int i = 0; i < 4; ++i) { h2[i] = scratch[i]; scratch[i] = head1[i]; }
+    return rc;
+}
+
 /* ABI 18: a tensor's gradient put together (parts + alpha2 * second parts + reg * W), then its Adam states in order (the three optimisers of
  * bbc/rsl_rl/algorithms/gail.py:107-132 stepped one after the other, gail.py:518-520; regularisers gail.py:503-511, penalty gail.py:487-501) */
 int qo_adam_stack_step(const qa_adam_stack_tensor *tensors, int32_t count, float beta1, float beta2, float eps, uint32_t *ticket, void *stream) {
@@ -2308,6 +2340,24 @@ int qo_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int
         }
     }
     out[0] = (float)(mode == QA_PAIR_ROW_L2 ? acc / (double)rows : acc / ((double)rows * (double)cols));
+    return QA_OK;
+}
+
+/* ABI 18: several pair losses in one call, the gradient optionally times a device scalar (the regulariser's coefficient, gail.py:353-357) */
+int64_t qo_pair_losses_scratch_bytes(const qa_pair_job *jobs, int32_t count) {
+    if (!jobs || count <= 0 || count > QA_PAIR_MAX_JOBS) return -1;
+    int64_t blocks = 0;
+    for (int t = 0; t < count; ++t) { if (jobs[t].rows <= 0) return -1; blocks += (jobs[t].rows + 255) / 256; }
+    return (int64_t)sizeof(float) * (blocks + 1);
+}
+int qo_pair_losses(const qa_pair_job *jobs, int32_t count, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!jobs || count <= 0 || count > QA_PAIR_MAX_JOBS || !scratch || scratch_bytes < qo_pair_losses_scratch_bytes(jobs, count)) return QA_E_ARG;
+    for (int t = 0; t < count; ++t) {
+        const qa_pair_job *J = &jobs[t];
+        int rc = qo_pair_loss(J->a, J->b, J->rows, J->cols, J->b_stride, J->mode, J->grad_a, J->out, scratch, scratch_bytes, stream);
+        if (rc != QA_OK) return rc;
+        if (J->grad_scale) for (int64_t i = 0; i < J->rows * J->cols; ++i) J->grad_a[i] *= J->grad_scale[0];
+    }
     return QA_OK;
 }
 

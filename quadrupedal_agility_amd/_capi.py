@@ -131,6 +131,11 @@ def bind(lib, prefix):
     f.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64] + [C.c_void_p] * 4
     f.restype = C.c_int
     f = getattr(lib, prefix + "grad_reduce"); f.argtypes = [C.c_void_p] * 5 + [C.c_int32, C.c_void_p]; f.restype = C.c_int
+    f = getattr(lib, prefix + "clip_adam_pair_step")
+    f.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+    f.restype = C.c_int
+    f = getattr(lib, prefix + "pair_losses_scratch_bytes"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int64
+    f = getattr(lib, prefix + "pair_losses"); f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "adam_stack_step"); f.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]; f.restype = C.c_int
     f = getattr(lib, prefix + "rollout_act")
     f.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 7
@@ -234,6 +239,18 @@ class QaWgradDesc(C.Structure):
 ADAM_STACK_MAX_TENSORS, ADAM_STACK_MAX_STATES = 16, 3
 
 
+class QaPairJob(C.Structure):
+    """qa_pair_job of include/qa_sim.h"""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int32), ("mode", C.c_int32), ("b_stride", C.c_int64),
+                ("grad_scale", C.c_void_p), ("grad_a", C.c_void_p), ("out", C.c_void_p)]
+
+
+class QaAdamPair(C.Structure):
+    """qa_adam_pair of include/qa_sim.h"""
+    _fields_ = [("split_tensor", C.c_int32), ("split_chunk", C.c_int32), ("lr2", C.c_void_p), ("max_norm2", C.c_float), ("kl", C.c_void_p),
+                ("desired_kl", C.c_float), ("kl_factor", C.c_float), ("lr_min", C.c_float), ("lr_max", C.c_float)]
+
+
 class QaAdamStackState(C.Structure):
     """qa_adam_stack_state of include/qa_sim.h"""
     _fields_ = [("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step", C.c_void_p), ("lr", C.c_void_p), ("weight_decay", C.c_float), ("pad_", C.c_int32)]
@@ -323,7 +340,7 @@ class QaTscDepthIo(C.Structure):
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "tsc_reset_dev", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "hybrid_ppo_loss", "hybrid_ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "linear_backward_weight_batch", "linear_backward_weight_batch_layout", "linear_backward_weight_batch_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "grad_reduce", "adam_stack_step", "rollout_act", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "linear_backward_weight_batch", "linear_backward_weight_batch_layout", "linear_backward_weight_batch_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "clip_adam_pair_step", "grad_reduce", "adam_stack_step", "rollout_act", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "pair_losses", "pair_losses_scratch_bytes", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
 
 _LIB = None
 # QA_LIB: another build of the SAME library (A/B measurements of a kernel variant, tools/r5_call.sh); there is still no fallback -- a missing file raises

@@ -539,6 +539,12 @@ struct AdamArgs {
     const float *red_src[QA_ADAM_MAX_INLINE];
     int64_t red_stride[QA_ADAM_MAX_INLINE];
     int32_t red_parts[QA_ADAM_MAX_INLINE];
+    // r6 (qa_clip_adam_pair_step): TWO optimisers in the same three launches -- tensors >= split_tensor / chunks >= split_chunk are the second one's, with its
+    // own clipping norm, step counter and learning rate; the KL rule (qa_kl_lr_rule) moves lr2 in the finalize launch, before the update reads it.
+    // split_chunk == 0: one optimiser.  The second head (coef, bc1, sqrt(bc2), norm) sits behind the arrival counter: scratch[4 + num_chunks + 1 ..].
+    int split_chunk, split_tensor;
+    float *lr2; float max_norm2;
+    const float *kl; float desired_kl, kl_factor, lr_min, lr_max;
 };
 __device__ __forceinline__ const float *adam_grad(const AdamArgs &a, int t) { return a.inline_grads ? a.gin[t] : a.grads[t]; }
 
@@ -604,22 +610,42 @@ __global__ void __launch_bounds__(256) qa_adam_sumsq_kernel(AdamArgs a) {
 }
 
 __global__ void __launch_bounds__(256) qa_adam_finalize_kernel(AdamArgs a) {
-    __shared__ double s_acc[256];
-    double acc = 0.0;
+    __shared__ double s_acc[256], s_acc2[256];
+    const int split = a.split_chunk > 0 ? a.split_chunk : a.num_chunks;
+    double acc = 0.0, acc2 = 0.0;
     if (a.max_norm > 0.f)          /* without clipping the per-chunk sums were not computed (and the norm is reported as 0) */
-        for (int c = threadIdx.x; c < a.num_chunks; c += 256) acc += (double)a.scratch[4 + c];
-    s_acc[threadIdx.x] = acc;
+        for (int c = threadIdx.x; c < split; c += 256) acc += (double)a.scratch[4 + c];
+    if (a.split_chunk > 0 && a.max_norm2 > 0.f)
+        for (int c = split + threadIdx.x; c < a.num_chunks; c += 256) acc2 += (double)a.scratch[4 + c];
+    s_acc[threadIdx.x] = acc; s_acc2[threadIdx.x] = acc2;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; __syncthreads(); }
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; s_acc2[threadIdx.x] += s_acc2[threadIdx.x + o]; } __syncthreads(); }
+    const int nt1 = a.split_chunk > 0 ? a.split_tensor : a.num_tensors;
     const float step = a.steps[0][0] + 1.0f;
+    const float step2 = a.split_chunk > 0 ? a.steps[nt1][0] + 1.0f : 0.f;
     __syncthreads();
-    for (int t = threadIdx.x; t < a.num_tensors; t += 256) a.steps[t][0] = step;
+    for (int t = threadIdx.x; t < a.num_tensors; t += 256) a.steps[t][0] = t < nt1 ? step : step2;
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(s_acc[0]);
         a.scratch[0] = a.max_norm > 0.f ? fminf(1.0f, a.max_norm / (norm + 1e-6f)) : 1.0f;
         a.scratch[1] = 1.0f - powf(a.beta1, step);
         a.scratch[2] = sqrtf(1.0f - powf(a.beta2, step));
         a.scratch[3] = norm;
+        if (a.split_chunk > 0) {
+            float *h = a.scratch + 4 + a.num_chunks + 1;
+            const float norm2 = (float)sqrt(s_acc2[0]);
+            h[0] = a.max_norm2 > 0.f ? fminf(1.0f, a.max_norm2 / (norm2 + 1e-6f)) : 1.0f;
+            h[1] = 1.0f - powf(a.beta1, step2);
+            h[2] = sqrtf(1.0f - powf(a.beta2, step2));
+            h[3] = norm2;
+            if (a.kl) {             /* qa_kl_lr_rule_kernel's rule (gail.py:367-379), on the second optimiser's learning rate */
+                const float k = a.kl[0], cur = a.lr2[0];
+                float out = cur;
+                if (k > a.desired_kl * 2.0f) out = fmaxf(a.lr_min, cur / a.kl_factor);
+                else if (k < a.desired_kl / 2.0f && k > 0.0f) out = fminf(a.lr_max, cur * a.kl_factor);
+                a.lr2[0] = out;
+            }
+        }
     }
 }
 
@@ -662,6 +688,100 @@ __global__ void __launch_bounds__(256) qa_pair_finish_kernel(const float *__rest
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) out[0] = (float)(s_acc[0] * (double)scale);
+}
+
+/* r6 (ABI 18): up to QA_PAIR_MAX_JOBS pair losses in ONE launch, finished by the last workgroup to arrive (the fixed-order double sum of
+ * qa_pair_finish_kernel over each job's partials), the gradient optionally times a device scalar -- a PPO chain step's regulariser + estimator losses were five
+ * launches (two losses, two finishes, the multiply by the regulariser's coefficient). */
+constexpr int PAIR_LDS_COLS = 47;        // 256 rows x (cols | 1) floats in LDS: <= 48 KB
+struct PairJobsArgs { qa_pair_job j[QA_PAIR_MAX_JOBS]; int32_t first_block[QA_PAIR_MAX_JOBS + 1]; int32_t n; float *partial; unsigned *ticket; };
+__global__ void __launch_bounds__(PAIR_BLOCK) qa_pair_losses_kernel(PairJobsArgs p) {
+    __shared__ float s_red[PAIR_BLOCK];
+    __shared__ double s_acc[PAIR_BLOCK];
+    __shared__ int s_last;
+    __shared__ float s_d[PAIR_BLOCK * (PAIR_LDS_COLS | 1)];
+    int t = 0;
+    while (t + 1 < p.n && (int)blockIdx.x >= p.first_block[t + 1]) ++t;
+    const float *a = p.j[t].a, *b = p.j[t].b;
+    const int64_t rows = p.j[t].rows, b_stride = p.j[t].b_stride;
+    const int cols = p.j[t].cols, mode = p.j[t].mode;
+    const bool scaled = p.j[t].grad_scale != nullptr;
+    const float gs = scaled ? p.j[t].grad_scale[0] : 1.0f;
+    const int64_t r0 = (int64_t)((int)blockIdx.x - p.first_block[t]) * PAIR_BLOCK;
+    const int64_t r = r0 + threadIdx.x;
+    float contrib = 0.f;
+    if (cols <= PAIR_LDS_COLS) {
+        // the block's rows through LDS: a lane-per-row walk over rows of 29 floats in global memory is 29 uncoalesced round trips twice over (qa_pair_loss:
+        // 11.8 us for 3,072 x 29); here the differences arrive in one coalesced sweep, a lane walks ITS row in LDS (an odd row stride: no bank conflict) in the
+        // same order with the same operations -- bit-identical to qa_pair_loss -- and the gradient leaves in one coalesced sweep
+        const int nrow = (int)min((int64_t)PAIR_BLOCK, rows - r0);
+        const int ld = cols | 1;
+        for (int i = threadIdx.x; i < nrow * cols; i += PAIR_BLOCK) {
+            const int rr = i / cols, c = i - rr * cols;
+            s_d[rr * ld + c] = a[(r0 + rr) * cols + c] - b[(r0 + rr) * b_stride + c];
+        }
+        __syncthreads();
+        if (r < rows) {
+            float *dr = s_d + threadIdx.x * ld;
+            float ss = 0.f;
+            for (int c = 0; c < cols; ++c) { const float d = dr[c]; ss = fmaf(d, d, ss); }
+            float sc;
+            if (mode == 0) {
+                const float nrm = sqrtf(ss);
+                sc = nrm > 0.f ? 1.0f / (nrm * (float)rows) : 0.f;
+                contrib = nrm;
+            } else {
+                sc = 2.0f / ((float)rows * (float)cols);
+                contrib = ss;
+            }
+            if (scaled) for (int c = 0; c < cols; ++c) dr[c] = (dr[c] * sc) * gs;           // (the separate multiply's rounding)
+            else for (int c = 0; c < cols; ++c) dr[c] = dr[c] * sc;
+        }
+        __syncthreads();
+        float *g0 = p.j[t].grad_a + r0 * cols;
+        for (int i = threadIdx.x; i < nrow * cols; i += PAIR_BLOCK) { const int rr = i / cols, c = i - rr * cols; g0[i] = s_d[rr * ld + c]; }
+    } else if (r < rows) {
+        const float *ar = a + r * cols, *br = b + r * b_stride;
+        float *gr = p.j[t].grad_a + r * cols;
+        float ss = 0.f;
+        for (int c = 0; c < cols; ++c) { const float d = ar[c] - br[c]; ss = fmaf(d, d, ss); }
+        float sc;
+        if (mode == 0) {
+            const float nrm = sqrtf(ss);
+            sc = nrm > 0.f ? 1.0f / (nrm * (float)rows) : 0.f;
+            contrib = nrm;
+        } else {
+            sc = 2.0f / ((float)rows * (float)cols);
+            contrib = ss;
+        }
+        if (scaled) for (int c = 0; c < cols; ++c) gr[c] = ((ar[c] - br[c]) * sc) * gs;           // (the separate multiply's rounding)
+        else for (int c = 0; c < cols; ++c) gr[c] = (ar[c] - br[c]) * sc;
+    }
+    s_red[threadIdx.x] = contrib;
+    __syncthreads();
+    for (int o = PAIR_BLOCK / 2; o > 0; o >>= 1) { if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        p.partial[blockIdx.x] = s_red[0];
+        __threadfence();
+        s_last = atomicAdd(p.ticket, 1u) == (unsigned)(p.first_block[p.n] - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int k = 0; k < p.n; ++k) {
+        const int lo = p.first_block[k], nb = p.first_block[k + 1] - lo;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nb; i += 256) acc += (double)__hip_atomic_load(p.partial + lo + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_acc[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s_acc[threadIdx.x] += s_acc[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) {
+            const float scale = p.j[k].mode == QA_PAIR_ROW_L2 ? 1.0f / (float)p.j[k].rows : 1.0f / ((float)p.j[k].rows * (float)p.j[k].cols);
+            p.j[k].out[0] = (float)(s_acc[0] * (double)scale);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *p.ticket = 0u;           // ready for the next launch (replays of a recorded step included)
 }
 
 /* ---- minibatch gather: dst_t[r, :] = src_t[idx[r], :] for up to QA_GATHER_MAX row-major fp32 tensors in one launch
@@ -725,9 +845,11 @@ __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
     float *p = a.params[t] + s0, *m = a.exp_avg[t] + s0, *v = a.exp_avg_sq[t] + s0;
     const float *g = adam_grad(a, t) + s0;
     const float step = SELF ? a.steps[0][0] + 1.0f : 0.f;
-    const float coef = SELF ? 1.0f : a.scratch[0], bc1 = SELF ? 1.0f - powf(a.beta1, step) : a.scratch[1],
-                bc2s = SELF ? sqrtf(1.0f - powf(a.beta2, step)) : a.scratch[2], wd = a.weight_decay[t];
-    const float step_size = a.lr[0] / bc1;
+    const bool second = !SELF && a.split_chunk > 0 && c >= a.split_chunk;           // (qa_clip_adam_pair_step)
+    const float *head = second ? a.scratch + 4 + a.num_chunks + 1 : a.scratch;
+    const float coef = SELF ? 1.0f : head[0], bc1 = SELF ? 1.0f - powf(a.beta1, step) : head[1],
+                bc2s = SELF ? sqrtf(1.0f - powf(a.beta2, step)) : head[2], wd = a.weight_decay[t];
+    const float step_size = (second ? a.lr2[0] : a.lr[0]) / bc1;
     for (int i = threadIdx.x; i < n; i += 256) {
         const float pi = p[i];
         const float gi = fmaf(wd, pi, g[i] * coef);
@@ -1399,12 +1521,22 @@ static int clip_adam_launch(float *const *params, const float *const *grads_dev,
                             float *const *exp_avg_sq, float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
                             const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1, float beta2, float eps,
                             float max_norm, float *scratch, int64_t scratch_floats, void *stream, const char *who,
-                            const float *const *red_src = nullptr, const int64_t *red_stride = nullptr, const int32_t *red_parts = nullptr) {
+                            const float *const *red_src = nullptr, const int64_t *red_stride = nullptr, const int32_t *red_parts = nullptr, const qa_adam_pair *pair = nullptr) {
     if (!params || (!grads_dev && !grads_host) || !exp_avg || !exp_avg_sq || !steps || !chunk_tensor || !chunk_start || !chunk_len || !weight_decay || !lr ||
         !scratch || num_tensors <= 0 || num_chunks <= 0 || scratch_floats < 4 + (int64_t)num_chunks || (grads_host && num_tensors > QA_ADAM_MAX_INLINE)) {
         snprintf(g_lerr, sizeof(g_lerr), "%s: bad argument", who); return QA_E_ARG; }
-    AdamArgs a{params, grads_dev, exp_avg, exp_avg_sq, steps, chunk_tensor, chunk_start, chunk_len, weight_decay, lr, scratch, num_chunks, num_tensors,
-               beta1, beta2, eps, max_norm, grads_host ? 1 : 0, {}, 0, {}, {}, {}};
+    AdamArgs a{};
+    a.params = params; a.grads = grads_dev; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.steps = steps; a.chunk_tensor = chunk_tensor; a.chunk_start = chunk_start;
+    a.chunk_len = chunk_len; a.weight_decay = weight_decay; a.lr = lr; a.scratch = scratch; a.num_chunks = num_chunks; a.num_tensors = num_tensors;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm; a.inline_grads = grads_host ? 1 : 0;
+    if (pair) {
+        if (!grads_host || pair->split_tensor <= 0 || pair->split_tensor >= num_tensors || pair->split_chunk <= 0 || pair->split_chunk >= num_chunks || !pair->lr2 ||
+            !(max_norm > 0.f) || !(pair->max_norm2 > 0.f) || scratch_floats < 4 + (int64_t)num_chunks + 1 + 4) {
+            snprintf(g_lerr, sizeof(g_lerr), "%s: two clipping optimisers (max_norm > 0 both), the host pointer form, 0 < split < count and scratch >= num_chunks + 9 floats expected", who);
+            return QA_E_ARG; }
+        a.split_chunk = pair->split_chunk; a.split_tensor = pair->split_tensor; a.lr2 = pair->lr2; a.max_norm2 = pair->max_norm2;
+        a.kl = pair->kl; a.desired_kl = pair->desired_kl; a.kl_factor = pair->kl_factor; a.lr_min = pair->lr_min; a.lr_max = pair->lr_max;
+    }
     if (grads_host) for (int t = 0; t < num_tensors; ++t) a.gin[t] = grads_host[t];
     if (red_src) {
         if (!grads_host || !(max_norm > 0.f) || !red_parts || !red_stride) {
@@ -1454,6 +1586,16 @@ int qa_clip_adam_step_reduce(float *const *params, const float *const *grads_hos
     if (!red_src_host || !red_stride_host || !red_parts_host) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_step_reduce: bad argument"); return QA_E_ARG; }
     return clip_adam_launch(params, nullptr, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay,
                             lr, beta1, beta2, eps, max_norm, scratch, scratch_floats, stream, "qa_clip_adam_step_reduce", red_src_host, red_stride_host, red_parts_host);
+}
+
+int qa_clip_adam_pair_step(float *const *params, const float *const *grads_host, float *const *exp_avg, float *const *exp_avg_sq,
+                           float *const *steps, int32_t num_tensors, const int32_t *chunk_tensor, const int32_t *chunk_start,
+                           const int32_t *chunk_len, int32_t num_chunks, const float *weight_decay, const float *lr, float beta1,
+                           float beta2, float eps, float max_norm, float *scratch, int64_t scratch_floats,
+                           const float *const *red_src_host, const int64_t *red_stride_host, const int32_t *red_parts_host, const qa_adam_pair *pair, void *stream) {
+    if (!pair) { snprintf(g_lerr, sizeof(g_lerr), "qa_clip_adam_pair_step: bad argument"); return QA_E_ARG; }
+    return clip_adam_launch(params, nullptr, grads_host, exp_avg, exp_avg_sq, steps, num_tensors, chunk_tensor, chunk_start, chunk_len, num_chunks, weight_decay,
+                            lr, beta1, beta2, eps, max_norm, scratch, scratch_floats, stream, "qa_clip_adam_pair_step", red_src_host, red_stride_host, red_parts_host, pair);
 }
 
 // dst[t][i] = sum_z src[t][z stride[t] + i], z < parts[t] ascending, for a handful of tensors in ONE launch: the gradients-in-parts of a step
@@ -1582,6 +1724,35 @@ int qa_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int
     hipLaunchKernelGGL(qa_pair_finish_kernel, dim3(1), dim3(256), 0, st, (const float *)scratch, nb, scale, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+static int pair_jobs_blocks(const qa_pair_job *jobs, int32_t count, int32_t *first_block) {
+    int blocks = 0;
+    for (int t = 0; t < count; ++t) {
+        const qa_pair_job &J = jobs[t];
+        if (!J.a || !J.b || !J.grad_a || !J.out || J.rows <= 0 || J.cols <= 0 || J.b_stride < J.cols || (J.mode != QA_PAIR_ROW_L2 && J.mode != QA_PAIR_MSE)) return -1;
+        if (first_block) first_block[t] = blocks;
+        blocks += (int)((J.rows + PAIR_BLOCK - 1) / PAIR_BLOCK);
+    }
+    if (first_block) first_block[count] = blocks;
+    return blocks;
+}
+int64_t qa_pair_losses_scratch_bytes(const qa_pair_job *jobs, int32_t count) {
+    if (!jobs || count <= 0 || count > QA_PAIR_MAX_JOBS) return -1;
+    const int blocks = pair_jobs_blocks(jobs, count, nullptr);
+    return blocks < 0 ? -1 : (int64_t)sizeof(float) * (blocks + 1);
+}
+int qa_pair_losses(const qa_pair_job *jobs, int32_t count, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!jobs || count <= 0 || count > QA_PAIR_MAX_JOBS || !scratch) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_losses: 1..%d jobs and a scratch buffer expected", QA_PAIR_MAX_JOBS); return QA_E_ARG; }
+    PairJobsArgs p{};
+    const int blocks = pair_jobs_blocks(jobs, count, p.first_block);
+    if (blocks < 0 || scratch_bytes < (int64_t)sizeof(float) * (blocks + 1)) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_losses: bad job or scratch too small"); return QA_E_ARG; }
+    for (int t = 0; t < count; ++t) p.j[t] = jobs[t];
+    p.n = count; p.ticket = (unsigned *)scratch; p.partial = (float *)scratch + 1;
+    hipLaunchKernelGGL(qa_pair_losses_kernel, dim3(blocks), dim3(PAIR_BLOCK), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_losses: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -872,6 +872,38 @@ def pair_loss_raw(a, b, mode):
     return out, grad
 
 
+_pair_scratch = {}
+
+
+def pair_losses_raw(jobs):
+    """several qa_pair_loss problems in ONE launch (qa_pair_losses, ABI 18).  jobs: [(a, b, mode, grad_scale)] with grad_scale a 0-d ROCm tensor or None;
+    -> [(loss (0-d, unscaled), d loss / d a times grad_scale)].  The launches of one call site must follow each other on one stream (they share the
+    arrival counter's word)."""
+    lib = _capi.load_library()
+    n = len(jobs)
+    recs = (_capi.QaPairJob * n)()
+    outs, keep = [], []
+    dev = jobs[0][0].device
+    for i, (a, b, mode, scale) in enumerate(jobs):
+        a = _f32c(a.detach())
+        assert b.dtype == torch.float32 and b.stride(1) == 1 and a.shape == b.shape
+        grad = torch.empty_like(a)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        if scale is not None:
+            assert torch.is_tensor(scale) and scale.dtype == torch.float32 and scale.numel() == 1 and scale.device == dev
+        r = recs[i]
+        r.a, r.b, r.rows, r.cols, r.mode, r.b_stride = a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], int(mode), b.stride(0)
+        r.grad_scale, r.grad_a, r.out = (scale.data_ptr() if scale is not None else None), grad.data_ptr(), out.data_ptr()
+        outs.append((out, grad)); keep.append(a)
+    nb = int(lib.qa_pair_losses_scratch_bytes(C.cast(recs, C.c_void_p), n))
+    key = (dev, nb)
+    sc = _pair_scratch.get(key)
+    if sc is None:
+        sc = _pair_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)          # the arrival counter: zeroed ONCE
+    _check(lib.qa_pair_losses(C.cast(recs, C.c_void_p), n, _ptr(sc), nb, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "qa_pair_losses")
+    return outs
+
+
 def gather_rows(idx, srcs, dsts=None, block_dev=None):
     """[src[idx] for src in srcs] for row-major fp32 tensors (N, w) in ONE launch; idx (rows) int64 on the device.  `dsts`
     (dense (rows, w) tensors) are allocated when not given.  With block_dev (0-d int64 device tensor) idx is a (blocks, rows)
@@ -951,12 +983,13 @@ class ClipAdam:
                    betas=g0["betas"], eps=g0["eps"], lr_dev=None, lr_val=None)
         self._tab = tab
 
-    def step(self):
+    def _prepare(self, for_pair=False):
+        """-> None (nothing to step), False (the PyTorch calls must take this step) or dict(tab, params, ptrs, pend, lr_dev, inline)"""
         opt = self.opt
         items = [(p, g) for g in opt.param_groups for p in g["params"] if p.grad is not None]
         params = [p for p, _ in items]
         if not items:
-            return
+            return None
         g0 = opt.param_groups[0]
         ok = (ENABLED and params[0].is_cuda and not g0.get("amsgrad", False) and not g0.get("maximize", False)
               and all(("exp_avg" in opt.state.get(p, {})) and torch.is_tensor(opt.state[p]["step"]) and opt.state[p]["step"].is_cuda for p in params)
@@ -969,19 +1002,41 @@ class ClipAdam:
             can = (ok and self.max_norm > 0 and len(params) <= 64 and
                    all(e is None or e[2] <= self.WIDE_PARTS or p.numel() <= self.CHUNK for p, e in zip(params, pend)))
             if not can:
+                if for_pair:
+                    return False                # (the caller steps the two optimisers one after the other: that path finishes the parts it cannot take)
                 flush_pending_grads(params)
                 pend = None
         else:
             pend = None
         if not ok:
-            return self._torch_step(params)
+            return False
         tab = self._tab
         if (tab is None or len(tab["items"]) != len(params) or any(a is not b for a, b in zip(tab["items"], params))
                 or any(opt.state[p] is not s or s["exp_avg"].data_ptr() != e for p, s, e in zip(params, tab["state_refs"], tab["exp_avg_ptrs"]))):
             self._build(items)          # first use, or load_state_dict() replaced the state tensors
         t = self._tab
         ptrs = [p.grad.data_ptr() for p in params]
-        inline = len(ptrs) <= 64                        # QA_ADAM_MAX_INLINE: the pointers ride in the kernel arguments, no table copy
+        lr = g0["lr"]
+        if torch.is_tensor(lr):
+            lr_dev = lr if lr.dtype == torch.float32 else None
+            if lr_dev is None:
+                return False
+        else:
+            if t["lr_dev"] is None:
+                t["lr_dev"] = torch.zeros((), dtype=torch.float32, device=params[0].device)
+            if t["lr_val"] != float(lr):
+                t["lr_dev"].fill_(float(lr)); t["lr_val"] = float(lr)
+            lr_dev = t["lr_dev"]
+        return dict(tab=t, params=params, ptrs=ptrs, pend=pend, lr_dev=lr_dev, inline=len(ptrs) <= 64)      # QA_ADAM_MAX_INLINE: the pointers ride in the kernel arguments
+
+    def step(self):
+        pre = self._prepare()
+        if pre is None:
+            return
+        if pre is False:
+            opt = self.opt
+            return self._torch_step([p for g in opt.param_groups for p in g["params"] if p.grad is not None])
+        t, params, ptrs, pend, lr_dev, inline = pre["tab"], pre["params"], pre["ptrs"], pre["pend"], pre["lr_dev"], pre["inline"]
         if not inline and torch.cuda.is_current_stream_capturing():
             # The table path uploads ONE shared pinned host table; a captured copy of it reads the host memory at REPLAY time, so every
             # recording but the last would step with the last recording's (or freed) gradient addresses.  Refuse: the
@@ -996,17 +1051,6 @@ class ClipAdam:
             t["copied"] = torch.cuda.Event()
             t["copied"].record()
             t["grad_ptrs"] = ptrs
-        lr = g0["lr"]
-        if torch.is_tensor(lr):
-            lr_dev = lr if lr.dtype == torch.float32 else None
-            if lr_dev is None:
-                return self._torch_step(params)
-        else:
-            if t["lr_dev"] is None:
-                t["lr_dev"] = torch.zeros((), dtype=torch.float32, device=params[0].device)
-            if t["lr_val"] != float(lr):
-                t["lr_dev"].fill_(float(lr)); t["lr_val"] = float(lr)
-            lr_dev = t["lr_dev"]
         lib = _capi.load_library()
         stream = C.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream)
         if pend is not None:
@@ -1032,6 +1076,81 @@ class ClipAdam:
                                    _ptr(t["scratch"]), t["scratch"].numel(), stream)
         if rc != 0:
             raise RuntimeError(f"qa_clip_adam_step failed with code {rc}: {lib.qa_last_error().decode()}")
+
+
+class ClipAdamPair:
+    """`first.step(); kl rule on second's learning rate; second.step()` of two ClipAdam objects as THREE launches instead of seven
+    (qa_clip_adam_pair_step, ABI 18): the tail of a PPO minibatch step (gail.py:359-362, 367-379, 405-408).  `step()` returns False when the pair launch
+    cannot take the step (state not created yet, a fallback condition of either optimiser, more than 64 tensors together): the caller then steps them one
+    after the other as before."""
+
+    def __init__(self, first, second):
+        self.first, self.second = first, second
+        self._tab = None
+
+    def warm(self):
+        """build the merged tables now (gradients must exist, nothing is launched): call before recording a step whose first paired launch would
+        otherwise happen inside the capture"""
+        return self.step(dry=True)
+
+    def step(self, kl=None, desired_kl=0.0, factor=1.5, lr_min=1e-5, lr_max=1e-2, dry=False):
+        a, b = self.first, self.second
+        self.why_not = None
+        if not (ENABLED and a.max_norm > 0 and b.max_norm > 0):
+            self.why_not = "an optimiser without clipping"
+            return False
+        ga, gb = a.opt.param_groups[0], b.opt.param_groups[0]
+        if ga["betas"] != gb["betas"] or ga["eps"] != gb["eps"] or not (torch.is_tensor(gb["lr"]) and gb["lr"].dtype == torch.float32 and gb["lr"].is_cuda):
+            self.why_not = "different betas / eps, or the second learning rate is not a device scalar"
+            return False
+        if kl is not None and not (torch.is_tensor(kl) and kl.is_cuda and kl.dtype == torch.float32 and kl.numel() == 1):
+            self.why_not = "kl is not a device fp32 scalar"
+            return False
+        pa = a._prepare(for_pair=True)
+        if not pa:
+            self.why_not = f"the first optimiser cannot take the fused step ({pa})"
+            return False
+        pb = b._prepare(for_pair=True)
+        if not pb or len(pa["ptrs"]) + len(pb["ptrs"]) > 64:
+            self.why_not = f"the second optimiser cannot take the fused step ({pb if not pb else 'more than 64 tensors together'})"
+            return False
+        ta, tb = pa["tab"], pb["tab"]
+        m = self._tab
+        if m is None or m["ta"] is not ta or m["tb"] is not tb:
+            if torch.cuda.is_current_stream_capturing():
+                # the merged tables are a dozen small device copies: recorded, they would replay with every step (measured: 12 launches, 56 us of a
+                # task-level step).  `warm()` builds them before a capture; without it this recording keeps the two steps apart
+                self.why_not = "the merged tables do not exist yet and a capture is running (call warm() first)"
+                return False
+            cat = lambda k: torch.cat([ta[k], tb[k]])
+            m = self._tab = dict(ta=ta, tb=tb, params=cat("params"), exp_avg=cat("exp_avg"), exp_avg_sq=cat("exp_avg_sq"), steps=cat("steps"),
+                                 chunk_tensor=torch.cat([ta["chunk_tensor"], tb["chunk_tensor"] + ta["n"]]), chunk_start=cat("chunk_start"), chunk_len=cat("chunk_len"),
+                                 wd=cat("wd"), n=ta["n"] + tb["n"], num_chunks=ta["num_chunks"] + tb["num_chunks"],
+                                 scratch=torch.zeros(ta["num_chunks"] + tb["num_chunks"] + 9, dtype=torch.float32, device=ta["params"].device))
+        if dry:
+            return True
+        ptrs = pa["ptrs"] + pb["ptrs"]
+        n = len(ptrs)
+        pend = (pa["pend"] or [None] * len(pa["ptrs"])) + (pb["pend"] or [None] * len(pb["ptrs"]))
+        src = (C.c_void_p * n)(*[(e[1].data_ptr() if e is not None else 0) for e in pend])
+        stride = (C.c_int64 * n)(*[(e[3] if e is not None else 0) for e in pend])
+        parts = (C.c_int32 * n)(*[(e[2] if e is not None else 0) for e in pend])
+        pair = _capi.QaAdamPair(ta["n"], ta["num_chunks"], pb["lr_dev"].data_ptr(), b.max_norm, kl.data_ptr() if kl is not None else None,
+                                float(desired_kl), float(factor), float(lr_min), float(lr_max))
+        lib = _capi.load_library()
+        params = pa["params"] + pb["params"]
+        rc = lib.qa_clip_adam_pair_step(_ptr(m["params"]), (C.c_void_p * n)(*ptrs), _ptr(m["exp_avg"]), _ptr(m["exp_avg_sq"]), _ptr(m["steps"]), m["n"],
+                                        _ptr(m["chunk_tensor"]), _ptr(m["chunk_start"]), _ptr(m["chunk_len"]), m["num_chunks"], _ptr(m["wd"]),
+                                        _ptr(pa["lr_dev"]), float(ta["betas"][0]), float(ta["betas"][1]), float(ta["eps"]), a.max_norm,
+                                        _ptr(m["scratch"]), m["scratch"].numel(), src, stride, parts, C.byref(pair),
+                                        C.c_void_p(torch.cuda.current_stream(params[0].device).cuda_stream))
+        for p in params:
+            e = _PENDING.pop(p.data_ptr(), None)
+            if e is not None:
+                _retire(e[1])
+        if rc != 0:
+            raise RuntimeError(f"qa_clip_adam_pair_step failed with code {rc}: {lib.qa_last_error().decode()}")
+        return True
 
 
 class StackedAdam:

@@ -108,6 +108,8 @@ class SSInfoGAIL:
         self._step_ac = ClipAdam(self.optim_ac, max_grad_norm)
         self._step_estimator = ClipAdam(self.optim_estimator, max_grad_norm)
         self._step_hist_encoder = ClipAdam(self.optim_hist_encoder, max_grad_norm)
+        self._step_pair = (fused_mod.ClipAdamPair(self._step_estimator, self._step_ac)
+                           if (self._on_gpu and max_grad_norm and os.environ.get("QA_ADAM_PAIR", "1") != "0") else None)
         self._step_disc = [ClipAdam(o, None) if isinstance(o, optim.Adam) else o for o in (self.optim_d, self.optim_q_eps, self.optim_q_c)]
         self._disc_stack = (fused_mod.StackedAdam([self.optim_d, self.optim_q_eps, self.optim_q_c])
                             if (self._on_gpu and isinstance(self.optim_d, optim.Adam) and os.environ.get("QA_DISC_STACKED_ADAM", "1") != "0") else None)
@@ -716,9 +718,14 @@ class SSInfoGAIL:
         if hist_latent is None:
             with torch.no_grad():
                 hist_latent = ac.infer_hist_latent(obs[:, c:d])
-        priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
-        g_priv = g_priv * priv_reg_coef
-        estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
+        if torch.is_tensor(priv_reg_coef) and priv_reg_coef.dtype == torch.float32 and priv_reg_coef.device == obs.device and os.environ.get("QA_PAIR_LOSSES", "1") != "0":
+            # r6 (ABI 18): both losses, their finishes and the coefficient's multiply in ONE launch (were five)
+            (priv_reg_loss, g_priv), (estimator_loss, g_est) = fused_mod.pair_losses_raw(
+                [(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2, priv_reg_coef), (est, obs[:, a:b], fused_mod.PAIR_MSE, None)])
+        else:
+            priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
+            g_priv = g_priv * priv_reg_coef
+            estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
         out, dmu, dstd, dvalue = fused_mod.ppo_loss_raw(mu, ac.std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
                                                         clip=self.clip_param, c_surr=self.surrogate_loss_coef, c_value=self.value_loss_coef,
                                                         c_bound=self.bounds_loss_coef, c_entropy=self.entropy_coef,
@@ -737,6 +744,12 @@ class SSInfoGAIL:
         if sides is not None:                        # chain steps (few rows): the estimator's optimiser beside the actor-critic's, disjoint parameters
             with sides.fork(0):
                 self._step_estimator.step()
+        elif (self._step_pair is not None and self.use_fused_loss and (kl_mean is None or (kl_mean.dtype == torch.float32 and kl_mean.is_contiguous()))
+              and self._step_pair.step(kl_mean, self.desired_kl)):
+            # r6 (ABI 18): both clipped Adam steps and the KL rule between them as three launches instead of seven (fused.ClipAdamPair)
+            if fused_mod.pending_grads():
+                fused_mod.flush_pending_grads()
+            return
         else:
             self._step_estimator.step()              # clip_grad_norm_(max_grad_norm) + Adam, three launches on the GPU
         if kl_mean is not None:

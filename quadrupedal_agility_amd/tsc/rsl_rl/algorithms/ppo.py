@@ -364,9 +364,15 @@ class PPO:
                                             clip=self.clip_param, c_value=self.value_loss_coef, c_entropy=self.entropy_coef,
                                             clipped_value=self.use_clipped_value_loss)
             out, dlogits, dmean, dstd, dvalue = res
-            priv_reg_loss, g_priv = fused.pair_loss_raw(priv_latent, hist_latent, fused.PAIR_ROW_L2)
-            est_loss, g_est = fused.pair_loss_raw(est, obs[:, self._priv_slice(True)], fused.PAIR_MSE)
-            chain.backward(g_est, dlogits, dmean, dvalue, g_priv * coef)
+            if torch.is_tensor(coef) and coef.dtype == torch.float32 and coef.device == obs.device and os.environ.get("QA_PAIR_LOSSES", "1") != "0":
+                # r6 (ABI 18): both losses, their finishes and the coefficient's multiply in ONE launch (were five); same arithmetic
+                (priv_reg_loss, g_priv), (est_loss, g_est) = fused.pair_losses_raw(
+                    [(priv_latent, hist_latent, fused.PAIR_ROW_L2, coef), (est, obs[:, self._priv_slice(True)], fused.PAIR_MSE, None)])
+            else:
+                priv_reg_loss, g_priv = fused.pair_loss_raw(priv_latent, hist_latent, fused.PAIR_ROW_L2)
+                est_loss, g_est = fused.pair_loss_raw(est, obs[:, self._priv_slice(True)], fused.PAIR_MSE)
+                g_priv = g_priv * coef
+            chain.backward(g_est, dlogits, dmean, dvalue, g_priv)
             if self.grad_sync is not None:
                 fused.flush_pending_grads()
             ac.std.grad = dstd.view_as(ac.std)
@@ -444,7 +450,16 @@ class PPO:
                     rows.insert(1, got[-1] if cflat is not None else rows[0])
                     return self._minibatch_forward_backward(rows, hl, self._coef_dev)
 
+                # (an attribute: its merged device tables are read by every REPLAY -- as a local of this capture block they were freed when it
+                # returned, and the replays faulted)
+                pair = self._step_pair = fused.ClipAdamPair(self._step_estimator, self._step_ac) if os.environ.get("QA_ADAM_PAIR", "1") != "0" else None
+
                 def apply(kl):
+                    # r6 (ABI 18): the two clipped Adam steps and the KL rule between them as three launches (same kernels, same sums: bit-identical)
+                    if pair is not None and kl.dtype == torch.float32 and pair.step(kl, self.desired_kl):
+                        return
+                    if pair is not None and os.environ.get("QA_DEBUG_GRAPH"):
+                        print("[tsc ppo] the paired optimiser launch was not taken:", pair.why_not)
                     self._step_estimator.step()
                     fused.kl_lr_rule(kl, self.desired_kl, self._lr_dev)
                     self._step_ac.step()
@@ -463,6 +478,8 @@ class PPO:
                     front()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                if pair is not None:
+                    pair.warm()                 # the merged optimiser tables, built OUTSIDE the capture (the gradients of the pass above exist)
                 ac.distribution_d = ac.distribution_c = None
                 gc.collect()
                 self.optimizer.zero_grad(set_to_none=True); self.estimator_optimizer.zero_grad(set_to_none=True)

@@ -302,7 +302,9 @@ def test_data_parallel_update_as_two_graphs_around_the_collective(monkeypatch):
             runner, _ = task_registry.make_alg_runner(env, name="go2_locomotion", args=args, train_cfg=tcfg, log_root=None)
             assert (runner.alg.grad_sync is not None) == dp
             runner.learn(3, init_at_random_ep_len=True)
-            assert len(runner.alg._ac_graph) == runner.alg.num_mini_batches      # one recorded step per minibatch slot
+            # data-parallel: one recorded step per minibatch slot (the collective sits between its two graphs); one GPU, chain steps (r6): the slots of an
+            # epoch in ONE recording
+            assert len(runner.alg._ac_graph) == (runner.alg.num_mini_batches if dp else 1)
             assert all((gb is not None) == dp for _, gb, _ in runner.alg._ac_graph)
             res.append({k: v.clone() for k, v in runner.alg.actor_critic.state_dict().items()})
             res.append(float(runner.alg.lr_ac))
@@ -397,6 +399,114 @@ def test_clip_adam_hip_matches_pytorch(wd, lr_tensor, max_norm):
         # with weight decay the moments inherit the (ill-conditioned, see _close_params) parameter differences x wd
         assert torch.allclose(sa[i]["exp_avg"], sb[i]["exp_avg"], rtol=2e-5, atol=1e-6 if wd else 1e-8)
         assert torch.allclose(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
+
+
+def _two_nets(dev, seed=11):
+    torch.manual_seed(seed)
+    est = torch.nn.Sequential(torch.nn.Linear(53, 128), torch.nn.ELU(), torch.nn.Linear(128, 9)).to(dev)
+    ac = torch.nn.Sequential(torch.nn.Linear(101, 512), torch.nn.ELU(), torch.nn.Linear(512, 2300), torch.nn.ELU(), torch.nn.Linear(2300, 12)).to(dev)
+    return est, ac
+
+
+def _grads_for(mods, k, scale):
+    g = torch.Generator().manual_seed(200 + k)
+    for m in mods:
+        for p in m.parameters():
+            p.grad = (torch.randn(p.shape, generator=g) * scale).to(p.device)
+
+
+@pytest.mark.gpu
+def test_clip_adam_pair_equals_the_two_steps_and_the_rule_one_after_the_other():
+    """qa_clip_adam_pair_step (ABI 18): estimator step, KL rule on the actor-critic's learning rate, actor-critic step in three launches -- the same
+    kernels with the same sums as the seven launches one after the other: bit-identical parameters, moments, step counts and learning rate"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    res = []
+    for paired in (False, True):
+        est, ac = _two_nets("cuda")
+        kw = dict(fused=True, capturable=True)
+        lr_ac = torch.tensor(1e-3, device="cuda")
+        o_est, o_ac = torch.optim.Adam(est.parameters(), lr=2e-4, **kw), torch.optim.Adam([{"params": ac.parameters(), "weight_decay": 1e-4}], lr=lr_ac, **kw)
+        s_est, s_ac = fused.ClipAdam(o_est, 1.0), fused.ClipAdam(o_ac, 0.7)
+        pair = fused.ClipAdamPair(s_est, s_ac)
+        took = []
+        for k in range(7):
+            _grads_for((est, ac), k, 3.0 if k % 2 else 0.01)          # clipped and unclipped steps
+            kl = torch.tensor([0.05, 0.001, 0.01, 0.0, 0.03, 0.002, 0.01][k], device="cuda")       # down, up, keep, keep (0), down, up, keep
+            if paired and pair.step(kl, 0.01):
+                took.append(k)
+                continue
+            s_est.step()
+            fused.kl_lr_rule(kl, 0.01, lr_ac)
+            s_ac.step()
+        assert took == (list(range(1, 7)) if paired else [])          # step 0 creates the optimisers' state through PyTorch
+        torch.cuda.synchronize()
+        st = [p.detach().clone() for m in (est, ac) for p in m.parameters()]
+        for o in (o_est, o_ac):
+            for p in o.param_groups[0]["params"]:
+                st += [o.state[p]["exp_avg"].clone(), o.state[p]["exp_avg_sq"].clone(), o.state[p]["step"].clone().float()]
+        res.append((st, float(lr_ac)))
+    (a, la), (b, lb) = res
+    assert la == lb and la != 1e-3
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
+def test_clip_adam_pair_twin_equals_its_halves():
+    """the C twin of the pair entry against the single-optimiser twin called twice with the rule between (host tables)"""
+    lib = load_oracle()
+    single = lib.qo_clip_adam_step_reduce
+    single.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64] + [C.c_void_p] * 4
+    pairf = lib.qo_clip_adam_pair_step
+    pairf.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+    from quadrupedal_agility_amd._capi import QaAdamPair
+    rng = np.random.default_rng(4)
+    sizes = [53 * 16, 16, 16 * 3, 101 * 40, 40, 5000]
+    nt = 3
+    def state():
+        r = np.random.default_rng(9)
+        return ([r.standard_normal(n).astype(np.float32) for n in sizes], [np.zeros(n, np.float32) for n in sizes], [np.zeros(n, np.float32) for n in sizes],
+                [np.zeros(1, np.float32) for _ in sizes])
+    ct, cs, cl = [], [], []
+    for t, n in enumerate(sizes):
+        for s0 in range(0, n, 2048):
+            ct.append(t); cs.append(s0); cl.append(min(2048, n - s0))
+    nc = sum(1 for t in ct if t < nt)
+    ct, cs, cl = (np.array(x, np.int32) for x in (ct, cs, cl))
+    wd = np.array([0, 0, 0, 1e-4, 1e-4, 1e-4], np.float32)
+    tab = lambda arrs: (C.c_void_p * len(arrs))(*[x.ctypes.data for x in arrs])
+    zero = lambda ty, n: (ty * n)()
+    out = []
+    for paired in (True, False):
+        p, m, v, st = state()
+        lr1, lr2 = np.array([2e-4], np.float32), np.array([1e-3], np.float32)
+        scratch = np.zeros(len(ct) + 9, np.float32)
+        for k in range(4):
+            r = np.random.default_rng(50 + k)
+            g = [(r.standard_normal(n) * (3.0 if k % 2 else 0.01)).astype(np.float32) for n in sizes]
+            kl = np.array([[0.05, 0.001, 0.01, 0.03][k]], np.float32)
+            if paired:
+                pr = QaAdamPair(nt, nc, lr2.ctypes.data, 0.7, kl.ctypes.data, 0.01, 1.5, 1e-5, 1e-2)
+                rc = pairf(tab(p), tab(g), tab(m), tab(v), tab(st), len(sizes), ct.ctypes.data, cs.ctypes.data, cl.ctypes.data, len(ct), wd.ctypes.data, lr1.ctypes.data,
+                           0.9, 0.999, 1e-8, 1.0, scratch.ctypes.data, scratch.size, None, None, None, C.byref(pr), None)
+                assert rc == 0
+            else:
+                n2 = len(sizes) - nt
+                rc = single(tab(p[:nt]), tab(g[:nt]), tab(m[:nt]), tab(v[:nt]), tab(st[:nt]), nt, ct.ctypes.data, cs.ctypes.data, cl.ctypes.data, nc, wd.ctypes.data,
+                            lr1.ctypes.data, 0.9, 0.999, 1e-8, 1.0, scratch.ctypes.data, scratch.size, zero(C.c_void_p, nt), zero(C.c_int64, nt), zero(C.c_int32, nt), None)
+                assert rc == 0
+                if kl[0] > 0.02: lr2[0] = max(np.float32(1e-5), lr2[0] / np.float32(1.5))
+                elif 0 < kl[0] < 0.005: lr2[0] = min(np.float32(1e-2), lr2[0] * np.float32(1.5))
+                ct2 = (ct[nc:] - nt).astype(np.int32); cs2 = cs[nc:].copy(); cl2 = cl[nc:].copy(); wd2 = wd[nt:].copy()
+                rc = single(tab(p[nt:]), tab(g[nt:]), tab(m[nt:]), tab(v[nt:]), tab(st[nt:]), n2, ct2.ctypes.data, cs2.ctypes.data, cl2.ctypes.data, len(ct2), wd2.ctypes.data,
+                            lr2.ctypes.data, 0.9, 0.999, 1e-8, 0.7, scratch.ctypes.data, scratch.size, zero(C.c_void_p, n2), zero(C.c_int64, n2), zero(C.c_int32, n2), None)
+                assert rc == 0
+        out.append((p, m, v, st, float(lr2[0])))
+    a, b = out
+    assert a[4] == b[4] != 1e-3
+    for xs, ys in zip(a[:4], b[:4]):
+        for x, y in zip(xs, ys):
+            assert np.array_equal(x, y)
+    assert a[3][0][0] == 4 and a[3][-1][0] == 4
 
 
 # ------------------------------------------------------------------ rollout bookkeeping kernels
@@ -673,6 +783,51 @@ def test_pair_loss_kernel_matches_torch_and_oracle(mode, rows, cols):
     assert qo.qo_pair_loss(an.ctypes.data, wn.ctypes.data + 12, rows, cols, cols + 7, mode, g.ctypes.data, out.ctypes.data, None, 0, None) == 0
     assert abs(out[0] * 0.7 - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
     np.testing.assert_allclose(g * 0.7, ref_a.grad.numpy(), rtol=2e-4, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 300, 3072, 24576])
+def test_pair_losses_launch_equals_the_losses_one_by_one(rows):
+    """qa_pair_losses (ABI 18): the regulariser's and the estimator's loss of a PPO step in one launch, the first gradient times a device scalar --
+    bit-identical to qa_pair_loss twice + the multiply, over several launches in a row (the arrival counter resets itself)"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    torch.manual_seed(rows)
+    coef = torch.tensor(0.037, device="cuda")
+    for rep in range(3):
+        p, h = torch.randn(rows, 29, device="cuda"), torch.randn(rows, 29, device="cuda")
+        if rows > 2:
+            h[2] = p[2]                                   # a zero row: the norm's subgradient
+        est, wide = torch.randn(rows, 4, device="cuda"), torch.randn(rows, 53, device="cuda")
+        (l1, g1), (l2, g2) = fused.pair_losses_raw([(p, h, fused.PAIR_ROW_L2, coef), (est, wide[:, 7:11], fused.PAIR_MSE, None)])
+        r1, q1 = fused.pair_loss_raw(p, h, fused.PAIR_ROW_L2)
+        r2, q2 = fused.pair_loss_raw(est, wide[:, 7:11], fused.PAIR_MSE)
+        assert torch.equal(l1, r1) and torch.equal(l2, r2) and torch.equal(g1, q1 * coef) and torch.equal(g2, q2), rep
+
+
+def test_pair_losses_twin_equals_the_single_twin():
+    from quadrupedal_agility_amd._capi import QaPairJob
+    lib = load_oracle()
+    rng = np.random.default_rng(2)
+    rows = 700
+    p, h = rng.standard_normal((rows, 29)).astype(np.float32), rng.standard_normal((rows, 29)).astype(np.float32)
+    est, wide = rng.standard_normal((rows, 4)).astype(np.float32), rng.standard_normal((rows, 53)).astype(np.float32)
+    coef = np.array([0.25], np.float32)
+    g1, g2, o1, o2 = np.zeros_like(p), np.zeros_like(est), np.zeros(1, np.float32), np.zeros(1, np.float32)
+    jobs = (QaPairJob * 2)()
+    jobs[0] = QaPairJob(p.ctypes.data, h.ctypes.data, rows, 29, 0, 29, coef.ctypes.data, g1.ctypes.data, o1.ctypes.data)
+    jobs[1] = QaPairJob(est.ctypes.data, wide.ctypes.data + 28, rows, 4, 1, 53, None, g2.ctypes.data, o2.ctypes.data)
+    lib.qo_pair_losses_scratch_bytes.restype = C.c_int64; lib.qo_pair_losses_scratch_bytes.argtypes = [C.c_void_p, C.c_int32]
+    lib.qo_pair_losses.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    nb = lib.qo_pair_losses_scratch_bytes(C.cast(jobs, C.c_void_p), 2)
+    assert nb == 4 * (2 * 3 + 1)
+    sc = np.zeros(nb, np.uint8)
+    assert lib.qo_pair_losses(C.cast(jobs, C.c_void_p), 2, sc.ctypes.data, nb, None) == 0
+    r1, r2, q1, q2 = np.zeros_like(p), np.zeros_like(est), np.zeros(1, np.float32), np.zeros(1, np.float32)
+    lib.qo_pair_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    assert lib.qo_pair_loss(p.ctypes.data, h.ctypes.data, rows, 29, 29, 0, r1.ctypes.data, q1.ctypes.data, None, 0, None) == 0
+    assert lib.qo_pair_loss(est.ctypes.data, wide.ctypes.data + 28, rows, 4, 53, 1, r2.ctypes.data, q2.ctypes.data, None, 0, None) == 0
+    assert o1[0] == q1[0] and o2[0] == q2[0] and np.array_equal(g1, r1 * coef[0]) and np.array_equal(g2, r2)
+    assert lib.qo_pair_losses(C.cast(jobs, C.c_void_p), 5, sc.ctypes.data, nb, None) != 0           # more than QA_PAIR_MAX_JOBS
 
 
 @pytest.mark.gpu

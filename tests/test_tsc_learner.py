@@ -124,7 +124,7 @@ def test_recorded_update_equals_eager_update(N, sync_phases):
     Adam state --, 1 records, 2-4 are replay sessions), with the host reading nothing between updates and with a device sync after
     every phase (torch's stale batch reductions only showed without syncs and only from the second replay session on:
     profiles/r2_hipgraph_stale_reductions.md).  Both runs issue the same kernels in the same order, so the parameters, the learning
-    rate and the loss read-out are held to 1e-6 (2e-4 at 8,192 envs: see the assertion) -- not to the 2e-3 of a check that would pass on a frozen bias."""
+    rate and the loss read-out are held to 1e-6 (8,192 envs: a schedule that follows the amplification, see the assertion) -- not to the 2e-3 of a check that would pass on a frozen bias."""
     mods, algs = _mine()
     res = {}
     for mode in ("eager", "recorded"):
@@ -159,12 +159,19 @@ def test_recorded_update_equals_eager_update(N, sync_phases):
         moved = 0
         for k, (pe, pr) in enumerate(zip(e["snaps"][it], r["snaps"][it])):
             d = (pe.double().cpu() - pr.double().cpu()).abs().max().item()
-            # 1024 envs: both runs launch the same kernels (r6: the chain step, eager and recorded alike) -> 1e-6.  8192 envs (49,152-row steps on the library's
-            # GEMMs, whose split of a product can differ between an eager call and a recorded one): the first difference is 7e-7 .. 1.1e-6 after update 1
-            # and grows with the Adam steps -- an element whose gradient is rounding-sized moves by up to the learning rate (1e-3) in EITHER direction.  It
-            # depends on the box, not on the run (four runs on one box gave the same digits): 1.1e-6, 6.6e-6 and 4.2e-5 after update 2 on three r6 boxes.
-            # Held to 2e-4 = a tenth of the learning rate and of what a frozen gradient shows (2e-3, the r2 stale-reduction finding this test guards)
-            assert d <= (1e-6 if N <= 1024 else 2e-4), f"update {it}, tensor {k}: recorded and eager differ by {d}"
+            # 1024 envs: both runs launch the same kernels (r6: the chain step, eager and recorded alike) -> 1e-6.
+            if N <= 1024:
+                assert d <= 1e-6, f"update {it}, tensor {k}: recorded and eager differ by {d}"
+                continue
+            # 8192 envs (49,152-row steps on the library's GEMMs, whose split of a product can differ between an eager call and a recorded one): the first
+            # difference is ~1e-6 after update 1 and grows ~10x per update -- Adam normalises every gradient to O(learning rate), the adaptive rate follows,
+            # and a tensor like the 18 log-stds (one sum over all rows each) differs in EVERY element.  How fast depends on the box, not on the run (four
+            # runs on one box gave the same digits); on five r6 boxes: <= 1.1e-6 after update 1, 1.1e-6 .. 4.2e-5 after update 2, <= 3.3e-4 after update 3.
+            # What the test guards -- a stale reduction under replay, the r2 finding -- freezes or corrupts a whole tensor: 8e-3 per recorded update (8 steps
+            # at 1e-3), i.e. 8e-3 x `it` by update `it`, NaN / inf at worst; the schedule 1e-5, 1e-4, 1e-3, 1e-2 stays under that, and the "every tensor
+            # moved" check below sees a frozen one directly
+            bound = (1e-6, 1e-5, 1e-4, 1e-3, 1e-2)[it]
+            assert d <= bound, f"update {it}, tensor {k}: recorded and eager differ by {d} (bound {bound})"
         if it:           # every tensor these steps train moved (the history encoder is the DAgger step's: 8 tensors stay) -- no frozen gradient
             moved = sum(int(not torch.equal(a, b)) for a, b in zip(r["snaps"][it][:-1], r["snaps"][it - 1][:-1]))
             assert moved == len(r["snaps"][it]) - 1 - 8, f"update {it}: {moved} tensors moved"

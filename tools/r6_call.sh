@@ -79,7 +79,7 @@ stack2)    # 512-element chunks in the stacked optimiser launch; the task-level 
     done
     ;;
 stack3)    # several steps per recorded graph (QA_STEP_UNROLL) + the task-level DAgger update as replays
-    timeout 2400 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py tests/test_grad_parts.py -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR|Error" $O/pytest.log | head -5
+    timeout 2400 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py tests/test_grad_parts.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR|Error" $O/pytest.log | head -5
     for i in 1 2; do timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2> $O/bench_cfg3.err < /dev/null | grep '"metric"' > $O/bench_cfg3_$i.json; done
     QA_STEP_UNROLL=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_one_step_per_replay.json
     for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
@@ -88,6 +88,62 @@ stack3)    # several steps per recorded graph (QA_STEP_UNROLL) + the task-level 
     timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2.json
     QA_BENCH_TRACE=1 timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2> $O/tsc_trace.err < /dev/null | grep '"metric"' > $O/bench_tsc1024_20_5.json; grep "per-iteration\|capture" $O/tsc_trace.err
     line $O/bench_*.json
+    ;;
+tests3)    # the suites the stack3 call did not reach
+    timeout 2400 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py tests/test_grad_parts.py tests/test_fused_learner.py tests/test_golden_learner.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    ;;
+pair)      # ABI 18 second half: two clipped Adam steps + the KL rule as three launches
+    timeout 2400 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py tests/test_grad_parts.py tests/test_fused_learner.py tests/test_golden_learner.py tests/test_distributed_gpu.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
+    QA_ADAM_PAIR=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_seven_launches.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024.json
+    QA_ADAM_PAIR=0 timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_seven_launches.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_step_sequence_512.txt 2>&1; cat $O/ppo_step_sequence_512.txt
+    ;;
+pair2)     # + qa_pair_losses; why the task-level step did not take the paired optimiser launch
+    timeout 2400 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py tests/test_grad_parts.py tests/test_fused_learner.py tests/test_golden_learner.py tests/test_distributed_gpu.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 1024 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_1024.json
+    QA_DEBUG_GRAPH=1 timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>$O/tsc.err < /dev/null > $O/tsc.log; grep '"metric"' $O/tsc.log > $O/bench_tsc1024.json; grep -v '"metric"' $O/tsc.log | sort | uniq -c | head -5
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_step_sequence_512.txt 2>&1; cat $O/ppo_step_sequence_512.txt
+    ;;
+pair3)     # qa_pair_losses through LDS
+    timeout 900 python -m pytest tests/test_fused_learner.py tests/test_train_chain.py tests/test_tsc_learner.py -m gpu -q -k "pair or training or recorded" > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
+    timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_step_sequence_512.txt 2>&1; grep -E "pair|launches" $O/ppo_step_sequence_512.txt
+    rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_hybrid_ppo_loss_kernel mid > $O/tsc_step_sequence_1024.txt 2>&1; cat $O/tsc_step_sequence_1024.txt
+    ;;
+pair4)     # the paired launch's tables built before the task-level capture
+    timeout 1200 python -m pytest tests/test_tsc_learner.py tests/test_train_chain.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_$i.json; done
+    timeout 400 python bench.py --tsc --num_envs 512 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc512.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_hybrid_ppo_loss_kernel mid > $O/tsc_step_sequence_1024.txt 2>&1; tail -1 $O/tsc_step_sequence_1024.txt
+    ;;
+dbg)       # the task-level recorded update aborts since pair.warm(): where
+    QA_DEBUG_GRAPH=1 timeout 300 python bench.py --tsc --num_envs 1024 --steps 2 --warmup 2 --no_cpu_baseline > $O/tsc.log 2>&1 < /dev/null; tail -25 $O/tsc.log | cut -c1-300
+    echo ---- without warm
+    timeout 300 python bench.py --tsc --num_envs 1024 --steps 2 --warmup 2 --no_cpu_baseline > $O/tsc2.log 2>&1 < /dev/null; tail -5 $O/tsc2.log | cut -c1-300
+    echo ---- serialised launches
+    AMD_SERIALIZE_KERNEL=3 HIP_LAUNCH_BLOCKING=1 QA_TSC_UPDATE_GRAPH=0 timeout 300 python bench.py --tsc --num_envs 1024 --steps 2 --warmup 2 --no_cpu_baseline > $O/tsc3.log 2>&1 < /dev/null; tail -5 $O/tsc3.log | cut -c1-300
     ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
@@ -120,7 +176,7 @@ tsc)       # the task-level learner's step as chain launches: parity, its suites
     line $O/bench_*.json
     ;;
 quick)     # a plan change in the batched products: parity + the lines + one step each
-    timeout 900 python -m pytest tests/test_train_chain.py tests/test_grad_parts.py tests/test_golden_learner.py -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
+    timeout 900 python -m pytest tests/test_train_chain.py tests/test_grad_parts.py tests/test_golden_learner.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
     for i in 1 2; do
       timeout 300 python bench.py --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_512_chain_$i.json
       timeout 400 python bench.py --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_chain_$i.json
