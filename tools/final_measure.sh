@@ -32,6 +32,12 @@ timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --terrain trimesh --n
 for NE in 2048 1024 512; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs $NE --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_${NE}_per_gpu.json; done
 QA_TRAIN_CHAIN=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu_autograd_steps.json
 QA_TRAIN_CHAIN=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_autograd_steps.json
+# (r6) the same lines with ABI 17's chain launches but without ABI 18's tails (stacked / paired optimiser launches, one launch for the pair losses, several steps per replay)
+A17="QA_DISC_STACKED_ADAM=0 QA_ADAM_PAIR=0 QA_PAIR_LOSSES=0 QA_STEP_UNROLL=0"
+env $A17 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu_abi17_steps.json
+env $A17 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_abi17_steps.json
+env $A17 timeout 500 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024_abi17_steps.json
+QA_TRAIN_CHAIN=0 timeout 500 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024_autograd_steps.json
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_512_per_gpu.json
 # (r4) the data-parallel code path with TWO ranks sharing this one GPU (gloo through host memory): a bound on the path's own cost, not a scaling measurement
 QA_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --scaling strong --no_cpu_baseline 2> $O/bench_shared_strong.err < /dev/null | grep '"metric"' > $O/bench_cfg2_two_ranks_one_gpu_strong.json
@@ -52,8 +58,16 @@ f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $
 [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid > $O/rollout_step_sequence.txt 2>&1      # (r4) every launch of ONE env step of the recorded rollout
 grep '"metric"' /tmp/prof.log > $O/bench_under_rocprof.json
 rm -rf /tmp/prof
+# (r6) one chain step each: the PPO step at the 512-env share, the discriminator step of config 3, the task-level step at 1024 envs
+timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --num_envs 512 --steps 4 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_ppo_loss_kernel mid > $O/ppo_chain_step_sequence_512.txt 2>&1
+rm -rf /tmp/prof
+timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 3 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_disc_loss_kernel mid > $O/disc_chain_step_sequence_4096.txt 2>&1
+rm -rf /tmp/prof
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 6 --warmup 3 < /dev/null > /tmp/prof2.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_tsc_kernel_stats.csv
 f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid > $O/tsc_env_step_sequence.txt 2>&1
+[ -n "$f" ] && python $R/tools/step_sequence.py "$f" qa_hybrid_ppo_loss_kernel mid > $O/tsc_chain_step_sequence_1024.txt 2>&1
 rm -rf /tmp/prof
 ls -la $O

@@ -145,6 +145,14 @@ dbg)       # the task-level recorded update aborts since pair.warm(): where
     echo ---- serialised launches
     AMD_SERIALIZE_KERNEL=3 HIP_LAUNCH_BLOCKING=1 QA_TSC_UPDATE_GRAPH=0 timeout 300 python bench.py --tsc --num_envs 1024 --steps 2 --warmup 2 --no_cpu_baseline > $O/tsc3.log 2>&1 < /dev/null; tail -5 $O/tsc3.log | cut -c1-300
     ;;
+fin)       # sums of squares + finalize in one launch
+    timeout 2400 python -m pytest tests/test_fused_learner.py tests/test_train_chain.py tests/test_tsc_learner.py tests/test_gpu_train.py tests/test_grad_parts.py tests/test_golden_learner.py tests/test_learner_lockstep.py tests/test_distributed_gpu.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3.json
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2.json
+    timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024.json
+    line $O/bench_*.json
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
