@@ -1000,19 +1000,9 @@ __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArg
     const int nd = a.nd, nc = a.nc, w = 1 + nc;
     if (e < a.N) {
     const float HALF_LOG_2PI = 0.91893853320467274178f, EPS = 1.1920928955078125e-07f;
-    // r6: every input of the env in registers BEFORE the first store.  The rows are written through pointers the compiler cannot tell apart from the inputs, so a
-    // load behind a store waited for it: 18 means x (load -> arithmetic -> four stores) in series was most of this launch's 32 us at 1024 envs
-    const float *__restrict__ lgp = a.logits + (int64_t)e * nd;
-    const float *__restrict__ mp = a.mean + (int64_t)e * nc;
-    float lg[16], mreg[32], sreg[32];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) lg[i] = i < nd ? lgp[i] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { mreg[j] = j < nc ? mp[j] : 0.f; sreg[j] = j < nc ? a.std[j] : 1.f; }
-    const float val = a.value[e];
+    const float *lg = a.logits + (int64_t)e * nd;
     float mx = lg[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) if (i < nd) mx = fmaxf(mx, lg[i]);
+    for (int i = 1; i < nd; ++i) mx = fmaxf(mx, lg[i]);
     float p[16], sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { p[i] = i < nd ? expf(lg[i] - mx) : 0.f; sum += p[i]; }
@@ -1034,35 +1024,25 @@ __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArg
     float *act = a.actions + (int64_t)e * w, *sa = a.st_actions + (int64_t)e * w;
     act[0] = (float)choice; sa[0] = (float)choice;
     float logp_c = 0.f;
-    float vreg[32];
+    for (int b = 0; 4 * b < nc; ++b) {          // Box-Muller on the 4 uniforms of a Philox block: 4 normals (as qa_rollout_act)
+        const F4 q = rng4(a.seed, (uint32_t)(e + a.env0), step, RS_ACT_NOISE, b);
+        const float r0 = sqrtf(-2.0f * logf(fmaxf(q.v[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(q.v[2], 1e-7f)));
+        float s0, c0, s1, c1;
+        sincosf(6.28318530717958647692f * q.v[1], &s0, &c0);
+        sincosf(6.28318530717958647692f * q.v[3], &s1, &c1);
+        const float eps4[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {               // Box-Muller on the 4 uniforms of a Philox block: 4 normals (as qa_rollout_act)
-        if (4 * b < nc) {
-            const F4 q = rng4(a.seed, (uint32_t)(e + a.env0), step, RS_ACT_NOISE, b);
-            const float r0 = sqrtf(-2.0f * logf(fmaxf(q.v[0], 1e-7f))), r1 = sqrtf(-2.0f * logf(fmaxf(q.v[2], 1e-7f)));
-            float s0, c0, s1, c1;
-            sincosf(6.28318530717958647692f * q.v[1], &s0, &c0);
-            sincosf(6.28318530717958647692f * q.v[3], &s1, &c1);
-            const float eps4[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = 4 * b + k;
-                if (j < nc) {
-                    const float m = mreg[j], sd = sreg[j], v = m + sd * eps4[k], d = v - m;
-                    logp_c += -(d * d) / (2.0f * sd * sd) - logf(sd) - HALF_LOG_2PI;
-                    vreg[j] = v;
-                }
+        for (int k = 0; k < 4; ++k) {
+            const int j = 4 * b + k;
+            if (j < nc) {
+                const float m = a.mean[(int64_t)e * nc + j], s = a.std[j], v = m + s * eps4[k], d = v - m;
+                logp_c += -(d * d) / (2.0f * s * s) - logf(s) - HALF_LOG_2PI;
+                act[1 + j] = v; sa[1 + j] = v;
+                a.st_mu[(int64_t)e * nc + j] = m; a.st_sigma[(int64_t)e * nc + j] = s;
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        if (j < nc) {
-            act[1 + j] = vreg[j]; sa[1 + j] = vreg[j];
-            a.st_mu[(int64_t)e * nc + j] = mreg[j]; a.st_sigma[(int64_t)e * nc + j] = sreg[j];
-        }
-    }
-    a.st_logp_d[e] = logp_d; a.st_logp_c[e] = logp_c; a.st_values[e] = val;
+    a.st_logp_d[e] = logp_d; a.st_logp_c[e] = logp_c; a.st_values[e] = a.value[e];
     }
     if (a.hist) {
         // roll by one slot (oldest first), newest slot = this step's action.  Out of place when the caller gives a second buffer (hist_in != hist):
