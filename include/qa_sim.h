@@ -634,6 +634,11 @@ typedef struct qa_adam_stack_tensor {
 } qa_adam_stack_tensor;
 int qa_adam_stack_step(const qa_adam_stack_tensor *tensors_host, int32_t count, float beta1, float beta2, float eps, uint32_t *ticket, void *stream);
 
+/* ABI 18: acc[i] += *src_host[i] for i < count <= QA_ACC_MAX (src_host: a HOST array of device pointers to single floats): the six values a PPO
+ * minibatch step logs (bbc/rsl_rl/algorithms/gail.py:275-283) come out of three kernels; this adds them onto the update's accumulator in one launch. */
+#define QA_ACC_MAX 16
+int qa_accumulate_scalars(float *acc, const float *const *src_host, int32_t count, void *stream);
+
 /* Two small losses of the PPO step with their gradient in the same pass (a (rows, cols) contiguous, b (rows, cols) with row
  * stride b_stride, fp32 device pointers; grad_a (rows, cols); out[1]):
  *   QA_PAIR_ROW_L2: out = mean_r ||a_r - b_r||_2, grad_a = (a - b) / (||a_r - b_r|| rows), 0 where the norm is 0 -- the

@@ -2343,6 +2343,13 @@ int qo_pair_loss(const float *a, const float *b, int64_t rows, int32_t cols, int
     return QA_OK;
 }
 
+int qo_accumulate_scalars(float *acc, const float *const *src, int32_t count, void *stream) {
+    (void)stream;
+    if (!acc || !src || count <= 0 || count > QA_ACC_MAX) return QA_E_ARG;
+    for (int i = 0; i < count; ++i) { if (!src[i]) return QA_E_ARG; acc[i] += src[i][0]; }
+    return QA_OK;
+}
+
 /* ABI 18: several pair losses in one call, the gradient optionally times a device scalar (the regulariser's coefficient, gail.py:353-357) */
 int64_t qo_pair_losses_scratch_bytes(const qa_pair_job *jobs, int32_t count) {
     if (!jobs || count <= 0 || count > QA_PAIR_MAX_JOBS) return -1;

@@ -813,6 +813,14 @@ __global__ void __launch_bounds__(256) qa_gather_rows_kernel(GatherArgs a) {
     }
 }
 
+/* acc[i] += *src[i], i < n <= 16: a step's logged scalars (they live in different kernels' outputs) onto the update's accumulator in one launch -- was a
+ * torch.stack (a copy kernel) + an add per minibatch step (gail.py:275-283 sums the same six values on the host) */
+struct AccArgs { float *acc; const float *src[QA_ACC_MAX]; int n; };
+__global__ void qa_accumulate_scalars_kernel(AccArgs a) {
+    const int i = threadIdx.x;
+    if (i < a.n) a.acc[i] += a.src[i][0];
+}
+
 /* KL-adaptive learning rate (gail.py:367-379) on device scalars: one thread */
 __global__ void qa_kl_lr_rule_kernel(const float *kl, float desired_kl, float factor, float lr_min, float lr_max, float *lr) {
     const float k = kl[0], cur = lr[0];
@@ -1753,6 +1761,17 @@ int qa_pair_losses(const qa_pair_job *jobs, int32_t count, void *scratch, int64_
     hipLaunchKernelGGL(qa_pair_losses_kernel, dim3(blocks), dim3(PAIR_BLOCK), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_pair_losses: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_accumulate_scalars(float *acc, const float *const *src_host, int32_t count, void *stream) {
+    if (!acc || !src_host || count <= 0 || count > QA_ACC_MAX) { snprintf(g_lerr, sizeof(g_lerr), "qa_accumulate_scalars: 1..%d scalars expected", QA_ACC_MAX); return QA_E_ARG; }
+    AccArgs a{};
+    a.acc = acc; a.n = count;
+    for (int i = 0; i < count; ++i) { if (!src_host[i]) { snprintf(g_lerr, sizeof(g_lerr), "qa_accumulate_scalars: null source %d", i); return QA_E_ARG; } a.src[i] = src_host[i]; }
+    hipLaunchKernelGGL(qa_accumulate_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_accumulate_scalars: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

@@ -904,6 +904,19 @@ def pair_losses_raw(jobs):
     return outs
 
 
+def accumulate_scalars(acc, scalars):
+    """acc[i] += scalars[i] (0-d / 1-element fp32 ROCm tensors, possibly views of different kernels' outputs) in ONE launch (qa_accumulate_scalars) instead of
+    torch.stack + add_; falls back to those for anything else"""
+    n = len(scalars)
+    if not (ENABLED and acc.is_cuda and acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() >= n and n <= 16
+            and all(torch.is_tensor(x) and x.dtype == torch.float32 and x.numel() == 1 and x.device == acc.device for x in scalars)):
+        acc[:n].add_(torch.stack([x.reshape(()) for x in scalars]))
+        return
+    lib = _capi.load_library()
+    _check(lib.qa_accumulate_scalars(_ptr(acc), (C.c_void_p * n)(*[x.data_ptr() for x in scalars]), n, C.c_void_p(torch.cuda.current_stream(acc.device).cuda_stream)),
+           "qa_accumulate_scalars")
+
+
 def gather_rows(idx, srcs, dsts=None, block_dev=None):
     """[src[idx] for src in srcs] for row-major fp32 tensors (N, w) in ONE launch; idx (rows) int64 on the device.  `dsts`
     (dense (rows, w) tensors) are allocated when not given.  With block_dev (0-d int64 device tensor) idx is a (blocks, rows)

@@ -381,7 +381,7 @@ class SSInfoGAIL:
                             for i in range(nmb):
                                 stats, kl = front(i)
                                 self._ac_apply(kl)
-                                self._acc_ac.add_(torch.stack(stats))
+                                fused_mod.accumulate_scalars(self._acc_ac, stats)       # (one launch; was torch.stack + add_)
                                 for o in (self.optim_ac, self.optim_estimator):
                                     o.zero_grad(set_to_none=True)
                         graphs.append((g, None, None))
@@ -391,7 +391,7 @@ class SSInfoGAIL:
                             with _no_gc(), torch.cuda.graph(g, pool=pool):
                                 stats, kl = front(i)
                                 self._ac_apply(kl)
-                                self._acc_ac.add_(torch.stack(stats))
+                                fused_mod.accumulate_scalars(self._acc_ac, stats)
                             graphs.append((g, None, None))
                         else:
                             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -267,7 +267,7 @@ class PPO:
                 if self.desired_kl is not None and self.schedule == "adaptive":
                     self._adapt_from_kl(kl)
                 self._step_ac.step()
-                sums += stats
+                self._add_stats(sums, stats)
                 continue
             ac.act(obs, hist_encoding=False)
             logp_d = ac.get_actions_log_prob_d(actions[:, 0])
@@ -376,7 +376,7 @@ class PPO:
             if self.grad_sync is not None:
                 fused.flush_pending_grads()
             ac.std.grad = dstd.view_as(ac.std)
-            return out[4], torch.stack([out[2], out[1], est_loss, priv_reg_loss])
+            return out[4], (out[2], out[1], est_loss, priv_reg_loss)       # (a tuple: `_add_stats` puts them on the accumulator in one launch)
         if self.use_fused_loss and obs.is_cuda and fused.ENABLED and isinstance(ac.std, nn.Parameter):
             from quadrupedal_agility_amd.rsl_rl.modules.actor_critic import _head
             emb = ac.actor(obs, False)
@@ -398,6 +398,14 @@ class PPO:
         est_loss.backward()
         loss.backward()
         return kl, torch.stack(stats)
+
+    @staticmethod
+    def _add_stats(acc, stats):
+        """the step's four logged values onto the accumulator: a stacked tensor (autograd path), or four device scalars (chain path: one launch)"""
+        if torch.is_tensor(stats):
+            acc.add_(stats)
+        else:
+            fused.accumulate_scalars(acc, list(stats))
 
     def _train_chain(self, obs, cobs):
         """train_chain.TscTrainChain for this minibatch size, or None (many rows, the critic on another row than the actor, head widths the fused
@@ -488,13 +496,14 @@ class PPO:
                     with _no_gc(), torch.cuda.graph(g):
                         kl, stats = front()
                         apply(kl.reshape(()))
-                        self._acc.add_(stats)
+                        self._add_stats(self._acc, stats)
                     self._graph = (g, None)
                 else:
                     ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                     pool = torch.cuda.graph_pool_handle()
                     with _no_gc(), torch.cuda.graph(ga, pool=pool):
-                        kl, self._stats_tmp = front()
+                        kl, st_ = front()
+                        self._stats_tmp = st_ if torch.is_tensor(st_) else torch.stack(list(st_))
                         grads = [p.grad for p in params if p.grad is not None]
                         packed = grads + [kl.detach().reshape(1)]
                         self._bucket = torch._utils._flatten_dense_tensors(packed)          # lives in the graphs' pool

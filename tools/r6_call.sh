@@ -145,7 +145,7 @@ dbg)       # the task-level recorded update aborts since pair.warm(): where
     echo ---- serialised launches
     AMD_SERIALIZE_KERNEL=3 HIP_LAUNCH_BLOCKING=1 QA_TSC_UPDATE_GRAPH=0 timeout 300 python bench.py --tsc --num_envs 1024 --steps 2 --warmup 2 --no_cpu_baseline > $O/tsc3.log 2>&1 < /dev/null; tail -5 $O/tsc3.log | cut -c1-300
     ;;
-fin)       # sums of squares + finalize in one launch
+fin)       # a learner change: its suites and the lines it moves
     timeout 2400 python -m pytest tests/test_fused_learner.py tests/test_train_chain.py tests/test_tsc_learner.py tests/test_gpu_train.py tests/test_grad_parts.py tests/test_golden_learner.py tests/test_learner_lockstep.py tests/test_distributed_gpu.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
     for i in 1 2; do timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_$i.json; done
     timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3.json
@@ -161,6 +161,10 @@ prio)      # the discriminator chain's stream at high priority beside the PPO st
     cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
     timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
     f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid | grep -E "hybrid|launches"
+    ;;
+fastr6)    # config 3, 1024 envs x 1,000 iterations on the round's final learner (chain steps, stacked / paired optimiser launches): the SAME 32 seeds r5's final code ran
+    timeout 2500 python tools/d2_many.py --out $O --arms fast:31-62 --workers 4 --job_timeout 900 --budget_s 2000 > $O/d2_many.log 2>&1
+    tail -6 $O/d2_many.log
     ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
