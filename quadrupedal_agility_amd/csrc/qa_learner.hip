@@ -1302,25 +1302,31 @@ __global__ void __launch_bounds__(256) qa_disc_step_tail_kernel(TailArgs a) {
     __syncthreads();
     if (!last) return;
     __threadfence();
+    // r6: the last workgroup's tail spread over its threads -- one thread doing 64 atomic loads, 11 read-modify-writes behind stores it cannot tell apart from them
+    // and the prior's 5 was ~20 dependent round trips; the sums keep their order (thread 0 adds the staged partials as before)
+    __shared__ float s_part[TAIL_MAX * TAIL_WG];
+    __shared__ float s_o[11];
+    if (tid < a.nt * TAIL_WG) s_part[tid] = __hip_atomic_load(a.partial + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (tid == 0) {
         double tot[TAIL_MAX];
         for (int t = 0; t < a.nt; ++t) {
             double s = 0.0;
-            for (int k = 0; k < TAIL_WG; ++k) s += (double)__hip_atomic_load(a.partial + t * TAIL_WG + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < TAIL_WG; ++k) s += (double)s_part[t * TAIL_WG + k];
             tot[t] = s;
         }
         double wd = 0.0;
         for (int t = 1; t < a.nt; ++t) wd += tot[t];
-        float o[11];
-        o[0] = a.hs[1]; o[1] = a.hs[2]; o[2] = a.hs[3]; o[3] = a.hs[4];
-        o[4] = (float)(tot[0] * (double)a.inv_rows); o[5] = (float)tot[a.nt - 1]; o[6] = (float)wd;
-        o[7] = a.hs[5]; o[8] = a.hs[6]; o[9] = a.hs[7]; o[10] = a.hs[8];
-        for (int k = 0; k < 11; ++k) { a.out[k] = o[k]; if (a.acc) a.acc[k] += o[k]; }
+        s_o[4] = (float)(tot[0] * (double)a.inv_rows); s_o[5] = (float)tot[a.nt - 1]; s_o[6] = (float)wd;
         if (a.step) a.step[0] += 1;
-        // the class prior's EMA towards this step's mean class probabilities of the unlabelled batch (gail.py:463-464)
-        if (a.prior) for (int k = 0; k < a.prior_dim; ++k) a.prior[k] = fmaf(a.prior_c, a.hs[9 + k], a.prior[k] * (1.0f - a.prior_c));
         *a.ticket = 0u;                 // ready for the next launch (replays of a recorded step included)
     }
+    if (tid >= 32 && tid < 32 + 4) s_o[tid - 32] = a.hs[1 + tid - 32];                 // o[0..3] = hs[1..4]
+    if (tid >= 40 && tid < 40 + 4) s_o[7 + tid - 40] = a.hs[5 + tid - 40];             // o[7..10] = hs[5..8]
+    // the class prior's EMA towards this step's mean class probabilities of the unlabelled batch (gail.py:463-464)
+    if (a.prior && tid >= 64 && tid < 64 + a.prior_dim) { const int k = tid - 64; a.prior[k] = fmaf(a.prior_c, a.hs[9 + k], a.prior[k] * (1.0f - a.prior_c)); }
+    __syncthreads();
+    if (tid < 11) { const float o = s_o[tid]; a.out[tid] = o; if (a.acc) a.acc[tid] += o; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1687,14 +1693,18 @@ __global__ void __launch_bounds__(256) qa_adam_stack_kernel(StackArgs a) {
         p[i] = pi;
     }
     __syncthreads();
+    __shared__ int s_last;
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(a.ticket, 1u) == (unsigned)(a.blocks - 1)) {          // every workgroup has read the old step counts by now
-            for (int k = 0; k < a.n; ++k)
-                for (int s = 0; s < a.t[k].num_states; ++s) a.t[k].state[s].step[0] += 1.0f;
-            *a.ticket = 0u;
-        }
+        s_last = atomicAdd(a.ticket, 1u) == (unsigned)(a.blocks - 1);          // every workgroup has read the old step counts by now
     }
+    __syncthreads();
+    if (!s_last) return;
+    // one thread per (tensor, state): the counters are up to 48 separate device words, and one thread bumping them one after the other was 18 dependent
+    // round trips -- most of this launch's 38 us
+    const int k = threadIdx.x / QA_ADAM_STACK_MAX_STATES, st = threadIdx.x % QA_ADAM_STACK_MAX_STATES;
+    if (k < a.n && st < a.t[k].num_states) a.t[k].state[st].step[0] += 1.0f;
+    if (threadIdx.x == 0) *a.ticket = 0u;
 }
 int qa_adam_stack_step(const qa_adam_stack_tensor *tensors_host, int32_t count, float beta1, float beta2, float eps, uint32_t *ticket, void *stream) {
     if (!tensors_host || count <= 0 || count > QA_ADAM_STACK_MAX_TENSORS || !ticket) { snprintf(g_lerr, sizeof(g_lerr), "qa_adam_stack_step: 1..%d tensors and a ticket word expected", QA_ADAM_STACK_MAX_TENSORS); return QA_E_ARG; }

@@ -850,7 +850,7 @@ class SSInfoGAIL:
             gp_proxies = None
             dchain.pack()
             d_all, eps_all, logits_all = dchain.forward(x_all)
-            g = dchain.penalty_gradient()                       # (on a side stream, with its three weight-gradient products: `wait_penalty`)
+            g = dchain.penalty_gradient()                       # d logit / d x on the unlabelled rows: the penalty's argument
             c_all = torch.softmax(logits_all, -1)               # (the objective kernel clamps)
             if self.disc_normalizer is not None and self.grad_sync is None:
                 # the input normaliser folds in this step's batches (gail.py:524-528, at the end of the step there): nothing else in the step reads or

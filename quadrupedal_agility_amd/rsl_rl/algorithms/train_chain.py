@@ -387,7 +387,8 @@ class DiscTrainChain:
         b.finish()
         self.fwd, self.pen, self.bwd = f, p, b
         self._packer = _Packer([f, p, b])
-        # opt-in side streams (QA_TRAIN_CHAIN_SIDES=1; measured slower): 1 / 2 = the second and third optimiser, 3 = what `beside()` is handed
+        # opt-in side streams (QA_TRAIN_CHAIN_SIDES=1; measured slower): 3 = what `beside()` is handed.  (The three optimisers were once forked onto 1 / 2 as
+        # well -- they share the trunk's parameters and must run one after the other: removed in r6.)
         self.sides = _Sides(dev, 4) if (SIDE_STREAMS and prefix == "qa_") else None
         # weight-gradient products: (rows, g tensor, g col, n, x tensor, x col, k)
         self._wg = {}
@@ -428,18 +429,6 @@ class DiscTrainChain:
     def wait_penalty(self):
         """before the first reader of `penalty_gradient()`'s result on the calling stream"""
         return None          # (the penalty path runs on the calling stream: nothing to wait for)
-
-    def parallel(self, fns):
-        """independent pieces of work side by side: the first on the calling stream, the others on side streams 1, 2, ...; joined before returning"""
-        if not self.sides or len(fns) > 3:
-            for fn in fns:
-                fn()
-            return
-        for i, fn in enumerate(fns[1:]):
-            with self.sides.fork(1 + i):
-                fn()
-        fns[0]()
-        self.sides.join()
 
     def beside(self, fn):
         """run `fn` on a side stream from here; `backward()` joins it"""

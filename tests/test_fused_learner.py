@@ -831,6 +831,36 @@ def test_pair_losses_twin_equals_the_single_twin():
 
 
 @pytest.mark.gpu
+def test_accumulate_scalars_is_stack_and_add():
+    """qa_accumulate_scalars (ABI 18): scalars that live in different tensors onto an accumulator in one launch; anything else falls back to torch"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    torch.manual_seed(0)
+    out = torch.randn(8, device="cuda")
+    a, b = torch.randn((), device="cuda"), torch.randn(1, device="cuda")
+    parts = [out[1], out[2], out[3], out[4], a, b]
+    acc, ref = torch.randn(6, device="cuda"), None
+    ref = acc.clone()
+    for _ in range(3):
+        fused.accumulate_scalars(acc, parts)
+        ref += torch.stack([x.reshape(()) for x in parts])
+    assert torch.equal(acc, ref)
+    acc64 = torch.zeros(6, dtype=torch.float64, device="cuda")         # not fp32: the torch expression
+    fused.accumulate_scalars(acc64, [x.double() for x in parts])
+    assert torch.allclose(acc64, torch.stack([x.reshape(()) for x in parts]).double())
+
+
+def test_accumulate_scalars_twin():
+    lib = load_oracle()
+    lib.qo_accumulate_scalars.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    acc = np.arange(4, dtype=np.float32)
+    xs = [np.array([v], np.float32) for v in (0.5, -1.0, 2.0)]
+    ptrs = (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+    assert lib.qo_accumulate_scalars(acc.ctypes.data, ptrs, 3, None) == 0
+    assert np.array_equal(acc, np.array([0.5, 0.0, 4.0, 3.0], np.float32))
+    assert lib.qo_accumulate_scalars(acc.ctypes.data, ptrs, 17, None) != 0
+
+
+@pytest.mark.gpu
 def test_gather_rows_kernel_is_exact():
     from quadrupedal_agility_amd.rsl_rl.algorithms.fused import gather_rows
     torch.manual_seed(3)
