@@ -431,14 +431,16 @@ constexpr int NORM_MAX_BATCHES = 4;
 struct NormArgs { const float *batch[NORM_MAX_BATCHES]; int64_t n[NORM_MAX_BATCHES]; int k, d; double *mean, *var, *count; };
 
 __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) {
-    __shared__ double s_red[1024];
-    __shared__ double s_col[16];
+    // r6: the batches' passes side by side -- pass 1 of every batch, ONE barrier, the column means; pass 2 of every batch, one barrier, the merges in batch
+    // order.  (Before: per batch two passes and four barriers in sequence, 22 us for three 1,228 x 98 batches, at the end of each of the discriminator's 80
+    // steps.)  Every sum keeps its lanes, its order and its precision; the Chan merges run in the batches' order: bit-identical.
+    __shared__ double s_red[NORM_MAX_BATCHES][1024];
+    __shared__ double s_col[NORM_MAX_BATCHES][16], s_m2[NORM_MAX_BATCHES][16];
     const int CW = 16, RL = 1024 / CW;
     const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
     const int c = blockIdx.x * CW + cl;
     const bool col = c < a.d;
-    double run_mean = (col && rl == 0) ? a.mean[c] : 0.0, run_var = (col && rl == 0) ? a.var[c] : 0.0;
-    double count = *a.count;
+    const int64_t st = (int64_t)RL * a.d;
     for (int b = 0; b < a.k; ++b) {
         const float *x = a.batch[b];
         const int64_t n = a.n[b];
@@ -446,7 +448,6 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
         if (col) {       // 8 loads in flight per lane, 4 independent accumulators (a lone dependent chain is latency-bound)
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             int64_t r = rl;
-            const int64_t st = (int64_t)RL * a.d;
             for (; r + 7 * RL < n; r += 8 * RL) {
                 const float *q = x + r * a.d + c;
                 const float v0 = q[0], v1 = q[st], v2 = q[2 * st], v3 = q[3 * st], v4 = q[4 * st], v5 = q[5 * st], v6 = q[6 * st], v7 = q[7 * st];
@@ -455,21 +456,24 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
             for (; r < n; r += RL) a0 += (double)x[r * a.d + c];
             acc = (a0 + a1) + (a2 + a3);
         }
-        s_red[threadIdx.x] = acc;
-        __syncthreads();
-        if (rl == 0) {
-            double t = 0.0;
+        s_red[b][threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (rl < a.k) {          // row lane b adds batch b's 64 lane sums, in lane order
+        double t = 0.0;
 #pragma unroll
-            for (int q = 0; q < RL; ++q) t += s_red[q * CW + cl];
-            s_col[cl] = t / (double)n;
-        }
-        __syncthreads();
-        const double bm = s_col[cl];
-        acc = 0.0;
+        for (int q = 0; q < RL; ++q) t += s_red[rl][q * CW + cl];
+        s_col[rl][cl] = t / (double)a.n[rl];
+    }
+    __syncthreads();
+    for (int b = 0; b < a.k; ++b) {
+        const float *x = a.batch[b];
+        const int64_t n = a.n[b];
+        const double bm = s_col[b][cl];
+        double acc = 0.0;
         if (col) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             int64_t r = rl;
-            const int64_t st = (int64_t)RL * a.d;
             for (; r + 7 * RL < n; r += 8 * RL) {
                 const float *q = x + r * a.d + c;
                 const double d0 = (double)q[0] - bm, d1 = (double)q[st] - bm, d2 = (double)q[2 * st] - bm, d3 = (double)q[3 * st] - bm;
@@ -479,25 +483,29 @@ __global__ void __launch_bounds__(1024) qa_normalizer_update_kernel(NormArgs a) 
             for (; r < n; r += RL) { const double dlt = (double)x[r * a.d + c] - bm; a0 += dlt * dlt; }
             acc = (a0 + a1) + (a2 + a3);
         }
-        __syncthreads();
-        s_red[threadIdx.x] = acc;
-        __syncthreads();
-        if (rl == 0 && col) {
-            double m2b = 0.0;
+        s_red[b][threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (rl < a.k) {
+        double m2b = 0.0;
 #pragma unroll
-            for (int q = 0; q < RL; ++q) m2b += s_red[q * CW + cl];
-            const double bv = m2b / (double)n, nb = (double)n;
+        for (int q = 0; q < RL; ++q) m2b += s_red[rl][q * CW + cl];
+        s_m2[rl][cl] = m2b;
+    }
+    __syncthreads();
+    if (rl == 0 && col) {
+        double run_mean = a.mean[c], run_var = a.var[c], count = *a.count;
+        for (int b = 0; b < a.k; ++b) {
+            const double nb = (double)a.n[b], bm = s_col[b][cl], bv = s_m2[b][cl] / nb;
             const double delta = bm - run_mean, total = count + nb;
             const double m2 = run_var * count + bv * nb + delta * delta * count * nb / total;
             run_mean += delta * nb / total;
             run_var = m2 / total;
+            count += nb;
         }
-        count += (double)n;
-        __syncthreads();
+        a.mean[c] = run_mean; a.var[c] = run_var;
     }
-    if (rl == 0 && col) { a.mean[c] = run_mean; a.var[c] = run_var; }
 }
-
 __global__ void qa_normalizer_count_kernel(NormArgs a) {
     double count = *a.count;
     for (int b = 0; b < a.k; ++b) count += (double)a.n[b];
@@ -1651,7 +1659,8 @@ int qa_grad_reduce(float *const *dst_host, const float *const *src_host, const i
 // gradient penalty's product times alpha2, the weight regulariser reg * W) and then the tensor's Adam states applied in order: the trunk's parameters sit in
 // all three of the reference's optimisers (gail.py:107-132, 518-520).  Replaces per step: qa_grad_reduce, two multi-tensor adds, one add, three
 // qa_adam_update<true> launches.  Element i of a chunk belongs to thread i % 256 in both adam_reduce_chunk branches and in the update loop.
-constexpr int STACK_CHUNK = 512;      // two elements per thread: ~450 workgroups for the discriminator's 190 k parameters (2048-element chunks: 47 us; these: see DESIGN 4.21)
+constexpr int STACK_CHUNK = 512;      // two elements per thread: ~450 workgroups for the discriminator's 190 k parameters (2048-element chunks: 47 us; 512: 38, 29.5 once the step counters
+                                      // are bumped by one thread each; 256 with the moments loaded up front: 32.6)
 struct StackArgs { qa_adam_stack_tensor t[QA_ADAM_STACK_MAX_TENSORS]; int32_t first_block[QA_ADAM_STACK_MAX_TENSORS + 1]; int32_t n, blocks; float beta1, beta2, eps; unsigned *ticket; };
 __global__ void __launch_bounds__(256) qa_adam_stack_kernel(StackArgs a) {
     __shared__ float s_q[256];

@@ -166,6 +166,15 @@ fastr6)    # config 3, 1024 envs x 1,000 iterations on the round's final learner
     timeout 2500 python tools/d2_many.py --out $O --arms fast:31-62 --workers 4 --job_timeout 900 --budget_s 2000 > $O/d2_many.log 2>&1
     tail -6 $O/d2_many.log
     ;;
+tails)     # the last workgroup's serial tails (stacked optimiser's step counters, discriminator tail) spread over its threads
+    timeout 2400 python -m pytest tests/test_fused_learner.py tests/test_train_chain.py tests/test_gpu_train.py tests/test_learner_lockstep.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_$i.json; done
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_512.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 3 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_disc_loss_kernel" mid > $O/disc_step_sequence.txt 2>&1; cat $O/disc_step_sequence.txt
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
