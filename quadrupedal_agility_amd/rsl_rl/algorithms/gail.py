@@ -647,10 +647,15 @@ class SSInfoGAIL:
             if hist_latent is None:
                 with torch.no_grad():
                     hist_latent = ac.infer_hist_latent(obs[:, c:d])
-            priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
-            g_priv = g_priv * priv_reg_coef
             est = self.estimator(obs[:, :a])
-            estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
+            if torch.is_tensor(priv_reg_coef) and priv_reg_coef.dtype == torch.float32 and priv_reg_coef.device == obs.device and os.environ.get("QA_PAIR_LOSSES", "1") != "0":
+                # r6 (ABI 18): one launch, rows through LDS (qa_pair_loss walks 24,576 rows of 29 floats lane by lane: 29 us each)
+                (priv_reg_loss, g_priv), (estimator_loss, g_est) = fused_mod.pair_losses_raw(
+                    [(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2, priv_reg_coef), (est, obs[:, a:b], fused_mod.PAIR_MSE, None)])
+            else:
+                priv_reg_loss, g_priv = fused_mod.pair_loss_raw(priv_latent, hist_latent, fused_mod.PAIR_ROW_L2)
+                g_priv = g_priv * priv_reg_coef
+                estimator_loss, g_est = fused_mod.pair_loss_raw(est, obs[:, a:b], fused_mod.PAIR_MSE)
         mu = ac._actor_mean(obs.detach(), False)
         if self.branch_streams:
             cur.wait_stream(s_critic)

@@ -175,6 +175,14 @@ tails)     # the last workgroup's serial tails (stacked optimiser's step counter
     timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --amp --steps 3 --warmup 3 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
     f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_disc_loss_kernel" mid > $O/disc_step_sequence.txt 2>&1; cat $O/disc_step_sequence.txt
     ;;
+cfg2pl)    # config 2 at 4096 envs: the two pair losses of the 24,576-row step as one launch through LDS, A / B on one box
+    timeout 1500 python -m pytest tests/test_fused_learner.py tests/test_gpu_train.py tests/test_golden_learner.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do
+      timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_one_launch_$i.json
+      QA_PAIR_LOSSES=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_five_launches_$i.json
+    done
+    line $O/bench_*.json
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
