@@ -1008,13 +1008,17 @@ struct HybridActArgs {
     float *actions, *st_actions, *st_mu, *st_sigma, *st_logp_d, *st_logp_c, *st_values, *hist;
     const float *hist_in;
     int hist_len;
+    int epb;        // envs per 128-thread workgroup (r6): the first epb threads sample, all 128 roll the workgroup's envs' history
 };
-/* one thread per env: softmax over <= 16 logits, inverse-CDF choice, <= 32 Gaussian parameters, the storage rows and the action-history roll */
+/* one thread per env: softmax over <= 16 logits, inverse-CDF choice, <= 32 Gaussian parameters, the storage rows and the action-history roll.
+ * r6: few envs per workgroup.  With 128 envs per workgroup the out-of-place roll is 19 rounds of (8 loads, 8 stores) per thread whatever N is -- 19 dependent
+ * round trips, ~28 of the launch's 32 us at 1024 AND at 8192 envs; the host picks epb so that the launch has >= ~256 workgroups and the roll is 1-5 rounds. */
 __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArgs a) {
-    const int e = blockIdx.x * 128 + threadIdx.x;
+    const int e = blockIdx.x * a.epb + threadIdx.x;
     const int64_t step = a.step_ptr ? *a.step_ptr : a.step_host;
     const int nd = a.nd, nc = a.nc, w = 1 + nc;
-    if (e < a.N) {
+    const bool mine = (int)threadIdx.x < a.epb && e < a.N;
+    if (mine) {
     const float HALF_LOG_2PI = 0.91893853320467274178f, EPS = 1.1920928955078125e-07f;
     const float *lg = a.logits + (int64_t)e * nd;
     float mx = lg[0];
@@ -1065,7 +1069,7 @@ __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArg
         // the workgroup's 128 envs are one contiguous run of both buffers, copied with coalesced accesses by all threads; in place (hist_in == hist)
         // every thread moves its own env's block front to back.
         __syncthreads();                       // the block's `actions` rows are written
-        const int e0 = blockIdx.x * 128, ne = min(128, a.N - e0), per = a.hist_len * w;
+        const int e0 = blockIdx.x * a.epb, ne = min(a.epb, a.N - e0), per = a.hist_len * w;
         if (a.hist_in != a.hist) {
             const float *__restrict__ src = a.hist_in + (int64_t)e0 * per;
             const float *__restrict__ newest = a.actions + (int64_t)e0 * w;
@@ -1083,7 +1087,7 @@ __global__ void __launch_bounds__(128) qa_rollout_act_hybrid_kernel(HybridActArg
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int i = i0 + 128 * u; if (i < total) dst[i] = v[u]; }
             }
-        } else if (e < a.N) {
+        } else if (mine) {
             float *h = a.hist + (int64_t)e * per;
             for (int o = 0; o < per - w; ++o) h[o] = h[o + w];
             for (int j = 0; j < w; ++j) h[per - w + j] = a.actions[(int64_t)e * w + j];
@@ -1888,9 +1892,11 @@ int qa_rollout_act_hybrid(const float *logits, const float *mean, const float *s
     if (!logits || !mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp_d || !st_logp_c || !st_values || num_envs <= 0 ||
         nd <= 0 || nd > 16 || nc_all <= 0 || nc_all > 32 || (action_history && hist_len <= 0) || (action_history_in && !action_history)) {
         snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_hybrid: bad argument (nd <= 16, nc_all <= 32)"); return QA_E_ARG; }
+    int epb = 128;
+    while (epb > 4 && (num_envs + epb - 1) / epb < 256) epb >>= 1;           // >= ~256 workgroups, 4..128 envs each
     HybridActArgs a{logits, mean, std, value, seed, step_dev, step, (int)num_envs, (int)env_id_offset, (int)nd, (int)nc_all, actions, st_actions, st_mu, st_sigma,
-                    st_logp_d, st_logp_c, st_values, action_history, action_history_in ? action_history_in : action_history, (int)hist_len};
-    hipLaunchKernelGGL(qa_rollout_act_hybrid_kernel, dim3((num_envs + 127) / 128), dim3(128), 0, (hipStream_t)stream, a);
+                    st_logp_d, st_logp_c, st_values, action_history, action_history_in ? action_history_in : action_history, (int)hist_len, epb};
+    hipLaunchKernelGGL(qa_rollout_act_hybrid_kernel, dim3((num_envs + epb - 1) / epb), dim3(128), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_hybrid: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;

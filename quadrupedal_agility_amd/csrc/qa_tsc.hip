@@ -452,14 +452,31 @@ __global__ void __launch_bounds__(1024) qa_tsc_reset_stats_kernel(const uint8_t 
     __syncthreads();
     const float cnt = cnt_s;
     if (cnt <= 0.f) return;                      // nobody reset: the means keep their values
-    for (int k = 0; k < num_terms; ++k) {
-        float a = 0.f;
-        for (int64_t e = t; e < n; e += 1024) a += flags[e] ? sums[(int64_t)k * n + e] : 0.f;
+    // r6: eight terms per pass -- their loads in flight together, one barrier ladder for all of them (was: per term a pass over the envs and a ten-step
+    // ladder, eight dependent rounds, 11 us per env step of the task-level rollout).  Per term the same lanes add the same envs in the same order.
+    constexpr int G = 8;
+    __shared__ float redk[G][1024];
+    for (int k0 = 0; k0 < num_terms; k0 += G) {
+        float a[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) a[j] = 0.f;
+        for (int64_t e = t; e < n; e += 1024) {
+            const bool f = flags[e] != 0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) if (k0 + j < num_terms) a[j] += f ? sums[(int64_t)(k0 + j) * n + e] : 0.f;
+        }
         __syncthreads();
-        red[t] = a;
+#pragma unroll
+        for (int j = 0; j < G; ++j) redk[j][t] = a[j];
         __syncthreads();
-        for (int w = 512; w > 0; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
-        if (t == 0) means[k] = red[0] / cnt * inv_len_s;
+        for (int w = 512; w > 0; w >>= 1) {
+            if (t < w) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) redk[j][t] += redk[j][t + w];
+            }
+            __syncthreads();
+        }
+        if (t < G && k0 + t < num_terms) means[k0 + t] = redk[t][0] / cnt * inv_len_s;
     }
 }
 

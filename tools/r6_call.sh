@@ -183,6 +183,15 @@ cfg2pl)    # config 2 at 4096 envs: the two pair losses of the 24,576-row step a
     done
     line $O/bench_*.json
     ;;
+epb)       # qa_rollout_act_hybrid with few envs per workgroup
+    timeout 1800 python -m pytest tests/test_tsc_learner.py tests/test_tsc_glue.py tests/test_tsc_course_env.py tests/test_tsc_env.py tests/test_tsc_student.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_$i.json; done
+    timeout 600 python bench.py --tsc --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc8192.json
+    line $O/bench_*.json
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
+    timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
+    f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid | grep -E "hybrid|launches"
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
