@@ -697,6 +697,11 @@ int qa_episode_means(const float *episode_stats, const int64_t *step_dev, int64_
 int qa_rollout_act(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
                    int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
                    float *st_values, void *stream);
+/* ABI 18: qa_rollout_act, and in the same launch the step's observation rows into the storage (RolloutStorage.add_transitions' `observations[step].copy_`,
+ * rollout_storage.py:60-74): st_obs[r][0 .. obs_width) = obs[r][0 .. obs_width), row strides st_obs_stride / obs_stride (floats). */
+int qa_rollout_act_store(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
+                         int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                         float *st_values, const float *obs, int64_t obs_stride, int32_t obs_width, float *st_obs, int64_t st_obs_stride, void *stream);
 /* qa_rollout_act_hybrid (ABI 13): the task-level teacher's sampling and bookkeeping of one env step (tsc/rsl_rl/modules/actor_critic.py:252-261
  * `act` / `get_actions_log_prob_d` / `_c`, tsc/rsl_rl/algorithms/ppo.py:101-125, RolloutStorage.add_transitions, and the runner's action history,
  * tsc/rsl_rl/runners/on_policy_runner.py:199-203) in one launch.  logits (N, nd), mean (N, nc_all), std (nc_all), value (N):

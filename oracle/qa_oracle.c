@@ -2070,6 +2070,16 @@ int qo_rollout_act(const float *mean, const float *std, const float *value, cons
     }
     return QA_OK;
 }
+
+int qo_rollout_act_store(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
+                         int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                         float *st_values, const float *obs, int64_t obs_stride, int32_t obs_width, float *st_obs, int64_t st_obs_stride, void *stream) {
+    if (!obs || !st_obs || obs_width <= 0 || obs_stride < obs_width || st_obs_stride < obs_width) return QA_E_ARG;
+    int rc = qo_rollout_act(mean, std, value, noise, seed, step_dev, step, num_envs, env_id_offset, actions, st_actions, st_mu, st_sigma, st_logp, st_values, stream);
+    if (rc != QA_OK) return rc;
+    for (int64_t r = 0; r < num_envs; ++r) for (int c = 0; c < obs_width; ++c) st_obs[r * st_obs_stride + c] = obs[r * obs_stride + c];
+    return QA_OK;
+}
 int qo_tsc_push(float *root_states, int64_t num_envs, int64_t *step_dev, int32_t *ticket, int32_t push_interval, float max_push_vel_xy, uint64_t seed,
                 int32_t env_id_offset, void *stream) {
     (void)stream; (void)ticket;         /* tsc/legged_gym/envs/base/legged_robot.py:905-915 */

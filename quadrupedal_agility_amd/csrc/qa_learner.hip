@@ -898,12 +898,10 @@ __global__ void __launch_bounds__(256) qa_adam_update_kernel(AdamArgs a) {
 // the runner's per-episode logging sums, another ~12 launches.
 constexpr int RS_ACT_NOISE = 20;
 
-__global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ value,
+__device__ __forceinline__ void rollout_act_one(const int e, const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ value,
                                                              const float *__restrict__ noise, uint64_t seed, const int64_t *step_ptr, int64_t step_host, int N, int env0,
                                                              float *__restrict__ actions, float *__restrict__ st_actions, float *__restrict__ st_mu,
                                                              float *__restrict__ st_sigma, float *__restrict__ st_logp, float *__restrict__ st_values) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= N) return;
     const int64_t step = step_ptr ? *step_ptr : step_host;
     const float HALF_LOG_2PI = 0.91893853320467274178f;
     float eps[12];
@@ -931,6 +929,43 @@ __global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__rest
     }
     st_logp[e] = logp;
     st_values[e] = value[e];
+}
+__global__ void __launch_bounds__(256) qa_rollout_act_kernel(const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ value,
+                                                             const float *__restrict__ noise, uint64_t seed, const int64_t *step_ptr, int64_t step_host, int N, int env0,
+                                                             float *__restrict__ actions, float *__restrict__ st_actions, float *__restrict__ st_mu,
+                                                             float *__restrict__ st_sigma, float *__restrict__ st_logp, float *__restrict__ st_values) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N) return;
+    rollout_act_one(e, mean, std, value, noise, seed, step_ptr, step_host, N, env0, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
+}
+// r6 (qa_rollout_act_store): the same sampling with the step's OBSERVATION rows copied into the storage by the same launch (RolloutStorage.add_transitions,
+// rollout_storage.py:60-74: was a strided copy launch of its own, 5-7 us per env step).  ACT_EPB envs per 256-thread workgroup: the first ACT_EPB threads sample,
+// all 256 copy the workgroup's rows, 8 loads in flight per thread (3 rounds for 8 x 671 floats).
+constexpr int ACT_EPB = 8;
+__global__ void __launch_bounds__(256) qa_rollout_act_store_kernel(const float *__restrict__ mean, const float *__restrict__ std, const float *__restrict__ value,
+                                                                   const float *__restrict__ noise, uint64_t seed, const int64_t *step_ptr, int64_t step_host, int N, int env0,
+                                                                   float *__restrict__ actions, float *__restrict__ st_actions, float *__restrict__ st_mu,
+                                                                   float *__restrict__ st_sigma, float *__restrict__ st_logp, float *__restrict__ st_values,
+                                                                   const float *__restrict__ obs, int64_t obs_stride, int width, float *__restrict__ st_obs, int64_t st_stride) {
+    const int e0 = blockIdx.x * ACT_EPB, ne = min(ACT_EPB, N - e0);
+    const int total = ne * width;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 256 * u, total - 1);
+            const int le = i / width, c = i - le * width;
+            v[u] = obs[(int64_t)(e0 + le) * obs_stride + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < total) { const int le = i / width, c = i - le * width; st_obs[(int64_t)(e0 + le) * st_stride + c] = v[u]; }
+        }
+    }
+    const int e = e0 + (int)threadIdx.x;
+    if ((int)threadIdx.x < ne)
+        rollout_act_one(e, mean, std, value, noise, seed, step_ptr, step_host, N, env0, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
 }
 
 constexpr int RS_TSC_PUSH = 22, RS_TSC_START = 23;
@@ -1843,6 +1878,19 @@ int qa_rollout_act(const float *mean, const float *std, const float *value, cons
                        (int)num_envs, (int)env_id_offset, actions, st_actions, st_mu, st_sigma, st_logp, st_values);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    return QA_OK;
+}
+
+int qa_rollout_act_store(const float *mean, const float *std, const float *value, const float *noise, uint64_t seed, const int64_t *step_dev,
+                         int64_t step, int32_t num_envs, int32_t env_id_offset, float *actions, float *st_actions, float *st_mu, float *st_sigma, float *st_logp,
+                         float *st_values, const float *obs, int64_t obs_stride, int32_t obs_width, float *st_obs, int64_t st_obs_stride, void *stream) {
+    if (!mean || !std || !value || !actions || !st_actions || !st_mu || !st_sigma || !st_logp || !st_values || num_envs <= 0 || !obs || !st_obs || obs_width <= 0 ||
+        obs_stride < obs_width || st_obs_stride < obs_width || (int64_t)ACT_EPB * obs_width > INT32_MAX) {
+        snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_store: bad argument"); return QA_E_ARG; }
+    hipLaunchKernelGGL(qa_rollout_act_store_kernel, dim3((num_envs + ACT_EPB - 1) / ACT_EPB), dim3(256), 0, (hipStream_t)stream, mean, std, value, noise, seed, step_dev, step,
+                       (int)num_envs, (int)env_id_offset, actions, st_actions, st_mu, st_sigma, st_logp, st_values, obs, obs_stride, (int)obs_width, st_obs, st_obs_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_rollout_act_store: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
 }
 

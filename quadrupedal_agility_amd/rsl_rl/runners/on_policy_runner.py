@@ -325,11 +325,22 @@ class OnPolicyRunner:
             mean, value = chain.forward(obs) if chain is not None else alg.act_mean_value(obs, obs, hist_encoding)
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             ctr = env._step_ctr
-            rc = lib.qa_rollout_act(P(mean), P(std), P(value), None, seed, P(ctr) if ctr is not None else None, int(env.common_step_counter), N, int(env.qcfg.env_id_offset),
-                                    P(self._act_buf), P(st.actions[t]), P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob[t]), P(st.values[t]), stream)
-            if rc != 0:
-                raise RuntimeError(f"qa_rollout_act failed with code {rc}: {lib.qa_last_error().decode()}")
-            st.observations[t].copy_(obs)
+            so = st.observations[t]
+            if (obs.dim() == 2 and obs.dtype == torch.float32 and obs.stride(1) == 1 and so.stride(1) == 1 and so.shape == obs.shape
+                    and os.environ.get("QA_ACT_STORE", "0") == "1"):
+                # r6 (ABI 18), opt-in: the observation rows go to the storage in the sampling launch instead of a copy launch of their own.  Measured: rollout
+                # 4.04 -> 3.97 ms at 4096 envs, 2.81 -> 2.85 ms at 512 (the merged launch is longer than the two 5 us ones it replaces): off
+                rc = lib.qa_rollout_act_store(P(mean), P(std), P(value), None, seed, P(ctr) if ctr is not None else None, int(env.common_step_counter), N, int(env.qcfg.env_id_offset),
+                                              P(self._act_buf), P(st.actions[t]), P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob[t]), P(st.values[t]),
+                                              P(obs), int(obs.stride(0)), int(obs.shape[1]), P(so), int(so.stride(0)), stream)
+                if rc != 0:
+                    raise RuntimeError(f"qa_rollout_act_store failed with code {rc}: {lib.qa_last_error().decode()}")
+            else:
+                rc = lib.qa_rollout_act(P(mean), P(std), P(value), None, seed, P(ctr) if ctr is not None else None, int(env.common_step_counter), N, int(env.qcfg.env_id_offset),
+                                        P(self._act_buf), P(st.actions[t]), P(st.mu[t]), P(st.sigma[t]), P(st.actions_log_prob[t]), P(st.values[t]), stream)
+                if rc != 0:
+                    raise RuntimeError(f"qa_rollout_act failed with code {rc}: {lib.qa_last_error().decode()}")
+                so.copy_(obs)
             next_obs, _, _rew, _dones, infos, _, _ = env.step(self._act_buf)
             log_ptrs = (P(self._cur) if logging else None, P(self._fin_vals[i]) if logging else None, P(self._fin_mask[i]) if logging else None)
             if dchain is None:

@@ -590,6 +590,48 @@ def test_rollout_kernels_hip_match_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 7, 512, 4099])
+def test_rollout_act_store_is_rollout_act_plus_the_row_copy(N):
+    """qa_rollout_act_store (ABI 18): the sampling launch with the observation rows' copy into the (padded) storage folded in -- every output bit-identical to
+    qa_rollout_act, the rows exact, the storage's padding column untouched"""
+    from quadrupedal_agility_amd import _capi
+    lib = _capi.load_library()
+    c = {k: v.cuda() for k, v in _rollout_case(N, 3).items()}
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    step_dev = torch.tensor([77], dtype=torch.int64, device="cuda")
+    obs = torch.randn(N, 672, device="cuda")[:, :671]                      # rows of a wider arena tensor
+    res = []
+    for store in (False, True):
+        g = {k: torch.zeros(N, 12, device="cuda") for k in ("a", "sa", "smu", "ssig")}; gl = torch.zeros(N, device="cuda"); gv = torch.zeros(N, device="cuda")
+        so_full = torch.full((N, 688), -7.0, device="cuda"); so = so_full[:, :671]
+        if store:
+            assert lib.qa_rollout_act_store(P(c["mean"]), P(c["std"]), P(c["value"]), None, 9, P(step_dev), 0, N, 5, P(g["a"]), P(g["sa"]), P(g["smu"]), P(g["ssig"]), P(gl), P(gv),
+                                            P(obs), obs.stride(0), 671, P(so), so.stride(0), st) == 0
+        else:
+            assert lib.qa_rollout_act(P(c["mean"]), P(c["std"]), P(c["value"]), None, 9, P(step_dev), 0, N, 5, P(g["a"]), P(g["sa"]), P(g["smu"]), P(g["ssig"]), P(gl), P(gv), st) == 0
+            so.copy_(obs)
+        torch.cuda.synchronize()
+        res.append([g[k] for k in ("a", "sa", "smu", "ssig")] + [gl, gv, so_full])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert torch.equal(res[1][-1][:, :671], obs) and bool((res[1][-1][:, 671:] == -7.0).all())
+
+
+def test_rollout_act_store_twin():
+    lo = load_oracle()
+    lo.qo_rollout_act_store.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 6 + [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    N = 37
+    n = {k: np.ascontiguousarray(v.numpy()) for k, v in _rollout_case(N, 4).items()}
+    p = lambda x: x.ctypes.data
+    o = {k: np.zeros((N, 12), np.float32) for k in ("a", "sa", "smu", "ssig")}; ol = np.zeros(N, np.float32); ov = np.zeros(N, np.float32)
+    obs = np.random.default_rng(0).standard_normal((N, 16)).astype(np.float32); so = np.full((N, 20), -1.0, np.float32)
+    assert lo.qo_rollout_act_store(p(n["mean"]), p(n["std"]), p(n["value"]), p(n["noise"]), 9, None, 1, N, 0, p(o["a"]), p(o["sa"]), p(o["smu"]), p(o["ssig"]), p(ol), p(ov),
+                                   p(obs), 16, 13, p(so), 20, None) == 0
+    assert np.array_equal(so[:, :13], obs[:, :13]) and (so[:, 13:] == -1.0).all() and np.allclose(o["a"], n["mean"] + n["std"] * n["noise"], atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_fused_rollout_fills_the_storage_consistently():
     from torch.distributions import Normal
     from tests.test_gpu_train import _make

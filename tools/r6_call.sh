@@ -192,6 +192,16 @@ epb)       # qa_rollout_act_hybrid with few envs per workgroup
     timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -- python $R/bench.py --tsc --num_envs 1024 --steps 3 --warmup 2 --no_cpu_baseline < /dev/null > /tmp/prof.log 2>&1
     f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/step_sequence.py "$f" "qa_env_step_kernel" mid | grep -E "hybrid|launches"
     ;;
+store)     # the observation rows' storage copy inside the sampling launch
+    timeout 2400 python -m pytest tests/test_fused_learner.py tests/test_gpu_train.py tests/test_golden_learner.py tests/test_learner_lockstep.py tests/test_full_size_properties.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do
+      timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_store_$i.json
+      QA_ACT_STORE=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_copy_$i.json
+    done
+    timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_store.json
+    QA_ACT_STORE=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_copy.json
+    line $O/bench_*.json
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
