@@ -746,6 +746,12 @@ int64_t qa_disc_loss_scratch_bytes(int64_t rows);
 int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
                  int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
                  float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream);
+/* ABI 18: the same with the class LOGITS in place of c: the softmax of Discriminator.forward (discriminator.py:66; max, exp, sum, divide) and its backward
+ * happen inside -- grad_logits = d loss / d logits = p (g - <g, p>) with g the gradient w.r.t. the clamped probabilities as above; a discriminator chain step
+ * made three launches of them (softmax, the product grad x output, the softmax backward).  Everything else, `out` included, as qa_disc_loss. */
+int qa_disc_loss_logits(const float *d, const float *eps, const float *logits, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                        int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                        float *grad_d, float *grad_eps, float *grad_logits, float *out, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Sampling front of a discriminator step: what three `feed_forward_generator`s (bbc/rsl_rl/storage/replay_buffer.py:38-47,
  * bbc/rsl_rl/datasets/motion_loader.py feed_forward_generator_lb / _ulb) hand to update_ss_info_gail, drawn from index tables made once per

@@ -2271,6 +2271,32 @@ int qo_disc_loss(const float *d, const float *eps, const float *c, const int64_t
     return QA_OK;
 }
 
+/* ABI 18: class logits in, gradient w.r.t. the logits out (softmax + its backward around qo_disc_loss; discriminator.py:66) */
+int qo_disc_loss_logits(const float *d, const float *eps, const float *logits, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                        int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                        float *grad_d, float *grad_eps, float *grad_logits, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    if (!logits || !grad_logits || b_lb <= 0 || b_pi <= 0 || b_ulb <= 0) return QA_E_ARG;
+    const int64_t B = (int64_t)b_lb + b_pi + b_ulb;
+    float *p = (float *)malloc(sizeof(float) * 5 * (size_t)B);
+    if (!p) return QA_E_ARG;
+    for (int64_t r = 0; r < B; ++r) {
+        float m = logits[r * 5], s = 0.f;
+        for (int j = 1; j < 5; ++j) m = fmaxf(m, logits[r * 5 + j]);
+        for (int j = 0; j < 5; ++j) { p[r * 5 + j] = expf(logits[r * 5 + j] - m); s += p[r * 5 + j]; }
+        for (int j = 0; j < 5; ++j) p[r * 5 + j] = p[r * 5 + j] / s;
+    }
+    int rc = qo_disc_loss(d, eps, p, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, grad_d, grad_eps, grad_logits, out,
+                          scratch, scratch_bytes, stream);
+    if (rc == QA_OK)
+        for (int64_t r = 0; r < B; ++r) {
+            float dot = 0.f;
+            for (int j = 0; j < 5; ++j) dot += grad_logits[r * 5 + j] * p[r * 5 + j];
+            for (int j = 0; j < 5; ++j) grad_logits[r * 5 + j] = p[r * 5 + j] * (grad_logits[r * 5 + j] - dot);
+        }
+    free(p);
+    return rc;
+}
+
 int qo_disc_prepare(const float *const *batches, const int64_t *rows, int32_t num_batches, int32_t dim, const float *task_mask,
                     const float *frame_mult, const float *task_weight_dev, const double *mean, const double *var, float epsilon, float clip,
                     float *out, void *stream) {

@@ -154,6 +154,9 @@ def bind(lib, prefix):
     f = getattr(lib, prefix + "disc_loss")
     f.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
     f.restype = C.c_int
+    f = getattr(lib, prefix + "disc_loss_logits")
+    f.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
+    f.restype = C.c_int
     f = getattr(lib, prefix + "disc_prepare")
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     f.restype = C.c_int
@@ -344,7 +347,7 @@ class QaTscDepthIo(C.Structure):
 
 ABI_SYMBOLS = ["arena_bytes", "create", "destroy", "tensor_info", "env_step", "env_step_dev", "reset_all", "simulate",
                "set_mocap", "debug_post_physics", "env_physics_step", "tsc_reset", "tsc_reset_dev", "simulate_if", "gae", "ppo_loss", "ppo_loss_scratch_bytes", "hybrid_ppo_loss", "hybrid_ppo_loss_scratch_bytes", "elu_backward_bias",
-               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "linear_backward_weight_batch", "linear_backward_weight_batch_layout", "linear_backward_weight_batch_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "clip_adam_pair_step", "grad_reduce", "adam_stack_step", "rollout_act", "rollout_act_store", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "pair_losses", "pair_losses_scratch_bytes", "accumulate_scalars", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
+               "elu_backward_bias_scratch_bytes", "narrow_wgrad", "narrow_wgrad_scratch_bytes", "linear_forward", "linear_backward_input", "linear_backward_weight", "linear_backward_weight_scratch_bytes", "linear_backward_weight_layout", "linear_backward_weight_batch", "linear_backward_weight_batch_layout", "linear_backward_weight_batch_scratch_bytes", "slab_sum", "linear_forward_split", "linear_forward_split_scratch_bytes", "depth_stem_forward", "depth_stem_backward", "depth_stem_backward_scratch_bytes", "conv_nhwc_forward", "conv_nhwc_backward_input", "conv_nhwc_backward_weight", "conv_nhwc_backward_weight_scratch_bytes", "elu_backward_pad", "normalizer_update", "normalizer_apply", "clip_adam_step", "clip_adam_step_hostgrads", "clip_adam_step_reduce", "clip_adam_pair_step", "grad_reduce", "adam_stack_step", "rollout_act", "rollout_act_store", "rollout_act_hybrid", "rollout_post", "rollout_post_amp", "disc_loss", "disc_loss_logits", "disc_loss_scratch_bytes", "disc_prepare", "disc_sample_prepare", "disc_step_tail", "disc_step_tail_scratch_bytes", "pair_loss", "pair_loss_scratch_bytes", "pair_losses", "pair_losses_scratch_bytes", "accumulate_scalars", "gather_rows", "kl_lr_rule", "episode_means", "set_lean_exports", "mlp_packed_floats", "mlp_pack", "mlp_forward", "mlp_strands", "mlp_groups", "mlp_set_groups", "tsc_set_commands", "tsc_goal_step", "tsc_observations", "tsc_depth_update", "tsc_reset_stats", "tsc_push", "tsc_start_pose", "tsc_reset_where", "last_error", "abi_version"]
 
 _LIB = None
 # QA_LIB: another build of the SAME library (A/B measurements of a kernel variant, tools/r5_call.sh); there is still no fallback -- a missing file raises

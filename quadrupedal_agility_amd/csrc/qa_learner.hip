@@ -1212,6 +1212,7 @@ struct DiscArgs {
     float *gd, *geps, *gc; float *partial;
     int b_lb, b_pi, b_ulb;
     float c_ss, c_disc, c_us;
+    int from_logits;        // r6 (qa_disc_loss_logits): `c` holds the class LOGITS; the softmax (discriminator.py:66) and its backward happen here, gc = d loss / d logits
 };
 
 __global__ void __launch_bounds__(DISC_BLOCK) qa_disc_loss_kernel(DiscArgs a) {
@@ -1222,10 +1223,22 @@ __global__ void __launch_bounds__(DISC_BLOCK) qa_disc_loss_kernel(DiscArgs a) {
     for (int k = 0; k <= DISC_SUMS; ++k) part[k] = 0.f;
     if (i < B) {
         const float c_info = a.info_coef[0];
-        float c[5];
+        float c[5], craw[5];
         bool pass[5];               /* torch.clamp(c, 1e-20) of Discriminator.forward applied here: clamped entries pass no gradient */
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { const float cr = a.c[(int64_t)i * 5 + j]; pass[j] = cr >= 1e-20f; c[j] = fmaxf(cr, 1e-20f); }
+        for (int j = 0; j < 5; ++j) craw[j] = a.c[(int64_t)i * 5 + j];
+        if (a.from_logits) {        /* softmax over the 5 class logits: max, exp, sum, divide (torch.softmax's steps) */
+            float zm = craw[0];
+#pragma unroll
+            for (int j = 1; j < 5; ++j) zm = fmaxf(zm, craw[j]);
+            float zs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { craw[j] = expf(craw[j] - zm); zs += craw[j]; }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) craw[j] = craw[j] / zs;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { pass[j] = craw[j] >= 1e-20f; c[j] = fmaxf(craw[j], 1e-20f); }
         int arg = 0;
 #pragma unroll
         for (int j = 1; j < 5; ++j) if (c[j] > c[arg]) arg = j;
@@ -1276,7 +1289,16 @@ __global__ void __launch_bounds__(DISC_BLOCK) qa_disc_loss_kernel(DiscArgs a) {
         }
         a.gd[i] = gd; a.geps[i] = ge;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) a.gc[(int64_t)i * 5 + j] = pass[j] ? gc[j] : 0.f;
+        for (int j = 0; j < 5; ++j) gc[j] = pass[j] ? gc[j] : 0.f;
+        if (a.from_logits) {        /* softmax backward: d loss / d z_j = p_j (g_j - sum_k g_k p_k), p the UNclamped softmax output */
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) dot += gc[j] * craw[j];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) gc[j] = craw[j] * (gc[j] - dot);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a.gc[(int64_t)i * 5 + j] = gc[j];
     }
 #pragma unroll
     for (int k = 0; k <= DISC_SUMS; ++k) {
@@ -1978,21 +2000,33 @@ int qa_rollout_post_amp(const float *rew, const int64_t *reset, const uint8_t *t
 
 int64_t qa_disc_loss_scratch_bytes(int64_t rows) { return rows <= 0 ? -1 : (int64_t)sizeof(float) * (DISC_SUMS + 1) * ((rows + DISC_BLOCK - 1) / DISC_BLOCK); }
 
-int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
-                 int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
-                 float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
+static int disc_loss_launch(const char *who, int from_logits, const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps,
+                            const float *policy_c, int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                            float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
     const int64_t B = (int64_t)b_lb + b_pi + b_ulb;
     if (!d || !eps || !c || !label_lb || !policy_eps || !policy_c || !info_coef_dev || !grad_d || !grad_eps || !grad_c || !out || !scratch ||
         b_lb <= 0 || b_pi <= 0 || b_ulb <= 0 || scratch_bytes < qa_disc_loss_scratch_bytes(B)) {
-        snprintf(g_lerr, sizeof(g_lerr), "qa_disc_loss: bad argument"); return QA_E_ARG; }
-    DiscArgs a{d, eps, c, label_lb, policy_eps, policy_c, info_coef_dev, grad_d, grad_eps, grad_c, (float *)scratch, b_lb, b_pi, b_ulb, c_ss, c_disc, c_us};
+        snprintf(g_lerr, sizeof(g_lerr), "%s: bad argument", who); return QA_E_ARG; }
+    DiscArgs a{d, eps, c, label_lb, policy_eps, policy_c, info_coef_dev, grad_d, grad_eps, grad_c, (float *)scratch, b_lb, b_pi, b_ulb, c_ss, c_disc, c_us, from_logits};
     const int blocks = (int)((B + DISC_BLOCK - 1) / DISC_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(qa_disc_loss_kernel, dim3(blocks), dim3(DISC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(qa_disc_finish_kernel, dim3(1), dim3(64), 0, st, (const float *)scratch, blocks, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, out);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "qa_disc_loss: %s", hipGetErrorString(e)); return QA_E_DEVICE; }
+    if (e != hipSuccess) { snprintf(g_lerr, sizeof(g_lerr), "%s: %s", who, hipGetErrorString(e)); return QA_E_DEVICE; }
     return QA_OK;
+}
+int qa_disc_loss(const float *d, const float *eps, const float *c, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                 int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                 float *grad_d, float *grad_eps, float *grad_c, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    return disc_loss_launch("qa_disc_loss", 0, d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, grad_d, grad_eps, grad_c,
+                            out, scratch, scratch_bytes, stream);
+}
+int qa_disc_loss_logits(const float *d, const float *eps, const float *logits, const int64_t *label_lb, const float *policy_eps, const float *policy_c,
+                        int32_t b_lb, int32_t b_pi, int32_t b_ulb, float c_ss, const float *info_coef_dev, float c_disc, float c_us,
+                        float *grad_d, float *grad_eps, float *grad_logits, float *out, void *scratch, int64_t scratch_bytes, void *stream) {
+    return disc_loss_launch("qa_disc_loss_logits", 1, d, eps, logits, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, c_ss, info_coef_dev, c_disc, c_us, grad_d, grad_eps,
+                            grad_logits, out, scratch, scratch_bytes, stream);
 }
 
 int qa_disc_sample_prepare(const qa_disc_sample_io *io, int32_t dim, int32_t c_dim, const float *task_mask, const float *frame_mult,

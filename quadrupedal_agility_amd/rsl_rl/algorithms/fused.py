@@ -1296,8 +1296,9 @@ class _DiscLoss(torch.autograd.Function):
         return ((gd * g_loss).view(sd), (ge * g_loss).view(se), (gc * g_loss).view(sc)) + (None,) * 10
 
 
-def disc_loss_raw(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, *, c_ss, info_coef_dev, c_disc, c_us):
-    """qa_disc_loss without the autograd wrapper: (stats[16], d loss/d d, d loss/d eps, d loss/d c) shaped like d, eps, c"""
+def disc_loss_raw(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, *, c_ss, info_coef_dev, c_disc, c_us, from_logits=False):
+    """qa_disc_loss without the autograd wrapper: (stats[16], d loss/d d, d loss/d eps, d loss/d c) shaped like d, eps, c.  from_logits (qa_disc_loss_logits,
+    ABI 18): `c` holds the class LOGITS -- the softmax and its backward run inside the launch, the last result is d loss / d logits"""
     lib = _capi.load_library()
     dc, ec, cc = _f32c(d.detach()), _f32c(eps.detach()), _f32c(c.detach())
     pe, pc = _f32c(policy_eps), _f32c(policy_c)
@@ -1308,9 +1309,10 @@ def disc_loss_raw(d, eps, c, label_lb, policy_eps, policy_c, b_lb, b_pi, b_ulb, 
     out = torch.empty(16, dtype=torch.float32, device=dc.device)
     n = int(lib.qa_disc_loss_scratch_bytes(B))
     scratch = torch.empty(n, dtype=torch.uint8, device=dc.device)
-    rc = lib.qa_disc_loss(_ptr(dc), _ptr(ec), _ptr(cc), _ptr(lab), _ptr(pe), _ptr(pc), b_lb, b_pi, b_ulb, float(c_ss), _ptr(info_coef_dev),
-                          float(c_disc), float(c_us), _ptr(gd), _ptr(ge), _ptr(gc), _ptr(out), _ptr(scratch), n,
-                          C.c_void_p(torch.cuda.current_stream(dc.device).cuda_stream))
+    fn = lib.qa_disc_loss_logits if from_logits else lib.qa_disc_loss
+    rc = fn(_ptr(dc), _ptr(ec), _ptr(cc), _ptr(lab), _ptr(pe), _ptr(pc), b_lb, b_pi, b_ulb, float(c_ss), _ptr(info_coef_dev),
+            float(c_disc), float(c_us), _ptr(gd), _ptr(ge), _ptr(gc), _ptr(out), _ptr(scratch), n,
+            C.c_void_p(torch.cuda.current_stream(dc.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"qa_disc_loss failed with code {rc}: {lib.qa_last_error().decode()}")
     return out, gd.view(d.shape), ge.view(eps.shape), gc.view(c.shape)

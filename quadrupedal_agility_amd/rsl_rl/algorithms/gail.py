@@ -856,7 +856,9 @@ class SSInfoGAIL:
             dchain.pack()
             d_all, eps_all, logits_all = dchain.forward(x_all)
             g = dchain.penalty_gradient()                       # d logit / d x on the unlabelled rows: the penalty's argument
-            c_all = torch.softmax(logits_all, -1)               # (the objective kernel clamps)
+            # r6 (ABI 18): the class head's softmax and its backward run inside the objective's launch (qa_disc_loss_logits) -- three launches fewer per step
+            logits_in_kernel = os.environ.get("QA_DISC_LOSS_LOGITS", "1") != "0"
+            c_all = logits_all if logits_in_kernel else torch.softmax(logits_all, -1)               # (the objective kernel clamps)
             if self.disc_normalizer is not None and self.grad_sync is None:
                 # the input normaliser folds in this step's batches (gail.py:524-528, at the end of the step there): nothing else in the step reads or
                 # writes its moments, so the fold runs beside the step instead of behind it
@@ -879,7 +881,8 @@ class SSInfoGAIL:
             self._info_max_dev.fill_(float(self.info_max_coef_on)) if not torch.cuda.is_current_stream_capturing() else None
             kw = dict(c_ss=self.ss_coef, info_coef_dev=self._info_max_dev, c_disc=self.disc_coef, c_us=self.us_coef)
             if direct:
-                hs, g_d, g_eps, g_c = fused_mod.disc_loss_raw(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0], **kw)
+                hs, g_d, g_eps, g_c = fused_mod.disc_loss_raw(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0],
+                                                              from_logits=dchain is not None and logits_in_kernel, **kw)
             else:
                 heads, hs = disc_loss(d_all, eps_all, c_all, label_lb, policy_eps, policy_c, b_lb, b_pi, expert_ulb.shape[0], **kw)
             ss_loss, info_max_loss, disc_loss_v, us_loss = hs[1], hs[2], hs[3], hs[4]
@@ -957,8 +960,8 @@ class SSInfoGAIL:
             o.zero_grad()
         stack_src = None
         if dchain is not None:
-            with torch.no_grad():       # softmax backward on (rows, 5): d loss / d logits = c * (g_c - <g_c, c>), one launch
-                g_logits = torch._softmax_backward_data(g_c, c_all, -1, torch.float32)
+            with torch.no_grad():       # softmax backward on (rows, 5): d loss / d logits = c * (g_c - <g_c, c>): inside the objective's launch, or torch's two
+                g_logits = g_c if logits_in_kernel else torch._softmax_backward_data(g_c, c_all, -1, torch.float32)
             # r6 (ABI 18): the products stay in parts and ONE launch adds them (the penalty's with its factor, the regularisers' 2 c W), writes `.grad`
             # and applies the three optimisers' states in order (fused.StackedAdam) -- unless gradients travel between ranks first
             stack = self._disc_stack if (fold_reg and self.grad_sync is None and self._disc_stack is not None and self._disc_stack.ready()) else None

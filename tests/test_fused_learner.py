@@ -716,6 +716,52 @@ def test_disc_loss_hip_matches_oracle_and_pytorch(sizes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sizes", [(1, 1, 1), (37, 41, 29), (1228, 1228, 1228)])
+def test_disc_loss_from_logits_is_softmax_loss_softmax_backward(sizes):
+    """qa_disc_loss_logits (ABI 18): the class head's softmax and its backward inside the objective's launch, against torch.softmax -> qa_disc_loss ->
+    torch's softmax backward (three launches more per discriminator step)"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    b_lb, b_pi, b_ulb = sizes
+    B = sum(sizes)
+    g = torch.Generator().manual_seed(B)
+    d, eps = torch.randn(B, 1, generator=g).cuda(), torch.randn(B, 1, generator=g).cuda()
+    logits = (torch.randn(B, 5, generator=g) * 3).cuda()
+    logits[0, 0] = 200.0                                              # a saturated row: the other classes' probabilities underflow below the clamp
+    label = torch.randint(0, 5, (b_lb,), generator=g).cuda()
+    pe, pc = torch.randn(b_pi, 1, generator=g).cuda(), torch.softmax(torch.randn(b_pi, 5, generator=g), -1).cuda()
+    kw = dict(c_ss=1.3, info_coef_dev=torch.tensor(0.7, device="cuda"), c_disc=0.9, c_us=0.4)
+    hs1, gd1, ge1, gl1 = fused.disc_loss_raw(d, eps, logits, label, pe, pc, b_lb, b_pi, b_ulb, from_logits=True, **kw)
+    c = torch.softmax(logits, -1)
+    hs0, gd0, ge0, gc0 = fused.disc_loss_raw(d, eps, c, label, pe, pc, b_lb, b_pi, b_ulb, **kw)
+    gl0 = torch._softmax_backward_data(gc0, c, -1, torch.float32)
+    assert torch.allclose(hs1, hs0, rtol=1e-6, atol=1e-7) and torch.equal(gd1, gd0) and torch.equal(ge1, ge0)
+    assert torch.allclose(gl1, gl0, rtol=2e-5, atol=1e-9), float((gl1 - gl0).abs().max())
+
+
+def test_disc_loss_logits_twin_equals_softmax_around_the_twin():
+    lib = load_oracle()
+    sig = [C.c_void_p] * 6 + [C.c_int32] * 3 + [C.c_float, C.c_void_p, C.c_float, C.c_float] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]
+    lib.qo_disc_loss.argtypes = sig; lib.qo_disc_loss_logits.argtypes = sig
+    b_lb, b_pi, b_ulb = 5, 7, 6
+    B = 18
+    r = np.random.default_rng(1)
+    d, eps = r.standard_normal(B).astype(np.float32), r.standard_normal(B).astype(np.float32)
+    z = (r.standard_normal((B, 5)) * 2).astype(np.float32)
+    lab = r.integers(0, 5, b_lb).astype(np.int64); pe = r.standard_normal(b_pi).astype(np.float32)
+    pc = np.abs(r.standard_normal((b_pi, 5))).astype(np.float32); info = np.array([0.7], np.float32)
+    p = lambda x: x.ctypes.data
+    def run(fn, c):
+        gd, ge, gc, out = np.zeros(B, np.float32), np.zeros(B, np.float32), np.zeros((B, 5), np.float32), np.zeros(16, np.float32)
+        assert fn(p(d), p(eps), p(c), p(lab), p(pe), p(pc), b_lb, b_pi, b_ulb, 1.3, p(info), 0.9, 0.4, p(gd), p(ge), p(gc), p(out), None, 0, None) == 0
+        return gd, ge, gc, out
+    gd1, ge1, gl1, o1 = run(lib.qo_disc_loss_logits, z)
+    e = np.exp(z - z.max(1, keepdims=True)); sm = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    gd0, ge0, gc0, o0 = run(lib.qo_disc_loss, sm)
+    gl0 = sm * (gc0 - (gc0 * sm).sum(1, keepdims=True))
+    assert np.allclose(o1, o0, rtol=1e-5, atol=1e-6) and np.allclose(gd1, gd0) and np.allclose(ge1, ge0) and np.allclose(gl1, gl0, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
 def test_amp_iteration_with_and_without_fused_heads():
     """one AMP iteration (80 discriminator steps, eager) through qa_disc_loss and through the eager head losses"""
     from tests.test_gpu_train import _make
