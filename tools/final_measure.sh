@@ -33,7 +33,7 @@ for NE in 2048 1024 512; do timeout 400 python bench.py --gpus 1 --steps 20 --wa
 QA_TRAIN_CHAIN=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu_autograd_steps.json
 QA_TRAIN_CHAIN=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_autograd_steps.json
 # (r6) the same lines with ABI 17's chain launches but without ABI 18's tails (stacked / paired optimiser launches, one launch for the pair losses, several steps per replay)
-A17="QA_DISC_STACKED_ADAM=0 QA_ADAM_PAIR=0 QA_PAIR_LOSSES=0 QA_STEP_UNROLL=0"
+A17="QA_DISC_STACKED_ADAM=0 QA_ADAM_PAIR=0 QA_PAIR_LOSSES=0 QA_STEP_UNROLL=0 QA_DISC_LOSS_LOGITS=0"
 env $A17 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --num_envs 512 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_512_per_gpu_abi17_steps.json
 env $A17 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --amp --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg3_amp_abi17_steps.json
 env $A17 timeout 500 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc_teacher_1024_abi17_steps.json
