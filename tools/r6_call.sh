@@ -202,6 +202,11 @@ store)     # the observation rows' storage copy inside the sampling launch
     QA_ACT_STORE=0 timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_cfg2_copy.json
     line $O/bench_*.json
     ;;
+pmcchain)  # SQ counters of the PPO training step's launches at 3,072 rows
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_c
+    timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace --output-format csv -d /tmp/pmc_c -- python $R/tools/pmc_policy.py train 3072 < /dev/null > /tmp/pmc_c.log 2>&1; tail -2 /tmp/pmc_c.log
+    cd $R; python tools/pmc_policy.py summarize /tmp/pmc_c train > $O/train_chain_sq_counters.txt 2>&1; cat $O/train_chain_sq_counters.txt
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
