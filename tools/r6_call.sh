@@ -207,6 +207,16 @@ pmcchain)  # SQ counters of the PPO training step's launches at 3,072 rows
     timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU --kernel-trace --output-format csv -d /tmp/pmc_c -- python $R/tools/pmc_policy.py train 3072 < /dev/null > /tmp/pmc_c.log 2>&1; tail -2 /tmp/pmc_c.log
     cd $R; python tools/pmc_policy.py summarize /tmp/pmc_c train > $O/train_chain_sq_counters.txt 2>&1; cat $O/train_chain_sq_counters.txt
     ;;
+tsccurve)  # the task-level teacher's training curves, chain steps against autograd steps: 8 seeds x 300 iterations at 1024 envs, four processes at a time
+    for s in 1 2 3 4 5 6 7 8; do
+      ( timeout 600 python tools/tsc_train_curve.py --seed $s --iters 300 --num_envs 1024 --out $O/chain_s$s.json > $O/chain_s$s.log 2>&1; tail -1 $O/chain_s$s.log ) &
+      ( QA_TRAIN_CHAIN=0 timeout 600 python tools/tsc_train_curve.py --seed $s --iters 300 --num_envs 1024 --out $O/autograd_s$s.json > $O/autograd_s$s.log 2>&1; tail -1 $O/autograd_s$s.log ) &
+      if [ $((s % 2)) -eq 0 ]; then wait; fi
+    done
+    wait
+    python tools/tsc_train_curve.py merge $O/merged.json $O/chain_s*.json -- $O/autograd_s*.json
+    rm -f $O/*.log
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
