@@ -918,6 +918,66 @@ def test_pair_losses_twin_equals_the_single_twin():
     assert lib.qo_pair_losses(C.cast(jobs, C.c_void_p), 5, sc.ctypes.data, nb, None) != 0           # more than QA_PAIR_MAX_JOBS
 
 
+def _stack_case(seed=0):
+    """ragged tensors for qa_adam_stack_step: (numel, parts1, parts2, states) -- single elements, chunk boundaries (32 / 512), no parts, few parts, more than 16
+    parts in either source (the 32-element chunk walk), one to three optimiser states"""
+    shapes = [(1, 0, 0, 1), (31, 1, 0, 2), (32, 5, 3, 3), (33, 17, 0, 1), (511, 16, 20, 2), (512, 40, 3, 3), (513, 0, 0, 3), (2049, 2, 17, 1), (700, 64, 0, 2), (5000, 3, 0, 3)]
+    r = np.random.default_rng(seed)
+    T = []
+    for n, p1, p2, ns in shapes:
+        f = lambda *sh: r.standard_normal(sh).astype(np.float32)
+        s1, s2 = n + r.integers(0, 5), n + r.integers(0, 5)
+        T.append(dict(n=n, p1=p1, p2=p2, ns=ns, s1=int(s1), s2=int(s2), param=f(n), grad=f(n), src1=f(max(p1, 1), s1) * 0.1, src2=f(max(p2, 1), s2) * 0.1, tmp=np.zeros(n, np.float32),
+                      m=[f(n) * 0.01 for _ in range(ns)], v=[np.abs(f(n)) * 0.01 for _ in range(ns)], step=[np.array([float(3 + k)], np.float32) for k in range(ns)],
+                      lr=[np.array([1e-3 * (k + 1)], np.float32) for k in range(ns)], wd=[0.0, 1e-3, 1e-2][:ns], alpha2=0.37, reg=[0.0, 2e-4][n % 2]))
+    return T
+
+
+def _run_stack(lib, prefix, T, to_dev, ticket_ptr, stream):
+    from quadrupedal_agility_amd._capi import QaAdamStackTensor
+    fn = getattr(lib, prefix + "adam_stack_step")
+    fn.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    recs = (QaAdamStackTensor * len(T))()
+    dev = []
+    for i, t in enumerate(T):
+        d = {k: to_dev(t[k]) for k in ("param", "grad", "src1", "src2", "tmp")}
+        d["m"], d["v"], d["step"], d["lr"] = ([to_dev(x) for x in t[k]] for k in ("m", "v", "step", "lr"))
+        dev.append(d)
+        rec = recs[i]
+        ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else x.ctypes.data
+        rec.param, rec.grad, rec.tmp, rec.numel, rec.num_states = ptr(d["param"]), ptr(d["grad"]), ptr(d["tmp"]), t["n"], t["ns"]
+        if t["p1"]:
+            rec.src1, rec.stride1, rec.parts1 = ptr(d["src1"]), t["s1"], t["p1"]
+        if t["p2"]:
+            rec.src2, rec.stride2, rec.parts2, rec.alpha2 = ptr(d["src2"]), t["s2"], t["p2"], t["alpha2"]
+        rec.reg = t["reg"]
+        for k in range(t["ns"]):
+            e = rec.state[k]
+            e.exp_avg, e.exp_avg_sq, e.step, e.lr, e.weight_decay = ptr(d["m"][k]), ptr(d["v"][k]), ptr(d["step"][k]), ptr(d["lr"][k]), t["wd"][k]
+    for _ in range(2):          # two steps in a row: the arrival counter resets itself, the step counters advance
+        assert fn(C.cast(recs, C.c_void_p), len(T), 0.9, 0.999, 1e-8, ticket_ptr, stream) == 0
+    return dev
+
+
+@pytest.mark.gpu
+def test_adam_stack_step_ragged_tensors_match_the_twin():
+    """qa_adam_stack_step over ragged sizes / part counts / state counts, HIP against the C twin (sums in double there: 2e-6 of the scale), two steps in a row"""
+    from quadrupedal_agility_amd import _capi
+    T = _stack_case()
+    host = _run_stack(load_oracle(), "qo_", [dict(t) for t in T], lambda x: x.copy(), np.zeros(1, np.uint32).ctypes.data, None)
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu = _run_stack(_capi.load_library(), "qa_", T, lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda(), ticket.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert int(ticket) == 0
+    for i, (h, g, t) in enumerate(zip(host, gpu, T)):
+        for key in ("param", "grad"):
+            a, b = g[key].cpu().numpy(), h[key]
+            assert np.allclose(a, b, rtol=2e-5, atol=2e-6 * (np.abs(b).max() + 1e-6)), (i, key, float(np.abs(a - b).max()))
+        for k in range(t["ns"]):
+            assert np.allclose(g["m"][k].cpu().numpy(), h["m"][k], rtol=2e-5, atol=1e-7) and np.allclose(g["v"][k].cpu().numpy(), h["v"][k], rtol=2e-5, atol=1e-9), (i, k)
+            assert float(g["step"][k]) == float(h["step"][k][0]) == 3 + k + 2
+
+
 @pytest.mark.gpu
 def test_accumulate_scalars_is_stack_and_add():
     """qa_accumulate_scalars (ABI 18): scalars that live in different tensors onto an accumulator in one launch; anything else falls back to torch"""
