@@ -892,6 +892,21 @@ def test_pair_losses_launch_equals_the_losses_one_by_one(rows):
         assert torch.equal(l1, r1) and torch.equal(l2, r2) and torch.equal(g1, q1 * coef) and torch.equal(g2, q2), rep
 
 
+@pytest.mark.gpu
+def test_pair_losses_wide_rows_and_four_jobs():
+    """rows wider than the LDS path takes (cols > 47: the lane-per-row walk) and the maximum of four jobs in one launch, against qa_pair_loss one by one"""
+    from quadrupedal_agility_amd.rsl_rl.algorithms import fused
+    torch.manual_seed(5)
+    rows = 777
+    coef = torch.tensor(1.7, device="cuda")
+    mk = lambda c: (torch.randn(rows, c, device="cuda"), torch.randn(rows, c + 3, device="cuda")[:, 1:1 + c])
+    jobs = [(*mk(64), fused.PAIR_ROW_L2, coef), (*mk(47), fused.PAIR_MSE, None), (*mk(48), fused.PAIR_ROW_L2, None), (*mk(1), fused.PAIR_MSE, coef)]
+    got = fused.pair_losses_raw(jobs)
+    for (a, b, mode, sc), (loss, grad) in zip(jobs, got):
+        r, q = fused.pair_loss_raw(a, b, mode)
+        assert torch.equal(loss, r) and torch.equal(grad, q * sc if sc is not None else q)
+
+
 def test_pair_losses_twin_equals_the_single_twin():
     from quadrupedal_agility_amd._capi import QaPairJob
     lib = load_oracle()

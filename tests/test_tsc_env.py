@@ -326,6 +326,23 @@ def test_oracle_reset_stats_match_the_reference_expression(n, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("terms", [1, 9, 11, 16])
+def test_hip_reset_stats_with_other_term_counts(terms):
+    """r6: the kernel adds eight terms per pass; fewer and more than eight (a second, partial group) against the twin, bit for bit"""
+    hip, lib = _capi.load_library(), load_oracle()
+    n = 3000
+    g = torch.Generator().manual_seed(terms)
+    flags = (torch.rand(n, generator=g) < 0.2).to(torch.uint8)
+    sums, means0 = torch.randn(terms, n, generator=g) * 30, torch.randn(terms, generator=g)
+    means, any_r = means0.clone().numpy(), np.zeros(1, np.uint8)
+    f, s = flags.numpy(), np.ascontiguousarray(sums.numpy())
+    assert lib.qo_tsc_reset_stats(f.ctypes.data, s.ctypes.data, n, terms, 20.0, means.ctypes.data, any_r.ctypes.data, None) == 0
+    fd, sd, md, ad = flags.cuda(), sums.cuda().contiguous(), means0.clone().cuda(), torch.zeros(1, dtype=torch.uint8, device="cuda")
+    assert hip.qa_tsc_reset_stats(fd.data_ptr(), sd.data_ptr(), n, terms, 20.0, md.data_ptr(), ad.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    assert int(ad.cpu()[0]) == int(any_r[0]) == 1 and np.array_equal(md.cpu().numpy(), means)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,p", [(1, 1.0), (64, 0.0), (64, 0.3), (1000, 0.05), (8192, 0.01), (8192, 1.0)])
 def test_hip_reset_stats_equal_the_twin_bit_for_bit(n, p):
     hip, lib = _capi.load_library(), load_oracle()
