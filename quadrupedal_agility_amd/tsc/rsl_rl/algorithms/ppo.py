@@ -458,6 +458,23 @@ class PPO:
                     rows.insert(1, got[-1] if cflat is not None else rows[0])
                     return self._minibatch_forward_backward(rows, hl, self._coef_dev)
 
+                # r6: on one GPU, with steps that run as chain launches (<= 8192 rows, ~0.65 ms each), the rollout is gathered into permuted order ONCE per
+                # update (the reference draws one permutation for all epochs, :122-170) and minibatch i is rows [i mb, (i + 1) mb) of that copy; the slots of an
+                # epoch are ONE recording -- 5 replays per update instead of 20 x (index copy, replay, gather).  The behaviour-level learner's scheme since r3.
+                nmb = self.num_mini_batches
+                self._epoch_graph = False
+                if sync is None and cflat is None and os.environ.get("QA_STEP_UNROLL", "1") != "0":
+                    srcs_all = flat + [self._hist_latent_all]
+                    bufs = fused.gather_rows(torch.arange(nmb * mb, device=dev), srcs_all)          # (also fills the buffers for the warm-up pass below)
+                    if self._train_chain(bufs[0][:mb], bufs[0][:mb]) is not None:
+                        self._perm_bufs, self._gather_srcs, self._epoch_graph = bufs, srcs_all, True
+
+                def front_slot(i):
+                    rows = [b[i * mb:(i + 1) * mb] for b in self._perm_bufs[:len(flat)]]
+                    hl = self._perm_bufs[len(flat)][i * mb:(i + 1) * mb]
+                    rows.insert(1, rows[0])
+                    return self._minibatch_forward_backward(rows, hl, self._coef_dev)
+
                 # (an attribute: its merged device tables are read by every REPLAY -- as a local of this capture block they were freed when it
                 # returned, and the replays faulted)
                 pair = self._step_pair = fused.ClipAdamPair(self._step_estimator, self._step_ac) if os.environ.get("QA_ADAM_PAIR", "1") != "0" else None
@@ -483,7 +500,7 @@ class PPO:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     self.optimizer.zero_grad(set_to_none=True); self.estimator_optimizer.zero_grad(set_to_none=True)
-                    front()
+                    front_slot(0) if self._epoch_graph else front()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 if pair is not None:
@@ -491,7 +508,16 @@ class PPO:
                 ac.distribution_d = ac.distribution_c = None
                 gc.collect()
                 self.optimizer.zero_grad(set_to_none=True); self.estimator_optimizer.zero_grad(set_to_none=True)
-                if sync is None:
+                if self._epoch_graph:
+                    g = torch.cuda.CUDAGraph()
+                    with _no_gc(), torch.cuda.graph(g):
+                        for i in range(nmb):
+                            kl, stats = front_slot(i)
+                            apply(kl.reshape(()))
+                            self._add_stats(self._acc, stats)
+                            self.optimizer.zero_grad(set_to_none=True); self.estimator_optimizer.zero_grad(set_to_none=True)
+                    self._graph = (g, None)
+                elif sync is None:
                     g = torch.cuda.CUDAGraph()
                     with _no_gc(), torch.cuda.graph(g):
                         kl, stats = front()
@@ -534,6 +560,11 @@ class PPO:
             self._hist_latent_all.copy_(ac.actor.infer_hist_latent(flat[0]))
         ga, gb = self._graph
         perm = torch.randperm(self.num_mini_batches * mb, device=dev)          # one permutation for all epochs (:122-170)
+        if getattr(self, "_epoch_graph", False):
+            fused.gather_rows(perm, self._gather_srcs, dsts=self._perm_bufs)
+            for _ in range(self.num_learning_epochs):
+                ga.replay()
+            return self._acc.clone()
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 self._mb_idx.copy_(perm[i * mb:(i + 1) * mb])

@@ -217,6 +217,13 @@ tsccurve)  # the task-level teacher's training curves, chain steps against autog
     python tools/tsc_train_curve.py merge $O/merged.json $O/chain_s*.json -- $O/autograd_s*.json
     rm -f $O/*.log
     ;;
+tscepoch)  # task-level learner: rollout gathered once per update, the epoch's slots as one recording
+    timeout 1800 python -m pytest tests/test_tsc_learner.py tests/test_tsc_glue.py tests/test_train_chain.py tests/test_distributed_gpu.py -m gpu -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2; grep -E "^FAILED|^ERROR" $O/pytest.log | head -8
+    for i in 1 2; do timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_$i.json; done
+    QA_STEP_UNROLL=0 timeout 400 python bench.py --tsc --num_envs 1024 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc1024_step_per_replay.json
+    timeout 400 python bench.py --tsc --num_envs 512 --steps 20 --warmup 5 --no_cpu_baseline 2>/dev/null < /dev/null | grep '"metric"' > $O/bench_tsc512.json
+    line $O/bench_*.json
+    ;;
 traffic)   # which of the task-level env step's three launches moves the bytes (per-kernel FETCH_SIZE / WRITE_SIZE)
     cd /tmp && export TMPDIR=/tmp
     for NE in 1024; do
